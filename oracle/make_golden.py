@@ -1,0 +1,150 @@
+"""Generate the committed fixtures under tests/golden from the LIVE reference
+(``/root/reference`` imported through ``oracle/refshim.py``).  TEST INFRASTRUCTURE ONLY.
+
+Run in the build container (the GPU box has no reference):
+
+    python oracle/make_golden.py
+
+Every fixture stores the inputs, the reference outputs and (for seeded-init models) a
+checksum of the weights; the weights themselves are reproduced on any box by
+``spk_oracle.init_*_params`` (same torch CPU RNG stream as the reference constructors).
+The one real-weight fixture (the shipped PaiNN aspirin model,
+``interfaces/lammps/examples/aspirin/best_model``) stores its state dict.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import refshim, spk_oracle as O  # noqa: E402
+from schnetpack_amd import synthetic as S  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def ref_inputs(b):
+    n_mol = int(b["n_mol"])
+    counts = torch.bincount(b["idx_m"], minlength=n_mol)
+    return {
+        "_atomic_numbers": b["Z"], "_positions": b["R"].clone(), "_idx_i": b["idx_i"],
+        "_idx_j": b["idx_j"], "_offsets": b["offsets"], "_idx_m": b["idx_m"],
+        "_cell": torch.zeros(n_mol, 3, 3), "_pbc": torch.zeros(3 * n_mol, dtype=torch.bool),
+        "_n_atoms": counts,
+    }
+
+
+def checksum(p):
+    return float(sum(v.double().abs().sum() for v in p.values()))
+
+
+def run_reference(ns, rep, head_sd, b):
+    aw = ns.atomwise.Atomwise(n_in=rep.n_atom_basis, output_key="energy")
+    aw.load_state_dict(head_sd)
+    model = ns.model.NeuralNetworkPotential(
+        rep, input_modules=[ns.distances.PairwiseDistances()],
+        output_modules=[aw, ns.response.Forces()])
+    model.eval()
+    inp = ref_inputs(b)
+    out = model(inp)
+    res = {"energy": out["energy"].detach().numpy(), "forces": out["forces"].detach().numpy(),
+           "scalar_representation": inp["scalar_representation"].detach().numpy()}
+    if "vector_representation" in inp:
+        res["vector_representation"] = inp["vector_representation"].detach().numpy()
+    return res
+
+
+def save(name, b, res, **extra):
+    arrs = {"in_" + k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in b.items()}
+    arrs.update({"ref_" + k: v for k, v in res.items()})
+    arrs.update(extra)
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name, {k: getattr(v, "shape", v) for k, v in arrs.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = refshim.load()
+    nn = ns.nn
+
+    # --- L0 known answers (the reference's own golden tests, tests/nn/test_radial.py:6-74,
+    #     test_cutoff.py:7-42, test_activations.py:7-25, evaluated by the reference modules)
+    d = torch.linspace(0.0, 6.0, 25)
+    d2 = torch.tensor([[0.0, 0.3], [1.7, 4.99], [5.0, 7.5]])
+    ka = {
+        "d": d.numpy(), "d2": d2.numpy(),
+        "gauss20_5": nn.GaussianRBF(20, 5.0)(d).numpy(),
+        "gauss5_1p5_start0p5": nn.GaussianRBF(5, 1.5, start=0.5)(d2).numpy(),
+        "bessel20_5": nn.BesselRBF(20, 5.0)(d).numpy(),
+        "bessel7_3": nn.BesselRBF(7, 3.0)(d2).numpy(),
+        "cos5": nn.CosineCutoff(5.0)(d).numpy(),
+        "cos1p8": nn.CosineCutoff(1.8)(d2).numpy(),
+        "ssp_x": torch.linspace(-30, 30, 61).numpy(),
+        "ssp_y": nn.shifted_softplus(torch.linspace(-30, 30, 61)).numpy(),
+    }
+    # scatter_add golden incl. trailing dims, dim=1, unsorted indices (nn/scatter.py:7-34)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(17, 3, 8, generator=g)
+    idx = torch.randint(0, 6, (17,), generator=g)
+    ka["scat_x"] = x.numpy(); ka["scat_idx"] = idx.numpy()
+    ka["scat_y0"] = nn.scatter_add(x, idx, dim_size=7).numpy()
+    xt = x.permute(1, 0, 2).contiguous()
+    ka["scat_y1"] = nn.scatter_add(xt, idx, dim_size=7, dim=1).numpy()
+    np.savez_compressed(os.path.join(OUT, "nn_known_answers.npz"), **ka)
+    print("wrote nn_known_answers.npz")
+
+    head = O.init_atomwise_params(128, seed=1)
+
+    # --- cfg 1: ethanol, SchNet(128,3), seed 0
+    cases = [
+        ("schnet_ethanol", "schnet", S.molecule_batch("ethanol", 1, jitter=0.0), dict()),
+        ("schnet_aspirin8", "schnet", S.molecule_batch("aspirin", 8, seed=0), dict()),
+        ("painn_ethanol", "painn", S.molecule_batch("ethanol", 1, jitter=0.0), dict()),
+        ("painn_aspirin8", "painn", S.molecule_batch("aspirin", 8, seed=0), dict()),
+        ("schnet_bessel_aspirin2", "schnet", S.molecule_batch("aspirin", 2, seed=3),
+         dict(radial="bessel")),
+        ("painn_bessel_aspirin2", "painn", S.molecule_batch("aspirin", 2, seed=3),
+         dict(radial="bessel")),
+        # short cutoff: some pairs beyond the cutoff are kept in the list (skin-style) so that
+        # the [d < rc] mask of the cosine cutoff is exercised
+        ("schnet_skin_aspirin2", "schnet", S.molecule_batch("aspirin", 2, cutoff=5.0, seed=4),
+         dict(cutoff=3.5)),
+        ("painn_skin_aspirin2", "painn", S.molecule_batch("aspirin", 2, cutoff=5.0, seed=4),
+         dict(cutoff=3.5)),
+    ]
+    for name, kind, b, kw in cases:
+        cutoff = kw.get("cutoff", 5.0)
+        radial = kw.get("radial", "gaussian")
+        rb = nn.GaussianRBF(20, cutoff) if radial == "gaussian" else nn.BesselRBF(20, cutoff)
+        torch.manual_seed(0)
+        if kind == "schnet":
+            rep = ns.schnet.SchNet(128, 3, rb, nn.CosineCutoff(cutoff))
+            p = O.init_schnet_params(cutoff=cutoff, radial=radial)
+        else:
+            rep = ns.painn.PaiNN(128, 3, rb, nn.CosineCutoff(cutoff))
+            p = O.init_painn_params(cutoff=cutoff, radial=radial)
+        sd = rep.state_dict()
+        assert all(torch.equal(sd[k], p[k].to(sd[k].dtype)) for k in sd), name
+        res = run_reference(ns, rep, head, b)
+        save(name + ".npz", b, res, weights_checksum=checksum(p), kind=kind, cutoff=cutoff,
+             radial=radial, n_interactions=3)
+
+    # --- real weights: shipped PaiNN aspirin model (2 interactions)
+    sys.modules["ase.data"].atomic_masses = np.ones(119)
+    m = torch.load(os.path.join(refshim.REF_SRC, "..", "interfaces", "lammps", "examples",
+                                "aspirin", "best_model"), map_location="cpu", weights_only=False)
+    m.eval()
+    rep = m.representation
+    head_sd = m.output_modules[0].state_dict()
+    b = S.molecule_batch("aspirin", 4, seed=7, jitter=0.03)
+    res = run_reference(ns, rep, head_sd, b)
+    w = {"w_rep." + k: v.numpy() for k, v in rep.state_dict().items()}
+    w.update({"w_head." + k: v.numpy() for k, v in head_sd.items()})
+    save("painn_aspirin_pretrained.npz", b, res, kind="painn", cutoff=float(rep.cutoff),
+         radial="gaussian", n_interactions=int(rep.n_interactions), **w)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""CPU, build container only: pin the oracle against the LIVE reference modules
+(skipped on boxes without /root/reference)."""
+import pytest
+import torch
+
+from oracle import refshim, spk_oracle as O
+from schnetpack_amd import synthetic as S
+
+pytestmark = pytest.mark.skipif(not refshim.available(), reason="reference sources not present")
+
+
+def _ref_inputs(b):
+    n_mol = int(b["n_mol"])
+    return {"_atomic_numbers": b["Z"], "_positions": b["R"].clone(), "_idx_i": b["idx_i"],
+            "_idx_j": b["idx_j"], "_offsets": b["offsets"], "_idx_m": b["idx_m"],
+            "_cell": torch.zeros(n_mol, 3, 3), "_pbc": torch.zeros(3 * n_mol, dtype=torch.bool),
+            "_n_atoms": torch.bincount(b["idx_m"], minlength=n_mol)}
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+@pytest.mark.parametrize("shared", [False, True])
+def test_seeded_init_and_force_call(kind, shared):
+    ns = refshim.load()
+    torch.manual_seed(0)
+    rb, cf = ns.nn.GaussianRBF(20, 5.0), ns.nn.CosineCutoff(5.0)
+    if kind == "schnet":
+        if shared:
+            pytest.skip("shared_interactions aliases modules; covered by module tests")
+        rep = ns.schnet.SchNet(128, 3, rb, cf)
+        p = O.init_schnet_params()
+    else:
+        rep = ns.painn.PaiNN(128, 3, rb, cf, shared_filters=shared)
+        p = O.init_painn_params(shared_filters=shared)
+    sd = rep.state_dict()
+    assert set(sd) == set(p)
+    assert all(torch.equal(sd[k], p[k]) for k in sd)
+    torch.manual_seed(1)
+    aw = ns.atomwise.Atomwise(n_in=128, output_key="energy")
+    head = O.init_atomwise_params(128, seed=1)
+    assert all(torch.equal(v, head[k]) for k, v in aw.state_dict().items())
+    model = ns.model.NeuralNetworkPotential(rep, input_modules=[ns.distances.PairwiseDistances()],
+                                            output_modules=[aw, ns.response.Forces()])
+    model.eval()
+    b = S.molecule_batch("aspirin", 4, seed=11)
+    out = model(_ref_inputs(b))
+    o = O.energy_and_forces(kind, p, head, b, 3, shared_filters=shared)
+    assert (out["energy"] - o["energy"]).abs().max() / out["energy"].abs().max() < 2e-6
+    assert (out["forces"] - o["forces"]).abs().max() / out["forces"].abs().max() < 5e-6
+
+
+def test_reference_golden_nn_tests_hold_for_oracle():
+    """The reference L0 modules and the oracle functions agree on random input."""
+    ns = refshim.load()
+    d = torch.rand(50) * 6
+    torch.testing.assert_close(ns.nn.GaussianRBF(20, 5.0)(d), O.gaussian_rbf(d, *O.gaussian_rbf_params(20, 5.0)))
+    torch.testing.assert_close(ns.nn.BesselRBF(20, 5.0)(d), O.bessel_rbf(d, O.bessel_rbf_params(20, 5.0).float()))
+    torch.testing.assert_close(ns.nn.CosineCutoff(5.0)(d), O.cosine_cutoff(d, 5.0))
+    x = torch.randn(100) * 10
+    torch.testing.assert_close(ns.nn.shifted_softplus(x), O.shifted_softplus(x))
+
+
+def test_synthetic_neighbor_list_matches_reference_torch_list():
+    """Index parity of the synthetic generator's list vs TorchNeighborList (bit-exact as sets
+    per centre atom; the reference's argsort is not stable so order inside a row may differ)."""
+    ns = refshim.load()
+    if ns.neighborlist is None:
+        pytest.skip("neighborlist module not importable")
+    import numpy as np
+    b = S.molecule_batch("aspirin", 1, seed=2)
+    nl = ns.neighborlist.TorchNeighborList(cutoff=5.0)
+    inp = {"_atomic_numbers": b["Z"], "_positions": b["R"], "_cell": torch.zeros(3, 3),
+           "_pbc": torch.zeros(3, dtype=torch.bool)}
+    out = nl(inp)
+    ref = sorted(zip(out["_idx_i"].tolist(), out["_idx_j"].tolist()))
+    mine = sorted(zip(b["idx_i"].tolist(), b["idx_j"].tolist()))
+    assert ref == mine
+    assert bool((out["_idx_i"][1:] >= out["_idx_i"][:-1]).all())
