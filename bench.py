@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): M edge-messages/s of the eval-mode force call
+(PairwiseDistances -> SchNet(128, 3 interactions, 20 Gaussians, cosine cutoff 5 A) -> Atomwise ->
+Forces) on a 256-frame MD17-aspirin batch (configs[1]; N = 5376 atoms, E ~ 77.9k directed edges),
+synthetic jittered frames, seeded random-init weights, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).  A "step" is one complete force
+call (forward + first-order backward to the positions) over one batch.  The path shards by
+independent molecules: every rank owns its own 256-frame batch (weak scaling), no data-path
+collective.  edge-messages/s = E * n_interactions * steps / time, summed over ranks.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the launch
+stream in a separate eager pass) and `cpu_baseline` (the CPU oracle = torch restatement of the
+reference, timed on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0          # same guide, HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--kind", default="schnet", choices=["schnet", "painn"])
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the force call in a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--variant", default="auto", choices=["auto", "simple", "mfma"])
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from oracle import spk_oracle as O          # parameters (seeded init) + cpu_baseline leg only
+    from schnetpack_amd import _lib, model as M, synthetic as S
+    from schnetpack_amd.parallel import shard_frames
+
+    _lib.set_variant({"auto": _lib.VARIANT_AUTO, "simple": _lib.VARIANT_SIMPLE, "mfma": _lib.VARIANT_MFMA}[args.variant])
+    n_int, F, n_rbf, cutoff = 3, 128, 20, 5.0
+    rep_p = O.init_schnet_params() if args.kind == "schnet" else O.init_painn_params()
+    head_p = O.init_atomwise_params(F, seed=1)
+    model = M.build_model(args.kind, F, n_int, n_rbf, cutoff)
+    M.load_reference_params(model, rep_p, head_p)
+    model = model.to(dev).eval()
+
+    # weak scaling: rank r owns frames [r*frames, (r+1)*frames) of one global seeded trajectory
+    lo, hi = shard_frames(args.frames * world, rank, world)
+    batch = S.molecule_batch("aspirin", hi - lo, seed=1000 + rank if world > 1 else 0)
+    E = int(batch["idx_i"].shape[0])
+    N = int(batch["Z"].shape[0])
+    inp = M.batch_to_inputs(batch, dev)
+
+    def force_call():
+        out = model(dict(inp))
+        return out["energy"], out["forces"]
+
+    for _ in range(max(args.warmup, 3)):
+        e_ref, f_ref = force_call()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    force_call()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                ge, gf = force_call()
+            g.replay()
+            torch.cuda.synchronize()
+            err = float((gf - f_ref).abs().max() / f_ref.abs().max())
+            if not (err < 1e-5):
+                raise RuntimeError("graph replay deviates from eager: %g" % err)
+            graph = g
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            sys.stderr.write("[bench] HIP graph capture unavailable (%s); running eager\n" % exc)
+            graph = None
+            torch.cuda.synchronize()
+
+    step = graph.replay if graph is not None else force_call
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    E_total = E
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        et = torch.tensor([E], device=dev, dtype=torch.float64)
+        dist.all_reduce(et, op=dist.ReduceOp.SUM)
+        E_total = int(et.item())
+    value = E_total * n_int * args.steps / dt / 1e6
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---------------- per-kernel timing (separate eager pass, HIP events on the launch stream)
+    _lib.profile_enable(True)
+    _lib.profile_report()
+    psteps = min(args.steps, 20)
+    for _ in range(psteps):
+        force_call()
+    prof = _lib.profile_report()
+    _lib.profile_enable(False)
+    nf = F
+    flop_fwd = 2.0 * E * (n_rbf * nf + nf * nf)
+    algo = {  # algorithmic work per launch
+        "cfconv_fwd_mfma": ("mfma", flop_fwd), "cfconv_fwd_simple": ("mfma", flop_fwd),
+        "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd),
+        "cfconv_bwd_simple": ("mfma", 2 * flop_fwd),
+        "painn_msg_fwd_row": ("hbm", E * 3100.0 + N * 4096.0), "painn_msg_fwd_simple": ("hbm", E * 3100.0 + N * 4096.0),
+        "painn_msg_bwd_row": ("hbm", 2 * (E * 3100.0 + N * 4096.0)), "painn_msg_bwd_simple": ("hbm", 2 * (E * 3100.0 + N * 4096.0)),
+    }
+    kernels = {}
+    for tag, (cnt, ms) in prof.items():
+        kernels[tag] = {"launches_per_step": cnt / psteps, "avg_us": 1e3 * ms / max(cnt, 1), "us_per_step": 1e3 * ms / psteps}
+    cand = [t for t in kernels if t in algo]
+    roofline = None
+    if cand:
+        dom = max(cand, key=lambda t: kernels[t]["us_per_step"])
+        bound, work = algo[dom]
+        sec = kernels[dom]["avg_us"] * 1e-6
+        if bound == "mfma":
+            ach, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "avg_launch_us": round(kernels[dom]["avg_us"], 2), "algorithmic_per_launch": work}
+
+    # ---------------- scatter_add op alone (north_star: HBM roofline of the segmented sum)
+    from schnetpack_amd import ops
+    xs = torch.randn(E, F, device=dev)
+    idx = inp["_idx_i"]
+    rp = ops.segment_rowptr(idx, N)
+    for _ in range(3):
+        ops._scatter_raw(xs, idx, N, 0, rp)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    ev0.record()
+    for _ in range(reps):
+        ops._scatter_raw(xs, idx, N, 0, rp)
+    ev1.record()
+    torch.cuda.synchronize()
+    sc_us = 1e3 * ev0.elapsed_time(ev1) / reps
+    sc_bytes = 4.0 * E * F + 8.0 * E + 4.0 * N * F
+    scatter = {"shape": [E, F, N], "us": round(sc_us, 2), "achieved": round(sc_bytes / (sc_us * 1e-6) / 1e9, 1),
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+               "note": "includes launch gaps (torch events around 50 back-to-back calls)"}
+
+    # ---------------- CPU baseline: the oracle on the host cores, same batch, same weights
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        O.energy_and_forces(args.kind, rep_p, head_p, batch, n_int)
+        ts = []
+        for _ in range(args.cpu_reps):
+            c0 = time.perf_counter()
+            oc = O.energy_and_forces(args.kind, rep_p, head_p, batch, n_int)
+            ts.append(time.perf_counter() - c0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        cpu = {"value": round(E * n_int / med / 1e6, 4), "unit": "M edge-messages/s", "cores": ncores, "kind": "port",
+               "sample": "same %d-frame batch, median of %d force calls (%.2f s each), torch %s fp32" % (hi - lo, args.cpu_reps, med, torch.__version__),
+               "parity_rel_forces": float((f_ref.cpu() - oc["forces"]).abs().max() / oc["forces"].abs().max()),
+               "parity_rel_energy": float((e_ref.cpu() - oc["energy"]).abs().max() / oc["energy"].abs().max())}
+
+    info = _lib.device_info()
+    line = {
+        "metric": "M edge-messages/s (eval force call, MD17-aspirin 256-frame batch, %s)" % ("SchNet" if args.kind == "schnet" else "PaiNN"),
+        "value": round(value, 2), "unit": "M edge-messages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: MD17 aspirin x %d frames per GPU, %s(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0) + Atomwise + Forces; N=%d atoms, E=%d directed edges per GPU"
+                               % (hi - lo, "SchNet" if args.kind == "schnet" else "PaiNN", N, E),
+                   "n_atoms": N, "n_edges": E, "n_atom_basis": F, "frames_per_s": round((hi - lo) * world * args.steps / dt, 1),
+                   "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
+                   "hip_graph": graph is not None, "variant": args.variant, "compute_units": info["compute_units"]},
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "scatter_add": scatter,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

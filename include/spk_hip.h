@@ -1,0 +1,264 @@
+/*
+ * spk_hip.h -- C ABI of the MI355X-native (gfx950) message-passing core for SchNetPack.
+ *
+ * This is the drop-in boundary of the hot path: plain pointers and
+ * sizes, no torch types.  All pointers are DEVICE pointers unless a parameter name starts with
+ * `host_`.  All floating point data is fp32, row-major contiguous; index arrays are int64 exactly
+ * as the reference's batch dict delivers them (`_idx_i`, `_idx_j`, `_idx_m`,
+ * src/schnetpack/properties.py:23-32).  `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  Every entry point returns 0 on success or a negative SPK_ERR_* code;
+ * spk_last_error() returns a human readable message for the calling thread.  Nothing here
+ * falls back to a CPU implementation: without a GPU every compute entry point fails.
+ *
+ * Each entry point cites the reference interface it replaces (paths into
+ * /root/reference/src/schnetpack).
+ */
+#ifndef SPK_HIP_H
+#define SPK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPK_OK 0
+#define SPK_ERR_ARG (-1)     /* bad shape / unsupported size / null pointer */
+#define SPK_ERR_HIP (-2)     /* HIP runtime error (launch failure, no device) */
+#define SPK_ERR_INDEX (-3)   /* index out of range (reported by spk_edge_plan) */
+
+/* activation ids (nn/activations.py:9-22 shifted_softplus, torch.nn.functional.silu) */
+#define SPK_ACT_NONE 0
+#define SPK_ACT_SSP 1
+#define SPK_ACT_SILU 2
+
+/* radial basis kinds (nn/radial.py:18-48 GaussianRBF, :82-110 BesselRBF) */
+#define SPK_RBF_GAUSSIAN 0
+#define SPK_RBF_BESSEL 1
+
+/* kernel variant selection for the fused edge kernels */
+#define SPK_VARIANT_AUTO 0    /* MFMA kernels when the shape is supported, else simple */
+#define SPK_VARIANT_SIMPLE 1  /* straightforward HIP kernels (any shape), used as cross-check */
+#define SPK_VARIANT_MFMA 2    /* force the MFMA kernels (error if shape unsupported) */
+
+/* Radial basis x cosine cutoff description (nn/radial.py, nn/cutoff.py:14-57).
+ * gaussian: p0 = offsets[n_rbf], p1 = widths[n_rbf];  bessel: p0 = freqs[n_rbf], p1 unused. */
+typedef struct {
+  int32_t kind;
+  int32_t n_rbf;
+  const float* p0;
+  const float* p1;
+  float cutoff;
+} spk_radial_t;
+
+/* Neighbour-list description: what `_idx_i`, `_idx_j` look like plus the CSR row pointers and
+ * flags that spk_edge_plan() derives once per neighbour list. */
+typedef struct {
+  int64_t n_atoms;
+  int64_t n_edges;
+  const int64_t* idx_i;   /* [E] centre atom of every directed edge */
+  const int64_t* idx_j;   /* [E] neighbour atom */
+  const int32_t* rowptr;  /* [N+1] CSR offsets into the edge list; valid iff sorted != 0 */
+  int32_t sorted;         /* idx_i ascending (every reference neighbour list; neighborlist.py:450-453) */
+  int32_t symmetric;      /* for every edge (i<-j, r) the list also holds (j<-i, -r) */
+} spk_graph_t;
+
+/* ------------------------------------------------------------------ library / device info */
+int spk_version(void);
+const char* spk_last_error(void);
+/* host_info[0]=compute units, [1]=wavefront size, [2]=LDS bytes per workgroup, [3]=gfx arch number */
+int spk_device_info(int32_t* host_info);
+void spk_set_variant(int variant);
+int spk_get_variant(void);
+/* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py;
+ * off by default).  spk_profile_report() synchronises the device and returns lines
+ * "<kernel-tag> <launch count> <total ms>". */
+void spk_profile_enable(int on);
+const char* spk_profile_report(void);
+
+/* ------------------------------------------------------------------ neighbour-list plan
+ * Derives what the fused kernels need from the delivered index arrays: CSR row pointers,
+ * sortedness, index range check and (if r_ij != NULL) whether the list is symmetric.
+ * host_flags[0]=sorted, [1]=in_range, [2]=symmetric.  Synchronises the stream (one D2H copy of
+ * 16 bytes) -- call once per neighbour list, not per force call.  `scratch` >= 16 bytes device. */
+int spk_edge_plan(const int64_t* idx_i, const int64_t* idx_j, const float* r_ij, int64_t n_edges,
+                  int64_t n_atoms, int32_t* rowptr, int32_t* scratch, int32_t* host_flags,
+                  void* stream);
+
+/* ------------------------------------------------------------------ nn/scatter.py:7-34
+ * y[o, k, c] = sum_{e: idx[e]==k} x[o, e, c]   (x: [outer, E, inner], y: [outer, dim_size, inner]).
+ * rowptr may be NULL (then atomics are used); with rowptr the reduction is a deterministic
+ * segmented sum and y is written exactly once.  y is fully overwritten. */
+int spk_scatter_add_f32(const float* x, const int64_t* idx, const int32_t* rowptr, int64_t outer,
+                        int64_t n_edges, int64_t inner, int64_t dim_size, float* y, void* stream);
+/* transpose of the above (its backward): y[o, e, c] = x[o, idx[e], c] */
+int spk_gather_f32(const float* x, const int64_t* idx, int64_t outer, int64_t n_rows,
+                   int64_t n_edges, int64_t inner, float* y, void* stream);
+
+/* ------------------------------------------------------------------ nn/radial.py, nn/cutoff.py
+ * d: [n] distances -> phi [n, n_rbf] (may be NULL), fcut [n] (may be NULL). */
+int spk_radial_cutoff_f32(const float* d, int64_t n, const spk_radial_t* rb, float* phi,
+                          float* fcut, void* stream);
+/* backward of the pair (phi, fcut) w.r.t. d:  gd[n] = sum_k gphi[n,k] phi_k'(d) + gfcut[n] f'(d) */
+int spk_radial_cutoff_bwd_f32(const float* d, int64_t n, const spk_radial_t* rb, const float* gphi,
+                              const float* gfcut, float* gd, void* stream);
+/* r_ij [E,3] -> d [E] (representation/schnet.py:156) and optionally unit vectors u [E,3]
+ * (representation/painn.py:227-228) */
+int spk_edge_norm_f32(const float* r_ij, int64_t n_edges, float* d, float* u, void* stream);
+
+/* ------------------------------------------------------------------ nn/base.py:52-55 (Dense)
+ * y[m, o] = act(sum_k x[m,k] w[o,k] + b[o]) + res[m,o].  w is the torch Linear weight
+ * [n_out, k] row-major.  b, res, pre may be NULL; `pre` receives the pre-activation (saved for
+ * backward).  k % 8 == 0 and n_out % 32 == 0 select the fp32-MFMA kernel, otherwise the simple
+ * kernel runs. */
+int spk_dense_f32(const float* x, const float* w, const float* b, const float* res, float* y,
+                  float* pre, int64_t m, int32_t k, int32_t n_out, int32_t act, void* stream);
+/* input gradient: dx[m,k] = sum_o (dy[m,o] * act'(pre[m,o])) w[o,k]  (+ res[m,k]).
+ * pre may be NULL iff act == SPK_ACT_NONE. */
+int spk_dense_bwd_input_f32(const float* dy, const float* pre, const float* w, const float* res,
+                            float* dx, int64_t m, int32_t k, int32_t n_out, int32_t act,
+                            void* stream);
+
+/* ------------------------------------------------------------------ representation/schnet.py:60-67
+ * Fused continuous-filter convolution of one interaction block:
+ *   W_e = (ssp(phi(d_e) W1^T + b1) W2^T + b2) * fcut(d_e);   y[i] = sum_{e->i} h[idx_j[e]] * W_e
+ * h: [N, nf] (output of in2f), r_ij: [E,3], filter weights w1 [nf, n_rbf], b1 [nf], w2 [nf, nf],
+ * b2 [nf].  y [N, nf] is fully overwritten.  Nothing of size E x nf is ever written to memory. */
+int spk_schnet_cfconv_fwd_f32(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
+                              const float* r_ij, const float* w1, const float* b1,
+                              const float* w2, const float* b2, int32_t nf, float* y,
+                              void* stream);
+/* First-order backward w.r.t. h and r_ij (what Forces, atomistic/response.py:59-76, asks for):
+ *   gh[j] = sum_{e: idx_j[e]==j} gy[idx_i[e]] * W_e        (fully overwritten)
+ *   gr[e] += (sum_f gy[i,f] h[j,f] dW_e[f]/dd) * r_e/d_e    (ACCUMULATED: interactions share r_ij)
+ * With g->symmetric the transposed sum runs as a second row-local segmented reduction (no
+ * atomics); otherwise float atomics are used. */
+int spk_schnet_cfconv_bwd_f32(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
+                              const float* gy, const float* r_ij, const float* w1,
+                              const float* b1, const float* w2, const float* b2, int32_t nf,
+                              float* gh, float* gr, void* stream);
+
+/* Whole SchNet representation (representation/schnet.py:147-173), eval-mode force path.
+ * Parameter block: pointers to the reference state_dict tensors of every interaction. */
+typedef struct {
+  const float* in2f_w;  /* interactions.l.in2f.weight             [nf, F]  */
+  const float* fn_w1;   /* interactions.l.filter_network.0.weight [nf, n_rbf] */
+  const float* fn_b1;   /* interactions.l.filter_network.0.bias   [nf] */
+  const float* fn_w2;   /* interactions.l.filter_network.1.weight [nf, nf] */
+  const float* fn_b2;   /* interactions.l.filter_network.1.bias   [nf] */
+  const float* f2out_w1; /* interactions.l.f2out.0.weight         [F, nf] */
+  const float* f2out_b1; /* interactions.l.f2out.0.bias           [F]  */
+  const float* f2out_w2; /* interactions.l.f2out.1.weight         [F, F] */
+  const float* f2out_b2; /* interactions.l.f2out.1.bias           [F]  */
+} spk_schnet_layer_t;
+
+typedef struct {
+  int32_t n_atom_basis;   /* F */
+  int32_t n_filters;      /* nf */
+  int32_t n_interactions;
+  int32_t reserved;
+  const spk_schnet_layer_t* layers; /* HOST array of n_interactions entries (device pointers inside) */
+} spk_schnet_t;
+
+/* floats needed in `saved` (kept from forward to backward) and `scratch` (per call) */
+int64_t spk_schnet_saved_floats(const spk_schnet_t* m, int64_t n_atoms);
+int64_t spk_schnet_scratch_floats(const spk_schnet_t* m, int64_t n_atoms);
+/* x0 [N,F] = embedding rows (+ electronic embeddings) computed by the caller;
+ * x_out [N,F] = scalar_representation. */
+int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb,
+                           const float* x0, const float* r_ij, float* x_out, float* saved,
+                           float* scratch, void* stream);
+/* gx_out [N,F] = dL/d scalar_representation  ->  gr [E,3] = dL/d r_ij (overwritten) and
+ * gx0 [N,F] = dL/d x0 (may be NULL). */
+int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb,
+                            const float* gx_out, const float* r_ij, const float* saved,
+                            float* scratch, float* gr, float* gx0, void* stream);
+
+/* ------------------------------------------------------------------ representation/painn.py:31-67
+ * Fused PaiNN message of one interaction block (filters never materialised; the reference
+ * allocates [E,1,3F*n_int], painn.py:232):
+ *   Phi_e = (phi(d_e) Wf^T + bf) * fcut(d_e)          (Wf, bf: the 3F rows of this layer)
+ *   m_e = Phi_e * c[idx_j[e]]  -> (m_q | m_R | m_mu)
+ *   q_out[i] = q[i] + sum m_q;  mu_out[i] = mu[i] + sum (m_R (x) u_e + m_mu * mu[idx_j[e]])
+ * c: [N,3F] output of interatomic_context_net, q: [N,F], mu: [N,3,F]. */
+int spk_painn_message_fwd_f32(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
+                              const float* q, const float* mu, const float* r_ij,
+                              const float* wf, const float* bf, int32_t F, float* q_out,
+                              float* mu_out, void* stream);
+/* First-order backward of the message w.r.t. c, mu and r_ij given gq_out [N,F], gmu_out [N,3,F]:
+ *   gc [N,3F] (overwritten), gmu [N,3,F] (overwritten, includes the residual path gmu_out),
+ *   gr [E,3] (ACCUMULATED).  The residual path of q is the caller's (gq = gq_out + ctx-net bwd). */
+int spk_painn_message_bwd_f32(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
+                              const float* mu, const float* gq_out, const float* gmu_out,
+                              const float* r_ij, const float* wf, const float* bf, int32_t F,
+                              float* gc, float* gmu, float* gr, void* stream);
+
+/* representation/painn.py:92-117 -- the elementwise parts of PaiNNMixing around its three
+ * Dense layers.  mix [N,3,2F] = mu_channel_mix(mu) = (V | W).
+ *   ctx[n] = (q[n] | sqrt(sum_x V[n,x]^2 + eps))                         [N,2F] */
+int spk_painn_mix_ctx_f32(const float* q, const float* mix, int64_t n_atoms, int32_t F, float eps,
+                          float* ctx, void* stream);
+/*   a [N,3F] = intraatomic_context_net(ctx) = (a_q | a_mu | a_qmu)
+ *   q_out = q + a_q + a_qmu * sum_x V W ;  mu_out = mu + a_mu * W */
+int spk_painn_mix_update_f32(const float* q, const float* mu, const float* mix, const float* a,
+                             int64_t n_atoms, int32_t F, float* q_out, float* mu_out,
+                             void* stream);
+/* backward of the update w.r.t. a and mix (the direct residual paths gq_out -> q and
+ * gmu_out -> mu are the caller's): ga [N,3F], gmix [N,3,2F] (overwritten; `mu` is unused). */
+int spk_painn_mix_update_bwd_f32(const float* mu, const float* mix, const float* a,
+                                 const float* gq_out, const float* gmu_out, int64_t n_atoms,
+                                 int32_t F, float* ga, float* gmix, void* stream);
+/* backward of the ctx assembly given g_ctx [N,2F] (from the Dense backward):
+ *   gmix[:, :, :F] += g_ctx[:, F:] V / |V| ;  gq = gq_out + g_ctx[:, :F] */
+int spk_painn_mix_ctx_bwd_f32(const float* mix, const float* g_ctx, const float* gq_out,
+                              int64_t n_atoms, int32_t F, float eps, float* gmix_inout,
+                              float* gq, void* stream);
+
+/* Whole PaiNN representation (representation/painn.py:207-256), eval-mode force path. */
+typedef struct {
+  const float* ctx_w1;  /* interactions.l.interatomic_context_net.0.weight [F, F]  */
+  const float* ctx_b1;  /* ...0.bias [F] */
+  const float* ctx_w2;  /* interactions.l.interatomic_context_net.1.weight [3F, F] */
+  const float* ctx_b2;  /* ...1.bias [3F] */
+  const float* filt_w;  /* filter_net.weight rows [3F*l, 3F*(l+1)) (row 0 if shared_filters) [3F, n_rbf] */
+  const float* filt_b;  /* filter_net.bias, same rows [3F] */
+  const float* mix_w;   /* mixing.l.mu_channel_mix.weight [2F, F] */
+  const float* ictx_w1; /* mixing.l.intraatomic_context_net.0.weight [F, 2F] */
+  const float* ictx_b1; /* ...0.bias [F] */
+  const float* ictx_w2; /* mixing.l.intraatomic_context_net.1.weight [3F, F] */
+  const float* ictx_b2; /* ...1.bias [3F] */
+} spk_painn_layer_t;
+
+typedef struct {
+  int32_t n_atom_basis;
+  int32_t n_interactions;
+  float epsilon;          /* PaiNNMixing epsilon (painn.py:73) */
+  int32_t reserved;
+  const spk_painn_layer_t* layers; /* HOST array of n_interactions entries */
+} spk_painn_t;
+
+int64_t spk_painn_saved_floats(const spk_painn_t* m, int64_t n_atoms);
+int64_t spk_painn_scratch_floats(const spk_painn_t* m, int64_t n_atoms);
+/* q0 [N,F] = embedding rows; outputs scalar_representation q_out [N,F] and
+ * vector_representation mu_out [N,3,F]. */
+int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb,
+                          const float* q0, const float* r_ij, float* q_out, float* mu_out,
+                          float* saved, float* scratch, void* stream);
+/* gq_out / gmu_out may be NULL (treated as zero, not both) -> gr [E,3] (overwritten),
+ * gq0 [N,F] (may be NULL). */
+int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb,
+                           const float* gq_out, const float* gmu_out, const float* r_ij,
+                           const float* saved, float* scratch, float* gr, float* gq0,
+                           void* stream);
+
+/* ------------------------------------------------------------------ small helpers
+ * out[n, :] = table[z[n], :]  (nn.Embedding lookup, schnet.py:161 / painn.py:239) */
+int spk_embedding_f32(const float* table, const int64_t* z, int64_t n, int32_t F, float* out,
+                      void* stream);
+/* y = a + b (n floats) */
+int spk_add_f32(const float* a, const float* b, int64_t n, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPK_HIP_H */

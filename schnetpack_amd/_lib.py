@@ -1,0 +1,192 @@
+"""ctypes binding of the C ABI declared in ``include/spk_hip.h`` (libspk_hip.so).
+
+The library is built in-tree by ``schnetpack_amd/csrc/build.py`` (hipcc, gfx950).  There is no
+CPU fallback: if the shared library is missing, or a tensor is not a contiguous fp32 tensor on a
+ROCm device, the call raises.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libspk_hip.so")
+
+SPK_ACT_NONE, SPK_ACT_SSP, SPK_ACT_SILU = 0, 1, 2
+SPK_RBF_GAUSSIAN, SPK_RBF_BESSEL = 0, 1
+VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_MFMA = 0, 1, 2
+
+c_f = ctypes.c_void_p  # device pointers travel as void*
+c_i64 = ctypes.c_int64
+c_i32 = ctypes.c_int32
+
+
+class SpkHipError(RuntimeError):
+    pass
+
+
+class RadialT(ctypes.Structure):
+    _fields_ = [("kind", c_i32), ("n_rbf", c_i32), ("p0", c_f), ("p1", c_f),
+                ("cutoff", ctypes.c_float)]
+
+
+class GraphT(ctypes.Structure):
+    _fields_ = [("n_atoms", c_i64), ("n_edges", c_i64), ("idx_i", c_f), ("idx_j", c_f),
+                ("rowptr", c_f), ("sorted", c_i32), ("symmetric", c_i32)]
+
+
+class SchnetLayerT(ctypes.Structure):
+    _fields_ = [(n, c_f) for n in ("in2f_w", "fn_w1", "fn_b1", "fn_w2", "fn_b2", "f2out_w1",
+                                   "f2out_b1", "f2out_w2", "f2out_b2")]
+
+
+class SchnetT(ctypes.Structure):
+    _fields_ = [("n_atom_basis", c_i32), ("n_filters", c_i32), ("n_interactions", c_i32),
+                ("reserved", c_i32), ("layers", ctypes.POINTER(SchnetLayerT))]
+
+
+class PainnLayerT(ctypes.Structure):
+    _fields_ = [(n, c_f) for n in ("ctx_w1", "ctx_b1", "ctx_w2", "ctx_b2", "filt_w", "filt_b",
+                                   "mix_w", "ictx_w1", "ictx_b1", "ictx_w2", "ictx_b2")]
+
+
+class PainnT(ctypes.Structure):
+    _fields_ = [("n_atom_basis", c_i32), ("n_interactions", c_i32), ("epsilon", ctypes.c_float),
+                ("reserved", c_i32), ("layers", ctypes.POINTER(PainnLayerT))]
+
+
+P = ctypes.POINTER
+# name -> (restype, argtypes); mirrors include/spk_hip.h one to one
+_PROTOS = {
+    "spk_version": (ctypes.c_int, []),
+    "spk_last_error": (ctypes.c_char_p, []),
+    "spk_device_info": (ctypes.c_int, [P(c_i32)]),
+    "spk_set_variant": (None, [ctypes.c_int]),
+    "spk_get_variant": (ctypes.c_int, []),
+    "spk_profile_enable": (None, [ctypes.c_int]),
+    "spk_profile_report": (ctypes.c_char_p, []),
+    "spk_edge_plan": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, P(c_i32), c_f]),
+    "spk_scatter_add_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i64, c_f, c_f]),
+    "spk_gather_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_i64, c_f, c_f]),
+    "spk_radial_cutoff_f32": (ctypes.c_int, [c_f, c_i64, P(RadialT), c_f, c_f, c_f]),
+    "spk_radial_cutoff_bwd_f32": (ctypes.c_int, [c_f, c_i64, P(RadialT), c_f, c_f, c_f, c_f]),
+    "spk_edge_norm_f32": (ctypes.c_int, [c_f, c_i64, c_f, c_f, c_f]),
+    "spk_dense_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
+    "spk_dense_bwd_input_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
+    "spk_schnet_cfconv_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f]),
+    "spk_schnet_cfconv_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
+    "spk_schnet_saved_floats": (c_i64, [P(SchnetT), c_i64]),
+    "spk_schnet_scratch_floats": (c_i64, [P(SchnetT), c_i64]),
+    "spk_schnet_forward_f32": (ctypes.c_int, [P(SchnetT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f]),
+    "spk_schnet_backward_f32": (ctypes.c_int, [P(SchnetT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "spk_painn_message_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
+    "spk_painn_message_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_f]),
+    "spk_painn_mix_ctx_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, ctypes.c_float, c_f, c_f]),
+    "spk_painn_mix_update_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i32, c_f, c_f, c_f]),
+    "spk_painn_mix_update_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_f, c_f, c_f]),
+    "spk_painn_mix_ctx_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i32, ctypes.c_float, c_f, c_f, c_f]),
+    "spk_painn_saved_floats": (c_i64, [P(PainnT), c_i64]),
+    "spk_painn_scratch_floats": (c_i64, [P(PainnT), c_i64]),
+    "spk_painn_forward_f32": (ctypes.c_int, [P(PainnT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "spk_painn_backward_f32": (ctypes.c_int, [P(PainnT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "spk_embedding_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_f, c_f]),
+    "spk_add_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_f, c_f]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def exported_symbols():
+    """Names declared by include/spk_hip.h (used by the CPU symbol test)."""
+    return sorted(_PROTOS)
+
+
+def lib():
+    """Load libspk_hip.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise SpkHipError(
+                    "libspk_hip.so not found at %s -- build it with "
+                    "`python -m schnetpack_amd.csrc.build` (hipcc, gfx950); there is no CPU "
+                    "fallback" % LIB_PATH)
+            # torch must be imported first so that the HIP runtime already loaded by torch
+            # (soname libamdhip64.so.7) is the one this library binds to.
+            handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+            for name, (res, args) in _PROTOS.items():
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().spk_last_error()
+        raise SpkHipError("spk_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise SpkHipError(
+                "schnetpack_amd: the HIP path needs tensors on a ROCm device (got %s); there is "
+                "no CPU fallback" % t.device)
+
+
+def fptr(t):
+    """Device pointer of a contiguous fp32 tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise SpkHipError("expected a contiguous float32 ROCm tensor, got %s %s contiguous=%s"
+                          % (t.device, t.dtype, t.is_contiguous()))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def iptr(t, dtype=torch.int64):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise SpkHipError("expected a contiguous %s ROCm tensor, got %s %s" % (dtype, t.device, t.dtype))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def set_variant(v):
+    lib().spk_set_variant(int(v))
+
+
+def get_variant():
+    return int(lib().spk_get_variant())
+
+
+def device_info():
+    arr = (c_i32 * 4)()
+    check(lib().spk_device_info(arr))
+    return {"compute_units": arr[0], "wavefront": arr[1], "lds_bytes": arr[2], "gfx": arr[3]}
+
+
+def profile_enable(on=True):
+    lib().spk_profile_enable(1 if on else 0)
+
+
+def profile_report():
+    """{tag: (count, total_ms)} of the kernels launched since the last report."""
+    txt = lib().spk_profile_report().decode()
+    out = {}
+    for line in txt.splitlines():
+        tag, cnt, ms = line.split()
+        out[tag] = (int(cnt), float(ms))
+    return out

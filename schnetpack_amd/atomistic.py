@@ -1,0 +1,96 @@
+"""Minimal mirrors of the reference *callers* either side of the hot path, so that a complete
+force call can be assembled without the reference package (which cannot be imported on the GPU
+box): ``PairwiseDistances`` (atomistic/distances.py:9-26), ``Atomwise``
+(atomistic/atomwise.py:14-88, energy head only) and ``Forces`` (atomistic/response.py:18-92,
+forces only).  In a real integration the reference's own modules are used unchanged -- they only
+see ``schnetpack.nn.scatter_add`` / ``Dense`` / the representation classes.
+"""
+from typing import Callable, Dict, List, Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import properties
+from .nn import build_mlp, scatter_add
+
+__all__ = ["PairwiseDistances", "Atomwise", "Forces"]
+
+
+class PairwiseDistances(nn.Module):
+    """Rij = R[idx_j] - R[idx_i] + offsets; autograd scatters dE/dRij back onto atoms."""
+
+    def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        R = inputs[properties.R]
+        offsets = inputs[properties.offsets]
+        idx_i = inputs[properties.idx_i].long()
+        idx_j = inputs[properties.idx_j].long()
+        inputs[properties.Rij] = R[idx_j] - R[idx_i] + offsets
+        return inputs
+
+
+class Atomwise(nn.Module):
+    """Per-atom MLP + sum over ``idx_m`` (aggregation_mode 'sum' / 'avg' / None)."""
+
+    def __init__(self, n_in: int, n_out: int = 1, n_hidden: Optional[Union[int, Sequence[int]]] = None,
+                 n_layers: int = 2, activation: Callable = F.silu, aggregation_mode: str = "sum",
+                 output_key: str = "y", per_atom_output_key: Optional[str] = None,
+                 n_molecules_key: Optional[str] = "_n_molecules"):
+        super().__init__()
+        self.output_key = output_key
+        self.model_outputs = [output_key]
+        self.per_atom_output_key = per_atom_output_key
+        if per_atom_output_key is not None:
+            self.model_outputs.append(per_atom_output_key)
+        self.n_out = n_out
+        if aggregation_mode is None and per_atom_output_key is None:
+            raise ValueError("If `aggregation_mode` is None, `per_atom_output_key` needs to be set,"
+                             " since no accumulated output will be returned!")
+        self.outnet = build_mlp(n_in=n_in, n_out=n_out, n_hidden=n_hidden, n_layers=n_layers,
+                                activation=activation)
+        self.aggregation_mode = aggregation_mode
+        self.n_molecules_key = n_molecules_key
+
+    def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        y = self.outnet(inputs["scalar_representation"])
+        if self.per_atom_output_key is not None:
+            inputs[self.per_atom_output_key] = y
+        if self.aggregation_mode is not None:
+            idx_m = inputs[properties.idx_m]
+            # the reference reads int(idx_m[-1]) + 1 (a device sync, atomwise.py:80); a host-side
+            # molecule count in the batch dict avoids it when present
+            if self.n_molecules_key is not None and self.n_molecules_key in inputs:
+                maxm = int(inputs[self.n_molecules_key])
+            else:
+                maxm = int(idx_m[-1]) + 1
+            y = scatter_add(y, idx_m, dim_size=maxm)
+            y = torch.squeeze(y, -1)
+            if self.aggregation_mode == "avg":
+                y = y / inputs[properties.n_atoms]
+        inputs[self.output_key] = y
+        return inputs
+
+
+class Forces(nn.Module):
+    """forces = -dE/dR by autograd (create_graph = training), like the reference."""
+
+    def __init__(self, calc_forces: bool = True, energy_key: str = properties.energy,
+                 force_key: str = properties.forces):
+        super().__init__()
+        self.calc_forces = calc_forces
+        self.energy_key = energy_key
+        self.force_key = force_key
+        self.model_outputs = [force_key] if calc_forces else []
+        self.required_derivatives = [properties.R] if calc_forces else []
+
+    def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        Epred = inputs[self.energy_key]
+        go: List[Optional[torch.Tensor]] = [torch.ones_like(Epred)]
+        grads = torch.autograd.grad([Epred], [inputs[p] for p in self.required_derivatives],
+                                    grad_outputs=go, create_graph=self.training)
+        if self.calc_forces:
+            dEdR = grads[0]
+            if dEdR is None:
+                dEdR = torch.zeros_like(inputs[properties.R])
+            inputs[self.force_key] = -dEdR
+        return inputs

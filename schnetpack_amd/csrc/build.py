@@ -1,0 +1,67 @@
+"""Build libspk_hip.so in-tree with hipcc for gfx950 (no torch headers involved).
+
+    python -m schnetpack_amd.csrc.build [--force]
+
+The shared library travels to the GPU box with the repo snapshot (it is git-ignored, not
+gpurun-ignored).  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_painn.hip"]
+HEADERS = ["spk_common.h", os.path.join("..", "..", "include", "spk_hip.h")]
+LIB = os.path.join(HERE, "libspk_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+         "-mcode-object-version=5", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    objs = []
+    procs = []
+    for s in srcs:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(HERE, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if out and verbose:
+            sys.stdout.write(out.decode(errors="replace"))
+        if p.returncode != 0:
+            failed = True
+            print("FAILED:", s)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

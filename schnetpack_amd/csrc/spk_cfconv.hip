@@ -1,0 +1,441 @@
+// Fused SchNet continuous-filter convolution (representation/schnet.py:60-67) for gfx950.
+//
+//   d_e = |r_e|;  phi_k(d_e) (nn/radial.py);  fc = cosine_cutoff(d_e) (nn/cutoff.py)
+//   a_e = W1 phi_e + b1;  z_e = ssp(a_e);  g_e = W2 z_e + b2;  W_e = g_e * fc
+//   y_i = sum_{e -> i} h_{j(e)} * W_e
+//
+// MFMA kernel: one wavefront owns a tile of 32 consecutive edges (lanes 0..31 and 32..63 both map
+// to edge l & 31).  The filter MLP runs as two chained T-GEMMs (see spk_dense.hip) with the
+// packed filter weights staged once per workgroup in LDS; the [32 edge x nf] filter tile lives
+// only in registers.  Modulation gathers h[j] as 16-byte pieces, the per-centre-atom reduction goes
+// through a small per-wave LDS transposition buffer, and each (segment, feature) is flushed with
+// one float atomic (idx_i sorted => few segments per tile).
+//
+// Backward (first order, what Forces needs): forward-mode derivative through the filter MLP
+// (a' = W1 phi', z' = sigmoid(a) a', g' = W2 z'), so dW_e/dd is available per edge without
+// storing anything of size E x nf:
+//   gr_e += (sum_f gy_i h_j (g' fc + g fc')) r_e / d_e
+//   gh_j  = sum_{e: j(e)=j} gy_{i(e)} W_e
+// On a symmetric neighbour list W_e == W_{e'} for the reversed edge, so gh is again a row-local
+// segmented reduction (gather gy of the neighbours); otherwise float atomics on gh[j].
+#include "spk_common.h"
+
+#define TPAD 36  // row stride (floats) of the per-wave transposition buffer: 32 + 4 => conflict-free b128 writes
+
+struct CfArgs {
+  const float* h;      // [N, NF]
+  const float* gy;     // [N, NF]  (backward only)
+  const float* rij;    // [E, 3]
+  const int64_t* idx_i;
+  const int64_t* idx_j;
+  const float* w1;     // [NF, n_rbf]
+  const float* b1;     // [NF]
+  const float* w2;     // [NF, NF]
+  const float* b2;     // [NF]
+  float* y;            // fwd: [N, NF] (pre-zeroed);  bwd: gh [N, NF] (pre-zeroed)
+  float* gr;           // bwd: [E, 3] accumulated
+  int64_t E;
+  int64_t N;
+  RadialDev rb;
+};
+
+// ------------------------------------------------------------------------------------------
+// simple kernels: one workgroup per edge, one thread per filter channel; any NF / n_rbf.
+// ------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void k_cfconv_simple(CfArgs a, int NF, int sym) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sphi = sm;                    // n_rbf
+  float* sdphi = sphi + a.rb.n_rbf;    // n_rbf
+  float* sz = sdphi + a.rb.n_rbf;      // NF
+  float* szp = sz + NF;                // NF
+  float* sred = szp + NF;              // blockDim/64
+  const int f = threadIdx.x;
+  for (int64_t e = blockIdx.x; e < a.E; e += gridDim.x) {
+    const int64_t i = a.idx_i[e], j = a.idx_j[e];
+    const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    float fc, dfc;
+    spk_cutoff_eval(a.rb.cutoff, d, fc, dfc);
+    __syncthreads();
+    if (f < a.rb.n_rbf) { float p, dp; spk_rbf_eval(a.rb, f, d, p, dp); sphi[f] = p; sdphi[f] = dp; }
+    __syncthreads();
+    float z = 0.f, zp = 0.f;
+    if (f < NF) {
+      float av = a.b1[f], ap = 0.f;
+      for (int k = 0; k < a.rb.n_rbf; ++k) {
+        float wv = a.w1[f * a.rb.n_rbf + k];
+        av = fmaf(wv, sphi[k], av);
+        ap = fmaf(wv, sdphi[k], ap);
+      }
+      float sg;
+      spk_softplus_sigmoid(av, z, sg);
+      z -= SPK_LN2_F;
+      zp = sg * ap;
+      sz[f] = z; szp[f] = zp;
+    }
+    __syncthreads();
+    float contrib = 0.f;
+    if (f < NF) {
+      float g = a.b2[f], gp = 0.f;
+      for (int k = 0; k < NF; ++k) {
+        float wv = a.w2[(int64_t)f * NF + k];
+        g = fmaf(wv, sz[k], g);
+        gp = fmaf(wv, szp[k], gp);
+      }
+      const float W = g * fc;
+      if (!BWD) {
+        unsafeAtomicAdd(&a.y[i * NF + f], a.h[j * NF + f] * W);
+      } else {
+        const float Wp = gp * fc + g * dfc;
+        const float gyi = a.gy[i * NF + f];
+        contrib = gyi * a.h[j * NF + f] * Wp;
+        // gh[j] += gy[i] * W_e   (general form; identical to the symmetric row-local form)
+        unsafeAtomicAdd(&a.y[j * NF + f], gyi * W);
+      }
+    }
+    if (BWD) {
+      contrib = spk_wave_sum(contrib);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = contrib;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) tot += sred[wv];
+        if (d > 0.f) {
+          const float s = tot / d;
+          a.gr[3 * e] += s * rx; a.gr[3 * e + 1] += s * ry; a.gr[3 * e + 2] += s * rz;
+        }
+      }
+    }
+  }
+  (void)sym;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA kernels
+// ------------------------------------------------------------------------------------------
+// Packed LDS image of a weight matrix W[NOUT][K] (row-major, K padded with zeros to 8*KB):
+//   P[((t * KB + ug) * 64 + lane) * 4 + v] = W[32 t + (lane & 31)][8 ug + 4 (lane >> 5) + v]
+// so one ds_read_b128 per lane delivers the A operands of 4 consecutive k-steps, conflict-free.
+template <int NWAVES>
+__device__ __forceinline__ void stage_packed(float* dst, const float* __restrict__ w, int nout,
+                                             int K, int KB) {
+  const int total = (nout / 32) * KB * 64;  // float4 slots
+  for (int s = threadIdx.x; s < total; s += NWAVES * 64) {
+    const int lane = s & 63;
+    const int ug = (s >> 6) % KB;
+    const int t = (s >> 6) / KB;
+    const int row = 32 * t + (lane & 31);
+    const int k0 = 8 * ug + 4 * (lane >> 5);
+    f32x4 v;
+    v.x = (k0 + 0 < K) ? w[(int64_t)row * K + k0 + 0] : 0.f;
+    v.y = (k0 + 1 < K) ? w[(int64_t)row * K + k0 + 1] : 0.f;
+    v.z = (k0 + 2 < K) ? w[(int64_t)row * K + k0 + 2] : 0.f;
+    v.w = (k0 + 3 < K) ? w[(int64_t)row * K + k0 + 3] : 0.f;
+    *(f32x4*)(dst + (int64_t)s * 4) = v;
+  }
+}
+
+template <int NF, int KPB, int NWAVES, bool BWD, bool SYM>
+__global__ __launch_bounds__(NWAVES * 64) void k_cfconv_mfma(CfArgs a) {
+  constexpr int NT = NF / 32;   // feature tiles
+  constexpr int KB2 = NF / 8;   // k-blocks (of 8) of the second GEMM
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW2 = smem;                         // NF*NF
+  float* sW1 = sW2 + NF * NF;                // NF*KPB*8
+  float* sb1 = sW1 + NF * KPB * 8;           // NF
+  float* sb2 = sb1 + NF;                     // NF
+  float* sT = sb2 + NF;                      // NWAVES * 32 * TPAD
+  int* sI = (int*)(sT + NWAVES * 32 * TPAD); // NWAVES * 36
+
+  stage_packed<NWAVES>(sW2, a.w2, NF, NF, KB2);
+  stage_packed<NWAVES>(sW1, a.w1, NF, a.rb.n_rbf, KPB);
+  for (int s = threadIdx.x; s < NF; s += NWAVES * 64) { sb1[s] = a.b1[s]; sb2[s] = a.b2[s]; }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  float* myT = sT + wv * (32 * TPAD);
+  int* myI = sI + wv * 36;
+  const int64_t ntiles = (a.E + 31) / 32;
+
+  for (int64_t tile = (int64_t)blockIdx.x * NWAVES + wv; tile < ntiles;
+       tile += (int64_t)gridDim.x * NWAVES) {
+    const int64_t e = tile * 32 + el;
+    const bool valid = e < a.E;
+    const int64_t ec = valid ? e : (a.E - 1);
+    const float rx = a.rij[3 * ec], ry = a.rij[3 * ec + 1], rz = a.rij[3 * ec + 2];
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    float fc, dfc;
+    spk_cutoff_eval(a.rb.cutoff, d, fc, dfc);
+    if (!valid) { fc = 0.f; dfc = 0.f; }
+    const int64_t j = a.idx_j[ec];
+    const int64_t i = a.idx_i[ec];
+    // segment bookkeeping for the row-local reduction: centre atom of every tile edge (-1 = pad)
+    if (hi == 0) myI[el] = valid ? (int)i : -1;
+    if (lane == 0) myI[32] = -1;
+
+    // ---- radial basis for this lane's k slots: kk = 8u + 4hi + v
+    float phi[KPB][4], dphi[KPB][4];
+#pragma unroll
+    for (int u = 0; u < KPB; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float p, dp;
+        spk_rbf_eval(a.rb, 8 * u + 4 * hi + v, d, p, dp);
+        phi[u][v] = p;
+        dphi[u][v] = dp;
+      }
+
+    // ---- GEMM 1 (transposed): a^T[f][e] = sum_k W1[f][k] phi[e][k] + b1[f]
+    f32x16 z[NT];
+    f32x16 zp[BWD ? NT : 1];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[c][r] = sb1[32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi];
+      if (BWD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zp[BWD ? c : 0][r] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < KPB; ++u) {
+        const f32x4 wq = *(const f32x4*)(sW1 + ((c * KPB + u) * 64 + lane) * 4);
+        z[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.x, phi[u][0], z[c], 0, 0, 0);
+        z[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.y, phi[u][1], z[c], 0, 0, 0);
+        z[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.z, phi[u][2], z[c], 0, 0, 0);
+        z[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.w, phi[u][3], z[c], 0, 0, 0);
+        if (BWD) {
+          f32x16& q = zp[BWD ? c : 0];
+          q = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.x, dphi[u][0], q, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.y, dphi[u][1], q, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.z, dphi[u][2], q, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.w, dphi[u][3], q, 0, 0, 0);
+        }
+      }
+      // activation: z = ssp(a); z' = sigmoid(a) a'
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sp, sg;
+        spk_softplus_sigmoid(z[c][r], sp, sg);
+        z[c][r] = sp - SPK_LN2_F;
+        if (BWD) zp[BWD ? c : 0][r] *= sg;
+      }
+    }
+
+    float dsum = 0.f;  // BWD: sum_f gy_i h_j dW/dd over this lane's features
+    // flush mask of this lane's 16-edge half for the segmented reduction
+    spk_wave_lds_sync();
+    unsigned flushmask = 0;
+    {
+      const int base = 16 * hi;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int ci = myI[base + k], ni = myI[base + k + 1];
+        if (k == 15 || ci != ni) flushmask |= (1u << k);
+      }
+    }
+
+    // ---- GEMM 2 per output tile t, modulation, reduction
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      f32x16 g, gp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { g[r] = sb2[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi]; gp[r] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 wq = *(const f32x4*)(sW2 + ((t * KB2 + 4 * c + q) * 64 + lane) * 4);
+          g = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.x, z[c][4 * q + 0], g, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.y, z[c][4 * q + 1], g, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.z, z[c][4 * q + 2], g, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.w, z[c][4 * q + 3], g, 0, 0, 0);
+          if (BWD) {
+            const f32x16& zq = zp[BWD ? c : 0];
+            gp = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.x, zq[4 * q + 0], gp, 0, 0, 0);
+            gp = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.y, zq[4 * q + 1], gp, 0, 0, 0);
+            gp = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.z, zq[4 * q + 2], gp, 0, 0, 0);
+            gp = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.w, zq[4 * q + 3], gp, 0, 0, 0);
+          }
+        }
+      }
+      // modulation with gathered neighbour rows; lane holds features 32t + 8q + 4hi + v
+      const bool use_lds = !BWD || SYM;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * t + 8 * q + 4 * hi;
+        f32x4 p;
+        if (!BWD) {
+          const f32x4 hj = *(const f32x4*)(a.h + j * NF + col);
+          p.x = g[4 * q + 0] * fc * hj.x; p.y = g[4 * q + 1] * fc * hj.y;
+          p.z = g[4 * q + 2] * fc * hj.z; p.w = g[4 * q + 3] * fc * hj.w;
+        } else {
+          const f32x4 hj = *(const f32x4*)(a.h + j * NF + col);
+          const f32x4 gyi = *(const f32x4*)(a.gy + i * NF + col);
+          float W0 = g[4 * q + 0] * fc, W1v = g[4 * q + 1] * fc, W2v = g[4 * q + 2] * fc, W3 = g[4 * q + 3] * fc;
+          dsum += gyi.x * hj.x * (gp[4 * q + 0] * fc + g[4 * q + 0] * dfc);
+          dsum += gyi.y * hj.y * (gp[4 * q + 1] * fc + g[4 * q + 1] * dfc);
+          dsum += gyi.z * hj.z * (gp[4 * q + 2] * fc + g[4 * q + 2] * dfc);
+          dsum += gyi.w * hj.w * (gp[4 * q + 3] * fc + g[4 * q + 3] * dfc);
+          if (SYM) {
+            const f32x4 gyj = *(const f32x4*)(a.gy + j * NF + col);
+            p.x = W0 * gyj.x; p.y = W1v * gyj.y; p.z = W2v * gyj.z; p.w = W3 * gyj.w;
+          } else if (valid) {
+            float* dst = a.y + j * NF + col;
+            unsafeAtomicAdd(dst + 0, W0 * gyi.x);
+            unsafeAtomicAdd(dst + 1, W1v * gyi.y);
+            unsafeAtomicAdd(dst + 2, W2v * gyi.z);
+            unsafeAtomicAdd(dst + 3, W3 * gyi.w);
+          }
+        }
+        if (use_lds) *(f32x4*)(myT + el * TPAD + 8 * q + 4 * hi) = p;
+      }
+      if (use_lds) {
+        spk_wave_lds_sync();
+        // lane (fl = el, half = hi) scans its 16 edges of column fl, flushing at segment ends
+        float acc = 0.f;
+        const int base = 16 * hi;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          acc += myT[(base + k) * TPAD + el];
+          if (flushmask & (1u << k)) {
+            const int ci = myI[base + k];
+            if (ci >= 0) unsafeAtomicAdd(a.y + (int64_t)ci * NF + 32 * t + el, acc);
+            acc = 0.f;
+          }
+        }
+        spk_wave_lds_sync();
+      }
+    }
+    if (BWD) {
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (hi == 0 && valid && d > 0.f) {
+        const float s = dsum / d;
+        a.gr[3 * e] += s * rx; a.gr[3 * e + 1] += s * ry; a.gr[3 * e + 2] += s * rz;
+      }
+    }
+    spk_wave_lds_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static int check_graph(const spk_graph_t* g, const char* who) {
+  SPK_CHECK_ARG(g != nullptr, "%s: null graph", who);
+  SPK_CHECK_ARG(g->n_atoms >= 0 && g->n_edges >= 0 && g->n_atoms < (1LL << 31) && g->n_edges < (1LL << 31), "%s: bad graph sizes", who);
+  SPK_CHECK_ARG(g->n_edges == 0 || (g->idx_i && g->idx_j), "%s: null index arrays", who);
+  return SPK_OK;
+}
+
+template <int NF, int KPB, bool BWD, bool SYM>
+static int launch_mfma(const CfArgs& a, hipStream_t stream) {
+  constexpr int NWAVES = 8;
+  const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + NWAVES * 32 * TPAD) * sizeof(float) +
+                     (size_t)NWAVES * 36 * sizeof(int);
+  auto kern = k_cfconv_mfma<NF, KPB, NWAVES, BWD, SYM>;
+  SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t ntiles = (a.E + 31) / 32;
+  int grid = (int)((ntiles + NWAVES - 1) / NWAVES);
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  if (grid < 1) grid = 1;
+  SpkProfScope prof(BWD ? (SYM ? "cfconv_bwd_mfma_sym" : "cfconv_bwd_mfma_atomic") : "cfconv_fwd_mfma", stream);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+template <bool BWD>
+static int launch_simple(const CfArgs& a, int NF, int sym, hipStream_t stream) {
+  int threads = ((NF > a.rb.n_rbf ? NF : a.rb.n_rbf) + 63) / 64 * 64;
+  SPK_CHECK_ARG(threads <= 1024, "cfconv: n_filters=%d too large", NF);
+  const size_t lds = (size_t)(2 * a.rb.n_rbf + 2 * NF + 16) * sizeof(float);
+  int grid = (int)(a.E < 65535 * 16 ? a.E : 65535 * 16);
+  if (grid < 1) grid = 1;
+  SpkProfScope prof(BWD ? "cfconv_bwd_simple" : "cfconv_fwd_simple", stream);
+  hipLaunchKernelGGL(k_cfconv_simple<BWD>, dim3(grid), dim3(threads), lds, stream, a, NF, sym);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+template <bool BWD>
+static int cfconv_dispatch(const CfArgs& a, int NF, bool sym, hipStream_t stream, const char* who) {
+  const int variant = spk_get_variant();
+  const int kpb = (a.rb.n_rbf + 7) / 8;
+  const bool al = (((uintptr_t)a.h | (uintptr_t)a.gy | (uintptr_t)a.y) % 16) == 0;
+  const bool mfma_ok = (NF == 128 || NF == 64) && kpb >= 1 && kpb <= 4 && al;
+  SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || mfma_ok, "%s: shape nf=%d n_rbf=%d not supported by the MFMA kernel", who, NF, a.rb.n_rbf);
+  if (!mfma_ok || variant == SPK_VARIANT_SIMPLE) return launch_simple<BWD>(a, NF, sym ? 1 : 0, stream);
+#define SPK_CF_CASE(NFv, KPBv)                                                      \
+  if (NF == NFv && kpb == KPBv) {                                                   \
+    if (!BWD) return launch_mfma<NFv, KPBv, false, false>(a, stream);               \
+    return sym ? launch_mfma<NFv, KPBv, BWD, true>(a, stream)                       \
+               : launch_mfma<NFv, KPBv, BWD, false>(a, stream);                     \
+  }
+  SPK_CF_CASE(128, 1) SPK_CF_CASE(128, 2) SPK_CF_CASE(128, 3) SPK_CF_CASE(128, 4)
+  SPK_CF_CASE(64, 1) SPK_CF_CASE(64, 2) SPK_CF_CASE(64, 3) SPK_CF_CASE(64, 4)
+#undef SPK_CF_CASE
+  spk_set_error("%s: internal dispatch error", who);
+  return SPK_ERR_ARG;
+}
+
+int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
+                            const float* r_ij, const float* w1, const float* b1, const float* w2,
+                            const float* b2, int nf, float* y, hipStream_t stream) {
+  const char* who = "spk_schnet_cfconv_fwd_f32";
+  int rc = check_graph(g, who);
+  if (rc) return rc;
+  SPK_CHECK_ARG(rb && rb->n_rbf >= 1 && rb->n_rbf <= 256, "%s: bad radial basis", who);
+  SPK_CHECK_ARG(nf >= 1 && nf % 4 == 0, "%s: n_filters=%d must be a multiple of 4", who, nf);
+  if (g->n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(y != nullptr, "%s: null output", who);
+  SPK_HIP_TRY(hipMemsetAsync(y, 0, (size_t)g->n_atoms * nf * sizeof(float), stream));
+  if (g->n_edges == 0) return SPK_OK;
+  SPK_CHECK_ARG(h && r_ij && w1 && b1 && w2 && b2, "%s: null pointer", who);
+  CfArgs a;
+  a.h = h; a.gy = nullptr; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr;
+  a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
+  return cfconv_dispatch<false>(a, nf, false, stream, who);
+}
+
+int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
+                            const float* gy, const float* r_ij, const float* w1, const float* b1,
+                            const float* w2, const float* b2, int nf, float* gh, float* gr,
+                            hipStream_t stream) {
+  const char* who = "spk_schnet_cfconv_bwd_f32";
+  int rc = check_graph(g, who);
+  if (rc) return rc;
+  SPK_CHECK_ARG(rb && rb->n_rbf >= 1 && rb->n_rbf <= 256, "%s: bad radial basis", who);
+  SPK_CHECK_ARG(nf >= 1 && nf % 4 == 0, "%s: n_filters=%d must be a multiple of 4", who, nf);
+  if (g->n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(gh != nullptr, "%s: null output", who);
+  SPK_HIP_TRY(hipMemsetAsync(gh, 0, (size_t)g->n_atoms * nf * sizeof(float), stream));
+  if (g->n_edges == 0) return SPK_OK;
+  SPK_CHECK_ARG(h && gy && r_ij && w1 && b1 && w2 && b2 && gr, "%s: null pointer", who);
+  CfArgs a;
+  a.h = h; a.gy = gy; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr;
+  a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
+  // the row-local transposed reduction needs idx_i sorted AND a symmetric list
+  const bool sym = g->symmetric && g->sorted;
+  return cfconv_dispatch<true>(a, nf, sym, stream, who);
+}
+
+extern "C" int spk_schnet_cfconv_fwd_f32(const spk_graph_t* g, const spk_radial_t* rb,
+                                         const float* h, const float* r_ij, const float* w1,
+                                         const float* b1, const float* w2, const float* b2,
+                                         int32_t nf, float* y, void* stream) {
+  return spk_cfconv_fwd_internal(g, rb, h, r_ij, w1, b1, w2, b2, nf, y, (hipStream_t)stream);
+}
+
+extern "C" int spk_schnet_cfconv_bwd_f32(const spk_graph_t* g, const spk_radial_t* rb,
+                                         const float* h, const float* gy, const float* r_ij,
+                                         const float* w1, const float* b1, const float* w2,
+                                         const float* b2, int32_t nf, float* gh, float* gr,
+                                         void* stream) {
+  return spk_cfconv_bwd_internal(g, rb, h, gy, r_ij, w1, b1, w2, b2, nf, gh, gr, (hipStream_t)stream);
+}

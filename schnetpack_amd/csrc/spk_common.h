@@ -1,0 +1,153 @@
+// Shared device/host helpers for the gfx950 kernels.  Wavefront = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/spk_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SPK_PI_F 3.14159265358979323846f
+#define SPK_LN2_F 0.69314718055994530942f
+
+// ---------------------------------------------------------------- host error handling
+void spk_set_error(const char* fmt, ...);
+
+#define SPK_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      spk_set_error(__VA_ARGS__);       \
+      return SPK_ERR_ARG;               \
+    }                                   \
+  } while (0)
+
+#define SPK_HIP_TRY(expr)                                                             \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      spk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                    __LINE__);                                                        \
+      return SPK_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)
+
+#define SPK_LAUNCH_CHECK() SPK_HIP_TRY(hipGetLastError())
+
+static inline int spk_grid_for(int64_t work_items, int per_block, int max_blocks) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+int spk_num_cus();
+
+// ---------------------------------------------------------------- per-kernel HIP-event profiling
+// (off by default; bench.py enables it for a separate pass to time individual kernels on the
+// stream they are launched on)
+bool spk_prof_enabled();
+void spk_prof_begin(const char* tag, hipStream_t stream);
+void spk_prof_end(hipStream_t stream);
+struct SpkProfScope {
+  hipStream_t s; bool on;
+  SpkProfScope(const char* tag, hipStream_t stream) : s(stream), on(spk_prof_enabled()) { if (on) spk_prof_begin(tag, s); }
+  ~SpkProfScope() { if (on) spk_prof_end(s); }
+};
+
+// ---------------------------------------------------------------- device math
+// softplus(x) = max(x,0) + log(1 + exp(-|x|)) and sigmoid(x) from one exp.
+// Equivalent to torch's softplus(beta=1, threshold=20) to fp32 round-off.
+__device__ __forceinline__ void spk_softplus_sigmoid(float x, float& sp, float& sg) {
+  float t = __expf(-fabsf(x));
+  float one_t = 1.0f + t;
+  float inv = __frcp_rn(one_t);
+  sp = fmaxf(x, 0.0f) + __logf(one_t);
+  sg = (x >= 0.0f) ? inv : t * inv;
+}
+__device__ __forceinline__ float spk_ssp(float x) {
+  float t = __expf(-fabsf(x));
+  return fmaxf(x, 0.0f) + __logf(1.0f + t) - SPK_LN2_F;
+}
+__device__ __forceinline__ float spk_sigmoid(float x) {
+  float t = __expf(-fabsf(x));
+  float inv = __frcp_rn(1.0f + t);
+  return (x >= 0.0f) ? inv : t * inv;
+}
+template <int ACT>
+__device__ __forceinline__ float spk_act(float x) {
+  if (ACT == SPK_ACT_SSP) return spk_ssp(x);
+  if (ACT == SPK_ACT_SILU) return x * spk_sigmoid(x);
+  return x;
+}
+// derivative of the activation at pre-activation x
+template <int ACT>
+__device__ __forceinline__ float spk_act_grad(float x) {
+  if (ACT == SPK_ACT_SSP) return spk_sigmoid(x);
+  if (ACT == SPK_ACT_SILU) {
+    float s = spk_sigmoid(x);
+    return s * (1.0f + x * (1.0f - s));
+  }
+  return 1.0f;
+}
+
+// Device-side copy of the radial description (passed by value to kernels).
+struct RadialDev {
+  int kind;
+  int n_rbf;
+  const float* p0;
+  const float* p1;
+  float cutoff;
+};
+static inline RadialDev spk_radial_dev(const spk_radial_t* rb) {
+  RadialDev r;
+  r.kind = rb->kind; r.n_rbf = rb->n_rbf; r.p0 = rb->p0; r.p1 = rb->p1; r.cutoff = rb->cutoff;
+  return r;
+}
+
+// phi_k(d) and d phi_k / dd  (nn/radial.py:11-15 gaussian, :105-110 bessel)
+__device__ __forceinline__ void spk_rbf_eval(const RadialDev& rb, int k, float d, float& phi,
+                                             float& dphi) {
+  if (k >= rb.n_rbf) { phi = 0.f; dphi = 0.f; return; }
+  if (rb.kind == SPK_RBF_GAUSSIAN) {
+    float w = rb.p1[k];
+    float c = -0.5f / (w * w);
+    float t = d - rb.p0[k];
+    phi = expf(c * t * t);
+    dphi = 2.0f * c * t * phi;
+  } else {
+    float om = rb.p0[k];
+    float s, co;
+    sincosf(om * d, &s, &co);
+    if (d == 0.0f) { phi = s; dphi = 0.f; }
+    else { float inv = 1.0f / d; phi = s * inv; dphi = (om * co - phi) * inv; }
+  }
+}
+// cosine cutoff and derivative (nn/cutoff.py:14-33)
+__device__ __forceinline__ void spk_cutoff_eval(float rc, float d, float& f, float& df) {
+  if (d < rc) {
+    float s, c;
+    float a = SPK_PI_F / rc;
+    sincosf(d * a, &s, &c);
+    f = 0.5f * (c + 1.0f);
+    df = -0.5f * a * s;
+  } else { f = 0.f; df = 0.f; }
+}
+
+__device__ __forceinline__ float spk_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float spk_readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// wave-local LDS hand-off between lanes of ONE wavefront (no other wave touches the buffer)
+__device__ __forceinline__ void spk_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

@@ -1,0 +1,161 @@
+// Dense layers (nn/base.py:52-55) on the fp32 matrix cores of gfx950.
+//
+// "T-GEMM" convention used by every MFMA kernel of this library (v_mfma_f32_32x32x2_f32,
+// exact fp32, 64 lanes):
+//   the wave computes a 32x32 tile of OUT^T:  rows = output features i, columns = samples m.
+//   A operand (weights):  lane l holds A[i = i0 + (l & 31)][kk],
+//   B operand (samples):  lane l holds B[kk][m = m0 + (l & 31)] = in[m][kk],
+//   where for k-step s = 4u + v the lane half hi = l >> 5 supplies kk = 8u + 4hi + v
+//   (any bijection between (step, half) and kk is legal as long as A and B agree; this one lets
+//   each lane fetch 4 consecutive kk with one 16-byte load),
+//   C/D accumulator:      acc[r] <-> row i = i0 + (r & 3) + 8 (r >> 2) + 4 hi, column m0 + (l & 31).
+//   Because the accumulator rows use the same (r>>2, r&3, hi) -> index map as the k-steps, an
+//   accumulator tile can be fed straight back as the B operand of the next layer (chained GEMMs
+//   without leaving registers) -- used by the fused cfconv kernels.
+#include "spk_common.h"
+
+template <int ACT, bool TRANS, int PRO>
+__global__ __launch_bounds__(256) void k_dense_mfma(
+    const float* __restrict__ in, const float* __restrict__ pre_in, const float* __restrict__ w,
+    const float* __restrict__ b, const float* res, float* out,
+    float* __restrict__ pre_out, int64_t M, int KC, int NW, int64_t ntasks) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  const int tcount = NW / 32;
+  for (int64_t task = blockIdx.x * 4 + wv; task < ntasks; task += (int64_t)gridDim.x * 4) {
+    const int64_t mt = task / tcount;
+    const int t = (int)(task % tcount);
+    const int64_t m = mt * 32 + el;
+    const bool valid = m < M;
+    const int64_t mc = valid ? m : (M - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b ? b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
+    const float* inrow = in + mc * KC;
+    const float* prow = PRO != SPK_ACT_NONE ? pre_in + mc * KC : nullptr;
+    const int nug = KC / 8;
+    for (int ug = 0; ug < nug; ++ug) {
+      const int kk0 = 8 * ug + 4 * hi;
+      f32x4 bv = *(const f32x4*)(inrow + kk0);
+      if (PRO != SPK_ACT_NONE) {
+        f32x4 pv = *(const f32x4*)(prow + kk0);
+        bv.x *= spk_act_grad<PRO>(pv.x); bv.y *= spk_act_grad<PRO>(pv.y);
+        bv.z *= spk_act_grad<PRO>(pv.z); bv.w *= spk_act_grad<PRO>(pv.w);
+      }
+      f32x4 av;
+      if (!TRANS) {
+        av = *(const f32x4*)(w + (int64_t)(32 * t + el) * KC + kk0);
+      } else {
+        const float* wp = w + (int64_t)kk0 * NW + 32 * t + el;
+        av.x = wp[0]; av.y = wp[NW]; av.z = wp[2 * (int64_t)NW]; av.w = wp[3 * (int64_t)NW];
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t off = m * NW + 32 * t + 8 * q + 4 * hi;
+        f32x4 o;
+        o.x = acc[4 * q]; o.y = acc[4 * q + 1]; o.z = acc[4 * q + 2]; o.w = acc[4 * q + 3];
+        if (pre_out) *(f32x4*)(pre_out + off) = o;
+        o.x = spk_act<ACT>(o.x); o.y = spk_act<ACT>(o.y); o.z = spk_act<ACT>(o.z); o.w = spk_act<ACT>(o.w);
+        if (res) { f32x4 rv = *(const f32x4*)(res + off); o += rv; }
+        *(f32x4*)(out + off) = o;
+      }
+    }
+  }
+}
+
+// Straightforward kernel for any shape: one thread per output element.
+__global__ void k_dense_simple(const float* __restrict__ in, const float* __restrict__ pre_in,
+                               const float* __restrict__ w, const float* __restrict__ b,
+                               const float* res, float* out,
+                               float* __restrict__ pre_out, int64_t M, int KC, int NW, int act,
+                               int trans, int pro) {
+  const int64_t total = M * (int64_t)NW;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = t / NW;
+    const int i = (int)(t % NW);
+    float acc = b ? b[i] : 0.f;
+    for (int kk = 0; kk < KC; ++kk) {
+      float v = in[m * KC + kk];
+      if (pro == SPK_ACT_SSP) v *= spk_act_grad<SPK_ACT_SSP>(pre_in[m * KC + kk]);
+      else if (pro == SPK_ACT_SILU) v *= spk_act_grad<SPK_ACT_SILU>(pre_in[m * KC + kk]);
+      float a = trans ? w[(int64_t)kk * NW + i] : w[(int64_t)i * KC + kk];
+      acc = fmaf(a, v, acc);
+    }
+    if (pre_out) pre_out[t] = acc;
+    if (act == SPK_ACT_SSP) acc = spk_ssp(acc);
+    else if (act == SPK_ACT_SILU) acc = acc * spk_sigmoid(acc);
+    if (res) acc += res[t];
+    out[t] = acc;
+  }
+}
+
+static bool aligned16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
+
+// in [M,KC] -> out [M,NW]
+static int dense_dispatch(const float* in, const float* pre_in, const float* w, const float* b,
+                          const float* res, float* out, float* pre_out, int64_t M, int KC, int NW,
+                          int act, bool trans, int pro, hipStream_t stream, const char* who) {
+  SPK_CHECK_ARG(M >= 0 && KC > 0 && NW > 0, "%s: bad sizes M=%lld K=%d N=%d", who, (long long)M, KC, NW);
+  if (M == 0) return SPK_OK;
+  SPK_CHECK_ARG(in && w && out, "%s: null pointer", who);
+  SPK_CHECK_ARG(act >= 0 && act <= 2 && pro >= 0 && pro <= 2, "%s: unknown activation", who);
+  SPK_CHECK_ARG(pro == SPK_ACT_NONE || pre_in != nullptr, "%s: pre-activation required", who);
+  const int variant = spk_get_variant();
+  const bool shape_ok = (KC % 8 == 0) && (NW % 32 == 0) && aligned16(in) && aligned16(pre_in) &&
+                        aligned16(w) && aligned16(res) && aligned16(out) && aligned16(pre_out);
+  SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || shape_ok, "%s: shape K=%d N=%d not supported by the MFMA kernel", who, KC, NW);
+  SpkProfScope prof(trans ? "dense_bwd" : "dense_fwd", stream);
+  if (shape_ok && variant != SPK_VARIANT_SIMPLE) {
+    const int64_t ntasks = ((M + 31) / 32) * (NW / 32);
+    const int grid = spk_grid_for(ntasks, 4, spk_num_cus() * 8);
+#define SPK_DENSE_LAUNCH(A, T, P)                                                               \
+  hipLaunchKernelGGL((k_dense_mfma<A, T, P>), dim3(grid), dim3(256), 0, stream, in, pre_in, w, b, \
+                     res, out, pre_out, M, KC, NW, ntasks)
+    if (!trans) {
+      if (act == SPK_ACT_NONE) SPK_DENSE_LAUNCH(SPK_ACT_NONE, false, SPK_ACT_NONE);
+      else if (act == SPK_ACT_SSP) SPK_DENSE_LAUNCH(SPK_ACT_SSP, false, SPK_ACT_NONE);
+      else SPK_DENSE_LAUNCH(SPK_ACT_SILU, false, SPK_ACT_NONE);
+    } else {
+      if (pro == SPK_ACT_NONE) SPK_DENSE_LAUNCH(SPK_ACT_NONE, true, SPK_ACT_NONE);
+      else if (pro == SPK_ACT_SSP) SPK_DENSE_LAUNCH(SPK_ACT_NONE, true, SPK_ACT_SSP);
+      else SPK_DENSE_LAUNCH(SPK_ACT_NONE, true, SPK_ACT_SILU);
+    }
+#undef SPK_DENSE_LAUNCH
+  } else {
+    const int grid = spk_grid_for(M * NW, 256, spk_num_cus() * 16);
+    hipLaunchKernelGGL(k_dense_simple, dim3(grid), dim3(256), 0, stream, in, pre_in, w, b, res, out,
+                       pre_out, M, KC, NW, act, trans ? 1 : 0, pro);
+  }
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_dense_f32(const float* x, const float* w, const float* b, const float* res,
+                             float* y, float* pre, int64_t m, int32_t k, int32_t n_out,
+                             int32_t act, void* stream) {
+  return dense_dispatch(x, nullptr, w, b, res, y, pre, m, k, n_out, act, false, SPK_ACT_NONE,
+                        (hipStream_t)stream, "spk_dense_f32");
+}
+
+extern "C" int spk_dense_bwd_input_f32(const float* dy, const float* pre, const float* w,
+                                       const float* res, float* dx, int64_t m, int32_t k,
+                                       int32_t n_out, int32_t act, void* stream) {
+  // contraction over the n_out outputs; result width k
+  return dense_dispatch(dy, pre, w, nullptr, res, dx, nullptr, m, n_out, k, SPK_ACT_NONE, true, act,
+                        (hipStream_t)stream, "spk_dense_bwd_input_f32");
+}
+
+// internal C++ entry used by the whole-representation drivers
+int spk_dense_internal(const float* in, const float* pre_in, const float* w, const float* b,
+                       const float* res, float* out, float* pre_out, int64_t M, int KC, int NW,
+                       int act, bool trans, int pro, hipStream_t stream) {
+  return dense_dispatch(in, pre_in, w, b, res, out, pre_out, M, KC, NW, act, trans, pro, stream,
+                        "spk_dense");
+}

@@ -1,0 +1,610 @@
+// PaiNN (representation/painn.py) for gfx950: fused equivariant message (+ first-order backward),
+// the elementwise parts of the mixing block, and whole-representation drivers.
+//
+// Message kernels are HBM/L2-bound gathers, so they are organised around the centre atom:
+// one wavefront owns one CSR row, lanes own features (VPL = F/64 consecutive channels per lane =>
+// every neighbour row is read as one coalesced 4F-byte burst), the per-atom sums stay in registers
+// (no atomics, no cross-lane reduction) and are written once.  The filter slice
+// Phi_e = (phi(d_e) Wf^T + bf) fcut(d_e) is recomputed per edge from register-resident weights
+// (n_rbf <= NRBF FMAs per channel); the reference's [E, 3F n_int] filter tensor never exists.
+#include "spk_common.h"
+
+int spk_dense_internal(const float* in, const float* pre_in, const float* w, const float* b,
+                       const float* res, float* out, float* pre_out, int64_t M, int KC, int NW,
+                       int act, bool trans, int pro, hipStream_t stream);
+
+struct MsgArgs {
+  const float* c;       // [N, 3F] context-net output
+  const float* q;       // [N, F]
+  const float* mu;      // [N, 3, F]
+  const float* gq_out;  // bwd [N, F]
+  const float* gmu_out; // bwd [N, 3, F]
+  const float* rij;     // [E, 3]
+  const int64_t* idx_i;
+  const int64_t* idx_j;
+  const int32_t* rowptr;
+  const float* wf;      // [3F, n_rbf] rows of this layer
+  const float* bf;      // [3F]
+  float* q_out;         // fwd [N, F]
+  float* mu_out;        // fwd [N, 3, F]
+  float* gc;            // bwd [N, 3F]
+  float* gmu;           // bwd [N, 3, F]
+  float* gr;            // bwd [E, 3] accumulated
+  int64_t E, N;
+  int F;
+  RadialDev rb;
+};
+
+// ------------------------------------------------------------------------------------------
+// row kernels (sorted idx_i; backward additionally needs a symmetric list)
+// ------------------------------------------------------------------------------------------
+template <int VPL, int NRBF, bool BWD>
+__global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int F = a.F;
+  const int K = a.rb.n_rbf;
+  // register-resident filter weights of this lane's channels: part p in (q, R, mu)
+  float w[3][VPL][NRBF];
+  float bias[3][VPL];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int row = p * F + VPL * lane + v;
+      bias[p][v] = a.bf[row];
+#pragma unroll
+      for (int k = 0; k < NRBF; ++k) w[p][v][k] = (k < K) ? a.wf[(int64_t)row * K + k] : 0.f;
+    }
+
+  for (int64_t atom = (int64_t)blockIdx.x * 4 + wv; atom < a.N; atom += (int64_t)gridDim.x * 4) {
+    const int32_t e0 = a.rowptr[atom], e1 = a.rowptr[atom + 1];
+    const int64_t fo = (int64_t)VPL * lane;  // first channel of this lane
+    float accq[VPL], accv[3][VPL];           // fwd: dq, dmu ; bwd: gc_q, S
+    float accR[VPL];                         // bwd: gc_R
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) { accq[v] = 0.f; accR[v] = 0.f; accv[0][v] = accv[1][v] = accv[2][v] = 0.f; }
+    // values at the centre atom needed by the backward
+    float gqa[VPL], gma[3][VPL];
+    if (BWD) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        gqa[v] = a.gq_out[atom * F + fo + v];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) gma[x][v] = a.gmu_out[(atom * 3 + x) * F + fo + v];
+      }
+    }
+    for (int32_t cs = e0; cs < e1; cs += 64) {
+      // lanes = edges: geometry of up to 64 edges of this row at once
+      const int32_t em = cs + lane;
+      const bool ev = em < e1;
+      const int32_t emc = ev ? em : (e1 - 1);
+      const int jl = (int)a.idx_j[emc];
+      const float rx = a.rij[3 * (int64_t)emc], ry = a.rij[3 * (int64_t)emc + 1], rz = a.rij[3 * (int64_t)emc + 2];
+      const float dl = sqrtf(rx * rx + ry * ry + rz * rz);
+      const float inv = 1.0f / dl;
+      const float uxl = rx * inv, uyl = ry * inv, uzl = rz * inv;
+      float fcl, dfcl;
+      spk_cutoff_eval(a.rb.cutoff, dl, fcl, dfcl);
+      float grx = 0.f, gry = 0.f, grz = 0.f;  // bwd: geometry gradient of this lane's edge
+      const int n = (e1 - cs) < 64 ? (e1 - cs) : 64;
+      for (int t = 0; t < n; ++t) {
+        const int64_t j = __builtin_amdgcn_readlane(jl, t);
+        const float d = spk_readlane_f(dl, t);
+        const float ux = spk_readlane_f(uxl, t), uy = spk_readlane_f(uyl, t), uz = spk_readlane_f(uzl, t);
+        const float fc = spk_readlane_f(fcl, t), dfc = spk_readlane_f(dfcl, t);
+        // lane k evaluates phi_k(d)
+        float pl, dpl;
+        spk_rbf_eval(a.rb, lane, d, pl, dpl);
+        float P[3][VPL], Pd[3][VPL];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) { P[p][v] = bias[p][v]; Pd[p][v] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < NRBF; ++k) {
+          const float s = spk_readlane_f(pl, k);
+          const float sd = BWD ? spk_readlane_f(dpl, k) : 0.f;
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+              P[p][v] = fmaf(w[p][v][k], s, P[p][v]);
+              if (BWD) Pd[p][v] = fmaf(w[p][v][k], sd, Pd[p][v]);
+            }
+        }
+        const float* cj = a.c + j * 3 * F + fo;
+        const float* muj = a.mu + j * 3 * F + fo;
+        if (!BWD) {
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) {
+            const float mq = P[0][v] * fc * cj[v];
+            const float mR = P[1][v] * fc * cj[F + v];
+            const float mm = P[2][v] * fc * cj[2 * F + v];
+            accq[v] += mq;
+            accv[0][v] += mR * ux + mm * muj[v];
+            accv[1][v] += mR * uy + mm * muj[F + v];
+            accv[2][v] += mR * uz + mm * muj[2 * F + v];
+          }
+        } else {
+          const float* gqb = a.gq_out + j * F + fo;
+          const float* gmb = a.gmu_out + j * 3 * F + fo;
+          float dd = 0.f, tux = 0.f, tuy = 0.f, tuz = 0.f;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) {
+            const float Fq = P[0][v] * fc, FR = P[1][v] * fc, Fm = P[2][v] * fc;
+            const float dFq = Pd[0][v] * fc + P[0][v] * dfc;
+            const float dFR = Pd[1][v] * fc + P[1][v] * dfc;
+            const float dFm = Pd[2][v] * fc + P[2][v] * dfc;
+            const float cq = cj[v], cR = cj[F + v], cm = cj[2 * F + v];
+            const float mb0 = muj[v], mb1 = muj[F + v], mb2 = muj[2 * F + v];
+            const float gb0 = gmb[v], gb1 = gmb[F + v], gb2 = gmb[2 * F + v];
+            // (1) transposed sums for the centre atom acting as neighbour of b (reverse edge)
+            accq[v] += Fq * gqb[v];
+            accR[v] -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
+            accv[0][v] += Fm * gb0; accv[1][v] += Fm * gb1; accv[2][v] += Fm * gb2;
+            // (2) geometry gradient of edge (atom <- b)
+            const float gu = gma[0][v] * ux + gma[1][v] * uy + gma[2][v] * uz;
+            const float gm = gma[0][v] * mb0 + gma[1][v] * mb1 + gma[2][v] * mb2;
+            dd += cq * gqa[v] * dFq + cR * gu * dFR + cm * gm * dFm;
+            const float mR = FR * cR;
+            tux += gma[0][v] * mR; tuy += gma[1][v] * mR; tuz += gma[2][v] * mR;
+          }
+          dd = spk_wave_sum(dd); tux = spk_wave_sum(tux); tuy = spk_wave_sum(tuy); tuz = spk_wave_sum(tuz);
+          if (lane == t) {
+            const float dot = tux * ux + tuy * uy + tuz * uz;
+            const float invd = 1.0f / d;
+            grx = dd * ux + (tux - dot * ux) * invd;
+            gry = dd * uy + (tuy - dot * uy) * invd;
+            grz = dd * uz + (tuz - dot * uz) * invd;
+          }
+        }
+      }
+      if (BWD && ev && dl > 0.f) {
+        a.gr[3 * (int64_t)em] += grx; a.gr[3 * (int64_t)em + 1] += gry; a.gr[3 * (int64_t)em + 2] += grz;
+      }
+    }
+    if (!BWD) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        a.q_out[atom * F + fo + v] = a.q[atom * F + fo + v] + accq[v];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+          a.mu_out[(atom * 3 + x) * F + fo + v] = a.mu[(atom * 3 + x) * F + fo + v] + accv[x][v];
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const float ma0 = a.mu[(atom * 3 + 0) * F + fo + v], ma1 = a.mu[(atom * 3 + 1) * F + fo + v],
+                    ma2 = a.mu[(atom * 3 + 2) * F + fo + v];
+        const float cma = a.c[atom * 3 * F + 2 * F + fo + v];
+        a.gc[atom * 3 * F + fo + v] = accq[v];
+        a.gc[atom * 3 * F + F + fo + v] = accR[v];
+        a.gc[atom * 3 * F + 2 * F + fo + v] = ma0 * accv[0][v] + ma1 * accv[1][v] + ma2 * accv[2][v];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+          a.gmu[(atom * 3 + x) * F + fo + v] = gma[x][v] + cma * accv[x][v];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// simple kernels: one workgroup per edge, one thread per channel, float atomics; any F / n_rbf,
+// any edge order, no symmetry assumption.  Outputs must be pre-initialised by the launcher
+// (fwd: q_out = q, mu_out = mu; bwd: gc = 0, gmu = gmu_out).
+// ------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void k_painn_msg_simple(MsgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = a.rb.n_rbf, F = a.F;
+  float* sphi = sm;
+  float* sdphi = sm + K;
+  float* sred = sdphi + K;  // 4 * (blockDim/64)
+  const int f = threadIdx.x;
+  const int nw = blockDim.x >> 6;
+  for (int64_t e = blockIdx.x; e < a.E; e += gridDim.x) {
+    const int64_t i = a.idx_i[e], j = a.idx_j[e];
+    const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float inv = 1.0f / d;
+    const float ux = rx * inv, uy = ry * inv, uz = rz * inv;
+    float fc, dfc;
+    spk_cutoff_eval(a.rb.cutoff, d, fc, dfc);
+    __syncthreads();
+    if (f < K) { float p, dp; spk_rbf_eval(a.rb, f, d, p, dp); sphi[f] = p; sdphi[f] = dp; }
+    __syncthreads();
+    float dd = 0.f, tux = 0.f, tuy = 0.f, tuz = 0.f;
+    if (f < F) {
+      float P[3], Pd[3];
+      for (int p = 0; p < 3; ++p) {
+        const int row = p * F + f;
+        float s = a.bf[row], sd = 0.f;
+        for (int k = 0; k < K; ++k) {
+          const float wv = a.wf[(int64_t)row * K + k];
+          s = fmaf(wv, sphi[k], s);
+          sd = fmaf(wv, sdphi[k], sd);
+        }
+        P[p] = s; Pd[p] = sd;
+      }
+      const float cq = a.c[j * 3 * F + f], cR = a.c[j * 3 * F + F + f], cm = a.c[j * 3 * F + 2 * F + f];
+      const float mb0 = a.mu[(j * 3 + 0) * F + f], mb1 = a.mu[(j * 3 + 1) * F + f], mb2 = a.mu[(j * 3 + 2) * F + f];
+      const float Fq = P[0] * fc, FR = P[1] * fc, Fm = P[2] * fc;
+      if (!BWD) {
+        const float mq = Fq * cq, mR = FR * cR, mm = Fm * cm;
+        unsafeAtomicAdd(&a.q_out[i * F + f], mq);
+        unsafeAtomicAdd(&a.mu_out[(i * 3 + 0) * F + f], mR * ux + mm * mb0);
+        unsafeAtomicAdd(&a.mu_out[(i * 3 + 1) * F + f], mR * uy + mm * mb1);
+        unsafeAtomicAdd(&a.mu_out[(i * 3 + 2) * F + f], mR * uz + mm * mb2);
+      } else {
+        const float gq = a.gq_out[i * F + f];
+        const float g0 = a.gmu_out[(i * 3 + 0) * F + f], g1 = a.gmu_out[(i * 3 + 1) * F + f], g2 = a.gmu_out[(i * 3 + 2) * F + f];
+        const float gu = g0 * ux + g1 * uy + g2 * uz;
+        const float gm = g0 * mb0 + g1 * mb1 + g2 * mb2;
+        // gc[j] += Phi * mbar ;  gmu[j] += m_mu * gmu_out[i]
+        unsafeAtomicAdd(&a.gc[j * 3 * F + f], Fq * gq);
+        unsafeAtomicAdd(&a.gc[j * 3 * F + F + f], FR * gu);
+        unsafeAtomicAdd(&a.gc[j * 3 * F + 2 * F + f], Fm * gm);
+        const float mm = Fm * cm;
+        unsafeAtomicAdd(&a.gmu[(j * 3 + 0) * F + f], mm * g0);
+        unsafeAtomicAdd(&a.gmu[(j * 3 + 1) * F + f], mm * g1);
+        unsafeAtomicAdd(&a.gmu[(j * 3 + 2) * F + f], mm * g2);
+        const float dFq = Pd[0] * fc + P[0] * dfc, dFR = Pd[1] * fc + P[1] * dfc, dFm = Pd[2] * fc + P[2] * dfc;
+        dd = cq * gq * dFq + cR * gu * dFR + cm * gm * dFm;
+        const float mR = FR * cR;
+        tux = g0 * mR; tuy = g1 * mR; tuz = g2 * mR;
+      }
+    }
+    if (BWD) {
+      dd = spk_wave_sum(dd); tux = spk_wave_sum(tux); tuy = spk_wave_sum(tuy); tuz = spk_wave_sum(tuz);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) {
+        const int wq = threadIdx.x >> 6;
+        sred[4 * wq] = dd; sred[4 * wq + 1] = tux; sred[4 * wq + 2] = tuy; sred[4 * wq + 3] = tuz;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0 && d > 0.f) {
+        float D = 0.f, X = 0.f, Y = 0.f, Z = 0.f;
+        for (int wq = 0; wq < nw; ++wq) { D += sred[4 * wq]; X += sred[4 * wq + 1]; Y += sred[4 * wq + 2]; Z += sred[4 * wq + 3]; }
+        const float dot = X * ux + Y * uy + Z * uz;
+        a.gr[3 * e] += D * ux + (X - dot * ux) * inv;
+        a.gr[3 * e + 1] += D * uy + (Y - dot * uy) * inv;
+        a.gr[3 * e + 2] += D * uz + (Z - dot * uz) * inv;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers of the message
+// ------------------------------------------------------------------------------------------
+static int check_msg(const spk_graph_t* g, const spk_radial_t* rb, int F, const char* who) {
+  SPK_CHECK_ARG(g != nullptr && rb != nullptr, "%s: null graph/radial", who);
+  SPK_CHECK_ARG(g->n_atoms >= 0 && g->n_edges >= 0 && g->n_atoms < (1LL << 31) && g->n_edges < (1LL << 31), "%s: bad graph sizes", who);
+  SPK_CHECK_ARG(g->n_edges == 0 || (g->idx_i && g->idx_j), "%s: null index arrays", who);
+  SPK_CHECK_ARG(F >= 1 && F <= 1024, "%s: n_atom_basis=%d unsupported", who, F);
+  SPK_CHECK_ARG(rb->n_rbf >= 1 && rb->n_rbf <= 256, "%s: n_rbf=%d unsupported", who, rb->n_rbf);
+  return SPK_OK;
+}
+
+template <bool BWD>
+static int msg_dispatch(const MsgArgs& a, bool row_ok, hipStream_t stream, const char* who) {
+  const int variant = spk_get_variant();
+  const int F = a.F, K = a.rb.n_rbf;
+  const bool shape_ok = row_ok && (F == 64 || F == 128) && K <= 32;
+  SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || shape_ok, "%s: shape F=%d n_rbf=%d (or unsorted/asymmetric list) not supported by the row kernel", who, F, K);
+  if (shape_ok && variant != SPK_VARIANT_SIMPLE) {
+    const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 8);
+    SpkProfScope prof(BWD ? "painn_msg_bwd_row" : "painn_msg_fwd_row", stream);
+#define SPK_MSG_CASE(VPLv, NRBFv)                                                              \
+  hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD>), dim3(grid), dim3(256), 0, stream, a)
+    if (F == 64) { if (K <= 20) SPK_MSG_CASE(1, 20); else SPK_MSG_CASE(1, 32); }
+    else { if (K <= 20) SPK_MSG_CASE(2, 20); else SPK_MSG_CASE(2, 32); }
+#undef SPK_MSG_CASE
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
+  // simple path: initialise outputs, then atomics
+  const size_t nf = (size_t)a.N * F;
+  if (!BWD) {
+    SPK_HIP_TRY(hipMemcpyAsync(a.q_out, a.q, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    SPK_HIP_TRY(hipMemcpyAsync(a.mu_out, a.mu, 3 * nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  } else {
+    SPK_HIP_TRY(hipMemsetAsync(a.gc, 0, 3 * nf * sizeof(float), stream));
+    SPK_HIP_TRY(hipMemcpyAsync(a.gmu, a.gmu_out, 3 * nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
+  if (a.E == 0) return SPK_OK;
+  int threads = ((F > K ? F : K) + 63) / 64 * 64;
+  const size_t lds = (size_t)(2 * K + 4 * 16 + 8) * sizeof(float);
+  int grid = (int)(a.E < 65535 * 16 ? a.E : 65535 * 16);
+  SpkProfScope prof(BWD ? "painn_msg_bwd_simple" : "painn_msg_fwd_simple", stream);
+  hipLaunchKernelGGL(k_painn_msg_simple<BWD>, dim3(grid), dim3(threads), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+int spk_painn_message_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
+                                   const float* q, const float* mu, const float* r_ij,
+                                   const float* wf, const float* bf, int F, float* q_out,
+                                   float* mu_out, hipStream_t stream) {
+  const char* who = "spk_painn_message_fwd_f32";
+  int rc = check_msg(g, rb, F, who);
+  if (rc) return rc;
+  if (g->n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(c && q && mu && wf && bf && q_out && mu_out && (g->n_edges == 0 || r_ij), "%s: null pointer", who);
+  MsgArgs a = {};
+  a.c = c; a.q = q; a.mu = mu; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j; a.rowptr = g->rowptr;
+  a.wf = wf; a.bf = bf; a.q_out = q_out; a.mu_out = mu_out; a.E = g->n_edges; a.N = g->n_atoms; a.F = F;
+  a.rb = spk_radial_dev(rb);
+  return msg_dispatch<false>(a, g->sorted && g->rowptr, stream, who);
+}
+
+int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
+                                   const float* mu, const float* gq_out, const float* gmu_out,
+                                   const float* r_ij, const float* wf, const float* bf, int F,
+                                   float* gc, float* gmu, float* gr, hipStream_t stream) {
+  const char* who = "spk_painn_message_bwd_f32";
+  int rc = check_msg(g, rb, F, who);
+  if (rc) return rc;
+  if (g->n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(c && mu && gq_out && gmu_out && wf && bf && gc && gmu && (g->n_edges == 0 || (r_ij && gr)), "%s: null pointer", who);
+  MsgArgs a = {};
+  a.c = c; a.mu = mu; a.gq_out = gq_out; a.gmu_out = gmu_out; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
+  a.rowptr = g->rowptr; a.wf = wf; a.bf = bf; a.gc = gc; a.gmu = gmu; a.gr = gr; a.E = g->n_edges; a.N = g->n_atoms;
+  a.F = F; a.rb = spk_radial_dev(rb);
+  return msg_dispatch<true>(a, g->sorted && g->symmetric && g->rowptr, stream, who);
+}
+
+extern "C" int spk_painn_message_fwd_f32(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
+                                         const float* q, const float* mu, const float* r_ij,
+                                         const float* wf, const float* bf, int32_t F, float* q_out,
+                                         float* mu_out, void* stream) {
+  return spk_painn_message_fwd_internal(g, rb, c, q, mu, r_ij, wf, bf, F, q_out, mu_out, (hipStream_t)stream);
+}
+
+extern "C" int spk_painn_message_bwd_f32(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
+                                         const float* mu, const float* gq_out, const float* gmu_out,
+                                         const float* r_ij, const float* wf, const float* bf, int32_t F,
+                                         float* gc, float* gmu, float* gr, void* stream) {
+  return spk_painn_message_bwd_internal(g, rb, c, mu, gq_out, gmu_out, r_ij, wf, bf, F, gc, gmu, gr, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// mixing block: elementwise parts (per atom, per channel)
+// ------------------------------------------------------------------------------------------
+// ctx[n] = (q[n] | sqrt(sum_x V^2 + eps)),  mix [N,3,2F] = (V | W)
+__global__ void k_mix_ctx(const float* __restrict__ q, const float* __restrict__ mix, int64_t N,
+                          int F, float eps, float* __restrict__ ctx) {
+  const int64_t total = N * (int64_t)F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = t / F;
+    const int f = (int)(t % F);
+    const float v0 = mix[(n * 3 + 0) * 2 * F + f], v1 = mix[(n * 3 + 1) * 2 * F + f], v2 = mix[(n * 3 + 2) * 2 * F + f];
+    ctx[n * 2 * F + f] = q[t];
+    ctx[n * 2 * F + F + f] = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + eps);
+  }
+}
+
+// q_out = q + a_q + a_qmu sum_x V W ; mu_out = mu + a_mu W
+__global__ void k_mix_update(const float* __restrict__ q, const float* __restrict__ mu,
+                             const float* __restrict__ mix, const float* __restrict__ a, int64_t N,
+                             int F, float* q_out, float* mu_out) {
+  const int64_t total = N * (int64_t)F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = t / F;
+    const int f = (int)(t % F);
+    const float aq = a[n * 3 * F + f], am = a[n * 3 * F + F + f], aqm = a[n * 3 * F + 2 * F + f];
+    float s = 0.f;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const float V = mix[(n * 3 + x) * 2 * F + f], W = mix[(n * 3 + x) * 2 * F + F + f];
+      s += V * W;
+      mu_out[(n * 3 + x) * F + f] = mu[(n * 3 + x) * F + f] + am * W;
+    }
+    q_out[t] = q[t] + aq + aqm * s;
+  }
+}
+
+// backward of k_mix_update w.r.t. a and mix (direct paths into q, mu are the caller's residuals)
+__global__ void k_mix_update_bwd(const float* __restrict__ mix, const float* __restrict__ a,
+                                 const float* __restrict__ gq_out, const float* __restrict__ gmu_out,
+                                 int64_t N, int F, float* __restrict__ ga, float* __restrict__ gmix) {
+  const int64_t total = N * (int64_t)F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = t / F;
+    const int f = (int)(t % F);
+    const float am = a[n * 3 * F + F + f], aqm = a[n * 3 * F + 2 * F + f];
+    const float gq = gq_out[t];
+    float s = 0.f, gam = 0.f;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const float V = mix[(n * 3 + x) * 2 * F + f], W = mix[(n * 3 + x) * 2 * F + F + f];
+      const float gm = gmu_out[(n * 3 + x) * F + f];
+      s += V * W;
+      gam += gm * W;
+      gmix[(n * 3 + x) * 2 * F + f] = gq * aqm * W;                 // dL/dV (norm term added later)
+      gmix[(n * 3 + x) * 2 * F + F + f] = gq * aqm * V + gm * am;   // dL/dW
+    }
+    ga[n * 3 * F + f] = gq;
+    ga[n * 3 * F + F + f] = gam;
+    ga[n * 3 * F + 2 * F + f] = gq * s;
+  }
+}
+
+// backward of k_mix_ctx: gV += g_ctx[:,F:] V / Vn ; gq = gq_out + g_ctx[:, :F]
+__global__ void k_mix_ctx_bwd(const float* __restrict__ mix, const float* __restrict__ g_ctx,
+                              const float* __restrict__ gq_out, int64_t N, int F, float eps,
+                              float* gmix, float* gq) {
+  const int64_t total = N * (int64_t)F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = t / F;
+    const int f = (int)(t % F);
+    const float v0 = mix[(n * 3 + 0) * 2 * F + f], v1 = mix[(n * 3 + 1) * 2 * F + f], v2 = mix[(n * 3 + 2) * 2 * F + f];
+    const float vn = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + eps);
+    const float s = g_ctx[n * 2 * F + F + f] / vn;
+    gmix[(n * 3 + 0) * 2 * F + f] += s * v0;
+    gmix[(n * 3 + 1) * 2 * F + f] += s * v1;
+    gmix[(n * 3 + 2) * 2 * F + f] += s * v2;
+    gq[t] = gq_out[t] + g_ctx[n * 2 * F + f];
+  }
+}
+
+#define SPK_EW_GRID(n) dim3(spk_grid_for((n), 256, spk_num_cus() * 16)), dim3(256), 0, stream
+
+extern "C" int spk_painn_mix_ctx_f32(const float* q, const float* mix, int64_t N, int32_t F, float eps,
+                                     float* ctx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return SPK_OK;
+  SPK_CHECK_ARG(q && mix && ctx && N > 0 && F > 0, "spk_painn_mix_ctx_f32: bad input");
+  hipLaunchKernelGGL(k_mix_ctx, SPK_EW_GRID(N * F), q, mix, N, F, eps, ctx);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_painn_mix_update_f32(const float* q, const float* mu, const float* mix,
+                                        const float* a, int64_t N, int32_t F, float* q_out,
+                                        float* mu_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return SPK_OK;
+  SPK_CHECK_ARG(q && mu && mix && a && q_out && mu_out && N > 0 && F > 0, "spk_painn_mix_update_f32: bad input");
+  hipLaunchKernelGGL(k_mix_update, SPK_EW_GRID(N * F), q, mu, mix, a, N, F, q_out, mu_out);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_painn_mix_update_bwd_f32(const float* mu, const float* mix, const float* a,
+                                            const float* gq_out, const float* gmu_out, int64_t N,
+                                            int32_t F, float* ga, float* gmix, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)mu;
+  if (N == 0) return SPK_OK;
+  SPK_CHECK_ARG(mix && a && gq_out && gmu_out && ga && gmix && N > 0 && F > 0, "spk_painn_mix_update_bwd_f32: bad input");
+  hipLaunchKernelGGL(k_mix_update_bwd, SPK_EW_GRID(N * F), mix, a, gq_out, gmu_out, N, F, ga, gmix);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_painn_mix_ctx_bwd_f32(const float* mix, const float* g_ctx, const float* gq_out,
+                                         int64_t N, int32_t F, float eps, float* gmix_inout,
+                                         float* gq, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return SPK_OK;
+  SPK_CHECK_ARG(mix && g_ctx && gq_out && gmix_inout && gq && N > 0 && F > 0, "spk_painn_mix_ctx_bwd_f32: bad input");
+  hipLaunchKernelGGL(k_mix_ctx_bwd, SPK_EW_GRID(N * F), mix, g_ctx, gq_out, N, F, eps, gmix_inout, gq);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// whole-representation drivers (representation/painn.py:207-256), eval-mode force path
+// ------------------------------------------------------------------------------------------
+#define SPK_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// per layer saved for backward: preA [F] | c [3F] | mu_in [3F] | mix [6F] | preB [F] | a [3F]
+static inline int64_t painn_saved_per_atom(int F) { return 17 * (int64_t)F; }
+
+extern "C" int64_t spk_painn_saved_floats(const spk_painn_t* m, int64_t N) {
+  if (!m) return 0;
+  return (int64_t)m->n_interactions * N * painn_saved_per_atom(m->n_atom_basis);
+}
+extern "C" int64_t spk_painn_scratch_floats(const spk_painn_t* m, int64_t N) {
+  if (!m) return 0;
+  return N * 24 * (int64_t)m->n_atom_basis;
+}
+
+extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
+                                     const spk_radial_t* rb, const float* q0, const float* r_ij,
+                                     float* q_out, float* mu_out, float* saved, float* scratch,
+                                     void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const char* who = "spk_painn_forward_f32";
+  SPK_CHECK_ARG(m && m->layers && g && rb, "%s: null argument", who);
+  const int64_t N = g->n_atoms;
+  const int F = m->n_atom_basis, L = m->n_interactions;
+  if (N == 0) return SPK_OK;
+  SPK_CHECK_ARG(q0 && q_out && mu_out && (L == 0 || (saved && scratch)), "%s: null buffer", who);
+  const size_t nf = (size_t)N * F;
+  if (L == 0) {
+    SPK_HIP_TRY(hipMemcpyAsync(q_out, q0, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    SPK_HIP_TRY(hipMemsetAsync(mu_out, 0, 3 * nf * sizeof(float), stream));
+    return SPK_OK;
+  }
+  float* c1 = scratch;            // [N,F]
+  float* q1 = c1 + nf;            // [N,F]
+  float* mu1 = q1 + nf;           // [N,3F]
+  float* ctx = mu1 + 3 * nf;      // [N,2F]
+  float* a1 = ctx + 2 * nf;       // [N,F]
+  const int64_t per = painn_saved_per_atom(F) * N;
+  // mu entering the first interaction is zero (painn.py:246)
+  SPK_HIP_TRY(hipMemsetAsync(saved + 4 * nf, 0, 3 * nf * sizeof(float), stream));
+  for (int l = 0; l < L; ++l) {
+    const spk_painn_layer_t& P = m->layers[l];
+    float* S = saved + l * per;
+    float* preA = S; float* c = S + nf; float* mu_in = S + 4 * nf; float* mix = S + 7 * nf;
+    float* preB = S + 13 * nf; float* av = S + 14 * nf;
+    const float* qin = (l == 0) ? q0 : q_out;
+    SPK_TRY(spk_dense_internal(qin, nullptr, P.ctx_w1, P.ctx_b1, nullptr, c1, preA, N, F, F, SPK_ACT_SILU, false, SPK_ACT_NONE, stream));
+    SPK_TRY(spk_dense_internal(c1, nullptr, P.ctx_w2, P.ctx_b2, nullptr, c, nullptr, N, F, 3 * F, SPK_ACT_NONE, false, SPK_ACT_NONE, stream));
+    SPK_TRY(spk_painn_message_fwd_internal(g, rb, c, qin, mu_in, r_ij, P.filt_w, P.filt_b, F, q1, mu1, stream));
+    SPK_TRY(spk_dense_internal(mu1, nullptr, P.mix_w, nullptr, nullptr, mix, nullptr, 3 * N, F, 2 * F, SPK_ACT_NONE, false, SPK_ACT_NONE, stream));
+    SPK_TRY(spk_painn_mix_ctx_f32(q1, mix, N, F, m->epsilon, ctx, stream));
+    SPK_TRY(spk_dense_internal(ctx, nullptr, P.ictx_w1, P.ictx_b1, nullptr, a1, preB, N, 2 * F, F, SPK_ACT_SILU, false, SPK_ACT_NONE, stream));
+    SPK_TRY(spk_dense_internal(a1, nullptr, P.ictx_w2, P.ictx_b2, nullptr, av, nullptr, N, F, 3 * F, SPK_ACT_NONE, false, SPK_ACT_NONE, stream));
+    float* mu_next = (l == L - 1) ? mu_out : (saved + (l + 1) * per + 4 * nf);
+    SPK_TRY(spk_painn_mix_update_f32(q1, mu1, mix, av, N, F, q_out, mu_next, stream));
+  }
+  return SPK_OK;
+}
+
+extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g,
+                                      const spk_radial_t* rb, const float* gq_out,
+                                      const float* gmu_out, const float* r_ij, const float* saved,
+                                      float* scratch, float* gr, float* gq0, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const char* who = "spk_painn_backward_f32";
+  SPK_CHECK_ARG(m && m->layers && g && rb, "%s: null argument", who);
+  const int64_t N = g->n_atoms, E = g->n_edges;
+  const int F = m->n_atom_basis, L = m->n_interactions;
+  if (E > 0) {
+    SPK_CHECK_ARG(gr != nullptr, "%s: null gr", who);
+    SPK_HIP_TRY(hipMemsetAsync(gr, 0, (size_t)E * 3 * sizeof(float), stream));
+  }
+  if (N == 0) return SPK_OK;
+  SPK_CHECK_ARG((gq_out || gmu_out) && (L == 0 || (saved && scratch)), "%s: null buffer", who);
+  const size_t nf = (size_t)N * F;
+  // scratch layout
+  float* ga = scratch;             // [N,3F]
+  float* gmix = ga + 3 * nf;       // [N,6F]
+  float* ga1 = gmix + 6 * nf;      // [N,F]
+  float* gctx = ga1 + nf;          // [N,2F]
+  float* gq1 = gctx + 2 * nf;      // [N,F]
+  float* gmu1 = gq1 + nf;          // [N,3F]
+  float* gc = gmu1 + 3 * nf;       // [N,3F]
+  float* gc1 = gc + 3 * nf;        // [N,F]
+  float* gq = gc1 + nf;            // [N,F]   running dL/dq
+  float* gmu = gq + nf;            // [N,3F]  running dL/dmu
+  if (gq_out) SPK_HIP_TRY(hipMemcpyAsync(gq, gq_out, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  else SPK_HIP_TRY(hipMemsetAsync(gq, 0, nf * sizeof(float), stream));
+  if (gmu_out) SPK_HIP_TRY(hipMemcpyAsync(gmu, gmu_out, 3 * nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  else SPK_HIP_TRY(hipMemsetAsync(gmu, 0, 3 * nf * sizeof(float), stream));
+  const int64_t per = painn_saved_per_atom(F) * N;
+  for (int l = L - 1; l >= 0; --l) {
+    const spk_painn_layer_t& P = m->layers[l];
+    const float* S = saved + l * per;
+    const float* preA = S; const float* c = S + nf; const float* mu_in = S + 4 * nf; const float* mix = S + 7 * nf;
+    const float* preB = S + 13 * nf; const float* av = S + 14 * nf;
+    // ---- mixing backward
+    SPK_TRY(spk_painn_mix_update_bwd_f32(nullptr, mix, av, gq, gmu, N, F, ga, gmix, stream));
+    SPK_TRY(spk_dense_internal(ga, nullptr, P.ictx_w2, nullptr, nullptr, ga1, nullptr, N, 3 * F, F, SPK_ACT_NONE, true, SPK_ACT_NONE, stream));
+    SPK_TRY(spk_dense_internal(ga1, preB, P.ictx_w1, nullptr, nullptr, gctx, nullptr, N, F, 2 * F, SPK_ACT_NONE, true, SPK_ACT_SILU, stream));
+    SPK_TRY(spk_painn_mix_ctx_bwd_f32(mix, gctx, gq, N, F, m->epsilon, gmix, gq1, stream));
+    // mu1 -> mix is a bias-free Dense over [3N, F]; residual path adds gmu
+    SPK_TRY(spk_dense_internal(gmix, nullptr, P.mix_w, nullptr, gmu, gmu1, nullptr, 3 * N, 2 * F, F, SPK_ACT_NONE, true, SPK_ACT_NONE, stream));
+    // ---- message backward: gc, gmu (incl. residual), gr +=
+    SPK_TRY(spk_painn_message_bwd_internal(g, rb, c, mu_in, gq1, gmu1, r_ij, P.filt_w, P.filt_b, F, gc, gmu, gr, stream));
+    // ---- context net backward; residual path adds gq1
+    SPK_TRY(spk_dense_internal(gc, nullptr, P.ctx_w2, nullptr, nullptr, gc1, nullptr, N, 3 * F, F, SPK_ACT_NONE, true, SPK_ACT_NONE, stream));
+    float* out = (l == 0 && gq0) ? gq0 : gq;
+    SPK_TRY(spk_dense_internal(gc1, preA, P.ctx_w1, nullptr, gq1, out, nullptr, N, F, F, SPK_ACT_NONE, true, SPK_ACT_SILU, stream));
+  }
+  return SPK_OK;
+}

@@ -1,0 +1,431 @@
+// Library plumbing + the HBM-bound index kernels: neighbour-list plan, segmented scatter_add,
+// gather, radial basis / cutoff expansion, embedding lookup.
+#include "spk_common.h"
+#include <string.h>
+
+// ---------------------------------------------------------------- error / info
+static thread_local char g_err[512] = "";
+static int g_variant = SPK_VARIANT_AUTO;
+static int g_num_cus = 0;
+
+void spk_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int spk_num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cus = prop.multiProcessorCount;
+    else
+      g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+extern "C" int spk_version(void) { return 100; }
+extern "C" const char* spk_last_error(void) { return g_err; }
+extern "C" void spk_set_variant(int v) { g_variant = v; }
+extern "C" int spk_get_variant(void) { return g_variant; }
+
+extern "C" int spk_device_info(int32_t* host_info) {
+  SPK_CHECK_ARG(host_info != nullptr, "spk_device_info: null output");
+  int dev = 0;
+  SPK_HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  SPK_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  host_info[0] = prop.multiProcessorCount;
+  host_info[1] = prop.warpSize;
+  host_info[2] = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+  int arch = 0;
+  const char* p = strstr(prop.gcnArchName, "gfx");
+  if (p) arch = (int)strtol(p + 3, nullptr, 16) == 0x950 ? 950 : (int)strtol(p + 3, nullptr, 10);
+  host_info[3] = arch;
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------- HIP-event profiling
+#include <vector>
+#include <string>
+#include <map>
+struct ProfRec { std::string tag; hipEvent_t a, b; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+static std::string g_report;
+
+bool spk_prof_enabled() { return g_prof; }
+void spk_prof_begin(const char* tag, hipStream_t stream) {
+  ProfRec r; r.tag = tag;
+  if (!g_pool.empty()) { r.a = g_pool.back().first; r.b = g_pool.back().second; g_pool.pop_back(); }
+  else { if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return; }
+  hipEventRecord(r.a, stream);
+  g_recs.push_back(r);
+}
+void spk_prof_end(hipStream_t stream) {
+  if (!g_recs.empty()) hipEventRecord(g_recs.back().b, stream);
+}
+extern "C" void spk_profile_enable(int on) { g_prof = on != 0; }
+// Synchronises the device, folds all recorded (begin,end) pairs into per-tag totals and returns a
+// text table "tag count total_ms\n..." (valid until the next call); clears the records.
+extern "C" const char* spk_profile_report(void) {
+  hipDeviceSynchronize();
+  std::map<std::string, std::pair<long, double>> acc;
+  for (auto& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { acc[r.tag].first += 1; acc[r.tag].second += ms; }
+    g_pool.push_back({r.a, r.b});
+  }
+  g_recs.clear();
+  g_report.clear();
+  char line[256];
+  for (auto& kv : acc) {
+    snprintf(line, sizeof(line), "%s %ld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    g_report += line;
+  }
+  return g_report.c_str();
+}
+
+// ---------------------------------------------------------------- neighbour-list plan
+__global__ void k_plan_flags(const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j,
+                             int64_t E, int64_t N, int32_t* flags) {
+  int bad_sort = 0, bad_range = 0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i = idx_i[e], j = idx_j[e];
+    if (i < 0 || i >= N || j < 0 || j >= N) bad_range = 1;
+    if (e > 0 && idx_i[e - 1] > i) bad_sort = 1;
+  }
+  if (bad_sort) atomicOr(&flags[0], 1);
+  if (bad_range) atomicOr(&flags[1], 1);
+}
+
+// rowptr[r] = first edge e with idx_i[e] >= r  (requires ascending idx_i)
+__global__ void k_rowptr(const int64_t* __restrict__ idx_i, int64_t E, int64_t N,
+                         int32_t* __restrict__ rowptr) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e <= E;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t prev = (e > 0) ? idx_i[e - 1] : -1;
+    int64_t cur = (e < E) ? idx_i[e] : N;
+    if (prev < -1) prev = -1;
+    if (cur > N) cur = N;
+    for (int64_t r = prev + 1; r <= cur; ++r) rowptr[r] = (int32_t)e;
+  }
+}
+
+// every edge (i<-j, r) must have a partner (j<-i, -r) in row j
+__global__ void k_symmetry(const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j,
+                           const float* __restrict__ rij, const int32_t* __restrict__ rowptr,
+                           int64_t E, int32_t* flags) {
+  int asym = 0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i = idx_i[e], j = idx_j[e];
+    float rx = rij[3 * e], ry = rij[3 * e + 1], rz = rij[3 * e + 2];
+    bool found = false;
+    for (int32_t q = rowptr[j]; q < rowptr[j + 1]; ++q) {
+      if (idx_j[q] == i && rij[3 * (int64_t)q] == -rx && rij[3 * (int64_t)q + 1] == -ry &&
+          rij[3 * (int64_t)q + 2] == -rz) { found = true; break; }
+    }
+    if (!found) asym = 1;
+  }
+  if (asym) atomicOr(&flags[2], 1);
+}
+
+extern "C" int spk_edge_plan(const int64_t* idx_i, const int64_t* idx_j, const float* r_ij,
+                             int64_t E, int64_t N, int32_t* rowptr, int32_t* scratch,
+                             int32_t* host_flags, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(E >= 0 && N >= 0 && N < (1LL << 31) && E < (1LL << 31),
+                "spk_edge_plan: sizes out of range (N=%lld E=%lld)", (long long)N, (long long)E);
+  SPK_CHECK_ARG(rowptr && scratch && host_flags, "spk_edge_plan: null pointer");
+  SPK_CHECK_ARG(E == 0 || (idx_i && idx_j), "spk_edge_plan: null index arrays");
+  SPK_HIP_TRY(hipMemsetAsync(scratch, 0, 4 * sizeof(int32_t), stream));
+  int32_t f[4] = {0, 0, 0, 0};
+  if (E > 0) {
+    int grid = spk_grid_for(E, 256, 4096);
+    hipLaunchKernelGGL(k_plan_flags, dim3(grid), dim3(256), 0, stream, idx_i, idx_j, E, N, scratch);
+    SPK_LAUNCH_CHECK();
+    SPK_HIP_TRY(hipMemcpyAsync(f, scratch, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    SPK_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  int sorted = !f[0], in_range = !f[1], symmetric = 0;
+  if (sorted && in_range) {
+    int grid = spk_grid_for(E + 1, 256, 4096);
+    hipLaunchKernelGGL(k_rowptr, dim3(grid), dim3(256), 0, stream, idx_i, E, N, rowptr);
+    SPK_LAUNCH_CHECK();
+    if (r_ij && E > 0) {
+      hipLaunchKernelGGL(k_symmetry, dim3(spk_grid_for(E, 256, 4096)), dim3(256), 0, stream, idx_i,
+                         idx_j, r_ij, rowptr, E, scratch);
+      SPK_LAUNCH_CHECK();
+      SPK_HIP_TRY(hipMemcpyAsync(f, scratch, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+      SPK_HIP_TRY(hipStreamSynchronize(stream));
+      symmetric = !f[2];
+    } else if (E == 0) {
+      symmetric = 1;
+    }
+  }
+  host_flags[0] = sorted;
+  host_flags[1] = in_range;
+  host_flags[2] = symmetric;
+  if (!in_range) {
+    spk_set_error("spk_edge_plan: neighbour index out of range [0, %lld)", (long long)N);
+    return SPK_ERR_INDEX;
+  }
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------- scatter_add (nn/scatter.py)
+// Segmented sum over CSR rows: one thread per (outer, row, VEC-chunk of inner); consecutive
+// threads read consecutive addresses of every edge row (coalesced), y written exactly once.
+template <int VEC>
+__global__ void k_segsum(const float* __restrict__ x, const int32_t* __restrict__ rowptr,
+                         int64_t outer, int64_t E, int64_t inner, int64_t N,
+                         float* __restrict__ y) {
+  const int64_t cpr = inner / VEC;  // chunks per row
+  const int64_t total = outer * N * cpr;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t c = t % cpr;
+    int64_t k = (t / cpr) % N;
+    int64_t o = t / (cpr * N);
+    int32_t e0 = rowptr[k], e1 = rowptr[k + 1];
+    const float* xp = x + (o * E) * inner + c * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    int32_t e = e0;
+    for (; e + 4 <= e1; e += 4) {
+      float tmp[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* p = xp + (int64_t)(e + u) * inner;
+        if (VEC == 4) { f32x4 q = *(const f32x4*)p; tmp[u][0] = q.x; tmp[u][1 % VEC] = q.y; tmp[u][2 % VEC] = q.z; tmp[u][3 % VEC] = q.w; }
+        else { tmp[u][0] = p[0]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += tmp[u][v];
+    }
+    for (; e < e1; ++e) {
+      const float* p = xp + (int64_t)e * inner;
+      if (VEC == 4) { f32x4 q = *(const f32x4*)p; acc[0] += q.x; acc[1 % VEC] += q.y; acc[2 % VEC] += q.z; acc[3 % VEC] += q.w; }
+      else { acc[0] += p[0]; }
+    }
+    float* yp = y + (o * N + k) * inner + c * VEC;
+    if (VEC == 4) { f32x4 q; q.x = acc[0]; q.y = acc[1 % VEC]; q.z = acc[2 % VEC]; q.w = acc[3 % VEC]; *(f32x4*)yp = q; }
+    else { yp[0] = acc[0]; }
+  }
+}
+
+__global__ void k_scatter_atomic(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                 int64_t outer, int64_t E, int64_t inner, int64_t N,
+                                 float* __restrict__ y) {
+  const int64_t total = outer * E * inner;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t c = t % inner;
+    int64_t e = (t / inner) % E;
+    int64_t o = t / (inner * E);
+    int64_t k = idx[e];
+    if (k >= 0 && k < N) unsafeAtomicAdd(&y[(o * N + k) * inner + c], x[t]);
+  }
+}
+
+extern "C" int spk_scatter_add_f32(const float* x, const int64_t* idx, const int32_t* rowptr,
+                                   int64_t outer, int64_t E, int64_t inner, int64_t N, float* y,
+                                   void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(outer >= 0 && E >= 0 && inner >= 0 && N >= 0, "spk_scatter_add_f32: negative size");
+  int64_t out_elems = outer * N * inner;
+  if (out_elems == 0) return SPK_OK;
+  SPK_CHECK_ARG(y != nullptr, "spk_scatter_add_f32: null output");
+  if (E == 0) { SPK_HIP_TRY(hipMemsetAsync(y, 0, out_elems * sizeof(float), stream)); return SPK_OK; }
+  SPK_CHECK_ARG(x != nullptr && (idx != nullptr || rowptr != nullptr), "spk_scatter_add_f32: null input");
+  const int maxb = spk_num_cus() * 16;
+  if (rowptr) {
+    bool vec4 = (inner % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+    if (vec4) {
+      int grid = spk_grid_for(outer * N * (inner / 4), 256, maxb);
+      SpkProfScope prof("scatter_add_segsum", stream);
+      hipLaunchKernelGGL(k_segsum<4>, dim3(grid), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
+    } else {
+      int grid = spk_grid_for(outer * N * inner, 256, maxb);
+      hipLaunchKernelGGL(k_segsum<1>, dim3(grid), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
+    }
+    SPK_LAUNCH_CHECK();
+  } else {
+    SPK_HIP_TRY(hipMemsetAsync(y, 0, out_elems * sizeof(float), stream));
+    int grid = spk_grid_for(outer * E * inner, 256, maxb);
+    hipLaunchKernelGGL(k_scatter_atomic, dim3(grid), dim3(256), 0, stream, x, idx, outer, E, inner, N, y);
+    SPK_LAUNCH_CHECK();
+  }
+  return SPK_OK;
+}
+
+template <int VEC>
+__global__ void k_gather(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                         int64_t outer, int64_t R, int64_t E, int64_t inner,
+                         float* __restrict__ y) {
+  const int64_t cpr = inner / VEC;
+  const int64_t total = outer * E * cpr;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t c = t % cpr;
+    int64_t e = (t / cpr) % E;
+    int64_t o = t / (cpr * E);
+    int64_t k = idx[e];
+    const float* xp = x + (o * R + k) * inner + c * VEC;
+    float* yp = y + (o * E + e) * inner + c * VEC;
+    if (VEC == 4) *(f32x4*)yp = *(const f32x4*)xp;
+    else yp[0] = xp[0];
+  }
+}
+
+extern "C" int spk_gather_f32(const float* x, const int64_t* idx, int64_t outer, int64_t R,
+                              int64_t E, int64_t inner, float* y, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(outer >= 0 && E >= 0 && inner >= 0 && R >= 0, "spk_gather_f32: negative size");
+  if (outer * E * inner == 0) return SPK_OK;
+  SPK_CHECK_ARG(x && idx && y, "spk_gather_f32: null pointer");
+  const int maxb = spk_num_cus() * 16;
+  bool vec4 = (inner % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+  if (vec4)
+    hipLaunchKernelGGL(k_gather<4>, dim3(spk_grid_for(outer * E * (inner / 4), 256, maxb)), dim3(256), 0, stream, x, idx, outer, R, E, inner, y);
+  else
+    hipLaunchKernelGGL(k_gather<1>, dim3(spk_grid_for(outer * E * inner, 256, maxb)), dim3(256), 0, stream, x, idx, outer, R, E, inner, y);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------- radial basis x cutoff
+__global__ void k_radial_cutoff(const float* __restrict__ d, int64_t n, RadialDev rb,
+                                float* __restrict__ phi, float* __restrict__ fcut) {
+  const int K = rb.n_rbf;
+  const int64_t total = n * (int64_t)(K + 1);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t e = t / (K + 1);
+    int k = (int)(t % (K + 1));
+    float dd = d[e];
+    if (k < K) {
+      if (phi) { float p, dp; spk_rbf_eval(rb, k, dd, p, dp); phi[e * K + k] = p; }
+    } else if (fcut) {
+      float f, df; spk_cutoff_eval(rb.cutoff, dd, f, df); fcut[e] = f;
+    }
+  }
+}
+
+__global__ void k_radial_cutoff_bwd(const float* __restrict__ d, int64_t n, RadialDev rb,
+                                    const float* __restrict__ gphi, const float* __restrict__ gfcut,
+                                    float* __restrict__ gd) {
+  const int K = rb.n_rbf;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    float dd = d[e];
+    float acc = 0.f;
+    if (gphi)
+      for (int k = 0; k < K; ++k) { float p, dp; spk_rbf_eval(rb, k, dd, p, dp); acc += gphi[e * K + k] * dp; }
+    if (gfcut) { float f, df; spk_cutoff_eval(rb.cutoff, dd, f, df); acc += gfcut[e] * df; }
+    gd[e] = acc;
+  }
+}
+
+static int check_radial(const spk_radial_t* rb, const char* who) {
+  SPK_CHECK_ARG(rb != nullptr, "%s: null radial description", who);
+  SPK_CHECK_ARG(rb->kind == SPK_RBF_GAUSSIAN || rb->kind == SPK_RBF_BESSEL, "%s: unknown rbf kind %d", who, rb->kind);
+  SPK_CHECK_ARG(rb->n_rbf >= 1 && rb->n_rbf <= 1024, "%s: n_rbf=%d unsupported", who, rb->n_rbf);
+  SPK_CHECK_ARG(rb->p0 != nullptr && (rb->kind == SPK_RBF_BESSEL || rb->p1 != nullptr), "%s: null rbf parameters", who);
+  SPK_CHECK_ARG(rb->cutoff > 0.f, "%s: cutoff must be positive", who);
+  return SPK_OK;
+}
+
+extern "C" int spk_radial_cutoff_f32(const float* d, int64_t n, const spk_radial_t* rb, float* phi,
+                                     float* fcut, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_radial(rb, "spk_radial_cutoff_f32");
+  if (rc) return rc;
+  if (n == 0) return SPK_OK;
+  SPK_CHECK_ARG(d != nullptr && n > 0, "spk_radial_cutoff_f32: bad input");
+  int grid = spk_grid_for(n * (rb->n_rbf + 1), 256, spk_num_cus() * 16);
+  hipLaunchKernelGGL(k_radial_cutoff, dim3(grid), dim3(256), 0, stream, d, n, spk_radial_dev(rb), phi, fcut);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_radial_cutoff_bwd_f32(const float* d, int64_t n, const spk_radial_t* rb,
+                                         const float* gphi, const float* gfcut, float* gd,
+                                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_radial(rb, "spk_radial_cutoff_bwd_f32");
+  if (rc) return rc;
+  if (n == 0) return SPK_OK;
+  SPK_CHECK_ARG(d != nullptr && gd != nullptr && n > 0, "spk_radial_cutoff_bwd_f32: bad input");
+  int grid = spk_grid_for(n, 256, spk_num_cus() * 16);
+  hipLaunchKernelGGL(k_radial_cutoff_bwd, dim3(grid), dim3(256), 0, stream, d, n, spk_radial_dev(rb), gphi, gfcut, gd);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+__global__ void k_edge_norm(const float* __restrict__ rij, int64_t E, float* __restrict__ d,
+                            float* __restrict__ u) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    float x = rij[3 * e], y = rij[3 * e + 1], z = rij[3 * e + 2];
+    float dd = sqrtf(x * x + y * y + z * z);
+    if (d) d[e] = dd;
+    if (u) { u[3 * e] = x / dd; u[3 * e + 1] = y / dd; u[3 * e + 2] = z / dd; }
+  }
+}
+
+extern "C" int spk_edge_norm_f32(const float* r_ij, int64_t E, float* d, float* u, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (E == 0) return SPK_OK;
+  SPK_CHECK_ARG(r_ij != nullptr && E > 0, "spk_edge_norm_f32: bad input");
+  hipLaunchKernelGGL(k_edge_norm, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, r_ij, E, d, u);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------- embedding / add
+__global__ void k_embedding(const float* __restrict__ table, const int64_t* __restrict__ z,
+                            int64_t n, int F, float* __restrict__ out) {
+  const int64_t total = n * (int64_t)F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t a = t / F;
+    int f = (int)(t % F);
+    out[t] = table[z[a] * F + f];
+  }
+}
+
+extern "C" int spk_embedding_f32(const float* table, const int64_t* z, int64_t n, int32_t F,
+                                 float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return SPK_OK;
+  SPK_CHECK_ARG(table && z && out && F > 0 && n > 0, "spk_embedding_f32: bad input");
+  hipLaunchKernelGGL(k_embedding, dim3(spk_grid_for(n * F, 256, spk_num_cus() * 16)), dim3(256), 0, stream, table, z, n, F, out);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                      float* __restrict__ y) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x)
+    y[t] = a[t] + b[t];
+}
+
+extern "C" int spk_add_f32(const float* a, const float* b, int64_t n, float* y, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return SPK_OK;
+  SPK_CHECK_ARG(a && b && y && n > 0, "spk_add_f32: bad input");
+  hipLaunchKernelGGL(k_add, dim3(spk_grid_for(n, 256, spk_num_cus() * 16)), dim3(256), 0, stream, a, b, n, y);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

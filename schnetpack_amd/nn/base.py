@@ -1,0 +1,50 @@
+"""Mirror of ``schnetpack.nn.base.Dense`` (nn/base.py:14-55) on the fp32-MFMA dense kernel."""
+from typing import Callable, Union
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import xavier_uniform_, zeros_
+
+from .. import _lib, ops
+from .activations import shifted_softplus
+
+__all__ = ["Dense", "activation_id"]
+
+
+def activation_id(activation):
+    """Map an activation callable to the kernel epilogue id (None if it is not fusable)."""
+    if activation is None or isinstance(activation, nn.Identity):
+        return _lib.SPK_ACT_NONE
+    if activation is shifted_softplus or getattr(activation, "__name__", "") == "shifted_softplus":
+        return _lib.SPK_ACT_SSP
+    if activation is F.silu or isinstance(activation, nn.SiLU) or getattr(activation, "__name__", "") == "silu":
+        return _lib.SPK_ACT_SILU
+    return None
+
+
+class Dense(nn.Linear):
+    r"""y = activation(x W^T + b); same constructor, parameters (``weight``, ``bias``) and
+    initialisation (xavier_uniform / zeros) as the reference."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True,
+                 activation: Union[Callable, nn.Module] = None,
+                 weight_init: Callable = xavier_uniform_, bias_init: Callable = zeros_):
+        self.weight_init = weight_init
+        self.bias_init = bias_init
+        super().__init__(in_features, out_features, bias)
+        self.activation = activation
+        if self.activation is None:
+            self.activation = nn.Identity()
+
+    def reset_parameters(self):
+        self.weight_init(self.weight)
+        if self.bias is not None:
+            self.bias_init(self.bias)
+
+    def forward(self, input: torch.Tensor):
+        act = activation_id(self.activation)
+        if act is None:
+            # unknown activation callable: linear part on the HIP kernel, activation by the caller's function
+            return self.activation(ops.dense(input, self.weight, self.bias, _lib.SPK_ACT_NONE))
+        return ops.dense(input, self.weight, self.bias, act)

@@ -1,0 +1,70 @@
+"""Mirror of ``schnetpack.nn.radial`` (nn/radial.py:11-110): GaussianRBF, BesselRBF."""
+from math import pi
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+
+__all__ = ["gaussian_rbf", "GaussianRBF", "BesselRBF"]
+
+
+def gaussian_rbf(inputs: torch.Tensor, offsets: torch.Tensor, widths: torch.Tensor):
+    """exp(-0.5 / w^2 (d - mu)^2) -- torch formula on the tensor's own device; differentiable to
+    any order (used on the training path and for ``trainable=True``)."""
+    coeff = -0.5 / torch.pow(widths, 2)
+    diff = inputs[..., None] - offsets
+    return torch.exp(coeff * torch.pow(diff, 2))
+
+
+def _needs_composite(module, inputs):
+    """Training (double backward) or trainable basis parameters need the differentiable
+    composite; the eval path uses the HIP kernel."""
+    return module.training and torch.is_grad_enabled() and inputs.requires_grad
+
+
+class GaussianRBF(nn.Module):
+    r"""Gaussian radial basis functions; buffers/params ``widths``, ``offsets``, attr ``n_rbf``."""
+
+    def __init__(self, n_rbf: int, cutoff: float, start: float = 0.0, trainable: bool = False):
+        super().__init__()
+        self.n_rbf = n_rbf
+        offset = torch.linspace(start, cutoff, n_rbf)
+        widths = torch.FloatTensor(torch.abs(offset[1] - offset[0]) * torch.ones_like(offset))
+        self.trainable = trainable
+        if trainable:
+            self.widths = nn.Parameter(widths)
+            self.offsets = nn.Parameter(offset)
+        else:
+            self.register_buffer("widths", widths)
+            self.register_buffer("offsets", offset)
+
+    def kernel_args(self, cutoff: float):
+        return (_lib.SPK_RBF_GAUSSIAN, self.n_rbf, self.offsets.detach(), self.widths.detach(), float(cutoff))
+
+    def forward(self, inputs: torch.Tensor):
+        ops._check_float(inputs, "GaussianRBF")
+        if self.trainable or _needs_composite(self, inputs):
+            return gaussian_rbf(inputs, self.offsets, self.widths)
+        return ops.RadialCutoffFn.apply(inputs, _lib.SPK_RBF_GAUSSIAN, self.offsets, self.widths, 1.0, True, False)
+
+
+class BesselRBF(nn.Module):
+    """sin(k pi d / rc) / d  (0th order Bessel); buffer ``freqs``, attr ``n_rbf``."""
+
+    def __init__(self, n_rbf: int, cutoff: float):
+        super().__init__()
+        self.n_rbf = n_rbf
+        freqs = torch.arange(1, n_rbf + 1) * pi / cutoff
+        self.register_buffer("freqs", freqs)
+
+    def kernel_args(self, cutoff: float):
+        return (_lib.SPK_RBF_BESSEL, self.n_rbf, self.freqs.detach().float(), None, float(cutoff))
+
+    def forward(self, inputs):
+        ops._check_float(inputs, "BesselRBF")
+        if _needs_composite(self, inputs):
+            ax = inputs[..., None] * self.freqs
+            norm = torch.where(inputs == 0, torch.tensor(1.0, device=inputs.device), inputs)
+            return torch.sin(ax) / norm[..., None]
+        return ops.RadialCutoffFn.apply(inputs, _lib.SPK_RBF_BESSEL, self.freqs.float(), None, 1.0, True, False)

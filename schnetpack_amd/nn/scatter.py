@@ -1,0 +1,16 @@
+"""Mirror of ``schnetpack.nn.scatter`` (nn/scatter.py:7-34) on the HIP path."""
+import torch
+
+from .. import ops
+
+__all__ = ["scatter_add"]
+
+
+def scatter_add(x: torch.Tensor, idx_i: torch.Tensor, dim_size: int, dim: int = 0) -> torch.Tensor:
+    """Sum over values with the same indices: ``zeros(shape).index_add(dim, idx_i, x)``.
+
+    Same signature, argument meaning and output shape/dtype/device as the reference.  Sorted
+    indices (every reference neighbour list, ``idx_m``) take the deterministic segmented-sum
+    kernel; unsorted ones use float atomics.  Differentiable to any order.
+    """
+    return ops.scatter_add(x, idx_i, dim_size, dim)

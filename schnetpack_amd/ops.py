@@ -1,0 +1,366 @@
+"""Python face of the HIP kernels: neighbour-list plans, autograd functions.
+
+Two regimes:
+
+* eval / MD / ASE (``module.training == False``): whole-representation fused functions
+  (``SchNetFn`` / ``PaiNNFn``) -- one C call forward, one C call for the first-order backward
+  w.r.t. geometry.  Not differentiable twice.
+* training (force loss => double backward): primitives that are closed under differentiation --
+  ``scatter_add`` <-> ``gather`` are each other's transposes (both HIP), Dense forward runs on
+  the MFMA kernel with a backward written in differentiable torch algebra.
+
+There is no CPU path: CPU tensors raise ``SpkHipError``.
+"""
+import collections
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import SpkHipError, check, fptr, iptr, lib, stream
+
+
+# ----------------------------------------------------------------------------- plans
+class EdgePlan:
+    """CSR row pointers + flags of one neighbour list (``spk_edge_plan``).  Built once per
+    list (one 16-byte D2H sync) and cached; holds references to the index tensors."""
+
+    def __init__(self, idx_i, idx_j, n_atoms, r_ij=None):
+        _lib.require_device(idx_i, idx_j)
+        self.idx_i = idx_i.long().contiguous()
+        self.idx_j = idx_j.long().contiguous()
+        self.n_atoms = int(n_atoms)
+        self.n_edges = int(self.idx_i.shape[0])
+        dev = self.idx_i.device
+        self.rowptr = torch.empty(self.n_atoms + 1, dtype=torch.int32, device=dev)
+        scratch = torch.zeros(4, dtype=torch.int32, device=dev)
+        flags = (ctypes.c_int32 * 4)()
+        r = None
+        if r_ij is not None and self.n_edges > 0:
+            r = r_ij.detach().float().contiguous()
+        with torch.cuda.device(dev):
+            check(lib().spk_edge_plan(iptr(self.idx_i), iptr(self.idx_j), fptr(r), self.n_edges,
+                                      self.n_atoms, iptr(self.rowptr, torch.int32),
+                                      iptr(scratch, torch.int32), flags, stream()))
+        self.sorted = bool(flags[0])
+        self.symmetric = bool(flags[2])
+        self._graph = _lib.GraphT(self.n_atoms, self.n_edges, iptr(self.idx_i), iptr(self.idx_j),
+                                  iptr(self.rowptr, torch.int32) if self.sorted else None,
+                                  int(self.sorted), int(self.symmetric))
+
+    def graph(self):
+        return ctypes.byref(self._graph)
+
+
+_PLAN_CACHE = collections.OrderedDict()
+_PLAN_CACHE_SIZE = 16
+
+
+def edge_plan(idx_i, idx_j, n_atoms, r_ij=None):
+    """Cached plan of a neighbour list, keyed by the identity/version of the index tensors."""
+    key = (idx_i.data_ptr(), idx_j.data_ptr(), idx_i._version, idx_j._version,
+           int(idx_i.shape[0]), int(n_atoms), str(idx_i.device), r_ij is not None)
+    plan = _PLAN_CACHE.get(key)
+    if plan is not None and plan._src[0] is idx_i and plan._src[1] is idx_j:
+        _PLAN_CACHE.move_to_end(key)
+        return plan
+    plan = EdgePlan(idx_i, idx_j, n_atoms, r_ij)
+    plan._src = (idx_i, idx_j)  # keep the storage alive => data_ptr cannot be recycled
+    _PLAN_CACHE[key] = plan
+    while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+        _PLAN_CACHE.popitem(last=False)
+    return plan
+
+
+def segment_rowptr(idx, dim_size):
+    """rowptr tensor if ``idx`` is ascending, else None (cached)."""
+    plan = edge_plan(idx, idx, dim_size, None)
+    return plan.rowptr if plan.sorted else None
+
+
+# ----------------------------------------------------------------------------- scatter / gather
+def _as_3d(x, dim):
+    dim = dim % x.dim()
+    outer = 1
+    for s in x.shape[:dim]:
+        outer *= int(s)
+    inner = 1
+    for s in x.shape[dim + 1:]:
+        inner *= int(s)
+    return dim, outer, int(x.shape[dim]), inner
+
+
+def _scatter_raw(x, idx, dim_size, dim, rowptr):
+    x = x.contiguous()
+    dim, outer, E, inner = _as_3d(x, dim)
+    shape = list(x.shape)
+    shape[dim] = int(dim_size)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().spk_scatter_add_f32(fptr(x), iptr(idx), iptr(rowptr, torch.int32) if rowptr is not None else None,
+                                        outer, E, inner, int(dim_size), fptr(y), stream()))
+    return y
+
+
+def _gather_raw(x, idx, dim):
+    x = x.contiguous()
+    dim, outer, R, inner = _as_3d(x, dim)
+    shape = list(x.shape)
+    shape[dim] = int(idx.shape[0])
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().spk_gather_f32(fptr(x), iptr(idx), outer, R, int(idx.shape[0]), inner, fptr(y), stream()))
+    return y
+
+
+class ScatterAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, dim_size, dim, rowptr):
+        ctx.save_for_backward(idx)
+        ctx.dim = dim
+        ctx.rowptr = rowptr
+        return _scatter_raw(x, idx, dim_size, dim, rowptr)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        return GatherFn.apply(gy, idx, ctx.dim, ctx.rowptr), None, None, None, None
+
+
+class GatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, dim, rowptr):
+        ctx.save_for_backward(idx)
+        ctx.dim = dim
+        ctx.rows = int(x.shape[dim])
+        ctx.rowptr = rowptr
+        return _gather_raw(x, idx, dim)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        rp = ctx.rowptr
+        if rp is not None and rp.shape[0] != ctx.rows + 1:
+            rp = None
+        return ScatterAddFn.apply(gy, idx, ctx.rows, ctx.dim, rp), None, None, None
+
+
+def _check_float(x, who):
+    if not x.is_cuda:
+        raise SpkHipError("%s: tensor on %s -- schnetpack_amd runs on ROCm devices only (no CPU "
+                          "fallback)" % (who, x.device))
+    if x.dtype != torch.float32:
+        raise SpkHipError("%s: dtype %s unsupported; the HIP path computes in float32" % (who, x.dtype))
+
+
+def scatter_add(x, idx_i, dim_size, dim=0):
+    """nn/scatter.py:7-34 -- sum over values with the same index (HIP, differentiable to any
+    order through ``gather``)."""
+    _check_float(x, "scatter_add")
+    idx = idx_i.long().contiguous()
+    rowptr = segment_rowptr(idx, int(dim_size)) if idx.shape[0] > 0 else None
+    return ScatterAddFn.apply(x, idx, int(dim_size), int(dim), rowptr)
+
+
+def gather(x, idx, dim=0, rowptr=None):
+    """x.index_select(dim, idx) on the HIP path (the transpose of scatter_add)."""
+    _check_float(x, "gather")
+    return GatherFn.apply(x, idx.long().contiguous(), int(dim), rowptr)
+
+
+# ----------------------------------------------------------------------------- radial / cutoff
+def radial_struct(kind, n_rbf, p0, p1, cutoff):
+    return _lib.RadialT(int(kind), int(n_rbf), fptr(p0), fptr(p1) if p1 is not None else None, float(cutoff))
+
+
+class RadialCutoffFn(torch.autograd.Function):
+    """(phi [.., n_rbf], fcut [..]) of distances; first-order backward on the HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, d, kind, p0, p1, cutoff, want_phi, want_cut):
+        dc = d.contiguous()
+        n = dc.numel()
+        n_rbf = int(p0.shape[0])
+        rb = radial_struct(kind, n_rbf, p0, p1, cutoff)
+        phi = torch.empty(tuple(d.shape) + (n_rbf,), dtype=torch.float32, device=d.device) if want_phi else None
+        fc = torch.empty(d.shape, dtype=torch.float32, device=d.device) if want_cut else None
+        with torch.cuda.device(d.device):
+            check(lib().spk_radial_cutoff_f32(fptr(dc), n, ctypes.byref(rb), fptr(phi), fptr(fc), stream()))
+        ctx.save_for_backward(dc, p0, p1 if p1 is not None else p0)
+        ctx.meta = (kind, cutoff, p1 is not None)
+        if want_phi and want_cut:
+            return phi, fc
+        return phi if want_phi else fc
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        dc, p0, p1 = ctx.saved_tensors
+        kind, cutoff, has_p1 = ctx.meta
+        rb = radial_struct(kind, int(p0.shape[0]), p0, p1 if has_p1 else None, cutoff)
+        gphi = gfc = None
+        for g in grads:
+            if g is None:
+                continue
+            if g.dim() == dc.dim() + 1:
+                gphi = g.contiguous()
+            else:
+                gfc = g.contiguous()
+        gd = torch.empty_like(dc)
+        with torch.cuda.device(dc.device):
+            check(lib().spk_radial_cutoff_bwd_f32(fptr(dc), dc.numel(), ctypes.byref(rb), fptr(gphi), fptr(gfc), fptr(gd), stream()))
+        return gd, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- dense
+_ACT_IDS = {None: _lib.SPK_ACT_NONE, "none": _lib.SPK_ACT_NONE, "ssp": _lib.SPK_ACT_SSP, "silu": _lib.SPK_ACT_SILU}
+
+
+def _act_grad(pre, act):
+    if act == _lib.SPK_ACT_SSP:
+        return torch.sigmoid(pre)
+    if act == _lib.SPK_ACT_SILU:
+        s = torch.sigmoid(pre)
+        return s * (1.0 + pre * (1.0 - s))
+    return None
+
+
+def dense_raw(x, w, b, act, res=None, want_pre=False):
+    """y = act(x w^T + b) (+ res) on the HIP kernels; x: [..., k]."""
+    k = int(x.shape[-1])
+    x2 = x.contiguous().view(-1, k)
+    m, n_out = int(x2.shape[0]), int(w.shape[0])
+    y = torch.empty((m, n_out), dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(y) if want_pre else None
+    r2 = res.contiguous().view(-1, n_out) if res is not None else None
+    with torch.cuda.device(x.device):
+        check(lib().spk_dense_f32(fptr(x2), fptr(w.contiguous()), fptr(b.contiguous()) if b is not None else None,
+                                  fptr(r2), fptr(y), fptr(pre), m, k, n_out, int(act), stream()))
+    out_shape = tuple(x.shape[:-1]) + (n_out,)
+    return y.view(out_shape), (pre.view(out_shape) if pre is not None else None)
+
+
+class DenseFn(torch.autograd.Function):
+    """nn/base.py:52-55.  Forward: HIP (fp32 MFMA when k % 8 == 0 and n_out % 32 == 0).
+    Backward: differentiable torch algebra.  Under ``create_graph=True`` (training on forces) the
+    pre-activation is re-derived from the graph tensors so that the second order (act'' terms)
+    is exact."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        y, pre = dense_raw(x, w, b, act, want_pre=(act != _lib.SPK_ACT_NONE))
+        ctx.act = act
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, b if b is not None else w, pre if pre is not None else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, b, pre = ctx.saved_tensors
+        g = gy
+        if ctx.act != _lib.SPK_ACT_NONE:
+            if torch.is_grad_enabled():
+                pre = torch.nn.functional.linear(x, w, b if ctx.has_bias else None)
+            g = gy * _act_grad(pre, ctx.act)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = g @ w
+        if ctx.needs_input_grad[1]:
+            gw = g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.reshape(-1, g.shape[-1]).sum(0)
+        return gx, gw, gb, None
+
+
+def dense(x, w, b=None, act=None):
+    _check_float(x, "dense")
+    a = _ACT_IDS[act] if not isinstance(act, int) else act
+    return DenseFn.apply(x, w, b, a)
+
+
+# ----------------------------------------------------------------------------- fused SchNet
+class SchNetFn(torch.autograd.Function):
+    """scalar_representation = SchNet(x0, r_ij) (representation/schnet.py:147-173), fused.
+    Backward returns dL/dx0 and dL/dr_ij only (eval-mode force path)."""
+
+    @staticmethod
+    def forward(ctx, x0, r_ij, plan, rb_args, model_struct, keep):
+        N, F = int(x0.shape[0]), int(x0.shape[1])
+        dev = x0.device
+        x0c = x0.contiguous()
+        rc = r_ij.contiguous()
+        L = lib()
+        out = torch.empty((N, F), dtype=torch.float32, device=dev)
+        saved = torch.empty(max(1, int(L.spk_schnet_saved_floats(ctypes.byref(model_struct), N))), dtype=torch.float32, device=dev)
+        scratch = torch.empty(max(1, int(L.spk_schnet_scratch_floats(ctypes.byref(model_struct), N))), dtype=torch.float32, device=dev)
+        rb = radial_struct(*rb_args)
+        with torch.cuda.device(dev):
+            check(L.spk_schnet_forward_f32(ctypes.byref(model_struct), plan.graph(), ctypes.byref(rb), fptr(x0c), fptr(rc),
+                                           fptr(out), fptr(saved), fptr(scratch), stream()))
+        ctx.save_for_backward(rc, saved)
+        ctx.plan, ctx.rb_args, ctx.model_struct, ctx.keep = plan, rb_args, model_struct, keep
+        ctx.scratch = scratch
+        ctx.shape = (N, F)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gx):
+        rc, saved = ctx.saved_tensors
+        N, F = ctx.shape
+        dev = rc.device
+        L = lib()
+        gr = torch.empty_like(rc)
+        gx0 = torch.empty((N, F), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        rb = radial_struct(*ctx.rb_args)
+        with torch.cuda.device(dev):
+            check(L.spk_schnet_backward_f32(ctypes.byref(ctx.model_struct), ctx.plan.graph(), ctypes.byref(rb),
+                                            fptr(gx.contiguous()), fptr(rc), fptr(saved), fptr(ctx.scratch),
+                                            fptr(gr), fptr(gx0), stream()))
+        return gx0, (gr if ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+# ----------------------------------------------------------------------------- fused PaiNN
+class PaiNNFn(torch.autograd.Function):
+    """(scalar_representation, vector_representation) = PaiNN(q0, r_ij)
+    (representation/painn.py:207-256), fused; first-order backward w.r.t. q0 and r_ij."""
+
+    @staticmethod
+    def forward(ctx, q0, r_ij, plan, rb_args, model_struct, keep):
+        N, F = int(q0.shape[0]), int(q0.shape[1])
+        dev = q0.device
+        q0c = q0.contiguous()
+        rc = r_ij.contiguous()
+        L = lib()
+        q = torch.empty((N, F), dtype=torch.float32, device=dev)
+        mu = torch.empty((N, 3, F), dtype=torch.float32, device=dev)
+        saved = torch.empty(max(1, int(L.spk_painn_saved_floats(ctypes.byref(model_struct), N))), dtype=torch.float32, device=dev)
+        scratch = torch.empty(max(1, int(L.spk_painn_scratch_floats(ctypes.byref(model_struct), N))), dtype=torch.float32, device=dev)
+        rb = radial_struct(*rb_args)
+        with torch.cuda.device(dev):
+            check(L.spk_painn_forward_f32(ctypes.byref(model_struct), plan.graph(), ctypes.byref(rb), fptr(q0c), fptr(rc),
+                                          fptr(q), fptr(mu), fptr(saved), fptr(scratch), stream()))
+        ctx.save_for_backward(rc, saved)
+        ctx.plan, ctx.rb_args, ctx.model_struct, ctx.keep = plan, rb_args, model_struct, keep
+        ctx.scratch = scratch
+        ctx.shape = (N, F)
+        return q, mu
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gq, gmu):
+        rc, saved = ctx.saved_tensors
+        N, F = ctx.shape
+        dev = rc.device
+        L = lib()
+        gr = torch.empty_like(rc)
+        gq0 = torch.empty((N, F), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        rb = radial_struct(*ctx.rb_args)
+        if gq is None and gmu is None:
+            gq = torch.zeros((N, F), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.spk_painn_backward_f32(ctypes.byref(ctx.model_struct), ctx.plan.graph(), ctypes.byref(rb),
+                                           fptr(gq.contiguous()) if gq is not None else None,
+                                           fptr(gmu.contiguous()) if gmu is not None else None,
+                                           fptr(rc), fptr(saved), fptr(ctx.scratch), fptr(gr), fptr(gq0), stream()))
+        return gq0, (gr if ctx.needs_input_grad[1] else None), None, None, None, None

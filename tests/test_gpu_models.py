@@ -1,0 +1,163 @@
+"""GPU parity of complete force calls (PairwiseDistances -> SchNet/PaiNN -> Atomwise -> Forces)
+against the committed reference fixtures (tests/golden, generated from the live reference by
+oracle/make_golden.py) and against the CPU oracle; plus size-independent properties at the
+BASELINE.json sizes.
+
+Tolerance (north_star): energies / forces within 1e-5 relative (fp32), relative = max|a-b|/max|b|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import MODEL_CASES, golden_params, load_golden, rel_err
+from oracle import spk_oracle as O
+from schnetpack_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["mfma", "simple"])
+def variant(request):
+    from schnetpack_amd import _lib
+    _lib.set_variant(_lib.VARIANT_SIMPLE if request.param == "simple" else _lib.VARIANT_AUTO)
+    yield request.param
+    _lib.set_variant(_lib.VARIANT_AUTO)
+
+
+def _build(meta, dev, rep_p, head_p):
+    from schnetpack_amd import model as M
+    kind = str(meta["kind"])
+    kw = {}
+    if kind == "painn" and "filter_net.weight" in rep_p:
+        F = rep_p["embedding.weight"].shape[1]
+        kw["shared_filters"] = rep_p["filter_net.weight"].shape[0] == 3 * F
+    m = M.build_model(kind, n_atom_basis=128, n_interactions=int(meta["n_interactions"]),
+                      n_rbf=20, cutoff=float(meta["cutoff"]), radial=str(meta["radial"]), **kw)
+    M.load_reference_params(m, rep_p, head_p)
+    return m.to(dev)
+
+
+def _force_call(model, batch, dev):
+    from schnetpack_amd import model as M
+    inp = M.batch_to_inputs(batch, dev)
+    out = model(inp)
+    res = {"energy": out["energy"].detach().cpu(), "forces": out["forces"].detach().cpu(),
+           "scalar_representation": inp["scalar_representation"].detach().cpu()}
+    if "vector_representation" in inp:
+        res["vector_representation"] = inp["vector_representation"].detach().cpu()
+    return res
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_force_call_matches_reference_golden(dev, variant, case):
+    batch, ref, meta = load_golden(case)
+    rep_p, head_p = golden_params(meta)
+    model = _build(meta, dev, rep_p, head_p).eval()
+    out = _force_call(model, batch, dev)
+    assert rel_err(out["energy"], ref["energy"]) < TOL
+    assert rel_err(out["forces"], ref["forces"]) < TOL
+    assert rel_err(out["scalar_representation"], ref["scalar_representation"]) < TOL
+    if "vector_representation" in ref:
+        assert rel_err(out["vector_representation"], ref["vector_representation"]) < TOL
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_training_mode_double_backward_matches_oracle(dev, kind):
+    """Force-matching loss: gradients w.r.t. the weights need the second order of the hot path
+    (Forces(create_graph=True), atomistic/response.py:67)."""
+    from schnetpack_amd import model as M
+    b = S.molecule_batch("aspirin", 3, seed=12)
+    rep_p = O.init_schnet_params() if kind == "schnet" else O.init_painn_params()
+    head_p = O.init_atomwise_params(128, seed=1)
+    g = torch.Generator().manual_seed(0)
+    Et = torch.randn(3, generator=g)
+    Ft = torch.randn(b["Z"].shape[0], 3, generator=g)
+
+    # oracle on CPU with autograd
+    rp = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and k.endswith(("weight", "bias")) else v) for k, v in rep_p.items()}
+    hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
+    R = b["R"].clone().requires_grad_(True)
+    r_ij = O.pairwise_vectors(R, b["idx_i"], b["idx_j"], b["offsets"])
+    if kind == "schnet":
+        x = O.schnet_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, 3)
+    else:
+        x, _ = O.painn_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, 3)
+    E = O.atomwise_energy(x, b["idx_m"], 3, hp)
+    (dEdR,) = torch.autograd.grad([E.sum()], [R], create_graph=True)
+    loss_o = 0.01 * ((E - Et) ** 2).mean() + 0.99 * ((-dEdR - Ft) ** 2).mean()
+    names = [k for k, v in rp.items() if torch.is_tensor(v) and v.requires_grad]
+    go = dict(zip(names, torch.autograd.grad(loss_o, [rp[k] for k in names], allow_unused=True)))
+
+    model = M.build_model(kind)
+    M.load_reference_params(model, rep_p, head_p)
+    model = model.to(dev).train()
+    out = model(M.batch_to_inputs(b, dev))
+    loss = 0.01 * ((out["energy"] - Et.to(dev)) ** 2).mean() + 0.99 * ((out["forces"] - Ft.to(dev)) ** 2).mean()
+    assert abs(float(loss) - float(loss_o)) / abs(float(loss_o)) < 1e-4
+    loss.backward()
+    got = dict(model.representation.named_parameters())
+    worst = 0.0
+    for k in names:
+        if go[k] is None:
+            continue
+        gh = got[k].grad
+        assert gh is not None, k
+        worst = max(worst, rel_err(gh.cpu(), go[k]))
+    assert worst < 1e-3, worst  # second-order fp32 accumulations; loose but catches wrong algebra
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_bench_scale_properties(dev, kind):
+    """cfg 2/3 sizes (256 aspirin frames, N=5376, E~77.9k): (i) equals the CPU oracle on a
+    16-frame subset; (ii) total force on every molecule vanishes (translation invariance);
+    (iii) frames are independent: the energies of the first 16 frames do not change when the other
+    240 are removed; (iv) both kernel variants agree."""
+    from schnetpack_amd import _lib, model as M
+    rep_p = O.init_schnet_params() if kind == "schnet" else O.init_painn_params()
+    head_p = O.init_atomwise_params(128, seed=1)
+    model = M.build_model(kind)
+    M.load_reference_params(model, rep_p, head_p)
+    model = model.to(dev).eval()
+    big = S.molecule_batch("aspirin", 256, seed=0)
+    small = S.molecule_batch("aspirin", 16, seed=0)
+    assert torch.equal(big["R"][: 16 * 21], small["R"])
+    ob = _force_call(model, big, dev)
+    osm = _force_call(model, small, dev)
+    oo = O.energy_and_forces(kind, rep_p, head_p, small, 3)
+    assert rel_err(osm["energy"], oo["energy"]) < TOL
+    assert rel_err(osm["forces"], oo["forces"]) < TOL
+    assert rel_err(ob["energy"][:16], osm["energy"]) < 2e-6
+    assert rel_err(ob["forces"][: 16 * 21], osm["forces"]) < 2e-6
+    net = ob["forces"].view(256, 21, 3).sum(1)
+    assert float(net.abs().max()) < 1e-4 * float(ob["forces"].abs().max()) * 21
+    _lib.set_variant(_lib.VARIANT_SIMPLE)
+    try:
+        os_ = _force_call(model, big, dev)
+    finally:
+        _lib.set_variant(_lib.VARIANT_AUTO)
+    assert rel_err(os_["energy"], ob["energy"]) < TOL
+    assert rel_err(os_["forces"], ob["forces"]) < TOL
+
+
+def test_state_dict_round_trip_and_repeat_calls(dev):
+    """Module parameters live on the device; repeated calls (plan cache) give identical results."""
+    from schnetpack_amd import model as M
+    rep_p = O.init_schnet_params()
+    model = M.build_model("schnet")
+    M.load_reference_params(model, rep_p, O.init_atomwise_params(128, seed=1))
+    model = model.to(dev).eval()
+    b = S.molecule_batch("ethanol", 2, seed=1)
+    inp = M.batch_to_inputs(b, dev)
+    o1 = model(dict(inp))
+    o2 = model(dict(inp))
+    assert torch.equal(o1["energy"], o2["energy"])
+    assert rel_err(o1["forces"].cpu(), o2["forces"].cpu()) < 1e-6
+    sd = model.representation.state_dict()
+    assert set(sd) == set(rep_p)

@@ -1,0 +1,451 @@
+"""GPU parity tests of the individual C-ABI entry points against the CPU oracle.
+
+Tolerance: max|hip - oracle| / max|oracle| <= 1e-5 (fp32; BASELINE.json north_star) unless the
+op is exact (index work, gather), where the comparison is bit-exact.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from oracle import spk_oracle as O
+from schnetpack_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["mfma", "simple"])
+def variant(request):
+    from schnetpack_amd import _lib
+    _lib.set_variant(_lib.VARIANT_SIMPLE if request.param == "simple" else _lib.VARIANT_AUTO)
+    yield request.param
+    _lib.set_variant(_lib.VARIANT_AUTO)
+
+
+def test_library_loads_on_gfx950(dev):
+    from schnetpack_amd import _lib
+    assert _lib.lib().spk_version() >= 100
+    info = _lib.device_info()
+    assert info["wavefront"] == 64
+    assert info["compute_units"] >= 64
+    assert info["gfx"] == 950
+
+
+def test_cpu_tensors_fail_loudly(dev):
+    from schnetpack_amd import ops
+    from schnetpack_amd._lib import SpkHipError
+    with pytest.raises(SpkHipError):
+        ops.scatter_add(torch.ones(3, 2), torch.tensor([0, 0, 1]), 2)
+
+
+# ----------------------------------------------------------------------------- edge plan
+def test_edge_plan_flags_and_rowptr(dev):
+    from schnetpack_amd import ops
+    from schnetpack_amd._lib import SpkHipError
+    b = S.molecule_batch("aspirin", 3, seed=1)
+    r = O.pairwise_vectors(b["R"], b["idx_i"], b["idx_j"], b["offsets"])
+    N = b["Z"].shape[0]
+    plan = ops.EdgePlan(b["idx_i"].to(dev), b["idx_j"].to(dev), N, r.to(dev))
+    assert plan.sorted and plan.symmetric
+    counts = torch.bincount(b["idx_i"], minlength=N)
+    expect = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]).int()
+    assert torch.equal(plan.rowptr.cpu(), expect)
+    # drop one edge -> asymmetric; shuffle -> unsorted
+    plan2 = ops.EdgePlan(b["idx_i"][1:].to(dev), b["idx_j"][1:].to(dev), N, r[1:].to(dev))
+    assert plan2.sorted and not plan2.symmetric
+    perm = torch.randperm(b["idx_i"].shape[0], generator=torch.Generator().manual_seed(0))
+    plan3 = ops.EdgePlan(b["idx_i"][perm].to(dev), b["idx_j"][perm].to(dev), N, r[perm].to(dev))
+    assert not plan3.sorted and not plan3.symmetric
+    bad = b["idx_j"].clone()
+    bad[5] = N
+    with pytest.raises(SpkHipError):
+        ops.EdgePlan(b["idx_i"].to(dev), bad.to(dev), N, None)
+    # empty list
+    e = torch.zeros(0, dtype=torch.long, device=dev)
+    plan4 = ops.EdgePlan(e, e, 4, None)
+    assert plan4.sorted and plan4.n_edges == 0
+    assert torch.equal(plan4.rowptr.cpu(), torch.zeros(5, dtype=torch.int32))
+
+
+# ----------------------------------------------------------------------------- scatter_add
+def test_scatter_add_golden_known_answers(dev):
+    from schnetpack_amd.nn import scatter_add
+    ka = np.load(GOLDEN + "/nn_known_answers.npz")
+    x = torch.from_numpy(ka["scat_x"]).to(dev)
+    idx = torch.from_numpy(ka["scat_idx"]).to(dev)
+    y0 = scatter_add(x, idx, dim_size=7)
+    assert rel_err(y0.cpu(), torch.from_numpy(ka["scat_y0"])) < TOL
+    xt = x.permute(1, 0, 2).contiguous()
+    y1 = scatter_add(xt, idx, dim_size=7, dim=1)
+    assert rel_err(y1.cpu(), torch.from_numpy(ka["scat_y1"])) < TOL
+
+
+@pytest.mark.parametrize("shape,dim,n,sorted_idx", [
+    ((300, 128), 0, 40, True), ((300, 128), 0, 40, False), ((257, 3, 64), 0, 33, True),
+    ((5, 200, 7), 1, 19, False), ((5, 200, 8), 1, 19, True), ((1000, 1), 0, 77, True),
+    ((64,), 0, 5, True), ((0, 16), 0, 4, True)])
+def test_scatter_add_matches_oracle(dev, shape, dim, n, sorted_idx):
+    from schnetpack_amd.nn import scatter_add
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g)
+    idx = torch.randint(0, n, (shape[dim],), generator=g)
+    if sorted_idx:
+        idx = idx.sort().values
+    y = scatter_add(x.to(dev), idx.to(dev), n, dim)
+    ref = O.scatter_add(x, idx, n, dim)
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    if ref.numel():
+        assert rel_err(y.cpu(), ref) < TOL
+
+
+def test_scatter_add_first_and_second_order_autograd(dev):
+    """backward = gather, double backward = scatter again (Forces with create_graph=True)."""
+    from schnetpack_amd.nn import scatter_add
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(50, 6, generator=g)
+    w = torch.randn(9, 6, generator=g)
+    idx = torch.randint(0, 9, (50,), generator=g).sort().values
+
+    def run(x, w, idx, fn):
+        x = x.clone().requires_grad_(True)
+        w = w.clone().requires_grad_(True)
+        y = fn(x * x, idx, 9)
+        (gx,) = torch.autograd.grad((y * w).sum(), [x], create_graph=True)
+        (gw,) = torch.autograd.grad((gx ** 2).sum(), [w])
+        return gx.detach().cpu(), gw.cpu()
+
+    gx_h, gw_h = run(x.to(dev), w.to(dev), idx.to(dev), scatter_add)
+    gx_o, gw_o = run(x, w, idx, O.scatter_add)
+    assert rel_err(gx_h, gx_o) < TOL and rel_err(gw_h, gw_o) < TOL
+
+
+def test_scatter_add_large_bitwise_stable_when_sorted(dev):
+    """At bench scale: segmented path is deterministic (two runs bit-identical) and agrees with
+    the atomic path to round-off."""
+    from schnetpack_amd import ops
+    E, C, N = 77928, 128, 5376
+    g = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, N, (E,), generator=g).sort().values.to(dev)
+    x = torch.randn(E, C, generator=g).to(dev)
+    rp = ops.segment_rowptr(idx, N)
+    assert rp is not None
+    y1 = ops._scatter_raw(x, idx, N, 0, rp)
+    y2 = ops._scatter_raw(x, idx, N, 0, rp)
+    y3 = ops._scatter_raw(x, idx, N, 0, None)
+    assert torch.equal(y1, y2)
+    assert rel_err(y3, y1) < TOL
+    # linearity: scatter(a x) == a scatter(x)
+    assert rel_err(ops._scatter_raw(2.0 * x, idx, N, 0, rp), 2.0 * y1) < 1e-6
+
+
+# ----------------------------------------------------------------------------- radial / cutoff
+def test_radial_cutoff_known_answers(dev):
+    from schnetpack_amd.nn import BesselRBF, CosineCutoff, GaussianRBF
+    ka = np.load(GOLDEN + "/nn_known_answers.npz")
+    d = torch.from_numpy(ka["d"]).to(dev)
+    d2 = torch.from_numpy(ka["d2"]).to(dev)
+    g = GaussianRBF(20, 5.0).to(dev).eval()
+    assert rel_err(g(d).cpu(), torch.from_numpy(ka["gauss20_5"])) < TOL
+    g2 = GaussianRBF(5, 1.5, start=0.5).to(dev).eval()
+    y = g2(d2)
+    assert y.shape == (3, 2, 5)
+    assert rel_err(y.cpu(), torch.from_numpy(ka["gauss5_1p5_start0p5"])) < TOL
+    bz = BesselRBF(20, 5.0).to(dev).eval()
+    assert rel_err(bz(d).cpu(), torch.from_numpy(ka["bessel20_5"])) < TOL
+    assert rel_err(BesselRBF(7, 3.0).to(dev).eval()(d2).cpu(), torch.from_numpy(ka["bessel7_3"])) < TOL
+    c = CosineCutoff(5.0).to(dev).eval()
+    assert rel_err(c(d).cpu(), torch.from_numpy(ka["cos5"])) < TOL
+    c2 = CosineCutoff(1.8).to(dev).eval()
+    out = c2(d2).cpu()
+    assert rel_err(out, torch.from_numpy(ka["cos1p8"])) < TOL
+    assert float(out[2, 0]) == 0.0 and float(out[2, 1]) == 0.0  # zero beyond the cutoff
+    assert float(c2.cutoff) == pytest.approx(1.8)
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "bessel"])
+def test_radial_cutoff_backward(dev, kind):
+    from schnetpack_amd.nn import BesselRBF, CosineCutoff, GaussianRBF
+    g = torch.Generator().manual_seed(1)
+    d = (torch.rand(200, generator=g) * 5.5 + 0.3)
+    gphi = torch.randn(200, 20, generator=g)
+    gfc = torch.randn(200, generator=g)
+    rb = (GaussianRBF(20, 5.0) if kind == "gaussian" else BesselRBF(20, 5.0)).to(dev).eval()
+    cf = CosineCutoff(5.0).to(dev).eval()
+    dd = d.to(dev).requires_grad_(True)
+    loss = (rb(dd) * gphi.to(dev)).sum() + (cf(dd) * gfc.to(dev)).sum()
+    (gd,) = torch.autograd.grad(loss, [dd])
+    dc = d.clone().double().requires_grad_(True)
+    if kind == "gaussian":
+        off, w = O.gaussian_rbf_params(20, 5.0)
+        phi = O.gaussian_rbf(dc, off.double(), w.double())
+    else:
+        phi = O.bessel_rbf(dc, O.bessel_rbf_params(20, 5.0).double())
+    lo = (phi * gphi.double()).sum() + (O.cosine_cutoff(dc, 5.0) * gfc.double()).sum()
+    (gd_o,) = torch.autograd.grad(lo, [dc])
+    assert rel_err(gd.cpu(), gd_o) < TOL
+
+
+# ----------------------------------------------------------------------------- dense
+@pytest.mark.parametrize("m,k,n,act", [(5376, 128, 128, "ssp"), (100, 128, 128, None), (77, 256, 128, "silu"),
+                                       (33, 128, 384, None), (640, 128, 64, "silu"), (50, 20, 128, "ssp"),
+                                       (31, 64, 1, None), (1, 128, 128, "ssp")])
+def test_dense_forward_backward(dev, variant, m, k, n, act):
+    from schnetpack_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g) * 0.1
+    gy = torch.randn(m, n, generator=g)
+    actf = {None: None, "ssp": O.shifted_softplus, "silu": O.silu}[act]
+    xo = x.clone().double().requires_grad_(True)
+    yo = O.dense(xo, w.double(), b.double(), actf)
+    (gxo,) = torch.autograd.grad((yo * gy.double()).sum(), [xo])
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.dense(xd, w.to(dev), b.to(dev), act)
+    assert rel_err(y.detach().cpu(), yo.detach()) < TOL
+    # first-order input gradient through the HIP backward kernel
+    from schnetpack_amd import _lib
+    a = ops._ACT_IDS[act]
+    _, pre = ops.dense_raw(x.to(dev), w.to(dev), b.to(dev), a, want_pre=True)
+    dx = torch.empty(m, k, device=dev)
+    _lib.check(_lib.lib().spk_dense_bwd_input_f32(_lib.fptr(gy.to(dev)), _lib.fptr(pre), _lib.fptr(w.to(dev)), None,
+                                                   _lib.fptr(dx), m, k, n, a, _lib.stream()))
+    assert rel_err(dx.cpu(), gxo) < TOL
+    # autograd (differentiable composite backward)
+    (gx,) = torch.autograd.grad((y * gy.to(dev)).sum(), [xd])
+    assert rel_err(gx.cpu(), gxo) < TOL
+
+
+def test_dense_residual_and_preactivation(dev, variant):
+    from schnetpack_amd import ops, _lib
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(70, 128, generator=g)
+    w = torch.randn(128, 128, generator=g) / 11.0
+    b = torch.randn(128, generator=g)
+    r = torch.randn(70, 128, generator=g)
+    y, pre = ops.dense_raw(x.to(dev), w.to(dev), b.to(dev), _lib.SPK_ACT_SSP, res=r.to(dev), want_pre=True)
+    pre_o = O.dense(x.double(), w.double(), b.double())
+    assert rel_err(pre.cpu(), pre_o) < TOL
+    assert rel_err(y.cpu(), O.shifted_softplus(pre_o) + r.double()) < TOL
+
+
+# ----------------------------------------------------------------------------- cfconv
+def _cfconv_oracle(h, r, idx_i, idx_j, p, n_atoms, kind, gy):
+    """fp64 oracle: y, and (gh, gr) for upstream gradient gy"""
+    h = h.double().requires_grad_(True)
+    r = r.double().requires_grad_(True)
+    d = torch.sqrt((r * r).sum(1))
+    if kind == "gaussian":
+        off, w = O.gaussian_rbf_params(p["n_rbf"], 5.0)
+        phi = O.gaussian_rbf(d, off.double(), w.double())
+    else:
+        phi = O.bessel_rbf(d, O.bessel_rbf_params(p["n_rbf"], 5.0).double())
+    fc = O.cosine_cutoff(d, 5.0)
+    W = O.dense(phi, p["w1"].double(), p["b1"].double(), O.shifted_softplus)
+    W = O.dense(W, p["w2"].double(), p["b2"].double()) * fc[:, None]
+    y = O.scatter_add(h[idx_j] * W, idx_i, n_atoms)
+    gh, gr = torch.autograd.grad((y * gy.double()).sum(), [h, r])
+    return y.detach(), gh, gr
+
+
+def _cfconv_hip(dev, h, r, idx_i, idx_j, p, n_atoms, kind, gy):
+    from schnetpack_amd import _lib, ops
+    plan = ops.EdgePlan(idx_i.to(dev), idx_j.to(dev), n_atoms, r.to(dev))
+    if kind == "gaussian":
+        off, w = O.gaussian_rbf_params(p["n_rbf"], 5.0)
+        rb = ops.radial_struct(_lib.SPK_RBF_GAUSSIAN, p["n_rbf"], off.to(dev), w.to(dev), 5.0)
+        keep = (off, w)
+    else:
+        fr = O.bessel_rbf_params(p["n_rbf"], 5.0).float().to(dev)
+        rb = ops.radial_struct(_lib.SPK_RBF_BESSEL, p["n_rbf"], fr, None, 5.0)
+        keep = (fr,)
+    nf = h.shape[1]
+    t = {k: v.to(dev).contiguous() for k, v in p.items() if torch.is_tensor(v)}
+    hd, rd, gyd = h.to(dev).contiguous(), r.to(dev).contiguous(), gy.to(dev).contiguous()
+    y = torch.empty(n_atoms, nf, device=dev)
+    L = _lib.lib()
+    _lib.check(L.spk_schnet_cfconv_fwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(hd), _lib.fptr(rd), _lib.fptr(t["w1"]),
+                                           _lib.fptr(t["b1"]), _lib.fptr(t["w2"]), _lib.fptr(t["b2"]), nf, _lib.fptr(y), _lib.stream()))
+    gh = torch.empty(n_atoms, nf, device=dev)
+    gr = torch.zeros(r.shape[0], 3, device=dev)
+    _lib.check(L.spk_schnet_cfconv_bwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(hd), _lib.fptr(gyd), _lib.fptr(rd),
+                                           _lib.fptr(t["w1"]), _lib.fptr(t["b1"]), _lib.fptr(t["w2"]), _lib.fptr(t["b2"]), nf,
+                                           _lib.fptr(gh), _lib.fptr(gr), _lib.stream()))
+    torch.cuda.synchronize()
+    del keep
+    return y.cpu(), gh.cpu(), gr.cpu(), plan
+
+
+def _filter_params(nf, n_rbf, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"n_rbf": n_rbf, "w1": torch.randn(nf, n_rbf, generator=g) * 0.4, "b1": torch.randn(nf, generator=g) * 0.2,
+            "w2": torch.randn(nf, nf, generator=g) / nf ** 0.5, "b2": torch.randn(nf, generator=g) * 0.2}
+
+
+@pytest.mark.parametrize("graph", ["aspirin_sym", "random_sorted", "random_unsorted", "ragged_tail"])
+@pytest.mark.parametrize("nf,n_rbf,kind", [(128, 20, "gaussian"), (64, 20, "gaussian"), (128, 16, "bessel"), (96, 11, "gaussian")])
+def test_cfconv_forward_backward(dev, variant, graph, nf, n_rbf, kind):
+    g = torch.Generator().manual_seed(11)
+    if graph == "aspirin_sym":
+        b = S.molecule_batch("aspirin", 5, seed=2)
+        r = O.pairwise_vectors(b["R"], b["idx_i"], b["idx_j"], b["offsets"])
+        idx_i, idx_j, n_atoms = b["idx_i"], b["idx_j"], b["Z"].shape[0]
+    else:
+        rb = S.random_graph_batch(150 if graph != "ragged_tail" else 7, 9 if graph != "ragged_tail" else 5,
+                                  seed=5, sort=(graph != "random_unsorted"))
+        r, idx_i, idx_j, n_atoms = rb["r_ij"], rb["idx_i"], rb["idx_j"], rb["Z"].shape[0]
+        if graph == "ragged_tail":  # 35 edges: one full tile + 3 edges; atom 6 has no edges
+            keep = idx_i < 6
+            r, idx_i, idx_j = r[keep], idx_i[keep], idx_j[keep]
+    p = _filter_params(nf, n_rbf, 3)
+    h = torch.randn(n_atoms, nf, generator=g)
+    gy = torch.randn(n_atoms, nf, generator=g)
+    yo, gho, gro = _cfconv_oracle(h, r, idx_i, idx_j, p, n_atoms, kind, gy)
+    y, gh, gr, plan = _cfconv_hip(dev, h, r, idx_i, idx_j, p, n_atoms, kind, gy)
+    assert plan.symmetric == (graph == "aspirin_sym")
+    assert rel_err(y, yo) < TOL
+    assert rel_err(gh, gho) < TOL
+    assert rel_err(gr, gro) < TOL
+
+
+def test_cfconv_empty_and_isolated(dev, variant):
+    p = _filter_params(128, 20, 1)
+    h = torch.randn(4, 128)
+    e = torch.zeros(0, dtype=torch.long)
+    y, gh, gr, _ = _cfconv_hip(dev, h, torch.zeros(0, 3), e, e, p, 4, "gaussian", torch.randn(4, 128))
+    assert float(y.abs().max()) == 0.0 and float(gh.abs().max()) == 0.0 and gr.shape == (0, 3)
+
+
+def test_cfconv_mfma_equals_simple_at_bench_scale(dev):
+    """cfg 2 shape (N=5376, E~77.9k, F=128): both kernel variants and both transposed-sum paths
+    agree; linear in h."""
+    from schnetpack_amd import _lib
+    b = S.molecule_batch("aspirin", 256, seed=0)
+    r = O.pairwise_vectors(b["R"], b["idx_i"], b["idx_j"], b["offsets"])
+    N = b["Z"].shape[0]
+    p = _filter_params(128, 20, 9)
+    g = torch.Generator().manual_seed(1)
+    h = torch.randn(N, 128, generator=g)
+    gy = torch.randn(N, 128, generator=g)
+    _lib.set_variant(_lib.VARIANT_MFMA)
+    y1, gh1, gr1, plan = _cfconv_hip(dev, h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
+    assert plan.symmetric
+    y1b, _, _, _ = _cfconv_hip(dev, 3.0 * h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
+    _lib.set_variant(_lib.VARIANT_SIMPLE)
+    y2, gh2, gr2, _ = _cfconv_hip(dev, h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
+    _lib.set_variant(_lib.VARIANT_AUTO)
+    assert rel_err(y1, y2) < TOL and rel_err(gh1, gh2) < TOL and rel_err(gr1, gr2) < TOL
+    assert rel_err(y1b, 3.0 * y1) < 2e-6
+    # reversed edges carry opposite geometry gradients on a symmetric list: sum_e gr_e r_e parity
+    assert torch.isfinite(gr1).all()
+
+
+# ----------------------------------------------------------------------------- PaiNN message
+def _msg_oracle(c, q, mu, r, idx_i, idx_j, wf, bf, n_atoms, F, gq, gmu):
+    c = c.double().requires_grad_(True)
+    mu = mu.double().requires_grad_(True)
+    r = r.double().requires_grad_(True)
+    d = torch.sqrt((r * r).sum(1, keepdim=True))
+    u = r / d
+    off, w = O.gaussian_rbf_params(wf.shape[1], 5.0)
+    phi = O.gaussian_rbf(d, off.double(), w.double())
+    Wij = O.dense(phi, wf.double(), bf.double()) * O.cosine_cutoff(d, 5.0)[..., None]
+    m = Wij * c.unsqueeze(1)[idx_j]
+    dq = O.scatter_add(m[..., :F], idx_i, n_atoms)
+    dmu = O.scatter_add(m[..., F:2 * F] * u[..., None] + m[..., 2 * F:] * mu[idx_j], idx_i, n_atoms)
+    qo = q.double().unsqueeze(1) + dq
+    muo = mu + dmu
+    gc, gmu_in, gr = torch.autograd.grad((qo.squeeze(1) * gq.double()).sum() + (muo * gmu.double()).sum(), [c, mu, r])
+    return qo.squeeze(1).detach(), muo.detach(), gc, gmu_in, gr
+
+
+@pytest.mark.parametrize("graph", ["aspirin_sym", "random_sorted", "random_unsorted"])
+@pytest.mark.parametrize("F,n_rbf", [(128, 20), (64, 20), (128, 25), (96, 20)])
+def test_painn_message_forward_backward(dev, variant, graph, F, n_rbf):
+    from schnetpack_amd import _lib, ops
+    g = torch.Generator().manual_seed(21)
+    if graph == "aspirin_sym":
+        b = S.molecule_batch("aspirin", 4, seed=6)
+        r = O.pairwise_vectors(b["R"], b["idx_i"], b["idx_j"], b["offsets"])
+        idx_i, idx_j, N = b["idx_i"], b["idx_j"], b["Z"].shape[0]
+    else:
+        rb_ = S.random_graph_batch(90, 70 if graph == "random_sorted" else 8, seed=8, sort=(graph != "random_unsorted"))
+        r, idx_i, idx_j, N = rb_["r_ij"], rb_["idx_i"], rb_["idx_j"], rb_["Z"].shape[0]
+    c = torch.randn(N, 3 * F, generator=g)
+    q = torch.randn(N, F, generator=g)
+    mu = torch.randn(N, 3, F, generator=g)
+    wf = torch.randn(3 * F, n_rbf, generator=g) * 0.3
+    bf = torch.randn(3 * F, generator=g) * 0.1
+    gq = torch.randn(N, F, generator=g)
+    gmu = torch.randn(N, 3, F, generator=g)
+    qo, muo, gco, gmuo, gro = _msg_oracle(c, q, mu, r, idx_i, idx_j, wf, bf, N, F, gq, gmu)
+    plan = ops.EdgePlan(idx_i.to(dev), idx_j.to(dev), N, r.to(dev))
+    off, w = O.gaussian_rbf_params(n_rbf, 5.0)
+    offd, wd = off.to(dev), w.to(dev)
+    rb = ops.radial_struct(_lib.SPK_RBF_GAUSSIAN, n_rbf, offd, wd, 5.0)
+    D = lambda t: t.to(dev).contiguous()
+    cd, qd, mud, rd, wfd, bfd, gqd, gmud = map(D, (c, q, mu, r, wf, bf, gq, gmu))
+    q_out = torch.empty(N, F, device=dev)
+    mu_out = torch.empty(N, 3, F, device=dev)
+    L = _lib.lib()
+    _lib.check(L.spk_painn_message_fwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(qd), _lib.fptr(mud), _lib.fptr(rd),
+                                           _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(q_out), _lib.fptr(mu_out), _lib.stream()))
+    assert rel_err(q_out.cpu(), qo) < TOL
+    assert rel_err(mu_out.cpu(), muo) < TOL
+    gc = torch.empty(N, 3 * F, device=dev)
+    gmu_in = torch.empty(N, 3, F, device=dev)
+    gr = torch.zeros(r.shape[0], 3, device=dev)
+    _lib.check(L.spk_painn_message_bwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(mud), _lib.fptr(gqd), _lib.fptr(gmud),
+                                           _lib.fptr(rd), _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(gc), _lib.fptr(gmu_in), _lib.fptr(gr),
+                                           _lib.stream()))
+    assert rel_err(gc.cpu(), gco) < TOL
+    assert rel_err(gmu_in.cpu(), gmuo) < TOL
+    assert rel_err(gr.cpu(), gro) < TOL
+
+
+def test_painn_mixing_elementwise(dev):
+    from schnetpack_amd import _lib
+    g = torch.Generator().manual_seed(31)
+    N, F, eps = 57, 128, 1e-8
+    q = torch.randn(N, F, generator=g)
+    mu = torch.randn(N, 3, F, generator=g)
+    mix = torch.randn(N, 3, 2 * F, generator=g)
+    a = torch.randn(N, 3 * F, generator=g)
+    gq = torch.randn(N, F, generator=g)
+    gmu = torch.randn(N, 3, F, generator=g)
+    gctx = torch.randn(N, 2 * F, generator=g)
+    # oracle
+    mixo = mix.double().requires_grad_(True)
+    ao = a.double().requires_grad_(True)
+    V, W = mixo[..., :F], mixo[..., F:]
+    Vn = torch.sqrt((V * V).sum(1) + eps)
+    ctx_o = torch.cat([q.double(), Vn], -1)
+    qo = q.double() + ao[:, :F] + ao[:, 2 * F:] * (V * W).sum(1)
+    muo = mu.double() + ao[:, None, F:2 * F] * W
+    ga_o, gmix_o = torch.autograd.grad((qo * gq.double()).sum() + (muo * gmu.double()).sum() + (ctx_o * gctx.double()).sum(), [ao, mixo])
+    D = lambda t: t.to(dev).contiguous()
+    qd, mud, mixd, ad, gqd, gmud, gctxd = map(D, (q, mu, mix, a, gq, gmu, gctx))
+    L = _lib.lib()
+    ctx = torch.empty(N, 2 * F, device=dev)
+    _lib.check(L.spk_painn_mix_ctx_f32(_lib.fptr(qd), _lib.fptr(mixd), N, F, eps, _lib.fptr(ctx), _lib.stream()))
+    assert rel_err(ctx.cpu(), ctx_o.detach()) < TOL
+    q_out, mu_out = torch.empty(N, F, device=dev), torch.empty(N, 3, F, device=dev)
+    _lib.check(L.spk_painn_mix_update_f32(_lib.fptr(qd), _lib.fptr(mud), _lib.fptr(mixd), _lib.fptr(ad), N, F, _lib.fptr(q_out), _lib.fptr(mu_out), _lib.stream()))
+    assert rel_err(q_out.cpu(), qo.detach()) < TOL and rel_err(mu_out.cpu(), muo.detach()) < TOL
+    ga, gmix = torch.empty(N, 3 * F, device=dev), torch.empty(N, 3, 2 * F, device=dev)
+    _lib.check(L.spk_painn_mix_update_bwd_f32(None, _lib.fptr(mixd), _lib.fptr(ad), _lib.fptr(gqd), _lib.fptr(gmud), N, F, _lib.fptr(ga), _lib.fptr(gmix), _lib.stream()))
+    gq1 = torch.empty(N, F, device=dev)
+    _lib.check(L.spk_painn_mix_ctx_bwd_f32(_lib.fptr(mixd), _lib.fptr(gctxd), _lib.fptr(gqd), N, F, eps, _lib.fptr(gmix), _lib.fptr(gq1), _lib.stream()))
+    assert rel_err(ga.cpu(), ga_o) < TOL
+    assert rel_err(gmix.cpu(), gmix_o) < TOL
+    assert rel_err(gq1.cpu(), gq.double() + gctx.double()[:, :F]) < TOL
