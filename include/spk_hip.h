@@ -40,6 +40,7 @@ extern "C" {
 #define SPK_VARIANT_AUTO 0    /* MFMA kernels when the shape is supported, else simple */
 #define SPK_VARIANT_SIMPLE 1  /* straightforward HIP kernels (any shape), used as cross-check */
 #define SPK_VARIANT_MFMA 2    /* force the MFMA kernels (error if shape unsupported) */
+#define SPK_VARIANT_MFMA_DIRECTED 3 /* MFMA kernels, but one filter per DIRECTED edge even on symmetric lists */
 
 /* Radial basis x cosine cutoff description (nn/radial.py, nn/cutoff.py:14-57).
  * gaussian: p0 = offsets[n_rbf], p1 = widths[n_rbf];  bessel: p0 = freqs[n_rbf], p1 unused. */
@@ -61,6 +62,9 @@ typedef struct {
   const int32_t* rowptr;  /* [N+1] CSR offsets into the edge list; valid iff sorted != 0 */
   int32_t sorted;         /* idx_i ascending (every reference neighbour list; neighborlist.py:450-453) */
   int32_t symmetric;      /* for every edge (i<-j, r) the list also holds (j<-i, -r) */
+  const int32_t* rev;     /* [E] index of the reversed edge (valid iff symmetric); may be NULL */
+  const int32_t* half;    /* [n_half] the canonical edge of every undirected pair (e < rev[e]), ascending; may be NULL */
+  int64_t n_half;         /* = E/2 on a symmetric list */
 } spk_graph_t;
 
 /* ------------------------------------------------------------------ library / device info */
@@ -79,11 +83,12 @@ const char* spk_profile_report(void);
 /* ------------------------------------------------------------------ neighbour-list plan
  * Derives what the fused kernels need from the delivered index arrays: CSR row pointers,
  * sortedness, index range check and (if r_ij != NULL) whether the list is symmetric.
- * host_flags[0]=sorted, [1]=in_range, [2]=symmetric.  Synchronises the stream (one D2H copy of
+ * host_flags[0]=sorted, [1]=in_range, [2]=symmetric.  `rev` ([E] int32, may be NULL) receives the
+ * index of the reversed edge of every edge (-1 if none).  Synchronises the stream (one D2H copy of
  * 16 bytes) -- call once per neighbour list, not per force call.  `scratch` >= 16 bytes device. */
 int spk_edge_plan(const int64_t* idx_i, const int64_t* idx_j, const float* r_ij, int64_t n_edges,
-                  int64_t n_atoms, int32_t* rowptr, int32_t* scratch, int32_t* host_flags,
-                  void* stream);
+                  int64_t n_atoms, int32_t* rowptr, int32_t* rev, int32_t* scratch,
+                  int32_t* host_flags, void* stream);
 
 /* ------------------------------------------------------------------ nn/scatter.py:7-34
  * y[o, k, c] = sum_{e: idx[e]==k} x[o, e, c]   (x: [outer, E, inner], y: [outer, dim_size, inner]).
@@ -94,6 +99,15 @@ int spk_scatter_add_f32(const float* x, const int64_t* idx, const int32_t* rowpt
 /* transpose of the above (its backward): y[o, e, c] = x[o, idx[e], c] */
 int spk_gather_f32(const float* x, const int64_t* idx, int64_t outer, int64_t n_rows,
                    int64_t n_edges, int64_t inner, float* y, void* stream);
+
+/* ------------------------------------------------------------------ atomistic/distances.py:14-26
+ * r_ij[e] = (R[idx_j[e]] - R[idx_i[e]]) + offsets[e]   (offsets may be NULL). */
+int spk_pairwise_f32(const float* R, const int64_t* idx_i, const int64_t* idx_j,
+                     const float* offsets, int64_t n_edges, float* r_ij, void* stream);
+/* its backward w.r.t. R:  gR[a] = sum_{e: idx_j[e]==a} gr[e] - sum_{e: idx_i[e]==a} gr[e]
+ * ([N,3], overwritten) -- where dE/dR_ij lands on the atoms (forces = -gR). */
+int spk_pairwise_bwd_f32(const float* gr, const int64_t* idx_i, const int64_t* idx_j,
+                         int64_t n_edges, int64_t n_atoms, float* gR, void* stream);
 
 /* ------------------------------------------------------------------ nn/radial.py, nn/cutoff.py
  * d: [n] distances -> phi [n, n_rbf] (may be NULL), fcut [n] (may be NULL). */

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libspk_hip.so")
 
 SPK_ACT_NONE, SPK_ACT_SSP, SPK_ACT_SILU = 0, 1, 2
 SPK_RBF_GAUSSIAN, SPK_RBF_BESSEL = 0, 1
-VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_MFMA = 0, 1, 2
+VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_MFMA, VARIANT_MFMA_DIRECTED = 0, 1, 2, 3
 
 c_f = ctypes.c_void_p  # device pointers travel as void*
 c_i64 = ctypes.c_int64
@@ -33,7 +33,8 @@ class RadialT(ctypes.Structure):
 
 class GraphT(ctypes.Structure):
     _fields_ = [("n_atoms", c_i64), ("n_edges", c_i64), ("idx_i", c_f), ("idx_j", c_f),
-                ("rowptr", c_f), ("sorted", c_i32), ("symmetric", c_i32)]
+                ("rowptr", c_f), ("sorted", c_i32), ("symmetric", c_i32), ("rev", c_f), ("half", c_f),
+                ("n_half", c_i64)]
 
 
 class SchnetLayerT(ctypes.Structure):
@@ -66,9 +67,11 @@ _PROTOS = {
     "spk_get_variant": (ctypes.c_int, []),
     "spk_profile_enable": (None, [ctypes.c_int]),
     "spk_profile_report": (ctypes.c_char_p, []),
-    "spk_edge_plan": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, P(c_i32), c_f]),
+    "spk_edge_plan": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, c_f, P(c_i32), c_f]),
     "spk_scatter_add_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i64, c_f, c_f]),
     "spk_gather_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_i64, c_f, c_f]),
+    "spk_pairwise_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_f, c_f]),
+    "spk_pairwise_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_f, c_f]),
     "spk_radial_cutoff_f32": (ctypes.c_int, [c_f, c_i64, P(RadialT), c_f, c_f, c_f]),
     "spk_radial_cutoff_bwd_f32": (ctypes.c_int, [c_f, c_i64, P(RadialT), c_f, c_f, c_f, c_f]),
     "spk_edge_norm_f32": (ctypes.c_int, [c_f, c_i64, c_f, c_f, c_f]),

@@ -22,10 +22,11 @@ class PairwiseDistances(nn.Module):
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         R = inputs[properties.R]
-        offsets = inputs[properties.offsets]
+        offsets = inputs.get(properties.offsets)
         idx_i = inputs[properties.idx_i].long()
         idx_j = inputs[properties.idx_j].long()
-        inputs[properties.Rij] = R[idx_j] - R[idx_i] + offsets
+        from . import ops
+        inputs[properties.Rij] = ops.pairwise_vectors(R, idx_i, idx_j, offsets)
         return inputs
 
 

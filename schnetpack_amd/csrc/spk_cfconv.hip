@@ -20,7 +20,6 @@
 // segmented reduction (gather gy of the neighbours); otherwise float atomics on gh[j].
 #include "spk_common.h"
 
-#define TPAD 36  // row stride (floats) of the per-wave transposition buffer: 32 + 4 => conflict-free b128 writes
 
 struct CfArgs {
   const float* h;      // [N, NF]
@@ -36,6 +35,9 @@ struct CfArgs {
   float* gr;           // bwd: [E, 3] accumulated
   int64_t E;
   int64_t N;
+  const int32_t* half;  // pair kernel: canonical edge of every undirected pair
+  const int32_t* rev;   // pair kernel: reversed edge
+  int64_t n_half;
   RadialDev rb;
 };
 
@@ -118,66 +120,107 @@ __global__ void k_cfconv_simple(CfArgs a, int NF, int sym) {
 // Packed LDS image of a weight matrix W[NOUT][K] (row-major, K padded with zeros to 8*KB):
 //   P[((t * KB + ug) * 64 + lane) * 4 + v] = W[32 t + (lane & 31)][8 ug + 4 (lane >> 5) + v]
 // so one ds_read_b128 per lane delivers the A operands of 4 consecutive k-steps, conflict-free.
-template <int NWAVES>
-__device__ __forceinline__ void stage_packed(float* dst, const float* __restrict__ w, int nout,
-                                             int K, int KB) {
-  const int total = (nout / 32) * KB * 64;  // float4 slots
-  for (int s = threadIdx.x; s < total; s += NWAVES * 64) {
-    const int lane = s & 63;
-    const int ug = (s >> 6) % KB;
-    const int t = (s >> 6) / KB;
-    const int row = 32 * t + (lane & 31);
-    const int k0 = 8 * ug + 4 * (lane >> 5);
-    f32x4 v;
-    v.x = (k0 + 0 < K) ? w[(int64_t)row * K + k0 + 0] : 0.f;
-    v.y = (k0 + 1 < K) ? w[(int64_t)row * K + k0 + 1] : 0.f;
-    v.z = (k0 + 2 < K) ? w[(int64_t)row * K + k0 + 2] : 0.f;
-    v.w = (k0 + 3 < K) ? w[(int64_t)row * K + k0 + 3] : 0.f;
-    *(f32x4*)(dst + (int64_t)s * 4) = v;
+// All global loads of a thread are issued before the first LDS store (latency paid once).
+template <int NTHREADS, int SLOTS>
+__device__ __forceinline__ void stage_packed(float* dst, const float* __restrict__ w, int K, int KB) {
+  constexpr int PER = (SLOTS + NTHREADS - 1) / NTHREADS;
+  f32x4 v[PER];
+  const bool vec = (K & 3) == 0;
+#pragma unroll
+  for (int p = 0; p < PER; ++p) {
+    const int s = threadIdx.x + p * NTHREADS;
+    v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s < SLOTS) {
+      const int lane = s & 63;
+      const int ug = (s >> 6) % KB;
+      const int t = (s >> 6) / KB;
+      const int row = 32 * t + (lane & 31);
+      const int k0 = 8 * ug + 4 * (lane >> 5);
+      const float* src = w + (int64_t)row * K + k0;
+      if (vec) {
+        if (k0 < K) v[p] = *(const f32x4*)src;
+      } else {
+        if (k0 + 0 < K) v[p].x = src[0];
+        if (k0 + 1 < K) v[p].y = src[1];
+        if (k0 + 2 < K) v[p].z = src[2];
+        if (k0 + 3 < K) v[p].w = src[3];
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PER; ++p) {
+    const int s = threadIdx.x + p * NTHREADS;
+    if (s < SLOTS) *(f32x4*)(dst + (int64_t)s * 4) = v[p];
   }
 }
+
+#define SPK_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
+
+// Row stride (floats) of the per-wave transposition buffer: two 32-channel tiles + 4 pad floats
+// => conflict-free ds_write_b128 (8-lane groups hit 8 distinct 4-bank groups) and ds_read_b32.
+#define TP2 68
 
 template <int NF, int KPB, int NWAVES, bool BWD, bool SYM>
 __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_mfma(CfArgs a) {
   constexpr int NT = NF / 32;   // feature tiles
   constexpr int KB2 = NF / 8;   // k-blocks (of 8) of the second GEMM
+  constexpr bool USE_LDS = !BWD || SYM;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sW2 = smem;                         // NF*NF
-  float* sW1 = sW2 + NF * NF;                // NF*KPB*8
-  float* sb1 = sW1 + NF * KPB * 8;           // NF
-  float* sb2 = sb1 + NF;                     // NF
-  float* sT = sb2 + NF;                      // NWAVES * 32 * TPAD
-  int* sI = (int*)(sT + NWAVES * 32 * TPAD); // NWAVES * 36
+  float* sW2 = smem;                          // NF*NF
+  float* sW1 = sW2 + NF * NF;                 // NF*KPB*8
+  float* sb1 = sW1 + NF * KPB * 8;            // NF
+  float* sb2 = sb1 + NF;                      // NF
+  float* sT = sb2 + NF;                       // NWAVES * 32 * TP2
+  int* sCnt = (int*)(sT + NWAVES * 32 * TP2); // 4 ints
 
-  stage_packed<NWAVES>(sW2, a.w2, NF, NF, KB2);
-  stage_packed<NWAVES>(sW1, a.w1, NF, a.rb.n_rbf, KPB);
+  stage_packed<NWAVES * 64, NF * NF / 4>(sW2, a.w2, NF, KB2);
+  stage_packed<NWAVES * 64, NF * KPB * 2>(sW1, a.w1, a.rb.n_rbf, KPB);
   for (int s = threadIdx.x; s < NF; s += NWAVES * 64) { sb1[s] = a.b1[s]; sb2[s] = a.b2[s]; }
+  if (threadIdx.x == 0) sCnt[0] = 0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int hi = lane >> 5, el = lane & 31;
-  float* myT = sT + wv * (32 * TPAD);
-  int* myI = sI + wv * 36;
+  float* myT = sT + wv * (32 * TP2);
   const int64_t ntiles = (a.E + 31) / 32;
 
-  for (int64_t tile = (int64_t)blockIdx.x * NWAVES + wv; tile < ntiles;
-       tile += (int64_t)gridDim.x * NWAVES) {
+  // tiles of this workgroup: blockIdx.x + n * gridDim.x; waves take them from a shared counter so
+  // that every CU gets the same number of tiles (+-1) and its SIMDs stay evenly loaded
+  while (true) {
+    int nidx = 0;
+    if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
+    nidx = __builtin_amdgcn_readfirstlane(nidx);
+    const int64_t tile = (int64_t)blockIdx.x + (int64_t)nidx * gridDim.x;
+    if (tile >= ntiles) break;
+
     const int64_t e = tile * 32 + el;
     const bool valid = e < a.E;
     const int64_t ec = valid ? e : (a.E - 1);
     const float rx = a.rij[3 * ec], ry = a.rij[3 * ec + 1], rz = a.rij[3 * ec + 2];
+    const int64_t j = a.idx_j[ec];
+    const int64_t i = a.idx_i[ec];
     const float d = sqrtf(rx * rx + ry * ry + rz * rz);
     float fc, dfc;
     spk_cutoff_eval(a.rb.cutoff, d, fc, dfc);
     if (!valid) { fc = 0.f; dfc = 0.f; }
-    const int64_t j = a.idx_j[ec];
-    const int64_t i = a.idx_i[ec];
-    // segment bookkeeping for the row-local reduction: centre atom of every tile edge (-1 = pad)
-    if (hi == 0) myI[el] = valid ? (int)i : -1;
-    if (lane == 0) myI[32] = -1;
+    // segment structure of the tile (wave-uniform): bit k set <=> the run of centre atom idx_i
+    // ends at edge k.  Lanes 32..63 mirror lanes 0..31.
+    const int ieff = valid ? (int)i : -1;
+    const int inext = __shfl(ieff, (lane + 1) & 63, 64);
+    const unsigned long long bal = __ballot(ieff != inext);
+    const unsigned flushmask = __builtin_amdgcn_readfirstlane((unsigned)(bal & 0xffffffffull)) | 0x80000000u;
+
+    // forward only: all neighbour rows of the tile are requested up front (64 VGPRs)
+    f32x4 hjv[BWD ? 1 : NT][4];
+    if (!BWD) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hjv[BWD ? 0 : t][q] = *(const f32x4*)(a.h + j * NF + 32 * t + 8 * q + 4 * hi);
+    }
 
     // ---- radial basis for this lane's k slots: kk = 8u + 4hi + v
-    float phi[KPB][4], dphi[KPB][4];
+    float phi[KPB][4], dphi[BWD ? KPB : 1][4];
 #pragma unroll
     for (int u = 0; u < KPB; ++u)
 #pragma unroll
@@ -185,124 +228,140 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_mfma(CfArgs a) {
         float p, dp;
         spk_rbf_eval(a.rb, 8 * u + 4 * hi + v, d, p, dp);
         phi[u][v] = p;
-        dphi[u][v] = dp;
+        if (BWD) dphi[BWD ? u : 0][v] = dp;
       }
 
-    // ---- GEMM 1 (transposed): a^T[f][e] = sum_k W1[f][k] phi[e][k] + b1[f]
+    // ---- GEMM 1 (transposed): a^T[f][e] = sum_k W1[f][k] phi[e][k] + b1[f];  z = ssp(a)
     f32x16 z[NT];
     f32x16 zp[BWD ? NT : 1];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) z[c][r] = sb1[32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi];
-      if (BWD) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zp[BWD ? c : 0][r] = 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < KPB; ++u) {
-        const f32x4 wq = *(const f32x4*)(sW1 + ((c * KPB + u) * 64 + lane) * 4);
-        z[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.x, phi[u][0], z[c], 0, 0, 0);
-        z[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.y, phi[u][1], z[c], 0, 0, 0);
-        z[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.z, phi[u][2], z[c], 0, 0, 0);
-        z[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.w, phi[u][3], z[c], 0, 0, 0);
-        if (BWD) {
-          f32x16& q = zp[BWD ? c : 0];
-          q = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.x, dphi[u][0], q, 0, 0, 0);
-          q = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.y, dphi[u][1], q, 0, 0, 0);
-          q = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.z, dphi[u][2], q, 0, 0, 0);
-          q = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.w, dphi[u][3], q, 0, 0, 0);
-        }
-      }
-      // activation: z = ssp(a); z' = sigmoid(a) a'
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float sp, sg;
-        spk_softplus_sigmoid(z[c][r], sp, sg);
-        z[c][r] = sp - SPK_LN2_F;
-        if (BWD) zp[BWD ? c : 0][r] *= sg;
-      }
-    }
-
-    float dsum = 0.f;  // BWD: sum_f gy_i h_j dW/dd over this lane's features
-    // flush mask of this lane's 16-edge half for the segmented reduction
-    spk_wave_lds_sync();
-    unsigned flushmask = 0;
     {
-      const int base = 16 * hi;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int ci = myI[base + k], ni = myI[base + k + 1];
-        if (k == 15 || ci != ni) flushmask |= (1u << k);
-      }
-    }
-
-    // ---- GEMM 2 per output tile t, modulation, reduction
-#pragma unroll 1
-    for (int t = 0; t < NT; ++t) {
-      f32x16 g, gp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { g[r] = sb2[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi]; gp[r] = 0.f; }
+      f32x4 wq = *(const f32x4*)(sW1 + lane * 4);
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 wq = *(const f32x4*)(sW2 + ((t * KB2 + 4 * c + q) * 64 + lane) * 4);
-          g = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.x, z[c][4 * q + 0], g, 0, 0, 0);
-          g = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.y, z[c][4 * q + 1], g, 0, 0, 0);
-          g = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.z, z[c][4 * q + 2], g, 0, 0, 0);
-          g = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.w, z[c][4 * q + 3], g, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) z[c][r] = sb1[32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi];
+        if (BWD) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zp[BWD ? c : 0][r] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < KPB; ++u) {
+          const int nxt = c * KPB + u + 1;
+          f32x4 wn = wq;
+          if (nxt < NT * KPB) wn = *(const f32x4*)(sW1 + (nxt * 64 + lane) * 4);
+          z[c] = SPK_MFMA(wq.x, phi[u][0], z[c]);
+          z[c] = SPK_MFMA(wq.y, phi[u][1], z[c]);
+          z[c] = SPK_MFMA(wq.z, phi[u][2], z[c]);
+          z[c] = SPK_MFMA(wq.w, phi[u][3], z[c]);
           if (BWD) {
-            const f32x16& zq = zp[BWD ? c : 0];
-            gp = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.x, zq[4 * q + 0], gp, 0, 0, 0);
-            gp = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.y, zq[4 * q + 1], gp, 0, 0, 0);
-            gp = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.z, zq[4 * q + 2], gp, 0, 0, 0);
-            gp = __builtin_amdgcn_mfma_f32_32x32x2f32(wq.w, zq[4 * q + 3], gp, 0, 0, 0);
+            f32x16& q = zp[BWD ? c : 0];
+            q = SPK_MFMA(wq.x, dphi[BWD ? u : 0][0], q);
+            q = SPK_MFMA(wq.y, dphi[BWD ? u : 0][1], q);
+            q = SPK_MFMA(wq.z, dphi[BWD ? u : 0][2], q);
+            q = SPK_MFMA(wq.w, dphi[BWD ? u : 0][3], q);
           }
+          wq = wn;
         }
       }
-      // modulation with gathered neighbour rows; lane holds features 32t + 8q + 4hi + v
-      const bool use_lds = !BWD || SYM;
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float sp, sg;
+          spk_fast_softplus_sigmoid(z[c][r], sp, sg);
+          z[c][r] = sp - SPK_LN2_F;
+          if (BWD) zp[BWD ? c : 0][r] *= sg;
+        }
+    }
+
+    float dsum = 0.f;  // BWD: sum_f gy_i h_j dW/dd over this lane's channels
+
+    // ---- GEMM 2 per output tile t, modulation, segmented reduction per pair of tiles
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      // backward: the three gathered rows of this tile are requested before the 128 MFMAs
+      f32x4 hq[BWD ? 4 : 1], gyiq[BWD ? 4 : 1], gyjq[(BWD && SYM) ? 4 : 1];
+      if (BWD) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * t + 8 * q + 4 * hi;
+          hq[BWD ? q : 0] = *(const f32x4*)(a.h + j * NF + col);
+          gyiq[BWD ? q : 0] = *(const f32x4*)(a.gy + i * NF + col);
+          if (SYM) gyjq[(BWD && SYM) ? q : 0] = *(const f32x4*)(a.gy + j * NF + col);
+        }
+      }
+      f32x16 g, gp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { g[r] = sb2[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi]; gp[r] = 0.f; }
+      {
+        const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
+        f32x4 wq = *(const f32x4*)wbase;
+#pragma unroll
+        for (int ug = 0; ug < KB2; ++ug) {
+          const int c = ug >> 2, q = ug & 3;
+          f32x4 wn = wq;
+          if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
+          g = SPK_MFMA(wq.x, z[c][4 * q + 0], g);
+          g = SPK_MFMA(wq.y, z[c][4 * q + 1], g);
+          g = SPK_MFMA(wq.z, z[c][4 * q + 2], g);
+          g = SPK_MFMA(wq.w, z[c][4 * q + 3], g);
+          if (BWD) {
+            const f32x16& zq = zp[BWD ? c : 0];
+            gp = SPK_MFMA(wq.x, zq[4 * q + 0], gp);
+            gp = SPK_MFMA(wq.y, zq[4 * q + 1], gp);
+            gp = SPK_MFMA(wq.z, zq[4 * q + 2], gp);
+            gp = SPK_MFMA(wq.w, zq[4 * q + 3], gp);
+          }
+          wq = wn;
+        }
+      }
+      // modulation; lane holds channels 32t + 8q + 4hi + v of edge el
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int col = 32 * t + 8 * q + 4 * hi;
         f32x4 p;
         if (!BWD) {
-          const f32x4 hj = *(const f32x4*)(a.h + j * NF + col);
+          const f32x4 hj = hjv[BWD ? 0 : t][q];
           p.x = g[4 * q + 0] * fc * hj.x; p.y = g[4 * q + 1] * fc * hj.y;
           p.z = g[4 * q + 2] * fc * hj.z; p.w = g[4 * q + 3] * fc * hj.w;
         } else {
-          const f32x4 hj = *(const f32x4*)(a.h + j * NF + col);
-          const f32x4 gyi = *(const f32x4*)(a.gy + i * NF + col);
-          float W0 = g[4 * q + 0] * fc, W1v = g[4 * q + 1] * fc, W2v = g[4 * q + 2] * fc, W3 = g[4 * q + 3] * fc;
+          const f32x4 hj = hq[BWD ? q : 0];
+          const f32x4 gyi = gyiq[BWD ? q : 0];
+          const float W0 = g[4 * q + 0] * fc, W1v = g[4 * q + 1] * fc, W2v = g[4 * q + 2] * fc, W3 = g[4 * q + 3] * fc;
           dsum += gyi.x * hj.x * (gp[4 * q + 0] * fc + g[4 * q + 0] * dfc);
           dsum += gyi.y * hj.y * (gp[4 * q + 1] * fc + g[4 * q + 1] * dfc);
           dsum += gyi.z * hj.z * (gp[4 * q + 2] * fc + g[4 * q + 2] * dfc);
           dsum += gyi.w * hj.w * (gp[4 * q + 3] * fc + g[4 * q + 3] * dfc);
           if (SYM) {
-            const f32x4 gyj = *(const f32x4*)(a.gy + j * NF + col);
+            const f32x4 gyj = gyjq[(BWD && SYM) ? q : 0];
             p.x = W0 * gyj.x; p.y = W1v * gyj.y; p.z = W2v * gyj.z; p.w = W3 * gyj.w;
           } else if (valid) {
-            float* dst = a.y + j * NF + col;
+            float* dst = a.y + j * NF + 32 * t + 8 * q + 4 * hi;
             unsafeAtomicAdd(dst + 0, W0 * gyi.x);
             unsafeAtomicAdd(dst + 1, W1v * gyi.y);
             unsafeAtomicAdd(dst + 2, W2v * gyi.z);
             unsafeAtomicAdd(dst + 3, W3 * gyi.w);
           }
         }
-        if (use_lds) *(f32x4*)(myT + el * TPAD + 8 * q + 4 * hi) = p;
+        if (USE_LDS) *(f32x4*)(myT + el * TP2 + 32 * (t & 1) + 8 * q + 4 * hi) = p;
       }
-      if (use_lds) {
+      // after an odd tile (or the last one): lanes 0..31 own the channels of tile t-1 (or t if it is
+      // a lone tile), lanes 32..63 those of tile t; every lane scans the 32 edges of its column
+      if (USE_LDS && ((t & 1) == 1 || t == NT - 1)) {
+        const bool pair = (t & 1) == 1;
+        const int t0 = pair ? t - 1 : t;
         spk_wave_lds_sync();
-        // lane (fl = el, half = hi) scans its 16 edges of column fl, flushing at segment ends
-        float acc = 0.f;
-        const int base = 16 * hi;
+        float v[32];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          acc += myT[(base + k) * TPAD + el];
-          if (flushmask & (1u << k)) {
-            const int ci = myI[base + k];
-            if (ci >= 0) unsafeAtomicAdd(a.y + (int64_t)ci * NF + 32 * t + el, acc);
+        for (int k = 0; k < 32; ++k) v[k] = myT[k * TP2 + lane];
+        const bool active = pair || hi == 0;
+        float* ybase = a.y + 32 * t0 + lane;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          acc += v[k];
+          if ((flushmask >> k) & 1u) {   // wave-uniform
+            const int ci = __builtin_amdgcn_readlane(ieff, k);
+            if (ci >= 0 && active) unsafeAtomicAdd(ybase + (int64_t)ci * NF, acc);
             acc = 0.f;
           }
         }
@@ -316,7 +375,212 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_mfma(CfArgs a) {
         a.gr[3 * e] += s * rx; a.gr[3 * e + 1] += s * ry; a.gr[3 * e + 2] += s * rz;
       }
     }
-    spk_wave_lds_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pair kernel: on a symmetric neighbour list the filter of an edge and of its reverse are identical
+// (they depend on d only), so one tile holds 32 UNDIRECTED pairs (the canonical edge e < rev[e] of
+// each) and the filter MLP -- the MFMA work -- is evaluated once per pair, i.e. half as often:
+//   forward :  y[i] += h[j] * W_e            and   y[j] += h[i] * W_e
+//   backward:  gh[i] += gy[j] * W_e          and   gh[j] += gy[i] * W_e
+//              gr[e]  += (sum gy[i] h[j] W'_e) r_e / d   and   gr[rev e] -= (sum gy[j] h[i] W'_e) r_e / d
+// The transposition buffer carries the contribution to the centre atom in columns 0..31 (idx_i is
+// sorted inside the half list => segmented flush) and the contribution to the neighbour in columns
+// 32..63 (flushed per edge); both as coalesced 128-byte float atomics.
+// ------------------------------------------------------------------------------------------
+template <int NF, int KPB, int NWAVES, bool BWD>
+__global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
+  constexpr int NT = NF / 32;
+  constexpr int KB2 = NF / 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW2 = smem;
+  float* sW1 = sW2 + NF * NF;
+  float* sb1 = sW1 + NF * KPB * 8;
+  float* sb2 = sb1 + NF;
+  float* sT = sb2 + NF;
+  int* sCnt = (int*)(sT + NWAVES * 32 * TP2);
+
+  stage_packed<NWAVES * 64, NF * NF / 4>(sW2, a.w2, NF, KB2);
+  stage_packed<NWAVES * 64, NF * KPB * 2>(sW1, a.w1, a.rb.n_rbf, KPB);
+  for (int s = threadIdx.x; s < NF; s += NWAVES * 64) { sb1[s] = a.b1[s]; sb2[s] = a.b2[s]; }
+  if (threadIdx.x == 0) sCnt[0] = 0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  float* myT = sT + wv * (32 * TP2);
+  const int64_t ntiles = (a.n_half + 31) / 32;
+
+  while (true) {
+    int nidx = 0;
+    if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
+    nidx = __builtin_amdgcn_readfirstlane(nidx);
+    const int64_t tile = (int64_t)blockIdx.x + (int64_t)nidx * gridDim.x;
+    if (tile >= ntiles) break;
+
+    const int64_t hidx = tile * 32 + el;
+    const bool valid = hidx < a.n_half;
+    const int64_t e = a.half[valid ? hidx : (a.n_half - 1)];
+    const int64_t e2 = a.rev[e];
+    const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+    const int64_t j = a.idx_j[e];
+    const int64_t i = a.idx_i[e];
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    float fc, dfc;
+    spk_cutoff_eval(a.rb.cutoff, d, fc, dfc);
+    if (!valid) { fc = 0.f; dfc = 0.f; }
+    const int ieff = valid ? (int)i : -1;
+    const int jeff = valid ? (int)j : -1;
+    const int inext = __shfl(ieff, (lane + 1) & 63, 64);
+    const unsigned long long bal = __ballot(ieff != inext);
+    const unsigned flushmask = __builtin_amdgcn_readfirstlane((unsigned)(bal & 0xffffffffull)) | 0x80000000u;
+
+    float phi[KPB][4], dphi[BWD ? KPB : 1][4];
+#pragma unroll
+    for (int u = 0; u < KPB; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float p, dp;
+        spk_rbf_eval(a.rb, 8 * u + 4 * hi + v, d, p, dp);
+        phi[u][v] = p;
+        if (BWD) dphi[BWD ? u : 0][v] = dp;
+      }
+
+    f32x16 z[NT];
+    f32x16 zp[BWD ? NT : 1];
+    {
+      f32x4 wq = *(const f32x4*)(sW1 + lane * 4);
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[c][r] = sb1[32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi];
+        if (BWD) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zp[BWD ? c : 0][r] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < KPB; ++u) {
+          const int nxt = c * KPB + u + 1;
+          f32x4 wn = wq;
+          if (nxt < NT * KPB) wn = *(const f32x4*)(sW1 + (nxt * 64 + lane) * 4);
+          z[c] = SPK_MFMA(wq.x, phi[u][0], z[c]);
+          z[c] = SPK_MFMA(wq.y, phi[u][1], z[c]);
+          z[c] = SPK_MFMA(wq.z, phi[u][2], z[c]);
+          z[c] = SPK_MFMA(wq.w, phi[u][3], z[c]);
+          if (BWD) {
+            f32x16& q = zp[BWD ? c : 0];
+            q = SPK_MFMA(wq.x, dphi[BWD ? u : 0][0], q);
+            q = SPK_MFMA(wq.y, dphi[BWD ? u : 0][1], q);
+            q = SPK_MFMA(wq.z, dphi[BWD ? u : 0][2], q);
+            q = SPK_MFMA(wq.w, dphi[BWD ? u : 0][3], q);
+          }
+          wq = wn;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float sp, sg;
+          spk_fast_softplus_sigmoid(z[c][r], sp, sg);
+          z[c][r] = sp - SPK_LN2_F;
+          if (BWD) zp[BWD ? c : 0][r] *= sg;
+        }
+    }
+
+    float dsum1 = 0.f, dsum2 = 0.f;
+
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      // gathered rows of both end points, requested before the MFMAs of this tile
+      f32x4 hjq[4], hiq[4], gyiq[BWD ? 4 : 1], gyjq[BWD ? 4 : 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * t + 8 * q + 4 * hi;
+        hjq[q] = *(const f32x4*)(a.h + j * NF + col);
+        hiq[q] = *(const f32x4*)(a.h + i * NF + col);
+        if (BWD) {
+          gyiq[BWD ? q : 0] = *(const f32x4*)(a.gy + i * NF + col);
+          gyjq[BWD ? q : 0] = *(const f32x4*)(a.gy + j * NF + col);
+        }
+      }
+      f32x16 g, gp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { g[r] = sb2[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi]; gp[r] = 0.f; }
+      {
+        const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
+        f32x4 wq = *(const f32x4*)wbase;
+#pragma unroll
+        for (int ug = 0; ug < KB2; ++ug) {
+          const int c = ug >> 2, q = ug & 3;
+          f32x4 wn = wq;
+          if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
+          g = SPK_MFMA(wq.x, z[c][4 * q + 0], g);
+          g = SPK_MFMA(wq.y, z[c][4 * q + 1], g);
+          g = SPK_MFMA(wq.z, z[c][4 * q + 2], g);
+          g = SPK_MFMA(wq.w, z[c][4 * q + 3], g);
+          if (BWD) {
+            const f32x16& zq = zp[BWD ? c : 0];
+            gp = SPK_MFMA(wq.x, zq[4 * q + 0], gp);
+            gp = SPK_MFMA(wq.y, zq[4 * q + 1], gp);
+            gp = SPK_MFMA(wq.z, zq[4 * q + 2], gp);
+            gp = SPK_MFMA(wq.w, zq[4 * q + 3], gp);
+          }
+          wq = wn;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 pA, pB;
+        const f32x4 hj = hjq[q], hc = hiq[q];
+        const float W0 = g[4 * q + 0] * fc, W1v = g[4 * q + 1] * fc, W2v = g[4 * q + 2] * fc, W3 = g[4 * q + 3] * fc;
+        if (!BWD) {
+          pA.x = W0 * hj.x; pA.y = W1v * hj.y; pA.z = W2v * hj.z; pA.w = W3 * hj.w;
+          pB.x = W0 * hc.x; pB.y = W1v * hc.y; pB.z = W2v * hc.z; pB.w = W3 * hc.w;
+        } else {
+          const f32x4 gyi = gyiq[BWD ? q : 0], gyj = gyjq[BWD ? q : 0];
+          const float D0 = gp[4 * q + 0] * fc + g[4 * q + 0] * dfc, D1 = gp[4 * q + 1] * fc + g[4 * q + 1] * dfc;
+          const float D2 = gp[4 * q + 2] * fc + g[4 * q + 2] * dfc, D3 = gp[4 * q + 3] * fc + g[4 * q + 3] * dfc;
+          dsum1 += gyi.x * hj.x * D0 + gyi.y * hj.y * D1 + gyi.z * hj.z * D2 + gyi.w * hj.w * D3;
+          dsum2 += gyj.x * hc.x * D0 + gyj.y * hc.y * D1 + gyj.z * hc.z * D2 + gyj.w * hc.w * D3;
+          pA.x = W0 * gyj.x; pA.y = W1v * gyj.y; pA.z = W2v * gyj.z; pA.w = W3 * gyj.w;
+          pB.x = W0 * gyi.x; pB.y = W1v * gyi.y; pB.z = W2v * gyi.z; pB.w = W3 * gyi.w;
+        }
+        *(f32x4*)(myT + el * TP2 + 8 * q + 4 * hi) = pA;
+        *(f32x4*)(myT + el * TP2 + 32 + 8 * q + 4 * hi) = pB;
+      }
+      spk_wave_lds_sync();
+      {
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = myT[k * TP2 + lane];
+        float* ybase = a.y + 32 * t + el;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          acc += v[k];
+          const int ik = __builtin_amdgcn_readlane(ieff, k);
+          const int jk = __builtin_amdgcn_readlane(jeff, k);
+          const bool fl = hi ? true : (((flushmask >> k) & 1u) != 0);
+          const int row = hi ? jk : ik;
+          if (fl) {
+            if (row >= 0) unsafeAtomicAdd(ybase + (int64_t)row * NF, acc);
+            acc = 0.f;
+          }
+        }
+      }
+      spk_wave_lds_sync();
+    }
+    if (BWD) {
+      dsum1 += __shfl_xor(dsum1, 32, 64);
+      dsum2 += __shfl_xor(dsum2, 32, 64);
+      if (hi == 0 && valid && d > 0.f) {
+        const float s1 = dsum1 / d, s2 = dsum2 / d;
+        a.gr[3 * e] += s1 * rx; a.gr[3 * e + 1] += s1 * ry; a.gr[3 * e + 2] += s1 * rz;
+        a.gr[3 * e2] -= s2 * rx; a.gr[3 * e2 + 1] -= s2 * ry; a.gr[3 * e2 + 2] -= s2 * rz;
+      }
+    }
   }
 }
 
@@ -332,17 +596,44 @@ static int check_graph(const spk_graph_t* g, const char* who) {
 
 template <int NF, int KPB, bool BWD, bool SYM>
 static int launch_mfma(const CfArgs& a, hipStream_t stream) {
-  constexpr int NWAVES = 8;
-  const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + NWAVES * 32 * TPAD) * sizeof(float) +
-                     (size_t)NWAVES * 36 * sizeof(int);
+  // forward: 2 waves/SIMD (195 VGPRs); backward keeps value + derivative tiles of the hidden layer
+  // (128 VGPRs) plus prefetched gathers live => 1 wave/SIMD with the full 512-VGPR budget
+  constexpr int NWAVES = BWD ? 4 : 8;
+  const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + NWAVES * 32 * TP2) * sizeof(float) + 4 * sizeof(int);
   auto kern = k_cfconv_mfma<NF, KPB, NWAVES, BWD, SYM>;
-  SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static bool attr_set = false;  // once per instantiation (not a stream operation; keep it out of graph capture)
+  if (!attr_set) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   const int64_t ntiles = (a.E + 31) / 32;
+  // one persistent workgroup per CU; small problems use fewer, fuller workgroups
   int grid = (int)((ntiles + NWAVES - 1) / NWAVES);
   const int maxg = spk_num_cus();
   if (grid > maxg) grid = maxg;
   if (grid < 1) grid = 1;
   SpkProfScope prof(BWD ? (SYM ? "cfconv_bwd_mfma_sym" : "cfconv_bwd_mfma_atomic") : "cfconv_fwd_mfma", stream);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+template <int NF, int KPB, bool BWD>
+static int launch_pair(const CfArgs& a, hipStream_t stream) {
+  constexpr int NWAVES = BWD ? 4 : 8;
+  const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + NWAVES * 32 * TP2) * sizeof(float) + 4 * sizeof(int);
+  auto kern = k_cfconv_pair<NF, KPB, NWAVES, BWD>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t ntiles = (a.n_half + 31) / 32;
+  int grid = (int)((ntiles + NWAVES - 1) / NWAVES);
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  if (grid < 1) grid = 1;
+  SpkProfScope prof(BWD ? "cfconv_bwd_pair" : "cfconv_fwd_pair", stream);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
@@ -365,12 +656,14 @@ template <bool BWD>
 static int cfconv_dispatch(const CfArgs& a, int NF, bool sym, hipStream_t stream, const char* who) {
   const int variant = spk_get_variant();
   const int kpb = (a.rb.n_rbf + 7) / 8;
-  const bool al = (((uintptr_t)a.h | (uintptr_t)a.gy | (uintptr_t)a.y) % 16) == 0;
+  const bool al = (((uintptr_t)a.h | (uintptr_t)a.gy | (uintptr_t)a.y | (uintptr_t)a.w1 | (uintptr_t)a.w2) % 16) == 0;
   const bool mfma_ok = (NF == 128 || NF == 64) && kpb >= 1 && kpb <= 4 && al;
   SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || mfma_ok, "%s: shape nf=%d n_rbf=%d not supported by the MFMA kernel", who, NF, a.rb.n_rbf);
   if (!mfma_ok || variant == SPK_VARIANT_SIMPLE) return launch_simple<BWD>(a, NF, sym ? 1 : 0, stream);
+  const bool pair = sym && a.half && a.rev && a.n_half > 0 && variant != SPK_VARIANT_MFMA_DIRECTED;
 #define SPK_CF_CASE(NFv, KPBv)                                                      \
   if (NF == NFv && kpb == KPBv) {                                                   \
+    if (pair) return launch_pair<NFv, KPBv, BWD>(a, stream);                        \
     if (!BWD) return launch_mfma<NFv, KPBv, false, false>(a, stream);               \
     return sym ? launch_mfma<NFv, KPBv, BWD, true>(a, stream)                       \
                : launch_mfma<NFv, KPBv, BWD, false>(a, stream);                     \
@@ -399,7 +692,8 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   a.h = h; a.gy = nullptr; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
   a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr;
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
-  return cfconv_dispatch<false>(a, nf, false, stream, who);
+  a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
+  return cfconv_dispatch<false>(a, nf, g->symmetric && g->sorted, stream, who);
 }
 
 int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
@@ -420,6 +714,7 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   a.h = h; a.gy = gy; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
   a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr;
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
+  a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
   // the row-local transposed reduction needs idx_i sorted AND a symmetric list
   const bool sym = g->symmetric && g->sorted;
   return cfconv_dispatch<true>(a, nf, sym, stream, who);

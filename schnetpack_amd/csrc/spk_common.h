@@ -75,6 +75,21 @@ __device__ __forceinline__ float spk_sigmoid(float x) {
   float inv = __frcp_rn(1.0f + t);
   return (x >= 0.0f) ? inv : t * inv;
 }
+// Hardware-transcendental variant for the MFMA kernels (64 activations per lane and tile):
+// v_exp_f32 / v_log_f32 / v_rcp_f32 directly (1 ulp each, no denormal fix-ups: the arguments are
+// exp2 of a non-positive number and log2 of a value in [1, 2]).
+__device__ __forceinline__ void spk_fast_softplus_sigmoid(float x, float& sp, float& sg) {
+  const float t = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));
+  const float one_t = 1.0f + t;
+  const float inv = __builtin_amdgcn_rcpf(one_t);
+  sp = fmaf(0.69314718055994531f, __builtin_amdgcn_logf(one_t), fmaxf(x, 0.0f));
+  sg = (x >= 0.0f) ? inv : t * inv;
+}
+__device__ __forceinline__ float spk_fast_ssp(float x) {
+  const float t = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));
+  return fmaf(0.69314718055994531f, __builtin_amdgcn_logf(1.0f + t), fmaxf(x, 0.0f)) - SPK_LN2_F;
+}
+
 template <int ACT>
 __device__ __forceinline__ float spk_act(float x) {
   if (ACT == SPK_ACT_SSP) return spk_ssp(x);

@@ -14,6 +14,54 @@
 //   without leaving registers) -- used by the fused cfconv kernels.
 #include "spk_common.h"
 
+// One chunk = 8 k-blocks (64 contraction indices): 8 A + 8 B 16-byte operands per lane.  All loads
+// of a chunk are issued before its 32 MFMAs, and the next chunk is requested before the current one
+// is consumed (two register sets), so a wave pays the memory latency once instead of per k-block.
+#define DCH 8
+template <bool TRANS, int PRO>
+__device__ __forceinline__ void dense_load_chunk(f32x4 (&av)[DCH], f32x4 (&bv)[DCH], int c, int nug,
+                                                 const float* __restrict__ inrow,
+                                                 const float* __restrict__ prow,
+                                                 const float* __restrict__ w, int KC, int NW, int t,
+                                                 int el, int hi) {
+#pragma unroll
+  for (int u = 0; u < DCH; ++u) {
+    const int ug = c * DCH + u;
+    if (ug < nug) {
+      const int kk0 = 8 * ug + 4 * hi;
+      f32x4 b = *(const f32x4*)(inrow + kk0);
+      if (PRO != SPK_ACT_NONE) {
+        const f32x4 pv = *(const f32x4*)(prow + kk0);
+        b.x *= spk_act_grad<PRO>(pv.x); b.y *= spk_act_grad<PRO>(pv.y);
+        b.z *= spk_act_grad<PRO>(pv.z); b.w *= spk_act_grad<PRO>(pv.w);
+      }
+      bv[u] = b;
+      if (!TRANS) {
+        av[u] = *(const f32x4*)(w + (int64_t)(32 * t + el) * KC + kk0);
+      } else {
+        const float* wp = w + (int64_t)kk0 * NW + 32 * t + el;
+        f32x4 a4;
+        a4.x = wp[0]; a4.y = wp[NW]; a4.z = wp[2 * (int64_t)NW]; a4.w = wp[3 * (int64_t)NW];
+        av[u] = a4;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ f32x16 dense_mfma_chunk(const f32x4 (&av)[DCH], const f32x4 (&bv)[DCH], int c,
+                                                   int nug, f32x16 acc) {
+#pragma unroll
+  for (int u = 0; u < DCH; ++u) {
+    if (c * DCH + u < nug) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
 template <int ACT, bool TRANS, int PRO>
 __global__ __launch_bounds__(256) void k_dense_mfma(
     const float* __restrict__ in, const float* __restrict__ pre_in, const float* __restrict__ w,
@@ -22,37 +70,26 @@ __global__ __launch_bounds__(256) void k_dense_mfma(
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int hi = lane >> 5, el = lane & 31;
   const int tcount = NW / 32;
+  const int nug = KC / 8;
+  const int nch = (nug + DCH - 1) / DCH;
   for (int64_t task = blockIdx.x * 4 + wv; task < ntasks; task += (int64_t)gridDim.x * 4) {
     const int64_t mt = task / tcount;
     const int t = (int)(task % tcount);
     const int64_t m = mt * 32 + el;
     const bool valid = m < M;
     const int64_t mc = valid ? m : (M - 1);
+    const float* inrow = in + mc * KC;
+    const float* prow = PRO != SPK_ACT_NONE ? pre_in + mc * KC : nullptr;
+    f32x4 a0[DCH], b0[DCH], a1[DCH], b1[DCH];
+    dense_load_chunk<TRANS, PRO>(a0, b0, 0, nug, inrow, prow, w, KC, NW, t, el, hi);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = b ? b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
-    const float* inrow = in + mc * KC;
-    const float* prow = PRO != SPK_ACT_NONE ? pre_in + mc * KC : nullptr;
-    const int nug = KC / 8;
-    for (int ug = 0; ug < nug; ++ug) {
-      const int kk0 = 8 * ug + 4 * hi;
-      f32x4 bv = *(const f32x4*)(inrow + kk0);
-      if (PRO != SPK_ACT_NONE) {
-        f32x4 pv = *(const f32x4*)(prow + kk0);
-        bv.x *= spk_act_grad<PRO>(pv.x); bv.y *= spk_act_grad<PRO>(pv.y);
-        bv.z *= spk_act_grad<PRO>(pv.z); bv.w *= spk_act_grad<PRO>(pv.w);
-      }
-      f32x4 av;
-      if (!TRANS) {
-        av = *(const f32x4*)(w + (int64_t)(32 * t + el) * KC + kk0);
-      } else {
-        const float* wp = w + (int64_t)kk0 * NW + 32 * t + el;
-        av.x = wp[0]; av.y = wp[NW]; av.z = wp[2 * (int64_t)NW]; av.w = wp[3 * (int64_t)NW];
-      }
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    for (int c = 0; c < nch; c += 2) {
+      if (c + 1 < nch) dense_load_chunk<TRANS, PRO>(a1, b1, c + 1, nug, inrow, prow, w, KC, NW, t, el, hi);
+      acc = dense_mfma_chunk(a0, b0, c, nug, acc);
+      if (c + 2 < nch) dense_load_chunk<TRANS, PRO>(a0, b0, c + 2, nug, inrow, prow, w, KC, NW, t, el, hi);
+      if (c + 1 < nch) acc = dense_mfma_chunk(a1, b1, c + 1, nug, acc);
     }
     if (valid) {
 #pragma unroll

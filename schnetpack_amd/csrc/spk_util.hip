@@ -120,24 +120,25 @@ __global__ void k_rowptr(const int64_t* __restrict__ idx_i, int64_t E, int64_t N
 // every edge (i<-j, r) must have a partner (j<-i, -r) in row j
 __global__ void k_symmetry(const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j,
                            const float* __restrict__ rij, const int32_t* __restrict__ rowptr,
-                           int64_t E, int32_t* flags) {
+                           int64_t E, int32_t* flags, int32_t* __restrict__ rev) {
   int asym = 0;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
        e += (int64_t)gridDim.x * blockDim.x) {
     int64_t i = idx_i[e], j = idx_j[e];
     float rx = rij[3 * e], ry = rij[3 * e + 1], rz = rij[3 * e + 2];
-    bool found = false;
+    int32_t found = -1;
     for (int32_t q = rowptr[j]; q < rowptr[j + 1]; ++q) {
       if (idx_j[q] == i && rij[3 * (int64_t)q] == -rx && rij[3 * (int64_t)q + 1] == -ry &&
-          rij[3 * (int64_t)q + 2] == -rz) { found = true; break; }
+          rij[3 * (int64_t)q + 2] == -rz) { found = q; break; }
     }
-    if (!found) asym = 1;
+    if (rev) rev[e] = found;
+    if (found < 0 || found == e) asym = 1;
   }
   if (asym) atomicOr(&flags[2], 1);
 }
 
 extern "C" int spk_edge_plan(const int64_t* idx_i, const int64_t* idx_j, const float* r_ij,
-                             int64_t E, int64_t N, int32_t* rowptr, int32_t* scratch,
+                             int64_t E, int64_t N, int32_t* rowptr, int32_t* rev, int32_t* scratch,
                              int32_t* host_flags, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPK_CHECK_ARG(E >= 0 && N >= 0 && N < (1LL << 31) && E < (1LL << 31),
@@ -160,7 +161,7 @@ extern "C" int spk_edge_plan(const int64_t* idx_i, const int64_t* idx_j, const f
     SPK_LAUNCH_CHECK();
     if (r_ij && E > 0) {
       hipLaunchKernelGGL(k_symmetry, dim3(spk_grid_for(E, 256, 4096)), dim3(256), 0, stream, idx_i,
-                         idx_j, r_ij, rowptr, E, scratch);
+                         idx_j, r_ij, rowptr, E, scratch, rev);
       SPK_LAUNCH_CHECK();
       SPK_HIP_TRY(hipMemcpyAsync(f, scratch, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
       SPK_HIP_TRY(hipStreamSynchronize(stream));
@@ -388,6 +389,54 @@ extern "C" int spk_edge_norm_f32(const float* r_ij, int64_t E, float* d, float* 
   if (E == 0) return SPK_OK;
   SPK_CHECK_ARG(r_ij != nullptr && E > 0, "spk_edge_norm_f32: bad input");
   hipLaunchKernelGGL(k_edge_norm, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, r_ij, E, d, u);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------- pairwise vectors (distances.py)
+__global__ void k_pairwise(const float* __restrict__ R, const int64_t* __restrict__ idx_i,
+                           const int64_t* __restrict__ idx_j, const float* __restrict__ off,
+                           int64_t E, float* __restrict__ rij) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx_i[e], j = idx_j[e];
+    // same operation order as the reference: (R[j] - R[i]) + offsets  => r_ji == -r_ij bit-exactly
+    float x = R[3 * j] - R[3 * i], y = R[3 * j + 1] - R[3 * i + 1], z = R[3 * j + 2] - R[3 * i + 2];
+    if (off) { x += off[3 * e]; y += off[3 * e + 1]; z += off[3 * e + 2]; }
+    rij[3 * e] = x; rij[3 * e + 1] = y; rij[3 * e + 2] = z;
+  }
+}
+
+__global__ void k_pairwise_bwd(const float* __restrict__ gr, const int64_t* __restrict__ idx_i,
+                               const int64_t* __restrict__ idx_j, int64_t E, float* __restrict__ gR) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx_i[e], j = idx_j[e];
+    const float x = gr[3 * e], y = gr[3 * e + 1], z = gr[3 * e + 2];
+    unsafeAtomicAdd(&gR[3 * j], x); unsafeAtomicAdd(&gR[3 * j + 1], y); unsafeAtomicAdd(&gR[3 * j + 2], z);
+    unsafeAtomicAdd(&gR[3 * i], -x); unsafeAtomicAdd(&gR[3 * i + 1], -y); unsafeAtomicAdd(&gR[3 * i + 2], -z);
+  }
+}
+
+extern "C" int spk_pairwise_f32(const float* R, const int64_t* idx_i, const int64_t* idx_j,
+                                const float* offsets, int64_t E, float* r_ij, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (E == 0) return SPK_OK;
+  SPK_CHECK_ARG(R && idx_i && idx_j && r_ij && E > 0, "spk_pairwise_f32: bad input");
+  hipLaunchKernelGGL(k_pairwise, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, R, idx_i, idx_j, offsets, E, r_ij);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_pairwise_bwd_f32(const float* gr, const int64_t* idx_i, const int64_t* idx_j,
+                                    int64_t E, int64_t N, float* gR, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return SPK_OK;
+  SPK_CHECK_ARG(gR != nullptr && N > 0 && E >= 0, "spk_pairwise_bwd_f32: bad input");
+  SPK_HIP_TRY(hipMemsetAsync(gR, 0, (size_t)N * 3 * sizeof(float), stream));
+  if (E == 0) return SPK_OK;
+  SPK_CHECK_ARG(gr && idx_i && idx_j, "spk_pairwise_bwd_f32: null pointer");
+  hipLaunchKernelGGL(k_pairwise_bwd, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, gr, idx_i, idx_j, E, gR);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

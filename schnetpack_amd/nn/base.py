@@ -46,5 +46,7 @@ class Dense(nn.Linear):
         act = activation_id(self.activation)
         if act is None:
             # unknown activation callable: linear part on the HIP kernel, activation by the caller's function
-            return self.activation(ops.dense(input, self.weight, self.bias, _lib.SPK_ACT_NONE))
-        return ops.dense(input, self.weight, self.bias, act)
+            return self.activation(ops.dense(input, self.weight, self.bias, _lib.SPK_ACT_NONE, self.training))
+        # eval mode: geometry gradients only, forward + input-gradient on the HIP kernels;
+        # training mode: differentiable to second order
+        return ops.dense(input, self.weight, self.bias, act, self.training)

@@ -33,6 +33,8 @@ class EdgePlan:
         self.n_edges = int(self.idx_i.shape[0])
         dev = self.idx_i.device
         self.rowptr = torch.empty(self.n_atoms + 1, dtype=torch.int32, device=dev)
+        self.rev = torch.full((max(self.n_edges, 1),), -1, dtype=torch.int32, device=dev)
+        self.half = None
         scratch = torch.zeros(4, dtype=torch.int32, device=dev)
         flags = (ctypes.c_int32 * 4)()
         r = None
@@ -41,12 +43,23 @@ class EdgePlan:
         with torch.cuda.device(dev):
             check(lib().spk_edge_plan(iptr(self.idx_i), iptr(self.idx_j), fptr(r), self.n_edges,
                                       self.n_atoms, iptr(self.rowptr, torch.int32),
-                                      iptr(scratch, torch.int32), flags, stream()))
+                                      iptr(self.rev, torch.int32), iptr(scratch, torch.int32), flags, stream()))
         self.sorted = bool(flags[0])
         self.symmetric = bool(flags[2])
+        n_half = 0
+        if self.symmetric and self.n_edges > 0:
+            # canonical edge of every undirected pair (e < rev[e]); one-off compaction per list
+            ar = torch.arange(self.n_edges, dtype=torch.int32, device=dev)
+            self.half = torch.nonzero(self.rev[: self.n_edges] > ar).flatten().to(torch.int32).contiguous()
+            n_half = int(self.half.shape[0])
+            if 2 * n_half != self.n_edges:
+                self.symmetric = False
+                self.half, n_half = None, 0
         self._graph = _lib.GraphT(self.n_atoms, self.n_edges, iptr(self.idx_i), iptr(self.idx_j),
                                   iptr(self.rowptr, torch.int32) if self.sorted else None,
-                                  int(self.sorted), int(self.symmetric))
+                                  int(self.sorted), int(self.symmetric),
+                                  iptr(self.rev, torch.int32) if self.symmetric else None,
+                                  iptr(self.half, torch.int32) if self.half is not None else None, n_half)
 
     def graph(self):
         return ctypes.byref(self._graph)
@@ -168,6 +181,54 @@ def gather(x, idx, dim=0, rowptr=None):
     return GatherFn.apply(x, idx.long().contiguous(), int(dim), rowptr)
 
 
+# ----------------------------------------------------------------------------- pairwise vectors
+class PairwiseFn(torch.autograd.Function):
+    """r_ij = R[idx_j] - R[idx_i] (+ offsets)  (atomistic/distances.py:14-26).  Backward scatters
+    dL/dr_ij onto the atoms in one kernel; linear, so it is differentiable to any order through its
+    transpose ``PairwiseBwdFn``."""
+
+    @staticmethod
+    def forward(ctx, R, idx_i, idx_j, offsets):
+        Rc = R.contiguous()
+        E = int(idx_i.shape[0])
+        r = torch.empty((E, 3), dtype=torch.float32, device=R.device)
+        oc = offsets.contiguous() if offsets is not None else None
+        with torch.cuda.device(R.device):
+            check(lib().spk_pairwise_f32(fptr(Rc), iptr(idx_i), iptr(idx_j), fptr(oc), E, fptr(r), stream()))
+        ctx.save_for_backward(idx_i, idx_j)
+        ctx.n = int(R.shape[0])
+        ctx.has_off = offsets is not None
+        return r
+
+    @staticmethod
+    def backward(ctx, gr):
+        idx_i, idx_j = ctx.saved_tensors
+        gR = PairwiseBwdFn.apply(gr, idx_i, idx_j, ctx.n) if ctx.needs_input_grad[0] else None
+        goff = gr if (ctx.has_off and ctx.needs_input_grad[3]) else None
+        return gR, None, None, goff
+
+
+class PairwiseBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gr, idx_i, idx_j, n_atoms):
+        grc = gr.contiguous()
+        gR = torch.empty((n_atoms, 3), dtype=torch.float32, device=gr.device)
+        with torch.cuda.device(gr.device):
+            check(lib().spk_pairwise_bwd_f32(fptr(grc), iptr(idx_i), iptr(idx_j), int(idx_i.shape[0]), int(n_atoms), fptr(gR), stream()))
+        ctx.save_for_backward(idx_i, idx_j)
+        return gR
+
+    @staticmethod
+    def backward(ctx, ggR):
+        idx_i, idx_j = ctx.saved_tensors
+        return PairwiseFn.apply(ggR, idx_i, idx_j, None), None, None, None
+
+
+def pairwise_vectors(R, idx_i, idx_j, offsets=None):
+    _check_float(R, "pairwise_vectors")
+    return PairwiseFn.apply(R, idx_i.long().contiguous(), idx_j.long().contiguous(), offsets)
+
+
 # ----------------------------------------------------------------------------- radial / cutoff
 def radial_struct(kind, n_rbf, p0, p1, cutoff):
     return _lib.RadialT(int(kind), int(n_rbf), fptr(p0), fptr(p1) if p1 is not None else None, float(cutoff))
@@ -272,9 +333,37 @@ class DenseFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
-def dense(x, w, b=None, act=None):
+class DenseEvalFn(torch.autograd.Function):
+    """Eval-mode Dense: forward and the first-order input gradient both on the HIP kernels; the
+    weights are not differentiated (``Dense`` passes them detached when ``training`` is False)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        y, pre = dense_raw(x, w, b, act, want_pre=(act != _lib.SPK_ACT_NONE))
+        ctx.act = act
+        ctx.save_for_backward(w, pre if pre is not None else y)
+        ctx.k = int(x.shape[-1])
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        w, pre = ctx.saved_tensors
+        n_out = int(w.shape[0])
+        g2 = gy.contiguous().view(-1, n_out)
+        m = int(g2.shape[0])
+        dx = torch.empty((m, ctx.k), dtype=torch.float32, device=gy.device)
+        with torch.cuda.device(gy.device):
+            check(lib().spk_dense_bwd_input_f32(fptr(g2), fptr(pre.view(-1, n_out)) if ctx.act != _lib.SPK_ACT_NONE else None,
+                                                fptr(w.contiguous()), None, fptr(dx), m, ctx.k, n_out, int(ctx.act), stream()))
+        return dx.view(tuple(gy.shape[:-1]) + (ctx.k,)), None, None, None
+
+
+def dense(x, w, b=None, act=None, training=True):
     _check_float(x, "dense")
     a = _ACT_IDS[act] if not isinstance(act, int) else act
+    if not training:
+        return DenseEvalFn.apply(x, w.detach(), b.detach() if b is not None else None, a)
     return DenseFn.apply(x, w, b, a)
 
 

@@ -23,10 +23,13 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["mfma", "simple"])
+@pytest.fixture(params=["mfma", "simple", "directed"])
 def variant(request):
+    """mfma = default dispatch (pair kernel on symmetric lists), directed = MFMA kernel with one
+    filter per directed edge, simple = straightforward cross-check kernels."""
     from schnetpack_amd import _lib
-    _lib.set_variant(_lib.VARIANT_SIMPLE if request.param == "simple" else _lib.VARIANT_AUTO)
+    _lib.set_variant({"simple": _lib.VARIANT_SIMPLE, "directed": _lib.VARIANT_MFMA_DIRECTED,
+                      "mfma": _lib.VARIANT_AUTO}[request.param])
     yield request.param
     _lib.set_variant(_lib.VARIANT_AUTO)
 
@@ -157,7 +160,8 @@ def test_state_dict_round_trip_and_repeat_calls(dev):
     inp = M.batch_to_inputs(b, dev)
     o1 = model(dict(inp))
     o2 = model(dict(inp))
-    assert torch.equal(o1["energy"], o2["energy"])
-    assert rel_err(o1["forces"].cpu(), o2["forces"].cpu()) < 1e-6
+    # float atomics in the edge kernels: summation order (not the result to 1e-6) may differ
+    assert rel_err(o1["energy"].detach().cpu(), o2["energy"].detach().cpu()) < 1e-6
+    assert rel_err(o1["forces"].cpu(), o2["forces"].cpu()) < 2e-6
     sd = model.representation.state_dict()
     assert set(sd) == set(rep_p)

@@ -24,10 +24,13 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["mfma", "simple"])
+@pytest.fixture(params=["mfma", "simple", "directed"])
 def variant(request):
+    """mfma = default dispatch (pair kernel on symmetric lists), directed = MFMA kernel with one
+    filter per directed edge, simple = straightforward cross-check kernels."""
     from schnetpack_amd import _lib
-    _lib.set_variant(_lib.VARIANT_SIMPLE if request.param == "simple" else _lib.VARIANT_AUTO)
+    _lib.set_variant({"simple": _lib.VARIANT_SIMPLE, "directed": _lib.VARIANT_MFMA_DIRECTED,
+                      "mfma": _lib.VARIANT_AUTO}[request.param])
     yield request.param
     _lib.set_variant(_lib.VARIANT_AUTO)
 
@@ -60,6 +63,14 @@ def test_edge_plan_flags_and_rowptr(dev):
     counts = torch.bincount(b["idx_i"], minlength=N)
     expect = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]).int()
     assert torch.equal(plan.rowptr.cpu(), expect)
+    # reverse-edge map is an involution that swaps (i, j) and negates r; half list = canonical edges
+    rev = plan.rev[: plan.n_edges].long().cpu()
+    assert torch.equal(rev[rev], torch.arange(plan.n_edges))
+    assert torch.equal(b["idx_i"][rev], b["idx_j"]) and torch.equal(b["idx_j"][rev], b["idx_i"])
+    assert torch.equal(r[rev], -r)
+    half = plan.half.long().cpu()
+    assert half.shape[0] * 2 == plan.n_edges and bool((rev[half] > half).all())
+    assert bool((half[1:] > half[:-1]).all())
     # drop one edge -> asymmetric; shuffle -> unsorted
     plan2 = ops.EdgePlan(b["idx_i"][1:].to(dev), b["idx_j"][1:].to(dev), N, r[1:].to(dev))
     assert plan2.sorted and not plan2.symmetric
@@ -211,18 +222,20 @@ def test_dense_forward_backward(dev, variant, m, k, n, act):
     yo = O.dense(xo, w.double(), b.double(), actf)
     (gxo,) = torch.autograd.grad((yo * gy.double()).sum(), [xo])
     xd = x.to(dev).requires_grad_(True)
-    y = ops.dense(xd, w.to(dev), b.to(dev), act)
+    wd, bd, gyd = w.to(dev), b.to(dev), gy.to(dev)  # keep the device buffers alive across raw calls
+    y = ops.dense(xd, wd, bd, act)
     assert rel_err(y.detach().cpu(), yo.detach()) < TOL
     # first-order input gradient through the HIP backward kernel
     from schnetpack_amd import _lib
     a = ops._ACT_IDS[act]
-    _, pre = ops.dense_raw(x.to(dev), w.to(dev), b.to(dev), a, want_pre=True)
+    _, pre = ops.dense_raw(xd.detach(), wd, bd, a, want_pre=True)
     dx = torch.empty(m, k, device=dev)
-    _lib.check(_lib.lib().spk_dense_bwd_input_f32(_lib.fptr(gy.to(dev)), _lib.fptr(pre), _lib.fptr(w.to(dev)), None,
+    _lib.check(_lib.lib().spk_dense_bwd_input_f32(_lib.fptr(gyd), _lib.fptr(pre), _lib.fptr(wd), None,
                                                    _lib.fptr(dx), m, k, n, a, _lib.stream()))
+    torch.cuda.synchronize()
     assert rel_err(dx.cpu(), gxo) < TOL
     # autograd (differentiable composite backward)
-    (gx,) = torch.autograd.grad((y * gy.to(dev)).sum(), [xd])
+    (gx,) = torch.autograd.grad((y * gyd).sum(), [xd])
     assert rel_err(gx.cpu(), gxo) < TOL
 
 
@@ -233,7 +246,9 @@ def test_dense_residual_and_preactivation(dev, variant):
     w = torch.randn(128, 128, generator=g) / 11.0
     b = torch.randn(128, generator=g)
     r = torch.randn(70, 128, generator=g)
-    y, pre = ops.dense_raw(x.to(dev), w.to(dev), b.to(dev), _lib.SPK_ACT_SSP, res=r.to(dev), want_pre=True)
+    xd, wd, bd, rd = x.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    y, pre = ops.dense_raw(xd, wd, bd, _lib.SPK_ACT_SSP, res=rd, want_pre=True)
+    torch.cuda.synchronize()
     pre_o = O.dense(x.double(), w.double(), b.double())
     assert rel_err(pre.cpu(), pre_o) < TOL
     assert rel_err(y.cpu(), O.shifted_softplus(pre_o) + r.double()) < TOL
@@ -263,8 +278,8 @@ def _cfconv_hip(dev, h, r, idx_i, idx_j, p, n_atoms, kind, gy):
     plan = ops.EdgePlan(idx_i.to(dev), idx_j.to(dev), n_atoms, r.to(dev))
     if kind == "gaussian":
         off, w = O.gaussian_rbf_params(p["n_rbf"], 5.0)
-        rb = ops.radial_struct(_lib.SPK_RBF_GAUSSIAN, p["n_rbf"], off.to(dev), w.to(dev), 5.0)
-        keep = (off, w)
+        keep = (off.to(dev), w.to(dev))  # device buffers must outlive the raw C calls
+        rb = ops.radial_struct(_lib.SPK_RBF_GAUSSIAN, p["n_rbf"], keep[0], keep[1], 5.0)
     else:
         fr = O.bessel_rbf_params(p["n_rbf"], 5.0).float().to(dev)
         rb = ops.radial_struct(_lib.SPK_RBF_BESSEL, p["n_rbf"], fr, None, 5.0)
@@ -341,10 +356,13 @@ def test_cfconv_mfma_equals_simple_at_bench_scale(dev):
     y1, gh1, gr1, plan = _cfconv_hip(dev, h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
     assert plan.symmetric
     y1b, _, _, _ = _cfconv_hip(dev, 3.0 * h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
+    _lib.set_variant(_lib.VARIANT_MFMA_DIRECTED)
+    y3, gh3, gr3, _ = _cfconv_hip(dev, h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
     _lib.set_variant(_lib.VARIANT_SIMPLE)
     y2, gh2, gr2, _ = _cfconv_hip(dev, h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
     _lib.set_variant(_lib.VARIANT_AUTO)
     assert rel_err(y1, y2) < TOL and rel_err(gh1, gh2) < TOL and rel_err(gr1, gr2) < TOL
+    assert rel_err(y3, y2) < TOL and rel_err(gh3, gh2) < TOL and rel_err(gr3, gr2) < TOL
     assert rel_err(y1b, 3.0 * y1) < 2e-6
     # reversed edges carry opposite geometry gradients on a symmetric list: sum_e gr_e r_e parity
     assert torch.isfinite(gr1).all()
@@ -449,3 +467,33 @@ def test_painn_mixing_elementwise(dev):
     assert rel_err(ga.cpu(), ga_o) < TOL
     assert rel_err(gmix.cpu(), gmix_o) < TOL
     assert rel_err(gq1.cpu(), gq.double() + gctx.double()[:, :F]) < TOL
+
+
+# ----------------------------------------------------------------------------- pairwise vectors
+def test_pairwise_vectors_forward_backward_and_second_order(dev):
+    """r_ij = R[j] - R[i] + offsets (atomistic/distances.py:14-26): bit-exact forward (and the
+    reversed edge is the exact negation), atomic scatter backward, closed under differentiation."""
+    from schnetpack_amd import ops
+    b = S.molecule_batch("aspirin", 3, seed=5)
+    g = torch.Generator().manual_seed(2)
+    off = torch.randn(b["idx_i"].shape[0], 3, generator=g)
+    R = b["R"].clone()
+    ref = O.pairwise_vectors(R, b["idx_i"], b["idx_j"], off)
+    Rd = R.to(dev).requires_grad_(True)
+    ii, jj = b["idx_i"].to(dev), b["idx_j"].to(dev)
+    r = ops.pairwise_vectors(Rd, ii, jj, off.to(dev))
+    assert torch.equal(r.detach().cpu(), ref)
+    r0 = ops.pairwise_vectors(Rd, ii, jj, None)
+    assert torch.equal(r0.detach().cpu(), R[b["idx_j"]] - R[b["idx_i"]])
+    w = torch.randn(r.shape, generator=g)
+
+    def run(R, ii, jj, off, w, fn):
+        R = R.clone().requires_grad_(True)
+        rr = fn(R, ii, jj, off)
+        (gR,) = torch.autograd.grad(((rr ** 2) * w).sum(), [R], create_graph=True)
+        (g2,) = torch.autograd.grad((gR ** 2).sum(), [R])
+        return gR.detach().cpu(), g2.cpu()
+
+    gh, g2h = run(R.to(dev), ii, jj, off.to(dev), w.to(dev), ops.pairwise_vectors)
+    go, g2o = run(R.double(), b["idx_i"], b["idx_j"], off.double(), w.double(), O.pairwise_vectors)
+    assert rel_err(gh, go) < TOL and rel_err(g2h, g2o) < TOL
