@@ -133,6 +133,37 @@ int spk_dense_bwd_input_f32(const float* dy, const float* pre, const float* w, c
                             float* dx, int64_t m, int32_t k, int32_t n_out, int32_t act,
                             void* stream);
 
+/* Chain of up to 3 Dense layers in ONE launch (e.g. f2out.0 -> f2out.1 (+residual) -> next in2f of
+ * representation/schnet.py:33-36,60,69,168, or the input-gradient transposes of such a chain).  The
+ * activations of a 32-row tile stay in LDS between layers.  Layer l maps [m, k_l] -> [m, n_out_l] with
+ * k_{l+1} == n_out_l.  Shapes outside (k % 8 == 0, n_out % 32 == 0, <= 384) run layer by layer on the
+ * single-layer kernels and then need the `tmp` buffers for outputs that are not stored. */
+typedef struct {
+  const float* w;        /* torch Linear weight [n_out, k]; with trans != 0 the layer is the input-gradient
+                            of Linear([n, k_w] -> ...): w is [k, n_out] and y = x w */
+  const float* b;        /* [n_out] or NULL */
+  const float* res;      /* [m, n_out] or NULL, added after the activation (may alias out) */
+  float* out;            /* [m, n_out] or NULL (result not stored, only handed to the next layer) */
+  float* pre_out;        /* [m, n_out] or NULL: pre-activation, saved for backward */
+  const float* post_pre; /* [m, n_out] or NULL: the copy handed to the NEXT layer is multiplied by
+                            post_act'(post_pre) (backward through an activation) */
+  int32_t k, n_out, act, trans, post_act;
+} spk_chain_layer_t;
+
+typedef struct {
+  int32_t n_layers;      /* 1..3 */
+  int32_t in_act;        /* with in_pre: the input is multiplied by in_act'(in_pre) */
+  int64_t m;             /* rows */
+  const float* in;       /* [m, k_0] */
+  const float* in_pre;   /* [m, k_0] or NULL */
+  float* zero_ptr;       /* optional: buffer cleared by the same launch (must not alias any operand) */
+  int64_t zero_count;    /* floats */
+  float* tmp[2];         /* [m, max n_out] scratch, only used by the layer-by-layer path */
+  spk_chain_layer_t layers[3];
+} spk_chain_t;
+
+int spk_dense_chain_f32(const spk_chain_t* chain, void* stream);
+
 /* ------------------------------------------------------------------ representation/schnet.py:60-67
  * Fused continuous-filter convolution of one interaction block:
  *   W_e = (ssp(phi(d_e) W1^T + b1) W2^T + b2) * fcut(d_e);   y[i] = sum_{e->i} h[idx_j[e]] * W_e
@@ -170,12 +201,15 @@ typedef struct {
   int32_t n_atom_basis;   /* F */
   int32_t n_filters;      /* nf */
   int32_t n_interactions;
-  int32_t reserved;
+  int32_t reserved;       /* bit 0: `saved` was sized with spk_schnet_saved_floats_graph(): the forward keeps
+                             the raw filter outputs of every (undirected) edge so that the backward runs
+                             only the derivative GEMM */
   const spk_schnet_layer_t* layers; /* HOST array of n_interactions entries (device pointers inside) */
 } spk_schnet_t;
 
 /* floats needed in `saved` (kept from forward to backward) and `scratch` (per call) */
 int64_t spk_schnet_saved_floats(const spk_schnet_t* m, int64_t n_atoms);
+int64_t spk_schnet_saved_floats_graph(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb);
 int64_t spk_schnet_scratch_floats(const spk_schnet_t* m, int64_t n_atoms);
 /* x0 [N,F] = embedding rows (+ electronic embeddings) computed by the caller;
  * x_out [N,F] = scalar_representation. */

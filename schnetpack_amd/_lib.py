@@ -47,6 +47,16 @@ class SchnetT(ctypes.Structure):
                 ("reserved", c_i32), ("layers", ctypes.POINTER(SchnetLayerT))]
 
 
+class ChainLayerT(ctypes.Structure):
+    _fields_ = [("w", c_f), ("b", c_f), ("res", c_f), ("out", c_f), ("pre_out", c_f), ("post_pre", c_f),
+                ("k", c_i32), ("n_out", c_i32), ("act", c_i32), ("trans", c_i32), ("post_act", c_i32)]
+
+
+class ChainT(ctypes.Structure):
+    _fields_ = [("n_layers", c_i32), ("in_act", c_i32), ("m", c_i64), ("inp", c_f), ("in_pre", c_f),
+                ("zero_ptr", c_f), ("zero_count", c_i64), ("tmp", c_f * 2), ("layers", ChainLayerT * 3)]
+
+
 class PainnLayerT(ctypes.Structure):
     _fields_ = [(n, c_f) for n in ("ctx_w1", "ctx_b1", "ctx_w2", "ctx_b2", "filt_w", "filt_b",
                                    "mix_w", "ictx_w1", "ictx_b1", "ictx_w2", "ictx_b2")]
@@ -77,9 +87,11 @@ _PROTOS = {
     "spk_edge_norm_f32": (ctypes.c_int, [c_f, c_i64, c_f, c_f, c_f]),
     "spk_dense_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
     "spk_dense_bwd_input_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
+    "spk_dense_chain_f32": (ctypes.c_int, [P(ChainT), c_f]),
     "spk_schnet_cfconv_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f]),
     "spk_schnet_cfconv_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
     "spk_schnet_saved_floats": (c_i64, [P(SchnetT), c_i64]),
+    "spk_schnet_saved_floats_graph": (c_i64, [P(SchnetT), P(GraphT), P(RadialT)]),
     "spk_schnet_scratch_floats": (c_i64, [P(SchnetT), c_i64]),
     "spk_schnet_forward_f32": (ctypes.c_int, [P(SchnetT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f]),
     "spk_schnet_backward_f32": (ctypes.c_int, [P(SchnetT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

@@ -35,6 +35,8 @@ struct CfArgs {
   float* gr;           // bwd: [E, 3] accumulated
   int64_t E;
   int64_t N;
+  float* gsave;         // fwd: optional [n_tiles*32, NF] raw filter-MLP outputs g_e (before the cutoff)
+  const float* gload;   // bwd: the same buffer written by the forward of this interaction (or null)
   const int32_t* half;  // pair kernel: canonical edge of every undirected pair
   const int32_t* rev;   // pair kernel: reversed edge
   int64_t n_half;
@@ -389,7 +391,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_mfma(CfArgs a) {
 // sorted inside the half list => segmented flush) and the contribution to the neighbour in columns
 // 32..63 (flushed per edge); both as coalesced 128-byte float atomics.
 // ------------------------------------------------------------------------------------------
-template <int NF, int KPB, int NWAVES, bool BWD>
+// GS (backward only): the raw filter outputs g_e were saved by the forward kernel, so only the
+// derivative GEMM (g') runs here: 96 + 256 MFMAs per tile instead of 96 + 512, and z need not stay live.
+template <int NF, int KPB, int NWAVES, bool BWD, bool GS>
 __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
   constexpr int NT = NF / 32;
   constexpr int KB2 = NF / 8;
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
 #pragma unroll 1
     for (int t = 0; t < NT; ++t) {
       // gathered rows of both end points, requested before the MFMAs of this tile
-      f32x4 hjq[4], hiq[4], gyiq[BWD ? 4 : 1], gyjq[BWD ? 4 : 1];
+      f32x4 hjq[4], hiq[4], gyiq[BWD ? 4 : 1], gyjq[BWD ? 4 : 1], gsv[GS ? 4 : 1];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = 32 * t + 8 * q + 4 * hi;
@@ -504,6 +508,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
           gyiq[BWD ? q : 0] = *(const f32x4*)(a.gy + i * NF + col);
           gyjq[BWD ? q : 0] = *(const f32x4*)(a.gy + j * NF + col);
         }
+        if (GS) gsv[GS ? q : 0] = *(const f32x4*)(a.gload + (tile * 32 + el) * NF + col);
       }
       f32x16 g, gp;
 #pragma unroll
@@ -516,10 +521,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
           const int c = ug >> 2, q = ug & 3;
           f32x4 wn = wq;
           if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
-          g = SPK_MFMA(wq.x, z[c][4 * q + 0], g);
-          g = SPK_MFMA(wq.y, z[c][4 * q + 1], g);
-          g = SPK_MFMA(wq.z, z[c][4 * q + 2], g);
-          g = SPK_MFMA(wq.w, z[c][4 * q + 3], g);
+          if (!GS) {
+            g = SPK_MFMA(wq.x, z[c][4 * q + 0], g);
+            g = SPK_MFMA(wq.y, z[c][4 * q + 1], g);
+            g = SPK_MFMA(wq.z, z[c][4 * q + 2], g);
+            g = SPK_MFMA(wq.w, z[c][4 * q + 3], g);
+          }
           if (BWD) {
             const f32x16& zq = zp[BWD ? c : 0];
             gp = SPK_MFMA(wq.x, zq[4 * q + 0], gp);
@@ -528,6 +535,20 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
             gp = SPK_MFMA(wq.w, zq[4 * q + 3], gp);
           }
           wq = wn;
+        }
+      }
+      if (GS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 gq = gsv[GS ? q : 0];
+          g[4 * q + 0] = gq.x; g[4 * q + 1] = gq.y; g[4 * q + 2] = gq.z; g[4 * q + 3] = gq.w;
+        }
+      } else if (!BWD && a.gsave) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 gq;
+          gq.x = g[4 * q + 0]; gq.y = g[4 * q + 1]; gq.z = g[4 * q + 2]; gq.w = g[4 * q + 3];
+          *(f32x4*)(a.gsave + (tile * 32 + el) * NF + 32 * t + 8 * q + 4 * hi) = gq;
         }
       }
 #pragma unroll
@@ -618,11 +639,12 @@ static int launch_mfma(const CfArgs& a, hipStream_t stream) {
   return SPK_OK;
 }
 
-template <int NF, int KPB, bool BWD>
+template <int NF, int KPB, bool BWD, bool GS>
 static int launch_pair(const CfArgs& a, hipStream_t stream) {
-  constexpr int NWAVES = BWD ? 4 : 8;
+  // forward and the saved-filter backward fit 2 waves/SIMD; the recomputing backward needs 1 wave/SIMD
+  constexpr int NWAVES = (BWD && !GS) ? 4 : 8;
   const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + NWAVES * 32 * TP2) * sizeof(float) + 4 * sizeof(int);
-  auto kern = k_cfconv_pair<NF, KPB, NWAVES, BWD>;
+  auto kern = k_cfconv_pair<NF, KPB, NWAVES, BWD, GS>;
   static bool attr_set = false;
   if (!attr_set) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -633,7 +655,7 @@ static int launch_pair(const CfArgs& a, hipStream_t stream) {
   const int maxg = spk_num_cus();
   if (grid > maxg) grid = maxg;
   if (grid < 1) grid = 1;
-  SpkProfScope prof(BWD ? "cfconv_bwd_pair" : "cfconv_fwd_pair", stream);
+  SpkProfScope prof(BWD ? (GS ? "cfconv_bwd_pair_gs" : "cfconv_bwd_pair") : "cfconv_fwd_pair", stream);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
@@ -663,7 +685,8 @@ static int cfconv_dispatch(const CfArgs& a, int NF, bool sym, hipStream_t stream
   const bool pair = sym && a.half && a.rev && a.n_half > 0 && variant != SPK_VARIANT_MFMA_DIRECTED;
 #define SPK_CF_CASE(NFv, KPBv)                                                      \
   if (NF == NFv && kpb == KPBv) {                                                   \
-    if (pair) return launch_pair<NFv, KPBv, BWD>(a, stream);                        \
+    if (pair && BWD && a.gload) return launch_pair<NFv, KPBv, BWD, BWD>(a, stream); \
+    if (pair) return launch_pair<NFv, KPBv, BWD, false>(a, stream);                 \
     if (!BWD) return launch_mfma<NFv, KPBv, false, false>(a, stream);               \
     return sym ? launch_mfma<NFv, KPBv, BWD, true>(a, stream)                       \
                : launch_mfma<NFv, KPBv, BWD, false>(a, stream);                     \
@@ -675,9 +698,20 @@ static int cfconv_dispatch(const CfArgs& a, int NF, bool sym, hipStream_t stream
   return SPK_ERR_ARG;
 }
 
+// floats of filter save space per interaction if the pair kernel will run for this graph/shape, else 0
+int64_t spk_cfconv_gsave_floats(const spk_graph_t* g, const spk_radial_t* rb, int nf) {
+  const int variant = spk_get_variant();
+  const int kpb = (rb->n_rbf + 7) / 8;
+  const bool mfma_ok = (nf == 128 || nf == 64) && kpb >= 1 && kpb <= 4;
+  const bool pair = g->symmetric && g->sorted && g->half && g->rev && g->n_half > 0;
+  if (!mfma_ok || !pair || variant == SPK_VARIANT_SIMPLE || variant == SPK_VARIANT_MFMA_DIRECTED) return 0;
+  return ((g->n_half + 31) / 32) * 32 * (int64_t)nf;
+}
+
 int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
                             const float* r_ij, const float* w1, const float* b1, const float* w2,
-                            const float* b2, int nf, float* y, hipStream_t stream) {
+                            const float* b2, int nf, float* y, hipStream_t stream, bool pre_zeroed,
+                            float* gsave) {
   const char* who = "spk_schnet_cfconv_fwd_f32";
   int rc = check_graph(g, who);
   if (rc) return rc;
@@ -685,12 +719,12 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(nf >= 1 && nf % 4 == 0, "%s: n_filters=%d must be a multiple of 4", who, nf);
   if (g->n_atoms == 0) return SPK_OK;
   SPK_CHECK_ARG(y != nullptr, "%s: null output", who);
-  SPK_HIP_TRY(hipMemsetAsync(y, 0, (size_t)g->n_atoms * nf * sizeof(float), stream));
+  if (!pre_zeroed) SPK_HIP_TRY(hipMemsetAsync(y, 0, (size_t)g->n_atoms * nf * sizeof(float), stream));
   if (g->n_edges == 0) return SPK_OK;
   SPK_CHECK_ARG(h && r_ij && w1 && b1 && w2 && b2, "%s: null pointer", who);
   CfArgs a;
   a.h = h; a.gy = nullptr; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr; a.gsave = gsave; a.gload = nullptr;
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
   return cfconv_dispatch<false>(a, nf, g->symmetric && g->sorted, stream, who);
@@ -699,7 +733,7 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
 int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
                             const float* gy, const float* r_ij, const float* w1, const float* b1,
                             const float* w2, const float* b2, int nf, float* gh, float* gr,
-                            hipStream_t stream) {
+                            hipStream_t stream, bool pre_zeroed, const float* gload) {
   const char* who = "spk_schnet_cfconv_bwd_f32";
   int rc = check_graph(g, who);
   if (rc) return rc;
@@ -707,12 +741,12 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(nf >= 1 && nf % 4 == 0, "%s: n_filters=%d must be a multiple of 4", who, nf);
   if (g->n_atoms == 0) return SPK_OK;
   SPK_CHECK_ARG(gh != nullptr, "%s: null output", who);
-  SPK_HIP_TRY(hipMemsetAsync(gh, 0, (size_t)g->n_atoms * nf * sizeof(float), stream));
+  if (!pre_zeroed) SPK_HIP_TRY(hipMemsetAsync(gh, 0, (size_t)g->n_atoms * nf * sizeof(float), stream));
   if (g->n_edges == 0) return SPK_OK;
   SPK_CHECK_ARG(h && gy && r_ij && w1 && b1 && w2 && b2 && gr, "%s: null pointer", who);
   CfArgs a;
   a.h = h; a.gy = gy; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr; a.gsave = nullptr; a.gload = gload;
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
   // the row-local transposed reduction needs idx_i sorted AND a symmetric list
@@ -724,7 +758,7 @@ extern "C" int spk_schnet_cfconv_fwd_f32(const spk_graph_t* g, const spk_radial_
                                          const float* h, const float* r_ij, const float* w1,
                                          const float* b1, const float* w2, const float* b2,
                                          int32_t nf, float* y, void* stream) {
-  return spk_cfconv_fwd_internal(g, rb, h, r_ij, w1, b1, w2, b2, nf, y, (hipStream_t)stream);
+  return spk_cfconv_fwd_internal(g, rb, h, r_ij, w1, b1, w2, b2, nf, y, (hipStream_t)stream, false, nullptr);
 }
 
 extern "C" int spk_schnet_cfconv_bwd_f32(const spk_graph_t* g, const spk_radial_t* rb,
@@ -732,5 +766,5 @@ extern "C" int spk_schnet_cfconv_bwd_f32(const spk_graph_t* g, const spk_radial_
                                          const float* w1, const float* b1, const float* w2,
                                          const float* b2, int32_t nf, float* gh, float* gr,
                                          void* stream) {
-  return spk_cfconv_bwd_internal(g, rb, h, gy, r_ij, w1, b1, w2, b2, nf, gh, gr, (hipStream_t)stream);
+  return spk_cfconv_bwd_internal(g, rb, h, gy, r_ij, w1, b1, w2, b2, nf, gh, gr, (hipStream_t)stream, false, nullptr);
 }

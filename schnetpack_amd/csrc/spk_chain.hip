@@ -1,0 +1,264 @@
+// Fused chain of up to 3 Dense layers (nn/base.py:52-55 applied back to back, e.g. SchNet's
+// f2out.0 -> f2out.1 (+residual) -> next in2f, or their input-gradient transposes) in ONE launch.
+//
+// At N ~ 5k atoms a single Dense is latency- and launch-bound (~0.2 GFLOP), so the win is in
+// removing launches and HBM round trips: one workgroup (4 waves) owns a tile of 32 rows (atoms), the
+// activations of the tile travel from layer to layer through LDS (two ping-pong buffers,
+// [32][K+4] floats, conflict-free for the 16-byte accesses used), every wave computes the 32x32
+// output tiles t = wave, wave+4, ... of a layer with the fp32 MFMA in the T-GEMM convention of
+// spk_dense.hip (A = weights straight from L2, prefetched in chunks; B = activations from LDS).
+// Epilogue per layer: bias, activation, optional pre-activation store, optional residual add,
+// optional global store, optional "post" multiply by act'(pre) for the next layer's input
+// (backward chains).  The kernel can also zero a buffer for the following edge kernel, which
+// replaces a separate memset launch.
+#include "spk_common.h"
+
+#define CH_MAXL 3
+#define CH_MAXW 384
+
+struct ChainLayerDev {
+  const float* w;        // [NW, KC] (trans == 0) or [KC, NW] (trans == 1)
+  const float* b;        // [NW] or null
+  const float* res;      // [M, NW] or null: added after the activation
+  float* out;            // [M, NW] or null: result (after act and residual)
+  float* pre_out;        // [M, NW] or null: pre-activation
+  const float* post_pre; // [M, NW] or null: LDS copy handed to the next layer is multiplied by post_act'(post_pre)
+  int KC, NW, act, trans, post_act;
+};
+
+struct ChainArgs {
+  ChainLayerDev L[CH_MAXL];
+  int n_layers;
+  const float* in;       // [M, KC0]
+  const float* in_pre;   // or null: input is multiplied by in_act'(in_pre) while it is staged
+  int in_act;
+  int64_t M;
+  float* zero_ptr;       // optional buffer to clear (zero_count floats)
+  int64_t zero_count;
+};
+
+__device__ __forceinline__ float chain_act(int act, float x) {
+  if (act == SPK_ACT_SSP) return spk_fast_ssp(x);
+  if (act == SPK_ACT_SILU) return x * spk_sigmoid(x);
+  return x;
+}
+__device__ __forceinline__ float chain_act_grad(int act, float x) {
+  if (act == SPK_ACT_SSP) return spk_sigmoid(x);
+  if (act == SPK_ACT_SILU) { const float s = spk_sigmoid(x); return s * (1.0f + x * (1.0f - s)); }
+  return 1.0f;
+}
+
+#define CCH 8  // k-blocks per prefetch chunk
+
+template <bool TRANS>
+__device__ __forceinline__ void chain_load_a(f32x4 (&av)[CCH], int c, int nug, const float* __restrict__ w,
+                                             int KC, int NW, int t, int el, int hi) {
+#pragma unroll
+  for (int u = 0; u < CCH; ++u) {
+    const int ug = c * CCH + u;
+    if (ug < nug) {
+      const int kk0 = 8 * ug + 4 * hi;
+      if (!TRANS) {
+        av[u] = *(const f32x4*)(w + (int64_t)(32 * t + el) * KC + kk0);
+      } else {
+        const float* wp = w + (int64_t)kk0 * NW + 32 * t + el;
+        f32x4 a4;
+        a4.x = wp[0]; a4.y = wp[NW]; a4.z = wp[2 * (int64_t)NW]; a4.w = wp[3 * (int64_t)NW];
+        av[u] = a4;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ f32x16 chain_mfma(const f32x4 (&av)[CCH], int c, int nug, const float* __restrict__ brow,
+                                             int hi, f32x16 acc) {
+#pragma unroll
+  for (int u = 0; u < CCH; ++u) {
+    const int ug = c * CCH + u;
+    if (ug < nug) {
+      const f32x4 bv = *(const f32x4*)(brow + 8 * ug + 4 * hi);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv.w, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+template <bool TRANS>
+__device__ __forceinline__ f32x16 chain_tile(const ChainLayerDev& L, int t, const float* __restrict__ brow, int el,
+                                             int hi) {
+  const int nug = L.KC / 8;
+  const int nch = (nug + CCH - 1) / CCH;
+  f32x4 a0[CCH], a1[CCH];
+  chain_load_a<TRANS>(a0, 0, nug, L.w, L.KC, L.NW, t, el, hi);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = L.b ? L.b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
+  for (int c = 0; c < nch; c += 2) {
+    if (c + 1 < nch) chain_load_a<TRANS>(a1, c + 1, nug, L.w, L.KC, L.NW, t, el, hi);
+    acc = chain_mfma(a0, c, nug, brow, hi, acc);
+    if (c + 2 < nch) chain_load_a<TRANS>(a0, c + 2, nug, L.w, L.KC, L.NW, t, el, hi);
+    if (c + 1 < nch) acc = chain_mfma(a1, c + 1, nug, brow, hi, acc);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* buf0 = smem;               // [32][ldw]
+  float* buf1 = smem + 32 * ldw;    // [32][ldw]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+
+  // optional clear of a buffer for the kernel that follows
+  if (a.zero_ptr) {
+    const int64_t n4 = a.zero_count / 4;
+    f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t s = blockIdx.x * 256 + threadIdx.x; s < n4; s += (int64_t)gridDim.x * 256) ((f32x4*)a.zero_ptr)[s] = z4;
+    for (int64_t s = 4 * n4 + blockIdx.x * 256 + threadIdx.x; s < a.zero_count; s += (int64_t)gridDim.x * 256) a.zero_ptr[s] = 0.f;
+  }
+
+  const int64_t ntiles = (a.M + 31) / 32;
+  for (int64_t mt = blockIdx.x; mt < ntiles; mt += gridDim.x) {
+    const int64_t m0 = mt * 32;
+    // ---- stage the input tile [32][KC0] into buf0 (coalesced 16-byte rows)
+    {
+      const int KC0 = a.L[0].KC;
+      const int q4 = KC0 / 4;
+      for (int s = threadIdx.x; s < 32 * q4; s += 256) {
+        const int row = s / q4, c4 = s % q4;
+        int64_t m = m0 + row;
+        if (m >= a.M) m = a.M - 1;
+        f32x4 v = *(const f32x4*)(a.in + m * KC0 + 4 * c4);
+        if (a.in_pre) {
+          const f32x4 p = *(const f32x4*)(a.in_pre + m * KC0 + 4 * c4);
+          v.x *= chain_act_grad(a.in_act, p.x); v.y *= chain_act_grad(a.in_act, p.y);
+          v.z *= chain_act_grad(a.in_act, p.z); v.w *= chain_act_grad(a.in_act, p.w);
+        }
+        *(f32x4*)(buf0 + row * ldw + 4 * c4) = v;
+      }
+    }
+    __syncthreads();
+    float* cur = buf0;
+    float* nxt = buf1;
+    const int64_t m = m0 + el;
+    const bool valid = m < a.M;
+    for (int l = 0; l < a.n_layers; ++l) {
+      const ChainLayerDev& L = a.L[l];
+      const bool last = (l == a.n_layers - 1);
+      const int tcount = L.NW / 32;
+      const float* brow = cur + el * ldw;
+      for (int t = wv; t < tcount; t += 4) {
+        f32x16 acc = L.trans ? chain_tile<true>(L, t, brow, el, hi) : chain_tile<false>(L, t, brow, el, hi);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * t + 8 * q + 4 * hi;
+          const int64_t off = m * L.NW + col;
+          f32x4 o;
+          o.x = acc[4 * q]; o.y = acc[4 * q + 1]; o.z = acc[4 * q + 2]; o.w = acc[4 * q + 3];
+          if (L.pre_out && valid) *(f32x4*)(L.pre_out + off) = o;
+          if (L.act != SPK_ACT_NONE) {
+            o.x = chain_act(L.act, o.x); o.y = chain_act(L.act, o.y); o.z = chain_act(L.act, o.z); o.w = chain_act(L.act, o.w);
+          }
+          if (L.res && valid) { const f32x4 rv = *(const f32x4*)(L.res + off); o += rv; }
+          if (L.out && valid) *(f32x4*)(L.out + off) = o;
+          if (!last) {
+            if (L.post_pre && valid) {
+              const f32x4 p = *(const f32x4*)(L.post_pre + off);
+              o.x *= chain_act_grad(L.post_act, p.x); o.y *= chain_act_grad(L.post_act, p.y);
+              o.z *= chain_act_grad(L.post_act, p.z); o.w *= chain_act_grad(L.post_act, p.w);
+            }
+            *(f32x4*)(nxt + el * ldw + col) = o;
+          }
+        }
+      }
+      __syncthreads();
+      float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+int spk_dense_internal(const float* in, const float* pre_in, const float* w, const float* b,
+                       const float* res, float* out, float* pre_out, int64_t M, int KC, int NW,
+                       int act, bool trans, int pro, hipStream_t stream);
+
+static bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
+
+// true if the fused kernel can run this chain
+static bool chain_supported(const spk_chain_t* c) {
+  if (c->n_layers < 1 || c->n_layers > CH_MAXL) return false;
+  if (!al16(c->in) || !al16(c->in_pre) || !al16(c->zero_ptr)) return false;
+  int kc = c->layers[0].k;
+  for (int l = 0; l < c->n_layers; ++l) {
+    const spk_chain_layer_t& L = c->layers[l];
+    if (L.k != kc) return false;
+    if (L.k % 8 != 0 || L.n_out % 32 != 0 || L.k > CH_MAXW || L.n_out > CH_MAXW) return false;
+    if (!al16(L.w) || !al16(L.b) || !al16(L.res) || !al16(L.out) || !al16(L.pre_out) || !al16(L.post_pre)) return false;
+    kc = L.n_out;
+  }
+  return true;
+}
+
+extern "C" int spk_dense_chain_f32(const spk_chain_t* c, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const char* who = "spk_dense_chain_f32";
+  SPK_CHECK_ARG(c != nullptr && c->n_layers >= 1 && c->n_layers <= CH_MAXL, "%s: 1..%d layers", who, CH_MAXL);
+  SPK_CHECK_ARG(c->m >= 0, "%s: negative row count", who);
+  if (c->m == 0 && !(c->zero_ptr && c->zero_count > 0)) return SPK_OK;
+  const int variant = spk_get_variant();
+  if (c->m > 0 && chain_supported(c) && variant != SPK_VARIANT_SIMPLE) {
+    ChainArgs a = {};
+    int maxw = c->layers[0].k;
+    for (int l = 0; l < c->n_layers; ++l) {
+      const spk_chain_layer_t& S = c->layers[l];
+      SPK_CHECK_ARG(S.w != nullptr, "%s: null weight in layer %d", who, l);
+      ChainLayerDev& D = a.L[l];
+      D.w = S.w; D.b = S.b; D.res = S.res; D.out = S.out; D.pre_out = S.pre_out; D.post_pre = S.post_pre;
+      D.KC = S.k; D.NW = S.n_out; D.act = S.act; D.trans = S.trans; D.post_act = S.post_act;
+      if (S.n_out > maxw) maxw = S.n_out;
+    }
+    SPK_CHECK_ARG(c->in != nullptr, "%s: null input", who);
+    a.n_layers = c->n_layers; a.in = c->in; a.in_pre = c->in_pre; a.in_act = c->in_act; a.M = c->m;
+    a.zero_ptr = c->zero_ptr; a.zero_count = c->zero_ptr ? c->zero_count : 0;
+    const int ldw = maxw + 4;
+    const size_t lds = (size_t)2 * 32 * ldw * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+      SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_dense_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 32 * (CH_MAXW + 4) * sizeof(float))));
+      attr_lds = 2 * 32 * (CH_MAXW + 4) * sizeof(float);
+    }
+    const int64_t ntiles = (c->m + 31) / 32;
+    int grid = (int)(ntiles < 4096 ? ntiles : 4096);
+    SpkProfScope prof(c->n_layers == 1 ? "chain1" : (c->n_layers == 2 ? "chain2" : "chain3"), stream);
+    hipLaunchKernelGGL(k_dense_chain, dim3(grid), dim3(256), lds, stream, a, ldw);
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
+  // general path: layer by layer on the single-layer kernels (any shape)
+  if (c->zero_ptr && c->zero_count > 0) SPK_HIP_TRY(hipMemsetAsync(c->zero_ptr, 0, (size_t)c->zero_count * sizeof(float), stream));
+  if (c->m == 0) return SPK_OK;
+  SPK_CHECK_ARG(c->in != nullptr, "%s: null input", who);
+  const float* cur = c->in;
+  const float* cur_pre = c->in_pre;
+  int cur_act = c->in_pre ? c->in_act : SPK_ACT_NONE;
+  for (int l = 0; l < c->n_layers; ++l) {
+    const spk_chain_layer_t& S = c->layers[l];
+    const bool last = (l == c->n_layers - 1);
+    float* dst = S.out;
+    if (!dst) {
+      SPK_CHECK_ARG(!last && c->tmp[l & 1] != nullptr, "%s: layer %d needs an output or a temporary buffer", who, l);
+      dst = c->tmp[l & 1];
+    }
+    int rc = spk_dense_internal(cur, cur_pre, S.w, S.b, S.res, dst, S.pre_out, c->m, S.k, S.n_out, S.act, S.trans != 0, cur_act, stream);
+    if (rc) return rc;
+    cur = dst;
+    cur_pre = S.post_pre;
+    cur_act = S.post_pre ? S.post_act : SPK_ACT_NONE;
+  }
+  return SPK_OK;
+}

@@ -499,6 +499,14 @@ extern "C" int spk_painn_mix_ctx_bwd_f32(const float* mix, const float* g_ctx, c
 // ------------------------------------------------------------------------------------------
 #define SPK_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+static spk_chain_layer_t mk_layer(const float* w, const float* b, const float* res, float* out, float* pre_out,
+                                  const float* post_pre, int k, int n_out, int act, int trans, int post_act) {
+  spk_chain_layer_t L;
+  L.w = w; L.b = b; L.res = res; L.out = out; L.pre_out = pre_out; L.post_pre = post_pre;
+  L.k = k; L.n_out = n_out; L.act = act; L.trans = trans; L.post_act = post_act;
+  return L;
+}
+
 // per layer saved for backward: preA [F] | c [3F] | mu_in [3F] | mix [6F] | preB [F] | a [3F]
 static inline int64_t painn_saved_per_atom(int F) { return 17 * (int64_t)F; }
 
@@ -542,13 +550,28 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
     float* preA = S; float* c = S + nf; float* mu_in = S + 4 * nf; float* mix = S + 7 * nf;
     float* preB = S + 13 * nf; float* av = S + 14 * nf;
     const float* qin = (l == 0) ? q0 : q_out;
-    SPK_TRY(spk_dense_internal(qin, nullptr, P.ctx_w1, P.ctx_b1, nullptr, c1, preA, N, F, F, SPK_ACT_SILU, false, SPK_ACT_NONE, stream));
-    SPK_TRY(spk_dense_internal(c1, nullptr, P.ctx_w2, P.ctx_b2, nullptr, c, nullptr, N, F, 3 * F, SPK_ACT_NONE, false, SPK_ACT_NONE, stream));
+    {  // c = ctx_w2 silu(ctx_w1 q + b1) + b2   (one launch)
+      spk_chain_t ch = {};
+      ch.n_layers = 2; ch.m = N; ch.in = qin; ch.tmp[0] = c1; ch.tmp[1] = a1;
+      ch.layers[0] = mk_layer(P.ctx_w1, P.ctx_b1, nullptr, nullptr, preA, nullptr, F, F, SPK_ACT_SILU, 0, 0);
+      ch.layers[1] = mk_layer(P.ctx_w2, P.ctx_b2, nullptr, c, nullptr, nullptr, F, 3 * F, SPK_ACT_NONE, 0, 0);
+      SPK_TRY(spk_dense_chain_f32(&ch, stream));
+    }
     SPK_TRY(spk_painn_message_fwd_internal(g, rb, c, qin, mu_in, r_ij, P.filt_w, P.filt_b, F, q1, mu1, stream));
-    SPK_TRY(spk_dense_internal(mu1, nullptr, P.mix_w, nullptr, nullptr, mix, nullptr, 3 * N, F, 2 * F, SPK_ACT_NONE, false, SPK_ACT_NONE, stream));
+    {  // mix = mu1 W_mix^T over [3N, F]
+      spk_chain_t ch = {};
+      ch.n_layers = 1; ch.m = 3 * N; ch.in = mu1;
+      ch.layers[0] = mk_layer(P.mix_w, nullptr, nullptr, mix, nullptr, nullptr, F, 2 * F, SPK_ACT_NONE, 0, 0);
+      SPK_TRY(spk_dense_chain_f32(&ch, stream));
+    }
     SPK_TRY(spk_painn_mix_ctx_f32(q1, mix, N, F, m->epsilon, ctx, stream));
-    SPK_TRY(spk_dense_internal(ctx, nullptr, P.ictx_w1, P.ictx_b1, nullptr, a1, preB, N, 2 * F, F, SPK_ACT_SILU, false, SPK_ACT_NONE, stream));
-    SPK_TRY(spk_dense_internal(a1, nullptr, P.ictx_w2, P.ictx_b2, nullptr, av, nullptr, N, F, 3 * F, SPK_ACT_NONE, false, SPK_ACT_NONE, stream));
+    {  // a = ictx_w2 silu(ictx_w1 ctx + b1) + b2
+      spk_chain_t ch = {};
+      ch.n_layers = 2; ch.m = N; ch.in = ctx; ch.tmp[0] = c1; ch.tmp[1] = a1;
+      ch.layers[0] = mk_layer(P.ictx_w1, P.ictx_b1, nullptr, nullptr, preB, nullptr, 2 * F, F, SPK_ACT_SILU, 0, 0);
+      ch.layers[1] = mk_layer(P.ictx_w2, P.ictx_b2, nullptr, av, nullptr, nullptr, F, 3 * F, SPK_ACT_NONE, 0, 0);
+      SPK_TRY(spk_dense_chain_f32(&ch, stream));
+    }
     float* mu_next = (l == L - 1) ? mu_out : (saved + (l + 1) * per + 4 * nf);
     SPK_TRY(spk_painn_mix_update_f32(q1, mu1, mix, av, N, F, q_out, mu_next, stream));
   }
@@ -594,17 +617,30 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
     const float* preB = S + 13 * nf; const float* av = S + 14 * nf;
     // ---- mixing backward
     SPK_TRY(spk_painn_mix_update_bwd_f32(nullptr, mix, av, gq, gmu, N, F, ga, gmix, stream));
-    SPK_TRY(spk_dense_internal(ga, nullptr, P.ictx_w2, nullptr, nullptr, ga1, nullptr, N, 3 * F, F, SPK_ACT_NONE, true, SPK_ACT_NONE, stream));
-    SPK_TRY(spk_dense_internal(ga1, preB, P.ictx_w1, nullptr, nullptr, gctx, nullptr, N, F, 2 * F, SPK_ACT_NONE, true, SPK_ACT_SILU, stream));
+    {  // g_ctx = ((ga W_d) * silu'(preB)) W_c
+      spk_chain_t ch = {};
+      ch.n_layers = 2; ch.m = N; ch.in = ga; ch.tmp[0] = ga1; ch.tmp[1] = gc1;
+      ch.layers[0] = mk_layer(P.ictx_w2, nullptr, nullptr, nullptr, nullptr, preB, 3 * F, F, SPK_ACT_NONE, 1, SPK_ACT_SILU);
+      ch.layers[1] = mk_layer(P.ictx_w1, nullptr, nullptr, gctx, nullptr, nullptr, F, 2 * F, SPK_ACT_NONE, 1, 0);
+      SPK_TRY(spk_dense_chain_f32(&ch, stream));
+    }
     SPK_TRY(spk_painn_mix_ctx_bwd_f32(mix, gctx, gq, N, F, m->epsilon, gmix, gq1, stream));
-    // mu1 -> mix is a bias-free Dense over [3N, F]; residual path adds gmu
-    SPK_TRY(spk_dense_internal(gmix, nullptr, P.mix_w, nullptr, gmu, gmu1, nullptr, 3 * N, 2 * F, F, SPK_ACT_NONE, true, SPK_ACT_NONE, stream));
+    {  // mu1 -> mix is a bias-free Dense over [3N, F]; residual path adds gmu
+      spk_chain_t ch = {};
+      ch.n_layers = 1; ch.m = 3 * N; ch.in = gmix;
+      ch.layers[0] = mk_layer(P.mix_w, nullptr, gmu, gmu1, nullptr, nullptr, 2 * F, F, SPK_ACT_NONE, 1, 0);
+      SPK_TRY(spk_dense_chain_f32(&ch, stream));
+    }
     // ---- message backward: gc, gmu (incl. residual), gr +=
     SPK_TRY(spk_painn_message_bwd_internal(g, rb, c, mu_in, gq1, gmu1, r_ij, P.filt_w, P.filt_b, F, gc, gmu, gr, stream));
-    // ---- context net backward; residual path adds gq1
-    SPK_TRY(spk_dense_internal(gc, nullptr, P.ctx_w2, nullptr, nullptr, gc1, nullptr, N, 3 * F, F, SPK_ACT_NONE, true, SPK_ACT_NONE, stream));
-    float* out = (l == 0 && gq0) ? gq0 : gq;
-    SPK_TRY(spk_dense_internal(gc1, preA, P.ctx_w1, nullptr, gq1, out, nullptr, N, F, F, SPK_ACT_NONE, true, SPK_ACT_SILU, stream));
+    {  // context net backward; residual path adds gq1
+      float* out = (l == 0 && gq0) ? gq0 : gq;
+      spk_chain_t ch = {};
+      ch.n_layers = 2; ch.m = N; ch.in = gc; ch.tmp[0] = ga1; ch.tmp[1] = gc1;
+      ch.layers[0] = mk_layer(P.ctx_w2, nullptr, nullptr, nullptr, nullptr, preA, 3 * F, F, SPK_ACT_NONE, 1, SPK_ACT_SILU);
+      ch.layers[1] = mk_layer(P.ctx_w1, nullptr, gq1, out, nullptr, nullptr, F, F, SPK_ACT_NONE, 1, 0);
+      SPK_TRY(spk_dense_chain_f32(&ch, stream));
+    }
   }
   return SPK_OK;
 }

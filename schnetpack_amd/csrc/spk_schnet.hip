@@ -1,17 +1,19 @@
 // Whole-representation drivers for SchNet (representation/schnet.py:147-173): every kernel of one
 // forward (or one first-order backward) is enqueued on the caller's stream from a single C call.
+// Per interaction: ONE fused edge kernel (cfconv) and ONE fused atom-wise chain kernel
+// (f2out.0 -> f2out.1 + residual -> next in2f; resp. their transposes in the backward), which also
+// clears the accumulation buffer of the next edge kernel.
 #include "spk_common.h"
 
-int spk_dense_internal(const float* in, const float* pre_in, const float* w, const float* b,
-                       const float* res, float* out, float* pre_out, int64_t M, int KC, int NW,
-                       int act, bool trans, int pro, hipStream_t stream);
 int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
                             const float* r_ij, const float* w1, const float* b1, const float* w2,
-                            const float* b2, int nf, float* y, hipStream_t stream);
+                            const float* b2, int nf, float* y, hipStream_t stream, bool pre_zeroed,
+                            float* gsave);
+int64_t spk_cfconv_gsave_floats(const spk_graph_t* g, const spk_radial_t* rb, int nf);
 int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
                             const float* gy, const float* r_ij, const float* w1, const float* b1,
                             const float* w2, const float* b2, int nf, float* gh, float* gr,
-                            hipStream_t stream);
+                            hipStream_t stream, bool pre_zeroed, const float* gload);
 
 static int check_model(const spk_schnet_t* m, const char* who) {
   SPK_CHECK_ARG(m != nullptr && m->layers != nullptr, "%s: null model", who);
@@ -19,17 +21,34 @@ static int check_model(const spk_schnet_t* m, const char* who) {
   return SPK_OK;
 }
 
+// saved: per interaction h [N,nf] | pre3 [N,F], followed (optionally) by the raw filter outputs
+// g_e of every interaction ([n_half_padded, nf] each) when `n_edges_hint` > 0 was given
 extern "C" int64_t spk_schnet_saved_floats(const spk_schnet_t* m, int64_t n_atoms) {
   if (!m) return 0;
   return (int64_t)m->n_interactions * n_atoms * (m->n_filters + m->n_atom_basis);
 }
+extern "C" int64_t spk_schnet_saved_floats_graph(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb) {
+  if (!m || !g || !rb) return 0;
+  return spk_schnet_saved_floats(m, g->n_atoms) + (int64_t)m->n_interactions * spk_cfconv_gsave_floats(g, rb, m->n_filters);
+}
 
+// scratch: forward  y0 | y1 | t0 | t1            (2 nf + 2 max(F, nf))
+//          backward gh0 | gh1 | gy | gxb | t0 | t1
 extern "C" int64_t spk_schnet_scratch_floats(const spk_schnet_t* m, int64_t n_atoms) {
   if (!m) return 0;
-  return n_atoms * (2 * (int64_t)m->n_filters + 2 * (int64_t)m->n_atom_basis);
+  const int64_t mx = m->n_filters > m->n_atom_basis ? m->n_filters : m->n_atom_basis;
+  return n_atoms * (3 * (int64_t)m->n_filters + (int64_t)m->n_atom_basis + 2 * mx);
 }
 
 #define SPK_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+static spk_chain_layer_t mk_layer(const float* w, const float* b, const float* res, float* out, float* pre_out,
+                                  const float* post_pre, int k, int n_out, int act, int trans, int post_act) {
+  spk_chain_layer_t L;
+  L.w = w; L.b = b; L.res = res; L.out = out; L.pre_out = pre_out; L.post_pre = post_pre;
+  L.k = k; L.n_out = n_out; L.act = act; L.trans = trans; L.post_act = post_act;
+  return L;
+}
 
 extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* g,
                                       const spk_radial_t* rb, const float* x0, const float* r_ij,
@@ -46,17 +65,40 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
     SPK_HIP_TRY(hipMemcpyAsync(x_out, x0, (size_t)N * F * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return SPK_OK;
   }
-  float* y = scratch;                       // [N, NF]
-  float* t = scratch + N * (int64_t)NF;     // [N, F]
+  const int64_t mx = NF > F ? NF : F;
+  float* ybuf[2] = {scratch, scratch + N * (int64_t)NF};
+  float* tmp0 = scratch + 2 * N * (int64_t)NF;
+  float* tmp1 = tmp0 + N * mx;
+  auto hbuf = [&](int l) { return saved + (int64_t)l * N * (NF + F); };
+  const int64_t gsz = (m->reserved & 1) ? spk_cfconv_gsave_floats(g, rb, NF) : 0;  // bit 0: saved has filter space
+  float* gbase = saved + (int64_t)L * N * (NF + F);
+  // prelude: h_0 = in2f_0(x0); clear y of the first edge kernel
+  {
+    spk_chain_t c = {};
+    c.n_layers = 1; c.m = N; c.in = x0; c.zero_ptr = ybuf[0]; c.zero_count = N * (int64_t)NF;
+    c.tmp[0] = tmp0; c.tmp[1] = tmp1;
+    c.layers[0] = mk_layer(m->layers[0].in2f_w, nullptr, nullptr, hbuf(0), nullptr, nullptr, F, NF, SPK_ACT_NONE, 0, 0);
+    SPK_TRY(spk_dense_chain_f32(&c, stream));
+  }
   for (int l = 0; l < L; ++l) {
     const spk_schnet_layer_t& P = m->layers[l];
-    float* h = saved + (int64_t)l * N * (NF + F);
+    float* h = hbuf(l);
     float* pre3 = h + N * (int64_t)NF;
+    float* y = ybuf[l & 1];
     const float* xin = (l == 0) ? x0 : x_out;
-    SPK_TRY(spk_dense_internal(xin, nullptr, P.in2f_w, nullptr, nullptr, h, nullptr, N, F, NF, SPK_ACT_NONE, false, SPK_ACT_NONE, stream));
-    SPK_TRY(spk_cfconv_fwd_internal(g, rb, h, r_ij, P.fn_w1, P.fn_b1, P.fn_w2, P.fn_b2, NF, y, stream));
-    SPK_TRY(spk_dense_internal(y, nullptr, P.f2out_w1, P.f2out_b1, nullptr, t, pre3, N, NF, F, SPK_ACT_SSP, false, SPK_ACT_NONE, stream));
-    SPK_TRY(spk_dense_internal(t, nullptr, P.f2out_w2, P.f2out_b2, xin, x_out, nullptr, N, F, F, SPK_ACT_NONE, false, SPK_ACT_NONE, stream));
+    SPK_TRY(spk_cfconv_fwd_internal(g, rb, h, r_ij, P.fn_w1, P.fn_b1, P.fn_w2, P.fn_b2, NF, y, stream, true,
+                                    gsz > 0 ? gbase + l * gsz : nullptr));
+    spk_chain_t c = {};
+    c.m = N; c.in = y; c.tmp[0] = tmp0; c.tmp[1] = tmp1;
+    c.layers[0] = mk_layer(P.f2out_w1, P.f2out_b1, nullptr, nullptr, pre3, nullptr, NF, F, SPK_ACT_SSP, 0, 0);
+    c.layers[1] = mk_layer(P.f2out_w2, P.f2out_b2, xin, x_out, nullptr, nullptr, F, F, SPK_ACT_NONE, 0, 0);
+    c.n_layers = 2;
+    if (l + 1 < L) {
+      c.layers[2] = mk_layer(m->layers[l + 1].in2f_w, nullptr, nullptr, hbuf(l + 1), nullptr, nullptr, F, NF, SPK_ACT_NONE, 0, 0);
+      c.n_layers = 3;
+      c.zero_ptr = ybuf[(l + 1) & 1]; c.zero_count = N * (int64_t)NF;
+    }
+    SPK_TRY(spk_dense_chain_f32(&c, stream));
   }
   return SPK_OK;
 }
@@ -81,23 +123,48 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
     if (gx0) SPK_HIP_TRY(hipMemcpyAsync(gx0, gx_out, (size_t)N * F * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return SPK_OK;
   }
-  float* gt = scratch;                              // [N, F]
-  float* gy = gt + N * (int64_t)F;                  // [N, NF]
-  float* gh = gy + N * (int64_t)NF;                 // [N, NF]
-  float* gxb = gh + N * (int64_t)NF;                // [N, F]
+  const int64_t mx = NF > F ? NF : F;
+  float* ghbuf[2] = {scratch, scratch + N * (int64_t)NF};
+  float* gy = scratch + 2 * N * (int64_t)NF;
+  float* gxb = gy + N * (int64_t)NF;
+  float* tmp0 = gxb + N * (int64_t)F;
+  float* tmp1 = tmp0 + N * mx;
+  auto hbuf = [&](int l) { return saved + (int64_t)l * N * (NF + F); };
+  auto pre3 = [&](int l) { return saved + (int64_t)l * N * (NF + F) + N * (int64_t)NF; };
+  const int64_t gsz = (m->reserved & 1) ? spk_cfconv_gsave_floats(g, rb, NF) : 0;
+  const float* gbase = saved + (int64_t)L * N * (NF + F);
+  // prelude: gy_{L-1} = ((gx W4) * ssp'(pre3)) W3 ; clear gh of the first edge kernel
+  {
+    const spk_schnet_layer_t& P = m->layers[L - 1];
+    spk_chain_t c = {};
+    c.n_layers = 2; c.m = N; c.in = gx_out; c.zero_ptr = ghbuf[(L - 1) & 1]; c.zero_count = N * (int64_t)NF;
+    c.tmp[0] = tmp0; c.tmp[1] = tmp1;
+    c.layers[0] = mk_layer(P.f2out_w2, nullptr, nullptr, nullptr, nullptr, pre3(L - 1), F, F, SPK_ACT_NONE, 1, SPK_ACT_SSP);
+    c.layers[1] = mk_layer(P.f2out_w1, nullptr, nullptr, gy, nullptr, nullptr, F, NF, SPK_ACT_NONE, 1, 0);
+    SPK_TRY(spk_dense_chain_f32(&c, stream));
+  }
   const float* gx = gx_out;
   for (int l = L - 1; l >= 0; --l) {
     const spk_schnet_layer_t& P = m->layers[l];
-    const float* h = saved + (int64_t)l * N * (NF + F);
-    const float* pre3 = h + N * (int64_t)NF;
-    // f2out.1: x_new = x + t W4^T + b4
-    SPK_TRY(spk_dense_internal(gx, nullptr, P.f2out_w2, nullptr, nullptr, gt, nullptr, N, F, F, SPK_ACT_NONE, true, SPK_ACT_NONE, stream));
-    // f2out.0: t = ssp(y W3^T + b3)
-    SPK_TRY(spk_dense_internal(gt, pre3, P.f2out_w1, nullptr, nullptr, gy, nullptr, N, F, NF, SPK_ACT_NONE, true, SPK_ACT_SSP, stream));
-    SPK_TRY(spk_cfconv_bwd_internal(g, rb, h, gy, r_ij, P.fn_w1, P.fn_b1, P.fn_w2, P.fn_b2, NF, gh, gr, stream));
+    float* gh = ghbuf[l & 1];
+    SPK_TRY(spk_cfconv_bwd_internal(g, rb, hbuf(l), gy, r_ij, P.fn_w1, P.fn_b1, P.fn_w2, P.fn_b2, NF, gh, gr, stream, true,
+                                    gsz > 0 ? gbase + l * gsz : nullptr));
+    if (l == 0 && !gx0) break;  // dL/dx0 not requested (eval path): nothing below feeds dL/dr_ij
+    float* out = (l == 0) ? gx0 : gxb;
+    spk_chain_t c = {};
+    c.m = N; c.in = gh; c.tmp[0] = tmp0; c.tmp[1] = tmp1;
     // in2f: h = x W_in^T ; residual path adds gx
-    float* out = (l == 0 && gx0) ? gx0 : gxb;
-    SPK_TRY(spk_dense_internal(gh, nullptr, P.in2f_w, nullptr, gx, out, nullptr, N, NF, F, SPK_ACT_NONE, true, SPK_ACT_NONE, stream));
+    c.layers[0] = mk_layer(P.in2f_w, nullptr, gx, out, nullptr, nullptr, NF, F, SPK_ACT_NONE, 1, 0);
+    c.n_layers = 1;
+    if (l > 0) {
+      const spk_schnet_layer_t& Q = m->layers[l - 1];
+      c.layers[0].post_pre = nullptr;
+      c.layers[1] = mk_layer(Q.f2out_w2, nullptr, nullptr, nullptr, nullptr, pre3(l - 1), F, F, SPK_ACT_NONE, 1, SPK_ACT_SSP);
+      c.layers[2] = mk_layer(Q.f2out_w1, nullptr, nullptr, gy, nullptr, nullptr, F, NF, SPK_ACT_NONE, 1, 0);
+      c.n_layers = 3;
+      c.zero_ptr = ghbuf[(l - 1) & 1]; c.zero_count = N * (int64_t)NF;
+    }
+    SPK_TRY(spk_dense_chain_f32(&c, stream));
     gx = out;
   }
   return SPK_OK;

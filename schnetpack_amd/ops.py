@@ -380,9 +380,15 @@ class SchNetFn(torch.autograd.Function):
         rc = r_ij.contiguous()
         L = lib()
         out = torch.empty((N, F), dtype=torch.float32, device=dev)
-        saved = torch.empty(max(1, int(L.spk_schnet_saved_floats(ctypes.byref(model_struct), N))), dtype=torch.float32, device=dev)
-        scratch = torch.empty(max(1, int(L.spk_schnet_scratch_floats(ctypes.byref(model_struct), N))), dtype=torch.float32, device=dev)
         rb = radial_struct(*rb_args)
+        # keep the raw filter outputs for the backward when a gradient w.r.t. the geometry will be asked for
+        model_struct.reserved = 1 if r_ij.requires_grad else 0
+        if model_struct.reserved:
+            n_saved = int(L.spk_schnet_saved_floats_graph(ctypes.byref(model_struct), plan.graph(), ctypes.byref(rb)))
+        else:
+            n_saved = int(L.spk_schnet_saved_floats(ctypes.byref(model_struct), N))
+        saved = torch.empty(max(1, n_saved), dtype=torch.float32, device=dev)
+        scratch = torch.empty(max(1, int(L.spk_schnet_scratch_floats(ctypes.byref(model_struct), N))), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             check(L.spk_schnet_forward_f32(ctypes.byref(model_struct), plan.graph(), ctypes.byref(rb), fptr(x0c), fptr(rc),
                                            fptr(out), fptr(saved), fptr(scratch), stream()))

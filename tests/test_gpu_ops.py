@@ -497,3 +497,105 @@ def test_pairwise_vectors_forward_backward_and_second_order(dev):
     gh, g2h = run(R.to(dev), ii, jj, off.to(dev), w.to(dev), ops.pairwise_vectors)
     go, g2o = run(R.double(), b["idx_i"], b["idx_j"], off.double(), w.double(), O.pairwise_vectors)
     assert rel_err(gh, go) < TOL and rel_err(g2h, g2o) < TOL
+
+
+# ----------------------------------------------------------------------------- fused dense chain
+def _chain_struct(_lib, m, inp, layers, in_pre=None, in_act=0, zero=None, tmp=None):
+    c = _lib.ChainT()
+    c.n_layers = len(layers)
+    c.in_act = in_act
+    c.m = m
+    c.inp = _lib.fptr(inp)
+    c.in_pre = _lib.fptr(in_pre)
+    c.zero_ptr = _lib.fptr(zero)
+    c.zero_count = zero.numel() if zero is not None else 0
+    if tmp is not None:
+        c.tmp[0] = tmp[0].data_ptr()
+        c.tmp[1] = tmp[1].data_ptr()
+    for l, L in enumerate(layers):
+        for k in ("w", "b", "res", "out", "pre_out", "post_pre"):
+            setattr(c.layers[l], k, _lib.fptr(L.get(k)))
+        for k in ("k", "n_out", "act", "trans", "post_act"):
+            setattr(c.layers[l], k, int(L.get(k, 0)))
+    return c
+
+
+@pytest.mark.parametrize("m", [5376, 37])
+def test_dense_chain_forward_style(dev, variant, m):
+    """f2out.0 (ssp, pre saved) -> f2out.1 (+ residual, stored) -> in2f (stored), buffer cleared."""
+    from schnetpack_amd import _lib
+    g = torch.Generator().manual_seed(41)
+    F = 128
+    y = torch.randn(m, F, generator=g)
+    x = torch.randn(m, F, generator=g)
+    w3, b3 = torch.randn(F, F, generator=g) / 11, torch.randn(F, generator=g) * 0.1
+    w4, b4 = torch.randn(F, F, generator=g) / 11, torch.randn(F, generator=g) * 0.1
+    win = torch.randn(F, F, generator=g) / 11
+    pre_o = O.dense(y.double(), w3.double(), b3.double())
+    x_o = x.double() + O.dense(O.shifted_softplus(pre_o), w4.double(), b4.double())
+    h_o = O.dense(x_o, win.double())
+    D = lambda t: t.to(dev).contiguous()
+    yd, xd, w3d, b3d, w4d, b4d, wind = map(D, (y, x, w3, b3, w4, b4, win))
+    pre = torch.empty(m, F, device=dev)
+    h = torch.empty(m, F, device=dev)
+    junk = torch.ones(1000, device=dev)
+    tmp = (torch.empty(m, F, device=dev), torch.empty(m, F, device=dev))
+    c = _chain_struct(_lib, m, yd, [
+        dict(w=w3d, b=b3d, pre_out=pre, k=F, n_out=F, act=_lib.SPK_ACT_SSP),
+        dict(w=w4d, b=b4d, res=xd, out=xd, k=F, n_out=F),
+        dict(w=wind, out=h, k=F, n_out=F)], zero=junk, tmp=tmp)
+    _lib.check(_lib.lib().spk_dense_chain_f32(ctypes.byref(c), _lib.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(pre.cpu(), pre_o) < TOL
+    assert rel_err(xd.cpu(), x_o) < TOL      # in-place residual update
+    assert rel_err(h.cpu(), h_o) < TOL
+    assert float(junk.abs().max()) == 0.0
+
+
+def test_dense_chain_backward_style(dev, variant):
+    """(gh W_in + gx) -> (. W4) * ssp'(pre3) -> (. W3): the transposed chain of the backward."""
+    from schnetpack_amd import _lib
+    g = torch.Generator().manual_seed(43)
+    m, F, NF = 777, 128, 64
+    gh = torch.randn(m, NF, generator=g)
+    gx = torch.randn(m, F, generator=g)
+    pre3 = torch.randn(m, F, generator=g)
+    win = torch.randn(NF, F, generator=g) / 8     # in2f  [nf, F]
+    w4 = torch.randn(F, F, generator=g) / 11      # f2out.1 [F, F]
+    w3 = torch.randn(F, NF, generator=g) / 8      # f2out.0 [F, nf]
+    gx_o = gx.double() + gh.double() @ win.double()
+    gt_o = (gx_o @ w4.double()) * torch.sigmoid(pre3.double())
+    gy_o = gt_o @ w3.double()
+    D = lambda t: t.to(dev).contiguous()
+    ghd, gxd, pred, wind, w4d, w3d = map(D, (gh, gx, pre3, win, w4, w3))
+    gx_new = torch.empty(m, F, device=dev)
+    gy = torch.empty(m, NF, device=dev)
+    tmp = (torch.empty(m, F, device=dev), torch.empty(m, F, device=dev))
+    c = _chain_struct(_lib, m, ghd, [
+        dict(w=wind, res=gxd, out=gx_new, k=NF, n_out=F, trans=1),
+        dict(w=w4d, post_pre=pred, post_act=_lib.SPK_ACT_SSP, k=F, n_out=F, trans=1),
+        dict(w=w3d, out=gy, k=F, n_out=NF, trans=1)], tmp=tmp)
+    _lib.check(_lib.lib().spk_dense_chain_f32(ctypes.byref(c), _lib.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(gx_new.cpu(), gx_o) < TOL
+    assert rel_err(gy.cpu(), gy_o) < TOL
+
+
+def test_dense_chain_odd_shapes_use_layerwise_path(dev):
+    """n_rbf -> F -> 1 style shapes (k % 8 != 0, n_out % 32 != 0) run layer by layer."""
+    from schnetpack_amd import _lib
+    g = torch.Generator().manual_seed(44)
+    m = 91
+    x = torch.randn(m, 20, generator=g)
+    w1, b1 = torch.randn(64, 20, generator=g) / 4, torch.randn(64, generator=g) * 0.1
+    w2, b2 = torch.randn(1, 64, generator=g) / 8, torch.randn(1, generator=g)
+    o = O.dense(O.silu(O.dense(x.double(), w1.double(), b1.double())), w2.double(), b2.double())
+    D = lambda t: t.to(dev).contiguous()
+    xd, w1d, b1d, w2d, b2d = map(D, (x, w1, b1, w2, b2))
+    out = torch.empty(m, 1, device=dev)
+    tmp = (torch.empty(m, 64, device=dev), torch.empty(m, 64, device=dev))
+    c = _chain_struct(_lib, m, xd, [dict(w=w1d, b=b1d, k=20, n_out=64, act=_lib.SPK_ACT_SILU),
+                                    dict(w=w2d, b=b2d, out=out, k=64, n_out=1)], tmp=tmp)
+    _lib.check(_lib.lib().spk_dense_chain_f32(ctypes.byref(c), _lib.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), o) < TOL
