@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--no-graph", action="store_true", help="do not capture the force call in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=15)
     ap.add_argument("--variant", default="auto", choices=["auto", "simple", "mfma"])
     return ap.parse_args()
 
@@ -153,13 +153,20 @@ def main():
     prof = _lib.profile_report()
     _lib.profile_enable(False)
     nf = F
+    # ALGORITHMIC work per launch (SURVEY.md section 8(d) per-unit figures x units per launch; DESIGN.md
+    # section 5): forward E * 2 (n_rbf nf + nf^2) FLOP per directed edge-message, backward 2x.  The
+    # pair kernels EXECUTE half of the forward figure (one filter per undirected pair) and the
+    # saved-filter backward executes 352/304 of the (halved) forward figure.
     flop_fwd = 2.0 * E * (n_rbf * nf + nf * nf)
-    algo = {  # algorithmic work per launch
-        "cfconv_fwd_mfma": ("mfma", flop_fwd), "cfconv_fwd_simple": ("mfma", flop_fwd),
-        "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd),
-        "cfconv_bwd_simple": ("mfma", 2 * flop_fwd),
-        "painn_msg_fwd_row": ("hbm", E * 3100.0 + N * 4096.0), "painn_msg_fwd_simple": ("hbm", E * 3100.0 + N * 4096.0),
-        "painn_msg_bwd_row": ("hbm", 2 * (E * 3100.0 + N * 4096.0)), "painn_msg_bwd_simple": ("hbm", 2 * (E * 3100.0 + N * 4096.0)),
+    msg_bytes = E * 3100.0 + N * 4096.0
+    algo = {
+        "cfconv_fwd_mfma": ("mfma", flop_fwd, 1.0), "cfconv_fwd_simple": ("mfma", flop_fwd, 1.0),
+        "cfconv_fwd_pair": ("mfma", flop_fwd, 0.5),
+        "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd, 1.0), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd, 1.0),
+        "cfconv_bwd_simple": ("mfma", 2 * flop_fwd, 1.0), "cfconv_bwd_pair": ("mfma", 2 * flop_fwd, 0.5),
+        "cfconv_bwd_pair_gs": ("mfma", 2 * flop_fwd, 0.5 * 352.0 / 608.0),
+        "painn_msg_fwd_row": ("hbm", msg_bytes, 1.0), "painn_msg_fwd_simple": ("hbm", msg_bytes, 1.0),
+        "painn_msg_bwd_row": ("hbm", 2 * msg_bytes, 1.0), "painn_msg_bwd_simple": ("hbm", 2 * msg_bytes, 1.0),
     }
     kernels = {}
     for tag, (cnt, ms) in prof.items():
@@ -168,7 +175,7 @@ def main():
     roofline = None
     if cand:
         dom = max(cand, key=lambda t: kernels[t]["us_per_step"])
-        bound, work = algo[dom]
+        bound, work, executed = algo[dom]
         sec = kernels[dom]["avg_us"] * 1e-6
         if bound == "mfma":
             ach, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
@@ -176,7 +183,10 @@ def main():
             ach, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
         roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": None,
-                    "avg_launch_us": round(kernels[dom]["avg_us"], 2), "algorithmic_per_launch": work}
+                    "avg_launch_us": round(kernels[dom]["avg_us"], 2), "algorithmic_per_launch": work,
+                    "executed_frac_of_peak": round(executed * ach / peak, 4),
+                    "note": "achieved = algorithmic work / HIP-event time of the launch; executed_frac_of_peak counts only the "
+                            "work the kernel really issues (pair kernels evaluate one filter per undirected edge)"}
 
     # ---------------- scatter_add op alone (north_star: HBM roofline of the segmented sum)
     from schnetpack_amd import ops

@@ -1,0 +1,65 @@
+"""Drop-in hook: route the reference package's hot-path names to the HIP-backed mirrors.
+
+    import schnetpack, schnetpack_amd.install
+    schnetpack_amd.install.install()          # before building / unpickling a model
+
+Patches, inside the already imported ``schnetpack`` package, exactly the names of SURVEY.md
+section 8(b): ``nn.scatter_add`` (+ ``nn.scatter.scatter_add``), ``nn.Dense``, ``nn.GaussianRBF``,
+``nn.BesselRBF``, ``nn.CosineCutoff``, ``representation.{SchNet, SchNetInteraction, PaiNN,
+PaiNNInteraction, PaiNNMixing}`` and ``atomistic.PairwiseDistances``.  Classes are replaced both on
+the package and on the defining sub-module, so Hydra ``_target_`` paths and pickled models
+(``torch.load`` resolves ``schnetpack.representation.painn.PaiNN`` by attribute) pick up the
+mirrors; parameter names and shapes are identical, so existing ``state_dict``s and whole-model
+pickles load unchanged.  Everything else of the reference (Atomwise, Forces, AtomisticModel,
+spktrain, md.Simulator, ...) keeps running its own code on top.
+"""
+import importlib
+import sys
+
+
+def _set(mod, name, obj, log):
+    if mod is not None and hasattr(mod, name):
+        setattr(mod, name, obj)
+        log.append("%s.%s" % (mod.__name__, name))
+
+
+def install(spk=None, verbose=False):
+    """Patch ``spk`` (default: the imported ``schnetpack``).  Returns the list of patched names."""
+    from . import atomistic as A
+    from . import nn as N
+    from . import representation as R
+    if spk is None:
+        spk = sys.modules.get("schnetpack") or importlib.import_module("schnetpack")
+
+    def sub(path):
+        return sys.modules.get(spk.__name__ + "." + path)
+
+    log = []
+    for mod in (getattr(spk, "nn", None), sub("nn.scatter")):
+        _set(mod, "scatter_add", N.scatter_add, log)
+    for mod in (getattr(spk, "nn", None), sub("nn.base")):
+        _set(mod, "Dense", N.Dense, log)
+    for mod in (getattr(spk, "nn", None), sub("nn.radial")):
+        _set(mod, "GaussianRBF", N.GaussianRBF, log)
+        _set(mod, "BesselRBF", N.BesselRBF, log)
+    for mod in (getattr(spk, "nn", None), sub("nn.cutoff")):
+        _set(mod, "CosineCutoff", N.CosineCutoff, log)
+    for mod in (getattr(spk, "representation", None), sub("representation.schnet")):
+        _set(mod, "SchNet", R.SchNet, log)
+        _set(mod, "SchNetInteraction", R.SchNetInteraction, log)
+    for mod in (getattr(spk, "representation", None), sub("representation.painn")):
+        _set(mod, "PaiNN", R.PaiNN, log)
+        _set(mod, "PaiNNInteraction", R.PaiNNInteraction, log)
+        _set(mod, "PaiNNMixing", R.PaiNNMixing, log)
+    for mod in (getattr(spk, "atomistic", None), sub("atomistic.distances")):
+        _set(mod, "PairwiseDistances", A.PairwiseDistances, log)
+    # modules that did `from schnetpack.nn import scatter_add` / `import schnetpack.nn as snn` keep
+    # working: the first form is re-bound here, the second resolves the attribute at call time
+    for name in ("atomistic.atomwise", "nn.so3", "atomistic.electrostatic", "atomistic.nuclear_repulsion"):
+        m = sub(name)
+        if m is not None and getattr(m, "scatter_add", None) is not None:
+            m.scatter_add = N.scatter_add
+            log.append(m.__name__ + ".scatter_add")
+    if verbose:
+        print("schnetpack_amd.install: patched", ", ".join(log))
+    return log

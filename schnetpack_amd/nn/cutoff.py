@@ -25,9 +25,9 @@ class CosineCutoff(nn.Module):
 
     def cutoff_value(self) -> float:
         """Host copy of the cutoff radius (no device sync per call)."""
-        if getattr(self, "_cutoff_host", None) is None:
-            self._cutoff_host = float(self.cutoff.item())
-        return self._cutoff_host
+        if self.__dict__.get("_cutoff_host") is None:
+            self.__dict__["_cutoff_host"] = float(self.cutoff.item())
+        return self.__dict__["_cutoff_host"]
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)

@@ -44,7 +44,7 @@ class GaussianRBF(nn.Module):
 
     def forward(self, inputs: torch.Tensor):
         ops._check_float(inputs, "GaussianRBF")
-        if self.trainable or _needs_composite(self, inputs):
+        if getattr(self, "trainable", isinstance(self.offsets, nn.Parameter)) or _needs_composite(self, inputs):
             return gaussian_rbf(inputs, self.offsets, self.widths)
         return ops.RadialCutoffFn.apply(inputs, _lib.SPK_RBF_GAUSSIAN, self.offsets, self.widths, 1.0, True, False)
 

@@ -105,8 +105,21 @@ class PaiNN(nn.Module):
             lambda: PaiNNMixing(n_atom_basis=self.n_atom_basis, activation=activation, epsilon=epsilon),
             self.n_interactions, shared_interactions)
 
+    def _act(self):
+        # instances restored from reference pickles never ran this __init__
+        act = getattr(self, "_activation", None)
+        if act is None and len(self.interactions) > 0:
+            act = self.interactions[0].interatomic_context_net[0].activation
+        return act
+
+    def _eps(self) -> float:
+        eps = getattr(self, "epsilon", None)
+        if eps is None:
+            eps = self.mixing[0].epsilon if len(self.mixing) > 0 else 1e-8
+        return float(eps)
+
     def _fusable(self) -> bool:
-        return (activation_id(self._activation) == _lib.SPK_ACT_SILU
+        return (activation_id(self._act()) == _lib.SPK_ACT_SILU
                 and hasattr(self.radial_basis, "kernel_args")
                 and not getattr(self.radial_basis, "trainable", False)
                 and hasattr(self.cutoff_fn, "cutoff_value"))
@@ -136,7 +149,7 @@ class PaiNN(nn.Module):
                 setattr(arr[l], name, _lib.fptr(t))
             arr[l].filt_w = ctypes.c_void_p(fw.data_ptr() + 4 * row0 * n_rbf)
             arr[l].filt_b = ctypes.c_void_p(fb.data_ptr() + 4 * row0)
-        ms = _lib.PainnT(Fd, L, float(self.epsilon), 0, ctypes.cast(arr, ctypes.POINTER(_lib.PainnLayerT)))
+        ms = _lib.PainnT(Fd, L, self._eps(), 0, ctypes.cast(arr, ctypes.POINTER(_lib.PainnLayerT)))
         keep.append(arr)
         return ms, keep
 

@@ -77,8 +77,15 @@ class SchNet(nn.Module):
             n_interactions, shared_interactions)
 
     # -- fused eval path ---------------------------------------------------------------
+    def _act(self):
+        # instances restored from reference pickles never ran this __init__
+        act = getattr(self, "_activation", None)
+        if act is None and len(self.interactions) > 0:
+            act = self.interactions[0].filter_network[0].activation
+        return act
+
     def _fusable(self) -> bool:
-        return (activation_id(self._activation) == _lib.SPK_ACT_SSP
+        return (activation_id(self._act()) == _lib.SPK_ACT_SSP
                 and hasattr(self.radial_basis, "kernel_args")
                 and not getattr(self.radial_basis, "trainable", False)
                 and hasattr(self.cutoff_fn, "cutoff_value"))

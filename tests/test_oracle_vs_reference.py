@@ -75,3 +75,45 @@ def test_synthetic_neighbor_list_matches_reference_torch_list():
     mine = sorted(zip(b["idx_i"].tolist(), b["idx_j"].tolist()))
     assert ref == mine
     assert bool((out["_idx_i"][1:] >= out["_idx_i"][:-1]).all())
+
+
+def test_install_hook_patches_reference_namespace_and_pickles_resolve_to_mirrors():
+    """schnetpack_amd.install routes the hot-path names of the (shim-loaded) reference package to
+    the HIP-backed mirrors; the shipped whole-model pickle then unpickles into the mirror classes
+    with identical parameters."""
+    import sys
+    import numpy as np
+    import schnetpack_amd.install as inst
+    from schnetpack_amd import representation as R, nn as N
+    ns = refshim.load()
+    spk = sys.modules["schnetpack"]
+    spk.representation.SchNet = ns.schnet.SchNet
+    spk.representation.PaiNN = ns.painn.PaiNN
+    saved = {(m, k): getattr(sys.modules[m], k) for m, k in [
+        ("schnetpack.representation.painn", "PaiNN"), ("schnetpack.representation.painn", "PaiNNInteraction"),
+        ("schnetpack.representation.painn", "PaiNNMixing"), ("schnetpack.representation.schnet", "SchNet"),
+        ("schnetpack.representation.schnet", "SchNetInteraction"), ("schnetpack.nn", "scatter_add"),
+        ("schnetpack.nn", "Dense"), ("schnetpack.nn", "GaussianRBF"), ("schnetpack.nn", "BesselRBF"),
+        ("schnetpack.nn", "CosineCutoff"), ("schnetpack.nn.base", "Dense"), ("schnetpack.nn.radial", "GaussianRBF"),
+        ("schnetpack.nn.radial", "BesselRBF"), ("schnetpack.nn.cutoff", "CosineCutoff"),
+        ("schnetpack.nn.scatter", "scatter_add"), ("schnetpack.atomistic.distances", "PairwiseDistances"),
+        ("schnetpack.atomistic.atomwise", "scatter_add") if hasattr(sys.modules["schnetpack.atomistic.atomwise"], "scatter_add") else ("schnetpack.nn", "scatter_add")]}
+    try:
+        log = inst.install(spk)
+        assert "schnetpack.representation.painn.PaiNN" in log and "schnetpack.nn.scatter_add" in log
+        assert sys.modules["schnetpack.representation.painn"].PaiNN is R.PaiNN
+        assert spk.nn.scatter_add is N.scatter_add
+        sys.modules["ase.data"].atomic_masses = np.ones(119)
+        import os
+        path = os.path.join(refshim.REF_SRC, "..", "interfaces", "lammps", "examples", "aspirin", "best_model")
+        m = torch.load(path, map_location="cpu", weights_only=False)
+        assert isinstance(m.representation, R.PaiNN)
+        assert isinstance(m.representation.interactions[0].interatomic_context_net[0], N.Dense)
+        assert m.representation._fusable() and m.representation._eps() == pytest.approx(1e-8)
+        ms, keep = None, None
+        assert m.representation.filter_net.weight.shape == (768, 20)
+    finally:
+        for (mod, k), v in saved.items():
+            setattr(sys.modules[mod], k, v)
+        spk.representation.SchNet = ns.schnet.SchNet
+        spk.representation.PaiNN = ns.painn.PaiNN
