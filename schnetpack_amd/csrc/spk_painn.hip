@@ -43,7 +43,18 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int F = a.F;
   const int K = a.rb.n_rbf;
-  // register-resident filter weights of this lane's channels: part p in (q, R, mu)
+  // register-resident filter weights of this lane's channels: part p in (q, R, mu).  The slice
+  // [3F, K] is read once per workgroup with coalesced loads into a transposed, padded LDS image
+  // (conflict-free writes), from which every lane picks its rows.
+  extern __shared__ __attribute__((aligned(16))) float swf[];   // [K][3F + 1]
+  {
+    const int ld = 3 * F + 1;
+    for (int s = threadIdx.x; s < 3 * F * K; s += 256) {
+      const int row = s / K, k = s - row * K;
+      swf[k * ld + row] = a.wf[s];
+    }
+    __syncthreads();
+  }
   float w[3][VPL][NRBF];
   float bias[3][VPL];
 #pragma unroll
@@ -53,7 +64,7 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       const int row = p * F + VPL * lane + v;
       bias[p][v] = a.bf[row];
 #pragma unroll
-      for (int k = 0; k < NRBF; ++k) w[p][v][k] = (k < K) ? a.wf[(int64_t)row * K + k] : 0.f;
+      for (int k = 0; k < NRBF; ++k) w[p][v][k] = (k < K) ? swf[k * (3 * F + 1) + row] : 0.f;
     }
 
   for (int64_t atom = (int64_t)blockIdx.x * 4 + wv; atom < a.N; atom += (int64_t)gridDim.x * 4) {
@@ -87,75 +98,103 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       spk_cutoff_eval(a.rb.cutoff, dl, fcl, dfcl);
       float grx = 0.f, gry = 0.f, grz = 0.f;  // bwd: geometry gradient of this lane's edge
       const int n = (e1 - cs) < 64 ? (e1 - cs) : 64;
-      for (int t = 0; t < n; ++t) {
-        const int64_t j = __builtin_amdgcn_readlane(jl, t);
-        const float d = spk_readlane_f(dl, t);
-        const float ux = spk_readlane_f(uxl, t), uy = spk_readlane_f(uyl, t), uz = spk_readlane_f(uzl, t);
-        const float fc = spk_readlane_f(fcl, t), dfc = spk_readlane_f(dfcl, t);
-        // lane k evaluates phi_k(d)
-        float pl, dpl;
-        spk_rbf_eval(a.rb, lane, d, pl, dpl);
-        float P[3][VPL], Pd[3][VPL];
+      // neighbour rows are requested one edge ahead (explicit double buffer): the row kernel is
+      // bound by the latency of these dependent gathers, not by their bandwidth
+      constexpr bool PF = !BWD;  // the backward is register-bound (2 waves/SIMD matter more than the prefetch)
+      float cjr[PF ? 2 : 1][3][VPL], mujr[PF ? 2 : 1][3][VPL], gqbr[1][VPL], gmbr[1][3][VPL];
+      auto load_rows = [&](int slot, int t) {
+        const int64_t jj = __builtin_amdgcn_readlane(jl, t);
+        const float* cj = a.c + jj * 3 * F + fo;
+        const float* muj = a.mu + jj * 3 * F + fo;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-          for (int v = 0; v < VPL; ++v) { P[p][v] = bias[p][v]; Pd[p][v] = 0.f; }
+          for (int v = 0; v < VPL; ++v) { cjr[slot][p][v] = cj[p * F + v]; mujr[slot][p][v] = muj[p * F + v]; }
+        if (BWD) {
+          const float* gqb = a.gq_out + jj * F + fo;
+          const float* gmb = a.gmu_out + jj * 3 * F + fo;
 #pragma unroll
-        for (int k = 0; k < NRBF; ++k) {
-          const float s = spk_readlane_f(pl, k);
-          const float sd = BWD ? spk_readlane_f(dpl, k) : 0.f;
+          for (int v = 0; v < VPL; ++v) {
+            gqbr[0][v] = gqb[v];
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) {
-              P[p][v] = fmaf(w[p][v][k], s, P[p][v]);
-              if (BWD) Pd[p][v] = fmaf(w[p][v][k], sd, Pd[p][v]);
-            }
+            for (int p = 0; p < 3; ++p) gmbr[0][p][v] = gmb[p * F + v];
+          }
         }
-        const float* cj = a.c + j * 3 * F + fo;
-        const float* muj = a.mu + j * 3 * F + fo;
-        if (!BWD) {
+      };
+      if (PF) load_rows(0, 0);
+      for (int t2 = 0; t2 < n; t2 += 2) {
 #pragma unroll
-          for (int v = 0; v < VPL; ++v) {
-            const float mq = P[0][v] * fc * cj[v];
-            const float mR = P[1][v] * fc * cj[F + v];
-            const float mm = P[2][v] * fc * cj[2 * F + v];
-            accq[v] += mq;
-            accv[0][v] += mR * ux + mm * muj[v];
-            accv[1][v] += mR * uy + mm * muj[F + v];
-            accv[2][v] += mR * uz + mm * muj[2 * F + v];
-          }
-        } else {
-          const float* gqb = a.gq_out + j * F + fo;
-          const float* gmb = a.gmu_out + j * 3 * F + fo;
-          float dd = 0.f, tux = 0.f, tuy = 0.f, tuz = 0.f;
+        for (int par0 = 0; par0 < 2; ++par0) {
+          const int t = t2 + par0;
+          const int par = PF ? par0 : 0;
+          if (t < n) {
+            if (PF) { if (t + 1 < n) load_rows(par ^ 1, t + 1); }
+            else load_rows(0, t);
+            const float d = spk_readlane_f(dl, t);
+            const float ux = spk_readlane_f(uxl, t), uy = spk_readlane_f(uyl, t), uz = spk_readlane_f(uzl, t);
+            const float fc = spk_readlane_f(fcl, t), dfc = spk_readlane_f(dfcl, t);
+            // lane k evaluates phi_k(d)
+            float pl, dpl;
+            spk_rbf_eval(a.rb, lane, d, pl, dpl);
+            float P[3][VPL], Pd[3][VPL];
 #pragma unroll
-          for (int v = 0; v < VPL; ++v) {
-            const float Fq = P[0][v] * fc, FR = P[1][v] * fc, Fm = P[2][v] * fc;
-            const float dFq = Pd[0][v] * fc + P[0][v] * dfc;
-            const float dFR = Pd[1][v] * fc + P[1][v] * dfc;
-            const float dFm = Pd[2][v] * fc + P[2][v] * dfc;
-            const float cq = cj[v], cR = cj[F + v], cm = cj[2 * F + v];
-            const float mb0 = muj[v], mb1 = muj[F + v], mb2 = muj[2 * F + v];
-            const float gb0 = gmb[v], gb1 = gmb[F + v], gb2 = gmb[2 * F + v];
-            // (1) transposed sums for the centre atom acting as neighbour of b (reverse edge)
-            accq[v] += Fq * gqb[v];
-            accR[v] -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
-            accv[0][v] += Fm * gb0; accv[1][v] += Fm * gb1; accv[2][v] += Fm * gb2;
-            // (2) geometry gradient of edge (atom <- b)
-            const float gu = gma[0][v] * ux + gma[1][v] * uy + gma[2][v] * uz;
-            const float gm = gma[0][v] * mb0 + gma[1][v] * mb1 + gma[2][v] * mb2;
-            dd += cq * gqa[v] * dFq + cR * gu * dFR + cm * gm * dFm;
-            const float mR = FR * cR;
-            tux += gma[0][v] * mR; tuy += gma[1][v] * mR; tuz += gma[2][v] * mR;
-          }
-          dd = spk_wave_sum(dd); tux = spk_wave_sum(tux); tuy = spk_wave_sum(tuy); tuz = spk_wave_sum(tuz);
-          if (lane == t) {
-            const float dot = tux * ux + tuy * uy + tuz * uz;
-            const float invd = 1.0f / d;
-            grx = dd * ux + (tux - dot * ux) * invd;
-            gry = dd * uy + (tuy - dot * uy) * invd;
-            grz = dd * uz + (tuz - dot * uz) * invd;
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int v = 0; v < VPL; ++v) { P[p][v] = bias[p][v]; Pd[p][v] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < NRBF; ++k) {
+              const float s = spk_readlane_f(pl, k);
+              const float sd = BWD ? spk_readlane_f(dpl, k) : 0.f;
+#pragma unroll
+              for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                  P[p][v] = fmaf(w[p][v][k], s, P[p][v]);
+                  if (BWD) Pd[p][v] = fmaf(w[p][v][k], sd, Pd[p][v]);
+                }
+            }
+            if (!BWD) {
+#pragma unroll
+              for (int v = 0; v < VPL; ++v) {
+                const float mq = P[0][v] * fc * cjr[par][0][v];
+                const float mR = P[1][v] * fc * cjr[par][1][v];
+                const float mm = P[2][v] * fc * cjr[par][2][v];
+                accq[v] += mq;
+                accv[0][v] += mR * ux + mm * mujr[par][0][v];
+                accv[1][v] += mR * uy + mm * mujr[par][1][v];
+                accv[2][v] += mR * uz + mm * mujr[par][2][v];
+              }
+            } else {
+              float dd = 0.f, tux = 0.f, tuy = 0.f, tuz = 0.f;
+#pragma unroll
+              for (int v = 0; v < VPL; ++v) {
+                const float Fq = P[0][v] * fc, FR = P[1][v] * fc, Fm = P[2][v] * fc;
+                const float dFq = Pd[0][v] * fc + P[0][v] * dfc;
+                const float dFR = Pd[1][v] * fc + P[1][v] * dfc;
+                const float dFm = Pd[2][v] * fc + P[2][v] * dfc;
+                const float cq = cjr[par][0][v], cR = cjr[par][1][v], cm = cjr[par][2][v];
+                const float mb0 = mujr[par][0][v], mb1 = mujr[par][1][v], mb2 = mujr[par][2][v];
+                const float gb0 = gmbr[0][0][v], gb1 = gmbr[0][1][v], gb2 = gmbr[0][2][v];
+                // (1) transposed sums for the centre atom acting as neighbour of b (reverse edge)
+                accq[v] += Fq * gqbr[0][v];
+                accR[v] -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
+                accv[0][v] += Fm * gb0; accv[1][v] += Fm * gb1; accv[2][v] += Fm * gb2;
+                // (2) geometry gradient of edge (atom <- b)
+                const float gu = gma[0][v] * ux + gma[1][v] * uy + gma[2][v] * uz;
+                const float gm = gma[0][v] * mb0 + gma[1][v] * mb1 + gma[2][v] * mb2;
+                dd += cq * gqa[v] * dFq + cR * gu * dFR + cm * gm * dFm;
+                const float mR = FR * cR;
+                tux += gma[0][v] * mR; tuy += gma[1][v] * mR; tuz += gma[2][v] * mR;
+              }
+              dd = spk_wave_sum(dd); tux = spk_wave_sum(tux); tuy = spk_wave_sum(tuy); tuz = spk_wave_sum(tuz);
+              if (lane == t) {
+                const float dot = tux * ux + tuy * uy + tuz * uz;
+                const float invd = 1.0f / d;
+                grx = dd * ux + (tux - dot * ux) * invd;
+                gry = dd * uy + (tuy - dot * uy) * invd;
+                grz = dd * uz + (tuz - dot * uz) * invd;
+              }
+            }
           }
         }
       }
@@ -293,10 +332,12 @@ static int msg_dispatch(const MsgArgs& a, bool row_ok, hipStream_t stream, const
   const bool shape_ok = row_ok && (F == 64 || F == 128) && K <= 32;
   SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || shape_ok, "%s: shape F=%d n_rbf=%d (or unsorted/asymmetric list) not supported by the row kernel", who, F, K);
   if (shape_ok && variant != SPK_VARIANT_SIMPLE) {
-    const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 8);
+    // persistent waves: every wave walks several CSR rows, so the per-wave weight set-up is amortised
+    const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 2);
+    const size_t lds = (size_t)K * (3 * F + 1) * sizeof(float);
     SpkProfScope prof(BWD ? "painn_msg_bwd_row" : "painn_msg_fwd_row", stream);
 #define SPK_MSG_CASE(VPLv, NRBFv)                                                              \
-  hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD>), dim3(grid), dim3(256), 0, stream, a)
+  hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD>), dim3(grid), dim3(256), lds, stream, a)
     if (F == 64) { if (K <= 20) SPK_MSG_CASE(1, 20); else SPK_MSG_CASE(1, 32); }
     else { if (K <= 20) SPK_MSG_CASE(2, 20); else SPK_MSG_CASE(2, 32); }
 #undef SPK_MSG_CASE

@@ -5,9 +5,15 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider --tb=line 2>&1 | tail -25 > $OUT/pytest.log
+timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider --tb=line -x 2>&1 | tail -6 > $OUT/pytest.log
 cat $OUT/pytest.log
-timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_schnet.json 2> $OUT/bench.err
-echo rc=$?; cat $OUT/bench_schnet.json; grep -v amdgpu.ids $OUT/bench.err | grep -v Warning | tail -5
-timeout 300 python bench.py --kind painn --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_painn.json 2> $OUT/bench2.err
-echo rc=$?; cat $OUT/bench_painn.json; grep -v amdgpu.ids $OUT/bench2.err | grep -v Warning | tail -5
+for K in schnet painn; do
+timeout 300 python bench.py --kind $K --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_$K.json 2> $OUT/bench_$K.err
+echo rc=$?; python - <<PY
+import json
+d=json.load(open("$OUT/bench_$K.json"))
+print("$K", d["value"], "M edge-msg/s", d["ms_per_step"], "ms/step graph", d["config"]["hip_graph"])
+for k,v in sorted(d["kernels"].items()): print("   %-24s x%.0f  %.1f us  -> %.0f us/step" % (k, v["launches_per_step"], v["avg_us"], v["us_per_step"]))
+print("   roofline", d["roofline"])
+PY
+done
