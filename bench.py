@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the force call in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=15)
-    ap.add_argument("--variant", default="auto", choices=["auto", "simple", "mfma"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "simple", "mfma", "directed", "pair", "mol"])
     return ap.parse_args()
 
 
@@ -65,7 +65,8 @@ def main():
     from schnetpack_amd import _lib, model as M, synthetic as S
     from schnetpack_amd.parallel import shard_frames
 
-    _lib.set_variant({"auto": _lib.VARIANT_AUTO, "simple": _lib.VARIANT_SIMPLE, "mfma": _lib.VARIANT_MFMA}[args.variant])
+    _lib.set_variant({"auto": _lib.VARIANT_AUTO, "simple": _lib.VARIANT_SIMPLE, "mfma": _lib.VARIANT_MFMA,
+                      "directed": _lib.VARIANT_MFMA_DIRECTED, "pair": _lib.VARIANT_MFMA_PAIR, "mol": _lib.VARIANT_MFMA_MOL}[args.variant])
     n_int, F, n_rbf, cutoff = 3, 128, 20, 5.0
     rep_p = O.init_schnet_params() if args.kind == "schnet" else O.init_painn_params()
     head_p = O.init_atomwise_params(F, seed=1)

@@ -41,6 +41,8 @@ extern "C" {
 #define SPK_VARIANT_SIMPLE 1  /* straightforward HIP kernels (any shape), used as cross-check */
 #define SPK_VARIANT_MFMA 2    /* force the MFMA kernels (error if shape unsupported) */
 #define SPK_VARIANT_MFMA_DIRECTED 3 /* MFMA kernels, but one filter per DIRECTED edge even on symmetric lists */
+#define SPK_VARIANT_MFMA_PAIR 4     /* pair kernels (the default on symmetric lists) */
+#define SPK_VARIANT_MFMA_MOL 5      /* experiment: group-local pair kernel accumulating in LDS (block-diagonal lists) */
 
 /* Radial basis x cosine cutoff description (nn/radial.py, nn/cutoff.py:14-57).
  * gaussian: p0 = offsets[n_rbf], p1 = widths[n_rbf];  bessel: p0 = freqs[n_rbf], p1 unused. */
@@ -65,6 +67,15 @@ typedef struct {
   const int32_t* rev;     /* [E] index of the reversed edge (valid iff symmetric); may be NULL */
   const int32_t* half;    /* [n_half] the canonical edge of every undirected pair (e < rev[e]), ascending; may be NULL */
   int64_t n_half;         /* = E/2 on a symmetric list */
+  /* optional block-diagonal structure (batches of molecules): consecutive atom ranges that no edge leaves.
+   * [n_groups+1] prefix arrays: first atom, first entry in `half`, first 32-pair tile (tiles aligned to
+   * groups).  n_groups == 0: unknown / not block diagonal. */
+  const int32_t* grp_atom0;
+  const int32_t* grp_pair0;
+  const int32_t* grp_tile0;
+  int32_t n_groups;
+  int32_t max_group_atoms;
+  int64_t n_tiles_grouped; /* = grp_tile0[n_groups] */
 } spk_graph_t;
 
 /* ------------------------------------------------------------------ library / device info */
@@ -183,6 +194,10 @@ int spk_schnet_cfconv_bwd_f32(const spk_graph_t* g, const spk_radial_t* rb, cons
                               const float* b1, const float* w2, const float* b2, int32_t nf,
                               float* gh, float* gr, void* stream);
 
+/* Kernel-tuning aid: device buffer (>= 32 int64) that receives shader-clock stamps of wave 0 of workgroup 0
+ * at the phase boundaries of the pair kernels; NULL disables it (default). */
+void spk_cfconv_set_debug_buffer(void* device_buffer);
+
 /* Whole SchNet representation (representation/schnet.py:147-173), eval-mode force path.
  * Parameter block: pointers to the reference state_dict tensors of every interaction. */
 typedef struct {
@@ -195,6 +210,11 @@ typedef struct {
   const float* f2out_b1; /* interactions.l.f2out.0.bias           [F]  */
   const float* f2out_w2; /* interactions.l.f2out.1.weight         [F, F] */
   const float* f2out_b2; /* interactions.l.f2out.1.bias           [F]  */
+  /* optional transposed copies ([in, out] row-major) of the three atom-wise weights: with them the
+   * forward chains read the weights with coalesced loads; NULL = use the [out, in] originals */
+  const float* in2f_wT;   /* [F, nf] */
+  const float* f2out_w1T; /* [nf, F] */
+  const float* f2out_w2T; /* [F, F]  */
 } spk_schnet_layer_t;
 
 typedef struct {
@@ -275,6 +295,12 @@ typedef struct {
   const float* ictx_b1; /* ...0.bias [F] */
   const float* ictx_w2; /* mixing.l.intraatomic_context_net.1.weight [3F, F] */
   const float* ictx_b2; /* ...1.bias [3F] */
+  /* optional transposed copies ([in, out] row-major) for coalesced weight reads in the forward; NULL = unused */
+  const float* ctx_w1T;  /* [F, F]   */
+  const float* ctx_w2T;  /* [F, 3F]  */
+  const float* mix_wT;   /* [F, 2F]  */
+  const float* ictx_w1T; /* [2F, F]  */
+  const float* ictx_w2T; /* [F, 3F]  */
 } spk_painn_layer_t;
 
 typedef struct {

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libspk_hip.so")
 
 SPK_ACT_NONE, SPK_ACT_SSP, SPK_ACT_SILU = 0, 1, 2
 SPK_RBF_GAUSSIAN, SPK_RBF_BESSEL = 0, 1
-VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_MFMA, VARIANT_MFMA_DIRECTED = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_MFMA, VARIANT_MFMA_DIRECTED, VARIANT_MFMA_PAIR, VARIANT_MFMA_MOL = 0, 1, 2, 3, 4, 5
 
 c_f = ctypes.c_void_p  # device pointers travel as void*
 c_i64 = ctypes.c_int64
@@ -34,12 +34,13 @@ class RadialT(ctypes.Structure):
 class GraphT(ctypes.Structure):
     _fields_ = [("n_atoms", c_i64), ("n_edges", c_i64), ("idx_i", c_f), ("idx_j", c_f),
                 ("rowptr", c_f), ("sorted", c_i32), ("symmetric", c_i32), ("rev", c_f), ("half", c_f),
-                ("n_half", c_i64)]
+                ("n_half", c_i64), ("grp_atom0", c_f), ("grp_pair0", c_f), ("grp_tile0", c_f),
+                ("n_groups", c_i32), ("max_group_atoms", c_i32), ("n_tiles_grouped", c_i64)]
 
 
 class SchnetLayerT(ctypes.Structure):
     _fields_ = [(n, c_f) for n in ("in2f_w", "fn_w1", "fn_b1", "fn_w2", "fn_b2", "f2out_w1",
-                                   "f2out_b1", "f2out_w2", "f2out_b2")]
+                                   "f2out_b1", "f2out_w2", "f2out_b2", "in2f_wT", "f2out_w1T", "f2out_w2T")]
 
 
 class SchnetT(ctypes.Structure):
@@ -59,7 +60,8 @@ class ChainT(ctypes.Structure):
 
 class PainnLayerT(ctypes.Structure):
     _fields_ = [(n, c_f) for n in ("ctx_w1", "ctx_b1", "ctx_w2", "ctx_b2", "filt_w", "filt_b",
-                                   "mix_w", "ictx_w1", "ictx_b1", "ictx_w2", "ictx_b2")]
+                                   "mix_w", "ictx_w1", "ictx_b1", "ictx_w2", "ictx_b2",
+                                   "ctx_w1T", "ctx_w2T", "mix_wT", "ictx_w1T", "ictx_w2T")]
 
 
 class PainnT(ctypes.Structure):
@@ -90,6 +92,7 @@ _PROTOS = {
     "spk_dense_chain_f32": (ctypes.c_int, [P(ChainT), c_f]),
     "spk_schnet_cfconv_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f]),
     "spk_schnet_cfconv_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
+    "spk_cfconv_set_debug_buffer": (None, [c_f]),
     "spk_schnet_saved_floats": (c_i64, [P(SchnetT), c_i64]),
     "spk_schnet_saved_floats_graph": (c_i64, [P(SchnetT), P(GraphT), P(RadialT)]),
     "spk_schnet_scratch_floats": (c_i64, [P(SchnetT), c_i64]),

@@ -35,11 +35,17 @@ struct CfArgs {
   float* gr;           // bwd: [E, 3] accumulated
   int64_t E;
   int64_t N;
+  long long* dbg;       // optional: cycle stamps of wave 0 / workgroup 0 (kernel tuning aid)
   float* gsave;         // fwd: optional [n_tiles*32, NF] raw filter-MLP outputs g_e (before the cutoff)
   const float* gload;   // bwd: the same buffer written by the forward of this interaction (or null)
   const int32_t* half;  // pair kernel: canonical edge of every undirected pair
   const int32_t* rev;   // pair kernel: reversed edge
   int64_t n_half;
+  const int32_t* grp_atom0;  // mol kernel: [G+1] first atom of every group
+  const int32_t* grp_pair0;  // [G+1] first entry of the group in `half`
+  const int32_t* grp_tile0;  // [G+1] first (group-aligned) tile of the group
+  int n_groups;
+  int max_group_atoms;
   RadialDev rb;
 };
 
@@ -381,20 +387,298 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_mfma(CfArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Pair kernel: on a symmetric neighbour list the filter of an edge and of its reverse are identical
+// Pair kernels: on a symmetric neighbour list the filter of an edge and of its reverse are identical
 // (they depend on d only), so one tile holds 32 UNDIRECTED pairs (the canonical edge e < rev[e] of
 // each) and the filter MLP -- the MFMA work -- is evaluated once per pair, i.e. half as often:
 //   forward :  y[i] += h[j] * W_e            and   y[j] += h[i] * W_e
 //   backward:  gh[i] += gy[j] * W_e          and   gh[j] += gy[i] * W_e
 //              gr[e]  += (sum gy[i] h[j] W'_e) r_e / d   and   gr[rev e] -= (sum gy[j] h[i] W'_e) r_e / d
-// The transposition buffer carries the contribution to the centre atom in columns 0..31 (idx_i is
-// sorted inside the half list => segmented flush) and the contribution to the neighbour in columns
-// 32..63 (flushed per edge); both as coalesced 128-byte float atomics.
+//
+// GEMM 2 runs with SWAPPED operands (A = hidden activations, lane = pair; B = packed W2): the output
+// tile then has rows = pairs and columns = channels, i.e. every lane owns one channel and its 16
+// accumulator registers are 16 pairs of the tile.  Consequences: the neighbour rows are gathered as
+// coalesced 128-byte row segments (lanes = consecutive channels), the per-centre-atom sum is a
+// per-lane running sum over registers (idx_i is sorted inside the half list: flush at run ends), no
+// LDS transposition is needed, and every flush is a coalesced float atomic.
+//
+// GS (backward): the raw filter outputs g_e were saved by the forward kernel, so only the derivative
+// GEMM (g') runs: 96 + 256 MFMAs per tile instead of 96 + 512.
+// MOL: the list is block diagonal with small blocks (a batch of molecules): a workgroup owns whole
+// groups of atoms, accumulates their rows in LDS (conflict-free ds_add_f32: lanes = channels) and writes
+// them once -- no global atomics, no memset.  Tiles are aligned to the groups.
 // ------------------------------------------------------------------------------------------
-// GS (backward only): the raw filter outputs g_e were saved by the forward kernel, so only the
-// derivative GEMM (g') runs here: 96 + 256 MFMAs per tile instead of 96 + 512, and z need not stay live.
-template <int NF, int KPB, int NWAVES, bool BWD, bool GS>
+struct __attribute__((aligned(16))) EdgeRec { int i; int j; float fc; float dfc; };
+
+// register r of the half hi holds pair (r & 3) + 8 (r >> 2) + 4 hi of the tile
+__device__ __forceinline__ int pair_of(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+template <int NF, int KPB, int NWAVES, bool BWD, bool GS, bool MOL>
 __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
+  constexpr int NT = NF / 32;
+  constexpr int KB2 = NF / 8;
+#define SPK_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
+  SPK_STAMP(0);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW2 = smem;                                   // NF*NF
+  float* sW1 = sW2 + NF * NF;                          // NF*KPB*8
+  float* sb1 = sW1 + NF * KPB * 8;                     // NF
+  float* sb2 = sb1 + NF;                               // NF
+  EdgeRec* sE = (EdgeRec*)(sb2 + NF);                  // NWAVES * 32 records
+  constexpr int DS = BWD ? 2 * 32 * 33 : 0;            // backward: per-wave [2][32 pairs][32 lanes + 1 pad] partial sums
+  float* sD = (float*)(sE + NWAVES * 32);              // NWAVES * DS floats
+  float* sY = sD + NWAVES * DS;                        // MOL: max_group_atoms * NF
+  int* sCnt = (int*)(sY + (MOL ? (int64_t)a.max_group_atoms * NF : 0));
+
+  stage_packed<NWAVES * 64, NF * NF / 4>(sW2, a.w2, NF, KB2);
+  stage_packed<NWAVES * 64, NF * KPB * 2>(sW1, a.w1, a.rb.n_rbf, KPB);
+  for (int s = threadIdx.x; s < NF; s += NWAVES * 64) { sb1[s] = a.b1[s]; sb2[s] = a.b2[s]; }
+  if (!MOL && threadIdx.x == 0) sCnt[0] = 0;
+  __syncthreads();
+  SPK_STAMP(1);
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  EdgeRec* myE = sE + wv * 32;
+  float* myD = sD + wv * DS;
+
+  const int ngroups = MOL ? a.n_groups : 1;
+  for (int grp = MOL ? (int)blockIdx.x : 0; grp < ngroups; grp += MOL ? (int)gridDim.x : 1) {
+    int ga0 = 0, ga1 = 0, gp0 = 0, gp1 = (int)a.n_half, gt0 = 0;
+    if (MOL) {
+      ga0 = a.grp_atom0[grp]; ga1 = a.grp_atom0[grp + 1];
+      gp0 = a.grp_pair0[grp]; gp1 = a.grp_pair0[grp + 1];
+      gt0 = a.grp_tile0[grp];
+      for (int s2 = threadIdx.x; s2 < (ga1 - ga0) * NF; s2 += NWAVES * 64) sY[s2] = 0.f;
+      if (threadIdx.x == 0) sCnt[0] = 0;
+      __syncthreads();
+    }
+    const int gtiles = (gp1 - gp0 + 31) / 32;
+
+    while (true) {
+      int nidx = 0;
+      if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
+      nidx = __builtin_amdgcn_readfirstlane(nidx);
+      // MOL: the group's tiles; otherwise tiles blockIdx.x + n * gridDim.x of the whole list
+      const int ltile = MOL ? nidx : (int)blockIdx.x + nidx * (int)gridDim.x;
+      if (ltile >= gtiles) break;
+      const int64_t gtile = (int64_t)gt0 + ltile;        // addresses the saved filters
+
+      // ---- per-pair geometry (lanes 32..63 mirror lanes 0..31)
+      const int pfirst = gp0 + 32 * ltile;
+      const int nvalid = (gp1 - pfirst) < 32 ? (gp1 - pfirst) : 32;
+      const bool valid = el < nvalid;
+      const int64_t e = a.half[pfirst + (valid ? el : (nvalid - 1))];
+      const int64_t e2 = a.rev[e];
+      const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+      const int i = (int)a.idx_i[e], j = (int)a.idx_j[e];
+      const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+      float fc, dfc;
+      spk_cutoff_eval_fast(a.rb.cutoff, d, fc, dfc);
+      if (!valid) { fc = 0.f; dfc = 0.f; }
+      if (hi == 0) { EdgeRec er; er.i = i - ga0; er.j = j - ga0; er.fc = fc; er.dfc = dfc; myE[el] = er; }
+
+      float phi[KPB][4], dphi[BWD ? KPB : 1][4];
+#pragma unroll
+      for (int u = 0; u < KPB; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float p, dp;
+          spk_rbf_eval_fast(a.rb, 8 * u + 4 * hi + v, d, p, dp);
+          phi[u][v] = p;
+          if (BWD) dphi[BWD ? u : 0][v] = dp;
+        }
+      SPK_STAMP(2);
+
+      // ---- GEMM 1 (rows = hidden channels, columns = pairs): a = W1 phi + b1; z = ssp(a); z' = sigma(a) W1 phi'
+      f32x16 z[(BWD && GS) ? 1 : NT];
+      f32x16 zp[BWD ? NT : 1];
+      {
+        f32x4 wq = *(const f32x4*)(sW1 + lane * 4);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+          f32x16 zc, zq;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { zc[r] = sb1[32 * c + pair_of(r, hi)]; zq[r] = 0.f; }
+#pragma unroll
+          for (int u = 0; u < KPB; ++u) {
+            const int nxt = c * KPB + u + 1;
+            f32x4 wn = wq;
+            if (nxt < NT * KPB) wn = *(const f32x4*)(sW1 + (nxt * 64 + lane) * 4);
+            zc = SPK_MFMA(wq.x, phi[u][0], zc);
+            zc = SPK_MFMA(wq.y, phi[u][1], zc);
+            zc = SPK_MFMA(wq.z, phi[u][2], zc);
+            zc = SPK_MFMA(wq.w, phi[u][3], zc);
+            if (BWD) {
+              zq = SPK_MFMA(wq.x, dphi[BWD ? u : 0][0], zq);
+              zq = SPK_MFMA(wq.y, dphi[BWD ? u : 0][1], zq);
+              zq = SPK_MFMA(wq.z, dphi[BWD ? u : 0][2], zq);
+              zq = SPK_MFMA(wq.w, dphi[BWD ? u : 0][3], zq);
+            }
+            wq = wn;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float sp, sg;
+            spk_fast_softplus_sigmoid(zc[r], sp, sg);
+            zc[r] = sp - SPK_LN2_F;
+            if (BWD) zq[r] *= sg;
+          }
+          if (!(BWD && GS)) z[(BWD && GS) ? 0 : c] = zc;
+          if (BWD) zp[BWD ? c : 0] = zq;
+        }
+      }
+      spk_wave_lds_sync();   // myE visible to the whole wave
+      // run structure of this lane's 16 pairs: bit r set <=> the centre atom changes after register r
+      unsigned runmask = 0x8000u;
+      {
+        int prev = myE[pair_of(0, hi)].i;
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+          const int cur = myE[pair_of(r, hi)].i;
+          if (cur != prev) runmask |= 1u << (r - 1);
+          prev = cur;
+        }
+      }
+      // backward: the per-pair sums over channels run over LANES in this layout; every lane keeps its
+      // partial (pair, lane) in LDS (own slot, no atomics), the pair owners add the 32 partials at the end
+      SPK_STAMP(3);
+
+      // ---- per output tile t: gathers, GEMM 2 (rows = pairs, columns = channels), modulation, sums
+#pragma unroll 1
+      for (int t = 0; t < NT; ++t) {
+        const int c0 = 32 * t + el;   // this lane's channel
+        // forward / recomputing backward: all neighbour rows of the tile are requested before the MFMAs.
+        // Saved-filter backward (2 waves/SIMD => 256 VGPRs): rows are requested after the MFMAs, 8 pairs
+        // at a time, to bound the live registers.
+        constexpr bool LATE = BWD && GS;
+        constexpr int RG = LATE ? 8 : 16;   // pairs per gather group
+        float hj[RG], hc[RG], gyi[BWD ? RG : 1], gyj[BWD ? RG : 1];
+        if (!LATE) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const EdgeRec er = myE[pair_of(r, hi)];
+            // 32-bit element offsets (n_atoms * nf < 2^31, checked by the launcher): one VGPR per address
+            const unsigned oi = (unsigned)(er.i + ga0) * NF + c0, oj = (unsigned)(er.j + ga0) * NF + c0;
+            hj[LATE ? 0 : r] = a.h[oj];
+            hc[LATE ? 0 : r] = a.h[oi];
+            if (BWD) { gyi[(BWD && !LATE) ? r : 0] = a.gy[oi]; gyj[(BWD && !LATE) ? r : 0] = a.gy[oj]; }
+          }
+        }
+        f32x16 g, gp;
+        const float bias2 = sb2[c0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g[r] = bias2; gp[r] = 0.f; }
+        {
+          const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
+          f32x4 wq = *(const f32x4*)wbase;
+#pragma unroll
+          for (int ug = 0; ug < KB2; ++ug) {
+            const int c = ug >> 2, q = ug & 3;
+            f32x4 wn = wq;
+            if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
+            if (!GS) {
+              const f32x16& zc = z[(BWD && GS) ? 0 : c];
+              g = SPK_MFMA(zc[4 * q + 0], wq.x, g);
+              g = SPK_MFMA(zc[4 * q + 1], wq.y, g);
+              g = SPK_MFMA(zc[4 * q + 2], wq.z, g);
+              g = SPK_MFMA(zc[4 * q + 3], wq.w, g);
+            }
+            if (BWD) {
+              const f32x16& zq = zp[BWD ? c : 0];
+              gp = SPK_MFMA(zq[4 * q + 0], wq.x, gp);
+              gp = SPK_MFMA(zq[4 * q + 1], wq.y, gp);
+              gp = SPK_MFMA(zq[4 * q + 2], wq.z, gp);
+              gp = SPK_MFMA(zq[4 * q + 3], wq.w, gp);
+            }
+            wq = wn;
+          }
+        }
+        SPK_STAMP(4 + 3 * t);
+        if (!BWD && a.gsave) {
+          float* gts = a.gsave + gtile * 32 * NF;   // this tile's filters, saved for the backward
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gts[(unsigned)pair_of(r, hi) * NF + c0] = g[r];
+        }
+        // lane = channel c0: running sum over this lane's pairs for the centre atoms, one add per pair
+        // for the neighbours
+        float acc = 0.f;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += RG) {
+          float gl[LATE ? RG : 1];
+          if (LATE) {
+            __builtin_amdgcn_sched_barrier(0);   // keep the second gather group behind the first group's math
+            const float* gtp = a.gload + gtile * 32 * NF;
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr) {
+              const EdgeRec er = myE[pair_of(r0 + rr, hi)];
+              const unsigned oi = (unsigned)(er.i + ga0) * NF + c0, oj = (unsigned)(er.j + ga0) * NF + c0;
+              hj[rr] = a.h[oj]; hc[rr] = a.h[oi];
+              gyi[BWD ? rr : 0] = a.gy[oi]; gyj[BWD ? rr : 0] = a.gy[oj];
+              gl[LATE ? rr : 0] = gtp[(unsigned)pair_of(r0 + rr, hi) * NF + c0];
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < RG; ++rr) {
+            const int r = r0 + rr;
+            const EdgeRec er = myE[pair_of(r, hi)];
+            const float gv = LATE ? gl[LATE ? rr : 0] : g[r];
+            const float W = gv * er.fc;
+            float toI, toJ;
+            if (!BWD) {
+              toI = W * hj[rr];
+              toJ = W * hc[rr];
+            } else {
+              const float D = gp[r] * er.fc + gv * er.dfc;
+              float* slot = myD + pair_of(r, hi) * 33 + el;
+              const float p1 = gyi[BWD ? rr : 0] * hj[rr] * D, p2 = gyj[BWD ? rr : 0] * hc[rr] * D;
+              if (t == 0) { slot[0] = p1; slot[32 * 33] = p2; }
+              else { slot[0] += p1; slot[32 * 33] += p2; }
+              toI = W * gyj[BWD ? rr : 0];
+              toJ = W * gyi[BWD ? rr : 0];
+            }
+            acc += toI;
+            if (MOL) {
+              atomicAdd(sY + er.j * NF + c0, toJ);
+              if ((runmask >> r) & 1u) { atomicAdd(sY + er.i * NF + c0, acc); acc = 0.f; }
+            } else {
+              unsafeAtomicAdd(a.y + ((unsigned)er.j * NF + c0), toJ);
+              if ((runmask >> r) & 1u) { unsafeAtomicAdd(a.y + ((unsigned)er.i * NF + c0), acc); acc = 0.f; }
+            }
+          }
+        }
+        SPK_STAMP(6 + 3 * t);
+      }
+      if (BWD) {
+        spk_wave_lds_sync();
+        if (hi == 0 && valid && d > 0.f) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int k2 = 0; k2 < 32; ++k2) { s1 += myD[el * 33 + k2]; s2 += myD[32 * 33 + el * 33 + k2]; }
+          s1 /= d; s2 /= d;
+          a.gr[3 * e] += s1 * rx; a.gr[3 * e + 1] += s1 * ry; a.gr[3 * e + 2] += s1 * rz;
+          a.gr[3 * e2] -= s2 * rx; a.gr[3 * e2 + 1] -= s2 * ry; a.gr[3 * e2 + 2] -= s2 * rz;
+        }
+      }
+      spk_wave_lds_sync();   // myE / myD may be rewritten by the next tile
+      SPK_STAMP(20);
+    }
+    if (MOL) {
+      // the group's rows are complete: one coalesced store per row
+      __syncthreads();
+      for (int s2 = threadIdx.x; s2 < (ga1 - ga0) * NF; s2 += NWAVES * 64) a.y[(int64_t)ga0 * NF + s2] = sY[s2];
+      __syncthreads();
+    }
+  }
+  SPK_STAMP(21);
+#undef SPK_STAMP
+}
+
+// Transposition variant of the pair kernel (GEMM 2 with rows = channels, columns = pairs; the products
+// go through a per-wave LDS transposition buffer before the segmented flush).  Its per-pair sums over
+// channels are per-LANE sums over registers, which saves ~30 VGPRs against the lane = channel layout:
+// the saved-filter backward fits 2 waves/SIMD only in this form, so it is the one dispatched for it.
+template <int NF, int KPB, int NWAVES, bool BWD, bool GS>
+__global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_t(CfArgs a) {
   constexpr int NT = NF / 32;
   constexpr int KB2 = NF / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -639,12 +923,36 @@ static int launch_mfma(const CfArgs& a, hipStream_t stream) {
   return SPK_OK;
 }
 
-template <int NF, int KPB, bool BWD, bool GS>
+template <int NF, int KPB, bool BWD, bool GS, bool MOL>
 static int launch_pair(const CfArgs& a, hipStream_t stream) {
-  // forward and the saved-filter backward fit 2 waves/SIMD; the recomputing backward needs 1 wave/SIMD
+  // forward and the saved-filter backward: 2 waves/SIMD (<= 256 VGPRs); recomputing backward: 1 wave/SIMD
   constexpr int NWAVES = (BWD && !GS) ? 4 : 8;
+  const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + (BWD ? NWAVES * 2 * 32 * 33 : 0) + (MOL ? (size_t)a.max_group_atoms * NF : 0)) * sizeof(float) +
+                     (size_t)NWAVES * 32 * sizeof(EdgeRec) + 4 * sizeof(int);
+  auto kern = k_cfconv_pair<NF, KPB, NWAVES, BWD, GS, MOL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  int grid;
+  if (MOL) grid = a.n_groups;
+  else grid = (int)(((a.n_half + 31) / 32 + NWAVES - 1) / NWAVES);
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  if (grid < 1) grid = 1;
+  SpkProfScope prof(BWD ? (GS ? (MOL ? "cfconv_bwd_mol_gs" : "cfconv_bwd_pair_gs") : (MOL ? "cfconv_bwd_mol" : "cfconv_bwd_pair"))
+                        : (MOL ? "cfconv_fwd_mol" : "cfconv_fwd_pair"), stream);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+template <int NF, int KPB>
+static int launch_pair_t_bwd_gs(const CfArgs& a, hipStream_t stream) {
+  constexpr int NWAVES = 8;
   const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + NWAVES * 32 * TP2) * sizeof(float) + 4 * sizeof(int);
-  auto kern = k_cfconv_pair<NF, KPB, NWAVES, BWD, GS>;
+  auto kern = k_cfconv_pair_t<NF, KPB, NWAVES, true, true>;
   static bool attr_set = false;
   if (!attr_set) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -655,10 +963,17 @@ static int launch_pair(const CfArgs& a, hipStream_t stream) {
   const int maxg = spk_num_cus();
   if (grid > maxg) grid = maxg;
   if (grid < 1) grid = 1;
-  SpkProfScope prof(BWD ? (GS ? "cfconv_bwd_pair_gs" : "cfconv_bwd_pair") : "cfconv_fwd_pair", stream);
+  SpkProfScope prof("cfconv_bwd_pair_gs", stream);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
+}
+
+// largest group (atoms) whose LDS accumulator fits next to the staged weights
+static int mol_max_atoms(int NF, int kpb) {
+  const size_t fixed = (size_t)(NF * NF + NF * kpb * 8 + 2 * NF + 8 * 2 * 32 * 33) * sizeof(float) + 8 * 32 * sizeof(EdgeRec) + 64;
+  const size_t avail = 160 * 1024 - fixed;
+  return (int)(avail / (NF * sizeof(float)));
 }
 
 template <bool BWD>
@@ -682,11 +997,18 @@ static int cfconv_dispatch(const CfArgs& a, int NF, bool sym, hipStream_t stream
   const bool mfma_ok = (NF == 128 || NF == 64) && kpb >= 1 && kpb <= 4 && al;
   SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || mfma_ok, "%s: shape nf=%d n_rbf=%d not supported by the MFMA kernel", who, NF, a.rb.n_rbf);
   if (!mfma_ok || variant == SPK_VARIANT_SIMPLE) return launch_simple<BWD>(a, NF, sym ? 1 : 0, stream);
-  const bool pair = sym && a.half && a.rev && a.n_half > 0 && variant != SPK_VARIANT_MFMA_DIRECTED;
+  const bool pair = sym && a.half && a.rev && a.n_half > 0 && variant != SPK_VARIANT_MFMA_DIRECTED &&
+                    a.N * (int64_t)NF < (1LL << 31);
+  // group-local LDS accumulation: measured SLOWER than global float atomics on gfx950 (ds_add_f32 rate),
+  // kept only as an explicitly selectable experiment
+  const bool mol = pair && a.n_groups > 0 && a.grp_atom0 && a.max_group_atoms <= mol_max_atoms(NF, kpb) &&
+                   variant == SPK_VARIANT_MFMA_MOL;
 #define SPK_CF_CASE(NFv, KPBv)                                                      \
   if (NF == NFv && kpb == KPBv) {                                                   \
-    if (pair && BWD && a.gload) return launch_pair<NFv, KPBv, BWD, BWD>(a, stream); \
-    if (pair) return launch_pair<NFv, KPBv, BWD, false>(a, stream);                 \
+    if (mol && BWD && a.gload) return launch_pair<NFv, KPBv, BWD, BWD, true>(a, stream);   \
+    if (mol) return launch_pair<NFv, KPBv, BWD, false, true>(a, stream);                   \
+    if (pair && BWD && a.gload) return launch_pair_t_bwd_gs<NFv, KPBv>(a, stream);         \
+    if (pair) return launch_pair<NFv, KPBv, BWD, false, false>(a, stream);                 \
     if (!BWD) return launch_mfma<NFv, KPBv, false, false>(a, stream);               \
     return sym ? launch_mfma<NFv, KPBv, BWD, true>(a, stream)                       \
                : launch_mfma<NFv, KPBv, BWD, false>(a, stream);                     \
@@ -698,6 +1020,11 @@ static int cfconv_dispatch(const CfArgs& a, int NF, bool sym, hipStream_t stream
   return SPK_ERR_ARG;
 }
 
+static long long* g_cf_dbg = nullptr;
+static long long* spk_cf_debug_buffer() { return g_cf_dbg; }
+// tuning aid: device buffer of >= 32 int64 that receives cycle-counter stamps of wave 0 / workgroup 0
+extern "C" void spk_cfconv_set_debug_buffer(void* p) { g_cf_dbg = (long long*)p; }
+
 // floats of filter save space per interaction if the pair kernel will run for this graph/shape, else 0
 int64_t spk_cfconv_gsave_floats(const spk_graph_t* g, const spk_radial_t* rb, int nf) {
   const int variant = spk_get_variant();
@@ -705,7 +1032,9 @@ int64_t spk_cfconv_gsave_floats(const spk_graph_t* g, const spk_radial_t* rb, in
   const bool mfma_ok = (nf == 128 || nf == 64) && kpb >= 1 && kpb <= 4;
   const bool pair = g->symmetric && g->sorted && g->half && g->rev && g->n_half > 0;
   if (!mfma_ok || !pair || variant == SPK_VARIANT_SIMPLE || variant == SPK_VARIANT_MFMA_DIRECTED) return 0;
-  return ((g->n_half + 31) / 32) * 32 * (int64_t)nf;
+  int64_t tiles = (g->n_half + 31) / 32;
+  if (variant == SPK_VARIANT_MFMA_MOL && g->n_groups > 0 && g->n_tiles_grouped > tiles) tiles = g->n_tiles_grouped;  // group-aligned tiling
+  return tiles * 32 * (int64_t)nf;
 }
 
 int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
@@ -724,9 +1053,10 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(h && r_ij && w1 && b1 && w2 && b2, "%s: null pointer", who);
   CfArgs a;
   a.h = h; a.gy = nullptr; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr; a.gsave = gsave; a.gload = nullptr;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr; a.gsave = gsave; a.gload = nullptr; a.dbg = spk_cf_debug_buffer();
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
+  a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
   return cfconv_dispatch<false>(a, nf, g->symmetric && g->sorted, stream, who);
 }
 
@@ -746,9 +1076,10 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(h && gy && r_ij && w1 && b1 && w2 && b2 && gr, "%s: null pointer", who);
   CfArgs a;
   a.h = h; a.gy = gy; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr; a.gsave = nullptr; a.gload = gload;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr; a.gsave = nullptr; a.gload = gload; a.dbg = spk_cf_debug_buffer();
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
+  a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
   // the row-local transposed reduction needs idx_i sorted AND a symmetric list
   const bool sym = g->symmetric && g->sorted;
   return cfconv_dispatch<true>(a, nf, sym, stream, who);

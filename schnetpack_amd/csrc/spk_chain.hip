@@ -48,61 +48,48 @@ __device__ __forceinline__ float chain_act_grad(int act, float x) {
   return 1.0f;
 }
 
-#define CCH 8  // k-blocks per prefetch chunk
+#define CCH 8  // k-blocks per prefetch chunk (64 contraction indices, 32 MFMAs)
 
-template <bool TRANS>
-__device__ __forceinline__ void chain_load_a(f32x4 (&av)[CCH], int c, int nug, const float* __restrict__ w,
-                                             int KC, int NW, int t, int el, int hi) {
+// A operands of one chunk (8 k-blocks): every layer of the fused kernel is "k-major" (w is [KC, NW]
+// row-major: the transposed copy of a Linear weight for forward layers, the Linear weight itself for
+// input-gradient layers), so a wave reads 4 coalesced 128-byte rows per k-block.  KC % 64 == 0: no
+// guards, no divergent control flow between the loads.
+__device__ __forceinline__ void chain_load_a(f32x4 (&av)[CCH], const float* __restrict__ w, int NW, int t, int c,
+                                             int el, int hi) {
+  const float* wp = w + ((int64_t)(8 * c * CCH + 4 * hi)) * NW + 32 * t + el;
 #pragma unroll
   for (int u = 0; u < CCH; ++u) {
-    const int ug = c * CCH + u;
-    if (ug < nug) {
-      const int kk0 = 8 * ug + 4 * hi;
-      if (!TRANS) {
-        av[u] = *(const f32x4*)(w + (int64_t)(32 * t + el) * KC + kk0);
-      } else {
-        const float* wp = w + (int64_t)kk0 * NW + 32 * t + el;
-        f32x4 a4;
-        a4.x = wp[0]; a4.y = wp[NW]; a4.z = wp[2 * (int64_t)NW]; a4.w = wp[3 * (int64_t)NW];
-        av[u] = a4;
-      }
-    }
+    f32x4 a4;
+    a4.x = wp[0]; a4.y = wp[NW]; a4.z = wp[2 * (int64_t)NW]; a4.w = wp[3 * (int64_t)NW];
+    av[u] = a4;
+    wp += 8 * (int64_t)NW;
   }
 }
 
-__device__ __forceinline__ f32x16 chain_mfma(const f32x4 (&av)[CCH], int c, int nug, const float* __restrict__ brow,
-                                             int hi, f32x16 acc) {
+__device__ __forceinline__ f32x16 chain_mfma(const f32x4 (&av)[CCH], int c, const float* __restrict__ brow, int hi,
+                                             f32x16 acc) {
+  f32x4 bv[CCH];
+#pragma unroll
+  for (int u = 0; u < CCH; ++u) bv[u] = *(const f32x4*)(brow + 8 * (c * CCH + u) + 4 * hi);
 #pragma unroll
   for (int u = 0; u < CCH; ++u) {
-    const int ug = c * CCH + u;
-    if (ug < nug) {
-      const f32x4 bv = *(const f32x4*)(brow + 8 * ug + 4 * hi);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv.w, acc, 0, 0, 0);
-    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
   }
   return acc;
 }
 
-template <bool TRANS>
-__device__ __forceinline__ f32x16 chain_tile(const ChainLayerDev& L, int t, const float* __restrict__ brow, int el,
-                                             int hi) {
-  const int nug = L.KC / 8;
-  const int nch = (nug + CCH - 1) / CCH;
-  f32x4 a0[CCH], a1[CCH];
-  chain_load_a<TRANS>(a0, 0, nug, L.w, L.KC, L.NW, t, el, hi);
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = L.b ? L.b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
-  for (int c = 0; c < nch; c += 2) {
-    if (c + 1 < nch) chain_load_a<TRANS>(a1, c + 1, nug, L.w, L.KC, L.NW, t, el, hi);
-    acc = chain_mfma(a0, c, nug, brow, hi, acc);
-    if (c + 2 < nch) chain_load_a<TRANS>(a0, c + 2, nug, L.w, L.KC, L.NW, t, el, hi);
-    if (c + 1 < nch) acc = chain_mfma(a1, c + 1, nug, brow, hi, acc);
-  }
-  return acc;
+// Work of one wave = a stream of chunks (layer l, tile t = wave + 4 n, chunk c).  The weights do not
+// depend on the data, so the A operands are always requested one chunk ahead -- across tile and layer
+// boundaries too -- with two statically named register sets (KC % 128 == 0 => an even number of chunks
+// per tile, so the parity never flips): a wave pays the L2 latency of the weights once per launch.
+__device__ __forceinline__ bool chain_next_tile(const ChainArgs& a, int l, int t, int wv, int& l2, int& t2) {
+  if (t + 4 < a.L[l].NW / 32) { l2 = l; t2 = t + 4; return true; }
+  for (int q = l + 1; q < a.n_layers; ++q)
+    if (wv < a.L[q].NW / 32) { l2 = q; t2 = wv; return true; }
+  return false;
 }
 
 __global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
@@ -123,35 +110,79 @@ __global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
   const int64_t ntiles = (a.M + 31) / 32;
   for (int64_t mt = blockIdx.x; mt < ntiles; mt += gridDim.x) {
     const int64_t m0 = mt * 32;
-    // ---- stage the input tile [32][KC0] into buf0 (coalesced 16-byte rows)
+    f32x4 a0[CCH], a1[CCH];
+    {  // first chunk of this wave's stream, requested before the input tile is staged
+      int l2 = 0, t2 = wv;
+      bool have = wv < a.L[0].NW / 32;
+      if (!have) have = chain_next_tile(a, 0, 1 << 20, wv, l2, t2);
+      if (have) chain_load_a(a0, a.L[l2].w, a.L[l2].NW, t2, 0, el, hi);
+    }
+    // ---- stage the input tile [32][KC0] into buf0 (coalesced 16-byte rows); all loads of a thread
+    //      are in flight together (KC0 <= 384 => at most 12 pieces per thread)
     {
       const int KC0 = a.L[0].KC;
       const int q4 = KC0 / 4;
-      for (int s = threadIdx.x; s < 32 * q4; s += 256) {
-        const int row = s / q4, c4 = s % q4;
-        int64_t m = m0 + row;
-        if (m >= a.M) m = a.M - 1;
-        f32x4 v = *(const f32x4*)(a.in + m * KC0 + 4 * c4);
-        if (a.in_pre) {
-          const f32x4 p = *(const f32x4*)(a.in_pre + m * KC0 + 4 * c4);
-          v.x *= chain_act_grad(a.in_act, p.x); v.y *= chain_act_grad(a.in_act, p.y);
-          v.z *= chain_act_grad(a.in_act, p.z); v.w *= chain_act_grad(a.in_act, p.w);
+      const int total = 32 * q4;
+      f32x4 v[12], pz[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const int s = threadIdx.x + 256 * i;
+        if (s < total) {
+          const int row = s / q4, c4 = s - row * q4;
+          int64_t mm = m0 + row;
+          if (mm >= a.M) mm = a.M - 1;
+          v[i] = *(const f32x4*)(a.in + mm * KC0 + 4 * c4);
+          if (a.in_pre) pz[i] = *(const f32x4*)(a.in_pre + mm * KC0 + 4 * c4);
         }
-        *(f32x4*)(buf0 + row * ldw + 4 * c4) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const int s = threadIdx.x + 256 * i;
+        if (s < total) {
+          const int row = s / q4, c4 = s - row * q4;
+          f32x4 x = v[i];
+          if (a.in_pre) {
+            x.x *= chain_act_grad(a.in_act, pz[i].x); x.y *= chain_act_grad(a.in_act, pz[i].y);
+            x.z *= chain_act_grad(a.in_act, pz[i].z); x.w *= chain_act_grad(a.in_act, pz[i].w);
+          }
+          *(f32x4*)(buf0 + row * ldw + 4 * c4) = x;
+        }
       }
     }
     __syncthreads();
-    float* cur = buf0;
-    float* nxt = buf1;
     const int64_t m = m0 + el;
     const bool valid = m < a.M;
     for (int l = 0; l < a.n_layers; ++l) {
       const ChainLayerDev& L = a.L[l];
       const bool last = (l == a.n_layers - 1);
+      const float* brow = ((l & 1) ? buf1 : buf0) + el * ldw;
+      float* nxt = (l & 1) ? buf0 : buf1;
+      const int nch = L.KC / (8 * CCH);   // even
       const int tcount = L.NW / 32;
-      const float* brow = cur + el * ldw;
       for (int t = wv; t < tcount; t += 4) {
-        f32x16 acc = L.trans ? chain_tile<true>(L, t, brow, el, hi) : chain_tile<false>(L, t, brow, el, hi);
+        // epilogue operands (residual, act' argument) are requested before the MFMAs of the tile
+        f32x4 rv[4], pv[4];
+        const bool has_res = L.res && valid, has_post = (!last) && L.post_pre && valid;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t off = m * L.NW + 32 * t + 8 * q + 4 * hi;
+          rv[q] = has_res ? *(const f32x4*)(L.res + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+          pv[q] = has_post ? *(const f32x4*)(L.post_pre + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = L.b ? L.b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
+        for (int c = 0; c < nch; c += 2) {
+          chain_load_a(a1, L.w, L.NW, t, c + 1, el, hi);
+          acc = chain_mfma(a0, c, brow, hi, acc);
+          if (c + 2 < nch) {
+            chain_load_a(a0, L.w, L.NW, t, c + 2, el, hi);
+          } else {
+            int l2, t2;
+            if (chain_next_tile(a, l, t, wv, l2, t2)) chain_load_a(a0, a.L[l2].w, a.L[l2].NW, t2, 0, el, hi);
+          }
+          acc = chain_mfma(a1, c + 1, brow, hi, acc);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int col = 32 * t + 8 * q + 4 * hi;
@@ -162,11 +193,11 @@ __global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
           if (L.act != SPK_ACT_NONE) {
             o.x = chain_act(L.act, o.x); o.y = chain_act(L.act, o.y); o.z = chain_act(L.act, o.z); o.w = chain_act(L.act, o.w);
           }
-          if (L.res && valid) { const f32x4 rv = *(const f32x4*)(L.res + off); o += rv; }
+          if (has_res) o += rv[q];
           if (L.out && valid) *(f32x4*)(L.out + off) = o;
           if (!last) {
-            if (L.post_pre && valid) {
-              const f32x4 p = *(const f32x4*)(L.post_pre + off);
+            if (has_post) {
+              const f32x4 p = pv[q];
               o.x *= chain_act_grad(L.post_act, p.x); o.y *= chain_act_grad(L.post_act, p.y);
               o.z *= chain_act_grad(L.post_act, p.z); o.w *= chain_act_grad(L.post_act, p.w);
             }
@@ -175,7 +206,6 @@ __global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
         }
       }
       __syncthreads();
-      float* tmp = cur; cur = nxt; nxt = tmp;
     }
   }
 }
@@ -197,7 +227,8 @@ static bool chain_supported(const spk_chain_t* c) {
   for (int l = 0; l < c->n_layers; ++l) {
     const spk_chain_layer_t& L = c->layers[l];
     if (L.k != kc) return false;
-    if (L.k % 8 != 0 || L.n_out % 32 != 0 || L.k > CH_MAXW || L.n_out > CH_MAXW) return false;
+    if (!L.trans) return false;  // the fused kernel reads k-major weights only (see chain_load_a)
+    if (L.k % 128 != 0 || L.n_out % 32 != 0 || L.k > CH_MAXW || L.n_out > CH_MAXW) return false;
     if (!al16(L.w) || !al16(L.b) || !al16(L.res) || !al16(L.out) || !al16(L.pre_out) || !al16(L.post_pre)) return false;
     kc = L.n_out;
   }
@@ -219,7 +250,7 @@ extern "C" int spk_dense_chain_f32(const spk_chain_t* c, void* stream_) {
       SPK_CHECK_ARG(S.w != nullptr, "%s: null weight in layer %d", who, l);
       ChainLayerDev& D = a.L[l];
       D.w = S.w; D.b = S.b; D.res = S.res; D.out = S.out; D.pre_out = S.pre_out; D.post_pre = S.post_pre;
-      D.KC = S.k; D.NW = S.n_out; D.act = S.act; D.trans = S.trans; D.post_act = S.post_act;
+      D.KC = S.k; D.NW = S.n_out; D.act = S.act; D.trans = 1; D.post_act = S.post_act;
       if (S.n_out > maxw) maxw = S.n_out;
     }
     SPK_CHECK_ARG(c->in != nullptr, "%s: null input", who);

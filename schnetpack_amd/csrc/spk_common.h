@@ -150,6 +150,35 @@ __device__ __forceinline__ void spk_cutoff_eval(float rc, float d, float& f, flo
   } else { f = 0.f; df = 0.f; }
 }
 
+// Hardware-transcendental variants for the MFMA edge kernels (v_exp_f32, v_sin_f32, v_cos_f32: ~1e-6
+// absolute; arguments are bounded: Gaussian exponent <= 0, angles < n_rbf/2 revolutions).  They keep
+// the per-tile set-up short and register-light; the simple kernels and the element-wise entry points
+// use the accurate library versions (the two families are cross-checked by the tests).
+__device__ __forceinline__ void spk_rbf_eval_fast(const RadialDev& rb, int k, float d, float& phi, float& dphi) {
+  if (k >= rb.n_rbf) { phi = 0.f; dphi = 0.f; return; }
+  if (rb.kind == SPK_RBF_GAUSSIAN) {
+    const float w = rb.p1[k];
+    const float c = -0.5f * __builtin_amdgcn_rcpf(w * w);
+    const float t = d - rb.p0[k];
+    phi = __builtin_amdgcn_exp2f(1.4426950408889634f * c * t * t);
+    dphi = 2.0f * c * t * phi;
+  } else {
+    const float om = rb.p0[k];
+    const float rev = om * d * 0.15915494309189535f;   // angle in revolutions
+    const float s = __builtin_amdgcn_sinf(rev), co = __builtin_amdgcn_cosf(rev);
+    if (d == 0.0f) { phi = s; dphi = 0.f; }
+    else { const float inv = __builtin_amdgcn_rcpf(d); phi = s * inv; dphi = (om * co - phi) * inv; }
+  }
+}
+__device__ __forceinline__ void spk_cutoff_eval_fast(float rc, float d, float& f, float& df) {
+  if (d < rc) {
+    const float inv = __builtin_amdgcn_rcpf(rc);
+    const float rev = 0.5f * d * inv;                   // pi d / rc in revolutions
+    f = 0.5f * (__builtin_amdgcn_cosf(rev) + 1.0f);
+    df = -0.5f * SPK_PI_F * inv * __builtin_amdgcn_sinf(rev);
+  } else { f = 0.f; df = 0.f; }
+}
+
 __device__ __forceinline__ float spk_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -82,6 +82,10 @@ __global__ __launch_bounds__(256) void k_dense_mfma(
     const float* prow = PRO != SPK_ACT_NONE ? pre_in + mc * KC : nullptr;
     f32x4 a0[DCH], b0[DCH], a1[DCH], b1[DCH];
     dense_load_chunk<TRANS, PRO>(a0, b0, 0, nug, inrow, prow, w, KC, NW, t, el, hi);
+    f32x4 rv[4];  // residual rows, requested ahead of the MFMAs
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      rv[q] = (res && valid) ? *(const f32x4*)(res + m * NW + 32 * t + 8 * q + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = b ? b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void k_dense_mfma(
         o.x = acc[4 * q]; o.y = acc[4 * q + 1]; o.z = acc[4 * q + 2]; o.w = acc[4 * q + 3];
         if (pre_out) *(f32x4*)(pre_out + off) = o;
         o.x = spk_act<ACT>(o.x); o.y = spk_act<ACT>(o.y); o.z = spk_act<ACT>(o.z); o.w = spk_act<ACT>(o.w);
-        if (res) { f32x4 rv = *(const f32x4*)(res + off); o += rv; }
+        if (res) o += rv[q];
         *(f32x4*)(out + off) = o;
       }
     }

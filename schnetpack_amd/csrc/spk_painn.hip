@@ -548,6 +548,12 @@ static spk_chain_layer_t mk_layer(const float* w, const float* b, const float* r
   return L;
 }
 
+static spk_chain_layer_t mk_fwd(const float* w, const float* wT, const float* b, float* out, float* pre_out,
+                                int k, int n_out, int act) {
+  return wT ? mk_layer(wT, b, nullptr, out, pre_out, nullptr, k, n_out, act, 1, 0)
+            : mk_layer(w, b, nullptr, out, pre_out, nullptr, k, n_out, act, 0, 0);
+}
+
 // per layer saved for backward: preA [F] | c [3F] | mu_in [3F] | mix [6F] | preB [F] | a [3F]
 static inline int64_t painn_saved_per_atom(int F) { return 17 * (int64_t)F; }
 
@@ -594,23 +600,23 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
     {  // c = ctx_w2 silu(ctx_w1 q + b1) + b2   (one launch)
       spk_chain_t ch = {};
       ch.n_layers = 2; ch.m = N; ch.in = qin; ch.tmp[0] = c1; ch.tmp[1] = a1;
-      ch.layers[0] = mk_layer(P.ctx_w1, P.ctx_b1, nullptr, nullptr, preA, nullptr, F, F, SPK_ACT_SILU, 0, 0);
-      ch.layers[1] = mk_layer(P.ctx_w2, P.ctx_b2, nullptr, c, nullptr, nullptr, F, 3 * F, SPK_ACT_NONE, 0, 0);
+      ch.layers[0] = mk_fwd(P.ctx_w1, P.ctx_w1T, P.ctx_b1, nullptr, preA, F, F, SPK_ACT_SILU);
+      ch.layers[1] = mk_fwd(P.ctx_w2, P.ctx_w2T, P.ctx_b2, c, nullptr, F, 3 * F, SPK_ACT_NONE);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     SPK_TRY(spk_painn_message_fwd_internal(g, rb, c, qin, mu_in, r_ij, P.filt_w, P.filt_b, F, q1, mu1, stream));
     {  // mix = mu1 W_mix^T over [3N, F]
       spk_chain_t ch = {};
       ch.n_layers = 1; ch.m = 3 * N; ch.in = mu1;
-      ch.layers[0] = mk_layer(P.mix_w, nullptr, nullptr, mix, nullptr, nullptr, F, 2 * F, SPK_ACT_NONE, 0, 0);
+      ch.layers[0] = mk_fwd(P.mix_w, P.mix_wT, nullptr, mix, nullptr, F, 2 * F, SPK_ACT_NONE);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     SPK_TRY(spk_painn_mix_ctx_f32(q1, mix, N, F, m->epsilon, ctx, stream));
     {  // a = ictx_w2 silu(ictx_w1 ctx + b1) + b2
       spk_chain_t ch = {};
       ch.n_layers = 2; ch.m = N; ch.in = ctx; ch.tmp[0] = c1; ch.tmp[1] = a1;
-      ch.layers[0] = mk_layer(P.ictx_w1, P.ictx_b1, nullptr, nullptr, preB, nullptr, 2 * F, F, SPK_ACT_SILU, 0, 0);
-      ch.layers[1] = mk_layer(P.ictx_w2, P.ictx_b2, nullptr, av, nullptr, nullptr, F, 3 * F, SPK_ACT_NONE, 0, 0);
+      ch.layers[0] = mk_fwd(P.ictx_w1, P.ictx_w1T, P.ictx_b1, nullptr, preB, 2 * F, F, SPK_ACT_SILU);
+      ch.layers[1] = mk_fwd(P.ictx_w2, P.ictx_w2T, P.ictx_b2, av, nullptr, F, 3 * F, SPK_ACT_NONE);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     float* mu_next = (l == L - 1) ? mu_out : (saved + (l + 1) * per + 4 * nf);

@@ -42,12 +42,22 @@ extern "C" int64_t spk_schnet_scratch_floats(const spk_schnet_t* m, int64_t n_at
 
 #define SPK_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// forward layer from either the [out,in] weight or its transposed copy (coalesced reads)
+static spk_chain_layer_t mk_fwd(const float* w, const float* wT, const float* b, const float* res, float* out,
+                                float* pre_out, int k, int n_out, int act);
+
 static spk_chain_layer_t mk_layer(const float* w, const float* b, const float* res, float* out, float* pre_out,
                                   const float* post_pre, int k, int n_out, int act, int trans, int post_act) {
   spk_chain_layer_t L;
   L.w = w; L.b = b; L.res = res; L.out = out; L.pre_out = pre_out; L.post_pre = post_pre;
   L.k = k; L.n_out = n_out; L.act = act; L.trans = trans; L.post_act = post_act;
   return L;
+}
+
+static spk_chain_layer_t mk_fwd(const float* w, const float* wT, const float* b, const float* res, float* out,
+                                float* pre_out, int k, int n_out, int act) {
+  return wT ? mk_layer(wT, b, res, out, pre_out, nullptr, k, n_out, act, 1, 0)
+            : mk_layer(w, b, res, out, pre_out, nullptr, k, n_out, act, 0, 0);
 }
 
 extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* g,
@@ -77,7 +87,7 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
     spk_chain_t c = {};
     c.n_layers = 1; c.m = N; c.in = x0; c.zero_ptr = ybuf[0]; c.zero_count = N * (int64_t)NF;
     c.tmp[0] = tmp0; c.tmp[1] = tmp1;
-    c.layers[0] = mk_layer(m->layers[0].in2f_w, nullptr, nullptr, hbuf(0), nullptr, nullptr, F, NF, SPK_ACT_NONE, 0, 0);
+    c.layers[0] = mk_fwd(m->layers[0].in2f_w, m->layers[0].in2f_wT, nullptr, nullptr, hbuf(0), nullptr, F, NF, SPK_ACT_NONE);
     SPK_TRY(spk_dense_chain_f32(&c, stream));
   }
   for (int l = 0; l < L; ++l) {
@@ -90,11 +100,11 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
                                     gsz > 0 ? gbase + l * gsz : nullptr));
     spk_chain_t c = {};
     c.m = N; c.in = y; c.tmp[0] = tmp0; c.tmp[1] = tmp1;
-    c.layers[0] = mk_layer(P.f2out_w1, P.f2out_b1, nullptr, nullptr, pre3, nullptr, NF, F, SPK_ACT_SSP, 0, 0);
-    c.layers[1] = mk_layer(P.f2out_w2, P.f2out_b2, xin, x_out, nullptr, nullptr, F, F, SPK_ACT_NONE, 0, 0);
+    c.layers[0] = mk_fwd(P.f2out_w1, P.f2out_w1T, P.f2out_b1, nullptr, nullptr, pre3, NF, F, SPK_ACT_SSP);
+    c.layers[1] = mk_fwd(P.f2out_w2, P.f2out_w2T, P.f2out_b2, xin, x_out, nullptr, F, F, SPK_ACT_NONE);
     c.n_layers = 2;
     if (l + 1 < L) {
-      c.layers[2] = mk_layer(m->layers[l + 1].in2f_w, nullptr, nullptr, hbuf(l + 1), nullptr, nullptr, F, NF, SPK_ACT_NONE, 0, 0);
+      c.layers[2] = mk_fwd(m->layers[l + 1].in2f_w, m->layers[l + 1].in2f_wT, nullptr, nullptr, hbuf(l + 1), nullptr, F, NF, SPK_ACT_NONE);
       c.n_layers = 3;
       c.zero_ptr = ybuf[(l + 1) & 1]; c.zero_count = N * (int64_t)NF;
     }

@@ -55,14 +55,66 @@ class EdgePlan:
             if 2 * n_half != self.n_edges:
                 self.symmetric = False
                 self.half, n_half = None, 0
+        self.groups = None
+        n_groups = max_ga = n_tiles_g = 0
+        if self.symmetric and n_half > 0:
+            self.groups = _block_diagonal_groups(self.idx_i, self.idx_j, self.half, self.n_atoms)
+            if self.groups is not None:
+                n_groups = int(self.groups[0].shape[0]) - 1
+                max_ga = int(self.groups[3])
+                n_tiles_g = int(self.groups[4])
+        gp = self.groups
         self._graph = _lib.GraphT(self.n_atoms, self.n_edges, iptr(self.idx_i), iptr(self.idx_j),
                                   iptr(self.rowptr, torch.int32) if self.sorted else None,
                                   int(self.sorted), int(self.symmetric),
                                   iptr(self.rev, torch.int32) if self.symmetric else None,
-                                  iptr(self.half, torch.int32) if self.half is not None else None, n_half)
+                                  iptr(self.half, torch.int32) if self.half is not None else None, n_half,
+                                  iptr(gp[0], torch.int32) if gp else None, iptr(gp[1], torch.int32) if gp else None,
+                                  iptr(gp[2], torch.int32) if gp else None, n_groups, max_ga, n_tiles_g)
 
     def graph(self):
         return ctypes.byref(self._graph)
+
+
+_MAX_GROUP_ATOMS = 128   # upper bound for the LDS accumulator of the group-local kernels
+
+
+def _block_diagonal_groups(idx_i, idx_j, half, n_atoms):
+    """Block-diagonal structure of a symmetric neighbour list (plan time, one small D2H sync):
+    connected ranges of atoms that no edge leaves (molecules of a batch), merged greedily into groups of
+    at most cap = min(128, max(largest molecule, N / compute units)) atoms.  Returns (atom0 [G+1],
+    pair0 [G+1], tile0 [G+1] int32 device tensors, max atoms per group, total tiles) or None when the
+    list is not block diagonal with small blocks."""
+    dev = idx_i.device
+    ar = torch.arange(n_atoms, device=dev)
+    mj = ar.clone()
+    mj.scatter_reduce_(0, idx_i, idx_j, reduce="amax", include_self=True)
+    cm = torch.cummax(mj, 0).values
+    ends = torch.nonzero(cm == ar).flatten() + 1          # a component ends after every such atom
+    ends_h = ends.cpu()
+    sizes = torch.diff(ends_h, prepend=torch.zeros(1, dtype=ends_h.dtype))
+    if sizes.numel() == 0 or int(sizes.max()) > _MAX_GROUP_ATOMS:
+        return None
+    try:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    except Exception:  # pragma: no cover
+        n_cu = 256
+    cap = min(_MAX_GROUP_ATOMS, max(int(sizes.max()), -(-n_atoms // n_cu)))
+    atom0 = [0]
+    cur = 0
+    for sz in sizes.tolist():
+        if cur + sz > cap and cur > 0:
+            atom0.append(atom0[-1] + cur)
+            cur = 0
+        cur += sz
+    atom0.append(atom0[-1] + cur)
+    atom0_t = torch.tensor(atom0, dtype=torch.int64, device=dev)
+    hi = idx_i[half.long()]                                # centre atom of every canonical pair (ascending)
+    pair0 = torch.searchsorted(hi, atom0_t).to(torch.int32)
+    tiles = (torch.diff(pair0.long()) + 31) // 32
+    tile0 = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(tiles, 0)]).to(torch.int32)
+    max_atoms = int(torch.diff(atom0_t).max())
+    return (atom0_t.to(torch.int32).contiguous(), pair0.contiguous(), tile0.contiguous(), max_atoms, int(tile0[-1]))
 
 
 _PLAN_CACHE = collections.OrderedDict()

@@ -127,6 +127,11 @@ class PaiNN(nn.Module):
     def _model_struct(self):
         L = self.n_interactions
         Fd = self.n_atom_basis
+        params = list(self.filter_net.parameters()) + [p for m in list(self.interactions) + list(self.mixing) for p in m.parameters()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cache = self.__dict__.get("_struct_cache")
+        if cache is not None and cache[0] == key:
+            return cache[1], cache[2]
         arr = (_lib.PainnLayerT * max(L, 1))()
         keep = []
         fw = self.filter_net.weight.detach().contiguous()
@@ -147,10 +152,15 @@ class PaiNN(nn.Module):
                 t = t.detach().contiguous()
                 keep.append(t)
                 setattr(arr[l], name, _lib.fptr(t))
+                if name in ("ctx_w1", "ctx_w2", "mix_w", "ictx_w1", "ictx_w2"):
+                    tt = t.t().contiguous()  # [in, out]: coalesced weight reads in the forward chains
+                    keep.append(tt)
+                    setattr(arr[l], name + "T", _lib.fptr(tt))
             arr[l].filt_w = ctypes.c_void_p(fw.data_ptr() + 4 * row0 * n_rbf)
             arr[l].filt_b = ctypes.c_void_p(fb.data_ptr() + 4 * row0)
         ms = _lib.PainnT(Fd, L, self._eps(), 0, ctypes.cast(arr, ctypes.POINTER(_lib.PainnLayerT)))
         keep.append(arr)
+        self.__dict__["_struct_cache"] = (key, ms, keep)
         return ms, keep
 
     def forward(self, inputs: Dict[str, torch.Tensor]):

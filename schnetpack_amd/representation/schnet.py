@@ -91,8 +91,14 @@ class SchNet(nn.Module):
                 and hasattr(self.cutoff_fn, "cutoff_value"))
 
     def _model_struct(self):
-        """ctypes parameter block (device pointers of the state_dict tensors)."""
+        """ctypes parameter block (device pointers of the state_dict tensors + cached transposed
+        copies of the atom-wise weights for coalesced reads; rebuilt when a parameter changes)."""
         L = len(self.interactions)
+        params = [p for it in self.interactions for p in it.parameters()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cache = self.__dict__.get("_struct_cache")
+        if cache is not None and cache[0] == key:
+            return cache[1], cache[2]
         arr = (_lib.SchnetLayerT * max(L, 1))()
         keep = []
         for l, it in enumerate(self.interactions):
@@ -100,12 +106,14 @@ class SchNet(nn.Module):
                   it.filter_network[1].weight, it.filter_network[1].bias, it.f2out[0].weight,
                   it.f2out[0].bias, it.f2out[1].weight, it.f2out[1].bias]
             ts = [t.detach().contiguous() for t in ts]
+            ts += [ts[0].t().contiguous(), ts[5].t().contiguous(), ts[7].t().contiguous()]
             keep.extend(ts)
             for name, t in zip([f[0] for f in _lib.SchnetLayerT._fields_], ts):
                 setattr(arr[l], name, _lib.fptr(t))
         ms = _lib.SchnetT(self.n_atom_basis, self.n_filters, L, 0,
                           ctypes.cast(arr, ctypes.POINTER(_lib.SchnetLayerT)))
         keep.append(arr)
+        self.__dict__["_struct_cache"] = (key, ms, keep)
         return ms, keep
 
     def forward(self, inputs: Dict[str, torch.Tensor]):

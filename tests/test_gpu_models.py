@@ -23,13 +23,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["mfma", "simple", "directed"])
+@pytest.fixture(params=["mfma", "simple", "directed", "mol"])
 def variant(request):
-    """mfma = default dispatch (pair kernel on symmetric lists), directed = MFMA kernel with one
-    filter per directed edge, simple = straightforward cross-check kernels."""
+    """mfma = default dispatch (pair kernels on symmetric lists), mol = group-local LDS-accumulating pair
+    kernel (experiment, block-diagonal lists), directed = MFMA kernel with one filter per directed edge,
+    simple = straightforward cross-check kernels."""
     from schnetpack_amd import _lib
     _lib.set_variant({"simple": _lib.VARIANT_SIMPLE, "directed": _lib.VARIANT_MFMA_DIRECTED,
-                      "mfma": _lib.VARIANT_AUTO}[request.param])
+                      "mol": _lib.VARIANT_MFMA_MOL, "mfma": _lib.VARIANT_AUTO}[request.param])
     yield request.param
     _lib.set_variant(_lib.VARIANT_AUTO)
 

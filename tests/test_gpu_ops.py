@@ -24,13 +24,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["mfma", "simple", "directed"])
+@pytest.fixture(params=["mfma", "simple", "directed", "mol"])
 def variant(request):
-    """mfma = default dispatch (pair kernel on symmetric lists), directed = MFMA kernel with one
-    filter per directed edge, simple = straightforward cross-check kernels."""
+    """mfma = default dispatch (pair kernels on symmetric lists), mol = group-local LDS-accumulating pair
+    kernel (experiment, block-diagonal lists), directed = MFMA kernel with one filter per directed edge,
+    simple = straightforward cross-check kernels."""
     from schnetpack_amd import _lib
     _lib.set_variant({"simple": _lib.VARIANT_SIMPLE, "directed": _lib.VARIANT_MFMA_DIRECTED,
-                      "mfma": _lib.VARIANT_AUTO}[request.param])
+                      "mol": _lib.VARIANT_MFMA_MOL, "mfma": _lib.VARIANT_AUTO}[request.param])
     yield request.param
     _lib.set_variant(_lib.VARIANT_AUTO)
 
@@ -71,6 +72,17 @@ def test_edge_plan_flags_and_rowptr(dev):
     half = plan.half.long().cpu()
     assert half.shape[0] * 2 == plan.n_edges and bool((rev[half] > half).all())
     assert bool((half[1:] > half[:-1]).all())
+    # block-diagonal groups: 3 molecules of 21 atoms, group-aligned tiles
+    atom0, pair0, tile0, max_atoms, n_tiles = plan.groups
+    assert atom0.cpu().tolist() == [0, 21, 42, 63] and max_atoms == 21
+    p0 = pair0.cpu().tolist()
+    assert p0[0] == 0 and p0[-1] == half.shape[0]
+    hi_atoms = b["idx_i"][half]
+    for gidx in range(3):
+        seg = hi_atoms[p0[gidx]:p0[gidx + 1]]
+        assert bool(((seg >= 21 * gidx) & (seg < 21 * (gidx + 1))).all())
+    assert tile0.cpu().tolist() == np.cumsum([0] + [-(-(p0[k + 1] - p0[k]) // 32) for k in range(3)]).tolist()
+    assert n_tiles == int(tile0[-1])
     # drop one edge -> asymmetric; shuffle -> unsorted
     plan2 = ops.EdgePlan(b["idx_i"][1:].to(dev), b["idx_j"][1:].to(dev), N, r[1:].to(dev))
     assert plan2.sorted and not plan2.symmetric
@@ -358,11 +370,14 @@ def test_cfconv_mfma_equals_simple_at_bench_scale(dev):
     y1b, _, _, _ = _cfconv_hip(dev, 3.0 * h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
     _lib.set_variant(_lib.VARIANT_MFMA_DIRECTED)
     y3, gh3, gr3, _ = _cfconv_hip(dev, h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
+    _lib.set_variant(_lib.VARIANT_MFMA_MOL)
+    y4, gh4, gr4, _ = _cfconv_hip(dev, h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
     _lib.set_variant(_lib.VARIANT_SIMPLE)
     y2, gh2, gr2, _ = _cfconv_hip(dev, h, r, b["idx_i"], b["idx_j"], p, N, "gaussian", gy)
     _lib.set_variant(_lib.VARIANT_AUTO)
     assert rel_err(y1, y2) < TOL and rel_err(gh1, gh2) < TOL and rel_err(gr1, gr2) < TOL
     assert rel_err(y3, y2) < TOL and rel_err(gh3, gh2) < TOL and rel_err(gr3, gr2) < TOL
+    assert rel_err(y4, y2) < TOL and rel_err(gh4, gh2) < TOL and rel_err(gr4, gr2) < TOL
     assert rel_err(y1b, 3.0 * y1) < 2e-6
     # reversed edges carry opposite geometry gradients on a symmetric list: sum_e gr_e r_e parity
     assert torch.isfinite(gr1).all()
