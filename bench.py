@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kind", default="schnet", choices=["schnet", "painn"])
     ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--workload", default="aspirin", choices=["aspirin", "water"],
+                    help="aspirin: configs[1]/[2] (256-frame MD17 batch, the default); water: configs[4] per-GPU "
+                         "share (one 32k-atom bulk-water PBC replica / PIMD bead per GPU)")
+    ap.add_argument("--water-side", type=int, default=22, help="molecules per box edge (22 -> 31 944 atoms)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the force call in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=15)
@@ -76,7 +80,10 @@ def main():
 
     # weak scaling: rank r owns frames [r*frames, (r+1)*frames) of one global seeded trajectory
     lo, hi = shard_frames(args.frames * world, rank, world)
-    batch = S.molecule_batch("aspirin", hi - lo, seed=1000 + rank if world > 1 else 0)
+    if args.workload == "water":
+        batch = S.water_box(n_side=args.water_side, seed=rank)   # one replica (bead) per rank
+    else:
+        batch = S.molecule_batch("aspirin", hi - lo, seed=1000 + rank if world > 1 else 0)
     E = int(batch["idx_i"].shape[0])
     N = int(batch["Z"].shape[0])
     inp = M.batch_to_inputs(batch, dev)
@@ -225,18 +232,20 @@ def main():
         ts.sort()
         med = ts[len(ts) // 2]
         cpu = {"value": round(E * n_int / med / 1e6, 4), "unit": "M edge-messages/s", "cores": ncores, "kind": "port",
-               "sample": "same %d-frame batch, median of %d force calls (%.2f s each), torch %s fp32" % (hi - lo, args.cpu_reps, med, torch.__version__),
+               "sample": "same %d-frame batch (or box), median of %d force calls (%.2f s each), torch %s fp32" % (hi - lo, args.cpu_reps, med, torch.__version__),
                "parity_rel_forces": float((f_ref.cpu() - oc["forces"]).abs().max() / oc["forces"].abs().max()),
                "parity_rel_energy": float((e_ref.cpu() - oc["energy"]).abs().max() / oc["energy"].abs().max())}
 
     info = _lib.device_info()
     line = {
-        "metric": "M edge-messages/s (eval force call, MD17-aspirin 256-frame batch, %s)" % ("SchNet" if args.kind == "schnet" else "PaiNN"),
+        "metric": "M edge-messages/s (eval force call, %s, %s)" % ("MD17-aspirin 256-frame batch" if args.workload == "aspirin" else "32k-atom bulk-water PBC box", "SchNet" if args.kind == "schnet" else "PaiNN"),
         "value": round(value, 2), "unit": "M edge-messages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: MD17 aspirin x %d frames per GPU, %s(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0) + Atomwise + Forces; N=%d atoms, E=%d directed edges per GPU"
-                               % (hi - lo, "SchNet" if args.kind == "schnet" else "PaiNN", N, E),
+        "config": {"workload": ("configs[1]: MD17 aspirin x %d frames per GPU, %s(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0) + Atomwise + Forces; N=%d atoms, E=%d directed edges per GPU"
+                                % (hi - lo, "SchNet" if args.kind == "schnet" else "PaiNN", N, E)) if args.workload == "aspirin" else
+                               ("configs[4] per-GPU share: bulk-water PBC box, one replica per GPU, %s(128, 3, 20, 5.0) + Atomwise + Forces; N=%d atoms, E=%d directed edges per GPU; ns/day at 0.5 fs per force call = %.3f"
+                                % ("SchNet" if args.kind == "schnet" else "PaiNN", N, E, args.steps / dt * 0.5 * 86400e-6)),
                    "n_atoms": N, "n_edges": E, "n_atom_basis": F, "frames_per_s": round((hi - lo) * world * args.steps / dt, 1),
                    "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                    "hip_graph": graph is not None, "variant": args.variant, "compute_units": info["compute_units"]},

@@ -52,7 +52,7 @@ def golden_params(meta):
 MODEL_CASES = ["schnet_ethanol.npz", "schnet_aspirin8.npz", "painn_ethanol.npz",
                "painn_aspirin8.npz", "schnet_bessel_aspirin2.npz", "painn_bessel_aspirin2.npz",
                "schnet_skin_aspirin2.npz", "painn_skin_aspirin2.npz",
-               "painn_aspirin_pretrained.npz"]
+               "painn_aspirin_pretrained.npz", "schnet_water192.npz", "painn_water192.npz"]
 
 
 def rel_err(a, b):
