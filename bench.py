@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the force call in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=15)
+    ap.add_argument("--mode", default="eval", choices=["eval", "train"],
+                    help="eval: the headline force call (default).  train: configs[3] — one AdamW step of the force-matching "
+                         "loss on --train-frames aspirin frames per GPU, gradients averaged with one flat all-reduce")
+    ap.add_argument("--train-frames", type=int, default=8)
     ap.add_argument("--variant", default="auto", choices=["auto", "simple", "mfma", "directed", "pair", "mol"])
     return ap.parse_args()
 
@@ -77,6 +81,9 @@ def main():
     model = M.build_model(args.kind, F, n_int, n_rbf, cutoff)
     M.load_reference_params(model, rep_p, head_p)
     model = model.to(dev).eval()
+
+    if args.mode == "train":
+        return train_main(args, rank, world, dev, dist, model, rep_p, head_p)
 
     # weak scaling: rank r owns frames [r*frames, (r+1)*frames) of one global seeded trajectory
     lo, hi = shard_frames(args.frames * world, rank, world)
@@ -196,6 +203,22 @@ def main():
                     "note": "achieved = algorithmic work / HIP-event time of the launch; executed_frac_of_peak counts only the "
                             "work the kernel really issues (pair kernels evaluate one filter per undirected edge)"}
 
+    # HBM traffic of the dominant kernel from the committed PMC pass of this workload (scripts/gpu_pmc_traffic.sh:
+    # separate --pmc passes for FETCH_SIZE and WRITE_SIZE; KiB per dispatch; gfx950 correction: FETCH_SIZE x 2)
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_%s_%s.json" % (args.kind, args.workload))
+    if roofline is not None and os.path.exists(pmc_file):
+        try:
+            c = json.load(open(pmc_file))["counters"].get(roofline["kernel"])
+            if c and "FETCH_SIZE_raw_per_launch" in c and "WRITE_SIZE_raw_per_launch" in c:
+                rd = 2.0 * 1024.0 * c["FETCH_SIZE_raw_per_launch"]
+                wr = 1024.0 * c["WRITE_SIZE_raw_per_launch"]
+                roofline["traffic"] = rd + wr
+                roofline["traffic_detail"] = {"read_bytes": rd, "write_bytes": wr, "source": os.path.relpath(pmc_file, ROOT),
+                                              "note": "rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch, collected "
+                                                      "in separate --pmc passes of this command; Infinity-Cache hits are counted"}
+        except Exception as exc:  # pragma: no cover
+            sys.stderr.write("[bench] could not read %s: %s\n" % (pmc_file, exc))
+
     # ---------------- scatter_add op alone (north_star: HBM roofline of the segmented sum)
     from schnetpack_amd import ops
     xs = torch.randn(E, F, device=dev)
@@ -246,10 +269,110 @@ def main():
                                 % (hi - lo, "SchNet" if args.kind == "schnet" else "PaiNN", N, E)) if args.workload == "aspirin" else
                                ("configs[4] per-GPU share: bulk-water PBC box, one replica per GPU, %s(128, 3, 20, 5.0) + Atomwise + Forces; N=%d atoms, E=%d directed edges per GPU; ns/day at 0.5 fs per force call = %.3f"
                                 % ("SchNet" if args.kind == "schnet" else "PaiNN", N, E, args.steps / dt * 0.5 * 86400e-6)),
-                   "n_atoms": N, "n_edges": E, "n_atom_basis": F, "frames_per_s": round((hi - lo) * world * args.steps / dt, 1),
+                   "n_atoms": N, "n_edges": E, "frames_per_s": round((hi - lo) * world * args.steps / dt, 1),
                    "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                    "hip_graph": graph is not None, "variant": args.variant, "compute_units": info["compute_units"]},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "scatter_add": scatter,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def train_main(args, rank, world, dev, dist, model, rep_p, head_p):
+    """configs[3] (SURVEY.md section 8 cfg 4): rMD17-aspirin training step, PaiNN/SchNet in train() mode
+    (Forces with create_graph=True -> double backward through the differentiable HIP primitives), loss
+    0.01 MSE(E) + 0.99 MSE(F), AdamW(lr 1e-3), 8 frames per GPU, ONE all-reduce of one flat gradient
+    bucket per step (RCCL; bucket views, no copy kernels)."""
+    from oracle import spk_oracle as O
+    from schnetpack_amd import model as M, synthetic as S
+    from schnetpack_amd.parallel import FlatGradAllReduce
+    n_int = 3
+    model.train()
+    reducer = FlatGradAllReduce(model.parameters(), as_views=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    pool = []
+    for k in range(8):                      # 8 different resident mini-batches, cycled
+        b = S.molecule_batch("aspirin", args.train_frames, seed=5000 + 97 * rank + k)
+        g = torch.Generator().manual_seed(k + 31 * rank)
+        pool.append((b, M.batch_to_inputs(b, dev), torch.randn(args.train_frames, generator=g).to(dev),
+                     torch.randn(b["Z"].shape[0], 3, generator=g).to(dev)))
+
+    def step(i):
+        b, inp, Et, Ft = pool[i % len(pool)]
+        reducer.zero()
+        out = model(dict(inp))
+        loss = 0.01 * ((out["energy"] - Et) ** 2).mean() + 0.99 * ((out["forces"] - Ft) ** 2).mean()
+        loss.backward()
+        reducer()
+        opt.step()
+        return loss
+
+    losses = [float(step(i)) for i in range(max(args.warmup, 2))]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        ncores = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(ncores)
+        b, _, Et, Ft = pool[0]
+        Et, Ft = Et.cpu(), Ft.cpu()
+        rp = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() and k.endswith(("weight", "bias")) else v) for k, v in rep_p.items()}
+        hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
+        leaves = [v for v in list(rp.values()) + list(hp.values()) if torch.is_tensor(v) and v.requires_grad]
+        copt = torch.optim.AdamW(leaves, lr=1e-3)
+
+        def cpu_step():
+            copt.zero_grad()
+            R = b["R"].clone().requires_grad_(True)
+            r_ij = O.pairwise_vectors(R, b["idx_i"], b["idx_j"], b["offsets"])
+            if args.kind == "schnet":
+                x = O.schnet_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, n_int)
+            else:
+                x, _ = O.painn_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, n_int)
+            E = O.atomwise_energy(x, b["idx_m"], args.train_frames, hp)
+            (dEdR,) = torch.autograd.grad([E.sum()], [R], create_graph=True)
+            l = 0.01 * ((E - Et) ** 2).mean() + 0.99 * ((-dEdR - Ft) ** 2).mean()
+            l.backward()
+            copt.step()
+        cpu_step()
+        ts = []
+        for _ in range(args.cpu_reps):
+            c0 = time.perf_counter()
+            cpu_step()
+            ts.append(time.perf_counter() - c0)
+        ts.sort()
+        cpu = {"value": round(args.train_frames / ts[len(ts) // 2], 2), "unit": "samples/s", "cores": ncores, "kind": "port",
+               "sample": "same %d-frame training step on the oracle (torch CPU autograd), median of %d" % (args.train_frames, args.cpu_reps)}
+    kind = "SchNet" if args.kind == "schnet" else "PaiNN"
+    line = {
+        "metric": "training samples/s (rMD17-aspirin force-matching step, %s)" % kind,
+        "value": round(args.train_frames * world * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[3]: rMD17 aspirin training, %d frames per GPU (global batch %d), %s(128, 3, 20, 5.0) + Atomwise + "
+                               "Forces(create_graph), loss 0.01 MSE(E) + 0.99 MSE(F), AdamW lr 1e-3, one flat-bucket all-reduce of %d floats per step"
+                               % (args.train_frames, args.train_frames * world, kind, reducer.numel),
+                   "parallelism": "dp%d" % world, "first_loss": losses[0], "last_loss": float(loss)},
+        "roofline": None, "cpu_baseline": cpu,
     }
     print(json.dumps(line))
     if dist is not None:

@@ -119,6 +119,29 @@ int spk_pairwise_f32(const float* R, const int64_t* idx_i, const int64_t* idx_j,
  * ([N,3], overwritten) -- where dE/dR_ij lands on the atoms (forces = -gR). */
 int spk_pairwise_bwd_f32(const float* gr, const int64_t* idx_i, const int64_t* idx_j,
                          int64_t n_edges, int64_t n_atoms, float* gR, void* stream);
+/* same result with the plan of the list: on sorted + symmetric lists (g->rowptr, g->rev) a segmented
+ * row sum gR[a] = sum_{e in row(a)} (gr[rev[e]] - gr[e]) -- no atomics, deterministic; other lists
+ * take the atomic kernel above. */
+int spk_pairwise_bwd_graph_f32(const float* gr, const spk_graph_t* g, float* gR, void* stream);
+
+/* ------------------------------------------------------------------ atomistic/atomwise.py:69-88
+ * The default output head, build_mlp(n_in, 1, n_layers=2) (nn/blocks.py:38-57) + sum over idx_m:
+ *   y_n = w2 . act(W1 x_n + b1) + b2,   E[idx_m[n]] += y_n           (E [n_mol] is overwritten)
+ * x [N, n_in], w1 [n_hidden, n_in], b1 [n_hidden] or NULL, w2 [n_hidden], b2 [1] or NULL,
+ * idx_m [N] int64 (entries outside [0, n_mol) are ignored) or NULL (then E must be NULL too),
+ * pre [N, n_hidden] receives the hidden pre-activations (NULL: not kept), y_atom [N] or NULL.
+ * Fused kernel shapes: n_in % 32 == 0, n_hidden % 32 == 0, act in {SSP, SILU}
+ * (spk_atomwise_supported); other heads run through spk_dense_f32 + spk_scatter_add_f32. */
+int spk_atomwise_supported(int32_t n_in, int32_t n_hidden, int32_t act);
+int spk_atomwise_fwd_f32(const float* x, const float* w1, const float* b1, const float* w2,
+                         const float* b2, const int64_t* idx_m, int64_t n_atoms, int32_t n_in,
+                         int32_t n_hidden, int32_t act, int64_t n_mol, float* pre, float* y_atom,
+                         float* E, void* stream);
+/* first-order backward w.r.t. x:  gx[n] = (gE[idx_m[n]] + gy_atom[n]) * W1^T (w2 * act'(pre_n));
+ * either of (gE, idx_m) / gy_atom may be NULL. */
+int spk_atomwise_bwd_f32(const float* gE, const float* gy_atom, const float* pre, const float* w1,
+                         const float* w2, const int64_t* idx_m, int64_t n_atoms, int32_t n_in,
+                         int32_t n_hidden, int32_t act, int64_t n_mol, float* gx, void* stream);
 
 /* ------------------------------------------------------------------ nn/radial.py, nn/cutoff.py
  * d: [n] distances -> phi [n, n_rbf] (may be NULL), fcut [n] (may be NULL). */

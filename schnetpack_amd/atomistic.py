@@ -11,8 +11,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import properties
-from .nn import build_mlp, scatter_add
+from . import _lib, ops, properties
+from .nn import Dense, build_mlp, scatter_add
+from .nn.base import activation_id
 
 __all__ = ["PairwiseDistances", "Atomwise", "Forces"]
 
@@ -25,7 +26,6 @@ class PairwiseDistances(nn.Module):
         offsets = inputs.get(properties.offsets)
         idx_i = inputs[properties.idx_i].long()
         idx_j = inputs[properties.idx_j].long()
-        from . import ops
         inputs[properties.Rij] = ops.pairwise_vectors(R, idx_i, idx_j, offsets)
         return inputs
 
@@ -52,8 +52,39 @@ class Atomwise(nn.Module):
         self.aggregation_mode = aggregation_mode
         self.n_molecules_key = n_molecules_key
 
+    def _fused_head(self, x):
+        """(w1, b1, w2, b2, act id) when the head is the default 2-layer / width-1 MLP the fused HIP
+        kernel covers and the module is in the eval regime; else None."""
+        if self.training or self.aggregation_mode is None or self.n_out != 1 or x.dim() != 2:
+            return None
+        net = self.outnet
+        if not (isinstance(net, nn.Sequential) and len(net) == 2 and all(isinstance(l, Dense) for l in net)):
+            return None
+        act = activation_id(net[0].activation)
+        if act is None or activation_id(net[1].activation) != _lib.SPK_ACT_NONE:
+            return None
+        if net[1].out_features != 1 or not ops.atomwise_supported(net[0].in_features, net[0].out_features, act):
+            return None
+        d = lambda p: p.detach() if p is not None else None
+        return d(net[0].weight), d(net[0].bias), d(net[1].weight), d(net[1].bias), act
+
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        y = self.outnet(inputs["scalar_representation"])
+        x = inputs["scalar_representation"]
+        head = self._fused_head(x)
+        if head is not None:
+            idx_m = inputs[properties.idx_m]
+            if self.n_molecules_key is not None and self.n_molecules_key in inputs:
+                maxm = int(inputs[self.n_molecules_key])
+            else:
+                maxm = int(idx_m[-1]) + 1
+            y, y_atom = ops.AtomwiseFn.apply(x, head[0], head[1], head[2], head[3], idx_m.long().contiguous(), maxm, head[4])
+            if self.per_atom_output_key is not None:
+                inputs[self.per_atom_output_key] = y_atom
+            if self.aggregation_mode == "avg":
+                y = y / inputs[properties.n_atoms]
+            inputs[self.output_key] = y
+            return inputs
+        y = self.outnet(x)
         if self.per_atom_output_key is not None:
             inputs[self.per_atom_output_key] = y
         if self.aggregation_mode is not None:

@@ -193,6 +193,206 @@ extern "C" int spk_dense_bwd_input_f32(const float* dy, const float* pre, const 
                         (hipStream_t)stream, "spk_dense_bwd_input_f32");
 }
 
+// ---------------------------------------------------------------- Atomwise head (atomistic/atomwise.py:69-88)
+// Default head = build_mlp(n_in, 1, n_layers=2): y_n = w2 . act(W1 x_n + b1) + b2, E[idx_m[n]] += y_n.
+// One wave owns 32 atoms and walks all hidden tiles; the second (width-1) layer is a per-lane dot
+// product over the accumulator registers + one cross-half shuffle; the molecule sum is one float
+// atomic per atom (n_atoms atomics on n_mol addresses).
+template <int ACT>
+__global__ __launch_bounds__(256) void k_atomwise_fwd(
+    const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const int64_t* __restrict__ idx_m,
+    int64_t M, int KC, int H, int64_t n_mol, float* __restrict__ pre, float* __restrict__ y_atom,
+    float* __restrict__ E) {
+  // molecule sums: segmented scan inside the wave, then one LDS slot per molecule of the block's
+  // 128 consecutive atoms, then ONE global atomic per (block, molecule) -- float atomics that meet on
+  // one cache line serialise at the memory side, so a 32 k-atom box must not issue 32 k of them.
+  __shared__ float s_sum[128];
+  __shared__ int s_flag[128];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  const int nug = KC / 8;
+  const int nch = (nug + DCH - 1) / DCH;
+  const int64_t ntiles = (M + 31) / 32;
+  for (int64_t mt0 = (int64_t)blockIdx.x * 4; mt0 < ntiles; mt0 += (int64_t)gridDim.x * 4) {
+    const int64_t mt = mt0 + wv;
+    const int64_t m = mt * 32 + el;
+    const bool valid = m < M;
+    const int64_t mc = valid ? m : (M - 1);
+    const float* inrow = x + mc * KC;
+    const int64_t mol = (idx_m && valid) ? idx_m[m] : -1;
+    const int64_t mol0 = idx_m ? idx_m[mt0 * 32] : 0;
+    if (threadIdx.x < 128) { s_sum[threadIdx.x] = 0.f; s_flag[threadIdx.x] = 0; }
+    __syncthreads();
+    float part = 0.f;
+    if (mt < ntiles) {
+      for (int t = 0; t < H / 32; ++t) {
+        f32x4 a0[DCH], b0[DCH], a1[DCH], b1v[DCH];
+        dense_load_chunk<false, SPK_ACT_NONE>(a0, b0, 0, nug, inrow, nullptr, w1, KC, H, t, el, hi);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b1 ? b1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
+        for (int c = 0; c < nch; c += 2) {
+          if (c + 1 < nch) dense_load_chunk<false, SPK_ACT_NONE>(a1, b1v, c + 1, nug, inrow, nullptr, w1, KC, H, t, el, hi);
+          acc = dense_mfma_chunk(a0, b0, c, nug, acc);
+          if (c + 2 < nch) dense_load_chunk<false, SPK_ACT_NONE>(a0, b0, c + 2, nug, inrow, nullptr, w1, KC, H, t, el, hi);
+          if (c + 1 < nch) acc = dense_mfma_chunk(a1, b1v, c + 1, nug, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f0 = 32 * t + 8 * q + 4 * hi;
+          const f32x4 wv2 = *(const f32x4*)(w2 + f0);
+          f32x4 o;
+          o.x = acc[4 * q]; o.y = acc[4 * q + 1]; o.z = acc[4 * q + 2]; o.w = acc[4 * q + 3];
+          if (pre && valid) *(f32x4*)(pre + m * H + f0) = o;
+          part += wv2.x * spk_act<ACT>(o.x) + wv2.y * spk_act<ACT>(o.y) + wv2.z * spk_act<ACT>(o.z) + wv2.w * spk_act<ACT>(o.w);
+        }
+      }
+      part += __shfl_xor(part, 32, 64);
+      const float y = part + (b2 ? b2[0] : 0.f);
+      if (valid && hi == 0 && y_atom) y_atom[m] = y;
+      if (E) {
+        // segmented inclusive scan over the 32 atoms of the tile (segments = runs of equal molecule id)
+        const int64_t mprev = __shfl_up(mol, 1, 64);
+        int head = (el == 0 || mprev != mol) ? 1 : 0;
+        float v = (mol >= 0 && mol < n_mol) ? y : 0.f;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+          const float vu = __shfl_up(v, d, 64);
+          const int hu = __shfl_up(head, d, 64);
+          if (el >= d && !head) { v += vu; head = hu; }
+        }
+        const int64_t mnext = __shfl_down(mol, 1, 64);
+        const bool last = (el == 31) || (mnext != mol);
+        if (hi == 0 && last && mol >= 0 && mol < n_mol) {
+          const int64_t rel = mol - mol0;
+          if (rel >= 0 && rel < 128) { atomicAdd(&s_sum[rel], v); s_flag[rel] = 1; }
+          else unsafeAtomicAdd(&E[mol], v);
+        }
+      }
+    }
+    __syncthreads();
+    if (E && threadIdx.x < 128 && s_flag[threadIdx.x]) unsafeAtomicAdd(&E[mol0 + threadIdx.x], s_sum[threadIdx.x]);
+    __syncthreads();
+  }
+}
+
+// gx[n][k] = sum_f s_n w2[f] act'(pre[n][f]) W1[f][k],  s_n = gE[idx_m[n]] (+ gy_atom[n]).
+template <int ACT>
+__global__ __launch_bounds__(256) void k_atomwise_bwd(
+    const float* __restrict__ gE, const float* __restrict__ gy_atom, const float* __restrict__ pre,
+    const float* __restrict__ w1, const float* __restrict__ w2, const int64_t* __restrict__ idx_m,
+    int64_t M, int KC /*=H*/, int NW /*=n_in*/, int64_t n_mol, float* __restrict__ gx, int64_t ntasks) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  const int tcount = NW / 32;
+  const int nug = KC / 8;
+  for (int64_t task = blockIdx.x * 4 + wv; task < ntasks; task += (int64_t)gridDim.x * 4) {
+    const int64_t mt = task / tcount;
+    const int t = (int)(task % tcount);
+    const int64_t m = mt * 32 + el;
+    const bool valid = m < M;
+    const int64_t mc = valid ? m : (M - 1);
+    float s = gy_atom ? gy_atom[mc] : 0.f;
+    if (gE && idx_m) {
+      const int64_t mol = idx_m[mc];
+      if (mol >= 0 && mol < n_mol) s += gE[mol];
+    }
+    const float* prow = pre + mc * KC;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ug0 = 0; ug0 < nug; ug0 += DCH) {
+      f32x4 av[DCH], bv[DCH];
+#pragma unroll
+      for (int u = 0; u < DCH; ++u) {
+        const int ug = ug0 + u;
+        if (ug < nug) {
+          const int kk0 = 8 * ug + 4 * hi;
+          const f32x4 pv = *(const f32x4*)(prow + kk0);
+          const f32x4 v2 = *(const f32x4*)(w2 + kk0);
+          f32x4 b;
+          b.x = s * v2.x * spk_act_grad<ACT>(pv.x); b.y = s * v2.y * spk_act_grad<ACT>(pv.y);
+          b.z = s * v2.z * spk_act_grad<ACT>(pv.z); b.w = s * v2.w * spk_act_grad<ACT>(pv.w);
+          bv[u] = b;
+          const float* wp = w1 + (int64_t)kk0 * NW + 32 * t + el;
+          f32x4 a4;
+          a4.x = wp[0]; a4.y = wp[NW]; a4.z = wp[2 * (int64_t)NW]; a4.w = wp[3 * (int64_t)NW];
+          av[u] = a4;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < DCH; ++u) {
+        if (ug0 + u < nug) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+        }
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 o;
+        o.x = acc[4 * q]; o.y = acc[4 * q + 1]; o.z = acc[4 * q + 2]; o.w = acc[4 * q + 3];
+        *(f32x4*)(gx + m * NW + 32 * t + 8 * q + 4 * hi) = o;
+      }
+    }
+  }
+}
+
+static bool atomwise_shape_ok(int n_in, int n_hidden) { return n_in > 0 && n_hidden > 0 && n_in % 32 == 0 && n_hidden % 32 == 0; }
+
+extern "C" int spk_atomwise_supported(int32_t n_in, int32_t n_hidden, int32_t act) {
+  return atomwise_shape_ok(n_in, n_hidden) && (act == SPK_ACT_SSP || act == SPK_ACT_SILU) ? 1 : 0;
+}
+
+extern "C" int spk_atomwise_fwd_f32(const float* x, const float* w1, const float* b1, const float* w2,
+                                    const float* b2, const int64_t* idx_m, int64_t n_atoms,
+                                    int32_t n_in, int32_t n_hidden, int32_t act, int64_t n_mol,
+                                    float* pre, float* y_atom, float* E, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(n_atoms >= 0 && n_mol >= 0, "spk_atomwise_fwd_f32: bad sizes");
+  SPK_CHECK_ARG(spk_atomwise_supported(n_in, n_hidden, act), "spk_atomwise_fwd_f32: head %d -> %d -> 1 (act %d) not supported by the fused kernel", n_in, n_hidden, act);
+  SPK_CHECK_ARG((E == nullptr) == (idx_m == nullptr), "spk_atomwise_fwd_f32: E and idx_m go together");
+  SPK_CHECK_ARG(E != nullptr || y_atom != nullptr, "spk_atomwise_fwd_f32: no output requested");
+  if (E && n_mol > 0) SPK_HIP_TRY(hipMemsetAsync(E, 0, (size_t)n_mol * sizeof(float), stream));
+  if (n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(x && w1 && w2, "spk_atomwise_fwd_f32: null pointer");
+  SPK_CHECK_ARG(aligned16(x) && aligned16(w1) && aligned16(w2) && aligned16(pre), "spk_atomwise_fwd_f32: 16-byte alignment required");
+  SpkProfScope prof("atomwise_fwd", stream);
+  const int64_t ntiles = (n_atoms + 31) / 32;
+  const int grid = spk_grid_for(ntiles, 4, spk_num_cus() * 8);
+  if (act == SPK_ACT_SILU)
+    hipLaunchKernelGGL((k_atomwise_fwd<SPK_ACT_SILU>), dim3(grid), dim3(256), 0, stream, x, w1, b1, w2, b2, idx_m, n_atoms, n_in, n_hidden, n_mol, pre, y_atom, E);
+  else
+    hipLaunchKernelGGL((k_atomwise_fwd<SPK_ACT_SSP>), dim3(grid), dim3(256), 0, stream, x, w1, b1, w2, b2, idx_m, n_atoms, n_in, n_hidden, n_mol, pre, y_atom, E);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_atomwise_bwd_f32(const float* gE, const float* gy_atom, const float* pre,
+                                    const float* w1, const float* w2, const int64_t* idx_m,
+                                    int64_t n_atoms, int32_t n_in, int32_t n_hidden, int32_t act,
+                                    int64_t n_mol, float* gx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(n_atoms >= 0, "spk_atomwise_bwd_f32: bad sizes");
+  SPK_CHECK_ARG(spk_atomwise_supported(n_in, n_hidden, act), "spk_atomwise_bwd_f32: head %d -> %d -> 1 (act %d) not supported by the fused kernel", n_in, n_hidden, act);
+  if (n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(pre && w1 && w2 && gx && (gy_atom || (gE && idx_m)), "spk_atomwise_bwd_f32: null pointer");
+  SPK_CHECK_ARG(aligned16(pre) && aligned16(w1) && aligned16(w2) && aligned16(gx), "spk_atomwise_bwd_f32: 16-byte alignment required");
+  SpkProfScope prof("atomwise_bwd", stream);
+  const int64_t ntasks = ((n_atoms + 31) / 32) * (n_in / 32);
+  const int grid = spk_grid_for(ntasks, 4, spk_num_cus() * 8);
+  if (act == SPK_ACT_SILU)
+    hipLaunchKernelGGL((k_atomwise_bwd<SPK_ACT_SILU>), dim3(grid), dim3(256), 0, stream, gE, gy_atom, pre, w1, w2, idx_m, n_atoms, n_hidden, n_in, n_mol, gx, ntasks);
+  else
+    hipLaunchKernelGGL((k_atomwise_bwd<SPK_ACT_SSP>), dim3(grid), dim3(256), 0, stream, gE, gy_atom, pre, w1, w2, idx_m, n_atoms, n_hidden, n_in, n_mol, gx, ntasks);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 // internal C++ entry used by the whole-representation drivers
 int spk_dense_internal(const float* in, const float* pre_in, const float* w, const float* b,
                        const float* res, float* out, float* pre_out, int64_t M, int KC, int NW,

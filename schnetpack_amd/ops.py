@@ -25,8 +25,10 @@ class EdgePlan:
     """CSR row pointers + flags of one neighbour list (``spk_edge_plan``).  Built once per
     list (one 16-byte D2H sync) and cached; holds references to the index tensors."""
 
-    def __init__(self, idx_i, idx_j, n_atoms, r_ij=None):
+    def __init__(self, idx_i, idx_j, n_atoms, r_ij=None, want_groups=None):
         _lib.require_device(idx_i, idx_j)
+        if want_groups is None:
+            want_groups = _lib.get_variant() == _lib.VARIANT_MFMA_MOL
         self.idx_i = idx_i.long().contiguous()
         self.idx_j = idx_j.long().contiguous()
         self.n_atoms = int(n_atoms)
@@ -57,7 +59,7 @@ class EdgePlan:
                 self.half, n_half = None, 0
         self.groups = None
         n_groups = max_ga = n_tiles_g = 0
-        if self.symmetric and n_half > 0:
+        if want_groups and self.symmetric and n_half > 0:   # only the experimental group-local kernels need it
             self.groups = _block_diagonal_groups(self.idx_i, self.idx_j, self.half, self.n_atoms)
             if self.groups is not None:
                 n_groups = int(self.groups[0].shape[0]) - 1
@@ -123,13 +125,14 @@ _PLAN_CACHE_SIZE = 16
 
 def edge_plan(idx_i, idx_j, n_atoms, r_ij=None):
     """Cached plan of a neighbour list, keyed by the identity/version of the index tensors."""
+    want_groups = _lib.get_variant() == _lib.VARIANT_MFMA_MOL
     key = (idx_i.data_ptr(), idx_j.data_ptr(), idx_i._version, idx_j._version,
-           int(idx_i.shape[0]), int(n_atoms), str(idx_i.device), r_ij is not None)
+           int(idx_i.shape[0]), int(n_atoms), str(idx_i.device), r_ij is not None, want_groups)
     plan = _PLAN_CACHE.get(key)
     if plan is not None and plan._src[0] is idx_i and plan._src[1] is idx_j:
         _PLAN_CACHE.move_to_end(key)
         return plan
-    plan = EdgePlan(idx_i, idx_j, n_atoms, r_ij)
+    plan = EdgePlan(idx_i, idx_j, n_atoms, r_ij, want_groups)
     plan._src = (idx_i, idx_j)  # keep the storage alive => data_ptr cannot be recycled
     _PLAN_CACHE[key] = plan
     while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
@@ -250,30 +253,36 @@ class PairwiseFn(torch.autograd.Function):
         ctx.save_for_backward(idx_i, idx_j)
         ctx.n = int(R.shape[0])
         ctx.has_off = offsets is not None
+        # the plan of the list (cached; the representation asks for the same one): on symmetric sorted
+        # lists the backward is a segmented row sum instead of 6 atomics per edge
+        ctx.plan = edge_plan(idx_i, idx_j, ctx.n, r) if (E > 0 and ctx.needs_input_grad[0]) else None
         return r
 
     @staticmethod
     def backward(ctx, gr):
         idx_i, idx_j = ctx.saved_tensors
-        gR = PairwiseBwdFn.apply(gr, idx_i, idx_j, ctx.n) if ctx.needs_input_grad[0] else None
+        gR = PairwiseBwdFn.apply(gr, idx_i, idx_j, ctx.n, ctx.plan) if ctx.needs_input_grad[0] else None
         goff = gr if (ctx.has_off and ctx.needs_input_grad[3]) else None
         return gR, None, None, goff
 
 
 class PairwiseBwdFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gr, idx_i, idx_j, n_atoms):
+    def forward(ctx, gr, idx_i, idx_j, n_atoms, plan=None):
         grc = gr.contiguous()
         gR = torch.empty((n_atoms, 3), dtype=torch.float32, device=gr.device)
         with torch.cuda.device(gr.device):
-            check(lib().spk_pairwise_bwd_f32(fptr(grc), iptr(idx_i), iptr(idx_j), int(idx_i.shape[0]), int(n_atoms), fptr(gR), stream()))
+            if plan is not None:
+                check(lib().spk_pairwise_bwd_graph_f32(fptr(grc), plan.graph(), fptr(gR), stream()))
+            else:
+                check(lib().spk_pairwise_bwd_f32(fptr(grc), iptr(idx_i), iptr(idx_j), int(idx_i.shape[0]), int(n_atoms), fptr(gR), stream()))
         ctx.save_for_backward(idx_i, idx_j)
         return gR
 
     @staticmethod
     def backward(ctx, ggR):
         idx_i, idx_j = ctx.saved_tensors
-        return PairwiseFn.apply(ggR, idx_i, idx_j, None), None, None, None
+        return PairwiseFn.apply(ggR, idx_i, idx_j, None), None, None, None, None
 
 
 def pairwise_vectors(R, idx_i, idx_j, offsets=None):
@@ -417,6 +426,45 @@ def dense(x, w, b=None, act=None, training=True):
     if not training:
         return DenseEvalFn.apply(x, w.detach(), b.detach() if b is not None else None, a)
     return DenseFn.apply(x, w, b, a)
+
+
+# ----------------------------------------------------------------------------- fused Atomwise head
+class AtomwiseFn(torch.autograd.Function):
+    """E_m = sum_{n in m} (w2 . act(W1 x_n + b1) + b2)  (atomistic/atomwise.py:69-88 with the default
+    2-layer head), eval regime: one launch forward, one launch for the first-order gradient w.r.t. x;
+    the weights are not differentiated.  Returns (E [n_mol], y_atom [N, 1])."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, idx_m, n_mol, act):
+        xc = x.contiguous()
+        N, n_in = int(xc.shape[0]), int(xc.shape[1])
+        H = int(w1.shape[0])
+        dev = x.device
+        pre = torch.empty((N, H), dtype=torch.float32, device=dev)
+        y_atom = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        E = torch.empty((int(n_mol),), dtype=torch.float32, device=dev)
+        w1c, w2c = w1.contiguous(), w2.contiguous().view(-1)
+        with torch.cuda.device(dev):
+            check(lib().spk_atomwise_fwd_f32(fptr(xc), fptr(w1c), fptr(b1), fptr(w2c), fptr(b2), iptr(idx_m),
+                                             N, n_in, H, int(act), int(n_mol), fptr(pre), fptr(y_atom), fptr(E), stream()))
+        ctx.save_for_backward(pre, w1c, w2c, idx_m)
+        ctx.meta = (N, n_in, H, int(act), int(n_mol))
+        return E, y_atom
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gE, gy):
+        pre, w1c, w2c, idx_m = ctx.saved_tensors
+        N, n_in, H, act, n_mol = ctx.meta
+        gx = torch.empty((N, n_in), dtype=torch.float32, device=pre.device)
+        with torch.cuda.device(pre.device):
+            check(lib().spk_atomwise_bwd_f32(fptr(gE.contiguous()), fptr(gy.contiguous().view(-1)), fptr(pre), fptr(w1c), fptr(w2c),
+                                             iptr(idx_m), N, n_in, H, act, n_mol, fptr(gx), stream()))
+        return (gx,) + (None,) * 7
+
+
+def atomwise_supported(n_in, n_hidden, act):
+    return bool(lib().spk_atomwise_supported(int(n_in), int(n_hidden), int(act)))
 
 
 # ----------------------------------------------------------------------------- fused SchNet

@@ -26,17 +26,58 @@ def shard_systems(systems: List, rank: int, world: int) -> List:
 
 class FlatGradAllReduce:
     """Average the gradients of ``params`` over all ranks with ONE all-reduce of one flat fp32
-    buffer (what DDP does with a single bucket).  Parameters without a gradient contribute zeros
-    so that every rank reduces the same layout."""
+    buffer (what DDP does with a single bucket).
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    ``as_views=False``: gradients are copied into the bucket and back; parameters without a gradient
+    contribute zeros so that every rank reduces the same layout.
+    ``as_views=True`` (DDP's ``gradient_as_bucket_view``): every ``p.grad`` IS a view of the bucket, so
+    autograd accumulates straight into it and the step costs no copy kernels; clear the gradients
+    with :meth:`zero` (``optimizer.zero_grad(set_to_none=True)`` would drop the views)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], as_views: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.as_views = as_views
+        if as_views and self.params:
+            self._bind()
+
+    def _bind(self):
+        dev = self.params[0].device
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        """Clear all gradients with one fill (views mode)."""
+        if self.flat is not None:
+            self.flat.zero_()
+
+    def _reduce(self, group):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
 
     def __call__(self, group=None):
-        import torch.distributed as dist
         if not self.params:
+            return
+        if self.as_views:
+            off = 0
+            for p in self.params:     # a gradient that was re-created (e.g. after set_to_none) is re-bound
+                n = p.numel()
+                view = self.flat[off:off + n]
+                if p.grad is None:
+                    view.zero_()
+                    p.grad = view.view_as(p)
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad.reshape(-1))
+                    p.grad = view.view_as(p)
+                off += n
+            self._reduce(group)
             return
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
@@ -49,9 +90,7 @@ class FlatGradAllReduce:
             else:
                 self.flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+        self._reduce(group)
         off = 0
         for p in self.params:
             n = p.numel()

@@ -21,4 +21,16 @@ for KIND in schnet painn; do
   grep -o '{"metric.*' $OUT/rp_$KIND.log > $OUT/${KIND}_bench_under_rocprof.json
   rm -rf $OUT/rp_$KIND $OUT/rp_$KIND.log
 done
+echo "== water box (configs[4] per-GPU share)"
+for KIND in schnet painn; do
+  timeout 900 python bench.py --workload water --kind $KIND --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_water_$KIND.json 2> $OUT/bench_water_$KIND.err; echo "rc=$?"; cut -c1-400 $OUT/bench_water_$KIND.json
+done
+echo "== training step (configs[3])"
+for KIND in schnet painn; do
+  timeout 600 python bench.py --mode train --kind $KIND --steps 50 --warmup 5 --cpu-reps 5 > $OUT/bench_train_$KIND.json 2> $OUT/bench_train_$KIND.err; echo "rc=$?"; cut -c1-300 $OUT/bench_train_$KIND.json
+done
+echo "== PMC traffic"
+bash $ROOT/scripts/gpu_pmc_traffic.sh $TAG schnet aspirin
+bash $ROOT/scripts/gpu_pmc_traffic.sh $TAG painn aspirin
+bash $ROOT/scripts/gpu_pmc_traffic.sh $TAG painn water
 du -sh $OUT

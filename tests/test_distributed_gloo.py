@@ -58,3 +58,61 @@ def test_flat_grad_allreduce_and_sharding_world2():
         mean = (T(res[0][0][k]) + T(res[1][0][k])) / 2
         assert torch.allclose(T(res[0][1][k]), mean) and torch.allclose(T(res[1][1][k]), mean)
     assert res[0][2] == list(range(7)) and res[1][2] == list(range(7))
+
+
+def _train_worker(rank, world, port, q):
+    """Three AdamW steps of a small MLP on the rank's half of a batch with the bucket-view reducer."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from schnetpack_amd.parallel import FlatGradAllReduce, shard_frames
+    net, data, target = _toy_problem()
+    lo, hi = shard_frames(data.shape[0], rank, world)
+    red = FlatGradAllReduce(net.parameters(), as_views=True)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+    for step in range(3):
+        red.zero()
+        if step == 1:
+            opt.zero_grad(set_to_none=True)        # a caller that drops the views: must be re-bound
+        loss = ((net(data[lo:hi]) - target[lo:hi]) ** 2).mean()
+        loss.backward()
+        red()
+        assert all(p.grad.data_ptr() >= red.flat.data_ptr() for p in net.parameters())
+        opt.step()
+    q.put((rank, [p.detach().tolist() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _toy_problem():
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.SiLU(), torch.nn.Linear(8, 2))
+    data = torch.randn(8, 6)
+    target = torch.randn(8, 2)
+    return net, data, target
+
+
+def test_bucket_view_training_world2_equals_single_process():
+    """Equal shards + mean loss: the rank-averaged gradient IS the full-batch gradient, so two
+    ranks must walk exactly the trajectory of one process on the whole batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    net, data, target = _toy_problem()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+    for _ in range(3):
+        opt.zero_grad()
+        ((net(data) - target) ** 2).mean().backward()
+        opt.step()
+    for k, p in enumerate(net.parameters()):
+        for r in range(2):
+            assert torch.allclose(torch.tensor(res[r][k]), p.detach(), atol=1e-6), (r, k)
+    assert res[0] == res[1]

@@ -166,3 +166,55 @@ def test_state_dict_round_trip_and_repeat_calls(dev):
     assert rel_err(o1["forces"].cpu(), o2["forces"].cpu()) < 2e-6
     sd = model.representation.state_dict()
     assert set(sd) == set(rep_p)
+
+
+# ----------------------------------------------------------------------------- Atomwise head
+@pytest.mark.parametrize("n_in,act,agg,n_atoms", [(128, "silu", "sum", 21 * 5), (128, "ssp", "avg", 77),
+                                                   (64, "silu", "sum", 1), (192, "silu", "sum", 4000),
+                                                   (30, "silu", "sum", 50)])
+def test_atomwise_head_eval_matches_oracle(dev, n_in, act, agg, n_atoms):
+    """Energy head (atomistic/atomwise.py:69-88): fused eval-mode kernel pair (forward + dE/dx) against
+    fp64 torch; ragged molecules, per-atom outputs, 'avg' aggregation, a tile that is not full, and a
+    width the fused kernel does not cover (30: goes through Dense + scatter_add, same numbers)."""
+    import torch.nn.functional as Fn
+    from schnetpack_amd import atomistic, ops, properties
+    from schnetpack_amd.nn import shifted_softplus
+    g = torch.Generator().manual_seed(n_in + n_atoms)
+    fn = Fn.silu if act == "silu" else shifted_softplus
+    torch.manual_seed(3)
+    head = atomistic.Atomwise(n_in=n_in, activation=fn, aggregation_mode=agg, output_key="energy",
+                              per_atom_output_key="e_atom")
+    with torch.no_grad():
+        for p in head.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+    sizes = []
+    left = n_atoms
+    while left > 0:
+        s = min(left, int(torch.randint(1, 40, (1,), generator=g)))
+        sizes.append(s)
+        left -= s
+    idx_m = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    x = torch.randn(n_atoms, n_in, generator=g)
+    wE = torch.randn(len(sizes), generator=g)
+    wA = torch.randn(n_atoms, 1, generator=g)
+
+    xd = x.double().requires_grad_(True)
+    sd = {k: v.double() for k, v in head.state_dict().items()}
+    h = fn(xd @ sd["outnet.0.weight"].T + sd["outnet.0.bias"])
+    ya = h @ sd["outnet.1.weight"].T + sd["outnet.1.bias"]
+    Eo = torch.zeros(len(sizes), dtype=torch.float64).index_add_(0, idx_m, ya[:, 0])
+    if agg == "avg":
+        Eo = Eo / torch.tensor(sizes, dtype=torch.float64)
+    (gxo,) = torch.autograd.grad((Eo * wE.double()).sum() + (ya * wA.double()).sum(), [xd])
+
+    head = head.to(dev).eval()
+    assert (head._fused_head(x.to(dev)) is not None) == (n_in % 32 == 0)
+    xg = x.to(dev).requires_grad_(True)
+    out = head({"scalar_representation": xg, properties.idx_m: idx_m.to(dev),
+                properties.n_atoms: torch.tensor(sizes, device=dev), "_n_molecules": len(sizes)})
+    assert out["energy"].shape == (len(sizes),) and out["e_atom"].shape == (n_atoms, 1)
+    assert rel_err(out["energy"].detach().cpu(), Eo.detach()) < TOL
+    assert rel_err(out["e_atom"].detach().cpu(), ya.detach()) < TOL
+    (gx,) = torch.autograd.grad((out["energy"] * wE.to(dev)).sum() + (out["e_atom"] * wA.to(dev)).sum(), [xg])
+    assert rel_err(gx.cpu(), gxo) < TOL

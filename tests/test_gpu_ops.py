@@ -59,7 +59,7 @@ def test_edge_plan_flags_and_rowptr(dev):
     b = S.molecule_batch("aspirin", 3, seed=1)
     r = O.pairwise_vectors(b["R"], b["idx_i"], b["idx_j"], b["offsets"])
     N = b["Z"].shape[0]
-    plan = ops.EdgePlan(b["idx_i"].to(dev), b["idx_j"].to(dev), N, r.to(dev))
+    plan = ops.EdgePlan(b["idx_i"].to(dev), b["idx_j"].to(dev), N, r.to(dev), want_groups=True)
     assert plan.sorted and plan.symmetric
     counts = torch.bincount(b["idx_i"], minlength=N)
     expect = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]).int()
@@ -512,6 +512,44 @@ def test_pairwise_vectors_forward_backward_and_second_order(dev):
     gh, g2h = run(R.to(dev), ii, jj, off.to(dev), w.to(dev), ops.pairwise_vectors)
     go, g2o = run(R.double(), b["idx_i"], b["idx_j"], off.double(), w.double(), O.pairwise_vectors)
     assert rel_err(gh, go) < TOL and rel_err(g2h, g2o) < TOL
+    # no offsets: the list is symmetric => segmented row-sum backward (no atomics)
+    gh, g2h = run(R.to(dev), ii, jj, None, w.to(dev), ops.pairwise_vectors)
+    go, g2o = run(R.double(), b["idx_i"], b["idx_j"], torch.zeros_like(off).double(), w.double(), O.pairwise_vectors)
+    assert rel_err(gh, go) < TOL and rel_err(g2h, g2o) < TOL
+
+
+@pytest.mark.parametrize("system", ["aspirin", "water", "ragged"])
+def test_pairwise_backward_row_sum_equals_atomic_scatter(dev, system):
+    """spk_pairwise_bwd_graph_f32 (segmented row sum over rev[e] on symmetric sorted lists) against the
+    fp64 oracle and against the atomic kernel; rows longer than 16 edges (water: ~52) and empty rows."""
+    from schnetpack_amd import _lib, ops
+    if system == "aspirin":
+        b = S.molecule_batch("aspirin", 5, seed=2)
+    elif system == "water":
+        b = S.water_box(n_side=4, seed=1)
+    else:   # isolated atoms (empty rows) between molecules
+        b = S.molecule_batch("ethanol", 3, seed=2)
+        b["R"] = torch.cat([b["R"], torch.full((4, 3), 50.0) + 20 * torch.arange(4.0)[:, None]])
+        b["Z"] = torch.cat([b["Z"], torch.ones(4, dtype=torch.long)])
+    N = b["Z"].shape[0]
+    r = O.pairwise_vectors(b["R"], b["idx_i"], b["idx_j"], b["offsets"])
+    ii, jj = b["idx_i"].to(dev), b["idx_j"].to(dev)
+    plan = ops.EdgePlan(ii, jj, N, r.to(dev))
+    assert plan.sorted and plan.symmetric
+    gr = torch.randn(r.shape, generator=torch.Generator().manual_seed(4))
+    expect = torch.zeros(N, 3, dtype=torch.float64)
+    expect.index_add_(0, b["idx_j"], gr.double())
+    expect.index_add_(0, b["idx_i"], -gr.double())
+    grd = gr.to(dev)
+    g_row = torch.full((N, 3), float("nan"), device=dev)
+    g_at = torch.full((N, 3), float("nan"), device=dev)
+    _lib.check(_lib.lib().spk_pairwise_bwd_graph_f32(_lib.fptr(grd), plan.graph(), _lib.fptr(g_row), _lib.stream()))
+    _lib.check(_lib.lib().spk_pairwise_bwd_f32(_lib.fptr(grd), _lib.iptr(ii), _lib.iptr(jj), ii.shape[0], N, _lib.fptr(g_at), _lib.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(g_row.cpu(), expect) < TOL and rel_err(g_at.cpu(), expect) < TOL
+    g_row2 = torch.empty_like(g_row)
+    _lib.check(_lib.lib().spk_pairwise_bwd_graph_f32(_lib.fptr(grd), plan.graph(), _lib.fptr(g_row2), _lib.stream()))
+    assert torch.equal(g_row, g_row2)          # deterministic
 
 
 # ----------------------------------------------------------------------------- fused dense chain
