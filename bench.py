@@ -239,6 +239,24 @@ def main():
                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                "note": "includes launch gaps (torch events around 50 back-to-back calls)"}
 
+    # ---------------- neighbour-list rebuild on the device for this workload
+    from schnetpack_amd import neighborlist as NL
+    nl_cell = batch["cell"].reshape(1, 3, 3).to(dev) if args.workload == "water" else None
+    nl_pbc = torch.tensor([True, True, True], device=dev) if args.workload == "water" else None
+    nl_kw = dict(idx_m=inp["_idx_m"], cell=nl_cell, pbc=nl_pbc, n_systems=int(batch["n_mol"]))
+    nl = NL.neighbor_list(inp["_positions"].detach(), cutoff, **nl_kw)
+    t_nl = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        NL.neighbor_list(inp["_positions"].detach(), cutoff, **nl_kw)
+        torch.cuda.synchronize()
+        t_nl.append(time.perf_counter() - c0)
+    t_nl.sort()
+    nbl = {"pairs": int(nl["_idx_i"].shape[0]), "matches_input_list": int(nl["_idx_i"].shape[0]) == E,
+           "build_ms": round(1e3 * t_nl[len(t_nl) // 2], 4), "M_pairs_per_s": round(E / t_nl[len(t_nl) // 2] / 1e6, 1),
+           "note": "count + fill incl. allocation and the one D2H of the pair count (wall clock, median of 5)"}
+
     # ---------------- CPU baseline: the oracle on the host cores, same batch, same weights
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -259,6 +277,14 @@ def main():
                "parity_rel_forces": float((f_ref.cpu() - oc["forces"]).abs().max() / oc["forces"].abs().max()),
                "parity_rel_energy": float((e_ref.cpu() - oc["energy"]).abs().max() / oc["energy"].abs().max())}
 
+    if cpu is not None and args.workload == "aspirin":
+        # the reference's per-molecule TorchNeighborList loop, restated (oracle/nbl_oracle.py), same batch
+        from oracle import nbl_oracle as NB
+        c0 = time.perf_counter()
+        oi, _, _, _ = NB.batch_neighbor_list(batch["R"], batch["idx_m"], None, None, cutoff)
+        nbl["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - c0), 2)
+        nbl["cpu_oracle_pairs"] = int(oi.shape[0])
+
     info = _lib.device_info()
     line = {
         "metric": "M edge-messages/s (eval force call, %s, %s)" % ("MD17-aspirin 256-frame batch" if args.workload == "aspirin" else "32k-atom bulk-water PBC box", "SchNet" if args.kind == "schnet" else "PaiNN"),
@@ -272,7 +298,7 @@ def main():
                    "n_atoms": N, "n_edges": E, "frames_per_s": round((hi - lo) * world * args.steps / dt, 1),
                    "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                    "hip_graph": graph is not None, "variant": args.variant, "compute_units": info["compute_units"]},
-        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "scatter_add": scatter,
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "scatter_add": scatter, "neighbor_list": nbl,
     }
     print(json.dumps(line))
     if dist is not None:

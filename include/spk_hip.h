@@ -124,6 +124,27 @@ int spk_pairwise_bwd_f32(const float* gr, const int64_t* idx_i, const int64_t* i
  * take the atomic kernel above. */
 int spk_pairwise_bwd_graph_f32(const float* gr, const spk_graph_t* g, float* gR, void* stream);
 
+/* ------------------------------------------------------------------ transform/neighborlist.py:438-507
+ * (TorchNeighborList) and md/neighborlist_md.py:100-159 -- cell-list neighbour list on the device for
+ * a batch of independent systems (molecules / MD replicas).  Result: every DIRECTED pair (i, j, S)
+ * with |R_j - R_i + S.cell| < cutoff (i != j or S != 0), S integer shifts along the periodic axes,
+ * offsets = S.cell, idx_i ascending (rowptr is its CSR), deterministic order inside a row,
+ * symmetric by construction.
+ *   R [n_atoms,3]; idx_m [n_atoms] int64 ascending system index or NULL (one system);
+ *   cell [n_sys,3,3] row vectors or NULL; pbc [n_sys,3] bytes (torch.bool) or NULL (not periodic).
+ * Two phases because the pair count is data dependent and the caller owns all memory:
+ *   spk_nbl_count_f32  bins the atoms, counts, writes rowptr [n_atoms+1] and returns the number of
+ *                      pairs through n_edges_host (synchronises the stream once);
+ *   spk_nbl_fill_f32   writes idx_i, idx_j [n_edges] int64, shifts [n_edges,3] int32 (may be NULL)
+ *                      and offsets [n_edges,3]; same R / idx_m / cutoff / workspace as the count. */
+int64_t spk_nbl_workspace_bytes(int64_t n_atoms, int64_t n_sys);
+int spk_nbl_count_f32(const float* R, const int64_t* idx_m, const float* cell, const uint8_t* pbc,
+                      int64_t n_atoms, int64_t n_sys, float cutoff, void* workspace,
+                      int32_t* rowptr, int64_t* n_edges_host, void* stream);
+int spk_nbl_fill_f32(const float* R, const int64_t* idx_m, int64_t n_atoms, int64_t n_sys,
+                     float cutoff, const void* workspace, const int32_t* rowptr, int64_t n_edges,
+                     int64_t* idx_i, int64_t* idx_j, int32_t* shifts, float* offsets, void* stream);
+
 /* ------------------------------------------------------------------ atomistic/atomwise.py:69-88
  * The default output head, build_mlp(n_in, 1, n_layers=2) (nn/blocks.py:38-57) + sum over idx_m:
  *   y_n = w2 . act(W1 x_n + b1) + b2,   E[idx_m[n]] += y_n           (E [n_mol] is overwritten)

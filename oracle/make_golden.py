@@ -149,5 +149,61 @@ def main():
          radial="gaussian", n_interactions=int(rep.n_interactions), **w)
 
 
+def neighbor_list_goldens(ns):
+    """(1) the reference's own precomputed Argon vectors (tests/conftest.py:192-447), lifted out of the
+    fixture functions; (2) TorchNeighborList outputs (transform/neighborlist.py:438-553) on seeded
+    systems: orthorhombic, triclinic + mixed pbc, a cell smaller than the cutoff (several images of the
+    same atom), no pbc, fp64 positions."""
+    import ast
+    import types
+    from oracle import nbl_oracle as NB
+    src = open(os.path.join(refshim.REF_SRC, "..", "tests", "conftest.py")).read()
+    props = types.SimpleNamespace(Z="_atomic_numbers", R="_positions", cell="_cell", pbc="_pbc", n_atoms="_n_atoms",
+                                  idx_i="_idx_i", idx_j="_idx_j", offsets="_offsets", Rij="_Rij")
+    env = {"np": np, "torch": torch, "spk": types.SimpleNamespace(properties=props)}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("environment_periodic", "environment_nonperiodic"):
+            node.decorator_list = []
+            exec(compile(ast.Module([node], []), "conftest", "exec"), env)
+    arrs = {}
+    for tag in ("periodic", "nonperiodic"):
+        cutoff, p, nb = env["environment_" + tag]()
+        arrs[tag + "_cutoff"] = cutoff
+        for k in ("_positions", "_cell", "_pbc"):
+            arrs[tag + k] = p[k].numpy()
+        for k, v in nb.items():
+            arrs[tag + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "nbl_argon.npz"), **arrs)
+    print("wrote nbl_argon.npz", {k: getattr(v, "shape", v) for k, v in arrs.items()})
+
+    g = torch.Generator().manual_seed(11)
+    cases = {
+        "ortho": (torch.rand(60, 3, generator=g) * torch.tensor([7.0, 6.0, 8.0]), torch.diag(torch.tensor([7.0, 6.0, 8.0])), [True, True, True], 5.0),
+        "triclinic_mixed": (torch.rand(50, 3, generator=g) * 9.0 - 1.0, torch.tensor([[9.0, 0.0, 0.0], [2.5, 8.0, 0.0], [1.0, -1.5, 10.0]]), [True, True, False], 4.0),
+        "small_cell": (torch.rand(12, 3, generator=g) * 3.5, torch.tensor([[3.6, 0.0, 0.0], [0.4, 3.5, 0.0], [0.0, 0.3, 4.0]]), [True, True, True], 5.0),
+        "free": (torch.randn(80, 3, generator=g) * 4.0, torch.zeros(3, 3), [False, False, False], 3.0),
+        # (positions inside the cell along the periodic axes: TorchNeighborList only searches +-ceil(cutoff/height)
+        #  images of the UNWRAPPED positions, so it misses pairs of atoms that sit several cells apart)
+        "slab_fp64": (torch.rand(40, 3, generator=g, dtype=torch.float64) * torch.tensor([6.0, 6.5, 12.0], dtype=torch.float64), torch.diag(torch.tensor([6.0, 6.5, 30.0], dtype=torch.float64)), [True, True, False], 4.5),
+    }
+    arrs = {"names": np.array(sorted(cases))}
+    for name, (R, cell, pbc, rc) in cases.items():
+        pbc = torch.tensor(pbc)
+        nl = ns.neighborlist.TorchNeighborList(rc)
+        i, j, off = nl._build_neighbor_list(None, R, cell, pbc, rc)
+        S = torch.round(off @ torch.linalg.inv(cell)).long() if bool(pbc.any()) else torch.zeros(i.shape[0], 3, dtype=torch.long)
+        order = NB.canonical_order(i, j, S)
+        arrs.update({name + "_R": R.numpy(), name + "_cell": cell.numpy(), name + "_pbc": pbc.numpy(), name + "_cutoff": rc,
+                     name + "_idx_i": i[order].numpy(), name + "_idx_j": j[order].numpy(), name + "_S": S[order].numpy(),
+                     name + "_offsets": off[order].numpy()})
+        print("  nbl case", name, "pairs", int(i.shape[0]))
+    np.savez_compressed(os.path.join(OUT, "nbl_cases.npz"), **arrs)
+    print("wrote nbl_cases.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "nbl":
+        neighbor_list_goldens(refshim.load())
+    else:
+        main()
+        neighbor_list_goldens(refshim.load())

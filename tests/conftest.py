@@ -16,6 +16,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def load_npz(name):
+    """Raw arrays of a fixture file."""
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return {k: (z[k].item() if z[k].shape == () else z[k]) for k in z.files}
+
+
 def load_golden(name):
     """Return (batch dict of tensors, reference outputs dict of tensors, meta dict)."""
     z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)

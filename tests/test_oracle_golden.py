@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, MODEL_CASES, golden_params, load_golden, rel_err
+from conftest import GOLDEN, MODEL_CASES, golden_params, load_golden, load_npz, rel_err
 from oracle import spk_oracle as O
 
 KA = np.load(GOLDEN + "/nn_known_answers.npz")
@@ -89,3 +89,34 @@ def test_neighbor_list_symmetric_sorted():
     assert bool((ii[1:] >= ii[:-1]).all())
     fwd = set(zip(ii.tolist(), jj.tolist()))
     assert all((j, i) in fwd for i, j in fwd)
+
+
+# ----------------------------------------------------------------------------- neighbour list (row f1)
+def test_nbl_oracle_reproduces_reference_argon_vectors():
+    """The reference's precomputed Argon neighbourhoods (tests/conftest.py:192-447): same pairs and
+    distance vectors after the canonical sort of its own test (tests/data/test_transforms.py:53-104)."""
+    from oracle import nbl_oracle as NB
+    g = load_npz("nbl_argon.npz")
+    for tag in ("periodic", "nonperiodic"):
+        R = torch.from_numpy(g[tag + "_positions"])
+        cell = torch.from_numpy(g[tag + "_cell"]).reshape(3, 3)
+        pbc = torch.from_numpy(g[tag + "_pbc"])
+        i, j, S, off = NB.neighbor_list(R, cell, pbc, float(g[tag + "_cutoff"]))
+        Rij = R[j] - R[i] + off
+        ri, rj, rRij = (torch.from_numpy(g[tag + k]) for k in ("_idx_i", "_idx_j", "_Rij"))
+        assert i.shape == ri.shape, tag
+        key = lambda a, b, v: np.lexsort((np.round(v[:, 2].numpy(), 3), np.round(v[:, 1].numpy(), 3), np.round(v[:, 0].numpy(), 3), b.numpy(), a.numpy()))
+        o1, o2 = key(i, j, Rij), key(ri, rj, rRij)
+        assert torch.equal(i[o1], ri[o2]) and torch.equal(j[o1], rj[o2]), tag
+        assert torch.allclose(Rij[o1], rRij[o2], atol=1e-4), tag
+
+
+def test_nbl_oracle_reproduces_torch_neighbor_list_fixtures():
+    from oracle import nbl_oracle as NB
+    g = load_npz("nbl_cases.npz")
+    for name in [str(n) for n in g["names"]]:
+        R = torch.from_numpy(g[name + "_R"])
+        i, j, S, off = NB.neighbor_list(R, torch.from_numpy(g[name + "_cell"]), torch.from_numpy(g[name + "_pbc"]), float(g[name + "_cutoff"]))
+        assert torch.equal(i, torch.from_numpy(g[name + "_idx_i"])) and torch.equal(j, torch.from_numpy(g[name + "_idx_j"])), name
+        assert torch.equal(S, torch.from_numpy(g[name + "_S"])), name
+        assert torch.allclose(off, torch.from_numpy(g[name + "_offsets"]), atol=1e-6), name

@@ -117,3 +117,30 @@ def test_install_hook_patches_reference_namespace_and_pickles_resolve_to_mirrors
             setattr(sys.modules[mod], k, v)
         spk.representation.SchNet = ns.schnet.SchNet
         spk.representation.PaiNN = ns.painn.PaiNN
+
+
+def test_nbl_oracle_equals_live_torch_neighbor_list():
+    """oracle/nbl_oracle.py against the reference's TorchNeighborList class itself
+    (transform/neighborlist.py:438-553) on seeded systems, incl. the transform's forward()."""
+    from oracle import nbl_oracle as NB
+    ns = refshim.load()
+    if ns.neighborlist is None:
+        pytest.skip("reference neighbour-list module not importable: %s" % ns.neighborlist_error)
+    g = torch.Generator().manual_seed(5)
+    cases = [
+        (torch.rand(45, 3, generator=g) * 7.0, torch.diag(torch.tensor([7.0, 6.0, 8.0])), [True, True, True], 5.0),
+        (torch.rand(30, 3, generator=g) * 9.0, torch.tensor([[9.0, 0, 0], [2.0, 8.0, 0], [1.0, -1.0, 9.5]]), [True, False, True], 4.0),
+        (torch.rand(8, 3, generator=g) * 3.0, torch.diag(torch.tensor([3.2, 3.4, 3.1])), [True, True, True], 5.0),
+        (torch.randn(50, 3, generator=g) * 3.0, torch.zeros(3, 3), [False, False, False], 3.5),
+    ]
+    for R, cell, pbc, rc in cases:
+        pbc = torch.tensor(pbc)
+        tnl = ns.neighborlist.TorchNeighborList(rc)
+        out = tnl({"_atomic_numbers": torch.ones(R.shape[0], dtype=torch.long), "_positions": R, "_cell": cell.reshape(1, 3, 3), "_pbc": pbc})
+        i, j, off = out["_idx_i"], out["_idx_j"], out["_offsets"]
+        assert bool((i[1:] >= i[:-1]).all())
+        S = torch.round(off @ torch.linalg.inv(cell)).long() if bool(pbc.any()) else torch.zeros(i.shape[0], 3, dtype=torch.long)
+        order = NB.canonical_order(i, j, S)
+        oi, oj, oS, oo = NB.neighbor_list(R, cell, pbc, rc)
+        assert torch.equal(i[order], oi) and torch.equal(j[order], oj) and torch.equal(S[order], oS)
+        assert torch.allclose(off[order], oo, atol=1e-6)
