@@ -145,6 +145,26 @@ int spk_nbl_fill_f32(const float* R, const int64_t* idx_m, int64_t n_atoms, int6
                      float cutoff, const void* workspace, const int32_t* rowptr, int64_t n_edges,
                      int64_t* idx_i, int64_t* idx_j, int32_t* shifts, float* offsets, void* stream);
 
+/* ------------------------------------------------------------------ md/integrators.py
+ * Elementwise MD steps on device arrays (any unit system; dt in the caller's time unit).
+ * spk_md_half_step_f32      p += half_dt * F over n floats                       (:59-70)
+ * spk_md_kick_drift_f32     first half step + velocity-Verlet main step fused    (:59-70, :97-110):
+ *                           p += dt/2 F (skipped when F is NULL);  R += dt p / m,  masses [n_atoms];
+ *                           with R_ref / flag: flag[0] |= 1 when any atom is further than
+ *                           sqrt(max_disp2) from R_ref (neighbour-list skin, md/neighborlist_md.py:80-90)
+ * spk_md_ring_polymer_step_f32   ring-polymer main step (:204-229) for the beads
+ *                           [bead0, bead0+n_local) of this rank from ALL beads q_all, p_all
+ *                           [n_beads, n_atoms, 3]; A [4, n_beads, n_beads] = C^T diag(P_ij) C for
+ *                           (ij) = pp, pq, qp, qq (C: normal_model_transformation.py:38-68,
+ *                           P: integrators.py:152-199); q_out, p_out [n_local, n_atoms, 3]. */
+int spk_md_half_step_f32(float* p, const float* F, float half_dt, int64_t n, void* stream);
+int spk_md_kick_drift_f32(float* R, float* p, const float* F, const float* masses, float dt,
+                          int64_t n_atoms, const float* R_ref, float max_disp2, int32_t* flag,
+                          void* stream);
+int spk_md_ring_polymer_step_f32(const float* q_all, const float* p_all, const float* masses,
+                                 const float* A, int32_t n_beads, int64_t n_atoms, int32_t bead0,
+                                 int32_t n_local, float* q_out, float* p_out, void* stream);
+
 /* ------------------------------------------------------------------ atomistic/atomwise.py:69-88
  * The default output head, build_mlp(n_in, 1, n_layers=2) (nn/blocks.py:38-57) + sum over idx_m:
  *   y_n = w2 . act(W1 x_n + b1) + b2,   E[idx_m[n]] += y_n           (E [n_mol] is overwritten)

@@ -201,9 +201,63 @@ def neighbor_list_goldens(ns):
     print("wrote nbl_cases.npz")
 
 
+def ring_polymer_goldens():
+    """Execute the reference's own RingPolymer._init_propagator / _main_step (md/integrators.py:152-229)
+    and NormalModeTransformer (md/utils/normal_model_transformation.py) on seeded beads.  The two modules
+    pull in the whole MD package, so the two methods are lifted out with ``ast`` and run against a
+    minimal System stand-in that has exactly the normal-mode properties of md/system.py:444-482."""
+    import ast
+    import importlib.util
+    import types
+    md_dir = os.path.join(refshim.REF_SRC, "schnetpack", "md")
+    spec = importlib.util.spec_from_file_location("_ref_nmt", os.path.join(md_dir, "utils", "normal_model_transformation.py"))
+    nmt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(nmt)
+    tree = ast.parse(open(os.path.join(md_dir, "integrators.py")).read())
+    rp = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "RingPolymer"][0]
+    fns = {}
+    env = {"torch": torch, "np": np, "System": object}
+    for node in rp.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("_init_propagator", "_main_step"):
+            exec(compile(ast.Module([node], []), "integrators", "exec"), env)
+            fns[node.name] = env[node.name]
+
+    class Sys:
+        def __init__(self, q, p, m, nb):
+            self.positions, self.momenta, self.masses = q, p, m
+            self.nm_transform = nmt.NormalModeTransformer(nb)
+        positions_normal = property(lambda s: s.nm_transform.beads2normal(s.positions),
+                                    lambda s, v: setattr(s, "positions", s.nm_transform.normal2beads(v)))
+        momenta_normal = property(lambda s: s.nm_transform.beads2normal(s.momenta),
+                                  lambda s, v: setattr(s, "momenta", s.nm_transform.normal2beads(v)))
+
+    arrs = {}
+    g = torch.Generator().manual_seed(21)
+    for nb in (1, 2, 4, 5, 8):
+        omega, dt = 40.0 + 3.0 * nb, 0.0005
+        me = types.SimpleNamespace(n_beads=nb, omega=omega, time_step=dt)
+        omega_normal, prop = fns["_init_propagator"](me)
+        me.propagator = prop
+        q = torch.randn(nb, 7, 3, generator=g, dtype=torch.float64)
+        p = torch.randn(nb, 7, 3, generator=g, dtype=torch.float64)
+        m = (torch.rand(1, 7, 1, generator=g, dtype=torch.float64) * 15 + 1)
+        sysm = Sys(q.clone(), p.clone(), m, nb)
+        fns["_main_step"](me, sysm)
+        t = "b%d_" % nb
+        arrs.update({t + "omega": omega, t + "dt": dt, t + "C": sysm.nm_transform.c_transform.numpy(),
+                     t + "propagator": prop[..., 0, 0].numpy(), t + "omega_normal": omega_normal.numpy(),
+                     t + "q": q.numpy(), t + "p": p.numpy(), t + "m": m.numpy(),
+                     t + "q_out": sysm.positions.numpy(), t + "p_out": sysm.momenta.numpy()})
+    np.savez_compressed(os.path.join(OUT, "md_ring_polymer.npz"), **arrs)
+    print("wrote md_ring_polymer.npz", sorted(k for k in arrs if k.startswith("b8_")))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "nbl":
+    if len(sys.argv) > 1 and sys.argv[1] == "md":
+        ring_polymer_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "nbl":
         neighbor_list_goldens(refshim.load())
     else:
         main()
         neighbor_list_goldens(refshim.load())
+        ring_polymer_goldens()

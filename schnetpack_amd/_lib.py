@@ -87,6 +87,9 @@ _PROTOS = {
     "spk_nbl_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "spk_nbl_count_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, ctypes.c_float, c_f, c_f, ctypes.POINTER(ctypes.c_int64), c_f]),
     "spk_nbl_fill_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i64, ctypes.c_float, c_f, c_f, c_i64, c_f, c_f, c_f, c_f, c_f]),
+    "spk_md_half_step_f32": (ctypes.c_int, [c_f, c_f, ctypes.c_float, c_i64, c_f]),
+    "spk_md_kick_drift_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, ctypes.c_float, c_i64, c_f, ctypes.c_float, c_f, c_f]),
+    "spk_md_ring_polymer_step_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i32, c_i64, c_i32, c_i32, c_f, c_f, c_f]),
     "spk_atomwise_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "spk_atomwise_fwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i64, c_f, c_f, c_f, c_f]),
     "spk_atomwise_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i64, c_f, c_f]),

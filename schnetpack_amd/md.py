@@ -1,0 +1,243 @@
+"""MD steps around the force call: the velocity-Verlet and ring-polymer
+integrators of the reference (md/integrators.py:24-229) on fused HIP kernels, and a bead-parallel ring
+polymer (one bead per rank, one all-gather per step).  Unit agnostic: ``time_step`` is in the unit system
+of the tensors handed in (the reference's MD internal units are kJ/mol, nm, Dalton => ps; 1 fs = 1e-3).
+
+``state`` objects only need ``positions``, ``momenta``, ``forces`` ([n_replicas, n_atoms, 3]) and
+``masses`` ([1, n_atoms, 1] or [n_atoms]) attributes -- what ``schnetpack.md.System`` has.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, fptr, lib, stream
+
+__all__ = ["VelocityVerlet", "RingPolymer", "normal_mode_matrix", "ring_polymer_propagator", "ring_polymer_matrices",
+           "KB_MD", "HBAR_MD", "FS_MD"]
+
+# reference MD internal units (kJ/mol, nm, Dalton): time unit = 1 ps (units.py:10-40)
+FS_MD = 1.0e-3
+KB_MD = 8.314462618e-3          # kJ / (mol K)
+HBAR_MD = 6.350779923e-2        # kJ / mol * ps
+
+
+def _flat_masses(masses: torch.Tensor, n_atoms: int) -> torch.Tensor:
+    m = masses.reshape(-1)
+    if m.numel() != n_atoms:
+        raise _lib.SpkHipError("masses: expected %d entries, got %d" % (n_atoms, m.numel()))
+    return m.float().contiguous()
+
+
+class VelocityVerlet:
+    """md/integrators.py:24-110.  ``half_step`` / ``main_step`` as in the reference, plus
+    ``first_half_and_main_step`` which fuses the two that are adjacent in the MD loop
+    (md/simulator.py:126-150) into one pass and evaluates the neighbour-list skin criterion on the way."""
+
+    ring_polymer = False
+    pressure_control = False
+
+    def __init__(self, time_step: float):
+        self.time_step = float(time_step)
+
+    def half_step(self, state):
+        p = state.momenta
+        with torch.cuda.device(p.device):
+            check(lib().spk_md_half_step_f32(fptr(p), fptr(state.forces.contiguous()), 0.5 * self.time_step, p.numel(), stream()))
+
+    def main_step(self, state):
+        self.first_half_and_main_step(state, kick=False)
+
+    def first_half_and_main_step(self, state, kick: bool = True, reference_positions: Optional[torch.Tensor] = None,
+                                 max_displacement: float = 0.0, flag: Optional[torch.Tensor] = None):
+        R, p = state.positions, state.momenta
+        n_rep = R.shape[0] if R.dim() == 3 else 1
+        n_atoms = R.numel() // 3
+        m = _flat_masses(state.masses, n_atoms // n_rep)
+        if n_rep > 1:
+            m = m.repeat(n_rep)
+        F = state.forces.contiguous() if kick else None
+        with torch.cuda.device(R.device):
+            check(lib().spk_md_kick_drift_f32(fptr(R), fptr(p), fptr(F), fptr(m), self.time_step, n_atoms,
+                                              fptr(reference_positions), float(max_displacement) ** 2,
+                                              _lib.iptr(flag, torch.int32) if flag is not None else None, stream()))
+
+
+def normal_mode_matrix(n_beads: int) -> torch.Tensor:
+    """C[k, n] (md/utils/normal_model_transformation.py:38-68), float64."""
+    B = n_beads
+    n = torch.arange(1, B + 1, dtype=torch.float64)
+    C = torch.zeros(B, B, dtype=torch.float64)
+    C[0] = 1.0
+    for k in range(1, B // 2 + 1):
+        C[k] = math.sqrt(2.0) * torch.cos(2.0 * math.pi * k * n / B)
+    for k in range(B // 2 + 1, B):
+        C[k] = math.sqrt(2.0) * torch.sin(2.0 * math.pi * k * n / B)
+    if B % 2 == 0:
+        C[B // 2] = torch.where(n.long() % 2 == 0, 1.0, -1.0).double()
+    return C / math.sqrt(B)
+
+
+def ring_polymer_propagator(n_beads: int, omega: float, time_step: float) -> torch.Tensor:
+    """[n_beads, 2, 2] free ring-polymer propagator in normal modes (md/integrators.py:152-199)."""
+    on = 2.0 * omega * torch.sin(torch.arange(n_beads).float() * math.pi / n_beads)
+    odt = on * time_step
+    P = torch.zeros(n_beads, 2, 2)
+    P[:, 0, 0] = torch.cos(odt)
+    P[:, 1, 1] = torch.cos(odt)
+    P[:, 0, 1] = -torch.sin(odt) * on
+    P[1:, 1, 0] = torch.sin(odt)[1:] / on[1:]
+    P[0, 1, 0] = time_step
+    return P
+
+
+def ring_polymer_matrices(n_beads: int, omega: float, time_step: float) -> torch.Tensor:
+    """A [4, B, B] = C^T diag(P_ij) C for (ij) = pp, pq, qp, qq: transform, propagate and back-transform
+    folded into bead-space matrices (they are linear maps; evaluated in float64, stored float32)."""
+    C = normal_mode_matrix(n_beads)
+    P = ring_polymer_propagator(n_beads, omega, time_step).double()
+    return torch.stack([C.t() @ torch.diag(P[:, i, j]) @ C for (i, j) in ((0, 0), (0, 1), (1, 0), (1, 1))]).float().contiguous()
+
+
+class RingPolymer(VelocityVerlet):
+    """md/integrators.py:113-229.  ``positions`` / ``momenta`` are [n_beads, n_atoms, 3].
+
+    Single process: all beads local.  Bead-parallel (``group`` given, one contiguous bead chunk per rank,
+    SURVEY.md section 8(e)): the rank's [n_local, n_atoms, 3] positions and momenta are packed into one
+    buffer, all-gathered ONCE per step (RCCL over xGMI; 2 x 384 KB per rank at 32 k atoms) and every
+    rank evaluates only its own beads of the mixed result -- no second exchange for the back-transform.
+    """
+
+    ring_polymer = True
+
+    def __init__(self, time_step: float, n_beads: int, temperature: float, omega: Optional[float] = None,
+                 group=None, compute_fn=None):
+        super().__init__(time_step)
+        self.n_beads = int(n_beads)
+        self.omega = float(omega) if omega is not None else KB_MD * n_beads * temperature / HBAR_MD
+        self.A = ring_polymer_matrices(self.n_beads, self.omega, self.time_step)
+        self.group = group
+        self._compute = compute_fn or _ring_polymer_hip
+        self._A_dev = None
+
+    def _bead_range(self):
+        if self.group is None:
+            return 0, self.n_beads, 1
+        import torch.distributed as dist
+        from .parallel import shard_frames
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        lo, hi = shard_frames(self.n_beads, rank, world)
+        if (hi - lo) * world != self.n_beads:
+            raise ValueError("bead-parallel ring polymer needs n_beads divisible by the number of ranks")
+        return lo, hi, world
+
+    def main_step(self, state):
+        q, p = state.positions, state.momenta
+        lo, hi, world = self._bead_range()
+        n_local = hi - lo
+        if q.shape[0] != n_local:
+            raise ValueError("expected %d local beads, got %d" % (n_local, q.shape[0]))
+        n_atoms = q.shape[1]
+        if self._A_dev is None or self._A_dev.device != q.device:
+            self._A_dev = self.A.to(q.device)
+        if world > 1:
+            import torch.distributed as dist
+            local = torch.stack([q, p]).contiguous()                      # [2, n_local, n, 3]
+            allb = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(allb, local.view(-1), group=self.group)
+            allb = allb.view((world,) + tuple(local.shape))                # [world, 2, n_local, n, 3]
+            q_all = allb[:, 0].reshape(self.n_beads, n_atoms, 3).contiguous()
+            p_all = allb[:, 1].reshape(self.n_beads, n_atoms, 3).contiguous()
+        else:
+            q_all, p_all = q.contiguous(), p.contiguous()
+        q_new, p_new = self._compute(q_all, p_all, state.masses, self._A_dev, lo, n_local)
+        state.positions, state.momenta = q_new, p_new
+
+
+def _ring_polymer_hip(q_all, p_all, masses, A, bead0, n_local):
+    B, n_atoms = int(q_all.shape[0]), int(q_all.shape[1])
+    m = _flat_masses(masses, n_atoms).to(q_all.device)
+    q_out = torch.empty((n_local, n_atoms, 3), dtype=torch.float32, device=q_all.device)
+    p_out = torch.empty_like(q_out)
+    with torch.cuda.device(q_all.device):
+        check(lib().spk_md_ring_polymer_step_f32(fptr(q_all), fptr(p_all), fptr(m), fptr(A), B, n_atoms, int(bead0), int(n_local),
+                                                 fptr(q_out), fptr(p_out), stream()))
+    return q_out, p_out
+
+
+class MDState:
+    """Minimal stand-in for ``schnetpack.md.System`` (md/system.py): the tensors the integrators touch."""
+
+    def __init__(self, positions, momenta, masses, forces=None):
+        self.positions, self.momenta, self.masses = positions, momenta, masses
+        self.forces = forces if forces is not None else torch.zeros_like(positions)
+
+
+class NVESimulation:
+    """The inner loop of ``md.Simulator.simulate`` (md/simulator.py:124-157) for plain NVE dynamics of ONE
+    batch of systems on one GPU, everything resident on the device:
+
+        kick + drift + skin check (1 kernel)  ->  [neighbour-list rebuild + graph re-capture if an atom left
+        the skin]  ->  force call (HIP-graph replay)  ->  kick (1 kernel)
+
+    One scalar D2H per step (the skin flag).  ``inputs`` is the batch dict on the device with
+    ``_positions`` [N,3], ``_atomic_numbers``, ``_idx_m``, ``_n_atoms`` and (periodic) ``_cell`` / ``_pbc``;
+    positions, masses, time step and the model's energy must share one unit system
+    (forces = -dE/dpositions)."""
+
+    def __init__(self, model, inputs, masses, time_step, cutoff, cutoff_shell=1.0, use_graph=True):
+        from . import properties
+        from .forcecall import GraphedForceCall
+        from .neighborlist import NeighborListMD
+        self.P = properties
+        self.inputs = dict(inputs)
+        R = inputs[properties.R].detach().float().contiguous().clone()
+        self.state = MDState(R.unsqueeze(0), torch.zeros_like(R).unsqueeze(0), masses.float().reshape(1, -1, 1))
+        self.integrator = VelocityVerlet(time_step)
+        self.nl = NeighborListMD(cutoff, cutoff_shell, filter_buffer=False)
+        self.force_call = GraphedForceCall(model, use_graph=use_graph)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=R.device)
+        self.n_molecules = int(inputs[properties.n_atoms].shape[0])
+        self.energy = None
+        self._lists = None
+        self.t_rebuild = 0.0          # wall time spent in list rebuilds + graph re-captures (synchronised)
+        self._forces(rebuild=True)
+
+    def _forces(self, rebuild):
+        import time
+        P = self.P
+        R = self.state.positions[0]
+        rebuild = rebuild or self._lists is None
+        if rebuild:
+            t0 = time.perf_counter()
+            self.inputs[P.R] = R
+            self._lists = self.nl.get_neighbors(self.inputs)
+            self.flag.zero_()
+        call = dict(self.inputs)
+        call.update(self._lists)
+        call[P.R] = R
+        call["_n_molecules"] = self.n_molecules
+        out = self.force_call(call)
+        if rebuild:
+            torch.cuda.synchronize(R.device)
+            self.t_rebuild += time.perf_counter() - t0
+        self.state.forces = out["forces"].unsqueeze(0)
+        self.energy = out["energy"]
+
+    def step(self, n_steps=1):
+        half_skin = 0.5 * self.nl.cutoff_shell
+        for _ in range(n_steps):
+            self.integrator.first_half_and_main_step(self.state, True, self.nl.previous_positions, half_skin, self.flag)
+            moved = bool(self.flag.item())            # the one host sync of the step
+            if moved:
+                self.nl._list = None                  # force the rebuild with the new positions
+            self._forces(rebuild=moved)
+            self.integrator.half_step(self.state)
+
+    def kinetic_energy(self):
+        p, m = self.state.momenta[0], self.state.masses.reshape(-1, 1)
+        return 0.5 * (p * p / m).sum()
+
+    def total_energy(self):
+        return float(self.energy.sum() + self.kinetic_energy())

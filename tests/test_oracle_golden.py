@@ -120,3 +120,21 @@ def test_nbl_oracle_reproduces_torch_neighbor_list_fixtures():
         assert torch.equal(i, torch.from_numpy(g[name + "_idx_i"])) and torch.equal(j, torch.from_numpy(g[name + "_idx_j"])), name
         assert torch.equal(S, torch.from_numpy(g[name + "_S"])), name
         assert torch.allclose(off, torch.from_numpy(g[name + "_offsets"]), atol=1e-6), name
+
+
+# ----------------------------------------------------------------------------- MD steps (row f3)
+def test_md_oracle_reproduces_reference_ring_polymer_step():
+    """oracle/md_oracle.py against outputs of the reference's own RingPolymer._init_propagator /
+    _main_step + NormalModeTransformer (executed by oracle/make_golden.py)."""
+    from oracle import md_oracle as MD
+    g = load_npz("md_ring_polymer.npz")
+    for nb in (1, 2, 4, 5, 8):
+        t = "b%d_" % nb
+        C = MD.normal_mode_matrix(nb)
+        assert torch.allclose(C, torch.from_numpy(g[t + "C"]), atol=1e-14)
+        on, P = MD.ring_polymer_propagator(nb, float(g[t + "omega"]), float(g[t + "dt"]))
+        assert torch.equal(on, torch.from_numpy(g[t + "omega_normal"])) and torch.equal(P, torch.from_numpy(g[t + "propagator"]))
+        q, p, m = (torch.from_numpy(g[t + k]) for k in ("q", "p", "m"))
+        q2, p2 = MD.ring_polymer_main_step(q, p, m, C, P)
+        assert torch.allclose(q2, torch.from_numpy(g[t + "q_out"]), atol=1e-13)
+        assert torch.allclose(p2, torch.from_numpy(g[t + "p_out"]), atol=1e-12)
