@@ -62,13 +62,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (there is no CPU fallback of the product path)")
+    local = local % torch.cuda.device_count()      # (several ranks may share a device in the gloo self-test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" is RCCL on ROCm.  SPK_BENCH_BACKEND=gloo lets two ranks share ONE device so that the multi-rank
+        # control flow (sharding, barriers, max-over-ranks timing) can be exercised on a single-GPU box.
+        backend = os.environ.get("SPK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from oracle import spk_oracle as O          # parameters (seeded init) + cpu_baseline leg only
     from schnetpack_amd import _lib, model as M, synthetic as S
@@ -149,10 +156,11 @@ def main():
     dt = time.perf_counter() - t0
     E_total = E
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        et = torch.tensor([E], device=dev, dtype=torch.float64)
+        et = torch.tensor([E], device=rdev, dtype=torch.float64)
         dist.all_reduce(et, op=dist.ReduceOp.SUM)
         E_total = int(et.item())
     value = E_total * n_int * args.steps / dt / 1e6
@@ -349,7 +357,7 @@ def md_main(args, rank, world, dev, dist, model):
     dt = time.perf_counter() - t0
     E_list = int(sim._lists["_idx_i"].shape[0])
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else torch.device("cpu"), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank != 0:
@@ -425,7 +433,7 @@ def train_main(args, rank, world, dev, dist, model, rep_p, head_p):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else torch.device("cpu"), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank != 0:
