@@ -238,6 +238,17 @@ typedef struct {
 } spk_chain_t;
 
 int spk_dense_chain_f32(const spk_chain_t* chain, void* stream);
+/* tuning / test hook: force the row-tile height of the fused chain kernel (16 or 32; 0 = by size:
+ * 16-row tiles on v_mfma_f32_16x16x4_f32 while 32-row tiles would not give every CU two workgroups). */
+/* Packed image of a Linear weight w [n_out, k_in] for the fused chain kernels (layer `trans` code 2):
+ *   transposed == 0: the forward layer y = x W^T  (contraction k_in,  width n_out)
+ *   transposed == 1: the input-gradient layer gx = gy W (contraction n_out, width k_in)
+ *   P[((t KB + ug) 64 + lane) 4 + v] = A[32 t + (lane & 31)][8 ug + 4 (lane >> 5) + v],  KB = contraction / 8;
+ * contraction % 8 == 0 and width % 32 == 0.  packed holds n_out * k_in floats. */
+int spk_pack_weight_f32(const float* w, int32_t n_out, int32_t k_in, int32_t transposed, float* packed, void* stream);
+void spk_chain_set_rows(int32_t rows);
+/* tuning aid: device buffer of >= 16 int64 receiving cycle stamps of workgroup 0 (NULL: off) */
+void spk_chain_set_debug_buffer(void* p);
 
 /* ------------------------------------------------------------------ representation/schnet.py:60-67
  * Fused continuous-filter convolution of one interaction block:
@@ -289,9 +300,17 @@ typedef struct {
                              the raw filter outputs of every (undirected) edge so that the backward runs
                              only the derivative GEMM */
   const spk_schnet_layer_t* layers; /* HOST array of n_interactions entries (device pointers inside) */
+  const float* wpack;     /* optional (may be NULL): packed images of the Dense weights, spk_schnet_packed_floats()
+                             floats filled by spk_schnet_pack_weights_f32(); refresh it when the weights change */
 } spk_schnet_t;
 
 /* floats needed in `saved` (kept from forward to backward) and `scratch` (per call) */
+/* Packed weight images: the fused Dense-chain kernels read every weight as fully coalesced 16-byte-per-lane
+ * tiles (spk_pack_weight_f32).  0 floats = these shapes have no packed form (the drivers then read the plain
+ * / transposed weights); otherwise allocate that many floats, fill them once per weight update and put the
+ * pointer into m->wpack (the `wpack` field of the struct passed here is ignored). */
+int64_t spk_schnet_packed_floats(const spk_schnet_t* m);
+int spk_schnet_pack_weights_f32(const spk_schnet_t* m, float* wpack, void* stream);
 int64_t spk_schnet_saved_floats(const spk_schnet_t* m, int64_t n_atoms);
 int64_t spk_schnet_saved_floats_graph(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb);
 int64_t spk_schnet_scratch_floats(const spk_schnet_t* m, int64_t n_atoms);
@@ -373,8 +392,11 @@ typedef struct {
   float epsilon;          /* PaiNNMixing epsilon (painn.py:73) */
   int32_t reserved;
   const spk_painn_layer_t* layers; /* HOST array of n_interactions entries */
+  const float* wpack;     /* optional packed weight images (spk_painn_packed_floats / spk_painn_pack_weights_f32) */
 } spk_painn_t;
 
+int64_t spk_painn_packed_floats(const spk_painn_t* m);
+int spk_painn_pack_weights_f32(const spk_painn_t* m, float* wpack, void* stream);
 int64_t spk_painn_saved_floats(const spk_painn_t* m, int64_t n_atoms);
 int64_t spk_painn_scratch_floats(const spk_painn_t* m, int64_t n_atoms);
 /* q0 [N,F] = embedding rows; outputs scalar_representation q_out [N,F] and

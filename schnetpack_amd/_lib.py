@@ -45,7 +45,7 @@ class SchnetLayerT(ctypes.Structure):
 
 class SchnetT(ctypes.Structure):
     _fields_ = [("n_atom_basis", c_i32), ("n_filters", c_i32), ("n_interactions", c_i32),
-                ("reserved", c_i32), ("layers", ctypes.POINTER(SchnetLayerT))]
+                ("reserved", c_i32), ("layers", ctypes.POINTER(SchnetLayerT)), ("wpack", c_f)]
 
 
 class ChainLayerT(ctypes.Structure):
@@ -66,7 +66,7 @@ class PainnLayerT(ctypes.Structure):
 
 class PainnT(ctypes.Structure):
     _fields_ = [("n_atom_basis", c_i32), ("n_interactions", c_i32), ("epsilon", ctypes.c_float),
-                ("reserved", c_i32), ("layers", ctypes.POINTER(PainnLayerT))]
+                ("reserved", c_i32), ("layers", ctypes.POINTER(PainnLayerT)), ("wpack", c_f)]
 
 
 P = ctypes.POINTER
@@ -90,6 +90,13 @@ _PROTOS = {
     "spk_md_half_step_f32": (ctypes.c_int, [c_f, c_f, ctypes.c_float, c_i64, c_f]),
     "spk_md_kick_drift_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, ctypes.c_float, c_i64, c_f, ctypes.c_float, c_f, c_f]),
     "spk_md_ring_polymer_step_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i32, c_i64, c_i32, c_i32, c_f, c_f, c_f]),
+    "spk_pack_weight_f32": (ctypes.c_int, [c_f, c_i32, c_i32, c_i32, c_f, c_f]),
+    "spk_schnet_packed_floats": (c_i64, [P(SchnetT)]),
+    "spk_schnet_pack_weights_f32": (ctypes.c_int, [P(SchnetT), c_f, c_f]),
+    "spk_painn_packed_floats": (c_i64, [P(PainnT)]),
+    "spk_painn_pack_weights_f32": (ctypes.c_int, [P(PainnT), c_f, c_f]),
+    "spk_chain_set_rows": (None, [c_i32]),
+    "spk_chain_set_debug_buffer": (None, [c_f]),
     "spk_atomwise_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "spk_atomwise_fwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i64, c_f, c_f, c_f, c_f]),
     "spk_atomwise_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i64, c_f, c_f]),

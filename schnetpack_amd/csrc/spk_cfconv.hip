@@ -1048,7 +1048,7 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(nf >= 1 && nf % 4 == 0, "%s: n_filters=%d must be a multiple of 4", who, nf);
   if (g->n_atoms == 0) return SPK_OK;
   SPK_CHECK_ARG(y != nullptr, "%s: null output", who);
-  if (!pre_zeroed) SPK_HIP_TRY(hipMemsetAsync(y, 0, (size_t)g->n_atoms * nf * sizeof(float), stream));
+  if (!pre_zeroed) { int _zr = spk_zero_async(y, (size_t)g->n_atoms * nf * sizeof(float), stream); if (_zr) return _zr; }
   if (g->n_edges == 0) return SPK_OK;
   SPK_CHECK_ARG(h && r_ij && w1 && b1 && w2 && b2, "%s: null pointer", who);
   CfArgs a;
@@ -1071,7 +1071,7 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(nf >= 1 && nf % 4 == 0, "%s: n_filters=%d must be a multiple of 4", who, nf);
   if (g->n_atoms == 0) return SPK_OK;
   SPK_CHECK_ARG(gh != nullptr, "%s: null output", who);
-  if (!pre_zeroed) SPK_HIP_TRY(hipMemsetAsync(gh, 0, (size_t)g->n_atoms * nf * sizeof(float), stream));
+  if (!pre_zeroed) { int _zr = spk_zero_async(gh, (size_t)g->n_atoms * nf * sizeof(float), stream); if (_zr) return _zr; }
   if (g->n_edges == 0) return SPK_OK;
   SPK_CHECK_ARG(h && gy && r_ij && w1 && b1 && w2 && b2 && gr, "%s: null pointer", who);
   CfArgs a;

@@ -17,7 +17,7 @@
 #define CH_MAXW 384
 
 struct ChainLayerDev {
-  const float* w;        // [NW, KC] (trans == 0) or [KC, NW] (trans == 1)
+  const float* w;        // packed image of the [NW, KC] matrix (spk_pack_weight_f32)
   const float* b;        // [NW] or null
   const float* res;      // [M, NW] or null: added after the activation
   float* out;            // [M, NW] or null: result (after act and residual)
@@ -35,7 +35,9 @@ struct ChainArgs {
   int64_t M;
   float* zero_ptr;       // optional buffer to clear (zero_count floats)
   int64_t zero_count;
+  long long* dbg;        // tuning aid: cycle stamps of thread 0 of workgroup 0 (null in production)
 };
+#define CH_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ float chain_act(int act, float x) {
   if (act == SPK_ACT_SSP) return spk_fast_ssp(x);
@@ -48,22 +50,17 @@ __device__ __forceinline__ float chain_act_grad(int act, float x) {
   return 1.0f;
 }
 
+
 #define CCH 8  // k-blocks per prefetch chunk (64 contraction indices, 32 MFMAs)
 
-// A operands of one chunk (8 k-blocks): every layer of the fused kernel is "k-major" (w is [KC, NW]
-// row-major: the transposed copy of a Linear weight for forward layers, the Linear weight itself for
-// input-gradient layers), so a wave reads 4 coalesced 128-byte rows per k-block.  KC % 64 == 0: no
-// guards, no divergent control flow between the loads.
-__device__ __forceinline__ void chain_load_a(f32x4 (&av)[CCH], const float* __restrict__ w, int NW, int t, int c,
-                                             int el, int hi) {
-  const float* wp = w + ((int64_t)(8 * c * CCH + 4 * hi)) * NW + 32 * t + el;
+// A operands of one chunk (8 k-blocks).  The fused kernels read weights in the PACKED image made by
+// spk_pack_weight_f32:  P[((t KB + ug) 64 + lane) 4 + v] = A[32 t + (lane & 31)][8 ug + 4 (lane >> 5) + v]
+// (A[i][kk] = the [n_out, k] matrix of the layer), so every k-block of a tile is ONE fully coalesced
+// 16-byte-per-lane load (1 KB per instruction, a quarter of the memory instructions of k-major rows).
+__device__ __forceinline__ void chain_load_a(f32x4 (&av)[CCH], const float* __restrict__ w, int KB, int t, int c, int lane) {
+  const f32x4* wp = (const f32x4*)w + ((int64_t)t * KB + c * CCH) * 64 + lane;
 #pragma unroll
-  for (int u = 0; u < CCH; ++u) {
-    f32x4 a4;
-    a4.x = wp[0]; a4.y = wp[NW]; a4.z = wp[2 * (int64_t)NW]; a4.w = wp[3 * (int64_t)NW];
-    av[u] = a4;
-    wp += 8 * (int64_t)NW;
-  }
+  for (int u = 0; u < CCH; ++u) av[u] = wp[u * 64];
 }
 
 __device__ __forceinline__ f32x16 chain_mfma(const f32x4 (&av)[CCH], int c, const float* __restrict__ brow, int hi,
@@ -92,10 +89,10 @@ __device__ __forceinline__ bool chain_next_tile(const ChainArgs& a, int l, int t
   return false;
 }
 
-__global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
+__global__ __launch_bounds__(256, 2) void k_dense_chain(ChainArgs a, int ld0, int ld1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* buf0 = smem;               // [32][ldw]
-  float* buf1 = smem + 32 * ldw;    // [32][ldw]
+  float* buf0 = smem;               // [32][ld0]: the input tile, later the output of layer 1
+  float* buf1 = smem + 32 * ld0;    // [32][ld1]: the output of layer 0
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int hi = lane >> 5, el = lane & 31;
 
@@ -115,50 +112,56 @@ __global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
       int l2 = 0, t2 = wv;
       bool have = wv < a.L[0].NW / 32;
       if (!have) have = chain_next_tile(a, 0, 1 << 20, wv, l2, t2);
-      if (have) chain_load_a(a0, a.L[l2].w, a.L[l2].NW, t2, 0, el, hi);
+      if (have) chain_load_a(a0, a.L[l2].w, a.L[l2].KC / 8, t2, 0, lane);
     }
-    // ---- stage the input tile [32][KC0] into buf0 (coalesced 16-byte rows); all loads of a thread
-    //      are in flight together (KC0 <= 384 => at most 12 pieces per thread)
+    // ---- stage the input tile [32][KC0] into buf0 (coalesced 16-byte rows) in two batches of up to 6
+    //      pieces per thread (KC0 <= 384), all loads of a batch in flight together
     {
       const int KC0 = a.L[0].KC;
       const int q4 = KC0 / 4;
       const int total = 32 * q4;
-      f32x4 v[12], pz[12];
+      for (int i0 = 0; i0 < 12; i0 += 6) {
+        if (threadIdx.x + 256 * i0 >= total) break;
+        f32x4 v[6], pz[6];
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        const int s = threadIdx.x + 256 * i;
-        if (s < total) {
-          const int row = s / q4, c4 = s - row * q4;
-          int64_t mm = m0 + row;
-          if (mm >= a.M) mm = a.M - 1;
-          v[i] = *(const f32x4*)(a.in + mm * KC0 + 4 * c4);
-          if (a.in_pre) pz[i] = *(const f32x4*)(a.in_pre + mm * KC0 + 4 * c4);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        const int s = threadIdx.x + 256 * i;
-        if (s < total) {
-          const int row = s / q4, c4 = s - row * q4;
-          f32x4 x = v[i];
-          if (a.in_pre) {
-            x.x *= chain_act_grad(a.in_act, pz[i].x); x.y *= chain_act_grad(a.in_act, pz[i].y);
-            x.z *= chain_act_grad(a.in_act, pz[i].z); x.w *= chain_act_grad(a.in_act, pz[i].w);
+        for (int i = 0; i < 6; ++i) {
+          const int s = threadIdx.x + 256 * (i0 + i);
+          if (s < total) {
+            const int row = s / q4, c4 = s - row * q4;
+            int64_t mm = m0 + row;
+            if (mm >= a.M) mm = a.M - 1;
+            v[i] = *(const f32x4*)(a.in + mm * KC0 + 4 * c4);
+            if (a.in_pre) pz[i] = *(const f32x4*)(a.in_pre + mm * KC0 + 4 * c4);
           }
-          *(f32x4*)(buf0 + row * ldw + 4 * c4) = x;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int s = threadIdx.x + 256 * (i0 + i);
+          if (s < total) {
+            const int row = s / q4, c4 = s - row * q4;
+            f32x4 x = v[i];
+            if (a.in_pre) {
+              x.x *= chain_act_grad(a.in_act, pz[i].x); x.y *= chain_act_grad(a.in_act, pz[i].y);
+              x.z *= chain_act_grad(a.in_act, pz[i].z); x.w *= chain_act_grad(a.in_act, pz[i].w);
+            }
+            *(f32x4*)(buf0 + row * ld0 + 4 * c4) = x;
+          }
         }
       }
     }
     __syncthreads();
     const int64_t m = m0 + el;
     const bool valid = m < a.M;
+#pragma unroll 1
     for (int l = 0; l < a.n_layers; ++l) {
       const ChainLayerDev& L = a.L[l];
       const bool last = (l == a.n_layers - 1);
-      const float* brow = ((l & 1) ? buf1 : buf0) + el * ldw;
+      const float* brow = ((l & 1) ? buf1 + el * ld1 : buf0 + el * ld0);
       float* nxt = (l & 1) ? buf0 : buf1;
+      const int ldn = (l & 1) ? ld0 : ld1;
       const int nch = L.KC / (8 * CCH);   // even
       const int tcount = L.NW / 32;
+#pragma unroll 1
       for (int t = wv; t < tcount; t += 4) {
         // epilogue operands (residual, act' argument) are requested before the MFMAs of the tile
         f32x4 rv[4], pv[4];
@@ -173,13 +176,13 @@ __global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = L.b ? L.b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
         for (int c = 0; c < nch; c += 2) {
-          chain_load_a(a1, L.w, L.NW, t, c + 1, el, hi);
+          chain_load_a(a1, L.w, L.KC / 8, t, c + 1, lane);
           acc = chain_mfma(a0, c, brow, hi, acc);
           if (c + 2 < nch) {
-            chain_load_a(a0, L.w, L.NW, t, c + 2, el, hi);
+            chain_load_a(a0, L.w, L.KC / 8, t, c + 2, lane);
           } else {
             int l2, t2;
-            if (chain_next_tile(a, l, t, wv, l2, t2)) chain_load_a(a0, a.L[l2].w, a.L[l2].NW, t2, 0, el, hi);
+            if (chain_next_tile(a, l, t, wv, l2, t2)) chain_load_a(a0, a.L[l2].w, a.L[l2].KC / 8, t2, 0, lane);
           }
           acc = chain_mfma(a1, c + 1, brow, hi, acc);
         }
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
               o.x *= chain_act_grad(L.post_act, p.x); o.y *= chain_act_grad(L.post_act, p.y);
               o.z *= chain_act_grad(L.post_act, p.z); o.w *= chain_act_grad(L.post_act, p.w);
             }
-            *(f32x4*)(nxt + el * ldw + col) = o;
+            *(f32x4*)(nxt + el * ldn + col) = o;
           }
         }
       }
@@ -209,6 +212,200 @@ __global__ __launch_bounds__(256) void k_dense_chain(ChainArgs a, int ldw) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// 16-row variant for small row counts (N ~ 5 k atoms = 168 tiles of 32 rows cannot fill 256 CUs and
+// leave one wave per SIMD with every latency exposed): tiles of 16 rows on v_mfma_f32_16x16x4_f32
+// (A: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], acc[r] <-> row 4 (l >> 4) + r,
+// col l & 15; k-step s = 4u + v uses kk = 16u + 4 (l >> 4) + v so a lane again fetches 4 consecutive kk
+// with one 16-byte access).  Twice the workgroups, half the LDS and registers each => two workgroups per
+// CU; a wave owns PAIRS of adjacent 16-feature tiles: two independent accumulators (the 16x16x4 form
+// has a 40-cycle dependent latency against a 32-cycle issue) that share the activation operand.
+#define C16 4   // u-steps per prefetch chunk: 64 contraction indices, 2 x 16 MFMAs
+
+// same packed image: lane (h, el) of the 16x16x4 form needs A[32 p + 16 k + el][16 u + 4 h + v], which is the
+// 16-byte unit of packed lane (h & 1) * 32 + 16 k + el in k-block 2 u + (h >> 1)
+__device__ __forceinline__ void chain16_load_a(f32x4 (&av)[2][C16], const float* __restrict__ w, int KB, int p, int c,
+                                               int el, int h) {
+  const f32x4* wp = (const f32x4*)w + ((int64_t)p * KB + 2 * c * C16 + (h >> 1)) * 64 + (h & 1) * 32 + el;
+#pragma unroll
+  for (int u = 0; u < C16; ++u) {
+    av[0][u] = wp[u * 128];
+    av[1][u] = wp[u * 128 + 16];
+  }
+}
+
+__device__ __forceinline__ void chain16_mfma(const f32x4 (&av)[2][C16], int c, const float* __restrict__ brow, int h,
+                                             f32x4& acc0, f32x4& acc1) {
+  f32x4 bv[C16];
+#pragma unroll
+  for (int u = 0; u < C16; ++u) bv[u] = *(const f32x4*)(brow + 16 * (c * C16 + u) + 4 * h);
+#pragma unroll
+  for (int u = 0; u < C16; ++u) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u].x, bv[u].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u].x, bv[u].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u].y, bv[u].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u].y, bv[u].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u].z, bv[u].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u].z, bv[u].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u].w, bv[u].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u].w, bv[u].w, acc1, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_dense_chain16(ChainArgs a, int ld0, int ld1) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* buf0 = smem;               // [16][ld0]
+  float* buf1 = smem + 16 * ld0;    // [16][ld1]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 4, el = lane & 15;
+
+  if (a.zero_ptr) {
+    const int64_t n4 = a.zero_count / 4;
+    f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t s = blockIdx.x * 256 + threadIdx.x; s < n4; s += (int64_t)gridDim.x * 256) ((f32x4*)a.zero_ptr)[s] = z4;
+    for (int64_t s = 4 * n4 + blockIdx.x * 256 + threadIdx.x; s < a.zero_count; s += (int64_t)gridDim.x * 256) a.zero_ptr[s] = 0.f;
+  }
+
+  CH_STAMP(0);
+  const int64_t ntiles = (a.M + 15) / 16;
+  for (int64_t mt = blockIdx.x; mt < ntiles; mt += gridDim.x) {
+    const int64_t m0 = mt * 16;
+    f32x4 a0[2][C16], a1[2][C16];
+    {
+      int l2 = 0, t2 = wv;
+      bool have = wv < a.L[0].NW / 32;
+      if (!have) have = chain_next_tile(a, 0, 1 << 20, wv, l2, t2);
+      if (have) chain16_load_a(a0, a.L[l2].w, a.L[l2].KC / 8, t2, 0, el, h);
+    }
+    {  // stage the input tile [16][KC0] (KC0 <= 384 => at most 6 pieces per thread)
+      const int KC0 = a.L[0].KC;
+      const int q4 = KC0 / 4;
+      const int total = 16 * q4;
+      f32x4 v[6], pz[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int s = threadIdx.x + 256 * i;
+        if (s < total) {
+          const int row = s / q4, c4 = s - row * q4;
+          int64_t mm = m0 + row;
+          if (mm >= a.M) mm = a.M - 1;
+          v[i] = *(const f32x4*)(a.in + mm * KC0 + 4 * c4);
+          if (a.in_pre) pz[i] = *(const f32x4*)(a.in_pre + mm * KC0 + 4 * c4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int s = threadIdx.x + 256 * i;
+        if (s < total) {
+          const int row = s / q4, c4 = s - row * q4;
+          f32x4 x = v[i];
+          if (a.in_pre) {
+            x.x *= chain_act_grad(a.in_act, pz[i].x); x.y *= chain_act_grad(a.in_act, pz[i].y);
+            x.z *= chain_act_grad(a.in_act, pz[i].z); x.w *= chain_act_grad(a.in_act, pz[i].w);
+          }
+          *(f32x4*)(buf0 + row * ld0 + 4 * c4) = x;
+        }
+      }
+    }
+    __syncthreads();
+    CH_STAMP(1);
+    const int64_t m = m0 + el;
+    const bool valid = m < a.M;
+    for (int l = 0; l < a.n_layers; ++l) {
+      const ChainLayerDev& L = a.L[l];
+      const bool last = (l == a.n_layers - 1);
+      const float* brow = ((l & 1) ? buf1 + el * ld1 : buf0 + el * ld0);
+      float* nxt = (l & 1) ? buf0 : buf1;
+      const int ldn = (l & 1) ? ld0 : ld1;
+      const int nch = L.KC / (16 * C16);   // even (KC % 128 == 0)
+      const int pcount = L.NW / 32;        // pairs of 16-feature tiles
+      for (int p = wv; p < pcount; p += 4) {
+        f32x4 rv[2], pv[2];
+        const bool has_res = L.res && valid, has_post = (!last) && L.post_pre && valid;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int64_t off = m * L.NW + 32 * p + 16 * k + 4 * h;
+          rv[k] = has_res ? *(const f32x4*)(L.res + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+          pv[k] = has_post ? *(const f32x4*)(L.post_pre + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 acc0, acc1;
+        if (L.b) { acc0 = *(const f32x4*)(L.b + 32 * p + 4 * h); acc1 = *(const f32x4*)(L.b + 32 * p + 16 + 4 * h); }
+        else { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0; }
+        for (int c = 0; c < nch; c += 2) {
+          chain16_load_a(a1, L.w, L.KC / 8, p, c + 1, el, h);
+          chain16_mfma(a0, c, brow, h, acc0, acc1);
+          if (c + 2 < nch) {
+            chain16_load_a(a0, L.w, L.KC / 8, p, c + 2, el, h);
+          } else {
+            int l2, t2;
+            if (chain_next_tile(a, l, p, wv, l2, t2)) chain16_load_a(a0, a.L[l2].w, a.L[l2].KC / 8, t2, 0, el, h);
+          }
+          chain16_mfma(a1, c + 1, brow, h, acc0, acc1);
+        }
+        if (p == wv) CH_STAMP(2 + 3 * l);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int col = 32 * p + 16 * k + 4 * h;
+          const int64_t off = m * L.NW + col;
+          f32x4 o = k ? acc1 : acc0;
+          if (L.pre_out && valid) *(f32x4*)(L.pre_out + off) = o;
+          if (L.act != SPK_ACT_NONE) {
+            o.x = chain_act(L.act, o.x); o.y = chain_act(L.act, o.y); o.z = chain_act(L.act, o.z); o.w = chain_act(L.act, o.w);
+          }
+          if (has_res) o += rv[k];
+          if (L.out && valid) *(f32x4*)(L.out + off) = o;
+          if (!last) {
+            if (has_post) {
+              const f32x4 pp = pv[k];
+              o.x *= chain_act_grad(L.post_act, pp.x); o.y *= chain_act_grad(L.post_act, pp.y);
+              o.z *= chain_act_grad(L.post_act, pp.z); o.w *= chain_act_grad(L.post_act, pp.w);
+            }
+            *(f32x4*)(nxt + el * ldn + col) = o;
+          }
+        }
+      }
+      CH_STAMP(3 + 3 * l);
+      __syncthreads();
+      CH_STAMP(4 + 3 * l);
+    }
+  }
+  CH_STAMP(12);
+}
+
+// ---- packed weight image ------------------------------------------------------------------
+// w is a Linear weight [n_out, k_in].  transposed == 0: the layer y = x W^T (A[i][kk] = W[i][kk], contraction
+// over k_in); transposed == 1: the input-gradient layer gx = gy W (A[i][kk] = W[kk][i], contraction over n_out).
+__global__ void k_pack_weight(const float* __restrict__ w, int n_out, int k_in, int transposed, float* __restrict__ P) {
+  const int KC = transposed ? n_out : k_in, NW = transposed ? k_in : n_out;
+  const int KB = KC / 8;
+  const int64_t total = (int64_t)KC * NW;
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(s & 3), lane = (int)((s >> 2) & 63);
+    const int64_t blk = s >> 8;
+    const int ug = (int)(blk % KB), t = (int)(blk / KB);
+    const int i = 32 * t + (lane & 31), kk = 8 * ug + 4 * (lane >> 5) + v;
+    P[s] = transposed ? w[(int64_t)kk * k_in + i] : w[(int64_t)i * k_in + kk];
+  }
+}
+
+int spk_pack_weight_internal(const float* w, int n_out, int k_in, int transposed, float* packed, hipStream_t stream);
+extern "C" int spk_pack_weight_f32(const float* w, int32_t n_out, int32_t k_in, int32_t transposed, float* packed, void* stream_) {
+  return spk_pack_weight_internal(w, n_out, k_in, transposed, packed, (hipStream_t)stream_);
+}
+int spk_pack_weight_internal(const float* w, int n_out, int k_in, int transposed, float* packed, hipStream_t stream) {
+  const int KC = transposed ? n_out : k_in, NW = transposed ? k_in : n_out;
+  SPK_CHECK_ARG(w && packed && n_out > 0 && k_in > 0, "spk_pack_weight_f32: bad input");
+  SPK_CHECK_ARG(KC % 8 == 0 && NW % 32 == 0, "spk_pack_weight_f32: contraction length %d must be a multiple of 8, output width %d of 32", KC, NW);
+  hipLaunchKernelGGL(k_pack_weight, dim3(spk_grid_for((int64_t)KC * NW, 256, spk_num_cus() * 8)), dim3(256), 0, stream, w, n_out, k_in, transposed, packed);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+static long long* g_chain_dbg = nullptr;
+extern "C" void spk_chain_set_debug_buffer(void* p) { g_chain_dbg = (long long*)p; }
+static int g_chain_rows = 0;   // 0: by size, 16 / 32: forced (tests, tuning)
+extern "C" void spk_chain_set_rows(int rows) { g_chain_rows = (rows == 16 || rows == 32) ? rows : 0; }
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -227,7 +424,7 @@ static bool chain_supported(const spk_chain_t* c) {
   for (int l = 0; l < c->n_layers; ++l) {
     const spk_chain_layer_t& L = c->layers[l];
     if (L.k != kc) return false;
-    if (!L.trans) return false;  // the fused kernel reads k-major weights only (see chain_load_a)
+    if (L.trans != 2) return false;  // the fused kernels read packed weights only (see chain_load_a)
     if (L.k % 128 != 0 || L.n_out % 32 != 0 || L.k > CH_MAXW || L.n_out > CH_MAXW) return false;
     if (!al16(L.w) || !al16(L.b) || !al16(L.res) || !al16(L.out) || !al16(L.pre_out) || !al16(L.post_pre)) return false;
     kc = L.n_out;
@@ -250,28 +447,46 @@ extern "C" int spk_dense_chain_f32(const spk_chain_t* c, void* stream_) {
       SPK_CHECK_ARG(S.w != nullptr, "%s: null weight in layer %d", who, l);
       ChainLayerDev& D = a.L[l];
       D.w = S.w; D.b = S.b; D.res = S.res; D.out = S.out; D.pre_out = S.pre_out; D.post_pre = S.post_pre;
-      D.KC = S.k; D.NW = S.n_out; D.act = S.act; D.trans = 1; D.post_act = S.post_act;
+      D.KC = S.k; D.NW = S.n_out; D.act = S.act; D.trans = 2; D.post_act = S.post_act;
       if (S.n_out > maxw) maxw = S.n_out;
     }
     SPK_CHECK_ARG(c->in != nullptr, "%s: null input", who);
     a.n_layers = c->n_layers; a.in = c->in; a.in_pre = c->in_pre; a.in_act = c->in_act; a.M = c->m;
     a.zero_ptr = c->zero_ptr; a.zero_count = c->zero_ptr ? c->zero_count : 0;
-    const int ldw = maxw + 4;
-    const size_t lds = (size_t)2 * 32 * ldw * sizeof(float);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-      SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_dense_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 32 * (CH_MAXW + 4) * sizeof(float))));
-      attr_lds = 2 * 32 * (CH_MAXW + 4) * sizeof(float);
+    a.dbg = g_chain_dbg;
+    (void)maxw;
+    // buf0 holds the input tile and (3 layers) the output of layer 1; buf1 the output of layer 0
+    int w0 = c->layers[0].k, w1 = c->n_layers > 1 ? c->layers[0].n_out : 0;
+    if (c->n_layers > 2 && c->layers[1].n_out > w0) w0 = c->layers[1].n_out;
+    const int ld0 = w0 + 4, ld1 = w1 + 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+      const int max_lds = (int)(2 * 32 * (CH_MAXW + 4) * sizeof(float));
+      SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_dense_chain, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+      SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_dense_chain16, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+      attr_done = true;
     }
-    const int64_t ntiles = (c->m + 31) / 32;
-    int grid = (int)(ntiles < 4096 ? ntiles : 4096);
+    // 16-row tiles while 32-row tiles would leave CUs idle or alone with one workgroup
+    const int64_t ntiles32 = (c->m + 31) / 32;
+    const bool rows16 = g_chain_rows ? (g_chain_rows == 16) : (ntiles32 < 2 * (int64_t)spk_num_cus());
     SpkProfScope prof(c->n_layers == 1 ? "chain1" : (c->n_layers == 2 ? "chain2" : "chain3"), stream);
-    hipLaunchKernelGGL(k_dense_chain, dim3(grid), dim3(256), lds, stream, a, ldw);
+    if (rows16) {
+      const int64_t ntiles = (c->m + 15) / 16;
+      const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
+      const size_t lds = (size_t)16 * (ld0 + ld1) * sizeof(float);
+      hipLaunchKernelGGL(k_dense_chain16, dim3(grid), dim3(256), lds, stream, a, ld0, ld1);
+    } else {
+      const int grid = (int)(ntiles32 < 4096 ? ntiles32 : 4096);
+      const size_t lds = (size_t)32 * (ld0 + ld1) * sizeof(float);
+      hipLaunchKernelGGL(k_dense_chain, dim3(grid), dim3(256), lds, stream, a, ld0, ld1);
+    }
     SPK_LAUNCH_CHECK();
     return SPK_OK;
   }
   // general path: layer by layer on the single-layer kernels (any shape)
-  if (c->zero_ptr && c->zero_count > 0) SPK_HIP_TRY(hipMemsetAsync(c->zero_ptr, 0, (size_t)c->zero_count * sizeof(float), stream));
+  for (int l = 0; l < c->n_layers; ++l)
+    SPK_CHECK_ARG(c->layers[l].trans != 2, "%s: packed weights (trans == 2) need k %% 128 == 0, n_out %% 32 == 0, widths <= %d, 16-byte aligned buffers and a variant other than 'simple'", who, CH_MAXW);
+  if (c->zero_ptr && c->zero_count > 0) { int _zr = spk_zero_async(c->zero_ptr, (size_t)c->zero_count * sizeof(float), stream); if (_zr) return _zr; }
   if (c->m == 0) return SPK_OK;
   SPK_CHECK_ARG(c->in != nullptr, "%s: null input", who);
   const float* cur = c->in;

@@ -44,6 +44,11 @@ static inline int spk_grid_for(int64_t work_items, int per_block, int max_blocks
 
 int spk_num_cus();
 
+// Zero `bytes` (a multiple of 4) bytes with a KERNEL launch.  hipMemsetAsync must not be used in this library:
+// captured into a HIP graph it becomes a memset node, and on ROCm 7.2 replays of such graphs left the target
+// un-cleared from the second replay on (NaN energies / forces in replayed force calls).
+int spk_zero_async(void* p, size_t bytes, hipStream_t stream);
+
 // ---------------------------------------------------------------- per-kernel HIP-event profiling
 // (off by default; bench.py enables it for a separate pass to time individual kernels on the
 // stream they are launched on)

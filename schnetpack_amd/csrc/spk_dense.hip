@@ -357,7 +357,7 @@ extern "C" int spk_atomwise_fwd_f32(const float* x, const float* w1, const float
   SPK_CHECK_ARG(spk_atomwise_supported(n_in, n_hidden, act), "spk_atomwise_fwd_f32: head %d -> %d -> 1 (act %d) not supported by the fused kernel", n_in, n_hidden, act);
   SPK_CHECK_ARG((E == nullptr) == (idx_m == nullptr), "spk_atomwise_fwd_f32: E and idx_m go together");
   SPK_CHECK_ARG(E != nullptr || y_atom != nullptr, "spk_atomwise_fwd_f32: no output requested");
-  if (E && n_mol > 0) SPK_HIP_TRY(hipMemsetAsync(E, 0, (size_t)n_mol * sizeof(float), stream));
+  if (E && n_mol > 0) { int _zr = spk_zero_async(E, (size_t)n_mol * sizeof(float), stream); if (_zr) return _zr; }
   if (n_atoms == 0) return SPK_OK;
   SPK_CHECK_ARG(x && w1 && w2, "spk_atomwise_fwd_f32: null pointer");
   SPK_CHECK_ARG(aligned16(x) && aligned16(w1) && aligned16(w2) && aligned16(pre), "spk_atomwise_fwd_f32: 16-byte alignment required");

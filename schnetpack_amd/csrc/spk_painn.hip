@@ -350,7 +350,7 @@ static int msg_dispatch(const MsgArgs& a, bool row_ok, hipStream_t stream, const
     SPK_HIP_TRY(hipMemcpyAsync(a.q_out, a.q, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
     SPK_HIP_TRY(hipMemcpyAsync(a.mu_out, a.mu, 3 * nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
   } else {
-    SPK_HIP_TRY(hipMemsetAsync(a.gc, 0, 3 * nf * sizeof(float), stream));
+    { int _zr = spk_zero_async(a.gc, 3 * nf * sizeof(float), stream); if (_zr) return _zr; }
     SPK_HIP_TRY(hipMemcpyAsync(a.gmu, a.gmu_out, 3 * nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   if (a.E == 0) return SPK_OK;
@@ -540,6 +540,32 @@ extern "C" int spk_painn_mix_ctx_bwd_f32(const float* mix, const float* g_ctx, c
 // ------------------------------------------------------------------------------------------
 #define SPK_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+#include "spk_pack.h"
+// order of the packed images in spk_painn_t::wpack: per interaction ctx.0, ctx.1, mu_channel_mix, intra ctx.0, intra ctx.1
+static bool painn_pack_shapes_ok(const spk_painn_t* m) { return m->n_atom_basis == 128; }   // widths F, 2F, 3F <= 384, all % 128
+static SpkPackTable painn_pack_table(const spk_painn_t* m) {
+  SpkPackTable T;
+  const int F = m->n_atom_basis;
+  for (int l = 0; l < m->n_interactions; ++l) {
+    const spk_painn_layer_t& P = m->layers[l];
+    T.add(P.ctx_w1, P.ctx_w1T, F, F);
+    T.add(P.ctx_w2, P.ctx_w2T, 3 * F, F);
+    T.add(P.mix_w, P.mix_wT, 2 * F, F);
+    T.add(P.ictx_w1, P.ictx_w1T, F, 2 * F);
+    T.add(P.ictx_w2, P.ictx_w2T, 3 * F, F);
+  }
+  T.base = m->wpack;
+  return T;
+}
+extern "C" int64_t spk_painn_packed_floats(const spk_painn_t* m) {
+  if (!m || !m->layers || m->n_interactions <= 0 || !painn_pack_shapes_ok(m)) return 0;
+  return painn_pack_table(m).total;
+}
+extern "C" int spk_painn_pack_weights_f32(const spk_painn_t* m, float* wpack, void* stream) {
+  SPK_CHECK_ARG(m && wpack && spk_painn_packed_floats(m) > 0, "spk_painn_pack_weights_f32: model shapes have no packed form (see spk_painn_packed_floats)");
+  return spk_pack_all(painn_pack_table(m), wpack, (hipStream_t)stream);
+}
+
 static spk_chain_layer_t mk_layer(const float* w, const float* b, const float* res, float* out, float* pre_out,
                                   const float* post_pre, int k, int n_out, int act, int trans, int post_act) {
   spk_chain_layer_t L;
@@ -573,6 +599,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
   hipStream_t stream = (hipStream_t)stream_;
   const char* who = "spk_painn_forward_f32";
   SPK_CHECK_ARG(m && m->layers && g && rb, "%s: null argument", who);
+  const SpkPackTable ptab = (m->wpack && painn_pack_shapes_ok(m)) ? painn_pack_table(m) : SpkPackTable();
   const int64_t N = g->n_atoms;
   const int F = m->n_atom_basis, L = m->n_interactions;
   if (N == 0) return SPK_OK;
@@ -580,7 +607,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
   const size_t nf = (size_t)N * F;
   if (L == 0) {
     SPK_HIP_TRY(hipMemcpyAsync(q_out, q0, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    SPK_HIP_TRY(hipMemsetAsync(mu_out, 0, 3 * nf * sizeof(float), stream));
+    { int _zr = spk_zero_async(mu_out, 3 * nf * sizeof(float), stream); if (_zr) return _zr; }
     return SPK_OK;
   }
   float* c1 = scratch;            // [N,F]
@@ -590,7 +617,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
   float* a1 = ctx + 2 * nf;       // [N,F]
   const int64_t per = painn_saved_per_atom(F) * N;
   // mu entering the first interaction is zero (painn.py:246)
-  SPK_HIP_TRY(hipMemsetAsync(saved + 4 * nf, 0, 3 * nf * sizeof(float), stream));
+  { int _zr = spk_zero_async(saved + 4 * nf, 3 * nf * sizeof(float), stream); if (_zr) return _zr; }
   for (int l = 0; l < L; ++l) {
     const spk_painn_layer_t& P = m->layers[l];
     float* S = saved + l * per;
@@ -602,6 +629,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
       ch.n_layers = 2; ch.m = N; ch.in = qin; ch.tmp[0] = c1; ch.tmp[1] = a1;
       ch.layers[0] = mk_fwd(P.ctx_w1, P.ctx_w1T, P.ctx_b1, nullptr, preA, F, F, SPK_ACT_SILU);
       ch.layers[1] = mk_fwd(P.ctx_w2, P.ctx_w2T, P.ctx_b2, c, nullptr, F, 3 * F, SPK_ACT_NONE);
+      spk_apply_pack(ch, ptab);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     SPK_TRY(spk_painn_message_fwd_internal(g, rb, c, qin, mu_in, r_ij, P.filt_w, P.filt_b, F, q1, mu1, stream));
@@ -609,6 +637,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
       spk_chain_t ch = {};
       ch.n_layers = 1; ch.m = 3 * N; ch.in = mu1;
       ch.layers[0] = mk_fwd(P.mix_w, P.mix_wT, nullptr, mix, nullptr, F, 2 * F, SPK_ACT_NONE);
+      spk_apply_pack(ch, ptab);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     SPK_TRY(spk_painn_mix_ctx_f32(q1, mix, N, F, m->epsilon, ctx, stream));
@@ -617,6 +646,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
       ch.n_layers = 2; ch.m = N; ch.in = ctx; ch.tmp[0] = c1; ch.tmp[1] = a1;
       ch.layers[0] = mk_fwd(P.ictx_w1, P.ictx_w1T, P.ictx_b1, nullptr, preB, 2 * F, F, SPK_ACT_SILU);
       ch.layers[1] = mk_fwd(P.ictx_w2, P.ictx_w2T, P.ictx_b2, av, nullptr, F, 3 * F, SPK_ACT_NONE);
+      spk_apply_pack(ch, ptab);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     float* mu_next = (l == L - 1) ? mu_out : (saved + (l + 1) * per + 4 * nf);
@@ -632,11 +662,12 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
   hipStream_t stream = (hipStream_t)stream_;
   const char* who = "spk_painn_backward_f32";
   SPK_CHECK_ARG(m && m->layers && g && rb, "%s: null argument", who);
+  const SpkPackTable ptab = (m->wpack && painn_pack_shapes_ok(m)) ? painn_pack_table(m) : SpkPackTable();
   const int64_t N = g->n_atoms, E = g->n_edges;
   const int F = m->n_atom_basis, L = m->n_interactions;
   if (E > 0) {
     SPK_CHECK_ARG(gr != nullptr, "%s: null gr", who);
-    SPK_HIP_TRY(hipMemsetAsync(gr, 0, (size_t)E * 3 * sizeof(float), stream));
+    { int _zr = spk_zero_async(gr, (size_t)E * 3 * sizeof(float), stream); if (_zr) return _zr; }
   }
   if (N == 0) return SPK_OK;
   SPK_CHECK_ARG((gq_out || gmu_out) && (L == 0 || (saved && scratch)), "%s: null buffer", who);
@@ -653,9 +684,9 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
   float* gq = gc1 + nf;            // [N,F]   running dL/dq
   float* gmu = gq + nf;            // [N,3F]  running dL/dmu
   if (gq_out) SPK_HIP_TRY(hipMemcpyAsync(gq, gq_out, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
-  else SPK_HIP_TRY(hipMemsetAsync(gq, 0, nf * sizeof(float), stream));
+  else { int _zr = spk_zero_async(gq, nf * sizeof(float), stream); if (_zr) return _zr; }
   if (gmu_out) SPK_HIP_TRY(hipMemcpyAsync(gmu, gmu_out, 3 * nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
-  else SPK_HIP_TRY(hipMemsetAsync(gmu, 0, 3 * nf * sizeof(float), stream));
+  else { int _zr = spk_zero_async(gmu, 3 * nf * sizeof(float), stream); if (_zr) return _zr; }
   const int64_t per = painn_saved_per_atom(F) * N;
   for (int l = L - 1; l >= 0; --l) {
     const spk_painn_layer_t& P = m->layers[l];
@@ -669,6 +700,7 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
       ch.n_layers = 2; ch.m = N; ch.in = ga; ch.tmp[0] = ga1; ch.tmp[1] = gc1;
       ch.layers[0] = mk_layer(P.ictx_w2, nullptr, nullptr, nullptr, nullptr, preB, 3 * F, F, SPK_ACT_NONE, 1, SPK_ACT_SILU);
       ch.layers[1] = mk_layer(P.ictx_w1, nullptr, nullptr, gctx, nullptr, nullptr, F, 2 * F, SPK_ACT_NONE, 1, 0);
+      spk_apply_pack(ch, ptab);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     SPK_TRY(spk_painn_mix_ctx_bwd_f32(mix, gctx, gq, N, F, m->epsilon, gmix, gq1, stream));
@@ -676,6 +708,7 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
       spk_chain_t ch = {};
       ch.n_layers = 1; ch.m = 3 * N; ch.in = gmix;
       ch.layers[0] = mk_layer(P.mix_w, nullptr, gmu, gmu1, nullptr, nullptr, 2 * F, F, SPK_ACT_NONE, 1, 0);
+      spk_apply_pack(ch, ptab);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     // ---- message backward: gc, gmu (incl. residual), gr +=
@@ -686,6 +719,7 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
       ch.n_layers = 2; ch.m = N; ch.in = gc; ch.tmp[0] = ga1; ch.tmp[1] = gc1;
       ch.layers[0] = mk_layer(P.ctx_w2, nullptr, nullptr, nullptr, nullptr, preA, 3 * F, F, SPK_ACT_NONE, 1, SPK_ACT_SILU);
       ch.layers[1] = mk_layer(P.ctx_w1, nullptr, gq1, out, nullptr, nullptr, F, F, SPK_ACT_NONE, 1, 0);
+      spk_apply_pack(ch, ptab);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
   }

@@ -42,6 +42,30 @@ extern "C" int64_t spk_schnet_scratch_floats(const spk_schnet_t* m, int64_t n_at
 
 #define SPK_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+#include "spk_pack.h"
+// order of the packed images in spk_schnet_t::wpack: per interaction in2f, f2out.0, f2out.1 (forward, transposed each)
+static bool schnet_pack_shapes_ok(const spk_schnet_t* m) { return m->n_atom_basis % 128 == 0 && m->n_filters % 128 == 0 && m->n_atom_basis <= 384 && m->n_filters <= 384; }
+static SpkPackTable schnet_pack_table(const spk_schnet_t* m) {
+  SpkPackTable T;
+  const int F = m->n_atom_basis, NF = m->n_filters;
+  for (int l = 0; l < m->n_interactions; ++l) {
+    const spk_schnet_layer_t& P = m->layers[l];
+    T.add(P.in2f_w, P.in2f_wT, NF, F);
+    T.add(P.f2out_w1, P.f2out_w1T, F, NF);
+    T.add(P.f2out_w2, P.f2out_w2T, F, F);
+  }
+  T.base = m->wpack;
+  return T;
+}
+extern "C" int64_t spk_schnet_packed_floats(const spk_schnet_t* m) {
+  if (!m || !m->layers || m->n_interactions <= 0 || !schnet_pack_shapes_ok(m)) return 0;
+  return schnet_pack_table(m).total;
+}
+extern "C" int spk_schnet_pack_weights_f32(const spk_schnet_t* m, float* wpack, void* stream) {
+  SPK_CHECK_ARG(m && wpack && spk_schnet_packed_floats(m) > 0, "spk_schnet_pack_weights_f32: model shapes have no packed form (see spk_schnet_packed_floats)");
+  return spk_pack_all(schnet_pack_table(m), wpack, (hipStream_t)stream);
+}
+
 // forward layer from either the [out,in] weight or its transposed copy (coalesced reads)
 static spk_chain_layer_t mk_fwd(const float* w, const float* wT, const float* b, const float* res, float* out,
                                 float* pre_out, int k, int n_out, int act);
@@ -66,6 +90,7 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
   hipStream_t stream = (hipStream_t)stream_;
   const char* who = "spk_schnet_forward_f32";
   SPK_TRY(check_model(m, who));
+  const SpkPackTable ptab = (m->wpack && schnet_pack_shapes_ok(m)) ? schnet_pack_table(m) : SpkPackTable();
   SPK_CHECK_ARG(g != nullptr && rb != nullptr, "%s: null graph/radial", who);
   const int64_t N = g->n_atoms;
   const int F = m->n_atom_basis, NF = m->n_filters, L = m->n_interactions;
@@ -88,6 +113,7 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
     c.n_layers = 1; c.m = N; c.in = x0; c.zero_ptr = ybuf[0]; c.zero_count = N * (int64_t)NF;
     c.tmp[0] = tmp0; c.tmp[1] = tmp1;
     c.layers[0] = mk_fwd(m->layers[0].in2f_w, m->layers[0].in2f_wT, nullptr, nullptr, hbuf(0), nullptr, F, NF, SPK_ACT_NONE);
+    spk_apply_pack(c, ptab);
     SPK_TRY(spk_dense_chain_f32(&c, stream));
   }
   for (int l = 0; l < L; ++l) {
@@ -108,6 +134,7 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
       c.n_layers = 3;
       c.zero_ptr = ybuf[(l + 1) & 1]; c.zero_count = N * (int64_t)NF;
     }
+    spk_apply_pack(c, ptab);
     SPK_TRY(spk_dense_chain_f32(&c, stream));
   }
   return SPK_OK;
@@ -120,12 +147,13 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   hipStream_t stream = (hipStream_t)stream_;
   const char* who = "spk_schnet_backward_f32";
   SPK_TRY(check_model(m, who));
+  const SpkPackTable ptab = (m->wpack && schnet_pack_shapes_ok(m)) ? schnet_pack_table(m) : SpkPackTable();
   SPK_CHECK_ARG(g != nullptr && rb != nullptr, "%s: null graph/radial", who);
   const int64_t N = g->n_atoms, E = g->n_edges;
   const int F = m->n_atom_basis, NF = m->n_filters, L = m->n_interactions;
   if (E > 0) {
     SPK_CHECK_ARG(gr != nullptr, "%s: null gr", who);
-    SPK_HIP_TRY(hipMemsetAsync(gr, 0, (size_t)E * 3 * sizeof(float), stream));
+    { int _zr = spk_zero_async(gr, (size_t)E * 3 * sizeof(float), stream); if (_zr) return _zr; }
   }
   if (N == 0) return SPK_OK;
   SPK_CHECK_ARG(gx_out && (L == 0 || (saved && scratch)), "%s: null buffer", who);
@@ -151,6 +179,7 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
     c.tmp[0] = tmp0; c.tmp[1] = tmp1;
     c.layers[0] = mk_layer(P.f2out_w2, nullptr, nullptr, nullptr, nullptr, pre3(L - 1), F, F, SPK_ACT_NONE, 1, SPK_ACT_SSP);
     c.layers[1] = mk_layer(P.f2out_w1, nullptr, nullptr, gy, nullptr, nullptr, F, NF, SPK_ACT_NONE, 1, 0);
+    spk_apply_pack(c, ptab);
     SPK_TRY(spk_dense_chain_f32(&c, stream));
   }
   const float* gx = gx_out;
@@ -174,6 +203,7 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
       c.n_layers = 3;
       c.zero_ptr = ghbuf[(l - 1) & 1]; c.zero_count = N * (int64_t)NF;
     }
+    spk_apply_pack(c, ptab);
     SPK_TRY(spk_dense_chain_f32(&c, stream));
     gx = out;
   }

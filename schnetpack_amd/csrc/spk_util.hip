@@ -145,7 +145,7 @@ extern "C" int spk_edge_plan(const int64_t* idx_i, const int64_t* idx_j, const f
                 "spk_edge_plan: sizes out of range (N=%lld E=%lld)", (long long)N, (long long)E);
   SPK_CHECK_ARG(rowptr && scratch && host_flags, "spk_edge_plan: null pointer");
   SPK_CHECK_ARG(E == 0 || (idx_i && idx_j), "spk_edge_plan: null index arrays");
-  SPK_HIP_TRY(hipMemsetAsync(scratch, 0, 4 * sizeof(int32_t), stream));
+  { int _zr = spk_zero_async(scratch, 4 * sizeof(int32_t), stream); if (_zr) return _zr; }
   int32_t f[4] = {0, 0, 0, 0};
   if (E > 0) {
     int grid = spk_grid_for(E, 256, 4096);
@@ -246,7 +246,7 @@ extern "C" int spk_scatter_add_f32(const float* x, const int64_t* idx, const int
   int64_t out_elems = outer * N * inner;
   if (out_elems == 0) return SPK_OK;
   SPK_CHECK_ARG(y != nullptr, "spk_scatter_add_f32: null output");
-  if (E == 0) { SPK_HIP_TRY(hipMemsetAsync(y, 0, out_elems * sizeof(float), stream)); return SPK_OK; }
+  if (E == 0) { { int _zr = spk_zero_async(y, out_elems * sizeof(float), stream); if (_zr) return _zr; } return SPK_OK; }
   SPK_CHECK_ARG(x != nullptr && (idx != nullptr || rowptr != nullptr), "spk_scatter_add_f32: null input");
   const int maxb = spk_num_cus() * 16;
   if (rowptr) {
@@ -261,7 +261,7 @@ extern "C" int spk_scatter_add_f32(const float* x, const int64_t* idx, const int
     }
     SPK_LAUNCH_CHECK();
   } else {
-    SPK_HIP_TRY(hipMemsetAsync(y, 0, out_elems * sizeof(float), stream));
+    { int _zr = spk_zero_async(y, out_elems * sizeof(float), stream); if (_zr) return _zr; }
     int grid = spk_grid_for(outer * E * inner, 256, maxb);
     hipLaunchKernelGGL(k_scatter_atomic, dim3(grid), dim3(256), 0, stream, x, idx, outer, E, inner, N, y);
     SPK_LAUNCH_CHECK();
@@ -393,6 +393,27 @@ extern "C" int spk_edge_norm_f32(const float* r_ij, int64_t E, float* d, float* 
   return SPK_OK;
 }
 
+// ---------------------------------------------------------------- zero fill (kernel, never a memset node)
+__global__ void k_zero_words(uint32_t* __restrict__ p, size_t n) {
+  const size_t n4 = n / 4;
+  uint4 z = {0u, 0u, 0u, 0u};
+  for (size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x; s < n4; s += (size_t)gridDim.x * blockDim.x) ((uint4*)p)[s] = z;
+  for (size_t s = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; s < n; s += (size_t)gridDim.x * blockDim.x) p[s] = 0u;
+}
+__global__ void k_zero_words_unaligned(uint32_t* __restrict__ p, size_t n) {
+  for (size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x; s < n; s += (size_t)gridDim.x * blockDim.x) p[s] = 0u;
+}
+int spk_zero_async(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return SPK_OK;
+  SPK_CHECK_ARG(p != nullptr && bytes % 4 == 0 && ((uintptr_t)p % 4) == 0, "spk_zero_async: needs a 4-byte aligned buffer of whole words");
+  const size_t n = bytes / 4;
+  const int grid = spk_grid_for((int64_t)((n + 3) / 4), 256, spk_num_cus() * 8);
+  if (((uintptr_t)p % 16) == 0) hipLaunchKernelGGL(k_zero_words, dim3(grid), dim3(256), 0, stream, (uint32_t*)p, n);
+  else hipLaunchKernelGGL(k_zero_words_unaligned, dim3(spk_grid_for((int64_t)n, 256, spk_num_cus() * 8)), dim3(256), 0, stream, (uint32_t*)p, n);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 // ---------------------------------------------------------------- pairwise vectors (distances.py)
 __global__ void k_pairwise(const float* __restrict__ R, const int64_t* __restrict__ idx_i,
                            const int64_t* __restrict__ idx_j, const float* __restrict__ off,
@@ -458,7 +479,7 @@ extern "C" int spk_pairwise_bwd_f32(const float* gr, const int64_t* idx_i, const
   hipStream_t stream = (hipStream_t)stream_;
   if (N == 0) return SPK_OK;
   SPK_CHECK_ARG(gR != nullptr && N > 0 && E >= 0, "spk_pairwise_bwd_f32: bad input");
-  SPK_HIP_TRY(hipMemsetAsync(gR, 0, (size_t)N * 3 * sizeof(float), stream));
+  { int _zr = spk_zero_async(gR, (size_t)N * 3 * sizeof(float), stream); if (_zr) return _zr; }
   if (E == 0) return SPK_OK;
   SPK_CHECK_ARG(gr && idx_i && idx_j, "spk_pairwise_bwd_f32: null pointer");
   hipLaunchKernelGGL(k_pairwise_bwd, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, gr, idx_i, idx_j, E, gR);

@@ -7,6 +7,7 @@ the reference's [E, 1, 3F n_int] filter tensor, painn.py:232, never exists), fir
 w.r.t. ``_Rij``.  Training mode: differentiable primitive path.
 """
 import ctypes
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -158,8 +159,17 @@ class PaiNN(nn.Module):
                     setattr(arr[l], name + "T", _lib.fptr(tt))
             arr[l].filt_w = ctypes.c_void_p(fw.data_ptr() + 4 * row0 * n_rbf)
             arr[l].filt_b = ctypes.c_void_p(fb.data_ptr() + 4 * row0)
-        ms = _lib.PainnT(Fd, L, self._eps(), 0, ctypes.cast(arr, ctypes.POINTER(_lib.PainnLayerT)))
+        ms = _lib.PainnT(Fd, L, self._eps(), 0, ctypes.cast(arr, ctypes.POINTER(_lib.PainnLayerT)), None)
         keep.append(arr)
+        # packed images of the atom-wise weights for the fused Dense chains (0 floats: shapes without one)
+        n_pack = int(_lib.lib().spk_painn_packed_floats(ctypes.byref(ms))) if L > 0 else 0
+        if n_pack > 0 and not os.environ.get("SPK_NO_PACK"):
+            dev = next(self.parameters()).device
+            wpack = torch.empty(n_pack, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().spk_painn_pack_weights_f32(ctypes.byref(ms), _lib.fptr(wpack), _lib.stream()))
+            ms.wpack = _lib.fptr(wpack)
+            keep.append(wpack)
         self.__dict__["_struct_cache"] = (key, ms, keep)
         return ms, keep
 

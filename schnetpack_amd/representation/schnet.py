@@ -8,6 +8,7 @@ what ``Forces`` asks for.  In training mode (force loss => double backward) it r
 differentiable primitive path: HIP Dense / gather / scatter_add with torch elementwise algebra.
 """
 import ctypes
+import os
 from typing import Callable, Dict, List, Optional, Union
 
 import torch
@@ -111,8 +112,16 @@ class SchNet(nn.Module):
             for name, t in zip([f[0] for f in _lib.SchnetLayerT._fields_], ts):
                 setattr(arr[l], name, _lib.fptr(t))
         ms = _lib.SchnetT(self.n_atom_basis, self.n_filters, L, 0,
-                          ctypes.cast(arr, ctypes.POINTER(_lib.SchnetLayerT)))
+                          ctypes.cast(arr, ctypes.POINTER(_lib.SchnetLayerT)), None)
         keep.append(arr)
+        # packed images of the atom-wise weights for the fused Dense chains (0 floats: shapes without one)
+        n_pack = int(_lib.lib().spk_schnet_packed_floats(ctypes.byref(ms))) if L > 0 else 0
+        if n_pack > 0 and not os.environ.get("SPK_NO_PACK"):
+            wpack = torch.empty(n_pack, dtype=torch.float32, device=params[0].device)
+            with torch.cuda.device(wpack.device):
+                _lib.check(_lib.lib().spk_schnet_pack_weights_f32(ctypes.byref(ms), _lib.fptr(wpack), _lib.stream()))
+            ms.wpack = _lib.fptr(wpack)
+            keep.append(wpack)
         self.__dict__["_struct_cache"] = (key, ms, keep)
         return ms, keep
 

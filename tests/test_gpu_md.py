@@ -103,6 +103,31 @@ def test_graphed_force_call_equals_eager(dev, kind):
     assert fc.n_captures == 2 and rel_err(got["forces"].cpu(), ref["forces"]) < TOL
 
 
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+@pytest.mark.parametrize("n_mol", [6, 40, 256])
+def test_graph_replays_stay_correct(dev, kind, n_mol):
+    """Regression: every replay of the captured force call (not only the first) reproduces the eager
+    result.  (hipMemsetAsync captured as a memset node left its target un-cleared from the second replay on;
+    the library clears buffers with a kernel now -- spk_zero_async.)"""
+    from schnetpack_amd import model as M
+    from schnetpack_amd.forcecall import GraphedForceCall
+    rep_p = O.init_schnet_params() if kind == "schnet" else O.init_painn_params()
+    head_p = O.init_atomwise_params(128, seed=1)
+    model = M.build_model(kind)
+    M.load_reference_params(model, rep_p, head_p)
+    model = model.to(dev).eval()
+    b = S.molecule_batch("aspirin", n_mol, seed=3)
+    inp = M.batch_to_inputs(b, dev)
+    want = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in inp.items()})
+    we, wf = want["energy"].detach().cpu(), want["forces"].detach().cpu()
+    fc = GraphedForceCall(model)
+    for it in range(5):
+        got = fc(dict(inp)) if it % 2 == 0 else fc.replay()
+        assert rel_err(got["forces"].cpu(), wf) < 1e-5, (it, "forces")
+        assert rel_err(got["energy"].cpu(), we) < 1e-5, (it, "energy")
+    assert fc.n_captures == 1
+
+
 def test_nve_loop_conserves_energy_and_follows_oracle_trajectory(dev):
     """End to end: device neighbour list with skin + graphed SchNet force call + fused Verlet kernels.
     (i) the first 10 steps follow a float64 CPU integration of the ORACLE forces; (ii) total energy is

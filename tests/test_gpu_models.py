@@ -104,7 +104,7 @@ def test_training_mode_double_backward_matches_oracle(dev, kind):
     model = model.to(dev).train()
     out = model(M.batch_to_inputs(b, dev))
     loss = 0.01 * ((out["energy"] - Et.to(dev)) ** 2).mean() + 0.99 * ((out["forces"] - Ft.to(dev)) ** 2).mean()
-    assert abs(float(loss) - float(loss_o)) / abs(float(loss_o)) < 1e-4
+    assert abs(float(loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach())) < 1e-4
     loss.backward()
     got = dict(model.representation.named_parameters())
     worst = 0.0
@@ -218,3 +218,21 @@ def test_atomwise_head_eval_matches_oracle(dev, n_in, act, agg, n_atoms):
     assert rel_err(out["e_atom"].detach().cpu(), ya.detach()) < TOL
     (gx,) = torch.autograd.grad((out["energy"] * wE.to(dev)).sum() + (out["e_atom"] * wA.to(dev)).sum(), [xg])
     assert rel_err(gx.cpu(), gxo) < TOL
+
+
+@pytest.mark.parametrize("rows", [16, 32])
+@pytest.mark.parametrize("name", ["schnet_aspirin8.npz", "painn_aspirin8.npz", "painn_water192.npz"])
+def test_force_call_golden_with_both_chain_tile_heights(dev, name, rows):
+    """The fused Dense chains (SchNet f2out / in2f, PaiNN context nets and mixing, widths 128 / 256 / 384,
+    forward and transposed) on 16-row and on 32-row tiles reproduce the reference fixtures."""
+    from schnetpack_amd import _lib
+    b, ref, meta = load_golden(name)
+    rep_p, head_p = golden_params(meta)
+    model = _build(meta, dev, rep_p, head_p).eval()
+    _lib.lib().spk_chain_set_rows(rows)
+    try:
+        out = _force_call(model, b, dev)
+    finally:
+        _lib.lib().spk_chain_set_rows(0)
+    assert rel_err(out["energy"], ref["energy"]) < TOL
+    assert rel_err(out["forces"], ref["forces"]) < TOL

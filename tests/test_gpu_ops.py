@@ -573,10 +573,50 @@ def _chain_struct(_lib, m, inp, layers, in_pre=None, in_act=0, zero=None, tmp=No
     return c
 
 
-@pytest.mark.parametrize("m", [5376, 37])
-def test_dense_chain_forward_style(dev, variant, m):
-    """f2out.0 (ssp, pre saved) -> f2out.1 (+ residual, stored) -> in2f (stored), buffer cleared."""
+@pytest.fixture(params=[0, 16, 32])
+def chain_rows(request):
+    """Row-tile height of the fused chain kernel: by size, 16 (v_mfma_f32_16x16x4_f32), 32 (32x32x2)."""
     from schnetpack_amd import _lib
+    _lib.lib().spk_chain_set_rows(request.param)
+    yield request.param
+    _lib.lib().spk_chain_set_rows(0)
+
+
+def _pack(w, transposed):
+    """spk_pack_weight_f32 image of a Linear weight [n_out, k_in] (device tensor)."""
+    from schnetpack_amd import _lib
+    P = torch.empty(w.numel(), device=w.device)
+    _lib.check(_lib.lib().spk_pack_weight_f32(_lib.fptr(w), w.shape[0], w.shape[1], transposed, _lib.fptr(P), _lib.stream()))
+    return P
+
+
+def test_pack_weight_layout(dev):
+    """P[((t KB + ug) 64 + lane) 4 + v] = A[32 t + (lane & 31)][8 ug + 4 (lane >> 5) + v], A = W or W^T."""
+    g = torch.Generator().manual_seed(3)
+    W = torch.randn(96, 40, generator=g)             # [n_out, k_in]
+    for transposed, A in ((0, W), (1, W.t())):        # A [width, contraction]
+        if transposed:
+            Wd = torch.randn(40, 96, generator=g)    # contraction 40 = n_out, width 96 = k_in
+            A = Wd.t()
+        else:
+            Wd = W
+        P = _pack(Wd.to(dev).contiguous(), transposed).cpu()
+        NW, KC = A.shape
+        KB = KC // 8
+        s = torch.arange(NW * KC)
+        v, lane, blk = s & 3, (s >> 2) & 63, s >> 8
+        ug, t = blk % KB, blk // KB
+        assert torch.equal(P, A[32 * t + (lane & 31), 8 * ug + 4 * (lane >> 5) + v])
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("m", [5376, 37])
+def test_dense_chain_forward_style(dev, variant, m, chain_rows, packed):
+    """f2out.0 (ssp, pre saved) -> f2out.1 (+ residual, stored) -> in2f (stored), buffer cleared.
+    packed: the fused kernels (16- and 32-row tiles); plain weights: layer by layer."""
+    from schnetpack_amd import _lib
+    if packed and variant == "simple":
+        pytest.skip("packed weights are an MFMA-kernel format")
     g = torch.Generator().manual_seed(41)
     F = 128
     y = torch.randn(m, F, generator=g)
@@ -593,10 +633,14 @@ def test_dense_chain_forward_style(dev, variant, m):
     h = torch.empty(m, F, device=dev)
     junk = torch.ones(1000, device=dev)
     tmp = (torch.empty(m, F, device=dev), torch.empty(m, F, device=dev))
+    tr = 0
+    if packed:
+        w3d, w4d, wind = _pack(w3d, 0), _pack(w4d, 0), _pack(wind, 0)
+        tr = 2
     c = _chain_struct(_lib, m, yd, [
-        dict(w=w3d, b=b3d, pre_out=pre, k=F, n_out=F, act=_lib.SPK_ACT_SSP),
-        dict(w=w4d, b=b4d, res=xd, out=xd, k=F, n_out=F),
-        dict(w=wind, out=h, k=F, n_out=F)], zero=junk, tmp=tmp)
+        dict(w=w3d, b=b3d, pre_out=pre, k=F, n_out=F, act=_lib.SPK_ACT_SSP, trans=tr),
+        dict(w=w4d, b=b4d, res=xd, out=xd, k=F, n_out=F, trans=tr),
+        dict(w=wind, out=h, k=F, n_out=F, trans=tr)], zero=junk, tmp=tmp)
     _lib.check(_lib.lib().spk_dense_chain_f32(ctypes.byref(c), _lib.stream()))
     torch.cuda.synchronize()
     assert rel_err(pre.cpu(), pre_o) < TOL
@@ -605,11 +649,14 @@ def test_dense_chain_forward_style(dev, variant, m):
     assert float(junk.abs().max()) == 0.0
 
 
-def test_dense_chain_backward_style(dev, variant):
+@pytest.mark.parametrize("NF,packed", [(64, False), (128, False), (128, True), (384, True)])
+def test_dense_chain_backward_style(dev, variant, NF, packed, chain_rows):
     """(gh W_in + gx) -> (. W4) * ssp'(pre3) -> (. W3): the transposed chain of the backward."""
     from schnetpack_amd import _lib
+    if packed and variant == "simple":
+        pytest.skip("packed weights are an MFMA-kernel format")
     g = torch.Generator().manual_seed(43)
-    m, F, NF = 777, 128, 64
+    m, F = 777, 128
     gh = torch.randn(m, NF, generator=g)
     gx = torch.randn(m, F, generator=g)
     pre3 = torch.randn(m, F, generator=g)
@@ -624,10 +671,14 @@ def test_dense_chain_backward_style(dev, variant):
     gx_new = torch.empty(m, F, device=dev)
     gy = torch.empty(m, NF, device=dev)
     tmp = (torch.empty(m, F, device=dev), torch.empty(m, F, device=dev))
+    tr = 1
+    if packed:
+        wind, w4d, w3d = _pack(wind, 1), _pack(w4d, 1), _pack(w3d, 1)
+        tr = 2
     c = _chain_struct(_lib, m, ghd, [
-        dict(w=wind, res=gxd, out=gx_new, k=NF, n_out=F, trans=1),
-        dict(w=w4d, post_pre=pred, post_act=_lib.SPK_ACT_SSP, k=F, n_out=F, trans=1),
-        dict(w=w3d, out=gy, k=F, n_out=NF, trans=1)], tmp=tmp)
+        dict(w=wind, res=gxd, out=gx_new, k=NF, n_out=F, trans=tr),
+        dict(w=w4d, post_pre=pred, post_act=_lib.SPK_ACT_SSP, k=F, n_out=F, trans=tr),
+        dict(w=w3d, out=gy, k=F, n_out=NF, trans=tr)], tmp=tmp)
     _lib.check(_lib.lib().spk_dense_chain_f32(ctypes.byref(c), _lib.stream()))
     torch.cuda.synchronize()
     assert rel_err(gx_new.cpu(), gx_o) < TOL
