@@ -111,6 +111,13 @@ int spk_scatter_add_f32(const float* x, const int64_t* idx, const int32_t* rowpt
 int spk_gather_f32(const float* x, const int64_t* idx, int64_t outer, int64_t n_rows,
                    int64_t n_edges, int64_t inner, float* y, void* stream);
 
+/* CSR row pointers rowptr [n_rows + 1] of an ASCENDING index (idx_i of a neighbour list, idx_m) computed
+ * on the device without a host round trip, so that the call can be part of a captured HIP graph whose index
+ * buffers are refilled between replays (static-shape training steps).  err (device int32, may be NULL) is
+ * OR-ed with 1 if idx is not ascending and with 2 if an entry is outside [0, n_rows); the caller polls it. */
+int spk_segment_rowptr_i32(const int64_t* idx, int64_t n, int64_t n_rows, int32_t* rowptr, int32_t* err,
+                           void* stream);
+
 /* ------------------------------------------------------------------ atomistic/distances.py:14-26
  * r_ij[e] = (R[idx_j[e]] - R[idx_i[e]]) + offsets[e]   (offsets may be NULL). */
 int spk_pairwise_f32(const float* R, const int64_t* idx_i, const int64_t* idx_j,

@@ -117,6 +117,33 @@ __global__ void k_rowptr(const int64_t* __restrict__ idx_i, int64_t E, int64_t N
   }
 }
 
+// CSR row pointers of an ascending index on the device only (no host round trip: usable inside a HIP graph).
+// err[0] |= 1 if the index is not ascending, |= 2 if an entry is outside [0, n_rows).
+__global__ void k_rowptr_checked(const int64_t* __restrict__ idx, int64_t E, int64_t N, int32_t* __restrict__ rowptr,
+                                 int32_t* __restrict__ err) {
+  int bad = 0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e <= E; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t prev = (e > 0) ? idx[e - 1] : -1;
+    int64_t cur = (e < E) ? idx[e] : N;
+    if (e < E && (cur < 0 || cur >= N)) bad |= 2;
+    if (e > 0 && e < E && prev > cur) bad |= 1;
+    if (prev < -1) prev = -1;
+    if (cur > N) cur = N;
+    for (int64_t r = prev + 1; r <= cur; ++r) rowptr[r] = (int32_t)e;
+  }
+  if (bad && err) atomicOr(err, bad);
+}
+
+extern "C" int spk_segment_rowptr_i32(const int64_t* idx, int64_t n, int64_t n_rows, int32_t* rowptr, int32_t* err,
+                                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(n >= 0 && n_rows >= 0 && n < (1LL << 31) && rowptr != nullptr && (n == 0 || idx != nullptr),
+                "spk_segment_rowptr_i32: bad input");
+  hipLaunchKernelGGL(k_rowptr_checked, dim3(spk_grid_for(n + 1, 256, 4096)), dim3(256), 0, stream, idx, n, n_rows, rowptr, err);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 // every edge (i<-j, r) must have a partner (j<-i, -r) in row j
 __global__ void k_symmetry(const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j,
                            const float* __restrict__ rij, const int32_t* __restrict__ rowptr,

@@ -140,8 +140,65 @@ def edge_plan(idx_i, idx_j, n_atoms, r_ij=None):
     return plan
 
 
+class StaticLists:
+    """Static-shape mode for HIP-graph replays of the differentiable (training) path.
+
+    Plans are normally cached on the identity / version of the index tensors and validated with a host
+    round trip -- neither survives a graph whose index BUFFERS are refilled between replays.  Inside
+    ``with StaticLists() as sl:`` (and in the captured graph) every index tensor declared with
+    ``sl.declare_sorted(idx, n_rows)`` gets its CSR row pointers from a device-only kernel launched by
+    ``sl.refresh()`` (capture that call at the start of the step); all other indices take the atomic
+    scatter; neighbour-list plans (symmetry, reverse map) are not used.  ``sl.check()`` polls the device
+    flag that the refresh kernels raise when a declared index was not ascending / in range."""
+
+    def __init__(self):
+        self.entries = {}
+        self.err = None
+
+    def declare_sorted(self, idx, n_rows):
+        _lib.require_device(idx)
+        if idx.dtype != torch.int64 or not idx.is_contiguous():
+            raise SpkHipError("StaticLists.declare_sorted: needs a contiguous int64 tensor")
+        if self.err is None:
+            self.err = torch.zeros(1, dtype=torch.int32, device=idx.device)
+        self.entries[id(idx)] = (idx, int(n_rows), torch.zeros(int(n_rows) + 1, dtype=torch.int32, device=idx.device))
+
+    def refresh(self):
+        for idx, n_rows, rowptr in self.entries.values():
+            with torch.cuda.device(idx.device):
+                check(lib().spk_segment_rowptr_i32(iptr(idx), int(idx.shape[0]), n_rows, iptr(rowptr, torch.int32),
+                                                   iptr(self.err, torch.int32), stream()))
+
+    def rowptr(self, idx, dim_size):
+        e = self.entries.get(id(idx))
+        return e[2] if (e is not None and e[0] is idx and e[1] == int(dim_size)) else None
+
+    def check(self):
+        if self.err is not None:
+            f = int(self.err.item())
+            if f:
+                self.err.zero_()
+                raise SpkHipError("StaticLists: a declared index was %s" % ("not ascending" if f & 1 else "out of range"))
+
+    def __enter__(self):
+        global _STATIC
+        self._prev = _STATIC
+        _STATIC = self
+        return self
+
+    def __exit__(self, *exc):
+        global _STATIC
+        _STATIC = self._prev
+        return False
+
+
+_STATIC = None
+
+
 def segment_rowptr(idx, dim_size):
-    """rowptr tensor if ``idx`` is ascending, else None (cached)."""
+    """rowptr tensor if ``idx`` is ascending, else None (cached; device-only in static-shape mode)."""
+    if _STATIC is not None:
+        return _STATIC.rowptr(idx, dim_size)
     plan = edge_plan(idx, idx, dim_size, None)
     return plan.rowptr if plan.sorted else None
 
@@ -255,7 +312,7 @@ class PairwiseFn(torch.autograd.Function):
         ctx.has_off = offsets is not None
         # the plan of the list (cached; the representation asks for the same one): on symmetric sorted
         # lists the backward is a segmented row sum instead of 6 atomics per edge
-        ctx.plan = edge_plan(idx_i, idx_j, ctx.n, r) if (E > 0 and ctx.needs_input_grad[0]) else None
+        ctx.plan = edge_plan(idx_i, idx_j, ctx.n, r) if (E > 0 and ctx.needs_input_grad[0] and _STATIC is None) else None
         return r
 
     @staticmethod

@@ -1,0 +1,137 @@
+"""Static-shape training step replayed as HIP graphs (SURVEY.md section 8, configs[3] / cfg 4).
+
+The differentiable path (``module.training``: HIP scatter/gather/Dense primitives, double backward through
+``Forces(create_graph=True)``) is a few hundred small launches per step at rMD17 batch sizes -- launch bound.
+Instead of a tracing compiler the step is captured once into a HIP graph and replayed:
+
+* shapes are made static by padding the neighbour list of every batch to ``max_edges`` with inert pairs
+  (self pairs of the last atom with an offset beyond the cutoff: the cosine cutoff and its derivative vanish
+  there, so energies, forces and all gradients are exactly those of the unpadded batch);
+* the index tensors are static BUFFERS refilled per step; their CSR row pointers are recomputed inside the
+  graph by a device-only kernel (``ops.StaticLists``), no plan cache, no host round trip;
+* gradients are views of one flat bucket (``parallel.FlatGradAllReduce(as_views=True)``): cleared with one
+  fill, all-reduced with one RCCL call between the two graphs (backward | optimizer) when there are ranks;
+* AdamW runs ``capturable`` so that its step is part of the graph.
+
+The first two calls of :meth:`GraphedTrainStep.step` run eagerly (allocator / autotune warm-up; they are
+real optimizer steps), the third captures, every later one replays.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import ops, properties
+from .parallel import FlatGradAllReduce
+
+__all__ = ["GraphedTrainStep", "pad_edges"]
+
+
+def pad_edges(idx_i, idx_j, offsets, n_atoms: int, max_edges: int, cutoff: float):
+    """Pad a neighbour list (idx_i ascending) to ``max_edges`` pairs with inert entries
+    (i = j = n_atoms - 1, offset = (2 cutoff + 1, 0, 0)): d = 2 cutoff + 1 > cutoff => f_cut = f_cut' = 0."""
+    E = int(idx_i.shape[0])
+    if E > max_edges:
+        raise ValueError("neighbour list has %d pairs, capacity is %d" % (E, max_edges))
+    pad = max_edges - E
+    last = n_atoms - 1
+    ii = torch.cat([idx_i, torch.full((pad,), last, dtype=idx_i.dtype, device=idx_i.device)])
+    jj = torch.cat([idx_j, torch.full((pad,), last, dtype=idx_j.dtype, device=idx_j.device)])
+    po = torch.zeros((pad, 3), dtype=offsets.dtype, device=offsets.device)
+    po[:, 0] = 2.0 * cutoff + 1.0
+    return ii, jj, torch.cat([offsets, po])
+
+
+class GraphedTrainStep:
+    """Force-matching training step ``loss = w_E MSE(E) + w_F MSE(F)`` (the reference's task block,
+    examples/.../config.yaml) for batches of a fixed number of atoms / molecules and at most ``max_edges``
+    pairs.  ``load(batch, E_target, F_target)`` fills the static buffers, ``step()`` runs one optimizer step
+    and returns the (device) loss of that step."""
+
+    def __init__(self, model, n_atoms: int, n_molecules: int, max_edges: int, cutoff: float, lr: float = 1e-3,
+                 loss_weights=(0.01, 0.99), group=None, use_graph: bool = True, warmup_steps: int = 2):
+        self.model = model.train()
+        dev = next(model.parameters()).device
+        self.dev, self.N, self.M, self.Emax, self.cutoff = dev, int(n_atoms), int(n_molecules), int(max_edges), float(cutoff)
+        self.wE, self.wF = loss_weights
+        self.group, self.use_graph, self.warmup_steps = group, use_graph, warmup_steps
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        self.buf = {
+            properties.Z: z(self.N, dt=torch.int64), properties.R: z(self.N, 3),
+            properties.idx_i: z(self.Emax, dt=torch.int64), properties.idx_j: z(self.Emax, dt=torch.int64),
+            properties.offsets: z(self.Emax, 3), properties.idx_m: z(self.N, dt=torch.int64),
+        }
+        self.E_t, self.F_t = z(self.M), z(self.N, 3)
+        self.loss = z(())
+        self.lists = ops.StaticLists()
+        self.lists.declare_sorted(self.buf[properties.idx_i], self.N)
+        self.lists.declare_sorted(self.buf[properties.idx_m], self.M)
+        self.reducer = FlatGradAllReduce(model.parameters(), as_views=True)
+        self.opt = torch.optim.AdamW(model.parameters(), lr=lr, capturable=True)
+        self.n_steps = 0
+        self.g_bwd = self.g_opt = None
+
+    # ---------------------------------------------------------------- data
+    def load(self, batch: Dict[str, torch.Tensor], E_target: torch.Tensor, F_target: torch.Tensor):
+        """batch: Z, R, idx_i, idx_j, offsets, idx_m (host or device tensors of the synthetic / collate layout)."""
+        if int(batch["Z"].shape[0]) != self.N:
+            raise ValueError("batch has %d atoms, the step was built for %d" % (batch["Z"].shape[0], self.N))
+        ii, jj, off = pad_edges(batch["idx_i"], batch["idx_j"], batch["offsets"].float(), self.N, self.Emax, self.cutoff)
+        with torch.no_grad():
+            self.buf[properties.Z].copy_(batch["Z"], non_blocking=True)
+            self.buf[properties.R].copy_(batch["R"].float(), non_blocking=True)
+            self.buf[properties.idx_i].copy_(ii, non_blocking=True)
+            self.buf[properties.idx_j].copy_(jj, non_blocking=True)
+            self.buf[properties.offsets].copy_(off, non_blocking=True)
+            self.buf[properties.idx_m].copy_(batch["idx_m"], non_blocking=True)
+            self.E_t.copy_(E_target, non_blocking=True)
+            self.F_t.copy_(F_target, non_blocking=True)
+
+    # ---------------------------------------------------------------- the step
+    def _forward_backward(self):
+        self.lists.refresh()
+        self.reducer.zero()
+        inputs = dict(self.buf)
+        inputs[properties.R] = self.buf[properties.R].detach().requires_grad_(False)
+        inputs["_n_molecules"] = self.M
+        out = self.model(inputs)
+        loss = self.wE * ((out["energy"] - self.E_t) ** 2).mean() + self.wF * ((out["forces"] - self.F_t) ** 2).mean()
+        loss.backward()
+        self.loss.copy_(loss.detach())
+
+    def _eager_step(self):
+        with self.lists:
+            self._forward_backward()
+        self.reducer(self.group)
+        self.opt.step()
+
+    def _capture(self):
+        torch.cuda.synchronize(self.dev)
+        multi = self.group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                           and torch.distributed.get_world_size() > 1)
+        self.g_bwd = torch.cuda.CUDAGraph()
+        with self.lists:
+            with torch.cuda.graph(self.g_bwd):
+                self._forward_backward()
+                if not multi:
+                    self.opt.step()
+        if multi:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=self.g_bwd.pool()):
+                self.opt.step()
+
+    def step(self) -> torch.Tensor:
+        self.n_steps += 1
+        if not self.use_graph or self.n_steps <= self.warmup_steps:
+            self._eager_step()
+            return self.loss
+        if self.g_bwd is None:
+            self._capture()
+        self.g_bwd.replay()
+        if self.g_opt is not None:
+            self.reducer(self.group)
+            self.g_opt.replay()
+        return self.loss
+
+    def check(self):
+        """Poll the device-side validity flag of the declared index tensors (one D2H)."""
+        self.lists.check()

@@ -1,0 +1,105 @@
+"""Static-shape, HIP-graph training step (configs[3]): equals the plain eager training loop."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import spk_oracle as O
+from schnetpack_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    return torch.device("cuda", 0)
+
+
+def _model(kind, dev):
+    from schnetpack_amd import model as M
+    rep_p = O.init_schnet_params() if kind == "schnet" else O.init_painn_params()
+    model = M.build_model(kind)
+    M.load_reference_params(model, rep_p, O.init_atomwise_params(128, seed=1))
+    return model.to(dev)
+
+
+def _batches(n, frames):
+    out = []
+    for k in range(n):
+        b = S.molecule_batch("aspirin", frames, seed=100 + k)
+        g = torch.Generator().manual_seed(k)
+        out.append((b, torch.randn(frames, generator=g), torch.randn(b["Z"].shape[0], 3, generator=g)))
+    return out
+
+
+def test_padding_is_inert(dev):
+    """Padded pairs (self pairs beyond the cutoff) change neither energies nor forces nor weight gradients."""
+    from schnetpack_amd import model as M
+    from schnetpack_amd.train import pad_edges
+    b = S.molecule_batch("aspirin", 3, seed=5)
+    N = b["Z"].shape[0]
+    ii, jj, off = pad_edges(b["idx_i"], b["idx_j"], b["offsets"], N, b["idx_i"].shape[0] + 77, 5.0)
+    assert bool((ii[1:] >= ii[:-1]).all())
+    for kind in ("schnet", "painn"):
+        res = []
+        for bb in (b, dict(b, idx_i=ii, idx_j=jj, offsets=off)):
+            model = _model(kind, dev).train()
+            out = model(M.batch_to_inputs(bb, dev))
+            loss = (out["energy"] ** 2).mean() + (out["forces"] ** 2).mean()
+            loss.backward()
+            res.append((out["energy"].detach().cpu(), out["forces"].detach().cpu(),
+                        torch.cat([p.grad.reshape(-1).cpu() for p in model.parameters() if p.grad is not None])))
+        for a, c in zip(*res):
+            assert rel_err(a, c) < 1e-6, kind
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_graphed_training_step_equals_eager_loop(dev, kind):
+    """6 AdamW steps on 6 different batches (different pair counts, padded to one capacity): the replayed
+    graphs walk the trajectory of the plain loop (standard AdamW, unpadded lists, plan cache)."""
+    from schnetpack_amd import model as M
+    from schnetpack_amd.train import GraphedTrainStep
+    frames, steps = 4, 6
+    data = _batches(steps, frames)
+    N = data[0][0]["Z"].shape[0]
+    emax = max(int(b["idx_i"].shape[0]) for b, _, _ in data) + 10
+    assert len({int(b["idx_i"].shape[0]) for b, _, _ in data}) > 1
+
+    ref = _model(kind, dev).train()
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    ref_losses = []
+    for b, Et, Ft in data:
+        opt.zero_grad()
+        out = ref(M.batch_to_inputs(b, dev))
+        loss = 0.01 * ((out["energy"] - Et.to(dev)) ** 2).mean() + 0.99 * ((out["forces"] - Ft.to(dev)) ** 2).mean()
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+
+    model = _model(kind, dev)
+    ts = GraphedTrainStep(model, N, frames, emax, 5.0, lr=1e-3)
+    losses = []
+    for b, Et, Ft in data:
+        ts.load(b, Et, Ft)
+        losses.append(float(ts.step()))
+    ts.check()
+    assert ts.g_bwd is not None and ts.n_steps == steps          # steps 3.. were graph replays
+    assert max(abs(a - c) / abs(c) for a, c in zip(losses, ref_losses)) < 1e-4, (losses, ref_losses)
+    worst = max(rel_err(p.detach().cpu(), q.detach().cpu()) for p, q in zip(model.parameters(), ref.parameters()))
+    assert worst < 1e-3, worst
+
+
+def test_static_lists_flag_unsorted_index(dev):
+    from schnetpack_amd import ops
+    from schnetpack_amd._lib import SpkHipError
+    sl = ops.StaticLists()
+    idx = torch.tensor([0, 0, 1, 3, 3, 5], device=dev)
+    sl.declare_sorted(idx, 7)
+    sl.refresh()
+    sl.check()
+    assert sl.rowptr(idx, 7).cpu().tolist() == [0, 2, 3, 3, 5, 5, 6, 6]
+    idx.copy_(torch.tensor([0, 2, 1, 3, 3, 5], device=dev))
+    sl.refresh()
+    with pytest.raises(SpkHipError):
+        sl.check()
