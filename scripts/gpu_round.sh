@@ -29,6 +29,10 @@ echo "== training step (configs[3])"
 for KIND in schnet painn; do
   timeout 600 python bench.py --mode train --kind $KIND --steps 50 --warmup 5 --cpu-reps 5 > $OUT/bench_train_$KIND.json 2> $OUT/bench_train_$KIND.err; echo "rc=$?"; cut -c1-300 $OUT/bench_train_$KIND.json
 done
+echo "== MD loop (NVE, device neighbour list with skin, graph replay)"
+for W in aspirin water; do for KIND in schnet painn; do
+  timeout 600 python bench.py --mode md --workload $W --kind $KIND --steps 200 --warmup 10 > $OUT/bench_md_${W}_$KIND.json 2> $OUT/bench_md_${W}_$KIND.err; echo "rc=$?"; cut -c1-200 $OUT/bench_md_${W}_$KIND.json
+done; done
 echo "== PMC traffic"
 bash $ROOT/scripts/gpu_pmc_traffic.sh $TAG schnet aspirin
 bash $ROOT/scripts/gpu_pmc_traffic.sh $TAG painn aspirin
