@@ -197,10 +197,27 @@ __global__ __launch_bounds__(256) void k_nbl_desc(const float* __restrict__ R, c
   }
 }
 
-__global__ void k_nbl_binoffsets(NblSys* __restrict__ sys, int64_t n_sys) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int run = 0;
-    for (int64_t m = 0; m < n_sys; ++m) { const int nbins = sys[m].bin0; sys[m].bin0 = run; run += nbins; }
+// exclusive scan of the per-system bin counts (left in bin0 by k_nbl_desc) -> bin offsets; one block
+__global__ __launch_bounds__(256) void k_nbl_binoffsets(NblSys* __restrict__ sys, int64_t n_sys) {
+  __shared__ int part[256];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n_sys; base += 256) {
+    const int64_t m = base + threadIdx.x;
+    const int v = m < n_sys ? sys[m].bin0 : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 1; st < 256; st <<= 1) {
+      const int add = (int)threadIdx.x >= st ? part[threadIdx.x - st] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (m < n_sys) sys[m].bin0 = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry += part[255];
+    __syncthreads();
   }
 }
 
@@ -343,7 +360,7 @@ static int nbl_prepare(NblWs& w, const float* R, const int64_t* idx_m, const flo
   hipLaunchKernelGGL(k_nbl_atom0, dim3(spk_grid_for(N, 256, spk_num_cus() * 8)), dim3(256), 0, stream, idx_m, N, n_sys, w.atom0, w.total);
   hipLaunchKernelGGL(k_nbl_atom0_fix, dim3(1), dim3(64), 0, stream, N, n_sys, w.atom0);
   hipLaunchKernelGGL(k_nbl_desc, dim3((unsigned)n_sys), dim3(256), 0, stream, R, cell, pbc, w.atom0, cutoff, w.sys, w.total);
-  hipLaunchKernelGGL(k_nbl_binoffsets, dim3(1), dim3(64), 0, stream, w.sys, n_sys);
+  hipLaunchKernelGGL(k_nbl_binoffsets, dim3(1), dim3(256), 0, stream, w.sys, n_sys);
   hipLaunchKernelGGL(k_nbl_bin, dim3(spk_grid_for(N, 256, spk_num_cus() * 8)), dim3(256), 0, stream, R, idx_m, w.sys, N, w.key, w.ids, w.wrap);
   SPK_LAUNCH_CHECK();
   size_t tmp = w.sort_tmp_bytes;
