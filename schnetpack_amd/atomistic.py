@@ -117,7 +117,18 @@ class Forces(nn.Module):
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         Epred = inputs[self.energy_key]
-        go: List[Optional[torch.Tensor]] = [torch.ones_like(Epred)]
+        # grad_outputs = ones (response.py:63); one cached buffer per shape instead of a fill launch per call
+        # (never cached from inside a graph capture: that memory belongs to the graph)
+        cache = self.__dict__.setdefault("_ones_cache", {})
+        key = (tuple(Epred.shape), Epred.device, Epred.dtype)
+        ones = cache.get(key)
+        if ones is None:
+            ones = torch.ones_like(Epred)
+            if not (Epred.is_cuda and torch.cuda.is_current_stream_capturing()):
+                if len(cache) > 8:
+                    cache.clear()
+                cache[key] = ones
+        go: List[Optional[torch.Tensor]] = [ones]
         grads = torch.autograd.grad([Epred], [inputs[p] for p in self.required_derivatives],
                                     grad_outputs=go, create_graph=self.training)
         if self.calc_forces:

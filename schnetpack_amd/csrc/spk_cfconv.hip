@@ -32,7 +32,8 @@ struct CfArgs {
   const float* w2;     // [NF, NF]
   const float* b2;     // [NF]
   float* y;            // fwd: [N, NF] (pre-zeroed);  bwd: gh [N, NF] (pre-zeroed)
-  float* gr;           // bwd: [E, 3] accumulated
+  float* gr;           // bwd: [E, 3] accumulated (pair kernels: assigned when gr_assign != 0)
+  int gr_assign;       // pair kernels write every edge exactly once: the first interaction of a backward can assign
   int64_t E;
   int64_t N;
   long long* dbg;       // optional: cycle stamps of wave 0 / workgroup 0 (kernel tuning aid)
@@ -650,13 +651,18 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
       }
       if (BWD) {
         spk_wave_lds_sync();
-        if (hi == 0 && valid && d > 0.f) {
+        if (hi == 0 && valid) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int k2 = 0; k2 < 32; ++k2) { s1 += myD[el * 33 + k2]; s2 += myD[32 * 33 + el * 33 + k2]; }
-          s1 /= d; s2 /= d;
-          a.gr[3 * e] += s1 * rx; a.gr[3 * e + 1] += s1 * ry; a.gr[3 * e + 2] += s1 * rz;
-          a.gr[3 * e2] -= s2 * rx; a.gr[3 * e2 + 1] -= s2 * ry; a.gr[3 * e2 + 2] -= s2 * rz;
+          s1 = d > 0.f ? s1 / d : 0.f; s2 = d > 0.f ? s2 / d : 0.f;
+          if (a.gr_assign) {
+            a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
+            a.gr[3 * e2] = -s2 * rx; a.gr[3 * e2 + 1] = -s2 * ry; a.gr[3 * e2 + 2] = -s2 * rz;
+          } else {
+            a.gr[3 * e] += s1 * rx; a.gr[3 * e + 1] += s1 * ry; a.gr[3 * e + 2] += s1 * rz;
+            a.gr[3 * e2] -= s2 * rx; a.gr[3 * e2 + 1] -= s2 * ry; a.gr[3 * e2 + 2] -= s2 * rz;
+          }
         }
       }
       spk_wave_lds_sync();   // myE / myD may be rewritten by the next tile
@@ -880,10 +886,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_t(CfArgs a) {
     if (BWD) {
       dsum1 += __shfl_xor(dsum1, 32, 64);
       dsum2 += __shfl_xor(dsum2, 32, 64);
-      if (hi == 0 && valid && d > 0.f) {
-        const float s1 = dsum1 / d, s2 = dsum2 / d;
-        a.gr[3 * e] += s1 * rx; a.gr[3 * e + 1] += s1 * ry; a.gr[3 * e + 2] += s1 * rz;
-        a.gr[3 * e2] -= s2 * rx; a.gr[3 * e2 + 1] -= s2 * ry; a.gr[3 * e2 + 2] -= s2 * rz;
+      if (hi == 0 && valid) {
+        const float s1 = d > 0.f ? dsum1 / d : 0.f, s2 = d > 0.f ? dsum2 / d : 0.f;
+        if (a.gr_assign) {
+          a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
+          a.gr[3 * e2] = -s2 * rx; a.gr[3 * e2 + 1] = -s2 * ry; a.gr[3 * e2 + 2] = -s2 * rz;
+        } else {
+          a.gr[3 * e] += s1 * rx; a.gr[3 * e + 1] += s1 * ry; a.gr[3 * e + 2] += s1 * rz;
+          a.gr[3 * e2] -= s2 * rx; a.gr[3 * e2 + 1] -= s2 * ry; a.gr[3 * e2 + 2] -= s2 * rz;
+        }
       }
     }
   }
@@ -1053,7 +1064,7 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(h && r_ij && w1 && b1 && w2 && b2, "%s: null pointer", who);
   CfArgs a;
   a.h = h; a.gy = nullptr; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr; a.gsave = gsave; a.gload = nullptr; a.dbg = spk_cf_debug_buffer();
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr; a.gr_assign = 0; a.gsave = gsave; a.gload = nullptr; a.dbg = spk_cf_debug_buffer();
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
   a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
@@ -1063,7 +1074,7 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
 int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
                             const float* gy, const float* r_ij, const float* w1, const float* b1,
                             const float* w2, const float* b2, int nf, float* gh, float* gr,
-                            hipStream_t stream, bool pre_zeroed, const float* gload) {
+                            hipStream_t stream, bool pre_zeroed, const float* gload, bool gr_assign) {
   const char* who = "spk_schnet_cfconv_bwd_f32";
   int rc = check_graph(g, who);
   if (rc) return rc;
@@ -1076,7 +1087,7 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(h && gy && r_ij && w1 && b1 && w2 && b2 && gr, "%s: null pointer", who);
   CfArgs a;
   a.h = h; a.gy = gy; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr; a.gsave = nullptr; a.gload = gload; a.dbg = spk_cf_debug_buffer();
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr; a.gr_assign = (gr_assign && spk_cfconv_gsave_floats(g, rb, nf) > 0) ? 1 : 0; a.gsave = nullptr; a.gload = gload; a.dbg = spk_cf_debug_buffer();
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
   a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
@@ -1097,5 +1108,5 @@ extern "C" int spk_schnet_cfconv_bwd_f32(const spk_graph_t* g, const spk_radial_
                                          const float* w1, const float* b1, const float* w2,
                                          const float* b2, int32_t nf, float* gh, float* gr,
                                          void* stream) {
-  return spk_cfconv_bwd_internal(g, rb, h, gy, r_ij, w1, b1, w2, b2, nf, gh, gr, (hipStream_t)stream, false, nullptr);
+  return spk_cfconv_bwd_internal(g, rb, h, gy, r_ij, w1, b1, w2, b2, nf, gh, gr, (hipStream_t)stream, false, nullptr, false);
 }

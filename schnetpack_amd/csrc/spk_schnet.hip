@@ -13,7 +13,7 @@ int64_t spk_cfconv_gsave_floats(const spk_graph_t* g, const spk_radial_t* rb, in
 int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
                             const float* gy, const float* r_ij, const float* w1, const float* b1,
                             const float* w2, const float* b2, int nf, float* gh, float* gr,
-                            hipStream_t stream, bool pre_zeroed, const float* gload);
+                            hipStream_t stream, bool pre_zeroed, const float* gload, bool gr_assign);
 
 static int check_model(const spk_schnet_t* m, const char* who) {
   SPK_CHECK_ARG(m != nullptr && m->layers != nullptr, "%s: null model", who);
@@ -151,9 +151,12 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   SPK_CHECK_ARG(g != nullptr && rb != nullptr, "%s: null graph/radial", who);
   const int64_t N = g->n_atoms, E = g->n_edges;
   const int F = m->n_atom_basis, NF = m->n_filters, L = m->n_interactions;
+  // with saved filters the pair kernel runs and writes every entry of gr exactly once per interaction: the
+  // first interaction of the backward assigns, the others accumulate -- no clearing pass
+  const bool gr_assign = L > 0 && (m->reserved & 1) && E > 0 && spk_cfconv_gsave_floats(g, rb, NF) > 0;
   if (E > 0) {
     SPK_CHECK_ARG(gr != nullptr, "%s: null gr", who);
-    { int _zr = spk_zero_async(gr, (size_t)E * 3 * sizeof(float), stream); if (_zr) return _zr; }
+    if (!gr_assign) { int _zr = spk_zero_async(gr, (size_t)E * 3 * sizeof(float), stream); if (_zr) return _zr; }
   }
   if (N == 0) return SPK_OK;
   SPK_CHECK_ARG(gx_out && (L == 0 || (saved && scratch)), "%s: null buffer", who);
@@ -187,7 +190,7 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
     const spk_schnet_layer_t& P = m->layers[l];
     float* gh = ghbuf[l & 1];
     SPK_TRY(spk_cfconv_bwd_internal(g, rb, hbuf(l), gy, r_ij, P.fn_w1, P.fn_b1, P.fn_w2, P.fn_b2, NF, gh, gr, stream, true,
-                                    gsz > 0 ? gbase + l * gsz : nullptr));
+                                    gsz > 0 ? gbase + l * gsz : nullptr, gr_assign && l == L - 1));
     if (l == 0 && !gx0) break;  // dL/dx0 not requested (eval path): nothing below feeds dL/dr_ij
     float* out = (l == 0) ? gx0 : gxb;
     spk_chain_t c = {};
