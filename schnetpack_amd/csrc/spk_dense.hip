@@ -277,6 +277,117 @@ __global__ __launch_bounds__(256) void k_atomwise_fwd(
   }
 }
 
+// Same head for the common widths (n_hidden 32 or 64, n_in <= 512): 16-atom tiles on v_mfma_f32_16x16x4_f32,
+// the work of a tile split over all 4 waves (2 pairs of 16-feature tiles x 2 halves of the contraction)
+// instead of one wave walking everything, the x tile staged once in LDS.  Twice as many, four times
+// shorter workgroups: 17 -> ~8 us at 5 k atoms.  A workgroup owns a contiguous range of tiles and keeps
+// the molecule sums of its atoms in LDS until the end (one global atomic per workgroup and molecule).
+template <int ACT>
+__global__ __launch_bounds__(256) void k_atomwise_fwd16(
+    const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const int64_t* __restrict__ idx_m,
+    int64_t M, int F, int H, int64_t n_mol, float* __restrict__ pre, float* __restrict__ y_atom,
+    float* __restrict__ E, int64_t tiles_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float s_sum[128];
+  __shared__ int s_flag[128];
+  const int ld = F + 4;
+  float* xs = smem;                       // [16][F + 4]
+  float* red = xs + 16 * ld;              // [2 pairs][2 tiles][64 lanes][4]: partial sums of the upper k half
+  float* sy = red + 1024;                 // [16] per-atom outputs of the tile
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 4, el = lane & 15;
+  const int p = wv & 1, khalf = wv >> 1;
+  const int64_t ntiles = (M + 15) / 16;
+  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
+  int64_t t1 = t0 + tiles_per_block;
+  if (t1 > ntiles) t1 = ntiles;
+  if (threadIdx.x < 128) { s_sum[threadIdx.x] = 0.f; s_flag[threadIdx.x] = 0; }
+  const int64_t mol0 = (idx_m && t0 < ntiles) ? idx_m[t0 * 16] : 0;
+  const bool has_pair = 32 * p < H;
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int64_t m0 = tile * 16;
+    const int q4 = F / 4;
+    for (int s = threadIdx.x; s < 16 * q4; s += 256) {
+      const int row = s / q4, c4 = s - row * q4;
+      int64_t mm = m0 + row;
+      if (mm >= M) mm = M - 1;
+      *(f32x4*)(xs + row * ld + 4 * c4) = *(const f32x4*)(x + mm * F + 4 * c4);
+    }
+    if (threadIdx.x < 16) sy[threadIdx.x] = 0.f;
+    __syncthreads();
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (has_pair) {
+      const int kb = khalf * (F / 2);
+      const float* wr0 = w1 + (int64_t)(32 * p + el) * F + kb + 4 * h;
+      const float* wr1 = wr0 + 16 * (int64_t)F;
+      const float* br = xs + el * ld + kb + 4 * h;
+      for (int u = 0; u < F / 32; ++u) {
+        const f32x4 b = *(const f32x4*)(br + 16 * u);
+        const f32x4 a0 = *(const f32x4*)(wr0 + 16 * u), a1 = *(const f32x4*)(wr1 + 16 * u);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0);
+      }
+      if (khalf == 1) {
+        *(f32x4*)(red + ((p * 2 + 0) * 64 + lane) * 4) = acc0;
+        *(f32x4*)(red + ((p * 2 + 1) * 64 + lane) * 4) = acc1;
+      }
+    }
+    __syncthreads();
+    if (has_pair && khalf == 0) {
+      const int64_t m = m0 + el;
+      const bool valid = m < M;
+      float part = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int f0 = 32 * p + 16 * k + 4 * h;
+        f32x4 o = (k ? acc1 : acc0) + *(const f32x4*)(red + ((p * 2 + k) * 64 + lane) * 4);
+        if (b1) o += *(const f32x4*)(b1 + f0);
+        if (pre && valid) *(f32x4*)(pre + m * H + f0) = o;
+        const f32x4 wv2 = *(const f32x4*)(w2 + f0);
+        part += wv2.x * spk_act<ACT>(o.x) + wv2.y * spk_act<ACT>(o.y) + wv2.z * spk_act<ACT>(o.z) + wv2.w * spk_act<ACT>(o.w);
+      }
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      if (h == 0) atomicAdd(&sy[el], part);
+    }
+    __syncthreads();
+    if (wv == 0 && lane < 16) {
+      const int64_t m = m0 + lane;
+      const bool valid = m < M;
+      const float y = sy[lane] + (b2 ? b2[0] : 0.f);
+      if (valid && y_atom) y_atom[m] = y;
+      if (E) {
+        const int64_t mol = valid ? idx_m[m] : -1;
+        const int64_t mprev = __shfl_up(mol, 1, 16);
+        int head = (lane == 0 || mprev != mol) ? 1 : 0;
+        float v = (mol >= 0 && mol < n_mol) ? y : 0.f;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+          const float vu = __shfl_up(v, d, 16);
+          const int hu = __shfl_up(head, d, 16);
+          if (lane >= d && !head) { v += vu; head = hu; }
+        }
+        const int64_t mnext = __shfl_down(mol, 1, 16);
+        const bool last = (lane == 15) || (mnext != mol);
+        if (last && mol >= 0 && mol < n_mol) {
+          const int64_t rel = mol - mol0;
+          if (rel >= 0 && rel < 128) { s_sum[rel] += v; s_flag[rel] = 1; }   // only this wave touches s_sum inside the loop
+          else unsafeAtomicAdd(&E[mol], v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (E && threadIdx.x < 128 && s_flag[threadIdx.x]) unsafeAtomicAdd(&E[mol0 + threadIdx.x], s_sum[threadIdx.x]);
+}
+
 // gx[n][k] = sum_f s_n w2[f] act'(pre[n][f]) W1[f][k],  s_n = gE[idx_m[n]] (+ gy_atom[n]).
 template <int ACT>
 __global__ __launch_bounds__(256) void k_atomwise_bwd(
@@ -362,6 +473,22 @@ extern "C" int spk_atomwise_fwd_f32(const float* x, const float* w1, const float
   SPK_CHECK_ARG(x && w1 && w2, "spk_atomwise_fwd_f32: null pointer");
   SPK_CHECK_ARG(aligned16(x) && aligned16(w1) && aligned16(w2) && aligned16(pre), "spk_atomwise_fwd_f32: 16-byte alignment required");
   SpkProfScope prof("atomwise_fwd", stream);
+  // small systems (at most one 16-atom tile per workgroup slot): the 4-wave-per-tile kernel; large ones keep the
+  // one-wave-per-32-atoms kernel, whose 128-atom workgroups issue 4x fewer same-address molecule atomics
+  if ((n_hidden == 32 || n_hidden == 64) && n_in <= 512 && (!b1 || aligned16(b1)) && spk_get_variant() != SPK_VARIANT_SIMPLE &&
+      (n_atoms + 15) / 16 <= 2 * (int64_t)spk_num_cus()) {
+    const int64_t nt16 = (n_atoms + 15) / 16;
+    const int64_t nblk = nt16 < 2 * (int64_t)spk_num_cus() ? nt16 : 2 * (int64_t)spk_num_cus();
+    const int64_t tpb = (nt16 + nblk - 1) / nblk;
+    const int grid16 = (int)((nt16 + tpb - 1) / tpb);
+    const size_t lds = sizeof(float) * (16 * (size_t)(n_in + 4) + 1024 + 16);
+    if (act == SPK_ACT_SILU)
+      hipLaunchKernelGGL((k_atomwise_fwd16<SPK_ACT_SILU>), dim3(grid16), dim3(256), lds, stream, x, w1, b1, w2, b2, idx_m, n_atoms, n_in, n_hidden, n_mol, pre, y_atom, E, tpb);
+    else
+      hipLaunchKernelGGL((k_atomwise_fwd16<SPK_ACT_SSP>), dim3(grid16), dim3(256), lds, stream, x, w1, b1, w2, b2, idx_m, n_atoms, n_in, n_hidden, n_mol, pre, y_atom, E, tpb);
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
   const int64_t ntiles = (n_atoms + 31) / 32;
   const int grid = spk_grid_for(ntiles, 4, spk_num_cus() * 8);
   if (act == SPK_ACT_SILU)
