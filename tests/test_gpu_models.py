@@ -170,7 +170,7 @@ def test_state_dict_round_trip_and_repeat_calls(dev):
 
 # ----------------------------------------------------------------------------- Atomwise head
 @pytest.mark.parametrize("n_in,act,agg,n_atoms", [(128, "silu", "sum", 21 * 5), (128, "ssp", "avg", 77),
-                                                   (64, "silu", "sum", 1), (192, "silu", "sum", 4000),
+                                                   (64, "silu", "sum", 1), (192, "silu", "sum", 4000), (128, "silu", "sum", 9000),
                                                    (30, "silu", "sum", 50)])
 def test_atomwise_head_eval_matches_oracle(dev, n_in, act, agg, n_atoms):
     """Energy head (atomistic/atomwise.py:69-88): fused eval-mode kernel pair (forward + dE/dx) against
