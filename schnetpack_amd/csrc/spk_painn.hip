@@ -38,8 +38,31 @@ struct MsgArgs {
 // ------------------------------------------------------------------------------------------
 // row kernels (sorted idx_i; backward additionally needs a symmetric list)
 // ------------------------------------------------------------------------------------------
+// The VPL (1 or 2) consecutive channels of a lane are one value of type VT: float, or a 2-vector so that the
+// filter recomputation and the message algebra compile to packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32:
+// two channels per VALU lane and cycle -- the fp32 vector peak of the CU assumes them; the scalar form of the
+// backward issued 445 v_fma + 98 v_pk_fma per edge).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int VPL> struct MsgVec;
+template <> struct MsgVec<1> {
+  typedef float T;
+  static __device__ __forceinline__ T load(const float* p) { return p[0]; }
+  static __device__ __forceinline__ void store(float* p, T v) { p[0] = v; }
+  static __device__ __forceinline__ float sum(T v) { return v; }
+  static __device__ __forceinline__ T zero() { return 0.f; }
+};
+template <> struct MsgVec<2> {
+  typedef f32x2 T;
+  static __device__ __forceinline__ T load(const float* p) { return *(const f32x2*)p; }
+  static __device__ __forceinline__ void store(float* p, T v) { *(f32x2*)p = v; }
+  static __device__ __forceinline__ float sum(T v) { return v.x + v.y; }
+  static __device__ __forceinline__ T zero() { return f32x2{0.f, 0.f}; }
+};
+
 template <int VPL, int NRBF, bool BWD>
 __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
+  typedef MsgVec<VPL> MV;
+  typedef typename MV::T VT;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int F = a.F;
   const int K = a.rb.n_rbf;
@@ -55,34 +78,34 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
     }
     __syncthreads();
   }
-  float w[3][VPL][NRBF];
-  float bias[3][VPL];
+  VT w[3][NRBF];
+  VT bias[3];
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < 3; ++p) {
+    float tb[VPL];
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      const int row = p * F + VPL * lane + v;
-      bias[p][v] = a.bf[row];
+    for (int v = 0; v < VPL; ++v) tb[v] = a.bf[p * F + VPL * lane + v];
+    bias[p] = MV::load(tb);
 #pragma unroll
-      for (int k = 0; k < NRBF; ++k) w[p][v][k] = (k < K) ? swf[k * (3 * F + 1) + row] : 0.f;
+    for (int k = 0; k < NRBF; ++k) {
+      float tw[VPL];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) tw[v] = (k < K) ? swf[k * (3 * F + 1) + p * F + VPL * lane + v] : 0.f;
+      w[p][k] = MV::load(tw);
     }
+  }
 
   for (int64_t atom = (int64_t)blockIdx.x * 4 + wv; atom < a.N; atom += (int64_t)gridDim.x * 4) {
     const int32_t e0 = a.rowptr[atom], e1 = a.rowptr[atom + 1];
     const int64_t fo = (int64_t)VPL * lane;  // first channel of this lane
-    float accq[VPL], accv[3][VPL];           // fwd: dq, dmu ; bwd: gc_q, S
-    float accR[VPL];                         // bwd: gc_R
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) { accq[v] = 0.f; accR[v] = 0.f; accv[0][v] = accv[1][v] = accv[2][v] = 0.f; }
+    VT accq = MV::zero(), accR = MV::zero();                                   // fwd: dq ; bwd: gc_q, gc_R
+    VT accv[3] = {MV::zero(), MV::zero(), MV::zero()};                        // fwd: dmu ; bwd: S
     // values at the centre atom needed by the backward
-    float gqa[VPL], gma[3][VPL];
+    VT gqa = MV::zero(), gma[3] = {MV::zero(), MV::zero(), MV::zero()};
     if (BWD) {
+      gqa = MV::load(a.gq_out + atom * F + fo);
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        gqa[v] = a.gq_out[atom * F + fo + v];
-#pragma unroll
-        for (int x = 0; x < 3; ++x) gma[x][v] = a.gmu_out[(atom * 3 + x) * F + fo + v];
-      }
+      for (int x = 0; x < 3; ++x) gma[x] = MV::load(a.gmu_out + (atom * 3 + x) * F + fo);
     }
     for (int32_t cs = e0; cs < e1; cs += 64) {
       // lanes = edges: geometry of up to 64 edges of this row at once
@@ -101,24 +124,17 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       // neighbour rows are requested one edge ahead (explicit double buffer): the row kernel is
       // bound by the latency of these dependent gathers, not by their bandwidth
       constexpr bool PF = !BWD;  // the backward is register-bound (2 waves/SIMD matter more than the prefetch)
-      float cjr[PF ? 2 : 1][3][VPL], mujr[PF ? 2 : 1][3][VPL], gqbr[1][VPL], gmbr[1][3][VPL];
+      VT cjr[PF ? 2 : 1][3], mujr[PF ? 2 : 1][3], gqbr = MV::zero(), gmbr[3] = {MV::zero(), MV::zero(), MV::zero()};
       auto load_rows = [&](int slot, int t) {
         const int64_t jj = __builtin_amdgcn_readlane(jl, t);
         const float* cj = a.c + jj * 3 * F + fo;
         const float* muj = a.mu + jj * 3 * F + fo;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int v = 0; v < VPL; ++v) { cjr[slot][p][v] = cj[p * F + v]; mujr[slot][p][v] = muj[p * F + v]; }
+        for (int p = 0; p < 3; ++p) { cjr[slot][p] = MV::load(cj + p * F); mujr[slot][p] = MV::load(muj + p * F); }
         if (BWD) {
-          const float* gqb = a.gq_out + jj * F + fo;
-          const float* gmb = a.gmu_out + jj * 3 * F + fo;
+          gqbr = MV::load(a.gq_out + jj * F + fo);
 #pragma unroll
-          for (int v = 0; v < VPL; ++v) {
-            gqbr[0][v] = gqb[v];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) gmbr[0][p][v] = gmb[p * F + v];
-          }
+          for (int p = 0; p < 3; ++p) gmbr[p] = MV::load(a.gmu_out + jj * 3 * F + fo + p * F);
         }
       };
       if (PF) load_rows(0, 0);
@@ -136,56 +152,44 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
             // lane k evaluates phi_k(d)
             float pl, dpl;
             spk_rbf_eval(a.rb, lane, d, pl, dpl);
-            float P[3][VPL], Pd[3][VPL];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-              for (int v = 0; v < VPL; ++v) { P[p][v] = bias[p][v]; Pd[p][v] = 0.f; }
+            VT P[3] = {bias[0], bias[1], bias[2]};
+            VT Pd[3] = {MV::zero(), MV::zero(), MV::zero()};
 #pragma unroll
             for (int k = 0; k < NRBF; ++k) {
               const float s = spk_readlane_f(pl, k);
               const float sd = BWD ? spk_readlane_f(dpl, k) : 0.f;
 #pragma unroll
-              for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int v = 0; v < VPL; ++v) {
-                  P[p][v] = fmaf(w[p][v][k], s, P[p][v]);
-                  if (BWD) Pd[p][v] = fmaf(w[p][v][k], sd, Pd[p][v]);
-                }
+              for (int p = 0; p < 3; ++p) {
+                P[p] = w[p][k] * s + P[p];
+                if (BWD) Pd[p] = w[p][k] * sd + Pd[p];
+              }
             }
             if (!BWD) {
-#pragma unroll
-              for (int v = 0; v < VPL; ++v) {
-                const float mq = P[0][v] * fc * cjr[par][0][v];
-                const float mR = P[1][v] * fc * cjr[par][1][v];
-                const float mm = P[2][v] * fc * cjr[par][2][v];
-                accq[v] += mq;
-                accv[0][v] += mR * ux + mm * mujr[par][0][v];
-                accv[1][v] += mR * uy + mm * mujr[par][1][v];
-                accv[2][v] += mR * uz + mm * mujr[par][2][v];
-              }
+              const VT mq = P[0] * fc * cjr[par][0];
+              const VT mR = P[1] * fc * cjr[par][1];
+              const VT mm = P[2] * fc * cjr[par][2];
+              accq += mq;
+              accv[0] += mR * ux + mm * mujr[par][0];
+              accv[1] += mR * uy + mm * mujr[par][1];
+              accv[2] += mR * uz + mm * mujr[par][2];
             } else {
-              float dd = 0.f, tux = 0.f, tuy = 0.f, tuz = 0.f;
-#pragma unroll
-              for (int v = 0; v < VPL; ++v) {
-                const float Fq = P[0][v] * fc, FR = P[1][v] * fc, Fm = P[2][v] * fc;
-                const float dFq = Pd[0][v] * fc + P[0][v] * dfc;
-                const float dFR = Pd[1][v] * fc + P[1][v] * dfc;
-                const float dFm = Pd[2][v] * fc + P[2][v] * dfc;
-                const float cq = cjr[par][0][v], cR = cjr[par][1][v], cm = cjr[par][2][v];
-                const float mb0 = mujr[par][0][v], mb1 = mujr[par][1][v], mb2 = mujr[par][2][v];
-                const float gb0 = gmbr[0][0][v], gb1 = gmbr[0][1][v], gb2 = gmbr[0][2][v];
-                // (1) transposed sums for the centre atom acting as neighbour of b (reverse edge)
-                accq[v] += Fq * gqbr[0][v];
-                accR[v] -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
-                accv[0][v] += Fm * gb0; accv[1][v] += Fm * gb1; accv[2][v] += Fm * gb2;
-                // (2) geometry gradient of edge (atom <- b)
-                const float gu = gma[0][v] * ux + gma[1][v] * uy + gma[2][v] * uz;
-                const float gm = gma[0][v] * mb0 + gma[1][v] * mb1 + gma[2][v] * mb2;
-                dd += cq * gqa[v] * dFq + cR * gu * dFR + cm * gm * dFm;
-                const float mR = FR * cR;
-                tux += gma[0][v] * mR; tuy += gma[1][v] * mR; tuz += gma[2][v] * mR;
-              }
+              const VT Fq = P[0] * fc, FR = P[1] * fc, Fm = P[2] * fc;
+              const VT dFq = Pd[0] * fc + P[0] * dfc;
+              const VT dFR = Pd[1] * fc + P[1] * dfc;
+              const VT dFm = Pd[2] * fc + P[2] * dfc;
+              const VT cq = cjr[par][0], cR = cjr[par][1], cm = cjr[par][2];
+              const VT mb0 = mujr[par][0], mb1 = mujr[par][1], mb2 = mujr[par][2];
+              const VT gb0 = gmbr[0], gb1 = gmbr[1], gb2 = gmbr[2];
+              // (1) transposed sums for the centre atom acting as neighbour of b (reverse edge)
+              accq += Fq * gqbr;
+              accR -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
+              accv[0] += Fm * gb0; accv[1] += Fm * gb1; accv[2] += Fm * gb2;
+              // (2) geometry gradient of edge (atom <- b)
+              const VT gu = gma[0] * ux + gma[1] * uy + gma[2] * uz;
+              const VT gm = gma[0] * mb0 + gma[1] * mb1 + gma[2] * mb2;
+              const VT ddv = cq * gqa * dFq + cR * gu * dFR + cm * gm * dFm;
+              const VT mR = FR * cR;
+              float dd = MV::sum(ddv), tux = MV::sum(gma[0] * mR), tuy = MV::sum(gma[1] * mR), tuz = MV::sum(gma[2] * mR);
               dd = spk_wave_sum(dd); tux = spk_wave_sum(tux); tuy = spk_wave_sum(tuy); tuz = spk_wave_sum(tuz);
               if (lane == t) {
                 const float dot = tux * ux + tuy * uy + tuz * uz;
@@ -203,26 +207,19 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       }
     }
     if (!BWD) {
+      MV::store(a.q_out + atom * F + fo, MV::load(a.q + atom * F + fo) + accq);
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        a.q_out[atom * F + fo + v] = a.q[atom * F + fo + v] + accq[v];
-#pragma unroll
-        for (int x = 0; x < 3; ++x)
-          a.mu_out[(atom * 3 + x) * F + fo + v] = a.mu[(atom * 3 + x) * F + fo + v] + accv[x][v];
-      }
+      for (int x = 0; x < 3; ++x)
+        MV::store(a.mu_out + (atom * 3 + x) * F + fo, MV::load(a.mu + (atom * 3 + x) * F + fo) + accv[x]);
     } else {
+      const VT ma0 = MV::load(a.mu + (atom * 3 + 0) * F + fo), ma1 = MV::load(a.mu + (atom * 3 + 1) * F + fo),
+               ma2 = MV::load(a.mu + (atom * 3 + 2) * F + fo);
+      const VT cma = MV::load(a.c + atom * 3 * F + 2 * F + fo);
+      MV::store(a.gc + atom * 3 * F + fo, accq);
+      MV::store(a.gc + atom * 3 * F + F + fo, accR);
+      MV::store(a.gc + atom * 3 * F + 2 * F + fo, ma0 * accv[0] + ma1 * accv[1] + ma2 * accv[2]);
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const float ma0 = a.mu[(atom * 3 + 0) * F + fo + v], ma1 = a.mu[(atom * 3 + 1) * F + fo + v],
-                    ma2 = a.mu[(atom * 3 + 2) * F + fo + v];
-        const float cma = a.c[atom * 3 * F + 2 * F + fo + v];
-        a.gc[atom * 3 * F + fo + v] = accq[v];
-        a.gc[atom * 3 * F + F + fo + v] = accR[v];
-        a.gc[atom * 3 * F + 2 * F + fo + v] = ma0 * accv[0][v] + ma1 * accv[1][v] + ma2 * accv[2][v];
-#pragma unroll
-        for (int x = 0; x < 3; ++x)
-          a.gmu[(atom * 3 + x) * F + fo + v] = gma[x][v] + cma * accv[x][v];
-      }
+      for (int x = 0; x < 3; ++x) MV::store(a.gmu + (atom * 3 + x) * F + fo, gma[x] + cma * accv[x]);
     }
   }
 }
