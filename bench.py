@@ -406,8 +406,8 @@ def md_main(args, rank, world, dev, dist, model):
                    "M_edge_messages_per_s_in_list": round(E_list * n_int * steps_s * world / 1e6, 1),
                    "neighbor_list_rebuilds_in_timed_region": sim.nl.n_builds - b0,
                    "ms_per_rebuild_incl_recapture": round(1e3 * (sim.t_rebuild - tr0) / max(sim.nl.n_builds - b0, 1), 3),
-                   "fraction_of_time_in_rebuilds": round((sim.t_rebuild - tr0) / dt, 4), "graph_captures": sim.force_call.n_captures,
-                   "hip_graph": sim.force_call.graph is not None,
+                   "fraction_of_time_in_rebuilds": round((sim.t_rebuild - tr0) / dt, 4), "graph_captures": sim.n_captures,
+                   "hip_graph": sim.graph is not None,
                    "energy_drift_per_step_rel_to_kinetic": abs(sim.total_energy() - e0) / max(float(sim.kinetic_energy()), 1e-12) / args.steps,
                    "parallelism": "replicas only: %d independent rank(s), no collective" % world},
         "roofline": None, "cpu_baseline": None,

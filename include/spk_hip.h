@@ -157,8 +157,9 @@ int spk_nbl_fill_f32(const float* R, const int64_t* idx_m, int64_t n_atoms, int6
  * spk_md_half_step_f32      p += half_dt * F over n floats                       (:59-70)
  * spk_md_kick_drift_f32     first half step + velocity-Verlet main step fused    (:59-70, :97-110):
  *                           p += dt/2 F (skipped when F is NULL);  R += dt p / m,  masses [n_atoms];
- *                           with R_ref / flag: flag[0] |= 1 when any atom is further than
- *                           sqrt(max_disp2) from R_ref (neighbour-list skin, md/neighborlist_md.py:80-90)
+ *                           with R_ref / flag (int32 [2]): flag[0] |= 1 when any atom is further than
+ *                           sqrt(max_disp2) from R_ref (neighbour-list skin, md/neighborlist_md.py:80-90);
+ *                           flag[1] = max(flag[1], bits of the largest squared one-step displacement)
  * spk_md_ring_polymer_step_f32   ring-polymer main step (:204-229) for the beads
  *                           [bead0, bead0+n_local) of this rank from ALL beads q_all, p_all
  *                           [n_beads, n_atoms, 3]; A [4, n_beads, n_beads] = C^T diag(P_ij) C for

@@ -190,6 +190,12 @@ __device__ __forceinline__ float spk_wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float spk_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 __device__ __forceinline__ float spk_readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }

@@ -11,26 +11,36 @@ __global__ void k_md_half_step(float* __restrict__ p, const float* __restrict__ 
 
 // first half step + main step of velocity Verlet in one pass (md/integrators.py:59-70, :97-110):
 //   p += 1/2 dt F ;  R += dt p / m
-// and, for the neighbour-list skin (md/neighborlist_md.py:80-90), flag[0] |= any |R - R_ref|^2 > max_disp2.
+// and, for the neighbour-list skin (md/neighborlist_md.py:80-90), flag[0] |= any |R - R_ref|^2 > max_disp2;
+// flag[1] = running maximum of the squared displacement of ONE step (bits of a non-negative float, atomicMax),
+// which lets the caller keep a safety margin when it reads the flag one step late.
 __global__ void k_md_kick_drift(float* __restrict__ R, float* __restrict__ p, const float* __restrict__ F,
                                 const float* __restrict__ masses, float dt, int64_t n_atoms,
                                 const float* __restrict__ R_ref, float max_disp2, int32_t* __restrict__ flag) {
   bool moved = false;
+  float step2 = 0.f;
   for (int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; a < n_atoms; a += (int64_t)gridDim.x * blockDim.x) {
     const float dtm = dt / masses[a];
-    float d2 = 0.f;
+    float d2 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int64_t t = 3 * a + c;
       const float pn = F ? fmaf(0.5f * dt, F[t], p[t]) : p[t];
-      const float rn = fmaf(dtm, pn, R[t]);
+      const float dr = dtm * pn;
+      const float rn = R[t] + dr;
       p[t] = pn;
       R[t] = rn;
+      s2 = fmaf(dr, dr, s2);
       if (R_ref) { const float d = rn - R_ref[t]; d2 = fmaf(d, d, d2); }
     }
+    step2 = fmaxf(step2, s2);
     moved |= (R_ref != nullptr) && (d2 > max_disp2);
   }
-  if (flag && __any(moved)) { if ((threadIdx.x & 63) == 0) atomicOr((int*)flag, 1); }
+  if (flag) {
+    if (__any(moved)) { if ((threadIdx.x & 63) == 0) atomicOr((int*)flag, 1); }
+    step2 = spk_wave_max(step2);
+    if ((threadIdx.x & 63) == 0) atomicMax((int*)flag + 1, __float_as_int(step2));
+  }
 }
 
 // Ring-polymer main step (md/integrators.py:204-229 with the normal-mode matrix of

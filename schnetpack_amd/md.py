@@ -7,6 +7,7 @@ of the tensors handed in (the reference's MD internal units are kJ/mol, nm, Dalt
 ``masses`` ([1, n_atoms, 1] or [n_atoms]) attributes -- what ``schnetpack.md.System`` has.
 """
 import math
+import struct
 from typing import Optional
 
 import torch
@@ -176,64 +177,115 @@ class MDState:
 
 class NVESimulation:
     """The inner loop of ``md.Simulator.simulate`` (md/simulator.py:124-157) for plain NVE dynamics of ONE
-    batch of systems on one GPU, everything resident on the device:
+    batch of systems on one GPU, everything resident on the device.  One MD step is ONE HIP-graph replay
 
-        kick + drift + skin check (1 kernel)  ->  [neighbour-list rebuild + graph re-capture if an atom left
-        the skin]  ->  force call (HIP-graph replay)  ->  kick (1 kernel)
+        kick + drift + skin test (1 kernel)  ->  force call on the current list  ->  kick (1 kernel)
 
-    One scalar D2H per step (the skin flag).  ``inputs`` is the batch dict on the device with
-    ``_positions`` [N,3], ``_atomic_numbers``, ``_idx_m``, ``_n_atoms`` and (periodic) ``_cell`` / ``_pbc``;
-    positions, masses, time step and the model's energy must share one unit system
-    (forces = -dE/dpositions)."""
+    followed by one two-word D2H read.  Because the skin flag is read AFTER the step, the rebuild threshold is
+    ``shell / 2 - margin`` with ``margin`` at least twice (usually four times) the largest one-step displacement seen
+    (tracked by the kick-drift kernel): when the flag comes up, the forces of that step were still computed
+    with a valid list, and the list is rebuilt (and the graph re-captured) before the next one.  A step whose
+    displacement exceeds the margin raises.
+
+    ``inputs`` is the batch dict on the device with ``_positions`` [N,3], ``_atomic_numbers``, ``_idx_m``,
+    ``_n_atoms`` and (periodic) ``_cell`` / ``_pbc``; positions, masses, time step and the model's energy
+    must share one unit system (forces = -dE/dpositions)."""
 
     def __init__(self, model, inputs, masses, time_step, cutoff, cutoff_shell=1.0, use_graph=True):
         from . import properties
-        from .forcecall import GraphedForceCall
         from .neighborlist import NeighborListMD
         self.P = properties
+        self.model = model.eval()
         self.inputs = dict(inputs)
         R = inputs[properties.R].detach().float().contiguous().clone()
         self.state = MDState(R.unsqueeze(0), torch.zeros_like(R).unsqueeze(0), masses.float().reshape(1, -1, 1))
         self.integrator = VelocityVerlet(time_step)
         self.nl = NeighborListMD(cutoff, cutoff_shell, filter_buffer=False)
-        self.force_call = GraphedForceCall(model, use_graph=use_graph)
-        self.flag = torch.zeros(1, dtype=torch.int32, device=R.device)
+        self.use_graph = use_graph
+        self.flag = torch.zeros(2, dtype=torch.int32, device=R.device)
         self.n_molecules = int(inputs[properties.n_atoms].shape[0])
+        self.margin = 0.25 * cutoff_shell      # adapted to 4 x the largest one-step displacement once steps have run
         self.energy = None
-        self._lists = None
+        self.graph = None
+        self.n_captures = 0
         self.t_rebuild = 0.0          # wall time spent in list rebuilds + graph re-captures (synchronised)
-        self._forces(rebuild=True)
+        self._lists = None
+        self._rebuild()
 
-    def _forces(self, rebuild):
-        import time
-        P = self.P
-        R = self.state.positions[0]
-        rebuild = rebuild or self._lists is None
-        if rebuild:
-            t0 = time.perf_counter()
-            self.inputs[P.R] = R
-            self._lists = self.nl.get_neighbors(self.inputs)
-            self.flag.zero_()
+    # -- pieces of one step ------------------------------------------------------------------
+    def _call_inputs(self):
         call = dict(self.inputs)
         call.update(self._lists)
-        call[P.R] = R
+        call[self.P.R] = self.state.positions[0]          # the state tensor itself: no copy per step
         call["_n_molecules"] = self.n_molecules
-        out = self.force_call(call)
-        if rebuild:
-            torch.cuda.synchronize(R.device)
-            self.t_rebuild += time.perf_counter() - t0
-        self.state.forces = out["forces"].unsqueeze(0)
-        self.energy = out["energy"]
+        return call
+
+    def _force_eval(self):
+        out = self.model(self._call_inputs())
+        with torch.no_grad():
+            self._f.copy_(out["forces"].detach())
+            self._e.copy_(out["energy"].detach())
+
+    def _step_body(self):
+        thr = max(0.5 * self.nl.cutoff_shell - self.margin, 0.0)
+        self.integrator.first_half_and_main_step(self.state, True, self.nl.previous_positions, thr, self.flag)
+        self._force_eval()
+        self.integrator.half_step(self.state)
+
+    def _rebuild(self, new_list=True):
+        import time
+        t0 = time.perf_counter()
+        P = self.P
+        self.graph = None
+        if new_list:
+            self.inputs[P.R] = self.state.positions[0]
+            self.nl._list = None
+            self._lists = self.nl.get_neighbors(self.inputs)
+            self.flag.zero_()
+        if not new_list:
+            pass
+        elif self.energy is None:
+            out = self.model(self._call_inputs())              # first call: builds the plan, sizes the outputs
+            self._f = out["forces"].detach().clone()
+            self._e = out["energy"].detach().clone()
+            self.state.forces = self._f.unsqueeze(0)
+            self.energy = self._e
+        else:
+            self._force_eval()                                 # plan of the new list (one sync) outside any capture
+        if self.use_graph:
+            # capture records without executing: positions / momenta are untouched
+            if self.n_captures == 0:
+                torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_body()
+            self.graph = g
+            self.n_captures += 1
+        torch.cuda.synchronize(self.flag.device)
+        self.t_rebuild += time.perf_counter() - t0
 
     def step(self, n_steps=1):
-        half_skin = 0.5 * self.nl.cutoff_shell
         for _ in range(n_steps):
-            self.integrator.first_half_and_main_step(self.state, True, self.nl.previous_positions, half_skin, self.flag)
-            moved = bool(self.flag.item())            # the one host sync of the step
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._step_body()
+            moved, step_bits = self.flag.tolist()              # the one host sync of the step
+            step_disp = math.sqrt(struct.unpack("f", struct.pack("i", step_bits))[0])
+            if step_disp > self.margin:
+                raise RuntimeError("MD step moved an atom by %.3g, more than the skin margin %.3g: reduce the time step or "
+                                   "increase cutoff_shell" % (step_disp, self.margin))
+            shell = self.nl.cutoff_shell
+            # hysteresis: margin >= 2 x the largest one-step displacement at all times, re-tuned (= one re-capture,
+            # the threshold is baked into the captured kernel) only when the displacement scale changed by 2x
+            need = min(max(2.0 * step_disp, 0.01 * shell), 0.45 * shell)
+            retune = need > self.margin or 8.0 * need < self.margin
+            if retune:
+                self.margin = min(2.0 * need, 0.45 * shell)
             if moved:
-                self.nl._list = None                  # force the rebuild with the new positions
-            self._forces(rebuild=moved)
-            self.integrator.half_step(self.state)
+                self._rebuild(True)
+            elif retune:
+                self._rebuild(False)
 
     def kinetic_energy(self):
         p, m = self.state.momenta[0], self.state.masses.reshape(-1, 1)

@@ -36,14 +36,17 @@ def test_velocity_verlet_steps_match_oracle(dev):
     assert rel_err(st.positions.cpu(), R1) < 1e-6 and rel_err(st.momenta.cpu(), p1) < 1e-6
     # fused first half + main step with the skin criterion
     st2 = MDState(R.to(dev).clone(), p.to(dev).clone(), m.to(dev), F.to(dev))
-    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    flag = torch.zeros(2, dtype=torch.int32, device=dev)
     disp = (R1 - R.double()).norm(dim=-1).max().item()
     vv.first_half_and_main_step(st2, True, R.to(dev).reshape(-1, 3).contiguous(), 1.01 * disp, flag)
-    assert torch.equal(st2.positions, st.positions) and torch.equal(st2.momenta, st.momenta)
-    assert int(flag.item()) == 0
+    assert rel_err(st2.positions.cpu(), R1) < 1e-6 and torch.equal(st2.momenta, st.momenta)
+    assert int(flag[0].item()) == 0
+    # flag[1]: bits of the largest squared one-step displacement
+    step2 = flag[1:].view(torch.float32).item()
+    assert abs(step2 ** 0.5 - disp) < 1e-5 * disp
     st3 = MDState(R.to(dev).clone(), p.to(dev).clone(), m.to(dev), F.to(dev))
     vv.first_half_and_main_step(st3, True, R.to(dev).reshape(-1, 3).contiguous(), 0.99 * disp, flag)
-    assert int(flag.item()) == 1
+    assert int(flag[0].item()) == 1
 
 
 @pytest.mark.parametrize("nb", [1, 2, 4, 5, 8])
