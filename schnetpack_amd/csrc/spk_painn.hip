@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       float fcl, dfcl;
       spk_cutoff_eval(a.rb.cutoff, dl, fcl, dfcl);
       float grx = 0.f, gry = 0.f, grz = 0.f;  // bwd: geometry gradient of this lane's edge
-      const int n = (e1 - cs) < 64 ? (e1 - cs) : 64;
       // neighbour rows are requested one edge ahead (explicit double buffer): the row kernel is
       // bound by the latency of these dependent gathers, not by their bandwidth
       constexpr bool PF = !BWD;  // the backward is register-bound (2 waves/SIMD matter more than the prefetch)
@@ -137,14 +136,22 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
           for (int p = 0; p < 3; ++p) gmbr[p] = MV::load(a.gmu_out + jj * 3 * F + fo + p * F);
         }
       };
-      if (PF) load_rows(0, 0);
-      for (int t2 = 0; t2 < n; t2 += 2) {
+      // Pairs at or beyond the cutoff (skin / buffer pairs of MD lists) contribute exactly zero to every sum
+      // and gradient (f_c = f_c' = 0): they are dropped here, before their rows are fetched.  The row's live
+      // edges are walked through a bit mask (wave-uniform), so the one-edge-ahead prefetch stays intact.
+      uint64_t live = __ballot(ev && dl < a.rb.cutoff);
+      const int n_live = __popcll(live);
+      auto next_live = [&]() { const int t = __ffsll((long long)live) - 1; live &= live - 1; return t; };
+      int t_next = n_live > 0 ? next_live() : 0;
+      if (PF && n_live > 0) load_rows(0, t_next);
+      for (int t2 = 0; t2 < n_live; t2 += 2) {
 #pragma unroll
         for (int par0 = 0; par0 < 2; ++par0) {
-          const int t = t2 + par0;
           const int par = PF ? par0 : 0;
-          if (t < n) {
-            if (PF) { if (t + 1 < n) load_rows(par ^ 1, t + 1); }
+          if (t2 + par0 < n_live) {
+            const int t = t_next;
+            if (t2 + par0 + 1 < n_live) t_next = next_live();
+            if (PF) { if (t2 + par0 + 1 < n_live) load_rows(par ^ 1, t_next); }
             else load_rows(0, t);
             const float d = spk_readlane_f(dl, t);
             const float ux = spk_readlane_f(uxl, t), uy = spk_readlane_f(uyl, t), uz = spk_readlane_f(uzl, t);
