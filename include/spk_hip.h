@@ -76,6 +76,14 @@ typedef struct {
   int32_t n_groups;
   int32_t max_group_atoms;
   int64_t n_tiles_grouped; /* = grp_tile0[n_groups] */
+  /* Lists with pairs at or beyond the cutoff (MD skin lists, md/neighborlist_md.py:36-38): with filter_pairs != 0
+   * the fused SchNet representation compacts the pair list per call (pairs with d < cutoff keep their order) into
+   * its `saved` buffer and the cfconv kernels walk only those; the dropped pairs contribute exactly zero
+   * (f_c = f_c' = 0).  n_half_dev is set by the library (a device count that replaces n_half inside the kernels);
+   * callers leave it NULL. */
+  int32_t filter_pairs;
+  int32_t reserved0;
+  const int32_t* n_half_dev;
 } spk_graph_t;
 
 /* ------------------------------------------------------------------ library / device info */

@@ -35,7 +35,8 @@ class GraphT(ctypes.Structure):
     _fields_ = [("n_atoms", c_i64), ("n_edges", c_i64), ("idx_i", c_f), ("idx_j", c_f),
                 ("rowptr", c_f), ("sorted", c_i32), ("symmetric", c_i32), ("rev", c_f), ("half", c_f),
                 ("n_half", c_i64), ("grp_atom0", c_f), ("grp_pair0", c_f), ("grp_tile0", c_f),
-                ("n_groups", c_i32), ("max_group_atoms", c_i32), ("n_tiles_grouped", c_i64)]
+                ("n_groups", c_i32), ("max_group_atoms", c_i32), ("n_tiles_grouped", c_i64),
+                ("filter_pairs", c_i32), ("reserved0", c_i32), ("n_half_dev", c_f)]
 
 
 class SchnetLayerT(ctypes.Structure):

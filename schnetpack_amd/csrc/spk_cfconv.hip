@@ -42,6 +42,7 @@ struct CfArgs {
   const int32_t* half;  // pair kernel: canonical edge of every undirected pair
   const int32_t* rev;   // pair kernel: reversed edge
   int64_t n_half;
+  const int32_t* n_half_dev;  // optional device count (<= n_half) of a per-call compacted pair list
   const int32_t* grp_atom0;  // mol kernel: [G+1] first atom of every group
   const int32_t* grp_pair0;  // [G+1] first entry of the group in `half`
   const int32_t* grp_tile0;  // [G+1] first (group-aligned) tile of the group
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
 
   const int ngroups = MOL ? a.n_groups : 1;
   for (int grp = MOL ? (int)blockIdx.x : 0; grp < ngroups; grp += MOL ? (int)gridDim.x : 1) {
-    int ga0 = 0, ga1 = 0, gp0 = 0, gp1 = (int)a.n_half, gt0 = 0;
+    int ga0 = 0, ga1 = 0, gp0 = 0, gp1 = (int)(a.n_half_dev ? (int64_t)a.n_half_dev[0] : a.n_half), gt0 = 0;
     if (MOL) {
       ga0 = a.grp_atom0[grp]; ga1 = a.grp_atom0[grp + 1];
       gp0 = a.grp_pair0[grp]; gp1 = a.grp_pair0[grp + 1];
@@ -704,7 +705,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_t(CfArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int hi = lane >> 5, el = lane & 31;
   float* myT = sT + wv * (32 * TP2);
-  const int64_t ntiles = (a.n_half + 31) / 32;
+  const int64_t nhalf = a.n_half_dev ? (int64_t)a.n_half_dev[0] : a.n_half;
+  const int64_t ntiles = (nhalf + 31) / 32;
 
   while (true) {
     int nidx = 0;
@@ -714,8 +716,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_t(CfArgs a) {
     if (tile >= ntiles) break;
 
     const int64_t hidx = tile * 32 + el;
-    const bool valid = hidx < a.n_half;
-    const int64_t e = a.half[valid ? hidx : (a.n_half - 1)];
+    const bool valid = hidx < nhalf;
+    const int64_t e = a.half[valid ? hidx : (nhalf - 1)];
     const int64_t e2 = a.rev[e];
     const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
     const int64_t j = a.idx_j[e];
@@ -1036,6 +1038,49 @@ static long long* spk_cf_debug_buffer() { return g_cf_dbg; }
 // tuning aid: device buffer of >= 32 int64 that receives cycle-counter stamps of wave 0 / workgroup 0
 extern "C" void spk_cfconv_set_debug_buffer(void* p) { g_cf_dbg = (long long*)p; }
 
+// ---- per-call compaction of the pair list: canonical pairs with d < cutoff, order preserved -------------
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+__global__ void k_pair_live(const int32_t* __restrict__ half, const float* __restrict__ rij, int64_t n_half, float cutoff,
+                            unsigned char* __restrict__ flags) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_half; k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = half[k];
+    const float x = rij[3 * e], y = rij[3 * e + 1], z = rij[3 * e + 2];
+    flags[k] = sqrtf(x * x + y * y + z * z) < cutoff ? 1 : 0;
+  }
+}
+static size_t active_tmp_bytes(int64_t n_half) {
+  // the size query walks rocPRIM's device / config detection: ask once per size
+  static int64_t cached_n = -1;
+  static size_t cached_bytes = 0;
+  if (n_half != cached_n) {
+    size_t bytes = 0;
+    int32_t* p = nullptr; unsigned char* f = nullptr;
+    (void)rocprim::select(nullptr, bytes, p, f, p, p, (size_t)(n_half > 0 ? n_half : 1), (hipStream_t)0);
+    cached_n = n_half; cached_bytes = bytes;
+  }
+  return cached_bytes;
+}
+// workspace floats: active list [n_half] + count [4] + flags [n_half bytes] + rocprim temporary
+int64_t spk_active_pairs_floats(int64_t n_half) {
+  if (n_half <= 0) return 0;
+  return n_half + 4 + (n_half + 3) / 4 + 4 + (int64_t)((active_tmp_bytes(n_half) + 3) / 4) + 64;
+}
+int spk_active_pairs_internal(const spk_graph_t* g, const float* r_ij, float cutoff, float* ws, hipStream_t stream,
+                              const int32_t** half_out, const int32_t** count_out) {
+  const int64_t n = g->n_half;
+  int32_t* act = (int32_t*)ws;
+  int32_t* cnt = act + n;                                   // 4 words
+  unsigned char* flags = (unsigned char*)(cnt + 4);
+  void* tmp = (void*)(((uintptr_t)(flags + n) + 255) & ~(uintptr_t)255);
+  size_t tmp_bytes = active_tmp_bytes(n);
+  hipLaunchKernelGGL(k_pair_live, dim3(spk_grid_for(n, 256, spk_num_cus() * 8)), dim3(256), 0, stream, g->half, r_ij, n, cutoff, flags);
+  SPK_LAUNCH_CHECK();
+  SPK_HIP_TRY(rocprim::select(tmp, tmp_bytes, g->half, flags, act, cnt, (size_t)n, stream));
+  *half_out = act; *count_out = cnt;
+  return SPK_OK;
+}
+
 // floats of filter save space per interaction if the pair kernel will run for this graph/shape, else 0
 int64_t spk_cfconv_gsave_floats(const spk_graph_t* g, const spk_radial_t* rb, int nf) {
   const int variant = spk_get_variant();
@@ -1066,7 +1111,7 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   a.h = h; a.gy = nullptr; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
   a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr; a.gr_assign = 0; a.gsave = gsave; a.gload = nullptr; a.dbg = spk_cf_debug_buffer();
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
-  a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
+  a.half = g->half; a.rev = g->rev; a.n_half = g->n_half; a.n_half_dev = g->n_half_dev;
   a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
   return cfconv_dispatch<false>(a, nf, g->symmetric && g->sorted, stream, who);
 }
@@ -1087,9 +1132,9 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(h && gy && r_ij && w1 && b1 && w2 && b2 && gr, "%s: null pointer", who);
   CfArgs a;
   a.h = h; a.gy = gy; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr; a.gr_assign = (gr_assign && spk_cfconv_gsave_floats(g, rb, nf) > 0) ? 1 : 0; a.gsave = nullptr; a.gload = gload; a.dbg = spk_cf_debug_buffer();
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr; a.gr_assign = (gr_assign && !g->n_half_dev && spk_cfconv_gsave_floats(g, rb, nf) > 0) ? 1 : 0; a.gsave = nullptr; a.gload = gload; a.dbg = spk_cf_debug_buffer();
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
-  a.half = g->half; a.rev = g->rev; a.n_half = g->n_half;
+  a.half = g->half; a.rev = g->rev; a.n_half = g->n_half; a.n_half_dev = g->n_half_dev;
   a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
   // the row-local transposed reduction needs idx_i sorted AND a symmetric list
   const bool sym = g->symmetric && g->sorted;

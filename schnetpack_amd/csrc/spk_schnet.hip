@@ -27,9 +27,19 @@ extern "C" int64_t spk_schnet_saved_floats(const spk_schnet_t* m, int64_t n_atom
   if (!m) return 0;
   return (int64_t)m->n_interactions * n_atoms * (m->n_filters + m->n_atom_basis);
 }
+int64_t spk_active_pairs_floats(int64_t n_half);
+int spk_active_pairs_internal(const spk_graph_t* g, const float* r_ij, float cutoff, float* ws, hipStream_t stream,
+                              const int32_t** half_out, const int32_t** count_out);
+// the per-call compacted pair list lives behind the saved filters (only when the pair kernels run)
+static bool schnet_filter_on(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb) {
+  // (the experimental group-local kernels address `half` through per-group offsets: no compaction there)
+  return g->filter_pairs && g->n_half > 0 && spk_get_variant() != SPK_VARIANT_MFMA_MOL &&
+         spk_cfconv_gsave_floats(g, rb, m->n_filters) > 0;
+}
 extern "C" int64_t spk_schnet_saved_floats_graph(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb) {
   if (!m || !g || !rb) return 0;
-  return spk_schnet_saved_floats(m, g->n_atoms) + (int64_t)m->n_interactions * spk_cfconv_gsave_floats(g, rb, m->n_filters);
+  return spk_schnet_saved_floats(m, g->n_atoms) + (int64_t)m->n_interactions * spk_cfconv_gsave_floats(g, rb, m->n_filters) +
+         (schnet_filter_on(m, g, rb) ? spk_active_pairs_floats(g->n_half) : 0);
 }
 
 // scratch: forward  y0 | y1 | t0 | t1            (2 nf + 2 max(F, nf))
@@ -107,6 +117,14 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
   auto hbuf = [&](int l) { return saved + (int64_t)l * N * (NF + F); };
   const int64_t gsz = (m->reserved & 1) ? spk_cfconv_gsave_floats(g, rb, NF) : 0;  // bit 0: saved has filter space
   float* gbase = saved + (int64_t)L * N * (NF + F);
+  // skin lists: compact the pair list of THIS call (pairs inside the cutoff, order kept) behind the saved filters
+  spk_graph_t gact = *g;
+  if (gsz > 0 && schnet_filter_on(m, g, rb)) {
+    const int32_t *ah = nullptr, *ac = nullptr;
+    SPK_TRY(spk_active_pairs_internal(g, r_ij, rb->cutoff, gbase + (int64_t)L * gsz, stream, &ah, &ac));
+    gact.half = ah; gact.n_half_dev = ac;
+  }
+  g = &gact;
   // prelude: h_0 = in2f_0(x0); clear y of the first edge kernel
   {
     spk_chain_t c = {};
@@ -153,7 +171,7 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   const int F = m->n_atom_basis, NF = m->n_filters, L = m->n_interactions;
   // with saved filters the pair kernel runs and writes every entry of gr exactly once per interaction: the
   // first interaction of the backward assigns, the others accumulate -- no clearing pass
-  const bool gr_assign = L > 0 && (m->reserved & 1) && E > 0 && spk_cfconv_gsave_floats(g, rb, NF) > 0;
+  const bool gr_assign = L > 0 && (m->reserved & 1) && E > 0 && spk_cfconv_gsave_floats(g, rb, NF) > 0 && !schnet_filter_on(m, g, rb);
   if (E > 0) {
     SPK_CHECK_ARG(gr != nullptr, "%s: null gr", who);
     if (!gr_assign) { int _zr = spk_zero_async(gr, (size_t)E * 3 * sizeof(float), stream); if (_zr) return _zr; }
@@ -174,6 +192,13 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   auto pre3 = [&](int l) { return saved + (int64_t)l * N * (NF + F) + N * (int64_t)NF; };
   const int64_t gsz = (m->reserved & 1) ? spk_cfconv_gsave_floats(g, rb, NF) : 0;
   const float* gbase = saved + (int64_t)L * N * (NF + F);
+  // the compacted pair list written by the forward of this call
+  spk_graph_t gact = *g;
+  if (gsz > 0 && schnet_filter_on(m, g, rb)) {
+    const int32_t* ah = (const int32_t*)(gbase + (int64_t)L * gsz);
+    gact.half = ah; gact.n_half_dev = ah + g->n_half;
+  }
+  const bool filtered = gact.n_half_dev != nullptr;
   // prelude: gy_{L-1} = ((gx W4) * ssp'(pre3)) W3 ; clear gh of the first edge kernel
   {
     const spk_schnet_layer_t& P = m->layers[L - 1];
@@ -189,7 +214,7 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   for (int l = L - 1; l >= 0; --l) {
     const spk_schnet_layer_t& P = m->layers[l];
     float* gh = ghbuf[l & 1];
-    SPK_TRY(spk_cfconv_bwd_internal(g, rb, hbuf(l), gy, r_ij, P.fn_w1, P.fn_b1, P.fn_w2, P.fn_b2, NF, gh, gr, stream, true,
+    SPK_TRY(spk_cfconv_bwd_internal(filtered ? &gact : g, rb, hbuf(l), gy, r_ij, P.fn_w1, P.fn_b1, P.fn_w2, P.fn_b2, NF, gh, gr, stream, true,
                                     gsz > 0 ? gbase + l * gsz : nullptr, gr_assign && l == L - 1));
     if (l == 0 && !gx0) break;  // dL/dx0 not requested (eval path): nothing below feeds dL/dr_ij
     float* out = (l == 0) ? gx0 : gxb;

@@ -77,6 +77,24 @@ class EdgePlan:
     def graph(self):
         return ctypes.byref(self._graph)
 
+    # lists with pairs at or beyond the cutoff (MD skin lists): per-call compaction in the fused SchNet path
+    filter_pairs = None     # None: undecided, see decide_filter()
+
+    def set_filter(self, on: bool):
+        self.filter_pairs = bool(on)
+        self._graph.filter_pairs = 1 if on else 0
+
+    def decide_filter(self, r_ij, cutoff, threshold=0.05):
+        """Enable the per-call pair compaction if more than ``threshold`` of the pairs of the list are at or
+        beyond the cutoff right now (one D2H sync, once per list)."""
+        if self.filter_pairs is None:
+            if self.n_edges == 0 or not self.symmetric:
+                self.set_filter(False)
+            else:
+                d = torch.linalg.norm(r_ij.detach(), dim=1)
+                self.set_filter(float((d >= cutoff).float().mean()) > threshold)
+        return self.filter_pairs
+
 
 _MAX_GROUP_ATOMS = 128   # upper bound for the LDS accumulator of the group-local kernels
 

@@ -138,6 +138,8 @@ class SchNet(nn.Module):
 
         if not self.training and self._fusable():
             plan = ops.edge_plan(idx_i, idx_j, x.shape[0], r_ij)
+            if plan.filter_pairs is None:
+                plan.decide_filter(r_ij, self.cutoff_fn.cutoff_value())
             ms, keep = self._model_struct()
             rb_args = self.radial_basis.kernel_args(self.cutoff_fn.cutoff_value())
             # eval path: geometry gradients only (embedding / weights are not differentiated)

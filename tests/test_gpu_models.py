@@ -236,3 +236,33 @@ def test_force_call_golden_with_both_chain_tile_heights(dev, name, rows):
         _lib.lib().spk_chain_set_rows(0)
     assert rel_err(out["energy"], ref["energy"]) < TOL
     assert rel_err(out["forces"], ref["forces"]) < TOL
+
+
+@pytest.mark.parametrize("n_mol", [2, 64])
+def test_pair_filter_for_lists_with_skin(dev, n_mol):
+    """Lists that hold pairs beyond the cutoff (MD skin lists): the per-call compaction of the pair list
+    (spk_graph_t.filter_pairs) is switched on automatically, changes nothing in energies / forces, and
+    the result still equals the oracle (which evaluates every pair with f_c = 0 beyond the cutoff)."""
+    from schnetpack_amd import model as M, ops
+    rep_p = O.init_schnet_params(cutoff=3.5)
+    head_p = O.init_atomwise_params(128, seed=1)
+    model = M.build_model("schnet", 128, 3, 20, 3.5)
+    M.load_reference_params(model, rep_p, head_p)
+    model = model.to(dev).eval()
+    b = S.molecule_batch("aspirin", n_mol, cutoff=5.0, seed=4)      # list built with 5.0 A, model cutoff 3.5 A
+    res = {}
+    for force in (False, True, None):
+        inp = M.batch_to_inputs(b, dev)
+        r = O.pairwise_vectors(b["R"], b["idx_i"], b["idx_j"], b["offsets"]).to(dev)
+        plan = ops.edge_plan(inp["_idx_i"], inp["_idx_j"], b["Z"].shape[0], r)
+        if force is None:
+            assert plan.filter_pairs is None
+        else:
+            plan.set_filter(force)
+        out = model(inp)
+        assert plan.filter_pairs is (True if force is None else force)      # auto: > 5 % of the pairs are beyond 3.5 A
+        res[force] = (out["energy"].detach().cpu(), out["forces"].detach().cpu())
+    ref = O.energy_and_forces("schnet", rep_p, head_p, b, 3)
+    for k in res:
+        assert rel_err(res[k][0], ref["energy"]) < TOL and rel_err(res[k][1], ref["forces"]) < TOL, k
+    assert rel_err(res[True][1], res[False][1]) < 1e-6
