@@ -226,6 +226,19 @@ class NVESimulation:
             self._f.copy_(out["forces"].detach())
             self._e.copy_(out["energy"].detach())
 
+    def _prepare_plan(self):
+        """Edge plan (CSR, reverse map, skin-filter decision) of the current list without a full force call."""
+        from . import ops
+        P = self.P
+        R = self.state.positions[0]
+        ii, jj = self._lists[P.idx_i], self._lists[P.idx_j]
+        with torch.no_grad():
+            r = ops.pairwise_vectors(R.detach(), ii, jj, self._lists.get(P.offsets))
+            plan = ops.edge_plan(ii.long().contiguous(), jj.long().contiguous(), int(R.shape[0]), r)
+            rep = getattr(self.model, "representation", None)
+            if plan.filter_pairs is None and rep is not None and hasattr(rep, "cutoff_fn") and hasattr(rep.cutoff_fn, "cutoff_value"):
+                plan.decide_filter(r, rep.cutoff_fn.cutoff_value())
+
     def _step_body(self):
         thr = max(0.5 * self.nl.cutoff_shell - self.margin, 0.0)
         self.integrator.first_half_and_main_step(self.state, True, self.nl.previous_positions, thr, self.flag)
@@ -251,7 +264,7 @@ class NVESimulation:
             self.state.forces = self._f.unsqueeze(0)
             self.energy = self._e
         else:
-            self._force_eval()                                 # plan of the new list (one sync) outside any capture
+            self._prepare_plan()                               # plan of the new list (host syncs) outside any capture
         if self.use_graph:
             # capture records without executing: positions / momenta are untouched
             if self.n_captures == 0:
