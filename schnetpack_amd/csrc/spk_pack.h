@@ -39,6 +39,14 @@ static inline int spk_pack_all(const SpkPackTable& T, float* wpack, hipStream_t 
   return SPK_OK;
 }
 
+// packed image of the forward (transposed == 0) or input-gradient (== 1) layer of the weight `raw`, or NULL
+static inline const float* spk_packed_of(const SpkPackTable& T, const float* raw, int transposed) {
+  if (!T.base || spk_get_variant() == SPK_VARIANT_SIMPLE) return nullptr;
+  for (const SpkPackEntry& x : T.e)
+    if (x.raw == raw) return T.base + (transposed ? x.off_bwd : x.off_fwd);
+  return nullptr;
+}
+
 static inline void spk_apply_pack(spk_chain_t& c, const SpkPackTable& T) {
   if (!T.base || spk_get_variant() == SPK_VARIANT_SIMPLE) return;
   const float* repl[3] = {nullptr, nullptr, nullptr};

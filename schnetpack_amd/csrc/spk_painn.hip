@@ -493,6 +493,200 @@ __global__ void k_mix_ctx_bwd(const float* __restrict__ mix, const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused PaiNNMixing forward (representation/painn.py:99-117) for n_atom_basis = 128: channel mix of mu
+// ([3N, F] x [F, 2F]), norm, the two Dense layers of the intra-atomic context net and the update of (q, mu)
+// in ONE launch.  Everything is local to an atom, so a workgroup (4 waves) owns 16 atoms and walks the
+// stages with activations in LDS; weights come from the packed images (spk_pack_weight_f32) and the matrix
+// work runs on v_mfma_f32_16x16x4_f32.  Wave w owns the 32 features [32 w, 32 w + 32) in EVERY stage -- the
+// V and W halves of the channel mix for all three components, and the (q | mu | q mu) parts of the context
+// output -- so |V|, sum_x V W and the final update are register-local: the mixed tensor never comes back
+// from memory.  Replaces 4 launches (mix chain over 3N rows, mix_ctx, context chain, mix_update).
+// mix, preB and a are still written once: the backward reads them.
+// ------------------------------------------------------------------------------------------
+struct MixFwdArgs {
+  const float* q1; const float* mu1;
+  const float* wmix;            // packed, contraction F,  width 2F
+  const float* w1; const float* b1;   // packed, contraction 2F, width F
+  const float* w2; const float* b2;   // packed, contraction F,  width 3F
+  float eps;
+  int64_t N;
+  float* mix; float* preB; float* a; float* q_out; float* mu_out;
+};
+
+// A operands of pair p (32 output features) for u-steps [u0, u0 + 4) from a packed image with KB k-blocks.
+// p must be wave-uniform (callers pass readfirstlane'd wave indices): the address is then a SCALAR base plus one
+// per-lane byte offset shared by every load of the kernel (global_load ... v_off, s[base]) -- with per-lane 64-bit
+// addresses the compiler hoisted ~40 address pairs out of the tile loop and the kernel needed 340 registers.
+__device__ __forceinline__ void mix_load_a(f32x4 (&av)[2][4], const float* __restrict__ w, int KB, int p, int u0, int el, int h) {
+  const char* base = (const char*)w + (((int64_t)p * KB + 2 * u0) * 64) * 16;
+  const uint32_t off = (uint32_t)(((h >> 1) * 64 + (h & 1) * 32 + el) * 16);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    av[0][u] = *(const f32x4*)(base + off + u * 2048);
+    av[1][u] = *(const f32x4*)(base + off + u * 2048 + 256);
+  }
+}
+__device__ __forceinline__ void mix_mfma4(const f32x4 (&av)[2][4], const f32x4 (&bv)[4], f32x4& acc0, f32x4& acc1) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u].x, bv[u].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u].x, bv[u].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u].y, bv[u].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u].y, bv[u].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u].z, bv[u].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u].z, bv[u].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u].w, bv[u].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u].w, bv[u].w, acc1, 0, 0, 0);
+  }
+}
+// B operands of one 64-deep chunk c from an LDS row
+__device__ __forceinline__ void mix_load_b(f32x4 (&bv)[4], const float* __restrict__ brow, int c, int h) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) bv[u] = *(const f32x4*)(brow + 64 * c + 16 * u + 4 * h);
+}
+
+template <int F>
+__global__ __launch_bounds__(256, 2) void k_painn_mixing_fwd(MixFwdArgs a) {
+  static_assert(F == 128, "the weight stream below is written out for n_atom_basis = 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDA = F + 4, LDC = 2 * F + 4, LDH = F + 4;
+  constexpr int KB1 = F / 8, KB2 = 2 * F / 8;   // k-blocks of the packed images (contraction F resp. 2F)
+  float* sMu = smem;                 // [3][16][LDA]  mu entering the mixing
+  float* sCt = sMu + 48 * LDA;       // [16][LDC]     context input [q | |V|]
+  float* sHd = sCt + 16 * LDC;       // [16][LDH]     hidden layer
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 4, el = lane & 15;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t ntiles = (a.N + 15) / 16;
+  // The weights do not depend on the data: the 14 chunks (64 contraction indices of one 32-feature pair) a wave
+  // needs per tile are requested ONE CHUNK AHEAD through two register sets, across stage and tile boundaries.
+  f32x4 wa[2][4], wb[2][4];
+  if ((int64_t)blockIdx.x < ntiles) mix_load_a(wa, a.wmix, KB1, wv, 0, el, h);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t m0 = tile * 16;
+    const int64_t m = m0 + el;
+    const bool valid = m < a.N;
+    // ---- stage 0: mu tile (rows x-major: row = 16 x + atom) and q into LDS
+    constexpr int Q4 = F / 4;
+    for (int s = threadIdx.x; s < 48 * Q4; s += 256) {
+      const int row = s / Q4, c4 = s - row * Q4;
+      const int x = row >> 4, n = row & 15;
+      int64_t mm = m0 + n;
+      if (mm >= a.N) mm = a.N - 1;
+      *(f32x4*)(sMu + row * LDA + 4 * c4) = *(const f32x4*)(a.mu1 + (mm * 3 + x) * F + 4 * c4);
+    }
+    for (int s = threadIdx.x; s < 16 * Q4; s += 256) {
+      const int n = s / Q4, c4 = s - n * Q4;
+      int64_t mm = m0 + n;
+      if (mm >= a.N) mm = a.N - 1;
+      *(f32x4*)(sCt + n * LDC + 4 * c4) = *(const f32x4*)(a.q1 + mm * F + 4 * c4);
+    }
+    __syncthreads();
+    // ---- stage 1: channel mix; this wave: V = features [32 wv, +32), W = F + the same; the three components
+    //      x share every weight chunk (3 x 32 MFMAs per chunk)
+    f32x4 V[3][2], W[3][2];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { V[x][0] = z4; V[x][1] = z4; W[x][0] = z4; W[x][1] = z4; }
+    f32x4 bv[4];
+#define MIX_X3(WSET, C, ACC)                                                                      \
+    _Pragma("unroll") for (int x = 0; x < 3; ++x) {                                               \
+      mix_load_b(bv, sMu + (16 * x + el) * LDA, C, h);                                            \
+      mix_mfma4(WSET, bv, ACC[x][0], ACC[x][1]);                                                  \
+    }
+    mix_load_a(wb, a.wmix, KB1, wv, 4, el, h);             MIX_X3(wa, 0, V) __builtin_amdgcn_sched_barrier(0);
+    mix_load_a(wa, a.wmix, KB1, wv + F / 32, 0, el, h);    MIX_X3(wb, 1, V) __builtin_amdgcn_sched_barrier(0);
+    mix_load_a(wb, a.wmix, KB1, wv + F / 32, 4, el, h);    MIX_X3(wa, 0, W) __builtin_amdgcn_sched_barrier(0);
+    mix_load_a(wa, a.w1, KB2, wv, 0, el, h);               MIX_X3(wb, 1, W) __builtin_amdgcn_sched_barrier(0);
+#undef MIX_X3
+    f32x4 sVW[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int f0 = 32 * wv + 16 * k + 4 * h;
+      f32x4 n2 = {a.eps, a.eps, a.eps, a.eps};
+      sVW[k] = z4;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        n2 += V[x][k] * V[x][k];
+        sVW[k] += V[x][k] * W[x][k];
+        if (valid) {
+          *(f32x4*)(a.mix + (m * 3 + x) * 2 * F + f0) = V[x][k];
+          *(f32x4*)(a.mix + (m * 3 + x) * 2 * F + F + f0) = W[x][k];
+        }
+      }
+      f32x4 vn;
+      vn.x = sqrtf(n2.x); vn.y = sqrtf(n2.y); vn.z = sqrtf(n2.z); vn.w = sqrtf(n2.w);
+      *(f32x4*)(sCt + el * LDC + F + f0) = vn;
+    }
+    __syncthreads();
+    // ---- stage 2: hidden = silu([q | |V|] W1^T + b1), features [32 wv, +32), contraction 2F = 4 chunks
+    {
+      f32x4 acc0 = a.b1 ? *(const f32x4*)(a.b1 + 32 * wv + 4 * h) : z4;
+      f32x4 acc1 = a.b1 ? *(const f32x4*)(a.b1 + 32 * wv + 16 + 4 * h) : z4;
+      const float* brow = sCt + el * LDC;
+      mix_load_a(wb, a.w1, KB2, wv, 4, el, h);   mix_load_b(bv, brow, 0, h); mix_mfma4(wa, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wa, a.w1, KB2, wv, 8, el, h);   mix_load_b(bv, brow, 1, h); mix_mfma4(wb, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wb, a.w1, KB2, wv, 12, el, h);  mix_load_b(bv, brow, 2, h); mix_mfma4(wa, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wa, a.w2, KB1, wv, 0, el, h);   mix_load_b(bv, brow, 3, h); mix_mfma4(wb, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int f0 = 32 * wv + 16 * k + 4 * h;
+        f32x4 o = k ? acc1 : acc0;
+        if (valid) *(f32x4*)(a.preB + m * F + f0) = o;
+        o.x = o.x * spk_sigmoid(o.x); o.y = o.y * spk_sigmoid(o.y); o.z = o.z * spk_sigmoid(o.z); o.w = o.w * spk_sigmoid(o.w);
+        *(f32x4*)(sHd + el * LDH + f0) = o;
+      }
+    }
+    __syncthreads();
+    // ---- stage 3: a = hidden W2^T + b2, parts (q | mu | q mu) of features [32 wv, +32)
+    f32x4 A[3][2];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+      const int p = wv + part * (F / 32);
+      A[part][0] = a.b2 ? *(const f32x4*)(a.b2 + 32 * p + 4 * h) : z4;
+      A[part][1] = a.b2 ? *(const f32x4*)(a.b2 + 32 * p + 16 + 4 * h) : z4;
+    }
+    {
+      const float* brow = sHd + el * LDH;
+      const bool more = tile + gridDim.x < ntiles;
+      mix_load_a(wb, a.w2, KB1, wv, 4, el, h);                  mix_load_b(bv, brow, 0, h); mix_mfma4(wa, bv, A[0][0], A[0][1]); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wa, a.w2, KB1, wv + F / 32, 0, el, h);         mix_load_b(bv, brow, 1, h); mix_mfma4(wb, bv, A[0][0], A[0][1]); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wb, a.w2, KB1, wv + F / 32, 4, el, h);         mix_load_b(bv, brow, 0, h); mix_mfma4(wa, bv, A[1][0], A[1][1]); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wa, a.w2, KB1, wv + 2 * (F / 32), 0, el, h);   mix_load_b(bv, brow, 1, h); mix_mfma4(wb, bv, A[1][0], A[1][1]); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wb, a.w2, KB1, wv + 2 * (F / 32), 4, el, h);   mix_load_b(bv, brow, 0, h); mix_mfma4(wa, bv, A[2][0], A[2][1]); __builtin_amdgcn_sched_barrier(0);
+      if (more) mix_load_a(wa, a.wmix, KB1, wv, 0, el, h);      mix_load_b(bv, brow, 1, h); mix_mfma4(wb, bv, A[2][0], A[2][1]); __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- stage 4: q += a_q + a_qmu sum_x V W ;  mu += a_mu W      (painn.py:111-116); a is kept for the backward
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int f0 = 32 * wv + 16 * k + 4 * h;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) *(f32x4*)(a.a + m * 3 * F + part * F + f0) = A[part][k];
+        const f32x4 q = *(const f32x4*)(sCt + el * LDC + f0);
+        *(f32x4*)(a.q_out + m * F + f0) = q + A[0][k] + A[2][k] * sVW[k];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          const f32x4 mu = *(const f32x4*)(sMu + (16 * x + el) * LDA + f0);
+          *(f32x4*)(a.mu_out + (m * 3 + x) * F + f0) = mu + A[1][k] * W[x][k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int launch_painn_mixing_fwd(const MixFwdArgs& a, int F, hipStream_t stream) {
+  SPK_CHECK_ARG(F == 128, "fused PaiNN mixing: n_atom_basis must be 128");
+  const size_t lds = sizeof(float) * (48 * (size_t)(F + 4) + 16 * (size_t)(2 * F + 4) + 16 * (size_t)(F + 4));
+  const int64_t ntiles = (a.N + 15) / 16;
+  const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
+  SpkProfScope prof("painn_mixing_fwd", stream);
+  hipLaunchKernelGGL((k_painn_mixing_fwd<128>), dim3(grid), dim3(256), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 #define SPK_EW_GRID(n) dim3(spk_grid_for((n), 256, spk_num_cus() * 16)), dim3(256), 0, stream
 
 extern "C" int spk_painn_mix_ctx_f32(const float* q, const float* mix, int64_t N, int32_t F, float eps,
@@ -637,6 +831,17 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     SPK_TRY(spk_painn_message_fwd_internal(g, rb, c, qin, mu_in, r_ij, P.filt_w, P.filt_b, F, q1, mu1, stream));
+    float* mu_next = (l == L - 1) ? mu_out : (saved + (l + 1) * per + 4 * nf);
+    const float* pk_mix = spk_packed_of(ptab, P.mix_w, 0);
+    const float* pk_w1 = spk_packed_of(ptab, P.ictx_w1, 0);
+    const float* pk_w2 = spk_packed_of(ptab, P.ictx_w2, 0);
+    if (F == 128 && pk_mix && pk_w1 && pk_w2) {   // the whole PaiNNMixing block in one launch
+      MixFwdArgs ma;
+      ma.q1 = q1; ma.mu1 = mu1; ma.wmix = pk_mix; ma.w1 = pk_w1; ma.b1 = P.ictx_b1; ma.w2 = pk_w2; ma.b2 = P.ictx_b2;
+      ma.eps = m->epsilon; ma.N = N; ma.mix = mix; ma.preB = preB; ma.a = av; ma.q_out = q_out; ma.mu_out = mu_next;
+      SPK_TRY(launch_painn_mixing_fwd(ma, F, stream));
+      continue;
+    }
     {  // mix = mu1 W_mix^T over [3N, F]
       spk_chain_t ch = {};
       ch.n_layers = 1; ch.m = 3 * N; ch.in = mu1;
@@ -653,7 +858,6 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
       spk_apply_pack(ch, ptab);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
-    float* mu_next = (l == L - 1) ? mu_out : (saved + (l + 1) * per + 4 * nf);
     SPK_TRY(spk_painn_mix_update_f32(q1, mu1, mix, av, N, F, q_out, mu_next, stream));
   }
   return SPK_OK;
