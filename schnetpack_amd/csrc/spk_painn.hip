@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       float grx = 0.f, gry = 0.f, grz = 0.f;  // bwd: geometry gradient of this lane's edge
       // neighbour rows are requested one edge ahead (explicit double buffer): the row kernel is
       // bound by the latency of these dependent gathers, not by their bandwidth
-      constexpr bool PF = !BWD;  // the backward is register-bound (2 waves/SIMD matter more than the prefetch)
-      VT cjr[PF ? 2 : 1][3], mujr[PF ? 2 : 1][3], gqbr = MV::zero(), gmbr[3] = {MV::zero(), MV::zero(), MV::zero()};
+      constexpr bool PF = true;
+      VT cjr[PF ? 2 : 1][3], mujr[PF ? 2 : 1][3], gqbr[PF ? 2 : 1], gmbr[PF ? 2 : 1][3];
       auto load_rows = [&](int slot, int t) {
         const int64_t jj = __builtin_amdgcn_readlane(jl, t);
         const float* cj = a.c + jj * 3 * F + fo;
@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) { cjr[slot][p] = MV::load(cj + p * F); mujr[slot][p] = MV::load(muj + p * F); }
         if (BWD) {
-          gqbr = MV::load(a.gq_out + jj * F + fo);
+          gqbr[slot] = MV::load(a.gq_out + jj * F + fo);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) gmbr[p] = MV::load(a.gmu_out + jj * 3 * F + fo + p * F);
+          for (int p = 0; p < 3; ++p) gmbr[slot][p] = MV::load(a.gmu_out + jj * 3 * F + fo + p * F);
         }
       };
       // Pairs at or beyond the cutoff (skin / buffer pairs of MD lists) contribute exactly zero to every sum
@@ -186,9 +186,9 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
               const VT dFm = Pd[2] * fc + P[2] * dfc;
               const VT cq = cjr[par][0], cR = cjr[par][1], cm = cjr[par][2];
               const VT mb0 = mujr[par][0], mb1 = mujr[par][1], mb2 = mujr[par][2];
-              const VT gb0 = gmbr[0], gb1 = gmbr[1], gb2 = gmbr[2];
+              const VT gb0 = gmbr[par][0], gb1 = gmbr[par][1], gb2 = gmbr[par][2];
               // (1) transposed sums for the centre atom acting as neighbour of b (reverse edge)
-              accq += Fq * gqbr;
+              accq += Fq * gqbr[par];
               accR -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
               accv[0] += Fm * gb0; accv[1] += Fm * gb1; accv[2] += Fm * gb2;
               // (2) geometry gradient of edge (atom <- b)
