@@ -37,4 +37,5 @@ echo "== PMC traffic"
 bash $ROOT/scripts/gpu_pmc_traffic.sh $TAG schnet aspirin
 bash $ROOT/scripts/gpu_pmc_traffic.sh $TAG painn aspirin
 bash $ROOT/scripts/gpu_pmc_traffic.sh $TAG painn water
+bash $ROOT/scripts/gpu_pmc_traffic.sh $TAG schnet water
 du -sh $OUT
