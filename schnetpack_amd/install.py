@@ -23,8 +23,13 @@ def _set(mod, name, obj, log):
         log.append("%s.%s" % (mod.__name__, name))
 
 
-def install(spk=None, verbose=False):
-    """Patch ``spk`` (default: the imported ``schnetpack``).  Returns the list of patched names."""
+def install(spk=None, verbose=False, fused_head=False, neighbor_lists=False):
+    """Patch ``spk`` (default: the imported ``schnetpack``).  Returns the list of patched names.
+
+    ``fused_head=True`` also routes ``atomistic.Atomwise`` to the mirror whose default 2-layer energy head
+    runs as one fused kernel pair in eval mode (same constructor, ``state_dict`` keys and outputs).
+    ``neighbor_lists=True`` adds ``transform.HipNeighborList`` and replaces ``md.neighborlist_md.NeighborListMD``
+    by the device-side batched version (same constructor and ``get_neighbors``)."""
     from . import atomistic as A
     from . import nn as N
     from . import representation as R
@@ -60,6 +65,17 @@ def install(spk=None, verbose=False):
         if m is not None and getattr(m, "scatter_add", None) is not None:
             m.scatter_add = N.scatter_add
             log.append(m.__name__ + ".scatter_add")
+    if fused_head:
+        for mod in (getattr(spk, "atomistic", None), sub("atomistic.atomwise")):
+            _set(mod, "Atomwise", A.Atomwise, log)
+    if neighbor_lists:
+        from . import neighborlist as NL
+        for mod in (getattr(spk, "transform", None), sub("transform.neighborlist")):
+            if mod is not None:
+                setattr(mod, "HipNeighborList", NL.HipNeighborList)
+                log.append(mod.__name__ + ".HipNeighborList")
+        for mod in (sub("md"), sub("md.neighborlist_md")):
+            _set(mod, "NeighborListMD", NL.NeighborListMD, log)
     if verbose:
         print("schnetpack_amd.install: patched", ", ".join(log))
     return log

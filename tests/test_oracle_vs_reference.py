@@ -112,6 +112,15 @@ def test_install_hook_patches_reference_namespace_and_pickles_resolve_to_mirrors
         assert m.representation._fusable() and m.representation._eps() == pytest.approx(1e-8)
         ms, keep = None, None
         assert m.representation.filter_net.weight.shape == (768, 20)
+        # opt-in extras: fused energy head and the device neighbour lists
+        from schnetpack_amd import atomistic as A, neighborlist as NL
+        aw_mod = sys.modules["schnetpack.atomistic.atomwise"]
+        saved[("schnetpack.atomistic.atomwise", "Atomwise")] = aw_mod.Atomwise
+        log2 = inst.install(spk, fused_head=True, neighbor_lists=True)
+        assert aw_mod.Atomwise is A.Atomwise and "schnetpack.atomistic.atomwise.Atomwise" in log2
+        if ns.neighborlist is not None:
+            assert sys.modules["schnetpack.transform.neighborlist"].HipNeighborList is NL.HipNeighborList
+            delattr(sys.modules["schnetpack.transform.neighborlist"], "HipNeighborList")
     finally:
         for (mod, k), v in saved.items():
             setattr(sys.modules[mod], k, v)
