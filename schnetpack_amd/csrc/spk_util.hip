@@ -251,6 +251,25 @@ __global__ void k_segsum(const float* __restrict__ x, const int32_t* __restrict_
   }
 }
 
+// Few, long rows (e.g. per-atom energies of ONE 32 k-atom system summed into one molecule): one WAVEFRONT per
+// (outer, row, channel), lanes stride over the row's entries, wave reduction at the end -- the one-thread-per-row
+// kernel above would walk such a row serially.
+__global__ void k_segsum_wave(const float* __restrict__ x, const int32_t* __restrict__ rowptr, int64_t outer, int64_t E,
+                              int64_t inner, int64_t N, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t total = outer * N * inner;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < total; t += nwaves) {
+    const int64_t c = t % inner, k = (t / inner) % N, o = t / (inner * N);
+    const int32_t e0 = rowptr[k], e1 = rowptr[k + 1];
+    const float* xp = x + (o * E) * inner + c;
+    float acc = 0.f;
+    for (int32_t e = e0 + lane; e < e1; e += 64) acc += xp[(int64_t)e * inner];
+    acc = spk_wave_sum(acc);
+    if (lane == 0) y[(o * N + k) * inner + c] = acc;
+  }
+}
+
 __global__ void k_scatter_atomic(const float* __restrict__ x, const int64_t* __restrict__ idx,
                                  int64_t outer, int64_t E, int64_t inner, int64_t N,
                                  float* __restrict__ y) {
@@ -278,7 +297,9 @@ extern "C" int spk_scatter_add_f32(const float* x, const int64_t* idx, const int
   const int maxb = spk_num_cus() * 16;
   if (rowptr) {
     bool vec4 = (inner % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
-    if (vec4) {
+    if (outer * N * inner <= 4096 && E >= 256 * N) {   // few long rows
+      hipLaunchKernelGGL(k_segsum_wave, dim3(spk_grid_for(outer * N * inner * 64, 256, maxb)), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
+    } else if (vec4) {
       int grid = spk_grid_for(outer * N * (inner / 4), 256, maxb);
       SpkProfScope prof("scatter_add_segsum", stream);
       hipLaunchKernelGGL(k_segsum<4>, dim3(grid), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);

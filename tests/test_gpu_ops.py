@@ -703,3 +703,17 @@ def test_dense_chain_odd_shapes_use_layerwise_path(dev):
     _lib.check(_lib.lib().spk_dense_chain_f32(ctypes.byref(c), _lib.stream()))
     torch.cuda.synchronize()
     assert rel_err(out.cpu(), o) < TOL
+
+
+@pytest.mark.parametrize("inner,n_rows", [(1, 1), (1, 3), (3, 2), (8, 4)])
+def test_scatter_add_few_long_rows(dev, inner, n_rows):
+    """Per-atom values of a few large systems summed per system (Atomwise on one 32 k-atom box): the
+    wave-per-row kernel; rows of very different lengths, an empty row in the middle."""
+    from schnetpack_amd import ops
+    g = torch.Generator().manual_seed(inner + n_rows)
+    lens = [20000, 0, 7777, 301][:n_rows] if n_rows > 1 else [31944]
+    idx = torch.repeat_interleave(torch.arange(len(lens)), torch.tensor(lens))
+    x = torch.randn(idx.shape[0], inner, generator=g)
+    want = torch.zeros(len(lens), inner, dtype=torch.float64).index_add_(0, idx, x.double())
+    got = ops.scatter_add(x.to(dev), idx.to(dev), len(lens))
+    assert rel_err(got.cpu(), want) < 1e-5
