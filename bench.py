@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=15)
     ap.add_argument("--md-shell", type=float, default=1.0, help="--mode md: neighbour-list skin in Angstrom")
+    ap.add_argument("--beads", type=int, default=1, help="--mode md: ring-polymer MD with this many beads per GPU (folded into the batch)")
     ap.add_argument("--mode", default="eval", choices=["eval", "train", "md"],
                     help="eval: the headline force call (default).  train: configs[3] — one AdamW step of the force-matching "
                          "loss on --train-frames aspirin frames per GPU, gradients averaged with one flat all-reduce")
@@ -350,8 +351,9 @@ def md_main(args, rank, world, dev, dist, model):
     collective).  ns/day = steps/s x 0.5 fs x 86400e-6 per trajectory; random-init weights give an
     arbitrary but smooth potential, so energies are in model units: momenta start at zero and stay small."""
     from schnetpack_amd import model as M, synthetic as S
-    from schnetpack_amd.md import NVESimulation
-    n_int, dt_fs = 3, 0.5
+    from schnetpack_amd.md import NVESimulation, RPMDSimulation
+    n_int = 3
+    dt_fs = 0.5 if args.beads <= 1 else 0.2     # md.yaml resp. rpmd.yaml of the reference
     if args.workload == "water":
         batch = S.water_box(n_side=args.water_side, seed=rank)
         n_traj = 1
@@ -366,7 +368,10 @@ def md_main(args, rank, world, dev, dist, model):
         inp["_pbc"] = torch.tensor([True, True, True], device=dev)
     masses = torch.where(batch["Z"] == 1, 1.008, torch.where(batch["Z"] == 6, 12.011, 15.999)).to(dev)
     # model energy unit := eV-like; time step chosen so that atoms move ~1e-3 A per step
-    sim = NVESimulation(model, inp, masses, 0.02, cutoff=5.0, cutoff_shell=args.md_shell, use_graph=not args.no_graph)
+    if args.beads > 1:
+        sim = RPMDSimulation(model, inp, masses, 0.02, args.beads, cutoff=5.0, omega=3.0, cutoff_shell=args.md_shell, use_graph=not args.no_graph)
+    else:
+        sim = NVESimulation(model, inp, masses, 0.02, cutoff=5.0, cutoff_shell=args.md_shell, use_graph=not args.no_graph)
     sim.step(max(args.warmup, 2))
     e0 = sim.total_energy()
     b0 = sim.nl.n_builds
@@ -394,12 +399,12 @@ def md_main(args, rank, world, dev, dist, model):
     steps_s = args.steps / dt
     kind = "SchNet" if args.kind == "schnet" else "PaiNN"
     line = {
-        "metric": "MD ns/day per trajectory (NVE, 0.5 fs, %s, %s)" % ("MD17-aspirin x %d replicas" % n_traj if args.workload == "aspirin" else "32k-atom bulk-water PBC box", kind),
+        "metric": ("MD ns/day per trajectory (NVE, 0.5 fs, %s, %s)" if args.beads <= 1 else "RPMD ns/day per ring polymer (" + str(args.beads) + " beads, 0.2 fs, %s, %s)") % ("MD17-aspirin x %d replicas" % n_traj if args.workload == "aspirin" else "32k-atom bulk-water PBC box", kind),
         "value": round(steps_s * dt_fs * 86400e-6, 4), "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %s(128, 3, 20, 5.0) + Atomwise + Forces, velocity Verlet, device neighbour list with a %.1f A skin (%d pairs in the list), "
-                               "%d trajectories per GPU advanced together; N=%d atoms per GPU"
+        "config": {"workload": "%s: %s(128, 3, 20, 5.0) + Atomwise + Forces, " + ("velocity Verlet" if args.beads <= 1 else "ring-polymer integrator with %d beads folded into the batch" % args.beads) + ", device neighbour list with a %.1f A skin (%d pairs in the list), "
+                               "%d trajectories per GPU advanced together; N=%d atoms per bead and GPU"
                                % ("configs[1]-style MD17 aspirin batch" if args.workload == "aspirin" else "configs[4] per-GPU share (one bead / replica per GPU)",
                                   kind, args.md_shell, E_list, n_traj, N),
                    "trajectories_per_gpu": n_traj, "aggregate_ns_per_day": round(steps_s * dt_fs * 86400e-6 * n_traj * world, 3),

@@ -172,14 +172,16 @@ int spk_nbl_fill_f32(const float* R, const int64_t* idx_m, int64_t n_atoms, int6
  *                           [bead0, bead0+n_local) of this rank from ALL beads q_all, p_all
  *                           [n_beads, n_atoms, 3]; A [4, n_beads, n_beads] = C^T diag(P_ij) C for
  *                           (ij) = pp, pq, qp, qq (C: normal_model_transformation.py:38-68,
- *                           P: integrators.py:152-199); q_out, p_out [n_local, n_atoms, 3]. */
+ *                           P: integrators.py:152-199); q_out, p_out [n_local, n_atoms, 3].  Optional skin test as
+ *                           in spk_md_kick_drift_f32 (R_ref [n_local, n_atoms, 3] and flag int32 [2], or NULL). */
 int spk_md_half_step_f32(float* p, const float* F, float half_dt, int64_t n, void* stream);
 int spk_md_kick_drift_f32(float* R, float* p, const float* F, const float* masses, float dt,
                           int64_t n_atoms, const float* R_ref, float max_disp2, int32_t* flag,
                           void* stream);
 int spk_md_ring_polymer_step_f32(const float* q_all, const float* p_all, const float* masses,
                                  const float* A, int32_t n_beads, int64_t n_atoms, int32_t bead0,
-                                 int32_t n_local, float* q_out, float* p_out, void* stream);
+                                 int32_t n_local, float* q_out, float* p_out, const float* R_ref,
+                                 float max_disp2, int32_t* flag, void* stream);
 
 /* ------------------------------------------------------------------ atomistic/atomwise.py:69-88
  * The default output head, build_mlp(n_in, 1, n_layers=2) (nn/blocks.py:38-57) + sum over idx_m:

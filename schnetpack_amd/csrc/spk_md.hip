@@ -52,27 +52,47 @@ __global__ void k_md_kick_drift(float* __restrict__ R, float* __restrict__ p, co
 __global__ __launch_bounds__(256) void k_md_ring_polymer(const float* __restrict__ q_all, const float* __restrict__ p_all,
                                                          const float* __restrict__ masses, const float* __restrict__ A,
                                                          int B, int64_t n_atoms, int bead0, int n_local,
-                                                         float* __restrict__ q_out, float* __restrict__ p_out) {
+                                                         float* __restrict__ q_out, float* __restrict__ p_out,
+                                                         const float* __restrict__ R_ref, float max_disp2,
+                                                         int32_t* __restrict__ flag) {
   extern __shared__ float sA[];   // [4][B][B]
   for (int t = threadIdx.x; t < 4 * B * B; t += blockDim.x) sA[t] = A[t];
   __syncthreads();
   const int64_t n3 = 3 * n_atoms;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n3; t += (int64_t)gridDim.x * blockDim.x) {
-    const float m = masses[t / 3];
+  bool moved = false;
+  float step2 = 0.f;
+  // one thread per atom: the skin test needs the three components of its displacement
+  for (int64_t at = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; at < n_atoms; at += (int64_t)gridDim.x * blockDim.x) {
+    const float m = masses[at];
     const float im = 1.0f / m;
     for (int bl = 0; bl < n_local; ++bl) {
       const int b = bead0 + bl;
-      float pn = 0.f, qn = 0.f;
-      for (int n = 0; n < B; ++n) {
-        const float pv = p_all[(int64_t)n * n3 + t], qv = q_all[(int64_t)n * n3 + t];
-        pn = fmaf(sA[(0 * B + b) * B + n], pv, pn);
-        pn = fmaf(sA[(1 * B + b) * B + n] * m, qv, pn);
-        qn = fmaf(sA[(2 * B + b) * B + n] * im, pv, qn);
-        qn = fmaf(sA[(3 * B + b) * B + n], qv, qn);
+      float d2 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int64_t t = 3 * at + c;
+        float pn = 0.f, qn = 0.f;
+        for (int n = 0; n < B; ++n) {
+          const float pv = p_all[(int64_t)n * n3 + t], qv = q_all[(int64_t)n * n3 + t];
+          pn = fmaf(sA[(0 * B + b) * B + n], pv, pn);
+          pn = fmaf(sA[(1 * B + b) * B + n] * m, qv, pn);
+          qn = fmaf(sA[(2 * B + b) * B + n] * im, pv, qn);
+          qn = fmaf(sA[(3 * B + b) * B + n], qv, qn);
+        }
+        p_out[(int64_t)bl * n3 + t] = pn;
+        q_out[(int64_t)bl * n3 + t] = qn;
+        const float ds = qn - q_all[(int64_t)b * n3 + t];
+        s2 = fmaf(ds, ds, s2);
+        if (R_ref) { const float d = qn - R_ref[(int64_t)bl * n3 + t]; d2 = fmaf(d, d, d2); }
       }
-      p_out[(int64_t)bl * n3 + t] = pn;
-      q_out[(int64_t)bl * n3 + t] = qn;
+      step2 = fmaxf(step2, s2);
+      moved |= (R_ref != nullptr) && (d2 > max_disp2);
     }
+  }
+  if (flag) {
+    if (__any(moved)) { if ((threadIdx.x & 63) == 0) atomicOr((int*)flag, 1); }
+    step2 = spk_wave_max(step2);
+    if ((threadIdx.x & 63) == 0) atomicMax((int*)flag + 1, __float_as_int(step2));
   }
 }
 
@@ -102,7 +122,8 @@ extern "C" int spk_md_kick_drift_f32(float* R, float* p, const float* F, const f
 
 extern "C" int spk_md_ring_polymer_step_f32(const float* q_all, const float* p_all, const float* masses,
                                             const float* A, int32_t n_beads, int64_t n_atoms, int32_t bead0,
-                                            int32_t n_local, float* q_out, float* p_out, void* stream_) {
+                                            int32_t n_local, float* q_out, float* p_out, const float* R_ref,
+                                            float max_disp2, int32_t* flag, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPK_CHECK_ARG(n_beads >= 1 && n_beads <= 96 && n_atoms >= 0, "spk_md_ring_polymer_step_f32: bad sizes (n_beads <= 96)");
   SPK_CHECK_ARG(bead0 >= 0 && n_local >= 0 && bead0 + n_local <= n_beads, "spk_md_ring_polymer_step_f32: bead range outside [0, n_beads)");
@@ -110,8 +131,9 @@ extern "C" int spk_md_ring_polymer_step_f32(const float* q_all, const float* p_a
   SPK_CHECK_ARG(q_all && p_all && masses && A && q_out && p_out, "spk_md_ring_polymer_step_f32: null pointer");
   SPK_CHECK_ARG(q_out != q_all && p_out != p_all, "spk_md_ring_polymer_step_f32: outputs must not alias the inputs");
   const size_t lds = sizeof(float) * 4 * (size_t)n_beads * n_beads;
-  hipLaunchKernelGGL(k_md_ring_polymer, dim3(spk_grid_for(3 * n_atoms, 256, spk_num_cus() * 8)), dim3(256), lds, stream,
-                     q_all, p_all, masses, A, n_beads, n_atoms, bead0, n_local, q_out, p_out);
+  SPK_CHECK_ARG((R_ref == nullptr) || (flag != nullptr), "spk_md_ring_polymer_step_f32: R_ref needs a flag buffer");
+  hipLaunchKernelGGL(k_md_ring_polymer, dim3(spk_grid_for(n_atoms, 256, spk_num_cus() * 8)), dim3(256), lds, stream,
+                     q_all, p_all, masses, A, n_beads, n_atoms, bead0, n_local, q_out, p_out, R_ref, max_disp2, flag);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

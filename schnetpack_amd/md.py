@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import check, fptr, lib, stream
 
-__all__ = ["VelocityVerlet", "RingPolymer", "normal_mode_matrix", "ring_polymer_propagator", "ring_polymer_matrices",
+__all__ = ["VelocityVerlet", "RingPolymer", "NVESimulation", "RPMDSimulation", "MDState", "normal_mode_matrix", "ring_polymer_propagator", "ring_polymer_matrices",
            "KB_MD", "HBAR_MD", "FS_MD"]
 
 # reference MD internal units (kJ/mol, nm, Dalton): time unit = 1 ps (units.py:10-40)
@@ -156,14 +156,17 @@ class RingPolymer(VelocityVerlet):
         state.positions, state.momenta = q_new, p_new
 
 
-def _ring_polymer_hip(q_all, p_all, masses, A, bead0, n_local):
+def _ring_polymer_hip(q_all, p_all, masses, A, bead0, n_local, q_out=None, p_out=None, reference_positions=None,
+                      max_displacement=0.0, flag=None):
     B, n_atoms = int(q_all.shape[0]), int(q_all.shape[1])
     m = _flat_masses(masses, n_atoms).to(q_all.device)
-    q_out = torch.empty((n_local, n_atoms, 3), dtype=torch.float32, device=q_all.device)
-    p_out = torch.empty_like(q_out)
+    if q_out is None:
+        q_out = torch.empty((n_local, n_atoms, 3), dtype=torch.float32, device=q_all.device)
+        p_out = torch.empty_like(q_out)
     with torch.cuda.device(q_all.device):
         check(lib().spk_md_ring_polymer_step_f32(fptr(q_all), fptr(p_all), fptr(m), fptr(A), B, n_atoms, int(bead0), int(n_local),
-                                                 fptr(q_out), fptr(p_out), stream()))
+                                                 fptr(q_out), fptr(p_out), fptr(reference_positions), float(max_displacement) ** 2,
+                                                 _lib.iptr(flag, torch.int32) if flag is not None else None, stream()))
     return q_out, p_out
 
 
@@ -198,8 +201,8 @@ class NVESimulation:
         self.model = model.eval()
         self.inputs = dict(inputs)
         R = inputs[properties.R].detach().float().contiguous().clone()
-        self.state = MDState(R.unsqueeze(0), torch.zeros_like(R).unsqueeze(0), masses.float().reshape(1, -1, 1))
-        self.integrator = VelocityVerlet(time_step)
+        self._time_step = time_step
+        self._setup_state(R, masses)
         self.nl = NeighborListMD(cutoff, cutoff_shell, filter_buffer=False)
         self.use_graph = use_graph
         self.flag = torch.zeros(2, dtype=torch.int32, device=R.device)
@@ -212,11 +215,18 @@ class NVESimulation:
         self._lists = None
         self._rebuild()
 
+    def _setup_state(self, R, masses):
+        self.state = MDState(R.unsqueeze(0), torch.zeros_like(R).unsqueeze(0), masses.float().reshape(1, -1, 1))
+        self.integrator = VelocityVerlet(self._time_step)
+
     # -- pieces of one step ------------------------------------------------------------------
+    def _flatR(self):
+        return self.state.positions.view(-1, 3)
+
     def _call_inputs(self):
         call = dict(self.inputs)
         call.update(self._lists)
-        call[self.P.R] = self.state.positions[0]          # the state tensor itself: no copy per step
+        call[self.P.R] = self._flatR()                    # the state tensor itself: no copy per step
         call["_n_molecules"] = self.n_molecules
         return call
 
@@ -230,7 +240,7 @@ class NVESimulation:
         """Edge plan (CSR, reverse map, skin-filter decision) of the current list without a full force call."""
         from . import ops
         P = self.P
-        R = self.state.positions[0]
+        R = self._flatR()
         ii, jj = self._lists[P.idx_i], self._lists[P.idx_j]
         with torch.no_grad():
             r = ops.pairwise_vectors(R.detach(), ii, jj, self._lists.get(P.offsets))
@@ -251,7 +261,7 @@ class NVESimulation:
         P = self.P
         self.graph = None
         if new_list:
-            self.inputs[P.R] = self.state.positions[0]
+            self.inputs[P.R] = self._flatR()
             self.nl._list = None
             self._lists = self.nl.get_neighbors(self.inputs)
             self.flag.zero_()
@@ -261,7 +271,7 @@ class NVESimulation:
             out = self.model(self._call_inputs())              # first call: builds the plan, sizes the outputs
             self._f = out["forces"].detach().clone()
             self._e = out["energy"].detach().clone()
-            self.state.forces = self._f.unsqueeze(0)
+            self.state.forces = self._f.view(self.state.positions.shape)
             self.energy = self._e
         else:
             self._prepare_plan()                               # plan of the new list (host syncs) outside any capture
@@ -301,8 +311,68 @@ class NVESimulation:
                 self._rebuild(False)
 
     def kinetic_energy(self):
-        p, m = self.state.momenta[0], self.state.masses.reshape(-1, 1)
+        p, m = self.state.momenta, self.state.masses.reshape(1, -1, 1)
         return 0.5 * (p * p / m).sum()
 
     def total_energy(self):
         return float(self.energy.sum() + self.kinetic_energy())
+
+
+class RPMDSimulation(NVESimulation):
+    """Ring-polymer MD (md/integrators.py:113-229) of ``n_beads`` replicas of ONE batch of systems on one GPU: the
+    beads are folded into the batch dimension exactly as the reference does (md/calculators/base_calculator.py:
+    166-183), so one force call and one device neighbour list serve all beads.  One step is one graph replay:
+
+        kick (p += dt/2 F)  ->  ring-polymer main step (k_md_ring_polymer: bead mixing + skin test)  ->
+        force call of all beads  ->  kick
+
+    The conserved quantity is the ring-polymer Hamiltonian
+    ``sum_b [p_b^2 / 2m + V(q_b)] + sum_b 1/2 m omega^2 |q_b - q_{b+1}|^2`` (``total_energy``)."""
+
+    def __init__(self, model, inputs, masses, time_step, n_beads, cutoff, temperature=300.0, omega=None,
+                 cutoff_shell=1.0, use_graph=True):
+        from . import properties as P
+        self.n_beads = B = int(n_beads)
+        N = int(inputs[P.R].shape[0])
+        n_mol = int(inputs[P.n_atoms].shape[0])
+        rep = dict(inputs)
+        rep[P.R] = inputs[P.R].detach().float().repeat(B, 1)
+        rep[P.Z] = inputs[P.Z].repeat(B)
+        rep[P.idx_m] = (inputs[P.idx_m][None, :] + n_mol * torch.arange(B, device=inputs[P.idx_m].device)[:, None]).reshape(-1)
+        rep[P.n_atoms] = inputs[P.n_atoms].repeat(B)
+        if inputs.get(P.cell) is not None:
+            rep[P.cell] = inputs[P.cell].reshape(-1, 3, 3).repeat(B, 1, 1)
+        if inputs.get(P.pbc) is not None:
+            rep[P.pbc] = inputs[P.pbc].reshape(-1, 3).repeat(B, 1).reshape(-1)
+        self._rp = RingPolymer(time_step, B, temperature, omega=omega)
+        self._n1 = N
+        super().__init__(model, rep, masses, time_step, cutoff, cutoff_shell, use_graph)
+
+    def _setup_state(self, R, masses):
+        B, N = self.n_beads, self._n1
+        self.state = MDState(R.view(B, N, 3), torch.zeros(B, N, 3, device=R.device), masses.float().reshape(1, -1, 1))
+        self.integrator = self._rp
+        self._qt = torch.empty_like(self.state.positions)
+        self._pt = torch.empty_like(self.state.positions)
+        self._A = self._rp.A.to(R.device)
+
+    def _step_body(self):
+        thr = max(0.5 * self.nl.cutoff_shell - self.margin, 0.0)
+        st = self.state
+        self.integrator.half_step(st)
+        ref = self.nl.previous_positions
+        _ring_polymer_hip(st.positions, st.momenta, st.masses, self._A, 0, self.n_beads, self._qt, self._pt,
+                          ref, thr, self.flag)
+        with torch.no_grad():
+            st.positions.copy_(self._qt)
+            st.momenta.copy_(self._pt)
+        self._force_eval()
+        self.integrator.half_step(st)
+
+    def spring_energy(self):
+        q, m = self.state.positions, self.state.masses.reshape(1, -1, 1)
+        d = q - torch.roll(q, -1, 0)
+        return 0.5 * self._rp.omega ** 2 * (m * d * d).sum()
+
+    def total_energy(self):
+        return float(self.energy.sum() + self.kinetic_energy() + self.spring_energy())
