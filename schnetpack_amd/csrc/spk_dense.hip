@@ -153,19 +153,27 @@ static int dense_dispatch(const float* in, const float* pre_in, const float* w, 
                         aligned16(w) && aligned16(res) && aligned16(out) && aligned16(pre_out);
   SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || shape_ok, "%s: shape K=%d N=%d not supported by the MFMA kernel", who, KC, NW);
   SpkProfScope prof(trans ? "dense_bwd" : "dense_fwd", stream);
-  if (shape_ok && variant != SPK_VARIANT_SIMPLE) {
+  // MFMA instantiations: forward layers (activation epilogue, any weight layout) and input-gradient layers
+  // (k-major weights with an act' prologue); a layer that wants both goes to the simple kernel
+  const bool mfma_combo = (pro == SPK_ACT_NONE) || (act == SPK_ACT_NONE && trans);
+  if (shape_ok && mfma_combo && variant != SPK_VARIANT_SIMPLE) {
     const int64_t ntasks = ((M + 31) / 32) * (NW / 32);
     const int grid = spk_grid_for(ntasks, 4, spk_num_cus() * 8);
 #define SPK_DENSE_LAUNCH(A, T, P)                                                               \
   hipLaunchKernelGGL((k_dense_mfma<A, T, P>), dim3(grid), dim3(256), 0, stream, in, pre_in, w, b, \
                      res, out, pre_out, M, KC, NW, ntasks)
-    if (!trans) {
-      if (act == SPK_ACT_NONE) SPK_DENSE_LAUNCH(SPK_ACT_NONE, false, SPK_ACT_NONE);
-      else if (act == SPK_ACT_SSP) SPK_DENSE_LAUNCH(SPK_ACT_SSP, false, SPK_ACT_NONE);
-      else SPK_DENSE_LAUNCH(SPK_ACT_SILU, false, SPK_ACT_NONE);
+    if (pro == SPK_ACT_NONE) {
+      if (!trans) {
+        if (act == SPK_ACT_NONE) SPK_DENSE_LAUNCH(SPK_ACT_NONE, false, SPK_ACT_NONE);
+        else if (act == SPK_ACT_SSP) SPK_DENSE_LAUNCH(SPK_ACT_SSP, false, SPK_ACT_NONE);
+        else SPK_DENSE_LAUNCH(SPK_ACT_SILU, false, SPK_ACT_NONE);
+      } else {   // forward layer reading a transposed (k-major) copy of its weight
+        if (act == SPK_ACT_NONE) SPK_DENSE_LAUNCH(SPK_ACT_NONE, true, SPK_ACT_NONE);
+        else if (act == SPK_ACT_SSP) SPK_DENSE_LAUNCH(SPK_ACT_SSP, true, SPK_ACT_NONE);
+        else SPK_DENSE_LAUNCH(SPK_ACT_SILU, true, SPK_ACT_NONE);
+      }
     } else {
-      if (pro == SPK_ACT_NONE) SPK_DENSE_LAUNCH(SPK_ACT_NONE, true, SPK_ACT_NONE);
-      else if (pro == SPK_ACT_SSP) SPK_DENSE_LAUNCH(SPK_ACT_NONE, true, SPK_ACT_SSP);
+      if (pro == SPK_ACT_SSP) SPK_DENSE_LAUNCH(SPK_ACT_NONE, true, SPK_ACT_SSP);
       else SPK_DENSE_LAUNCH(SPK_ACT_NONE, true, SPK_ACT_SILU);
     }
 #undef SPK_DENSE_LAUNCH

@@ -266,3 +266,25 @@ def test_pair_filter_for_lists_with_skin(dev, n_mol):
     for k in res:
         assert rel_err(res[k][0], ref["energy"]) < TOL and rel_err(res[k][1], ref["forces"]) < TOL, k
     assert rel_err(res[True][1], res[False][1]) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+@pytest.mark.parametrize("F,n_rbf,radial,n_int", [(64, 20, "gaussian", 2), (96, 16, "bessel", 2), (128, 32, "gaussian", 1),
+                                                  (32, 8, "gaussian", 3), (256, 20, "gaussian", 1)])
+def test_force_call_other_model_sizes_match_oracle(dev, kind, F, n_rbf, radial, n_int):
+    """Model widths / bases away from the benchmark shape: every dispatch fallback on the way (nf = 64 MFMA
+    cfconv, the simple cfconv and message kernels for F = 96 / 32 / 256, one channel per lane for F = 64, chains
+    without packed weights, layer-wise Dense, the un-fused energy head for odd widths) against the oracle."""
+    from schnetpack_amd import model as M
+    rep_p = (O.init_schnet_params(F, n_int, n_rbf, 5.0, radial=radial) if kind == "schnet"
+             else O.init_painn_params(F, n_int, n_rbf, 5.0, radial=radial))
+    head_p = O.init_atomwise_params(F, seed=1)
+    model = M.build_model(kind, F, n_int, n_rbf, 5.0, radial)
+    M.load_reference_params(model, rep_p, head_p)
+    model = model.to(dev).eval()
+    b = S.molecule_batch("aspirin", 3, seed=21)
+    out = _force_call(model, b, dev)
+    ref = O.energy_and_forces(kind, rep_p, head_p, b, n_int, need_rep=True)
+    assert rel_err(out["energy"], ref["energy"]) < TOL
+    assert rel_err(out["forces"], ref["forces"]) < TOL
+    assert rel_err(out["scalar_representation"], ref["scalar_representation"]) < TOL

@@ -609,12 +609,15 @@ def test_pack_weight_layout(dev):
         assert torch.equal(P, A[32 * t + (lane & 31), 8 * ug + 4 * (lane >> 5) + v])
 
 
-@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("layout", ["rowmajor", "kmajor", "packed"])
 @pytest.mark.parametrize("m", [5376, 37])
-def test_dense_chain_forward_style(dev, variant, m, chain_rows, packed):
+def test_dense_chain_forward_style(dev, variant, m, chain_rows, layout):
     """f2out.0 (ssp, pre saved) -> f2out.1 (+ residual, stored) -> in2f (stored), buffer cleared.
-    packed: the fused kernels (16- and 32-row tiles); plain weights: layer by layer."""
+    packed: the fused kernels (16- and 32-row tiles); row-major [n_out, k] or k-major [k, n_out] (transposed
+    copy) weights: layer by layer -- the k-major form with an activation is what model widths without a packed
+    image use."""
     from schnetpack_amd import _lib
+    packed = layout == "packed"
     if packed and variant == "simple":
         pytest.skip("packed weights are an MFMA-kernel format")
     g = torch.Generator().manual_seed(41)
@@ -637,6 +640,9 @@ def test_dense_chain_forward_style(dev, variant, m, chain_rows, packed):
     if packed:
         w3d, w4d, wind = _pack(w3d, 0), _pack(w4d, 0), _pack(wind, 0)
         tr = 2
+    elif layout == "kmajor":
+        w3d, w4d, wind = w3d.t().contiguous(), w4d.t().contiguous(), wind.t().contiguous()
+        tr = 1
     c = _chain_struct(_lib, m, yd, [
         dict(w=w3d, b=b3d, pre_out=pre, k=F, n_out=F, act=_lib.SPK_ACT_SSP, trans=tr),
         dict(w=w4d, b=b4d, res=xd, out=xd, k=F, n_out=F, trans=tr),
