@@ -288,3 +288,62 @@ def test_force_call_other_model_sizes_match_oracle(dev, kind, F, n_rbf, radial, 
     assert rel_err(out["energy"], ref["energy"]) < TOL
     assert rel_err(out["forces"], ref["forces"]) < TOL
     assert rel_err(out["scalar_representation"], ref["scalar_representation"]) < TOL
+
+
+def _oracle_from_model(kind, model, b, n_int, shared_filters=False):
+    rep_p = {k: v.detach().cpu() for k, v in model.representation.state_dict().items()}
+    head_p = {k: v.detach().cpu() for k, v in model.output_modules[0].state_dict().items()}
+    return O.energy_and_forces(kind, rep_p, head_p, b, n_int, shared_filters=shared_filters, need_rep=True)
+
+
+@pytest.mark.parametrize("case", ["schnet_nf64", "schnet_nf256", "schnet_shared", "painn_shared_filters", "painn_shared_all",
+                                  "schnet_unsorted", "painn_unsorted", "schnet_lone_atoms", "painn_lone_atoms",
+                                  "schnet_no_grad", "painn_int32_idx"])
+def test_force_call_constructor_options_and_odd_inputs(dev, case):
+    """Constructor options of the reference classes (n_filters != n_atom_basis, shared_interactions,
+    shared_filters: schnet.py:99-145, painn.py:136-205) and inputs off the fast path (unsorted lists, atoms
+    without neighbours, int32 indices, energy-only calls) against the oracle evaluated with the SAME state_dict."""
+    from schnetpack_amd import model as M
+    torch.manual_seed(7)
+    kind = case.split("_")[0]
+    kw, shared_filters = {}, False
+    if case == "schnet_nf64":
+        kw = dict(n_filters=64)
+    elif case == "schnet_nf256":
+        kw = dict(n_filters=256)
+    elif case == "schnet_shared":
+        kw = dict(shared_interactions=True)
+    elif case == "painn_shared_filters":
+        kw, shared_filters = dict(shared_filters=True), True
+    elif case == "painn_shared_all":
+        kw, shared_filters = dict(shared_filters=True, shared_interactions=True), True
+    model = M.build_model(kind, 128, 3, 20, 5.0, "gaussian", **kw).to(dev).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.2, 0.2)       # biases are zero-initialised: make them count
+    b = S.molecule_batch("aspirin", 3, seed=33)
+    if case.endswith("unsorted"):
+        perm = torch.randperm(b["idx_i"].shape[0], generator=torch.Generator().manual_seed(1))
+        b = dict(b, idx_i=b["idx_i"][perm], idx_j=b["idx_j"][perm], offsets=b["offsets"][perm])
+    if case.endswith("lone_atoms"):
+        n_extra = 5
+        b = dict(b, R=torch.cat([b["R"], 100.0 + 30.0 * torch.arange(n_extra)[:, None] * torch.ones(n_extra, 3)]),
+                 Z=torch.cat([b["Z"], torch.tensor([1, 6, 8, 1, 6])]),
+                 idx_m=torch.cat([b["idx_m"], torch.full((n_extra,), 3)]), n_mol=4)
+    ref = _oracle_from_model(kind, model, b, 3, shared_filters)
+    inp = M.batch_to_inputs(b, dev)
+    if case == "painn_int32_idx":
+        inp["_idx_i"], inp["_idx_j"] = inp["_idx_i"].int(), inp["_idx_j"].int()
+    if case == "schnet_no_grad":
+        with torch.no_grad():
+            d = model.input_modules[0](inp)
+            d = model.representation(d)
+            d = model.output_modules[0](d)
+        assert rel_err(d["energy"].cpu(), ref["energy"]) < TOL
+        assert rel_err(d["scalar_representation"].cpu(), ref["scalar_representation"]) < TOL
+        return
+    out = model(inp)
+    assert rel_err(out["energy"].detach().cpu(), ref["energy"]) < TOL, case
+    assert rel_err(out["forces"].detach().cpu(), ref["forces"]) < TOL, case
+    assert rel_err(inp["scalar_representation"].detach().cpu(), ref["scalar_representation"]) < TOL, case
