@@ -72,14 +72,16 @@ def test_force_call_matches_reference_golden(dev, variant, case):
         assert rel_err(out["vector_representation"], ref["vector_representation"]) < TOL
 
 
+@pytest.mark.parametrize("F,n_rbf,radial", [(128, 20, "gaussian"), (64, 16, "bessel"), (96, 8, "gaussian")])
 @pytest.mark.parametrize("kind", ["schnet", "painn"])
-def test_training_mode_double_backward_matches_oracle(dev, kind):
+def test_training_mode_double_backward_matches_oracle(dev, kind, F, n_rbf, radial):
     """Force-matching loss: gradients w.r.t. the weights need the second order of the hot path
     (Forces(create_graph=True), atomistic/response.py:67)."""
     from schnetpack_amd import model as M
     b = S.molecule_batch("aspirin", 3, seed=12)
-    rep_p = O.init_schnet_params() if kind == "schnet" else O.init_painn_params()
-    head_p = O.init_atomwise_params(128, seed=1)
+    rep_p = (O.init_schnet_params(F, 3, n_rbf, 5.0, radial=radial) if kind == "schnet"
+             else O.init_painn_params(F, 3, n_rbf, 5.0, radial=radial))
+    head_p = O.init_atomwise_params(F, seed=1)
     g = torch.Generator().manual_seed(0)
     Et = torch.randn(3, generator=g)
     Ft = torch.randn(b["Z"].shape[0], 3, generator=g)
@@ -99,7 +101,7 @@ def test_training_mode_double_backward_matches_oracle(dev, kind):
     names = [k for k, v in rp.items() if torch.is_tensor(v) and v.requires_grad]
     go = dict(zip(names, torch.autograd.grad(loss_o, [rp[k] for k in names], allow_unused=True)))
 
-    model = M.build_model(kind)
+    model = M.build_model(kind, F, 3, n_rbf, 5.0, radial)
     M.load_reference_params(model, rep_p, head_p)
     model = model.to(dev).train()
     out = model(M.batch_to_inputs(b, dev))
