@@ -349,3 +349,31 @@ def test_force_call_constructor_options_and_odd_inputs(dev, case):
     assert rel_err(out["energy"].detach().cpu(), ref["energy"]) < TOL, case
     assert rel_err(out["forces"].detach().cpu(), ref["forces"]) < TOL, case
     assert rel_err(inp["scalar_representation"].detach().cpu(), ref["scalar_representation"]) < TOL, case
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_periodic_list_with_skin_matches_oracle(dev, kind):
+    """64 waters in a 12.4 A periodic box, neighbour list built by the device cell list with cutoff 5 + 1 A skin,
+    model cutoff 5 A: the skin pairs (33 % of the list) are dropped on the device (pair compaction / live-edge
+    mask); result equals the oracle, which evaluates every pair."""
+    from schnetpack_amd import model as M, neighborlist as NL, ops
+    wb = S.water_box(n_side=4, seed=3)
+    nl = NL.neighbor_list(wb["R"].to(dev), 6.0, None, wb["cell"].reshape(1, 3, 3).to(dev), torch.tensor([True, True, True], device=dev))
+    b = dict(wb, idx_i=nl["_idx_i"].cpu(), idx_j=nl["_idx_j"].cpu(), offsets=nl["_offsets"].cpu())
+    assert b["idx_i"].shape[0] > 1.3 * wb["idx_i"].shape[0]
+    rep_p = O.init_schnet_params() if kind == "schnet" else O.init_painn_params()
+    head_p = O.init_atomwise_params(128, seed=1)
+    model = M.build_model(kind)
+    M.load_reference_params(model, rep_p, head_p)
+    model = model.to(dev).eval()
+    inp = M.batch_to_inputs(b, dev)
+    out = model(inp)
+    ref = O.energy_and_forces(kind, rep_p, head_p, b, 3)
+    assert rel_err(out["energy"].detach().cpu(), ref["energy"]) < TOL
+    assert rel_err(out["forces"].detach().cpu(), ref["forces"]) < TOL
+    if kind == "schnet":
+        plan = list(ops._PLAN_CACHE.values())[-1]
+        assert plan.filter_pairs is True
+    # and the same forces as with the exact 5 A list
+    out5 = model(M.batch_to_inputs(wb, dev))
+    assert rel_err(out["forces"].detach().cpu(), out5["forces"].detach().cpu()) < 1e-5
