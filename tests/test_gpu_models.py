@@ -377,3 +377,36 @@ def test_periodic_list_with_skin_matches_oracle(dev, kind):
     # and the same forces as with the exact 5 A list
     out5 = model(M.batch_to_inputs(wb, dev))
     assert rel_err(out["forces"].detach().cpu(), out5["forces"].detach().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_dense_cluster_rows_longer_than_a_wavefront(dev, kind):
+    """260 atoms in a 10 A cube with a 5 A cutoff: ~70 neighbours per atom on average, up to ~125 -- CSR rows longer
+    than 64 edges (several passes of the PaiNN row kernel per atom, centre-atom runs spanning several 32-pair
+    tiles of the cfconv kernels) and a list built by the device cell list.  Forces against the oracle."""
+    from schnetpack_amd import model as M, neighborlist as NL
+    g = torch.Generator().manual_seed(17)
+    n = 300
+    R = torch.rand(n, 3, generator=g) * 10.0
+    # keep atoms apart (> 0.9 A) so that the random potential stays well conditioned
+    for _ in range(30):
+        d = torch.cdist(R, R) + 10 * torch.eye(n)
+        close = (d < 0.9).any(1)
+        if not bool(close.any()):
+            break
+        R[close] = torch.rand(int(close.sum()), 3, generator=g) * 10.0
+    Z = torch.tensor([1, 6, 7, 8])[torch.randint(0, 4, (n,), generator=g)]
+    nl = NL.neighbor_list(R.to(dev), 5.0)
+    b = {"Z": Z, "R": R, "idx_i": nl["_idx_i"].cpu(), "idx_j": nl["_idx_j"].cpu(), "offsets": nl["_offsets"].cpu(),
+         "idx_m": torch.zeros(n, dtype=torch.long), "n_mol": 1}
+    deg = torch.bincount(b["idx_i"], minlength=n)
+    assert int(deg.max()) > 100 and float(deg.float().mean()) > 64
+    rep_p = O.init_schnet_params() if kind == "schnet" else O.init_painn_params()
+    head_p = O.init_atomwise_params(128, seed=1)
+    model = M.build_model(kind)
+    M.load_reference_params(model, rep_p, head_p)
+    model = model.to(dev).eval()
+    out = model(M.batch_to_inputs(b, dev))
+    ref = O.energy_and_forces(kind, rep_p, head_p, b, 3)
+    assert rel_err(out["energy"].detach().cpu(), ref["energy"]) < TOL
+    assert rel_err(out["forces"].detach().cpu(), ref["forces"]) < 2 * TOL
