@@ -676,6 +676,123 @@ __global__ __launch_bounds__(256, 2) void k_painn_mixing_fwd(MixFwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused first half of the PaiNNMixing backward (n_atom_basis = 128): gradient of the update w.r.t. the context
+// output a and the mixed tensor (k_mix_update_bwd), the two transposed Dense layers of the intra-atomic context net,
+// and the gradient of the [q | |V|] context input (k_mix_ctx_bwd) in ONE launch -- 3 launches before.  Same
+// ownership as the forward: wave w owns features [32 w, 32 w + 32), so dL/dV, dL/dW, |V| stay in registers
+// between the stages.  Outputs: gq1 (dL/dq entering the mixing) and gmix (dL/d mixed tensor); the channel-mix
+// chain over 3N rows follows as before.
+// ------------------------------------------------------------------------------------------
+struct MixBwdArgs {
+  const float* gq; const float* gmu;      // dL/dq_out [N,F], dL/dmu_out [N,3,F]
+  const float* mix; const float* a; const float* preB;   // saved by the forward
+  const float* w2t;                       // packed input-gradient image of ictx_w2: contraction 3F, width F
+  const float* w1t;                       // packed input-gradient image of ictx_w1: contraction F,  width 2F
+  float eps;
+  int64_t N;
+  float* gq1; float* gmix;
+};
+
+template <int F>
+__global__ __launch_bounds__(256, 2) void k_painn_mixing_bwd(MixBwdArgs a) {
+  static_assert(F == 128, "the weight stream below is written out for n_atom_basis = 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDG = 3 * F + 4, LDT = F + 4;
+  constexpr int KB3 = 3 * F / 8, KB1 = F / 8;
+  float* sGa = smem;                 // [16][LDG]  dL/da  (q | mu | q mu)
+  float* sT = sGa + 16 * LDG;        // [16][LDT]  dL/d hidden pre-activation
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 4, el = lane & 15;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t ntiles = (a.N + 15) / 16;
+  f32x4 wa[2][4], wb[2][4], bv[4];
+  if ((int64_t)blockIdx.x < ntiles) mix_load_a(wa, a.w2t, KB3, wv, 0, el, h);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t m0 = tile * 16;
+    int64_t m = m0 + el;
+    const bool valid = m < a.N;
+    if (!valid) m = a.N - 1;
+    // ---- stage 0: gradient of the update (painn.py:111-116) for this wave's features
+    f32x4 V[3][2], gV[3][2], gq4[2], invn[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int f0 = 32 * wv + 16 * k + 4 * h;
+      const f32x4 amu = *(const f32x4*)(a.a + m * 3 * F + F + f0), aqm = *(const f32x4*)(a.a + m * 3 * F + 2 * F + f0);
+      gq4[k] = *(const f32x4*)(a.gq + m * F + f0);
+      f32x4 s = z4, gam = z4, n2 = {a.eps, a.eps, a.eps, a.eps};
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const f32x4 v = *(const f32x4*)(a.mix + (m * 3 + x) * 2 * F + f0);
+        const f32x4 w = *(const f32x4*)(a.mix + (m * 3 + x) * 2 * F + F + f0);
+        const f32x4 gm = *(const f32x4*)(a.gmu + (m * 3 + x) * F + f0);
+        V[x][k] = v;
+        s += v * w; gam += gm * w; n2 += v * v;
+        gV[x][k] = gq4[k] * aqm * w;                                   // dL/dV, the norm term follows in stage 2
+        if (valid) *(f32x4*)(a.gmix + (m * 3 + x) * 2 * F + F + f0) = gq4[k] * aqm * v + gm * amu;   // dL/dW
+      }
+      invn[k].x = 1.0f / sqrtf(n2.x); invn[k].y = 1.0f / sqrtf(n2.y); invn[k].z = 1.0f / sqrtf(n2.z); invn[k].w = 1.0f / sqrtf(n2.w);
+      *(f32x4*)(sGa + el * LDG + f0) = gq4[k];
+      *(f32x4*)(sGa + el * LDG + F + f0) = gam;
+      *(f32x4*)(sGa + el * LDG + 2 * F + f0) = gq4[k] * s;
+    }
+    __syncthreads();
+    // ---- stage 1: t = (ga W2) * silu'(preB), features [32 wv, +32), contraction 3F = 6 chunks
+    {
+      f32x4 acc0 = z4, acc1 = z4;
+      const float* brow = sGa + el * LDG;
+      mix_load_a(wb, a.w2t, KB3, wv, 4, el, h);   mix_load_b(bv, brow, 0, h); mix_mfma4(wa, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wa, a.w2t, KB3, wv, 8, el, h);   mix_load_b(bv, brow, 1, h); mix_mfma4(wb, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wb, a.w2t, KB3, wv, 12, el, h);  mix_load_b(bv, brow, 2, h); mix_mfma4(wa, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wa, a.w2t, KB3, wv, 16, el, h);  mix_load_b(bv, brow, 3, h); mix_mfma4(wb, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wb, a.w2t, KB3, wv, 20, el, h);  mix_load_b(bv, brow, 4, h); mix_mfma4(wa, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wa, a.w1t, KB1, wv, 0, el, h);   mix_load_b(bv, brow, 5, h); mix_mfma4(wb, bv, acc0, acc1); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int f0 = 32 * wv + 16 * k + 4 * h;
+        const f32x4 pb = *(const f32x4*)(a.preB + m * F + f0);
+        f32x4 o = k ? acc1 : acc0;
+        o.x *= spk_act_grad<SPK_ACT_SILU>(pb.x); o.y *= spk_act_grad<SPK_ACT_SILU>(pb.y);
+        o.z *= spk_act_grad<SPK_ACT_SILU>(pb.z); o.w *= spk_act_grad<SPK_ACT_SILU>(pb.w);
+        *(f32x4*)(sT + el * LDT + f0) = o;
+      }
+    }
+    __syncthreads();
+    // ---- stage 2: g_ctx = t W1: the q part feeds dL/dq, the |V| part the norm term of dL/dV
+    {
+      f32x4 q0 = z4, q1 = z4, n0 = z4, n1 = z4;
+      const float* brow = sT + el * LDT;
+      const bool more = tile + gridDim.x < ntiles;
+      mix_load_a(wb, a.w1t, KB1, wv, 4, el, h);              mix_load_b(bv, brow, 0, h); mix_mfma4(wa, bv, q0, q1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wa, a.w1t, KB1, wv + F / 32, 0, el, h);     mix_load_b(bv, brow, 1, h); mix_mfma4(wb, bv, q0, q1); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a(wb, a.w1t, KB1, wv + F / 32, 4, el, h);     mix_load_b(bv, brow, 0, h); mix_mfma4(wa, bv, n0, n1); __builtin_amdgcn_sched_barrier(0);
+      if (more) mix_load_a(wa, a.w2t, KB3, wv, 0, el, h);    mix_load_b(bv, brow, 1, h); mix_mfma4(wb, bv, n0, n1); __builtin_amdgcn_sched_barrier(0);
+      if (valid) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int f0 = 32 * wv + 16 * k + 4 * h;
+          *(f32x4*)(a.gq1 + m * F + f0) = gq4[k] + (k ? q1 : q0);
+          const f32x4 sc = (k ? n1 : n0) * invn[k];
+#pragma unroll
+          for (int x = 0; x < 3; ++x) *(f32x4*)(a.gmix + (m * 3 + x) * 2 * F + f0) = gV[x][k] + sc * V[x][k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int launch_painn_mixing_bwd(const MixBwdArgs& a, int F, hipStream_t stream) {
+  SPK_CHECK_ARG(F == 128, "fused PaiNN mixing backward: n_atom_basis must be 128");
+  const size_t lds = sizeof(float) * (16 * (size_t)(3 * F + 4) + 16 * (size_t)(F + 4));
+  const int64_t ntiles = (a.N + 15) / 16;
+  const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
+  SpkProfScope prof("painn_mixing_bwd", stream);
+  hipLaunchKernelGGL((k_painn_mixing_bwd<128>), dim3(grid), dim3(256), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 static int launch_painn_mixing_fwd(const MixFwdArgs& a, int F, hipStream_t stream) {
   SPK_CHECK_ARG(F == 128, "fused PaiNN mixing: n_atom_basis must be 128");
   const size_t lds = sizeof(float) * (48 * (size_t)(F + 4) + 16 * (size_t)(2 * F + 4) + 16 * (size_t)(F + 4));
@@ -902,6 +1019,15 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
     const float* preA = S; const float* c = S + nf; const float* mu_in = S + 4 * nf; const float* mix = S + 7 * nf;
     const float* preB = S + 13 * nf; const float* av = S + 14 * nf;
     // ---- mixing backward
+    const float* pk_w2t = spk_packed_of(ptab, P.ictx_w2, 1);
+    const float* pk_w1t = spk_packed_of(ptab, P.ictx_w1, 1);
+    const bool fused_mix = (F == 128 && pk_w2t && pk_w1t);
+    if (fused_mix) {   // update gradient + context net (transposed) + norm term in one launch
+      MixBwdArgs mb;
+      mb.gq = gq; mb.gmu = gmu; mb.mix = mix; mb.a = av; mb.preB = preB; mb.w2t = pk_w2t; mb.w1t = pk_w1t;
+      mb.eps = m->epsilon; mb.N = N; mb.gq1 = gq1; mb.gmix = gmix;
+      SPK_TRY(launch_painn_mixing_bwd(mb, F, stream));
+    } else {
     SPK_TRY(spk_painn_mix_update_bwd_f32(nullptr, mix, av, gq, gmu, N, F, ga, gmix, stream));
     {  // g_ctx = ((ga W_d) * silu'(preB)) W_c
       spk_chain_t ch = {};
@@ -912,6 +1038,7 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     SPK_TRY(spk_painn_mix_ctx_bwd_f32(mix, gctx, gq, N, F, m->epsilon, gmix, gq1, stream));
+    }
     {  // mu1 -> mix is a bias-free Dense over [3N, F]; residual path adds gmu
       spk_chain_t ch = {};
       ch.n_layers = 1; ch.m = 3 * N; ch.in = gmix;
