@@ -403,10 +403,11 @@ def md_main(args, rank, world, dev, dist, model):
         "value": round(steps_s * dt_fs * 86400e-6, 4), "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %s(128, 3, 20, 5.0) + Atomwise + Forces, " + ("velocity Verlet" if args.beads <= 1 else "ring-polymer integrator with %d beads folded into the batch" % args.beads) + ", device neighbour list with a %.1f A skin (%d pairs in the list), "
-                               "%d trajectories per GPU advanced together; N=%d atoms per bead and GPU"
-                               % ("configs[1]-style MD17 aspirin batch" if args.workload == "aspirin" else "configs[4] per-GPU share (one bead / replica per GPU)",
-                                  kind, args.md_shell, E_list, n_traj, N),
+        "config": {"workload": ("%s: %s(128, 3, 20, 5.0) + Atomwise + Forces, %s, device neighbour list with a %.1f A skin (%d pairs in the list), "
+                                "%d trajectories per GPU advanced together; N=%d atoms per bead and GPU"
+                                % ("configs[1]-style MD17 aspirin batch" if args.workload == "aspirin" else "configs[4] per-GPU share (one bead / replica per GPU)",
+                                   kind, "velocity Verlet" if args.beads <= 1 else "ring-polymer integrator with %d beads folded into the batch" % args.beads,
+                                   args.md_shell, E_list, n_traj, N)),
                    "trajectories_per_gpu": n_traj, "aggregate_ns_per_day": round(steps_s * dt_fs * 86400e-6 * n_traj * world, 3),
                    "M_edge_messages_per_s_in_list": round(E_list * n_int * steps_s * world / 1e6, 1),
                    "neighbor_list_rebuilds_in_timed_region": sim.nl.n_builds - b0,
