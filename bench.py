@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the force call in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=15)
-    ap.add_argument("--md-shell", type=float, default=1.0, help="--mode md: neighbour-list skin in Angstrom")
+    ap.add_argument("--md-shell", type=float, default=2.0, help="--mode md: neighbour-list skin in Angstrom")
     ap.add_argument("--beads", type=int, default=1, help="--mode md: ring-polymer MD with this many beads per GPU (folded into the batch)")
     ap.add_argument("--mode", default="eval", choices=["eval", "train", "md"],
                     help="eval: the headline force call (default).  train: configs[3] — one AdamW step of the force-matching "

@@ -1050,16 +1050,18 @@ __global__ void k_pair_live(const int32_t* __restrict__ half, const float* __res
   }
 }
 static size_t active_tmp_bytes(int64_t n_half) {
-  // the size query walks rocPRIM's device / config detection: ask once per size
-  static int64_t cached_n = -1;
-  static size_t cached_bytes = 0;
-  if (n_half != cached_n) {
+  // The size query walks rocPRIM's device / config detection (tens of ms): ask once per power-of-two bucket
+  // and use the bucket's (larger) requirement for every size inside it.
+  static size_t cached[64] = {0};
+  int b = 0;
+  while (((int64_t)1 << b) < n_half && b < 62) ++b;
+  if (cached[b] == 0) {
     size_t bytes = 0;
     int32_t* p = nullptr; unsigned char* f = nullptr;
-    (void)rocprim::select(nullptr, bytes, p, f, p, p, (size_t)(n_half > 0 ? n_half : 1), (hipStream_t)0);
-    cached_n = n_half; cached_bytes = bytes;
+    (void)rocprim::select(nullptr, bytes, p, f, p, p, (size_t)1 << b, (hipStream_t)0);
+    cached[b] = bytes > 0 ? bytes : 1;
   }
-  return cached_bytes;
+  return cached[b];
 }
 // workspace floats: active list [n_half] + count [4] + flags [n_half bytes] + rocprim temporary
 int64_t spk_active_pairs_floats(int64_t n_half) {

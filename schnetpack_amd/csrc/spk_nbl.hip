@@ -51,15 +51,17 @@ struct NblWs {     // carve-up of the caller's workspace
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static size_t nbl_sort_tmp_bytes(int64_t n) {
-  static int64_t cached_n = -1;   // the size query walks rocPRIM's device / config detection: ask once per size
-  static size_t cached_bytes = 0;
-  if (n != cached_n) {
+  // the size query walks rocPRIM's device / config detection (tens of ms): once per power-of-two bucket
+  static size_t cached[64] = {0};
+  int b = 0;
+  while (((int64_t)1 << b) < n && b < 62) ++b;
+  if (cached[b] == 0) {
     size_t bytes = 0;
     int* k = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
-    cached_n = n; cached_bytes = bytes;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)1 << b, 0, 32, (hipStream_t)0);
+    cached[b] = bytes > 0 ? bytes : 1;
   }
-  return cached_bytes;
+  return cached[b];
 }
 
 static size_t nbl_carve(NblWs& w, void* base, int64_t N, int64_t n_sys) {
