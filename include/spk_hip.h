@@ -429,6 +429,45 @@ int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g, const spk
                            const float* saved, float* scratch, float* gr, float* gq0,
                            void* stream);
 
+/* ------------------------------------------------------------------ deployment runtime
+ * Torch-free replacement of the deployed-model path: src/scripts/spkdeploy:16-40 writes a TorchScript archive
+ * (+ "cutoff" metadata), interfaces/lammps/pair_schnetpack.cpp:128 loads it with torch::jit::load and :328 calls
+ * model.forward on a dict of _positions / _atomic_numbers / _idx_i / _idx_j / _offsets / _idx_m / _cell and
+ * reads "energy" and "forces" back (:330-350).  Here schnetpack_amd.deploy.export_potential() writes a flat
+ * weight file (header + named fp32 tensors, little endian) and the functions below load it and run the same
+ * model: PairwiseDistances -> SchNet / PaiNN -> Atomwise(energy, sum) -> Forces -> AddOffsets(mean / atomref).
+ * A handle owns its device memory (weights, packed weight images, grow-only work buffers) and one stream; calls
+ * on one handle must not overlap.  ALL pointers of this section are HOST pointers.
+ *
+ * spk_potential_load / _from_memory   parse + upload; *out receives the handle.
+ * spk_potential_info                  host_info[0] kind (0 SchNet, 1 PaiNN), [1] n_atom_basis, [2] n_interactions,
+ *                                     [3] n_rbf, [4] radial kind, [5] n_filters, [6] head hidden width,
+ *                                     [7] embedding rows; *host_cutoff = the "cutoff" metadata of spkdeploy:36.
+ * spk_potential_compute               explicit neighbour list, as pair_schnetpack.cpp:196-283 assembles it:
+ *     z [n_atoms] int64, R [n_atoms,3] fp32, idx_i / idx_j [n_edges] int64 in ANY order (the LAMMPS list is
+ *     ordered by local index, not by tag; the runtime stable-sorts by idx_i on the host when needed),
+ *     offsets [n_edges,3] or NULL, idx_m [n_atoms] ascending or NULL (one system, n_mol = 1).
+ *     energy [n_mol] and forces [n_atoms,3] are written.
+ * spk_potential_compute_cell          the runtime builds the list itself on the device (spk_nbl_*): cell [n_mol,3,3]
+ *     row vectors or NULL, pbc [n_mol,3] bytes or NULL; skin > 0 keeps a (cutoff + skin) list until an atom
+ *     has moved more than skin / 2 since the list was built (md/neighborlist_md.py:80-90) or n_atoms / cell /
+ *     idx_m change.  host_stats (may be NULL): [0] pairs in the list, [1] 1 if the list was rebuilt by this call.
+ * Errors: SPK_ERR_ARG (bad file / unsupported head or shape / atomic number outside the embedding),
+ * SPK_ERR_INDEX (neighbour index out of range), SPK_ERR_HIP. */
+typedef struct spk_potential spk_potential_t;
+int spk_potential_load(const char* path, spk_potential_t** out);
+int spk_potential_from_memory(const void* host_blob, int64_t n_bytes, spk_potential_t** out);
+void spk_potential_free(spk_potential_t* p);
+int spk_potential_info(const spk_potential_t* p, int32_t* host_info, float* host_cutoff);
+int spk_potential_compute(spk_potential_t* p, int64_t n_atoms, const int64_t* host_z, const float* host_R,
+                          int64_t n_edges, const int64_t* host_idx_i, const int64_t* host_idx_j,
+                          const float* host_offsets, int64_t n_mol, const int64_t* host_idx_m,
+                          float* host_energy, float* host_forces);
+int spk_potential_compute_cell(spk_potential_t* p, int64_t n_atoms, const int64_t* host_z, const float* host_R,
+                               int64_t n_mol, const int64_t* host_idx_m, const float* host_cell,
+                               const uint8_t* host_pbc, float skin, float* host_energy, float* host_forces,
+                               int64_t* host_stats);
+
 /* ------------------------------------------------------------------ small helpers
  * out[n, :] = table[z[n], :]  (nn.Embedding lookup, schnet.py:161 / painn.py:239) */
 int spk_embedding_f32(const float* table, const int64_t* z, int64_t n, int32_t F, float* out,

@@ -252,12 +252,84 @@ def ring_polymer_goldens():
     print("wrote md_ring_polymer.npz", sorted(k for k in arrs if k.startswith("b8_")))
 
 
+def deploy_goldens(ns):
+    """Deployed-model goldens: the shipped PaiNN models processed like
+    src/scripts/spkdeploy:16-31 does (dtype casts dropped, AddOffsets.mean -> float32, torch.jit.script), fed
+    the input dict interfaces/lammps/pair_schnetpack.cpp:285-301 builds (one system, idx_m = 0, edges in
+    neighbour-list order of the LOCAL atom index -- here a random permutation -- and offsets = image shifts).
+    Two geometries per model: the free molecule and the same molecule in a small periodic cell (images inside
+    the cutoff).  Weights + AddOffsets statistics are stored so that the GPU box can rebuild the model."""
+    sys.modules["ase.data"].atomic_masses = np.ones(119)
+    casts = ("CastTo64", "CastTo32")
+    models = {
+        "aspirin": os.path.join(refshim.REF_SRC, "..", "interfaces", "lammps", "examples", "aspirin", "best_model"),
+        "ethanol": os.path.join(refshim.REF_SRC, "..", "tests", "testdata", "md_ethanol.model"),
+    }
+    arrs = {}
+    g = torch.Generator().manual_seed(21)
+    for name, path in models.items():
+        m = torch.load(path, map_location="cpu", weights_only=False)
+        if not hasattr(m.representation, "electronic_embeddings"):    # utils/compatibility.py:36-39 (2.0.4 pickles)
+            m.representation.electronic_embeddings = []
+        m.eval()
+        keep = torch.nn.ModuleList()
+        for pp in m.postprocessors:                 # spkdeploy:19-29
+            if type(pp).__name__ in casts:
+                continue
+            if type(pp).__name__ == "AddOffsets":
+                pp.mean = pp.mean.float()
+            keep.append(pp)
+        m.postprocessors = keep
+        try:
+            jm = torch.jit.script(m)
+            scripted = True
+        except Exception as e:  # pragma: no cover - the eager module computes the same function
+            print("  torch.jit.script failed (%s); using the eager module" % type(e).__name__)
+            jm, scripted = m, False
+        cutoff = float(m.representation.cutoff.item())
+        b = S.molecule_batch(name, 1, seed=5, jitter=0.02, cutoff=cutoff)
+        Z, R0 = b["Z"], b["R"].float()
+        n = int(Z.shape[0])
+        cell = torch.tensor([[7.5, 0.0, 0.0], [0.6, 8.0, 0.0], [0.0, -0.4, 7.0]])
+        for tag, pbc in (("free", torch.zeros(3, dtype=torch.bool)), ("pbc", torch.ones(3, dtype=torch.bool))):
+            R = R0 - R0.min(0).values + 0.3 if tag == "pbc" else R0
+            nl = ns.neighborlist.TorchNeighborList(cutoff)
+            i, j, off = nl._build_neighbor_list(Z, R, cell if tag == "pbc" else torch.zeros(3, 3), pbc, cutoff)
+            perm = torch.randperm(int(i.shape[0]), generator=g)
+            i, j, off = i[perm].contiguous(), j[perm].contiguous(), off[perm].float().contiguous()
+            inp = {"_positions": R.clone(), "_idx_i": i, "_idx_j": j, "_idx_m": torch.zeros(n, dtype=torch.long), "_offsets": off,
+                   "_cell": (cell if tag == "pbc" else torch.zeros(3, 3)), "_n_atoms": torch.tensor([n]), "_atomic_numbers": Z}
+            out = jm(inp)
+            t = "%s_%s_" % (name, tag)
+            arrs.update({t + "Z": Z.numpy(), t + "R": R.numpy(), t + "idx_i": i.numpy(), t + "idx_j": j.numpy(), t + "offsets": off.numpy(),
+                         t + "cell": inp["_cell"].numpy(), t + "pbc": pbc.numpy(), t + "energy": out["energy"].detach().float().numpy(),
+                         t + "forces": out["forces"].detach().float().numpy()})
+            print("  deploy case", t, "edges", int(i.shape[0]), "E", float(out["energy"]), "scripted", scripted)
+        rep = m.representation
+        arrs[name + "_cutoff"] = cutoff
+        arrs[name + "_n_interactions"] = int(rep.n_interactions)
+        arrs[name + "_mean"] = float(keep[0].mean) if len(keep) else 0.0
+        arrs[name + "_scripted"] = scripted
+        if name == "aspirin":       # these weights are already in painn_aspirin_pretrained.npz (w_rep.* / w_head.*)
+            arrs[name + "_weights_checksum"] = checksum(rep.state_dict()) + checksum(m.output_modules[0].state_dict())
+            continue
+        for k, v in rep.state_dict().items():
+            arrs[name + "_w_rep." + k] = v.numpy()
+        for k, v in m.output_modules[0].state_dict().items():
+            arrs[name + "_w_head." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "deploy_painn.npz"), **arrs)
+    print("wrote deploy_painn.npz")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "md":
         ring_polymer_goldens()
     elif len(sys.argv) > 1 and sys.argv[1] == "nbl":
         neighbor_list_goldens(refshim.load())
+    elif len(sys.argv) > 1 and sys.argv[1] == "deploy":
+        deploy_goldens(refshim.load())
     else:
         main()
         neighbor_list_goldens(refshim.load())
         ring_polymer_goldens()
+        deploy_goldens(refshim.load())

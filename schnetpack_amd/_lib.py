@@ -129,6 +129,17 @@ _PROTOS = {
     "spk_painn_backward_f32": (ctypes.c_int, [P(PainnT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "spk_embedding_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_f, c_f]),
     "spk_add_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_f, c_f]),
+    # deployment runtime (host pointers throughout)
+    "spk_potential_load": (ctypes.c_int, [ctypes.c_char_p, P(ctypes.c_void_p)]),
+    "spk_potential_from_memory": (ctypes.c_int, [ctypes.c_char_p, c_i64, P(ctypes.c_void_p)]),
+    "spk_potential_free": (None, [ctypes.c_void_p]),
+    "spk_potential_info": (ctypes.c_int, [ctypes.c_void_p, P(c_i32), P(ctypes.c_float)]),
+    "spk_potential_compute": (ctypes.c_int, [ctypes.c_void_p, c_i64, P(ctypes.c_int64), P(ctypes.c_float), c_i64, P(ctypes.c_int64),
+                                             P(ctypes.c_int64), P(ctypes.c_float), c_i64, P(ctypes.c_int64), P(ctypes.c_float),
+                                             P(ctypes.c_float)]),
+    "spk_potential_compute_cell": (ctypes.c_int, [ctypes.c_void_p, c_i64, P(ctypes.c_int64), P(ctypes.c_float), c_i64, P(ctypes.c_int64),
+                                                  P(ctypes.c_float), P(ctypes.c_uint8), ctypes.c_float, P(ctypes.c_float),
+                                                  P(ctypes.c_float), P(ctypes.c_int64)]),
 }
 
 _lib = None

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_painn.hip", "spk_nbl.hip", "spk_md.hip"]
+SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_painn.hip", "spk_nbl.hip", "spk_md.hip", "spk_potential.hip"]
 HEADERS = ["spk_common.h", os.path.join("..", "..", "include", "spk_hip.h")]
 LIB = os.path.join(HERE, "libspk_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
@@ -60,7 +60,25 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_native_example(force, verbose)
     return LIB
+
+
+RUN_SRC = os.path.join(HERE, "..", "..", "examples", "native", "spk_run.c")
+RUN_BIN = os.path.join(HERE, "spk_run")
+
+
+def build_native_example(force=False, verbose=True):
+    """Plain-C program on the deployment runtime (examples/native/spk_run.c): gcc, links libspk_hip.so only."""
+    if not os.path.exists(RUN_SRC):
+        return None
+    if force or _stale(RUN_BIN, [RUN_SRC, LIB, os.path.join(HERE, HEADERS[1])]):
+        cmd = [os.environ.get("CC", "gcc"), "-O2", "-Wall", "-std=c11", "-D_POSIX_C_SOURCE=199309L", RUN_SRC, "-o", RUN_BIN,
+               "-L" + HERE, "-lspk_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return RUN_BIN
 
 
 if __name__ == "__main__":

@@ -112,6 +112,15 @@ def test_install_hook_patches_reference_namespace_and_pickles_resolve_to_mirrors
         assert m.representation._fusable() and m.representation._eps() == pytest.approx(1e-8)
         ms, keep = None, None
         assert m.representation.filter_net.weight.shape == (768, 20)
+        # the unpickled reference model (reference NeuralNetworkPotential + Atomwise + Forces + AddOffsets around the
+        # mirror representation) exports for the torch-free runtime: what `spkdeploy best_model deployed` is for
+        import struct
+        from schnetpack_amd import deploy
+        blob = deploy.export_potential(m.eval())
+        ints = struct.unpack("<16i", blob[8:72])
+        flts = struct.unpack("<4f", blob[72:88])
+        assert ints[:6] == (1, 1, 128, 128, 2, 20) and ints[7] == 64 and ints[10] == 1 and ints[11] == 0
+        assert flts[0] == pytest.approx(5.0) and flts[2] == pytest.approx(float(m.postprocessors[1].mean), rel=1e-6)
         # opt-in extras: fused energy head and the device neighbour lists
         from schnetpack_amd import atomistic as A, neighborlist as NL
         aw_mod = sys.modules["schnetpack.atomistic.atomwise"]
