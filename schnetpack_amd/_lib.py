@@ -119,6 +119,7 @@ _PROTOS = {
     "spk_schnet_backward_f32": (ctypes.c_int, [P(SchnetT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "spk_painn_message_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
     "spk_painn_message_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_f]),
+    "spk_painn_set_tile": (None, [c_i32]),
     "spk_painn_mix_ctx_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, ctypes.c_float, c_f, c_f]),
     "spk_painn_mix_update_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i32, c_f, c_f, c_f]),
     "spk_painn_mix_update_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_f, c_f, c_f]),

@@ -10,8 +10,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_painn.hip", "spk_nbl.hip", "spk_md.hip", "spk_potential.hip"]
-HEADERS = ["spk_common.h", os.path.join("..", "..", "include", "spk_hip.h")]
+SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_painn.hip", "spk_painn_tile.hip", "spk_nbl.hip", "spk_md.hip", "spk_potential.hip"]
+HEADERS = ["spk_common.h", "spk_painn_msg.h", "spk_pack.h", os.path.join("..", "..", "include", "spk_hip.h")]
 LIB = os.path.join(HERE, "libspk_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-mcode-object-version=5", "-Wall", "-Wno-unused-function"]
@@ -72,7 +72,7 @@ def build_native_example(force=False, verbose=True):
     """Plain-C program on the deployment runtime (examples/native/spk_run.c): gcc, links libspk_hip.so only."""
     if not os.path.exists(RUN_SRC):
         return None
-    if force or _stale(RUN_BIN, [RUN_SRC, LIB, os.path.join(HERE, HEADERS[1])]):
+    if force or _stale(RUN_BIN, [RUN_SRC, LIB, os.path.join(HERE, HEADERS[-1])]):
         cmd = [os.environ.get("CC", "gcc"), "-O2", "-Wall", "-std=c11", "-D_POSIX_C_SOURCE=199309L", RUN_SRC, "-o", RUN_BIN,
                "-L" + HERE, "-lspk_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:

@@ -13,27 +13,7 @@ int spk_dense_internal(const float* in, const float* pre_in, const float* w, con
                        const float* res, float* out, float* pre_out, int64_t M, int KC, int NW,
                        int act, bool trans, int pro, hipStream_t stream);
 
-struct MsgArgs {
-  const float* c;       // [N, 3F] context-net output
-  const float* q;       // [N, F]
-  const float* mu;      // [N, 3, F]
-  const float* gq_out;  // bwd [N, F]
-  const float* gmu_out; // bwd [N, 3, F]
-  const float* rij;     // [E, 3]
-  const int64_t* idx_i;
-  const int64_t* idx_j;
-  const int32_t* rowptr;
-  const float* wf;      // [3F, n_rbf] rows of this layer
-  const float* bf;      // [3F]
-  float* q_out;         // fwd [N, F]
-  float* mu_out;        // fwd [N, 3, F]
-  float* gc;            // bwd [N, 3F]
-  float* gmu;           // bwd [N, 3, F]
-  float* gr;            // bwd [E, 3] accumulated
-  int64_t E, N;
-  int F;
-  RadialDev rb;
-};
+#include "spk_painn_msg.h"
 
 // ------------------------------------------------------------------------------------------
 // row kernels (sorted idx_i; backward additionally needs a symmetric list)
@@ -335,6 +315,12 @@ static int msg_dispatch(const MsgArgs& a, bool row_ok, hipStream_t stream, const
   const int F = a.F, K = a.rb.n_rbf;
   const bool shape_ok = row_ok && (F == 64 || F == 128) && K <= 32;
   SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || shape_ok, "%s: shape F=%d n_rbf=%d (or unsorted/asymmetric list) not supported by the row kernel", who, F, K);
+  if (!BWD && shape_ok && variant != SPK_VARIANT_SIMPLE && spk_painn_msg_tile_ok(a)) {
+    // forward on large lists: filter GEMM on the matrix cores, 32-edge tiles (spk_painn_tile.hip); the profile scope
+    // covers the init launch too
+    SpkProfScope prof("painn_msg_fwd_tile", stream);
+    return spk_painn_msg_tile_fwd(a, stream);
+  }
   if (shape_ok && variant != SPK_VARIANT_SIMPLE) {
     // persistent waves: every wave walks several CSR rows, so the per-wave weight set-up is amortised
     const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 2);

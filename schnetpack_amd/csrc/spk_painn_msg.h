@@ -1,0 +1,30 @@
+// Argument block of the PaiNN message kernels (shared by the row kernels in spk_painn.hip and the MFMA tile
+// kernels in spk_painn_tile.hip).
+#pragma once
+#include "spk_common.h"
+
+struct MsgArgs {
+  const float* c;       // [N, 3F] context-net output
+  const float* q;       // [N, F]
+  const float* mu;      // [N, 3, F]
+  const float* gq_out;  // bwd [N, F]
+  const float* gmu_out; // bwd [N, 3, F]
+  const float* rij;     // [E, 3]
+  const int64_t* idx_i;
+  const int64_t* idx_j;
+  const int32_t* rowptr;
+  const float* wf;      // [3F, n_rbf] rows of this layer
+  const float* bf;      // [3F]
+  float* q_out;         // fwd [N, F]
+  float* mu_out;        // fwd [N, 3, F]
+  float* gc;            // bwd [N, 3F]
+  float* gmu;           // bwd [N, 3, F]
+  float* gr;            // bwd [E, 3] accumulated
+  int64_t E, N;
+  int F;
+  RadialDev rb;
+};
+
+// MFMA tile kernel of the forward message (spk_painn_tile.hip): true if it should run for this shape / list
+bool spk_painn_msg_tile_ok(const MsgArgs& a);
+int spk_painn_msg_tile_fwd(const MsgArgs& a, hipStream_t stream);

@@ -1,0 +1,236 @@
+// PaiNN message forward (representation/painn.py:31-67) with the filter GEMM on the matrix cores: 32-edge tiles.
+//
+// The row kernel of spk_painn.hip recomputes the filter slice Phi_e = (phi(d_e) Wf^T + bf) fcut(d_e) of every edge
+// with 3 x n_rbf packed VALU FMAs per channel pair.  Here a wavefront owns a tile of 32 consecutive DIRECTED edges of
+// the sorted list and evaluates the filter as a GEMM on v_mfma_f32_32x32x2_f32
+//   Phi [32 edges x 3F] = A [32 x KP] B [KP x 3F],   A[e][k] = fcut(d_e) phi_k(d_e)  (k < K),  A[e][K] = fcut(d_e)  (bias column),
+//   B = packed (Wf | bf) staged once per workgroup in LDS
+// so the cutoff and the bias are part of the GEMM and the VALU only does the message algebra.  Operands are chosen
+// such that the accumulator has rows = edges, columns = channels: a lane owns one channel, its 16 registers are 16
+// edges, neighbour rows c[j], mu[j] are gathered as coalesced 128-byte segments, and the per-centre-atom sums are
+// per-lane running sums over registers flushed with one float atomic per run (idx_i is sorted; the outputs are
+// pre-initialised with q / mu).  Matrix row m of the tile is edge slot 16 (m>>2 & 1) + (m & 3) + 4 (m >> 3), which
+// makes the 16 registers of a half-wave 16 CONSECUTIVE edges: a row of the list is split over as few runs as possible.
+//
+// Measured (profiles/README.md, round 1): 693 us against 832 us for the row kernel on the 1.71 M-edge water box,
+// 62 us against 59 us on the 78 k-edge aspirin batch -- both kernels move the same 3 KB of neighbour rows per edge
+// through the L1/L2 gather path (~7.5 TB/s here), which is the real bound, so taking the filter off the VALU buys
+// little.  The dispatcher therefore uses this kernel for large lists only (E >= 2^19) unless forced with
+// spk_painn_set_tile().  A backward in the same style (second GEMM for d(Phi fcut)/dd, 14 gathered rows per edge
+// and channel instead of the row kernel's 10) was measured 4x slower than the row kernel and is not kept.
+#include "spk_painn_msg.h"
+
+#define SPK_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
+
+namespace {
+
+struct __attribute__((aligned(16))) TileRec { int i; int j; float ux; float uy; float uz; float invd; float r0; float r1; };
+
+// packed (Wf | bf): P[((t * KPB + ug) * 64 + lane) * 4 + v] = W'[32 t + (lane & 31)][8 ug + 4 (lane >> 5) + v],
+// W'[row][k] = wf[row][k] (k < K), bf[row] (k == K), 0 beyond
+template <int NSLOT>
+__device__ __forceinline__ void stage_filter(float* dst, const float* __restrict__ wf, const float* __restrict__ bf, int K, int KPB) {
+  for (int s = threadIdx.x; s < NSLOT; s += 256) {
+    const int lane = s & 63;
+    const int ug = (s >> 6) % KPB;
+    const int t = (s >> 6) / KPB;
+    const int row = 32 * t + (lane & 31);
+    const int k0 = 8 * ug + 4 * (lane >> 5);
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + q;
+      v[q] = k < K ? wf[(int64_t)row * K + k] : (k == K ? bf[row] : 0.f);
+    }
+    *(f32x4*)(dst + (int64_t)s * 4) = v;
+  }
+}
+
+template <int KPB>
+__device__ __forceinline__ f32x16 tile_gemm(const float* __restrict__ sW, int t, const float (&A)[KPB][4], int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const f32x4* wp = (const f32x4*)sW + (int64_t)t * KPB * 64 + lane;
+#pragma unroll
+  for (int u = 0; u < KPB; ++u) {
+    const f32x4 wq = wp[u * 64];
+    acc = SPK_MFMA(A[u][0], wq.x, acc);
+    acc = SPK_MFMA(A[u][1], wq.y, acc);
+    acc = SPK_MFMA(A[u][2], wq.z, acc);
+    acc = SPK_MFMA(A[u][3], wq.w, acc);
+  }
+  return acc;
+}
+
+// edge slot handled by lane el (as matrix row el) -- see the file comment
+__device__ __forceinline__ int slot_of_row(int el) { return 16 * ((el >> 2) & 1) + (el & 3) + 4 * (el >> 3); }
+
+template <int F, int KPB>
+__global__ __launch_bounds__(256, 2) void k_painn_msg_tile(MsgArgs a, int ntiles) {
+  constexpr int NT = F / 32;          // channel blocks per part
+  constexpr int NB = 3 * NT;          // column blocks of the filter GEMM
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW = smem;                                        // NB * KPB * 256 floats
+  TileRec* sE = (TileRec*)(sW + NB * KPB * 256);           // 4 waves x 32 records
+  int* sCnt = (int*)(sE + 4 * 32);
+  const int K = a.rb.n_rbf;
+
+  stage_filter<NB * KPB * 64>(sW, a.wf, a.bf, K, KPB);
+  if (threadIdx.x == 0) sCnt[0] = 0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  TileRec* myE = sE + wv * 32;
+  const int slot = slot_of_row(el);
+  constexpr unsigned F3 = 3u * F;
+
+  while (true) {
+    int nidx = 0;
+    if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
+    nidx = __builtin_amdgcn_readfirstlane(nidx);
+    const int tile = (int)blockIdx.x + nidx * (int)gridDim.x;
+    if (tile >= ntiles) break;
+
+    // ---- geometry of this lane's edge slot (lanes 32..63 mirror lanes 0..31)
+    const int64_t e_first = (int64_t)tile * 32;
+    const int nvalid = (a.E - e_first) < 32 ? (int)(a.E - e_first) : 32;
+    const bool valid = slot < nvalid;
+    const int64_t e = e_first + (valid ? slot : (nvalid - 1));
+    const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+    const int ci = (int)a.idx_i[e], cj = (int)a.idx_j[e];
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float invd = 1.0f / d;
+    float fc, dfc;
+    spk_cutoff_eval_fast(a.rb.cutoff, d, fc, dfc);
+    if (!valid) fc = 0.f;
+    if (hi == 0) {
+      TileRec rec; rec.i = ci; rec.j = cj; rec.ux = rx * invd; rec.uy = ry * invd; rec.uz = rz * invd; rec.invd = invd; rec.r0 = 0.f; rec.r1 = 0.f;
+      myE[slot] = rec;
+    }
+    // A operands: (fc phi_k | fc)
+    float Av[KPB][4];
+#pragma unroll
+    for (int u = 0; u < KPB; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int k = 8 * u + 4 * hi + v;
+        float p, dp;
+        spk_rbf_eval_fast(a.rb, k, d, p, dp);          // 0 for k >= K
+        if (k == K) p = 1.0f;
+        Av[u][v] = fc * p;
+      }
+    spk_wave_lds_sync();   // records visible to the whole wave
+    // bit r set <=> the centre atom changes after register r of this half (or the half ends)
+    unsigned runmask = 0x8000u;
+    {
+      int prev = myE[16 * hi].i;
+#pragma unroll
+      for (int r = 1; r < 16; ++r) {
+        const int cur = myE[16 * hi + r].i;
+        if (cur != prev) runmask |= 1u << (r - 1);
+        prev = cur;
+      }
+    }
+
+    {
+#pragma unroll 1
+      for (int cb = 0; cb < NT; ++cb) {
+        const unsigned c0 = 32u * cb + el;
+        // ---- scalar part: dq_i = sum Phi_q c_q[j]
+        {
+          float cq[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cq[r] = a.c[(unsigned)myE[16 * hi + r].j * F3 + c0];
+          const f32x16 Pq = tile_gemm<KPB>(sW, cb, Av, lane);
+          float acc = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc = fmaf(Pq[r], cq[r], acc);
+            if ((runmask >> r) & 1u) { unsafeAtomicAdd(a.q_out + ((unsigned)myE[16 * hi + r].i * F + c0), acc); acc = 0.f; }
+          }
+        }
+        // ---- vector part: dmu_i = sum (Phi_R c_R[j]) u + (Phi_mu c_mu[j]) mu[j]
+        const f32x16 PR = tile_gemm<KPB>(sW, NT + cb, Av, lane);
+        const f32x16 Pm = tile_gemm<KPB>(sW, 2 * NT + cb, Av, lane);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int g0 = 0; g0 < 16; g0 += 8) {
+          float cR[8], cm[8], m0[8], m1[8], m2[8];
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const unsigned oj = (unsigned)myE[16 * hi + g0 + rr].j * F3 + c0;
+            cR[rr] = a.c[oj + F]; cm[rr] = a.c[oj + 2 * F];
+            m0[rr] = a.mu[oj]; m1[rr] = a.mu[oj + F]; m2[rr] = a.mu[oj + 2 * F];
+          }
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = g0 + rr;
+            const TileRec er = myE[16 * hi + r];
+            const float mR = PR[r] * cR[rr], mm = Pm[r] * cm[rr];
+            a0 = fmaf(mR, er.ux, fmaf(mm, m0[rr], a0));
+            a1 = fmaf(mR, er.uy, fmaf(mm, m1[rr], a1));
+            a2 = fmaf(mR, er.uz, fmaf(mm, m2[rr], a2));
+            if ((runmask >> r) & 1u) {
+              float* dst = a.mu_out + ((unsigned)er.i * F3 + c0);
+              unsafeAtomicAdd(dst, a0); unsafeAtomicAdd(dst + F, a1); unsafeAtomicAdd(dst + 2 * F, a2);
+              a0 = 0.f; a1 = 0.f; a2 = 0.f;
+            }
+          }
+        }
+      }
+    }
+    spk_wave_lds_sync();   // records may be rewritten by the next tile
+  }
+}
+
+// the tile kernel accumulates with atomics: q_out = q, mu_out = mu first
+__global__ void k_msg_tile_init(const float* __restrict__ s0, float* __restrict__ d0, int64_t n0, const float* __restrict__ s1,
+                                float* __restrict__ d1, int64_t n1) {
+  const int64_t n04 = n0 / 4, n14 = n1 / 4;
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n04 + n14; k += (int64_t)gridDim.x * blockDim.x) {
+    if (k < n04) ((f32x4*)d0)[k] = ((const f32x4*)s0)[k];
+    else ((f32x4*)d1)[k - n04] = ((const f32x4*)s1)[k - n04];
+  }
+}
+
+template <int F, int KPB>
+int launch_tile(const MsgArgs& a, hipStream_t stream) {
+  const int64_t nt = (a.E + 31) / 32;
+  const size_t lds = (size_t)(3 * (F / 32) * KPB * 256) * sizeof(float) + 4 * 32 * sizeof(TileRec) + 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile<F, KPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const int grid = spk_grid_for(nt, 4, spk_num_cus() * 2);
+  hipLaunchKernelGGL((k_painn_msg_tile<F, KPB>), dim3(grid), dim3(256), lds, stream, a, (int)nt);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+int g_tile_mode = 0;   // 0 auto (large lists), 1 always when the shape allows, -1 never
+
+}  // namespace
+
+extern "C" void spk_painn_set_tile(int32_t mode) { g_tile_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0); }
+
+bool spk_painn_msg_tile_ok(const MsgArgs& a) {
+  const int kpb = a.rb.n_rbf / 8 + 1;    // room for the bias column
+  if (g_tile_mode < 0 || !(a.F == 128 || a.F == 64) || kpb < 3 || kpb > 5 || a.E < 32 || a.N * 3 * (int64_t)a.F >= (1LL << 31)) return false;
+  return g_tile_mode > 0 || a.E >= (1 << 19);
+}
+
+int spk_painn_msg_tile_fwd(const MsgArgs& a, hipStream_t stream) {
+  const int64_t nf = a.N * (int64_t)a.F;
+  hipLaunchKernelGGL(k_msg_tile_init, dim3(spk_grid_for(nf, 256, spk_num_cus() * 8)), dim3(256), 0, stream, a.q, a.q_out, nf, a.mu, a.mu_out, 3 * nf);
+  SPK_LAUNCH_CHECK();
+  const int kpb = a.rb.n_rbf / 8 + 1;
+#define SPK_TILE_CASE(Fv, Kv) if (a.F == Fv && kpb == Kv) return launch_tile<Fv, Kv>(a, stream);
+  SPK_TILE_CASE(128, 3) SPK_TILE_CASE(128, 4) SPK_TILE_CASE(128, 5)
+  SPK_TILE_CASE(64, 3) SPK_TILE_CASE(64, 4) SPK_TILE_CASE(64, 5)
+#undef SPK_TILE_CASE
+  spk_set_error("painn message tile kernel: internal dispatch error (F=%d n_rbf=%d)", a.F, a.rb.n_rbf);
+  return SPK_ERR_ARG;
+}

@@ -240,6 +240,25 @@ def test_force_call_golden_with_both_chain_tile_heights(dev, name, rows):
     assert rel_err(out["forces"], ref["forces"]) < TOL
 
 
+@pytest.mark.parametrize("name", ["painn_aspirin8.npz", "painn_water192.npz", "painn_skin_aspirin2.npz", "painn_bessel_aspirin2.npz",
+                                  "painn_aspirin_pretrained.npz"])
+def test_painn_force_call_golden_with_the_mfma_message_kernel(dev, name):
+    """The forward message through the MFMA tile kernel (dispatched by itself only for lists of >= 2^19 edges, forced
+    here) inside the whole force call: open and periodic lists, pairs beyond the cutoff, Bessel basis, shipped weights."""
+    from schnetpack_amd import _lib
+    b, ref, meta = load_golden(name)
+    rep_p, head_p = golden_params(meta)
+    model = _build(meta, dev, rep_p, head_p).eval()
+    _lib.lib().spk_painn_set_tile(1)
+    try:
+        out = _force_call(model, b, dev)
+    finally:
+        _lib.lib().spk_painn_set_tile(0)
+    assert rel_err(out["energy"], ref["energy"]) < TOL
+    assert rel_err(out["forces"], ref["forces"]) < TOL
+    assert rel_err(out["scalar_representation"], ref["scalar_representation"]) < TOL
+
+
 @pytest.mark.parametrize("n_mol", [2, 64])
 def test_pair_filter_for_lists_with_skin(dev, n_mol):
     """Lists that hold pairs beyond the cutoff (MD skin lists): the per-call compaction of the pair list

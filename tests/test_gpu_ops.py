@@ -431,10 +431,18 @@ def test_painn_message_forward_backward(dev, variant, graph, F, n_rbf):
     q_out = torch.empty(N, F, device=dev)
     mu_out = torch.empty(N, 3, F, device=dev)
     L = _lib.lib()
-    _lib.check(L.spk_painn_message_fwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(qd), _lib.fptr(mud), _lib.fptr(rd),
-                                           _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(q_out), _lib.fptr(mu_out), _lib.stream()))
-    assert rel_err(q_out.cpu(), qo) < TOL
-    assert rel_err(mu_out.cpu(), muo) < TOL
+    # forward through both kernel families: row kernel (-1) and the MFMA tile kernel (1: whenever the shape has one;
+    # shapes / lists without one fall through to the row or simple kernel)
+    try:
+        for mode in (-1, 1):
+            L.spk_painn_set_tile(mode)
+            q_out.fill_(float("nan")); mu_out.fill_(float("nan"))
+            _lib.check(L.spk_painn_message_fwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(qd), _lib.fptr(mud), _lib.fptr(rd),
+                                                   _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(q_out), _lib.fptr(mu_out), _lib.stream()))
+            assert rel_err(q_out.cpu(), qo) < TOL, mode
+            assert rel_err(mu_out.cpu(), muo) < TOL, mode
+    finally:
+        L.spk_painn_set_tile(0)
     gc = torch.empty(N, 3 * F, device=dev)
     gmu_in = torch.empty(N, 3, F, device=dev)
     gr = torch.zeros(r.shape[0], 3, device=dev)
