@@ -39,7 +39,8 @@ template <> struct MsgVec<2> {
   static __device__ __forceinline__ T zero() { return f32x2{0.f, 0.f}; }
 };
 
-template <int VPL, int NRBF, bool BWD>
+// GEOM (backward only): form the geometry gradient gr alone -- no neighbour gradients are gathered, no gc / gmu
+template <int VPL, int NRBF, bool BWD, bool GEOM = false>
 __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
   typedef MsgVec<VPL> MV;
   typedef typename MV::T VT;
@@ -103,14 +104,14 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       // neighbour rows are requested one edge ahead (explicit double buffer): the row kernel is
       // bound by the latency of these dependent gathers, not by their bandwidth
       constexpr bool PF = true;
-      VT cjr[PF ? 2 : 1][3], mujr[PF ? 2 : 1][3], gqbr[PF ? 2 : 1], gmbr[PF ? 2 : 1][3];
+      VT cjr[PF ? 2 : 1][3], mujr[PF ? 2 : 1][3], gqbr[PF ? 2 : 1] = {}, gmbr[PF ? 2 : 1][3] = {};
       auto load_rows = [&](int slot, int t) {
         const int64_t jj = __builtin_amdgcn_readlane(jl, t);
         const float* cj = a.c + jj * 3 * F + fo;
         const float* muj = a.mu + jj * 3 * F + fo;
 #pragma unroll
         for (int p = 0; p < 3; ++p) { cjr[slot][p] = MV::load(cj + p * F); mujr[slot][p] = MV::load(muj + p * F); }
-        if (BWD) {
+        if (BWD && !GEOM) {
           gqbr[slot] = MV::load(a.gq_out + jj * F + fo);
 #pragma unroll
           for (int p = 0; p < 3; ++p) gmbr[slot][p] = MV::load(a.gmu_out + jj * 3 * F + fo + p * F);
@@ -168,9 +169,11 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
               const VT mb0 = mujr[par][0], mb1 = mujr[par][1], mb2 = mujr[par][2];
               const VT gb0 = gmbr[par][0], gb1 = gmbr[par][1], gb2 = gmbr[par][2];
               // (1) transposed sums for the centre atom acting as neighbour of b (reverse edge)
-              accq += Fq * gqbr[par];
-              accR -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
-              accv[0] += Fm * gb0; accv[1] += Fm * gb1; accv[2] += Fm * gb2;
+              if (!GEOM) {
+                accq += Fq * gqbr[par];
+                accR -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
+                accv[0] += Fm * gb0; accv[1] += Fm * gb1; accv[2] += Fm * gb2;
+              }
               // (2) geometry gradient of edge (atom <- b)
               const VT gu = gma[0] * ux + gma[1] * uy + gma[2] * uz;
               const VT gm = gma[0] * mb0 + gma[1] * mb1 + gma[2] * mb2;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
 #pragma unroll
       for (int x = 0; x < 3; ++x)
         MV::store(a.mu_out + (atom * 3 + x) * F + fo, MV::load(a.mu + (atom * 3 + x) * F + fo) + accv[x]);
-    } else {
+    } else if (!GEOM) {
       const VT ma0 = MV::load(a.mu + (atom * 3 + 0) * F + fo), ma1 = MV::load(a.mu + (atom * 3 + 1) * F + fo),
                ma2 = MV::load(a.mu + (atom * 3 + 2) * F + fo);
       const VT cma = MV::load(a.c + atom * 3 * F + 2 * F + fo);
@@ -326,8 +329,11 @@ static int msg_dispatch(const MsgArgs& a, bool row_ok, hipStream_t stream, const
     const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 2);
     const size_t lds = (size_t)K * (3 * F + 1) * sizeof(float);
     SpkProfScope prof(BWD ? "painn_msg_bwd_row" : "painn_msg_fwd_row", stream);
-#define SPK_MSG_CASE(VPLv, NRBFv)                                                              \
-  hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD>), dim3(grid), dim3(256), lds, stream, a)
+#define SPK_MSG_CASE(VPLv, NRBFv)                                                                              \
+  do {                                                                                                         \
+    if (BWD && a.geom_only) hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, BWD>), dim3(grid), dim3(256), lds, stream, a); \
+    else hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, false>), dim3(grid), dim3(256), lds, stream, a);                 \
+  } while (0)
     if (F == 64) { if (K <= 20) SPK_MSG_CASE(1, 20); else SPK_MSG_CASE(1, 32); }
     else { if (K <= 20) SPK_MSG_CASE(2, 20); else SPK_MSG_CASE(2, 32); }
 #undef SPK_MSG_CASE
@@ -372,7 +378,7 @@ int spk_painn_message_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
 int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
                                    const float* mu, const float* gq_out, const float* gmu_out,
                                    const float* r_ij, const float* wf, const float* bf, int F,
-                                   float* gc, float* gmu, float* gr, hipStream_t stream) {
+                                   float* gc, float* gmu, float* gr, hipStream_t stream, bool geom_only = false) {
   const char* who = "spk_painn_message_bwd_f32";
   int rc = check_msg(g, rb, F, who);
   if (rc) return rc;
@@ -381,7 +387,7 @@ int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
   MsgArgs a = {};
   a.c = c; a.mu = mu; a.gq_out = gq_out; a.gmu_out = gmu_out; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
   a.rowptr = g->rowptr; a.wf = wf; a.bf = bf; a.gc = gc; a.gmu = gmu; a.gr = gr; a.E = g->n_edges; a.N = g->n_atoms;
-  a.F = F; a.rb = spk_radial_dev(rb);
+  a.F = F; a.rb = spk_radial_dev(rb); a.geom_only = geom_only ? 1 : 0;
   return msg_dispatch<true>(a, g->sorted && g->symmetric && g->rowptr, stream, who);
 }
 
@@ -1033,7 +1039,11 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
     // ---- message backward: gc, gmu (incl. residual), gr +=
-    SPK_TRY(spk_painn_message_bwd_internal(g, rb, c, mu_in, gq1, gmu1, r_ij, P.filt_w, P.filt_b, F, gc, gmu, gr, stream));
+    // (first interaction without dL/dq0, the eval path: only the geometry gradient is formed and the context-net
+    //  backward below it is skipped)
+    const bool last_geom_only = (l == 0 && !gq0);
+    SPK_TRY(spk_painn_message_bwd_internal(g, rb, c, mu_in, gq1, gmu1, r_ij, P.filt_w, P.filt_b, F, gc, gmu, gr, stream, last_geom_only));
+    if (last_geom_only) break;
     {  // context net backward; residual path adds gq1
       float* out = (l == 0 && gq0) ? gq0 : gq;
       spk_chain_t ch = {};
