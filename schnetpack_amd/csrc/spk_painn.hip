@@ -40,7 +40,8 @@ template <> struct MsgVec<2> {
 };
 
 // GEOM (backward only): form the geometry gradient gr alone -- no neighbour gradients are gathered, no gc / gmu
-template <int VPL, int NRBF, bool BWD, bool GEOM = false>
+// MU0: mu == 0 everywhere (first interaction): the mu rows of the neighbours are not gathered
+template <int VPL, int NRBF, bool BWD, bool GEOM = false, bool MU0 = false>
 __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
   typedef MsgVec<VPL> MV;
   typedef typename MV::T VT;
@@ -104,13 +105,13 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       // neighbour rows are requested one edge ahead (explicit double buffer): the row kernel is
       // bound by the latency of these dependent gathers, not by their bandwidth
       constexpr bool PF = true;
-      VT cjr[PF ? 2 : 1][3], mujr[PF ? 2 : 1][3], gqbr[PF ? 2 : 1] = {}, gmbr[PF ? 2 : 1][3] = {};
+      VT cjr[PF ? 2 : 1][3], mujr[PF ? 2 : 1][3] = {}, gqbr[PF ? 2 : 1] = {}, gmbr[PF ? 2 : 1][3] = {};
       auto load_rows = [&](int slot, int t) {
         const int64_t jj = __builtin_amdgcn_readlane(jl, t);
         const float* cj = a.c + jj * 3 * F + fo;
         const float* muj = a.mu + jj * 3 * F + fo;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { cjr[slot][p] = MV::load(cj + p * F); mujr[slot][p] = MV::load(muj + p * F); }
+        for (int p = 0; p < 3; ++p) { cjr[slot][p] = MV::load(cj + p * F); if (!MU0) mujr[slot][p] = MV::load(muj + p * F); }
         if (BWD && !GEOM) {
           gqbr[slot] = MV::load(a.gq_out + jj * F + fo);
 #pragma unroll
@@ -329,10 +330,12 @@ static int msg_dispatch(const MsgArgs& a, bool row_ok, hipStream_t stream, const
     const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 2);
     const size_t lds = (size_t)K * (3 * F + 1) * sizeof(float);
     SpkProfScope prof(BWD ? "painn_msg_bwd_row" : "painn_msg_fwd_row", stream);
-#define SPK_MSG_CASE(VPLv, NRBFv)                                                                              \
-  do {                                                                                                         \
-    if (BWD && a.geom_only) hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, BWD>), dim3(grid), dim3(256), lds, stream, a); \
-    else hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, false>), dim3(grid), dim3(256), lds, stream, a);                 \
+#define SPK_MSG_CASE(VPLv, NRBFv)                                                                                             \
+  do {                                                                                                                        \
+    if (BWD && a.geom_only && a.mu_zero) hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, BWD, true>), dim3(grid), dim3(256), lds, stream, a);  \
+    else if (BWD && a.geom_only) hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, BWD, false>), dim3(grid), dim3(256), lds, stream, a);      \
+    else if (!BWD && a.mu_zero) hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, false, !BWD>), dim3(grid), dim3(256), lds, stream, a);      \
+    else hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, false, false>), dim3(grid), dim3(256), lds, stream, a);                           \
   } while (0)
     if (F == 64) { if (K <= 20) SPK_MSG_CASE(1, 20); else SPK_MSG_CASE(1, 32); }
     else { if (K <= 20) SPK_MSG_CASE(2, 20); else SPK_MSG_CASE(2, 32); }
@@ -362,7 +365,7 @@ static int msg_dispatch(const MsgArgs& a, bool row_ok, hipStream_t stream, const
 int spk_painn_message_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
                                    const float* q, const float* mu, const float* r_ij,
                                    const float* wf, const float* bf, int F, float* q_out,
-                                   float* mu_out, hipStream_t stream) {
+                                   float* mu_out, hipStream_t stream, bool mu_zero = false) {
   const char* who = "spk_painn_message_fwd_f32";
   int rc = check_msg(g, rb, F, who);
   if (rc) return rc;
@@ -371,14 +374,14 @@ int spk_painn_message_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
   MsgArgs a = {};
   a.c = c; a.q = q; a.mu = mu; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j; a.rowptr = g->rowptr;
   a.wf = wf; a.bf = bf; a.q_out = q_out; a.mu_out = mu_out; a.E = g->n_edges; a.N = g->n_atoms; a.F = F;
-  a.rb = spk_radial_dev(rb);
+  a.rb = spk_radial_dev(rb); a.mu_zero = mu_zero ? 1 : 0;
   return msg_dispatch<false>(a, g->sorted && g->rowptr, stream, who);
 }
 
 int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
                                    const float* mu, const float* gq_out, const float* gmu_out,
                                    const float* r_ij, const float* wf, const float* bf, int F,
-                                   float* gc, float* gmu, float* gr, hipStream_t stream, bool geom_only = false) {
+                                   float* gc, float* gmu, float* gr, hipStream_t stream, bool geom_only = false, bool mu_zero = false) {
   const char* who = "spk_painn_message_bwd_f32";
   int rc = check_msg(g, rb, F, who);
   if (rc) return rc;
@@ -387,7 +390,7 @@ int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
   MsgArgs a = {};
   a.c = c; a.mu = mu; a.gq_out = gq_out; a.gmu_out = gmu_out; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
   a.rowptr = g->rowptr; a.wf = wf; a.bf = bf; a.gc = gc; a.gmu = gmu; a.gr = gr; a.E = g->n_edges; a.N = g->n_atoms;
-  a.F = F; a.rb = spk_radial_dev(rb); a.geom_only = geom_only ? 1 : 0;
+  a.F = F; a.rb = spk_radial_dev(rb); a.geom_only = geom_only ? 1 : 0; a.mu_zero = mu_zero ? 1 : 0;
   return msg_dispatch<true>(a, g->sorted && g->symmetric && g->rowptr, stream, who);
 }
 
@@ -939,7 +942,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
       spk_apply_pack(ch, ptab);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
-    SPK_TRY(spk_painn_message_fwd_internal(g, rb, c, qin, mu_in, r_ij, P.filt_w, P.filt_b, F, q1, mu1, stream));
+    SPK_TRY(spk_painn_message_fwd_internal(g, rb, c, qin, mu_in, r_ij, P.filt_w, P.filt_b, F, q1, mu1, stream, l == 0));   // mu_in == 0 for l == 0
     float* mu_next = (l == L - 1) ? mu_out : (saved + (l + 1) * per + 4 * nf);
     const float* pk_mix = spk_packed_of(ptab, P.mix_w, 0);
     const float* pk_w1 = spk_packed_of(ptab, P.ictx_w1, 0);
@@ -1042,7 +1045,7 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
     // (first interaction without dL/dq0, the eval path: only the geometry gradient is formed and the context-net
     //  backward below it is skipped)
     const bool last_geom_only = (l == 0 && !gq0);
-    SPK_TRY(spk_painn_message_bwd_internal(g, rb, c, mu_in, gq1, gmu1, r_ij, P.filt_w, P.filt_b, F, gc, gmu, gr, stream, last_geom_only));
+    SPK_TRY(spk_painn_message_bwd_internal(g, rb, c, mu_in, gq1, gmu1, r_ij, P.filt_w, P.filt_b, F, gc, gmu, gr, stream, last_geom_only, l == 0));
     if (last_geom_only) break;
     {  // context net backward; residual path adds gq1
       float* out = (l == 0 && gq0) ? gq0 : gq;

@@ -22,6 +22,7 @@ struct MsgArgs {
   float* gr;            // bwd [E, 3] accumulated
   int64_t E, N;
   int F;
+  int mu_zero;        // mu is known to be all zeros (first interaction, painn.py:246): its rows are not gathered
   int geom_only;      // bwd: only gr is wanted (first interaction of an eval-mode backward): gc / gmu are not formed
   RadialDev rb;
 };

@@ -66,7 +66,8 @@ __device__ __forceinline__ f32x16 tile_gemm(const float* __restrict__ sW, int t,
 // edge slot handled by lane el (as matrix row el) -- see the file comment
 __device__ __forceinline__ int slot_of_row(int el) { return 16 * ((el >> 2) & 1) + (el & 3) + 4 * (el >> 3); }
 
-template <int F, int KPB>
+// MU0: mu == 0 (first interaction): the mu part of the filter and the mu rows are skipped
+template <int F, int KPB, bool MU0>
 __global__ __launch_bounds__(256, 2) void k_painn_msg_tile(MsgArgs a, int ntiles) {
   constexpr int NT = F / 32;          // channel blocks per part
   constexpr int NB = 3 * NT;          // column blocks of the filter GEMM
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_tile(MsgArgs a, int ntiles
         }
         // ---- vector part: dmu_i = sum (Phi_R c_R[j]) u + (Phi_mu c_mu[j]) mu[j]
         const f32x16 PR = tile_gemm<KPB>(sW, NT + cb, Av, lane);
-        const f32x16 Pm = tile_gemm<KPB>(sW, 2 * NT + cb, Av, lane);
+        f32x16 Pm = PR;
+        if (!MU0) Pm = tile_gemm<KPB>(sW, 2 * NT + cb, Av, lane);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int g0 = 0; g0 < 16; g0 += 8) {
@@ -161,17 +163,18 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_tile(MsgArgs a, int ntiles
 #pragma unroll
           for (int rr = 0; rr < 8; ++rr) {
             const unsigned oj = (unsigned)myE[16 * hi + g0 + rr].j * F3 + c0;
-            cR[rr] = a.c[oj + F]; cm[rr] = a.c[oj + 2 * F];
-            m0[rr] = a.mu[oj]; m1[rr] = a.mu[oj + F]; m2[rr] = a.mu[oj + 2 * F];
+            cR[rr] = a.c[oj + F];
+            if (!MU0) { cm[rr] = a.c[oj + 2 * F]; m0[rr] = a.mu[oj]; m1[rr] = a.mu[oj + F]; m2[rr] = a.mu[oj + 2 * F]; }
+            else { cm[rr] = 0.f; m0[rr] = 0.f; m1[rr] = 0.f; m2[rr] = 0.f; }
           }
 #pragma unroll
           for (int rr = 0; rr < 8; ++rr) {
             const int r = g0 + rr;
             const TileRec er = myE[16 * hi + r];
-            const float mR = PR[r] * cR[rr], mm = Pm[r] * cm[rr];
-            a0 = fmaf(mR, er.ux, fmaf(mm, m0[rr], a0));
-            a1 = fmaf(mR, er.uy, fmaf(mm, m1[rr], a1));
-            a2 = fmaf(mR, er.uz, fmaf(mm, m2[rr], a2));
+            const float mR = PR[r] * cR[rr], mm = MU0 ? 0.f : Pm[r] * cm[rr];
+            a0 = fmaf(mR, er.ux, MU0 ? a0 : fmaf(mm, m0[rr], a0));
+            a1 = fmaf(mR, er.uy, MU0 ? a1 : fmaf(mm, m1[rr], a1));
+            a2 = fmaf(mR, er.uz, MU0 ? a2 : fmaf(mm, m2[rr], a2));
             if ((runmask >> r) & 1u) {
               float* dst = a.mu_out + ((unsigned)er.i * F3 + c0);
               unsafeAtomicAdd(dst, a0); unsafeAtomicAdd(dst + F, a1); unsafeAtomicAdd(dst + 2 * F, a2);
@@ -195,17 +198,17 @@ __global__ void k_msg_tile_init(const float* __restrict__ s0, float* __restrict_
   }
 }
 
-template <int F, int KPB>
+template <int F, int KPB, bool MU0>
 int launch_tile(const MsgArgs& a, hipStream_t stream) {
   const int64_t nt = (a.E + 31) / 32;
   const size_t lds = (size_t)(3 * (F / 32) * KPB * 256) * sizeof(float) + 4 * 32 * sizeof(TileRec) + 16;
   static bool attr_done = false;
   if (!attr_done) {
-    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile<F, KPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile<F, KPB, MU0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   const int grid = spk_grid_for(nt, 4, spk_num_cus() * 2);
-  hipLaunchKernelGGL((k_painn_msg_tile<F, KPB>), dim3(grid), dim3(256), lds, stream, a, (int)nt);
+  hipLaunchKernelGGL((k_painn_msg_tile<F, KPB, MU0>), dim3(grid), dim3(256), lds, stream, a, (int)nt);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -227,7 +230,7 @@ int spk_painn_msg_tile_fwd(const MsgArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(k_msg_tile_init, dim3(spk_grid_for(nf, 256, spk_num_cus() * 8)), dim3(256), 0, stream, a.q, a.q_out, nf, a.mu, a.mu_out, 3 * nf);
   SPK_LAUNCH_CHECK();
   const int kpb = a.rb.n_rbf / 8 + 1;
-#define SPK_TILE_CASE(Fv, Kv) if (a.F == Fv && kpb == Kv) return launch_tile<Fv, Kv>(a, stream);
+#define SPK_TILE_CASE(Fv, Kv) if (a.F == Fv && kpb == Kv) return a.mu_zero ? launch_tile<Fv, Kv, true>(a, stream) : launch_tile<Fv, Kv, false>(a, stream);
   SPK_TILE_CASE(128, 3) SPK_TILE_CASE(128, 4) SPK_TILE_CASE(128, 5)
   SPK_TILE_CASE(64, 3) SPK_TILE_CASE(64, 4) SPK_TILE_CASE(64, 5)
 #undef SPK_TILE_CASE

@@ -10,3 +10,13 @@ d=json.load(open("gpurun_out/q2/bench_$K.json"))
 print("$K", d["value"], d["ms_per_step"], {k: round(v["avg_us"],1) for k,v in d["kernels"].items()})
 PY
 done
+if [ "$1" = "water" ]; then
+  for K in painn schnet; do
+  timeout 400 python bench.py --kind $K --workload water --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/q2/bench_water_$K.json 2>/dev/null
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/q2/bench_water_$K.json"))
+print("water $K", d["value"], d["ms_per_step"], {k: round(v["avg_us"],1) for k,v in d["kernels"].items()})
+PY
+  done
+fi
