@@ -201,6 +201,11 @@ def main():
         "painn_msg_fwd_row": ("hbm", msg_bytes, 1.0), "painn_msg_fwd_simple": ("hbm", msg_bytes, 1.0),
         "painn_msg_bwd_row": ("hbm", 2 * msg_bytes, 1.0), "painn_msg_bwd_simple": ("hbm", 2 * msg_bytes, 1.0),
         "painn_msg_fwd_tile": ("hbm", msg_bytes, 1.0),
+        # first-interaction variants: mu == 0 (its 3F floats per neighbour are not gathered); geometry-only backward
+        # (c and mu of the neighbour: the forward's bytes; with mu == 0 only c)
+        "painn_msg_fwd_row_mu0": ("hbm", E * 1564.0 + N * 4096.0, 1.0), "painn_msg_fwd_tile_mu0": ("hbm", E * 1564.0 + N * 4096.0, 1.0),
+        "painn_msg_bwd_row_geom": ("hbm", E * 1564.0 + N * 4096.0, 1.0), "painn_msg_bwd_tile_geom": ("hbm", E * 1564.0 + N * 4096.0, 1.0),
+        "painn_msg_bwd_tile": ("hbm", 2 * msg_bytes, 1.0),
     }
     kernels = {}
     for tag, (cnt, ms) in prof.items():

@@ -79,7 +79,8 @@ typedef struct {
   /* Lists with pairs at or beyond the cutoff (MD skin lists, md/neighborlist_md.py:36-38): with filter_pairs != 0
    * the fused SchNet representation compacts the pair list per call (pairs with d < cutoff keep their order) into
    * its `saved` buffer and the cfconv kernels walk only those; the dropped pairs contribute exactly zero
-   * (f_c = f_c' = 0).  n_half_dev is set by the library (a device count that replaces n_half inside the kernels);
+   * (f_c = f_c' = 0).  The PaiNN message dispatch reads the flag as "this list has a skin" and keeps the row kernels,
+   * which drop such pairs before their rows are fetched.  n_half_dev is set by the library (a device count that replaces n_half inside the kernels);
    * callers leave it NULL. */
   int32_t filter_pairs;
   int32_t reserved0;

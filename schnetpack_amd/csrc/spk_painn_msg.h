@@ -22,6 +22,8 @@ struct MsgArgs {
   float* gr;            // bwd [E, 3] accumulated
   int64_t E, N;
   int F;
+  int skin_list;      // the list holds a sizeable share of pairs beyond the cutoff (spk_graph_t.filter_pairs): the row kernel drops them before
+                      // their rows are fetched, the tile kernel would pay the filter GEMM for them
   int mu_zero;        // mu is known to be all zeros (first interaction, painn.py:246): its rows are not gathered
   int geom_only;      // bwd: only gr is wanted (first interaction of an eval-mode backward): gc / gmu are not formed
   RadialDev rb;
@@ -30,3 +32,5 @@ struct MsgArgs {
 // MFMA tile kernel of the forward message (spk_painn_tile.hip): true if it should run for this shape / list
 bool spk_painn_msg_tile_ok(const MsgArgs& a);
 int spk_painn_msg_tile_fwd(const MsgArgs& a, hipStream_t stream);
+bool spk_painn_msg_tile_bwd_ok(const MsgArgs& a);
+int spk_painn_msg_tile_bwd(const MsgArgs& a, hipStream_t stream);

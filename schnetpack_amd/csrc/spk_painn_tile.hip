@@ -188,13 +188,237 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_tile(MsgArgs a, int ntiles
   }
 }
 
+// ---- backward (first order; sorted + symmetric list as for the row kernel: Phi_e = Phi_rev(e), u_rev(e) = -u_e) ----------
+// Two GEMMs per column block: value A = (fc phi_k | fc) and derivative A' = (fc phi_k' + fc' phi_k | fc') -> F = Phi fc and dF/dd.
+// The three parts (q, R, mu) are processed one after the other so that only one (F, dF) accumulator pair is live; the
+// per-edge sums over channels (dd, t_x, t_y, t_z -> geometry gradient) stay in 64 registers over the channel blocks and
+// are reduced over the lanes at the end of the tile (quad sums by DPP, 8 partials per edge through LDS).  gc / gmu of the
+// centre atom are flushed per run with float atomics (gc pre-zeroed, gmu pre-set to gmu_out by the launcher).
+// GEOM: geometry gradient only (no neighbour gradients gathered, nothing flushed); MU0: mu == 0 everywhere.
+// One workgroup per CU (launch bounds 256, 1): the wave may use the whole 512-entry register file (VGPR + AGPR), so the
+// gathers of a whole part are in flight behind the part's GEMMs.
+template <int F, int KPB, bool GEOM, bool MU0>
+__global__ __launch_bounds__(256, 1) void k_painn_msg_tile_bwd(MsgArgs a, int ntiles) {
+  constexpr int NT = F / 32;
+  constexpr int NB = 3 * NT;
+  constexpr int RSTR = 9;             // [32 edges][8 quad partials + 1 pad] per quantity
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW = smem;                                        // NB * KPB * 256 floats
+  TileRec* sE = (TileRec*)(sW + NB * KPB * 256);           // 4 waves x 32 records
+  float* sR = (float*)(sE + 4 * 32);                       // 4 waves x 4 quantities x 32 x RSTR
+  int* sCnt = (int*)(sR + 4 * 4 * 32 * RSTR);
+  const int K = a.rb.n_rbf;
+
+  stage_filter<NB * KPB * 64>(sW, a.wf, a.bf, K, KPB);
+  if (threadIdx.x == 0) sCnt[0] = 0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  TileRec* myE = sE + wv * 32;
+  float* myR = sR + wv * (4 * 32 * RSTR);
+  const int slot = slot_of_row(el);
+  constexpr unsigned F3 = 3u * F;
+
+  while (true) {
+    int nidx = 0;
+    if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
+    nidx = __builtin_amdgcn_readfirstlane(nidx);
+    const int tile = (int)blockIdx.x + nidx * (int)gridDim.x;
+    if (tile >= ntiles) break;
+
+    const int64_t e_first = (int64_t)tile * 32;
+    const int nvalid = (a.E - e_first) < 32 ? (int)(a.E - e_first) : 32;
+    const bool valid = slot < nvalid;
+    const int64_t e = e_first + (valid ? slot : (nvalid - 1));
+    const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+    const int ci = (int)a.idx_i[e], cj = (int)a.idx_j[e];
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float invd = 1.0f / d;
+    float fc, dfc;
+    spk_cutoff_eval_fast(a.rb.cutoff, d, fc, dfc);
+    if (!valid) { fc = 0.f; dfc = 0.f; }
+    if (hi == 0) {
+      TileRec rec; rec.i = ci; rec.j = cj; rec.ux = rx * invd; rec.uy = ry * invd; rec.uz = rz * invd; rec.invd = invd; rec.r0 = 0.f; rec.r1 = 0.f;
+      myE[slot] = rec;
+    }
+    float Av[KPB][4], Ad[KPB][4];
+#pragma unroll
+    for (int u = 0; u < KPB; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int k = 8 * u + 4 * hi + v;
+        float p, dp;
+        spk_rbf_eval_fast(a.rb, k, d, p, dp);
+        if (k == K) { p = 1.0f; dp = 0.f; }
+        Av[u][v] = fc * p;
+        Ad[u][v] = fc * dp + dfc * p;
+      }
+    spk_wave_lds_sync();
+    unsigned runmask = 0x8000u;
+    {
+      int prev = myE[16 * hi].i;
+#pragma unroll
+      for (int r = 1; r < 16; ++r) {
+        const int cur = myE[16 * hi + r].i;
+        if (cur != prev) runmask |= 1u << (r - 1);
+        prev = cur;
+      }
+    }
+    f32x16 sdd, stx, sty, stz;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sdd[r] = 0.f; stx[r] = 0.f; sty[r] = 0.f; stz[r] = 0.f; }
+
+#pragma unroll 1
+    for (int cb = 0; cb < NT; ++cb) {
+      const unsigned c0 = 32u * cb + el;
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- scalar part
+      {
+        f32x16 Pq = sdd;
+        if (!GEOM) Pq = tile_gemm<KPB>(sW, cb, Av, lane);
+        const f32x16 Dq = tile_gemm<KPB>(sW, cb, Ad, lane);
+        float accq = 0.f;
+#pragma unroll
+        for (int g0 = 0; g0 < 16; g0 += 4) {
+          float cq[4], gqa[4], gqb[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const TileRec er = myE[16 * hi + g0 + rr];
+            cq[rr] = a.c[(unsigned)er.j * F3 + c0];
+            gqa[rr] = a.gq_out[(unsigned)er.i * F + c0];
+            gqb[rr] = GEOM ? 0.f : a.gq_out[(unsigned)er.j * F + c0];
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int r = g0 + rr;
+            sdd[r] = fmaf(cq[rr] * gqa[rr], Dq[r], sdd[r]);
+            if (!GEOM) {
+              accq = fmaf(Pq[r], gqb[rr], accq);
+              if ((runmask >> r) & 1u) { unsafeAtomicAdd(a.gc + ((unsigned)myE[16 * hi + r].i * F3 + c0), accq); accq = 0.f; }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the gathers of one part at a time
+      // ---------------- R part
+      {
+        const f32x16 PR = tile_gemm<KPB>(sW, NT + cb, Av, lane);
+        const f32x16 DR = tile_gemm<KPB>(sW, NT + cb, Ad, lane);
+        float accR = 0.f;
+#pragma unroll
+        for (int g0 = 0; g0 < 16; g0 += 4) {
+          float cR[4], ga0[4], ga1[4], ga2[4], gb0[4], gb1[4], gb2[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const TileRec er = myE[16 * hi + g0 + rr];
+            const unsigned oj = (unsigned)er.j * F3 + c0, oi = (unsigned)er.i * F3 + c0;
+            cR[rr] = a.c[oj + F];
+            ga0[rr] = a.gmu_out[oi]; ga1[rr] = a.gmu_out[oi + F]; ga2[rr] = a.gmu_out[oi + 2 * F];
+            if (!GEOM) { gb0[rr] = a.gmu_out[oj]; gb1[rr] = a.gmu_out[oj + F]; gb2[rr] = a.gmu_out[oj + 2 * F]; }
+            else { gb0[rr] = 0.f; gb1[rr] = 0.f; gb2[rr] = 0.f; }
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int r = g0 + rr;
+            const TileRec er = myE[16 * hi + r];
+            const float gu = ga0[rr] * er.ux + ga1[rr] * er.uy + ga2[rr] * er.uz;
+            sdd[r] = fmaf(cR[rr] * gu, DR[r], sdd[r]);
+            const float mR = PR[r] * cR[rr];
+            stx[r] = fmaf(ga0[rr], mR, stx[r]); sty[r] = fmaf(ga1[rr], mR, sty[r]); stz[r] = fmaf(ga2[rr], mR, stz[r]);
+            if (!GEOM) {
+              accR = fmaf(-PR[r], gb0[rr] * er.ux + gb1[rr] * er.uy + gb2[rr] * er.uz, accR);
+              if ((runmask >> r) & 1u) { unsafeAtomicAdd(a.gc + ((unsigned)er.i * F3 + F + c0), accR); accR = 0.f; }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- mu part
+      if (!(GEOM && MU0)) {
+        f32x16 Pm = sdd, Dm = sdd;
+        if (!GEOM) Pm = tile_gemm<KPB>(sW, 2 * NT + cb, Av, lane);
+        if (!MU0) Dm = tile_gemm<KPB>(sW, 2 * NT + cb, Ad, lane);
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int g0 = 0; g0 < 16; g0 += 4) {
+          float cm[4], mb0[4], mb1[4], mb2[4], ga0[4], ga1[4], ga2[4], gb0[4], gb1[4], gb2[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const TileRec er = myE[16 * hi + g0 + rr];
+            const unsigned oj = (unsigned)er.j * F3 + c0, oi = (unsigned)er.i * F3 + c0;
+            if (!MU0) {
+              cm[rr] = a.c[oj + 2 * F];
+              mb0[rr] = a.mu[oj]; mb1[rr] = a.mu[oj + F]; mb2[rr] = a.mu[oj + 2 * F];
+              ga0[rr] = a.gmu_out[oi]; ga1[rr] = a.gmu_out[oi + F]; ga2[rr] = a.gmu_out[oi + 2 * F];
+            } else { cm[rr] = 0.f; mb0[rr] = 0.f; mb1[rr] = 0.f; mb2[rr] = 0.f; ga0[rr] = 0.f; ga1[rr] = 0.f; ga2[rr] = 0.f; }
+            if (!GEOM) { gb0[rr] = a.gmu_out[oj]; gb1[rr] = a.gmu_out[oj + F]; gb2[rr] = a.gmu_out[oj + 2 * F]; }
+            else { gb0[rr] = 0.f; gb1[rr] = 0.f; gb2[rr] = 0.f; }
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int r = g0 + rr;
+            if (!MU0) {
+              const float gm = ga0[rr] * mb0[rr] + ga1[rr] * mb1[rr] + ga2[rr] * mb2[rr];
+              sdd[r] = fmaf(cm[rr] * gm, Dm[r], sdd[r]);
+            }
+            if (!GEOM) {
+              v0 = fmaf(Pm[r], gb0[rr], v0); v1 = fmaf(Pm[r], gb1[rr], v1); v2 = fmaf(Pm[r], gb2[rr], v2);
+              if ((runmask >> r) & 1u) {
+                // gc[a][mu part] += mu_a . S,  gmu[a] += c_mu[a] S
+                const unsigned oi = (unsigned)myE[16 * hi + r].i * F3 + c0;
+                const float cma = a.c[oi + 2 * F];
+                if (!MU0) {
+                  const float ma0 = a.mu[oi], ma1 = a.mu[oi + F], ma2 = a.mu[oi + 2 * F];
+                  unsafeAtomicAdd(a.gc + oi + 2 * F, ma0 * v0 + ma1 * v1 + ma2 * v2);
+                }
+                unsafeAtomicAdd(a.gmu + oi, cma * v0);
+                unsafeAtomicAdd(a.gmu + oi + F, cma * v1);
+                unsafeAtomicAdd(a.gmu + oi + 2 * F, cma * v2);
+                v0 = 0.f; v1 = 0.f; v2 = 0.f;
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- per-edge sums over the 32 channel lanes of each half: quad sums by DPP, 8 partials per edge through LDS
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float w0 = sdd[r], w1 = stx[r], w2 = sty[r], w3 = stz[r];
+      w0 += __shfl_xor(w0, 1, 64); w1 += __shfl_xor(w1, 1, 64); w2 += __shfl_xor(w2, 1, 64); w3 += __shfl_xor(w3, 1, 64);
+      w0 += __shfl_xor(w0, 2, 64); w1 += __shfl_xor(w1, 2, 64); w2 += __shfl_xor(w2, 2, 64); w3 += __shfl_xor(w3, 2, 64);
+      if ((el & 3) == 0) {
+        float* dst = myR + (16 * hi + r) * RSTR + (el >> 2);
+        dst[0] = w0; dst[32 * RSTR] = w1; dst[2 * 32 * RSTR] = w2; dst[3 * 32 * RSTR] = w3;
+      }
+    }
+    spk_wave_lds_sync();
+    if (hi == 0 && valid) {
+      float dd = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+      const float* src = myR + slot * RSTR;
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) { dd += src[k2]; tx += src[32 * RSTR + k2]; ty += src[2 * 32 * RSTR + k2]; tz += src[3 * 32 * RSTR + k2]; }
+      if (d > 0.f) {
+        const float ux = rx * invd, uy = ry * invd, uz = rz * invd;
+        const float dot = tx * ux + ty * uy + tz * uz;
+        a.gr[3 * e] += dd * ux + (tx - dot * ux) * invd;
+        a.gr[3 * e + 1] += dd * uy + (ty - dot * uy) * invd;
+        a.gr[3 * e + 2] += dd * uz + (tz - dot * uz) * invd;
+      }
+    }
+    spk_wave_lds_sync();   // records / partials may be rewritten by the next tile
+  }
+}
+
 // the tile kernel accumulates with atomics: q_out = q, mu_out = mu first
 __global__ void k_msg_tile_init(const float* __restrict__ s0, float* __restrict__ d0, int64_t n0, const float* __restrict__ s1,
                                 float* __restrict__ d1, int64_t n1) {
   const int64_t n04 = n0 / 4, n14 = n1 / 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n04 + n14; k += (int64_t)gridDim.x * blockDim.x) {
-    if (k < n04) ((f32x4*)d0)[k] = ((const f32x4*)s0)[k];
-    else ((f32x4*)d1)[k - n04] = ((const f32x4*)s1)[k - n04];
+    if (k < n04) ((f32x4*)d0)[k] = s0 ? ((const f32x4*)s0)[k] : z4;
+    else ((f32x4*)d1)[k - n04] = s1 ? ((const f32x4*)s1)[k - n04] : z4;
   }
 }
 
@@ -213,6 +437,21 @@ int launch_tile(const MsgArgs& a, hipStream_t stream) {
   return SPK_OK;
 }
 
+template <int F, int KPB, bool GEOM, bool MU0>
+int launch_tile_bwd(const MsgArgs& a, hipStream_t stream) {
+  const int64_t nt = (a.E + 31) / 32;
+  const size_t lds = (size_t)(3 * (F / 32) * KPB * 256) * sizeof(float) + 4 * 32 * sizeof(TileRec) + 4 * 4 * 32 * 9 * sizeof(float) + 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile_bwd<F, KPB, GEOM, MU0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const int grid = spk_grid_for(nt, 4, spk_num_cus());
+  hipLaunchKernelGGL((k_painn_msg_tile_bwd<F, KPB, GEOM, MU0>), dim3(grid), dim3(256), lds, stream, a, (int)nt);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 int g_tile_mode = 0;   // 0 auto (large lists), 1 always when the shape allows, -1 never
 
 }  // namespace
@@ -222,7 +461,7 @@ extern "C" void spk_painn_set_tile(int32_t mode) { g_tile_mode = mode > 0 ? 1 : 
 bool spk_painn_msg_tile_ok(const MsgArgs& a) {
   const int kpb = a.rb.n_rbf / 8 + 1;    // room for the bias column
   if (g_tile_mode < 0 || !(a.F == 128 || a.F == 64) || kpb < 3 || kpb > 5 || a.E < 32 || a.N * 3 * (int64_t)a.F >= (1LL << 31)) return false;
-  return g_tile_mode > 0 || a.E >= (1 << 19);
+  return g_tile_mode > 0 || (a.E >= (1 << 19) && !a.skin_list);
 }
 
 int spk_painn_msg_tile_fwd(const MsgArgs& a, hipStream_t stream) {
@@ -236,4 +475,35 @@ int spk_painn_msg_tile_fwd(const MsgArgs& a, hipStream_t stream) {
 #undef SPK_TILE_CASE
   spk_set_error("painn message tile kernel: internal dispatch error (F=%d n_rbf=%d)", a.F, a.rb.n_rbf);
   return SPK_ERR_ARG;
+}
+
+// backward: gc = 0 and gmu = gmu_out first (unless only the geometry gradient is formed), then the tile kernel
+int spk_painn_msg_tile_bwd(const MsgArgs& a, hipStream_t stream) {
+  const int64_t nf = a.N * (int64_t)a.F;
+  if (!a.geom_only) {
+    hipLaunchKernelGGL(k_msg_tile_init, dim3(spk_grid_for(nf, 256, spk_num_cus() * 8)), dim3(256), 0, stream, (const float*)nullptr, a.gc, 3 * nf,
+                       a.gmu_out, a.gmu, 3 * nf);
+    SPK_LAUNCH_CHECK();
+  }
+  const int kpb = a.rb.n_rbf / 8 + 1;
+  const bool geom = a.geom_only != 0, mu0 = a.mu_zero != 0;
+#define SPK_TILE_CASE(Fv, Kv)                                                            \
+  if (a.F == Fv && kpb == Kv) {                                                          \
+    if (geom && mu0) return launch_tile_bwd<Fv, Kv, true, true>(a, stream);              \
+    if (geom) return launch_tile_bwd<Fv, Kv, true, false>(a, stream);                    \
+    if (mu0) return launch_tile_bwd<Fv, Kv, false, true>(a, stream);                     \
+    return launch_tile_bwd<Fv, Kv, false, false>(a, stream);                             \
+  }
+  SPK_TILE_CASE(128, 3) SPK_TILE_CASE(128, 4) SPK_TILE_CASE(64, 3) SPK_TILE_CASE(64, 4)
+#undef SPK_TILE_CASE
+  spk_set_error("painn message tile kernel (backward): no instance for F=%d n_rbf=%d", a.F, a.rb.n_rbf);
+  return SPK_ERR_ARG;
+}
+
+bool spk_painn_msg_tile_bwd_ok(const MsgArgs& a) {
+  const int kpb = a.rb.n_rbf / 8 + 1;
+  if (g_tile_mode < 0 || !(a.F == 128 || a.F == 64) || kpb < 3 || kpb > 4 || a.E < 32 || a.N * 3 * (int64_t)a.F >= (1LL << 31)) return false;
+  // measured (profiles/r01_painn_tile_experiment.json): the geometry-only variant (2 waves / SIMD, no spills) beats the row
+  // kernel by 25 %; the full variant needs the whole register file (1 wave / SIMD) and is 1.6 x slower than the row kernel
+  return g_tile_mode > 0 || (a.geom_only && !a.skin_list);
 }

@@ -270,7 +270,8 @@ int plan_list(spk_potential* p, int64_t N, int64_t E, bool want_filter) {
   g.rev = symmetric ? p->rev.as<int32_t>() : nullptr;
   g.half = (symmetric && n_half > 0) ? p->half.as<int32_t>() : nullptr;
   g.n_half = n_half;
-  g.filter_pairs = (want_filter && symmetric && n_half > 0 && p->h.kind == 0) ? 1 : 0;
+  // SchNet: per-call compaction of the pair list; PaiNN: hint that the list has a skin (keeps the row kernels, which mask dead pairs)
+  g.filter_pairs = (want_filter && (p->h.kind == 1 || (symmetric && n_half > 0))) ? 1 : 0;
   return SPK_OK;
 }
 

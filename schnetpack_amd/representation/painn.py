@@ -187,6 +187,9 @@ class PaiNN(nn.Module):
 
         if not self.training and self._fusable():
             plan = ops.edge_plan(idx_i, idx_j, n_atoms, r_ij)
+            if plan.filter_pairs is None and plan.n_edges >= (1 << 19):
+                # large lists: tells the message dispatch whether the list carries a skin (one sync per list)
+                plan.decide_filter(r_ij, self.cutoff_fn.cutoff_value())
             ms, keep = self._model_struct()
             rb_args = self.radial_basis.kernel_args(self.cutoff_fn.cutoff_value())
             # eval path: geometry gradients only (embedding / weights are not differentiated)

@@ -18,7 +18,10 @@ import csv, glob, collections, json, re
 TAGS = [("cfconv_fwd_pair", r"k_cfconv_pair<.*false, false, false>|k_cfconv_pair<[^>]*false, false>"),
         ("cfconv_bwd_pair_gs", r"k_cfconv_pair_t<"), ("cfconv_bwd_pair", r"k_cfconv_pair<.*true"),
         ("cfconv_fwd_mfma", r"k_cfconv_mfma<[^>]*false"), ("cfconv_bwd_mfma", r"k_cfconv_mfma<[^>]*true"),
-        ("painn_msg_fwd_row", r"k_painn_msg_row<[^>]*false>"), ("painn_msg_bwd_row", r"k_painn_msg_row<[^>]*true>"),
+        ("painn_msg_fwd_row", r"k_painn_msg_row<\d+, \d+, false, false, false>"), ("painn_msg_bwd_row", r"k_painn_msg_row<\d+, \d+, true, false, false>"),
+        ("painn_msg_fwd_row_mu0", r"k_painn_msg_row<\d+, \d+, false, false, true>"), ("painn_msg_bwd_row_geom", r"k_painn_msg_row<\d+, \d+, true, true"),
+        ("painn_msg_fwd_tile", r"k_painn_msg_tile<"), ("painn_msg_bwd_tile", r"k_painn_msg_tile_bwd<\d+, \d+, false"),
+        ("painn_msg_bwd_tile_geom", r"k_painn_msg_tile_bwd<\d+, \d+, true"),
         ("dense_chain", r"k_dense_chain"), ("scatter_add_segsum", r"k_segsum<4>")]
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -445,13 +445,19 @@ def test_painn_message_forward_backward(dev, variant, graph, F, n_rbf):
         L.spk_painn_set_tile(0)
     gc = torch.empty(N, 3 * F, device=dev)
     gmu_in = torch.empty(N, 3, F, device=dev)
-    gr = torch.zeros(r.shape[0], 3, device=dev)
-    _lib.check(L.spk_painn_message_bwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(mud), _lib.fptr(gqd), _lib.fptr(gmud),
-                                           _lib.fptr(rd), _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(gc), _lib.fptr(gmu_in), _lib.fptr(gr),
-                                           _lib.stream()))
-    assert rel_err(gc.cpu(), gco) < TOL
-    assert rel_err(gmu_in.cpu(), gmuo) < TOL
-    assert rel_err(gr.cpu(), gro) < TOL
+    try:
+        for mode in (-1, 1):     # row kernel, MFMA tile kernel (where the shape / list has one)
+            L.spk_painn_set_tile(mode)
+            gc.fill_(float("nan")); gmu_in.fill_(float("nan"))
+            gr = torch.zeros(r.shape[0], 3, device=dev)
+            _lib.check(L.spk_painn_message_bwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(mud), _lib.fptr(gqd), _lib.fptr(gmud),
+                                                   _lib.fptr(rd), _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(gc), _lib.fptr(gmu_in), _lib.fptr(gr),
+                                                   _lib.stream()))
+            assert rel_err(gc.cpu(), gco) < TOL, mode
+            assert rel_err(gmu_in.cpu(), gmuo) < TOL, mode
+            assert rel_err(gr.cpu(), gro) < TOL, mode
+    finally:
+        L.spk_painn_set_tile(0)
 
 
 def test_painn_mixing_elementwise(dev):
