@@ -12,12 +12,7 @@
 // pre-initialised with q / mu).  Matrix row m of the tile is edge slot 16 (m>>2 & 1) + (m & 3) + 4 (m >> 3), which
 // makes the 16 registers of a half-wave 16 CONSECUTIVE edges: a row of the list is split over as few runs as possible.
 //
-// Measured (profiles/README.md, round 1): 693 us against 832 us for the row kernel on the 1.71 M-edge water box,
-// 62 us against 59 us on the 78 k-edge aspirin batch -- both kernels move the same 3 KB of neighbour rows per edge
-// through the L1/L2 gather path (~7.5 TB/s here), which is the real bound, so taking the filter off the VALU buys
-// little.  The dispatcher therefore uses this kernel for large lists only (E >= 2^19) unless forced with
-// spk_painn_set_tile().  A backward in the same style (second GEMM for d(Phi fcut)/dd, 14 gathered rows per edge
-// and channel instead of the row kernel's 10) was measured 4x slower than the row kernel and is not kept.
+// Measurements and the dispatch rules that follow from them: DESIGN.md section 4.3, profiles/r01_painn_tile_experiment.json.
 #include "spk_painn_msg.h"
 
 #define SPK_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
