@@ -23,6 +23,22 @@ int spk_dense_internal(const float* in, const float* pre_in, const float* w, con
 // two channels per VALU lane and cycle -- the fp32 vector peak of the CU assumes them; the scalar form of the
 // backward issued 445 v_fma + 98 v_pk_fma per edge).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Sum over the 64 lanes without the LDS crossbar: four DPP adds give every lane the sum of its row of 16 (VALU latency
+// instead of four dependent ds_bpermute round trips), the four row sums are then read from lanes 15 / 31 / 47 / 63.  The
+// result is wave-uniform.  (The backward row kernel needs four such sums per edge; with __shfl_xor they were its longest
+// dependency chain.)
+__device__ __forceinline__ float spk_row16_sum_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float spk_wave_sum_dpp(float v) {
+  v = spk_row16_sum_dpp(v);
+  return (spk_readlane_f(v, 15) + spk_readlane_f(v, 31)) + (spk_readlane_f(v, 47) + spk_readlane_f(v, 63));
+}
+
 template <int VPL> struct MsgVec;
 template <> struct MsgVec<1> {
   typedef float T;
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
               const VT ddv = cq * gqa * dFq + cR * gu * dFR + cm * gm * dFm;
               const VT mR = FR * cR;
               float dd = MV::sum(ddv), tux = MV::sum(gma[0] * mR), tuy = MV::sum(gma[1] * mR), tuz = MV::sum(gma[2] * mR);
-              dd = spk_wave_sum(dd); tux = spk_wave_sum(tux); tuy = spk_wave_sum(tuy); tuz = spk_wave_sum(tuz);
+              dd = spk_wave_sum_dpp(dd); tux = spk_wave_sum_dpp(tux); tuy = spk_wave_sum_dpp(tuy); tuz = spk_wave_sum_dpp(tuz);
               if (lane == t) {
                 const float dot = tux * ux + tuy * uy + tuz * uz;
                 const float invd = 1.0f / d;
