@@ -58,6 +58,13 @@ __device__ __forceinline__ f32x16 tile_gemm(const float* __restrict__ sW, int t,
   return acc;
 }
 
+// sum over the 4 lanes of a quad with DPP (quad_perm [1,0,3,2] then [2,3,0,1]): VALU modifiers, no LDS crossbar round trip
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
+
 // edge slot handled by lane el (as matrix row el) -- see the file comment
 __device__ __forceinline__ int slot_of_row(int el) { return 16 * ((el >> 2) & 1) + (el & 3) + 4 * (el >> 3); }
 
@@ -380,9 +387,7 @@ __global__ __launch_bounds__(256, 1) void k_painn_msg_tile_bwd(MsgArgs a, int nt
     // ---- per-edge sums over the 32 channel lanes of each half: quad sums by DPP, 8 partials per edge through LDS
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float w0 = sdd[r], w1 = stx[r], w2 = sty[r], w3 = stz[r];
-      w0 += __shfl_xor(w0, 1, 64); w1 += __shfl_xor(w1, 1, 64); w2 += __shfl_xor(w2, 1, 64); w3 += __shfl_xor(w3, 1, 64);
-      w0 += __shfl_xor(w0, 2, 64); w1 += __shfl_xor(w1, 2, 64); w2 += __shfl_xor(w2, 2, 64); w3 += __shfl_xor(w3, 2, 64);
+      const float w0 = quad_sum(sdd[r]), w1 = quad_sum(stx[r]), w2 = quad_sum(sty[r]), w3 = quad_sum(stz[r]);
       if ((el & 3) == 0) {
         float* dst = myR + (16 * hi + r) * RSTR + (el >> 2);
         dst[0] = w0; dst[32 * RSTR] = w1; dst[2 * 32 * RSTR] = w2; dst[3 * 32 * RSTR] = w3;
