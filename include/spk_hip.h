@@ -363,9 +363,11 @@ int spk_painn_message_bwd_f32(const spk_graph_t* g, const spk_radial_t* rb, cons
                               const float* r_ij, const float* wf, const float* bf, int32_t F,
                               float* gc, float* gmu, float* gr, void* stream);
 
-/* Forward message kernel selection: 0 = automatic (the MFMA tile kernel for lists of >= 2^19 edges, where it was
- * measured faster than the row kernel), 1 = tile kernel whenever the shape has one (F in {64, 128}, 16 <= n_rbf <= 39,
- * sorted list), -1 = never.  Both compute the same function; the tests run each against the oracle. */
+/* Message kernel family: 0 = automatic -- the MFMA tile kernels where they were measured faster than the row kernels
+ * (forward: lists of >= 2^19 edges without a skin; backward: the geometry-only launch of the first interaction of an
+ * eval-mode backward, lists without a skin), 1 = tile kernels whenever the shape has one (F in {64, 128},
+ * 16 <= n_rbf <= 39 forward / <= 31 backward, sorted (+ symmetric) list), -1 = never.  All compute the same function; the
+ * tests run each family against the oracle and the reference fixtures. */
 void spk_painn_set_tile(int32_t mode);
 
 /* representation/painn.py:92-117 -- the elementwise parts of PaiNNMixing around its three
