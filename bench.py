@@ -197,7 +197,7 @@ def main():
         "cfconv_fwd_pair": ("mfma", flop_fwd, 0.5),
         "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd, 1.0), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd, 1.0),
         "cfconv_bwd_simple": ("mfma", 2 * flop_fwd, 1.0), "cfconv_bwd_pair": ("mfma", 2 * flop_fwd, 0.5),
-        "cfconv_bwd_pair_gs": ("mfma", 2 * flop_fwd, 0.5 * 352.0 / 608.0),
+        "cfconv_bwd_pair_gs": ("mfma", 2 * flop_fwd, 0.5 * 352.0 / 608.0), "cfconv_bwd_pair_gs_geom": ("mfma", 2 * flop_fwd, 0.5 * 352.0 / 608.0),
         "painn_msg_fwd_row": ("hbm", msg_bytes, 1.0), "painn_msg_fwd_simple": ("hbm", msg_bytes, 1.0),
         "painn_msg_bwd_row": ("hbm", 2 * msg_bytes, 1.0), "painn_msg_bwd_simple": ("hbm", 2 * msg_bytes, 1.0),
         "painn_msg_fwd_tile": ("hbm", msg_bytes, 1.0),

@@ -34,6 +34,7 @@ struct CfArgs {
   float* y;            // fwd: [N, NF] (pre-zeroed);  bwd: gh [N, NF] (pre-zeroed)
   float* gr;           // bwd: [E, 3] accumulated (pair kernels: assigned when gr_assign != 0)
   int gr_assign;       // pair kernels write every edge exactly once: the first interaction of a backward can assign
+  int skip_gh;         // saved-filter pair backward: dL/dh is not needed (first interaction of an eval-mode backward) => no transposed sum
   int64_t E;
   int64_t N;
   long long* dbg;       // optional: cycle stamps of wave 0 / workgroup 0 (kernel tuning aid)
@@ -684,7 +685,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
 // go through a per-wave LDS transposition buffer before the segmented flush).  Its per-pair sums over
 // channels are per-LANE sums over registers, which saves ~30 VGPRs against the lane = channel layout:
 // the saved-filter backward fits 2 waves/SIMD only in this form, so it is the one dispatched for it.
-template <int NF, int KPB, int NWAVES, bool BWD, bool GS>
+// SKIPGH (saved-filter backward only): dL/dh is not wanted -- no transposition, no transposed sum, no atomics
+template <int NF, int KPB, int NWAVES, bool BWD, bool GS, bool SKIPGH = false>
 __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_t(CfArgs a) {
   constexpr int NT = NF / 32;
   constexpr int KB2 = NF / 8;
@@ -860,9 +862,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_t(CfArgs a) {
           pA.x = W0 * gyj.x; pA.y = W1v * gyj.y; pA.z = W2v * gyj.z; pA.w = W3 * gyj.w;
           pB.x = W0 * gyi.x; pB.y = W1v * gyi.y; pB.z = W2v * gyi.z; pB.w = W3 * gyi.w;
         }
-        *(f32x4*)(myT + el * TP2 + 8 * q + 4 * hi) = pA;
-        *(f32x4*)(myT + el * TP2 + 32 + 8 * q + 4 * hi) = pB;
+        if (!SKIPGH) {
+          *(f32x4*)(myT + el * TP2 + 8 * q + 4 * hi) = pA;
+          *(f32x4*)(myT + el * TP2 + 32 + 8 * q + 4 * hi) = pB;
+        }
       }
+      if (SKIPGH) continue;   // geometry gradient only: nothing to scatter
       spk_wave_lds_sync();
       {
         float v[32];
@@ -965,10 +970,11 @@ template <int NF, int KPB>
 static int launch_pair_t_bwd_gs(const CfArgs& a, hipStream_t stream) {
   constexpr int NWAVES = 8;
   const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + NWAVES * 32 * TP2) * sizeof(float) + 4 * sizeof(int);
-  auto kern = k_cfconv_pair_t<NF, KPB, NWAVES, true, true>;
+  auto kern = a.skip_gh ? k_cfconv_pair_t<NF, KPB, NWAVES, true, true, true> : k_cfconv_pair_t<NF, KPB, NWAVES, true, true, false>;
   static bool attr_set = false;
   if (!attr_set) {
-    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_cfconv_pair_t<NF, KPB, NWAVES, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_cfconv_pair_t<NF, KPB, NWAVES, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const int64_t ntiles = (a.n_half + 31) / 32;
@@ -976,7 +982,7 @@ static int launch_pair_t_bwd_gs(const CfArgs& a, hipStream_t stream) {
   const int maxg = spk_num_cus();
   if (grid > maxg) grid = maxg;
   if (grid < 1) grid = 1;
-  SpkProfScope prof("cfconv_bwd_pair_gs", stream);
+  SpkProfScope prof(a.skip_gh ? "cfconv_bwd_pair_gs_geom" : "cfconv_bwd_pair_gs", stream);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
@@ -1111,7 +1117,7 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(h && r_ij && w1 && b1 && w2 && b2, "%s: null pointer", who);
   CfArgs a;
   a.h = h; a.gy = nullptr; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr; a.gr_assign = 0; a.gsave = gsave; a.gload = nullptr; a.dbg = spk_cf_debug_buffer();
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.gr = nullptr; a.gr_assign = 0; a.skip_gh = 0; a.gsave = gsave; a.gload = nullptr; a.dbg = spk_cf_debug_buffer();
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half; a.n_half_dev = g->n_half_dev;
   a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
@@ -1121,7 +1127,7 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
 int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
                             const float* gy, const float* r_ij, const float* w1, const float* b1,
                             const float* w2, const float* b2, int nf, float* gh, float* gr,
-                            hipStream_t stream, bool pre_zeroed, const float* gload, bool gr_assign) {
+                            hipStream_t stream, bool pre_zeroed, const float* gload, bool gr_assign, bool want_gh) {
   const char* who = "spk_schnet_cfconv_bwd_f32";
   int rc = check_graph(g, who);
   if (rc) return rc;
@@ -1134,7 +1140,7 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   SPK_CHECK_ARG(h && gy && r_ij && w1 && b1 && w2 && b2 && gr, "%s: null pointer", who);
   CfArgs a;
   a.h = h; a.gy = gy; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr; a.gr_assign = (gr_assign && !g->n_half_dev && spk_cfconv_gsave_floats(g, rb, nf) > 0) ? 1 : 0; a.gsave = nullptr; a.gload = gload; a.dbg = spk_cf_debug_buffer();
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = gh; a.gr = gr; a.skip_gh = want_gh ? 0 : 1; a.gr_assign = (gr_assign && !g->n_half_dev && spk_cfconv_gsave_floats(g, rb, nf) > 0) ? 1 : 0; a.gsave = nullptr; a.gload = gload; a.dbg = spk_cf_debug_buffer();
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half; a.n_half_dev = g->n_half_dev;
   a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
@@ -1155,5 +1161,5 @@ extern "C" int spk_schnet_cfconv_bwd_f32(const spk_graph_t* g, const spk_radial_
                                          const float* w1, const float* b1, const float* w2,
                                          const float* b2, int32_t nf, float* gh, float* gr,
                                          void* stream) {
-  return spk_cfconv_bwd_internal(g, rb, h, gy, r_ij, w1, b1, w2, b2, nf, gh, gr, (hipStream_t)stream, false, nullptr, false);
+  return spk_cfconv_bwd_internal(g, rb, h, gy, r_ij, w1, b1, w2, b2, nf, gh, gr, (hipStream_t)stream, false, nullptr, false, true);
 }

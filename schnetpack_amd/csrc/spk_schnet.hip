@@ -13,7 +13,7 @@ int64_t spk_cfconv_gsave_floats(const spk_graph_t* g, const spk_radial_t* rb, in
 int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
                             const float* gy, const float* r_ij, const float* w1, const float* b1,
                             const float* w2, const float* b2, int nf, float* gh, float* gr,
-                            hipStream_t stream, bool pre_zeroed, const float* gload, bool gr_assign);
+                            hipStream_t stream, bool pre_zeroed, const float* gload, bool gr_assign, bool want_gh);
 
 static int check_model(const spk_schnet_t* m, const char* who) {
   SPK_CHECK_ARG(m != nullptr && m->layers != nullptr, "%s: null model", who);
@@ -215,8 +215,9 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
     const spk_schnet_layer_t& P = m->layers[l];
     float* gh = ghbuf[l & 1];
     SPK_TRY(spk_cfconv_bwd_internal(filtered ? &gact : g, rb, hbuf(l), gy, r_ij, P.fn_w1, P.fn_b1, P.fn_w2, P.fn_b2, NF, gh, gr, stream, true,
-                                    gsz > 0 ? gbase + l * gsz : nullptr, gr_assign && l == L - 1));
-    if (l == 0 && !gx0) break;  // dL/dx0 not requested (eval path): nothing below feeds dL/dr_ij
+                                    gsz > 0 ? gbase + l * gsz : nullptr, gr_assign && l == L - 1, !(l == 0 && !gx0)));
+    if (l == 0 && !gx0) break;  // dL/dx0 not requested (eval path): nothing below feeds dL/dr_ij, and the edge kernel
+                                // above was told not to form dL/dh (no transposed sum, no atomics)
     float* out = (l == 0) ? gx0 : gxb;
     spk_chain_t c = {};
     c.m = N; c.in = gh; c.tmp[0] = tmp0; c.tmp[1] = tmp1;
