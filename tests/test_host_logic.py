@@ -133,3 +133,24 @@ def test_synthetic_batch_shapes_cfg2():
     assert b["idx_i"].dtype == torch.int64
     deg = torch.bincount(b["idx_i"], minlength=336).float().mean()
     assert 12.0 < float(deg) < 17.0  # ~14.5 neighbours within 5 A
+
+
+def test_bench_refuses_to_run_without_a_device():
+    """bench.py measures the HIP path only: on a box without a ROCm device it exits non-zero and prints no metric line."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("a ROCm device is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
+    assert '"metric"' not in res.stdout
+    assert "no CPU fallback" in res.stderr
+
+
+def test_bench_ranks_kernel_families_not_template_variants():
+    """The dominant-kernel rule of bench.py groups the compile-time variants of a kernel (text check: the rule is
+    part of the measurement contract described in DESIGN.md section 5)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    assert 'replace("_geom", "")' in src and 'replace("_mu0", "")' in src
