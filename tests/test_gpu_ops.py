@@ -403,7 +403,7 @@ def _msg_oracle(c, q, mu, r, idx_i, idx_j, wf, bf, n_atoms, F, gq, gmu):
 
 
 @pytest.mark.parametrize("graph", ["aspirin_sym", "random_sorted", "random_unsorted"])
-@pytest.mark.parametrize("F,n_rbf", [(128, 20), (64, 20), (128, 25), (96, 20)])
+@pytest.mark.parametrize("F,n_rbf", [(128, 20), (64, 20), (128, 25), (128, 32), (64, 16), (96, 20)])
 def test_painn_message_forward_backward(dev, variant, graph, F, n_rbf):
     from schnetpack_amd import _lib, ops
     g = torch.Generator().manual_seed(21)
