@@ -253,7 +253,7 @@ def test_runtime_argument_errors():
 @pytest.mark.gpu
 def test_plain_c_program_links_the_library_alone(tmp_path):
     """examples/native/spk_run.c (gcc, no Python / torch in the process) loads the file and reproduces the
-    ctypes-driven runtime bit for bit; what a LAMMPS pair style would do."""
+    ctypes-driven runtime; what a LAMMPS pair style would do."""
     import os
     import subprocess
     from schnetpack_amd.csrc import build as B
@@ -282,5 +282,6 @@ def test_plain_c_program_links_the_library_alone(tmp_path):
             F[int(w[1])] = [np.float32(x) for x in w[2:5]]
     pot = deploy.DeployedPotential(str(path))
     E2, F2 = pot.compute_cell(Z, R, cell, pbc)
-    assert E == E2[0] and np.array_equal(F, F2)
+    # same kernels, same inputs: equal up to the order of the few float atomics of the molecule sum
+    assert abs(float(E) - float(E2[0])) <= 2e-6 * abs(float(E2[0])) and np.abs(F - F2).max() <= 2e-6 * np.abs(F2).max()
     assert "PaiNN" in res.stderr
