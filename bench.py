@@ -51,16 +51,229 @@ def parse():
                          "loss on --train-frames aspirin frames per GPU, gradients averaged with one flat all-reduce")
     ap.add_argument("--train-frames", type=int, default=8)
     ap.add_argument("--variant", default="auto", choices=["auto", "simple", "mfma", "directed", "pair", "mol"])
+    ap.add_argument("--no-md", action="store_true", help="skip the `md` sub-object (ns/day of the on-device NVE loop) of the default line")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the `sweep` sub-object (padded-neighbour k = 16/32/64 graphs)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect the HBM counters of the dominant kernel in this run")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the few eager force calls rocprofv3 --pmc wraps
+    ap.add_argument("--md-steps", type=int, default=200)
+    ap.add_argument("--dry-run", action="store_true", help="rank wiring only (launcher, process group, barrier, max-over-ranks reduction), no device work: for the CPU test of --gpus N")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def dry_run(args, rank, world):
+    """The multi-rank control flow of the bench without device work (CPU test of `--gpus N`): process group, barrier,
+    max-over-ranks time, sum-over-ranks units; rank 0 prints a line marked `dry_run` that carries no measurement."""
+    import torch.distributed as dist
+    tmax, units = 1.0 + rank, 1.0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("SPK_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+        dist.barrier()
+        t = torch.tensor([tmax, units], dtype=torch.float64)
+        tm = t.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tmax, units = float(tm[0]), float(t[1])
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": None, "value": None, "n_gpus": world, "max_over_ranks": tmax, "units_over_ranks": units,
+                          "backend": dist.get_backend() if world > 1 else None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks exactly the way the driver would
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), one rank per GPU
+    over RCCL, and pass rank 0's JSON line through.  Fails loudly when the node has fewer devices."""
+    import subprocess
+    backend = os.environ.get("SPK_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and have < args.gpus and not args.dry_run:
+        raise SystemExit("bench.py --gpus %d: only %d ROCm device(s) visible (one rank per GPU; set SPK_BENCH_BACKEND=gloo to "
+                         "let ranks share a device for a control-flow test)" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# rocprofv3 kernel-name patterns of the profile tags (spk_profile_report) -- used to attribute PMC counters
+PMC_TAGS = [
+    ("cfconv_fwd_pair", r"k_cfconv_pair<[^>]*false, false, false>"), ("cfconv_bwd_pair_gs_geom", r"k_cfconv_pair_t<[^>]*true, true, true>"),
+    ("cfconv_bwd_pair_gs", r"k_cfconv_pair_t<[^>]*true, true, false>"), ("cfconv_bwd_pair", r"k_cfconv_pair_t<[^>]*true, false"),
+    ("cfconv_fwd_mol", r"k_cfconv_mol<[^>]*false>"), ("cfconv_bwd_mol", r"k_cfconv_mol<[^>]*true>"),
+    ("cfconv_fwd_mfma", r"k_cfconv_mfma<[^>]*false, (true|false)>"), ("cfconv_bwd_mfma_sym", r"k_cfconv_mfma<[^>]*true, true>"),
+    ("cfconv_bwd_mfma_atomic", r"k_cfconv_mfma<[^>]*true, false>"),
+    ("painn_msg_fwd_row", r"k_painn_msg_row<\d+, \d+, false, false, false>"), ("painn_msg_bwd_row", r"k_painn_msg_row<\d+, \d+, true, false, false>"),
+    ("painn_msg_fwd_row_mu0", r"k_painn_msg_row<\d+, \d+, false, false, true>"), ("painn_msg_bwd_row_geom", r"k_painn_msg_row<\d+, \d+, true, true"),
+    ("painn_msg_fwd_tile_mu0", r"k_painn_msg_tile<\d+, \d+, true"), ("painn_msg_fwd_tile", r"k_painn_msg_tile<"),
+    ("painn_msg_bwd_tile_geom", r"k_painn_msg_tile_bwd<\d+, \d+, true"), ("painn_msg_bwd_tile", r"k_painn_msg_tile_bwd<\d+, \d+, false"),
+    ("painn_mixing_fwd", r"k_painn_mixing_fwd"), ("painn_mixing_bwd", r"k_painn_mixing_bwd"),
+    ("dense_chain", r"k_dense_chain"), ("scatter_add_segsum", r"k_segsum<4>"),
+]
+
+
+def csrc_digest():
+    """sha256 (16 hex digits) over the kernel sources: ties a PMC record to the kernel revision it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "schnetpack_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def collect_pmc(args, timeout_s=170):
+    """HBM-side traffic per launch of every hot kernel, measured IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE and
+    WRITE_SIZE do not share a pass on gfx950; kernel-trace only) over a child of this script that runs three eager force
+    calls of the same workload.  Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: KiB per
+    dispatch, FETCH_SIZE x 2 on gfx950.  Returns {tag: {"read_bytes", "write_bytes", "kernel_name", "launches"}} or None."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="spk_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--kind", args.kind, "--workload", args.workload,
+                   "--frames", str(args.frames), "--water-side", str(args.water_side), "--variant", args.variant]
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)
+                p.wait()
+                return None
+            if rc != 0:
+                return None
+            acc, cnt, names = {}, {}, {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    name = row["Kernel_Name"]
+                    for tag, pat in PMC_TAGS:
+                        if re.search(pat, name):
+                            acc[tag] = acc.get(tag, 0.0) + float(row["Counter_Value"])
+                            cnt[tag] = cnt.get(tag, 0) + 1
+                            names[tag] = name[:100]
+                            break
+            for tag in acc:
+                r = res.setdefault(tag, {"kernel_name": names[tag]})
+                per = 1024.0 * acc[tag] / cnt[tag]
+                if counter == "FETCH_SIZE":
+                    r["read_bytes"] = 2.0 * per
+                else:
+                    r["write_bytes"] = per
+                r["launches_" + counter] = cnt[tag]
+    except Exception as exc:  # pragma: no cover - depends on the profiler
+        sys.stderr.write("[bench] PMC pass failed: %s\n" % exc)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res or None
+
+
+def reference_model(kind, rep_p, head_p, F, n_int, n_rbf, cutoff):
+    """The REFERENCE's own modules (NeuralNetworkPotential + PairwiseDistances + SchNet/PaiNN + Atomwise + Forces,
+    configs/model/nnp.yaml) through oracle/refshim.py (from /root/reference, or its byte-compiled build oracle/_ref on
+    the GPU box) with the given weights, on the CPU.  None when the reference is not available."""
+    try:
+        from oracle import refshim              # test infrastructure: used only for the cpu_baseline leg
+        if not refshim.available():
+            return None
+        ns = refshim.load()
+        rb, cf = ns.nn.GaussianRBF(n_rbf, cutoff), ns.nn.CosineCutoff(cutoff)
+        rep = (ns.schnet.SchNet if kind == "schnet" else ns.painn.PaiNN)(F, n_int, rb, cf)
+        aw = ns.atomwise.Atomwise(n_in=F, output_key="energy")
+        m = ns.model.NeuralNetworkPotential(rep, input_modules=[ns.distances.PairwiseDistances()], output_modules=[aw, ns.response.Forces()])
+        m.representation.load_state_dict(rep_p)
+        m.output_modules[0].load_state_dict(head_p)
+        return m.eval()
+    except Exception as exc:  # pragma: no cover
+        sys.stderr.write("[bench] reference modules unavailable (%s); cpu_baseline falls back to the oracle port\n" % exc)
+        return None
+
+
+def reference_inputs(batch):
+    n_mol = int(batch["n_mol"])
+    return {"_atomic_numbers": batch["Z"], "_positions": batch["R"].clone(), "_idx_i": batch["idx_i"], "_idx_j": batch["idx_j"],
+            "_offsets": batch["offsets"], "_idx_m": batch["idx_m"],
+            "_cell": batch["cell"].reshape(1, 3, 3) if "cell" in batch else torch.zeros(n_mol, 3, 3),
+            "_pbc": torch.zeros(3 * n_mol, dtype=torch.bool), "_n_atoms": torch.bincount(batch["idx_m"], minlength=n_mol)}
+
+
+def sweep_measure(model, dev, kind, n_atoms=16384, degrees=(16, 32, 64), reps=10):
+    """north_star's padded-neighbour sweep: fixed-degree graphs of stated (N, E = N k, F), representation forward +
+    first-order backward w.r.t. r_ij (what a force call asks of the hot path), eager launches timed with events.
+    `symmetric`: every atom is linked to its k nearest ring neighbours with antisymmetric pair vectors (the full,
+    symmetric, i-sorted structure every reference neighbour list has); `asymmetric`: random directed graph (general path)."""
+    from schnetpack_amd import synthetic as S
+    rep = model.representation
+    F = rep.n_atom_basis
+    n_int = len(rep.interactions)
+    rows = []
+    for sym in (True, False):
+        for k in (degrees if sym else degrees[1:2]):
+            b = S.ring_graph_batch(n_atoms, k, seed=k) if sym else S.random_graph_batch(n_atoms, k, seed=k)
+            inp = {"_atomic_numbers": b["Z"].to(dev), "_idx_i": b["idx_i"].to(dev), "_idx_j": b["idx_j"].to(dev)}
+            r = b["r_ij"].to(dev).requires_grad_(True)
+
+            def call():
+                d = dict(inp)
+                d["_Rij"] = r
+                x = rep(d)["scalar_representation"]
+                return torch.autograd.grad([x.sum()], [r])[0]
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            E = int(b["idx_i"].shape[0])
+            rows.append({"list": "symmetric" if sym else "asymmetric", "N": n_atoms, "k": k, "E": E, "F": F,
+                         "ms_fwd_bwd": round(ms, 4), "M_edge_messages_per_s": round(E * n_int / ms / 1e3, 1)})
+    return {"kind": kind, "what": "representation forward + backward w.r.t. r_ij on fixed-degree graphs, eager launches, per GPU", "rows": rows}
 
 
 def main():
     import faulthandler
     faulthandler.enable()
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (there is no CPU fallback of the product path)")
     local = local % torch.cuda.device_count()      # (several ranks may share a device in the gloo self-test)
@@ -77,6 +290,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from schnetpack_amd import _lib, model as M, synthetic as S
     from schnetpack_amd.parallel import shard_frames
@@ -115,6 +329,12 @@ def main():
         # detach: a live autograd graph from an earlier (default-stream) call would be pulled into
         # the HIP-graph capture through the AccumulateGrad node of the positions
         return out["energy"].detach(), out["forces"].detach()
+
+    if args.pmc_child:          # wrapped by `rocprofv3 --pmc` from collect_pmc(): a few eager calls, no output
+        for _ in range(3):
+            force_call()
+        torch.cuda.synchronize()
+        return
 
     for _ in range(max(args.warmup, 3)):
         e_ref, f_ref = force_call()
@@ -236,21 +456,34 @@ def main():
                     "note": "achieved = algorithmic work / HIP-event time of the launch; executed_frac_of_peak counts only the "
                             "work the kernel really issues (pair kernels evaluate one filter per undirected edge)"}
 
-    # HBM traffic of the dominant kernel from the committed PMC pass of this workload (scripts/gpu_pmc_traffic.sh:
-    # separate --pmc passes for FETCH_SIZE and WRITE_SIZE; KiB per dispatch; gfx950 correction: FETCH_SIZE x 2)
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_%s_%s.json" % (args.kind, args.workload))
-    if roofline is not None and os.path.exists(pmc_file):
-        try:
-            c = json.load(open(pmc_file))["counters"].get(roofline["kernel"])
-            if c and "FETCH_SIZE_raw_per_launch" in c and "WRITE_SIZE_raw_per_launch" in c:
-                rd = 2.0 * 1024.0 * c["FETCH_SIZE_raw_per_launch"]
-                wr = 1024.0 * c["WRITE_SIZE_raw_per_launch"]
-                roofline["traffic"] = rd + wr
-                roofline["traffic_detail"] = {"read_bytes": rd, "write_bytes": wr, "source": os.path.relpath(pmc_file, ROOT),
-                                              "note": "rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch, collected "
-                                                      "in separate --pmc passes of this command; Infinity-Cache hits are counted"}
-        except Exception as exc:  # pragma: no cover
-            sys.stderr.write("[bench] could not read %s: %s\n" % (pmc_file, exc))
+    # HBM traffic of the dominant kernel, measured in THIS run (collect_pmc: two `rocprofv3 --pmc` passes over a child of
+    # this script); the committed record of an earlier run is only the fallback, and says which kernel revision it is from
+    pmc = None
+    if roofline is not None and world == 1 and not args.no_pmc:
+        pmc = collect_pmc(args)
+    if roofline is not None and pmc is not None and roofline["kernel"] in pmc and "read_bytes" in pmc[roofline["kernel"]] and "write_bytes" in pmc[roofline["kernel"]]:
+        c = pmc[roofline["kernel"]]
+        roofline["traffic"] = c["read_bytes"] + c["write_bytes"]
+        roofline["traffic_detail"] = {"read_bytes": c["read_bytes"], "write_bytes": c["write_bytes"], "kernel_name": c["kernel_name"],
+                                      "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over 3 eager "
+                                                "force calls of this workload; KiB per dispatch, FETCH_SIZE x 2 (gfx950); Infinity-Cache hits are counted",
+                                      "csrc_digest": csrc_digest(),
+                                      "all_kernels": {t: {"read_bytes": v.get("read_bytes"), "write_bytes": v.get("write_bytes")} for t, v in pmc.items()}}
+    else:
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_%s_%s.json" % (args.kind, args.workload))
+        if roofline is not None and os.path.exists(pmc_file):
+            try:
+                rec = json.load(open(pmc_file))
+                c = rec["counters"].get(roofline["kernel"])
+                if c and "FETCH_SIZE_raw_per_launch" in c and "WRITE_SIZE_raw_per_launch" in c:
+                    rd = 2.0 * 1024.0 * c["FETCH_SIZE_raw_per_launch"]
+                    wr = 1024.0 * c["WRITE_SIZE_raw_per_launch"]
+                    roofline["traffic"] = rd + wr
+                    roofline["traffic_detail"] = {"read_bytes": rd, "write_bytes": wr, "source": os.path.relpath(pmc_file, ROOT) + " (committed record of an earlier run)",
+                                                  "record_csrc_digest": rec.get("csrc_digest"), "csrc_digest": csrc_digest(),
+                                                  "record_is_current": rec.get("csrc_digest") == csrc_digest()}
+            except Exception as exc:  # pragma: no cover
+                sys.stderr.write("[bench] could not read %s: %s\n" % (pmc_file, exc))
 
     # ---------------- scatter_add op alone (north_star: HBM roofline of the segmented sum) and the measured copy
     # bandwidth of this box beside it (fraction of nominal AND of measured copy bandwidth).
@@ -311,24 +544,40 @@ def main():
            "build_ms": round(1e3 * t_nl[len(t_nl) // 2], 4), "M_pairs_per_s": round(E / t_nl[len(t_nl) // 2] / 1e6, 1),
            "note": "count + fill incl. allocation and the one D2H of the pair count (wall clock, median of 5)"}
 
-    # ---------------- CPU baseline: the oracle on the host cores, same batch, same weights
+    # ---------------- CPU baseline: the reference's own modules on the host cores, same batch, same
+    # weights; the oracle restatement ("port") only where the reference is not available
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         # torch's intra-op pool stops scaling (and then degrades) on these small per-op sizes well before
         # the 100+ cores of a GPU host; 16 threads is the bounded, stated sample configuration
-        from oracle import spk_oracle as O          # test infrastructure: the CPU restatement, timed as the baseline
         ncores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(ncores)
-        O.energy_and_forces(args.kind, rep_p, head_p, batch, n_int)
+        ref_model = reference_model(args.kind, rep_p, head_p, F, n_int, n_rbf, cutoff)
+        if ref_model is not None:
+            def cpu_call():
+                o = ref_model(reference_inputs(batch))     # fresh tensors per call: the model writes into the dict
+                return {"energy": o["energy"].detach(), "forces": o["forces"].detach()}
+            kind_ = "reference"
+        else:
+            from oracle import spk_oracle as O          # test infrastructure: the CPU restatement, timed as the baseline
+            cpu_call = lambda: O.energy_and_forces(args.kind, rep_p, head_p, batch, n_int)
+            kind_ = "port"
+        c0 = time.perf_counter()
+        oc = cpu_call()
+        first = time.perf_counter() - c0
+        reps = max(1, min(args.cpu_reps, int(20.0 / max(first, 1e-3))))      # bounded sample: about 20 s of CPU work
         ts = []
-        for _ in range(args.cpu_reps):
+        for _ in range(reps):
             c0 = time.perf_counter()
-            oc = O.energy_and_forces(args.kind, rep_p, head_p, batch, n_int)
+            oc = cpu_call()
             ts.append(time.perf_counter() - c0)
         ts.sort()
         med = ts[len(ts) // 2]
-        cpu = {"value": round(E * n_int / med / 1e6, 4), "unit": "M edge-messages/s", "cores": ncores, "kind": "port",
-               "sample": "same %d-frame batch (or box), median of %d force calls (%.2f s each), torch %s fp32" % (hi - lo, args.cpu_reps, med, torch.__version__),
+        cpu = {"value": round(E * n_int / med / 1e6, 4), "unit": "M edge-messages/s", "cores": ncores, "kind": kind_,
+               "sample": "same %s, median of %d force calls (%.2f s each) of %s, torch %s fp32 CPU" % (
+                   "%d-frame batch" % (hi - lo) if args.workload == "aspirin" else "%d-atom box" % N, reps, med,
+                   "the reference's NeuralNetworkPotential (PairwiseDistances + representation + Atomwise + Forces) via oracle/refshim.py" if kind_ == "reference" else "the oracle restatement",
+                   torch.__version__),
                "parity_rel_forces": float((f_ref.cpu() - oc["forces"]).abs().max() / oc["forces"].abs().max()),
                "parity_rel_energy": float((e_ref.cpu() - oc["energy"]).abs().max() / oc["energy"].abs().max())}
 
@@ -339,6 +588,25 @@ def main():
         oi, _, _, _ = NB.batch_neighbor_list(batch["R"], batch["idx_m"], None, None, cutoff)
         nbl["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - c0), 2)
         nbl["cpu_oracle_pairs"] = int(oi.shape[0])
+
+    # ---------------- the other half of BASELINE's metric: MD ns/day (on-device NVE loop, rows f1-f3), aspirin x 256 and the
+    # 32k-atom water box, same model kind; and north_star's padded-neighbour sweep
+    md = None
+    if world == 1 and not args.no_md:
+        md = {}
+        for wl in ("aspirin", "water"):
+            try:
+                r = md_run(args, model, dev, wl, 0, 1, None, steps=args.md_steps if wl == "aspirin" else max(args.md_steps // 4, 20), warmup=10)
+                md[wl] = {k: r[k] for k in ("ns_per_day", "ms_per_step", "n_atoms", "pairs_in_list", "trajectories", "rebuilds", "fraction_in_rebuilds", "dt_fs", "steps", "hip_graph")}
+            except Exception as exc:  # pragma: no cover
+                md[wl] = {"error": str(exc)[:200]}
+        md["note"] = "NVE velocity Verlet, 0.5 fs, device neighbour list with a %.1f A skin, one HIP-graph replay per step; ns/day per trajectory" % args.md_shell
+    sweep = None
+    if world == 1 and not args.no_sweep:
+        try:
+            sweep = sweep_measure(model, dev, args.kind)
+        except Exception as exc:  # pragma: no cover
+            sweep = {"error": str(exc)[:200]}
 
     info = _lib.device_info()
     line = {
@@ -352,25 +620,26 @@ def main():
                                 % ("SchNet" if args.kind == "schnet" else "PaiNN", N, E, args.steps / dt * 0.5 * 86400e-6)),
                    "n_atoms": N, "n_edges": E, "frames_per_s": round((hi - lo) * world * args.steps / dt, 1),
                    "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
+                   "world_size": world, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
                    "hip_graph": graph is not None, "variant": args.variant, "compute_units": info["compute_units"]},
-        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "scatter_add": scatter, "neighbor_list": nbl,
+        "roofline": roofline, "cpu_baseline": cpu, "md": md, "sweep": sweep, "kernels": kernels, "scatter_add": scatter, "neighbor_list": nbl,
     }
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def md_main(args, rank, world, dev, dist, model):
+def md_run(args, model, dev, workload, rank, world, dist, steps, warmup):
     """NVE molecular dynamics, the whole step on the device: fused
     kick + drift + skin check, device neighbour list with a skin (rebuilt when an atom moved more than half
     of it), HIP-graph force call, kick.  Every rank integrates its own batch / box (replicas only, no
-    collective).  ns/day = steps/s x 0.5 fs x 86400e-6 per trajectory; random-init weights give an
-    arbitrary but smooth potential, so energies are in model units: momenta start at zero and stay small."""
+    collective).  ns/day = steps/s x dt x 86400e-6 per trajectory; random-init weights give an
+    arbitrary but smooth potential, so energies are in model units: momenta start at zero and stay small.
+    Returns the measurements of this rank (time = max over ranks)."""
     from schnetpack_amd import model as M, synthetic as S
     from schnetpack_amd.md import NVESimulation, RPMDSimulation
-    n_int = 3
     dt_fs = 0.5 if args.beads <= 1 else 0.2     # md.yaml resp. rpmd.yaml of the reference
-    if args.workload == "water":
+    if workload == "water":
         batch = S.water_box(n_side=args.water_side, seed=rank)
         n_traj = 1
     else:
@@ -379,7 +648,7 @@ def md_main(args, rank, world, dev, dist, model):
     inp = M.batch_to_inputs(batch, dev)
     N = int(batch["Z"].shape[0])
     inp["_n_atoms"] = torch.bincount(batch["idx_m"], minlength=int(batch["n_mol"])).to(dev)
-    if args.workload == "water":
+    if workload == "water":
         inp["_cell"] = batch["cell"].reshape(1, 3, 3).to(dev)
         inp["_pbc"] = torch.tensor([True, True, True], device=dev)
     masses = torch.where(batch["Z"] == 1, 1.008, torch.where(batch["Z"] == 6, 12.011, 15.999)).to(dev)
@@ -388,7 +657,7 @@ def md_main(args, rank, world, dev, dist, model):
         sim = RPMDSimulation(model, inp, masses, 0.02, args.beads, cutoff=5.0, omega=3.0, cutoff_shell=args.md_shell, use_graph=not args.no_graph)
     else:
         sim = NVESimulation(model, inp, masses, 0.02, cutoff=5.0, cutoff_shell=args.md_shell, use_graph=not args.no_graph)
-    sim.step(max(args.warmup, 2))
+    sim.step(max(warmup, 2))
     e0 = sim.total_energy()
     b0 = sim.nl.n_builds
     tr0 = sim.t_rebuild
@@ -397,40 +666,51 @@ def md_main(args, rank, world, dev, dist, model):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sim.step(args.steps)
+    sim.step(steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    E_list = int(sim._lists["_idx_i"].shape[0])
     if dist is not None:
         tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else torch.device("cpu"), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    steps_s = steps / dt
+    return {"ns_per_day": round(steps_s * dt_fs * 86400e-6, 4), "ms_per_step": round(1e3 * dt / steps, 4), "steps_per_s": steps_s, "dt_fs": dt_fs,
+            "n_atoms": N, "pairs_in_list": int(sim._lists["_idx_i"].shape[0]), "trajectories": n_traj, "steps": steps, "seconds": dt,
+            "rebuilds": sim.nl.n_builds - b0, "ms_per_rebuild": round(1e3 * (sim.t_rebuild - tr0) / max(sim.nl.n_builds - b0, 1), 3),
+            "fraction_in_rebuilds": round((sim.t_rebuild - tr0) / dt, 4), "graph_captures": sim.n_captures, "hip_graph": sim.graph is not None,
+            "energy_drift": abs(sim.total_energy() - e0) / max(float(sim.kinetic_energy()), 1e-12) / steps}
+
+
+def md_main(args, rank, world, dev, dist, model):
+    """`--mode md`: one line for the on-device MD loop of md_run()."""
+    n_int = 3
+    r = md_run(args, model, dev, args.workload, rank, world, dist, args.steps, args.warmup)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    steps_s = args.steps / dt
     kind = "SchNet" if args.kind == "schnet" else "PaiNN"
+    n_traj, N, E_list = r["trajectories"], r["n_atoms"], r["pairs_in_list"]
     line = {
         "metric": ("MD ns/day per trajectory (NVE, 0.5 fs, %s, %s)" if args.beads <= 1 else "RPMD ns/day per ring polymer (" + str(args.beads) + " beads, 0.2 fs, %s, %s)") % ("MD17-aspirin x %d replicas" % n_traj if args.workload == "aspirin" else "32k-atom bulk-water PBC box", kind),
-        "value": round(steps_s * dt_fs * 86400e-6, 4), "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": r["ns_per_day"], "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("%s: %s(128, 3, 20, 5.0) + Atomwise + Forces, %s, device neighbour list with a %.1f A skin (%d pairs in the list), "
                                 "%d trajectories per GPU advanced together; N=%d atoms per bead and GPU"
                                 % ("configs[1]-style MD17 aspirin batch" if args.workload == "aspirin" else "configs[4] per-GPU share (one bead / replica per GPU)",
                                    kind, "velocity Verlet" if args.beads <= 1 else "ring-polymer integrator with %d beads folded into the batch" % args.beads,
                                    args.md_shell, E_list, n_traj, N)),
-                   "trajectories_per_gpu": n_traj, "aggregate_ns_per_day": round(steps_s * dt_fs * 86400e-6 * n_traj * world, 3),
-                   "M_edge_messages_per_s_in_list": round(E_list * n_int * steps_s * world / 1e6, 1),
-                   "neighbor_list_rebuilds_in_timed_region": sim.nl.n_builds - b0,
-                   "ms_per_rebuild_incl_recapture": round(1e3 * (sim.t_rebuild - tr0) / max(sim.nl.n_builds - b0, 1), 3),
-                   "fraction_of_time_in_rebuilds": round((sim.t_rebuild - tr0) / dt, 4), "graph_captures": sim.n_captures,
-                   "hip_graph": sim.graph is not None,
-                   "energy_drift_per_step_rel_to_kinetic": abs(sim.total_energy() - e0) / max(float(sim.kinetic_energy()), 1e-12) / args.steps,
+                   "trajectories_per_gpu": n_traj, "aggregate_ns_per_day": round(r["ns_per_day"] * n_traj * world, 3),
+                   "M_edge_messages_per_s_in_list": round(E_list * n_int * r["steps_per_s"] * world / 1e6, 1),
+                   "neighbor_list_rebuilds_in_timed_region": r["rebuilds"],
+                   "ms_per_rebuild_incl_recapture": r["ms_per_rebuild"],
+                   "fraction_of_time_in_rebuilds": r["fraction_in_rebuilds"], "graph_captures": r["graph_captures"],
+                   "hip_graph": r["hip_graph"],
+                   "energy_drift_per_step_rel_to_kinetic": r["energy_drift"],
                    "parallelism": "replicas only: %d independent rank(s), no collective" % world},
         "roofline": None, "cpu_baseline": None,
     }

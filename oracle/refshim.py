@@ -4,21 +4,32 @@ The reference package cannot be imported whole in this container (``ase``,
 ``pytorch_lightning``, ``hydra`` ... are absent), but every module on
 the hot path depends on torch alone.  This shim registers path-only package stubs in
 ``sys.modules`` so that the individual sub-modules import unchanged from
-``/root/reference/src``.  It is used only (a) by ``oracle/make_golden.py`` to generate the
-committed fixtures under ``tests/golden`` and (b) by CPU tests that pin the oracle against
-the live reference when ``/root/reference`` is present.  Nothing that runs on the GPU box
-imports this file; ``/root/reference`` does not exist there.
+``/root/reference/src`` -- or, where that does not exist (the GPU box), from the byte-compiled
+build of the same package under ``oracle/_ref/src`` (``oracle/build_ref.py``; git-ignored, travels
+with the snapshot like the built ``.so``).  Users: ``oracle/make_golden.py`` (fixtures under
+``tests/golden``), the CPU tests that pin the oracle against the live reference, the ``-m gpu``
+tests that run the reference's own callers on top of the HIP classes / use the reference on the
+host CPU as the checker, and ``bench.py``'s ``cpu_baseline`` leg.  The product path never imports it.
 """
 import importlib
 import os
 import sys
 import types
 
-REF_SRC = os.environ.get("SPK_REFERENCE_SRC", "/root/reference/src")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIVE = "/root/reference/src"
+_BUILT = os.path.join(_HERE, "_ref", "src")
+REF_SRC = os.environ.get("SPK_REFERENCE_SRC") or (_LIVE if os.path.isdir(os.path.join(_LIVE, "schnetpack")) else _BUILT)
 
 
 def available() -> bool:
-    return os.path.isdir(os.path.join(REF_SRC, "schnetpack"))
+    root = os.path.join(REF_SRC, "schnetpack")
+    return os.path.isdir(root) and (os.path.exists(os.path.join(root, "properties.py")) or os.path.exists(os.path.join(root, "properties.pyc")))
+
+
+def sourceless() -> bool:
+    """True when the reference is the byte-compiled build (no ``.py`` files: TorchScript of it is unavailable)."""
+    return not os.path.exists(os.path.join(REF_SRC, "schnetpack", "properties.py"))
 
 
 def _stub(name, **attrs):
@@ -35,6 +46,20 @@ def load():
     if "schnetpack" in sys.modules and getattr(sys.modules["schnetpack"], "_spk_shim", False):
         return sys.modules["schnetpack"]._ns
     root = os.path.join(REF_SRC, "schnetpack")
+    sys.dont_write_bytecode = True     # never drop __pycache__ directories into the reference tree
+    import torch
+    jit_script = torch.jit.script
+    if sourceless():
+        # nn/scatter.py:26 decorates a helper with @torch.jit.script at import time, which needs the source text;
+        # the byte-compiled build runs that helper as plain Python -- the same ATen calls
+        torch.jit.script = lambda fn=None, *a, **k: fn
+    try:
+        return _load(root)
+    finally:
+        torch.jit.script = jit_script
+
+
+def _load(root):
     pkg = types.ModuleType("schnetpack")
     pkg.__path__ = [root]
     pkg.__version__ = "2.2.0"

@@ -17,10 +17,32 @@ import importlib
 import sys
 
 
+_ORIGINALS = []      # (module, name, original object) in patch order, for uninstall()
+
+
 def _set(mod, name, obj, log):
     if mod is not None and hasattr(mod, name):
+        if getattr(mod, name) is not obj:
+            _ORIGINALS.append((mod, name, getattr(mod, name)))
         setattr(mod, name, obj)
         log.append("%s.%s" % (mod.__name__, name))
+
+
+def uninstall():
+    """Undo every ``install()`` of this process: the reference's own classes / functions are put back
+    (models built or unpickled in between keep the classes they were made from)."""
+    n = len(_ORIGINALS)
+    while _ORIGINALS:
+        mod, name, orig = _ORIGINALS.pop()
+        if orig is _ABSENT:
+            if hasattr(mod, name):
+                delattr(mod, name)
+        else:
+            setattr(mod, name, orig)
+    return n
+
+
+_ABSENT = object()
 
 
 def install(spk=None, verbose=False, fused_head=False, neighbor_lists=False):
@@ -63,8 +85,7 @@ def install(spk=None, verbose=False, fused_head=False, neighbor_lists=False):
     for name in ("atomistic.atomwise", "nn.so3", "atomistic.electrostatic", "atomistic.nuclear_repulsion"):
         m = sub(name)
         if m is not None and getattr(m, "scatter_add", None) is not None:
-            m.scatter_add = N.scatter_add
-            log.append(m.__name__ + ".scatter_add")
+            _set(m, "scatter_add", N.scatter_add, log)
     if fused_head:
         for mod in (getattr(spk, "atomistic", None), sub("atomistic.atomwise")):
             _set(mod, "Atomwise", A.Atomwise, log)
@@ -72,6 +93,8 @@ def install(spk=None, verbose=False, fused_head=False, neighbor_lists=False):
         from . import neighborlist as NL
         for mod in (getattr(spk, "transform", None), sub("transform.neighborlist")):
             if mod is not None:
+                if not hasattr(mod, "HipNeighborList"):
+                    _ORIGINALS.append((mod, "HipNeighborList", _ABSENT))
                 setattr(mod, "HipNeighborList", NL.HipNeighborList)
                 log.append(mod.__name__ + ".HipNeighborList")
         for mod in (sub("md"), sub("md.neighborlist_md")):

@@ -126,6 +126,34 @@ def random_graph_batch(n_atoms: int, degree: int, seed: int = 0, box: float = 0.
     }
 
 
+def ring_graph_batch(n_atoms: int, degree: int, seed: int = 0, dmin: float = 0.8, dmax: float = 4.9) -> Dict[str, torch.Tensor]:
+    """Fixed-degree SYMMETRIC graph (north_star's padded-neighbour sweep): atom i is linked to i +- 1 .. i +- degree/2
+    (mod n_atoms), both directions present, ``idx_i`` ascending and ``idx_j`` ascending within a row -- the structure of
+    every reference neighbour list -- with antisymmetric pair vectors r_(j<-i) = -r_(i<-j) given directly (no positions)
+    and lengths uniform in (dmin, dmax)."""
+    assert degree % 2 == 0 and n_atoms > degree
+    rng = np.random.RandomState(seed)
+    half = degree // 2
+    i0 = np.repeat(np.arange(n_atoms, dtype=np.int64), half)
+    m = np.tile(np.arange(1, half + 1, dtype=np.int64), n_atoms)
+    j0 = (i0 + m) % n_atoms
+    v = rng.randn(n_atoms * half, 3).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v *= rng.uniform(dmin, dmax, size=(n_atoms * half, 1)).astype(np.float32)
+    ii = np.concatenate([i0, j0])
+    jj = np.concatenate([j0, i0])
+    r = np.concatenate([v, -v])
+    order = np.lexsort((jj, ii))
+    return {
+        "Z": torch.from_numpy(rng.randint(1, 10, size=n_atoms).astype(np.int64)),
+        "r_ij": torch.from_numpy(np.ascontiguousarray(r[order])),
+        "idx_i": torch.from_numpy(ii[order]),
+        "idx_j": torch.from_numpy(jj[order]),
+        "idx_m": torch.zeros(n_atoms, dtype=torch.int64),
+        "n_mol": 1,
+    }
+
+
 def water_box(n_side: int = 22, cutoff: float = 5.0, seed: int = 0, jitter: float = 0.3):
     """Bulk-water-like periodic box (SURVEY.md §8(d) cfg 5): n_side^3 molecules on a jittered
     cubic lattice at 0.0334 molecules/A^3, rigid TIP3P-like geometry, random orientations.

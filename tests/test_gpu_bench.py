@@ -1,0 +1,48 @@
+"""bench.py's contract on a real device: `--gpus N` starts N ranks by itself, and the default N=1 line carries
+`roofline`, `cpu_baseline`, the `md` (ns/day) half of BASELINE's metric and the padded-neighbour `sweep`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_gpus_2_runs_two_ranks():
+    """Two ranks (sharing the one device of this box over gloo; nccl = RCCL needs one device per rank) through the
+    same self-spawn path `bench.py --gpus 8` takes on an 8-GPU node."""
+    assert torch.cuda.is_available()
+    line = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--frames", "32", "--no-md", "--no-sweep", "--no-pmc", "--no-cpu-baseline"],
+                {"SPK_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["backend"] == "gloo"
+    assert line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 5
+
+
+def test_default_line_has_both_halves_of_the_metric():
+    line = _run(["--steps", "10", "--warmup", "3", "--md-steps", "40", "--water-side", "10", "--no-pmc", "--cpu-reps", "2"])
+    assert line["n_gpus"] == 1 and line["dtype"] == "f32" and line["value"] > 0
+    rf = line["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] < 1.5 and rf["peak"] > 0
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] in ("reference", "port") and cpu["value"] > 0 and cpu["parity_rel_forces"] < 1e-5
+    md = line["md"]
+    assert md["aspirin"]["ns_per_day"] > 0 and md["water"]["ns_per_day"] > 0 and md["aspirin"]["trajectories"] == 256
+    rows = line["sweep"]["rows"]
+    assert [r["k"] for r in rows if r["list"] == "symmetric"] == [16, 32, 64]
+    assert all(r["M_edge_messages_per_s"] > 0 and r["E"] == r["N"] * r["k"] for r in rows)

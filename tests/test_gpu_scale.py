@@ -1,0 +1,156 @@
+"""Force-call parity at the scale of configs[4] (a periodic bulk-water box, >= 2^19 directed edges), under the
+AUTOMATIC kernel dispatch -- the only size at which the tile-kernel dispatch (``n_edges >= 2^19``,
+representation/painn.py), the skin / no-skin decision, the 10^8 float atomics of a cfconv launch and the 32-bit
+offset guards are live.  Checker: the CPU oracle in float64 on the host (the reference's algorithm,
+representation/painn.py:207-256, representation/schnet.py:147-173), on the very boxes ``bench.py --workload water``
+times.  Tolerance 1e-5 relative (north_star), relative = max|a-b| / max|b|.
+
+* mid box   (15^3 molecules = 10 125 atoms, ~5.4e5 edges): both models, exact list and a 1 A skin list;
+* full box  (22^3 molecules = 31 944 atoms, ~1.71e6 edges, the bench workload itself): both models, once;
+* supercell (size-independent property): the 11^3 box replicated 2x2x2 is the same crystal -- per-atom forces of the
+  31 944-atom supercell equal the tiled forces of the 3 993-atom cell, the energy is 8x.
+"""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import spk_oracle as O
+from schnetpack_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def host_threads():
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
+    yield
+    torch.set_num_threads(old)
+
+
+def _host_mem_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def _params(kind):
+    rep = O.init_schnet_params() if kind == "schnet" else O.init_painn_params()
+    return rep, O.init_atomwise_params(128, seed=1)
+
+
+def _model(kind, dev, rep_p, head_p):
+    from schnetpack_amd import _lib, model as M
+    assert _lib.get_variant() == _lib.VARIANT_AUTO
+    m = M.build_model(kind)
+    M.load_reference_params(m, rep_p, head_p)
+    return m.to(dev).eval()
+
+
+def _oracle(kind, rep_p, head_p, batch):
+    # float64 needs ~75 KB per directed edge for PaiNN (autograd keeps the [E, 3F n_int] filter tensor and the per-layer
+    # message tensors); fall back to the reference's own fp32 arithmetic on a small host
+    E = int(batch["idx_i"].shape[0])
+    dtype = torch.float64 if _host_mem_gb() > 1.5 * 75e3 * E / 1e9 + 8 else torch.float32
+    return O.energy_and_forces(kind, rep_p, head_p, batch, 3, dtype=dtype)
+
+
+def _gpu_call(model, batch, dev):
+    from schnetpack_amd import model as M
+    out = model(M.batch_to_inputs(batch, dev))
+    return out["energy"].detach().cpu(), out["forces"].detach().cpu()
+
+
+_MID = {}
+
+
+def _mid_box():
+    if not _MID:
+        b = S.water_box(n_side=15, seed=3)
+        assert b["idx_i"].shape[0] >= (1 << 19), b["idx_i"].shape
+        _MID["box"] = b
+    return _MID["box"]
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_mid_box_force_call_auto_dispatch(dev, kind):
+    from schnetpack_amd import neighborlist as NL, ops
+    b = _mid_box()
+    rep_p, head_p = _params(kind)
+    ref = _oracle(kind, rep_p, head_p, b)
+    model = _model(kind, dev, rep_p, head_p)
+    e, f = _gpu_call(model, b, dev)
+    assert rel_err(e, ref["energy"]) < TOL
+    assert rel_err(f, ref["forces"]) < TOL
+    # the same box through the device neighbour list with a 1 A skin (MD lists): 1.7x the pairs, the ones beyond the
+    # cutoff contribute exactly zero, so the oracle result of the exact list is the truth for it as well
+    cell = b["cell"].reshape(1, 3, 3).to(dev)
+    nl = NL.neighbor_list(b["R"].to(dev), 6.0, idx_m=b["idx_m"].to(dev), cell=cell,
+                          pbc=torch.tensor([True, True, True], device=dev), n_systems=1)
+    skin = dict(b)
+    skin["idx_i"], skin["idx_j"], skin["offsets"] = nl["_idx_i"].cpu(), nl["_idx_j"].cpu(), nl["_offsets"].cpu()
+    assert skin["idx_i"].shape[0] > 1.4 * b["idx_i"].shape[0]
+    e2, f2 = _gpu_call(model, skin, dev)
+    assert rel_err(e2, ref["energy"]) < TOL
+    assert rel_err(f2, ref["forces"]) < TOL
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_full_box_force_call_auto_dispatch(dev, kind):
+    """The bench workload itself (``bench.py --workload water``: 31 944 atoms, 1.71 M directed edges)."""
+    b = S.water_box(n_side=22, seed=0)
+    assert b["Z"].shape[0] == 31944
+    rep_p, head_p = _params(kind)
+    model = _model(kind, dev, rep_p, head_p)
+    e, f = _gpu_call(model, b, dev)
+    ref = _oracle(kind, rep_p, head_p, b)
+    assert rel_err(e, ref["energy"]) < TOL
+    assert rel_err(f, ref["forces"]) < TOL
+    # graph-captured replay of the same call (what the bench times) reproduces it
+    from schnetpack_amd.forcecall import GraphedForceCall
+    from schnetpack_amd import model as M
+    gc = GraphedForceCall(model)
+    inp = M.batch_to_inputs(b, dev)
+    for _ in range(3):
+        out = gc(inp)
+    torch.cuda.synchronize()
+    assert rel_err(out["forces"].cpu(), ref["forces"]) < TOL
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_supercell_forces_tile(dev, kind):
+    from schnetpack_amd import neighborlist as NL
+    small = S.water_box(n_side=11, seed=7)
+    n = small["Z"].shape[0]
+    L = float(small["cell"][0, 0])
+    shifts = torch.tensor([[a, b_, c] for a in (0, 1) for b_ in (0, 1) for c in (0, 1)], dtype=torch.float32) * L
+    R = (small["R"][None, :, :] + shifts[:, None, :]).reshape(-1, 3)
+    Z = small["Z"].repeat(8)
+    assert R.shape[0] == 31944
+    cell = (small["cell"] * 2).reshape(1, 3, 3).to(dev)
+    idx_m = torch.zeros(R.shape[0], dtype=torch.long)
+    nl = NL.neighbor_list(R.to(dev), 5.0, idx_m=idx_m.to(dev), cell=cell,
+                          pbc=torch.tensor([True, True, True], device=dev), n_systems=1)
+    big = {"Z": Z, "R": R, "idx_i": nl["_idx_i"].cpu(), "idx_j": nl["_idx_j"].cpu(), "offsets": nl["_offsets"].cpu(),
+           "idx_m": idx_m, "n_mol": 1}
+    # (pairs within one float32 ulp of the cutoff may fall on the other side after the shift; they carry f_c ~ 0)
+    assert abs(int(big["idx_i"].shape[0]) - 8 * int(small["idx_i"].shape[0])) <= 32
+    rep_p, head_p = _params(kind)
+    ref = _oracle(kind, rep_p, head_p, small)
+    model = _model(kind, dev, rep_p, head_p)
+    e, f = _gpu_call(model, big, dev)
+    assert rel_err(f, ref["forces"].repeat(8, 1).float()) < TOL
+    assert abs(float(e[0]) - 8.0 * float(ref["energy"][0])) <= 2e-5 * abs(8.0 * float(ref["energy"][0]))

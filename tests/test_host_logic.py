@@ -148,6 +148,34 @@ def test_bench_refuses_to_run_without_a_device():
     assert "no CPU fallback" in res.stderr
 
 
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher starts 2 ranks itself (torch.distributed.run, 127.0.0.1) and the line
+    says n_gpus = 2; here as a dry run over gloo (rank wiring only -- the measured path needs devices)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPK_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["backend"] == "gloo"
+    assert line["max_over_ranks"] == 2.0 and line["units_over_ranks"] == 2.0
+    # a launcher that started a different number of ranks than --gpus asks for is an error, not a silent 1-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=600, env=env2)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr
+    # without devices the real multi-GPU run refuses loudly
+    if not torch.cuda.is_available():
+        env3 = {k: v for k, v in env.items() if k != "SPK_BENCH_BACKEND"}
+        res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env3)
+        assert res.returncode != 0 and "device(s) visible" in res.stderr and '"metric"' not in res.stdout
+
+
 def test_bench_ranks_kernel_families_not_template_variants():
     """The dominant-kernel rule of bench.py groups the compile-time variants of a kernel (text check: the rule is
     part of the measurement contract described in DESIGN.md section 5)."""

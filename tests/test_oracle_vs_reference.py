@@ -1,5 +1,5 @@
-"""CPU, build container only: pin the oracle against the LIVE reference modules
-(skipped on boxes without /root/reference)."""
+"""CPU: pin the oracle against the LIVE reference modules (from /root/reference, or from its byte-compiled
+build under oracle/_ref where /root/reference does not exist; skipped when neither is there)."""
 import pytest
 import torch
 
@@ -104,8 +104,8 @@ def test_install_hook_patches_reference_namespace_and_pickles_resolve_to_mirrors
         assert sys.modules["schnetpack.representation.painn"].PaiNN is R.PaiNN
         assert spk.nn.scatter_add is N.scatter_add
         sys.modules["ase.data"].atomic_masses = np.ones(119)
-        import os
-        path = os.path.join(refshim.REF_SRC, "..", "interfaces", "lammps", "examples", "aspirin", "best_model")
+        from oracle import build_ref
+        path = build_ref.data_path("lammps_aspirin_best_model")
         m = torch.load(path, map_location="cpu", weights_only=False)
         assert isinstance(m.representation, R.PaiNN)
         assert isinstance(m.representation.interactions[0].interatomic_context_net[0], N.Dense)
