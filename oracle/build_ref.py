@@ -86,5 +86,73 @@ def data_path(name: str) -> str:
     raise KeyError(name)
 
 
+
+
+# ------------------------------------------------------------------------------------------------ deployed models
+DEPLOYED = {"aspirin": "lammps_aspirin_best_model", "ethanol": "md_ethanol.model"}
+
+
+def deployed_path(name: str) -> str:
+    return os.path.join(OUT, "deployed", name + "_hip.pt")
+
+
+def build_deployed(verbose: bool = True):
+    """What `spkdeploy model deployed` (src/scripts/spkdeploy:16-40) produces when the HIP classes are installed: the
+    shipped reference pickles are unpickled INTO the mirrors (``schnetpack_amd.install``), the reference's own
+    ``NeuralNetworkPotential`` / ``Atomwise`` / ``Forces`` / ``AddOffsets`` code around them is scripted as is
+    (``torch.jit.script``; casts dropped, ``AddOffsets.mean`` -> float32, ``cutoff`` metadata) and saved to
+    ``oracle/_ref/deployed/<name>_hip.pt``.  Scripting needs the reference SOURCE text, so this runs in the build
+    container only; the GPU tests ``torch.jit.load`` the archives the way interfaces/lammps/pair_schnetpack.cpp:128 does
+    (after loading libspk_torch.so) and compare with the reference-generated fixtures tests/golden/deploy_painn.npz."""
+    if not source_available():
+        return []
+    import numpy as np
+    import torch
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import refshim
+    import schnetpack_amd.install as inst
+    if refshim.sourceless():
+        return []
+    refshim.load()
+    sys.modules["ase.data"].atomic_masses = np.ones(119)
+    spk = sys.modules["schnetpack"]
+    done = []
+    inst.install(spk)
+    try:
+        load_model = sys.modules["schnetpack.utils"].load_model
+        for name, data in DEPLOYED.items():
+            dst = deployed_path(name)
+            deps = [data_path(data), os.path.join(root, "schnetpack_amd", "csrc", "spk_torch.cpp")] + \
+                   [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(root, "schnetpack_amd")) for f in fs if f.endswith(".py")]
+            if os.path.exists(dst) and all(os.path.getmtime(dst) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+                done.append(dst)
+                continue
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m = load_model(data_path(data)).eval()
+                keep = torch.nn.ModuleList()
+                for pp in m.postprocessors:                 # spkdeploy:19-29
+                    if type(pp).__name__ in ("CastTo64", "CastTo32"):
+                        continue
+                    if type(pp).__name__ == "AddOffsets":
+                        pp.mean = pp.mean.float()
+                    keep.append(pp)
+                m.postprocessors = keep
+                jm = torch.jit.script(m)
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            meta = {"cutoff": str(jm.representation.cutoff.item()).encode("ascii")}      # spkdeploy:36
+            torch.jit.save(jm, dst, _extra_files=meta)
+            done.append(dst)
+            if verbose:
+                print("oracle/_ref: scripted %s -> %s" % (data, os.path.relpath(dst, root)))
+    finally:
+        inst.uninstall()
+    return done
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_deployed()

@@ -1,17 +1,18 @@
-"""Minimal mirrors of the reference *callers* either side of the hot path, so that a complete
-force call can be assembled without the reference package (which cannot be imported on the GPU
-box): ``PairwiseDistances`` (atomistic/distances.py:9-26), ``Atomwise``
-(atomistic/atomwise.py:14-88, energy head only) and ``Forces`` (atomistic/response.py:18-92,
-forces only).  In a real integration the reference's own modules are used unchanged -- they only
-see ``schnetpack.nn.scatter_add`` / ``Dense`` / the representation classes.
+"""Mirrors of the reference *callers* either side of the hot path, so that a complete force call can be
+assembled (and scripted) without the reference package: ``PairwiseDistances`` (atomistic/distances.py:9-26),
+``Atomwise`` (atomistic/atomwise.py:14-88) and ``Forces`` (atomistic/response.py:18-92).  In an integration the
+reference's own modules run unchanged on top of the HIP classes (tests/test_gpu_reference_callers.py) -- they only see
+``schnetpack.nn.scatter_add`` / ``Dense`` / the representation classes; ``install(fused_head=True)`` swaps in this
+``Atomwise`` for its one-kernel energy head.
 """
-from typing import Callable, Dict, List, Optional, Sequence, Union
+from typing import Callable, Dict, Final, List, Optional, Sequence, Union
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib, ops, properties
+from . import _lib, properties
+from . import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 from .nn import Dense, build_mlp, scatter_add
 from .nn.base import activation_id
 
@@ -19,24 +20,30 @@ __all__ = ["PairwiseDistances", "Atomwise", "Forces"]
 
 
 class PairwiseDistances(nn.Module):
-    """Rij = R[idx_j] - R[idx_i] + offsets; autograd scatters dE/dRij back onto atoms."""
+    """Rij = R[idx_j] - R[idx_i] + offsets; autograd lands dE/dRij back on the atoms (segmented row sum on
+    sorted symmetric lists) and on the offsets (stress via ``Strain``)."""
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         R = inputs[properties.R]
-        offsets = inputs.get(properties.offsets)
-        idx_i = inputs[properties.idx_i].long()
-        idx_j = inputs[properties.idx_j].long()
-        inputs[properties.Rij] = ops.pairwise_vectors(R, idx_i, idx_j, offsets)
+        offsets: Optional[torch.Tensor] = None
+        if properties.offsets in inputs:
+            offsets = inputs[properties.offsets]
+        idx_i = inputs[properties.idx_i]
+        idx_j = inputs[properties.idx_j]
+        inputs[properties.Rij] = torch.ops.spk_hip.pairwise(R, idx_i, idx_j, offsets)
         return inputs
 
 
 class Atomwise(nn.Module):
-    """Per-atom MLP + sum over ``idx_m`` (aggregation_mode 'sum' / 'avg' / None)."""
+    """Per-atom MLP + sum over ``idx_m`` (aggregation_mode 'sum' / 'avg' / None).  In eval mode the default head
+    (2 layers, width-1 output) is ONE kernel each way (``torch.ops.spk_hip.atomwise``)."""
+
+    _fused_head: Final[bool]
 
     def __init__(self, n_in: int, n_out: int = 1, n_hidden: Optional[Union[int, Sequence[int]]] = None,
                  n_layers: int = 2, activation: Callable = F.silu, aggregation_mode: str = "sum",
                  output_key: str = "y", per_atom_output_key: Optional[str] = None,
-                 n_molecules_key: Optional[str] = "_n_molecules"):
+                 n_molecules_key: str = "_n_molecules"):
         super().__init__()
         self.output_key = output_key
         self.model_outputs = [output_key]
@@ -51,33 +58,41 @@ class Atomwise(nn.Module):
                                 activation=activation)
         self.aggregation_mode = aggregation_mode
         self.n_molecules_key = n_molecules_key
+        self._head_act = 0
+        self._fused_head = self._head_fusable()
 
-    def _fused_head(self, x):
-        """(w1, b1, w2, b2, act id) when the head is the default 2-layer / width-1 MLP the fused HIP
-        kernel covers and the module is in the eval regime; else None."""
-        if self.training or self.aggregation_mode is None or self.n_out != 1 or x.dim() != 2:
-            return None
+    def _head_fusable(self) -> bool:
+        """True when the head is the default 2-layer / width-1 MLP the fused HIP kernel covers."""
+        if self.aggregation_mode is None or self.n_out != 1:
+            return False
         net = self.outnet
         if not (isinstance(net, nn.Sequential) and len(net) == 2 and all(isinstance(l, Dense) for l in net)):
-            return None
+            return False
         act = activation_id(net[0].activation)
-        if act is None or activation_id(net[1].activation) != _lib.SPK_ACT_NONE:
-            return None
-        if net[1].out_features != 1 or not ops.atomwise_supported(net[0].in_features, net[0].out_features, act):
-            return None
-        d = lambda p: p.detach() if p is not None else None
-        return d(net[0].weight), d(net[0].bias), d(net[1].weight), d(net[1].bias), act
+        if act is None or act == _lib.SPK_ACT_NONE or activation_id(net[1].activation) != _lib.SPK_ACT_NONE:
+            return False
+        if net[1].out_features != 1 or net[0].bias is None or net[1].bias is None:
+            return False
+        if not bool(_lib.lib().spk_atomwise_supported(int(net[0].in_features), int(net[0].out_features), int(act))):
+            return False
+        self._head_act = int(act)
+        return True
+
+    def _n_molecules(self, inputs: Dict[str, torch.Tensor], idx_m: torch.Tensor) -> int:
+        # the reference reads int(idx_m[-1]) + 1 (a device sync, atomwise.py:80); a host-side molecule count in the
+        # batch dict (python int or CPU tensor under `n_molecules_key`) avoids it when present
+        if self.n_molecules_key in inputs:
+            return int(inputs[self.n_molecules_key])
+        return int(idx_m[-1]) + 1
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         x = inputs["scalar_representation"]
-        head = self._fused_head(x)
-        if head is not None:
+        if self._fused_head and not self.training and x.dim() == 2:
             idx_m = inputs[properties.idx_m]
-            if self.n_molecules_key is not None and self.n_molecules_key in inputs:
-                maxm = int(inputs[self.n_molecules_key])
-            else:
-                maxm = int(idx_m[-1]) + 1
-            y, y_atom = ops.AtomwiseFn.apply(x, head[0], head[1], head[2], head[3], idx_m.long().contiguous(), maxm, head[4])
+            maxm = self._n_molecules(inputs, idx_m)
+            l0 = self.outnet[0]
+            l1 = self.outnet[1]
+            y, y_atom = torch.ops.spk_hip.atomwise(x, l0.weight, l0.bias, l1.weight, l1.bias, idx_m, maxm, self._head_act)
             if self.per_atom_output_key is not None:
                 inputs[self.per_atom_output_key] = y_atom
             if self.aggregation_mode == "avg":
@@ -89,12 +104,7 @@ class Atomwise(nn.Module):
             inputs[self.per_atom_output_key] = y
         if self.aggregation_mode is not None:
             idx_m = inputs[properties.idx_m]
-            # the reference reads int(idx_m[-1]) + 1 (a device sync, atomwise.py:80); a host-side
-            # molecule count in the batch dict avoids it when present
-            if self.n_molecules_key is not None and self.n_molecules_key in inputs:
-                maxm = int(inputs[self.n_molecules_key])
-            else:
-                maxm = int(idx_m[-1]) + 1
+            maxm = self._n_molecules(inputs, idx_m)
             y = scatter_add(y, idx_m, dim_size=maxm)
             y = torch.squeeze(y, -1)
             if self.aggregation_mode == "avg":
@@ -104,36 +114,42 @@ class Atomwise(nn.Module):
 
 
 class Forces(nn.Module):
-    """forces = -dE/dR by autograd (create_graph = training), like the reference."""
+    """forces = -dE/dR (and stress = dE/dstrain / volume) by autograd, ``create_graph = training``, like the reference."""
 
-    def __init__(self, calc_forces: bool = True, energy_key: str = properties.energy,
-                 force_key: str = properties.forces):
+    def __init__(self, calc_forces: bool = True, calc_stress: bool = False, energy_key: str = properties.energy,
+                 force_key: str = properties.forces, stress_key: str = properties.stress):
         super().__init__()
         self.calc_forces = calc_forces
+        self.calc_stress = calc_stress
         self.energy_key = energy_key
         self.force_key = force_key
-        self.model_outputs = [force_key] if calc_forces else []
-        self.required_derivatives = [properties.R] if calc_forces else []
+        self.stress_key = stress_key
+        self.model_outputs = []
+        if calc_forces:
+            self.model_outputs.append(force_key)
+        if calc_stress:
+            self.model_outputs.append(stress_key)
+        self.required_derivatives = []
+        if calc_forces:
+            self.required_derivatives.append(properties.R)
+        if calc_stress:
+            self.required_derivatives.append(properties.strain)
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         Epred = inputs[self.energy_key]
-        # grad_outputs = ones (response.py:63); one cached buffer per shape instead of a fill launch per call
-        # (never cached from inside a graph capture: that memory belongs to the graph)
-        cache = self.__dict__.setdefault("_ones_cache", {})
-        key = (tuple(Epred.shape), Epred.device, Epred.dtype)
-        ones = cache.get(key)
-        if ones is None:
-            ones = torch.ones_like(Epred)
-            if not (Epred.is_cuda and torch.cuda.is_current_stream_capturing()):
-                if len(cache) > 8:
-                    cache.clear()
-                cache[key] = ones
-        go: List[Optional[torch.Tensor]] = [ones]
-        grads = torch.autograd.grad([Epred], [inputs[p] for p in self.required_derivatives],
+        go: List[Optional[torch.Tensor]] = [torch.ones_like(Epred)]
+        grads = torch.autograd.grad([Epred], [inputs[prop] for prop in self.required_derivatives],
                                     grad_outputs=go, create_graph=self.training)
         if self.calc_forces:
             dEdR = grads[0]
             if dEdR is None:
                 dEdR = torch.zeros_like(inputs[properties.R])
             inputs[self.force_key] = -dEdR
+        if self.calc_stress:
+            stress = grads[-1]
+            if stress is None:
+                stress = torch.zeros_like(inputs[properties.cell])
+            cell = inputs[properties.cell]
+            volume = torch.sum(cell[:, 0, :] * torch.cross(cell[:, 1, :], cell[:, 2, :], dim=1), dim=1, keepdim=True)[:, :, None]
+            inputs[self.stress_key] = stress / volume
         return inputs

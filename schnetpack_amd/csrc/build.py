@@ -61,7 +61,31 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     build_native_example(force, verbose)
+    build_torch_ops(force, verbose)
     return LIB
+
+
+TORCH_SRC = os.path.join(HERE, "spk_torch.cpp")
+TORCH_LIB = os.path.join(HERE, "libspk_torch.so")
+
+
+def build_torch_ops(force=False, verbose=True):
+    """libspk_torch.so: the TORCH_LIBRARY(spk_hip) operator registrations (spk_torch.cpp; host C++ only, every operator
+    calls into libspk_hip.so), compiled against the installed PyTorch-ROCm headers and linked next to libspk_hip.so."""
+    if not (force or _stale(TORCH_LIB, [TORCH_SRC, LIB, os.path.join(HERE, HEADERS[-1])])):
+        return TORCH_LIB
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + p for p in ce.include_paths()] + ["-I/opt/rocm/include", TORCH_SRC, "-o", TORCH_LIB,
+            "-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip", "-lc10_hip", "-L" + HERE, "-lspk_hip",
+            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TORCH_LIB
 
 
 RUN_SRC = os.path.join(HERE, "..", "..", "examples", "native", "spk_run.c")

@@ -95,7 +95,8 @@ def export_potential(model, path: Optional[str] = None) -> bytes:
     if head_act not in (_lib.SPK_ACT_SSP, _lib.SPK_ACT_SILU) or activation_id(net[1].activation) != _lib.SPK_ACT_NONE:
         raise ValueError("deploy: unsupported head activation")
     F = int(rep.n_atom_basis)
-    rbk, n_rbf, p0, p1, cutoff = rep.radial_basis.kernel_args(rep.cutoff_fn.cutoff_value())
+    rbk, p0, p1 = rep.radial_basis.kernel_params()
+    n_rbf, cutoff = int(rep.radial_basis.n_rbf), float(rep.cutoff_fn.cutoff_value())
     tensors: Dict[str, np.ndarray] = {}
     tensors["embedding"] = _np(rep.embedding.weight)
     tensors["rbf_p0"] = _np(p0).reshape(-1)

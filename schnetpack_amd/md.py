@@ -237,17 +237,18 @@ class NVESimulation:
             self._e.copy_(out["energy"].detach())
 
     def _prepare_plan(self):
-        """Edge plan (CSR, reverse map, skin-filter decision) of the current list without a full force call."""
-        from . import ops
+        """Edge plan (CSR, reverse map, skin-filter decision) of the current list without a full force call: warms the
+        plan cache of the operator library outside any graph capture (one host sync per new list)."""
         P = self.P
         R = self._flatR()
         ii, jj = self._lists[P.idx_i], self._lists[P.idx_j]
         with torch.no_grad():
-            r = ops.pairwise_vectors(R.detach(), ii, jj, self._lists.get(P.offsets))
-            plan = ops.edge_plan(ii.long().contiguous(), jj.long().contiguous(), int(R.shape[0]), r)
+            r = torch.ops.spk_hip.pairwise(R.detach(), ii, jj, self._lists.get(P.offsets))
             rep = getattr(self.model, "representation", None)
-            if plan.filter_pairs is None and rep is not None and hasattr(rep, "cutoff_fn") and hasattr(rep.cutoff_fn, "cutoff_value"):
-                plan.decide_filter(r, rep.cutoff_fn.cutoff_value())
+            cutoff = 0.0
+            if rep is not None and hasattr(rep, "cutoff_fn") and hasattr(rep.cutoff_fn, "cutoff_value"):
+                cutoff = float(rep.cutoff_fn.cutoff_value())
+            torch.ops.spk_hip.edge_plan(ii, jj, int(R.shape[0]), r, cutoff)
 
     def _step_body(self):
         thr = max(0.5 * self.nl.cutoff_shell - self.margin, 0.0)

@@ -14,7 +14,11 @@ __all__ = ["NeuralNetworkPotential", "build_model", "batch_to_inputs"]
 
 
 class NeuralNetworkPotential(nn.Module):
-    """input_modules -> representation -> output_modules (dict in, dict out)."""
+    """input_modules -> representation -> output_modules (dict in, dict out); TorchScript-able like the reference's
+    (src/scripts/spkdeploy:16-40 scripts the whole model)."""
+
+    required_derivatives: List[str]
+    model_outputs: List[str]
 
     def __init__(self, representation: nn.Module, input_modules: List[nn.Module] = None,
                  output_modules: List[nn.Module] = None):

@@ -6,7 +6,8 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import xavier_uniform_, zeros_
 
-from .. import _lib, ops
+from .. import _lib
+from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 from .activations import shifted_softplus
 
 __all__ = ["Dense", "activation_id"]
@@ -25,7 +26,12 @@ def activation_id(activation):
 
 class Dense(nn.Linear):
     r"""y = activation(x W^T + b); same constructor, parameters (``weight``, ``bias``) and
-    initialisation (xavier_uniform / zeros) as the reference."""
+    initialisation (xavier_uniform / zeros) as the reference.
+
+    ``forward`` is one ``torch.ops.spk_hip.dense`` call (TorchScript-able).  Its autograd node serves both
+    regimes: a plain first-order backward (eval-mode ``Forces``) runs the input gradient on the HIP kernel and
+    forms weight gradients only if that pass asks for them; a recorded backward (``create_graph=True``, training on
+    forces) is differentiable torch algebra, exact to second order."""
 
     def __init__(self, in_features: int, out_features: int, bias: bool = True,
                  activation: Union[Callable, nn.Module] = None,
@@ -36,6 +42,13 @@ class Dense(nn.Linear):
         self.activation = activation
         if self.activation is None:
             self.activation = nn.Identity()
+        self._act_id = _act_code(self.activation)
+
+    def __setstate__(self, state):
+        # instances restored from reference pickles never ran this __init__
+        super().__setstate__(state)
+        if "_act_id" not in self.__dict__:
+            self._act_id = _act_code(self.activation)
 
     def reset_parameters(self):
         self.weight_init(self.weight)
@@ -43,10 +56,12 @@ class Dense(nn.Linear):
             self.bias_init(self.bias)
 
     def forward(self, input: torch.Tensor):
-        act = activation_id(self.activation)
-        if act is None:
-            # unknown activation callable: linear part on the HIP kernel, activation by the caller's function
-            return self.activation(ops.dense(input, self.weight, self.bias, _lib.SPK_ACT_NONE, self.training))
-        # eval mode: geometry gradients only, forward + input-gradient on the HIP kernels;
-        # training mode: differentiable to second order
-        return ops.dense(input, self.weight, self.bias, act, self.training)
+        if self._act_id >= 0:
+            return torch.ops.spk_hip.dense(input, self.weight, self.bias, self._act_id)
+        # unknown activation callable: linear part on the HIP kernel, activation by the caller's function
+        return self.activation(torch.ops.spk_hip.dense(input, self.weight, self.bias, 0))
+
+
+def _act_code(activation) -> int:
+    a = activation_id(activation)
+    return -1 if a is None else int(a)

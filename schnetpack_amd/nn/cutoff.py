@@ -1,10 +1,11 @@
 """Mirror of ``schnetpack.nn.cutoff.CosineCutoff`` (nn/cutoff.py:14-57)."""
 import math
+from typing import Optional
 
 import torch
 from torch import nn
 
-from .. import _lib, ops
+from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 
 __all__ = ["CosineCutoff", "cosine_cutoff"]
 
@@ -23,19 +24,23 @@ class CosineCutoff(nn.Module):
         self.register_buffer("cutoff", torch.FloatTensor([cutoff]))
         self._cutoff_host = float(cutoff)
 
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if "_cutoff_host" not in self.__dict__:      # reference pickles: read the buffer once (host copy, no sync per call)
+            self._cutoff_host = float(self.cutoff.item())
+
     def cutoff_value(self) -> float:
         """Host copy of the cutoff radius (no device sync per call)."""
-        if self.__dict__.get("_cutoff_host") is None:
-            self.__dict__["_cutoff_host"] = float(self.cutoff.item())
-        return self.__dict__["_cutoff_host"]
+        return self._cutoff_host
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
-        self._cutoff_host = None
+        if not self.cutoff.is_meta:
+            self._cutoff_host = float(self.cutoff.item())
 
     def forward(self, input: torch.Tensor):
-        ops._check_float(input, "CosineCutoff")
         if self.training and torch.is_grad_enabled() and input.requires_grad:
             return cosine_cutoff(input, self.cutoff)
-        dummy = self.cutoff  # any fp32 device tensor: the kernel ignores p0/p1 when phi is not requested
-        return ops.RadialCutoffFn.apply(input, _lib.SPK_RBF_BESSEL, dummy, None, self.cutoff_value(), False, True)
+        p1: Optional[torch.Tensor] = None
+        # (the kernel ignores p0/p1 when phi is not requested: any fp32 device tensor will do)
+        return torch.ops.spk_hip.radial_cutoff(input, 1, self.cutoff, p1, self._cutoff_host, False, True)[1]

@@ -1,10 +1,12 @@
 """Mirror of ``schnetpack.nn.radial`` (nn/radial.py:11-110): GaussianRBF, BesselRBF."""
 from math import pi
+from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib
+from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 
 __all__ = ["gaussian_rbf", "GaussianRBF", "BesselRBF"]
 
@@ -17,14 +19,10 @@ def gaussian_rbf(inputs: torch.Tensor, offsets: torch.Tensor, widths: torch.Tens
     return torch.exp(coeff * torch.pow(diff, 2))
 
 
-def _needs_composite(module, inputs):
-    """Training (double backward) or trainable basis parameters need the differentiable
-    composite; the eval path uses the HIP kernel."""
-    return module.training and torch.is_grad_enabled() and inputs.requires_grad
-
-
 class GaussianRBF(nn.Module):
-    r"""Gaussian radial basis functions; buffers/params ``widths``, ``offsets``, attr ``n_rbf``."""
+    r"""Gaussian radial basis functions; buffers/params ``widths``, ``offsets``, attr ``n_rbf``.
+    Eval: HIP kernel (first-order backward on the device); training (double backward) or trainable
+    basis parameters: the differentiable torch formula."""
 
     def __init__(self, n_rbf: int, cutoff: float, start: float = 0.0, trainable: bool = False):
         super().__init__()
@@ -39,14 +37,19 @@ class GaussianRBF(nn.Module):
             self.register_buffer("widths", widths)
             self.register_buffer("offsets", offset)
 
-    def kernel_args(self, cutoff: float):
-        return (_lib.SPK_RBF_GAUSSIAN, self.n_rbf, self.offsets.detach(), self.widths.detach(), float(cutoff))
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if "trainable" not in self.__dict__:      # reference pickles carry no such attribute
+            self.trainable = isinstance(self.offsets, nn.Parameter)
+
+    def kernel_params(self) -> Tuple[int, torch.Tensor, Optional[torch.Tensor]]:
+        """(kind, p0, p1) of ``spk_radial_t``: gaussian = (0, offsets, widths)."""
+        return 0, self.offsets, self.widths
 
     def forward(self, inputs: torch.Tensor):
-        ops._check_float(inputs, "GaussianRBF")
-        if getattr(self, "trainable", isinstance(self.offsets, nn.Parameter)) or _needs_composite(self, inputs):
+        if self.trainable or (self.training and torch.is_grad_enabled() and inputs.requires_grad):
             return gaussian_rbf(inputs, self.offsets, self.widths)
-        return ops.RadialCutoffFn.apply(inputs, _lib.SPK_RBF_GAUSSIAN, self.offsets, self.widths, 1.0, True, False)
+        return torch.ops.spk_hip.radial_cutoff(inputs, 0, self.offsets, self.widths, 1.0, True, False)[0]
 
 
 class BesselRBF(nn.Module):
@@ -58,13 +61,18 @@ class BesselRBF(nn.Module):
         freqs = torch.arange(1, n_rbf + 1) * pi / cutoff
         self.register_buffer("freqs", freqs)
 
-    def kernel_args(self, cutoff: float):
-        return (_lib.SPK_RBF_BESSEL, self.n_rbf, self.freqs.detach().float(), None, float(cutoff))
+    def kernel_params(self) -> Tuple[int, torch.Tensor, Optional[torch.Tensor]]:
+        """(kind, p0, p1) of ``spk_radial_t``: bessel = (1, freqs, None)."""
+        p1: Optional[torch.Tensor] = None
+        return 1, self.freqs, p1
 
-    def forward(self, inputs):
-        ops._check_float(inputs, "BesselRBF")
-        if _needs_composite(self, inputs):
+    def forward(self, inputs: torch.Tensor):
+        if self.training and torch.is_grad_enabled() and inputs.requires_grad:
             ax = inputs[..., None] * self.freqs
-            norm = torch.where(inputs == 0, torch.tensor(1.0, device=inputs.device), inputs)
+            norm = torch.where(inputs == 0, torch.ones_like(inputs), inputs)
             return torch.sin(ax) / norm[..., None]
-        return ops.RadialCutoffFn.apply(inputs, _lib.SPK_RBF_BESSEL, self.freqs.float(), None, 1.0, True, False)
+        p1: Optional[torch.Tensor] = None
+        return torch.ops.spk_hip.radial_cutoff(inputs, 1, self.freqs, p1, 1.0, True, False)[0]
+
+
+assert _lib.SPK_RBF_GAUSSIAN == 0 and _lib.SPK_RBF_BESSEL == 1

@@ -1,7 +1,7 @@
 """Mirror of ``schnetpack.nn.scatter`` (nn/scatter.py:7-34) on the HIP path."""
 import torch
 
-from .. import ops
+from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 
 __all__ = ["scatter_add"]
 
@@ -11,6 +11,7 @@ def scatter_add(x: torch.Tensor, idx_i: torch.Tensor, dim_size: int, dim: int = 
 
     Same signature, argument meaning and output shape/dtype/device as the reference.  Sorted
     indices (every reference neighbour list, ``idx_m``) take the deterministic segmented-sum
-    kernel; unsorted ones use float atomics.  Differentiable to any order.
+    kernel; unsorted ones use float atomics.  Differentiable to any order (its backward is the HIP
+    ``gather``, whose backward is this function).  TorchScript-able.
     """
-    return ops.scatter_add(x, idx_i, dim_size, dim)
+    return torch.ops.spk_hip.scatter_add(x, idx_i, dim_size, dim)

@@ -1,21 +1,20 @@
 """Mirror of ``schnetpack.representation.painn`` (representation/painn.py:14-256) on the gfx950
 kernels: same class names, constructor signatures, attributes and ``state_dict`` keys.
 
-Eval mode: ``ops.PaiNNFn`` -- context nets and mixing Dense layers on the fp32 MFMA kernel, the
-equivariant message as one fused row kernel per interaction (filters recomputed in registers;
-the reference's [E, 1, 3F n_int] filter tensor, painn.py:232, never exists), first-order backward
-w.r.t. ``_Rij``.  Training mode: differentiable primitive path.
+Eval mode: ONE operator, ``torch.ops.spk_hip.painn`` -- context nets and mixing Dense layers on the fp32 MFMA
+kernels, the equivariant message as one fused kernel per interaction (filters recomputed in registers; the
+reference's [E, 1, 3F n_int] filter tensor, painn.py:232, never exists), first-order backward w.r.t. ``_Rij`` and
+the embedding rows.  Training mode: differentiable primitive path.  Both are TorchScript-able.
 """
-import ctypes
-import os
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, Final, List, Optional
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _lib, ops
+from .. import _lib
 from .. import properties
+from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 from ..nn import Dense, replicate_module, scatter_add
 from ..nn.base import activation_id
 
@@ -34,10 +33,18 @@ class PaiNNInteraction(nn.Module):
             Dense(n_atom_basis, 3 * n_atom_basis, activation=None),
         )
 
-    def forward(self, q, mu, Wij, dir_ij, idx_i, idx_j, n_atoms: int):
+    def fused_weights(self) -> List[torch.Tensor]:
+        c0 = self.interatomic_context_net[0]
+        c1 = self.interatomic_context_net[1]
+        b0, b1 = c0.bias, c1.bias
+        assert b0 is not None and b1 is not None
+        return [c0.weight, b0, c1.weight, b1]
+
+    def forward(self, q: torch.Tensor, mu: torch.Tensor, Wij: torch.Tensor, dir_ij: torch.Tensor,
+                idx_i: torch.Tensor, idx_j: torch.Tensor, n_atoms: int):
         x = self.interatomic_context_net(q)
-        xj = ops.gather(x, idx_j, 0)
-        muj = ops.gather(mu, idx_j, 0)
+        xj = torch.ops.spk_hip.gather(x, idx_j, 0)
+        muj = torch.ops.spk_hip.gather(mu, idx_j, 0)
         x = Wij * xj
         dq, dmuR, dmumu = torch.split(x, self.n_atom_basis, dim=-1)
         dq = scatter_add(dq, idx_i, dim_size=n_atoms)
@@ -59,6 +66,13 @@ class PaiNNMixing(nn.Module):
         self.mu_channel_mix = Dense(n_atom_basis, 2 * n_atom_basis, activation=None, bias=False)
         self.epsilon = epsilon
 
+    def fused_weights(self) -> List[torch.Tensor]:
+        i0 = self.intraatomic_context_net[0]
+        i1 = self.intraatomic_context_net[1]
+        b0, b1 = i0.bias, i1.bias
+        assert b0 is not None and b1 is not None
+        return [self.mu_channel_mix.weight, i0.weight, b0, i1.weight, b1]
+
     def forward(self, q: torch.Tensor, mu: torch.Tensor):
         mu_mix = self.mu_channel_mix(mu)
         mu_V, mu_W = torch.split(mu_mix, self.n_atom_basis, dim=-1)
@@ -74,6 +88,8 @@ class PaiNNMixing(nn.Module):
 class PaiNN(nn.Module):
     """PaiNN representation; see the reference docstring (painn.py:120-157) for arguments."""
 
+    _fused: Final[bool]
+
     def __init__(self, n_atom_basis: int, n_interactions: int, radial_basis: nn.Module,
                  cutoff_fn: Optional[Callable] = None, activation: Optional[Callable] = F.silu,
                  shared_interactions: bool = False, shared_filters: bool = False,
@@ -86,7 +102,6 @@ class PaiNN(nn.Module):
         self.cutoff = cutoff_fn.cutoff
         self.radial_basis = radial_basis
         self.epsilon = epsilon
-        self._activation = activation
         if nuclear_embedding is None:
             nuclear_embedding = nn.Embedding(100, n_atom_basis)
         self.embedding = nuclear_embedding
@@ -105,73 +120,33 @@ class PaiNN(nn.Module):
         self.mixing = replicate_module(
             lambda: PaiNNMixing(n_atom_basis=self.n_atom_basis, activation=activation, epsilon=epsilon),
             self.n_interactions, shared_interactions)
+        self._fused = self._fusable()
 
-    def _act(self):
+    def __setstate__(self, state):
         # instances restored from reference pickles never ran this __init__
-        act = getattr(self, "_activation", None)
-        if act is None and len(self.interactions) > 0:
-            act = self.interactions[0].interatomic_context_net[0].activation
-        return act
+        super().__setstate__(state)
+        if not isinstance(self.__dict__.get("_modules", {}).get("electronic_embeddings"), nn.ModuleList):
+            self.electronic_embeddings = nn.ModuleList(self.__dict__.pop("electronic_embeddings", None) or [])
+        if "epsilon" not in self.__dict__:
+            self.epsilon = float(self.mixing[0].epsilon) if len(self.mixing) > 0 else 1e-8
+        if "_fused" not in self.__dict__:
+            self._fused = self._fusable()
 
     def _eps(self) -> float:
-        eps = getattr(self, "epsilon", None)
-        if eps is None:
-            eps = self.mixing[0].epsilon if len(self.mixing) > 0 else 1e-8
-        return float(eps)
+        return float(self.epsilon)
 
     def _fusable(self) -> bool:
-        return (activation_id(self._act()) == _lib.SPK_ACT_SILU
-                and hasattr(self.radial_basis, "kernel_args")
+        """The one-operator eval path covers SiLU context nets, the mirrored radial bases (not trainable) and cosine
+        cutoff within the kernels' shape limits (spk_painn.hip: n_atom_basis <= 1024, n_rbf <= 256)."""
+        if len(self.interactions) == 0:
+            return False
+        acts = [self.interactions[0].interatomic_context_net[0].activation, self.mixing[0].intraatomic_context_net[0].activation]
+        n_rbf = int(getattr(self.radial_basis, "n_rbf", 0))
+        return (all(activation_id(a) == _lib.SPK_ACT_SILU for a in acts)
+                and hasattr(self.radial_basis, "kernel_params")
                 and not getattr(self.radial_basis, "trainable", False)
-                and hasattr(self.cutoff_fn, "cutoff_value"))
-
-    def _model_struct(self):
-        L = self.n_interactions
-        Fd = self.n_atom_basis
-        params = list(self.filter_net.parameters()) + [p for m in list(self.interactions) + list(self.mixing) for p in m.parameters()]
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        cache = self.__dict__.get("_struct_cache")
-        if cache is not None and cache[0] == key:
-            return cache[1], cache[2]
-        arr = (_lib.PainnLayerT * max(L, 1))()
-        keep = []
-        fw = self.filter_net.weight.detach().contiguous()
-        fb = self.filter_net.bias.detach().contiguous()
-        keep += [fw, fb]
-        n_rbf = fw.shape[1]
-        for l in range(L):
-            it, mx = self.interactions[l], self.mixing[l]
-            row0 = 0 if self.share_filters else 3 * Fd * l
-            ts = {
-                "ctx_w1": it.interatomic_context_net[0].weight, "ctx_b1": it.interatomic_context_net[0].bias,
-                "ctx_w2": it.interatomic_context_net[1].weight, "ctx_b2": it.interatomic_context_net[1].bias,
-                "mix_w": mx.mu_channel_mix.weight,
-                "ictx_w1": mx.intraatomic_context_net[0].weight, "ictx_b1": mx.intraatomic_context_net[0].bias,
-                "ictx_w2": mx.intraatomic_context_net[1].weight, "ictx_b2": mx.intraatomic_context_net[1].bias,
-            }
-            for name, t in ts.items():
-                t = t.detach().contiguous()
-                keep.append(t)
-                setattr(arr[l], name, _lib.fptr(t))
-                if name in ("ctx_w1", "ctx_w2", "mix_w", "ictx_w1", "ictx_w2"):
-                    tt = t.t().contiguous()  # [in, out]: coalesced weight reads in the forward chains
-                    keep.append(tt)
-                    setattr(arr[l], name + "T", _lib.fptr(tt))
-            arr[l].filt_w = ctypes.c_void_p(fw.data_ptr() + 4 * row0 * n_rbf)
-            arr[l].filt_b = ctypes.c_void_p(fb.data_ptr() + 4 * row0)
-        ms = _lib.PainnT(Fd, L, self._eps(), 0, ctypes.cast(arr, ctypes.POINTER(_lib.PainnLayerT)), None)
-        keep.append(arr)
-        # packed images of the atom-wise weights for the fused Dense chains (0 floats: shapes without one)
-        n_pack = int(_lib.lib().spk_painn_packed_floats(ctypes.byref(ms))) if L > 0 else 0
-        if n_pack > 0 and not os.environ.get("SPK_NO_PACK"):
-            dev = next(self.parameters()).device
-            wpack = torch.empty(n_pack, dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(_lib.lib().spk_painn_pack_weights_f32(ctypes.byref(ms), _lib.fptr(wpack), _lib.stream()))
-            ms.wpack = _lib.fptr(wpack)
-            keep.append(wpack)
-        self.__dict__["_struct_cache"] = (key, ms, keep)
-        return ms, keep
+                and hasattr(self.cutoff_fn, "cutoff_value")
+                and self.n_atom_basis <= 1024 and 1 <= n_rbf <= 256)
 
     def forward(self, inputs: Dict[str, torch.Tensor]):
         atomic_numbers = inputs[properties.Z]
@@ -179,21 +154,24 @@ class PaiNN(nn.Module):
         idx_i = inputs[properties.idx_i]
         idx_j = inputs[properties.idx_j]
         n_atoms = atomic_numbers.shape[0]
-        ops._check_float(r_ij, "PaiNN")
 
         q = self.embedding(atomic_numbers)
         for embedding in self.electronic_embeddings:
             q = q + embedding(q, inputs)
 
-        if not self.training and self._fusable():
-            plan = ops.edge_plan(idx_i, idx_j, n_atoms, r_ij)
-            if plan.filter_pairs is None and plan.n_edges >= (1 << 19):
-                # large lists: tells the message dispatch whether the list carries a skin (one sync per list)
-                plan.decide_filter(r_ij, self.cutoff_fn.cutoff_value())
-            ms, keep = self._model_struct()
-            rb_args = self.radial_basis.kernel_args(self.cutoff_fn.cutoff_value())
-            # eval path: geometry gradients only (embedding / weights are not differentiated)
-            q, mu = ops.PaiNNFn.apply(q.detach(), r_ij, plan, rb_args, ms, keep)
+        if self._fused and not self.training:
+            # nine tensors per interaction in the order of spk_painn_layer_t (include/spk_hip.h), then filter_net.{weight, bias}
+            ws: List[torch.Tensor] = []
+            for interaction, mixing in zip(self.interactions, self.mixing):
+                ws += interaction.fused_weights()
+                ws += mixing.fused_weights()
+            fb = self.filter_net.bias
+            assert fb is not None
+            ws.append(self.filter_net.weight)
+            ws.append(fb)
+            kind, p0, p1 = self.radial_basis.kernel_params()
+            q, mu = torch.ops.spk_hip.painn(q, r_ij, idx_i, idx_j, ws, self.share_filters, self.epsilon, kind, p0, p1,
+                                            self.cutoff_fn.cutoff_value())
         else:
             d_ij = torch.norm(r_ij, dim=1, keepdim=True)
             dir_ij = r_ij / d_ij

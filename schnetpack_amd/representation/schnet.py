@@ -1,21 +1,21 @@
 """Mirror of ``schnetpack.representation.schnet`` (representation/schnet.py:14-173) on the
 gfx950 kernels: same class names, constructor signatures, attributes and ``state_dict`` keys.
 
-``SchNet.forward`` in eval mode runs the whole representation as one fused HIP call
-(``ops.SchNetFn``: in2f -> fused cfconv (RBF x cutoff x filter MLP x gather x segmented sum, no
-[E, F] tensor) -> f2out, for every interaction) and its first-order backward w.r.t. ``_Rij`` --
-what ``Forces`` asks for.  In training mode (force loss => double backward) it runs the
-differentiable primitive path: HIP Dense / gather / scatter_add with torch elementwise algebra.
+``SchNet.forward`` in eval mode runs the whole representation as ONE operator, ``torch.ops.spk_hip.schnet``
+(in2f -> fused cfconv (RBF x cutoff x filter MLP x gather x segmented sum, no [E, F] tensor) -> f2out, for every
+interaction; one C call forward, one C call for the first-order backward w.r.t. ``_Rij`` and the embedding rows --
+what ``Forces`` asks for).  In training mode (force loss => double backward) it runs the differentiable primitive
+path: HIP Dense / gather / scatter_add with torch elementwise algebra.  Both are TorchScript-able
+(reference tests/nn/test_schnet.py:83-96).
 """
-import ctypes
-import os
-from typing import Callable, Dict, List, Optional, Union
+from typing import Callable, Dict, Final, List, Optional, Union
 
 import torch
 from torch import nn
 
-from .. import _lib, ops
+from .. import _lib
 from .. import properties
+from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 from ..nn import Dense, scatter_add
 from ..nn import replicate_module
 from ..nn.activations import shifted_softplus
@@ -40,12 +40,22 @@ class SchNetInteraction(nn.Module):
             Dense(n_rbf, n_filters, activation=activation), Dense(n_filters, n_filters)
         )
 
+    def fused_weights(self) -> List[torch.Tensor]:
+        """The nine tensors of this block in the order of ``spk_schnet_layer_t`` (include/spk_hip.h)."""
+        fn0 = self.filter_network[0]
+        fn1 = self.filter_network[1]
+        o0 = self.f2out[0]
+        o1 = self.f2out[1]
+        b0, b1, b2, b3 = fn0.bias, fn1.bias, o0.bias, o1.bias
+        assert b0 is not None and b1 is not None and b2 is not None and b3 is not None
+        return [self.in2f.weight, fn0.weight, b0, fn1.weight, b1, o0.weight, b2, o1.weight, b3]
+
     def forward(self, x: torch.Tensor, f_ij: torch.Tensor, idx_i: torch.Tensor,
                 idx_j: torch.Tensor, rcut_ij: torch.Tensor):
         x = self.in2f(x)
         Wij = self.filter_network(f_ij)
         Wij = Wij * rcut_ij[:, None]
-        x_j = ops.gather(x, idx_j, 0)
+        x_j = torch.ops.spk_hip.gather(x, idx_j, 0)
         x_ij = x_j * Wij
         x = scatter_add(x_ij, idx_i, dim_size=x.shape[0])
         return self.f2out(x)
@@ -53,6 +63,8 @@ class SchNetInteraction(nn.Module):
 
 class SchNet(nn.Module):
     """SchNet representation; see the reference docstring (schnet.py:73-116) for arguments."""
+
+    _fused: Final[bool]
 
     def __init__(self, n_atom_basis: int, n_interactions: int, radial_basis: nn.Module,
                  cutoff_fn: Callable, n_filters: int = None, shared_interactions: bool = False,
@@ -71,79 +83,50 @@ class SchNet(nn.Module):
         if electronic_embeddings is None:
             electronic_embeddings = []
         self.electronic_embeddings = nn.ModuleList(electronic_embeddings)
-        self._activation = activation
         self.interactions = replicate_module(
             lambda: SchNetInteraction(n_atom_basis=self.n_atom_basis, n_rbf=self.radial_basis.n_rbf,
                                       n_filters=self.n_filters, activation=activation),
             n_interactions, shared_interactions)
+        self._fused = self._fusable()
 
-    # -- fused eval path ---------------------------------------------------------------
-    def _act(self):
+    def __setstate__(self, state):
         # instances restored from reference pickles never ran this __init__
-        act = getattr(self, "_activation", None)
-        if act is None and len(self.interactions) > 0:
-            act = self.interactions[0].filter_network[0].activation
-        return act
+        super().__setstate__(state)
+        if not isinstance(self.__dict__.get("_modules", {}).get("electronic_embeddings"), nn.ModuleList):
+            self.electronic_embeddings = nn.ModuleList(self.__dict__.pop("electronic_embeddings", None) or [])
+        if "_fused" not in self.__dict__:
+            self._fused = self._fusable()
 
     def _fusable(self) -> bool:
-        return (activation_id(self._act()) == _lib.SPK_ACT_SSP
-                and hasattr(self.radial_basis, "kernel_args")
+        """The one-operator eval path covers ssp filters / output nets, the mirrored radial bases (not trainable) and
+        cosine cutoff, within the kernels' shape limits (spk_cfconv.hip: n_filters % 4, n_rbf <= 256)."""
+        if len(self.interactions) == 0:
+            return True
+        it = self.interactions[0]
+        acts = [it.filter_network[0].activation, it.f2out[0].activation]
+        n_rbf = int(getattr(self.radial_basis, "n_rbf", 0))
+        return (all(activation_id(a) == _lib.SPK_ACT_SSP for a in acts)
+                and hasattr(self.radial_basis, "kernel_params")
                 and not getattr(self.radial_basis, "trainable", False)
-                and hasattr(self.cutoff_fn, "cutoff_value"))
-
-    def _model_struct(self):
-        """ctypes parameter block (device pointers of the state_dict tensors + cached transposed
-        copies of the atom-wise weights for coalesced reads; rebuilt when a parameter changes)."""
-        L = len(self.interactions)
-        params = [p for it in self.interactions for p in it.parameters()]
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        cache = self.__dict__.get("_struct_cache")
-        if cache is not None and cache[0] == key:
-            return cache[1], cache[2]
-        arr = (_lib.SchnetLayerT * max(L, 1))()
-        keep = []
-        for l, it in enumerate(self.interactions):
-            ts = [it.in2f.weight, it.filter_network[0].weight, it.filter_network[0].bias,
-                  it.filter_network[1].weight, it.filter_network[1].bias, it.f2out[0].weight,
-                  it.f2out[0].bias, it.f2out[1].weight, it.f2out[1].bias]
-            ts = [t.detach().contiguous() for t in ts]
-            ts += [ts[0].t().contiguous(), ts[5].t().contiguous(), ts[7].t().contiguous()]
-            keep.extend(ts)
-            for name, t in zip([f[0] for f in _lib.SchnetLayerT._fields_], ts):
-                setattr(arr[l], name, _lib.fptr(t))
-        ms = _lib.SchnetT(self.n_atom_basis, self.n_filters, L, 0,
-                          ctypes.cast(arr, ctypes.POINTER(_lib.SchnetLayerT)), None)
-        keep.append(arr)
-        # packed images of the atom-wise weights for the fused Dense chains (0 floats: shapes without one)
-        n_pack = int(_lib.lib().spk_schnet_packed_floats(ctypes.byref(ms))) if L > 0 else 0
-        if n_pack > 0 and not os.environ.get("SPK_NO_PACK"):
-            wpack = torch.empty(n_pack, dtype=torch.float32, device=params[0].device)
-            with torch.cuda.device(wpack.device):
-                _lib.check(_lib.lib().spk_schnet_pack_weights_f32(ctypes.byref(ms), _lib.fptr(wpack), _lib.stream()))
-            ms.wpack = _lib.fptr(wpack)
-            keep.append(wpack)
-        self.__dict__["_struct_cache"] = (key, ms, keep)
-        return ms, keep
+                and hasattr(self.cutoff_fn, "cutoff_value")
+                and self.n_filters % 4 == 0 and self.n_filters <= 1024 and 1 <= n_rbf <= 256)
 
     def forward(self, inputs: Dict[str, torch.Tensor]):
         atomic_numbers = inputs[properties.Z]
         r_ij = inputs[properties.Rij]
         idx_i = inputs[properties.idx_i]
         idx_j = inputs[properties.idx_j]
-        ops._check_float(r_ij, "SchNet")
 
         x = self.embedding(atomic_numbers)
         for embedding in self.electronic_embeddings:
             x = x + embedding(x, inputs)
 
-        if not self.training and self._fusable():
-            plan = ops.edge_plan(idx_i, idx_j, x.shape[0], r_ij)
-            if plan.filter_pairs is None:
-                plan.decide_filter(r_ij, self.cutoff_fn.cutoff_value())
-            ms, keep = self._model_struct()
-            rb_args = self.radial_basis.kernel_args(self.cutoff_fn.cutoff_value())
-            # eval path: geometry gradients only (embedding / weights are not differentiated)
-            x = ops.SchNetFn.apply(x.detach(), r_ij, plan, rb_args, ms, keep)
+        if self._fused and not self.training:
+            ws: List[torch.Tensor] = []
+            for interaction in self.interactions:
+                ws += interaction.fused_weights()
+            kind, p0, p1 = self.radial_basis.kernel_params()
+            x = torch.ops.spk_hip.schnet(x, r_ij, idx_i, idx_j, ws, self.n_filters, kind, p0, p1, self.cutoff_fn.cutoff_value())
         else:
             d_ij = torch.norm(r_ij, dim=1)
             f_ij = self.radial_basis(d_ij)

@@ -1,0 +1,78 @@
+"""``torch.ops.spk_hip.*`` -- the PyTorch-ROCm extension face of the HIP kernels.
+
+``libspk_torch.so`` (``csrc/spk_torch.cpp``, built in-tree next to ``libspk_hip.so``) registers the operators with
+``TORCH_LIBRARY``: C++ ``torch::autograd::Function`` wrappers, ROCm kernels (= calls into the C ABI of
+``include/spk_hip.h`` on torch's current stream), Meta kernels (shape inference) and a loud CPU refusal.  The module
+mirrors (``schnetpack_amd.nn``, ``.representation``, ``.atomistic``) call nothing else, which is what makes them
+TorchScript-able: ``torch.jit.script(SchNet(...))`` (reference tests/nn/test_schnet.py:83-96), ``spkdeploy``
+(src/scripts/spkdeploy:16-40), ``SchNetPackCalculator(script_model=True)``
+(md/calculators/schnetpack_calculator.py:105-107).  From C++ (interfaces/lammps/pair_schnetpack.cpp:128) a scripted model
+loads after ``dlopen("libspk_torch.so")``.
+
+Importing this module loads both shared libraries; it raises ``SpkHipError`` when either has not been built -- there is
+no eager / CPU fallback behind it.
+"""
+import os
+
+import torch
+
+from . import _lib
+from ._lib import SpkHipError
+
+TORCH_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libspk_torch.so")
+_loaded = False
+
+
+def load():
+    """Load libspk_hip.so, then the operator library (idempotent)."""
+    global _loaded
+    if _loaded:
+        return torch.ops.spk_hip
+    _lib.lib()      # RTLD_GLOBAL: libspk_torch.so resolves the C ABI from it
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise SpkHipError("libspk_torch.so not found at %s -- build it with `python -m schnetpack_amd.csrc.build` "
+                          "(there is no fallback path behind the torch.ops.spk_hip operators)" % TORCH_LIB_PATH)
+    torch.ops.load_library(TORCH_LIB_PATH)
+    _loaded = True
+    return torch.ops.spk_hip
+
+
+ops = load()
+
+OPERATORS = ["scatter_add", "gather", "pairwise", "pairwise_backward", "dense", "radial_cutoff", "schnet", "painn", "atomwise",
+             "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
+             "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare", "static_refresh", "static_enable",
+             "static_check", "static_clear", "clear_caches"]
+
+
+class StaticLists:
+    """Static-shape mode for HIP-graph replays of the differentiable (training) path.
+
+    Plans of index tensors are normally cached on tensor identity / version and validated with a host round trip --
+    neither survives a graph whose index BUFFERS are refilled between replays.  Inside ``with StaticLists() as sl:``
+    (and in the captured graph) every index tensor declared with ``sl.declare_sorted(idx, n_rows)`` gets its CSR row
+    pointers from a device-only kernel launched by ``sl.refresh()`` (capture that call at the start of the step); all
+    other indices take the atomic scatter; neighbour-list plans (symmetry, reverse map) are not used.  ``sl.check()``
+    polls the device flag that the refresh kernels raise when a declared index was not ascending / in range."""
+
+    def __init__(self):
+        ops.static_clear()
+
+    def declare_sorted(self, idx, n_rows):
+        return ops.static_declare(idx, int(n_rows))
+
+    def refresh(self):
+        ops.static_refresh()
+
+    def check(self):
+        f = int(ops.static_check())
+        if f:
+            raise SpkHipError("StaticLists: a declared index was %s" % ("not ascending" if f & 1 else "out of range"))
+
+    def __enter__(self):
+        ops.static_enable(True)
+        return self
+
+    def __exit__(self, *exc):
+        ops.static_enable(False)
+        return False

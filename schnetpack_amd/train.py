@@ -8,7 +8,7 @@ Instead of a tracing compiler the step is captured once into a HIP graph and rep
   (self pairs of the last atom with an offset beyond the cutoff: the cosine cutoff and its derivative vanish
   there, so energies, forces and all gradients are exactly those of the unpadded batch);
 * the index tensors are static BUFFERS refilled per step; their CSR row pointers are recomputed inside the
-  graph by a device-only kernel (``ops.StaticLists``), no plan cache, no host round trip;
+  graph by a device-only kernel (``torchops.StaticLists``), no plan cache, no host round trip;
 * gradients are views of one flat bucket (``parallel.FlatGradAllReduce(as_views=True)``): cleared with one
   fill, all-reduced with one RCCL call between the two graphs (backward | optimizer) when there are ranks;
 * AdamW runs ``capturable`` so that its step is part of the graph.
@@ -20,7 +20,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import ops, properties
+from . import properties, torchops
 from .parallel import FlatGradAllReduce
 
 __all__ = ["GraphedTrainStep", "pad_edges"]
@@ -62,7 +62,7 @@ class GraphedTrainStep:
         }
         self.E_t, self.F_t = z(self.M), z(self.N, 3)
         self.loss = z(())
-        self.lists = ops.StaticLists()
+        self.lists = torchops.StaticLists()
         self.lists.declare_sorted(self.buf[properties.idx_i], self.N)
         self.lists.declare_sorted(self.buf[properties.idx_m], self.M)
         self.reducer = FlatGradAllReduce(model.parameters(), as_views=True)

@@ -133,21 +133,26 @@ def test_full_box_force_call_auto_dispatch(dev, kind):
 @pytest.mark.parametrize("kind", ["schnet", "painn"])
 def test_supercell_forces_tile(dev, kind):
     from schnetpack_amd import neighborlist as NL
-    small = S.water_box(n_side=11, seed=7)
-    n = small["Z"].shape[0]
-    L = float(small["cell"][0, 0])
+    base = S.water_box(n_side=11, seed=7)
+    # coordinates and box edge on a 2^-16 A grid: the shifted copies R + n L are then EXACT in float32 (< 128 A), so the
+    # supercell is bit-for-bit the same crystal and any deviation is the kernels', not input rounding
+    q = 65536.0
+    L = round(float(base["cell"][0, 0]) * q) / q
+    Rs = torch.remainder(torch.round(base["R"].double() * q) / q, L).float()
+    pbc = torch.tensor([True, True, True], device=dev)
+
+    def box(R, edge, Z):
+        idx_m = torch.zeros(R.shape[0], dtype=torch.long)
+        cell = (torch.eye(3) * edge).reshape(1, 3, 3)
+        nl = NL.neighbor_list(R.to(dev), 5.0, idx_m=idx_m.to(dev), cell=cell.to(dev), pbc=pbc, n_systems=1)
+        return {"Z": Z, "R": R, "idx_i": nl["_idx_i"].cpu(), "idx_j": nl["_idx_j"].cpu(), "offsets": nl["_offsets"].cpu(),
+                "idx_m": idx_m, "n_mol": 1}
+    small = box(Rs, L, base["Z"])
     shifts = torch.tensor([[a, b_, c] for a in (0, 1) for b_ in (0, 1) for c in (0, 1)], dtype=torch.float32) * L
-    R = (small["R"][None, :, :] + shifts[:, None, :]).reshape(-1, 3)
-    Z = small["Z"].repeat(8)
-    assert R.shape[0] == 31944
-    cell = (small["cell"] * 2).reshape(1, 3, 3).to(dev)
-    idx_m = torch.zeros(R.shape[0], dtype=torch.long)
-    nl = NL.neighbor_list(R.to(dev), 5.0, idx_m=idx_m.to(dev), cell=cell,
-                          pbc=torch.tensor([True, True, True], device=dev), n_systems=1)
-    big = {"Z": Z, "R": R, "idx_i": nl["_idx_i"].cpu(), "idx_j": nl["_idx_j"].cpu(), "offsets": nl["_offsets"].cpu(),
-           "idx_m": idx_m, "n_mol": 1}
-    # (pairs within one float32 ulp of the cutoff may fall on the other side after the shift; they carry f_c ~ 0)
-    assert abs(int(big["idx_i"].shape[0]) - 8 * int(small["idx_i"].shape[0])) <= 32
+    Rb = (Rs[None, :, :] + shifts[:, None, :]).reshape(-1, 3)
+    assert Rb.shape[0] == 31944 and torch.equal((Rb.double() - shifts.double().repeat_interleave(Rs.shape[0], 0)).float(), Rs.repeat(8, 1))
+    big = box(Rb, 2 * L, base["Z"].repeat(8))
+    assert int(big["idx_i"].shape[0]) == 8 * int(small["idx_i"].shape[0]) >= (1 << 19)
     rep_p, head_p = _params(kind)
     ref = _oracle(kind, rep_p, head_p, small)
     model = _model(kind, dev, rep_p, head_p)

@@ -46,16 +46,19 @@ def test_compute_entry_points_fail_without_gpu_or_with_cpu_tensors():
     from schnetpack_amd import ops
     from schnetpack_amd._lib import SpkHipError
     from schnetpack_amd.nn import CosineCutoff, Dense, GaussianRBF, scatter_add
-    with pytest.raises(SpkHipError):
+    # the module mirrors go through torch.ops.spk_hip (its CPU dispatch key is a loud refusal), ops.* through ctypes
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         scatter_add(torch.ones(4, 2), torch.tensor([0, 0, 1, 1]), 2)
-    with pytest.raises(SpkHipError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         Dense(8, 32)(torch.ones(2, 8))
-    with pytest.raises(SpkHipError):
-        GaussianRBF(20, 5.0)(torch.ones(3))
-    with pytest.raises(SpkHipError):
-        CosineCutoff(5.0)(torch.ones(3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GaussianRBF(20, 5.0).eval()(torch.ones(3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        CosineCutoff(5.0).eval()(torch.ones(3))
     with pytest.raises(SpkHipError):
         ops.gather(torch.ones(3, 2), torch.tensor([0, 1]))
+    with pytest.raises(SpkHipError):
+        ops.scatter_add(torch.ones(4, 2), torch.tensor([0, 0, 1, 1]), 2)
 
 
 @pytest.mark.parametrize("kind", ["schnet", "painn"])
