@@ -835,11 +835,10 @@ void check_eval_backward(AutogradContext* ctx, const char* who, size_t first) {
 
 struct SchNetFn : public torch::autograd::Function<SchNetFn> {
   // tensor inputs in positions 0 (x0), 1 (r_ij), 6 / 7 (radial parameters) and 9.. (weights)
+  // save_filters: keep the raw filter outputs for the backward (decided by the caller: grad mode is off inside forward())
   static Tensor forward(AutogradContext* ctx, const Tensor& x0, const Tensor& r_ij, const Tensor& idx_i, const Tensor& idx_j,
                         int64_t n_filters, int64_t rbf_kind, const Tensor& p0, const c10::optional<Tensor>& p1, double cutoff,
-                        at::TensorList ws) {
-    // keep the raw filter outputs for the backward when a gradient w.r.t. the geometry may be asked for
-    const bool save_filters = r_ij.requires_grad() && at::GradMode::is_enabled();
+                        bool save_filters, at::TensorList ws) {
     at::AutoDispatchBelowADInplaceOrView guard;
     auto out = call_schnet_forward(x0, r_ij, idx_i, idx_j, ws, n_filters, rbf_kind, p0, p1, cutoff, save_filters);
     std::vector<Tensor> sv{r_ij, std::get<1>(out), std::get<2>(out), p0, (p1.has_value() && p1->defined()) ? *p1 : Tensor(), idx_i, idx_j};
@@ -859,7 +858,7 @@ struct SchNetFn : public torch::autograd::Function<SchNetFn> {
     Tensor gx = grads[0].defined() ? grads[0] : at::zeros({cfg[0], cfg[1]}, sv[0].options());
     auto res = call_schnet_backward(gx, sv[0], sv[1], sv[2], sv[5], sv[6], ws, cfg[2], cfg[3], sv[3], opt_of(sv[4]), ctx->saved_data["cutoff"].toDouble(),
                                     cfg[4] != 0, ctx->needs_input_grad(0));
-    variable_list out(9 + n_ws);
+    variable_list out(10 + n_ws);
     if (ctx->needs_input_grad(0)) out[0] = std::get<1>(res);
     if (ctx->needs_input_grad(1)) out[1] = std::get<0>(res);
     return out;
@@ -930,7 +929,9 @@ std::tuple<Tensor, Tensor> radial_cutoff_ad(const Tensor& d, int64_t kind, const
 }
 Tensor schnet_ad(const Tensor& x0, const Tensor& r_ij, const Tensor& idx_i, const Tensor& idx_j, at::TensorList ws, int64_t n_filters,
                  int64_t rbf_kind, const Tensor& p0, const c10::optional<Tensor>& p1, double cutoff) {
-  return SchNetFn::apply(x0, r_ij, idx_i, idx_j, n_filters, rbf_kind, p0, p1, cutoff, ws);
+  // a gradient w.r.t. the geometry may be asked for: keep the raw filter outputs so that the backward runs the derivative GEMM only
+  const bool save_filters = at::GradMode::is_enabled() && r_ij.requires_grad();
+  return SchNetFn::apply(x0, r_ij, idx_i, idx_j, n_filters, rbf_kind, p0, p1, cutoff, save_filters, ws);
 }
 std::tuple<Tensor, Tensor> painn_ad(const Tensor& q0, const Tensor& r_ij, const Tensor& idx_i, const Tensor& idx_j, at::TensorList ws,
                                     bool shared_filters, double eps, int64_t rbf_kind, const Tensor& p0, const c10::optional<Tensor>& p1,
@@ -1001,12 +1002,14 @@ Tensor atomwise_backward_op(const c10::optional<Tensor>& gE, const c10::optional
 }
 
 // (rowptr, rev, half, flags[sorted, symmetric, n_half, filter_pairs]) of a list; also warms the cache outside a graph capture
+// force_filter: -1 = decide from the geometry (cutoff > 0), 0 / 1 = switch the per-call pair compaction off / on for this list
 std::tuple<Tensor, Tensor, Tensor, Tensor> edge_plan_op(const Tensor& idx_i, const Tensor& idx_j, int64_t n_atoms, const c10::optional<Tensor>& r_ij,
-                                                        double cutoff) {
+                                                        double cutoff, int64_t force_filter) {
   require_device(idx_i, "edge_plan");
   Tensor r = (r_ij.has_value() && r_ij->defined()) ? *r_ij : Tensor();
   auto p = get_plan(idx_i, idx_j, n_atoms, r);
-  if (r.defined() && cutoff > 0) decide_filter(*p, r, cutoff);
+  if (force_filter >= 0) p->filter_pairs = (force_filter != 0 && p->symmetric && p->n_edges > 0) ? 1 : 0;
+  else if (r.defined() && cutoff > 0) decide_filter(*p, r, cutoff);
   Tensor flags = at::tensor(std::vector<int64_t>{p->sorted, p->symmetric, p->n_half, p->filter_pairs}, at::TensorOptions().dtype(at::kLong));
   auto iopt = at::TensorOptions().dtype(at::kInt).device(idx_i.device());
   return {p->rowptr, p->rev, p->half.defined() ? p->half : at::empty({0}, iopt), flags};
@@ -1148,7 +1151,7 @@ TORCH_LIBRARY(spk_hip, m) {
   m.def("painn_backward(Tensor? gq, Tensor? gmu, Tensor r_ij, Tensor saved, Tensor scratch, Tensor idx_i, Tensor idx_j, int n_atoms, Tensor[] weights, bool shared_filters, float epsilon, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, bool want_gq0) -> (Tensor, Tensor)");
   m.def("atomwise_forward(Tensor x, Tensor w1, Tensor? b1, Tensor w2, Tensor? b2, Tensor idx_m, int n_mol, int act) -> (Tensor, Tensor, Tensor)");
   m.def("atomwise_backward(Tensor? gE, Tensor? gy_atom, Tensor pre, Tensor w1, Tensor w2, Tensor idx_m, int n_mol, int act) -> Tensor");
-  m.def("edge_plan(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor? r_ij, float cutoff=0.0) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("edge_plan(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor? r_ij, float cutoff=0.0, int force_filter=-1) -> (Tensor, Tensor, Tensor, Tensor)");
   // static-shape mode + cache control (host-side state)
   m.def("static_declare(Tensor idx, int n_rows) -> Tensor");
   m.def("static_refresh() -> ()", static_refresh_op);

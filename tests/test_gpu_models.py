@@ -272,16 +272,15 @@ def test_pair_filter_for_lists_with_skin(dev, n_mol):
     model = model.to(dev).eval()
     b = S.molecule_batch("aspirin", n_mol, cutoff=5.0, seed=4)      # list built with 5.0 A, model cutoff 3.5 A
     res = {}
+    N = int(b["Z"].shape[0])
     for force in (False, True, None):
-        inp = M.batch_to_inputs(b, dev)
+        inp = M.batch_to_inputs(b, dev)        # fresh index tensors: a new plan in the operator library's cache
         r = O.pairwise_vectors(b["R"], b["idx_i"], b["idx_j"], b["offsets"]).to(dev)
-        plan = ops.edge_plan(inp["_idx_i"], inp["_idx_j"], b["Z"].shape[0], r)
-        if force is None:
-            assert plan.filter_pairs is None
-        else:
-            plan.set_filter(force)
+        flags = torch.ops.spk_hip.edge_plan(inp["_idx_i"], inp["_idx_j"], N, r, 0.0, -1 if force is None else int(force))[3]
+        assert int(flags[3]) == (-1 if force is None else int(force))           # [sorted, symmetric, n_half, filter_pairs]
         out = model(inp)
-        assert plan.filter_pairs is (True if force is None else force)      # auto: > 5 % of the pairs are beyond 3.5 A
+        flags = torch.ops.spk_hip.edge_plan(inp["_idx_i"], inp["_idx_j"], N, r)[3]
+        assert int(flags[3]) == (1 if force is None else int(force))            # auto: > 5 % of the pairs are beyond 3.5 A
         res[force] = (out["energy"].detach().cpu(), out["forces"].detach().cpu())
     ref = O.energy_and_forces("schnet", rep_p, head_p, b, 3)
     for k in res:
@@ -391,8 +390,8 @@ def test_periodic_list_with_skin_matches_oracle(dev, kind):
     assert rel_err(out["energy"].detach().cpu(), ref["energy"]) < TOL
     assert rel_err(out["forces"].detach().cpu(), ref["forces"]) < TOL
     if kind == "schnet":
-        plan = list(ops._PLAN_CACHE.values())[-1]
-        assert plan.filter_pairs is True
+        flags = torch.ops.spk_hip.edge_plan(inp["_idx_i"], inp["_idx_j"], int(b["Z"].shape[0]), inp["_Rij"].detach())[3]
+        assert int(flags[3]) == 1
     # and the same forces as with the exact 5 A list
     out5 = model(M.batch_to_inputs(wb, dev))
     assert rel_err(out["forces"].detach().cpu(), out5["forces"].detach().cpu()) < 1e-5

@@ -50,8 +50,8 @@ def test_scripted_model_equals_eager_and_oracle(dev, kind, tmp_path):
     for _ in range(3):                                       # incl. the profiling / optimised executor passes
         out_s = sm(dict(inp))
     assert rel_err(out_s["forces"].cpu(), ref["forces"]) < TOL and rel_err(out_s["energy"].cpu(), ref["energy"]) < TOL
-    assert torch.equal(out_s["energy"], out_e["energy"])
-    assert rel_err(out_s["forces"].cpu(), out_e["forces"].cpu()) < 2e-6     # (SchNet: float atomics, order varies)
+    # (SchNet's pair kernels sum with float atomics: the order, hence the last bits, vary from call to call)
+    assert rel_err(out_s["energy"].cpu(), out_e["energy"].cpu()) < 2e-6 and rel_err(out_s["forces"].cpu(), out_e["forces"].cpu()) < 2e-6
     # save -> load -> run; without the host-side molecule count (the reference's int(idx_m[-1]) + 1 path)
     p = str(tmp_path / "m.pt")
     torch.jit.save(sm, p)
