@@ -414,7 +414,13 @@ def main():
     # saved-filter backward executes 352/304 of the (halved) forward figure.
     flop_fwd = 2.0 * E * (n_rbf * nf + nf * nf)
     msg_bytes = E * 3100.0 + N * 4096.0
+    # molecule-resident forward (all interactions in one launch): the filter GEMMs of every interaction + the three Dense
+    # layers per interaction; executed = pair-shared filters, GEMM 1 repeated per channel tile, atom rows padded to 32
+    flop_dense = 2.0 * N * 3 * F * F
+    n_mol = int(batch["n_mol"])
+    exec_mol = n_int * (4096.0 * ((E // 2 + 31 * n_mol) // 32) * 4 * (4 * ((n_rbf + 7) // 8) + 64) + 4096.0 * n_mol * 3 * 4 * 64)
     algo = {
+        "schnet_mol_fwd": ("mfma", n_int * (flop_fwd + flop_dense), exec_mol / (n_int * (flop_fwd + flop_dense))),
         "cfconv_fwd_mfma": ("mfma", flop_fwd, 1.0), "cfconv_fwd_simple": ("mfma", flop_fwd, 1.0),
         "cfconv_fwd_pair": ("mfma", flop_fwd, 0.5),
         "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd, 1.0), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd, 1.0),

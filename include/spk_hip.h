@@ -85,6 +85,11 @@ typedef struct {
   int32_t filter_pairs;
   int32_t reserved0;
   const int32_t* n_half_dev;
+  /* optional ([n_edges] or NULL): position in `half` of the undirected pair every DIRECTED edge belongs to
+   * (edge_pair[half[k]] = edge_pair[rev[half[k]]] = k).  With it and the block-diagonal structure above (groups of at
+   * most 32 atoms) the fused SchNet representation runs molecule-resident: one workgroup per group, all interactions in
+   * one launch, per-atom row sums instead of float atomics (spk_schnet_mol.hip). */
+  const int32_t* edge_pair;
 } spk_graph_t;
 
 /* ------------------------------------------------------------------ library / device info */

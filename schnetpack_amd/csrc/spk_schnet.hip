@@ -53,6 +53,10 @@ extern "C" int64_t spk_schnet_scratch_floats(const spk_schnet_t* m, int64_t n_at
 #define SPK_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 #include "spk_pack.h"
+// molecule-resident path (spk_schnet_mol.hip): block-diagonal lists with <= 32 atoms per group
+bool spk_schnet_mol_eligible(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb);
+int spk_schnet_mol_forward(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                           const float* x0, const float* r_ij, float* x_out, float* saved, int64_t gsz, hipStream_t stream);
 // order of the packed images in spk_schnet_t::wpack: per interaction in2f, f2out.0, f2out.1 (forward, transposed each)
 static bool schnet_pack_shapes_ok(const spk_schnet_t* m) { return m->n_atom_basis % 128 == 0 && m->n_filters % 128 == 0 && m->n_atom_basis <= 384 && m->n_filters <= 384; }
 static SpkPackTable schnet_pack_table(const spk_schnet_t* m) {
@@ -117,6 +121,9 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
   auto hbuf = [&](int l) { return saved + (int64_t)l * N * (NF + F); };
   const int64_t gsz = (m->reserved & 1) ? spk_cfconv_gsave_floats(g, rb, NF) : 0;  // bit 0: saved has filter space
   float* gbase = saved + (int64_t)L * N * (NF + F);
+  // batches of small molecules with the filters saved for the backward: the whole forward is one molecule-resident launch
+  if (gsz > 0 && ptab.base && !schnet_filter_on(m, g, rb) && spk_schnet_mol_eligible(m, g, rb))
+    return spk_schnet_mol_forward(m, g, rb, ptab, x0, r_ij, x_out, saved, gsz, stream);
   // skin lists: compact the pair list of THIS call (pairs inside the cutoff, order kept) behind the saved filters
   spk_graph_t gact = *g;
   if (gsz > 0 && schnet_filter_on(m, g, rb)) {

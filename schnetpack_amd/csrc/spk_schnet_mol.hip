@@ -1,0 +1,409 @@
+// Molecule-resident SchNet representation (representation/schnet.py:147-173) for BATCHES OF SMALL MOLECULES.
+//
+// A batch produced by the reference's collate function (data/loader.py:35-46) is block diagonal: no edge leaves a
+// molecule.  With <= 32 atoms per block the whole representation of a block -- every interaction: in2f, the
+// continuous-filter convolution, f2out, the residual -- is local to ONE workgroup: the atom features live in LDS for the
+// whole kernel and nothing but the saved-for-backward tensors goes to memory.  One launch replaces the 1 + 2 L launches
+// of the general driver (spk_schnet.hip), the float atomics of the pair kernels and their memsets; configs[1] of
+// BASELINE.json (256 aspirin frames) maps one molecule onto each of the 256 compute units.
+//
+// Workgroup = 8 wavefronts, one group of atoms (a block, or several small blocks, <= 32 atoms).  Per interaction:
+//   A. task queue over  (pair tile, channel tile) filter tasks  +  4 in2f tasks:
+//        filter task: 32 undirected pairs -> phi -> GEMM 1 (hidden = ssp(W1 phi + b1), rows = hidden channels) ->
+//                     GEMM 2 with swapped operands (rows = pairs, columns = the 32 channels of the task) -> raw filter
+//                     outputs g to memory (the tensor the backward reads anyway; L2-resident, 78 KB per aspirin frame)
+//        in2f task:   h[:, 32t:32t+32] = x W_in^T   (T-GEMM, weights streamed from their packed image)
+//   B. y[a] = sum_{b in row(a)} h[b] * g[pair(a,b)] * f_c   -- a per-atom row sum over the directed CSR of the block,
+//        thread = (channel, atom quarter): no atomics, no scatter, deterministic
+//   C. t = ssp(y W3^T + b3);  x += t W4^T + b4      (two T-GEMM phases; the idle half of the workgroup stages the
+//        filter weights of the next interaction into LDS meanwhile)
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout: 1e-5 parity with the reference rules out bf16.
+#include "spk_common.h"
+#include "spk_pack.h"
+
+#define ML_MAXL 6
+#define ML_LD 132          // row stride (floats) of the [32][128] activation tiles in LDS: conflict-free 16-byte accesses
+#define ML_MAXPAIRS 512    // 32 atoms: at most 496 undirected pairs
+#define ML_MAXEDGES 1024
+#define ML_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
+
+struct MolLayerDev {
+  const float* in2f_p;                  // packed forward image of in2f.weight [NF, F] (spk_pack_weight_f32)
+  const float *w1, *b1, *w2, *b2;       // filter network, raw state_dict tensors
+  const float *o1_p, *o1_b, *o2_p, *o2_b;  // packed forward images of f2out.0 / f2out.1 and their biases
+};
+
+struct MolFwdArgs {
+  MolLayerDev L[ML_MAXL];
+  int n_layers;
+  const float* x0;          // [N, 128]
+  float* x_out;             // [N, 128]
+  const float* rij;         // [E, 3]
+  const int64_t* idx_i;
+  const int64_t* idx_j;
+  const int32_t* half;      // canonical edge of every undirected pair (ascending)
+  const int32_t* rowptr;    // CSR of idx_i
+  const int32_t* edge_pair; // position in `half` of the pair every directed edge belongs to
+  const int32_t* grp_atom0; // [G+1]
+  const int32_t* grp_pair0; // [G+1]
+  int n_groups;
+  float* saved;             // per interaction h [N,128] | pre3 [N,128]
+  float* gbase;             // per interaction [gsz] raw filter outputs, row = position of the pair in `half`
+  int64_t gsz, N;
+  RadialDev rb;
+};
+
+struct __attribute__((aligned(16))) MolPair { int i; int j; float fc; float dfc; };
+
+// register r of the half hi of a 32x32 accumulator holds row (r & 3) + 8 (r >> 2) + 4 hi
+__device__ __forceinline__ int ml_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// Packed LDS image of a weight matrix W[NOUT][K] (row-major, K padded with zeros to 8*KB):
+//   P[((t * KB + ug) * 64 + lane) * 4 + v] = W[32 t + (lane & 31)][8 ug + 4 (lane >> 5) + v]
+template <int NTHREADS, int SLOTS>
+__device__ __forceinline__ void ml_stage_packed(float* dst, const float* __restrict__ w, int K, int KB, int tid) {
+  constexpr int PER = (SLOTS + NTHREADS - 1) / NTHREADS;
+  constexpr int BATCH = PER < 4 ? PER : 4;       // loads in flight per thread (bounds the live registers)
+  const bool vec = (K & 3) == 0;
+#pragma unroll 1
+  for (int p0 = 0; p0 < PER; p0 += BATCH) {
+    f32x4 v[BATCH];
+#pragma unroll
+    for (int p = 0; p < BATCH; ++p) {
+      const int s = tid + (p0 + p) * NTHREADS;
+      v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (s < SLOTS) {
+        const int lane = s & 63;
+        const int ug = (s >> 6) % KB;
+        const int t = (s >> 6) / KB;
+        const int row = 32 * t + (lane & 31);
+        const int k0 = 8 * ug + 4 * (lane >> 5);
+        const float* src = w + (int64_t)row * K + k0;
+        if (vec) {
+          if (k0 < K) v[p] = *(const f32x4*)src;
+        } else {
+          if (k0 + 0 < K) v[p].x = src[0];
+          if (k0 + 1 < K) v[p].y = src[1];
+          if (k0 + 2 < K) v[p].z = src[2];
+          if (k0 + 3 < K) v[p].w = src[3];
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < BATCH; ++p) {
+      const int s = tid + (p0 + p) * NTHREADS;
+      if (s < SLOTS) *(f32x4*)(dst + (int64_t)s * 4) = v[p];
+    }
+  }
+}
+
+// One 32-column output tile of a Dense layer over the 32 atom rows of the group, T-GEMM convention of spk_dense.hip:
+// A = packed weights straight from L2 (16 k-blocks of 8, all requested up front), B = activations [32][ML_LD] in LDS;
+// accumulator rows = output features 32 t + ml_row(r, hi), columns = atoms (lane & 31).
+__device__ __forceinline__ f32x16 ml_dense_tile(const float* __restrict__ wp, const float* __restrict__ sIn, int t, int lane, f32x16 acc) {
+  const int hi = lane >> 5, el = lane & 31;
+  const f32x4* w4 = (const f32x4*)wp + ((int64_t)t * 16) * 64 + lane;
+  f32x4 av[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) av[u] = w4[u * 64];
+  const float* brow = sIn + el * ML_LD + 4 * hi;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const f32x4 bv = *(const f32x4*)(brow + 8 * u);
+    acc = ML_MFMA(av[u].x, bv.x, acc);
+    acc = ML_MFMA(av[u].y, bv.y, acc);
+    acc = ML_MFMA(av[u].z, bv.z, acc);
+    acc = ML_MFMA(av[u].w, bv.w, acc);
+  }
+  return acc;
+}
+
+template <int KPB>
+__global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
+  constexpr int NF = 128, NT = 4, KB2 = 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW2 = smem;                                  // NF*NF
+  float* sW1 = sW2 + NF * NF;                         // NF*KPB*8
+  float* sb1 = sW1 + NF * KPB * 8;                    // NF
+  float* sb2 = sb1 + NF;                              // NF
+  float* sX = sb2 + NF;                               // [32][ML_LD] atom features x_l
+  float* sH = sX + 32 * ML_LD;                        // h = in2f(x)
+  float* sY = sH + 32 * ML_LD;                        // y = cfconv output
+  float* sT = sY + 32 * ML_LD;                        // hidden layer of f2out
+  MolPair* sP = (MolPair*)(sT + 32 * ML_LD);          // per pair: local atoms, f_c, f_c'
+  int* sEb = (int*)(sP + ML_MAXPAIRS);                // per directed edge: (local pair << 8) | local neighbour
+  int* sRow = sEb + ML_MAXEDGES;                      // [33] local CSR
+  int* sCnt = sRow + 36;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+
+  for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+    const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
+    const int p0 = a.grp_pair0[grp], np = a.grp_pair0[grp + 1] - p0;
+    const int e0 = a.rowptr[a0], ne = a.rowptr[a0 + na] - e0;
+    const int ntile = (np + 31) / 32;
+    __syncthreads();   // the previous group is done with every LDS buffer
+
+    // ---- group set-up: features, local CSR, first filter weights
+    for (int s = tid; s < 32 * 32; s += 512) {
+      const int row = s >> 5, c4 = s & 31;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < na) v = *(const f32x4*)(a.x0 + (int64_t)(a0 + row) * NF + 4 * c4);
+      *(f32x4*)(sX + row * ML_LD + 4 * c4) = v;
+      *(f32x4*)(sY + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int s = tid; s < ne; s += 512) {
+      const int64_t e = (int64_t)e0 + s;
+      sEb[s] = ((a.edge_pair[e] - p0) << 8) | (int)(a.idx_j[e] - a0);
+    }
+    if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
+    ml_stage_packed<512, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
+    ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[0].w1, a.rb.n_rbf, KPB, tid);
+    if (tid < NF) { sb1[tid] = a.L[0].b1[tid]; sb2[tid] = a.L[0].b2[tid]; }
+
+    for (int l = 0; l < a.n_layers; ++l) {
+      const MolLayerDev& P = a.L[l];
+      float* h_g = a.saved + (int64_t)l * a.N * (2 * NF);
+      float* pre3_g = h_g + a.N * (int64_t)NF;
+      float* g_g = a.gbase + (int64_t)l * a.gsz + (int64_t)p0 * NF;
+      if (tid == 0) sCnt[0] = 0;
+      __syncthreads();
+
+      // ================= phase A: filter tasks (pair tile, channel tile) + in2f tasks, dynamic queue
+      const int nfilt = 4 * ntile;
+      while (true) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&sCnt[0], 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= nfilt + NT) break;
+        if (k >= nfilt) {
+          // ---- in2f: h[:, 32t : 32t+32] = x W_in^T
+          const int t = k - nfilt;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          acc = ml_dense_tile(P.in2f_p, sX, t, lane, acc);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *(f32x4*)(sH + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          continue;
+        }
+        const int tile = k >> 2, t = k & 3;
+        // ---- per-pair geometry (lanes 32..63 mirror lanes 0..31)
+        const int pfirst = 32 * tile;
+        const int nvalid = (np - pfirst) < 32 ? (np - pfirst) : 32;
+        const bool valid = el < nvalid;
+        const int64_t e = a.half[p0 + pfirst + (valid ? el : (nvalid - 1))];
+        const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+        const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+        float fc, dfc;
+        spk_cutoff_eval_fast(a.rb.cutoff, d, fc, dfc);
+        if (t == 0 && hi == 0 && valid) {
+          MolPair pr; pr.i = (int)(a.idx_i[e] - a0); pr.j = (int)(a.idx_j[e] - a0); pr.fc = fc; pr.dfc = dfc;
+          sP[pfirst + el] = pr;
+        }
+        float phi[KPB][4];
+#pragma unroll
+        for (int u = 0; u < KPB; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            float p, dp;
+            spk_rbf_eval_fast(a.rb, 8 * u + 4 * hi + v, d, p, dp);
+            phi[u][v] = p;
+          }
+        // ---- GEMM 1 (rows = hidden channels, columns = pairs): z = ssp(W1 phi + b1)
+        f32x16 z[NT];
+        {
+          f32x4 wq = *(const f32x4*)(sW1 + lane * 4);
+#pragma unroll
+          for (int c = 0; c < NT; ++c) {
+            f32x16 zc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zc[r] = sb1[32 * c + ml_row(r, hi)];
+#pragma unroll
+            for (int u = 0; u < KPB; ++u) {
+              const int nxt = c * KPB + u + 1;
+              f32x4 wn = wq;
+              if (nxt < NT * KPB) wn = *(const f32x4*)(sW1 + (nxt * 64 + lane) * 4);
+              zc = ML_MFMA(wq.x, phi[u][0], zc);
+              zc = ML_MFMA(wq.y, phi[u][1], zc);
+              zc = ML_MFMA(wq.z, phi[u][2], zc);
+              zc = ML_MFMA(wq.w, phi[u][3], zc);
+              wq = wn;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zc[r] = spk_fast_ssp(zc[r]);
+            z[c] = zc;
+          }
+        }
+        // ---- GEMM 2, operands swapped (rows = pairs, columns = channels 32 t + el): g = W2 z + b2
+        f32x16 g;
+        const int c0 = 32 * t + el;
+        const float bias2 = sb2[c0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = bias2;
+        {
+          const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
+          f32x4 wq = *(const f32x4*)wbase;
+#pragma unroll
+          for (int ug = 0; ug < KB2; ++ug) {
+            const int c = ug >> 2, q = ug & 3;
+            f32x4 wn = wq;
+            if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
+            g = ML_MFMA(z[c][4 * q + 0], wq.x, g);
+            g = ML_MFMA(z[c][4 * q + 1], wq.y, g);
+            g = ML_MFMA(z[c][4 * q + 2], wq.z, g);
+            g = ML_MFMA(z[c][4 * q + 3], wq.w, g);
+            wq = wn;
+          }
+        }
+        // raw filter outputs: row = pair, 128-byte row segments per half wave
+        float* gt = g_g + (int64_t)pfirst * NF + c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int pr = ml_row(r, hi);
+          if (pr < nvalid) gt[pr * NF] = g[r];
+        }
+      }
+      __syncthreads();   // h, the pair records and (workgroup scope) the filter outputs are complete
+
+      // ================= phase B: y[a] = sum over the row of a;  thread = (channel, atom quarter)
+      {
+        const int c = tid & 127, q4 = tid >> 7;
+        for (int at = q4; at < na; at += 4) {
+          const int rs = sRow[at], re = sRow[at + 1];
+          float acc = 0.f;
+          for (int eb = rs; eb < re; eb += 8) {
+            int rec[8];
+            float gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              rec[u] = (eb + u < re) ? sEb[eb + u] : -1;
+              gv[u] = (rec[u] >= 0) ? g_g[(int64_t)(rec[u] >> 8) * NF + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (rec[u] >= 0) acc = fmaf(sH[(rec[u] & 255) * ML_LD + c] * sP[rec[u] >> 8].fc, gv[u], acc);
+          }
+          sY[at * ML_LD + c] = acc;
+        }
+      }
+      __syncthreads();
+
+      // ================= phase C1: pre3 = y W3^T + b3 (saved), t = ssp(pre3); the other half saves h and stages weights
+      if (wv < NT) {
+        const int t = wv;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = P.o1_b[32 * t + ml_row(r, hi)];
+        acc = ml_dense_tile(P.o1_p, sY, t, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          if (el < na) *(f32x4*)(pre3_g + (int64_t)(a0 + el) * NF + 32 * t + 8 * q + 4 * hi) = pv;
+          *(f32x4*)(sT + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{spk_fast_ssp(pv.x), spk_fast_ssp(pv.y), spk_fast_ssp(pv.z), spk_fast_ssp(pv.w)};
+        }
+      } else {
+        const int t2 = tid - 256;
+        for (int s = t2; s < na * 32; s += 256) {
+          const int row = s >> 5, c4 = s & 31;
+          *(f32x4*)(h_g + (int64_t)(a0 + row) * NF + 4 * c4) = *(const f32x4*)(sH + row * ML_LD + 4 * c4);
+        }
+        if (l + 1 < a.n_layers) {     // the filter GEMMs of this interaction are done: their LDS images can be replaced
+          ml_stage_packed<256, NF * KPB * 2>(sW1, a.L[l + 1].w1, a.rb.n_rbf, KPB, t2);
+          if (t2 < NF) { sb1[t2] = a.L[l + 1].b1[t2]; sb2[t2] = a.L[l + 1].b2[t2]; }
+        }
+      }
+      __syncthreads();
+
+      // ================= phase C2: x += t W4^T + b4
+      if (wv < NT) {
+        const int t = wv;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = P.o2_b[32 * t + ml_row(r, hi)];
+        acc = ml_dense_tile(P.o2_p, sT, t, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float* xp = sX + el * ML_LD + 32 * t + 8 * q + 4 * hi;
+          f32x4 xv = *(const f32x4*)xp;
+          xv.x += acc[4 * q]; xv.y += acc[4 * q + 1]; xv.z += acc[4 * q + 2]; xv.w += acc[4 * q + 3];
+          if (el >= na) xv = f32x4{0.f, 0.f, 0.f, 0.f};       // padding rows stay zero (in2f has no bias: h pads stay zero too)
+          *(f32x4*)xp = xv;
+          if (l + 1 == a.n_layers && el < na) *(f32x4*)(a.x_out + (int64_t)(a0 + el) * NF + 32 * t + 8 * q + 4 * hi) = xv;
+        }
+      } else if (l + 1 < a.n_layers) {
+        ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l + 1].w2, NF, KB2, tid - 256);
+      }
+      // (the barrier at the top of the next interaction / group closes this phase)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static size_t mol_fwd_lds(int kpb) {
+  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
+         (ML_MAXEDGES + 36 + 4) * sizeof(int);
+}
+
+// Shapes / lists the molecule-resident kernels cover (everything else runs the general driver of spk_schnet.hip).
+bool spk_schnet_mol_eligible(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb) {
+  const int variant = spk_get_variant();
+  if (variant != SPK_VARIANT_AUTO && variant != SPK_VARIANT_MFMA_PAIR && variant != SPK_VARIANT_MFMA) return false;
+  if (getenv("SPK_NO_MOL")) return false;
+  if (m->n_atom_basis != 128 || m->n_filters != 128 || m->n_interactions < 1 || m->n_interactions > ML_MAXL || !m->wpack) return false;
+  const int kpb = (rb->n_rbf + 7) / 8;
+  if (kpb < 1 || kpb > 4) return false;
+  if (!(g->symmetric && g->sorted && g->half && g->rev && g->edge_pair && g->rowptr && g->n_half > 0)) return false;
+  if (g->n_groups <= 0 || !g->grp_atom0 || !g->grp_pair0 || g->max_group_atoms > 32) return false;
+  if (g->filter_pairs || g->n_half_dev) return false;       // skin lists: per-call compacted pair list (general driver)
+  return true;
+}
+
+template <int KPB>
+static int launch_mol_fwd(const MolFwdArgs& a, hipStream_t stream) {
+  const size_t lds = mol_fwd_lds(KPB);
+  auto kern = k_schnet_mol_fwd<KPB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  int grid = a.n_groups;
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  SpkProfScope prof("schnet_mol_fwd", stream);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// `saved` as laid out by spk_schnet_saved_floats_graph(): L x (h | pre3), then L x gsz floats of raw filter outputs.
+int spk_schnet_mol_forward(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                           const float* x0, const float* r_ij, float* x_out, float* saved, int64_t gsz, hipStream_t stream) {
+  MolFwdArgs a;
+  a.n_layers = m->n_interactions;
+  for (int l = 0; l < m->n_interactions; ++l) {
+    const spk_schnet_layer_t& P = m->layers[l];
+    MolLayerDev& D = a.L[l];
+    D.in2f_p = spk_packed_of(ptab, P.in2f_w, 0);
+    D.o1_p = spk_packed_of(ptab, P.f2out_w1, 0);
+    D.o2_p = spk_packed_of(ptab, P.f2out_w2, 0);
+    SPK_CHECK_ARG(D.in2f_p && D.o1_p && D.o2_p, "spk_schnet_mol_forward: packed weight images missing");
+    D.w1 = P.fn_w1; D.b1 = P.fn_b1; D.w2 = P.fn_w2; D.b2 = P.fn_b2; D.o1_b = P.f2out_b1; D.o2_b = P.f2out_b2;
+  }
+  a.x0 = x0; a.x_out = x_out; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
+  a.half = g->half; a.rowptr = g->rowptr; a.edge_pair = g->edge_pair; a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0;
+  a.n_groups = g->n_groups; a.saved = saved; a.N = g->n_atoms; a.gsz = gsz;
+  a.gbase = saved + (int64_t)m->n_interactions * g->n_atoms * (m->n_filters + m->n_atom_basis);
+  a.rb = spk_radial_dev(rb);
+  switch ((rb->n_rbf + 7) / 8) {
+    case 1: return launch_mol_fwd<1>(a, stream);
+    case 2: return launch_mol_fwd<2>(a, stream);
+    case 3: return launch_mol_fwd<3>(a, stream);
+    case 4: return launch_mol_fwd<4>(a, stream);
+  }
+  spk_set_error("spk_schnet_mol_forward: n_rbf = %d unsupported", rb->n_rbf);
+  return SPK_ERR_ARG;
+}

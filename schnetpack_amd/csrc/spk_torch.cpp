@@ -89,7 +89,7 @@ std::mutex g_mutex;
 
 // ------------------------------------------------------------------------------------------------ neighbour-list plan
 struct Plan {
-  Tensor idx_i, idx_j, rowptr, rev, half, grp_atom0, grp_pair0, grp_tile0;   // keep-alive + device data
+  Tensor idx_i, idx_j, rowptr, rev, half, edge_pair, grp_atom0, grp_pair0, grp_tile0;   // keep-alive + device data
   bool sorted = false, symmetric = false;
   int64_t n_atoms = 0, n_edges = 0, n_half = 0;
   int32_t n_groups = 0, max_group_atoms = 0;
@@ -119,15 +119,16 @@ struct Plan {
       g.n_tiles_grouped = n_tiles_grouped;
     }
     g.filter_pairs = filter_pairs > 0 ? 1 : 0;
+    g.edge_pair = edge_pair.defined() ? edge_pair.data_ptr<int32_t>() : nullptr;
     return g;
   }
 };
 
 Lru<Plan> g_plans(16);
-constexpr int64_t kMaxGroupAtoms = 128;
+constexpr int64_t kMaxGroupAtoms = 32;   // one 32-row MFMA tile of atoms per group (spk_schnet_mol.hip)
 
 // Block-diagonal structure of a symmetric list (molecule batches): connected atom ranges that no edge leaves, merged
-// greedily into groups of at most cap = min(128, max(largest molecule, N / compute units)) atoms.  Plan time only.
+// greedily into groups of at most 32 atoms.  Plan time only (one small D2H copy).
 void build_groups(Plan& p) {
   const int64_t N = p.n_atoms;
   auto dev = p.idx_i.device();
@@ -139,10 +140,7 @@ void build_groups(Plan& p) {
   if (ends_h.numel() == 0) return;
   Tensor sizes = at::diff(ends_h, 1, 0, at::zeros({1}, ends_h.options()));
   if (sizes.max().item<int64_t>() > kMaxGroupAtoms) return;
-  int32_t info[4] = {256, 64, 0, 0};
-  spk_device_info(info);
-  const int64_t n_cu = info[0] > 0 ? info[0] : 256;
-  const int64_t cap = std::min<int64_t>(kMaxGroupAtoms, std::max<int64_t>(sizes.max().item<int64_t>(), (N + n_cu - 1) / n_cu));
+  const int64_t cap = kMaxGroupAtoms;
   std::vector<int64_t> atom0{0};
   int64_t cur = 0;
   auto sz = sizes.accessor<int64_t, 1>();
@@ -170,7 +168,7 @@ void build_groups(Plan& p) {
 // Cached plan of a neighbour list (spk_edge_plan: one 16-byte D2H per NEW list; never inside a graph capture --
 // callers run one eager call per list first, as GraphedForceCall / the MD loops do).
 std::shared_ptr<Plan> get_plan(const Tensor& idx_i_in, const Tensor& idx_j_in, int64_t n_atoms, const Tensor& r_ij) {
-  const bool want_groups = spk_get_variant() == SPK_VARIANT_MFMA_MOL;
+  const bool want_groups = true;
   std::vector<uint64_t> key{(uint64_t)idx_i_in.data_ptr(), (uint64_t)idx_j_in.data_ptr(), version_of(idx_i_in), version_of(idx_j_in),
                             (uint64_t)idx_i_in.size(0), (uint64_t)n_atoms, (uint64_t)idx_i_in.device().index(), (uint64_t)r_ij.defined(),
                             (uint64_t)want_groups, (uint64_t)idx_i_in.scalar_type()};
@@ -208,7 +206,15 @@ std::shared_ptr<Plan> get_plan(const Tensor& idx_i_in, const Tensor& idx_j_in, i
       p->n_half = 0;
     }
   }
-  if (want_groups && p->symmetric && p->n_half > 0) build_groups(*p);
+  if (p->symmetric && p->n_half > 0) {
+    // position in `half` of the pair of every directed edge (molecule-resident SchNet kernels)
+    Tensor k = at::arange(p->n_half, iopt);
+    Tensor hl = p->half.to(at::kLong);
+    p->edge_pair = at::empty({p->n_edges}, iopt);
+    p->edge_pair.index_put_({hl}, k);
+    p->edge_pair.index_put_({p->rev.slice(0, 0, p->n_edges).index_select(0, hl).to(at::kLong)}, k);
+    if (want_groups) build_groups(*p);
+  }
   g_plans.put(key, p);
   return p;
 }
@@ -307,8 +313,8 @@ Tensor pairwise_bwd_raw(const Tensor& gr_in, const Tensor& idx_i_in, const Tenso
     // only a plan that already knows the geometry (built by the representation of this list) has the reverse map;
     // the vector handed to this function is a GRADIENT, never geometry: a plan is looked up, not built, from it
     std::vector<uint64_t> key{(uint64_t)idx_i_in.data_ptr(), (uint64_t)idx_j_in.data_ptr(), version_of(idx_i_in), version_of(idx_j_in),
-                              (uint64_t)idx_i_in.size(0), (uint64_t)n_atoms, (uint64_t)idx_i_in.device().index(), 1,
-                              (uint64_t)(spk_get_variant() == SPK_VARIANT_MFMA_MOL), (uint64_t)idx_i_in.scalar_type()};
+                              (uint64_t)idx_i_in.size(0), (uint64_t)n_atoms, (uint64_t)idx_i_in.device().index(), 1, 1,
+                              (uint64_t)idx_i_in.scalar_type()};
     std::lock_guard<std::mutex> lock(g_mutex);
     plan = g_plans.get(key);
   }

@@ -28,7 +28,7 @@ class EdgePlan:
     def __init__(self, idx_i, idx_j, n_atoms, r_ij=None, want_groups=None):
         _lib.require_device(idx_i, idx_j)
         if want_groups is None:
-            want_groups = _lib.get_variant() == _lib.VARIANT_MFMA_MOL
+            want_groups = True
         self.idx_i = idx_i.long().contiguous()
         self.idx_j = idx_j.long().contiguous()
         self.n_atoms = int(n_atoms)
@@ -58,8 +58,15 @@ class EdgePlan:
                 self.symmetric = False
                 self.half, n_half = None, 0
         self.groups = None
+        self.edge_pair = None
         n_groups = max_ga = n_tiles_g = 0
-        if want_groups and self.symmetric and n_half > 0:   # only the experimental group-local kernels need it
+        if self.symmetric and n_half > 0:
+            # position in `half` of the pair of every directed edge (molecule-resident SchNet kernels)
+            k = torch.arange(n_half, dtype=torch.int32, device=dev)
+            self.edge_pair = torch.empty(self.n_edges, dtype=torch.int32, device=dev)
+            self.edge_pair[self.half.long()] = k
+            self.edge_pair[self.rev[: self.n_edges][self.half.long()].long()] = k
+        if want_groups and self.symmetric and n_half > 0:   # block-diagonal structure: molecule-resident / group-local kernels
             self.groups = _block_diagonal_groups(self.idx_i, self.idx_j, self.half, self.n_atoms)
             if self.groups is not None:
                 n_groups = int(self.groups[0].shape[0]) - 1
@@ -72,7 +79,8 @@ class EdgePlan:
                                   iptr(self.rev, torch.int32) if self.symmetric else None,
                                   iptr(self.half, torch.int32) if self.half is not None else None, n_half,
                                   iptr(gp[0], torch.int32) if gp else None, iptr(gp[1], torch.int32) if gp else None,
-                                  iptr(gp[2], torch.int32) if gp else None, n_groups, max_ga, n_tiles_g)
+                                  iptr(gp[2], torch.int32) if gp else None, n_groups, max_ga, n_tiles_g, 0, 0, None,
+                                  iptr(self.edge_pair, torch.int32) if self.edge_pair is not None else None)
 
     def graph(self):
         return ctypes.byref(self._graph)
@@ -96,13 +104,13 @@ class EdgePlan:
         return self.filter_pairs
 
 
-_MAX_GROUP_ATOMS = 128   # upper bound for the LDS accumulator of the group-local kernels
+_MAX_GROUP_ATOMS = 32    # one 32-row MFMA tile of atoms per group (molecule-resident kernels, spk_schnet_mol.hip)
 
 
 def _block_diagonal_groups(idx_i, idx_j, half, n_atoms):
     """Block-diagonal structure of a symmetric neighbour list (plan time, one small D2H sync):
     connected ranges of atoms that no edge leaves (molecules of a batch), merged greedily into groups of
-    at most cap = min(128, max(largest molecule, N / compute units)) atoms.  Returns (atom0 [G+1],
+    at most 32 atoms.  Returns (atom0 [G+1],
     pair0 [G+1], tile0 [G+1] int32 device tensors, max atoms per group, total tiles) or None when the
     list is not block diagonal with small blocks."""
     dev = idx_i.device
@@ -115,11 +123,7 @@ def _block_diagonal_groups(idx_i, idx_j, half, n_atoms):
     sizes = torch.diff(ends_h, prepend=torch.zeros(1, dtype=ends_h.dtype))
     if sizes.numel() == 0 or int(sizes.max()) > _MAX_GROUP_ATOMS:
         return None
-    try:
-        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    except Exception:  # pragma: no cover
-        n_cu = 256
-    cap = min(_MAX_GROUP_ATOMS, max(int(sizes.max()), -(-n_atoms // n_cu)))
+    cap = _MAX_GROUP_ATOMS
     atom0 = [0]
     cur = 0
     for sz in sizes.tolist():
@@ -143,7 +147,7 @@ _PLAN_CACHE_SIZE = 16
 
 def edge_plan(idx_i, idx_j, n_atoms, r_ij=None):
     """Cached plan of a neighbour list, keyed by the identity/version of the index tensors."""
-    want_groups = _lib.get_variant() == _lib.VARIANT_MFMA_MOL
+    want_groups = True
     key = (idx_i.data_ptr(), idx_j.data_ptr(), idx_i._version, idx_j._version,
            int(idx_i.shape[0]), int(n_atoms), str(idx_i.device), r_ij is not None, want_groups)
     plan = _PLAN_CACHE.get(key)
