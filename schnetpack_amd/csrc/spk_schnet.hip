@@ -122,7 +122,7 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
   const int64_t gsz = (m->reserved & 1) ? spk_cfconv_gsave_floats(g, rb, NF) : 0;  // bit 0: saved has filter space
   float* gbase = saved + (int64_t)L * N * (NF + F);
   // batches of small molecules with the filters saved for the backward: the whole forward is one molecule-resident launch
-  if (gsz > 0 && ptab.base && !schnet_filter_on(m, g, rb) && spk_schnet_mol_eligible(m, g, rb))
+  if (gsz > 0 && ptab.base && spk_schnet_mol_eligible(m, g, rb))
     return spk_schnet_mol_forward(m, g, rb, ptab, x0, r_ij, x_out, saved, gsz, stream);
   // skin lists: compact the pair list of THIS call (pairs inside the cutoff, order kept) behind the saved filters
   spk_graph_t gact = *g;
@@ -178,7 +178,8 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   const int F = m->n_atom_basis, NF = m->n_filters, L = m->n_interactions;
   // with saved filters the pair kernel runs and writes every entry of gr exactly once per interaction: the
   // first interaction of the backward assigns, the others accumulate -- no clearing pass
-  const bool gr_assign = L > 0 && (m->reserved & 1) && E > 0 && spk_cfconv_gsave_floats(g, rb, NF) > 0 && !schnet_filter_on(m, g, rb);
+  const bool gr_assign = L > 0 && (m->reserved & 1) && E > 0 && spk_cfconv_gsave_floats(g, rb, NF) > 0 &&
+                         (!schnet_filter_on(m, g, rb) || (ptab.base && spk_schnet_mol_eligible(m, g, rb)));
   if (E > 0) {
     SPK_CHECK_ARG(gr != nullptr, "%s: null gr", who);
     if (!gr_assign) { int _zr = spk_zero_async(gr, (size_t)E * 3 * sizeof(float), stream); if (_zr) return _zr; }
@@ -199,9 +200,11 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   auto pre3 = [&](int l) { return saved + (int64_t)l * N * (NF + F) + N * (int64_t)NF; };
   const int64_t gsz = (m->reserved & 1) ? spk_cfconv_gsave_floats(g, rb, NF) : 0;
   const float* gbase = saved + (int64_t)L * N * (NF + F);
-  // the compacted pair list written by the forward of this call
+  // the compacted pair list written by the forward of this call (the molecule-resident forward writes none: it keeps
+  // the full pair list, and so does this backward then -- saved filters are addressed by pair position)
+  const bool mol_fwd = gsz > 0 && ptab.base && spk_schnet_mol_eligible(m, g, rb);
   spk_graph_t gact = *g;
-  if (gsz > 0 && schnet_filter_on(m, g, rb)) {
+  if (gsz > 0 && !mol_fwd && schnet_filter_on(m, g, rb)) {
     const int32_t* ah = (const int32_t*)(gbase + (int64_t)L * gsz);
     gact.half = ah; gact.n_half_dev = ah + g->n_half;
   }

@@ -357,7 +357,8 @@ bool spk_schnet_mol_eligible(const spk_schnet_t* m, const spk_graph_t* g, const 
   if (kpb < 1 || kpb > 4) return false;
   if (!(g->symmetric && g->sorted && g->half && g->rev && g->edge_pair && g->rowptr && g->n_half > 0)) return false;
   if (g->n_groups <= 0 || !g->grp_atom0 || !g->grp_pair0 || g->max_group_atoms > 32) return false;
-  if (g->filter_pairs || g->n_half_dev) return false;       // skin lists: per-call compacted pair list (general driver)
+  if (g->n_half_dev) return false;       // a per-call compacted pair list is already in place
+  // (skin lists, g->filter_pairs: pairs beyond the cutoff carry f_c = f_c' = 0 and contribute exactly zero here -- no compaction)
   return true;
 }
 
