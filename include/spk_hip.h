@@ -349,6 +349,11 @@ int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t* g, const s
                             const float* gx_out, const float* r_ij, const float* saved,
                             float* scratch, float* gr, float* gx0, void* stream);
 
+/* Kernel-tuning aid of the molecule-resident SchNet kernels (spk_schnet_mol.hip: block-diagonal lists with <= 32 atoms per
+ * block run every interaction inside one workgroup): device buffer (>= 64 int64) receiving cycle stamps of workgroup 0 at
+ * the phase boundaries; NULL disables it (default). */
+void spk_schnet_mol_set_debug_buffer(void* device_buffer);
+
 /* ------------------------------------------------------------------ representation/painn.py:31-67
  * Fused PaiNN message of one interaction block (filters never materialised; the reference
  * allocates [E,1,3F*n_int], painn.py:232):

@@ -57,6 +57,10 @@ extern "C" int64_t spk_schnet_scratch_floats(const spk_schnet_t* m, int64_t n_at
 bool spk_schnet_mol_eligible(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb);
 int spk_schnet_mol_forward(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
                            const float* x0, const float* r_ij, float* x_out, float* saved, int64_t gsz, hipStream_t stream);
+bool spk_schnet_mol_bwd_eligible(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb);
+int spk_schnet_mol_backward(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                            const float* gx_out, const float* r_ij, const float* saved, int64_t gsz, float* gr, float* gx0,
+                            hipStream_t stream);
 // order of the packed images in spk_schnet_t::wpack: per interaction in2f, f2out.0, f2out.1 (forward, transposed each)
 static bool schnet_pack_shapes_ok(const spk_schnet_t* m) { return m->n_atom_basis % 128 == 0 && m->n_filters % 128 == 0 && m->n_atom_basis <= 384 && m->n_filters <= 384; }
 static SpkPackTable schnet_pack_table(const spk_schnet_t* m) {
@@ -176,6 +180,11 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   SPK_CHECK_ARG(g != nullptr && rb != nullptr, "%s: null graph/radial", who);
   const int64_t N = g->n_atoms, E = g->n_edges;
   const int F = m->n_atom_basis, NF = m->n_filters, L = m->n_interactions;
+  // batches of small molecules: the whole backward is one molecule-resident launch (it assigns every entry of gr)
+  if (L > 0 && N > 0 && E > 0 && (m->reserved & 1) && ptab.base && gx_out && saved && gr && spk_schnet_mol_bwd_eligible(m, g, rb)) {
+    const int64_t gsz_m = spk_cfconv_gsave_floats(g, rb, NF);
+    if (gsz_m > 0) return spk_schnet_mol_backward(m, g, rb, ptab, gx_out, r_ij, saved, gsz_m, gr, gx0, stream);
+  }
   // with saved filters the pair kernel runs and writes every entry of gr exactly once per interaction: the
   // first interaction of the backward assigns, the others accumulate -- no clearing pass
   const bool gr_assign = L > 0 && (m->reserved & 1) && E > 0 && spk_cfconv_gsave_floats(g, rb, NF) > 0 &&

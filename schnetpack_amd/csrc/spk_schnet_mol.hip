@@ -51,7 +51,9 @@ struct MolFwdArgs {
   float* gbase;             // per interaction [gsz] raw filter outputs, row = position of the pair in `half`
   int64_t gsz, N;
   RadialDev rb;
+  long long* dbg;           // tuning aid: cycle stamps of thread 0 of workgroup 0 (null in production)
 };
+#define ML_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
 
 struct __attribute__((aligned(16))) MolPair { int i; int j; float fc; float dfc; };
 
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
     const int e0 = a.rowptr[a0], ne = a.rowptr[a0 + na] - e0;
     const int ntile = (np + 31) / 32;
     __syncthreads();   // the previous group is done with every LDS buffer
+    ML_STAMP(0);
 
     // ---- group set-up: features, local CSR, first filter weights
     for (int s = tid; s < 32 * 32; s += 512) {
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       float* g_g = a.gbase + (int64_t)l * a.gsz + (int64_t)p0 * NF;
       if (tid == 0) sCnt[0] = 0;
       __syncthreads();
+      ML_STAMP(1 + 5 * l);
 
       // ================= phase A: filter tasks (pair tile, channel tile) + in2f tasks, dynamic queue
       const int nfilt = 4 * ntile;
@@ -266,7 +270,9 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           if (pr < nvalid) gt[pr * NF] = g[r];
         }
       }
+      ML_STAMP(2 + 5 * l);
       __syncthreads();   // h, the pair records and (workgroup scope) the filter outputs are complete
+      ML_STAMP(3 + 5 * l);
 
       // ================= phase B: y[a] = sum over the row of a;  thread = (channel, atom quarter)
       {
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
         }
       }
       __syncthreads();
+      ML_STAMP(4 + 5 * l);
 
       // ================= phase C1: pre3 = y W3^T + b3 (saved), t = ssp(pre3); the other half saves h and stages weights
       if (wv < NT) {
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
         }
       }
       __syncthreads();
+      ML_STAMP(5 + 5 * l);
 
       // ================= phase C2: x += t W4^T + b4
       if (wv < NT) {
@@ -338,10 +346,15 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       }
       // (the barrier at the top of the next interaction / group closes this phase)
     }
+    ML_STAMP(31);
   }
 }
 
 // ------------------------------------------------------------------------------------------ host side
+static long long* g_mol_dbg = nullptr;
+// tuning aid: device buffer of >= 64 int64 that receives cycle stamps of thread 0 / workgroup 0 (NULL: off)
+extern "C" void spk_schnet_mol_set_debug_buffer(void* p) { g_mol_dbg = (long long*)p; }
+
 static size_t mol_fwd_lds(int kpb) {
   return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
          (ML_MAXEDGES + 36 + 4) * sizeof(int);
@@ -399,6 +412,7 @@ int spk_schnet_mol_forward(const spk_schnet_t* m, const spk_graph_t* g, const sp
   a.n_groups = g->n_groups; a.saved = saved; a.N = g->n_atoms; a.gsz = gsz;
   a.gbase = saved + (int64_t)m->n_interactions * g->n_atoms * (m->n_filters + m->n_atom_basis);
   a.rb = spk_radial_dev(rb);
+  a.dbg = g_mol_dbg;
   switch ((rb->n_rbf + 7) / 8) {
     case 1: return launch_mol_fwd<1>(a, stream);
     case 2: return launch_mol_fwd<2>(a, stream);
@@ -406,5 +420,374 @@ int spk_schnet_mol_forward(const spk_schnet_t* m, const spk_graph_t* g, const sp
     case 4: return launch_mol_fwd<4>(a, stream);
   }
   spk_set_error("spk_schnet_mol_forward: n_rbf = %d unsupported", rb->n_rbf);
+  return SPK_ERR_ARG;
+}
+
+// ==========================================================================================================
+// Backward (first order, what Forces asks for): dL/dr_ij and optionally dL/dx0 from dL/dx_L, one launch.
+//
+// Per interaction, last to first (notation of SURVEY.md Appendix B; everything below is local to the group):
+//   D1. gt = (gx W4) * ssp'(pre3)          D2. gy = gt W3                                (two T-GEMM phases)
+//   E.  task queue:  (pair tile, channel-tile pair) derivative tasks  +  row-sum tasks
+//         derivative task: phi, phi' -> GEMM 1 value and derivative (a, a') -> z' = sigmoid(a) a' -> GEMM 2' (rows =
+//           channels, columns = pairs: lane = pair) -> D = g' f_c + g f_c' with the SAVED raw filter outputs g ->
+//           s1 = sum_c gy_i h_j D,  s2 = sum_c gy_j h_i D  (in-lane sums over the 16 channels a lane owns, one LDS add per
+//           pair and task); the per-pair sums are kept in LDS across all interactions and become dL/dr once, at the end
+//         row-sum task:    gh[a] = sum_{b in row(a)} gy[b] * g[pair(a,b)] * f_c           (the transpose of the forward row sum)
+//   G.  gx += gh W_in                                                                    (T-GEMM phase)
+// ==========================================================================================================
+struct MolBwdLayerDev {
+  const float *w1, *b1, *w2;               // filter network (raw)
+  const float *in2f_t, *o1_t, *o2_t;       // packed input-gradient images of in2f / f2out.0 / f2out.1
+};
+
+struct MolBwdArgs {
+  MolBwdLayerDev L[ML_MAXL];
+  int n_layers;
+  const float* gx_out;      // [N, 128]
+  float* gx0;               // [N, 128] or null
+  float* gr;                // [E, 3], assigned
+  const float* rij;
+  const int64_t* idx_i;
+  const int64_t* idx_j;
+  const int32_t *half, *rev, *rowptr, *edge_pair, *grp_atom0, *grp_pair0;
+  int n_groups;
+  const float* saved;
+  const float* gbase;
+  int64_t gsz, N;
+  RadialDev rb;
+  long long* dbg;
+};
+
+template <int KPB>
+__global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
+  constexpr int NF = 128, NT = 4, KB2 = 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW2 = smem;                                  // NF*NF
+  float* sW1 = sW2 + NF * NF;                         // NF*KPB*8
+  float* sb1 = sW1 + NF * KPB * 8;                    // NF (+ NF unused: same footprint as the forward)
+  float* sGx = sb1 + 2 * NF;                          // [32][ML_LD] dL/dx of the current level
+  float* sH = sGx + 32 * ML_LD;                       // h_l (saved by the forward)
+  float* sGy = sH + 32 * ML_LD;                       // dL/dy_l
+  float* sGh = sGy + 32 * ML_LD;                      // dL/dh_l; before that the hidden gradient of f2out
+  MolPair* sP = (MolPair*)(sGh + 32 * ML_LD);         // per pair: local atoms, f_c, f_c'
+  int* sEb = (int*)(sP + ML_MAXPAIRS);                // per directed edge: (local pair << 8) | local neighbour
+  int* sRow = sEb + ML_MAXEDGES;                      // [33]
+  int* sCnt = sRow + 36;                              // [4]
+  float* sS = (float*)(sCnt + 4);                     // [ML_MAXPAIRS][2] per-pair geometry sums, all interactions
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+
+  for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+    const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
+    const int p0 = a.grp_pair0[grp], np = a.grp_pair0[grp + 1] - p0;
+    const int e0 = a.rowptr[a0], ne = a.rowptr[a0 + na] - e0;
+    const int ntile = (np + 31) / 32;
+    const int Ltop = a.n_layers - 1;
+    __syncthreads();
+
+    // ---- group set-up
+    for (int s = tid; s < 32 * 32; s += 512) {
+      const int row = s >> 5, c4 = s & 31;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < na) v = *(const f32x4*)(a.gx_out + (int64_t)(a0 + row) * NF + 4 * c4);
+      *(f32x4*)(sGx + row * ML_LD + 4 * c4) = v;
+      *(f32x4*)(sGh + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(sH + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int s = tid; s < ne; s += 512) {
+      const int64_t e = (int64_t)e0 + s;
+      sEb[s] = ((a.edge_pair[e] - p0) << 8) | (int)(a.idx_j[e] - a0);
+    }
+    for (int s = tid; s < np; s += 512) {
+      const int64_t e = a.half[p0 + s];
+      const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+      MolPair pr;
+      pr.i = (int)(a.idx_i[e] - a0); pr.j = (int)(a.idx_j[e] - a0);
+      spk_cutoff_eval_fast(a.rb.cutoff, sqrtf(rx * rx + ry * ry + rz * rz), pr.fc, pr.dfc);
+      sP[s] = pr;
+      sS[2 * s] = 0.f; sS[2 * s + 1] = 0.f;
+    }
+    if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
+    ml_stage_packed<512, NF * NF / 4>(sW2, a.L[Ltop].w2, NF, KB2, tid);
+    ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[Ltop].w1, a.rb.n_rbf, KPB, tid);
+    if (tid < NF) sb1[tid] = a.L[Ltop].b1[tid];
+    __syncthreads();
+    ML_STAMP(32);
+
+    for (int l = Ltop; l >= 0; --l) {
+      const MolBwdLayerDev& P = a.L[l];
+      const float* h_g = a.saved + (int64_t)l * a.N * (2 * NF);
+      const float* pre3_g = h_g + a.N * (int64_t)NF;
+      const float* g_g = a.gbase + (int64_t)l * a.gsz + (int64_t)p0 * NF;
+      const bool last = (l == 0) && !a.gx0;     // nothing below consumes dL/dh_0: no row sums, no in2f transpose
+
+      // ================= D1: gt = (gx W4) * ssp'(pre3);  the other half loads h_l
+      if (wv < NT) {
+        const int t = wv;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        f32x4 pv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          pv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (el < na) pv[q] = *(const f32x4*)(pre3_g + (int64_t)(a0 + el) * NF + 32 * t + 8 * q + 4 * hi);
+        }
+        acc = ml_dense_tile(P.o2_t, sGx, t, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)(sGh + el * ML_LD + 32 * t + 8 * q + 4 * hi) =
+              f32x4{acc[4 * q] * spk_sigmoid(pv[q].x), acc[4 * q + 1] * spk_sigmoid(pv[q].y), acc[4 * q + 2] * spk_sigmoid(pv[q].z), acc[4 * q + 3] * spk_sigmoid(pv[q].w)};
+      } else {
+        const int t2 = tid - 256;
+        for (int s = t2; s < na * 32; s += 256) {
+          const int row = s >> 5, c4 = s & 31;
+          *(f32x4*)(sH + row * ML_LD + 4 * c4) = *(const f32x4*)(h_g + (int64_t)(a0 + row) * NF + 4 * c4);
+        }
+      }
+      if (tid == 0) sCnt[0] = 0;
+      __syncthreads();
+      ML_STAMP(33 + 6 * (Ltop - l));
+
+      // ================= D2: gy = gt W3
+      if (wv < NT) {
+        const int t = wv;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = ml_dense_tile(P.o1_t, sGh, t, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)(sGy + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+      }
+      __syncthreads();
+      ML_STAMP(34 + 6 * (Ltop - l));
+
+      // ================= E: derivative tasks (pair tile, pair of channel tiles) + row-sum tasks (atom quarter, channel half)
+      const int nder = 2 * ntile;
+      const int nrow = last ? 0 : 8;
+      while (true) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&sCnt[0], 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= nder + nrow) break;
+        if (k >= nder) {
+          // ---- gh[a][c] = sum over the row of a of gy[b][c] g[pair][c] f_c
+          const int k2 = k - nder;
+          const int c = 64 * (k2 & 1) + lane;
+          for (int at = k2 >> 1; at < na; at += 4) {
+            const int rs = sRow[at], re = sRow[at + 1];
+            float acc = 0.f;
+            for (int eb = rs; eb < re; eb += 8) {
+              int rec[8];
+              float gv[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                rec[u] = (eb + u < re) ? sEb[eb + u] : -1;
+                gv[u] = (rec[u] >= 0) ? g_g[(int64_t)(rec[u] >> 8) * NF + c] : 0.f;
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (rec[u] >= 0) acc = fmaf(sGy[(rec[u] & 255) * ML_LD + c] * sP[rec[u] >> 8].fc, gv[u], acc);
+            }
+            sGh[at * ML_LD + c] = acc;
+          }
+          continue;
+        }
+        const int tile = k >> 1, tp = k & 1;
+        const int pfirst = 32 * tile;
+        const int nvalid = (np - pfirst) < 32 ? (np - pfirst) : 32;
+        const bool valid = el < nvalid;
+        const int pl = pfirst + (valid ? el : (nvalid - 1));
+        const int64_t e = a.half[p0 + pl];
+        const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+        const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+        const MolPair pr = sP[pl];
+        const float fc = valid ? pr.fc : 0.f, dfc = valid ? pr.dfc : 0.f;
+        float phi[KPB][4], dphi[KPB][4];
+#pragma unroll
+        for (int u = 0; u < KPB; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) spk_rbf_eval_fast(a.rb, 8 * u + 4 * hi + v, d, phi[u][v], dphi[u][v]);
+        // ---- GEMM 1, value and derivative (rows = hidden channels, columns = pairs): z' = sigmoid(W1 phi + b1) * (W1 phi')
+        f32x16 zp[NT];
+        {
+          f32x4 wq = *(const f32x4*)(sW1 + lane * 4);
+#pragma unroll
+          for (int c = 0; c < NT; ++c) {
+            f32x16 zc, zq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { zc[r] = sb1[32 * c + ml_row(r, hi)]; zq[r] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < KPB; ++u) {
+              const int nxt = c * KPB + u + 1;
+              f32x4 wn = wq;
+              if (nxt < NT * KPB) wn = *(const f32x4*)(sW1 + (nxt * 64 + lane) * 4);
+              zc = ML_MFMA(wq.x, phi[u][0], zc);
+              zc = ML_MFMA(wq.y, phi[u][1], zc);
+              zc = ML_MFMA(wq.z, phi[u][2], zc);
+              zc = ML_MFMA(wq.w, phi[u][3], zc);
+              zq = ML_MFMA(wq.x, dphi[u][0], zq);
+              zq = ML_MFMA(wq.y, dphi[u][1], zq);
+              zq = ML_MFMA(wq.z, dphi[u][2], zq);
+              zq = ML_MFMA(wq.w, dphi[u][3], zq);
+              wq = wn;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float sp, sg;
+              spk_fast_softplus_sigmoid(zc[r], sp, sg);
+              zq[r] *= sg;
+            }
+            zp[c] = zq;
+          }
+        }
+        // ---- GEMM 2' per channel tile (rows = channels 32 t + ml_row(r, hi), columns = pairs): g' = W2 z'
+        float s1 = 0.f, s2 = 0.f;
+        const float* grow = g_g + (int64_t)pl * NF + 4 * hi;
+        const float* gyi_p = sGy + pr.i * ML_LD + 4 * hi;
+        const float* gyj_p = sGy + pr.j * ML_LD + 4 * hi;
+        const float* hi_p = sH + pr.i * ML_LD + 4 * hi;
+        const float* hj_p = sH + pr.j * ML_LD + 4 * hi;
+#pragma unroll 1
+        for (int t = 2 * tp; t < 2 * tp + 2; ++t) {
+          f32x4 gl[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gl[q] = *(const f32x4*)(grow + 32 * t + 8 * q);      // saved raw filter outputs of this lane's pair
+          f32x16 gp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gp[r] = 0.f;
+          {
+            const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
+            f32x4 wq = *(const f32x4*)wbase;
+#pragma unroll
+            for (int ug = 0; ug < KB2; ++ug) {
+              const int c = ug >> 2, q = ug & 3;
+              f32x4 wn = wq;
+              if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
+              gp = ML_MFMA(wq.x, zp[c][4 * q + 0], gp);
+              gp = ML_MFMA(wq.y, zp[c][4 * q + 1], gp);
+              gp = ML_MFMA(wq.z, zp[c][4 * q + 2], gp);
+              gp = ML_MFMA(wq.w, zp[c][4 * q + 3], gp);
+              wq = wn;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = 32 * t + 8 * q;
+            const f32x4 gyi = *(const f32x4*)(gyi_p + col), gyj = *(const f32x4*)(gyj_p + col);
+            const f32x4 hvi = *(const f32x4*)(hi_p + col), hvj = *(const f32x4*)(hj_p + col);
+            const float D0 = gp[4 * q] * fc + gl[q].x * dfc, D1 = gp[4 * q + 1] * fc + gl[q].y * dfc;
+            const float D2 = gp[4 * q + 2] * fc + gl[q].z * dfc, D3 = gp[4 * q + 3] * fc + gl[q].w * dfc;
+            s1 += gyi.x * hvj.x * D0 + gyi.y * hvj.y * D1 + gyi.z * hvj.z * D2 + gyi.w * hvj.w * D3;
+            s2 += gyj.x * hvi.x * D0 + gyj.y * hvi.y * D1 + gyj.z * hvi.z * D2 + gyj.w * hvi.w * D3;
+          }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (hi == 0 && valid) { atomicAdd(&sS[2 * pl], s1); atomicAdd(&sS[2 * pl + 1], s2); }
+      }
+      ML_STAMP(35 + 6 * (Ltop - l));
+      __syncthreads();
+      ML_STAMP(36 + 6 * (Ltop - l));
+      if (last) break;
+
+      // ================= G: gx += gh W_in; the other half stages the filter weights of the next (lower) interaction
+      if (wv < NT) {
+        const int t = wv;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = ml_dense_tile(P.in2f_t, sGh, t, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float* xp = sGx + el * ML_LD + 32 * t + 8 * q + 4 * hi;
+          f32x4 xv = *(const f32x4*)xp;
+          xv.x += acc[4 * q]; xv.y += acc[4 * q + 1]; xv.z += acc[4 * q + 2]; xv.w += acc[4 * q + 3];
+          if (el >= na) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)xp = xv;
+          if (l == 0 && el < na) *(f32x4*)(a.gx0 + (int64_t)(a0 + el) * NF + 32 * t + 8 * q + 4 * hi) = xv;
+        }
+      } else if (l > 0) {
+        const int t2 = tid - 256;
+        ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l - 1].w2, NF, KB2, t2);
+        ml_stage_packed<256, NF * KPB * 2>(sW1, a.L[l - 1].w1, a.rb.n_rbf, KPB, t2);
+        if (t2 < NF) sb1[t2] = a.L[l - 1].b1[t2];
+      }
+      __syncthreads();
+      ML_STAMP(37 + 6 * (Ltop - l));
+    }
+
+    // ---- dL/dr of both directions of every pair, once for all interactions
+    for (int s = tid; s < np; s += 512) {
+      const int64_t e = a.half[p0 + s];
+      const int64_t e2 = a.rev[e];
+      const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+      const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+      const float inv = d > 0.f ? 1.0f / d : 0.f;
+      const float s1 = sS[2 * s] * inv, s2 = sS[2 * s + 1] * inv;
+      a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
+      a.gr[3 * e2] = -s2 * rx; a.gr[3 * e2 + 1] = -s2 * ry; a.gr[3 * e2 + 2] = -s2 * rz;
+    }
+    ML_STAMP(63);
+  }
+}
+
+static size_t mol_bwd_lds(int kpb) {
+  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 2 * ML_MAXPAIRS) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
+         (ML_MAXEDGES + 36 + 4) * sizeof(int);
+}
+
+template <int KPB>
+static int launch_mol_bwd(const MolBwdArgs& a, hipStream_t stream) {
+  const size_t lds = mol_bwd_lds(KPB);
+  auto kern = k_schnet_mol_bwd<KPB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  int grid = a.n_groups;
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  SpkProfScope prof("schnet_mol_bwd", stream);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// n_rbf up to 24 (3 k-blocks): the LDS budget of the backward (per-pair sums) ends there; wider bases take the general driver
+bool spk_schnet_mol_bwd_eligible(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb) {
+  return spk_schnet_mol_eligible(m, g, rb) && (rb->n_rbf + 7) / 8 <= 3 && !getenv("SPK_NO_MOL_BWD");
+}
+
+int spk_schnet_mol_backward(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                            const float* gx_out, const float* r_ij, const float* saved, int64_t gsz, float* gr, float* gx0,
+                            hipStream_t stream) {
+  MolBwdArgs a;
+  a.n_layers = m->n_interactions;
+  for (int l = 0; l < m->n_interactions; ++l) {
+    const spk_schnet_layer_t& P = m->layers[l];
+    MolBwdLayerDev& D = a.L[l];
+    D.in2f_t = spk_packed_of(ptab, P.in2f_w, 1);
+    D.o1_t = spk_packed_of(ptab, P.f2out_w1, 1);
+    D.o2_t = spk_packed_of(ptab, P.f2out_w2, 1);
+    SPK_CHECK_ARG(D.in2f_t && D.o1_t && D.o2_t, "spk_schnet_mol_backward: packed weight images missing");
+    D.w1 = P.fn_w1; D.b1 = P.fn_b1; D.w2 = P.fn_w2;
+  }
+  a.gx_out = gx_out; a.gx0 = gx0; a.gr = gr; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
+  a.half = g->half; a.rev = g->rev; a.rowptr = g->rowptr; a.edge_pair = g->edge_pair; a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0;
+  a.n_groups = g->n_groups; a.saved = saved; a.N = g->n_atoms; a.gsz = gsz;
+  a.gbase = saved + (int64_t)m->n_interactions * g->n_atoms * (m->n_filters + m->n_atom_basis);
+  a.rb = spk_radial_dev(rb);
+  a.dbg = g_mol_dbg;
+  switch ((rb->n_rbf + 7) / 8) {
+    case 1: return launch_mol_bwd<1>(a, stream);
+    case 2: return launch_mol_bwd<2>(a, stream);
+    case 3: return launch_mol_bwd<3>(a, stream);
+  }
+  spk_set_error("spk_schnet_mol_backward: n_rbf = %d unsupported", rb->n_rbf);
   return SPK_ERR_ARG;
 }

@@ -1,0 +1,33 @@
+"""Phase timing of the molecule-resident SchNet kernels (cycle stamps of thread 0 / workgroup 0)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from schnetpack_amd import _lib, model as M, synthetic as S
+dev = torch.device("cuda:0")
+b = S.molecule_batch("aspirin", int(sys.argv[1]) if len(sys.argv) > 1 else 256, seed=0)
+torch.manual_seed(0)
+m = M.build_model("schnet").to(dev).eval()
+inp = M.batch_to_inputs(b, dev)
+L = _lib.lib()
+dbg = torch.zeros(64, dtype=torch.int64, device=dev)
+for rep in range(3):
+    dbg.zero_()
+    L.spk_schnet_mol_set_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
+    out = m(dict(inp))
+    torch.cuda.synchronize()
+L.spk_schnet_mol_set_debug_buffer(None)
+st = dbg.cpu().tolist()
+names = {0: "fwd start", 31: "fwd end", 32: "bwd start", 63: "bwd end"}
+for l in range(3):
+    names.update({1 + 5 * l: "L%d staged" % l, 2 + 5 * l: "L%d A (thread 0 out of the queue)" % l, 3 + 5 * l: "L%d A barrier" % l, 4 + 5 * l: "L%d B done" % l, 5 + 5 * l: "L%d C1 done" % l})
+    names.update({33 + 6 * l: "bwd L%d D1 done" % (2 - l), 34 + 6 * l: "bwd L%d D2 done" % (2 - l), 35 + 6 * l: "bwd L%d E (thread 0 out)" % (2 - l),
+                  36 + 6 * l: "bwd L%d E barrier" % (2 - l), 37 + 6 * l: "bwd L%d G done" % (2 - l)})
+for base in (0, 32):
+    prev = st[base]
+    for k in sorted(names):
+        if k >= base and k < base + 32 and st[k]:
+            print("  %-36s %8d  (+%d)" % (names[k], st[k] - st[base], st[k] - prev)); prev = st[k]
+_lib.profile_enable(True); _lib.profile_report()
+for _ in range(20):
+    m(dict(inp))
+print({k: round(1e3 * v[1] / v[0], 1) for k, v in _lib.profile_report().items()})
