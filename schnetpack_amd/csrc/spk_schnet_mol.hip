@@ -55,7 +55,92 @@ struct MolFwdArgs {
 };
 #define ML_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
 
-struct __attribute__((aligned(16))) MolPair { int i; int j; float fc; float dfc; };
+// per pair of a group: local atoms i | j << 8, distance, f_c(d), f_c'(d) -- computed once per group, used by every interaction
+struct __attribute__((aligned(16))) MolPair { int ij; float d; float fc; float dfc; };
+
+// radial basis from parameters staged in LDS (nn/radial.py:11-15 gaussian, :105-110 bessel; hardware transcendentals as
+// spk_rbf_eval_fast)
+__device__ __forceinline__ void ml_rbf(int kind, int n_rbf, const float* __restrict__ p0, const float* __restrict__ p1, int k, float d,
+                                       float& phi, float& dphi) {
+  if (k >= n_rbf) { phi = 0.f; dphi = 0.f; return; }
+  if (kind == SPK_RBF_GAUSSIAN) {
+    const float w = p1[k];
+    const float c = -0.5f * __builtin_amdgcn_rcpf(w * w);
+    const float t = d - p0[k];
+    phi = __builtin_amdgcn_exp2f(1.4426950408889634f * c * t * t);
+    dphi = 2.0f * c * t * phi;
+  } else {
+    const float om = p0[k];
+    const float rev = om * d * 0.15915494309189535f;
+    const float s = __builtin_amdgcn_sinf(rev), co = __builtin_amdgcn_cosf(rev);
+    if (d == 0.0f) { phi = s; dphi = 0.f; }
+    else { const float inv = __builtin_amdgcn_rcpf(d); phi = s * inv; dphi = (om * co - phi) * inv; }
+  }
+}
+
+// pair records of a group: geometry is the same for every interaction
+__device__ __forceinline__ void ml_pair_records(MolPair* sP, const int32_t* __restrict__ half, const float* __restrict__ rij,
+                                                const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j, int p0, int np, int a0,
+                                                float cutoff, int tid) {
+  for (int s = tid; s < np; s += 512) {
+    const int64_t e = half[p0 + s];
+    const float rx = rij[3 * e], ry = rij[3 * e + 1], rz = rij[3 * e + 2];
+    MolPair pr;
+    pr.ij = (int)(idx_i[e] - a0) | ((int)(idx_j[e] - a0) << 8);
+    pr.d = sqrtf(rx * rx + ry * ry + rz * rz);
+    spk_cutoff_eval_fast(cutoff, pr.d, pr.fc, pr.dfc);
+    sP[s] = pr;
+  }
+}
+
+// y[at][c] = sum over the directed edges of the row of `at`:  sSrc[neighbour][c] * g[pair][c] * f_c(pair)
+// for the atoms at0, at0 + 4, at0 + 8, ... of one (channel, atom quarter) thread: THREE rows per round, up to RB loads of the
+// filter tensor in flight per row (one L2 round trip per round; rows of a molecule rarely exceed RB neighbours)
+template <int RB>
+__device__ __forceinline__ void ml_row_sums(float* __restrict__ sDst, const float* __restrict__ sSrc, const float* __restrict__ g_g, const MolPair* sP,
+                                            const int* sEb, const int* sRow, int na, int at0, int c) {
+  for (int at = at0; at < na; at += 12) {
+    int rs[3], re[3];
+    float acc[3];
+    float gv[3][RB];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int am = at + 4 * m;
+      rs[m] = am < na ? sRow[am] : 0;
+      re[m] = am < na ? sRow[am + 1] : 0;
+      acc[m] = 0.f;
+    }
+    while (true) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          // 32-bit element offsets from one base (a group's filter block is < 2^31 floats): one VGPR per address
+          const unsigned off = (rs[m] + u < re[m]) ? (unsigned)(sEb[rs[m] + u] >> 8) * 128u + (unsigned)c : (unsigned)c;
+          gv[m][u] = g_g[off];
+        }
+      // all loads of the round are in flight; keep the (cheap) LDS operands of the products behind them, row by row --
+      // hoisted above the loads they would double the live registers
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+          if (rs[m] + u < re[m]) {
+            const int rec = sEb[rs[m] + u];
+            acc[m] = fmaf(sSrc[(rec & 255) * ML_LD + c] * sP[rec >> 8].fc, gv[m][u], acc[m]);
+          }
+      }
+      bool more = false;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { rs[m] += RB; more = more || (rs[m] < re[m]); }
+      if (!more) break;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+      if (at + 4 * m < na) sDst[(at + 4 * m) * ML_LD + c] = acc[m];
+  }
+}
 
 // register r of the half hi of a 32x32 accumulator holds row (r & 3) + 8 (r >> 2) + 4 hi
 __device__ __forceinline__ int ml_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -65,7 +150,7 @@ __device__ __forceinline__ int ml_row(int r, int hi) { return (r & 3) + 8 * (r >
 template <int NTHREADS, int SLOTS>
 __device__ __forceinline__ void ml_stage_packed(float* dst, const float* __restrict__ w, int K, int KB, int tid) {
   constexpr int PER = (SLOTS + NTHREADS - 1) / NTHREADS;
-  constexpr int BATCH = PER < 4 ? PER : 4;       // loads in flight per thread (bounds the live registers)
+  constexpr int BATCH = PER < 8 ? PER : 8;       // loads in flight per thread (bounds the live registers)
   const bool vec = (K & 3) == 0;
 #pragma unroll 1
   for (int p0 = 0; p0 < PER; p0 += BATCH) {
@@ -102,12 +187,57 @@ __device__ __forceinline__ void ml_stage_packed(float* dst, const float* __restr
 // One 32-column output tile of a Dense layer over the 32 atom rows of the group, T-GEMM convention of spk_dense.hip:
 // A = packed weights straight from L2 (16 k-blocks of 8, all requested up front), B = activations [32][ML_LD] in LDS;
 // accumulator rows = output features 32 t + ml_row(r, hi), columns = atoms (lane & 31).
+// Global accesses as  wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: one VGPR per address instead of a 64-bit
+// pair -- with 64-bit per-lane addresses the compiler hoists dozens of address pairs out of the loops and spills them.
+template <class T>
+__device__ __forceinline__ T ml_ld(const void* sbase, unsigned voff) { return *(const T*)((const char*)sbase + voff); }
+template <class T>
+__device__ __forceinline__ void ml_st(void* sbase, unsigned voff, T v) { *(T*)((char*)sbase + voff) = v; }
+
+// (the weights do not depend on the data: ml_dense_load() is issued a phase EARLY -- before the barrier that completes the
+// activations -- so that a Dense phase pays no L2 round trip)
+__device__ __forceinline__ void ml_dense_load(f32x4 (&av)[16], const float* __restrict__ wp, int t /* wave-uniform */, int lane) {
+  const char* sb = (const char*)wp + (size_t)t * (16 * 64 * 16);
+#pragma unroll
+  for (int u = 0; u < 16; ++u) av[u] = ml_ld<f32x4>(sb, (unsigned)(lane * 16 + u * 1024));
+}
+__device__ __forceinline__ f32x16 ml_dense_mma(const f32x4 (&av)[16], const float* __restrict__ sIn, int lane, f32x16 acc) {
+  const int hi = lane >> 5, el = lane & 31;
+  const float* brow = sIn + el * ML_LD + 4 * hi;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const f32x4 bv = *(const f32x4*)(brow + 8 * u);
+    acc = ML_MFMA(av[u].x, bv.x, acc);
+    acc = ML_MFMA(av[u].y, bv.y, acc);
+    acc = ML_MFMA(av[u].z, bv.z, acc);
+    acc = ML_MFMA(av[u].w, bv.w, acc);
+  }
+  return acc;
+}
+// the same in halves of 8 k-blocks: the first half is requested a phase early (32 VGPRs across the phase in between), the
+// second half at the start of the phase -- its latency hides behind the 32 MFMAs of the first half
+__device__ __forceinline__ void ml_dense_load8(f32x4 (&av)[8], const float* __restrict__ wp, int t /* wave-uniform */, int lane, int half) {
+  const char* sb = (const char*)wp + (size_t)t * (16 * 64 * 16) + (size_t)half * (8 * 1024);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) av[u] = ml_ld<f32x4>(sb, (unsigned)(lane * 16 + u * 1024));
+}
+__device__ __forceinline__ f32x16 ml_dense_mma8(const f32x4 (&av)[8], const float* __restrict__ sIn, int lane, int half, f32x16 acc) {
+  const int hi = lane >> 5, el = lane & 31;
+  const float* brow = sIn + el * ML_LD + 4 * hi + 64 * half;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const f32x4 bv = *(const f32x4*)(brow + 8 * u);
+    acc = ML_MFMA(av[u].x, bv.x, acc);
+    acc = ML_MFMA(av[u].y, bv.y, acc);
+    acc = ML_MFMA(av[u].z, bv.z, acc);
+    acc = ML_MFMA(av[u].w, bv.w, acc);
+  }
+  return acc;
+}
 __device__ __forceinline__ f32x16 ml_dense_tile(const float* __restrict__ wp, const float* __restrict__ sIn, int t, int lane, f32x16 acc) {
   const int hi = lane >> 5, el = lane & 31;
-  const f32x4* w4 = (const f32x4*)wp + ((int64_t)t * 16) * 64 + lane;
   f32x4 av[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) av[u] = w4[u * 64];
+  ml_dense_load(av, wp, t, lane);
   const float* brow = sIn + el * ML_LD + 4 * hi;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
@@ -132,13 +262,19 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
   float* sH = sX + 32 * ML_LD;                        // h = in2f(x)
   float* sY = sH + 32 * ML_LD;                        // y = cfconv output
   float* sT = sY + 32 * ML_LD;                        // hidden layer of f2out
-  MolPair* sP = (MolPair*)(sT + 32 * ML_LD);          // per pair: local atoms, f_c, f_c'
+  MolPair* sP = (MolPair*)(sT + 32 * ML_LD);          // per pair: local atoms, d, f_c, f_c'
   int* sEb = (int*)(sP + ML_MAXPAIRS);                // per directed edge: (local pair << 8) | local neighbour
   int* sRow = sEb + ML_MAXEDGES;                      // [33] local CSR
-  int* sCnt = sRow + 36;
+  int* sCnt = sRow + 36;                              // [4]
+  float* sRb = (float*)(sCnt + 4);                    // [2][32] radial basis parameters
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wv: SGPR
   const int hi = lane >> 5, el = lane & 31;
+  if (tid < 64) {
+    const int k = tid & 31;
+    const float* src = (tid < 32) ? a.rb.p0 : a.rb.p1;
+    sRb[tid] = (src && k < a.rb.n_rbf) ? src[k] : 1.0f;
+  }
 
   for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
     const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
@@ -148,18 +284,17 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
     __syncthreads();   // the previous group is done with every LDS buffer
     ML_STAMP(0);
 
-    // ---- group set-up: features, local CSR, first filter weights
+    // ---- group set-up: features, local CSR, pair geometry (shared by all interactions), first filter weights
     for (int s = tid; s < 32 * 32; s += 512) {
       const int row = s >> 5, c4 = s & 31;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < na) v = *(const f32x4*)(a.x0 + (int64_t)(a0 + row) * NF + 4 * c4);
+      if (row < na) v = ml_ld<f32x4>(a.x0 + (size_t)a0 * NF, (unsigned)(s * 16));
       *(f32x4*)(sX + row * ML_LD + 4 * c4) = v;
       *(f32x4*)(sY + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int s = tid; s < ne; s += 512) {
-      const int64_t e = (int64_t)e0 + s;
-      sEb[s] = ((a.edge_pair[e] - p0) << 8) | (int)(a.idx_j[e] - a0);
-    }
+    for (int s = tid; s < ne; s += 512)
+      sEb[s] = ((ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0) << 8) | (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0);
+    ml_pair_records(sP, a.half, a.rij, a.idx_i, a.idx_j, p0, np, a0, a.rb.cutoff, tid);
     if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
     ml_stage_packed<512, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
     ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[0].w1, a.rb.n_rbf, KPB, tid);
@@ -174,7 +309,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       __syncthreads();
       ML_STAMP(1 + 5 * l);
 
-      // ================= phase A: filter tasks (pair tile, channel tile) + in2f tasks, dynamic queue
+      // ================= phase A: filter tasks (pair tile, channel tile) + in2f tasks, dynamic queue.  No global loads
+      // except the in2f weights: geometry and radial parameters come from LDS.
       const int nfilt = 4 * ntile;
       while (true) {
         int k = 0;
@@ -194,27 +330,16 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           continue;
         }
         const int tile = k >> 2, t = k & 3;
-        // ---- per-pair geometry (lanes 32..63 mirror lanes 0..31)
         const int pfirst = 32 * tile;
         const int nvalid = (np - pfirst) < 32 ? (np - pfirst) : 32;
-        const bool valid = el < nvalid;
-        const int64_t e = a.half[p0 + pfirst + (valid ? el : (nvalid - 1))];
-        const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
-        const float d = sqrtf(rx * rx + ry * ry + rz * rz);
-        float fc, dfc;
-        spk_cutoff_eval_fast(a.rb.cutoff, d, fc, dfc);
-        if (t == 0 && hi == 0 && valid) {
-          MolPair pr; pr.i = (int)(a.idx_i[e] - a0); pr.j = (int)(a.idx_j[e] - a0); pr.fc = fc; pr.dfc = dfc;
-          sP[pfirst + el] = pr;
-        }
+        const float d = sP[pfirst + (el < nvalid ? el : (nvalid - 1))].d;      // lanes 32..63 mirror lanes 0..31
         float phi[KPB][4];
 #pragma unroll
         for (int u = 0; u < KPB; ++u)
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            float p, dp;
-            spk_rbf_eval_fast(a.rb, 8 * u + 4 * hi + v, d, p, dp);
-            phi[u][v] = p;
+            float dp;
+            ml_rbf(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, 8 * u + 4 * hi + v, d, phi[u][v], dp);
           }
         // ---- GEMM 1 (rows = hidden channels, columns = pairs): z = ssp(W1 phi + b1)
         f32x16 z[NT];
@@ -263,61 +388,51 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           }
         }
         // raw filter outputs: row = pair, 128-byte row segments per half wave
-        float* gt = g_g + (int64_t)pfirst * NF + c0;
+        float* gt = g_g + (size_t)pfirst * NF + 32 * t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int pr = ml_row(r, hi);
-          if (pr < nvalid) gt[pr * NF] = g[r];
+          if (pr < nvalid) ml_st<float>(gt, (unsigned)((pr * NF + el) * 4), g[r]);
         }
       }
+      // first half of the f2out.0 weights of this wave's tile: requested now, used two barriers later
+      f32x4 av1a[8];
+      if (wv < NT) ml_dense_load8(av1a, P.o1_p, wv, lane, 0);
       ML_STAMP(2 + 5 * l);
-      __syncthreads();   // h, the pair records and (workgroup scope) the filter outputs are complete
+      __syncthreads();   // h and (workgroup scope) the filter outputs are complete
       ML_STAMP(3 + 5 * l);
 
       // ================= phase B: y[a] = sum over the row of a;  thread = (channel, atom quarter)
-      {
-        const int c = tid & 127, q4 = tid >> 7;
-        for (int at = q4; at < na; at += 4) {
-          const int rs = sRow[at], re = sRow[at + 1];
-          float acc = 0.f;
-          for (int eb = rs; eb < re; eb += 8) {
-            int rec[8];
-            float gv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              rec[u] = (eb + u < re) ? sEb[eb + u] : -1;
-              gv[u] = (rec[u] >= 0) ? g_g[(int64_t)(rec[u] >> 8) * NF + c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-              if (rec[u] >= 0) acc = fmaf(sH[(rec[u] & 255) * ML_LD + c] * sP[rec[u] >> 8].fc, gv[u], acc);
-          }
-          sY[at * ML_LD + c] = acc;
-        }
-      }
+      ml_row_sums<16>(sY, sH, g_g, sP, sEb, sRow, na, tid >> 7, tid & 127);
       __syncthreads();
       ML_STAMP(4 + 5 * l);
 
       // ================= phase C1: pre3 = y W3^T + b3 (saved), t = ssp(pre3); the other half saves h and stages weights
+      f32x4 av2a[8];
       if (wv < NT) {
         const int t = wv;
+        f32x4 av1b[8];
+        ml_dense_load8(av1b, P.o1_p, t, lane, 1);
+        ml_dense_load8(av2a, P.o2_p, t, lane, 0);     // first half of the f2out.1 weights for phase C2
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = P.o1_b[32 * t + ml_row(r, hi)];
-        acc = ml_dense_tile(P.o1_p, sY, t, lane, acc);
+        acc = ml_dense_mma8(av1a, sY, lane, 0, acc);
+        acc = ml_dense_mma8(av1b, sY, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-          if (el < na) *(f32x4*)(pre3_g + (int64_t)(a0 + el) * NF + 32 * t + 8 * q + 4 * hi) = pv;
+          if (el < na) ml_st<f32x4>(pre3_g + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4), pv);
           *(f32x4*)(sT + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{spk_fast_ssp(pv.x), spk_fast_ssp(pv.y), spk_fast_ssp(pv.z), spk_fast_ssp(pv.w)};
         }
       } else {
         const int t2 = tid - 256;
         for (int s = t2; s < na * 32; s += 256) {
           const int row = s >> 5, c4 = s & 31;
-          *(f32x4*)(h_g + (int64_t)(a0 + row) * NF + 4 * c4) = *(const f32x4*)(sH + row * ML_LD + 4 * c4);
+          ml_st<f32x4>(h_g + (size_t)a0 * NF, (unsigned)(s * 16), *(const f32x4*)(sH + row * ML_LD + 4 * c4));
         }
         if (l + 1 < a.n_layers) {     // the filter GEMMs of this interaction are done: their LDS images can be replaced
+          ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l + 1].w2, NF, KB2, t2);
           ml_stage_packed<256, NF * KPB * 2>(sW1, a.L[l + 1].w1, a.rb.n_rbf, KPB, t2);
           if (t2 < NF) { sb1[t2] = a.L[l + 1].b1[t2]; sb2[t2] = a.L[l + 1].b2[t2]; }
         }
@@ -328,10 +443,13 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       // ================= phase C2: x += t W4^T + b4
       if (wv < NT) {
         const int t = wv;
+        f32x4 av2b[8];
+        ml_dense_load8(av2b, P.o2_p, t, lane, 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = P.o2_b[32 * t + ml_row(r, hi)];
-        acc = ml_dense_tile(P.o2_p, sT, t, lane, acc);
+        acc = ml_dense_mma8(av2a, sT, lane, 0, acc);
+        acc = ml_dense_mma8(av2b, sT, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float* xp = sX + el * ML_LD + 32 * t + 8 * q + 4 * hi;
@@ -339,10 +457,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           xv.x += acc[4 * q]; xv.y += acc[4 * q + 1]; xv.z += acc[4 * q + 2]; xv.w += acc[4 * q + 3];
           if (el >= na) xv = f32x4{0.f, 0.f, 0.f, 0.f};       // padding rows stay zero (in2f has no bias: h pads stay zero too)
           *(f32x4*)xp = xv;
-          if (l + 1 == a.n_layers && el < na) *(f32x4*)(a.x_out + (int64_t)(a0 + el) * NF + 32 * t + 8 * q + 4 * hi) = xv;
+          if (l + 1 == a.n_layers && el < na) ml_st<f32x4>(a.x_out + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4), xv);
         }
-      } else if (l + 1 < a.n_layers) {
-        ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l + 1].w2, NF, KB2, tid - 256);
       }
       // (the barrier at the top of the next interaction / group closes this phase)
     }
@@ -356,7 +472,7 @@ static long long* g_mol_dbg = nullptr;
 extern "C" void spk_schnet_mol_set_debug_buffer(void* p) { g_mol_dbg = (long long*)p; }
 
 static size_t mol_fwd_lds(int kpb) {
-  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
+  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
          (ML_MAXEDGES + 36 + 4) * sizeof(int);
 }
 
@@ -470,14 +586,20 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
   float* sH = sGx + 32 * ML_LD;                       // h_l (saved by the forward)
   float* sGy = sH + 32 * ML_LD;                       // dL/dy_l
   float* sGh = sGy + 32 * ML_LD;                      // dL/dh_l; before that the hidden gradient of f2out
-  MolPair* sP = (MolPair*)(sGh + 32 * ML_LD);         // per pair: local atoms, f_c, f_c'
+  MolPair* sP = (MolPair*)(sGh + 32 * ML_LD);         // per pair: local atoms, d, f_c, f_c'
   int* sEb = (int*)(sP + ML_MAXPAIRS);                // per directed edge: (local pair << 8) | local neighbour
   int* sRow = sEb + ML_MAXEDGES;                      // [33]
   int* sCnt = sRow + 36;                              // [4]
-  float* sS = (float*)(sCnt + 4);                     // [ML_MAXPAIRS][2] per-pair geometry sums, all interactions
+  float* sRb = (float*)(sCnt + 4);                    // [2][32] radial basis parameters
+  float* sS = sRb + 64;                               // [ML_MAXPAIRS][2] per-pair geometry sums, all interactions
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wv: SGPR
   const int hi = lane >> 5, el = lane & 31;
+  if (tid < 64) {
+    const int k = tid & 31;
+    const float* src = (tid < 32) ? a.rb.p0 : a.rb.p1;
+    sRb[tid] = (src && k < a.rb.n_rbf) ? src[k] : 1.0f;
+  }
 
   for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
     const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
@@ -488,27 +610,20 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     __syncthreads();
 
     // ---- group set-up
+    f32x4 avA[8];                                    // first half of the weights of D1 of this wave (waves 0..3), requested a phase early
+    if (wv < NT) ml_dense_load8(avA, a.L[Ltop].o2_t, wv, lane, 0);
     for (int s = tid; s < 32 * 32; s += 512) {
       const int row = s >> 5, c4 = s & 31;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < na) v = *(const f32x4*)(a.gx_out + (int64_t)(a0 + row) * NF + 4 * c4);
+      if (row < na) v = ml_ld<f32x4>(a.gx_out + (size_t)a0 * NF, (unsigned)(s * 16));
       *(f32x4*)(sGx + row * ML_LD + 4 * c4) = v;
       *(f32x4*)(sGh + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
       *(f32x4*)(sH + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int s = tid; s < ne; s += 512) {
-      const int64_t e = (int64_t)e0 + s;
-      sEb[s] = ((a.edge_pair[e] - p0) << 8) | (int)(a.idx_j[e] - a0);
-    }
-    for (int s = tid; s < np; s += 512) {
-      const int64_t e = a.half[p0 + s];
-      const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
-      MolPair pr;
-      pr.i = (int)(a.idx_i[e] - a0); pr.j = (int)(a.idx_j[e] - a0);
-      spk_cutoff_eval_fast(a.rb.cutoff, sqrtf(rx * rx + ry * ry + rz * rz), pr.fc, pr.dfc);
-      sP[s] = pr;
-      sS[2 * s] = 0.f; sS[2 * s + 1] = 0.f;
-    }
+    for (int s = tid; s < ne; s += 512)
+      sEb[s] = ((ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0) << 8) | (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0);
+    ml_pair_records(sP, a.half, a.rij, a.idx_i, a.idx_j, p0, np, a0, a.rb.cutoff, tid);
+    for (int s = tid; s < 2 * np; s += 512) sS[s] = 0.f;
     if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
     ml_stage_packed<512, NF * NF / 4>(sW2, a.L[Ltop].w2, NF, KB2, tid);
     ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[Ltop].w1, a.rb.n_rbf, KPB, tid);
@@ -524,8 +639,12 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       const bool last = (l == 0) && !a.gx0;     // nothing below consumes dL/dh_0: no row sums, no in2f transpose
 
       // ================= D1: gt = (gx W4) * ssp'(pre3);  the other half loads h_l
+      f32x4 avB[8];
       if (wv < NT) {
         const int t = wv;
+        f32x4 avA2[8];
+        ml_dense_load8(avA2, P.o2_t, t, lane, 1);
+        ml_dense_load8(avB, P.o1_t, t, lane, 0);      // first half of the weights of D2
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -533,9 +652,10 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           pv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (el < na) pv[q] = *(const f32x4*)(pre3_g + (int64_t)(a0 + el) * NF + 32 * t + 8 * q + 4 * hi);
+          if (el < na) pv[q] = ml_ld<f32x4>(pre3_g + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4));
         }
-        acc = ml_dense_tile(P.o2_t, sGx, t, lane, acc);
+        acc = ml_dense_mma8(avA, sGx, lane, 0, acc);
+        acc = ml_dense_mma8(avA2, sGx, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(sGh + el * ML_LD + 32 * t + 8 * q + 4 * hi) =
@@ -544,7 +664,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         const int t2 = tid - 256;
         for (int s = t2; s < na * 32; s += 256) {
           const int row = s >> 5, c4 = s & 31;
-          *(f32x4*)(sH + row * ML_LD + 4 * c4) = *(const f32x4*)(h_g + (int64_t)(a0 + row) * NF + 4 * c4);
+          *(f32x4*)(sH + row * ML_LD + 4 * c4) = ml_ld<f32x4>(h_g + (size_t)a0 * NF, (unsigned)(s * 16));
         }
       }
       if (tid == 0) sCnt[0] = 0;
@@ -554,10 +674,13 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       // ================= D2: gy = gt W3
       if (wv < NT) {
         const int t = wv;
+        f32x4 avB2[8];
+        ml_dense_load8(avB2, P.o1_t, t, lane, 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = ml_dense_tile(P.o1_t, sGh, t, lane, acc);
+        acc = ml_dense_mma8(avB, sGh, lane, 0, acc);
+        acc = ml_dense_mma8(avB2, sGh, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(sGy + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -576,24 +699,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         if (k >= nder) {
           // ---- gh[a][c] = sum over the row of a of gy[b][c] g[pair][c] f_c
           const int k2 = k - nder;
-          const int c = 64 * (k2 & 1) + lane;
-          for (int at = k2 >> 1; at < na; at += 4) {
-            const int rs = sRow[at], re = sRow[at + 1];
-            float acc = 0.f;
-            for (int eb = rs; eb < re; eb += 8) {
-              int rec[8];
-              float gv[8];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                rec[u] = (eb + u < re) ? sEb[eb + u] : -1;
-                gv[u] = (rec[u] >= 0) ? g_g[(int64_t)(rec[u] >> 8) * NF + c] : 0.f;
-              }
-#pragma unroll
-              for (int u = 0; u < 8; ++u)
-                if (rec[u] >= 0) acc = fmaf(sGy[(rec[u] & 255) * ML_LD + c] * sP[rec[u] >> 8].fc, gv[u], acc);
-            }
-            sGh[at * ML_LD + c] = acc;
-          }
+          ml_row_sums<16>(sGh, sGy, g_g, sP, sEb, sRow, na, k2 >> 1, 64 * (k2 & 1) + lane);
           continue;
         }
         const int tile = k >> 1, tp = k & 1;
@@ -601,16 +707,20 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         const int nvalid = (np - pfirst) < 32 ? (np - pfirst) : 32;
         const bool valid = el < nvalid;
         const int pl = pfirst + (valid ? el : (nvalid - 1));
-        const int64_t e = a.half[p0 + pl];
-        const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
-        const float d = sqrtf(rx * rx + ry * ry + rz * rz);
         const MolPair pr = sP[pl];
         const float fc = valid ? pr.fc : 0.f, dfc = valid ? pr.dfc : 0.f;
+        const int pi = pr.ij & 255, pj = pr.ij >> 8;
+        // the saved raw filter outputs of this lane's pair for both channel tiles of the task: requested first, used last
+        f32x4 gl[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gl[tt][q] = ml_ld<f32x4>(g_g + 64 * tp, (unsigned)((pl * NF + 4 * hi + 32 * tt + 8 * q) * 4));
         float phi[KPB][4], dphi[KPB][4];
 #pragma unroll
         for (int u = 0; u < KPB; ++u)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) spk_rbf_eval_fast(a.rb, 8 * u + 4 * hi + v, d, phi[u][v], dphi[u][v]);
+          for (int v = 0; v < 4; ++v) ml_rbf(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, 8 * u + 4 * hi + v, pr.d, phi[u][v], dphi[u][v]);
         // ---- GEMM 1, value and derivative (rows = hidden channels, columns = pairs): z' = sigmoid(W1 phi + b1) * (W1 phi')
         f32x16 zp[NT];
         {
@@ -646,16 +756,13 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         }
         // ---- GEMM 2' per channel tile (rows = channels 32 t + ml_row(r, hi), columns = pairs): g' = W2 z'
         float s1 = 0.f, s2 = 0.f;
-        const float* grow = g_g + (int64_t)pl * NF + 4 * hi;
-        const float* gyi_p = sGy + pr.i * ML_LD + 4 * hi;
-        const float* gyj_p = sGy + pr.j * ML_LD + 4 * hi;
-        const float* hi_p = sH + pr.i * ML_LD + 4 * hi;
-        const float* hj_p = sH + pr.j * ML_LD + 4 * hi;
-#pragma unroll 1
-        for (int t = 2 * tp; t < 2 * tp + 2; ++t) {
-          f32x4 gl[4];
+        const float* gyi_p = sGy + pi * ML_LD + 4 * hi;
+        const float* gyj_p = sGy + pj * ML_LD + 4 * hi;
+        const float* hi_p = sH + pi * ML_LD + 4 * hi;
+        const float* hj_p = sH + pj * ML_LD + 4 * hi;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) gl[q] = *(const f32x4*)(grow + 32 * t + 8 * q);      // saved raw filter outputs of this lane's pair
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * tp + tt;
           f32x16 gp;
 #pragma unroll
           for (int r = 0; r < 16; ++r) gp[r] = 0.f;
@@ -679,8 +786,9 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
             const int col = 32 * t + 8 * q;
             const f32x4 gyi = *(const f32x4*)(gyi_p + col), gyj = *(const f32x4*)(gyj_p + col);
             const f32x4 hvi = *(const f32x4*)(hi_p + col), hvj = *(const f32x4*)(hj_p + col);
-            const float D0 = gp[4 * q] * fc + gl[q].x * dfc, D1 = gp[4 * q + 1] * fc + gl[q].y * dfc;
-            const float D2 = gp[4 * q + 2] * fc + gl[q].z * dfc, D3 = gp[4 * q + 3] * fc + gl[q].w * dfc;
+            const f32x4 gq = gl[tt][q];
+            const float D0 = gp[4 * q] * fc + gq.x * dfc, D1 = gp[4 * q + 1] * fc + gq.y * dfc;
+            const float D2 = gp[4 * q + 2] * fc + gq.z * dfc, D3 = gp[4 * q + 3] * fc + gq.w * dfc;
             s1 += gyi.x * hvj.x * D0 + gyi.y * hvj.y * D1 + gyi.z * hvj.z * D2 + gyi.w * hvj.w * D3;
             s2 += gyj.x * hvi.x * D0 + gyj.y * hvi.y * D1 + gyj.z * hvi.z * D2 + gyj.w * hvi.w * D3;
           }
@@ -689,6 +797,9 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         s2 += __shfl_xor(s2, 32, 64);
         if (hi == 0 && valid) { atomicAdd(&sS[2 * pl], s1); atomicAdd(&sS[2 * pl + 1], s2); }
       }
+      // out of the queue: request the weights of the next Dense phase of this wave before waiting for the others
+      if (wv < NT && !last) ml_dense_load8(avB, P.in2f_t, wv, lane, 0);
+      if (wv < NT && l > 0) ml_dense_load8(avA, a.L[l - 1].o2_t, wv, lane, 0);
       ML_STAMP(35 + 6 * (Ltop - l));
       __syncthreads();
       ML_STAMP(36 + 6 * (Ltop - l));
@@ -697,10 +808,13 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       // ================= G: gx += gh W_in; the other half stages the filter weights of the next (lower) interaction
       if (wv < NT) {
         const int t = wv;
+        f32x4 avB2[8];
+        ml_dense_load8(avB2, P.in2f_t, t, lane, 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = ml_dense_tile(P.in2f_t, sGh, t, lane, acc);
+        acc = ml_dense_mma8(avB, sGh, lane, 0, acc);
+        acc = ml_dense_mma8(avB2, sGh, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float* xp = sGx + el * ML_LD + 32 * t + 8 * q + 4 * hi;
@@ -708,7 +822,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           xv.x += acc[4 * q]; xv.y += acc[4 * q + 1]; xv.z += acc[4 * q + 2]; xv.w += acc[4 * q + 3];
           if (el >= na) xv = f32x4{0.f, 0.f, 0.f, 0.f};
           *(f32x4*)xp = xv;
-          if (l == 0 && el < na) *(f32x4*)(a.gx0 + (int64_t)(a0 + el) * NF + 32 * t + 8 * q + 4 * hi) = xv;
+          if (l == 0 && el < na) ml_st<f32x4>(a.gx0 + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4), xv);
         }
       } else if (l > 0) {
         const int t2 = tid - 256;
@@ -725,7 +839,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       const int64_t e = a.half[p0 + s];
       const int64_t e2 = a.rev[e];
       const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
-      const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+      const float d = sP[s].d;
       const float inv = d > 0.f ? 1.0f / d : 0.f;
       const float s1 = sS[2 * s] * inv, s2 = sS[2 * s + 1] * inv;
       a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
@@ -736,7 +850,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 }
 
 static size_t mol_bwd_lds(int kpb) {
-  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 2 * ML_MAXPAIRS) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
+  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64 + 2 * ML_MAXPAIRS) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
          (ML_MAXEDGES + 36 + 4) * sizeof(int);
 }
 
