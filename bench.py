@@ -109,6 +109,7 @@ def self_spawn(args):
 
 # rocprofv3 kernel-name patterns of the profile tags (spk_profile_report) -- used to attribute PMC counters
 PMC_TAGS = [
+    ("schnet_mol_fwd", r"k_schnet_mol_fwd<"), ("schnet_mol_bwd", r"k_schnet_mol_bwd<"),
     ("cfconv_fwd_pair", r"k_cfconv_pair<[^>]*false, false, false>"), ("cfconv_bwd_pair_gs_geom", r"k_cfconv_pair_t<[^>]*true, true, true>"),
     ("cfconv_bwd_pair_gs", r"k_cfconv_pair_t<[^>]*true, true, false>"), ("cfconv_bwd_pair", r"k_cfconv_pair_t<[^>]*true, false"),
     ("cfconv_fwd_mol", r"k_cfconv_mol<[^>]*false>"), ("cfconv_bwd_mol", r"k_cfconv_mol<[^>]*true>"),
@@ -421,6 +422,8 @@ def main():
     exec_mol = n_int * (4096.0 * ((E // 2 + 31 * n_mol) // 32) * 4 * (4 * ((n_rbf + 7) // 8) + 64) + 4096.0 * n_mol * 3 * 4 * 64)
     algo = {
         "schnet_mol_fwd": ("mfma", n_int * (flop_fwd + flop_dense), exec_mol / (n_int * (flop_fwd + flop_dense))),
+        # backward: value + derivative through the filter MLP (2x the forward figure, section 8(d)) + the three transposed Dense layers
+        "schnet_mol_bwd": ("mfma", n_int * (2 * flop_fwd + flop_dense), 1.0),
         "cfconv_fwd_mfma": ("mfma", flop_fwd, 1.0), "cfconv_fwd_simple": ("mfma", flop_fwd, 1.0),
         "cfconv_fwd_pair": ("mfma", flop_fwd, 0.5),
         "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd, 1.0), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd, 1.0),

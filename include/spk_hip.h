@@ -90,6 +90,8 @@ typedef struct {
    * most 32 atoms) the fused SchNet representation runs molecule-resident: one workgroup per group, all interactions in
    * one launch, per-atom row sums instead of float atomics (spk_schnet_mol.hip). */
   const int32_t* edge_pair;
+  int32_t max_group_pairs; /* largest number of undirected pairs inside one group (0: unknown) */
+  int32_t reserved1;
 } spk_graph_t;
 
 /* ------------------------------------------------------------------ library / device info */

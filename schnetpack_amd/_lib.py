@@ -36,7 +36,8 @@ class GraphT(ctypes.Structure):
                 ("rowptr", c_f), ("sorted", c_i32), ("symmetric", c_i32), ("rev", c_f), ("half", c_f),
                 ("n_half", c_i64), ("grp_atom0", c_f), ("grp_pair0", c_f), ("grp_tile0", c_f),
                 ("n_groups", c_i32), ("max_group_atoms", c_i32), ("n_tiles_grouped", c_i64),
-                ("filter_pairs", c_i32), ("reserved0", c_i32), ("n_half_dev", c_f), ("edge_pair", c_f)]
+                ("filter_pairs", c_i32), ("reserved0", c_i32), ("n_half_dev", c_f), ("edge_pair", c_f),
+                ("max_group_pairs", c_i32), ("reserved1", c_i32)]
 
 
 class SchnetLayerT(ctypes.Structure):

@@ -23,8 +23,8 @@
 
 #define ML_MAXL 6
 #define ML_LD 132          // row stride (floats) of the [32][128] activation tiles in LDS: conflict-free 16-byte accesses
-#define ML_MAXPAIRS 512    // 32 atoms: at most 496 undirected pairs
-#define ML_MAXEDGES 1024
+#define ML_MAXPAIRS 384    // pairs per group (28 fully connected atoms; LDS budget of the backward)
+#define ML_MAXEDGES 768
 #define ML_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
 
 struct MolLayerDev {
@@ -95,14 +95,15 @@ __device__ __forceinline__ void ml_pair_records(MolPair* sP, const int32_t* __re
 
 // y[at][c] = sum over the directed edges of the row of `at`:  sSrc[neighbour][c] * g[pair][c] * f_c(pair)
 // for the atoms at0, at0 + 4, at0 + 8, ... of one (channel, atom quarter) thread: THREE rows per round, up to RB loads of the
-// filter tensor in flight per row (one L2 round trip per round; rows of a molecule rarely exceed RB neighbours)
+// filter tensor in flight per row (one L2 round trip per round; rows of a molecule rarely exceed RB neighbours).  Branch-free:
+// entries beyond the end of a row re-read its last entry with weight 0, so the record reads and the loads issue back to back.
+// sEb: per directed edge (local pair << 8 | local neighbour, f_c of the pair).
 template <int RB>
-__device__ __forceinline__ void ml_row_sums(float* __restrict__ sDst, const float* __restrict__ sSrc, const float* __restrict__ g_g, const MolPair* sP,
-                                            const int* sEb, const int* sRow, int na, int at0, int c) {
+__device__ __forceinline__ void ml_row_sums(float* __restrict__ sDst, const float* __restrict__ sSrc, const float* __restrict__ g_g,
+                                            const int2* __restrict__ sEb, const int* __restrict__ sRow, int na, int at0, int c) {
   for (int at = at0; at < na; at += 12) {
     int rs[3], re[3];
     float acc[3];
-    float gv[3][RB];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       const int am = at + 4 * m;
@@ -111,26 +112,27 @@ __device__ __forceinline__ void ml_row_sums(float* __restrict__ sDst, const floa
       acc[m] = 0.f;
     }
     while (true) {
+      int2 rec[3][RB];
+      float gv[3][RB];
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-          // 32-bit element offsets from one base (a group's filter block is < 2^31 floats): one VGPR per address
-          const unsigned off = (rs[m] + u < re[m]) ? (unsigned)(sEb[rs[m] + u] >> 8) * 128u + (unsigned)c : (unsigned)c;
-          gv[m][u] = g_g[off];
+          const int last = re[m] > 0 ? re[m] - 1 : 0;
+          const int idx = rs[m] + u < re[m] ? rs[m] + u : last;
+          rec[m][u] = sEb[idx];
+          if (rs[m] + u >= re[m]) rec[m][u].y = 0;          // weight 0 beyond the row
         }
-      // all loads of the round are in flight; keep the (cheap) LDS operands of the products behind them, row by row --
-      // hoisted above the loads they would double the live registers
+      // 32-bit element offsets from one base (a group's filter block is < 2^31 floats): one VGPR per address
 #pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int u = 0; u < RB; ++u) gv[m][u] = g_g[(unsigned)(rec[m][u].x >> 8) * 128u + (unsigned)c];
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int u = 0; u < RB; ++u)
-          if (rs[m] + u < re[m]) {
-            const int rec = sEb[rs[m] + u];
-            acc[m] = fmaf(sSrc[(rec & 255) * ML_LD + c] * sP[rec >> 8].fc, gv[m][u], acc[m]);
-          }
-      }
+          acc[m] = fmaf(sSrc[(rec[m][u].x & 255) * ML_LD + c] * __int_as_float(rec[m][u].y), gv[m][u], acc[m]);
       bool more = false;
 #pragma unroll
       for (int m = 0; m < 3; ++m) { rs[m] += RB; more = more || (rs[m] < re[m]); }
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
   float* sY = sH + 32 * ML_LD;                        // y = cfconv output
   float* sT = sY + 32 * ML_LD;                        // hidden layer of f2out
   MolPair* sP = (MolPair*)(sT + 32 * ML_LD);          // per pair: local atoms, d, f_c, f_c'
-  int* sEb = (int*)(sP + ML_MAXPAIRS);                // per directed edge: (local pair << 8) | local neighbour
-  int* sRow = sEb + ML_MAXEDGES;                      // [33] local CSR
+  int2* sEb = (int2*)(sP + ML_MAXPAIRS);              // per directed edge: ((local pair << 8) | local neighbour, f_c)
+  int* sRow = (int*)(sEb + ML_MAXEDGES);              // [33] local CSR
   int* sCnt = sRow + 36;                              // [4]
   float* sRb = (float*)(sCnt + 4);                    // [2][32] radial basis parameters
 
@@ -292,9 +294,12 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       *(f32x4*)(sX + row * ML_LD + 4 * c4) = v;
       *(f32x4*)(sY + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int s = tid; s < ne; s += 512)
-      sEb[s] = ((ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0) << 8) | (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0);
     ml_pair_records(sP, a.half, a.rij, a.idx_i, a.idx_j, p0, np, a0, a.rb.cutoff, tid);
+    __syncthreads();
+    for (int s = tid; s < ne; s += 512) {
+      const int pl = ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0;
+      sEb[s] = make_int2((pl << 8) | (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0), __float_as_int(sP[pl].fc));
+    }
     if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
     ml_stage_packed<512, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
     ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[0].w1, a.rb.n_rbf, KPB, tid);
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
 
       // ================= phase A: filter tasks (pair tile, channel tile) + in2f tasks, dynamic queue.  No global loads
       // except the in2f weights: geometry and radial parameters come from LDS.
-      const int nfilt = 4 * ntile;
+      const int nfilt = 2 * ntile;
       while (true) {
         int k = 0;
         if (lane == 0) k = atomicAdd(&sCnt[0], 1);
@@ -329,7 +334,10 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
             *(f32x4*)(sH + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
           continue;
         }
-        const int tile = k >> 2, t = k & 3;
+        const int tile = k >> 1, tp = k & 1;       // (pair tile, pair of channel tiles): GEMM 1 + activation once per two GEMM 2
+        const bool st0 = (l == 0 && k == 0);
+#define ML_SUB(n) do { if (st0 && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
+        ML_SUB(64);
         const int pfirst = 32 * tile;
         const int nvalid = (np - pfirst) < 32 ? (np - pfirst) : 32;
         const float d = sP[pfirst + (el < nvalid ? el : (nvalid - 1))].d;      // lanes 32..63 mirror lanes 0..31
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
             float dp;
             ml_rbf(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, 8 * u + 4 * hi + v, d, phi[u][v], dp);
           }
+        ML_SUB(65);
         // ---- GEMM 1 (rows = hidden channels, columns = pairs): z = ssp(W1 phi + b1)
         f32x16 z[NT];
         {
@@ -366,54 +375,56 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
             z[c] = zc;
           }
         }
-        // ---- GEMM 2, operands swapped (rows = pairs, columns = channels 32 t + el): g = W2 z + b2
-        f32x16 g;
-        const int c0 = 32 * t + el;
-        const float bias2 = sb2[c0];
+        ML_SUB(66);
+        // ---- GEMM 2, operands swapped (rows = pairs, columns = channels 32 t + el): g = W2 z + b2, for the two channel tiles
+#pragma unroll 1
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * tp + tt;
+          f32x16 g;
+          const float bias2 = sb2[32 * t + el];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[r] = bias2;
-        {
-          const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
-          f32x4 wq = *(const f32x4*)wbase;
+          for (int r = 0; r < 16; ++r) g[r] = bias2;
+          {
+            const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
+            f32x4 wq = *(const f32x4*)wbase;
 #pragma unroll
-          for (int ug = 0; ug < KB2; ++ug) {
-            const int c = ug >> 2, q = ug & 3;
-            f32x4 wn = wq;
-            if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
-            g = ML_MFMA(z[c][4 * q + 0], wq.x, g);
-            g = ML_MFMA(z[c][4 * q + 1], wq.y, g);
-            g = ML_MFMA(z[c][4 * q + 2], wq.z, g);
-            g = ML_MFMA(z[c][4 * q + 3], wq.w, g);
-            wq = wn;
+            for (int ug = 0; ug < KB2; ++ug) {
+              const int c = ug >> 2, q = ug & 3;
+              f32x4 wn = wq;
+              if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
+              g = ML_MFMA(z[c][4 * q + 0], wq.x, g);
+              g = ML_MFMA(z[c][4 * q + 1], wq.y, g);
+              g = ML_MFMA(z[c][4 * q + 2], wq.z, g);
+              g = ML_MFMA(z[c][4 * q + 3], wq.w, g);
+              wq = wn;
+            }
+          }
+          if (tt == 0) ML_SUB(67);
+          // raw filter outputs: row = pair, 128-byte row segments per half wave
+          float* gt = g_g + (size_t)pfirst * NF + 32 * t;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pr = ml_row(r, hi);
+            if (pr < nvalid) ml_st<float>(gt, (unsigned)((pr * NF + el) * 4), g[r]);
           }
         }
-        // raw filter outputs: row = pair, 128-byte row segments per half wave
-        float* gt = g_g + (size_t)pfirst * NF + 32 * t;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int pr = ml_row(r, hi);
-          if (pr < nvalid) ml_st<float>(gt, (unsigned)((pr * NF + el) * 4), g[r]);
-        }
+        ML_SUB(68);
       }
-      // first half of the f2out.0 weights of this wave's tile: requested now, used two barriers later
-      f32x4 av1a[8];
-      if (wv < NT) ml_dense_load8(av1a, P.o1_p, wv, lane, 0);
       ML_STAMP(2 + 5 * l);
       __syncthreads();   // h and (workgroup scope) the filter outputs are complete
       ML_STAMP(3 + 5 * l);
 
       // ================= phase B: y[a] = sum over the row of a;  thread = (channel, atom quarter)
-      ml_row_sums<16>(sY, sH, g_g, sP, sEb, sRow, na, tid >> 7, tid & 127);
+      ml_row_sums<8>(sY, sH, g_g, sEb, sRow, na, tid >> 7, tid & 127);
       __syncthreads();
       ML_STAMP(4 + 5 * l);
 
       // ================= phase C1: pre3 = y W3^T + b3 (saved), t = ssp(pre3); the other half saves h and stages weights
-      f32x4 av2a[8];
       if (wv < NT) {
         const int t = wv;
-        f32x4 av1b[8];
+        f32x4 av1a[8], av1b[8];
+        ml_dense_load8(av1a, P.o1_p, t, lane, 0);
         ml_dense_load8(av1b, P.o1_p, t, lane, 1);
-        ml_dense_load8(av2a, P.o2_p, t, lane, 0);     // first half of the f2out.1 weights for phase C2
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = P.o1_b[32 * t + ml_row(r, hi)];
@@ -443,7 +454,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       // ================= phase C2: x += t W4^T + b4
       if (wv < NT) {
         const int t = wv;
-        f32x4 av2b[8];
+        f32x4 av2a[8], av2b[8];
+        ml_dense_load8(av2a, P.o2_p, t, lane, 0);
         ml_dense_load8(av2b, P.o2_p, t, lane, 1);
         f32x16 acc;
 #pragma unroll
@@ -473,7 +485,7 @@ extern "C" void spk_schnet_mol_set_debug_buffer(void* p) { g_mol_dbg = (long lon
 
 static size_t mol_fwd_lds(int kpb) {
   return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
-         (ML_MAXEDGES + 36 + 4) * sizeof(int);
+         (2 * ML_MAXEDGES + 36 + 4) * sizeof(int);
 }
 
 // Shapes / lists the molecule-resident kernels cover (everything else runs the general driver of spk_schnet.hip).
@@ -486,6 +498,7 @@ bool spk_schnet_mol_eligible(const spk_schnet_t* m, const spk_graph_t* g, const 
   if (kpb < 1 || kpb > 4) return false;
   if (!(g->symmetric && g->sorted && g->half && g->rev && g->edge_pair && g->rowptr && g->n_half > 0)) return false;
   if (g->n_groups <= 0 || !g->grp_atom0 || !g->grp_pair0 || g->max_group_atoms > 32) return false;
+  if (g->max_group_pairs <= 0 || g->max_group_pairs > ML_MAXPAIRS) return false;
   if (g->n_half_dev) return false;       // a per-call compacted pair list is already in place
   // (skin lists, g->filter_pairs: pairs beyond the cutoff carry f_c = f_c' = 0 and contribute exactly zero here -- no compaction)
   return true;
@@ -587,8 +600,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
   float* sGy = sH + 32 * ML_LD;                       // dL/dy_l
   float* sGh = sGy + 32 * ML_LD;                      // dL/dh_l; before that the hidden gradient of f2out
   MolPair* sP = (MolPair*)(sGh + 32 * ML_LD);         // per pair: local atoms, d, f_c, f_c'
-  int* sEb = (int*)(sP + ML_MAXPAIRS);                // per directed edge: (local pair << 8) | local neighbour
-  int* sRow = sEb + ML_MAXEDGES;                      // [33]
+  int2* sEb = (int2*)(sP + ML_MAXPAIRS);              // per directed edge: ((local pair << 8) | local neighbour, f_c)
+  int* sRow = (int*)(sEb + ML_MAXEDGES);              // [33]
   int* sCnt = sRow + 36;                              // [4]
   float* sRb = (float*)(sCnt + 4);                    // [2][32] radial basis parameters
   float* sS = sRb + 64;                               // [ML_MAXPAIRS][2] per-pair geometry sums, all interactions
@@ -610,8 +623,6 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     __syncthreads();
 
     // ---- group set-up
-    f32x4 avA[8];                                    // first half of the weights of D1 of this wave (waves 0..3), requested a phase early
-    if (wv < NT) ml_dense_load8(avA, a.L[Ltop].o2_t, wv, lane, 0);
     for (int s = tid; s < 32 * 32; s += 512) {
       const int row = s >> 5, c4 = s & 31;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -620,9 +631,12 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       *(f32x4*)(sGh + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
       *(f32x4*)(sH + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int s = tid; s < ne; s += 512)
-      sEb[s] = ((ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0) << 8) | (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0);
     ml_pair_records(sP, a.half, a.rij, a.idx_i, a.idx_j, p0, np, a0, a.rb.cutoff, tid);
+    __syncthreads();
+    for (int s = tid; s < ne; s += 512) {
+      const int pl = ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0;
+      sEb[s] = make_int2((pl << 8) | (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0), __float_as_int(sP[pl].fc));
+    }
     for (int s = tid; s < 2 * np; s += 512) sS[s] = 0.f;
     if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
     ml_stage_packed<512, NF * NF / 4>(sW2, a.L[Ltop].w2, NF, KB2, tid);
@@ -639,12 +653,11 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       const bool last = (l == 0) && !a.gx0;     // nothing below consumes dL/dh_0: no row sums, no in2f transpose
 
       // ================= D1: gt = (gx W4) * ssp'(pre3);  the other half loads h_l
-      f32x4 avB[8];
       if (wv < NT) {
         const int t = wv;
-        f32x4 avA2[8];
+        f32x4 avA[8], avA2[8];
+        ml_dense_load8(avA, P.o2_t, t, lane, 0);
         ml_dense_load8(avA2, P.o2_t, t, lane, 1);
-        ml_dense_load8(avB, P.o1_t, t, lane, 0);      // first half of the weights of D2
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -674,7 +687,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       // ================= D2: gy = gt W3
       if (wv < NT) {
         const int t = wv;
-        f32x4 avB2[8];
+        f32x4 avB[8], avB2[8];
+        ml_dense_load8(avB, P.o1_t, t, lane, 0);
         ml_dense_load8(avB2, P.o1_t, t, lane, 1);
         f32x16 acc;
 #pragma unroll
@@ -699,7 +713,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         if (k >= nder) {
           // ---- gh[a][c] = sum over the row of a of gy[b][c] g[pair][c] f_c
           const int k2 = k - nder;
-          ml_row_sums<16>(sGh, sGy, g_g, sP, sEb, sRow, na, k2 >> 1, 64 * (k2 & 1) + lane);
+          ml_row_sums<12>(sGh, sGy, g_g, sEb, sRow, na, k2 >> 1, 64 * (k2 & 1) + lane);
           continue;
         }
         const int tile = k >> 1, tp = k & 1;
@@ -797,9 +811,6 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         s2 += __shfl_xor(s2, 32, 64);
         if (hi == 0 && valid) { atomicAdd(&sS[2 * pl], s1); atomicAdd(&sS[2 * pl + 1], s2); }
       }
-      // out of the queue: request the weights of the next Dense phase of this wave before waiting for the others
-      if (wv < NT && !last) ml_dense_load8(avB, P.in2f_t, wv, lane, 0);
-      if (wv < NT && l > 0) ml_dense_load8(avA, a.L[l - 1].o2_t, wv, lane, 0);
       ML_STAMP(35 + 6 * (Ltop - l));
       __syncthreads();
       ML_STAMP(36 + 6 * (Ltop - l));
@@ -808,7 +819,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       // ================= G: gx += gh W_in; the other half stages the filter weights of the next (lower) interaction
       if (wv < NT) {
         const int t = wv;
-        f32x4 avB2[8];
+        f32x4 avB[8], avB2[8];
+        ml_dense_load8(avB, P.in2f_t, t, lane, 0);
         ml_dense_load8(avB2, P.in2f_t, t, lane, 1);
         f32x16 acc;
 #pragma unroll
@@ -851,7 +863,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 
 static size_t mol_bwd_lds(int kpb) {
   return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64 + 2 * ML_MAXPAIRS) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
-         (ML_MAXEDGES + 36 + 4) * sizeof(int);
+         (2 * ML_MAXEDGES + 36 + 4) * sizeof(int);
 }
 
 template <int KPB>

@@ -92,7 +92,7 @@ struct Plan {
   Tensor idx_i, idx_j, rowptr, rev, half, edge_pair, grp_atom0, grp_pair0, grp_tile0;   // keep-alive + device data
   bool sorted = false, symmetric = false;
   int64_t n_atoms = 0, n_edges = 0, n_half = 0;
-  int32_t n_groups = 0, max_group_atoms = 0;
+  int32_t n_groups = 0, max_group_atoms = 0, max_group_pairs = 0;
   int64_t n_tiles_grouped = 0;
   int filter_pairs = -1;     // -1: undecided
   bool has_r = false;
@@ -117,6 +117,7 @@ struct Plan {
       g.n_groups = n_groups;
       g.max_group_atoms = max_group_atoms;
       g.n_tiles_grouped = n_tiles_grouped;
+      g.max_group_pairs = max_group_pairs;
     }
     g.filter_pairs = filter_pairs > 0 ? 1 : 0;
     g.edge_pair = edge_pair.defined() ? edge_pair.data_ptr<int32_t>() : nullptr;
@@ -163,6 +164,7 @@ void build_groups(Plan& p) {
   p.n_groups = (int32_t)atom0.size() - 1;
   p.max_group_atoms = (int32_t)at::diff(atom0_t).max().item<int64_t>();
   p.n_tiles_grouped = tile0[-1].item<int64_t>();
+  p.max_group_pairs = (int32_t)at::diff(pair0.to(at::kLong)).max().item<int64_t>();
 }
 
 // Cached plan of a neighbour list (spk_edge_plan: one 16-byte D2H per NEW list; never inside a graph capture --

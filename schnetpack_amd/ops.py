@@ -80,7 +80,8 @@ class EdgePlan:
                                   iptr(self.half, torch.int32) if self.half is not None else None, n_half,
                                   iptr(gp[0], torch.int32) if gp else None, iptr(gp[1], torch.int32) if gp else None,
                                   iptr(gp[2], torch.int32) if gp else None, n_groups, max_ga, n_tiles_g, 0, 0, None,
-                                  iptr(self.edge_pair, torch.int32) if self.edge_pair is not None else None)
+                                  iptr(self.edge_pair, torch.int32) if self.edge_pair is not None else None,
+                                  int(gp[5]) if gp else 0, 0)
 
     def graph(self):
         return ctypes.byref(self._graph)
@@ -138,7 +139,8 @@ def _block_diagonal_groups(idx_i, idx_j, half, n_atoms):
     tiles = (torch.diff(pair0.long()) + 31) // 32
     tile0 = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(tiles, 0)]).to(torch.int32)
     max_atoms = int(torch.diff(atom0_t).max())
-    return (atom0_t.to(torch.int32).contiguous(), pair0.contiguous(), tile0.contiguous(), max_atoms, int(tile0[-1]))
+    max_pairs = int(torch.diff(pair0.long()).max()) if pair0.numel() > 1 else 0
+    return (atom0_t.to(torch.int32).contiguous(), pair0.contiguous(), tile0.contiguous(), max_atoms, int(tile0[-1]), max_pairs)
 
 
 _PLAN_CACHE = collections.OrderedDict()

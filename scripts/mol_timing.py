@@ -9,7 +9,7 @@ torch.manual_seed(0)
 m = M.build_model("schnet").to(dev).eval()
 inp = M.batch_to_inputs(b, dev)
 L = _lib.lib()
-dbg = torch.zeros(64, dtype=torch.int64, device=dev)
+dbg = torch.zeros(128, dtype=torch.int64, device=dev)
 for rep in range(3):
     dbg.zero_()
     L.spk_schnet_mol_set_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
@@ -27,6 +27,12 @@ for base in (0, 32):
     for k in sorted(names):
         if k >= base and k < base + 32 and st[k]:
             print("  %-36s %8d  (+%d)" % (names[k], st[k] - st[base], st[k] - prev)); prev = st[k]
+sub = {64: "task start", 65: "rbf done", 66: "gemm1 + act done", 67: "gemm2 done", 68: "stores issued"}
+print("first filter task of wave 0:")
+prev = st[64]
+for k in sorted(sub):
+    if st[k]:
+        print("  %-36s %8d  (+%d)" % (sub[k], st[k] - st[64], st[k] - prev)); prev = st[k]
 _lib.profile_enable(True); _lib.profile_report()
 for _ in range(20):
     m(dict(inp))
