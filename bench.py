@@ -419,11 +419,15 @@ def main():
     # layers per interaction; executed = pair-shared filters, GEMM 1 repeated per channel tile, atom rows padded to 32
     flop_dense = 2.0 * N * 3 * F * F
     n_mol = int(batch["n_mol"])
-    exec_mol = n_int * (4096.0 * ((E // 2 + 31 * n_mol) // 32) * 4 * (4 * ((n_rbf + 7) // 8) + 64) + 4096.0 * n_mol * 3 * 4 * 64)
+    # per pair tile of 32 undirected pairs: hidden layer once (4 x 4 KPB MFMAs), GEMM 2 (4 x 64), incidence accumulation (4 x 32);
+    # per molecule and interaction three Dense layers on a 32-row tile (3 x 4 x 64); one MFMA = 4096 FLOP
+    tiles_mol = (E // 2 + 31 * n_mol) // 32
+    exec_mol = n_int * 4096.0 * (tiles_mol * 4 * (4 * ((n_rbf + 7) // 8) + 64 + 32) + n_mol * 3 * 4 * 64)
+    exec_mol_bwd = n_int * 4096.0 * (tiles_mol * 2 * (8 * ((n_rbf + 7) // 8) + 128) + n_mol * 3 * 4 * 64)
     algo = {
         "schnet_mol_fwd": ("mfma", n_int * (flop_fwd + flop_dense), exec_mol / (n_int * (flop_fwd + flop_dense))),
         # backward: value + derivative through the filter MLP (2x the forward figure, section 8(d)) + the three transposed Dense layers
-        "schnet_mol_bwd": ("mfma", n_int * (2 * flop_fwd + flop_dense), 1.0),
+        "schnet_mol_bwd": ("mfma", n_int * (2 * flop_fwd + flop_dense), exec_mol_bwd / (n_int * (2 * flop_fwd + flop_dense))),
         "cfconv_fwd_mfma": ("mfma", flop_fwd, 1.0), "cfconv_fwd_simple": ("mfma", flop_fwd, 1.0),
         "cfconv_fwd_pair": ("mfma", flop_fwd, 0.5),
         "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd, 1.0), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd, 1.0),

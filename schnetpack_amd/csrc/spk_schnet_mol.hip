@@ -252,26 +252,48 @@ __device__ __forceinline__ f32x16 ml_dense_tile(const float* __restrict__ wp, co
   return acc;
 }
 
+// B operand of a Dense half-tile that is the SUM of two LDS tiles (the two teams' partial cfconv outputs)
+__device__ __forceinline__ f32x16 ml_dense_mma8_sum(const f32x4 (&av)[8], const float* __restrict__ sIn0, const float* __restrict__ sIn1, int lane, int half,
+                                                    f32x16 acc) {
+  const int hi = lane >> 5, el = lane & 31;
+  const int off = el * ML_LD + 4 * hi + 64 * half;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const f32x4 b0 = *(const f32x4*)(sIn0 + off + 8 * u), b1 = *(const f32x4*)(sIn1 + off + 8 * u);
+    acc = ML_MFMA(av[u].x, b0.x + b1.x, acc);
+    acc = ML_MFMA(av[u].y, b0.y + b1.y, acc);
+    acc = ML_MFMA(av[u].z, b0.z + b1.z, acc);
+    acc = ML_MFMA(av[u].w, b0.w + b1.w, acc);
+  }
+  return acc;
+}
+
+// Forward, third form.  The 8 waves are two TEAMS of four (one wave per SIMD each); wave t of a team owns channel tile t.
+// Per pair tile the team computes the hidden layer ONCE -- wave t its 32 hidden channels (12 MFMAs + 16 softplus per lane
+// instead of 48 + 64) -- and shares it through one LDS tile; every wave then runs GEMM 2 for its channel tile with the
+// hidden activations as A operand from LDS, writes the raw filter outputs (the tensor the backward reads), and accumulates
+//     y[a, c] += sum_pairs ( [i = a] h[j, c] + [j = a] h[i, c] ) W[pair, c]
+// ON THE MATRIX CORE: A = the 0/1 incidence of the pair tile (rows = atoms), B = the modulated products (rows = pairs,
+// columns = channels), 32 MFMAs per tile and wave, accumulator = 16 registers that live across all tiles of the wave.
+// No atomics, no re-read of the filters, no scatter pass; team 1 runs in2f while team 0 starts the first tile.
 template <int KPB>
 __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
-  constexpr int NF = 128, NT = 4, KB2 = 16;
+  constexpr int NF = 128, KB2 = 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sW2 = smem;                                  // NF*NF
   float* sW1 = sW2 + NF * NF;                         // NF*KPB*8
   float* sb1 = sW1 + NF * KPB * 8;                    // NF
   float* sb2 = sb1 + NF;                              // NF
   float* sX = sb2 + NF;                               // [32][ML_LD] atom features x_l
-  float* sH = sX + 32 * ML_LD;                        // h = in2f(x)
-  float* sY = sH + 32 * ML_LD;                        // y = cfconv output
-  float* sT = sY + 32 * ML_LD;                        // hidden layer of f2out
+  float* sH = sX + 32 * ML_LD;                        // h = in2f(x); later the hidden layer of f2out
+  float* sY = sH + 32 * ML_LD;                        // team 0: hidden activations of its pair tile, then its partial y
+  float* sT = sY + 32 * ML_LD;                        // team 1: the same
   MolPair* sP = (MolPair*)(sT + 32 * ML_LD);          // per pair: local atoms, d, f_c, f_c'
-  int2* sEb = (int2*)(sP + ML_MAXPAIRS);              // per directed edge: ((local pair << 8) | local neighbour, f_c)
-  int* sRow = (int*)(sEb + ML_MAXEDGES);              // [33] local CSR
-  int* sCnt = sRow + 36;                              // [4]
-  float* sRb = (float*)(sCnt + 4);                    // [2][32] radial basis parameters
+  float* sRb = (float*)(sP + ML_MAXPAIRS);            // [2][32] radial basis parameters
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wv: SGPR
   const int hi = lane >> 5, el = lane & 31;
+  const int team = wv >> 2, t = wv & 3;
   if (tid < 64) {
     const int k = tid & 31;
     const float* src = (tid < 32) ? a.rb.p0 : a.rb.p1;
@@ -281,26 +303,18 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
   for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
     const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
     const int p0 = a.grp_pair0[grp], np = a.grp_pair0[grp + 1] - p0;
-    const int e0 = a.rowptr[a0], ne = a.rowptr[a0 + na] - e0;
     const int ntile = (np + 31) / 32;
     __syncthreads();   // the previous group is done with every LDS buffer
     ML_STAMP(0);
 
-    // ---- group set-up: features, local CSR, pair geometry (shared by all interactions), first filter weights
+    // ---- group set-up: features, pair geometry (shared by all interactions), first filter weights
     for (int s = tid; s < 32 * 32; s += 512) {
       const int row = s >> 5, c4 = s & 31;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < na) v = ml_ld<f32x4>(a.x0 + (size_t)a0 * NF, (unsigned)(s * 16));
       *(f32x4*)(sX + row * ML_LD + 4 * c4) = v;
-      *(f32x4*)(sY + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     ml_pair_records(sP, a.half, a.rij, a.idx_i, a.idx_j, p0, np, a0, a.rb.cutoff, tid);
-    __syncthreads();
-    for (int s = tid; s < ne; s += 512) {
-      const int pl = ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0;
-      sEb[s] = make_int2((pl << 8) | (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0), __float_as_int(sP[pl].fc));
-    }
-    if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
     ml_stage_packed<512, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
     ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[0].w1, a.rb.n_rbf, KPB, tid);
     if (tid < NF) { sb1[tid] = a.L[0].b1[tid]; sb2[tid] = a.L[0].b2[tid]; }
@@ -310,158 +324,147 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       float* h_g = a.saved + (int64_t)l * a.N * (2 * NF);
       float* pre3_g = h_g + a.N * (int64_t)NF;
       float* g_g = a.gbase + (int64_t)l * a.gsz + (int64_t)p0 * NF;
-      if (tid == 0) sCnt[0] = 0;
       __syncthreads();
       ML_STAMP(1 + 5 * l);
 
-      // ================= phase A: filter tasks (pair tile, channel tile) + in2f tasks, dynamic queue.  No global loads
-      // except the in2f weights: geometry and radial parameters come from LDS.
-      const int nfilt = 2 * ntile;
-      while (true) {
-        int k = 0;
-        if (lane == 0) k = atomicAdd(&sCnt[0], 1);
-        k = __builtin_amdgcn_readfirstlane(k);
-        if (k >= nfilt + NT) break;
-        if (k >= nfilt) {
-          // ---- in2f: h[:, 32t : 32t+32] = x W_in^T
-          const int t = k - nfilt;
+      // ================= phase A: pair tiles, team 0 takes tiles 0, 2, 4, ..., team 1 in2f and then tiles 1, 3, ...
+      float* zbuf = team ? sT : sY;
+      f32x16 yacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yacc[r] = 0.f;
+      const int n0 = (ntile + 1) / 2, n1 = 1 + ntile / 2;
+      const int n_iter = n0 > n1 ? n0 : n1;
+      for (int it = 0; it < n_iter; ++it) {
+        const int tile = team == 0 ? 2 * it : 2 * it - 1;
+        const bool in2f = (team == 1 && it == 0);
+        const bool active = !in2f && tile < ntile;
+        const int pfirst = 32 * tile;
+        const int nvalid = active ? ((np - pfirst) < 32 ? (np - pfirst) : 32) : 0;
+        if (in2f) {
+          // ---- h[:, 32t : 32t+32] = x W_in^T  (kept in LDS for the modulation, saved for the backward)
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
           acc = ml_dense_tile(P.in2f_p, sX, t, lane, acc);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *(f32x4*)(sH + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-          continue;
-        }
-        const int tile = k >> 1, tp = k & 1;       // (pair tile, pair of channel tiles): GEMM 1 + activation once per two GEMM 2
-        const bool st0 = (l == 0 && k == 0);
-#define ML_SUB(n) do { if (st0 && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
-        ML_SUB(64);
-        const int pfirst = 32 * tile;
-        const int nvalid = (np - pfirst) < 32 ? (np - pfirst) : 32;
-        const float d = sP[pfirst + (el < nvalid ? el : (nvalid - 1))].d;      // lanes 32..63 mirror lanes 0..31
-        float phi[KPB][4];
-#pragma unroll
-        for (int u = 0; u < KPB; ++u)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            float dp;
-            ml_rbf(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, 8 * u + 4 * hi + v, d, phi[u][v], dp);
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 hv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *(f32x4*)(sH + el * ML_LD + 32 * t + 8 * q + 4 * hi) = hv;
+            if (el < na) ml_st<f32x4>(h_g + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4), hv);
           }
-        ML_SUB(65);
-        // ---- GEMM 1 (rows = hidden channels, columns = pairs): z = ssp(W1 phi + b1)
-        f32x16 z[NT];
-        {
-          f32x4 wq = *(const f32x4*)(sW1 + lane * 4);
+        } else if (active) {
+          // ---- this wave's quarter of the hidden layer: z[pairs][32t : 32t+32] = ssp(W1 phi + b1)
+          const float d = sP[pfirst + (el < nvalid ? el : (nvalid - 1))].d;      // lanes 32..63 mirror lanes 0..31
+          f32x16 zc;
 #pragma unroll
-          for (int c = 0; c < NT; ++c) {
-            f32x16 zc;
+          for (int r = 0; r < 16; ++r) zc[r] = sb1[32 * t + ml_row(r, hi)];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zc[r] = sb1[32 * c + ml_row(r, hi)];
+          for (int u = 0; u < KPB; ++u) {
+            const f32x4 wq = *(const f32x4*)(sW1 + ((t * KPB + u) * 64 + lane) * 4);
+            float ph[4];
 #pragma unroll
-            for (int u = 0; u < KPB; ++u) {
-              const int nxt = c * KPB + u + 1;
-              f32x4 wn = wq;
-              if (nxt < NT * KPB) wn = *(const f32x4*)(sW1 + (nxt * 64 + lane) * 4);
-              zc = ML_MFMA(wq.x, phi[u][0], zc);
-              zc = ML_MFMA(wq.y, phi[u][1], zc);
-              zc = ML_MFMA(wq.z, phi[u][2], zc);
-              zc = ML_MFMA(wq.w, phi[u][3], zc);
-              wq = wn;
+            for (int v = 0; v < 4; ++v) {
+              float dp;
+              ml_rbf(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, 8 * u + 4 * hi + v, d, ph[v], dp);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zc[r] = spk_fast_ssp(zc[r]);
-            z[c] = zc;
+            zc = ML_MFMA(wq.x, ph[0], zc);
+            zc = ML_MFMA(wq.y, ph[1], zc);
+            zc = ML_MFMA(wq.z, ph[2], zc);
+            zc = ML_MFMA(wq.w, ph[3], zc);
           }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *(f32x4*)(zbuf + el * ML_LD + 32 * t + 8 * q + 4 * hi) =
+                f32x4{spk_fast_ssp(zc[4 * q]), spk_fast_ssp(zc[4 * q + 1]), spk_fast_ssp(zc[4 * q + 2]), spk_fast_ssp(zc[4 * q + 3])};
         }
-        ML_SUB(66);
-        // ---- GEMM 2, operands swapped (rows = pairs, columns = channels 32 t + el): g = W2 z + b2, for the two channel tiles
-#pragma unroll 1
-        for (int tt = 0; tt < 2; ++tt) {
-          const int t = 2 * tp + tt;
+        __syncthreads();     // the team's hidden tile (and, in the first round, h) is complete
+        if (active) {
+          // ---- GEMM 2, operands swapped (rows = pairs, columns = channels 32 t + el): g = W2 z + b2, A operand from LDS
           f32x16 g;
-          const float bias2 = sb2[32 * t + el];
+          const int c0 = 32 * t + el;
+          const float bias2 = sb2[c0];
 #pragma unroll
           for (int r = 0; r < 16; ++r) g[r] = bias2;
           {
             const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
+            const float* zrow = zbuf + el * ML_LD + 4 * hi;
             f32x4 wq = *(const f32x4*)wbase;
+            f32x4 zq = *(const f32x4*)zrow;
 #pragma unroll
             for (int ug = 0; ug < KB2; ++ug) {
-              const int c = ug >> 2, q = ug & 3;
-              f32x4 wn = wq;
-              if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
-              g = ML_MFMA(z[c][4 * q + 0], wq.x, g);
-              g = ML_MFMA(z[c][4 * q + 1], wq.y, g);
-              g = ML_MFMA(z[c][4 * q + 2], wq.z, g);
-              g = ML_MFMA(z[c][4 * q + 3], wq.w, g);
-              wq = wn;
+              f32x4 wn = wq, zn = zq;
+              if (ug + 1 < KB2) { wn = *(const f32x4*)(wbase + (ug + 1) * 256); zn = *(const f32x4*)(zrow + 8 * (ug + 1)); }
+              g = ML_MFMA(zq.x, wq.x, g);
+              g = ML_MFMA(zq.y, wq.y, g);
+              g = ML_MFMA(zq.z, wq.z, g);
+              g = ML_MFMA(zq.w, wq.w, g);
+              wq = wn; zq = zn;
             }
           }
-          if (tt == 0) ML_SUB(67);
-          // raw filter outputs: row = pair, 128-byte row segments per half wave
+          // raw filter outputs for the backward: row = pair, 128-byte row segments per half wave
           float* gt = g_g + (size_t)pfirst * NF + 32 * t;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int pr = ml_row(r, hi);
             if (pr < nvalid) ml_st<float>(gt, (unsigned)((pr * NF + el) * 4), g[r]);
           }
+          // ---- modulation + accumulation on the matrix core: y[atom][c0] += [i = atom] W h[j][c0] + [j = atom] W h[i][c0]
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pr = ml_row(r, hi);
+            const bool ok = pr < nvalid;
+            const MolPair rec = sP[pfirst + (ok ? pr : 0)];
+            const int pi = rec.ij & 255, pj = rec.ij >> 8;
+            const float W = ok ? g[r] * rec.fc : 0.f;
+            const float tI = W * sH[pj * ML_LD + c0], tJ = W * sH[pi * ML_LD + c0];
+            yacc = ML_MFMA(pi == el ? 1.0f : 0.0f, tI, yacc);
+            yacc = ML_MFMA(pj == el ? 1.0f : 0.0f, tJ, yacc);
+          }
         }
-        ML_SUB(68);
+        __syncthreads();     // every wave of the team is done with the hidden tile
       }
       ML_STAMP(2 + 5 * l);
-      __syncthreads();   // h and (workgroup scope) the filter outputs are complete
-      ML_STAMP(3 + 5 * l);
-
-      // ================= phase B: y[a] = sum over the row of a;  thread = (channel, atom quarter)
-      ml_row_sums<8>(sY, sH, g_g, sEb, sRow, na, tid >> 7, tid & 127);
+      // the two teams' partial sums: rows = atoms ml_row(r, hi), columns = channels 32 t + el
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zbuf[ml_row(r, hi) * ML_LD + 32 * t + el] = yacc[r];
       __syncthreads();
       ML_STAMP(4 + 5 * l);
 
-      // ================= phase C1: pre3 = y W3^T + b3 (saved), t = ssp(pre3); the other half saves h and stages weights
-      if (wv < NT) {
-        const int t = wv;
-        f32x4 av1a[8], av1b[8];
-        ml_dense_load8(av1a, P.o1_p, t, lane, 0);
-        ml_dense_load8(av1b, P.o1_p, t, lane, 1);
+      // ================= phase C1: pre3 = (y0 + y1) W3^T + b3 (saved), hidden = ssp(pre3) -> sH; the other team stages weights
+      if (team == 0) {
+        f32x4 avA[8], avB[8];
+        ml_dense_load8(avA, P.o1_p, t, lane, 0);
+        ml_dense_load8(avB, P.o1_p, t, lane, 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = P.o1_b[32 * t + ml_row(r, hi)];
-        acc = ml_dense_mma8(av1a, sY, lane, 0, acc);
-        acc = ml_dense_mma8(av1b, sY, lane, 1, acc);
+        acc = ml_dense_mma8_sum(avA, sY, sT, lane, 0, acc);
+        acc = ml_dense_mma8_sum(avB, sY, sT, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
           if (el < na) ml_st<f32x4>(pre3_g + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4), pv);
-          *(f32x4*)(sT + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{spk_fast_ssp(pv.x), spk_fast_ssp(pv.y), spk_fast_ssp(pv.z), spk_fast_ssp(pv.w)};
+          *(f32x4*)(sH + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{spk_fast_ssp(pv.x), spk_fast_ssp(pv.y), spk_fast_ssp(pv.z), spk_fast_ssp(pv.w)};
         }
-      } else {
+      } else if (l + 1 < a.n_layers) {     // the filter GEMMs of this interaction are done: their LDS images can be replaced
         const int t2 = tid - 256;
-        for (int s = t2; s < na * 32; s += 256) {
-          const int row = s >> 5, c4 = s & 31;
-          ml_st<f32x4>(h_g + (size_t)a0 * NF, (unsigned)(s * 16), *(const f32x4*)(sH + row * ML_LD + 4 * c4));
-        }
-        if (l + 1 < a.n_layers) {     // the filter GEMMs of this interaction are done: their LDS images can be replaced
-          ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l + 1].w2, NF, KB2, t2);
-          ml_stage_packed<256, NF * KPB * 2>(sW1, a.L[l + 1].w1, a.rb.n_rbf, KPB, t2);
-          if (t2 < NF) { sb1[t2] = a.L[l + 1].b1[t2]; sb2[t2] = a.L[l + 1].b2[t2]; }
-        }
+        ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l + 1].w2, NF, KB2, t2);
+        ml_stage_packed<256, NF * KPB * 2>(sW1, a.L[l + 1].w1, a.rb.n_rbf, KPB, t2);
+        if (t2 < NF) { sb1[t2] = a.L[l + 1].b1[t2]; sb2[t2] = a.L[l + 1].b2[t2]; }
       }
       __syncthreads();
       ML_STAMP(5 + 5 * l);
 
-      // ================= phase C2: x += t W4^T + b4
-      if (wv < NT) {
-        const int t = wv;
-        f32x4 av2a[8], av2b[8];
-        ml_dense_load8(av2a, P.o2_p, t, lane, 0);
-        ml_dense_load8(av2b, P.o2_p, t, lane, 1);
+      // ================= phase C2: x += hidden W4^T + b4
+      if (team == 0) {
+        f32x4 avA[8], avB[8];
+        ml_dense_load8(avA, P.o2_p, t, lane, 0);
+        ml_dense_load8(avB, P.o2_p, t, lane, 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = P.o2_b[32 * t + ml_row(r, hi)];
-        acc = ml_dense_mma8(av2a, sT, lane, 0, acc);
-        acc = ml_dense_mma8(av2b, sT, lane, 1, acc);
+        acc = ml_dense_mma8(avA, sH, lane, 0, acc);
+        acc = ml_dense_mma8(avB, sH, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float* xp = sX + el * ML_LD + 32 * t + 8 * q + 4 * hi;
@@ -484,8 +487,7 @@ static long long* g_mol_dbg = nullptr;
 extern "C" void spk_schnet_mol_set_debug_buffer(void* p) { g_mol_dbg = (long long*)p; }
 
 static size_t mol_fwd_lds(int kpb) {
-  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
-         (2 * ML_MAXEDGES + 36 + 4) * sizeof(int);
+  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair);
 }
 
 // Shapes / lists the molecule-resident kernels cover (everything else runs the general driver of spk_schnet.hip).
@@ -655,9 +657,9 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       // ================= D1: gt = (gx W4) * ssp'(pre3);  the other half loads h_l
       if (wv < NT) {
         const int t = wv;
-        f32x4 avA[8], avA2[8];
+        f32x4 avA[8], avB[8];
         ml_dense_load8(avA, P.o2_t, t, lane, 0);
-        ml_dense_load8(avA2, P.o2_t, t, lane, 1);
+        ml_dense_load8(avB, P.o2_t, t, lane, 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           if (el < na) pv[q] = ml_ld<f32x4>(pre3_g + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4));
         }
         acc = ml_dense_mma8(avA, sGx, lane, 0, acc);
-        acc = ml_dense_mma8(avA2, sGx, lane, 1, acc);
+        acc = ml_dense_mma8(avB, sGx, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(sGh + el * ML_LD + 32 * t + 8 * q + 4 * hi) =
@@ -687,14 +689,14 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       // ================= D2: gy = gt W3
       if (wv < NT) {
         const int t = wv;
-        f32x4 avB[8], avB2[8];
-        ml_dense_load8(avB, P.o1_t, t, lane, 0);
-        ml_dense_load8(avB2, P.o1_t, t, lane, 1);
+        f32x4 avA[8], avB[8];
+        ml_dense_load8(avA, P.o1_t, t, lane, 0);
+        ml_dense_load8(avB, P.o1_t, t, lane, 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = ml_dense_mma8(avB, sGh, lane, 0, acc);
-        acc = ml_dense_mma8(avB2, sGh, lane, 1, acc);
+        acc = ml_dense_mma8(avA, sGh, lane, 0, acc);
+        acc = ml_dense_mma8(avB, sGh, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(sGy + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -819,14 +821,14 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       // ================= G: gx += gh W_in; the other half stages the filter weights of the next (lower) interaction
       if (wv < NT) {
         const int t = wv;
-        f32x4 avB[8], avB2[8];
-        ml_dense_load8(avB, P.in2f_t, t, lane, 0);
-        ml_dense_load8(avB2, P.in2f_t, t, lane, 1);
+        f32x4 avA[8], avB[8];
+        ml_dense_load8(avA, P.in2f_t, t, lane, 0);
+        ml_dense_load8(avB, P.in2f_t, t, lane, 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = ml_dense_mma8(avB, sGh, lane, 0, acc);
-        acc = ml_dense_mma8(avB2, sGh, lane, 1, acc);
+        acc = ml_dense_mma8(avA, sGh, lane, 0, acc);
+        acc = ml_dense_mma8(avB, sGh, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float* xp = sGx + el * ML_LD + 32 * t + 8 * q + 4 * hi;

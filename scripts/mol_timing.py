@@ -19,7 +19,7 @@ L.spk_schnet_mol_set_debug_buffer(None)
 st = dbg.cpu().tolist()
 names = {0: "fwd start", 31: "fwd end", 32: "bwd start", 63: "bwd end"}
 for l in range(3):
-    names.update({1 + 5 * l: "L%d staged" % l, 2 + 5 * l: "L%d A (thread 0 out of the queue)" % l, 3 + 5 * l: "L%d A barrier" % l, 4 + 5 * l: "L%d B done" % l, 5 + 5 * l: "L%d C1 done" % l})
+    names.update({1 + 5 * l: "L%d staged" % l, 2 + 5 * l: "L%d pair tiles done" % l, 4 + 5 * l: "L%d partial sums in LDS" % l, 5 + 5 * l: "L%d C1 done" % l})
     names.update({33 + 6 * l: "bwd L%d D1 done" % (2 - l), 34 + 6 * l: "bwd L%d D2 done" % (2 - l), 35 + 6 * l: "bwd L%d E (thread 0 out)" % (2 - l),
                   36 + 6 * l: "bwd L%d E barrier" % (2 - l), 37 + 6 * l: "bwd L%d G done" % (2 - l)})
 for base in (0, 32):
