@@ -191,6 +191,18 @@ int spk_md_ring_polymer_step_f32(const float* q_all, const float* p_all, const f
                                  int32_t n_local, float* q_out, float* p_out, const float* R_ref,
                                  float max_disp2, int32_t* flag, void* stream);
 
+/* PILE-L thermostat of ring-polymer MD (md/simulation_hooks/thermostats_rpmd.py:33-119), applied at the begin and the end of
+ * a step (md/simulation_hooks/thermostats.py:97-123): in normal modes p_nm' = c1_k p_nm + sqrt(m kB n_beads T) c2_k xi.  Folded
+ * into bead space:  p_out[b] = sum_b' M[0][b][b'] p_all[b'] + sqrt(m) noise_scale sum_k M[1][b][k] xi_k  for the beads
+ * [bead0, bead0 + n_local) of this rank; M [2, n_beads, n_beads] = (C^T diag(c1) C, C^T diag(c2)), noise_scale =
+ * sqrt(kB n_beads T).  xi_k ~ N(0, 1) comes from a counter-based generator (Philox-4x32-10, key = seed, counter = (atom
+ * component, mode pair, step, which)): it is a function of the counter alone, so bead-parallel ranks agree on it without an
+ * exchange.  step: host value, or read from the device word step_dev when that is not NULL (HIP-graph replays);
+ * which = 0 / 1 for the application at step begin / end.  n_beads <= 64. */
+int spk_md_pile_f32(const float* p_all, const float* masses, const float* M, float noise_scale, uint64_t seed,
+                    uint64_t step, const int64_t* step_dev, int32_t which, int32_t n_beads, int64_t n_atoms,
+                    int32_t bead0, int32_t n_local, float* p_out, void* stream);
+
 /* ------------------------------------------------------------------ atomistic/atomwise.py:69-88
  * The default output head, build_mlp(n_in, 1, n_layers=2) (nn/blocks.py:38-57) + sum over idx_m:
  *   y_n = w2 . act(W1 x_n + b1) + b2,   E[idx_m[n]] += y_n           (E [n_mol] is overwritten)

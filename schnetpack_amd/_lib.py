@@ -92,6 +92,7 @@ _PROTOS = {
     "spk_md_half_step_f32": (ctypes.c_int, [c_f, c_f, ctypes.c_float, c_i64, c_f]),
     "spk_md_kick_drift_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, ctypes.c_float, c_i64, c_f, ctypes.c_float, c_f, c_f]),
     "spk_md_ring_polymer_step_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i32, c_i64, c_i32, c_i32, c_f, c_f, c_f, ctypes.c_float, c_f, c_f]),
+    "spk_md_pile_f32": (ctypes.c_int, [c_f, c_f, c_f, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, c_f, c_i32, c_i32, c_i64, c_i32, c_i32, c_f, c_f]),
     "spk_pack_weight_f32": (ctypes.c_int, [c_f, c_i32, c_i32, c_i32, c_f, c_f]),
     "spk_schnet_packed_floats": (c_i64, [P(SchnetT)]),
     "spk_schnet_pack_weights_f32": (ctypes.c_int, [P(SchnetT), c_f, c_f]),

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import check, fptr, lib, stream
 
-__all__ = ["VelocityVerlet", "RingPolymer", "NVESimulation", "RPMDSimulation", "MDState", "normal_mode_matrix", "ring_polymer_propagator", "ring_polymer_matrices",
+__all__ = ["PILELocalThermostat", "pile_matrices", "VelocityVerlet", "RingPolymer", "NVESimulation", "RPMDSimulation", "MDState", "normal_mode_matrix", "ring_polymer_propagator", "ring_polymer_matrices",
            "KB_MD", "HBAR_MD", "FS_MD"]
 
 # reference MD internal units (kJ/mol, nm, Dalton): time unit = 1 ps (units.py:10-40)
@@ -168,6 +168,83 @@ def _ring_polymer_hip(q_all, p_all, masses, A, bead0, n_local, q_out=None, p_out
                                                  fptr(q_out), fptr(p_out), fptr(reference_positions), float(max_displacement) ** 2,
                                                  _lib.iptr(flag, torch.int32) if flag is not None else None, stream()))
     return q_out, p_out
+
+
+def pile_matrices(n_beads: int, omega: float, time_step: float, time_constant: float, thermostat_centroid: bool = True,
+                  damping_factor: float = 1.0) -> torch.Tensor:
+    """M [2, B, B] = (C^T diag(c1) C, C^T diag(c2)) of the PILE-L thermostat (md/simulation_hooks/thermostats_rpmd.py:66-92):
+    gamma_k = 2 omega_k (centroid: 1 / time_constant) x damping factor, c1 = exp(-dt/2 gamma), c2 = sqrt(1 - c1^2); the
+    transform to normal modes, the scaling and the back-transform folded into bead-space matrices (float64 -> float32)."""
+    C = normal_mode_matrix(n_beads)
+    on = 2.0 * omega * torch.sin(torch.arange(n_beads).float() * math.pi / n_beads)
+    gamma = 2.0 * on.double()
+    if thermostat_centroid:
+        gamma[0] = 1.0 / time_constant
+    gamma = gamma * damping_factor
+    c1 = torch.exp(-0.5 * time_step * gamma)
+    c2 = torch.sqrt(1.0 - c1 ** 2)
+    return torch.stack([C.t() @ torch.diag(c1) @ C, C.t() @ torch.diag(c2)]).float().contiguous()
+
+
+def _pile_hip(p_all, masses, M, noise_scale, seed, step, step_dev, which, bead0, n_local, p_out=None):
+    B, n_atoms = int(p_all.shape[0]), int(p_all.shape[1])
+    m = _flat_masses(masses, n_atoms).to(p_all.device)
+    if p_out is None:
+        p_out = torch.empty((n_local, n_atoms, 3), dtype=torch.float32, device=p_all.device)
+    with torch.cuda.device(p_all.device):
+        check(lib().spk_md_pile_f32(fptr(p_all), fptr(m), fptr(M), float(noise_scale), int(seed), int(step),
+                                    _lib.iptr(step_dev) if step_dev is not None else None, int(which), B, n_atoms, int(bead0), int(n_local),
+                                    fptr(p_out), stream()))
+    return p_out
+
+
+class PILELocalThermostat:
+    """Mirror of the reference's ``PILELocalThermostat`` (md/simulation_hooks/thermostats_rpmd.py:33-119; constructor
+    arguments and the two application points of md/simulation_hooks/thermostats.py:97-123) for the device ring polymer:
+    ``apply(state, step, which)`` replaces the momenta by ``C^T (c1 C p + sqrt(m kB n T) c2 xi)``.
+
+    Bead-parallel (``group``): ONE all-gather of the momenta per application; the noise is a counter-based stream
+    (Philox keyed by seed / step / atom / mode, ``spk_md_pile_f32``) that every rank regenerates identically, so there is
+    no second exchange and the trajectory does not depend on the number of ranks.  ``step_dev`` (a device int64 word the
+    caller increments inside its captured step) makes replays of a HIP graph draw fresh noise."""
+
+    ring_polymer = True
+
+    def __init__(self, temperature_bath: float, time_constant: float, thermostat_centroid: bool = True, damping_factor: float = 1.0,
+                 seed: int = 0, group=None, compute_fn=None):
+        self.temperature_bath, self.time_constant = float(temperature_bath), float(time_constant)
+        self.thermostat_centroid, self.damping_factor = bool(thermostat_centroid), float(damping_factor)
+        self.seed, self.group = int(seed), group
+        self._compute = compute_fn or _pile_hip
+        self.M = None
+        self._M_dev = None
+
+    def init(self, integrator: RingPolymer):
+        """``_init_thermostat``: coefficients from the normal-mode frequencies of the integrator."""
+        self.n_beads = integrator.n_beads
+        self.M = pile_matrices(self.n_beads, integrator.omega, integrator.time_step, self.time_constant, self.thermostat_centroid,
+                               self.damping_factor)
+        self.noise_scale = math.sqrt(KB_MD * self.n_beads * self.temperature_bath)
+        self._range = integrator._bead_range if self.group is None else RingPolymer(integrator.time_step, self.n_beads, 1.0, omega=1.0,
+                                                                                    group=self.group)._bead_range
+        return self
+
+    def apply(self, state, step: int = 0, which: int = 0, step_dev=None, out=None):
+        p = state.momenta
+        lo, hi, world = self._range()
+        n_local = hi - lo
+        if self._M_dev is None or self._M_dev.device != p.device:
+            self._M_dev = self.M.to(p.device)
+        if world > 1:
+            import torch.distributed as dist
+            local = p.contiguous()
+            allb = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(allb.view(-1), local.view(-1), group=self.group)
+            p_all = allb.reshape(self.n_beads, p.shape[1], 3)
+        else:
+            p_all = p.contiguous()
+        state.momenta = self._compute(p_all, state.masses, self._M_dev, self.noise_scale, self.seed, step, step_dev, which, lo, n_local, out)
+        return state.momenta
 
 
 class MDState:
@@ -331,8 +408,9 @@ class RPMDSimulation(NVESimulation):
     ``sum_b [p_b^2 / 2m + V(q_b)] + sum_b 1/2 m omega^2 |q_b - q_{b+1}|^2`` (``total_energy``)."""
 
     def __init__(self, model, inputs, masses, time_step, n_beads, cutoff, temperature=300.0, omega=None,
-                 cutoff_shell=1.0, use_graph=True):
+                 cutoff_shell=1.0, use_graph=True, thermostat: Optional["PILELocalThermostat"] = None):
         from . import properties as P
+        self.thermostat = thermostat
         self.n_beads = B = int(n_beads)
         N = int(inputs[P.R].shape[0])
         n_mol = int(inputs[P.n_atoms].shape[0])
@@ -356,10 +434,22 @@ class RPMDSimulation(NVESimulation):
         self._qt = torch.empty_like(self.state.positions)
         self._pt = torch.empty_like(self.state.positions)
         self._A = self._rp.A.to(R.device)
+        if self.thermostat is not None:          # NVT: PILE-L at step begin and end (md/simulator.py:126-150)
+            self.thermostat.init(self._rp)
+            self._M = self.thermostat.M.to(R.device)
+            self._stepc = torch.zeros(1, dtype=torch.int64, device=R.device)      # step counter on the device: fresh noise per graph replay
+
+    def _thermostat(self, which):
+        th, st = self.thermostat, self.state
+        _pile_hip(st.momenta, st.masses, self._M, th.noise_scale, th.seed, 0, self._stepc, which, 0, self.n_beads, self._pt)
+        with torch.no_grad():
+            st.momenta.copy_(self._pt)
 
     def _step_body(self):
         thr = max(0.5 * self.nl.cutoff_shell - self.margin, 0.0)
         st = self.state
+        if self.thermostat is not None:
+            self._thermostat(0)
         self.integrator.half_step(st)
         ref = self.nl.previous_positions
         _ring_polymer_hip(st.positions, st.momenta, st.masses, self._A, 0, self.n_beads, self._qt, self._pt,
@@ -369,6 +459,10 @@ class RPMDSimulation(NVESimulation):
             st.momenta.copy_(self._pt)
         self._force_eval()
         self.integrator.half_step(st)
+        if self.thermostat is not None:
+            self._thermostat(1)
+            with torch.no_grad():
+                self._stepc.add_(1)
 
     def spring_energy(self):
         q, m = self.state.positions, self.state.masses.reshape(1, -1, 1)

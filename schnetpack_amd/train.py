@@ -68,6 +68,7 @@ class GraphedTrainStep:
         self.reducer = FlatGradAllReduce(model.parameters(), as_views=True)
         self.opt = torch.optim.AdamW(model.parameters(), lr=lr, capturable=True)
         self.n_steps = 0
+        self._bad = None
         self.g_bwd = self.g_opt = None
 
     # ---------------------------------------------------------------- data
@@ -76,6 +77,14 @@ class GraphedTrainStep:
         if int(batch["Z"].shape[0]) != self.N:
             raise ValueError("batch has %d atoms, the step was built for %d" % (batch["Z"].shape[0], self.N))
         ii, jj, off = pad_edges(batch["idx_i"], batch["idx_j"], batch["offsets"].float(), self.N, self.Emax, self.cutoff)
+        # the refresh kernels validate the declared (sorted) indices only; neighbour indices and atomic numbers are checked
+        # here, asynchronously on whatever device the batch lives on (polled by check()): a malformed batch must not read or
+        # scatter out of bounds inside the replayed graph
+        n_emb = getattr(getattr(self.model.representation, "embedding", None), "num_embeddings", None)
+        bad = ((jj < 0) | (jj >= self.N)).any() | ((ii < 0) | (ii >= self.N)).any() | (batch["Z"] < 0).any()
+        if n_emb is not None:
+            bad = bad | (batch["Z"] >= n_emb).any()
+        self._bad = bad if self._bad is None else (self._bad.to(bad.device) | bad)
         with torch.no_grad():
             self.buf[properties.Z].copy_(batch["Z"], non_blocking=True)
             self.buf[properties.R].copy_(batch["R"].float(), non_blocking=True)
@@ -135,3 +144,6 @@ class GraphedTrainStep:
     def check(self):
         """Poll the device-side validity flag of the declared index tensors (one D2H)."""
         self.lists.check()
+        if self._bad is not None and bool(self._bad):
+            self._bad = None
+            raise torchops.SpkHipError("GraphedTrainStep: a loaded batch held a neighbour index or atomic number out of range")

@@ -175,3 +175,66 @@ def test_bead_parallel_ring_polymer_world2_equals_oracle():
     got_q = torch.cat([res[0][0], res[1][0]])
     got_p = torch.cat([res[0][1], res[1][1]])
     assert torch.allclose(got_q.double(), q2, atol=1e-5) and torch.allclose(got_p.double(), p2, atol=1e-4)
+
+
+def _pile_worker(rank, world, port, q):
+    """Bead-parallel PILE-L thermostat: 4 beads over 2 ranks, ONE all-gather of the momenta per application, the noise
+    regenerated on every rank from the counter alone (the compute function is the host restatement of the HIP kernel:
+    same Philox stream, same folded matrices)."""
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import md_oracle as MDO
+    from schnetpack_amd.md import MDState, PILELocalThermostat, RingPolymer
+    Q, P, M = _ring_problem()
+
+    def compute(p_all, masses, Mx, noise_scale, seed, step, step_dev, which, bead0, n_local, out=None):
+        B, n = p_all.shape[0], p_all.shape[1]
+        xi = MDO.pile_noise(B, n, seed, step, which)
+        det = torch.einsum("bn,nak->bak", Mx[0].double(), p_all.double())
+        noi = torch.einsum("bk,kat->bat", Mx[1].double(), xi)
+        res = det + torch.sqrt(masses.reshape(1, -1, 1).double()) * noise_scale * noi
+        return res[bead0:bead0 + n_local].float()
+
+    rp = RingPolymer(5e-4, 4, 300.0, omega=55.0, group=dist.group.WORLD, compute_fn=lambda *a, **k: None)
+    th = PILELocalThermostat(300.0, 0.1, seed=99, group=dist.group.WORLD, compute_fn=compute).init(rp)
+    lo, hi = 2 * rank, 2 * rank + 2
+    st = MDState(Q[lo:hi].clone(), P[lo:hi].clone(), M)
+    th.apply(st, step=5, which=0)
+    th.apply(st, step=5, which=1)
+    q.put((rank, st.momenta.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bead_parallel_pile_thermostat_world2_equals_single_process_oracle():
+    """Two ranks x two beads == all four beads in one process through the reference's formula
+    (thermostats_rpmd.py:102-119) with the same counter-based noise: no exchange beyond the momenta all-gather."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import md_oracle as MDO
+    from schnetpack_amd import md as MD
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pile_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, pp = q.get(timeout=60)
+        res[rank] = torch.tensor(pp)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Q, P, M = _ring_problem()
+    C = MDO.normal_mode_matrix(4)
+    c1, c2 = MDO.pile_coefficients(4, 55.0, 5e-4, 0.1)
+    kT = MD.KB_MD * 4 * 300.0
+    p1 = MDO.pile_apply(P.double(), M.double(), C, c1, c2, kT, MDO.pile_noise(4, 6, 99, 5, 0))
+    p2 = MDO.pile_apply(p1, M.double(), C, c1, c2, kT, MDO.pile_noise(4, 6, 99, 5, 1))
+    got = torch.cat([res[0], res[1]])
+    assert torch.allclose(got.double(), p2, rtol=1e-5, atol=1e-5 * float(p2.abs().max()))

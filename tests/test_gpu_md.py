@@ -1,4 +1,6 @@
 """GPU parity of the MD-step kernels and the graphed force call."""
+import math
+
 import pytest
 import torch
 
@@ -254,3 +256,75 @@ def test_nve_periodic_water_box_painn_conserves_energy(dev):
     assert sim.nl.n_builds >= 2
     # the list in use equals a fresh device search with cutoff + skin at the reference positions
     assert sim._lists["_idx_i"].shape[0] > 0
+
+
+# ----------------------------------------------------------------------------- PILE-L thermostat (row f3)
+@pytest.mark.parametrize("n_beads,n_local,bead0", [(4, 4, 0), (8, 8, 0), (8, 2, 4), (5, 5, 0), (16, 10, 3)])
+def test_pile_thermostat_kernel_matches_oracle_with_the_same_noise(dev, n_beads, n_local, bead0):
+    """spk_md_pile_f32 against the reference's formula (thermostats_rpmd.py:102-119, restated in oracle/md_oracle.py) fed the
+    SAME normal-mode noise -- the counter-based stream restated on the host (Philox-4x32-10 + Box-Muller)."""
+    from oracle import md_oracle as MDO
+    from schnetpack_amd import md as MD
+    g = torch.Generator().manual_seed(5)
+    n_atoms, omega, dt, tau, T = 37, 55.0, 5e-4, 0.1, 300.0
+    p = torch.randn(n_beads, n_atoms, 3, generator=g)
+    masses = (torch.rand(1, n_atoms, 1, generator=g) * 15 + 1)
+    M = MD.pile_matrices(n_beads, omega, dt, tau)
+    scale = math.sqrt(MD.KB_MD * n_beads * T)
+    seed, step, which = 0x1234567ABCDEF, 41, 1
+    got = MD._pile_hip(p.to(dev), masses.to(dev), M.to(dev), scale, seed, step, None, which, bead0, n_local).cpu()
+    C = MDO.normal_mode_matrix(n_beads)
+    c1, c2 = MDO.pile_coefficients(n_beads, omega, dt, tau)
+    xi = MDO.pile_noise(n_beads, n_atoms, seed, step, which)
+    ref = MDO.pile_apply(p.double(), masses.double(), C, c1, c2, MD.KB_MD * n_beads * T, xi)[bead0:bead0 + n_local]
+    assert torch.allclose(got.double(), ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    # a device-resident step counter gives the same stream as the host value
+    stepc = torch.tensor([step], dtype=torch.int64, device=dev)
+    got2 = MD._pile_hip(p.to(dev), masses.to(dev), M.to(dev), scale, seed, 0, stepc, which, bead0, n_local).cpu()
+    assert torch.equal(got, got2)
+
+
+def test_pile_thermostat_noise_statistics_and_equilibrium(dev):
+    """The stochastic part alone: normal-mode momenta of a free ring polymer under repeated application reach
+    <p_k^2> = m kB n T for every thermostatted mode (the fixed point of p' = c1 p + sqrt(m kB n T) c2 xi)."""
+    from oracle import md_oracle as MDO
+    from schnetpack_amd import md as MD
+    n_beads, n_atoms, omega, dt, tau, T = 4, 4096, 55.0, 5e-3, 0.02, 300.0
+    M = MD.pile_matrices(n_beads, omega, dt, tau).to(dev)
+    masses = torch.full((1, n_atoms, 1), 12.0, device=dev)
+    p = torch.zeros(n_beads, n_atoms, 3, device=dev)
+    scale = math.sqrt(MD.KB_MD * n_beads * T)
+    for step in range(400):
+        p = MD._pile_hip(p, masses, M, scale, 7, step, None, 0, 0, n_beads)
+    C = MDO.normal_mode_matrix(n_beads).float().to(dev)
+    pn = (C @ p.reshape(n_beads, -1)).view(p.shape)
+    var = (pn ** 2).mean(dim=(1, 2)).cpu()
+    target = 12.0 * MD.KB_MD * n_beads * T
+    assert torch.allclose(var, torch.full_like(var, target), rtol=0.05), (var, target)
+    # successive applications draw different noise; different seeds too
+    a = MD._pile_hip(p, masses, M, scale, 7, 1000, None, 0, 0, n_beads)
+    b = MD._pile_hip(p, masses, M, scale, 7, 1001, None, 0, 0, n_beads)
+    c = MD._pile_hip(p, masses, M, scale, 8, 1000, None, 0, 0, n_beads)
+    d = MD._pile_hip(p, masses, M, scale, 7, 1000, None, 1, 0, n_beads)
+    assert not torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+
+
+def test_rpmd_nvt_loop_with_pile_thermostat_thermalises(dev):
+    """RPMDSimulation(thermostat=PILELocalThermostat): the graph-replayed NVT loop (thermostat at step begin and end, device
+    step counter) heats a cold ring polymer towards the bath temperature and stays finite."""
+    from schnetpack_amd import md as MD, model as M
+    b = S.molecule_batch("aspirin", 4, seed=2)
+    torch.manual_seed(0)
+    model = M.build_model("schnet").to(dev).eval()
+    inp = M.batch_to_inputs(b, dev)
+    inp["_n_atoms"] = torch.bincount(b["idx_m"], minlength=4).to(dev)
+    masses = torch.where(b["Z"] == 1, 1.008, torch.where(b["Z"] == 6, 12.011, 15.999)).to(dev)
+    th = MD.PILELocalThermostat(300.0, 0.01, seed=3)
+    sim = MD.RPMDSimulation(model, inp, masses, 2e-4, 4, cutoff=5.0, omega=30.0, cutoff_shell=2.0, thermostat=th)
+    assert float(sim.kinetic_energy()) == 0.0
+    sim.step(300)
+    ke = float(sim.kinetic_energy())
+    n_dof = 3 * 4 * b["Z"].shape[0]
+    T_est = 2.0 * ke / (n_dof * MD.KB_MD) / 4          # ring-polymer momenta carry n_beads T
+    assert 50.0 < T_est < 900.0, T_est
+    assert int(sim._stepc.item()) == 300
