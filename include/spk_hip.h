@@ -138,6 +138,10 @@ int spk_segment_rowptr_i32(const int64_t* idx, int64_t n, int64_t n_rows, int32_
  * r_ij[e] = (R[idx_j[e]] - R[idx_i[e]]) + offsets[e]   (offsets may be NULL). */
 int spk_pairwise_f32(const float* R, const int64_t* idx_i, const int64_t* idx_j,
                      const float* offsets, int64_t n_edges, float* r_ij, void* stream);
+/* the same with n_atoms known: out-of-range neighbour indices are clamped for the read (never an out-of-bounds access; the
+ * reference's torch indexing raises a device assert) -- spk_edge_plan of the list reports SPK_ERR_INDEX */
+int spk_pairwise_n_f32(const float* R, const int64_t* idx_i, const int64_t* idx_j, const float* offsets,
+                       int64_t n_edges, int64_t n_atoms, float* r_ij, void* stream);
 /* its backward w.r.t. R:  gR[a] = sum_{e: idx_j[e]==a} gr[e] - sum_{e: idx_i[e]==a} gr[e]
  * ([N,3], overwritten) -- where dE/dR_ij lands on the atoms (forces = -gR). */
 int spk_pairwise_bwd_f32(const float* gr, const int64_t* idx_i, const int64_t* idx_j,

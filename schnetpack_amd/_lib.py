@@ -85,6 +85,7 @@ _PROTOS = {
     "spk_scatter_add_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i64, c_f, c_f]),
     "spk_gather_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_i64, c_f, c_f]),
     "spk_pairwise_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_f, c_f]),
+    "spk_pairwise_n_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f]),
     "spk_pairwise_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_f, c_f]),
     "spk_nbl_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "spk_nbl_count_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, ctypes.c_float, c_f, c_f, ctypes.POINTER(ctypes.c_int64), c_f]),

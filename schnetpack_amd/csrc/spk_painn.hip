@@ -563,8 +563,10 @@ __device__ __forceinline__ void mix_load_b(f32x4 (&bv)[4], const float* __restri
   for (int u = 0; u < 4; ++u) bv[u] = *(const f32x4*)(brow + 64 * c + 16 * u + 4 * h);
 }
 
-template <int F>
-__global__ __launch_bounds__(256, 2) void k_painn_mixing_fwd(MixFwdArgs a) {
+// MINB = 2: two workgroups per CU, 256 VGPRs (spills 268 B/lane to scratch); MINB = 1: one workgroup per CU with the full
+// 512-register budget (no scratch; the overflow sits in AGPRs).  Which one wins depends on how many 16-atom tiles a CU gets.
+template <int F, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_painn_mixing_fwd(MixFwdArgs a) {
   static_assert(F == 128, "the weight stream below is written out for n_atom_basis = 128");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LDA = F + 4, LDC = 2 * F + 4, LDH = F + 4;
@@ -711,8 +713,8 @@ struct MixBwdArgs {
   float* gq1; float* gmix;
 };
 
-template <int F>
-__global__ __launch_bounds__(256, 2) void k_painn_mixing_bwd(MixBwdArgs a) {
+template <int F, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_painn_mixing_bwd(MixBwdArgs a) {
   static_assert(F == 128, "the weight stream below is written out for n_atom_basis = 128");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LDG = 3 * F + 4, LDT = F + 4;
@@ -799,13 +801,23 @@ __global__ __launch_bounds__(256, 2) void k_painn_mixing_bwd(MixBwdArgs a) {
   }
 }
 
+// Measured (profiles/README.md, round 2): the spill-free variant wins at every size tried (cfg 3: forward 45.9 -> 42.9 us,
+// backward 34.3 -> 29.7 us; 32 k-atom box: 185 -> 166 us and 151 -> 130 us).  SPK_MIX_OCC=2 selects the two-workgroup form.
+static bool mix_one_block_per_cu(int64_t ntiles) {
+  static const char* env = getenv("SPK_MIX_OCC");
+  (void)ntiles;
+  return !(env && env[0] == '2');
+}
+
 static int launch_painn_mixing_bwd(const MixBwdArgs& a, int F, hipStream_t stream) {
   SPK_CHECK_ARG(F == 128, "fused PaiNN mixing backward: n_atom_basis must be 128");
   const size_t lds = sizeof(float) * (16 * (size_t)(3 * F + 4) + 16 * (size_t)(F + 4));
   const int64_t ntiles = (a.N + 15) / 16;
   const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
   SpkProfScope prof("painn_mixing_bwd", stream);
-  hipLaunchKernelGGL((k_painn_mixing_bwd<128>), dim3(grid), dim3(256), lds, stream, a);
+  // few tiles per CU (molecule batches): one workgroup per CU, no scratch; many tiles per CU: two resident workgroups
+  if (mix_one_block_per_cu(ntiles)) hipLaunchKernelGGL((k_painn_mixing_bwd<128, 1>), dim3(grid), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL((k_painn_mixing_bwd<128, 2>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -816,7 +828,8 @@ static int launch_painn_mixing_fwd(const MixFwdArgs& a, int F, hipStream_t strea
   const int64_t ntiles = (a.N + 15) / 16;
   const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
   SpkProfScope prof("painn_mixing_fwd", stream);
-  hipLaunchKernelGGL((k_painn_mixing_fwd<128>), dim3(grid), dim3(256), lds, stream, a);
+  if (mix_one_block_per_cu(ntiles)) hipLaunchKernelGGL((k_painn_mixing_fwd<128, 1>), dim3(grid), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL((k_painn_mixing_fwd<128, 2>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

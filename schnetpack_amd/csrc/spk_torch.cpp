@@ -300,7 +300,8 @@ Tensor pairwise_raw(const Tensor& R_in, const Tensor& idx_i_in, const Tensor& id
   const int64_t E = ii.size(0);
   c10::DeviceGuard guard(R.device());
   Tensor r = at::empty({E, 3}, R.options());
-  check(spk_pairwise_f32(fp(R), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), fp(off), E, fpm(r), stream_of(R)));
+  if (E > 0 && R.size(0) > 0)
+    check(spk_pairwise_n_f32(fp(R), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), fp(off), E, R.size(0), fpm(r), stream_of(R)));
   return r;
 }
 
@@ -1023,6 +1024,52 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> edge_plan_op(const Tensor& idx_i, con
   return {p->rowptr, p->rev, p->half.defined() ? p->half : at::empty({0}, iopt), flags};
 }
 
+// Plan made on the host by the collate function (schnetpack_amd/data.py, DataLoader workers): put it into the cache under the
+// key of the device index tensors -- no kernel, no device-to-host copy.  meta = [sorted, symmetric, n_half, n_groups,
+// max_group_atoms, max_group_pairs, filter_pairs (-1 unknown), n_tiles_grouped].
+void edge_plan_install_op(const Tensor& idx_i, const Tensor& idx_j, int64_t n_atoms, const Tensor& rowptr, const Tensor& rev, const Tensor& half,
+                          const Tensor& edge_pair, const Tensor& grp_atom0, const Tensor& grp_pair0, at::IntArrayRef meta) {
+  require_device(idx_i, "edge_plan_install");
+  TORCH_CHECK(meta.size() >= 8, "edge_plan_install: meta needs 8 entries");
+  auto p = std::make_shared<Plan>();
+  p->idx_i = i64(idx_i, "edge_plan_install");
+  p->idx_j = i64(idx_j, "edge_plan_install");
+  p->n_atoms = n_atoms;
+  p->n_edges = p->idx_i.size(0);
+  p->has_r = true;
+  auto i32 = [&](const Tensor& t, const char* what, int64_t want) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kInt && t.is_contiguous(), "edge_plan_install: ", what, " must be a contiguous int32 device tensor");
+    TORCH_CHECK(want < 0 || t.numel() == want, "edge_plan_install: ", what, " has ", t.numel(), " entries, expected ", want);
+    return t;
+  };
+  p->rowptr = i32(rowptr, "rowptr", n_atoms + 1);
+  p->sorted = meta[0] != 0;
+  p->symmetric = meta[1] != 0;
+  p->rev = i32(rev, "rev", std::max<int64_t>(p->n_edges, 1));
+  if (p->symmetric && p->n_edges > 0) {
+    p->n_half = meta[2];
+    TORCH_CHECK(2 * p->n_half == p->n_edges, "edge_plan_install: a symmetric list has n_edges = 2 n_half");
+    p->half = i32(half, "half", p->n_half);
+    p->edge_pair = i32(edge_pair, "edge_pair", p->n_edges);
+    if (meta[3] > 0) {
+      p->n_groups = (int32_t)meta[3];
+      p->grp_atom0 = i32(grp_atom0, "grp_atom0", meta[3] + 1);
+      p->grp_pair0 = i32(grp_pair0, "grp_pair0", meta[3] + 1);
+      // tile offsets of the group-aligned tiling (only the experimental group-local pair kernels read them)
+      Tensor tiles = at::floor_divide(at::diff(p->grp_pair0.to(at::kLong)) + 31, 32);
+      p->grp_tile0 = at::cat({at::zeros({1}, tiles.options()), at::cumsum(tiles, 0)}).to(at::kInt).contiguous();
+      p->max_group_atoms = (int32_t)meta[4];
+      p->max_group_pairs = (int32_t)meta[5];
+      p->n_tiles_grouped = meta[7];
+    }
+  }
+  p->filter_pairs = (int)meta[6];
+  std::vector<uint64_t> key{(uint64_t)idx_i.data_ptr(), (uint64_t)idx_j.data_ptr(), version_of(idx_i), version_of(idx_j),
+                            (uint64_t)idx_i.size(0), (uint64_t)n_atoms, (uint64_t)idx_i.device().index(), 1, 1, (uint64_t)idx_i.scalar_type()};
+  std::lock_guard<std::mutex> lock(g_mutex);
+  g_plans.put(key, p);
+}
+
 // static-shape mode (training-step graph replays)
 Tensor static_declare_op(const Tensor& idx, int64_t n_rows) {
   require_device(idx, "static_declare");
@@ -1160,6 +1207,7 @@ TORCH_LIBRARY(spk_hip, m) {
   m.def("atomwise_forward(Tensor x, Tensor w1, Tensor? b1, Tensor w2, Tensor? b2, Tensor idx_m, int n_mol, int act) -> (Tensor, Tensor, Tensor)");
   m.def("atomwise_backward(Tensor? gE, Tensor? gy_atom, Tensor pre, Tensor w1, Tensor w2, Tensor idx_m, int n_mol, int act) -> Tensor");
   m.def("edge_plan(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor? r_ij, float cutoff=0.0, int force_filter=-1) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("edge_plan_install(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor rowptr, Tensor rev, Tensor half, Tensor edge_pair, Tensor grp_atom0, Tensor grp_pair0, int[] meta) -> ()");
   // static-shape mode + cache control (host-side state)
   m.def("static_declare(Tensor idx, int n_rows) -> Tensor");
   m.def("static_refresh() -> ()", static_refresh_op);
@@ -1190,6 +1238,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm d
   m.impl("atomwise_backward", atomwise_backward_op);
   m.impl("edge_plan", edge_plan_op);
   m.impl("static_declare", static_declare_op);
+  m.impl("edge_plan_install", edge_plan_install_op);
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, Autograd, m) {

@@ -465,10 +465,14 @@ int spk_zero_async(void* p, size_t bytes, hipStream_t stream) {
 // ---------------------------------------------------------------- pairwise vectors (distances.py)
 __global__ void k_pairwise(const float* __restrict__ R, const int64_t* __restrict__ idx_i,
                            const int64_t* __restrict__ idx_j, const float* __restrict__ off,
-                           int64_t E, float* __restrict__ rij) {
+                           int64_t E, int64_t N, float* __restrict__ rij) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
        e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = idx_i[e], j = idx_j[e];
+    int64_t i = idx_i[e], j = idx_j[e];
+    if (N > 0) {   // a malformed list must not read out of bounds: clamp here, spk_edge_plan reports the index error
+      i = i < 0 ? 0 : (i >= N ? N - 1 : i);
+      j = j < 0 ? 0 : (j >= N ? N - 1 : j);
+    }
     // same operation order as the reference: (R[j] - R[i]) + offsets  => r_ji == -r_ij bit-exactly
     float x = R[3 * j] - R[3 * i], y = R[3 * j + 1] - R[3 * i + 1], z = R[3 * j + 2] - R[3 * i + 2];
     if (off) { x += off[3 * e]; y += off[3 * e + 1]; z += off[3 * e + 2]; }
@@ -477,10 +481,11 @@ __global__ void k_pairwise(const float* __restrict__ R, const int64_t* __restric
 }
 
 __global__ void k_pairwise_bwd(const float* __restrict__ gr, const int64_t* __restrict__ idx_i,
-                               const int64_t* __restrict__ idx_j, int64_t E, float* __restrict__ gR) {
+                               const int64_t* __restrict__ idx_j, int64_t E, int64_t N, float* __restrict__ gR) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx_i[e], j = idx_j[e];
+    if ((uint64_t)i >= (uint64_t)N || (uint64_t)j >= (uint64_t)N) continue;      // never scatter out of bounds
     const float x = gr[3 * e], y = gr[3 * e + 1], z = gr[3 * e + 2];
     unsafeAtomicAdd(&gR[3 * j], x); unsafeAtomicAdd(&gR[3 * j + 1], y); unsafeAtomicAdd(&gR[3 * j + 2], z);
     unsafeAtomicAdd(&gR[3 * i], -x); unsafeAtomicAdd(&gR[3 * i + 1], -y); unsafeAtomicAdd(&gR[3 * i + 2], -z);
@@ -517,7 +522,19 @@ extern "C" int spk_pairwise_f32(const float* R, const int64_t* idx_i, const int6
   hipStream_t stream = (hipStream_t)stream_;
   if (E == 0) return SPK_OK;
   SPK_CHECK_ARG(R && idx_i && idx_j && r_ij && E > 0, "spk_pairwise_f32: bad input");
-  hipLaunchKernelGGL(k_pairwise, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, R, idx_i, idx_j, offsets, E, r_ij);
+  hipLaunchKernelGGL(k_pairwise, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, R, idx_i, idx_j, offsets, E, (int64_t)0, r_ij);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// the same with the number of atoms known: indices outside [0, n_atoms) are clamped for the read (no out-of-bounds access);
+// the index error itself is reported by spk_edge_plan of the list
+extern "C" int spk_pairwise_n_f32(const float* R, const int64_t* idx_i, const int64_t* idx_j, const float* offsets, int64_t E,
+                                  int64_t n_atoms, float* r_ij, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (E == 0) return SPK_OK;
+  SPK_CHECK_ARG(R && idx_i && idx_j && r_ij && E > 0 && n_atoms > 0, "spk_pairwise_n_f32: bad input");
+  hipLaunchKernelGGL(k_pairwise, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, R, idx_i, idx_j, offsets, E, n_atoms, r_ij);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -530,7 +547,7 @@ extern "C" int spk_pairwise_bwd_f32(const float* gr, const int64_t* idx_i, const
   { int _zr = spk_zero_async(gR, (size_t)N * 3 * sizeof(float), stream); if (_zr) return _zr; }
   if (E == 0) return SPK_OK;
   SPK_CHECK_ARG(gr && idx_i && idx_j, "spk_pairwise_bwd_f32: null pointer");
-  hipLaunchKernelGGL(k_pairwise_bwd, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, gr, idx_i, idx_j, E, gR);
+  hipLaunchKernelGGL(k_pairwise_bwd, dim3(spk_grid_for(E, 256, spk_num_cus() * 16)), dim3(256), 0, stream, gr, idx_i, idx_j, E, N, gR);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

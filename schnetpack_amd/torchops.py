@@ -41,7 +41,7 @@ ops = load()
 
 OPERATORS = ["scatter_add", "gather", "pairwise", "pairwise_backward", "dense", "radial_cutoff", "schnet", "painn", "atomwise",
              "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
-             "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare", "static_refresh", "static_enable",
+             "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "edge_plan_install", "static_declare", "static_refresh", "static_enable",
              "static_check", "static_clear", "clear_caches"]
 
 

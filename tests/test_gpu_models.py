@@ -86,18 +86,19 @@ def test_training_mode_double_backward_matches_oracle(dev, kind, F, n_rbf, radia
     Et = torch.randn(3, generator=g)
     Ft = torch.randn(b["Z"].shape[0], 3, generator=g)
 
-    # oracle on CPU with autograd
-    rp = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and k.endswith(("weight", "bias")) else v) for k, v in rep_p.items()}
-    hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
-    R = b["R"].clone().requires_grad_(True)
-    r_ij = O.pairwise_vectors(R, b["idx_i"], b["idx_j"], b["offsets"])
+    # oracle on CPU with autograd, in float64: the checker's own rounding is out of the picture
+    rp = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and k.endswith(("weight", "bias")) else
+              (v.double() if v.is_floating_point() else v)) for k, v in rep_p.items()}
+    hp = {k: v.clone().double().requires_grad_(True) for k, v in head_p.items()}
+    R = b["R"].clone().double().requires_grad_(True)
+    r_ij = O.pairwise_vectors(R, b["idx_i"], b["idx_j"], b["offsets"].double())
     if kind == "schnet":
         x = O.schnet_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, 3)
     else:
         x, _ = O.painn_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, 3)
     E = O.atomwise_energy(x, b["idx_m"], 3, hp)
     (dEdR,) = torch.autograd.grad([E.sum()], [R], create_graph=True)
-    loss_o = 0.01 * ((E - Et) ** 2).mean() + 0.99 * ((-dEdR - Ft) ** 2).mean()
+    loss_o = 0.01 * ((E - Et.double()) ** 2).mean() + 0.99 * ((-dEdR - Ft.double()) ** 2).mean()
     names = [k for k, v in rp.items() if torch.is_tensor(v) and v.requires_grad]
     go = dict(zip(names, torch.autograd.grad(loss_o, [rp[k] for k in names], allow_unused=True)))
 
@@ -106,7 +107,7 @@ def test_training_mode_double_backward_matches_oracle(dev, kind, F, n_rbf, radia
     model = model.to(dev).train()
     out = model(M.batch_to_inputs(b, dev))
     loss = 0.01 * ((out["energy"] - Et.to(dev)) ** 2).mean() + 0.99 * ((out["forces"] - Ft.to(dev)) ** 2).mean()
-    assert abs(float(loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach())) < 1e-4
+    assert abs(float(loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach())) < 1e-5
     loss.backward()
     got = dict(model.representation.named_parameters())
     worst = 0.0
@@ -116,7 +117,9 @@ def test_training_mode_double_backward_matches_oracle(dev, kind, F, n_rbf, radia
         gh = got[k].grad
         assert gh is not None, k
         worst = max(worst, rel_err(gh.cpu(), go[k]))
-    assert worst < 1e-3, worst  # second-order fp32 accumulations; loose but catches wrong algebra
+    # weight gradients of the force-matching loss (second order of the hot path), fp32 on the device against the fp64 oracle,
+    # relative to the largest entry of each gradient tensor
+    assert worst < 1e-4, worst
 
 
 @pytest.mark.parametrize("kind", ["schnet", "painn"])
