@@ -73,8 +73,12 @@ def test_edge_plan_flags_and_rowptr(dev):
     assert half.shape[0] * 2 == plan.n_edges and bool((rev[half] > half).all())
     assert bool((half[1:] > half[:-1]).all())
     # block-diagonal groups: 3 molecules of 21 atoms, group-aligned tiles
-    atom0, pair0, tile0, max_atoms, n_tiles = plan.groups
+    atom0, pair0, tile0, max_atoms, n_tiles, max_pairs = plan.groups
     assert atom0.cpu().tolist() == [0, 21, 42, 63] and max_atoms == 21
+    assert max_pairs == max(int(pair0[k + 1] - pair0[k]) for k in range(3))
+    # position of the pair of every directed edge (molecule-resident kernels)
+    ep = plan.edge_pair.long().cpu()
+    assert torch.equal(ep[half], torch.arange(half.shape[0])) and torch.equal(ep[rev[half]], torch.arange(half.shape[0]))
     p0 = pair0.cpu().tolist()
     assert p0[0] == 0 and p0[-1] == half.shape[0]
     hi_atoms = b["idx_i"][half]
