@@ -240,8 +240,8 @@ int spk_edge_norm_f32(const float* r_ij, int64_t n_edges, float* d, float* u, vo
 /* ------------------------------------------------------------------ nn/base.py:52-55 (Dense)
  * y[m, o] = act(sum_k x[m,k] w[o,k] + b[o]) + res[m,o].  w is the torch Linear weight
  * [n_out, k] row-major.  b, res, pre may be NULL; `pre` receives the pre-activation (saved for
- * backward).  k % 8 == 0 and n_out % 32 == 0 select the fp32-MFMA kernel, otherwise the simple
- * kernel runs. */
+ * backward).  k % 4 == 0 and n_out % 4 == 0 select the fp32-MFMA kernel (partial tiles are masked), otherwise the
+ * simple kernel runs. */
 int spk_dense_f32(const float* x, const float* w, const float* b, const float* res, float* y,
                   float* pre, int64_t m, int32_t k, int32_t n_out, int32_t act, void* stream);
 /* input gradient: dx[m,k] = sum_o (dy[m,o] * act'(pre[m,o])) w[o,k]  (+ res[m,k]).
@@ -510,6 +510,39 @@ int spk_embedding_f32(const float* table, const int64_t* z, int64_t n, int32_t F
                       void* stream);
 /* y = a + b (n floats) */
 int spk_add_f32(const float* a, const float* b, int64_t n, float* y, void* stream);
+
+/* ------------------------------------------------------------------ training regime (force matching: every operator is
+ * differentiated twice, atomistic/response.py:59-68 with create_graph = training).  A family of kernels closed under
+ * differentiation -- the derivative of each member is another member -- so that the recorded backward and its backward are
+ * these launches (spk_train.hip).  All tensors dense row-major fp32; `a`, `c` operands may be NULL.
+ *
+ * out[t] = a[t] * act^(order)(z[t]) + c[t]      (act: SPK_ACT_*, derivative order 0..3; nn/activations.py:9-22, F.silu) */
+int spk_act_mul_f32(const float* a, const float* z, const float* c, int64_t n, int32_t act, int32_t order,
+                    float* out, void* stream);
+/* G[O,K] = U[n,O]^T X[n,K], gb[O] = column sums of U (gb may be NULL): weight / bias gradients of Dense (nn/base.py:52-55).
+ * spk_gemm_tn_plan reports the slice count of the contraction; with more than one slice the caller provides `ws`
+ * (ws_floats floats) and `tickets` (n_tiles zero-initialised uint32; the kernel leaves them zero).  Deterministic. */
+int spk_gemm_tn_plan(int64_t n, int32_t O, int32_t K, int32_t* n_slices, int64_t* ws_floats, int32_t* n_tiles);
+int spk_gemm_tn_f32(const float* U, const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, float* ws,
+                    uint32_t* tickets, void* stream);
+/* y[idx_out[e], :] += x[idx_src[e], :] * W[e, :]   (schnet.py:64-66 on materialised filters; y [n_out, F] overwritten).
+ * rowptr_out = CSR row pointers of an ascending idx_out (deterministic segmented sum) or NULL (float atomics). */
+int spk_cfconv_edge_f32(const float* x, const float* W, const int64_t* idx_out, const int64_t* idx_src,
+                        const int32_t* rowptr_out, int64_t n_edges, int64_t n_out, int64_t n_src, int32_t F, float* y,
+                        void* stream);
+/* out[e, :] = a[idx_a[e], :] * b[idx_b[e], :]   (the derivative of the above w.r.t. W) */
+int spk_edge_mul_f32(const float* a, const float* b, const int64_t* idx_a, const int64_t* idx_b, int64_t n_edges,
+                     int64_t n_a, int64_t n_b, int32_t F, float* out, void* stream);
+/* out[e, r] = a[e] * d^order/dd^order phi_r(d[e])   and   out[e] = a[e] * sum_r G[e, r] d^order/dd^order phi_r(d[e]);
+ * rb->kind 0 / 1 = the radial bases (nn/radial.py), 2 = the cosine cutoff (nn/cutoff.py:14-33) with one "basis function";
+ * order 0..3 */
+int spk_radial_d_f32(const float* d, const float* a, int64_t n, const spk_radial_t* rb, int32_t order, float* out,
+                     void* stream);
+int spk_radial_c_f32(const float* G, const float* d, const float* a, int64_t n, const spk_radial_t* rb, int32_t order,
+                     float* out, void* stream);
+/* out[r, f] = W[r, f] * s[r]   (Wij * rcut_ij[:, None], schnet.py:61)   and   out[r] = sum_f a[r, f] * b[r, f] */
+int spk_rowscale_f32(const float* W, const float* s, int64_t rows, int32_t F, float* out, void* stream);
+int spk_rowdot_f32(const float* a, const float* b, int64_t rows, int32_t F, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,15 @@ _PROTOS = {
     "spk_radial_cutoff_f32": (ctypes.c_int, [c_f, c_i64, P(RadialT), c_f, c_f, c_f]),
     "spk_radial_cutoff_bwd_f32": (ctypes.c_int, [c_f, c_i64, P(RadialT), c_f, c_f, c_f, c_f]),
     "spk_edge_norm_f32": (ctypes.c_int, [c_f, c_i64, c_f, c_f, c_f]),
+    "spk_act_mul_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i32, c_i32, c_f, c_f]),
+    "spk_gemm_tn_plan": (ctypes.c_int, [c_i64, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]),
+    "spk_gemm_tn_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f]),
+    "spk_cfconv_edge_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i32, c_f, c_f]),
+    "spk_edge_mul_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i32, c_f, c_f]),
+    "spk_radial_d_f32": (ctypes.c_int, [c_f, c_f, c_i64, P(RadialT), c_i32, c_f, c_f]),
+    "spk_radial_c_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, P(RadialT), c_i32, c_f, c_f]),
+    "spk_rowscale_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_f, c_f]),
+    "spk_rowdot_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_f, c_f]),
     "spk_dense_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
     "spk_dense_bwd_input_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
     "spk_dense_chain_f32": (ctypes.c_int, [P(ChainT), c_f]),

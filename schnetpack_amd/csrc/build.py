@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_schnet_mol.hip", "spk_painn.hip", "spk_painn_tile.hip", "spk_nbl.hip", "spk_md.hip", "spk_potential.hip"]
+SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_schnet_mol.hip", "spk_painn.hip", "spk_painn_tile.hip", "spk_nbl.hip", "spk_md.hip", "spk_potential.hip", "spk_train.hip"]
 HEADERS = ["spk_common.h", "spk_painn_msg.h", "spk_pack.h", os.path.join("..", "..", "include", "spk_hip.h")]
 LIB = os.path.join(HERE, "libspk_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
@@ -72,7 +72,7 @@ TORCH_LIB = os.path.join(HERE, "libspk_torch.so")
 def build_torch_ops(force=False, verbose=True):
     """libspk_torch.so: the TORCH_LIBRARY(spk_hip) operator registrations (spk_torch.cpp; host C++ only, every operator
     calls into libspk_hip.so), compiled against the installed PyTorch-ROCm headers and linked next to libspk_hip.so."""
-    if not (force or _stale(TORCH_LIB, [TORCH_SRC, LIB, os.path.join(HERE, HEADERS[-1])])):
+    if not (force or _stale(TORCH_LIB, [TORCH_SRC, os.path.join(HERE, "spk_torch_train.h"), LIB, os.path.join(HERE, HEADERS[-1])])):
         return TORCH_LIB
     import torch
     from torch.utils import cpp_extension as ce

@@ -24,26 +24,32 @@ __device__ __forceinline__ void dense_load_chunk(f32x4 (&av)[DCH], f32x4 (&bv)[D
                                                  const float* __restrict__ prow,
                                                  const float* __restrict__ w, int KC, int NW, int t,
                                                  int el, int hi) {
+  // KC and NW are multiples of 4 (not necessarily of 8 / 32): contraction groups past KC and weight rows past NW read as 0
+  const bool rin = 32 * t + el < NW;
 #pragma unroll
   for (int u = 0; u < DCH; ++u) {
     const int ug = c * DCH + u;
     if (ug < nug) {
       const int kk0 = 8 * ug + 4 * hi;
-      f32x4 b = *(const f32x4*)(inrow + kk0);
-      if (PRO != SPK_ACT_NONE) {
+      const bool kin = kk0 < KC;
+      f32x4 b{0.f, 0.f, 0.f, 0.f};
+      if (kin) b = *(const f32x4*)(inrow + kk0);
+      if (PRO != SPK_ACT_NONE && kin) {
         const f32x4 pv = *(const f32x4*)(prow + kk0);
         b.x *= spk_act_grad<PRO>(pv.x); b.y *= spk_act_grad<PRO>(pv.y);
         b.z *= spk_act_grad<PRO>(pv.z); b.w *= spk_act_grad<PRO>(pv.w);
       }
       bv[u] = b;
-      if (!TRANS) {
-        av[u] = *(const f32x4*)(w + (int64_t)(32 * t + el) * KC + kk0);
-      } else {
-        const float* wp = w + (int64_t)kk0 * NW + 32 * t + el;
-        f32x4 a4;
-        a4.x = wp[0]; a4.y = wp[NW]; a4.z = wp[2 * (int64_t)NW]; a4.w = wp[3 * (int64_t)NW];
-        av[u] = a4;
+      f32x4 a4{0.f, 0.f, 0.f, 0.f};
+      if (kin && rin) {
+        if (!TRANS) {
+          a4 = *(const f32x4*)(w + (int64_t)(32 * t + el) * KC + kk0);
+        } else {
+          const float* wp = w + (int64_t)kk0 * NW + 32 * t + el;
+          a4.x = wp[0]; a4.y = wp[NW]; a4.z = wp[2 * (int64_t)NW]; a4.w = wp[3 * (int64_t)NW];
+        }
       }
+      av[u] = a4;
     }
   }
 }
@@ -69,8 +75,8 @@ __global__ __launch_bounds__(256) void k_dense_mfma(
     float* __restrict__ pre_out, int64_t M, int KC, int NW, int64_t ntasks) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int hi = lane >> 5, el = lane & 31;
-  const int tcount = NW / 32;
-  const int nug = KC / 8;
+  const int tcount = (NW + 31) / 32;
+  const int nug = (KC + 7) / 8;
   const int nch = (nug + DCH - 1) / DCH;
   for (int64_t task = blockIdx.x * 4 + wv; task < ntasks; task += (int64_t)gridDim.x * 4) {
     const int64_t mt = task / tcount;
@@ -85,10 +91,13 @@ __global__ __launch_bounds__(256) void k_dense_mfma(
     f32x4 rv[4];  // residual rows, requested ahead of the MFMAs
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      rv[q] = (res && valid) ? *(const f32x4*)(res + m * NW + 32 * t + 8 * q + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rv[q] = (res && valid && 32 * t + 8 * q + 4 * hi < NW) ? *(const f32x4*)(res + m * NW + 32 * t + 8 * q + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = b ? b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const int col = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      acc[r] = (b && col < NW) ? b[col] : 0.f;
+    }
     for (int c = 0; c < nch; c += 2) {
       if (c + 1 < nch) dense_load_chunk<TRANS, PRO>(a1, b1, c + 1, nug, inrow, prow, w, KC, NW, t, el, hi);
       acc = dense_mfma_chunk(a0, b0, c, nug, acc);
@@ -98,6 +107,7 @@ __global__ __launch_bounds__(256) void k_dense_mfma(
     if (valid) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        if (32 * t + 8 * q + 4 * hi >= NW) continue;
         const int64_t off = m * NW + 32 * t + 8 * q + 4 * hi;
         f32x4 o;
         o.x = acc[4 * q]; o.y = acc[4 * q + 1]; o.z = acc[4 * q + 2]; o.w = acc[4 * q + 3];
@@ -149,7 +159,7 @@ static int dense_dispatch(const float* in, const float* pre_in, const float* w, 
   SPK_CHECK_ARG(act >= 0 && act <= 2 && pro >= 0 && pro <= 2, "%s: unknown activation", who);
   SPK_CHECK_ARG(pro == SPK_ACT_NONE || pre_in != nullptr, "%s: pre-activation required", who);
   const int variant = spk_get_variant();
-  const bool shape_ok = (KC % 8 == 0) && (NW % 32 == 0) && aligned16(in) && aligned16(pre_in) &&
+  const bool shape_ok = (KC % 4 == 0) && (NW % 4 == 0) && aligned16(in) && aligned16(pre_in) &&
                         aligned16(w) && aligned16(res) && aligned16(out) && aligned16(pre_out);
   SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || shape_ok, "%s: shape K=%d N=%d not supported by the MFMA kernel", who, KC, NW);
   SpkProfScope prof(trans ? "dense_bwd" : "dense_fwd", stream);
@@ -157,7 +167,7 @@ static int dense_dispatch(const float* in, const float* pre_in, const float* w, 
   // (k-major weights with an act' prologue); a layer that wants both goes to the simple kernel
   const bool mfma_combo = (pro == SPK_ACT_NONE) || (act == SPK_ACT_NONE && trans);
   if (shape_ok && mfma_combo && variant != SPK_VARIANT_SIMPLE) {
-    const int64_t ntasks = ((M + 31) / 32) * (NW / 32);
+    const int64_t ntasks = ((M + 31) / 32) * ((NW + 31) / 32);
     const int grid = spk_grid_for(ntasks, 4, spk_num_cus() * 8);
 #define SPK_DENSE_LAUNCH(A, T, P)                                                               \
   hipLaunchKernelGGL((k_dense_mfma<A, T, P>), dim3(grid), dim3(256), 0, stream, in, pre_in, w, b, \

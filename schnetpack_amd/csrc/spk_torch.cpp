@@ -706,6 +706,8 @@ const char* kEvalOnly =
     "its weights (or a recorded backward, create_graph=True) was requested.  Put the module in training mode (module.train()): the "
     "training path is differentiable to any order in all parameters.";
 
+#include "spk_torch_train.h"
+
 // ------------------------------------------------------------------------------------------------ autograd: primitives
 // scatter_add <-> gather are each other's transposes; both backward passes call the differentiable operator again, so the
 // pair is closed under differentiation (force training needs the second order, atomistic/response.py:67).
@@ -762,48 +764,45 @@ struct PairwiseBwdFn : public torch::autograd::Function<PairwiseBwdFn> {
   }
 };
 
-Tensor act_grad(const Tensor& pre, int64_t act) {
-  Tensor s = at::sigmoid(pre);
-  if (act == SPK_ACT_SSP) return s;
-  return s * (1.0 + pre * (1.0 - s));   // silu'
-}
-
-// Dense (nn/base.py:52-55).  Forward on the HIP kernel.  Backward, two regimes decided per backward pass:
-//  * plain first-order pass (grad mode off): input gradient on the HIP kernel; weight / bias gradients only when this
-//    pass really asks for them (needs_input_grad is per graph task: Forces' autograd.grad w.r.t. positions does not);
-//  * recorded pass (create_graph=True, training on forces): differentiable torch algebra with the pre-activation re-derived
-//    from the graph tensors, so the act'' terms of the second order are exact.
+// Dense (nn/base.py:52-55).  The node has two outputs, (y, pre-activation): the pre-activation is saved as an OUTPUT of the
+// node, so a recorded backward that multiplies by act'(pre) stays connected to x, w, b through this same node (its second
+// incoming gradient) and the act'' terms of the second order come out exact.  Backward, decided per backward pass:
+//  * plain first-order pass asking for the input gradient only (eval-mode Forces: needs_input_grad is per graph task, and
+//    autograd.grad w.r.t. the positions does not ask for the weights): one fused kernel, (gy . act'(pre)) W;
+//  * otherwise: u = gy . act'(pre) + gpre, gx = u W, (gw, gb) = (u^T x, column sums of u) -- three launches of the
+//    differentiable operators of spk_torch_train.h, so a recorded pass (create_graph=True) can be differentiated again.
 struct DenseFn : public torch::autograd::Function<DenseFn> {
-  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, int64_t act) {
+  static variable_list forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, int64_t act) {
     at::AutoDispatchBelowADInplaceOrView guard;
     auto yp = call_dense_forward(x, w, b, act);
     ctx->saved_data["act"] = act;
     ctx->saved_data["has_bias"] = b.has_value() && b->defined();
-    ctx->save_for_backward({x, w, (b.has_value() && b->defined()) ? *b : Tensor(), std::get<1>(yp)});
-    return std::get<0>(yp);
+    ctx->save_for_backward({x, w, std::get<1>(yp)});
+    return {std::get<0>(yp), std::get<1>(yp)};
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     auto saved = ctx->get_saved_variables();
-    const Tensor &x = saved[0], &w = saved[1], &b = saved[2];
-    Tensor pre = saved[3];
+    const Tensor &x = saved[0], &w = saved[1], &pre = saved[2];
     const int64_t act = ctx->saved_data["act"].toInt();
     const bool has_bias = ctx->saved_data["has_bias"].toBool();
-    const Tensor& gy = grads[0];
+    const Tensor &gy = grads[0], &gpre = grads[1];
     const bool recorded = at::GradMode::is_enabled();
     const bool need_w = ctx->needs_input_grad(1), need_b = has_bias && ctx->needs_input_grad(2);
+    const bool has_gpre = act != SPK_ACT_NONE && gpre.defined();
     Tensor gx, gw, gb;
-    if (!recorded && !need_w && !need_b) {
+    if (!gy.defined() && !has_gpre) return {gx, gw, gb, Tensor()};
+    if (!recorded && !need_w && !need_b && !has_gpre) {
       if (ctx->needs_input_grad(0)) gx = call_dense_backward_input(gy, pre, w, act);
       return {gx, gw, gb, Tensor()};
     }
-    Tensor g = gy;
-    if (act != SPK_ACT_NONE) {
-      if (recorded) pre = at::linear(x, w, has_bias ? c10::optional<Tensor>(b) : c10::nullopt);
-      g = gy * act_grad(pre, act);
+    Tensor u = gy;
+    if (act != SPK_ACT_NONE) u = gy.defined() ? call_act_mul(gy, pre, act, 1, opt_of(has_gpre ? gpre : Tensor())) : gpre;
+    if (ctx->needs_input_grad(0)) gx = call_matmul_nn(u, w);
+    if (need_w || need_b) {
+      auto r = call_matmul_tn(u, x);
+      if (need_w) gw = std::get<0>(r);
+      if (need_b) gb = std::get<1>(r);
     }
-    if (ctx->needs_input_grad(0)) gx = at::matmul(g, w);
-    if (need_w) gw = at::matmul(g.reshape({-1, g.size(-1)}).t(), x.reshape({-1, x.size(-1)}));
-    if (need_b) gb = g.reshape({-1, g.size(-1)}).sum(0);
     return {gx, gw, gb, Tensor()};
   }
 };
@@ -930,7 +929,7 @@ Tensor scatter_add_ad(const Tensor& x, const Tensor& idx, int64_t dim_size, int6
 Tensor gather_ad(const Tensor& x, const Tensor& idx, int64_t dim) { return GatherFn::apply(x, idx, dim); }
 Tensor pairwise_ad(const Tensor& R, const Tensor& ii, const Tensor& jj, const c10::optional<Tensor>& off) { return PairwiseFn::apply(R, ii, jj, off); }
 Tensor pairwise_backward_ad(const Tensor& gr, const Tensor& ii, const Tensor& jj, int64_t n) { return PairwiseBwdFn::apply(gr, ii, jj, n); }
-Tensor dense_ad(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, int64_t act) { return DenseFn::apply(x, w, b, act); }
+Tensor dense_ad(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, int64_t act) { return DenseFn::apply(x, w, b, act)[0]; }
 std::tuple<Tensor, Tensor> radial_cutoff_ad(const Tensor& d, int64_t kind, const Tensor& p0, const c10::optional<Tensor>& p1, double cutoff,
                                             bool want_phi, bool want_cut) {
   auto r = RadialCutoffFn::apply(d, kind, p0, p1, cutoff, want_phi, want_cut);
@@ -1215,6 +1214,8 @@ TORCH_LIBRARY(spk_hip, m) {
   m.def("static_check() -> int", static_check_op);
   m.def("static_clear() -> ()", static_clear_op);
   m.def("clear_caches() -> ()", clear_caches_op);
+  // training regime: operators closed under differentiation (spk_torch_train.h)
+  train_defs(m);
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm devices in PyTorch-ROCm
@@ -1239,6 +1240,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm d
   m.impl("edge_plan", edge_plan_op);
   m.impl("static_declare", static_declare_op);
   m.impl("edge_plan_install", edge_plan_install_op);
+  train_impl_device(m);
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, Autograd, m) {
@@ -1251,6 +1253,7 @@ TORCH_LIBRARY_IMPL(spk_hip, Autograd, m) {
   m.impl("schnet", schnet_ad);
   m.impl("painn", painn_ad);
   m.impl("atomwise", atomwise_ad);
+  train_impl_autograd(m);
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, CPU, m) {
@@ -1258,6 +1261,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CPU, m) {
                            "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
                            "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
+  for (const char* name : kTrainOps) m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, Meta, m) {
@@ -1279,4 +1283,5 @@ TORCH_LIBRARY_IMPL(spk_hip, Meta, m) {
   m.impl("schnet_backward", schnet_backward_meta);
   m.impl("painn_backward", painn_backward_meta);
   m.impl("atomwise_backward", atomwise_backward_meta);
+  train_impl_meta(m);
 }

@@ -1,0 +1,511 @@
+// Operators of the training regime (included by spk_torch.cpp inside its anonymous namespace).
+//
+// Force matching differentiates every operator twice (atomistic/response.py:59-68, create_graph = training).  The operators
+// below wrap the kernel family of spk_train.hip, which is closed under differentiation: each backward is written in terms of
+// the same differentiable operators, so the recorded backward pass and the backward of THAT pass are again these HIP launches.
+// Argument order of every autograd Function: required tensors first, optional tensors next, plain values last -- the
+// needs_input_grad() index of a required tensor is then its position (optional tensors that are absent take no slot).
+
+// ------------------------------------------------------------------------------------------------ raw launchers
+Tensor act_mul_raw(const OptT& a_in, const Tensor& z_in, int64_t act, int64_t order, const OptT& c_in) {
+  Tensor z = f32(z_in, "act_mul"), a = opt_f32(a_in, "act_mul"), c = opt_f32(c_in, "act_mul");
+  TORCH_CHECK(!a.defined() || a.sizes() == z.sizes(), "act_mul: a ", a.sizes(), " and z ", z.sizes(), " differ in shape");
+  TORCH_CHECK(!c.defined() || c.sizes() == z.sizes(), "act_mul: c ", c.sizes(), " and z ", z.sizes(), " differ in shape");
+  c10::DeviceGuard guard(z.device());
+  Tensor out = at::empty_like(z);
+  check(spk_act_mul_f32(fp(a), fp(z), fp(c), z.numel(), (int32_t)act, (int32_t)order, fpm(out), stream_of(z)));
+  return out;
+}
+
+Tensor linear_raw(const Tensor& x, const Tensor& w, const OptT& b) { return std::get<0>(dense_raw(x, w, b, SPK_ACT_NONE)); }
+Tensor matmul_nn_raw(const Tensor& u, const Tensor& w) {
+  TORCH_CHECK(w.dim() == 2 && u.size(-1) == w.size(0), "matmul_nn: u ", u.sizes(), " and weight ", w.sizes(), " do not match");
+  return dense_bwd_input_raw(u, Tensor(), w, SPK_ACT_NONE);
+}
+
+// ticket counters of the split contraction (zero between launches: the kernel resets them)
+Tensor g_tn_tickets;
+std::tuple<Tensor, Tensor> matmul_tn_raw(const Tensor& u_in, const Tensor& x_in) {
+  Tensor u = f32(u_in, "matmul_tn"), x = f32(x_in, "matmul_tn");
+  const int64_t O = u.size(-1), K = x.size(-1);
+  TORCH_CHECK(O > 0 && K > 0, "matmul_tn: empty feature dimension");
+  const int64_t n = u.numel() / O;
+  TORCH_CHECK(x.numel() / K == n, "matmul_tn: u ", u.sizes(), " and x ", x.sizes(), " differ in their leading dimensions");
+  c10::DeviceGuard guard(u.device());
+  Tensor G = at::empty({O, K}, u.options()), cs = at::empty({O}, u.options());
+  int32_t S = 1, tiles = 0;
+  int64_t wsf = 0;
+  check(spk_gemm_tn_plan(n, (int32_t)O, (int32_t)K, &S, &wsf, &tiles));
+  Tensor ws;
+  if (S > 1) {
+    ws = at::empty({wsf}, u.options());
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (!g_tn_tickets.defined() || g_tn_tickets.device() != u.device()) g_tn_tickets = at::zeros({4096}, u.options().dtype(at::kInt));
+  }
+  check(spk_gemm_tn_f32(fp(u), fp(x), n, (int32_t)O, (int32_t)K, fpm(G), fpm(cs), fpm(ws), S > 1 ? (uint32_t*)g_tn_tickets.data_ptr<int32_t>() : nullptr,
+                        stream_of(u)));
+  return {G, cs};
+}
+
+Tensor cfconv_raw(const Tensor& x_in, const Tensor& W_in, const Tensor& idx_out_in, const Tensor& idx_src_in, int64_t n_out) {
+  Tensor x = f32(x_in, "cfconv"), W = f32(W_in, "cfconv");
+  Tensor io = i64(idx_out_in, "cfconv"), is = i64(idx_src_in, "cfconv");
+  TORCH_CHECK(x.dim() == 2 && W.dim() == 2 && x.size(1) == W.size(1), "cfconv: x ", x.sizes(), " and W ", W.sizes(), " must be [n, F] and [E, F]");
+  const int64_t E = W.size(0), F = W.size(1);
+  TORCH_CHECK(io.dim() == 1 && is.dim() == 1 && io.size(0) == E && is.size(0) == E, "cfconv: index tensors must have ", E, " entries");
+  c10::DeviceGuard guard(x.device());
+  Tensor y = at::empty({n_out, F}, x.options());
+  Tensor rp = E > 0 ? segment_rowptr(idx_out_in.scalar_type() == at::kLong && idx_out_in.is_contiguous() ? idx_out_in : io, n_out) : Tensor();
+  if (E == 0) y.zero_();
+  check(spk_cfconv_edge_f32(fp(x), fp(W), E ? io.data_ptr<int64_t>() : nullptr, E ? is.data_ptr<int64_t>() : nullptr,
+                            rp.defined() ? rp.data_ptr<int32_t>() : nullptr, E, n_out, x.size(0), (int32_t)F, fpm(y), stream_of(x)));
+  return y;
+}
+
+Tensor edge_mul_raw(const Tensor& a_in, const Tensor& b_in, const Tensor& ia_in, const Tensor& ib_in) {
+  Tensor a = f32(a_in, "edge_mul"), b = f32(b_in, "edge_mul");
+  Tensor ia = i64(ia_in, "edge_mul"), ib = i64(ib_in, "edge_mul");
+  TORCH_CHECK(a.dim() == 2 && b.dim() == 2 && a.size(1) == b.size(1), "edge_mul: a ", a.sizes(), " and b ", b.sizes(), " must share the feature dimension");
+  TORCH_CHECK(ia.dim() == 1 && ib.dim() == 1 && ia.size(0) == ib.size(0), "edge_mul: index tensors differ in length");
+  c10::DeviceGuard guard(a.device());
+  Tensor out = at::empty({ia.size(0), a.size(1)}, a.options());
+  check(spk_edge_mul_f32(fp(a), fp(b), ia.data_ptr<int64_t>(), ib.data_ptr<int64_t>(), ia.size(0), a.size(0), b.size(0), (int32_t)a.size(1), fpm(out),
+                         stream_of(a)));
+  return out;
+}
+
+spk_radial_t radial_k_of(int64_t kind, const Tensor& p0, const Tensor& p1, double cutoff) {
+  spk_radial_t rb = radial_of(kind, p0, p1, cutoff);
+  if (kind == 2) rb.n_rbf = 1;
+  return rb;
+}
+
+Tensor radial_d_raw(const Tensor& d_in, const OptT& a_in, int64_t kind, const Tensor& p0_in, const OptT& p1_in, double cutoff, int64_t order) {
+  Tensor d = f32(d_in, "radial_d"), a = opt_f32(a_in, "radial_d");
+  Tensor p0 = f32(p0_in, "radial_d"), p1 = opt_f32(p1_in, "radial_d");
+  TORCH_CHECK(!a.defined() || a.sizes() == d.sizes(), "radial_d: a ", a.sizes(), " and d ", d.sizes(), " differ in shape");
+  c10::DeviceGuard guard(d.device());
+  auto shape = d.sizes().vec();
+  if (kind != 2) shape.push_back(p0.size(0));
+  Tensor out = at::empty(shape, d.options());
+  spk_radial_t rb = radial_k_of(kind, p0, p1, cutoff);
+  check(spk_radial_d_f32(fp(d), fp(a), d.numel(), &rb, (int32_t)order, fpm(out), stream_of(d)));
+  return out;
+}
+
+Tensor radial_c_raw(const Tensor& G_in, const Tensor& d_in, const OptT& a_in, int64_t kind, const Tensor& p0_in, const OptT& p1_in, double cutoff,
+                    int64_t order) {
+  Tensor G = f32(G_in, "radial_c"), d = f32(d_in, "radial_c"), a = opt_f32(a_in, "radial_c");
+  Tensor p0 = f32(p0_in, "radial_c"), p1 = opt_f32(p1_in, "radial_c");
+  TORCH_CHECK(kind == 0 || kind == 1, "radial_c: kind ", kind, " has no basis dimension to contract");
+  TORCH_CHECK(G.dim() == d.dim() + 1 && G.size(-1) == p0.size(0) && G.numel() == d.numel() * p0.size(0), "radial_c: G ", G.sizes(), " does not match d ",
+              d.sizes(), " x n_rbf ", p0.size(0));
+  TORCH_CHECK(!a.defined() || a.sizes() == d.sizes(), "radial_c: a ", a.sizes(), " and d ", d.sizes(), " differ in shape");
+  c10::DeviceGuard guard(d.device());
+  Tensor out = at::empty_like(d);
+  spk_radial_t rb = radial_k_of(kind, p0, p1, cutoff);
+  check(spk_radial_c_f32(fp(G), fp(d), fp(a), d.numel(), &rb, (int32_t)order, fpm(out), stream_of(d)));
+  return out;
+}
+
+Tensor rowscale_raw(const Tensor& W_in, const Tensor& s_in) {
+  Tensor W = f32(W_in, "rowscale"), s = f32(s_in, "rowscale");
+  TORCH_CHECK(W.dim() >= 1 && W.size(-1) > 0 && s.numel() * W.size(-1) == W.numel(), "rowscale: W ", W.sizes(), " needs one scale per row, got ", s.sizes());
+  c10::DeviceGuard guard(W.device());
+  Tensor out = at::empty_like(W);
+  check(spk_rowscale_f32(fp(W), fp(s), s.numel(), (int32_t)W.size(-1), fpm(out), stream_of(W)));
+  return out;
+}
+
+Tensor rowdot_raw(const Tensor& a_in, const Tensor& b_in) {
+  Tensor a = f32(a_in, "rowdot"), b = f32(b_in, "rowdot");
+  TORCH_CHECK(a.sizes() == b.sizes() && a.dim() >= 1 && a.size(-1) > 0, "rowdot: a ", a.sizes(), " and b ", b.sizes(), " differ in shape");
+  c10::DeviceGuard guard(a.device());
+  auto shape = a.sizes().vec();
+  shape.pop_back();
+  Tensor out = at::empty(shape, a.options());
+  check(spk_rowdot_f32(fp(a), fp(b), out.numel(), (int32_t)a.size(-1), fpm(out), stream_of(a)));
+  return out;
+}
+
+Tensor edge_norm_raw(const Tensor& r_in) {
+  Tensor r = f32(r_in, "edge_norm");
+  TORCH_CHECK(r.dim() == 2 && r.size(1) == 3, "edge_norm: r_ij must be [E, 3], got ", r.sizes());
+  c10::DeviceGuard guard(r.device());
+  Tensor d = at::empty({r.size(0)}, r.options());
+  check(spk_edge_norm_f32(fp(r), r.size(0), fpm(d), nullptr, stream_of(r)));
+  return d;
+}
+
+// ------------------------------------------------------------------------------------------------ dispatcher handles
+Tensor call_act_mul(const OptT& a, const Tensor& z, int64_t act, int64_t order, const OptT& c) {
+  static auto op = op_handle<Tensor(const OptT&, const Tensor&, int64_t, int64_t, const OptT&)>("spk_hip::act_mul");
+  return op.call(a, z, act, order, c);
+}
+Tensor call_linear(const Tensor& x, const Tensor& w, const OptT& b) {
+  static auto op = op_handle<Tensor(const Tensor&, const Tensor&, const OptT&)>("spk_hip::linear");
+  return op.call(x, w, b);
+}
+Tensor call_matmul_nn(const Tensor& u, const Tensor& w) {
+  static auto op = op_handle<Tensor(const Tensor&, const Tensor&)>("spk_hip::matmul_nn");
+  return op.call(u, w);
+}
+std::tuple<Tensor, Tensor> call_matmul_tn(const Tensor& u, const Tensor& x) {
+  static auto op = op_handle<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&)>("spk_hip::matmul_tn");
+  return op.call(u, x);
+}
+Tensor call_cfconv(const Tensor& x, const Tensor& W, const Tensor& io, const Tensor& is, int64_t n_out) {
+  static auto op = op_handle<Tensor(const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t)>("spk_hip::cfconv");
+  return op.call(x, W, io, is, n_out);
+}
+Tensor call_edge_mul(const Tensor& a, const Tensor& b, const Tensor& ia, const Tensor& ib) {
+  static auto op = op_handle<Tensor(const Tensor&, const Tensor&, const Tensor&, const Tensor&)>("spk_hip::edge_mul");
+  return op.call(a, b, ia, ib);
+}
+Tensor call_radial_d(const Tensor& d, const OptT& a, int64_t kind, const Tensor& p0, const OptT& p1, double cutoff, int64_t order) {
+  static auto op = op_handle<Tensor(const Tensor&, const OptT&, int64_t, const Tensor&, const OptT&, double, int64_t)>("spk_hip::radial_d");
+  return op.call(d, a, kind, p0, p1, cutoff, order);
+}
+Tensor call_radial_c(const Tensor& G, const Tensor& d, const OptT& a, int64_t kind, const Tensor& p0, const OptT& p1, double cutoff, int64_t order) {
+  static auto op = op_handle<Tensor(const Tensor&, const Tensor&, const OptT&, int64_t, const Tensor&, const OptT&, double, int64_t)>("spk_hip::radial_c");
+  return op.call(G, d, a, kind, p0, p1, cutoff, order);
+}
+Tensor call_rowscale(const Tensor& W, const Tensor& s) {
+  static auto op = op_handle<Tensor(const Tensor&, const Tensor&)>("spk_hip::rowscale");
+  return op.call(W, s);
+}
+Tensor call_rowdot(const Tensor& a, const Tensor& b) {
+  static auto op = op_handle<Tensor(const Tensor&, const Tensor&)>("spk_hip::rowdot");
+  return op.call(a, b);
+}
+Tensor call_edge_norm(const Tensor& r) {
+  static auto op = op_handle<Tensor(const Tensor&)>("spk_hip::edge_norm");
+  return op.call(r);
+}
+
+// ------------------------------------------------------------------------------------------------ autograd
+// out = a . act^(k)(z) + c
+struct ActMulFn : public torch::autograd::Function<ActMulFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& z, const OptT& a, const OptT& c, int64_t act, int64_t order) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const bool has_a = a.has_value() && a->defined(), has_c = c.has_value() && c->defined();
+    ctx->save_for_backward({z, has_a ? *a : Tensor()});
+    ctx->saved_data["cfg"] = std::vector<int64_t>{act, order, has_a, has_c};
+    return call_act_mul(a, z, act, order, c);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    auto cfg = ctx->saved_data["cfg"].toIntVector();
+    const Tensor &z = sv[0], &a = sv[1];
+    const bool has_a = cfg[2] != 0, has_c = cfg[3] != 0;
+    Tensor gz, ga, gc;
+    if (ctx->needs_input_grad(0)) gz = call_act_mul(has_a ? OptT(at::mul(g[0], a)) : OptT(g[0]), z, cfg[0], cfg[1] + 1, c10::nullopt);
+    if (has_a && ctx->needs_input_grad(1)) ga = call_act_mul(g[0], z, cfg[0], cfg[1], c10::nullopt);
+    if (has_c && ctx->needs_input_grad(has_a ? 2 : 1)) gc = g[0];
+    return {gz, ga, gc, Tensor(), Tensor()};
+  }
+};
+
+struct LinearFn : public torch::autograd::Function<LinearFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const OptT& b) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({x, w});
+    ctx->saved_data["has_bias"] = b.has_value() && b->defined();
+    return call_linear(x, w, b);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    const bool need_b = ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2);
+    Tensor gx, gw, gb;
+    if (ctx->needs_input_grad(0)) gx = call_matmul_nn(g[0], sv[1]);
+    if (ctx->needs_input_grad(1) || need_b) {
+      auto r = call_matmul_tn(g[0], sv[0]);
+      gw = std::get<0>(r);
+      if (need_b) gb = std::get<1>(r);
+    }
+    return {gx, gw, gb};
+  }
+};
+
+// out = u w   (u [..., O], w [O, K])
+struct MatmulNNFn : public torch::autograd::Function<MatmulNNFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& u, const Tensor& w) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({u, w});
+    return call_matmul_nn(u, w);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    Tensor gu, gw;
+    if (ctx->needs_input_grad(0)) gu = call_linear(g[0], sv[1], c10::nullopt);
+    if (ctx->needs_input_grad(1)) gw = std::get<0>(call_matmul_tn(sv[0], g[0]));
+    return {gu, gw};
+  }
+};
+
+// (G, cs) = (u^T x, column sums of u)   over the flattened leading dimensions
+struct MatmulTNFn : public torch::autograd::Function<MatmulTNFn> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& u, const Tensor& x) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({u, x});
+    auto r = call_matmul_tn(u, x);
+    return {std::get<0>(r), std::get<1>(r)};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &u = sv[0], &x = sv[1];
+    Tensor gu, gx;
+    if (ctx->needs_input_grad(0)) {
+      if (g[0].defined()) gu = call_linear(x, g[0], c10::nullopt).reshape(u.sizes());
+      if (g[1].defined()) gu = gu.defined() ? gu + g[1] : g[1].expand_as(u);
+    }
+    if (ctx->needs_input_grad(1) && g[0].defined()) gx = call_matmul_nn(u, g[0]).reshape(x.sizes());
+    return {gu, gx};
+  }
+};
+
+// y[out_e] += x[src_e] . W_e
+struct CfconvFn : public torch::autograd::Function<CfconvFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& W, const Tensor& io, const Tensor& is, int64_t n_out) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({x, W, io, is});
+    return call_cfconv(x, W, io, is, n_out);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    Tensor gx, gW;
+    if (ctx->needs_input_grad(0)) gx = call_cfconv(g[0], sv[1], sv[3], sv[2], sv[0].size(0));
+    if (ctx->needs_input_grad(1)) gW = call_edge_mul(g[0], sv[0], sv[2], sv[3]);
+    return {gx, gW, Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// out_e = a[ia_e] . b[ib_e]
+struct EdgeMulFn : public torch::autograd::Function<EdgeMulFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& a, const Tensor& b, const Tensor& ia, const Tensor& ib) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({a, b, ia, ib});
+    return call_edge_mul(a, b, ia, ib);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    Tensor ga, gb;
+    if (ctx->needs_input_grad(0)) ga = call_cfconv(sv[1], g[0], sv[2], sv[3], sv[0].size(0));
+    if (ctx->needs_input_grad(1)) gb = call_cfconv(sv[0], g[0], sv[3], sv[2], sv[1].size(0));
+    return {ga, gb, Tensor(), Tensor()};
+  }
+};
+
+void check_fixed_basis(const Tensor& p0, const OptT& p1, const char* who) {
+  TORCH_CHECK(!p0.requires_grad() && !(p1.has_value() && p1->defined() && p1->requires_grad()), who,
+              ": the radial parameters are constants of this operator; trainable bases take the formula path of the module");
+}
+
+// out = a phi^(k)(d)
+struct RadialDFn : public torch::autograd::Function<RadialDFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& d, const Tensor& p0, const OptT& a, const OptT& p1, int64_t kind, double cutoff, int64_t order) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const bool has_a = a.has_value() && a->defined();
+    ctx->save_for_backward({d, p0, has_a ? *a : Tensor(), (p1.has_value() && p1->defined()) ? *p1 : Tensor()});
+    ctx->saved_data["cfg"] = std::vector<int64_t>{kind, order, has_a};
+    ctx->saved_data["cutoff"] = cutoff;
+    return call_radial_d(d, a, kind, p0, p1, cutoff, order);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    auto cfg = ctx->saved_data["cfg"].toIntVector();
+    const double cutoff = ctx->saved_data["cutoff"].toDouble();
+    const Tensor &d = sv[0], &p0 = sv[1], &a = sv[2];
+    const OptT p1 = opt_of(sv[3]);
+    const int64_t kind = cfg[0], k = cfg[1];
+    const bool has_a = cfg[2] != 0;
+    Tensor gd, ga;
+    if (kind == 2) {
+      if (ctx->needs_input_grad(0)) gd = call_radial_d(d, has_a ? OptT(at::mul(g[0], a)) : OptT(g[0]), kind, p0, p1, cutoff, k + 1);
+      if (has_a && ctx->needs_input_grad(2)) ga = call_radial_d(d, g[0], kind, p0, p1, cutoff, k);
+    } else {
+      if (ctx->needs_input_grad(0)) gd = call_radial_c(g[0], d, opt_of(a), kind, p0, p1, cutoff, k + 1);
+      if (has_a && ctx->needs_input_grad(2)) ga = call_radial_c(g[0], d, c10::nullopt, kind, p0, p1, cutoff, k);
+    }
+    return {gd, Tensor(), ga, Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// out = a sum_r G_r phi_r^(k)(d)
+struct RadialCFn : public torch::autograd::Function<RadialCFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& G, const Tensor& d, const Tensor& p0, const OptT& a, const OptT& p1, int64_t kind, double cutoff,
+                        int64_t order) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const bool has_a = a.has_value() && a->defined();
+    ctx->save_for_backward({G, d, p0, has_a ? *a : Tensor(), (p1.has_value() && p1->defined()) ? *p1 : Tensor()});
+    ctx->saved_data["cfg"] = std::vector<int64_t>{kind, order, has_a};
+    ctx->saved_data["cutoff"] = cutoff;
+    return call_radial_c(G, d, a, kind, p0, p1, cutoff, order);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    auto cfg = ctx->saved_data["cfg"].toIntVector();
+    const double cutoff = ctx->saved_data["cutoff"].toDouble();
+    const Tensor &G = sv[0], &d = sv[1], &p0 = sv[2], &a = sv[3];
+    const OptT p1 = opt_of(sv[4]);
+    const int64_t kind = cfg[0], k = cfg[1];
+    const bool has_a = cfg[2] != 0;
+    Tensor gG, gd, ga;
+    Tensor ag = has_a ? at::mul(g[0], a) : g[0];
+    if (ctx->needs_input_grad(0)) gG = call_radial_d(d, ag, kind, p0, p1, cutoff, k);
+    if (ctx->needs_input_grad(1)) gd = call_radial_c(G, d, ag, kind, p0, p1, cutoff, k + 1);
+    if (has_a && ctx->needs_input_grad(3)) ga = call_radial_c(G, d, g[0], kind, p0, p1, cutoff, k);
+    return {gG, gd, Tensor(), ga, Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+struct RowscaleFn : public torch::autograd::Function<RowscaleFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& W, const Tensor& s) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({W, s});
+    return call_rowscale(W, s);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    Tensor gW, gs;
+    if (ctx->needs_input_grad(0)) gW = call_rowscale(g[0], sv[1]);
+    if (ctx->needs_input_grad(1)) gs = call_rowdot(g[0], sv[0]).reshape(sv[1].sizes());
+    return {gW, gs};
+  }
+};
+struct RowdotFn : public torch::autograd::Function<RowdotFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& a, const Tensor& b) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({a, b});
+    return call_rowdot(a, b);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    Tensor ga, gb;
+    if (ctx->needs_input_grad(0)) ga = call_rowscale(sv[1], g[0]);
+    if (ctx->needs_input_grad(1)) gb = call_rowscale(sv[0], g[0]);
+    return {ga, gb};
+  }
+};
+
+// d = |r_ij|; dd/dr = r / d with d the node's own (differentiable) output
+struct EdgeNormFn : public torch::autograd::Function<EdgeNormFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& r) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    Tensor d = call_edge_norm(r);
+    ctx->save_for_backward({r, d});
+    return d;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    return {call_rowscale(sv[0], at::div(g[0], sv[1]))};
+  }
+};
+
+Tensor act_mul_ad(const OptT& a, const Tensor& z, int64_t act, int64_t order, const OptT& c) { return ActMulFn::apply(z, a, c, act, order); }
+Tensor linear_ad(const Tensor& x, const Tensor& w, const OptT& b) { return LinearFn::apply(x, w, b); }
+Tensor matmul_nn_ad(const Tensor& u, const Tensor& w) { return MatmulNNFn::apply(u, w); }
+std::tuple<Tensor, Tensor> matmul_tn_ad(const Tensor& u, const Tensor& x) {
+  auto r = MatmulTNFn::apply(u, x);
+  return {r[0], r[1]};
+}
+Tensor cfconv_ad(const Tensor& x, const Tensor& W, const Tensor& io, const Tensor& is, int64_t n_out) { return CfconvFn::apply(x, W, io, is, n_out); }
+Tensor edge_mul_ad(const Tensor& a, const Tensor& b, const Tensor& ia, const Tensor& ib) { return EdgeMulFn::apply(a, b, ia, ib); }
+Tensor radial_d_ad(const Tensor& d, const OptT& a, int64_t kind, const Tensor& p0, const OptT& p1, double cutoff, int64_t order) {
+  check_fixed_basis(p0, p1, "spk_hip::radial_d");
+  return RadialDFn::apply(d, p0, a, p1, kind, cutoff, order);
+}
+Tensor radial_c_ad(const Tensor& G, const Tensor& d, const OptT& a, int64_t kind, const Tensor& p0, const OptT& p1, double cutoff, int64_t order) {
+  check_fixed_basis(p0, p1, "spk_hip::radial_c");
+  return RadialCFn::apply(G, d, p0, a, p1, kind, cutoff, order);
+}
+Tensor rowscale_ad(const Tensor& W, const Tensor& s) { return RowscaleFn::apply(W, s); }
+Tensor rowdot_ad(const Tensor& a, const Tensor& b) { return RowdotFn::apply(a, b); }
+Tensor edge_norm_ad(const Tensor& r) { return EdgeNormFn::apply(r); }
+
+// ------------------------------------------------------------------------------------------------ Meta
+Tensor act_mul_meta(const OptT&, const Tensor& z, int64_t, int64_t, const OptT&) { return at::empty_like(z); }
+Tensor linear_meta(const Tensor& x, const Tensor& w, const OptT&) {
+  auto shape = x.sizes().vec();
+  shape.back() = w.size(0);
+  return at::empty(shape, x.options());
+}
+Tensor matmul_nn_meta(const Tensor& u, const Tensor& w) {
+  auto shape = u.sizes().vec();
+  shape.back() = w.size(1);
+  return at::empty(shape, u.options());
+}
+std::tuple<Tensor, Tensor> matmul_tn_meta(const Tensor& u, const Tensor& x) {
+  return {at::empty({u.size(-1), x.size(-1)}, u.options()), at::empty({u.size(-1)}, u.options())};
+}
+Tensor cfconv_meta(const Tensor& x, const Tensor& W, const Tensor&, const Tensor&, int64_t n_out) { return at::empty({n_out, W.size(1)}, x.options()); }
+Tensor edge_mul_meta(const Tensor& a, const Tensor&, const Tensor& ia, const Tensor&) { return at::empty({ia.size(0), a.size(1)}, a.options()); }
+Tensor radial_d_meta(const Tensor& d, const OptT&, int64_t kind, const Tensor& p0, const OptT&, double, int64_t) {
+  auto shape = d.sizes().vec();
+  if (kind != 2) shape.push_back(p0.size(0));
+  return at::empty(shape, d.options());
+}
+Tensor radial_c_meta(const Tensor&, const Tensor& d, const OptT&, int64_t, const Tensor&, const OptT&, double, int64_t) { return at::empty_like(d); }
+Tensor rowscale_meta(const Tensor& W, const Tensor&) { return at::empty_like(W); }
+Tensor rowdot_meta(const Tensor& a, const Tensor&) {
+  auto shape = a.sizes().vec();
+  shape.pop_back();
+  return at::empty(shape, a.options());
+}
+Tensor edge_norm_meta(const Tensor& r) { return at::empty({r.size(0)}, r.options()); }
+
+// ------------------------------------------------------------------------------------------------ registration
+const char* const kTrainOps[] = {"act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm"};
+
+void train_defs(torch::Library& m) {
+  m.def("act_mul(Tensor? a, Tensor z, int act, int order, Tensor? c=None) -> Tensor");                   // a . act^(order)(z) + c
+  m.def("linear(Tensor x, Tensor weight, Tensor? bias) -> Tensor");                                       // x W^T + b
+  m.def("matmul_nn(Tensor u, Tensor weight) -> Tensor");                                                  // u W
+  m.def("matmul_tn(Tensor u, Tensor x) -> (Tensor, Tensor)");                                             // (u^T x, column sums of u)
+  m.def("cfconv(Tensor x, Tensor W, Tensor idx_out, Tensor idx_src, int n_out) -> Tensor");               // schnet.py:64-66
+  m.def("edge_mul(Tensor a, Tensor b, Tensor idx_a, Tensor idx_b) -> Tensor");
+  m.def("radial_d(Tensor d, Tensor? a, int kind, Tensor p0, Tensor? p1, float cutoff, int order) -> Tensor");   // nn/radial.py, nn/cutoff.py, order-th derivative
+  m.def("radial_c(Tensor G, Tensor d, Tensor? a, int kind, Tensor p0, Tensor? p1, float cutoff, int order) -> Tensor");
+  m.def("rowscale(Tensor W, Tensor s) -> Tensor");                                                        // Wij * rcut_ij[:, None], schnet.py:61
+  m.def("rowdot(Tensor a, Tensor b) -> Tensor");
+  m.def("edge_norm(Tensor r_ij) -> Tensor");                                                              // torch.norm(r_ij, dim=1), schnet.py:156
+}
+void train_impl_device(torch::Library& m) {
+  m.impl("act_mul", act_mul_raw);
+  m.impl("linear", linear_raw);
+  m.impl("matmul_nn", matmul_nn_raw);
+  m.impl("matmul_tn", matmul_tn_raw);
+  m.impl("cfconv", cfconv_raw);
+  m.impl("edge_mul", edge_mul_raw);
+  m.impl("radial_d", radial_d_raw);
+  m.impl("radial_c", radial_c_raw);
+  m.impl("rowscale", rowscale_raw);
+  m.impl("rowdot", rowdot_raw);
+  m.impl("edge_norm", edge_norm_raw);
+}
+void train_impl_autograd(torch::Library& m) {
+  m.impl("act_mul", act_mul_ad);
+  m.impl("linear", linear_ad);
+  m.impl("matmul_nn", matmul_nn_ad);
+  m.impl("matmul_tn", matmul_tn_ad);
+  m.impl("cfconv", cfconv_ad);
+  m.impl("edge_mul", edge_mul_ad);
+  m.impl("radial_d", radial_d_ad);
+  m.impl("radial_c", radial_c_ad);
+  m.impl("rowscale", rowscale_ad);
+  m.impl("rowdot", rowdot_ad);
+  m.impl("edge_norm", edge_norm_ad);
+}
+void train_impl_meta(torch::Library& m) {
+  m.impl("act_mul", act_mul_meta);
+  m.impl("linear", linear_meta);
+  m.impl("matmul_nn", matmul_nn_meta);
+  m.impl("matmul_tn", matmul_tn_meta);
+  m.impl("cfconv", cfconv_meta);
+  m.impl("edge_mul", edge_mul_meta);
+  m.impl("radial_d", radial_d_meta);
+  m.impl("radial_c", radial_c_meta);
+  m.impl("rowscale", rowscale_meta);
+  m.impl("rowdot", rowdot_meta);
+  m.impl("edge_norm", edge_norm_meta);
+}

@@ -1,0 +1,418 @@
+// Primitives of the TRAINING regime (force matching: loss on -dE/dR => every operator is differentiated twice,
+// atomistic/response.py:59-68 with create_graph = training).
+//
+// The eval regime runs a whole representation in one or two launches; a training step cannot (its backward is itself
+// differentiated), so it is assembled from a small family of kernels that is CLOSED under differentiation -- the
+// derivative of each is another member, so the recorded backward and the backward of that backward are the same few
+// hand-written launches instead of chains of framework element-wise kernels and library GEMMs for 168-row operands:
+//
+//   act_mul        a . act^(k)(z) [+ c]                    d/da -> act_mul(k),          d/dz -> act_mul(k + 1)
+//   gemm_tn        U^T X  (+ column sums of U)             with the Dense kernels (x W^T, u W) closed under d/d(anything)
+//   cfconv_edge    y[out_e] += x[src_e] . W_e              d/dx -> cfconv_edge (roles swapped), d/dW -> edge_mul
+//   edge_mul       a[ia_e] . b[ib_e]                       d/da, d/db -> cfconv_edge
+//   radial_d       a_e phi_r^(k)(d_e)                      d/da -> radial_c(k),         d/dd -> radial_c(k + 1)
+//   radial_c       a_e sum_r G_er phi_r^(k)(d_e)           d/dG -> radial_d(k),         d/dd -> radial_c(k + 1)
+//   rowscale/rowdot  W_ef s_e  /  sum_f a_ef b_ef          each other's derivatives
+//
+// (schnet.py:54-69 = Dense, Dense, rowscale, cfconv_edge, Dense, Dense; nn/radial.py, nn/cutoff.py = radial_d.)
+#include "spk_common.h"
+
+// ------------------------------------------------------------------------------------------------ activations, order k
+// shifted softplus: ssp' = s, ssp'' = s(1-s), ssp''' = s(1-s)(1-2s), ssp'''' = s(1-s)(1-6s+6s^2)   (s = sigmoid)
+// silu = z s: silu' = s(1 + z(1-s)), silu'' = s(1-s)(2 + z(1-2s)), silu''' = s(1-s)(3(1-2s) + z(1-6s+6s^2))
+__device__ __forceinline__ float act_order(int act, int order, float z) {
+  if (act == SPK_ACT_NONE) return order == 0 ? z : (order == 1 ? 1.f : 0.f);
+  const float s = spk_sigmoid(z);
+  const float s1 = s * (1.f - s);
+  if (act == SPK_ACT_SSP) {
+    switch (order) {
+      case 0: return spk_ssp(z);
+      case 1: return s;
+      case 2: return s1;
+      case 3: return s1 * (1.f - 2.f * s);
+      default: return s1 * (1.f - 6.f * s + 6.f * s * s);
+    }
+  }
+  switch (order) {
+    case 0: return z * s;
+    case 1: return s * (1.f + z * (1.f - s));
+    case 2: return s1 * (2.f + z * (1.f - 2.f * s));
+    default: return s1 * (3.f * (1.f - 2.f * s) + z * (1.f - 6.f * s + 6.f * s * s));
+  }
+}
+
+__global__ void k_act_mul(const float* __restrict__ a, const float* __restrict__ z, const float* __restrict__ c, int64_t n, int act, int order,
+                          float* __restrict__ out) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    float v = act_order(act, order, z[t]);
+    if (a) v *= a[t];
+    if (c) v += c[t];
+    out[t] = v;
+  }
+}
+
+extern "C" int spk_act_mul_f32(const float* a, const float* z, const float* c, int64_t n, int32_t act, int32_t order, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(n >= 0 && act >= 0 && act <= 2, "spk_act_mul_f32: bad arguments");
+  SPK_CHECK_ARG(order >= 0 && order <= (act == SPK_ACT_SILU ? 3 : 4), "spk_act_mul_f32: derivative order %d not provided", order);
+  if (n == 0) return SPK_OK;
+  SPK_CHECK_ARG(z && out, "spk_act_mul_f32: null pointer");
+  SpkProfScope prof("act_mul", stream);
+  hipLaunchKernelGGL(k_act_mul, dim3(spk_grid_for(n, 256, spk_num_cus() * 16)), dim3(256), 0, stream, a, z, c, n, act, order, out);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ G = U^T X (weight gradients)
+// U [n, O], X [n, K] row-major, G [O, K]; the contraction runs over the n samples, so both MFMA operands are
+// lane-contiguous in memory as they lie (lane el of half hi holds U[n = 2s + hi][o0 + el] and X[2s + hi][k0 + el]).
+// One wave per (32 x 32 tile of G, slice of n); slices meet in a workspace and the LAST wave of a tile (ticket counter,
+// self-resetting) adds them in slice order -- deterministic, one launch.  Tiles with k0 == 0 also carry the column sums
+// of U (bias gradient).
+#define TN_BATCH 16
+__global__ __launch_bounds__(64) void k_gemm_tn(const float* __restrict__ U, const float* __restrict__ X, int64_t n, int O, int K, int tiles_k, int S,
+                                                int64_t rows_per_slice, float* __restrict__ G, float* __restrict__ gb, float* __restrict__ ws,
+                                                float* __restrict__ wsb, unsigned* __restrict__ tickets) {
+  const int lane = threadIdx.x, hi = lane >> 5, el = lane & 31;
+  const int tile = blockIdx.x, s = blockIdx.y;
+  const int to = tile / tiles_k, tk = tile % tiles_k;
+  const int o = 32 * to + el, k = 32 * tk + el;
+  const bool o_ok = o < O, k_ok = k < K;
+  const int64_t r0 = s * rows_per_slice;
+  const int64_t r1 = (r0 + rows_per_slice < n) ? r0 + rows_per_slice : n;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float usum = 0.f;
+  const float* up = U + (o_ok ? o : 0);
+  const float* xp = X + (k_ok ? k : 0);
+  for (int64_t rb = r0; rb < r1; rb += 2 * TN_BATCH) {
+    float av[TN_BATCH], bv[TN_BATCH];
+#pragma unroll
+    for (int q = 0; q < TN_BATCH; ++q) {
+      const int64_t row = rb + 2 * q + hi;
+      const bool ok = row < r1;
+      av[q] = (ok && o_ok) ? up[row * O] : 0.f;
+      bv[q] = (ok && k_ok) ? xp[row * K] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < TN_BATCH; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+      usum += av[q];
+    }
+  }
+  usum += __shfl_xor(usum, 32, 64);
+  const int Op = 32 * ((O + 31) / 32), Kp = 32 * tiles_k;
+  if (S == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oo = 32 * to + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (oo < O && k_ok) G[(int64_t)oo * K + k] = acc[r];
+    }
+    if (gb && tk == 0 && hi == 0 && o_ok) gb[o] = usum;
+    return;
+  }
+  float* wt = ws + ((int64_t)s * Op + 32 * to) * Kp + 32 * tk;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) wt[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * hi) * Kp + el] = acc[r];
+  if (gb && tk == 0 && hi == 0) wsb[(int64_t)s * Op + 32 * to + el] = usum;
+  __threadfence();
+  unsigned ticket = 0;
+  if (lane == 0) ticket = atomicAdd(&tickets[tile], 1u);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != (unsigned)(S - 1)) return;
+  __threadfence();
+  if (lane == 0) tickets[tile] = 0u;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    const int oo = 32 * to + rr;
+    float v = 0.f;
+    for (int q = 0; q < S; ++q) v += __builtin_nontemporal_load(ws + ((int64_t)q * Op + oo) * Kp + 32 * tk + el);
+    if (oo < O && k_ok) G[(int64_t)oo * K + k] = v;
+  }
+  if (gb && tk == 0 && hi == 0 && o_ok) {
+    float v = 0.f;
+    for (int q = 0; q < S; ++q) v += __builtin_nontemporal_load(wsb + (int64_t)q * Op + o);
+    gb[o] = v;
+  }
+}
+
+// slices / workspace sizes for a problem (host helper shared with the caller that allocates the workspace)
+extern "C" int spk_gemm_tn_plan(int64_t n, int32_t O, int32_t K, int32_t* n_slices, int64_t* ws_floats, int32_t* n_tiles) {
+  SPK_CHECK_ARG(n >= 0 && O > 0 && K > 0 && n_slices && ws_floats && n_tiles, "spk_gemm_tn_plan: bad arguments");
+  const int tiles = ((O + 31) / 32) * ((K + 31) / 32);
+  int64_t S = (n + 127) / 128;
+  const int64_t cap = (int64_t)(4 * spk_num_cus() * 4 / tiles);          // ~4 waves per SIMD over the chip
+  if (S > cap) S = cap;
+  if (S > 256) S = 256;
+  if (S < 1) S = 1;
+  *n_slices = (int32_t)S;
+  *n_tiles = tiles;
+  const int64_t Op = 32 * ((O + 31) / 32), Kp = 32 * ((K + 31) / 32);
+  *ws_floats = S > 1 ? S * Op * (Kp + 1) : 0;
+  return SPK_OK;
+}
+
+extern "C" int spk_gemm_tn_f32(const float* U, const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, float* ws, uint32_t* tickets,
+                               void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int32_t S, tiles;
+  int64_t wsf;
+  int rc = spk_gemm_tn_plan(n, O, K, &S, &wsf, &tiles);
+  if (rc) return rc;
+  SPK_CHECK_ARG(G != nullptr && (n == 0 || (U && X)), "spk_gemm_tn_f32: null pointer");
+  SPK_CHECK_ARG(S == 1 || (ws && tickets), "spk_gemm_tn_f32: workspace / ticket buffer required for %d slices", S);
+  SPK_CHECK_ARG(tiles <= 4096, "spk_gemm_tn_f32: %d output tiles (max 4096)", tiles);
+  SpkProfScope prof("gemm_tn", stream);
+  const int64_t Op = 32 * ((O + 31) / 32), Kp = 32 * ((K + 31) / 32);
+  int64_t rps = (n + S - 1) / S;
+  rps += rps & 1;                                                       // whole MFMA steps per slice
+  if (rps < 2) rps = 2;
+  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(64), 0, stream, U, X, n, O, K, (K + 31) / 32, S, rps, G, gb, ws, ws ? ws + (int64_t)S * Op * Kp : nullptr,
+                     (unsigned*)tickets);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ cfconv on materialised filters
+// y[out_e, :] += x[src_e, :] . W[e, :]   (schnet.py:64-66: x_j * Wij, scatter_add over idx_i)
+template <int V>
+__global__ void k_cfconv_rows(const float* __restrict__ x, const float* __restrict__ W, const int32_t* __restrict__ rowptr, const int64_t* __restrict__ src,
+                              int64_t n_out, int64_t n_src, int F, float* __restrict__ y) {
+  const int FV = F / V;
+  const int64_t total = n_out * FV;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / FV;
+    const int c = (int)(t % FV) * V;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    const int e1 = rowptr[row + 1];
+    for (int e = rowptr[row]; e < e1; ++e) {
+      const int64_t j = src[e];
+      if ((uint64_t)j >= (uint64_t)n_src) continue;
+      if (V == 4) {
+        const f32x4 xv = *(const f32x4*)(x + j * F + c), wv = *(const f32x4*)(W + (int64_t)e * F + c);
+        acc[0] = fmaf(xv.x, wv.x, acc[0]); acc[1 % V] = fmaf(xv.y, wv.y, acc[1 % V]);
+        acc[2 % V] = fmaf(xv.z, wv.z, acc[2 % V]); acc[3 % V] = fmaf(xv.w, wv.w, acc[3 % V]);
+      } else {
+        acc[0] = fmaf(x[j * F + c], W[(int64_t)e * F + c], acc[0]);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) y[row * F + c + v] = acc[v];
+  }
+}
+
+__global__ void k_cfconv_atomic(const float* __restrict__ x, const float* __restrict__ W, const int64_t* __restrict__ out, const int64_t* __restrict__ src,
+                                int64_t E, int64_t n_out, int64_t n_src, int F, float* __restrict__ y) {
+  const int64_t total = E * F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = t / F;
+    const int f = (int)(t % F);
+    const int64_t i = out[e], j = src[e];
+    if ((uint64_t)i >= (uint64_t)n_out || (uint64_t)j >= (uint64_t)n_src) continue;
+    unsafeAtomicAdd(y + i * F + f, x[j * F + f] * W[t]);
+  }
+}
+
+extern "C" int spk_cfconv_edge_f32(const float* x, const float* W, const int64_t* idx_out, const int64_t* idx_src, const int32_t* rowptr_out, int64_t E,
+                                   int64_t n_out, int64_t n_src, int32_t F, float* y, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(E >= 0 && n_out >= 0 && n_src >= 0 && F > 0, "spk_cfconv_edge_f32: bad sizes");
+  if (n_out == 0) return SPK_OK;
+  SPK_CHECK_ARG(y != nullptr, "spk_cfconv_edge_f32: null output");
+  SPK_CHECK_ARG(E == 0 || (x && W && idx_out && idx_src), "spk_cfconv_edge_f32: null pointer");
+  SPK_CHECK_ARG(E < (1ll << 31), "spk_cfconv_edge_f32: more than 2^31 pairs");
+  SpkProfScope prof("cfconv_edge", stream);
+  const int maxb = spk_num_cus() * 16;
+  if (rowptr_out) {
+    const bool v4 = (F % 4 == 0) && (((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0);
+    if (v4) hipLaunchKernelGGL(k_cfconv_rows<4>, dim3(spk_grid_for(n_out * (F / 4), 256, maxb)), dim3(256), 0, stream, x, W, rowptr_out, idx_src, n_out, n_src, F, y);
+    else hipLaunchKernelGGL(k_cfconv_rows<1>, dim3(spk_grid_for(n_out * F, 256, maxb)), dim3(256), 0, stream, x, W, rowptr_out, idx_src, n_out, n_src, F, y);
+  } else {
+    int rc = spk_zero_async(y, (size_t)n_out * F * sizeof(float), stream);
+    if (rc) return rc;
+    if (E > 0) hipLaunchKernelGGL(k_cfconv_atomic, dim3(spk_grid_for(E * F, 256, maxb)), dim3(256), 0, stream, x, W, idx_out, idx_src, E, n_out, n_src, F, y);
+  }
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// out[e, :] = a[ia_e, :] . b[ib_e, :]
+template <int V>
+__global__ void k_edge_mul(const float* __restrict__ a, const float* __restrict__ b, const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
+                           int64_t E, int64_t na, int64_t nb, int F, float* __restrict__ out) {
+  const int FV = F / V;
+  const int64_t total = E * FV;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = t / FV;
+    const int c = (int)(t % FV) * V;
+    const int64_t i = ia[e], j = ib[e];
+    const bool ok = (uint64_t)i < (uint64_t)na && (uint64_t)j < (uint64_t)nb;
+    if (V == 4) {
+      f32x4 o{0.f, 0.f, 0.f, 0.f};
+      if (ok) o = *(const f32x4*)(a + i * F + c) * *(const f32x4*)(b + j * F + c);
+      *(f32x4*)(out + e * F + c) = o;
+    } else {
+      out[e * F + c] = ok ? a[i * F + c] * b[j * F + c] : 0.f;
+    }
+  }
+}
+
+extern "C" int spk_edge_mul_f32(const float* a, const float* b, const int64_t* idx_a, const int64_t* idx_b, int64_t E, int64_t na, int64_t nb, int32_t F,
+                                float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(E >= 0 && na >= 0 && nb >= 0 && F > 0, "spk_edge_mul_f32: bad sizes");
+  if (E == 0) return SPK_OK;
+  SPK_CHECK_ARG(a && b && idx_a && idx_b && out, "spk_edge_mul_f32: null pointer");
+  SpkProfScope prof("edge_mul", stream);
+  const int maxb = spk_num_cus() * 16;
+  const bool v4 = (F % 4 == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0);
+  if (v4) hipLaunchKernelGGL(k_edge_mul<4>, dim3(spk_grid_for(E * (F / 4), 256, maxb)), dim3(256), 0, stream, a, b, idx_a, idx_b, E, na, nb, F, out);
+  else hipLaunchKernelGGL(k_edge_mul<1>, dim3(spk_grid_for(E * F, 256, maxb)), dim3(256), 0, stream, a, b, idx_a, idx_b, E, na, nb, F, out);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ radial functions, order k
+// kind 0: Gaussian exp(c t^2), t = d - mu, c = -1/(2 w^2)   (nn/radial.py:11-15)
+// kind 1: Bessel sin(f d) / d                                (nn/radial.py:105-110; value 0 at d = 0 like the reference's guard)
+// kind 2: cosine cutoff 0.5 (cos(pi d / rc) + 1) [d < rc]    (nn/cutoff.py:14-33), one "basis function"
+__device__ __forceinline__ float radial_order(const RadialDev& rb, int r, int order, float d) {
+  if (rb.kind == SPK_RBF_GAUSSIAN) {
+    const float w = rb.p1[r];
+    const float c = -0.5f / (w * w);
+    const float t = d - rb.p0[r];
+    const float phi = expf(c * t * t);
+    const float u = 2.f * c * t;                 // phi' / phi
+    switch (order) {
+      case 0: return phi;
+      case 1: return u * phi;
+      case 2: return (2.f * c + u * u) * phi;
+      default: return (6.f * c * u + u * u * u) * phi;
+    }
+  }
+  if (rb.kind == SPK_RBF_BESSEL) {
+    if (d == 0.f) return 0.f;
+    const float f = rb.p0[r];
+    float s, co;
+    sincosf(f * d, &s, &co);
+    const float q = 1.f / d;
+    switch (order) {
+      case 0: return s * q;
+      case 1: return (f * co - s * q) * q;
+      case 2: return ((2.f * q * q - f * f) * s - 2.f * f * q * co) * q;
+      default: return ((6.f * q * q - f * f) * f * co + (3.f * f * f - 6.f * q * q) * q * s) * q;
+    }
+  }
+  if (!(d < rb.cutoff)) return 0.f;
+  const float a = SPK_PI_F / rb.cutoff;
+  float s, co;
+  sincosf(a * d, &s, &co);
+  switch (order) {
+    case 0: return 0.5f * (co + 1.f);
+    case 1: return -0.5f * a * s;
+    case 2: return -0.5f * a * a * co;
+    default: return 0.5f * a * a * a * s;
+  }
+}
+
+__global__ void k_radial_d(const float* __restrict__ d, const float* __restrict__ a, int64_t n, RadialDev rb, int R, int order, float* __restrict__ out) {
+  const int64_t total = n * R;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = t / R;
+    float v = radial_order(rb, (int)(t % R), order, d[e]);
+    if (a) v *= a[e];
+    out[t] = v;
+  }
+}
+
+__global__ void k_radial_c(const float* __restrict__ G, const float* __restrict__ d, const float* __restrict__ a, int64_t n, RadialDev rb, int R, int order,
+                           float* __restrict__ out) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float dd = d[e];
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) acc = fmaf(G[e * R + r], radial_order(rb, r, order, dd), acc);
+    out[e] = a ? acc * a[e] : acc;
+  }
+}
+
+static int check_radial_k(const spk_radial_t* rb, int order, const char* who) {
+  SPK_CHECK_ARG(rb != nullptr, "%s: null radial description", who);
+  SPK_CHECK_ARG(rb->kind >= 0 && rb->kind <= 2, "%s: unknown radial kind %d", who, rb->kind);
+  SPK_CHECK_ARG(order >= 0 && order <= 3, "%s: derivative order %d not provided", who, order);
+  if (rb->kind == 2) {
+    SPK_CHECK_ARG(rb->cutoff > 0.f, "%s: cutoff must be positive", who);
+  } else {
+    SPK_CHECK_ARG(rb->n_rbf >= 1 && rb->n_rbf <= 1024, "%s: n_rbf=%d unsupported", who, rb->n_rbf);
+    SPK_CHECK_ARG(rb->p0 != nullptr && (rb->kind == SPK_RBF_BESSEL || rb->p1 != nullptr), "%s: null rbf parameters", who);
+  }
+  return SPK_OK;
+}
+
+extern "C" int spk_radial_d_f32(const float* d, const float* a, int64_t n, const spk_radial_t* rb, int32_t order, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_radial_k(rb, order, "spk_radial_d_f32");
+  if (rc) return rc;
+  if (n <= 0) return SPK_OK;
+  SPK_CHECK_ARG(d && out, "spk_radial_d_f32: null pointer");
+  SpkProfScope prof("radial_d", stream);
+  const int R = rb->kind == 2 ? 1 : rb->n_rbf;
+  hipLaunchKernelGGL(k_radial_d, dim3(spk_grid_for(n * R, 256, spk_num_cus() * 16)), dim3(256), 0, stream, d, a, n, spk_radial_dev(rb), R, order, out);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_radial_c_f32(const float* G, const float* d, const float* a, int64_t n, const spk_radial_t* rb, int32_t order, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_radial_k(rb, order, "spk_radial_c_f32");
+  if (rc) return rc;
+  if (n <= 0) return SPK_OK;
+  SPK_CHECK_ARG(G && d && out, "spk_radial_c_f32: null pointer");
+  SpkProfScope prof("radial_c", stream);
+  const int R = rb->kind == 2 ? 1 : rb->n_rbf;
+  hipLaunchKernelGGL(k_radial_c, dim3(spk_grid_for(n, 256, spk_num_cus() * 16)), dim3(256), 0, stream, G, d, a, n, spk_radial_dev(rb), R, order, out);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ row scale / row dot
+__global__ void k_rowscale(const float* __restrict__ W, const float* __restrict__ s, int64_t rows, int F, float* __restrict__ out) {
+  const int64_t total = rows * F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) out[t] = W[t] * s[t / F];
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ a, const float* __restrict__ b, int64_t rows, int F, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    float acc = 0.f;
+    for (int f = lane; f < F; f += 64) acc = fmaf(a[row * F + f], b[row * F + f], acc);
+    acc = spk_wave_sum(acc);
+    if (lane == 0) out[row] = acc;
+  }
+}
+
+extern "C" int spk_rowscale_f32(const float* W, const float* s, int64_t rows, int32_t F, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(rows >= 0 && F > 0, "spk_rowscale_f32: bad sizes");
+  if (rows == 0) return SPK_OK;
+  SPK_CHECK_ARG(W && s && out, "spk_rowscale_f32: null pointer");
+  SpkProfScope prof("rowscale", stream);
+  hipLaunchKernelGGL(k_rowscale, dim3(spk_grid_for(rows * F, 256, spk_num_cus() * 16)), dim3(256), 0, stream, W, s, rows, F, out);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_rowdot_f32(const float* a, const float* b, int64_t rows, int32_t F, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(rows >= 0 && F > 0, "spk_rowdot_f32: bad sizes");
+  if (rows == 0) return SPK_OK;
+  SPK_CHECK_ARG(a && b && out, "spk_rowdot_f32: null pointer");
+  SpkProfScope prof("rowdot", stream);
+  hipLaunchKernelGGL(k_rowdot, dim3(spk_grid_for(rows, 4, spk_num_cus() * 16)), dim3(256), 0, stream, a, b, rows, F, out);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

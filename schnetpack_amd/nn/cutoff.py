@@ -11,7 +11,7 @@ __all__ = ["CosineCutoff", "cosine_cutoff"]
 
 
 def cosine_cutoff(input: torch.Tensor, cutoff: torch.Tensor):
-    """0.5 (cos(pi d / rc) + 1) [d < rc] -- differentiable torch formula (training path)."""
+    """0.5 (cos(pi d / rc) + 1) [d < rc] -- the torch formula, on the tensor's own device (functional form of the reference)."""
     input_cut = 0.5 * (torch.cos(input * math.pi / cutoff) + 1.0)
     return input_cut * (input < cutoff).float()
 
@@ -39,8 +39,9 @@ class CosineCutoff(nn.Module):
             self._cutoff_host = float(self.cutoff.item())
 
     def forward(self, input: torch.Tensor):
-        if self.training and torch.is_grad_enabled() and input.requires_grad:
-            return cosine_cutoff(input, self.cutoff)
         p1: Optional[torch.Tensor] = None
+        if self.training and torch.is_grad_enabled() and input.requires_grad:
+            # differentiable to the third order on the device (force training differentiates twice)
+            return torch.ops.spk_hip.radial_d(input, None, 2, self.cutoff, p1, self._cutoff_host, 0)
         # (the kernel ignores p0/p1 when phi is not requested: any fp32 device tensor will do)
         return torch.ops.spk_hip.radial_cutoff(input, 1, self.cutoff, p1, self._cutoff_host, False, True)[1]

@@ -21,8 +21,8 @@ def gaussian_rbf(inputs: torch.Tensor, offsets: torch.Tensor, widths: torch.Tens
 
 class GaussianRBF(nn.Module):
     r"""Gaussian radial basis functions; buffers/params ``widths``, ``offsets``, attr ``n_rbf``.
-    Eval: HIP kernel (first-order backward on the device); training (double backward) or trainable
-    basis parameters: the differentiable torch formula."""
+    Eval: HIP kernel with a fused first-order backward; training (force loss => double backward): the HIP operator
+    ``radial_d`` whose derivatives of every order are again HIP launches; trainable basis parameters: the torch formula."""
 
     def __init__(self, n_rbf: int, cutoff: float, start: float = 0.0, trainable: bool = False):
         super().__init__()
@@ -47,8 +47,10 @@ class GaussianRBF(nn.Module):
         return 0, self.offsets, self.widths
 
     def forward(self, inputs: torch.Tensor):
-        if self.trainable or (self.training and torch.is_grad_enabled() and inputs.requires_grad):
+        if self.trainable:
             return gaussian_rbf(inputs, self.offsets, self.widths)
+        if self.training and torch.is_grad_enabled() and inputs.requires_grad:
+            return torch.ops.spk_hip.radial_d(inputs, None, 0, self.offsets, self.widths, 1.0, 0)
         return torch.ops.spk_hip.radial_cutoff(inputs, 0, self.offsets, self.widths, 1.0, True, False)[0]
 
 
@@ -67,11 +69,9 @@ class BesselRBF(nn.Module):
         return 1, self.freqs, p1
 
     def forward(self, inputs: torch.Tensor):
-        if self.training and torch.is_grad_enabled() and inputs.requires_grad:
-            ax = inputs[..., None] * self.freqs
-            norm = torch.where(inputs == 0, torch.ones_like(inputs), inputs)
-            return torch.sin(ax) / norm[..., None]
         p1: Optional[torch.Tensor] = None
+        if self.training and torch.is_grad_enabled() and inputs.requires_grad:
+            return torch.ops.spk_hip.radial_d(inputs, None, 1, self.freqs, p1, 1.0, 0)
         return torch.ops.spk_hip.radial_cutoff(inputs, 1, self.freqs, p1, 1.0, True, False)[0]
 
 

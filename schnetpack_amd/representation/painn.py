@@ -173,11 +173,11 @@ class PaiNN(nn.Module):
             q, mu = torch.ops.spk_hip.painn(q, r_ij, idx_i, idx_j, ws, self.share_filters, self.epsilon, kind, p0, p1,
                                             self.cutoff_fn.cutoff_value())
         else:
-            d_ij = torch.norm(r_ij, dim=1, keepdim=True)
+            d_ij = torch.ops.spk_hip.edge_norm(r_ij).unsqueeze(1)
             dir_ij = r_ij / d_ij
             phi_ij = self.radial_basis(d_ij)
             fcut = self.cutoff_fn(d_ij)
-            filters = self.filter_net(phi_ij) * fcut[..., None]
+            filters = torch.ops.spk_hip.rowscale(self.filter_net(phi_ij), fcut)    # filter_net(phi_ij) * fcut[..., None]
             if self.share_filters:
                 filter_list = [filters] * self.n_interactions
             else:

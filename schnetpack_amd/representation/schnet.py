@@ -5,7 +5,8 @@ gfx950 kernels: same class names, constructor signatures, attributes and ``state
 (in2f -> fused cfconv (RBF x cutoff x filter MLP x gather x segmented sum, no [E, F] tensor) -> f2out, for every
 interaction; one C call forward, one C call for the first-order backward w.r.t. ``_Rij`` and the embedding rows --
 what ``Forces`` asks for).  In training mode (force loss => double backward) it runs the differentiable primitive
-path: HIP Dense / gather / scatter_add with torch elementwise algebra.  Both are TorchScript-able
+path: HIP operators that are closed under differentiation (Dense, radial functions, ``rowscale``, ``cfconv``; csrc/spk_train.hip),
+so the recorded backward and its backward are HIP launches too.  Both are TorchScript-able
 (reference tests/nn/test_schnet.py:83-96).
 """
 from typing import Callable, Dict, Final, List, Optional, Union
@@ -16,7 +17,7 @@ from torch import nn
 from .. import _lib
 from .. import properties
 from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
-from ..nn import Dense, scatter_add
+from ..nn import Dense
 from ..nn import replicate_module
 from ..nn.activations import shifted_softplus
 from ..nn.base import activation_id
@@ -54,10 +55,8 @@ class SchNetInteraction(nn.Module):
                 idx_j: torch.Tensor, rcut_ij: torch.Tensor):
         x = self.in2f(x)
         Wij = self.filter_network(f_ij)
-        Wij = Wij * rcut_ij[:, None]
-        x_j = torch.ops.spk_hip.gather(x, idx_j, 0)
-        x_ij = x_j * Wij
-        x = scatter_add(x_ij, idx_i, dim_size=x.shape[0])
+        Wij = torch.ops.spk_hip.rowscale(Wij, rcut_ij)                             # Wij * rcut_ij[:, None]
+        x = torch.ops.spk_hip.cfconv(x, Wij, idx_i, idx_j, x.shape[0])              # scatter_add(x[idx_j] * Wij, idx_i)
         return self.f2out(x)
 
 
@@ -128,7 +127,7 @@ class SchNet(nn.Module):
             kind, p0, p1 = self.radial_basis.kernel_params()
             x = torch.ops.spk_hip.schnet(x, r_ij, idx_i, idx_j, ws, self.n_filters, kind, p0, p1, self.cutoff_fn.cutoff_value())
         else:
-            d_ij = torch.norm(r_ij, dim=1)
+            d_ij = torch.ops.spk_hip.edge_norm(r_ij)
             f_ij = self.radial_basis(d_ij)
             rcut_ij = self.cutoff_fn(d_ij)
             for interaction in self.interactions:

@@ -1,0 +1,138 @@
+"""The kernels of the training regime (csrc/spk_train.hip and the masked Dense tiles) against the float64 formulas of
+tests/cpu_reference_kernels.py (evaluated on the host), through ``torch.ops.spk_hip`` -- values, then first and second
+derivatives through the operators' own autograd, on the shapes a SchNet / PaiNN training step produces (168 atoms, 2.4 k pairs,
+widths 20 / 64 / 128 / 1) and on awkward ones."""
+import pytest
+import torch
+
+import cpu_reference_kernels as crk
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+ops = torch.ops.spk_hip
+TOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def rnd(*s, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(s))
+    return torch.randn(*s, generator=g)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+def test_act_mul(dev, act, order):
+    z, a, c = 3 * rnd(777, 33), rnd(777, 33, seed=1), rnd(777, 33, seed=2)
+    ref = crk.act_mul(a.double(), z.double(), act, order, c.double())
+    got = ops.act_mul(a.to(dev), z.to(dev), act, order, c.to(dev))
+    assert rel_err(got.cpu(), ref) < TOL
+    assert rel_err(ops.act_mul(None, z.to(dev), act, order).cpu(), crk.act_mul(None, z.double(), act, order)) < TOL or (act == 0 and order >= 2)
+
+
+@pytest.mark.parametrize("n,k,o", [(168, 128, 128), (2432, 20, 128), (2432, 128, 20), (168, 64, 1), (168, 1, 64), (5, 12, 36), (1000, 132, 100), (70, 128, 1152)])
+def test_linear_and_matmul_nn_any_width(dev, n, k, o):
+    """x W^T + b and u W on the MFMA tiles for widths that are multiples of 4 (masked partial tiles) and on the simple kernel
+    otherwise."""
+    x, w, b, u = rnd(n, k), rnd(o, k, seed=1) / k ** 0.5, rnd(o, seed=2), rnd(n, o, seed=3)
+    assert rel_err(ops.linear(x.to(dev), w.to(dev), b.to(dev)).cpu(), x.double() @ w.double().t() + b.double()) < TOL
+    assert rel_err(ops.linear(x.to(dev), w.to(dev), None).cpu(), x.double() @ w.double().t()) < TOL
+    assert rel_err(ops.matmul_nn(u.to(dev), w.to(dev)).cpu(), u.double() @ w.double()) < TOL
+    for act in (1, 2):
+        y = ops.dense(x.to(dev), w.to(dev), b.to(dev), act)
+        assert rel_err(y.cpu(), crk.act_order(x.double() @ w.double().t() + b.double(), act, 0)) < TOL
+
+
+@pytest.mark.parametrize("n,o,k", [(168, 128, 128), (2432, 128, 20), (2432, 20, 128), (168, 1, 64), (168, 64, 1), (1, 5, 7), (7, 33, 65), (20000, 128, 128), (3, 1152, 20)])
+def test_matmul_tn(dev, n, o, k):
+    u, x = rnd(n, o), rnd(n, k, seed=1)
+    G, cs = ops.matmul_tn(u.to(dev), x.to(dev))
+    assert rel_err(G.cpu(), u.double().t() @ x.double()) < TOL
+    assert rel_err(cs.cpu(), u.double().sum(0)) < TOL
+    G2, cs2 = ops.matmul_tn(u.to(dev), x.to(dev))          # tickets were left clean; slices are added in a fixed order
+    assert torch.equal(G, G2) and torch.equal(cs, cs2)
+
+
+def _lists(n_atoms, E, seed):
+    g = torch.Generator().manual_seed(seed)
+    ii = torch.randint(0, n_atoms, (E,), generator=g).sort().values
+    jj = torch.randint(0, n_atoms, (E,), generator=g)
+    return ii, jj
+
+
+@pytest.mark.parametrize("N,E,F", [(168, 2432, 128), (50, 300, 20), (9, 0, 8), (33, 100, 7)])
+def test_cfconv_and_edge_mul(dev, N, E, F):
+    ii, jj = _lists(N, E, 3)
+    x, W, a = rnd(N, F), rnd(E, F, seed=1), rnd(N, F, seed=2)
+    ref = crk.cfconv(x.double(), W.double(), ii, jj, N)
+    torch.ops.spk_hip.clear_caches()
+    got = ops.cfconv(x.to(dev), W.to(dev), ii.to(dev), jj.to(dev), N)                 # ascending output index: segmented sum
+    assert rel_err(got.cpu(), ref) < TOL or E == 0
+    assert E > 0 or float(got.abs().max()) == 0.0
+    got_t = ops.cfconv(x.to(dev), W.to(dev), jj.to(dev), ii.to(dev), N)               # unsorted output index: atomics
+    assert rel_err(got_t.cpu(), crk.cfconv(x.double(), W.double(), jj, ii, N)) < TOL or E == 0
+    if E:
+        assert rel_err(ops.edge_mul(a.to(dev), x.to(dev), ii.to(dev), jj.to(dev)).cpu(), a.double()[ii] * x.double()[jj]) < TOL
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+def test_radial_functions_and_their_derivatives(dev, kind, order):
+    R = 20
+    d = torch.rand(3000, generator=torch.Generator().manual_seed(5)) * 5.5 + 0.4        # some pairs beyond the cutoff
+    a, G = rnd(3000), rnd(3000, R, seed=1)
+    p0 = torch.linspace(0.0, 5.0, R) if kind == 0 else torch.arange(1, R + 1) * torch.pi / 5.0
+    p1 = torch.full((R,), 5.0 / (R - 1)) if kind == 0 else None
+    ref = crk.radial_d(d.double(), a.double(), kind, p0.double(), None if p1 is None else p1.double(), 5.0, order)
+    got = ops.radial_d(d.to(dev), a.to(dev), kind, p0.to(dev), None if p1 is None else p1.to(dev), 5.0, order)
+    assert got.shape == ref.shape and rel_err(got.cpu(), ref) < 5e-6
+    if kind != 2:
+        ref = crk.radial_c(G.double(), d.double(), a.double(), kind, p0.double(), None if p1 is None else p1.double(), 5.0, order)
+        got = ops.radial_c(G.to(dev), d.to(dev), a.to(dev), kind, p0.to(dev), None if p1 is None else p1.to(dev), 5.0, order)
+        assert rel_err(got.cpu(), ref) < 5e-6
+
+
+def test_rowscale_rowdot_edge_norm(dev):
+    W, s, b = rnd(2432, 128), rnd(2432, seed=1), rnd(2432, 128, seed=2)
+    assert rel_err(ops.rowscale(W.to(dev), s.to(dev)).cpu(), W.double() * s.double()[:, None]) < TOL
+    assert rel_err(ops.rowdot(W.to(dev), b.to(dev)).cpu(), (W.double() * b.double()).sum(1)) < TOL
+    W3 = rnd(100, 1, 36)
+    assert rel_err(ops.rowscale(W3.to(dev), s[:100, None].to(dev)).cpu(), W3.double() * s[:100, None, None].double()) < TOL
+    r = rnd(999, 3)
+    assert rel_err(ops.edge_norm(r.to(dev)).cpu(), r.double().norm(dim=1)) < TOL
+
+
+def test_second_derivatives_on_the_device(dev):
+    """One interaction's worth of the family chained on the device: d -> (phi, f_c) -> filter Dense -> rowscale -> cfconv ->
+    Dense; the gradient w.r.t. d is taken with create_graph and a function of it is differentiated w.r.t. the weights --
+    against the same chain on float64 torch formulas."""
+    N, E, F, R = 60, 700, 64, 20
+    ii, jj = _lists(N, E, 11)
+    d0 = torch.rand(E, generator=torch.Generator().manual_seed(1)) * 4.5 + 0.5
+    x0, w1, b1, w2 = rnd(N, F), rnd(F, R) / R ** 0.5, rnd(F, seed=1) * 0.1, rnd(F, F, seed=2) / F ** 0.5
+    p0, p1 = torch.linspace(0.0, 5.0, R), torch.full((R,), 5.0 / (R - 1))
+
+    def chain(o, d, x, w1, b1, w2, p0, p1, ii, jj):
+        phi = o["radial_d"](d, None, 0, p0, p1, 5.0, 0)
+        fc = o["radial_d"](d, None, 2, p0, None, 5.0, 0)
+        W = o["rowscale"](o["dense"](phi, w1, b1, 1), fc)
+        y = o["cfconv"](x, W, ii, jj, x.shape[0])
+        y = o["dense"](y, w2, None, 1)
+        (gd,) = torch.autograd.grad(y.sum(), [d], create_graph=True)
+        return (gd ** 2).sum() + (y ** 2).sum()
+
+    hip = {k: getattr(ops, k) for k in ("radial_d", "rowscale", "dense", "cfconv")}
+    ref = dict(crk.KERNELS, dense=lambda x, w, b, act: crk.dense_forward(x, w, b, act)[0])
+    leaves_h = [t.to(dev).requires_grad_(True) for t in (d0, x0, w1, b1, w2)]
+    leaves_r = [t.double().requires_grad_(True) for t in (d0, x0, w1, b1, w2)]
+    lh = chain(hip, *leaves_h, p0.to(dev), p1.to(dev), ii.to(dev), jj.to(dev))
+    lr = chain(ref, *leaves_r, p0.double(), p1.double(), ii, jj)
+    assert abs(float(lh) - float(lr)) < 1e-5 * abs(float(lr))
+    gh = torch.autograd.grad(lh, leaves_h)
+    gr = torch.autograd.grad(lr, leaves_r)
+    for a, b, name in zip(gh, gr, ("d", "x", "w1", "b1", "w2")):
+        assert rel_err(a.cpu(), b) < 2e-5, name
