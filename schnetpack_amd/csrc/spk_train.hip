@@ -66,20 +66,27 @@ extern "C" int spk_act_mul_f32(const float* a, const float* z, const float* c, i
 // ------------------------------------------------------------------------------------------------ G = U^T X (weight gradients)
 // U [n, O], X [n, K] row-major, G [O, K]; the contraction runs over the n samples, so both MFMA operands are
 // lane-contiguous in memory as they lie (lane el of half hi holds U[n = 2s + hi][o0 + el] and X[2s + hi][k0 + el]).
-// One wave per (32 x 32 tile of G, slice of n); slices meet in a workspace and the LAST wave of a tile (ticket counter,
-// self-resetting) adds them in slice order -- deterministic, one launch.  Tiles with k0 == 0 also carry the column sums
-// of U (bias gradient).
-#define TN_BATCH 16
-__global__ __launch_bounds__(64) void k_gemm_tn(const float* __restrict__ U, const float* __restrict__ X, int64_t n, int O, int K, int tiles_k, int S,
-                                                int64_t rows_per_slice, float* __restrict__ G, float* __restrict__ gb, float* __restrict__ ws,
-                                                float* __restrict__ wsb, unsigned* __restrict__ tickets) {
-  const int lane = threadIdx.x, hi = lane >> 5, el = lane & 31;
+// One workgroup of 8 waves per (32 x 32 tile of G, slice of n): the waves split the slice, meet in LDS, and -- when n needs
+// more than one slice -- the slices meet in a workspace where the LAST workgroup of a tile (ticket counter, self-resetting)
+// adds them in slice order: deterministic, one launch.  Tiles with k0 == 0 also carry the column sums of U (bias gradient).
+#define TN_BATCH 32
+#define TN_WAVES 8
+#define TN_ROWS_PER_BLOCK 512
+__global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_tn(const float* __restrict__ U, const float* __restrict__ X, int64_t n, int O, int K, int tiles_k,
+                                                           int S, int64_t rows_per_slice, int64_t rows_per_wave, float* __restrict__ G,
+                                                           float* __restrict__ gb, float* __restrict__ ws, float* __restrict__ wsb,
+                                                           unsigned* __restrict__ tickets) {
+  __shared__ float red[TN_WAVES][32][33];
+  __shared__ float redb[TN_WAVES][32];
+  __shared__ unsigned s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, el = lane & 31;
   const int tile = blockIdx.x, s = blockIdx.y;
   const int to = tile / tiles_k, tk = tile % tiles_k;
   const int o = 32 * to + el, k = 32 * tk + el;
   const bool o_ok = o < O, k_ok = k < K;
-  const int64_t r0 = s * rows_per_slice;
-  const int64_t r1 = (r0 + rows_per_slice < n) ? r0 + rows_per_slice : n;
+  const int64_t slice_end = ((s + 1) * rows_per_slice < n) ? (s + 1) * rows_per_slice : n;
+  const int64_t r0 = s * rows_per_slice + wv * rows_per_wave;
+  const int64_t r1 = (r0 + rows_per_wave < slice_end) ? r0 + rows_per_wave : slice_end;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -102,55 +109,63 @@ __global__ __launch_bounds__(64) void k_gemm_tn(const float* __restrict__ U, con
     }
   }
   usum += __shfl_xor(usum, 32, 64);
-  const int Op = 32 * ((O + 31) / 32), Kp = 32 * tiles_k;
-  if (S == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int oo = 32 * to + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (oo < O && k_ok) G[(int64_t)oo * K + k] = acc[r];
+  for (int r = 0; r < 16; ++r) red[wv][(r & 3) + 8 * (r >> 2) + 4 * hi][el] = acc[r];
+  if (hi == 0) redb[wv][el] = usum;
+  __syncthreads();
+  // thread t owns outputs (row t / 32 + 16 h, column t % 32), h = 0, 1
+  const int orow = tid >> 5, ocol = tid & 31;
+  float v0 = 0.f, v1 = 0.f, vb = 0.f;
+#pragma unroll
+  for (int w = 0; w < TN_WAVES; ++w) {
+    v0 += red[w][orow][ocol];
+    v1 += red[w][orow + 16][ocol];
+  }
+  if (tid < 32)
+#pragma unroll
+    for (int w = 0; w < TN_WAVES; ++w) vb += redb[w][tid];
+  const int go0 = 32 * to + orow, go1 = go0 + 16, gk = 32 * tk + ocol;
+  const bool want_b = gb != nullptr && tk == 0 && tid < 32;
+  if (S > 1) {
+    float* wt = ws + ((int64_t)s * gridDim.x + tile) * 1024;
+    wt[tid] = v0;
+    wt[tid + 512] = v1;
+    if (want_b) wsb[((int64_t)s * gridDim.x + tile) * 32 + tid] = vb;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(&tickets[tile], 1u);
+    __syncthreads();
+    if (s_ticket != (unsigned)(S - 1)) return;
+    __threadfence();
+    if (tid == 0) tickets[tile] = 0u;
+    v0 = 0.f; v1 = 0.f; vb = 0.f;
+    for (int q = 0; q < S; ++q) {
+      const float* wq = ws + ((int64_t)q * gridDim.x + tile) * 1024;
+      v0 += wq[tid];
+      v1 += wq[tid + 512];
+      if (want_b) vb += wsb[((int64_t)q * gridDim.x + tile) * 32 + tid];
     }
-    if (gb && tk == 0 && hi == 0 && o_ok) gb[o] = usum;
-    return;
   }
-  float* wt = ws + ((int64_t)s * Op + 32 * to) * Kp + 32 * tk;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) wt[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * hi) * Kp + el] = acc[r];
-  if (gb && tk == 0 && hi == 0) wsb[(int64_t)s * Op + 32 * to + el] = usum;
-  __threadfence();
-  unsigned ticket = 0;
-  if (lane == 0) ticket = atomicAdd(&tickets[tile], 1u);
-  ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket != (unsigned)(S - 1)) return;
-  __threadfence();
-  if (lane == 0) tickets[tile] = 0u;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    const int oo = 32 * to + rr;
-    float v = 0.f;
-    for (int q = 0; q < S; ++q) v += __builtin_nontemporal_load(ws + ((int64_t)q * Op + oo) * Kp + 32 * tk + el);
-    if (oo < O && k_ok) G[(int64_t)oo * K + k] = v;
+  if (gk < K) {
+    if (go0 < O) G[(int64_t)go0 * K + gk] = v0;
+    if (go1 < O) G[(int64_t)go1 * K + gk] = v1;
   }
-  if (gb && tk == 0 && hi == 0 && o_ok) {
-    float v = 0.f;
-    for (int q = 0; q < S; ++q) v += __builtin_nontemporal_load(wsb + (int64_t)q * Op + o);
-    gb[o] = v;
-  }
+  if (want_b && 32 * to + tid < O) gb[32 * to + tid] = vb;
 }
 
 // slices / workspace sizes for a problem (host helper shared with the caller that allocates the workspace)
 extern "C" int spk_gemm_tn_plan(int64_t n, int32_t O, int32_t K, int32_t* n_slices, int64_t* ws_floats, int32_t* n_tiles) {
   SPK_CHECK_ARG(n >= 0 && O > 0 && K > 0 && n_slices && ws_floats && n_tiles, "spk_gemm_tn_plan: bad arguments");
   const int tiles = ((O + 31) / 32) * ((K + 31) / 32);
-  int64_t S = (n + 127) / 128;
-  const int64_t cap = (int64_t)(4 * spk_num_cus() * 4 / tiles);          // ~4 waves per SIMD over the chip
+  int64_t S = (n + TN_ROWS_PER_BLOCK - 1) / TN_ROWS_PER_BLOCK;
+  int64_t cap = (int64_t)(2 * spk_num_cus()) / tiles;                     // two workgroups per CU over the chip
+  if (cap < 1) cap = 1;
   if (S > cap) S = cap;
-  if (S > 256) S = 256;
+  if (S > 128) S = 128;
   if (S < 1) S = 1;
   *n_slices = (int32_t)S;
   *n_tiles = tiles;
-  const int64_t Op = 32 * ((O + 31) / 32), Kp = 32 * ((K + 31) / 32);
-  *ws_floats = S > 1 ? S * Op * (Kp + 1) : 0;
+  *ws_floats = S > 1 ? S * (int64_t)tiles * (1024 + 32) : 0;
   return SPK_OK;
 }
 
@@ -165,43 +180,59 @@ extern "C" int spk_gemm_tn_f32(const float* U, const float* X, int64_t n, int32_
   SPK_CHECK_ARG(S == 1 || (ws && tickets), "spk_gemm_tn_f32: workspace / ticket buffer required for %d slices", S);
   SPK_CHECK_ARG(tiles <= 4096, "spk_gemm_tn_f32: %d output tiles (max 4096)", tiles);
   SpkProfScope prof("gemm_tn", stream);
-  const int64_t Op = 32 * ((O + 31) / 32), Kp = 32 * ((K + 31) / 32);
-  int64_t rps = (n + S - 1) / S;
-  rps += rps & 1;                                                       // whole MFMA steps per slice
-  if (rps < 2) rps = 2;
-  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(64), 0, stream, U, X, n, O, K, (K + 31) / 32, S, rps, G, gb, ws, ws ? ws + (int64_t)S * Op * Kp : nullptr,
-                     (unsigned*)tickets);
+  int64_t rpw = (n + (int64_t)S * TN_WAVES - 1) / ((int64_t)S * TN_WAVES);
+  rpw += rpw & 1;                                                       // whole MFMA steps per wave
+  if (rpw < 2) rpw = 2;
+  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(64 * TN_WAVES), 0, stream, U, X, n, O, K, (K + 31) / 32, S, rpw * TN_WAVES, rpw, G, gb, ws,
+                     ws ? ws + (int64_t)S * tiles * 1024 : nullptr, (unsigned*)tickets);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ cfconv on materialised filters
 // y[out_e, :] += x[src_e, :] . W[e, :]   (schnet.py:64-66: x_j * Wij, scatter_add over idx_i)
+// one workgroup per output row: threads = (feature chunks) x (edge slots); the slots walk the row's pairs together and meet
+// in LDS, so a long row (the padded tail of a static-shape training batch, a dense neighbourhood) costs its length / slots
 template <int V>
-__global__ void k_cfconv_rows(const float* __restrict__ x, const float* __restrict__ W, const int32_t* __restrict__ rowptr, const int64_t* __restrict__ src,
-                              int64_t n_out, int64_t n_src, int F, float* __restrict__ y) {
-  const int FV = F / V;
-  const int64_t total = n_out * FV;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = t / FV;
-    const int c = (int)(t % FV) * V;
-    float acc[V];
+__global__ __launch_bounds__(256) void k_cfconv_rows(const float* __restrict__ x, const float* __restrict__ W, const int32_t* __restrict__ rowptr,
+                                                     const int64_t* __restrict__ src, int64_t n_out, int64_t n_src, int F, int chunks, int slots,
+                                                     float* __restrict__ y) {
+  __shared__ float red[256 * V];
+  const int tid = threadIdx.x;
+  const int slot = tid / chunks, ch = tid % chunks;
+  for (int64_t row = blockIdx.x; row < n_out; row += gridDim.x) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    for (int c0 = 0; c0 < F; c0 += chunks * V) {
+      const int c = c0 + ch * V;
+      float acc[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) acc[v] = 0.f;
-    const int e1 = rowptr[row + 1];
-    for (int e = rowptr[row]; e < e1; ++e) {
-      const int64_t j = src[e];
-      if ((uint64_t)j >= (uint64_t)n_src) continue;
-      if (V == 4) {
-        const f32x4 xv = *(const f32x4*)(x + j * F + c), wv = *(const f32x4*)(W + (int64_t)e * F + c);
-        acc[0] = fmaf(xv.x, wv.x, acc[0]); acc[1 % V] = fmaf(xv.y, wv.y, acc[1 % V]);
-        acc[2 % V] = fmaf(xv.z, wv.z, acc[2 % V]); acc[3 % V] = fmaf(xv.w, wv.w, acc[3 % V]);
-      } else {
-        acc[0] = fmaf(x[j * F + c], W[(int64_t)e * F + c], acc[0]);
+      for (int v = 0; v < V; ++v) acc[v] = 0.f;
+      if (slot < slots && c < F) {
+        for (int e = e0 + slot; e < e1; e += slots) {
+          const int64_t j = src[e];
+          if ((uint64_t)j >= (uint64_t)n_src) continue;
+          if (V == 4) {
+            const f32x4 xv = *(const f32x4*)(x + j * F + c), wv = *(const f32x4*)(W + (int64_t)e * F + c);
+            acc[0] = fmaf(xv.x, wv.x, acc[0]); acc[1 % V] = fmaf(xv.y, wv.y, acc[1 % V]);
+            acc[2 % V] = fmaf(xv.z, wv.z, acc[2 % V]); acc[3 % V] = fmaf(xv.w, wv.w, acc[3 % V]);
+          } else {
+            acc[0] = fmaf(x[j * F + c], W[(int64_t)e * F + c], acc[0]);
+          }
+        }
       }
-    }
 #pragma unroll
-    for (int v = 0; v < V; ++v) y[row * F + c + v] = acc[v];
+      for (int v = 0; v < V; ++v) red[tid * V + v] = acc[v];
+      __syncthreads();
+      if (slot == 0 && c < F) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float t = 0.f;
+          for (int q = 0; q < slots; ++q) t += red[(q * chunks + ch) * V + v];      // fixed order: deterministic
+          y[row * F + c + v] = t;
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -229,8 +260,13 @@ extern "C" int spk_cfconv_edge_f32(const float* x, const float* W, const int64_t
   const int maxb = spk_num_cus() * 16;
   if (rowptr_out) {
     const bool v4 = (F % 4 == 0) && (((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0);
-    if (v4) hipLaunchKernelGGL(k_cfconv_rows<4>, dim3(spk_grid_for(n_out * (F / 4), 256, maxb)), dim3(256), 0, stream, x, W, rowptr_out, idx_src, n_out, n_src, F, y);
-    else hipLaunchKernelGGL(k_cfconv_rows<1>, dim3(spk_grid_for(n_out * F, 256, maxb)), dim3(256), 0, stream, x, W, rowptr_out, idx_src, n_out, n_src, F, y);
+    const int per = v4 ? F / 4 : F;
+    const int chunks = per < 256 ? per : 256;
+    int slots = 256 / chunks;
+    if (slots > 16) slots = 16;
+    const int grid = spk_grid_for(n_out, 1, maxb * 4);
+    if (v4) hipLaunchKernelGGL(k_cfconv_rows<4>, dim3(grid), dim3(256), 0, stream, x, W, rowptr_out, idx_src, n_out, n_src, F, chunks, slots, y);
+    else hipLaunchKernelGGL(k_cfconv_rows<1>, dim3(grid), dim3(256), 0, stream, x, W, rowptr_out, idx_src, n_out, n_src, F, chunks, slots, y);
   } else {
     int rc = spk_zero_async(y, (size_t)n_out * F * sizeof(float), stream);
     if (rc) return rc;

@@ -56,6 +56,28 @@ class FlatGradAllReduce:
         if self.flat is not None:
             self.flat.zero_()
 
+    def release(self):
+        """Drop the gradients (``p.grad = None``) so that the next backward hands its tensors over instead of adding them
+        into the bucket views -- one launch per parameter saved; follow the backward with :meth:`pack`."""
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        """Gather the freshly produced gradients into the flat bucket with ONE concatenation and re-bind every ``p.grad`` as
+        a view of it (so the all-reduce and the optimizer see one buffer).  Parameters the backward did not reach count as
+        zeros."""
+        if not self.params:
+            return
+        if self.flat is None:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=self.params[0].device)
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        torch.cat(parts, out=self.flat)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
     def _reduce(self, group):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -9,8 +9,9 @@ Instead of a tracing compiler the step is captured once into a HIP graph and rep
   there, so energies, forces and all gradients are exactly those of the unpadded batch);
 * the index tensors are static BUFFERS refilled per step; their CSR row pointers are recomputed inside the
   graph by a device-only kernel (``torchops.StaticLists``), no plan cache, no host round trip;
-* gradients are views of one flat bucket (``parallel.FlatGradAllReduce(as_views=True)``): cleared with one
-  fill, all-reduced with one RCCL call between the two graphs (backward | optimizer) when there are ranks;
+* gradients leave the backward as the tensors its last kernels wrote (no accumulate-into-bucket launch per parameter),
+  are gathered into one flat bucket by ONE concatenation (``parallel.FlatGradAllReduce.pack``) and re-bound as views of
+  it; the bucket is all-reduced with one RCCL call between the two graphs (backward | optimizer) when there are ranks;
 * AdamW runs ``capturable`` so that its step is part of the graph.
 
 The first two calls of :meth:`GraphedTrainStep.step` run eagerly (allocator / autotune warm-up; they are
@@ -98,13 +99,14 @@ class GraphedTrainStep:
     # ---------------------------------------------------------------- the step
     def _forward_backward(self):
         self.lists.refresh()
-        self.reducer.zero()
+        self.reducer.release()
         inputs = dict(self.buf)
         inputs[properties.R] = self.buf[properties.R].detach().requires_grad_(False)
         inputs["_n_molecules"] = self.M
         out = self.model(inputs)
         loss = self.wE * ((out["energy"] - self.E_t) ** 2).mean() + self.wF * ((out["forces"] - self.F_t) ** 2).mean()
         loss.backward()
+        self.reducer.pack()
         self.loss.copy_(loss.detach())
 
     def _eager_step(self):
