@@ -133,6 +133,9 @@ int spk_gather_f32(const float* x, const int64_t* idx, int64_t outer, int64_t n_
  * OR-ed with 1 if idx is not ascending and with 2 if an entry is outside [0, n_rows); the caller polls it. */
 int spk_segment_rowptr_i32(const int64_t* idx, int64_t n, int64_t n_rows, int32_t* rowptr, int32_t* err,
                            void* stream);
+/* err[0] |= 2 if an entry of idx lies outside [0, hi): device-only validation of the unsorted indices (idx_j, Z) of a
+ * static-shape training step, launched next to the row-pointer refresh inside the captured graph */
+int spk_index_range_check(const int64_t* idx, int64_t n, int64_t hi, int32_t* err, void* stream);
 
 /* ------------------------------------------------------------------ atomistic/distances.py:14-26
  * r_ij[e] = (R[idx_j[e]] - R[idx_i[e]]) + offsets[e]   (offsets may be NULL). */

@@ -105,6 +105,7 @@ _PROTOS = {
     "spk_atomwise_fwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i64, c_f, c_f, c_f, c_f]),
     "spk_atomwise_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i64, c_f, c_f]),
     "spk_segment_rowptr_i32": (ctypes.c_int, [c_f, c_i64, c_i64, c_f, c_f, c_f]),
+    "spk_index_range_check": (ctypes.c_int, [c_f, c_i64, c_i64, c_f, c_f]),
     "spk_pairwise_bwd_graph_f32": (ctypes.c_int, [c_f, P(GraphT), c_f, c_f]),
     "spk_radial_cutoff_f32": (ctypes.c_int, [c_f, c_i64, P(RadialT), c_f, c_f, c_f]),
     "spk_radial_cutoff_bwd_f32": (ctypes.c_int, [c_f, c_i64, P(RadialT), c_f, c_f, c_f, c_f]),

@@ -239,6 +239,7 @@ void decide_filter(Plan& p, const Tensor& r_ij, double cutoff) {
 // static_refresh() inside the captured step; every other index takes the atomic scatter.
 struct StaticEntry { Tensor idx, rowptr; int64_t n_rows; };
 std::vector<StaticEntry> g_static;
+std::vector<std::pair<Tensor, int64_t>> g_static_ranges;   // unsorted indices that must lie in [0, hi)
 Tensor g_static_err;
 bool g_static_on = false;
 
@@ -1080,11 +1081,24 @@ Tensor static_declare_op(const Tensor& idx, int64_t n_rows) {
   g_static.push_back({idx, at::zeros({n_rows + 1}, at::TensorOptions().dtype(at::kInt).device(idx.device())), n_rows});
   return g_static.back().rowptr;
 }
+void static_declare_range_op(const Tensor& idx, int64_t hi) {
+  require_device(idx, "static_declare_range");
+  TORCH_CHECK(idx.scalar_type() == at::kLong && idx.is_contiguous(), "static_declare_range: needs a contiguous int64 tensor");
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (!g_static_err.defined()) g_static_err = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(idx.device()));
+  for (auto& e : g_static_ranges)
+    if (e.first.data_ptr() == idx.data_ptr()) { e.second = hi; return; }
+  g_static_ranges.emplace_back(idx, hi);
+}
 void static_refresh_op() {
   for (auto& e : g_static) {
     c10::DeviceGuard guard(e.idx.device());
     check(spk_segment_rowptr_i32(e.idx.data_ptr<int64_t>(), e.idx.size(0), e.n_rows, e.rowptr.data_ptr<int32_t>(), g_static_err.data_ptr<int32_t>(),
                                  stream_of(e.idx)));
+  }
+  for (auto& e : g_static_ranges) {
+    c10::DeviceGuard guard(e.first.device());
+    check(spk_index_range_check(e.first.data_ptr<int64_t>(), e.first.numel(), e.second, g_static_err.data_ptr<int32_t>(), stream_of(e.first)));
   }
 }
 void static_enable_op(bool on) { g_static_on = on; }
@@ -1097,6 +1111,7 @@ int64_t static_check_op() {
 void static_clear_op() {
   std::lock_guard<std::mutex> lock(g_mutex);
   g_static.clear();
+  g_static_ranges.clear();
   g_static_err = Tensor();
   g_static_on = false;
 }
@@ -1209,6 +1224,7 @@ TORCH_LIBRARY(spk_hip, m) {
   m.def("edge_plan_install(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor rowptr, Tensor rev, Tensor half, Tensor edge_pair, Tensor grp_atom0, Tensor grp_pair0, int[] meta) -> ()");
   // static-shape mode + cache control (host-side state)
   m.def("static_declare(Tensor idx, int n_rows) -> Tensor");
+  m.def("static_declare_range(Tensor idx, int hi) -> ()");
   m.def("static_refresh() -> ()", static_refresh_op);
   m.def("static_enable(bool on) -> ()", static_enable_op);
   m.def("static_check() -> int", static_check_op);
@@ -1239,6 +1255,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm d
   m.impl("atomwise_backward", atomwise_backward_op);
   m.impl("edge_plan", edge_plan_op);
   m.impl("static_declare", static_declare_op);
+  m.impl("static_declare_range", static_declare_range_op);
   m.impl("edge_plan_install", edge_plan_install_op);
   train_impl_device(m);
 }
@@ -1259,7 +1276,7 @@ TORCH_LIBRARY_IMPL(spk_hip, Autograd, m) {
 TORCH_LIBRARY_IMPL(spk_hip, CPU, m) {
   for (const char* name : {"scatter_add", "gather", "pairwise", "pairwise_backward", "dense", "radial_cutoff", "schnet", "painn", "atomwise",
                            "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
-                           "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare"})
+                           "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare", "static_declare_range"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
   for (const char* name : kTrainOps) m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }

@@ -144,6 +144,23 @@ extern "C" int spk_segment_rowptr_i32(const int64_t* idx, int64_t n, int64_t n_r
   return SPK_OK;
 }
 
+// err[0] |= 2 if an entry of idx is outside [0, hi)  (device only: neighbour indices / atomic numbers of a static-shape step)
+__global__ void k_range_checked(const int64_t* __restrict__ idx, int64_t n, int64_t hi, int32_t* __restrict__ err) {
+  int bad = 0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    if ((uint64_t)idx[e] >= (uint64_t)hi) bad = 2;
+  if (bad) atomicOr(err, bad);
+}
+
+extern "C" int spk_index_range_check(const int64_t* idx, int64_t n, int64_t hi, int32_t* err, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(n >= 0 && hi >= 0 && err != nullptr && (n == 0 || idx != nullptr), "spk_index_range_check: bad input");
+  if (n == 0) return SPK_OK;
+  hipLaunchKernelGGL(k_range_checked, dim3(spk_grid_for(n, 256, 4096)), dim3(256), 0, stream, idx, n, hi, err);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 // every edge (i<-j, r) must have a partner (j<-i, -r) in row j
 __global__ void k_symmetry(const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j,
                            const float* __restrict__ rij, const int32_t* __restrict__ rowptr,
@@ -329,10 +346,11 @@ __global__ void k_gather(const float* __restrict__ x, const int64_t* __restrict_
     int64_t e = (t / cpr) % E;
     int64_t o = t / (cpr * E);
     int64_t k = idx[e];
-    const float* xp = x + (o * R + k) * inner + c * VEC;
+    const bool ok = (uint64_t)k < (uint64_t)R;      // an index out of range reads nothing (rows of zeros), never out of bounds
+    const float* xp = x + (o * R + (ok ? k : 0)) * inner + c * VEC;
     float* yp = y + (o * E + e) * inner + c * VEC;
-    if (VEC == 4) *(f32x4*)yp = *(const f32x4*)xp;
-    else yp[0] = xp[0];
+    if (VEC == 4) *(f32x4*)yp = ok ? *(const f32x4*)xp : f32x4{0.f, 0.f, 0.f, 0.f};
+    else yp[0] = ok ? xp[0] : 0.f;
   }
 }
 

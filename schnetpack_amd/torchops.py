@@ -41,8 +41,10 @@ ops = load()
 
 OPERATORS = ["scatter_add", "gather", "pairwise", "pairwise_backward", "dense", "radial_cutoff", "schnet", "painn", "atomwise",
              "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
-             "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "edge_plan_install", "static_declare", "static_refresh", "static_enable",
-             "static_check", "static_clear", "clear_caches"]
+             "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "edge_plan_install", "static_declare", "static_declare_range", "static_refresh", "static_enable",
+             "static_check", "static_clear", "clear_caches",
+             # training regime: operators closed under differentiation (csrc/spk_torch_train.h)
+             "act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm"]
 
 
 class StaticLists:
@@ -53,13 +55,18 @@ class StaticLists:
     (and in the captured graph) every index tensor declared with ``sl.declare_sorted(idx, n_rows)`` gets its CSR row
     pointers from a device-only kernel launched by ``sl.refresh()`` (capture that call at the start of the step); all
     other indices take the atomic scatter; neighbour-list plans (symmetry, reverse map) are not used.  ``sl.check()``
-    polls the device flag that the refresh kernels raise when a declared index was not ascending / in range."""
+    polls the device flag that the refresh kernels raise when a declared index was not ascending / in range
+    (``declare_range`` adds unsorted indices -- ``idx_j``, atomic numbers -- to that check)."""
 
     def __init__(self):
         ops.static_clear()
 
     def declare_sorted(self, idx, n_rows):
         return ops.static_declare(idx, int(n_rows))
+
+    def declare_range(self, idx, hi):
+        """``idx`` (any order) must lie in [0, hi): checked on the device by every ``refresh()``."""
+        ops.static_declare_range(idx, int(hi))
 
     def refresh(self):
         ops.static_refresh()

@@ -12,7 +12,7 @@ Instead of a tracing compiler the step is captured once into a HIP graph and rep
 * gradients leave the backward as the tensors its last kernels wrote (no accumulate-into-bucket launch per parameter),
   are gathered into one flat bucket by ONE concatenation (``parallel.FlatGradAllReduce.pack``) and re-bound as views of
   it; the bucket is all-reduced with one RCCL call between the two graphs (backward | optimizer) when there are ranks;
-* AdamW runs ``capturable`` so that its step is part of the graph.
+* AdamW runs ``capturable`` and ``fused`` (one multi-tensor kernel) so that its step is a few nodes of the graph.
 
 The first two calls of :meth:`GraphedTrainStep.step` run eagerly (allocator / autotune warm-up; they are
 real optimizer steps), the third captures, every later one replays.
@@ -66,33 +66,41 @@ class GraphedTrainStep:
         self.lists = torchops.StaticLists()
         self.lists.declare_sorted(self.buf[properties.idx_i], self.N)
         self.lists.declare_sorted(self.buf[properties.idx_m], self.M)
+        self.lists.declare_range(self.buf[properties.idx_j], self.N)
+        n_emb = getattr(getattr(model.representation, "embedding", None), "num_embeddings", None)
+        if n_emb is not None:
+            self.lists.declare_range(self.buf[properties.Z], int(n_emb))
+        self._pad_offsets = torch.zeros(self.Emax, 3, device=dev)
+        self._pad_offsets[:, 0] = 2.0 * self.cutoff + 1.0
         self.reducer = FlatGradAllReduce(model.parameters(), as_views=True)
-        self.opt = torch.optim.AdamW(model.parameters(), lr=lr, capturable=True)
+        # one multi-tensor kernel per step (the foreach form with capturable state costs two broadcast divisions PER PARAMETER)
+        self.opt = torch.optim.AdamW(model.parameters(), lr=lr, capturable=True, fused=True)
         self.n_steps = 0
-        self._bad = None
         self.g_bwd = self.g_opt = None
 
     # ---------------------------------------------------------------- data
     def load(self, batch: Dict[str, torch.Tensor], E_target: torch.Tensor, F_target: torch.Tensor):
-        """batch: Z, R, idx_i, idx_j, offsets, idx_m (host or device tensors of the synthetic / collate layout)."""
+        """batch: Z, R, idx_i, idx_j, offsets, idx_m (host or device tensors of the synthetic / collate layout).  The pair
+        list is written into the static buffers and padded there (see :func:`pad_edges`); index validation runs on the
+        device inside the step (``StaticLists.refresh``: idx_i / idx_m ascending and in range, idx_j and Z in range) and is
+        polled by :meth:`check` -- the kernels themselves never read or scatter out of bounds."""
         if int(batch["Z"].shape[0]) != self.N:
             raise ValueError("batch has %d atoms, the step was built for %d" % (batch["Z"].shape[0], self.N))
-        ii, jj, off = pad_edges(batch["idx_i"], batch["idx_j"], batch["offsets"].float(), self.N, self.Emax, self.cutoff)
-        # the refresh kernels validate the declared (sorted) indices only; neighbour indices and atomic numbers are checked
-        # here, asynchronously on whatever device the batch lives on (polled by check()): a malformed batch must not read or
-        # scatter out of bounds inside the replayed graph
-        n_emb = getattr(getattr(self.model.representation, "embedding", None), "num_embeddings", None)
-        bad = ((jj < 0) | (jj >= self.N)).any() | ((ii < 0) | (ii >= self.N)).any() | (batch["Z"] < 0).any()
-        if n_emb is not None:
-            bad = bad | (batch["Z"] >= n_emb).any()
-        self._bad = bad if self._bad is None else (self._bad.to(bad.device) | bad)
+        E = int(batch["idx_i"].shape[0])
+        if E > self.Emax:
+            raise ValueError("neighbour list has %d pairs, capacity is %d" % (E, self.Emax))
+        b = self.buf
         with torch.no_grad():
-            self.buf[properties.Z].copy_(batch["Z"], non_blocking=True)
-            self.buf[properties.R].copy_(batch["R"].float(), non_blocking=True)
-            self.buf[properties.idx_i].copy_(ii, non_blocking=True)
-            self.buf[properties.idx_j].copy_(jj, non_blocking=True)
-            self.buf[properties.offsets].copy_(off, non_blocking=True)
-            self.buf[properties.idx_m].copy_(batch["idx_m"], non_blocking=True)
+            b[properties.Z].copy_(batch["Z"], non_blocking=True)
+            b[properties.R].copy_(batch["R"], non_blocking=True)
+            b[properties.idx_m].copy_(batch["idx_m"], non_blocking=True)
+            b[properties.idx_i][:E].copy_(batch["idx_i"], non_blocking=True)
+            b[properties.idx_j][:E].copy_(batch["idx_j"], non_blocking=True)
+            b[properties.offsets][:E].copy_(batch["offsets"], non_blocking=True)
+            if E < self.Emax:                                   # inert tail: self pairs of the last atom beyond the cutoff
+                b[properties.idx_i][E:].fill_(self.N - 1)
+                b[properties.idx_j][E:].fill_(self.N - 1)
+                b[properties.offsets][E:].copy_(self._pad_offsets[E:])
             self.E_t.copy_(E_target, non_blocking=True)
             self.F_t.copy_(F_target, non_blocking=True)
 
@@ -146,6 +154,3 @@ class GraphedTrainStep:
     def check(self):
         """Poll the device-side validity flag of the declared index tensors (one D2H)."""
         self.lists.check()
-        if self._bad is not None and bool(self._bad):
-            self._bad = None
-            raise torchops.SpkHipError("GraphedTrainStep: a loaded batch held a neighbour index or atomic number out of range")

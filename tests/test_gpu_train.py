@@ -103,3 +103,23 @@ def test_static_lists_flag_unsorted_index(dev):
     sl.refresh()
     with pytest.raises(SpkHipError):
         sl.check()
+
+
+def test_malformed_batch_is_flagged_on_the_device_and_reads_nothing_out_of_bounds(dev):
+    """A neighbour index outside [0, n_atoms) in a loaded batch: the step runs (the kernels clamp / skip, no out-of-bounds
+    access), the refresh kernels raise the device flag, check() reports it."""
+    from schnetpack_amd._lib import SpkHipError
+    from schnetpack_amd.train import GraphedTrainStep
+    (b, Et, Ft), = _batches(1, 2)
+    N, E = b["Z"].shape[0], int(b["idx_i"].shape[0])
+    ts = GraphedTrainStep(_model("schnet", dev), N, 2, E + 20, 5.0, use_graph=False)
+    ts.load(b, Et, Ft)
+    ts.step()
+    ts.check()
+    bad = dict(b, idx_j=b["idx_j"].clone())
+    bad["idx_j"][3] = N + 5
+    ts.load(bad, Et, Ft)
+    ts.step()
+    torch.cuda.synchronize()
+    with pytest.raises(SpkHipError, match="out of range"):
+        ts.check()
