@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 OUT=gpurun_out/r02g; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_gpu_train_ops.py -x -q 2>&1 | tail -15
-timeout 900 python -m pytest tests/test_gpu_models.py tests/test_gpu_ops.py tests/test_gpu_reference_callers.py tests/test_gpu_torchscript.py -x -q -k "training or train or dense or Dense or weight or script" 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_models.py tests/test_gpu_ops.py -x -q -k "train or dense or Dense or weight or gather or static or malformed" 2>&1 | tail -8
 for KIND in schnet painn; do
   timeout 600 python bench.py --mode train --kind $KIND --steps 50 --warmup 5 --cpu-reps 2 > $OUT/bench_train_$KIND.json 2> $OUT/bench_train_$KIND.err; echo "rc=$?"; cut -c1-400 $OUT/bench_train_$KIND.json
 done
