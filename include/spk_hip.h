@@ -529,11 +529,12 @@ int spk_gemm_tn_plan(int64_t n, int32_t O, int32_t K, int32_t* n_slices, int64_t
 int spk_gemm_tn_f32(const float* U, const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, float* ws,
                     uint32_t* tickets, void* stream);
 /* y[idx_out[e], :] += x[idx_src[e], :] * W[e, :]   (schnet.py:64-66 on materialised filters; y [n_out, F] overwritten).
- * rowptr_out = CSR row pointers of an ascending idx_out (deterministic segmented sum) or NULL (float atomics). */
+ * rowptr_out = CSR row pointers of an ascending idx_out (deterministic segmented sum) or NULL (float atomics).
+ * idx_src may be NULL: identity (x has one row per pair). */
 int spk_cfconv_edge_f32(const float* x, const float* W, const int64_t* idx_out, const int64_t* idx_src,
                         const int32_t* rowptr_out, int64_t n_edges, int64_t n_out, int64_t n_src, int32_t F, float* y,
                         void* stream);
-/* out[e, :] = a[idx_a[e], :] * b[idx_b[e], :]   (the derivative of the above w.r.t. W) */
+/* out[e, :] = a[idx_a[e], :] * b[idx_b[e], :]   (the derivative of the above w.r.t. W); either index may be NULL: identity */
 int spk_edge_mul_f32(const float* a, const float* b, const int64_t* idx_a, const int64_t* idx_b, int64_t n_edges,
                      int64_t n_a, int64_t n_b, int32_t F, float* out, void* stream);
 /* out[e, r] = a[e] * d^order/dd^order phi_r(d[e])   and   out[e] = a[e] * sum_r G[e, r] d^order/dd^order phi_r(d[e]);
@@ -545,6 +546,19 @@ int spk_radial_c_f32(const float* G, const float* d, const float* a, int64_t n, 
                      float* out, void* stream);
 /* out[r, f] = W[r, f] * s[r]   (Wij * rcut_ij[:, None], schnet.py:61)   and   out[r] = sum_f a[r, f] * b[r, f] */
 int spk_rowscale_f32(const float* W, const float* s, int64_t rows, int32_t F, float* out, void* stream);
+/* 3-vector algebra of PaiNN (painn.py:55-66, 99-117) on V-type [M, 3, F], s-type [M, F] and u-type [M, 3] operands; V / s operands
+ * carry a row stride in floats (ldA / ldB) so the halves of a split tensor are read in place; `out` is dense.
+ *   SCALE:    out[m,k,f] = A[m,k,f] B[m,f]            (A: V, B: s)      DOT:     out[m,f] = sum_k A[m,k,f] B[m,k,f]   (A, B: V)
+ *   OUTER:    out[m,k,f] = A[m,f] B[m,k]              (A: s, B: u)      CONTRACT: out[m,f] = sum_k A[m,k,f] B[m,k]    (A: V, B: u)
+ *   ROWDOT:   out[m,k]   = sum_f A[m,k,f] B[m,f]      (A: V, B: s)
+ * The five are closed under differentiation (spk_train.hip). */
+#define SPK_VEC3_SCALE 0
+#define SPK_VEC3_DOT 1
+#define SPK_VEC3_OUTER 2
+#define SPK_VEC3_CONTRACT 3
+#define SPK_VEC3_ROWDOT 4
+int spk_vec3_f32(int32_t op, const float* A, int64_t ldA, const float* B, int64_t ldB, int64_t M, int32_t F, float* out,
+                 void* stream);
 int spk_rowdot_f32(const float* a, const float* b, int64_t rows, int32_t F, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -120,6 +120,56 @@ __global__ __launch_bounds__(256) void k_dense_mfma(
   }
 }
 
+// Long contractions with few output tiles (the input gradient of PaiNN's filter layer: [E, 1152] x [1152, 20] -- one column
+// tile, 18 chunks): the four waves of a workgroup share ONE 32 x 32 tile, wave w takes chunks w, w + 4, ..., the partial tiles
+// meet in LDS in wave order (deterministic).  Linear layers only (bias, no activation / prologue / residual).
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_dense_mfma_splitk(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                                                           float* __restrict__ out, int64_t M, int KC, int NW) {
+  __shared__ float red[3][32][33];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  const int tcount = (NW + 31) / 32;
+  const int nug = (KC + 7) / 8;
+  const int nch = (nug + DCH - 1) / DCH;
+  const int64_t task = blockIdx.x;
+  const int64_t mt = task / tcount;
+  const int t = (int)(task % tcount);
+  const int64_t m = mt * 32 + el;
+  const bool valid = m < M;
+  const float* inrow = in + (valid ? m : (M - 1)) * KC;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32x4 a0[DCH], b0[DCH], a1[DCH], b1[DCH];
+  if (wv < nch) dense_load_chunk<TRANS, SPK_ACT_NONE>(a0, b0, wv, nug, inrow, nullptr, w, KC, NW, t, el, hi);
+  for (int c = wv; c < nch; c += 8) {
+    if (c + 4 < nch) dense_load_chunk<TRANS, SPK_ACT_NONE>(a1, b1, c + 4, nug, inrow, nullptr, w, KC, NW, t, el, hi);
+    acc = dense_mfma_chunk(a0, b0, c, nug, acc);
+    if (c + 8 < nch) dense_load_chunk<TRANS, SPK_ACT_NONE>(a0, b0, c + 8, nug, inrow, nullptr, w, KC, NW, t, el, hi);
+    if (c + 4 < nch) acc = dense_mfma_chunk(a1, b1, c + 4, nug, acc);
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv - 1][(r & 3) + 8 * (r >> 2) + 4 * hi][el] = acc[r];
+  }
+  __syncthreads();
+  if (wv == 0 && valid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = 32 * t + 8 * q + 4 * hi;
+      if (col >= NW) continue;
+      f32x4 o;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 4 * q + v, rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        o[v] = ((acc[r] + red[0][rr][el]) + red[1][rr][el]) + red[2][rr][el] + (b ? b[col + v] : 0.f);
+      }
+      *(f32x4*)(out + m * NW + col) = o;
+    }
+  }
+}
+
 // Straightforward kernel for any shape: one thread per output element.
 __global__ void k_dense_simple(const float* __restrict__ in, const float* __restrict__ pre_in,
                                const float* __restrict__ w, const float* __restrict__ b,
@@ -168,6 +218,12 @@ static int dense_dispatch(const float* in, const float* pre_in, const float* w, 
   const bool mfma_combo = (pro == SPK_ACT_NONE) || (act == SPK_ACT_NONE && trans);
   if (shape_ok && mfma_combo && variant != SPK_VARIANT_SIMPLE) {
     const int64_t ntasks = ((M + 31) / 32) * ((NW + 31) / 32);
+    if (KC >= 512 && ntasks <= 2 * (int64_t)spk_num_cus() && act == SPK_ACT_NONE && pro == SPK_ACT_NONE && !res && !pre_out) {
+      if (trans) hipLaunchKernelGGL((k_dense_mfma_splitk<true>), dim3((unsigned)ntasks), dim3(256), 0, stream, in, w, b, out, M, KC, NW);
+      else hipLaunchKernelGGL((k_dense_mfma_splitk<false>), dim3((unsigned)ntasks), dim3(256), 0, stream, in, w, b, out, M, KC, NW);
+      SPK_LAUNCH_CHECK();
+      return SPK_OK;
+    }
     const int grid = spk_grid_for(ntasks, 4, spk_num_cus() * 8);
 #define SPK_DENSE_LAUNCH(A, T, P)                                                               \
   hipLaunchKernelGGL((k_dense_mfma<A, T, P>), dim3(grid), dim3(256), 0, stream, in, pre_in, w, b, \

@@ -47,30 +47,94 @@ std::tuple<Tensor, Tensor> matmul_tn_raw(const Tensor& u_in, const Tensor& x_in)
   return {G, cs};
 }
 
-Tensor cfconv_raw(const Tensor& x_in, const Tensor& W_in, const Tensor& idx_out_in, const Tensor& idx_src_in, int64_t n_out) {
+bool has(const OptT& t) { return t.has_value() && t->defined(); }
+
+Tensor edge_mul_raw(const Tensor& a_in, const Tensor& b_in, const OptT& ia_in, const OptT& ib_in) {
+  Tensor a = f32(a_in, "edge_mul"), b = f32(b_in, "edge_mul");
+  TORCH_CHECK(has(ia_in) || has(ib_in), "edge_mul: at least one index is required (use a plain product otherwise)");
+  Tensor ia = has(ia_in) ? i64(*ia_in, "edge_mul") : Tensor(), ib = has(ib_in) ? i64(*ib_in, "edge_mul") : Tensor();
+  TORCH_CHECK(a.dim() == 2 && b.dim() == 2 && a.size(1) == b.size(1), "edge_mul: a ", a.sizes(), " and b ", b.sizes(), " must share the feature dimension");
+  const int64_t E = ia.defined() ? ia.size(0) : ib.size(0);
+  TORCH_CHECK((!ia.defined() || (ia.dim() == 1 && ia.size(0) == E)) && (!ib.defined() || (ib.dim() == 1 && ib.size(0) == E)), "edge_mul: index tensors differ in length");
+  TORCH_CHECK(ia.defined() || a.size(0) == E, "edge_mul: a without an index must have one row per pair");
+  TORCH_CHECK(ib.defined() || b.size(0) == E, "edge_mul: b without an index must have one row per pair");
+  c10::DeviceGuard guard(a.device());
+  Tensor out = at::empty({E, a.size(1)}, a.options());
+  check(spk_edge_mul_f32(fp(a), fp(b), ia.defined() ? ia.data_ptr<int64_t>() : nullptr, ib.defined() ? ib.data_ptr<int64_t>() : nullptr, E, a.size(0), b.size(0),
+                         (int32_t)a.size(1), fpm(out), stream_of(a)));
+  return out;
+}
+
+Tensor cfconv_raw(const Tensor& x_in, const Tensor& W_in, const OptT& idx_out_in, const OptT& idx_src_in, int64_t n_out) {
+  if (!has(idx_out_in)) {      // one output row per pair: y[e] = x[src_e] . W_e
+    TORCH_CHECK(n_out == W_in.size(0), "cfconv: without an output index n_out must be the number of pairs");
+    return edge_mul_raw(W_in, x_in, c10::nullopt, idx_src_in);
+  }
   Tensor x = f32(x_in, "cfconv"), W = f32(W_in, "cfconv");
-  Tensor io = i64(idx_out_in, "cfconv"), is = i64(idx_src_in, "cfconv");
+  Tensor io = i64(*idx_out_in, "cfconv"), is = has(idx_src_in) ? i64(*idx_src_in, "cfconv") : Tensor();
   TORCH_CHECK(x.dim() == 2 && W.dim() == 2 && x.size(1) == W.size(1), "cfconv: x ", x.sizes(), " and W ", W.sizes(), " must be [n, F] and [E, F]");
   const int64_t E = W.size(0), F = W.size(1);
-  TORCH_CHECK(io.dim() == 1 && is.dim() == 1 && io.size(0) == E && is.size(0) == E, "cfconv: index tensors must have ", E, " entries");
+  TORCH_CHECK(io.dim() == 1 && io.size(0) == E && (!is.defined() || (is.dim() == 1 && is.size(0) == E)), "cfconv: index tensors must have ", E, " entries");
+  TORCH_CHECK(is.defined() || x.size(0) == E, "cfconv: x without a source index must have one row per pair");
   c10::DeviceGuard guard(x.device());
   Tensor y = at::empty({n_out, F}, x.options());
-  Tensor rp = E > 0 ? segment_rowptr(idx_out_in.scalar_type() == at::kLong && idx_out_in.is_contiguous() ? idx_out_in : io, n_out) : Tensor();
+  Tensor rp = E > 0 ? segment_rowptr(idx_out_in->scalar_type() == at::kLong && idx_out_in->is_contiguous() ? *idx_out_in : io, n_out) : Tensor();
   if (E == 0) y.zero_();
-  check(spk_cfconv_edge_f32(fp(x), fp(W), E ? io.data_ptr<int64_t>() : nullptr, E ? is.data_ptr<int64_t>() : nullptr,
+  check(spk_cfconv_edge_f32(fp(x), fp(W), E ? io.data_ptr<int64_t>() : nullptr, (E && is.defined()) ? is.data_ptr<int64_t>() : nullptr,
                             rp.defined() ? rp.data_ptr<int32_t>() : nullptr, E, n_out, x.size(0), (int32_t)F, fpm(y), stream_of(x)));
   return y;
 }
 
-Tensor edge_mul_raw(const Tensor& a_in, const Tensor& b_in, const Tensor& ia_in, const Tensor& ib_in) {
-  Tensor a = f32(a_in, "edge_mul"), b = f32(b_in, "edge_mul");
-  Tensor ia = i64(ia_in, "edge_mul"), ib = i64(ib_in, "edge_mul");
-  TORCH_CHECK(a.dim() == 2 && b.dim() == 2 && a.size(1) == b.size(1), "edge_mul: a ", a.sizes(), " and b ", b.sizes(), " must share the feature dimension");
-  TORCH_CHECK(ia.dim() == 1 && ib.dim() == 1 && ia.size(0) == ib.size(0), "edge_mul: index tensors differ in length");
-  c10::DeviceGuard guard(a.device());
-  Tensor out = at::empty({ia.size(0), a.size(1)}, a.options());
-  check(spk_edge_mul_f32(fp(a), fp(b), ia.data_ptr<int64_t>(), ib.data_ptr<int64_t>(), ia.size(0), a.size(0), b.size(0), (int32_t)a.size(1), fpm(out),
-                         stream_of(a)));
+// ---- 3-vector algebra: operands are read in place through a row stride where their layout allows it
+struct Rows { Tensor keep; const float* p; int64_t rows, width, ld; };
+Rows rows_of(const Tensor& x, const char* who) {
+  require_device(x, who);
+  TORCH_CHECK(x.scalar_type() == at::kFloat, who, ": dtype ", x.scalar_type(), " unsupported; the HIP path computes in float32");
+  TORCH_CHECK(x.dim() >= 1 && x.size(-1) > 0, who, ": empty feature dimension");
+  const int64_t width = x.size(-1), rows = x.numel() / width;
+  bool ok = x.stride(-1) == 1 || width == 1;
+  int64_t ld = -1, expected = -1;
+  for (int64_t d = x.dim() - 2; ok && d >= 0; --d) {
+    if (x.size(d) == 1) continue;
+    if (ld < 0) { ld = x.stride(d); expected = ld * x.size(d); }
+    else if (x.stride(d) != expected) ok = false;
+    else expected *= x.size(d);
+  }
+  if (ld < 0) ld = width;
+  if (!ok || ld < width || rows == 0) {
+    Tensor c = x.contiguous();
+    return {c, c.data_ptr<float>(), rows, width, width};
+  }
+  return {x, x.data_ptr<float>(), rows, width, ld};
+}
+
+Tensor vec3_raw(int64_t op, const Tensor& A_in, const Tensor& B_in) {
+  static const char* names[] = {"vscale", "vdot", "vouter", "vcontract", "vrowdot"};
+  TORCH_CHECK(op >= 0 && op <= 4, "vec3: unknown operation ", op);
+  const char* who = names[op];
+  const bool a_is_v = op != SPK_VEC3_OUTER;                       // A: V-type except for OUTER (s-type)
+  const bool b_is_u = op == SPK_VEC3_OUTER || op == SPK_VEC3_CONTRACT;
+  Rows A = rows_of(A_in, who);
+  Tensor Bu = b_is_u ? f32(B_in, who) : Tensor();
+  Rows B = b_is_u ? Rows{Bu, Bu.data_ptr<float>(), Bu.numel() / 3, 3, 3} : rows_of(B_in, who);
+  const int64_t F = A.width;
+  const int64_t M = a_is_v ? A.rows / 3 : A.rows;
+  TORCH_CHECK(!a_is_v || (A_in.dim() >= 2 && A_in.size(-2) == 3 && A.rows == 3 * M), who, ": expected a [..., 3, F] operand, got ", A_in.sizes());
+  if (b_is_u) {
+    TORCH_CHECK(Bu.numel() == 3 * M && Bu.size(-1) == 3, who, ": expected a [..., 3] operand with ", M, " rows, got ", B_in.sizes());
+  } else if (op == SPK_VEC3_DOT) {
+    TORCH_CHECK(B.width == F && B.rows == 3 * M && B_in.dim() >= 2 && B_in.size(-2) == 3, who, ": operands ", A_in.sizes(), " and ", B_in.sizes(), " differ");
+  } else {
+    TORCH_CHECK(B.width == F && B.rows == M, who, ": expected one [F] row per vector, got ", B_in.sizes(), " for ", A_in.sizes());
+  }
+  c10::DeviceGuard guard(A_in.device());
+  Tensor out;
+  auto lead = [&](const Tensor& t, int64_t drop) { auto v = t.sizes().vec(); v.resize(v.size() - drop); return v; };
+  if (op == SPK_VEC3_SCALE) out = at::empty(A_in.sizes(), A_in.options().memory_format(at::MemoryFormat::Contiguous));
+  else if (op == SPK_VEC3_DOT || op == SPK_VEC3_CONTRACT) { auto v = lead(A_in, 2); v.push_back(1); v.push_back(F); out = at::empty(v, A_in.options()); }
+  else if (op == SPK_VEC3_OUTER) { auto v = lead(B_in, 1); v.push_back(3); v.push_back(F); out = at::empty(v, A_in.options()); }
+  else { auto v = lead(A_in, 1); out = at::empty(v, A_in.options()); }
+  check(spk_vec3_f32((int32_t)op, A.p, A.ld, B.p, B.ld, M, (int32_t)F, fpm(out), stream_of(A_in)));
   return out;
 }
 
@@ -154,13 +218,17 @@ std::tuple<Tensor, Tensor> call_matmul_tn(const Tensor& u, const Tensor& x) {
   static auto op = op_handle<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&)>("spk_hip::matmul_tn");
   return op.call(u, x);
 }
-Tensor call_cfconv(const Tensor& x, const Tensor& W, const Tensor& io, const Tensor& is, int64_t n_out) {
-  static auto op = op_handle<Tensor(const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t)>("spk_hip::cfconv");
+Tensor call_cfconv(const Tensor& x, const Tensor& W, const OptT& io, const OptT& is, int64_t n_out) {
+  static auto op = op_handle<Tensor(const Tensor&, const Tensor&, const OptT&, const OptT&, int64_t)>("spk_hip::cfconv");
   return op.call(x, W, io, is, n_out);
 }
-Tensor call_edge_mul(const Tensor& a, const Tensor& b, const Tensor& ia, const Tensor& ib) {
-  static auto op = op_handle<Tensor(const Tensor&, const Tensor&, const Tensor&, const Tensor&)>("spk_hip::edge_mul");
+Tensor call_edge_mul(const Tensor& a, const Tensor& b, const OptT& ia, const OptT& ib) {
+  static auto op = op_handle<Tensor(const Tensor&, const Tensor&, const OptT&, const OptT&)>("spk_hip::edge_mul");
   return op.call(a, b, ia, ib);
+}
+Tensor call_vec3(int64_t opc, const Tensor& A, const Tensor& B) {
+  static auto op = op_handle<Tensor(int64_t, const Tensor&, const Tensor&)>("spk_hip::vec3");
+  return op.call(opc, A, B);
 }
 Tensor call_radial_d(const Tensor& d, const OptT& a, int64_t kind, const Tensor& p0, const OptT& p1, double cutoff, int64_t order) {
   static auto op = op_handle<Tensor(const Tensor&, const OptT&, int64_t, const Tensor&, const OptT&, double, int64_t)>("spk_hip::radial_d");
@@ -264,35 +332,75 @@ struct MatmulTNFn : public torch::autograd::Function<MatmulTNFn> {
   }
 };
 
-// y[out_e] += x[src_e] . W_e
+// y[out_e] += x[src_e] . W_e   (an absent index is the identity)
 struct CfconvFn : public torch::autograd::Function<CfconvFn> {
-  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& W, const Tensor& io, const Tensor& is, int64_t n_out) {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& W, const OptT& io, const OptT& is, int64_t n_out) {
     at::AutoDispatchBelowADInplaceOrView guard;
-    ctx->save_for_backward({x, W, io, is});
+    ctx->save_for_backward({x, W, has(io) ? *io : Tensor(), has(is) ? *is : Tensor()});
     return call_cfconv(x, W, io, is, n_out);
   }
   static variable_list backward(AutogradContext* ctx, variable_list g) {
     auto sv = ctx->get_saved_variables();
     Tensor gx, gW;
-    if (ctx->needs_input_grad(0)) gx = call_cfconv(g[0], sv[1], sv[3], sv[2], sv[0].size(0));
-    if (ctx->needs_input_grad(1)) gW = call_edge_mul(g[0], sv[0], sv[2], sv[3]);
+    if (ctx->needs_input_grad(0)) gx = call_cfconv(g[0], sv[1], opt_of(sv[3]), opt_of(sv[2]), sv[0].size(0));
+    if (ctx->needs_input_grad(1)) gW = call_edge_mul(g[0], sv[0], opt_of(sv[2]), opt_of(sv[3]));
     return {gx, gW, Tensor(), Tensor(), Tensor()};
   }
 };
 
 // out_e = a[ia_e] . b[ib_e]
 struct EdgeMulFn : public torch::autograd::Function<EdgeMulFn> {
-  static Tensor forward(AutogradContext* ctx, const Tensor& a, const Tensor& b, const Tensor& ia, const Tensor& ib) {
+  static Tensor forward(AutogradContext* ctx, const Tensor& a, const Tensor& b, const OptT& ia, const OptT& ib) {
     at::AutoDispatchBelowADInplaceOrView guard;
-    ctx->save_for_backward({a, b, ia, ib});
+    ctx->save_for_backward({a, b, has(ia) ? *ia : Tensor(), has(ib) ? *ib : Tensor()});
     return call_edge_mul(a, b, ia, ib);
   }
   static variable_list backward(AutogradContext* ctx, variable_list g) {
     auto sv = ctx->get_saved_variables();
     Tensor ga, gb;
-    if (ctx->needs_input_grad(0)) ga = call_cfconv(sv[1], g[0], sv[2], sv[3], sv[0].size(0));
-    if (ctx->needs_input_grad(1)) gb = call_cfconv(sv[0], g[0], sv[3], sv[2], sv[1].size(0));
+    if (ctx->needs_input_grad(0)) ga = call_cfconv(sv[1], g[0], opt_of(sv[2]), opt_of(sv[3]), sv[0].size(0));
+    if (ctx->needs_input_grad(1)) gb = call_cfconv(sv[0], g[0], opt_of(sv[3]), opt_of(sv[2]), sv[1].size(0));
     return {ga, gb, Tensor(), Tensor()};
+  }
+};
+
+// the five 3-vector products: each backward is two of the others
+struct Vec3Fn : public torch::autograd::Function<Vec3Fn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& A, const Tensor& B, int64_t op) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({A, B});
+    ctx->saved_data["op"] = op;
+    return call_vec3(op, A, B);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gl) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &A = sv[0], &B = sv[1], &g = gl[0];
+    const int64_t op = ctx->saved_data["op"].toInt();
+    const bool nA = ctx->needs_input_grad(0), nB = ctx->needs_input_grad(1);
+    Tensor gA, gB;
+    switch (op) {
+      case SPK_VEC3_SCALE:      // V s
+        if (nA) gA = call_vec3(SPK_VEC3_SCALE, g, B);
+        if (nB) gB = call_vec3(SPK_VEC3_DOT, g, A).reshape(B.sizes());
+        break;
+      case SPK_VEC3_DOT:        // sum_k A B
+        if (nA) gA = call_vec3(SPK_VEC3_SCALE, B, g);
+        if (nB) gB = call_vec3(SPK_VEC3_SCALE, A, g);
+        break;
+      case SPK_VEC3_OUTER:      // s u_k
+        if (nA) gA = call_vec3(SPK_VEC3_CONTRACT, g, B).reshape(A.sizes());
+        if (nB) gB = call_vec3(SPK_VEC3_ROWDOT, g, A).reshape(B.sizes());
+        break;
+      case SPK_VEC3_CONTRACT:   // sum_k G u_k
+        if (nA) gA = call_vec3(SPK_VEC3_OUTER, g, B).reshape(A.sizes());
+        if (nB) gB = call_vec3(SPK_VEC3_ROWDOT, A, g).reshape(B.sizes());
+        break;
+      default:                  // sum_f G s
+        if (nA) gA = call_vec3(SPK_VEC3_OUTER, B, g).reshape(A.sizes());
+        if (nB) gB = call_vec3(SPK_VEC3_CONTRACT, A, g).reshape(B.sizes());
+        break;
+    }
+    return {gA, gB, Tensor()};
   }
 };
 
@@ -409,8 +517,9 @@ std::tuple<Tensor, Tensor> matmul_tn_ad(const Tensor& u, const Tensor& x) {
   auto r = MatmulTNFn::apply(u, x);
   return {r[0], r[1]};
 }
-Tensor cfconv_ad(const Tensor& x, const Tensor& W, const Tensor& io, const Tensor& is, int64_t n_out) { return CfconvFn::apply(x, W, io, is, n_out); }
-Tensor edge_mul_ad(const Tensor& a, const Tensor& b, const Tensor& ia, const Tensor& ib) { return EdgeMulFn::apply(a, b, ia, ib); }
+Tensor cfconv_ad(const Tensor& x, const Tensor& W, const OptT& io, const OptT& is, int64_t n_out) { return CfconvFn::apply(x, W, io, is, n_out); }
+Tensor edge_mul_ad(const Tensor& a, const Tensor& b, const OptT& ia, const OptT& ib) { return EdgeMulFn::apply(a, b, ia, ib); }
+Tensor vec3_ad(int64_t op, const Tensor& A, const Tensor& B) { return Vec3Fn::apply(A, B, op); }
 Tensor radial_d_ad(const Tensor& d, const OptT& a, int64_t kind, const Tensor& p0, const OptT& p1, double cutoff, int64_t order) {
   check_fixed_basis(p0, p1, "spk_hip::radial_d");
   return RadialDFn::apply(d, p0, a, p1, kind, cutoff, order);
@@ -438,8 +547,19 @@ Tensor matmul_nn_meta(const Tensor& u, const Tensor& w) {
 std::tuple<Tensor, Tensor> matmul_tn_meta(const Tensor& u, const Tensor& x) {
   return {at::empty({u.size(-1), x.size(-1)}, u.options()), at::empty({u.size(-1)}, u.options())};
 }
-Tensor cfconv_meta(const Tensor& x, const Tensor& W, const Tensor&, const Tensor&, int64_t n_out) { return at::empty({n_out, W.size(1)}, x.options()); }
-Tensor edge_mul_meta(const Tensor& a, const Tensor&, const Tensor& ia, const Tensor&) { return at::empty({ia.size(0), a.size(1)}, a.options()); }
+Tensor cfconv_meta(const Tensor& x, const Tensor& W, const OptT&, const OptT&, int64_t n_out) { return at::empty({n_out, W.size(1)}, x.options()); }
+Tensor edge_mul_meta(const Tensor& a, const Tensor& b, const OptT& ia, const OptT& ib) {
+  const int64_t E = has(ia) ? ia->size(0) : (has(ib) ? ib->size(0) : a.size(0));
+  return at::empty({E, a.size(1)}, a.options());
+}
+Tensor vec3_meta(int64_t op, const Tensor& A, const Tensor& B) {
+  auto lead = [](const Tensor& t, int64_t drop) { auto v = t.sizes().vec(); v.resize(v.size() - drop); return v; };
+  const int64_t F = A.size(-1);
+  if (op == SPK_VEC3_SCALE) return at::empty(A.sizes(), A.options());
+  if (op == SPK_VEC3_DOT || op == SPK_VEC3_CONTRACT) { auto v = lead(A, 2); v.push_back(1); v.push_back(F); return at::empty(v, A.options()); }
+  if (op == SPK_VEC3_OUTER) { auto v = lead(B, 1); v.push_back(3); v.push_back(F); return at::empty(v, A.options()); }
+  return at::empty(lead(A, 1), A.options());
+}
 Tensor radial_d_meta(const Tensor& d, const OptT&, int64_t kind, const Tensor& p0, const OptT&, double, int64_t) {
   auto shape = d.sizes().vec();
   if (kind != 2) shape.push_back(p0.size(0));
@@ -455,15 +575,16 @@ Tensor rowdot_meta(const Tensor& a, const Tensor&) {
 Tensor edge_norm_meta(const Tensor& r) { return at::empty({r.size(0)}, r.options()); }
 
 // ------------------------------------------------------------------------------------------------ registration
-const char* const kTrainOps[] = {"act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm"};
+const char* const kTrainOps[] = {"act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm", "vec3"};
 
 void train_defs(torch::Library& m) {
   m.def("act_mul(Tensor? a, Tensor z, int act, int order, Tensor? c=None) -> Tensor");                   // a . act^(order)(z) + c
   m.def("linear(Tensor x, Tensor weight, Tensor? bias) -> Tensor");                                       // x W^T + b
   m.def("matmul_nn(Tensor u, Tensor weight) -> Tensor");                                                  // u W
   m.def("matmul_tn(Tensor u, Tensor x) -> (Tensor, Tensor)");                                             // (u^T x, column sums of u)
-  m.def("cfconv(Tensor x, Tensor W, Tensor idx_out, Tensor idx_src, int n_out) -> Tensor");               // schnet.py:64-66
-  m.def("edge_mul(Tensor a, Tensor b, Tensor idx_a, Tensor idx_b) -> Tensor");
+  m.def("cfconv(Tensor x, Tensor W, Tensor? idx_out, Tensor? idx_src, int n_out) -> Tensor");             // schnet.py:64-66 (None: identity)
+  m.def("edge_mul(Tensor a, Tensor b, Tensor? idx_a, Tensor? idx_b) -> Tensor");                          // Wij * x[idx_j], painn.py:57
+  m.def("vec3(int op, Tensor A, Tensor B) -> Tensor");                                                    // 3-vector products of painn.py:60-63, 104-114
   m.def("radial_d(Tensor d, Tensor? a, int kind, Tensor p0, Tensor? p1, float cutoff, int order) -> Tensor");   // nn/radial.py, nn/cutoff.py, order-th derivative
   m.def("radial_c(Tensor G, Tensor d, Tensor? a, int kind, Tensor p0, Tensor? p1, float cutoff, int order) -> Tensor");
   m.def("rowscale(Tensor W, Tensor s) -> Tensor");                                                        // Wij * rcut_ij[:, None], schnet.py:61
@@ -477,6 +598,7 @@ void train_impl_device(torch::Library& m) {
   m.impl("matmul_tn", matmul_tn_raw);
   m.impl("cfconv", cfconv_raw);
   m.impl("edge_mul", edge_mul_raw);
+  m.impl("vec3", vec3_raw);
   m.impl("radial_d", radial_d_raw);
   m.impl("radial_c", radial_c_raw);
   m.impl("rowscale", rowscale_raw);
@@ -490,6 +612,7 @@ void train_impl_autograd(torch::Library& m) {
   m.impl("matmul_tn", matmul_tn_ad);
   m.impl("cfconv", cfconv_ad);
   m.impl("edge_mul", edge_mul_ad);
+  m.impl("vec3", vec3_ad);
   m.impl("radial_d", radial_d_ad);
   m.impl("radial_c", radial_c_ad);
   m.impl("rowscale", rowscale_ad);
@@ -503,6 +626,7 @@ void train_impl_meta(torch::Library& m) {
   m.impl("matmul_tn", matmul_tn_meta);
   m.impl("cfconv", cfconv_meta);
   m.impl("edge_mul", edge_mul_meta);
+  m.impl("vec3", vec3_meta);
   m.impl("radial_d", radial_d_meta);
   m.impl("radial_c", radial_c_meta);
   m.impl("rowscale", rowscale_meta);

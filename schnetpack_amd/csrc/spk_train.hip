@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_cfconv_rows(const float* __restrict__ x
       for (int v = 0; v < V; ++v) acc[v] = 0.f;
       if (slot < slots && c < F) {
         for (int e = e0 + slot; e < e1; e += slots) {
-          const int64_t j = src[e];
+          const int64_t j = src ? src[e] : e;
           if ((uint64_t)j >= (uint64_t)n_src) continue;
           if (V == 4) {
             const f32x4 xv = *(const f32x4*)(x + j * F + c), wv = *(const f32x4*)(W + (int64_t)e * F + c);
@@ -242,7 +242,7 @@ __global__ void k_cfconv_atomic(const float* __restrict__ x, const float* __rest
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = t / F;
     const int f = (int)(t % F);
-    const int64_t i = out[e], j = src[e];
+    const int64_t i = out[e], j = src ? src[e] : e;
     if ((uint64_t)i >= (uint64_t)n_out || (uint64_t)j >= (uint64_t)n_src) continue;
     unsafeAtomicAdd(y + i * F + f, x[j * F + f] * W[t]);
   }
@@ -254,7 +254,7 @@ extern "C" int spk_cfconv_edge_f32(const float* x, const float* W, const int64_t
   SPK_CHECK_ARG(E >= 0 && n_out >= 0 && n_src >= 0 && F > 0, "spk_cfconv_edge_f32: bad sizes");
   if (n_out == 0) return SPK_OK;
   SPK_CHECK_ARG(y != nullptr, "spk_cfconv_edge_f32: null output");
-  SPK_CHECK_ARG(E == 0 || (x && W && idx_out && idx_src), "spk_cfconv_edge_f32: null pointer");
+  SPK_CHECK_ARG(E == 0 || (x && W && idx_out), "spk_cfconv_edge_f32: null pointer");
   SPK_CHECK_ARG(E < (1ll << 31), "spk_cfconv_edge_f32: more than 2^31 pairs");
   SpkProfScope prof("cfconv_edge", stream);
   const int maxb = spk_num_cus() * 16;
@@ -285,7 +285,7 @@ __global__ void k_edge_mul(const float* __restrict__ a, const float* __restrict_
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = t / FV;
     const int c = (int)(t % FV) * V;
-    const int64_t i = ia[e], j = ib[e];
+    const int64_t i = ia ? ia[e] : e, j = ib ? ib[e] : e;
     const bool ok = (uint64_t)i < (uint64_t)na && (uint64_t)j < (uint64_t)nb;
     if (V == 4) {
       f32x4 o{0.f, 0.f, 0.f, 0.f};
@@ -302,7 +302,7 @@ extern "C" int spk_edge_mul_f32(const float* a, const float* b, const int64_t* i
   hipStream_t stream = (hipStream_t)stream_;
   SPK_CHECK_ARG(E >= 0 && na >= 0 && nb >= 0 && F > 0, "spk_edge_mul_f32: bad sizes");
   if (E == 0) return SPK_OK;
-  SPK_CHECK_ARG(a && b && idx_a && idx_b && out, "spk_edge_mul_f32: null pointer");
+  SPK_CHECK_ARG(a && b && out, "spk_edge_mul_f32: null pointer");
   SpkProfScope prof("edge_mul", stream);
   const int maxb = spk_num_cus() * 16;
   const bool v4 = (F % 4 == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0);
@@ -449,6 +449,83 @@ extern "C" int spk_rowdot_f32(const float* a, const float* b, int64_t rows, int3
   SPK_CHECK_ARG(a && b && out, "spk_rowdot_f32: null pointer");
   SpkProfScope prof("rowdot", stream);
   hipLaunchKernelGGL(k_rowdot, dim3(spk_grid_for(rows, 4, spk_num_cus() * 16)), dim3(256), 0, stream, a, b, rows, F, out);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ 3-vector algebra (PaiNN, painn.py:55-66, 99-117)
+// V-type operands are [M, 3, F] (Cartesian component in the middle), s-type [M, F], u-type [M, 3]; every V / s operand comes with a
+// row stride (ld) so that the halves of a split tensor are read in place.  Five kernels, closed under differentiation:
+//   vscale(V, s)[m,k,f] = V s        d/dV -> vscale(g, s)    d/ds -> vdot(g, V)
+//   vdot(A, B)[m,f] = sum_k A B      d/dA -> vscale(B, g)    d/dB -> vscale(A, g)
+//   vouter(s, u)[m,k,f] = s u_k      d/ds -> vcontract(g, u) d/du -> vrowdot(g, s)
+//   vcontract(G, u)[m,f] = sum_k G u_k   d/dG -> vouter(g, u)    d/du -> vrowdot(G, g)
+//   vrowdot(G, s)[m,k] = sum_f G s       d/dG -> vouter(s, g)    d/ds -> vcontract(G, g)
+__global__ void k_vscale(const float* __restrict__ V, int64_t ldV, const float* __restrict__ s, int64_t lds, int64_t M, int F, float* __restrict__ out) {
+  const int64_t total = M * 3 * F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(t % F);
+    const int64_t row = t / F, m = row / 3;
+    out[t] = V[row * ldV + f] * s[m * lds + f];
+  }
+}
+__global__ void k_vdot(const float* __restrict__ A, int64_t ldA, const float* __restrict__ B, int64_t ldB, int64_t M, int F, float* __restrict__ out) {
+  const int64_t total = M * F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(t % F);
+    const int64_t m = t / F;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc = fmaf(A[(3 * m + k) * ldA + f], B[(3 * m + k) * ldB + f], acc);
+    out[t] = acc;
+  }
+}
+__global__ void k_vouter(const float* __restrict__ s, int64_t lds, const float* __restrict__ u, int64_t M, int F, float* __restrict__ out) {
+  const int64_t total = M * 3 * F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(t % F);
+    const int64_t row = t / F, m = row / 3;
+    out[t] = s[m * lds + f] * u[row];
+  }
+}
+__global__ void k_vcontract(const float* __restrict__ G, int64_t ldG, const float* __restrict__ u, int64_t M, int F, float* __restrict__ out) {
+  const int64_t total = M * F;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(t % F);
+    const int64_t m = t / F;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc = fmaf(G[(3 * m + k) * ldG + f], u[3 * m + k], acc);
+    out[t] = acc;
+  }
+}
+// one wave per (m, k) row
+__global__ __launch_bounds__(256) void k_vrowdot(const float* __restrict__ G, int64_t ldG, const float* __restrict__ s, int64_t lds, int64_t M, int F,
+                                                 float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6); row < 3 * M; row += (int64_t)gridDim.x * 4) {
+    const int64_t m = row / 3;
+    float acc = 0.f;
+    for (int f = lane; f < F; f += 64) acc = fmaf(G[row * ldG + f], s[m * lds + f], acc);
+    acc = spk_wave_sum(acc);
+    if (lane == 0) out[row] = acc;
+  }
+}
+
+extern "C" int spk_vec3_f32(int32_t op, const float* A, int64_t ldA, const float* B, int64_t ldB, int64_t M, int32_t F, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(op >= 0 && op <= 4 && M >= 0 && F > 0, "spk_vec3_f32: bad arguments");
+  if (M == 0) return SPK_OK;
+  SPK_CHECK_ARG(A && B && out, "spk_vec3_f32: null pointer");
+  SpkProfScope prof("vec3", stream);
+  const int maxb = spk_num_cus() * 16;
+  switch (op) {
+    case SPK_VEC3_SCALE: hipLaunchKernelGGL(k_vscale, dim3(spk_grid_for(M * 3 * F, 256, maxb)), dim3(256), 0, stream, A, ldA, B, ldB, M, F, out); break;
+    case SPK_VEC3_DOT: hipLaunchKernelGGL(k_vdot, dim3(spk_grid_for(M * F, 256, maxb)), dim3(256), 0, stream, A, ldA, B, ldB, M, F, out); break;
+    case SPK_VEC3_OUTER: hipLaunchKernelGGL(k_vouter, dim3(spk_grid_for(M * 3 * F, 256, maxb)), dim3(256), 0, stream, A, ldA, B, M, F, out); break;
+    case SPK_VEC3_CONTRACT: hipLaunchKernelGGL(k_vcontract, dim3(spk_grid_for(M * F, 256, maxb)), dim3(256), 0, stream, A, ldA, B, M, F, out); break;
+    default: hipLaunchKernelGGL(k_vrowdot, dim3(spk_grid_for(3 * M, 4, maxb)), dim3(256), 0, stream, A, ldA, B, ldB, M, F, out); break;
+  }
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

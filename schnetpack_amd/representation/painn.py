@@ -43,12 +43,14 @@ class PaiNNInteraction(nn.Module):
     def forward(self, q: torch.Tensor, mu: torch.Tensor, Wij: torch.Tensor, dir_ij: torch.Tensor,
                 idx_i: torch.Tensor, idx_j: torch.Tensor, n_atoms: int):
         x = self.interatomic_context_net(q)
-        xj = torch.ops.spk_hip.gather(x, idx_j, 0)
-        muj = torch.ops.spk_hip.gather(mu, idx_j, 0)
-        x = Wij * xj
+        n3 = x.shape[-1]
+        # x = Wij * x[idx_j]: one gather-multiply (the filters carry one row per pair: no index on that side)
+        x = torch.ops.spk_hip.edge_mul(Wij.reshape(-1, n3), x.reshape(-1, n3), None, idx_j)
         dq, dmuR, dmumu = torch.split(x, self.n_atom_basis, dim=-1)
-        dq = scatter_add(dq, idx_i, dim_size=n_atoms)
-        dmu = dmuR * dir_ij[..., None] + dmumu * muj
+        dq = scatter_add(dq, idx_i, dim_size=n_atoms).unsqueeze(1)
+        muj = torch.ops.spk_hip.gather(mu, idx_j, 0)
+        # dmu = dmuR * dir_ij[..., None] + dmumu * muj  (3-vector products that read the halves of the split in place)
+        dmu = torch.ops.spk_hip.vec3(2, dmuR, dir_ij) + torch.ops.spk_hip.vec3(0, muj, dmumu)
         dmu = scatter_add(dmu, idx_i, dim_size=n_atoms)
         return q + dq, mu + dmu
 
@@ -76,12 +78,14 @@ class PaiNNMixing(nn.Module):
     def forward(self, q: torch.Tensor, mu: torch.Tensor):
         mu_mix = self.mu_channel_mix(mu)
         mu_V, mu_W = torch.split(mu_mix, self.n_atom_basis, dim=-1)
-        mu_Vn = torch.sqrt(torch.sum(mu_V ** 2, dim=-2, keepdim=True) + self.epsilon)
+        # sum(mu_V ** 2, dim=-2, keepdim=True), dmu_intra * mu_W, sum(mu_V * mu_W, dim=1, keepdim=True): 3-vector products
+        # (vec3 codes: 0 = V * s, 1 = sum over the Cartesian axis of A * B) on the halves of mu_mix as they lie
+        mu_Vn = torch.sqrt(torch.ops.spk_hip.vec3(1, mu_V, mu_V) + self.epsilon)
         ctx = torch.cat([q, mu_Vn], dim=-1)
         x = self.intraatomic_context_net(ctx)
         dq_intra, dmu_intra, dqmu_intra = torch.split(x, self.n_atom_basis, dim=-1)
-        dmu_intra = dmu_intra * mu_W
-        dqmu_intra = dqmu_intra * torch.sum(mu_V * mu_W, dim=1, keepdim=True)
+        dmu_intra = torch.ops.spk_hip.vec3(0, mu_W, dmu_intra)
+        dqmu_intra = dqmu_intra * torch.ops.spk_hip.vec3(1, mu_V, mu_W)
         return q + dq_intra + dqmu_intra, mu + dmu_intra
 
 

@@ -44,7 +44,11 @@ OPERATORS = ["scatter_add", "gather", "pairwise", "pairwise_backward", "dense", 
              "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "edge_plan_install", "static_declare", "static_declare_range", "static_refresh", "static_enable",
              "static_check", "static_clear", "clear_caches",
              # training regime: operators closed under differentiation (csrc/spk_torch_train.h)
-             "act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm"]
+             "act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm", "vec3"]
+
+
+# operation codes of torch.ops.spk_hip.vec3 (include/spk_hip.h: SPK_VEC3_*)
+VEC3_SCALE, VEC3_DOT, VEC3_OUTER, VEC3_CONTRACT, VEC3_ROWDOT = 0, 1, 2, 3, 4
 
 
 class StaticLists:

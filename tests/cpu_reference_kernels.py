@@ -71,7 +71,28 @@ def radial_c(G, d, a, kind, p0, p1, cutoff, order):
 
 
 def cfconv(x, W, idx_out, idx_src, n_out):
-    return torch.zeros(n_out, W.shape[1], dtype=x.dtype, device=x.device).index_add(0, idx_out, x[idx_src] * W)
+    xs = x if idx_src is None else x[idx_src]
+    if idx_out is None:
+        return xs * W
+    return torch.zeros(n_out, W.shape[1], dtype=x.dtype, device=x.device).index_add(0, idx_out, xs * W)
+
+
+def edge_mul(a, b, ia, ib):
+    return (a if ia is None else a[ia]) * (b if ib is None else b[ib])
+
+
+def vec3(op, A, B):
+    """the five 3-vector products (include/spk_hip.h: SPK_VEC3_*); V: [..., 3, F], s: [..., F] (or [..., 1, F]), u: [..., 3]"""
+    F = A.shape[-1]
+    if op == 0:
+        return A * B.reshape(A.shape[:-2] + (1, F))
+    if op == 1:
+        return (A * B).sum(-2, keepdim=True)
+    if op == 2:
+        return A.reshape(B.shape[:-1] + (1, F)) * B[..., None]
+    if op == 3:
+        return (A * B[..., None]).sum(-2, keepdim=True)
+    return (A * B.reshape(A.shape[:-2] + (1, F))).sum(-1)
 
 
 def dense_forward(x, w, b, act):
@@ -104,7 +125,8 @@ KERNELS = {
     "matmul_nn": lambda u, w: u @ w,
     "matmul_tn": lambda u, x: (u.reshape(-1, u.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), u.reshape(-1, u.shape[-1]).sum(0)),
     "cfconv": cfconv,
-    "edge_mul": lambda a, b, ia, ib: a[ia] * b[ib],
+    "edge_mul": edge_mul,
+    "vec3": vec3,
     "radial_d": radial_d,
     "radial_c": radial_c,
     "rowscale": lambda W, s: W * s.reshape(W.shape[:-1])[..., None],

@@ -34,7 +34,8 @@ def test_act_mul(dev, act, order):
     assert rel_err(ops.act_mul(None, z.to(dev), act, order).cpu(), crk.act_mul(None, z.double(), act, order)) < TOL or (act == 0 and order >= 2)
 
 
-@pytest.mark.parametrize("n,k,o", [(168, 128, 128), (2432, 20, 128), (2432, 128, 20), (168, 64, 1), (168, 1, 64), (5, 12, 36), (1000, 132, 100), (70, 128, 1152)])
+@pytest.mark.parametrize("n,k,o", [(168, 128, 128), (2432, 20, 128), (2432, 128, 20), (168, 64, 1), (168, 1, 64), (5, 12, 36), (1000, 132, 100), (70, 128, 1152),
+                                   (2560, 20, 1152), (100, 640, 64), (33, 1000, 8)])
 def test_linear_and_matmul_nn_any_width(dev, n, k, o):
     """x W^T + b and u W on the MFMA tiles for widths that are multiples of 4 (masked partial tiles) and on the simple kernel
     otherwise."""
@@ -94,6 +95,42 @@ def test_radial_functions_and_their_derivatives(dev, kind, order):
         ref = crk.radial_c(G.double(), d.double(), a.double(), kind, p0.double(), None if p1 is None else p1.double(), 5.0, order)
         got = ops.radial_c(G.to(dev), d.to(dev), a.to(dev), kind, p0.to(dev), None if p1 is None else p1.to(dev), 5.0, order)
         assert rel_err(got.cpu(), ref) < 5e-6
+
+
+def test_identity_indices(dev):
+    N, E, F = 40, 300, 24
+    ii, jj = _lists(N, E, 9)
+    W, x, xe = rnd(E, F), rnd(N, F, seed=1), rnd(E, F, seed=2)
+    assert rel_err(ops.edge_mul(W.to(dev), x.to(dev), None, jj.to(dev)).cpu(), W.double() * x.double()[jj]) < TOL
+    assert rel_err(ops.cfconv(xe.to(dev), W.to(dev), ii.to(dev), None, N).cpu(), crk.cfconv(xe.double(), W.double(), ii, None, N)) < TOL
+    assert rel_err(ops.cfconv(x.to(dev), W.to(dev), None, jj.to(dev), E).cpu(), x.double()[jj] * W.double()) < TOL
+
+
+@pytest.mark.parametrize("op", [0, 1, 2, 3, 4])
+def test_three_vector_products_read_split_halves_in_place(dev, op):
+    """vec3 on dense operands and on halves of split tensors (row-strided views: no copy), against the formulas."""
+    M, F = 333, 48
+    V2, s3, u = rnd(M, 3, 2 * F), rnd(M, 1, 3 * F, seed=1), rnd(M, 3, seed=2)
+    Vd, sd = V2.to(dev), s3.to(dev)
+    for half in (0, 1):
+        V, Vr = Vd[..., half * F:(half + 1) * F], V2.double()[..., half * F:(half + 1) * F]
+        W, Wr = Vd[..., (1 - half) * F:(2 - half) * F], V2.double()[..., (1 - half) * F:(2 - half) * F]
+        sv, sr = sd[..., half * F:(half + 1) * F], s3.double()[..., half * F:(half + 1) * F]
+        if op == 0:
+            got, ref = ops.vec3(0, V, sv), crk.vec3(0, Vr, sr)
+        elif op == 1:
+            got, ref = ops.vec3(1, V, W), crk.vec3(1, Vr, Wr)
+        elif op == 2:
+            got, ref = ops.vec3(2, sv, u.to(dev)), crk.vec3(2, sr, u.double())
+        elif op == 3:
+            got, ref = ops.vec3(3, V, u.to(dev)), crk.vec3(3, Vr, u.double())
+        else:
+            got, ref = ops.vec3(4, V, sv), crk.vec3(4, Vr, sr)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert rel_err(got.cpu(), ref) < TOL
+    # transposed (non row-uniform) operand: falls back to a dense copy, same values
+    Vt = rnd(3, M, F).to(dev).permute(1, 0, 2)
+    assert rel_err(ops.vec3(1, Vt, Vt).cpu(), crk.vec3(1, Vt.cpu().double(), Vt.cpu().double())) < TOL
 
 
 def test_rowscale_rowdot_edge_norm(dev):

@@ -48,6 +48,16 @@ def _cases():
         "radial_d cutoff without a": (lambda d: ops.radial_d(d, None, 2, p0, None, 5.0, 0), (d,)),
         "radial_c gaussian": (lambda G, d, a: ops.radial_c(G, d, a, 0, p0, p1, 5.0, 0), (T(E, R), d, T(E))),
         "radial_c bessel'": (lambda G, d: ops.radial_c(G, d, None, 1, fr, None, 5.0, 1), (T(E, R), d)),
+        "edge_mul, identity index on a": (lambda a, b: ops.edge_mul(a, b, None, jj), (T(E, F), T(N, F))),
+        "cfconv, identity source": (lambda x, W: ops.cfconv(x, W, ii, None, N), (T(E, F), T(E, F))),
+        "cfconv, identity output": (lambda x, W: ops.cfconv(x, W, None, jj, E), (T(N, F), T(E, F))),
+        "vscale": (lambda V, s: ops.vec3(0, V, s), (T(N, 3, F), T(N, 1, F))),
+        "vscale on halves of split tensors": (lambda V, s: ops.vec3(0, V[..., F:], s[..., :F]), (T(N, 3, 2 * F), T(N, 1, 3 * F))),
+        "vdot": (lambda A, B: ops.vec3(1, A, B), (T(N, 3, F), T(N, 3, F))),
+        "vdot on the two halves of one tensor": (lambda A: ops.vec3(1, A[..., :F], A[..., F:]), (T(N, 3, 2 * F),)),
+        "vouter": (lambda s, u: ops.vec3(2, s, u), (T(E, 1, F), T(E, 3))),
+        "vcontract": (lambda G, u: ops.vec3(3, G, u), (T(E, 3, F), T(E, 3))),
+        "vrowdot": (lambda G, s: ops.vec3(4, G, s), (T(E, 3, F), T(E, 1, F))),
         "rowscale": (lambda W, s: ops.rowscale(W, s), (T(E, F), T(E))),
         "rowdot": (lambda a, b: ops.rowdot(a, b), (T(E, F), T(E, F))),
         "edge_norm": (lambda r: ops.edge_norm(r), (T(E, 3),)),
