@@ -218,7 +218,7 @@ static int dense_dispatch(const float* in, const float* pre_in, const float* w, 
   const bool mfma_combo = (pro == SPK_ACT_NONE) || (act == SPK_ACT_NONE && trans);
   if (shape_ok && mfma_combo && variant != SPK_VARIANT_SIMPLE) {
     const int64_t ntasks = ((M + 31) / 32) * ((NW + 31) / 32);
-    if (KC >= 512 && ntasks <= 2 * (int64_t)spk_num_cus() && act == SPK_ACT_NONE && pro == SPK_ACT_NONE && !res && !pre_out) {
+    if (KC >= 256 && ntasks <= 2 * (int64_t)spk_num_cus() && act == SPK_ACT_NONE && pro == SPK_ACT_NONE && !res && !pre_out) {
       if (trans) hipLaunchKernelGGL((k_dense_mfma_splitk<true>), dim3((unsigned)ntasks), dim3(256), 0, stream, in, w, b, out, M, KC, NW);
       else hipLaunchKernelGGL((k_dense_mfma_splitk<false>), dim3((unsigned)ntasks), dim3(256), 0, stream, in, w, b, out, M, KC, NW);
       SPK_LAUNCH_CHECK();
