@@ -27,6 +27,8 @@
 #define ML_MAXEDGES 768
 #define ML_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
 
+bool spk_schnet_mol_bwd_eligible(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb);
+
 struct MolLayerDev {
   const float* in2f_p;                  // packed forward image of in2f.weight [NF, F] (spk_pack_weight_f32)
   const float *w1, *b1, *w2, *b2;       // filter network, raw state_dict tensors
@@ -51,6 +53,7 @@ struct MolFwdArgs {
   float* gbase;             // per interaction [gsz] raw filter outputs, row = position of the pair in `half`
   int64_t gsz, N;
   RadialDev rb;
+  int compact;              // drop the pairs beyond the cutoff from the tiles (lists with a skin); the backward does the same
   long long* dbg;           // tuning aid: cycle stamps of thread 0 of workgroup 0 (null in production)
 };
 #define ML_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -78,19 +81,40 @@ __device__ __forceinline__ void ml_rbf(int kind, int n_rbf, const float* __restr
   }
 }
 
-// pair records of a group: geometry is the same for every interaction
-__device__ __forceinline__ void ml_pair_records(MolPair* sP, const int32_t* __restrict__ half, const float* __restrict__ rij,
-                                                const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j, int p0, int np, int a0,
-                                                float cutoff, int tid) {
-  for (int s = tid; s < np; s += 512) {
-    const int64_t e = half[p0 + s];
+// pair records of a group: geometry is the same for every interaction.  ij = local i | local j << 8 | position of the pair in the
+// group's pair list << 16.  With `compact` (lists with a skin: MD) only the pairs INSIDE the cutoff get a record -- the others
+// contribute exactly zero (f_c = f_c' = 0) and are not worth a tile of filter GEMMs; the order of the list is kept (ballot +
+// prefix over the waves: deterministic, the backward reproduces it), sMap[position] = record index or -1.  Returns the number of
+// records (uniform over the workgroup).  Contains workgroup barriers: call it from uniform code, np <= 512.
+__device__ __forceinline__ int ml_pair_records(MolPair* sP, short* sMap, int* sScan, const int32_t* __restrict__ half, const float* __restrict__ rij,
+                                               const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j, int p0, int np, int a0,
+                                               float cutoff, bool compact, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  MolPair pr;
+  bool keep = false;
+  if (tid < np) {
+    const int64_t e = half[p0 + tid];
     const float rx = rij[3 * e], ry = rij[3 * e + 1], rz = rij[3 * e + 2];
-    MolPair pr;
-    pr.ij = (int)(idx_i[e] - a0) | ((int)(idx_j[e] - a0) << 8);
+    pr.ij = (int)(idx_i[e] - a0) | ((int)(idx_j[e] - a0) << 8) | (tid << 16);
     pr.d = sqrtf(rx * rx + ry * ry + rz * rz);
     spk_cutoff_eval_fast(cutoff, pr.d, pr.fc, pr.dfc);
-    sP[s] = pr;
+    keep = !compact || pr.d < cutoff;
   }
+  const unsigned long long bal = __ballot(keep);
+  if (lane == 0) sScan[wv] = __popcll(bal);
+  __syncthreads();
+  int off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const int c = sScan[w];
+    if (w < wv) off += c;
+    total += c;
+  }
+  const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+  if (keep) sP[pos] = pr;
+  if (sMap && tid < np) sMap[tid] = keep ? (short)pos : (short)-1;
+  __syncthreads();
+  return total;
 }
 
 // y[at][c] = sum over the directed edges of the row of `at`:  sSrc[neighbour][c] * g[pair][c] * f_c(pair)
@@ -290,6 +314,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
   float* sT = sY + 32 * ML_LD;                        // team 1: the same
   MolPair* sP = (MolPair*)(sT + 32 * ML_LD);          // per pair: local atoms, d, f_c, f_c'
   float* sRb = (float*)(sP + ML_MAXPAIRS);            // [2][32] radial basis parameters
+  int* sScan = (int*)(sRb + 64);                      // [8] per-wave counts of the pair compaction
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wv: SGPR
   const int hi = lane >> 5, el = lane & 31;
@@ -302,8 +327,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
 
   for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
     const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
-    const int p0 = a.grp_pair0[grp], np = a.grp_pair0[grp + 1] - p0;
-    const int ntile = (np + 31) / 32;
+    const int p0 = a.grp_pair0[grp], np_list = a.grp_pair0[grp + 1] - p0;
     __syncthreads();   // the previous group is done with every LDS buffer
     ML_STAMP(0);
 
@@ -314,7 +338,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       if (row < na) v = ml_ld<f32x4>(a.x0 + (size_t)a0 * NF, (unsigned)(s * 16));
       *(f32x4*)(sX + row * ML_LD + 4 * c4) = v;
     }
-    ml_pair_records(sP, a.half, a.rij, a.idx_i, a.idx_j, p0, np, a0, a.rb.cutoff, tid);
+    const int np = ml_pair_records(sP, nullptr, sScan, a.half, a.rij, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid);
+    const int ntile = (np + 31) / 32;
     ml_stage_packed<512, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
     ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[0].w1, a.rb.n_rbf, KPB, tid);
     if (tid < NF) { sb1[tid] = a.L[0].b1[tid]; sb2[tid] = a.L[0].b2[tid]; }
@@ -401,20 +426,16 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
               wq = wn; zq = zn;
             }
           }
-          // raw filter outputs for the backward: row = pair, 128-byte row segments per half wave
-          float* gt = g_g + (size_t)pfirst * NF + 32 * t;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int pr = ml_row(r, hi);
-            if (pr < nvalid) ml_st<float>(gt, (unsigned)((pr * NF + el) * 4), g[r]);
-          }
-          // ---- modulation + accumulation on the matrix core: y[atom][c0] += [i = atom] W h[j][c0] + [j = atom] W h[i][c0]
+          // raw filter outputs for the backward (row = position of the pair in the list, 128-byte row segments per half wave)
+          // ---- and modulation + accumulation on the matrix core: y[atom][c0] += [i = atom] W h[j][c0] + [j = atom] W h[i][c0]
+          float* gt = g_g + 32 * t;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int pr = ml_row(r, hi);
             const bool ok = pr < nvalid;
             const MolPair rec = sP[pfirst + (ok ? pr : 0)];
-            const int pi = rec.ij & 255, pj = rec.ij >> 8;
+            const int pi = rec.ij & 255, pj = (rec.ij >> 8) & 255;
+            if (ok) ml_st<float>(gt, (unsigned)(((rec.ij >> 16) * NF + el) * 4), g[r]);
             const float W = ok ? g[r] * rec.fc : 0.f;
             const float tI = W * sH[pj * ML_LD + c0], tJ = W * sH[pi * ML_LD + c0];
             yacc = ML_MFMA(pi == el ? 1.0f : 0.0f, tI, yacc);
@@ -487,7 +508,7 @@ static long long* g_mol_dbg = nullptr;
 extern "C" void spk_schnet_mol_set_debug_buffer(void* p) { g_mol_dbg = (long long*)p; }
 
 static size_t mol_fwd_lds(int kpb) {
-  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair);
+  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64 + 8) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair);
 }
 
 // Shapes / lists the molecule-resident kernels cover (everything else runs the general driver of spk_schnet.hip).
@@ -543,6 +564,7 @@ int spk_schnet_mol_forward(const spk_schnet_t* m, const spk_graph_t* g, const sp
   a.n_groups = g->n_groups; a.saved = saved; a.N = g->n_atoms; a.gsz = gsz;
   a.gbase = saved + (int64_t)m->n_interactions * g->n_atoms * (m->n_filters + m->n_atom_basis);
   a.rb = spk_radial_dev(rb);
+  a.compact = spk_schnet_mol_bwd_eligible(m, g, rb) ? 1 : 0;     // only when the molecule-resident backward (which compacts too) will consume `saved`
   a.dbg = g_mol_dbg;
   switch ((rb->n_rbf + 7) / 8) {
     case 1: return launch_mol_fwd<1>(a, stream);
@@ -587,6 +609,7 @@ struct MolBwdArgs {
   const float* gbase;
   int64_t gsz, N;
   RadialDev rb;
+  int compact;              // as in the forward
   long long* dbg;
 };
 
@@ -607,6 +630,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
   int* sCnt = sRow + 36;                              // [4]
   float* sRb = (float*)(sCnt + 4);                    // [2][32] radial basis parameters
   float* sS = sRb + 64;                               // [ML_MAXPAIRS][2] per-pair geometry sums, all interactions
+  short* sMap = (short*)(sS + 2 * ML_MAXPAIRS);       // [ML_MAXPAIRS] position in the pair list -> record (-1: beyond the cutoff)
+  int* sScan = (int*)(sMap + ML_MAXPAIRS);            // [8]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wv: SGPR
   const int hi = lane >> 5, el = lane & 31;
@@ -618,9 +643,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 
   for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
     const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
-    const int p0 = a.grp_pair0[grp], np = a.grp_pair0[grp + 1] - p0;
+    const int p0 = a.grp_pair0[grp], np_list = a.grp_pair0[grp + 1] - p0;
     const int e0 = a.rowptr[a0], ne = a.rowptr[a0 + na] - e0;
-    const int ntile = (np + 31) / 32;
     const int Ltop = a.n_layers - 1;
     __syncthreads();
 
@@ -633,11 +657,16 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       *(f32x4*)(sGh + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
       *(f32x4*)(sH + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    ml_pair_records(sP, a.half, a.rij, a.idx_i, a.idx_j, p0, np, a0, a.rb.cutoff, tid);
-    __syncthreads();
+    const int np = ml_pair_records(sP, sMap, sScan, a.half, a.rij, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid);
+    const int ntile = (np + 31) / 32;
+    // per directed edge: (row of the saved filter tensor << 8 | local neighbour, f_c); edges of dropped pairs point at the
+    // first record's row with weight 0 (their own row was never written)
+    const int row0 = np > 0 ? (sP[0].ij >> 16) : 0;
     for (int s = tid; s < ne; s += 512) {
-      const int pl = ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0;
-      sEb[s] = make_int2((pl << 8) | (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0), __float_as_int(sP[pl].fc));
+      const int pos = ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0;
+      const int rec = sMap[pos];
+      const int nb = (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0);
+      sEb[s] = rec >= 0 ? make_int2((pos << 8) | nb, __float_as_int(sP[rec].fc)) : make_int2((row0 << 8) | nb, 0);
     }
     for (int s = tid; s < 2 * np; s += 512) sS[s] = 0.f;
     if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
@@ -706,7 +735,9 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 
       // ================= E: derivative tasks (pair tile, pair of channel tiles) + row-sum tasks (atom quarter, channel half)
       const int nder = 2 * ntile;
-      const int nrow = last ? 0 : 8;
+      const int nrow = (last || np == 0) ? 0 : 8;
+      if (np == 0 && !last)      // no pair inside the cutoff: dL/dh = 0 (the buffer still holds the hidden gradient of f2out)
+        for (int s = tid; s < 32 * 32; s += 512) *(f32x4*)(sGh + (s >> 5) * ML_LD + 4 * (s & 31)) = f32x4{0.f, 0.f, 0.f, 0.f};
       while (true) {
         int k = 0;
         if (lane == 0) k = atomicAdd(&sCnt[0], 1);
@@ -725,13 +756,14 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         const int pl = pfirst + (valid ? el : (nvalid - 1));
         const MolPair pr = sP[pl];
         const float fc = valid ? pr.fc : 0.f, dfc = valid ? pr.dfc : 0.f;
-        const int pi = pr.ij & 255, pj = pr.ij >> 8;
+        const int pi = pr.ij & 255, pj = (pr.ij >> 8) & 255;
+        const int grow = pr.ij >> 16;                       // row of this pair in the saved filter tensor
         // the saved raw filter outputs of this lane's pair for both channel tiles of the task: requested first, used last
         f32x4 gl[2][4];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) gl[tt][q] = ml_ld<f32x4>(g_g + 64 * tp, (unsigned)((pl * NF + 4 * hi + 32 * tt + 8 * q) * 4));
+          for (int q = 0; q < 4; ++q) gl[tt][q] = ml_ld<f32x4>(g_g + 64 * tp, (unsigned)((grow * NF + 4 * hi + 32 * tt + 8 * q) * 4));
         float phi[KPB][4], dphi[KPB][4];
 #pragma unroll
         for (int u = 0; u < KPB; ++u)
@@ -848,14 +880,18 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       ML_STAMP(37 + 6 * (Ltop - l));
     }
 
-    // ---- dL/dr of both directions of every pair, once for all interactions
-    for (int s = tid; s < np; s += 512) {
+    // ---- dL/dr of both directions of every pair, once for all interactions (pairs beyond the cutoff: zero)
+    for (int s = tid; s < np_list; s += 512) {
       const int64_t e = a.half[p0 + s];
       const int64_t e2 = a.rev[e];
+      const int rec = sMap[s];
+      float s1 = 0.f, s2 = 0.f;
+      if (rec >= 0) {
+        const float d = sP[rec].d;
+        const float inv = d > 0.f ? 1.0f / d : 0.f;
+        s1 = sS[2 * rec] * inv; s2 = sS[2 * rec + 1] * inv;
+      }
       const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
-      const float d = sP[s].d;
-      const float inv = d > 0.f ? 1.0f / d : 0.f;
-      const float s1 = sS[2 * s] * inv, s2 = sS[2 * s + 1] * inv;
       a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
       a.gr[3 * e2] = -s2 * rx; a.gr[3 * e2 + 1] = -s2 * ry; a.gr[3 * e2 + 2] = -s2 * rz;
     }
@@ -865,7 +901,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 
 static size_t mol_bwd_lds(int kpb) {
   return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64 + 2 * ML_MAXPAIRS) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
-         (2 * ML_MAXEDGES + 36 + 4) * sizeof(int);
+         (2 * ML_MAXEDGES + 36 + 4 + 8) * sizeof(int) + ML_MAXPAIRS * sizeof(short);
 }
 
 template <int KPB>
@@ -910,6 +946,7 @@ int spk_schnet_mol_backward(const spk_schnet_t* m, const spk_graph_t* g, const s
   a.n_groups = g->n_groups; a.saved = saved; a.N = g->n_atoms; a.gsz = gsz;
   a.gbase = saved + (int64_t)m->n_interactions * g->n_atoms * (m->n_filters + m->n_atom_basis);
   a.rb = spk_radial_dev(rb);
+  a.compact = 1;
   a.dbg = g_mol_dbg;
   switch ((rb->n_rbf + 7) / 8) {
     case 1: return launch_mol_bwd<1>(a, stream);

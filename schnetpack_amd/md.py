@@ -261,20 +261,31 @@ class NVESimulation:
 
         kick + drift + skin test (1 kernel)  ->  force call on the current list  ->  kick (1 kernel)
 
-    followed by one two-word D2H read.  Because the skin flag is read AFTER the step, the rebuild threshold is
-    ``shell / 2 - margin`` with ``margin`` at least twice (usually four times) the largest one-step displacement seen
-    (tracked by the kick-drift kernel): when the flag comes up, the forces of that step were still computed
-    with a valid list, and the list is rebuilt (and the graph re-captured) before the next one.  A step whose
-    displacement exceeds the margin raises.
+    and every ``check_every`` steps (adapted to the dynamics, at most ``max_check_every``) one two-word D2H read -- the only
+    host synchronisation of the loop.  Because the skin flag is read up to ``check_every`` steps AFTER it came up, the rebuild
+    threshold is ``shell / 2 - margin`` with ``margin`` at least twice (usually four times) ``check_every`` x the largest
+    one-step displacement seen (tracked by the kick-drift kernel): when the flag is read, the forces of all steps since it
+    came up were still computed with a valid list, and the list is rebuilt (and the graph re-captured) before the next
+    step.  A displacement that exceeds the margin raises.
+
+    Batches of small isolated molecules (no cell, at most 28 atoms each -- every pair of a molecule then fits the molecule-
+    resident kernels) skip the skin machinery altogether (``complete_list="auto"``): the list holds EVERY intramolecular pair,
+    which is a Verlet list with an infinite skin -- pairs beyond the cutoff contribute exactly zero (the kernels do not even give
+    them a tile) -- so it never has to be rebuilt, the kick-drift kernel tests nothing, and the loop is back-to-back graph
+    replays without a host synchronisation.
 
     ``inputs`` is the batch dict on the device with ``_positions`` [N,3], ``_atomic_numbers``, ``_idx_m``,
     ``_n_atoms`` and (periodic) ``_cell`` / ``_pbc``; positions, masses, time step and the model's energy
     must share one unit system (forces = -dE/dpositions)."""
 
-    def __init__(self, model, inputs, masses, time_step, cutoff, cutoff_shell=1.0, use_graph=True):
+    def __init__(self, model, inputs, masses, time_step, cutoff, cutoff_shell=1.0, use_graph=True, max_check_every=4,
+                 complete_list="auto"):
         from . import properties
         from .neighborlist import NeighborListMD
         self.P = properties
+        self._complete = self._wants_complete_list(inputs, complete_list)
+        self.max_check_every = max(int(max_check_every), 1)
+        self.check_every = 1            # raised once the displacement scale is known
         self.model = model.eval()
         self.inputs = dict(inputs)
         R = inputs[properties.R].detach().float().contiguous().clone()
@@ -295,6 +306,35 @@ class NVESimulation:
     def _setup_state(self, R, masses):
         self.state = MDState(R.unsqueeze(0), torch.zeros_like(R).unsqueeze(0), masses.float().reshape(1, -1, 1))
         self.integrator = VelocityVerlet(self._time_step)
+
+    # -- complete intramolecular lists ---------------------------------------------------------
+    MAX_COMPLETE_ATOMS = 28        # 28 * 27 / 2 = 378 pairs <= the 384 pairs a group of the molecule-resident kernels holds
+
+    def _wants_complete_list(self, inputs, mode) -> bool:
+        P = self.P
+        if mode is False or mode is None:
+            return False
+        pbc = inputs.get(P.pbc)
+        periodic = inputs.get(P.cell) is not None and pbc is not None and bool(pbc.any())
+        small = int(inputs[P.n_atoms].max()) <= self.MAX_COMPLETE_ATOMS
+        if mode is True and (periodic or not small):
+            raise ValueError("complete_list=True needs isolated molecules of at most %d atoms" % self.MAX_COMPLETE_ATOMS)
+        return (not periodic) and small
+
+    @staticmethod
+    def complete_pair_list(idx_m: torch.Tensor, n_atoms: torch.Tensor):
+        """Every ordered pair (i, j), i != j, of atoms of the same molecule; idx_i ascending, idx_j ascending within a row --
+        the order of the reference's neighbour lists (atoms of a molecule are contiguous)."""
+        dev = idx_m.device
+        N = int(idx_m.shape[0])
+        start = torch.cumsum(n_atoms, 0) - n_atoms                   # first atom of every molecule
+        counts = n_atoms[idx_m] - 1                                  # partners per atom
+        idx_i = torch.repeat_interleave(torch.arange(N, device=dev), counts)
+        seg = torch.cumsum(counts, 0) - counts
+        k = torch.arange(int(idx_i.shape[0]), device=dev) - seg[idx_i]
+        first = start[idx_m[idx_i]]
+        idx_j = first + k + (k >= (idx_i - first)).long()
+        return idx_i, idx_j
 
     # -- pieces of one step ------------------------------------------------------------------
     def _flatR(self):
@@ -328,8 +368,11 @@ class NVESimulation:
             torch.ops.spk_hip.edge_plan(ii, jj, int(R.shape[0]), r, cutoff)
 
     def _step_body(self):
-        thr = max(0.5 * self.nl.cutoff_shell - self.margin, 0.0)
-        self.integrator.first_half_and_main_step(self.state, True, self.nl.previous_positions, thr, self.flag)
+        if self._complete:
+            self.integrator.first_half_and_main_step(self.state, True)
+        else:
+            thr = max(0.5 * self.nl.cutoff_shell - self.margin, 0.0)
+            self.integrator.first_half_and_main_step(self.state, True, self.nl.previous_positions, thr, self.flag)
         self._force_eval()
         self.integrator.half_step(self.state)
 
@@ -338,7 +381,11 @@ class NVESimulation:
         t0 = time.perf_counter()
         P = self.P
         self.graph = None
-        if new_list:
+        if new_list and self._complete:
+            ii, jj = self.complete_pair_list(self.inputs[P.idx_m], self.inputs[P.n_atoms])
+            self._lists = {P.idx_i: ii, P.idx_j: jj, P.offsets: torch.zeros(ii.shape[0], 3, device=ii.device)}
+            self.nl.n_builds += 1
+        elif new_list:
             self.inputs[P.R] = self._flatR()
             self.nl._list = None
             self._lists = self.nl.get_neighbors(self.inputs)
@@ -366,20 +413,40 @@ class NVESimulation:
         self.t_rebuild += time.perf_counter() - t0
 
     def step(self, n_steps=1):
-        for _ in range(n_steps):
-            if self.graph is not None:
-                self.graph.replay()
-            else:
-                self._step_body()
-            moved, step_bits = self.flag.tolist()              # the one host sync of the step
+        import time
+        if self._complete:                     # nothing to watch: back-to-back replays, no host synchronisation
+            for _ in range(n_steps):
+                if self.graph is not None:
+                    self.graph.replay()
+                else:
+                    self._step_body()
+            return
+        done = 0
+        while done < n_steps:
+            k = min(self.check_every, n_steps - done)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                if self.graph is not None:
+                    self.graph.replay()
+                else:
+                    self._step_body()
+            done += k
+            moved, step_bits = self.flag.tolist()              # the one host sync of the chunk
+            t_step = (time.perf_counter() - t0) / k
             step_disp = math.sqrt(struct.unpack("f", struct.pack("i", step_bits))[0])
-            if step_disp > self.margin:
-                raise RuntimeError("MD step moved an atom by %.3g, more than the skin margin %.3g: reduce the time step or "
-                                   "increase cutoff_shell" % (step_disp, self.margin))
+            if k * step_disp > self.margin:
+                raise RuntimeError("MD: an atom moved by up to %.3g per step over %d unchecked steps, more than the skin margin %.3g: "
+                                   "reduce the time step or increase cutoff_shell" % (step_disp, k, self.margin))
             shell = self.nl.cutoff_shell
-            # hysteresis: margin >= 2 x the largest one-step displacement at all times, re-tuned (= one re-capture,
-            # the threshold is baked into the captured kernel) only when the displacement scale changed by 2x
-            need = min(max(2.0 * step_disp, 0.01 * shell), 0.45 * shell)
+            # steps between two looks at the flag: the host round trip (tens of microseconds) matters for sub-millisecond steps
+            # only, and every unchecked step costs margin (= earlier rebuilds): a few for small systems, one for large ones,
+            # never more than keep 2 k x the step displacement below a twentieth of the skin
+            kmax = int(0.05 * shell / (2.0 * step_disp)) if step_disp > 0.0 else self.max_check_every
+            self.check_every = max(1, min(self.max_check_every, kmax, int(1.2e-3 / max(t_step, 1e-6))))
+            # hysteresis: margin >= 2 x check_every x the largest one-step displacement at all times (and a floor that grows with
+            # check_every: speeds may still be ramping up), re-tuned (= one re-capture, the threshold is baked into the captured
+            # kernel) only when the displacement scale changed by 2x
+            need = min(max(2.0 * self.check_every * step_disp, 0.0125 * self.check_every * shell), 0.45 * shell)
             retune = need > self.margin or 8.0 * need < self.margin
             if retune:
                 self.margin = min(2.0 * need, 0.45 * shell)
@@ -408,7 +475,7 @@ class RPMDSimulation(NVESimulation):
     ``sum_b [p_b^2 / 2m + V(q_b)] + sum_b 1/2 m omega^2 |q_b - q_{b+1}|^2`` (``total_energy``)."""
 
     def __init__(self, model, inputs, masses, time_step, n_beads, cutoff, temperature=300.0, omega=None,
-                 cutoff_shell=1.0, use_graph=True, thermostat: Optional["PILELocalThermostat"] = None):
+                 cutoff_shell=1.0, use_graph=True, thermostat: Optional["PILELocalThermostat"] = None, complete_list="auto"):
         from . import properties as P
         self.thermostat = thermostat
         self.n_beads = B = int(n_beads)
@@ -425,7 +492,7 @@ class RPMDSimulation(NVESimulation):
             rep[P.pbc] = inputs[P.pbc].reshape(-1, 3).repeat(B, 1).reshape(-1)
         self._rp = RingPolymer(time_step, B, temperature, omega=omega)
         self._n1 = N
-        super().__init__(model, rep, masses, time_step, cutoff, cutoff_shell, use_graph)
+        super().__init__(model, rep, masses, time_step, cutoff, cutoff_shell, use_graph, complete_list=complete_list)
 
     def _setup_state(self, R, masses):
         B, N = self.n_beads, self._n1
@@ -451,9 +518,9 @@ class RPMDSimulation(NVESimulation):
         if self.thermostat is not None:
             self._thermostat(0)
         self.integrator.half_step(st)
-        ref = self.nl.previous_positions
+        ref = None if self._complete else self.nl.previous_positions       # complete lists: nothing to watch
         _ring_polymer_hip(st.positions, st.momenta, st.masses, self._A, 0, self.n_beads, self._qt, self._pt,
-                          ref, thr, self.flag)
+                          ref, thr, None if self._complete else self.flag)
         with torch.no_grad():
             st.positions.copy_(self._qt)
             st.momenta.copy_(self._pt)

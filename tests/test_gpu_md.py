@@ -133,8 +133,10 @@ def test_graph_replays_stay_correct(dev, kind, n_mol):
     assert fc.n_captures == 1
 
 
-def test_nve_loop_conserves_energy_and_follows_oracle_trajectory(dev):
-    """End to end: device neighbour list with skin + graphed SchNet force call + fused Verlet kernels.
+@pytest.mark.parametrize("complete_list", [False, "auto"])
+def test_nve_loop_conserves_energy_and_follows_oracle_trajectory(dev, complete_list):
+    """End to end: device neighbour list with skin (or, "auto" for these small isolated molecules, the complete intramolecular
+    list that never needs a rebuild and runs without host synchronisation) + graphed SchNet force call + fused Verlet kernels.
     (i) the first 10 steps follow a float64 CPU integration of the ORACLE forces; (ii) total energy is
     conserved over 400 steps while the list is rebuilt several times (forces are the exact gradient of the
     energy, the list never misses a pair)."""
@@ -149,7 +151,10 @@ def test_nve_loop_conserves_energy_and_follows_oracle_trajectory(dev):
     inp["_n_atoms"] = torch.full((4,), 21, device=dev)
     masses = torch.where(b["Z"] == 1, 1.008, torch.where(b["Z"] == 6, 12.011, 15.999))
     dt = 0.02
-    sim = NVESimulation(model, inp, masses.to(dev), dt, cutoff=5.0, cutoff_shell=0.3)
+    sim = NVESimulation(model, inp, masses.to(dev), dt, cutoff=5.0, cutoff_shell=0.3, complete_list=complete_list)
+    assert sim._complete == (complete_list == "auto")
+    if sim._complete:
+        assert int(sim._lists["_idx_i"].shape[0]) == 4 * 21 * 20
     g = torch.Generator().manual_seed(0)
     p0 = 0.3 * torch.randn(b["R"].shape, generator=g) * masses[:, None].sqrt()
     sim.state.momenta.copy_(p0.to(dev).unsqueeze(0))
@@ -176,7 +181,10 @@ def test_nve_loop_conserves_energy_and_follows_oracle_trajectory(dev):
     ke = float(sim.kinetic_energy())
     drift = abs(sim.total_energy() - e0)
     assert drift < 2e-3 * ke, (drift, ke, e0)
-    assert sim.nl.n_builds >= 2, sim.nl.n_builds
+    if sim._complete:
+        assert sim.nl.n_builds == 1 and sim.n_captures == 1        # one list, one captured graph for the whole run
+    else:
+        assert sim.nl.n_builds >= 2, sim.nl.n_builds
 
 
 def test_rpmd_loop_conserves_ring_polymer_energy_and_follows_oracle(dev):

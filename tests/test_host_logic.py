@@ -185,3 +185,13 @@ def test_bench_ranks_kernel_families_not_template_variants():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "bench.py")).read()
     assert 'replace("_geom", "")' in src and 'replace("_mu0", "")' in src
+
+
+def test_complete_intramolecular_pair_list():
+    """md.NVESimulation.complete_pair_list: every ordered pair of every molecule, rows ascending, neighbours ascending."""
+    from schnetpack_amd.md import NVESimulation
+    n_atoms = torch.tensor([3, 1, 4, 2])
+    idx_m = torch.repeat_interleave(torch.arange(4), n_atoms)
+    ii, jj = NVESimulation.complete_pair_list(idx_m, n_atoms)
+    want = [(i, j) for i in range(10) for j in range(10) if i != j and idx_m[i] == idx_m[j]]
+    assert list(zip(ii.tolist(), jj.tolist())) == want
