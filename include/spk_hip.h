@@ -370,6 +370,34 @@ int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t* g, const s
                             const float* gx_out, const float* r_ij, const float* saved,
                             float* scratch, float* gr, float* gx0, void* stream);
 
+/* ------------------------------------------------------------------ the standard potential in two launches
+ * PairwiseDistances -> SchNet -> Atomwise(sum) -> Forces  (atomistic/distances.py:14-26, representation/schnet.py:147-173,
+ * atomistic/atomwise.py:69-88 with the default head build_mlp(F, 1, n_layers=2), atomistic/response.py:59-76) for the lists the
+ * molecule-resident kernels cover (block-diagonal, <= 32 atoms and <= 384 pairs per block, F = n_filters = 128, n_rbf <= 24):
+ * r_ij is formed from the positions inside the forward launch, the energy head runs on the atom tile that is still in LDS, the
+ * backward launch starts from dL/dE and ends at dL/dR.  `m` as for spk_schnet_forward_f32 with bit 0 of `reserved` set, `saved`
+ * of spk_schnet_saved_floats_graph() floats, pre_h [N, n_hidden] kept from forward to backward.  _supported() returns 1 when
+ * the pair (model, list) is covered; the two entry points return SPK_ERR_ARG otherwise (run the separate entry points then). */
+typedef struct {
+  const float* w1;   /* outnet.0.weight [n_hidden, F] */
+  const float* w1t;  /* its transpose   [F, n_hidden] */
+  const float* b1;   /* outnet.0.bias   [n_hidden] */
+  const float* w2;   /* outnet.1.weight [1, n_hidden] */
+  const float* b2;   /* outnet.1.bias   [1] (may be NULL) */
+  int32_t n_hidden;  /* multiple of 32, <= 128 */
+  int32_t act;       /* SPK_ACT_SSP | SPK_ACT_SILU */
+} spk_head_t;
+int spk_schnet_potential_supported(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb);
+/* x0 [N,F] embedding rows, R [N,3], offsets [E,3] or NULL, idx_m [N] -> x_out [N,F], E [n_mol] (overwritten) */
+int spk_schnet_potential_forward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb,
+                                     const float* x0, const float* R, const float* offsets, const int64_t* idx_m, int64_t n_mol,
+                                     float* x_out, float* E, float* pre_h, float* saved, void* stream);
+/* gE [n_mol] = dL/dE, gx_out [N,F] = dL/d scalar_representation or NULL -> gR [N,3] = dL/dR (overwritten; forces = -gR for
+ * L = sum E), gx0 [N,F] = dL/dx0 or NULL */
+int spk_schnet_potential_backward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb,
+                                      const float* gE, const float* gx_out, const float* R, const float* offsets, const int64_t* idx_m,
+                                      const float* pre_h, const float* saved, float* gR, float* gx0, void* stream);
+
 /* Kernel-tuning aid of the molecule-resident SchNet kernels (spk_schnet_mol.hip: block-diagonal lists with <= 32 atoms per
  * block run every interaction inside one workgroup): device buffer (>= 64 int64) receiving cycle stamps of workgroup 0 at
  * the phase boundaries; NULL disables it (default). */

@@ -50,6 +50,10 @@ class SchnetT(ctypes.Structure):
                 ("reserved", c_i32), ("layers", ctypes.POINTER(SchnetLayerT)), ("wpack", c_f)]
 
 
+class HeadT(ctypes.Structure):
+    _fields_ = [("w1", c_f), ("w1t", c_f), ("b1", c_f), ("w2", c_f), ("b2", c_f), ("n_hidden", c_i32), ("act", c_i32)]
+
+
 class ChainLayerT(ctypes.Structure):
     _fields_ = [("w", c_f), ("b", c_f), ("res", c_f), ("out", c_f), ("pre_out", c_f), ("post_pre", c_f),
                 ("k", c_i32), ("n_out", c_i32), ("act", c_i32), ("trans", c_i32), ("post_act", c_i32)]
@@ -132,6 +136,9 @@ _PROTOS = {
     "spk_schnet_scratch_floats": (c_i64, [P(SchnetT), c_i64]),
     "spk_schnet_forward_f32": (ctypes.c_int, [P(SchnetT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f]),
     "spk_schnet_backward_f32": (ctypes.c_int, [P(SchnetT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "spk_schnet_potential_supported": (ctypes.c_int, [P(SchnetT), P(HeadT), P(GraphT), P(RadialT)]),
+    "spk_schnet_potential_forward_f32": (ctypes.c_int, [P(SchnetT), P(HeadT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_f, c_f]),
+    "spk_schnet_potential_backward_f32": (ctypes.c_int, [P(SchnetT), P(HeadT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "spk_painn_message_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
     "spk_painn_message_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_f]),
     "spk_painn_set_tile": (None, [c_i32]),

@@ -61,6 +61,20 @@ bool spk_schnet_mol_bwd_eligible(const spk_schnet_t* m, const spk_graph_t* g, co
 int spk_schnet_mol_backward(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
                             const float* gx_out, const float* r_ij, const float* saved, int64_t gsz, float* gr, float* gx0,
                             hipStream_t stream);
+struct MolHeadDev {      // (layout shared with spk_schnet_mol.hip)
+  const float *w1, *w1t, *b1, *w2, *b2;
+  int H, act;
+  const int64_t* idx_m;
+  float* E;
+  float* pre_h;
+  const float* gE;
+};
+int spk_schnet_mol_forward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                              const float* x0, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head, float* x_out,
+                              float* saved, int64_t gsz, hipStream_t stream);
+int spk_schnet_mol_backward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                               const float* gx_out, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head,
+                               const float* saved, int64_t gsz, float* gr, float* gR, float* gx0, hipStream_t stream);
 // order of the packed images in spk_schnet_t::wpack: per interaction in2f, f2out.0, f2out.1 (forward, transposed each)
 static bool schnet_pack_shapes_ok(const spk_schnet_t* m) { return m->n_atom_basis % 128 == 0 && m->n_filters % 128 == 0 && m->n_atom_basis <= 384 && m->n_filters <= 384; }
 static SpkPackTable schnet_pack_table(const spk_schnet_t* m) {
@@ -256,4 +270,53 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
     gx = out;
   }
   return SPK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The standard potential  PairwiseDistances -> SchNet -> Atomwise(sum) -> Forces  on batches of small molecules: TWO launches
+// (atomistic/distances.py:14-26, representation/schnet.py:147-173, atomistic/atomwise.py:69-88, atomistic/response.py:59-76).
+static bool potential_ok(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb) {
+  if (!m || !head || !g || !rb || !m->layers || m->n_interactions <= 0 || !(m->reserved & 1)) return false;
+  if (!m->wpack || !schnet_pack_shapes_ok(m)) return false;
+  if (!head->w1 || !head->w1t || !head->b1 || !head->w2 || head->n_hidden < 32 || head->n_hidden > 128 || head->n_hidden % 32) return false;
+  if (head->act != SPK_ACT_SSP && head->act != SPK_ACT_SILU) return false;
+  if (getenv("SPK_NO_POTENTIAL")) return false;
+  return spk_schnet_mol_eligible(m, g, rb) && spk_schnet_mol_bwd_eligible(m, g, rb) && spk_cfconv_gsave_floats(g, rb, m->n_filters) > 0;
+}
+extern "C" int spk_schnet_potential_supported(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb) {
+  return potential_ok(m, head, g, rb) ? 1 : 0;
+}
+
+extern "C" int spk_schnet_potential_forward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb,
+                                                const float* x0, const float* R, const float* offsets, const int64_t* idx_m, int64_t n_mol,
+                                                float* x_out, float* E, float* pre_h, float* saved, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const char* who = "spk_schnet_potential_forward_f32";
+  SPK_TRY(check_model(m, who));
+  SPK_CHECK_ARG(potential_ok(m, head, g, rb), "%s: model / list not covered by the fused potential (see spk_schnet_potential_supported)", who);
+  SPK_CHECK_ARG(n_mol >= 0 && (n_mol == 0 || E), "%s: null energy buffer", who);
+  if (n_mol > 0) { int zr = spk_zero_async(E, (size_t)n_mol * sizeof(float), stream); if (zr) return zr; }
+  if (g->n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(x0 && R && idx_m && x_out && pre_h && saved, "%s: null buffer", who);
+  MolHeadDev h;
+  h.w1 = head->w1; h.w1t = head->w1t; h.b1 = head->b1; h.w2 = head->w2; h.b2 = head->b2; h.H = head->n_hidden; h.act = head->act;
+  h.idx_m = idx_m; h.E = E; h.pre_h = pre_h; h.gE = nullptr;
+  return spk_schnet_mol_forward_ex(m, g, rb, schnet_pack_table(m), x0, nullptr, R, offsets, &h, x_out, saved,
+                                   spk_cfconv_gsave_floats(g, rb, m->n_filters), stream);
+}
+
+extern "C" int spk_schnet_potential_backward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb,
+                                                 const float* gE, const float* gx_out, const float* R, const float* offsets, const int64_t* idx_m,
+                                                 const float* pre_h, const float* saved, float* gR, float* gx0, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const char* who = "spk_schnet_potential_backward_f32";
+  SPK_TRY(check_model(m, who));
+  SPK_CHECK_ARG(potential_ok(m, head, g, rb), "%s: model / list not covered by the fused potential (see spk_schnet_potential_supported)", who);
+  if (g->n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(gE && R && idx_m && pre_h && saved && gR, "%s: null buffer", who);
+  MolHeadDev h;
+  h.w1 = head->w1; h.w1t = head->w1t; h.b1 = head->b1; h.w2 = head->w2; h.b2 = head->b2; h.H = head->n_hidden; h.act = head->act;
+  h.idx_m = idx_m; h.E = nullptr; h.pre_h = const_cast<float*>(pre_h); h.gE = gE;
+  return spk_schnet_mol_backward_ex(m, g, rb, schnet_pack_table(m), gx_out, nullptr, R, offsets, &h, saved,
+                                    spk_cfconv_gsave_floats(g, rb, m->n_filters), nullptr, gR, gx0, stream);
 }

@@ -35,12 +35,32 @@ struct MolLayerDev {
   const float *o1_p, *o1_b, *o2_p, *o2_b;  // packed forward images of f2out.0 / f2out.1 and their biases
 };
 
+// The callers either side of the representation, folded into the two launches when the model is the standard potential
+// (PairwiseDistances -> SchNet -> Atomwise(sum) -> Forces; atomistic/distances.py:14-26, atomwise.py:69-88, response.py:59-76):
+// r_ij is formed from the positions, the default 2-layer energy head runs on the atom tile that is still in LDS, and the
+// backward starts from dE/dE_mol and ends at dE/dR.
+struct MolHeadDev {
+  const float* w1;        // outnet.0.weight [H, F]   (null: no head)
+  const float* w1t;       // its transpose   [F, H]   (backward)
+  const float* b1;        // [H]
+  const float* w2;        // outnet.1.weight [H]
+  const float* b2;        // [1]
+  int H, act;
+  const int64_t* idx_m;   // [N]
+  float* E;               // forward: [n_mol], accumulated with one atomic per (group, molecule): cleared by the caller
+  float* pre_h;           // [N, H] pre-activation of the head's hidden layer (saved for the backward)
+  const float* gE;        // backward: dL/dE [n_mol]
+};
+
 struct MolFwdArgs {
   MolLayerDev L[ML_MAXL];
   int n_layers;
   const float* x0;          // [N, 128]
   float* x_out;             // [N, 128]
-  const float* rij;         // [E, 3]
+  const float* rij;         // [E, 3], or null: r_ij = R[j] - R[i] + offsets
+  const float* R;           // [N, 3]
+  const float* offsets;     // [E, 3] or null
+  MolHeadDev head;
   const int64_t* idx_i;
   const int64_t* idx_j;
   const int32_t* half;      // canonical edge of every undirected pair (ascending)
@@ -86,7 +106,17 @@ __device__ __forceinline__ void ml_rbf(int kind, int n_rbf, const float* __restr
 // contribute exactly zero (f_c = f_c' = 0) and are not worth a tile of filter GEMMs; the order of the list is kept (ballot +
 // prefix over the waves: deterministic, the backward reproduces it), sMap[position] = record index or -1.  Returns the number of
 // records (uniform over the workgroup).  Contains workgroup barriers: call it from uniform code, np <= 512.
+__device__ __forceinline__ void ml_edge_vector(const float* __restrict__ rij, const float* __restrict__ R, const float* __restrict__ offsets,
+                                               const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j, int64_t e, float& rx, float& ry,
+                                               float& rz) {
+  if (rij) { rx = rij[3 * e]; ry = rij[3 * e + 1]; rz = rij[3 * e + 2]; return; }
+  const int64_t i = idx_i[e], j = idx_j[e];
+  rx = R[3 * j] - R[3 * i]; ry = R[3 * j + 1] - R[3 * i + 1]; rz = R[3 * j + 2] - R[3 * i + 2];
+  if (offsets) { rx += offsets[3 * e]; ry += offsets[3 * e + 1]; rz += offsets[3 * e + 2]; }
+}
+
 __device__ __forceinline__ int ml_pair_records(MolPair* sP, short* sMap, int* sScan, const int32_t* __restrict__ half, const float* __restrict__ rij,
+                                               const float* __restrict__ R, const float* __restrict__ offsets,
                                                const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j, int p0, int np, int a0,
                                                float cutoff, bool compact, int tid) {
   const int lane = tid & 63, wv = tid >> 6;
@@ -94,7 +124,8 @@ __device__ __forceinline__ int ml_pair_records(MolPair* sP, short* sMap, int* sS
   bool keep = false;
   if (tid < np) {
     const int64_t e = half[p0 + tid];
-    const float rx = rij[3 * e], ry = rij[3 * e + 1], rz = rij[3 * e + 2];
+    float rx, ry, rz;
+    ml_edge_vector(rij, R, offsets, idx_i, idx_j, e, rx, ry, rz);
     pr.ij = (int)(idx_i[e] - a0) | ((int)(idx_j[e] - a0) << 8) | (tid << 16);
     pr.d = sqrtf(rx * rx + ry * ry + rz * rz);
     spk_cutoff_eval_fast(cutoff, pr.d, pr.fc, pr.dfc);
@@ -338,7 +369,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       if (row < na) v = ml_ld<f32x4>(a.x0 + (size_t)a0 * NF, (unsigned)(s * 16));
       *(f32x4*)(sX + row * ML_LD + 4 * c4) = v;
     }
-    const int np = ml_pair_records(sP, nullptr, sScan, a.half, a.rij, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid);
+    const int np = ml_pair_records(sP, nullptr, sScan, a.half, a.rij, a.R, a.offsets, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid);
     const int ntile = (np + 31) / 32;
     ml_stage_packed<512, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
     ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[0].w1, a.rb.n_rbf, KPB, tid);
@@ -498,6 +529,49 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       }
       // (the barrier at the top of the next interaction / group closes this phase)
     }
+    if (a.head.w1) {
+      // ================= energy head on the atom tile that is still in LDS: y = w2 . act(W1 x + b1) + b2, E[mol] += sum_atoms y
+      const MolHeadDev& Hd = a.head;
+      const int HT = Hd.H / 32;
+      __syncthreads();                    // x_L is complete
+      if (wv < HT) {
+        f32x4 av[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) av[u] = ml_ld<f32x4>(Hd.w1 + (size_t)(32 * wv) * NF, (unsigned)((el * NF + 8 * u + 4 * hi) * 4));
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = Hd.b1[32 * wv + ml_row(r, hi)];
+        acc = ml_dense_mma(av, sX, lane, acc);
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          if (el < na) ml_st<f32x4>(Hd.pre_h + (size_t)a0 * Hd.H + 32 * wv, (unsigned)((el * Hd.H + 8 * q + 4 * hi) * 4), pv);
+          const f32x4 wv2 = *(const f32x4*)(Hd.w2 + 32 * wv + 8 * q + 4 * hi);
+          if (Hd.act == SPK_ACT_SILU)
+            part += pv.x * spk_sigmoid(pv.x) * wv2.x + pv.y * spk_sigmoid(pv.y) * wv2.y + pv.z * spk_sigmoid(pv.z) * wv2.z + pv.w * spk_sigmoid(pv.w) * wv2.w;
+          else
+            part += spk_ssp(pv.x) * wv2.x + spk_ssp(pv.y) * wv2.y + spk_ssp(pv.z) * wv2.z + spk_ssp(pv.w) * wv2.w;
+        }
+        part += __shfl_xor(part, 32, 64);
+        if (hi == 0) sH[wv * 32 + el] = part;          // (sH: the hidden tile of the last f2out is no longer needed)
+      }
+      __syncthreads();
+      if (tid < 32) {
+        float y = Hd.b2 ? Hd.b2[0] : 0.f;
+        for (int w = 0; w < HT; ++w) y += sH[w * 32 + tid];
+        sH[4 * 32 + tid] = tid < na ? y : 0.f;
+      }
+      __syncthreads();
+      if (tid < na) {                                  // one atomic per (group, molecule), atoms summed in order
+        const int64_t mol = Hd.idx_m[a0 + tid];
+        if (tid == 0 || Hd.idx_m[a0 + tid - 1] != mol) {
+          float sum = 0.f;
+          for (int b = tid; b < na && Hd.idx_m[a0 + b] == mol; ++b) sum += sH[4 * 32 + b];
+          unsafeAtomicAdd(Hd.E + mol, sum);
+        }
+      }
+    }
     ML_STAMP(31);
   }
 }
@@ -546,9 +620,19 @@ static int launch_mol_fwd(const MolFwdArgs& a, hipStream_t stream) {
 }
 
 // `saved` as laid out by spk_schnet_saved_floats_graph(): L x (h | pre3), then L x gsz floats of raw filter outputs.
+int spk_schnet_mol_forward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                              const float* x0, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head, float* x_out,
+                              float* saved, int64_t gsz, hipStream_t stream);
 int spk_schnet_mol_forward(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
                            const float* x0, const float* r_ij, float* x_out, float* saved, int64_t gsz, hipStream_t stream) {
+  return spk_schnet_mol_forward_ex(m, g, rb, ptab, x0, r_ij, nullptr, nullptr, nullptr, x_out, saved, gsz, stream);
+}
+int spk_schnet_mol_forward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                              const float* x0, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head, float* x_out,
+                              float* saved, int64_t gsz, hipStream_t stream) {
   MolFwdArgs a;
+  a.R = R; a.offsets = offsets;
+  if (head) a.head = *head; else a.head.w1 = nullptr;
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_schnet_layer_t& P = m->layers[l];
@@ -599,8 +683,12 @@ struct MolBwdArgs {
   int n_layers;
   const float* gx_out;      // [N, 128]
   float* gx0;               // [N, 128] or null
-  float* gr;                // [E, 3], assigned
-  const float* rij;
+  float* gr;                // [E, 3], assigned (may be null when gR is asked for)
+  const float* rij;         // [E, 3], or null: from R / offsets
+  const float* R;
+  const float* offsets;
+  float* gR;                // [N, 3] or null: dL/dR, every entry written (the pairwise transpose folded in)
+  MolHeadDev head;          // head.w1t != null: dL/dx_L comes from the energy head (+ gx_out when that is given)
   const int64_t* idx_i;
   const int64_t* idx_j;
   const int32_t *half, *rev, *rowptr, *edge_pair, *grp_atom0, *grp_pair0;
@@ -652,12 +740,54 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     for (int s = tid; s < 32 * 32; s += 512) {
       const int row = s >> 5, c4 = s & 31;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < na) v = ml_ld<f32x4>(a.gx_out + (size_t)a0 * NF, (unsigned)(s * 16));
+      if (row < na && a.gx_out) v = ml_ld<f32x4>(a.gx_out + (size_t)a0 * NF, (unsigned)(s * 16));
       *(f32x4*)(sGx + row * ML_LD + 4 * c4) = v;
       *(f32x4*)(sGh + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
       *(f32x4*)(sH + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int np = ml_pair_records(sP, sMap, sScan, a.half, a.rij, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid);
+    if (a.head.w1t) {
+      // ---- dL/dx_L through the energy head: gx += (gE[mol] w2 . act'(pre_h)) W1
+      const MolHeadDev& Hd = a.head;
+      __syncthreads();
+      for (int s = tid; s < 32 * Hd.H; s += 512) {
+        const int row = s / Hd.H, k = s - row * Hd.H;
+        float v = 0.f;
+        if (row < na) {
+          const float pre = Hd.pre_h[(size_t)(a0 + row) * Hd.H + k];
+          const float sg = spk_sigmoid(pre);
+          const float da = Hd.act == SPK_ACT_SILU ? sg * (1.0f + pre * (1.0f - sg)) : sg;
+          v = Hd.gE[Hd.idx_m[a0 + row]] * Hd.w2[k] * da;
+        }
+        sGh[row * ML_LD + k] = v;
+      }
+      __syncthreads();
+      if (wv < NT) {
+        const int t = wv;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* brow = sGh + el * ML_LD + 4 * hi;
+        for (int u = 0; u < Hd.H / 8; ++u) {
+          const f32x4 av = ml_ld<f32x4>(Hd.w1t + (size_t)(32 * t) * Hd.H, (unsigned)((el * Hd.H + 8 * u + 4 * hi) * 4));
+          const f32x4 bv = *(const f32x4*)(brow + 8 * u);
+          acc = ML_MFMA(av.x, bv.x, acc);
+          acc = ML_MFMA(av.y, bv.y, acc);
+          acc = ML_MFMA(av.z, bv.z, acc);
+          acc = ML_MFMA(av.w, bv.w, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float* xp = sGx + el * ML_LD + 32 * t + 8 * q + 4 * hi;
+          f32x4 xv = *(const f32x4*)xp;
+          xv.x += acc[4 * q]; xv.y += acc[4 * q + 1]; xv.z += acc[4 * q + 2]; xv.w += acc[4 * q + 3];
+          if (el >= na) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)xp = xv;
+        }
+      }
+      __syncthreads();
+      for (int s = tid; s < 32 * 32; s += 512) *(f32x4*)(sGh + (s >> 5) * ML_LD + 4 * (s & 31)) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int np = ml_pair_records(sP, sMap, sScan, a.half, a.rij, a.R, a.offsets, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid);
     const int ntile = (np + 31) / 32;
     // per directed edge: (row of the saved filter tensor << 8 | local neighbour, f_c); edges of dropped pairs point at the
     // first record's row with weight 0 (their own row was never written)
@@ -881,19 +1011,42 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     }
 
     // ---- dL/dr of both directions of every pair, once for all interactions (pairs beyond the cutoff: zero)
-    for (int s = tid; s < np_list; s += 512) {
-      const int64_t e = a.half[p0 + s];
-      const int64_t e2 = a.rev[e];
-      const int rec = sMap[s];
-      float s1 = 0.f, s2 = 0.f;
-      if (rec >= 0) {
-        const float d = sP[rec].d;
-        const float inv = d > 0.f ? 1.0f / d : 0.f;
-        s1 = sS[2 * rec] * inv; s2 = sS[2 * rec + 1] * inv;
+    if (a.gr) {
+      for (int s = tid; s < np_list; s += 512) {
+        const int64_t e = a.half[p0 + s];
+        const int64_t e2 = a.rev[e];
+        const int rec = sMap[s];
+        float s1 = 0.f, s2 = 0.f;
+        if (rec >= 0) {
+          const float d = sP[rec].d;
+          const float inv = d > 0.f ? 1.0f / d : 0.f;
+          s1 = sS[2 * rec] * inv; s2 = sS[2 * rec + 1] * inv;
+        }
+        float rx, ry, rz;
+        ml_edge_vector(a.rij, a.R, a.offsets, a.idx_i, a.idx_j, e, rx, ry, rz);
+        a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
+        a.gr[3 * e2] = -s2 * rx; a.gr[3 * e2 + 1] = -s2 * ry; a.gr[3 * e2 + 2] = -s2 * rz;
       }
-      const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
-      a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
-      a.gr[3 * e2] = -s2 * rx; a.gr[3 * e2 + 1] = -s2 * ry; a.gr[3 * e2 + 2] = -s2 * rz;
+    }
+    // ---- dL/dR: the transpose of r_ij = R_j - R_i + offsets, per atom over its row (each pair of the atom appears once
+    //      there): the pair (i, j) with canonical vector r gives -(s1 + s2) r / d to i and +(s1 + s2) r / d to j.  Fixed order.
+    if (a.gR) {
+      for (int s = tid; s < 3 * na; s += 512) {
+        const int at = s / 3, comp = s - 3 * at;
+        float acc = 0.f;
+        for (int e = sRow[at]; e < sRow[at + 1]; ++e) {
+          const int pos = sEb[e].x >> 8;
+          const int rec = sMap[pos];
+          if (rec < 0) continue;
+          const MolPair pr = sP[rec];
+          const float inv = pr.d > 0.f ? 1.0f / pr.d : 0.f;
+          const float w = (sS[2 * rec] + sS[2 * rec + 1]) * inv;
+          float rv[3];
+          ml_edge_vector(a.rij, a.R, a.offsets, a.idx_i, a.idx_j, a.half[p0 + pos], rv[0], rv[1], rv[2]);
+          acc += ((pr.ij & 255) == at ? -w : w) * rv[comp];
+        }
+        a.gR[3 * (size_t)(a0 + at) + comp] = acc;
+      }
     }
     ML_STAMP(63);
   }
@@ -927,10 +1080,20 @@ bool spk_schnet_mol_bwd_eligible(const spk_schnet_t* m, const spk_graph_t* g, co
   return spk_schnet_mol_eligible(m, g, rb) && (rb->n_rbf + 7) / 8 <= 3 && !getenv("SPK_NO_MOL_BWD");
 }
 
+int spk_schnet_mol_backward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                               const float* gx_out, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head,
+                               const float* saved, int64_t gsz, float* gr, float* gR, float* gx0, hipStream_t stream);
 int spk_schnet_mol_backward(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
                             const float* gx_out, const float* r_ij, const float* saved, int64_t gsz, float* gr, float* gx0,
                             hipStream_t stream) {
+  return spk_schnet_mol_backward_ex(m, g, rb, ptab, gx_out, r_ij, nullptr, nullptr, nullptr, saved, gsz, gr, nullptr, gx0, stream);
+}
+int spk_schnet_mol_backward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
+                               const float* gx_out, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head,
+                               const float* saved, int64_t gsz, float* gr, float* gR, float* gx0, hipStream_t stream) {
   MolBwdArgs a;
+  a.R = R; a.offsets = offsets; a.gR = gR;
+  if (head) a.head = *head; else { a.head.w1 = nullptr; a.head.w1t = nullptr; }
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_schnet_layer_t& P = m->layers[l];

@@ -624,6 +624,134 @@ Tensor atomwise_backward_raw(const Tensor& gE_in, const Tensor& gy_in, const Ten
   return gx;
 }
 
+// ------------------------------------------------------------------------------------------------ the standard potential (raw)
+// PairwiseDistances -> SchNet -> Atomwise(sum) as ONE forward and ONE backward launch where the molecule-resident kernels cover
+// the list (spk_schnet_potential_*); everywhere else the same three stages through their own launchers -- the operator always
+// works, the fusion is a property of (model, list).
+struct HeadCache { Tensor w1, w1t, b1, w2, b2; };
+Lru<HeadCache> g_heads(8);
+std::shared_ptr<HeadCache> get_head(const Tensor& w1_in, const c10::optional<Tensor>& b1_in, const Tensor& w2_in, const c10::optional<Tensor>& b2_in) {
+  std::vector<uint64_t> key{(uint64_t)w1_in.data_ptr(), version_of(w1_in), (uint64_t)w2_in.data_ptr(), version_of(w2_in),
+                            (uint64_t)((b1_in.has_value() && b1_in->defined()) ? b1_in->data_ptr() : nullptr),
+                            (b1_in.has_value() && b1_in->defined()) ? version_of(*b1_in) : 0,
+                            (uint64_t)((b2_in.has_value() && b2_in->defined()) ? b2_in->data_ptr() : nullptr),
+                            (b2_in.has_value() && b2_in->defined()) ? version_of(*b2_in) : 0};
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (auto hit = g_heads.get(key)) return hit;
+  auto h = std::make_shared<HeadCache>();
+  h->w1 = f32(w1_in.detach(), "potential head");
+  h->w1t = h->w1.t().contiguous();
+  h->w2 = f32(w2_in.detach(), "potential head").reshape({-1});
+  h->b1 = opt_f32(b1_in, "potential head");
+  h->b2 = opt_f32(b2_in, "potential head");
+  if (h->b1.defined()) h->b1 = h->b1.detach();
+  if (h->b2.defined()) h->b2 = h->b2.detach();
+  g_heads.put(key, h);
+  return h;
+}
+
+std::shared_ptr<Plan> find_plan(const Tensor& idx_i, const Tensor& idx_j, int64_t n_atoms) {
+  std::vector<uint64_t> key{(uint64_t)idx_i.data_ptr(), (uint64_t)idx_j.data_ptr(), version_of(idx_i), version_of(idx_j), (uint64_t)idx_i.size(0),
+                            (uint64_t)n_atoms, (uint64_t)idx_i.device().index(), 1, 1, (uint64_t)idx_i.scalar_type()};
+  std::lock_guard<std::mutex> lock(g_mutex);
+  return g_plans.get(key);
+}
+
+struct PotentialCall {
+  std::shared_ptr<Plan> plan;
+  std::shared_ptr<SchnetModel> M;
+  std::shared_ptr<HeadCache> H;
+  spk_schnet_t m;
+  spk_head_t head;
+  spk_graph_t g;
+  spk_radial_t rb;
+  Tensor p0, p1;
+  bool fused;
+};
+PotentialCall potential_setup(const Tensor& R, const c10::optional<Tensor>& offsets, const Tensor& idx_i, const Tensor& idx_j, int64_t N, int64_t F,
+                              at::TensorList ws, at::TensorList head, int64_t n_filters, int64_t rbf_kind, const Tensor& p0_in,
+                              const c10::optional<Tensor>& p1_in, double cutoff, int64_t head_act) {
+  TORCH_CHECK(head.size() == 4, "schnet_potential: head = [outnet.0.weight, outnet.0.bias, outnet.1.weight, outnet.1.bias]");
+  PotentialCall c;
+  c.plan = find_plan(idx_i, idx_j, N);
+  if (!c.plan || c.plan->filter_pairs < 0) {       // first call on this list: the plan needs the geometry once
+    Tensor r = pairwise_raw(R.detach(), idx_i, idx_j, offsets);
+    c.plan = get_plan(idx_i, idx_j, N, r);
+    decide_filter(*c.plan, r, cutoff);
+  }
+  c.M = get_schnet(ws, F, n_filters);
+  c.H = get_head(head[0], head[1], head[2], head[3]);
+  c.p0 = f32(p0_in, "schnet_potential");
+  c.p1 = opt_f32(p1_in, "schnet_potential");
+  c.m = c.M->m;
+  c.m.reserved = 1;
+  c.g = c.plan->graph();
+  c.rb = radial_of(rbf_kind, c.p0, c.p1, cutoff);
+  c.head.w1 = fp(c.H->w1); c.head.w1t = fp(c.H->w1t); c.head.b1 = fp(c.H->b1); c.head.w2 = fp(c.H->w2); c.head.b2 = fp(c.H->b2);
+  c.head.n_hidden = (int32_t)c.H->w1.size(0); c.head.act = (int32_t)head_act;
+  c.fused = c.H->w1.dim() == 2 && c.H->w1.size(1) == F && c.H->w2.numel() == c.H->w1.size(0) && c.H->b1.defined() &&
+            spk_schnet_potential_supported(&c.m, &c.head, &c.g, &c.rb) != 0;
+  return c;
+}
+
+// -> (E [n_mol], scalar_representation [N, F], saved, pre_h); `saved` / `pre_h` are what the backward consumes
+std::tuple<Tensor, Tensor, Tensor, Tensor> schnet_potential_forward_raw(const Tensor& x0_in, const Tensor& R_in, const c10::optional<Tensor>& offsets_in,
+                                                                        const Tensor& idx_i, const Tensor& idx_j, const Tensor& idx_m_in, int64_t n_mol,
+                                                                        at::TensorList ws, at::TensorList head, int64_t n_filters, int64_t rbf_kind,
+                                                                        const Tensor& p0, const c10::optional<Tensor>& p1, double cutoff,
+                                                                        int64_t head_act) {
+  Tensor x0 = f32(x0_in, "schnet_potential"), R = f32(R_in, "schnet_potential");
+  Tensor off = opt_f32(offsets_in, "schnet_potential");
+  Tensor idx_m = i64(idx_m_in, "schnet_potential");
+  const int64_t N = x0.size(0), F = x0.size(1);
+  TORCH_CHECK(R.dim() == 2 && R.size(0) == N && R.size(1) == 3, "schnet_potential: positions ", R.sizes(), " do not match ", N, " atoms");
+  c10::DeviceGuard guard(x0.device());
+  PotentialCall c = potential_setup(R, offsets_in, idx_i, idx_j, N, F, ws, head, n_filters, rbf_kind, p0, p1, cutoff, head_act);
+  if (c.fused) {
+    Tensor x = at::empty({N, F}, x0.options()), E = at::empty({n_mol}, x0.options());
+    Tensor pre_h = at::empty({N, (int64_t)c.head.n_hidden}, x0.options());
+    Tensor saved = at::empty({std::max<int64_t>(1, spk_schnet_saved_floats_graph(&c.m, &c.g, &c.rb))}, x0.options());
+    check(spk_schnet_potential_forward_f32(&c.m, &c.head, &c.g, &c.rb, fp(x0), fp(R), fp(off), idx_m.data_ptr<int64_t>(), n_mol, fpm(x), fpm(E),
+                                           fpm(pre_h), fpm(saved), stream_of(x0)));
+    return {E, x, saved, pre_h};
+  }
+  Tensor r = pairwise_raw(R, idx_i, idx_j, offsets_in);
+  auto rep = schnet_forward_raw(x0, r, idx_i, idx_j, ws, n_filters, rbf_kind, p0, p1, cutoff, true);
+  auto hd = atomwise_forward_raw(std::get<0>(rep), head[0], head[1], head[2], head[3], idx_m, n_mol, head_act);
+  return {std::get<0>(hd), std::get<0>(rep), std::get<1>(rep), std::get<2>(hd)};
+}
+
+// -> (dL/dR [N, 3], dL/dx0 [N, F] or empty)
+std::tuple<Tensor, Tensor> schnet_potential_backward_raw(const c10::optional<Tensor>& gE_in, const c10::optional<Tensor>& gx_in, const Tensor& x0_in,
+                                                         const Tensor& R_in, const c10::optional<Tensor>& offsets_in, const Tensor& idx_i,
+                                                         const Tensor& idx_j, const Tensor& idx_m_in, int64_t n_mol, const Tensor& saved,
+                                                         const Tensor& pre_h, at::TensorList ws, at::TensorList head, int64_t n_filters,
+                                                         int64_t rbf_kind, const Tensor& p0, const c10::optional<Tensor>& p1, double cutoff,
+                                                         int64_t head_act, bool want_gx0) {
+  Tensor R = f32(R_in, "schnet_potential backward");
+  Tensor off = opt_f32(offsets_in, "schnet_potential backward");
+  Tensor idx_m = i64(idx_m_in, "schnet_potential backward");
+  const int64_t N = x0_in.size(0), F = x0_in.size(1);
+  c10::DeviceGuard guard(R.device());
+  Tensor gE = (gE_in.has_value() && gE_in->defined()) ? f32(*gE_in, "schnet_potential backward") : at::zeros({n_mol}, R.options());
+  Tensor gx = (gx_in.has_value() && gx_in->defined()) ? f32(*gx_in, "schnet_potential backward") : Tensor();
+  PotentialCall c = potential_setup(R, offsets_in, idx_i, idx_j, N, F, ws, head, n_filters, rbf_kind, p0, p1, cutoff, head_act);
+  if (c.fused) {
+    Tensor gR = at::empty({N, 3}, R.options());
+    Tensor gx0 = want_gx0 ? at::empty({N, F}, R.options()) : Tensor();
+    check(spk_schnet_potential_backward_f32(&c.m, &c.head, &c.g, &c.rb, fp(gE), fp(gx), fp(R), fp(off), idx_m.data_ptr<int64_t>(), fp(pre_h), fp(saved),
+                                            fpm(gR), fpm(gx0), stream_of(R)));
+    return {gR, gx0.defined() ? gx0 : at::empty({0}, R.options())};
+  }
+  Tensor r = pairwise_raw(R, idx_i, idx_j, offsets_in);
+  Tensor gxh = atomwise_backward_raw(gE, Tensor(), pre_h, head[0], head[2], idx_m, n_mol, head_act);
+  if (gx.defined()) gxh = gxh + gx;
+  Tensor scratch = at::empty({std::max<int64_t>(1, spk_schnet_scratch_floats(&c.m, N))}, R.options());
+  auto res = schnet_backward_raw(gxh, r, saved, scratch, *c.plan, ws, F, n_filters, rbf_kind, p0, p1, cutoff, true, want_gx0);
+  Tensor gR = pairwise_bwd_raw(std::get<0>(res), idx_i, idx_j, N);
+  return {gR, std::get<1>(res).defined() ? std::get<1>(res) : at::empty({0}, R.options())};
+}
+
 // ------------------------------------------------------------------------------------------------ dispatcher handles
 template <class Sig>
 c10::TypedOperatorHandle<Sig> op_handle(const char* name) {
@@ -701,6 +829,23 @@ Tensor call_radial_cutoff_backward(const Tensor& d, int64_t kind, const Tensor& 
   return op.call(d, kind, p0, p1, cutoff, gphi, gfc);
 }
 OptT opt_of(const Tensor& t) { return t.defined() ? OptT(t) : OptT(); }
+std::tuple<Tensor, Tensor, Tensor, Tensor> call_potential_forward(const Tensor& x0, const Tensor& R, const OptT& off, const Tensor& ii, const Tensor& jj,
+                                                                  const Tensor& idx_m, int64_t n_mol, at::TensorList ws, at::TensorList head, int64_t nf,
+                                                                  int64_t kind, const Tensor& p0, const OptT& p1, double cutoff, int64_t head_act) {
+  static auto op = op_handle<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const OptT&, const Tensor&, const Tensor&, const Tensor&,
+                                                                        int64_t, at::TensorList, at::TensorList, int64_t, int64_t, const Tensor&, const OptT&,
+                                                                        double, int64_t)>("spk_hip::schnet_potential_forward");
+  return op.call(x0, R, off, ii, jj, idx_m, n_mol, ws, head, nf, kind, p0, p1, cutoff, head_act);
+}
+std::tuple<Tensor, Tensor> call_potential_backward(const OptT& gE, const OptT& gx, const Tensor& x0, const Tensor& R, const OptT& off, const Tensor& ii,
+                                                   const Tensor& jj, const Tensor& idx_m, int64_t n_mol, const Tensor& saved, const Tensor& pre_h,
+                                                   at::TensorList ws, at::TensorList head, int64_t nf, int64_t kind, const Tensor& p0, const OptT& p1,
+                                                   double cutoff, int64_t head_act, bool want_gx0) {
+  static auto op = op_handle<std::tuple<Tensor, Tensor>(const OptT&, const OptT&, const Tensor&, const Tensor&, const OptT&, const Tensor&, const Tensor&,
+                                                        const Tensor&, int64_t, const Tensor&, const Tensor&, at::TensorList, at::TensorList, int64_t, int64_t,
+                                                        const Tensor&, const OptT&, double, int64_t, bool)>("spk_hip::schnet_potential_backward");
+  return op.call(gE, gx, x0, R, off, ii, jj, idx_m, n_mol, saved, pre_h, ws, head, nf, kind, p0, p1, cutoff, head_act, want_gx0);
+}
 
 const char* kEvalOnly =
     ": the fused eval-mode path computes first-order gradients w.r.t. the geometry and the input features only -- a gradient w.r.t. "
@@ -874,6 +1019,38 @@ struct SchNetFn : public torch::autograd::Function<SchNetFn> {
   }
 };
 
+// (E, scalar_representation) of the standard potential; first-order gradients w.r.t. the positions and the embedding rows
+struct SchnetPotentialFn : public torch::autograd::Function<SchnetPotentialFn> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& x0, const Tensor& R, const Tensor& idx_i, const Tensor& idx_j, const Tensor& idx_m,
+                               const Tensor& p0, const c10::optional<Tensor>& offsets, const c10::optional<Tensor>& p1, at::TensorList ws,
+                               at::TensorList head, int64_t n_mol, int64_t n_filters, int64_t rbf_kind, double cutoff, int64_t head_act) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto out = call_potential_forward(x0, R, offsets, idx_i, idx_j, idx_m, n_mol, ws, head, n_filters, rbf_kind, p0, p1, cutoff, head_act);
+    const bool has_off = offsets.has_value() && offsets->defined(), has_p1 = p1.has_value() && p1->defined();
+    std::vector<Tensor> sv{x0, R, idx_i, idx_j, idx_m, p0, has_off ? *offsets : Tensor(), has_p1 ? *p1 : Tensor(), std::get<2>(out), std::get<3>(out)};
+    for (const auto& w : ws) sv.push_back(w);
+    for (const auto& w : head) sv.push_back(w);
+    ctx->save_for_backward(sv);
+    ctx->saved_data["cfg"] = std::vector<int64_t>{n_mol, n_filters, rbf_kind, head_act, (int64_t)ws.size(), (int64_t)head.size(), has_off, has_p1};
+    ctx->saved_data["n_vars"] = (int64_t)(6 + (has_off ? 1 : 0) + (has_p1 ? 1 : 0) + ws.size() + head.size());
+    ctx->saved_data["cutoff"] = cutoff;
+    return {std::get<0>(out), std::get<1>(out)};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    check_eval_backward(ctx, "spk_hip::schnet_potential", 2);       // (before the saved tensors are touched: a pass that asks for
+    auto sv = ctx->get_saved_variables();                           //  weight gradients gets THIS message)
+    auto cfg = ctx->saved_data["cfg"].toIntVector();
+    const size_t n_ws = (size_t)cfg[4], n_head = (size_t)cfg[5];
+    std::vector<Tensor> ws(sv.begin() + 10, sv.begin() + 10 + n_ws), head(sv.begin() + 10 + n_ws, sv.begin() + 10 + n_ws + n_head);
+    auto res = call_potential_backward(opt_of(grads[0]), opt_of(grads[1]), sv[0], sv[1], opt_of(sv[6]), sv[2], sv[3], sv[4], cfg[0], sv[8], sv[9], ws, head,
+                                       cfg[1], cfg[2], sv[5], opt_of(sv[7]), ctx->saved_data["cutoff"].toDouble(), cfg[3], ctx->needs_input_grad(0));
+    variable_list out(8 + n_ws + n_head + 5);
+    if (ctx->needs_input_grad(0)) out[0] = std::get<1>(res);
+    if (ctx->needs_input_grad(1)) out[1] = std::get<0>(res);
+    return out;
+  }
+};
+
 struct PaiNNFn : public torch::autograd::Function<PaiNNFn> {
   static variable_list forward(AutogradContext* ctx, const Tensor& q0, const Tensor& r_ij, const Tensor& idx_i, const Tensor& idx_j,
                                bool shared_filters, double eps, int64_t rbf_kind, const Tensor& p0, const c10::optional<Tensor>& p1,
@@ -941,6 +1118,38 @@ Tensor schnet_ad(const Tensor& x0, const Tensor& r_ij, const Tensor& idx_i, cons
   // a gradient w.r.t. the geometry may be asked for: keep the raw filter outputs so that the backward runs the derivative GEMM only
   const bool save_filters = at::GradMode::is_enabled() && r_ij.requires_grad();
   return SchNetFn::apply(x0, r_ij, idx_i, idx_j, n_filters, rbf_kind, p0, p1, cutoff, save_filters, ws);
+}
+std::tuple<Tensor, Tensor> schnet_potential_ad(const Tensor& x0, const Tensor& R, const c10::optional<Tensor>& offsets, const Tensor& idx_i, const Tensor& idx_j,
+                                               const Tensor& idx_m, int64_t n_mol, at::TensorList ws, at::TensorList head, int64_t n_filters, int64_t rbf_kind,
+                                               const Tensor& p0, const c10::optional<Tensor>& p1, double cutoff, int64_t head_act) {
+  TORCH_CHECK(!(offsets.has_value() && offsets->defined() && offsets->requires_grad()),
+              "spk_hip::schnet_potential does not return a gradient w.r.t. the offsets (stress): run the modules separately for that");
+  auto r = SchnetPotentialFn::apply(x0, R, idx_i, idx_j, idx_m, p0, offsets, p1, ws, head, n_mol, n_filters, rbf_kind, cutoff, head_act);
+  return {r[0], r[1]};
+}
+std::tuple<Tensor, Tensor> schnet_potential_dev(const Tensor& x0, const Tensor& R, const c10::optional<Tensor>& offsets, const Tensor& idx_i, const Tensor& idx_j,
+                                                const Tensor& idx_m, int64_t n_mol, at::TensorList ws, at::TensorList head, int64_t n_filters, int64_t rbf_kind,
+                                                const Tensor& p0, const c10::optional<Tensor>& p1, double cutoff, int64_t head_act) {
+  auto r = schnet_potential_forward_raw(x0, R, offsets, idx_i, idx_j, idx_m, n_mol, ws, head, n_filters, rbf_kind, p0, p1, cutoff, head_act);
+  return {std::get<0>(r), std::get<1>(r)};
+}
+std::tuple<Tensor, Tensor> schnet_potential_meta(const Tensor& x0, const Tensor&, const c10::optional<Tensor>&, const Tensor&, const Tensor&, const Tensor&,
+                                                 int64_t n_mol, at::TensorList, at::TensorList, int64_t, int64_t, const Tensor&, const c10::optional<Tensor>&,
+                                                 double, int64_t) {
+  return {at::empty({n_mol}, x0.options()), at::empty_like(x0)};
+}
+std::tuple<Tensor, Tensor, Tensor, Tensor> schnet_potential_forward_meta(const Tensor& x0, const Tensor&, const c10::optional<Tensor>&, const Tensor& idx_i,
+                                                                         const Tensor&, const Tensor&, int64_t n_mol, at::TensorList ws, at::TensorList head,
+                                                                         int64_t nf, int64_t, const Tensor&, const c10::optional<Tensor>&, double, int64_t) {
+  const int64_t N = x0.size(0), L = (int64_t)ws.size() / kSchnetPerLayer;
+  return {at::empty({n_mol}, x0.options()), at::empty_like(x0), at::empty({L * (N * (nf + x0.size(1)) + (idx_i.size(0) / 2) * nf) + 1}, x0.options()),
+          at::empty({N, head.size() ? head[0].size(0) : 0}, x0.options())};
+}
+std::tuple<Tensor, Tensor> schnet_potential_backward_meta(const c10::optional<Tensor>&, const c10::optional<Tensor>&, const Tensor& x0, const Tensor& R,
+                                                          const c10::optional<Tensor>&, const Tensor&, const Tensor&, const Tensor&, int64_t, const Tensor&,
+                                                          const Tensor&, at::TensorList, at::TensorList, int64_t, int64_t, const Tensor&,
+                                                          const c10::optional<Tensor>&, double, int64_t, bool want_gx0) {
+  return {at::empty_like(R), want_gx0 ? at::empty_like(x0) : at::empty({0}, x0.options())};
 }
 std::tuple<Tensor, Tensor> painn_ad(const Tensor& q0, const Tensor& r_ij, const Tensor& idx_i, const Tensor& idx_j, at::TensorList ws,
                                     bool shared_filters, double eps, int64_t rbf_kind, const Tensor& p0, const c10::optional<Tensor>& p1,
@@ -1210,6 +1419,10 @@ TORCH_LIBRARY(spk_hip, m) {
   m.def("schnet(Tensor x0, Tensor r_ij, Tensor idx_i, Tensor idx_j, Tensor[] weights, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff) -> Tensor");  // representation/schnet.py:147-173
   m.def("painn(Tensor q0, Tensor r_ij, Tensor idx_i, Tensor idx_j, Tensor[] weights, bool shared_filters, float epsilon, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff) -> (Tensor, Tensor)");  // representation/painn.py:207-256
   m.def("atomwise(Tensor x, Tensor w1, Tensor? b1, Tensor w2, Tensor? b2, Tensor idx_m, int n_mol, int act) -> (Tensor, Tensor)");  // atomistic/atomwise.py:69-88
+  // PairwiseDistances -> SchNet -> Atomwise(sum): (energy, scalar_representation); two launches where the list allows it
+  m.def("schnet_potential(Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor)");
+  m.def("schnet_potential_forward(Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("schnet_potential_backward(Tensor? gE, Tensor? gx, Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor saved, Tensor pre_h, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act, bool want_gx0) -> (Tensor, Tensor)");
   // raw launchers (no autograd): forward returns the tensors its backward consumes
   m.def("dense_forward(Tensor x, Tensor weight, Tensor? bias, int act) -> (Tensor, Tensor)");
   m.def("dense_backward_input(Tensor gy, Tensor pre, Tensor weight, int act) -> Tensor");
@@ -1244,6 +1457,9 @@ TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm d
   m.impl("schnet", schnet_dev);
   m.impl("painn", painn_dev);
   m.impl("atomwise", atomwise_dev);
+  m.impl("schnet_potential", schnet_potential_dev);
+  m.impl("schnet_potential_forward", schnet_potential_forward_raw);
+  m.impl("schnet_potential_backward", schnet_potential_backward_raw);
   m.impl("dense_forward", dense_raw);
   m.impl("dense_backward_input", dense_bwd_input_raw);
   m.impl("radial_cutoff_backward", radial_cutoff_bwd_raw);
@@ -1270,13 +1486,15 @@ TORCH_LIBRARY_IMPL(spk_hip, Autograd, m) {
   m.impl("schnet", schnet_ad);
   m.impl("painn", painn_ad);
   m.impl("atomwise", atomwise_ad);
+  m.impl("schnet_potential", schnet_potential_ad);
   train_impl_autograd(m);
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, CPU, m) {
   for (const char* name : {"scatter_add", "gather", "pairwise", "pairwise_backward", "dense", "radial_cutoff", "schnet", "painn", "atomwise",
                            "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
-                           "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare", "static_declare_range"})
+                           "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare", "static_declare_range", "schnet_potential",
+                           "schnet_potential_forward", "schnet_potential_backward"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
   for (const char* name : kTrainOps) m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }
@@ -1300,5 +1518,8 @@ TORCH_LIBRARY_IMPL(spk_hip, Meta, m) {
   m.impl("schnet_backward", schnet_backward_meta);
   m.impl("painn_backward", painn_backward_meta);
   m.impl("atomwise_backward", atomwise_backward_meta);
+  m.impl("schnet_potential", schnet_potential_meta);
+  m.impl("schnet_potential_forward", schnet_potential_forward_meta);
+  m.impl("schnet_potential_backward", schnet_potential_backward_meta);
   train_impl_meta(m);
 }

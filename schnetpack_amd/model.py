@@ -1,6 +1,6 @@
 """Mirror of ``NeuralNetworkPotential`` (model/base.py:132-190) -- the one caller of the hot
 path -- plus helpers to assemble the benchmark models and to move batches to the device."""
-from typing import Dict, List, Optional
+from typing import Dict, Final, List, Optional
 
 import torch
 import torch.nn as nn
@@ -15,10 +15,17 @@ __all__ = ["NeuralNetworkPotential", "build_model", "batch_to_inputs"]
 
 class NeuralNetworkPotential(nn.Module):
     """input_modules -> representation -> output_modules (dict in, dict out); TorchScript-able like the reference's
-    (src/scripts/spkdeploy:16-40 scripts the whole model)."""
+    (src/scripts/spkdeploy:16-40 scripts the whole model).
+
+    The standard potential -- ``PairwiseDistances`` -> fused ``SchNet`` -> ``Atomwise`` (default head, summed or averaged over
+    the molecule) -> ``Forces`` without stress -- runs in eval mode as ONE operator, ``torch.ops.spk_hip.schnet_potential``:
+    on batches of small molecules the pair vectors, the representation and the energy head are one launch and the backward
+    that ``Forces`` triggers (dE/dE -> head -> representation -> dE/dR) is one launch; on every other list the operator runs
+    the same three stages through their own kernels.  Any other composition takes the module-by-module path below."""
 
     required_derivatives: List[str]
     model_outputs: List[str]
+    _potential: Final[bool]
 
     def __init__(self, representation: nn.Module, input_modules: List[nn.Module] = None,
                  output_modules: List[nn.Module] = None):
@@ -37,11 +44,47 @@ class NeuralNetworkPotential(nn.Module):
                 if k not in outs:
                     outs.append(k)
         self.model_outputs = outs
+        self._potential = self._is_standard_potential()
+
+    def _is_standard_potential(self) -> bool:
+        rep, ins, outs = self.representation, list(self.input_modules), list(self.output_modules)
+        if not (isinstance(rep, SchNet) and rep._fused and len(rep.interactions) > 0):
+            return False
+        if not (len(ins) == 1 and type(ins[0]) is PairwiseDistances and len(outs) >= 1):
+            return False
+        head = outs[0]
+        if not (isinstance(head, Atomwise) and head._fused_head and head.per_atom_output_key is None
+                and head.aggregation_mode in ("sum", "avg")):
+            return False
+        return all(type(m) is Forces and not m.calc_stress for m in outs[1:])
+
+    @torch.jit.unused
+    def _potential_forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        rep, head = self.representation, self.output_modules[0]
+        idx_m = inputs[properties.idx_m]
+        n_mol = head._n_molecules(inputs, idx_m)
+        kind, p0, p1 = rep.radial_basis.kernel_params()
+        l0, l1 = head.outnet[0], head.outnet[1]
+        E, x = torch.ops.spk_hip.schnet_potential(
+            rep.embed(inputs), inputs[properties.R], inputs.get(properties.offsets), inputs[properties.idx_i], inputs[properties.idx_j], idx_m,
+            n_mol, rep.interaction_weights(), [l0.weight, l0.bias, l1.weight, l1.bias], rep.n_filters, kind, p0, p1,
+            rep.cutoff_fn.cutoff_value(), head._head_act)
+        if head.aggregation_mode == "avg":
+            E = E / inputs[properties.n_atoms]
+        inputs["scalar_representation"] = x
+        inputs[head.output_key] = E
+        return inputs
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         for p in self.required_derivatives:
             if p in inputs:
                 inputs[p].requires_grad_()
+        if self._potential and not self.training and not torch.jit.is_scripting():
+            inputs = self._potential_forward(inputs)
+            for i, m in enumerate(self.output_modules):
+                if i > 0:
+                    inputs = m(inputs)
+            return {k: inputs[k] for k in self.model_outputs}
         for m in self.input_modules:
             inputs = m(inputs)
         inputs = self.representation(inputs)

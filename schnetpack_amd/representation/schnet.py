@@ -110,20 +110,29 @@ class SchNet(nn.Module):
                 and hasattr(self.cutoff_fn, "cutoff_value")
                 and self.n_filters % 4 == 0 and self.n_filters <= 1024 and 1 <= n_rbf <= 256)
 
+    def embed(self, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """x_0: nuclear embedding rows plus the electronic embeddings (schnet.py:160-165)."""
+        x = self.embedding(inputs[properties.Z])
+        for embedding in self.electronic_embeddings:
+            x = x + embedding(x, inputs)
+        return x
+
+    def interaction_weights(self) -> List[torch.Tensor]:
+        """The tensors of all interaction blocks in the order of ``spk_schnet_layer_t`` (what the fused operators take)."""
+        ws: List[torch.Tensor] = []
+        for interaction in self.interactions:
+            ws += interaction.fused_weights()
+        return ws
+
     def forward(self, inputs: Dict[str, torch.Tensor]):
-        atomic_numbers = inputs[properties.Z]
         r_ij = inputs[properties.Rij]
         idx_i = inputs[properties.idx_i]
         idx_j = inputs[properties.idx_j]
 
-        x = self.embedding(atomic_numbers)
-        for embedding in self.electronic_embeddings:
-            x = x + embedding(x, inputs)
+        x = self.embed(inputs)
 
         if self._fused and not self.training:
-            ws: List[torch.Tensor] = []
-            for interaction in self.interactions:
-                ws += interaction.fused_weights()
+            ws = self.interaction_weights()
             kind, p0, p1 = self.radial_basis.kernel_params()
             x = torch.ops.spk_hip.schnet(x, r_ij, idx_i, idx_j, ws, self.n_filters, kind, p0, p1, self.cutoff_fn.cutoff_value())
         else:

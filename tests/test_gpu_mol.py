@@ -100,3 +100,72 @@ def test_large_molecules_fall_back_to_the_general_driver(dev):
     assert "schnet_mol_fwd" not in tags
     ref = O.energy_and_forces("schnet", rep, head, b, 3)
     assert rel_err(f, ref["forces"]) < TOL
+
+
+@pytest.mark.parametrize("sizes,agg", [(["aspirin"] * 9, "sum"), (["ethanol", "aspirin", "atom", "dimer", "ethanol", "atom", "atom", "ethanol"], "sum"),
+                                        (["ethanol"] * 13, "avg")])
+def test_standard_potential_in_two_launches_equals_the_module_by_module_path(dev, sizes, agg):
+    """NeuralNetworkPotential([PairwiseDistances], SchNet, [Atomwise, Forces]) in eval mode is ONE operator (spk_hip::schnet_potential):
+    pair vectors + representation + energy head in one launch, head + representation + dE/dR in the backward launch.  Same
+    energies / forces / representation as the separate modules, and as the oracle."""
+    from schnetpack_amd import _lib, model as M
+    b = _mixed_batch(5, sizes)
+    rep, head = O.init_schnet_params(128, 3, 20, 5.0), O.init_atomwise_params(128, seed=1)
+    m = M.build_model("schnet", 128, 3, 20, 5.0)
+    M.load_reference_params(m, rep, head)
+    m.output_modules[0].aggregation_mode = agg
+    m = m.to(dev).eval()
+    assert m._potential
+    res = {}
+    for fused in (True, False):
+        m._potential = fused
+        _lib.profile_enable(True)
+        _lib.profile_report()
+        try:
+            inp = M.batch_to_inputs(b, dev)
+            inp["_n_atoms"] = torch.bincount(b["idx_m"], minlength=int(b["n_mol"])).to(dev)
+            out = m(inp)
+            res[fused] = (out["energy"].detach().cpu(), out["forces"].detach().cpu(), inp["scalar_representation"].detach().cpu(), _lib.profile_report())
+        finally:
+            _lib.profile_enable(False)
+    m._potential = True
+    tags = res[True][3]
+    assert "schnet_mol_fwd" in tags and "schnet_mol_bwd" in tags and "atomwise_fwd" not in tags and "atomwise_bwd" not in tags, tags
+    assert not any(t.startswith("pairwise") for t in tags), tags
+    assert "atomwise_fwd" in res[False][3]
+    for a, c in zip(res[True][:3], res[False][:3]):
+        assert rel_err(a, c) < 2e-6
+    ref = O.energy_and_forces("schnet", rep, head, b, 3)
+    e_ref = ref["energy"] / torch.bincount(b["idx_m"]).double() if agg == "avg" else ref["energy"]
+    f_ref = ref["forces"] if agg == "sum" else None
+    assert rel_err(res[True][0], e_ref) < TOL
+    if f_ref is not None:
+        assert rel_err(res[True][1], f_ref) < TOL
+
+
+def test_standard_potential_gradient_reaches_the_embedding_rows(dev):
+    """dE/dx0 (embedding rows as a leaf) and dE/dR from one backward of the fused operator against the separate operators."""
+    from schnetpack_amd import model as M
+    b = _mixed_batch(7, ["aspirin", "ethanol", "ethanol", "dimer"])
+    m = M.build_model("schnet").to(dev).eval()
+    inp = M.batch_to_inputs(b, dev)
+    rep, head = m.representation, m.output_modules[0]
+    kind, p0, p1 = rep.radial_basis.kernel_params()
+    l0, l1 = head.outnet[0], head.outnet[1]
+    got = []
+    for fused in (True, False):
+        x0 = rep.embed(inp).detach().requires_grad_(True)
+        R = inp["_positions"].detach().clone().requires_grad_(True)
+        if fused:
+            E, x = torch.ops.spk_hip.schnet_potential(x0, R, inp["_offsets"], inp["_idx_i"], inp["_idx_j"], inp["_idx_m"], int(b["n_mol"]),
+                                                      rep.interaction_weights(), [l0.weight, l0.bias, l1.weight, l1.bias], rep.n_filters, kind, p0, p1,
+                                                      rep.cutoff_fn.cutoff_value(), head._head_act)
+        else:
+            r = torch.ops.spk_hip.pairwise(R, inp["_idx_i"], inp["_idx_j"], inp["_offsets"])
+            x = torch.ops.spk_hip.schnet(x0, r, inp["_idx_i"], inp["_idx_j"], rep.interaction_weights(), rep.n_filters, kind, p0, p1, rep.cutoff_fn.cutoff_value())
+            E = torch.ops.spk_hip.atomwise(x, l0.weight, l0.bias, l1.weight, l1.bias, inp["_idx_m"], int(b["n_mol"]), head._head_act)[0]
+        w = torch.linspace(0.5, 1.5, E.shape[0], device=dev)
+        gx0, gR = torch.autograd.grad((E * w).sum() + 0.01 * (x ** 2).sum(), [x0, R])
+        got.append((E.detach().cpu(), gx0.cpu(), gR.cpu()))
+    for a, c in zip(*got):
+        assert rel_err(a, c) < 3e-6
