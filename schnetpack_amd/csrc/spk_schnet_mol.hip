@@ -152,7 +152,7 @@ __device__ __forceinline__ int ml_pair_records(MolPair* sP, short* sMap, int* sS
 // for the atoms at0, at0 + 4, at0 + 8, ... of one (channel, atom quarter) thread: THREE rows per round, up to RB loads of the
 // filter tensor in flight per row (one L2 round trip per round; rows of a molecule rarely exceed RB neighbours).  Branch-free:
 // entries beyond the end of a row re-read its last entry with weight 0, so the record reads and the loads issue back to back.
-// sEb: per directed edge (local pair << 8 | local neighbour, f_c of the pair).
+// sEb: per directed edge (row of the saved filter tensor << 8 | local neighbour [| 1 << 24: pair beyond the cutoff], f_c of the pair).
 template <int RB>
 __device__ __forceinline__ void ml_row_sums(float* __restrict__ sDst, const float* __restrict__ sSrc, const float* __restrict__ g_g,
                                             const int2* __restrict__ sEb, const int* __restrict__ sRow, int na, int at0, int c) {
@@ -182,7 +182,7 @@ __device__ __forceinline__ void ml_row_sums(float* __restrict__ sDst, const floa
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int u = 0; u < RB; ++u) gv[m][u] = g_g[(unsigned)(rec[m][u].x >> 8) * 128u + (unsigned)c];
+        for (int u = 0; u < RB; ++u) gv[m][u] = g_g[(unsigned)((rec[m][u].x >> 8) & 0xFFFF) * 128u + (unsigned)c];
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -533,9 +533,11 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       // ================= energy head on the atom tile that is still in LDS: y = w2 . act(W1 x + b1) + b2, E[mol] += sum_atoms y
       const MolHeadDev& Hd = a.head;
       const int HT = Hd.H / 32;
+      long long my_mol = -1;
+      if (wv == 1 && lane < 32) my_mol = lane < na ? Hd.idx_m[a0 + lane] : -2;      // wave 1: molecule id of atom `lane`
       __syncthreads();                    // x_L is complete
       if (wv < HT) {
-        f32x4 av[16];
+        f32x4 av[16];                     // (requested after the barrier: register arrays that live across one get spilled)
 #pragma unroll
         for (int u = 0; u < 16; ++u) av[u] = ml_ld<f32x4>(Hd.w1 + (size_t)(32 * wv) * NF, (unsigned)((el * NF + 8 * u + 4 * hi) * 4));
         f32x16 acc;
@@ -557,19 +559,23 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
         if (hi == 0) sH[wv * 32 + el] = part;          // (sH: the hidden tile of the last f2out is no longer needed)
       }
       __syncthreads();
-      if (tid < 32) {
-        float y = Hd.b2 ? Hd.b2[0] : 0.f;
-        for (int w = 0; w < HT; ++w) y += sH[w * 32 + tid];
-        sH[4 * 32 + tid] = tid < na ? y : 0.f;
-      }
-      __syncthreads();
-      if (tid < na) {                                  // one atomic per (group, molecule), atoms summed in order
-        const int64_t mol = Hd.idx_m[a0 + tid];
-        if (tid == 0 || Hd.idx_m[a0 + tid - 1] != mol) {
-          float sum = 0.f;
-          for (int b = tid; b < na && Hd.idx_m[a0 + b] == mol; ++b) sum += sH[4 * 32 + b];
-          unsafeAtomicAdd(Hd.E + mol, sum);
+      // wave 1 holds the molecule id of atom (lane) in my_mol: segment heads add their run, one atomic per (group, molecule)
+      if (wv == 1) {
+        float y = 0.f;
+        if (lane < 32) {
+          y = Hd.b2 ? Hd.b2[0] : 0.f;
+          for (int w = 0; w < HT; ++w) y += sH[w * 32 + lane];
+          if (lane >= na) y = 0.f;
         }
+        const long long prev = __shfl_up(my_mol, 1, 64);
+        const bool head_of_run = lane < na && (lane == 0 || prev != my_mol);
+        float sum = 0.f;
+        for (int b = 0; b < 32; ++b) {                 // runs are contiguous: every head walks forward while the id matches
+          const float yb = spk_readlane_f(y, b);
+          const long long mb = __shfl(my_mol, b, 64);
+          if (head_of_run && b >= lane && b < na && mb == my_mol) sum += yb;
+        }
+        if (head_of_run) unsafeAtomicAdd(Hd.E + my_mol, sum);
       }
     }
     ML_STAMP(31);
@@ -748,6 +754,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     if (a.head.w1t) {
       // ---- dL/dx_L through the energy head: gx += (gE[mol] w2 . act'(pre_h)) W1
       const MolHeadDev& Hd = a.head;
+      const int KH = Hd.H / 8;
       __syncthreads();
       for (int s = tid; s < 32 * Hd.H; s += 512) {
         const int row = s / Hd.H, k = s - row * Hd.H;
@@ -767,13 +774,18 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* brow = sGh + el * ML_LD + 4 * hi;
-        for (int u = 0; u < Hd.H / 8; ++u) {
-          const f32x4 av = ml_ld<f32x4>(Hd.w1t + (size_t)(32 * t) * Hd.H, (unsigned)((el * Hd.H + 8 * u + 4 * hi) * 4));
-          const f32x4 bv = *(const f32x4*)(brow + 8 * u);
-          acc = ML_MFMA(av.x, bv.x, acc);
-          acc = ML_MFMA(av.y, bv.y, acc);
-          acc = ML_MFMA(av.z, bv.z, acc);
-          acc = ML_MFMA(av.w, bv.w, acc);
+        for (int c = 0; c < KH; c += 4) {            // H is a multiple of 32: whole chunks of four k-blocks (A = rows of W1^T)
+          f32x4 a4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a4[u] = ml_ld<f32x4>(Hd.w1t + (size_t)(32 * t) * Hd.H, (unsigned)((el * Hd.H + 8 * (c + u) + 4 * hi) * 4));
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const f32x4 bv = *(const f32x4*)(brow + 8 * (c + u));
+            acc = ML_MFMA(a4[u].x, bv.x, acc);
+            acc = ML_MFMA(a4[u].y, bv.y, acc);
+            acc = ML_MFMA(a4[u].z, bv.z, acc);
+            acc = ML_MFMA(a4[u].w, bv.w, acc);
+          }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -796,7 +808,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       const int pos = ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0;
       const int rec = sMap[pos];
       const int nb = (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0);
-      sEb[s] = rec >= 0 ? make_int2((pos << 8) | nb, __float_as_int(sP[rec].fc)) : make_int2((row0 << 8) | nb, 0);
+      sEb[s] = rec >= 0 ? make_int2((pos << 8) | nb, __float_as_int(sP[rec].fc)) : make_int2((row0 << 8) | nb | (1 << 24), 0);
     }
     for (int s = tid; s < 2 * np; s += 512) sS[s] = 0.f;
     if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
@@ -1010,40 +1022,44 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       ML_STAMP(37 + 6 * (Ltop - l));
     }
 
-    // ---- dL/dr of both directions of every pair, once for all interactions (pairs beyond the cutoff: zero)
-    if (a.gr) {
-      for (int s = tid; s < np_list; s += 512) {
-        const int64_t e = a.half[p0 + s];
+    // ---- dL/dr of both directions of every pair, once for all interactions (pairs beyond the cutoff: zero); with gR the pair's
+    //      contribution (s1 + s2) r / d is parked in LDS for the per-atom pass below (sGh is free by now)
+    float* sV = sGh;                                    // [ML_MAXPAIRS][3]
+    if (a.gR) __syncthreads();
+    for (int s = tid; s < np_list; s += 512) {
+      const int64_t e = a.half[p0 + s];
+      const int rec = sMap[s];
+      float s1 = 0.f, s2 = 0.f;
+      if (rec >= 0) {
+        const float d = sP[rec].d;
+        const float inv = d > 0.f ? 1.0f / d : 0.f;
+        s1 = sS[2 * rec] * inv; s2 = sS[2 * rec + 1] * inv;
+      }
+      float rx, ry, rz;
+      ml_edge_vector(a.rij, a.R, a.offsets, a.idx_i, a.idx_j, e, rx, ry, rz);
+      if (a.gr) {
         const int64_t e2 = a.rev[e];
-        const int rec = sMap[s];
-        float s1 = 0.f, s2 = 0.f;
-        if (rec >= 0) {
-          const float d = sP[rec].d;
-          const float inv = d > 0.f ? 1.0f / d : 0.f;
-          s1 = sS[2 * rec] * inv; s2 = sS[2 * rec + 1] * inv;
-        }
-        float rx, ry, rz;
-        ml_edge_vector(a.rij, a.R, a.offsets, a.idx_i, a.idx_j, e, rx, ry, rz);
         a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
         a.gr[3 * e2] = -s2 * rx; a.gr[3 * e2 + 1] = -s2 * ry; a.gr[3 * e2 + 2] = -s2 * rz;
+      }
+      if (a.gR && rec >= 0) {
+        const float w = s1 + s2;
+        sV[3 * rec] = w * rx; sV[3 * rec + 1] = w * ry; sV[3 * rec + 2] = w * rz;
       }
     }
     // ---- dL/dR: the transpose of r_ij = R_j - R_i + offsets, per atom over its row (each pair of the atom appears once
     //      there): the pair (i, j) with canonical vector r gives -(s1 + s2) r / d to i and +(s1 + s2) r / d to j.  Fixed order.
     if (a.gR) {
+      __syncthreads();
       for (int s = tid; s < 3 * na; s += 512) {
         const int at = s / 3, comp = s - 3 * at;
         float acc = 0.f;
         for (int e = sRow[at]; e < sRow[at + 1]; ++e) {
-          const int pos = sEb[e].x >> 8;
-          const int rec = sMap[pos];
-          if (rec < 0) continue;
-          const MolPair pr = sP[rec];
-          const float inv = pr.d > 0.f ? 1.0f / pr.d : 0.f;
-          const float w = (sS[2 * rec] + sS[2 * rec + 1]) * inv;
-          float rv[3];
-          ml_edge_vector(a.rij, a.R, a.offsets, a.idx_i, a.idx_j, a.half[p0 + pos], rv[0], rv[1], rv[2]);
-          acc += ((pr.ij & 255) == at ? -w : w) * rv[comp];
+          const int x = sEb[e].x;
+          if (x & (1 << 24)) continue;
+          const int rec = sMap[(x >> 8) & 0xFFFF];
+          const float v = sV[3 * rec + comp];
+          acc += ((sP[rec].ij & 255) == at) ? -v : v;
         }
         a.gR[3 * (size_t)(a0 + at) + comp] = acc;
       }

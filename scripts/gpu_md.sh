@@ -1,7 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_md.py -x -q 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_mol.py tests/test_gpu_models.py tests/test_gpu_md.py tests/test_gpu_torchscript.py -x -q 2>&1 | tail -5
 timeout 600 python bench.py --steps 50 --warmup 5 --no-sweep --no-pmc --cpu-reps 2 --md-steps 400 > gpurun_out/t3.json 2> gpurun_out/t3.err; echo rc=$?
 python - <<PY
 import json

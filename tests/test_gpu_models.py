@@ -393,7 +393,8 @@ def test_periodic_list_with_skin_matches_oracle(dev, kind):
     assert rel_err(out["energy"].detach().cpu(), ref["energy"]) < TOL
     assert rel_err(out["forces"].detach().cpu(), ref["forces"]) < TOL
     if kind == "schnet":
-        flags = torch.ops.spk_hip.edge_plan(inp["_idx_i"], inp["_idx_j"], int(b["Z"].shape[0]), inp["_Rij"].detach())[3]
+        r_ij = torch.ops.spk_hip.pairwise(inp["_positions"].detach(), inp["_idx_i"], inp["_idx_j"], inp["_offsets"])
+        flags = torch.ops.spk_hip.edge_plan(inp["_idx_i"], inp["_idx_j"], int(b["Z"].shape[0]), r_ij)[3]
         assert int(flags[3]) == 1
     # and the same forces as with the exact 5 A list
     out5 = model(M.batch_to_inputs(wb, dev))
