@@ -613,7 +613,9 @@ def main():
                 md[wl] = {k: r[k] for k in ("ns_per_day", "ms_per_step", "n_atoms", "pairs_in_list", "trajectories", "rebuilds", "fraction_in_rebuilds", "dt_fs", "steps", "hip_graph")}
             except Exception as exc:  # pragma: no cover
                 md[wl] = {"error": str(exc)[:200]}
-        md["note"] = "NVE velocity Verlet, 0.5 fs, device neighbour list with a %.1f A skin, one HIP-graph replay per step; ns/day per trajectory" % args.md_shell
+        md["note"] = ("NVE velocity Verlet, 0.5 fs, one HIP-graph replay per step; ns/day per trajectory.  Water box: device neighbour list with a "
+                      "%.1f A skin.  Aspirin batch: isolated molecules of <= 28 atoms keep the COMPLETE intramolecular list (an infinite skin: no "
+                      "rebuilds, no host synchronisation; pairs beyond the cutoff get no tile in the kernels)" % args.md_shell)
     sweep = None
     if world == 1 and not args.no_sweep:
         try:
