@@ -169,3 +169,28 @@ def test_standard_potential_gradient_reaches_the_embedding_rows(dev):
         got.append((E.detach().cpu(), gx0.cpu(), gR.cpu()))
     for a, c in zip(*got):
         assert rel_err(a, c) < 3e-6
+
+
+def test_groups_whose_pairs_all_lie_beyond_the_cutoff(dev):
+    """A list with a skin can hold a molecule whose every pair is outside the model cutoff (here: two atoms 6 A apart in a 7 A
+    list).  Such a group gets no pair tile at all: finite results, zero forces on its atoms, the energies of isolated atoms --
+    and its neighbours in the batch are unaffected."""
+    from schnetpack_amd import model as M
+    far = {"Z": [8, 1], "R": np.array([[0.0, 0.0, 0.0], [6.0, 0.0, 0.0]]), "idx_i": np.array([0, 1]), "idx_j": np.array([1, 0])}
+    rng = np.random.RandomState(0)
+    asp = {"Z": S.ASPIRIN_Z, "R": np.asarray(S.ASPIRIN_R) + 0.05 * rng.randn(21, 3)}
+    ii, jj = S.neighbor_pairs_open(asp["R"], 7.0)            # a skin list for the aspirin too
+    asp.update(idx_i=ii, idx_j=jj)
+    b = S.collate([asp, far, dict(asp), far])
+    m = M.build_model("schnet").to(dev).eval()
+    out = m(M.batch_to_inputs(b, dev))
+    e, f = out["energy"].detach().cpu(), out["forces"].detach().cpu()
+    assert torch.isfinite(e).all() and torch.isfinite(f).all()
+    assert float(f[21:23].abs().max()) == 0.0 and float(f[44:46].abs().max()) == 0.0
+    assert abs(float(e[1] - e[3])) < 1e-6 * abs(float(e[1])) and abs(float(e[0] - e[2])) < 2e-6 * abs(float(e[0]))
+    # the same molecules with the exact 5 A lists
+    ii5, jj5 = S.neighbor_pairs_open(asp["R"], 5.0)
+    b5 = S.collate([dict(asp, idx_i=ii5, idx_j=jj5), {"Z": [8], "R": np.zeros((1, 3)), "idx_i": np.zeros(0, int), "idx_j": np.zeros(0, int)}])
+    out5 = m(M.batch_to_inputs(b5, dev))
+    assert rel_err(e[0:1], out5["energy"].detach().cpu()[0:1]) < 2e-6
+    assert rel_err(f[:21], out5["forces"].detach().cpu()[:21]) < 5e-6
