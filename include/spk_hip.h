@@ -556,6 +556,11 @@ int spk_act_mul_f32(const float* a, const float* z, const float* c, int64_t n, i
 int spk_gemm_tn_plan(int64_t n, int32_t O, int32_t K, int32_t* n_slices, int64_t* ws_floats, int32_t* n_tiles);
 int spk_gemm_tn_f32(const float* U, const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, float* ws,
                     uint32_t* tickets, void* stream);
+/* The two independent products of a Dense backward in ONE launch: out = a w (trans = 1: a [m, n_out], w [n_out, k] -> [m, k]) or
+ * a w^T (trans = 0: a [m, k] -> [m, n_out]), and (G, gb) as spk_gemm_tn_f32.  Widths of the first product must be multiples of 4. */
+int spk_gemm_pair_f32(const float* a, const float* w, int32_t trans, int64_t m, int32_t k, int32_t n_out, float* out,
+                      const float* U, const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, float* ws,
+                      uint32_t* tickets, void* stream);
 /* y[idx_out[e], :] += x[idx_src[e], :] * W[e, :]   (schnet.py:64-66 on materialised filters; y [n_out, F] overwritten).
  * rowptr_out = CSR row pointers of an ascending idx_out (deterministic segmented sum) or NULL (float atomics).
  * idx_src may be NULL: identity (x has one row per pair). */

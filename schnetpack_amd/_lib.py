@@ -117,6 +117,7 @@ _PROTOS = {
     "spk_act_mul_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i32, c_i32, c_f, c_f]),
     "spk_gemm_tn_plan": (ctypes.c_int, [c_i64, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]),
     "spk_gemm_tn_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f]),
+    "spk_gemm_pair_f32": (ctypes.c_int, [c_f, c_f, c_i32, c_i64, c_i32, c_i32, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f]),
     "spk_cfconv_edge_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i32, c_f, c_f]),
     "spk_edge_mul_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i32, c_f, c_f]),
     "spk_radial_d_f32": (ctypes.c_int, [c_f, c_f, c_i64, P(RadialT), c_i32, c_f, c_f]),

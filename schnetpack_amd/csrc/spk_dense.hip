@@ -13,6 +13,7 @@
 //   accumulator tile can be fed straight back as the B operand of the next layer (chained GEMMs
 //   without leaving registers) -- used by the fused cfconv kernels.
 #include "spk_common.h"
+#include "spk_gemm_tn.h"
 
 // One chunk = 8 k-blocks (64 contraction indices): 8 A + 8 B 16-byte operands per lane.  All loads
 // of a chunk are issued before its 32 MFMAs, and the next chunk is requested before the current one
@@ -68,17 +69,18 @@ __device__ __forceinline__ f32x16 dense_mfma_chunk(const f32x4 (&av)[DCH], const
   return acc;
 }
 
+// one wave walks the 32 x 32 output tiles first, first + stride, ...
 template <int ACT, bool TRANS, int PRO>
-__global__ __launch_bounds__(256) void k_dense_mfma(
+__device__ __forceinline__ void dense_tiles(
     const float* __restrict__ in, const float* __restrict__ pre_in, const float* __restrict__ w,
     const float* __restrict__ b, const float* res, float* out,
-    float* __restrict__ pre_out, int64_t M, int KC, int NW, int64_t ntasks) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* __restrict__ pre_out, int64_t M, int KC, int NW, int64_t ntasks, int64_t first, int64_t stride) {
+  const int lane = threadIdx.x & 63;
   const int hi = lane >> 5, el = lane & 31;
   const int tcount = (NW + 31) / 32;
   const int nug = (KC + 7) / 8;
   const int nch = (nug + DCH - 1) / DCH;
-  for (int64_t task = blockIdx.x * 4 + wv; task < ntasks; task += (int64_t)gridDim.x * 4) {
+  for (int64_t task = first; task < ntasks; task += stride) {
     const int64_t mt = task / tcount;
     const int t = (int)(task % tcount);
     const int64_t m = mt * 32 + el;
@@ -117,6 +119,28 @@ __global__ __launch_bounds__(256) void k_dense_mfma(
         *(f32x4*)(out + off) = o;
       }
     }
+  }
+}
+
+template <int ACT, bool TRANS, int PRO>
+__global__ __launch_bounds__(256) void k_dense_mfma(
+    const float* __restrict__ in, const float* __restrict__ pre_in, const float* __restrict__ w,
+    const float* __restrict__ b, const float* res, float* out,
+    float* __restrict__ pre_out, int64_t M, int KC, int NW, int64_t ntasks) {
+  dense_tiles<ACT, TRANS, PRO>(in, pre_in, w, b, res, out, pre_out, M, KC, NW, ntasks, blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4);
+}
+
+// Two independent GEMMs of a Dense backward in ONE launch: out = a w (TRANS) or a w^T, and (G, gb) = (U^T X, column sums of U).
+// The first nblk_dense workgroups (8 waves = 8 tile walkers) take the Dense tiles, the rest the (tile, slice) blocks of gemm_tn.
+template <bool TRANS>
+__global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_pair(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out, int64_t M,
+                                                             int KC, int NW, int64_t ntasks, int nblk_dense, GemmTnArgs tn) {
+  if ((int)blockIdx.x < nblk_dense) {
+    dense_tiles<SPK_ACT_NONE, TRANS, SPK_ACT_NONE>(in, nullptr, w, nullptr, nullptr, out, nullptr, M, KC, NW, ntasks,
+                                                   (int64_t)blockIdx.x * TN_WAVES + (threadIdx.x >> 6), (int64_t)nblk_dense * TN_WAVES);
+  } else {
+    const int r = (int)blockIdx.x - nblk_dense;
+    gemm_tn_block(tn, r % tn.n_tiles, r / tn.n_tiles);
   }
 }
 
@@ -265,6 +289,36 @@ extern "C" int spk_dense_bwd_input_f32(const float* dy, const float* pre, const 
   // contraction over the n_out outputs; result width k
   return dense_dispatch(dy, pre, w, nullptr, res, dx, nullptr, m, n_out, k, SPK_ACT_NONE, true, act,
                         (hipStream_t)stream, "spk_dense_bwd_input_f32");
+}
+
+extern "C" int spk_gemm_tn_plan(int64_t n, int32_t O, int32_t K, int32_t* n_slices, int64_t* ws_floats, int32_t* n_tiles);
+// out [m, n_out] = a w^T (trans = 0: a [m, k], w [n_out, k]) or out [m, k] = a w (trans = 1: a [m, n_out], w [n_out, k]),
+// and G [O, K] = U^T X, gb [O] = column sums of U (U [n, O], X [n, K]) -- both in one launch.  Returns SPK_ERR_ARG when the
+// first product does not fit the MFMA tiles (widths that are not multiples of 4): call the two entry points separately then.
+extern "C" int spk_gemm_pair_f32(const float* a, const float* w, int32_t trans, int64_t m, int32_t k, int32_t n_out, float* out, const float* U,
+                                 const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, float* ws, uint32_t* tickets, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int KC = trans ? n_out : k, NW = trans ? k : n_out;
+  SPK_CHECK_ARG(m >= 0 && KC > 0 && NW > 0 && KC % 4 == 0 && NW % 4 == 0, "spk_gemm_pair_f32: widths K=%d N=%d are not multiples of 4", KC, NW);
+  SPK_CHECK_ARG(aligned16(a) && aligned16(w) && aligned16(out), "spk_gemm_pair_f32: 16-byte alignment required");
+  int32_t S, tiles;
+  int64_t wsf;
+  int rc = spk_gemm_tn_plan(n, O, K, &S, &wsf, &tiles);
+  if (rc) return rc;
+  SPK_CHECK_ARG(G != nullptr && (n == 0 || (U && X)) && (m == 0 || (a && w && out)), "spk_gemm_pair_f32: null pointer");
+  SPK_CHECK_ARG(S == 1 || (ws && tickets), "spk_gemm_pair_f32: workspace / ticket buffer required for %d slices", S);
+  SPK_CHECK_ARG(tiles <= 4096, "spk_gemm_pair_f32: %d output tiles (max 4096)", tiles);
+  SpkProfScope prof("gemm_pair", stream);
+  const int64_t ntasks = ((m + 31) / 32) * ((NW + 31) / 32);
+  int64_t nb = (ntasks + TN_WAVES - 1) / TN_WAVES;
+  if (nb > 2 * (int64_t)spk_num_cus()) nb = 2 * (int64_t)spk_num_cus();
+  const int nblk_dense = (int)nb;
+  GemmTnArgs tn = spk_gemm_tn_args(U, X, n, O, K, S, tiles, G, gb, ws, tickets);
+  const unsigned grid = (unsigned)(nblk_dense + tiles * S);
+  if (trans) hipLaunchKernelGGL((k_gemm_pair<true>), dim3(grid), dim3(64 * TN_WAVES), 0, stream, a, w, out, m, KC, NW, ntasks, nblk_dense, tn);
+  else hipLaunchKernelGGL((k_gemm_pair<false>), dim3(grid), dim3(64 * TN_WAVES), 0, stream, a, w, out, m, KC, NW, ntasks, nblk_dense, tn);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
 }
 
 // ---------------------------------------------------------------- Atomwise head (atomistic/atomwise.py:69-88)

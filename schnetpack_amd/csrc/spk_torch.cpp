@@ -943,6 +943,13 @@ struct DenseFn : public torch::autograd::Function<DenseFn> {
     }
     Tensor u = gy;
     if (act != SPK_ACT_NONE) u = gy.defined() ? call_act_mul(gy, pre, act, 1, opt_of(has_gpre ? gpre : Tensor())) : gpre;
+    if (!recorded && ctx->needs_input_grad(0) && (need_w || need_b)) {
+      auto r = call_gemm_pair(u, w, true, u, x);                    // u W and u^T x (+ column sums) in one launch
+      gx = std::get<0>(r);
+      if (need_w) gw = std::get<1>(r);
+      if (need_b) gb = std::get<2>(r);
+      return {gx, gw, gb, Tensor()};
+    }
     if (ctx->needs_input_grad(0)) gx = call_matmul_nn(u, w);
     if (need_w || need_b) {
       auto r = call_matmul_tn(u, x);

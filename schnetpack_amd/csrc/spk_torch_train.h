@@ -47,6 +47,38 @@ std::tuple<Tensor, Tensor> matmul_tn_raw(const Tensor& u_in, const Tensor& x_in)
   return {G, cs};
 }
 
+// out = a w (trans) or a w^T, and (G, cs) = (u^T x, column sums of u): the two independent products of a Dense backward in ONE
+// launch where the shapes allow it (no autograd: used by backward passes that are not themselves recorded)
+std::tuple<Tensor, Tensor, Tensor> gemm_pair_raw(const Tensor& a_in, const Tensor& w_in, bool trans, const Tensor& u_in, const Tensor& x_in) {
+  Tensor a = f32(a_in, "gemm_pair"), w = f32(w_in, "gemm_pair"), u = f32(u_in, "gemm_pair"), x = f32(x_in, "gemm_pair");
+  TORCH_CHECK(w.dim() == 2 && a.size(-1) == (trans ? w.size(0) : w.size(1)), "gemm_pair: a ", a.sizes(), " and weight ", w.sizes(), " do not match");
+  const int64_t n_out = w.size(0), k = w.size(1), KC = trans ? n_out : k, NW = trans ? k : n_out;
+  const int64_t O = u.size(-1), K = x.size(-1), n = O > 0 ? u.numel() / O : 0;
+  const int64_t m = KC > 0 ? a.numel() / KC : 0;
+  if (KC % 4 != 0 || NW % 4 != 0 || m == 0 || n == 0) {
+    Tensor out = trans ? matmul_nn_raw(a, w) : linear_raw(a, w, c10::nullopt);
+    auto r = matmul_tn_raw(u, x);
+    return {out, std::get<0>(r), std::get<1>(r)};
+  }
+  TORCH_CHECK(x.numel() / K == n, "gemm_pair: u ", u.sizes(), " and x ", x.sizes(), " differ in their leading dimensions");
+  c10::DeviceGuard guard(a.device());
+  auto shape = a.sizes().vec();
+  shape.back() = NW;
+  Tensor out = at::empty(shape, a.options()), G = at::empty({O, K}, a.options()), cs = at::empty({O}, a.options());
+  int32_t S = 1, tiles = 0;
+  int64_t wsf = 0;
+  check(spk_gemm_tn_plan(n, (int32_t)O, (int32_t)K, &S, &wsf, &tiles));
+  Tensor ws;
+  if (S > 1) {
+    ws = at::empty({wsf}, a.options());
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (!g_tn_tickets.defined() || g_tn_tickets.device() != a.device()) g_tn_tickets = at::zeros({4096}, a.options().dtype(at::kInt));
+  }
+  check(spk_gemm_pair_f32(fp(a), fp(w), trans ? 1 : 0, m, (int32_t)k, (int32_t)n_out, fpm(out), fp(u), fp(x), n, (int32_t)O, (int32_t)K, fpm(G), fpm(cs),
+                          fpm(ws), S > 1 ? (uint32_t*)g_tn_tickets.data_ptr<int32_t>() : nullptr, stream_of(a)));
+  return {out, G, cs};
+}
+
 bool has(const OptT& t) { return t.has_value() && t->defined(); }
 
 Tensor edge_mul_raw(const Tensor& a_in, const Tensor& b_in, const OptT& ia_in, const OptT& ib_in) {
@@ -218,6 +250,10 @@ std::tuple<Tensor, Tensor> call_matmul_tn(const Tensor& u, const Tensor& x) {
   static auto op = op_handle<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&)>("spk_hip::matmul_tn");
   return op.call(u, x);
 }
+std::tuple<Tensor, Tensor, Tensor> call_gemm_pair(const Tensor& a, const Tensor& w, bool trans, const Tensor& u, const Tensor& x) {
+  static auto op = op_handle<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, bool, const Tensor&, const Tensor&)>("spk_hip::gemm_pair");
+  return op.call(a, w, trans, u, x);
+}
 Tensor call_cfconv(const Tensor& x, const Tensor& W, const OptT& io, const OptT& is, int64_t n_out) {
   static auto op = op_handle<Tensor(const Tensor&, const Tensor&, const OptT&, const OptT&, int64_t)>("spk_hip::cfconv");
   return op.call(x, W, io, is, n_out);
@@ -285,6 +321,13 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     auto sv = ctx->get_saved_variables();
     const bool need_b = ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2);
     Tensor gx, gw, gb;
+    if (!at::GradMode::is_enabled() && ctx->needs_input_grad(0) && (ctx->needs_input_grad(1) || need_b)) {
+      auto r = call_gemm_pair(g[0], sv[1], true, g[0], sv[0]);      // g w and g^T x in one launch
+      gx = std::get<0>(r);
+      gw = std::get<1>(r);
+      if (need_b) gb = std::get<2>(r);
+      return {gx, gw, gb};
+    }
     if (ctx->needs_input_grad(0)) gx = call_matmul_nn(g[0], sv[1]);
     if (ctx->needs_input_grad(1) || need_b) {
       auto r = call_matmul_tn(g[0], sv[0]);
@@ -305,6 +348,10 @@ struct MatmulNNFn : public torch::autograd::Function<MatmulNNFn> {
   static variable_list backward(AutogradContext* ctx, variable_list g) {
     auto sv = ctx->get_saved_variables();
     Tensor gu, gw;
+    if (!at::GradMode::is_enabled() && ctx->needs_input_grad(0) && ctx->needs_input_grad(1)) {
+      auto r = call_gemm_pair(g[0], sv[1], false, sv[0], g[0]);     // g w^T and u^T g in one launch
+      return {std::get<0>(r), std::get<1>(r)};
+    }
     if (ctx->needs_input_grad(0)) gu = call_linear(g[0], sv[1], c10::nullopt);
     if (ctx->needs_input_grad(1)) gw = std::get<0>(call_matmul_tn(sv[0], g[0]));
     return {gu, gw};
@@ -544,6 +591,11 @@ Tensor matmul_nn_meta(const Tensor& u, const Tensor& w) {
   shape.back() = w.size(1);
   return at::empty(shape, u.options());
 }
+std::tuple<Tensor, Tensor, Tensor> gemm_pair_meta(const Tensor& a, const Tensor& w, bool trans, const Tensor& u, const Tensor& x) {
+  auto shape = a.sizes().vec();
+  shape.back() = trans ? w.size(1) : w.size(0);
+  return {at::empty(shape, a.options()), at::empty({u.size(-1), x.size(-1)}, a.options()), at::empty({u.size(-1)}, a.options())};
+}
 std::tuple<Tensor, Tensor> matmul_tn_meta(const Tensor& u, const Tensor& x) {
   return {at::empty({u.size(-1), x.size(-1)}, u.options()), at::empty({u.size(-1)}, u.options())};
 }
@@ -575,13 +627,14 @@ Tensor rowdot_meta(const Tensor& a, const Tensor&) {
 Tensor edge_norm_meta(const Tensor& r) { return at::empty({r.size(0)}, r.options()); }
 
 // ------------------------------------------------------------------------------------------------ registration
-const char* const kTrainOps[] = {"act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm", "vec3"};
+const char* const kTrainOps[] = {"act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm", "vec3", "gemm_pair"};
 
 void train_defs(torch::Library& m) {
   m.def("act_mul(Tensor? a, Tensor z, int act, int order, Tensor? c=None) -> Tensor");                   // a . act^(order)(z) + c
   m.def("linear(Tensor x, Tensor weight, Tensor? bias) -> Tensor");                                       // x W^T + b
   m.def("matmul_nn(Tensor u, Tensor weight) -> Tensor");                                                  // u W
   m.def("matmul_tn(Tensor u, Tensor x) -> (Tensor, Tensor)");                                             // (u^T x, column sums of u)
+  m.def("gemm_pair(Tensor a, Tensor weight, bool trans, Tensor u, Tensor x) -> (Tensor, Tensor, Tensor)");  // raw: (a w | a w^T, u^T x, column sums of u), one launch
   m.def("cfconv(Tensor x, Tensor W, Tensor? idx_out, Tensor? idx_src, int n_out) -> Tensor");             // schnet.py:64-66 (None: identity)
   m.def("edge_mul(Tensor a, Tensor b, Tensor? idx_a, Tensor? idx_b) -> Tensor");                          // Wij * x[idx_j], painn.py:57
   m.def("vec3(int op, Tensor A, Tensor B) -> Tensor");                                                    // 3-vector products of painn.py:60-63, 104-114
@@ -596,6 +649,7 @@ void train_impl_device(torch::Library& m) {
   m.impl("linear", linear_raw);
   m.impl("matmul_nn", matmul_nn_raw);
   m.impl("matmul_tn", matmul_tn_raw);
+  m.impl("gemm_pair", gemm_pair_raw);
   m.impl("cfconv", cfconv_raw);
   m.impl("edge_mul", edge_mul_raw);
   m.impl("vec3", vec3_raw);
@@ -624,6 +678,7 @@ void train_impl_meta(torch::Library& m) {
   m.impl("linear", linear_meta);
   m.impl("matmul_nn", matmul_nn_meta);
   m.impl("matmul_tn", matmul_tn_meta);
+  m.impl("gemm_pair", gemm_pair_meta);
   m.impl("cfconv", cfconv_meta);
   m.impl("edge_mul", edge_mul_meta);
   m.impl("vec3", vec3_meta);

@@ -69,89 +69,8 @@ extern "C" int spk_act_mul_f32(const float* a, const float* z, const float* c, i
 // One workgroup of 8 waves per (32 x 32 tile of G, slice of n): the waves split the slice, meet in LDS, and -- when n needs
 // more than one slice -- the slices meet in a workspace where the LAST workgroup of a tile (ticket counter, self-resetting)
 // adds them in slice order: deterministic, one launch.  Tiles with k0 == 0 also carry the column sums of U (bias gradient).
-#define TN_BATCH 32
-#define TN_WAVES 8
-#define TN_ROWS_PER_BLOCK 512
-__global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_tn(const float* __restrict__ U, const float* __restrict__ X, int64_t n, int O, int K, int tiles_k,
-                                                           int S, int64_t rows_per_slice, int64_t rows_per_wave, float* __restrict__ G,
-                                                           float* __restrict__ gb, float* __restrict__ ws, float* __restrict__ wsb,
-                                                           unsigned* __restrict__ tickets) {
-  __shared__ float red[TN_WAVES][32][33];
-  __shared__ float redb[TN_WAVES][32];
-  __shared__ unsigned s_ticket;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, el = lane & 31;
-  const int tile = blockIdx.x, s = blockIdx.y;
-  const int to = tile / tiles_k, tk = tile % tiles_k;
-  const int o = 32 * to + el, k = 32 * tk + el;
-  const bool o_ok = o < O, k_ok = k < K;
-  const int64_t slice_end = ((s + 1) * rows_per_slice < n) ? (s + 1) * rows_per_slice : n;
-  const int64_t r0 = s * rows_per_slice + wv * rows_per_wave;
-  const int64_t r1 = (r0 + rows_per_wave < slice_end) ? r0 + rows_per_wave : slice_end;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float usum = 0.f;
-  const float* up = U + (o_ok ? o : 0);
-  const float* xp = X + (k_ok ? k : 0);
-  for (int64_t rb = r0; rb < r1; rb += 2 * TN_BATCH) {
-    float av[TN_BATCH], bv[TN_BATCH];
-#pragma unroll
-    for (int q = 0; q < TN_BATCH; ++q) {
-      const int64_t row = rb + 2 * q + hi;
-      const bool ok = row < r1;
-      av[q] = (ok && o_ok) ? up[row * O] : 0.f;
-      bv[q] = (ok && k_ok) ? xp[row * K] : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < TN_BATCH; ++q) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
-      usum += av[q];
-    }
-  }
-  usum += __shfl_xor(usum, 32, 64);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[wv][(r & 3) + 8 * (r >> 2) + 4 * hi][el] = acc[r];
-  if (hi == 0) redb[wv][el] = usum;
-  __syncthreads();
-  // thread t owns outputs (row t / 32 + 16 h, column t % 32), h = 0, 1
-  const int orow = tid >> 5, ocol = tid & 31;
-  float v0 = 0.f, v1 = 0.f, vb = 0.f;
-#pragma unroll
-  for (int w = 0; w < TN_WAVES; ++w) {
-    v0 += red[w][orow][ocol];
-    v1 += red[w][orow + 16][ocol];
-  }
-  if (tid < 32)
-#pragma unroll
-    for (int w = 0; w < TN_WAVES; ++w) vb += redb[w][tid];
-  const int go0 = 32 * to + orow, go1 = go0 + 16, gk = 32 * tk + ocol;
-  const bool want_b = gb != nullptr && tk == 0 && tid < 32;
-  if (S > 1) {
-    float* wt = ws + ((int64_t)s * gridDim.x + tile) * 1024;
-    wt[tid] = v0;
-    wt[tid + 512] = v1;
-    if (want_b) wsb[((int64_t)s * gridDim.x + tile) * 32 + tid] = vb;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_ticket = atomicAdd(&tickets[tile], 1u);
-    __syncthreads();
-    if (s_ticket != (unsigned)(S - 1)) return;
-    __threadfence();
-    if (tid == 0) tickets[tile] = 0u;
-    v0 = 0.f; v1 = 0.f; vb = 0.f;
-    for (int q = 0; q < S; ++q) {
-      const float* wq = ws + ((int64_t)q * gridDim.x + tile) * 1024;
-      v0 += wq[tid];
-      v1 += wq[tid + 512];
-      if (want_b) vb += wsb[((int64_t)q * gridDim.x + tile) * 32 + tid];
-    }
-  }
-  if (gk < K) {
-    if (go0 < O) G[(int64_t)go0 * K + gk] = v0;
-    if (go1 < O) G[(int64_t)go1 * K + gk] = v1;
-  }
-  if (want_b && 32 * to + tid < O) gb[32 * to + tid] = vb;
-}
+#include "spk_gemm_tn.h"
+__global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_tn(GemmTnArgs a) { gemm_tn_block(a, blockIdx.x, blockIdx.y); }
 
 // slices / workspace sizes for a problem (host helper shared with the caller that allocates the workspace)
 extern "C" int spk_gemm_tn_plan(int64_t n, int32_t O, int32_t K, int32_t* n_slices, int64_t* ws_floats, int32_t* n_tiles) {
@@ -180,11 +99,8 @@ extern "C" int spk_gemm_tn_f32(const float* U, const float* X, int64_t n, int32_
   SPK_CHECK_ARG(S == 1 || (ws && tickets), "spk_gemm_tn_f32: workspace / ticket buffer required for %d slices", S);
   SPK_CHECK_ARG(tiles <= 4096, "spk_gemm_tn_f32: %d output tiles (max 4096)", tiles);
   SpkProfScope prof("gemm_tn", stream);
-  int64_t rpw = (n + (int64_t)S * TN_WAVES - 1) / ((int64_t)S * TN_WAVES);
-  rpw += rpw & 1;                                                       // whole MFMA steps per wave
-  if (rpw < 2) rpw = 2;
-  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(64 * TN_WAVES), 0, stream, U, X, n, O, K, (K + 31) / 32, S, rpw * TN_WAVES, rpw, G, gb, ws,
-                     ws ? ws + (int64_t)S * tiles * 1024 : nullptr, (unsigned*)tickets);
+  GemmTnArgs a = spk_gemm_tn_args(U, X, n, O, K, S, tiles, G, gb, ws, tickets);
+  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(64 * TN_WAVES), 0, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -124,6 +124,8 @@ KERNELS = {
     "linear": lambda x, w, b: torch.nn.functional.linear(x, w, b),
     "matmul_nn": lambda u, w: u @ w,
     "matmul_tn": lambda u, x: (u.reshape(-1, u.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), u.reshape(-1, u.shape[-1]).sum(0)),
+    "gemm_pair": lambda a, w, trans, u, x: ((a @ w) if trans else torch.nn.functional.linear(a, w),
+                                            u.reshape(-1, u.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), u.reshape(-1, u.shape[-1]).sum(0)),
     "cfconv": cfconv,
     "edge_mul": edge_mul,
     "vec3": vec3,

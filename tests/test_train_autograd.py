@@ -147,5 +147,6 @@ def test_force_matching_step_matches_the_oracle(kind, radial):
     # the whole step is a few hundred operator calls of the HIP family (SchNet: Dense 5 x 3 + head, each forward / backward /
     # twice-backward = linear, matmul_nn, matmul_tn, act_mul; no torch matmul in between)
     if kind == "schnet":
-        assert sum(calls.values()) <= 220, dict(calls)
-        assert calls["matmul_tn"] >= 30 and calls["cfconv"] >= 12
+        assert sum(calls.values()) <= 190, dict(calls)
+        # weight gradients ride with the input gradient of the same layer in one launch wherever a pass needs both
+        assert calls["gemm_pair"] >= 25 and calls["matmul_tn"] + calls["gemm_pair"] >= 30 and calls["cfconv"] >= 12, dict(calls)
