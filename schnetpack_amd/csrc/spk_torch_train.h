@@ -55,7 +55,9 @@ std::tuple<Tensor, Tensor, Tensor> gemm_pair_raw(const Tensor& a_in, const Tenso
   const int64_t n_out = w.size(0), k = w.size(1), KC = trans ? n_out : k, NW = trans ? k : n_out;
   const int64_t O = u.size(-1), K = x.size(-1), n = O > 0 ? u.numel() / O : 0;
   const int64_t m = KC > 0 ? a.numel() / KC : 0;
-  if (KC % 4 != 0 || NW % 4 != 0 || m == 0 || n == 0) {
+  // (long contractions with few output tiles are better off in the split-K Dense kernel of their own)
+  const bool long_k = KC >= 256 && ((m + 31) / 32) * ((NW + 31) / 32) <= 512;
+  if (KC % 4 != 0 || NW % 4 != 0 || m == 0 || n == 0 || long_k) {
     Tensor out = trans ? matmul_nn_raw(a, w) : linear_raw(a, w, c10::nullopt);
     auto r = matmul_tn_raw(u, x);
     return {out, std::get<0>(r), std::get<1>(r)};
