@@ -22,6 +22,10 @@ echo "== training step (configs[3])"
 for KIND in schnet painn; do
   timeout 600 python bench.py --mode train --kind $KIND --steps 50 --warmup 5 --cpu-reps 5 > $OUT/bench_train_$KIND.json 2> $OUT/bench_train_$KIND.err; echo "rc=$?"; cut -c1-300 $OUT/bench_train_$KIND.json
 done
+echo "== training step at larger per-GPU batches"
+for FR in 32 128; do for KIND in schnet painn; do
+  timeout 600 python bench.py --mode train --kind $KIND --train-frames $FR --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_train_${KIND}_$FR.json 2> $OUT/bench_train_${KIND}_$FR.err; echo "rc=$? $(cut -c1-200 $OUT/bench_train_${KIND}_$FR.json | grep -o '"value": [0-9.]*, "unit": "[a-z/]*"') $(grep -o '"ms_per_step": [0-9.]*' $OUT/bench_train_${KIND}_$FR.json)"
+done; done
 echo "== RPMD NVE (4 beads x 64 aspirin)"; timeout 600 python bench.py --mode md --beads 4 --frames 64 --steps 200 --warmup 10 > $OUT/bench_rpmd_aspirin_schnet.json 2> $OUT/bench_rpmd.err; echo "rc=$?"; cut -c1-250 $OUT/bench_rpmd_aspirin_schnet.json
 for KIND in schnet painn; do
   echo "== rocprof $KIND"
