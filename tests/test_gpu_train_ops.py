@@ -188,3 +188,30 @@ def test_second_derivatives_on_the_device(dev):
     gr = torch.autograd.grad(lr, leaves_r)
     for a, b, name in zip(gh, gr, ("d", "x", "w1", "b1", "w2")):
         assert rel_err(a.cpu(), b) < 2e-5, name
+
+
+def test_training_operators_refuse_malformed_input(dev):
+    """Error behaviour of the operator layer: shape / order mismatches raise RuntimeError (TORCH_CHECK or the C ABI's SPK_ERR_ARG),
+    nothing is computed on a silent fallback."""
+    x, W = rnd(10, 8).to(dev), rnd(30, 8).to(dev)
+    ii = torch.randint(0, 10, (30,), device=dev).sort().values
+    with pytest.raises(RuntimeError, match="index tensors must have"):
+        ops.cfconv(x, W, ii[:-1], ii, 10)
+    with pytest.raises(RuntimeError, match="must be"):
+        ops.cfconv(x, rnd(30, 6).to(dev), ii, ii, 10)
+    with pytest.raises(RuntimeError, match="at least one index"):
+        ops.edge_mul(W, W, None, None)
+    with pytest.raises(RuntimeError, match="order"):
+        ops.act_mul(None, x, 2, 4)                              # silu: derivatives up to the third
+    with pytest.raises(RuntimeError, match="order"):
+        ops.radial_d(x[:, 0].contiguous(), None, 0, torch.linspace(0, 5, 4, device=dev), torch.ones(4, device=dev), 5.0, 4)
+    with pytest.raises(RuntimeError, match="no basis dimension"):
+        ops.radial_c(x, x[:, 0].contiguous(), None, 2, torch.ones(1, device=dev), None, 5.0, 0)
+    with pytest.raises(RuntimeError, match=r"expected a \[\.\.\., 3, F\] operand"):
+        ops.vec3(1, x, x)
+    with pytest.raises(RuntimeError, match="do not match"):
+        ops.gemm_pair(x, rnd(5, 7).to(dev), True, x, x)
+    with pytest.raises(RuntimeError, match="float32"):
+        ops.rowdot(x.double(), x.double())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.vec3(0, torch.zeros(2, 3, 4), torch.zeros(2, 4))
