@@ -398,6 +398,15 @@ int spk_schnet_potential_backward_f32(const spk_schnet_t* m, const spk_head_t* h
                                       const float* gE, const float* gx_out, const float* R, const float* offsets, const int64_t* idx_m,
                                       const float* pre_h, const float* saved, float* gR, float* gx0, void* stream);
 
+/* Energies and FORCES (= -dE/dR of the summed energy) from the same two launches and nothing else.  x0 may be NULL: the rows of
+ * the nuclear embedding table emb [n_types, F] (schnet.py:126-128) are then looked up by Z inside the forward launch.
+ * all_inside != 0: the caller guarantees that the atoms of every molecule lie inside one group of the plan and that every molecule
+ * has an atom; the energies are then stored instead of accumulated (no clearing launch). */
+int spk_schnet_potential_forces_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb,
+                                    const float* x0, const float* emb, const int64_t* Z, int32_t n_types, const float* R,
+                                    const float* offsets, const int64_t* idx_m, int64_t n_mol, int32_t all_inside, float* x_out,
+                                    float* E, float* F, float* pre_h, float* saved, void* stream);
+
 /* Kernel-tuning aid of the molecule-resident SchNet kernels (spk_schnet_mol.hip: block-diagonal lists with <= 32 atoms per
  * block run every interaction inside one workgroup): device buffer (>= 64 int64) receiving cycle stamps of workgroup 0 at
  * the phase boundaries; NULL disables it (default). */

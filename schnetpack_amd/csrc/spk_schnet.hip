@@ -68,10 +68,11 @@ struct MolHeadDev {      // (layout shared with spk_schnet_mol.hip)
   float* E;
   float* pre_h;
   const float* gE;
+  int direct_store, negate;
 };
 int spk_schnet_mol_forward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
                               const float* x0, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head, float* x_out,
-                              float* saved, int64_t gsz, hipStream_t stream);
+                              float* saved, int64_t gsz, hipStream_t stream, const float* emb = nullptr, const int64_t* Z = nullptr, int n_types = 0);
 int spk_schnet_mol_backward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
                                const float* gx_out, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head,
                                const float* saved, int64_t gsz, float* gr, float* gR, float* gx0, hipStream_t stream);
@@ -300,7 +301,7 @@ extern "C" int spk_schnet_potential_forward_f32(const spk_schnet_t* m, const spk
   SPK_CHECK_ARG(x0 && R && idx_m && x_out && pre_h && saved, "%s: null buffer", who);
   MolHeadDev h;
   h.w1 = head->w1; h.w1t = head->w1t; h.b1 = head->b1; h.w2 = head->w2; h.b2 = head->b2; h.H = head->n_hidden; h.act = head->act;
-  h.idx_m = idx_m; h.E = E; h.pre_h = pre_h; h.gE = nullptr;
+  h.idx_m = idx_m; h.E = E; h.pre_h = pre_h; h.gE = nullptr; h.direct_store = 0; h.negate = 0;
   return spk_schnet_mol_forward_ex(m, g, rb, schnet_pack_table(m), x0, nullptr, R, offsets, &h, x_out, saved,
                                    spk_cfconv_gsave_floats(g, rb, m->n_filters), stream);
 }
@@ -316,7 +317,33 @@ extern "C" int spk_schnet_potential_backward_f32(const spk_schnet_t* m, const sp
   SPK_CHECK_ARG(gE && R && idx_m && pre_h && saved && gR, "%s: null buffer", who);
   MolHeadDev h;
   h.w1 = head->w1; h.w1t = head->w1t; h.b1 = head->b1; h.w2 = head->w2; h.b2 = head->b2; h.H = head->n_hidden; h.act = head->act;
-  h.idx_m = idx_m; h.E = nullptr; h.pre_h = const_cast<float*>(pre_h); h.gE = gE;
+  h.idx_m = idx_m; h.E = nullptr; h.pre_h = const_cast<float*>(pre_h); h.gE = gE; h.direct_store = 0; h.negate = 0;
   return spk_schnet_mol_backward_ex(m, g, rb, schnet_pack_table(m), gx_out, nullptr, R, offsets, &h, saved,
                                     spk_cfconv_gsave_floats(g, rb, m->n_filters), nullptr, gR, gx0, stream);
+}
+
+// Energies and FORCES of the standard potential in the two launches, nothing else: x0 may be NULL (the rows of the nuclear
+// embedding table `emb` [n_types, F] are looked up by Z inside the forward launch), dL/dE is 1 (forces of the summed energy), the
+// backward writes -dE/dR.  all_inside != 0: the caller guarantees that every molecule's atoms lie inside ONE group of the plan and
+// that every molecule has an atom -- the energies are then stored, not accumulated, and E needs no clearing launch.
+extern "C" int spk_schnet_potential_forces_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb,
+                                               const float* x0, const float* emb, const int64_t* Z, int32_t n_types, const float* R,
+                                               const float* offsets, const int64_t* idx_m, int64_t n_mol, int32_t all_inside, float* x_out, float* E,
+                                               float* F, float* pre_h, float* saved, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const char* who = "spk_schnet_potential_forces_f32";
+  SPK_TRY(check_model(m, who));
+  SPK_CHECK_ARG(potential_ok(m, head, g, rb), "%s: model / list not covered by the fused potential (see spk_schnet_potential_supported)", who);
+  SPK_CHECK_ARG(n_mol >= 0 && (n_mol == 0 || E), "%s: null energy buffer", who);
+  SPK_CHECK_ARG(x0 || (emb && Z && n_types > 0), "%s: neither features nor an embedding table", who);
+  if (n_mol > 0 && !all_inside) { int zr = spk_zero_async(E, (size_t)n_mol * sizeof(float), stream); if (zr) return zr; }
+  if (g->n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(R && idx_m && x_out && F && pre_h && saved, "%s: null buffer", who);
+  MolHeadDev h;
+  h.w1 = head->w1; h.w1t = head->w1t; h.b1 = head->b1; h.w2 = head->w2; h.b2 = head->b2; h.H = head->n_hidden; h.act = head->act;
+  h.idx_m = idx_m; h.E = E; h.pre_h = pre_h; h.gE = nullptr; h.direct_store = all_inside ? 1 : 0; h.negate = 1;
+  const SpkPackTable ptab = schnet_pack_table(m);
+  const int64_t gsz = spk_cfconv_gsave_floats(g, rb, m->n_filters);
+  SPK_TRY(spk_schnet_mol_forward_ex(m, g, rb, ptab, x0, nullptr, R, offsets, &h, x_out, saved, gsz, stream, x0 ? nullptr : emb, Z, n_types));
+  return spk_schnet_mol_backward_ex(m, g, rb, ptab, nullptr, nullptr, R, offsets, &h, saved, gsz, nullptr, F, nullptr, stream);
 }

@@ -47,15 +47,20 @@ struct MolHeadDev {
   const float* b2;        // [1]
   int H, act;
   const int64_t* idx_m;   // [N]
-  float* E;               // forward: [n_mol], accumulated with one atomic per (group, molecule): cleared by the caller
+  float* E;               // forward: [n_mol], accumulated with one atomic per (group, molecule): cleared by the caller ...
   float* pre_h;           // [N, H] pre-activation of the head's hidden layer (saved for the backward)
-  const float* gE;        // backward: dL/dE [n_mol]
+  const float* gE;        // backward: dL/dE [n_mol]; null = ones (forces of the summed energy)
+  int direct_store;       // ... unless every molecule lies inside one group: plain stores, nothing to clear
+  int negate;             // backward: write -dL/dR (= the forces when gE is ones)
 };
 
 struct MolFwdArgs {
   MolLayerDev L[ML_MAXL];
   int n_layers;
-  const float* x0;          // [N, 128]
+  const float* x0;          // [N, 128], or null: rows of the embedding table
+  const float* emb;         // [n_types, 128] nuclear embedding table (schnet.py:126-128) with
+  const int64_t* Z;         // [N] atomic numbers
+  int n_types;
   float* x_out;             // [N, 128]
   const float* rij;         // [E, 3], or null: r_ij = R[j] - R[i] + offsets
   const float* R;           // [N, 3]
@@ -366,7 +371,13 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
     for (int s = tid; s < 32 * 32; s += 512) {
       const int row = s >> 5, c4 = s & 31;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < na) v = ml_ld<f32x4>(a.x0 + (size_t)a0 * NF, (unsigned)(s * 16));
+      if (row < na) {
+        if (a.x0) v = ml_ld<f32x4>(a.x0 + (size_t)a0 * NF, (unsigned)(s * 16));
+        else {
+          const long long z = a.Z[a0 + row];
+          if (z >= 0 && z < a.n_types) v = *(const f32x4*)(a.emb + (size_t)z * NF + 4 * c4);      // (out of range: zeros, flagged by the plan / caller)
+        }
+      }
       *(f32x4*)(sX + row * ML_LD + 4 * c4) = v;
     }
     const int np = ml_pair_records(sP, nullptr, sScan, a.half, a.rij, a.R, a.offsets, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid);
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           const long long mb = __shfl(my_mol, b, 64);
           if (head_of_run && b >= lane && b < na && mb == my_mol) sum += yb;
         }
-        if (head_of_run) unsafeAtomicAdd(Hd.E + my_mol, sum);
+        if (head_of_run) { if (Hd.direct_store) Hd.E[my_mol] = sum; else unsafeAtomicAdd(Hd.E + my_mol, sum); }
       }
     }
     ML_STAMP(31);
@@ -628,16 +639,17 @@ static int launch_mol_fwd(const MolFwdArgs& a, hipStream_t stream) {
 // `saved` as laid out by spk_schnet_saved_floats_graph(): L x (h | pre3), then L x gsz floats of raw filter outputs.
 int spk_schnet_mol_forward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
                               const float* x0, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head, float* x_out,
-                              float* saved, int64_t gsz, hipStream_t stream);
+                              float* saved, int64_t gsz, hipStream_t stream, const float* emb = nullptr, const int64_t* Z = nullptr, int n_types = 0);
 int spk_schnet_mol_forward(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
                            const float* x0, const float* r_ij, float* x_out, float* saved, int64_t gsz, hipStream_t stream) {
   return spk_schnet_mol_forward_ex(m, g, rb, ptab, x0, r_ij, nullptr, nullptr, nullptr, x_out, saved, gsz, stream);
 }
 int spk_schnet_mol_forward_ex(const spk_schnet_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab,
                               const float* x0, const float* r_ij, const float* R, const float* offsets, const MolHeadDev* head, float* x_out,
-                              float* saved, int64_t gsz, hipStream_t stream) {
+                              float* saved, int64_t gsz, hipStream_t stream, const float* emb, const int64_t* Z, int n_types) {
   MolFwdArgs a;
   a.R = R; a.offsets = offsets;
+  a.emb = emb; a.Z = Z; a.n_types = n_types;
   if (head) a.head = *head; else a.head.w1 = nullptr;
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
@@ -763,7 +775,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           const float pre = Hd.pre_h[(size_t)(a0 + row) * Hd.H + k];
           const float sg = spk_sigmoid(pre);
           const float da = Hd.act == SPK_ACT_SILU ? sg * (1.0f + pre * (1.0f - sg)) : sg;
-          v = Hd.gE[Hd.idx_m[a0 + row]] * Hd.w2[k] * da;
+          v = (Hd.gE ? Hd.gE[Hd.idx_m[a0 + row]] : 1.0f) * Hd.w2[k] * da;
         }
         sGh[row * ML_LD + k] = v;
       }
@@ -1061,7 +1073,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           const float v = sV[3 * rec + comp];
           acc += ((sP[rec].ij & 255) == at) ? -v : v;
         }
-        a.gR[3 * (size_t)(a0 + at) + comp] = acc;
+        a.gR[3 * (size_t)(a0 + at) + comp] = a.head.negate ? -acc : acc;
       }
     }
     ML_STAMP(63);
@@ -1109,7 +1121,7 @@ int spk_schnet_mol_backward_ex(const spk_schnet_t* m, const spk_graph_t* g, cons
                                const float* saved, int64_t gsz, float* gr, float* gR, float* gx0, hipStream_t stream) {
   MolBwdArgs a;
   a.R = R; a.offsets = offsets; a.gR = gR;
-  if (head) a.head = *head; else { a.head.w1 = nullptr; a.head.w1t = nullptr; }
+  if (head) a.head = *head; else { a.head.w1 = nullptr; a.head.w1t = nullptr; a.head.negate = 0; }
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_schnet_layer_t& P = m->layers[l];

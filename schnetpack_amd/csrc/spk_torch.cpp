@@ -96,6 +96,7 @@ struct Plan {
   int64_t n_tiles_grouped = 0;
   int filter_pairs = -1;     // -1: undecided
   bool has_r = false;
+  std::vector<std::pair<std::vector<uint64_t>, bool>> inside;   // per idx_m tensor: every molecule inside one group, none empty
 
   spk_graph_t graph() const {
     spk_graph_t g;
@@ -721,6 +722,29 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> schnet_potential_forward_raw(const Te
   return {std::get<0>(hd), std::get<0>(rep), std::get<1>(rep), std::get<2>(hd)};
 }
 
+// Does every molecule of idx_m lie inside ONE group of the plan, and has every molecule an atom?  (One D2H per (list, idx_m);
+// then the energy head stores its sums instead of accumulating them and the energy buffer needs no clearing launch.)
+bool molecules_inside_groups(Plan& p, const Tensor& idx_m, int64_t n_mol) {
+  std::vector<uint64_t> key{(uint64_t)idx_m.data_ptr(), version_of(idx_m), (uint64_t)idx_m.size(0), (uint64_t)n_mol};
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (auto& e : p.inside)
+      if (e.first == key) return e.second;
+  }
+  bool ok = p.n_groups > 0 && idx_m.size(0) == p.n_atoms && n_mol > 0;
+  if (ok) {
+    Tensor starts = p.grp_atom0.slice(0, 1, p.n_groups).to(at::kLong);                 // first atom of groups 1 .. G-1
+    Tensor split = starts.numel() > 0 ? (idx_m.index_select(0, starts) == idx_m.index_select(0, starts - 1)).any() : at::zeros({}, idx_m.options().dtype(at::kBool));
+    Tensor counts = at::bincount(idx_m.clamp(0, n_mol), {}, n_mol + 1);
+    Tensor good = (~split) & (counts.slice(0, 0, n_mol) > 0).all() & (counts.slice(0, n_mol, n_mol + 1) == 0).all() & (idx_m >= 0).all();
+    ok = good.item<bool>();
+  }
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (p.inside.size() >= 4) p.inside.erase(p.inside.begin());
+  p.inside.emplace_back(key, ok);
+  return ok;
+}
+
 // -> (dL/dR [N, 3], dL/dx0 [N, F] or empty)
 std::tuple<Tensor, Tensor> schnet_potential_backward_raw(const c10::optional<Tensor>& gE_in, const c10::optional<Tensor>& gx_in, const Tensor& x0_in,
                                                          const Tensor& R_in, const c10::optional<Tensor>& offsets_in, const Tensor& idx_i,
@@ -750,6 +774,42 @@ std::tuple<Tensor, Tensor> schnet_potential_backward_raw(const c10::optional<Ten
   auto res = schnet_backward_raw(gxh, r, saved, scratch, *c.plan, ws, F, n_filters, rbf_kind, p0, p1, cutoff, true, want_gx0);
   Tensor gR = pairwise_bwd_raw(std::get<0>(res), idx_i, idx_j, N);
   return {gR, std::get<1>(res).defined() ? std::get<1>(res) : at::empty({0}, R.options())};
+}
+
+// Energies and forces of the standard potential for eval: no autograd node, (E, F = -dE/dR, scalar_representation).  x0 or
+// (embedding table, Z) -- with the table the lookup happens inside the forward launch.
+std::tuple<Tensor, Tensor, Tensor> schnet_potential_forces_raw(const c10::optional<Tensor>& x0_in, const c10::optional<Tensor>& emb_in, const Tensor& Z_in,
+                                                               const Tensor& R_in, const c10::optional<Tensor>& offsets_in, const Tensor& idx_i,
+                                                               const Tensor& idx_j, const Tensor& idx_m_in, int64_t n_mol, at::TensorList ws,
+                                                               at::TensorList head, int64_t n_filters, int64_t rbf_kind, const Tensor& p0,
+                                                               const c10::optional<Tensor>& p1, double cutoff, int64_t head_act) {
+  const bool has_x0 = x0_in.has_value() && x0_in->defined();
+  TORCH_CHECK(has_x0 || (emb_in.has_value() && emb_in->defined()), "schnet_potential_forces: neither features nor an embedding table");
+  Tensor R = f32(R_in.detach(), "schnet_potential_forces");
+  Tensor off = opt_f32(offsets_in, "schnet_potential_forces");
+  Tensor idx_m = i64(idx_m_in, "schnet_potential_forces"), Z = i64(Z_in, "schnet_potential_forces");
+  Tensor x0 = has_x0 ? f32(x0_in->detach(), "schnet_potential_forces") : Tensor();
+  Tensor emb = has_x0 ? Tensor() : f32(emb_in->detach(), "schnet_potential_forces");
+  const int64_t N = R.size(0), F = has_x0 ? x0.size(1) : emb.size(1);
+  c10::DeviceGuard guard(R.device());
+  c10::optional<Tensor> off_d = off.defined() ? c10::optional<Tensor>(off) : c10::optional<Tensor>();
+  PotentialCall c = potential_setup(R, off_d, idx_i, idx_j, N, F, ws, head, n_filters, rbf_kind, p0, p1, cutoff, head_act);
+  if (c.fused) {
+    const bool inside = molecules_inside_groups(*c.plan, idx_m, n_mol);
+    Tensor x = at::empty({N, F}, R.options()), E = at::empty({n_mol}, R.options()), Fo = at::empty({N, 3}, R.options());
+    Tensor pre_h = at::empty({N, (int64_t)c.head.n_hidden}, R.options());
+    Tensor saved = at::empty({std::max<int64_t>(1, spk_schnet_saved_floats_graph(&c.m, &c.g, &c.rb))}, R.options());
+    check(spk_schnet_potential_forces_f32(&c.m, &c.head, &c.g, &c.rb, fp(x0), fp(emb), Z.data_ptr<int64_t>(), emb.defined() ? (int32_t)emb.size(0) : 0, fp(R),
+                                          fp(off), idx_m.data_ptr<int64_t>(), n_mol, inside ? 1 : 0, fpm(x), fpm(E), fpm(Fo), fpm(pre_h), fpm(saved),
+                                          stream_of(R)));
+    return {E, Fo, x};
+  }
+  if (!has_x0) x0 = emb.index_select(0, Z);
+  auto fw = schnet_potential_forward_raw(x0, R, off_d, idx_i, idx_j, idx_m, n_mol, ws, head, n_filters, rbf_kind, p0, p1, cutoff, head_act);
+  Tensor ones = at::ones({n_mol}, R.options());
+  auto bw = schnet_potential_backward_raw(ones, c10::nullopt, x0, R, off_d, idx_i, idx_j, idx_m, n_mol, std::get<2>(fw), std::get<3>(fw), ws, head, n_filters,
+                                          rbf_kind, p0, p1, cutoff, head_act, false);
+  return {std::get<0>(fw), at::neg(std::get<0>(bw)), std::get<1>(fw)};
 }
 
 // ------------------------------------------------------------------------------------------------ dispatcher handles
@@ -1058,6 +1118,23 @@ struct SchnetPotentialFn : public torch::autograd::Function<SchnetPotentialFn> {
   }
 };
 
+// Outputs of the no-autograd eval operators (schnet_potential_forces) pass through this node: no kernel, the value is an alias --
+// but a backward pass that reaches it (parameter gradients of an eval-mode model) raises the eval-only message instead of
+// "does not require grad".
+struct EvalGuardFn : public torch::autograd::Function<EvalGuardFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& y, at::TensorList params) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->saved_data["n"] = (int64_t)params.size();
+    return y.alias();
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list) {
+    TORCH_CHECK(false, "spk_hip::schnet_potential_forces", kEvalOnly);
+    return variable_list((size_t)ctx->saved_data["n"].toInt() + 1);
+  }
+};
+Tensor eval_guard_ad(const Tensor& y, at::TensorList params) { return EvalGuardFn::apply(y, params); }
+Tensor eval_guard_dev(const Tensor& y, at::TensorList) { return y.alias(); }
+
 struct PaiNNFn : public torch::autograd::Function<PaiNNFn> {
   static variable_list forward(AutogradContext* ctx, const Tensor& q0, const Tensor& r_ij, const Tensor& idx_i, const Tensor& idx_j,
                                bool shared_filters, double eps, int64_t rbf_kind, const Tensor& p0, const c10::optional<Tensor>& p1,
@@ -1144,6 +1221,13 @@ std::tuple<Tensor, Tensor> schnet_potential_meta(const Tensor& x0, const Tensor&
                                                  int64_t n_mol, at::TensorList, at::TensorList, int64_t, int64_t, const Tensor&, const c10::optional<Tensor>&,
                                                  double, int64_t) {
   return {at::empty({n_mol}, x0.options()), at::empty_like(x0)};
+}
+std::tuple<Tensor, Tensor, Tensor> schnet_potential_forces_meta(const c10::optional<Tensor>& x0, const c10::optional<Tensor>& emb, const Tensor&, const Tensor& R,
+                                                                const c10::optional<Tensor>&, const Tensor&, const Tensor&, const Tensor&, int64_t n_mol,
+                                                                at::TensorList, at::TensorList, int64_t, int64_t, const Tensor&, const c10::optional<Tensor>&,
+                                                                double, int64_t) {
+  const int64_t F = (x0.has_value() && x0->defined()) ? x0->size(1) : emb->size(1);
+  return {at::empty({n_mol}, R.options()), at::empty_like(R), at::empty({R.size(0), F}, R.options())};
 }
 std::tuple<Tensor, Tensor, Tensor, Tensor> schnet_potential_forward_meta(const Tensor& x0, const Tensor&, const c10::optional<Tensor>&, const Tensor& idx_i,
                                                                          const Tensor&, const Tensor&, int64_t n_mol, at::TensorList ws, at::TensorList head,
@@ -1428,6 +1512,8 @@ TORCH_LIBRARY(spk_hip, m) {
   m.def("atomwise(Tensor x, Tensor w1, Tensor? b1, Tensor w2, Tensor? b2, Tensor idx_m, int n_mol, int act) -> (Tensor, Tensor)");  // atomistic/atomwise.py:69-88
   // PairwiseDistances -> SchNet -> Atomwise(sum): (energy, scalar_representation); two launches where the list allows it
   m.def("schnet_potential(Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor)");
+  m.def("schnet_potential_forces(Tensor? x0, Tensor? embedding, Tensor Z, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor, Tensor)");  // eval: (E, forces, scalar_representation), no autograd
+  m.def("eval_guard(Tensor(a) y, Tensor[] params) -> Tensor(a)");      // alias of y whose backward raises the eval-only message
   m.def("schnet_potential_forward(Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("schnet_potential_backward(Tensor? gE, Tensor? gx, Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor saved, Tensor pre_h, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act, bool want_gx0) -> (Tensor, Tensor)");
   // raw launchers (no autograd): forward returns the tensors its backward consumes
@@ -1466,6 +1552,8 @@ TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm d
   m.impl("atomwise", atomwise_dev);
   m.impl("schnet_potential", schnet_potential_dev);
   m.impl("schnet_potential_forward", schnet_potential_forward_raw);
+  m.impl("schnet_potential_forces", schnet_potential_forces_raw);
+  m.impl("eval_guard", eval_guard_dev);
   m.impl("schnet_potential_backward", schnet_potential_backward_raw);
   m.impl("dense_forward", dense_raw);
   m.impl("dense_backward_input", dense_bwd_input_raw);
@@ -1494,6 +1582,7 @@ TORCH_LIBRARY_IMPL(spk_hip, Autograd, m) {
   m.impl("painn", painn_ad);
   m.impl("atomwise", atomwise_ad);
   m.impl("schnet_potential", schnet_potential_ad);
+  m.impl("eval_guard", eval_guard_ad);
   train_impl_autograd(m);
 }
 
@@ -1501,7 +1590,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CPU, m) {
   for (const char* name : {"scatter_add", "gather", "pairwise", "pairwise_backward", "dense", "radial_cutoff", "schnet", "painn", "atomwise",
                            "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
                            "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare", "static_declare_range", "schnet_potential",
-                           "schnet_potential_forward", "schnet_potential_backward"})
+                           "schnet_potential_forward", "schnet_potential_backward", "schnet_potential_forces"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
   for (const char* name : kTrainOps) m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }
@@ -1527,6 +1616,8 @@ TORCH_LIBRARY_IMPL(spk_hip, Meta, m) {
   m.impl("atomwise_backward", atomwise_backward_meta);
   m.impl("schnet_potential", schnet_potential_meta);
   m.impl("schnet_potential_forward", schnet_potential_forward_meta);
+  m.impl("schnet_potential_forces", schnet_potential_forces_meta);
+  m.impl("eval_guard", eval_guard_dev);
   m.impl("schnet_potential_backward", schnet_potential_backward_meta);
   train_impl_meta(m);
 }

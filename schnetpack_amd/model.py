@@ -26,6 +26,7 @@ class NeuralNetworkPotential(nn.Module):
     required_derivatives: List[str]
     model_outputs: List[str]
     _potential: Final[bool]
+    _potential_forces: Final[bool]
 
     def __init__(self, representation: nn.Module, input_modules: List[nn.Module] = None,
                  output_modules: List[nn.Module] = None):
@@ -45,6 +46,10 @@ class NeuralNetworkPotential(nn.Module):
                     outs.append(k)
         self.model_outputs = outs
         self._potential = self._is_standard_potential()
+        # ... and when the only other output is Forces' -dE/dR, energies AND forces come from the two launches directly
+        outs_l = list(self.output_modules)
+        self._potential_forces = (self._potential and len(outs_l) == 2 and outs_l[1].calc_forces
+                                  and outs_l[1].energy_key == outs_l[0].output_key and outs_l[0].aggregation_mode == "sum")
 
     def _is_standard_potential(self) -> bool:
         rep, ins, outs = self.representation, list(self.input_modules), list(self.output_modules)
@@ -75,10 +80,36 @@ class NeuralNetworkPotential(nn.Module):
         inputs[head.output_key] = E
         return inputs
 
+    @torch.jit.unused
+    def _potential_forces_forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Energies and forces straight from the two launches (no autograd node: eval only; the embedding rows are looked up
+        inside the forward launch when the nuclear embedding is a plain table)."""
+        rep, head, frc = self.representation, self.output_modules[0], self.output_modules[1]
+        idx_m = inputs[properties.idx_m]
+        kind, p0, p1 = rep.radial_basis.kernel_params()
+        l0, l1 = head.outnet[0], head.outnet[1]
+        plain = type(rep.embedding) is nn.Embedding and len(rep.electronic_embeddings) == 0
+        with torch.no_grad():
+            x0 = None if plain else rep.embed(inputs)
+            E, F, x = torch.ops.spk_hip.schnet_potential_forces(
+                x0, rep.embedding.weight if plain else None, inputs[properties.Z], inputs[properties.R], inputs.get(properties.offsets),
+                inputs[properties.idx_i], inputs[properties.idx_j], idx_m, head._n_molecules(inputs, idx_m), rep.interaction_weights(),
+                [l0.weight, l0.bias, l1.weight, l1.bias], rep.n_filters, kind, p0, p1, rep.cutoff_fn.cutoff_value(), head._head_act)
+        if torch.is_grad_enabled():      # a backward pass into this eval-mode model gets the eval-only message, not silence
+            guard = [l0.weight]
+            E, F = torch.ops.spk_hip.eval_guard(E, guard), torch.ops.spk_hip.eval_guard(F, guard)
+        inputs["scalar_representation"] = x
+        inputs[head.output_key] = E
+        inputs[frc.force_key] = F
+        return inputs
+
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         for p in self.required_derivatives:
             if p in inputs:
                 inputs[p].requires_grad_()
+        if self._potential_forces and not self.training and not torch.jit.is_scripting():
+            inputs = self._potential_forces_forward(inputs)
+            return {k: inputs[k] for k in self.model_outputs}
         if self._potential and not self.training and not torch.jit.is_scripting():
             inputs = self._potential_forward(inputs)
             for i, m in enumerate(self.output_modules):

@@ -118,7 +118,9 @@ def test_standard_potential_in_two_launches_equals_the_module_by_module_path(dev
     assert m._potential
     res = {}
     for fused in (True, False):
+        # (the flags are fixed at construction; the aggregation mode was changed after it)
         m._potential = fused
+        m._potential_forces = fused and agg == "sum"       # energies AND forces straight from the two launches
         _lib.profile_enable(True)
         _lib.profile_report()
         try:
@@ -128,11 +130,17 @@ def test_standard_potential_in_two_launches_equals_the_module_by_module_path(dev
             res[fused] = (out["energy"].detach().cpu(), out["forces"].detach().cpu(), inp["scalar_representation"].detach().cpu(), _lib.profile_report())
         finally:
             _lib.profile_enable(False)
-    m._potential = True
+    m._potential, m._potential_forces = True, agg == "sum"
     tags = res[True][3]
     assert "schnet_mol_fwd" in tags and "schnet_mol_bwd" in tags and "atomwise_fwd" not in tags and "atomwise_bwd" not in tags, tags
     assert not any(t.startswith("pairwise") for t in tags), tags
     assert "atomwise_fwd" in res[False][3]
+    if agg == "sum":       # the forces route and the autograd route of the fused operator agree bit for bit
+        m._potential_forces = False
+        inp = M.batch_to_inputs(b, dev)
+        out = m(inp)
+        m._potential_forces = True
+        assert torch.equal(out["forces"].detach().cpu(), res[True][1]) and rel_err(out["energy"].detach().cpu(), res[True][0]) < 1e-6
     for a, c in zip(res[True][:3], res[False][:3]):
         assert rel_err(a, c) < 2e-6
     ref = O.energy_and_forces("schnet", rep, head, b, 3)
@@ -194,3 +202,47 @@ def test_groups_whose_pairs_all_lie_beyond_the_cutoff(dev):
     out5 = m(M.batch_to_inputs(b5, dev))
     assert rel_err(e[0:1], out5["energy"].detach().cpu()[0:1]) < 2e-6
     assert rel_err(f[:21], out5["forces"].detach().cpu()[:21]) < 5e-6
+
+
+def test_energy_store_versus_accumulation_and_custom_embeddings(dev):
+    """schnet_potential_forces: (i) molecules that each lie inside one group get their energies STORED (no clearing launch),
+    a molecule that straddles two groups (two disconnected fragments under one idx_m) takes the accumulate route -- same numbers as
+    the separate modules either way; (ii) the in-launch embedding lookup equals the module's own lookup (x0 path)."""
+    from schnetpack_amd import model as M
+    b = _mixed_batch(11, ["aspirin", "ethanol", "aspirin", "ethanol", "ethanol"])
+    m = M.build_model("schnet").to(dev).eval()
+    assert m._potential_forces
+
+    def run(batch, modular):
+        m._potential, m._potential_forces = (not modular), (not modular)
+        try:
+            out = m(M.batch_to_inputs(batch, dev))
+        finally:
+            m._potential, m._potential_forces = True, True
+        return out["energy"].detach().cpu(), out["forces"].detach().cpu()
+
+    e1, f1 = run(b, False)
+    e0, f0 = run(b, True)
+    assert rel_err(e1, e0) < 2e-6 and rel_err(f1, f0) < 5e-6
+    # merge molecules 1 and 2 under one id (an "ethanol + aspirin" complex of two disconnected fragments: 30 atoms, two groups)
+    b2 = dict(b)
+    idx_m = b["idx_m"].clone()
+    idx_m[idx_m >= 2] -= 1
+    b2["idx_m"], b2["n_mol"] = idx_m, int(b["n_mol"]) - 1
+    e1, f1 = run(b2, False)
+    e0, f0 = run(b2, True)
+    assert e1.shape[0] == 4 and rel_err(e1, e0) < 2e-6 and rel_err(f1, f0) < 5e-6
+    # x0 route: an embedding module that is not a plain table
+    class Shifted(torch.nn.Embedding):
+        def forward(self, z):
+            return super().forward(z) + 0.0
+    emb = Shifted(100, 128).to(dev)
+    emb.load_state_dict(m.representation.embedding.state_dict())
+    plain = m.representation.embedding
+    m.representation.embedding = emb
+    try:
+        e2, f2 = run(b, False)
+    finally:
+        m.representation.embedding = plain
+    e1, f1 = run(b, False)
+    assert torch.equal(e2, e1) and torch.equal(f2, f1)
