@@ -776,6 +776,15 @@ std::tuple<Tensor, Tensor> schnet_potential_backward_raw(const c10::optional<Ten
   return {gR, std::get<1>(res).defined() ? std::get<1>(res) : at::empty({0}, R.options())};
 }
 
+// Warm-up for callers that capture the force call into a HIP graph right after a list change (md.NVESimulation): evaluates the
+// molecule / group relation of an EXISTING plan now, outside the capture (it costs one D2H).  Returns 1 if energies can be stored.
+int64_t potential_plan_op(const Tensor& idx_i, const Tensor& idx_j, int64_t n_atoms, const Tensor& idx_m, int64_t n_mol) {
+  auto plan = find_plan(idx_i, idx_j, n_atoms);
+  if (!plan || plan->n_groups <= 0) return 0;
+  c10::DeviceGuard guard(idx_i.device());
+  return molecules_inside_groups(*plan, i64(idx_m, "potential_plan"), n_mol) ? 1 : 0;
+}
+
 // Energies and forces of the standard potential for eval: no autograd node, (E, F = -dE/dR, scalar_representation).  x0 or
 // (embedding table, Z) -- with the table the lookup happens inside the forward launch.
 std::tuple<Tensor, Tensor, Tensor> schnet_potential_forces_raw(const c10::optional<Tensor>& x0_in, const c10::optional<Tensor>& emb_in, const Tensor& Z_in,
@@ -1513,6 +1522,7 @@ TORCH_LIBRARY(spk_hip, m) {
   // PairwiseDistances -> SchNet -> Atomwise(sum): (energy, scalar_representation); two launches where the list allows it
   m.def("schnet_potential(Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor)");
   m.def("schnet_potential_forces(Tensor? x0, Tensor? embedding, Tensor Z, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor, Tensor)");  // eval: (E, forces, scalar_representation), no autograd
+  m.def("potential_plan(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor idx_m, int n_mol) -> int");
   m.def("eval_guard(Tensor(a) y, Tensor[] params) -> Tensor(a)");      // alias of y whose backward raises the eval-only message
   m.def("schnet_potential_forward(Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("schnet_potential_backward(Tensor? gE, Tensor? gx, Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor saved, Tensor pre_h, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act, bool want_gx0) -> (Tensor, Tensor)");
@@ -1554,6 +1564,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm d
   m.impl("schnet_potential_forward", schnet_potential_forward_raw);
   m.impl("schnet_potential_forces", schnet_potential_forces_raw);
   m.impl("eval_guard", eval_guard_dev);
+  m.impl("potential_plan", potential_plan_op);
   m.impl("schnet_potential_backward", schnet_potential_backward_raw);
   m.impl("dense_forward", dense_raw);
   m.impl("dense_backward_input", dense_bwd_input_raw);
@@ -1590,7 +1601,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CPU, m) {
   for (const char* name : {"scatter_add", "gather", "pairwise", "pairwise_backward", "dense", "radial_cutoff", "schnet", "painn", "atomwise",
                            "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
                            "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare", "static_declare_range", "schnet_potential",
-                           "schnet_potential_forward", "schnet_potential_backward", "schnet_potential_forces"})
+                           "schnet_potential_forward", "schnet_potential_backward", "schnet_potential_forces", "potential_plan"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
   for (const char* name : kTrainOps) m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }

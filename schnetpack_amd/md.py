@@ -366,6 +366,8 @@ class NVESimulation:
             if rep is not None and hasattr(rep, "cutoff_fn") and hasattr(rep.cutoff_fn, "cutoff_value"):
                 cutoff = float(rep.cutoff_fn.cutoff_value())
             torch.ops.spk_hip.edge_plan(ii, jj, int(R.shape[0]), r, cutoff)
+            if getattr(self.model, "_potential_forces", False):      # the energy-store decision of the fused potential: one D2H, now
+                torch.ops.spk_hip.potential_plan(ii, jj, int(R.shape[0]), self.inputs[P.idx_m], self.n_molecules)
 
     def _step_body(self):
         if self._complete:

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_train_ops.py -x -q 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_mol.py tests/test_gpu_models.py tests/test_gpu_md.py tests/test_torch_ops.py -x -q 2>&1 | tail -2
 timeout 600 python bench.py --steps 100 --warmup 10 --no-sweep --no-md --no-pmc --cpu-reps 2 > gpurun_out/t2.json 2> gpurun_out/t2.err; echo rc=$?
 python - <<PY
 import json

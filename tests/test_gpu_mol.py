@@ -135,12 +135,13 @@ def test_standard_potential_in_two_launches_equals_the_module_by_module_path(dev
     assert "schnet_mol_fwd" in tags and "schnet_mol_bwd" in tags and "atomwise_fwd" not in tags and "atomwise_bwd" not in tags, tags
     assert not any(t.startswith("pairwise") for t in tags), tags
     assert "atomwise_fwd" in res[False][3]
-    if agg == "sum":       # the forces route and the autograd route of the fused operator agree bit for bit
+    if agg == "sum":       # the forces route and the autograd route of the fused operator (same kernels; the per-pair sums of the
+        # backward meet in LDS in task order, so two runs agree to rounding, not bit for bit)
         m._potential_forces = False
         inp = M.batch_to_inputs(b, dev)
         out = m(inp)
         m._potential_forces = True
-        assert torch.equal(out["forces"].detach().cpu(), res[True][1]) and rel_err(out["energy"].detach().cpu(), res[True][0]) < 1e-6
+        assert rel_err(out["forces"].detach().cpu(), res[True][1]) < 2e-6 and rel_err(out["energy"].detach().cpu(), res[True][0]) < 1e-6
     for a, c in zip(res[True][:3], res[False][:3]):
         assert rel_err(a, c) < 2e-6
     ref = O.energy_and_forces("schnet", rep, head, b, 3)
@@ -245,4 +246,4 @@ def test_energy_store_versus_accumulation_and_custom_embeddings(dev):
     finally:
         m.representation.embedding = plain
     e1, f1 = run(b, False)
-    assert torch.equal(e2, e1) and torch.equal(f2, f1)
+    assert rel_err(e2, e1) < 1e-6 and rel_err(f2, f1) < 2e-6
