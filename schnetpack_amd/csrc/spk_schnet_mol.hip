@@ -123,14 +123,17 @@ __device__ __forceinline__ void ml_edge_vector(const float* __restrict__ rij, co
 __device__ __forceinline__ int ml_pair_records(MolPair* sP, short* sMap, int* sScan, const int32_t* __restrict__ half, const float* __restrict__ rij,
                                                const float* __restrict__ R, const float* __restrict__ offsets,
                                                const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j, int p0, int np, int a0,
-                                               float cutoff, bool compact, int tid) {
+                                               float cutoff, bool compact, int tid, float* r_keep = nullptr) {
+  // r_keep (3 floats of the caller, or null): the vector of the pair at position `tid` of the list (np <= 512: one pair per thread)
   const int lane = tid & 63, wv = tid >> 6;
   MolPair pr;
   bool keep = false;
+  if (r_keep) { r_keep[0] = 0.f; r_keep[1] = 0.f; r_keep[2] = 0.f; }
   if (tid < np) {
     const int64_t e = half[p0 + tid];
     float rx, ry, rz;
     ml_edge_vector(rij, R, offsets, idx_i, idx_j, e, rx, ry, rz);
+    if (r_keep) { r_keep[0] = rx; r_keep[1] = ry; r_keep[2] = rz; }
     pr.ij = (int)(idx_i[e] - a0) | ((int)(idx_j[e] - a0) << 8) | (tid << 16);
     pr.d = sqrtf(rx * rx + ry * ry + rz * rz);
     spk_cutoff_eval_fast(cutoff, pr.d, pr.fc, pr.dfc);
@@ -786,17 +789,22 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* brow = sGh + el * ML_LD + 4 * hi;
-        for (int c = 0; c < KH; c += 4) {            // H is a multiple of 32: whole chunks of four k-blocks (A = rows of W1^T)
-          f32x4 a4[4];
+        for (int c = 0; c < KH; c += 8) {            // H is a multiple of 32 (KH of 4): chunks of eight k-blocks, masked (A = rows of W1^T)
+          f32x4 a8[8];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) a4[u] = ml_ld<f32x4>(Hd.w1t + (size_t)(32 * t) * Hd.H, (unsigned)((el * Hd.H + 8 * (c + u) + 4 * hi) * 4));
+          for (int u = 0; u < 8; ++u) {
+            a8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c + u < KH) a8[u] = ml_ld<f32x4>(Hd.w1t + (size_t)(32 * t) * Hd.H, (unsigned)((el * Hd.H + 8 * (c + u) + 4 * hi) * 4));
+          }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const f32x4 bv = *(const f32x4*)(brow + 8 * (c + u));
-            acc = ML_MFMA(a4[u].x, bv.x, acc);
-            acc = ML_MFMA(a4[u].y, bv.y, acc);
-            acc = ML_MFMA(a4[u].z, bv.z, acc);
-            acc = ML_MFMA(a4[u].w, bv.w, acc);
+          for (int u = 0; u < 8; ++u) {
+            if (c + u < KH) {
+              const f32x4 bv = *(const f32x4*)(brow + 8 * (c + u));
+              acc = ML_MFMA(a8[u].x, bv.x, acc);
+              acc = ML_MFMA(a8[u].y, bv.y, acc);
+              acc = ML_MFMA(a8[u].z, bv.z, acc);
+              acc = ML_MFMA(a8[u].w, bv.w, acc);
+            }
           }
         }
 #pragma unroll
@@ -808,10 +816,10 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           *(f32x4*)xp = xv;
         }
       }
-      __syncthreads();
-      for (int s = tid; s < 32 * 32; s += 512) *(f32x4*)(sGh + (s >> 5) * ML_LD + 4 * (s & 31)) = f32x4{0.f, 0.f, 0.f, 0.f};
+      // (sGh is rewritten in full by the first Dense phase below: no clearing pass)
     }
-    const int np = ml_pair_records(sP, sMap, sScan, a.half, a.rij, a.R, a.offsets, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid);
+    float pr3[3];             // this thread's pair vector: used again at the very end (dL/dr, dL/dR) without going back to memory
+    const int np = ml_pair_records(sP, sMap, sScan, a.half, a.rij, a.R, a.offsets, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid, pr3);
     const int ntile = (np + 31) / 32;
     // per directed edge: (row of the saved filter tensor << 8 | local neighbour, f_c); edges of dropped pairs point at the
     // first record's row with weight 0 (their own row was never written)
@@ -1038,8 +1046,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     //      contribution (s1 + s2) r / d is parked in LDS for the per-atom pass below (sGh is free by now)
     float* sV = sGh;                                    // [ML_MAXPAIRS][3]
     if (a.gR) __syncthreads();
-    for (int s = tid; s < np_list; s += 512) {
-      const int64_t e = a.half[p0 + s];
+    if (tid < np_list) {                                // one pair per thread (np_list <= ML_MAXPAIRS < 512), its vector still in registers
+      const int s = tid;
       const int rec = sMap[s];
       float s1 = 0.f, s2 = 0.f;
       if (rec >= 0) {
@@ -1047,9 +1055,9 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         const float inv = d > 0.f ? 1.0f / d : 0.f;
         s1 = sS[2 * rec] * inv; s2 = sS[2 * rec + 1] * inv;
       }
-      float rx, ry, rz;
-      ml_edge_vector(a.rij, a.R, a.offsets, a.idx_i, a.idx_j, e, rx, ry, rz);
+      const float rx = pr3[0], ry = pr3[1], rz = pr3[2];
       if (a.gr) {
+        const int64_t e = a.half[p0 + s];
         const int64_t e2 = a.rev[e];
         a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
         a.gr[3 * e2] = -s2 * rx; a.gr[3 * e2 + 1] = -s2 * ry; a.gr[3 * e2 + 2] = -s2 * rz;
