@@ -23,8 +23,18 @@ Tensor matmul_nn_raw(const Tensor& u, const Tensor& w) {
   return dense_bwd_input_raw(u, Tensor(), w, SPK_ACT_NONE);
 }
 
-// ticket counters of the split contraction (zero between launches: the kernel resets them)
-Tensor g_tn_tickets;
+// ticket counters of the split contraction (zero between launches: the kernel resets them).  One buffer per (device, stream):
+// launches on one stream are ordered, launches on different streams must not share counters.
+std::vector<std::pair<std::pair<int64_t, void*>, Tensor>> g_tn_tickets;
+uint32_t* tn_tickets(const Tensor& like) {
+  const std::pair<int64_t, void*> key{(int64_t)like.device().index(), stream_of(like)};
+  std::lock_guard<std::mutex> lock(g_mutex);
+  for (auto& e : g_tn_tickets)
+    if (e.first == key) return (uint32_t*)e.second.data_ptr<int32_t>();
+  if (g_tn_tickets.size() >= 16) g_tn_tickets.erase(g_tn_tickets.begin());
+  g_tn_tickets.emplace_back(key, at::zeros({4096}, like.options().dtype(at::kInt)));
+  return (uint32_t*)g_tn_tickets.back().second.data_ptr<int32_t>();
+}
 std::tuple<Tensor, Tensor> matmul_tn_raw(const Tensor& u_in, const Tensor& x_in) {
   Tensor u = f32(u_in, "matmul_tn"), x = f32(x_in, "matmul_tn");
   const int64_t O = u.size(-1), K = x.size(-1);
@@ -37,13 +47,8 @@ std::tuple<Tensor, Tensor> matmul_tn_raw(const Tensor& u_in, const Tensor& x_in)
   int64_t wsf = 0;
   check(spk_gemm_tn_plan(n, (int32_t)O, (int32_t)K, &S, &wsf, &tiles));
   Tensor ws;
-  if (S > 1) {
-    ws = at::empty({wsf}, u.options());
-    std::lock_guard<std::mutex> lock(g_mutex);
-    if (!g_tn_tickets.defined() || g_tn_tickets.device() != u.device()) g_tn_tickets = at::zeros({4096}, u.options().dtype(at::kInt));
-  }
-  check(spk_gemm_tn_f32(fp(u), fp(x), n, (int32_t)O, (int32_t)K, fpm(G), fpm(cs), fpm(ws), S > 1 ? (uint32_t*)g_tn_tickets.data_ptr<int32_t>() : nullptr,
-                        stream_of(u)));
+  if (S > 1) ws = at::empty({wsf}, u.options());
+  check(spk_gemm_tn_f32(fp(u), fp(x), n, (int32_t)O, (int32_t)K, fpm(G), fpm(cs), fpm(ws), S > 1 ? tn_tickets(u) : nullptr, stream_of(u)));
   return {G, cs};
 }
 
@@ -71,13 +76,9 @@ std::tuple<Tensor, Tensor, Tensor> gemm_pair_raw(const Tensor& a_in, const Tenso
   int64_t wsf = 0;
   check(spk_gemm_tn_plan(n, (int32_t)O, (int32_t)K, &S, &wsf, &tiles));
   Tensor ws;
-  if (S > 1) {
-    ws = at::empty({wsf}, a.options());
-    std::lock_guard<std::mutex> lock(g_mutex);
-    if (!g_tn_tickets.defined() || g_tn_tickets.device() != a.device()) g_tn_tickets = at::zeros({4096}, a.options().dtype(at::kInt));
-  }
+  if (S > 1) ws = at::empty({wsf}, a.options());
   check(spk_gemm_pair_f32(fp(a), fp(w), trans ? 1 : 0, m, (int32_t)k, (int32_t)n_out, fpm(out), fp(u), fp(x), n, (int32_t)O, (int32_t)K, fpm(G), fpm(cs),
-                          fpm(ws), S > 1 ? (uint32_t*)g_tn_tickets.data_ptr<int32_t>() : nullptr, stream_of(a)));
+                          fpm(ws), S > 1 ? tn_tickets(a) : nullptr, stream_of(a)));
   return {out, G, cs};
 }
 
