@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0          # same guide, HBM3E spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kind", default="schnet", choices=["schnet", "painn"])
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--workload", default="aspirin", choices=["aspirin", "water"],
