@@ -445,6 +445,19 @@ def main():
     kernels = {}
     for tag, (cnt, ms) in prof.items():
         kernels[tag] = {"launches_per_step": cnt / psteps, "avg_us": 1e3 * ms / max(cnt, 1), "us_per_step": 1e3 * ms / psteps}
+    # every kernel with an algorithmic-work model also carries its own fraction of the peak (the N-sized PaiNN kernels: SURVEY.md
+    # section 8(d): mixing N * 360 kFLOP per interaction forward, 2x backward -- the backward launch leaves the channel-mix
+    # transpose to a chain launch, so its own share is the two transposed context layers + the products: N * 2 * 2 (2F F + F 3F))
+    mix_flop = N * 2.0 * (3 * F * 2 * F + 2 * F * F + F * 3 * F)
+    algo_n = {"painn_mixing_fwd": mix_flop, "painn_mixing_bwd": N * 4.0 * (2 * F * F + F * 3 * F)}
+    for tag, kd in kernels.items():
+        if tag in algo:
+            bound, work, _ = algo[tag]
+            kd["frac_of_peak"] = round(work / (kd["avg_us"] * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12 if bound == "mfma" else HBM_PEAK_GBS * 1e9), 4)
+            kd["bound"] = bound
+        elif tag in algo_n:
+            kd["frac_of_peak"] = round(algo_n[tag] / (kd["avg_us"] * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
+            kd["bound"] = "mfma"
     cand = [t for t in kernels if t in algo]
     roofline = None
     if cand:

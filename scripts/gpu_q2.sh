@@ -1,5 +1,17 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_ops.py tests/test_gpu_models.py -x -q -k "train or matmul or gemm" 2>&1 | grep -v Warning | tail -4
-for KIND in schnet painn; do timeout 600 python bench.py --mode train --kind $KIND --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo; done
+mkdir -p gpurun_out/r02k
+timeout 900 python bench.py --kind painn --steps 100 --warmup 10 > gpurun_out/r02k/bench_painn.json 2> gpurun_out/r02k/bench_painn.err; echo rc=$?
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r02k/bench_painn.json"))
+print(d["value"], d["ms_per_step"])
+print({a:(round(v["avg_us"],1), v.get("frac_of_peak"), v.get("bound")) for a,v in d["kernels"].items()})
+PY
+timeout 900 python bench.py --steps 100 --warmup 10 > gpurun_out/r02k/bench_schnet.json 2> gpurun_out/r02k/bench_schnet.err; echo rc=$?
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r02k/bench_schnet.json"))
+print(d["value"], d["ms_per_step"], {a:(round(v["avg_us"],1), v.get("frac_of_peak")) for a,v in d["kernels"].items()})
+PY
