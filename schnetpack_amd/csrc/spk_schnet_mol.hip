@@ -1071,17 +1071,22 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     //      there): the pair (i, j) with canonical vector r gives -(s1 + s2) r / d to i and +(s1 + s2) r / d to j.  Fixed order.
     if (a.gR) {
       __syncthreads();
-      for (int s = tid; s < 3 * na; s += 512) {
+      // eight lanes per (atom, component): they walk the row's edges with stride 8 and meet by shuffles (fixed order)
+      const int slot = tid & 7, q = tid >> 3;          // q < 64 >= 3 * na / ... : na <= 21 atoms fill 63 of the 64 groups; larger groups loop
+      for (int s = q; s < 3 * na; s += 64) {
         const int at = s / 3, comp = s - 3 * at;
         float acc = 0.f;
-        for (int e = sRow[at]; e < sRow[at + 1]; ++e) {
+        for (int e = sRow[at] + slot; e < sRow[at + 1]; e += 8) {
           const int x = sEb[e].x;
           if (x & (1 << 24)) continue;
           const int rec = sMap[(x >> 8) & 0xFFFF];
           const float v = sV[3 * rec + comp];
           acc += ((sP[rec].ij & 255) == at) ? -v : v;
         }
-        a.gR[3 * (size_t)(a0 + at) + comp] = a.head.negate ? -acc : acc;
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (slot == 0) a.gR[3 * (size_t)(a0 + at) + comp] = a.head.negate ? -acc : acc;
       }
     }
     ML_STAMP(63);
