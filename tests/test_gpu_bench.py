@@ -43,6 +43,7 @@ def test_default_line_has_both_halves_of_the_metric():
     assert cpu["kind"] in ("reference", "port") and cpu["value"] > 0 and cpu["parity_rel_forces"] < 1e-5
     md = line["md"]
     assert md["aspirin"]["ns_per_day"] > 0 and md["water"]["ns_per_day"] > 0 and md["aspirin"]["trajectories"] == 256
+    assert any("frac_of_peak" in v for v in line["kernels"].values())      # every modelled kernel carries its own roofline fraction
     rows = line["sweep"]["rows"]
     assert [r["k"] for r in rows if r["list"] == "symmetric"] == [16, 32, 64]
     assert all(r["M_edge_messages_per_s"] > 0 and r["E"] == r["N"] * r["k"] for r in rows)
