@@ -156,57 +156,6 @@ __device__ __forceinline__ int ml_pair_records(MolPair* sP, short* sMap, int* sS
   return total;
 }
 
-// y[at][c] = sum over the directed edges of the row of `at`:  sSrc[neighbour][c] * g[pair][c] * f_c(pair)
-// for the atoms at0, at0 + 4, at0 + 8, ... of one (channel, atom quarter) thread: THREE rows per round, up to RB loads of the
-// filter tensor in flight per row (one L2 round trip per round; rows of a molecule rarely exceed RB neighbours).  Branch-free:
-// entries beyond the end of a row re-read its last entry with weight 0, so the record reads and the loads issue back to back.
-// sEb: per directed edge (row of the saved filter tensor << 8 | local neighbour [| 1 << 24: pair beyond the cutoff], f_c of the pair).
-template <int RB>
-__device__ __forceinline__ void ml_row_sums(float* __restrict__ sDst, const float* __restrict__ sSrc, const float* __restrict__ g_g,
-                                            const int2* __restrict__ sEb, const int* __restrict__ sRow, int na, int at0, int c) {
-  for (int at = at0; at < na; at += 12) {
-    int rs[3], re[3];
-    float acc[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int am = at + 4 * m;
-      rs[m] = am < na ? sRow[am] : 0;
-      re[m] = am < na ? sRow[am + 1] : 0;
-      acc[m] = 0.f;
-    }
-    while (true) {
-      int2 rec[3][RB];
-      float gv[3][RB];
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-          const int last = re[m] > 0 ? re[m] - 1 : 0;
-          const int idx = rs[m] + u < re[m] ? rs[m] + u : last;
-          rec[m][u] = sEb[idx];
-          if (rs[m] + u >= re[m]) rec[m][u].y = 0;          // weight 0 beyond the row
-        }
-      // 32-bit element offsets from one base (a group's filter block is < 2^31 floats): one VGPR per address
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int u = 0; u < RB; ++u) gv[m][u] = g_g[(unsigned)((rec[m][u].x >> 8) & 0xFFFF) * 128u + (unsigned)c];
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int u = 0; u < RB; ++u)
-          acc[m] = fmaf(sSrc[(rec[m][u].x & 255) * ML_LD + c] * __int_as_float(rec[m][u].y), gv[m][u], acc[m]);
-      bool more = false;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) { rs[m] += RB; more = more || (rs[m] < re[m]); }
-      if (!more) break;
-    }
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-      if (at + 4 * m < na) sDst[(at + 4 * m) * ML_LD + c] = acc[m];
-  }
-}
-
 // register r of the half hi of a 32x32 accumulator holds row (r & 3) + 8 (r >> 2) + 4 hi
 __device__ __forceinline__ int ml_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -258,6 +207,52 @@ template <class T>
 __device__ __forceinline__ T ml_ld(const void* sbase, unsigned voff) { return *(const T*)((const char*)sbase + voff); }
 template <class T>
 __device__ __forceinline__ void ml_st(void* sbase, unsigned voff, T v) { *(T*)((char*)sbase + voff) = v; }
+
+// gh[at][c] = sum over the directed edges of the row of `at`:  sSrc[neighbour][c] * g[pair][c] * f_c(pair)   (the transpose of
+// the forward's row sum), as a task of one wavefront per atom.
+// sEb: per directed edge (row of the saved filter tensor << 8 | local neighbour [| 1 << 24: pair beyond the cutoff], f_c of the pair).
+// A lane owns FOUR channels (16-byte loads: 32 lanes span the 128 channels, a wave-load moves two whole filter rows) and the two
+// halves of the wavefront take the even / odd entries of a row, meeting through one shuffle at the end.  RB entries per half are
+// in flight at once, so a row of <= 2 RB neighbours costs ONE round trip to the saved filters (which the forward
+// left in L2 / Infinity Cache).  Branch-free: entries beyond the end of a row re-read its last entry with weight 0.  Fixed
+// summation order.  (The first form -- a lane per channel, 4-byte loads, four dependent round trips per task -- made the
+// row-sum waves the stragglers of phase E: 18 k of its 79 k cycles.)
+template <int RB>
+__device__ __forceinline__ void ml_row_sums4(float* __restrict__ sDst, const float* __restrict__ sSrc, const float* __restrict__ g_g,
+                                             const int2* __restrict__ sEb, const int* __restrict__ sRow, int at, int lane) {
+  const int hi = lane >> 5;
+  const unsigned c4 = 4u * (unsigned)(lane & 31);
+  int rs = sRow[at] + hi;
+  const int re = sRow[at + 1];
+  const int last = re > 0 ? re - 1 : 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  while (true) {
+    int2 rec[RB];
+    f32x4 gv[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int idx = rs + 2 * u;
+      rec[u] = sEb[idx < re ? idx : last];
+      if (idx >= re) rec[u].y = 0;                 // weight 0 beyond the row
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) gv[u] = ml_ld<f32x4>(g_g, ((unsigned)((rec[u].x >> 8) & 0xFFFF) * 128u + c4) * 4u);
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const f32x4 sv = *(const f32x4*)(sSrc + (rec[u].x & 255) * ML_LD + c4);
+      const float w = __int_as_float(rec[u].y);
+      acc.x = fmaf(sv.x * w, gv[u].x, acc.x);
+      acc.y = fmaf(sv.y * w, gv[u].y, acc.y);
+      acc.z = fmaf(sv.z * w, gv[u].z, acc.z);
+      acc.w = fmaf(sv.w * w, gv[u].w, acc.w);
+    }
+    rs += 2 * RB;
+    if (rs - hi >= re) break;                      // (wave-uniform: both halves leave together)
+  }
+  acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+  acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+  if (hi == 0) *(f32x4*)(sDst + at * ML_LD + c4) = acc;
+}
 
 // (the weights do not depend on the data: ml_dense_load() is issued a phase EARLY -- before the barrier that completes the
 // activations -- so that a Dense phase pays no L2 round trip)
@@ -750,6 +745,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     sRb[tid] = (src && k < a.rb.n_rbf) ? src[k] : 1.0f;
   }
 
+  if (a.dbg && tid == 0) { a.dbg[128 + 4 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime(); a.dbg[130 + 4 * blockIdx.x] = (long long)__builtin_readcyclecounter(); }
   for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
     const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
     const int p0 = a.grp_pair0[grp], np_list = a.grp_pair0[grp + 1] - p0;
@@ -757,20 +753,25 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     const int Ltop = a.n_layers - 1;
     __syncthreads();
 
-    // ---- group set-up
+    // ---- group set-up.  Everything here is short and latency-bound, so the independent pieces share their round trips and
+    //      barriers: the head's hidden gradient is filled while the pair records are loaded (the first barrier inside
+    //      ml_pair_records() publishes both), the head GEMM (waves 0-3) runs beside the per-edge records (waves 4-7), and the
+    //      filter weights of the top interaction are staged by the idle half of the two Dense phases below -- the derivative tasks
+    //      of phase E are their first reader.
+    const bool with_head = a.head.w1t != nullptr;
     for (int s = tid; s < 32 * 32; s += 512) {
       const int row = s >> 5, c4 = s & 31;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < na && a.gx_out) v = ml_ld<f32x4>(a.gx_out + (size_t)a0 * NF, (unsigned)(s * 16));
       *(f32x4*)(sGx + row * ML_LD + 4 * c4) = v;
-      *(f32x4*)(sGh + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
       *(f32x4*)(sH + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!with_head) *(f32x4*)(sGh + row * ML_LD + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (a.head.w1t) {
-      // ---- dL/dx_L through the energy head: gx += (gE[mol] w2 . act'(pre_h)) W1
+    ML_STAMP(120);
+    if (with_head) {
+      // ---- dL/dx_L through the energy head, part 1: the hidden gradient gE[mol] w2 . act'(pre_h) -> sGh[:, :H]
+      //      (the columns beyond H are not read by part 2, and the first Dense phase rewrites sGh in full)
       const MolHeadDev& Hd = a.head;
-      const int KH = Hd.H / 8;
-      __syncthreads();
       for (int s = tid; s < 32 * Hd.H; s += 512) {
         const int row = s / Hd.H, k = s - row * Hd.H;
         float v = 0.f;
@@ -782,8 +783,16 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         }
         sGh[row * ML_LD + k] = v;
       }
-      __syncthreads();
-      if (wv < NT) {
+    }
+    float pr3[3];             // this thread's pair vector: used again at the very end (dL/dr, dL/dR) without going back to memory
+    const int np = ml_pair_records(sP, sMap, sScan, a.half, a.rij, a.R, a.offsets, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid, pr3);
+    const int ntile = (np + 31) / 32;
+    ML_STAMP(123);
+    if (wv < NT) {
+      if (with_head) {
+        // ---- part 2: gx += hidden gradient x W1
+        const MolHeadDev& Hd = a.head;
+        const int KH = Hd.H / 8;
         const int t = wv;
         f32x16 acc;
 #pragma unroll
@@ -816,25 +825,20 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           *(f32x4*)xp = xv;
         }
       }
-      // (sGh is rewritten in full by the first Dense phase below: no clearing pass)
+    } else {
+      // per directed edge: (row of the saved filter tensor << 8 | local neighbour, f_c); edges of dropped pairs point at the
+      // first record's row with weight 0 (their own row was never written)
+      const int t2 = tid - 256;
+      const int row0 = np > 0 ? (sP[0].ij >> 16) : 0;
+      for (int s = t2; s < ne; s += 256) {
+        const int pos = ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0;
+        const int rec = sMap[pos];
+        const int nb = (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0);
+        sEb[s] = rec >= 0 ? make_int2((pos << 8) | nb, __float_as_int(sP[rec].fc)) : make_int2((row0 << 8) | nb | (1 << 24), 0);
+      }
+      for (int s = t2; s < 2 * np; s += 256) sS[s] = 0.f;
+      if (t2 <= na) sRow[t2] = a.rowptr[a0 + t2] - e0;
     }
-    float pr3[3];             // this thread's pair vector: used again at the very end (dL/dr, dL/dR) without going back to memory
-    const int np = ml_pair_records(sP, sMap, sScan, a.half, a.rij, a.R, a.offsets, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid, pr3);
-    const int ntile = (np + 31) / 32;
-    // per directed edge: (row of the saved filter tensor << 8 | local neighbour, f_c); edges of dropped pairs point at the
-    // first record's row with weight 0 (their own row was never written)
-    const int row0 = np > 0 ? (sP[0].ij >> 16) : 0;
-    for (int s = tid; s < ne; s += 512) {
-      const int pos = ml_ld<int>(a.edge_pair + e0, (unsigned)s * 4u) - p0;
-      const int rec = sMap[pos];
-      const int nb = (int)(ml_ld<long long>(a.idx_j + e0, (unsigned)s * 8u) - a0);
-      sEb[s] = rec >= 0 ? make_int2((pos << 8) | nb, __float_as_int(sP[rec].fc)) : make_int2((row0 << 8) | nb | (1 << 24), 0);
-    }
-    for (int s = tid; s < 2 * np; s += 512) sS[s] = 0.f;
-    if (tid <= na) sRow[tid] = a.rowptr[a0 + tid] - e0;
-    ml_stage_packed<512, NF * NF / 4>(sW2, a.L[Ltop].w2, NF, KB2, tid);
-    ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[Ltop].w1, a.rb.n_rbf, KPB, tid);
-    if (tid < NF) sb1[tid] = a.L[Ltop].b1[tid];
     __syncthreads();
     ML_STAMP(32);
 
@@ -845,7 +849,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       const float* g_g = a.gbase + (int64_t)l * a.gsz + (int64_t)p0 * NF;
       const bool last = (l == 0) && !a.gx0;     // nothing below consumes dL/dh_0: no row sums, no in2f transpose
 
-      // ================= D1: gt = (gx W4) * ssp'(pre3);  the other half loads h_l
+      // ================= D1: gt = (gx W4) * ssp'(pre3);  the other half stages W2 of this interaction's filter network
       if (wv < NT) {
         const int t = wv;
         f32x4 avA[8], avB[8];
@@ -867,17 +871,14 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           *(f32x4*)(sGh + el * ML_LD + 32 * t + 8 * q + 4 * hi) =
               f32x4{acc[4 * q] * spk_sigmoid(pv[q].x), acc[4 * q + 1] * spk_sigmoid(pv[q].y), acc[4 * q + 2] * spk_sigmoid(pv[q].z), acc[4 * q + 3] * spk_sigmoid(pv[q].w)};
       } else {
-        const int t2 = tid - 256;
-        for (int s = t2; s < na * 32; s += 256) {
-          const int row = s >> 5, c4 = s & 31;
-          *(f32x4*)(sH + row * ML_LD + 4 * c4) = ml_ld<f32x4>(h_g + (size_t)a0 * NF, (unsigned)(s * 16));
-        }
+        // (sW2 was last read by the derivative tasks of the interaction above: two barriers ago)
+        ml_stage_packed<256, NF * NF / 4>(sW2, P.w2, NF, KB2, tid - 256);
       }
       if (tid == 0) sCnt[0] = 0;
       __syncthreads();
       ML_STAMP(33 + 6 * (Ltop - l));
 
-      // ================= D2: gy = gt W3
+      // ================= D2: gy = gt W3;  the other half loads h_l and stages W1, b1
       if (wv < NT) {
         const int t = wv;
         f32x4 avA[8], avB[8];
@@ -891,13 +892,21 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(sGy + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+      } else {
+        const int t2 = tid - 256;
+        for (int s = t2; s < na * 32; s += 256) {
+          const int row = s >> 5, c4 = s & 31;
+          *(f32x4*)(sH + row * ML_LD + 4 * c4) = ml_ld<f32x4>(h_g + (size_t)a0 * NF, (unsigned)(s * 16));
+        }
+        ml_stage_packed<256, NF * KPB * 2>(sW1, P.w1, a.rb.n_rbf, KPB, t2);
+        if (t2 < NF) sb1[t2] = P.b1[t2];
       }
       __syncthreads();
       ML_STAMP(34 + 6 * (Ltop - l));
 
-      // ================= E: derivative tasks (pair tile, pair of channel tiles) + row-sum tasks (atom quarter, channel half)
+      // ================= E: derivative tasks (pair tile, pair of channel tiles) + row-sum tasks (one atom, all channels)
       const int nder = 2 * ntile;
-      const int nrow = (last || np == 0) ? 0 : 8;
+      const int nrow = (last || np == 0) ? 0 : na;
       if (np == 0 && !last)      // no pair inside the cutoff: dL/dh = 0 (the buffer still holds the hidden gradient of f2out)
         for (int s = tid; s < 32 * 32; s += 512) *(f32x4*)(sGh + (s >> 5) * ML_LD + 4 * (s & 31)) = f32x4{0.f, 0.f, 0.f, 0.f};
       while (true) {
@@ -907,8 +916,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         if (k >= nder + nrow) break;
         if (k >= nder) {
           // ---- gh[a][c] = sum over the row of a of gy[b][c] g[pair][c] f_c
-          const int k2 = k - nder;
-          ml_row_sums<12>(sGh, sGy, g_g, sEb, sRow, na, k2 >> 1, 64 * (k2 & 1) + lane);
+          ml_row_sums4<10>(sGh, sGy, g_g, sEb, sRow, k - nder, lane);
           continue;
         }
         const int tile = k >> 1, tp = k & 1;
@@ -1012,7 +1020,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       ML_STAMP(36 + 6 * (Ltop - l));
       if (last) break;
 
-      // ================= G: gx += gh W_in; the other half stages the filter weights of the next (lower) interaction
+      // ================= G: gx += gh W_in
       if (wv < NT) {
         const int t = wv;
         f32x4 avA[8], avB[8];
@@ -1032,11 +1040,6 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           *(f32x4*)xp = xv;
           if (l == 0 && el < na) ml_st<f32x4>(a.gx0 + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4), xv);
         }
-      } else if (l > 0) {
-        const int t2 = tid - 256;
-        ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l - 1].w2, NF, KB2, t2);
-        ml_stage_packed<256, NF * KPB * 2>(sW1, a.L[l - 1].w1, a.rb.n_rbf, KPB, t2);
-        if (t2 < NF) sb1[t2] = a.L[l - 1].b1[t2];
       }
       __syncthreads();
       ML_STAMP(37 + 6 * (Ltop - l));
@@ -1091,6 +1094,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
     }
     ML_STAMP(63);
   }
+  if (a.dbg && tid == 0) { a.dbg[129 + 4 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime(); a.dbg[131 + 4 * blockIdx.x] = (long long)__builtin_readcyclecounter(); }
 }
 
 static size_t mol_bwd_lds(int kpb) {

@@ -9,7 +9,7 @@ torch.manual_seed(0)
 m = M.build_model("schnet").to(dev).eval()
 inp = M.batch_to_inputs(b, dev)
 L = _lib.lib()
-dbg = torch.zeros(128, dtype=torch.int64, device=dev)
+dbg = torch.zeros(128 + 4 * 1024, dtype=torch.int64, device=dev)
 for rep in range(3):
     dbg.zero_()
     L.spk_schnet_mol_set_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
@@ -27,6 +27,19 @@ for base in (0, 32):
     for k in sorted(names):
         if k >= base and k < base + 32 and st[k]:
             print("  %-36s %8d  (+%d)" % (names[k], st[k] - st[base], st[k] - prev)); prev = st[k]
+import numpy as np
+print("fwd L0 phase A iteration stamps (cycles from L0 staged):", [st[k] - st[1] for k in range(100, 110) if st[k]])
+print("bwd set-up of block 0 (cycles from the first instruction):", {k: st[k] - st[130] for k in (120, 121, 122, 123, 124, 32) if st[k]})
+blk = np.array(st[128:128 + 4 * 256]).reshape(256, 4)
+t0 = blk[:, 0].min()
+print("bwd blocks (100 MHz real time, us): start min/max %.2f %.2f   end min/median/max %.2f %.2f %.2f" % (
+    (blk[:, 0].min() - t0) / 100, (blk[:, 0].max() - t0) / 100, (blk[:, 1].min() - t0) / 100, np.median(blk[:, 1] - t0) / 100, (blk[:, 1].max() - t0) / 100))
+cyc = blk[:, 3] - blk[:, 2]
+dur = (blk[:, 1] - blk[:, 0]) / 100.0
+print("bwd per-block cycles min/median/max %d %d %d; duration us min/median/max %.1f %.1f %.1f; clock GHz median %.3f" % (
+    cyc.min(), np.median(cyc), cyc.max(), dur.min(), np.median(dur), dur.max(), np.median(cyc / dur) / 1e3))
+slow = np.argsort(-blk[:, 1])[:8]
+print("latest blocks:", [(int(b), round((blk[b, 0] - t0) / 100, 1), round((blk[b, 1] - t0) / 100, 1), int(cyc[b])) for b in slow])
 sub = {64: "task start", 65: "rbf done", 66: "gemm1 + act done", 67: "gemm2 done", 68: "stores issued"}
 print("first filter task of wave 0:")
 prev = st[64]
