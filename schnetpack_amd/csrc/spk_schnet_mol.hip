@@ -681,13 +681,13 @@ int spk_schnet_mol_forward_ex(const spk_schnet_t* m, const spk_graph_t* g, const
 //
 // Per interaction, last to first (notation of SURVEY.md Appendix B; everything below is local to the group):
 //   D1. gt = (gx W4) * ssp'(pre3)          D2. gy = gt W3                                (two T-GEMM phases)
-//   E.  task queue:  (pair tile, channel-tile pair) derivative tasks  +  row-sum tasks
+//   E.  task queue:  (pair tile, channel-tile pair) derivative tasks  +  row-sum tasks  +  the four tiles of G
 //         derivative task: phi, phi' -> GEMM 1 value and derivative (a, a') -> z' = sigmoid(a) a' -> GEMM 2' (rows =
 //           channels, columns = pairs: lane = pair) -> D = g' f_c + g f_c' with the SAVED raw filter outputs g ->
 //           s1 = sum_c gy_i h_j D,  s2 = sum_c gy_j h_i D  (in-lane sums over the 16 channels a lane owns, one LDS add per
 //           pair and task); the per-pair sums are kept in LDS across all interactions and become dL/dr once, at the end
 //         row-sum task:    gh[a] = sum_{b in row(a)} gy[b] * g[pair(a,b)] * f_c           (the transpose of the forward row sum)
-//   G.  gx += gh W_in                                                                    (T-GEMM phase)
+//         G task (channel tile t): gx[:, 32 t : 32 t + 32] += gh W_in -- waits for the row sums only (LDS counter)
 // ==========================================================================================================
 struct MolBwdLayerDev {
   const float *w1, *b1, *w2;               // filter network (raw)
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         // (sW2 was last read by the derivative tasks of the interaction above: two barriers ago)
         ml_stage_packed<256, NF * NF / 4>(sW2, P.w2, NF, KB2, tid - 256);
       }
-      if (tid == 0) sCnt[0] = 0;
+      if (tid == 0) { sCnt[0] = 0; sCnt[1] = 0; }
       __syncthreads();
       ML_STAMP(33 + 6 * (Ltop - l));
 
@@ -905,18 +905,52 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       ML_STAMP(34 + 6 * (Ltop - l));
 
       // ================= E: derivative tasks (pair tile, pair of channel tiles) + row-sum tasks (one atom, all channels)
+      // The queue hands out the derivative tasks first, then the row sums, then -- unless nothing below consumes dL/dx -- the four
+      // channel tiles of G (gx += gh W_in): G only waits for the row sums (a counter in LDS), not for the derivative tasks, so it
+      // runs on the waves that the second round of derivative tasks leaves idle instead of being a phase of its own.
       const int nder = 2 * ntile;
       const int nrow = (last || np == 0) ? 0 : na;
-      if (np == 0 && !last)      // no pair inside the cutoff: dL/dh = 0 (the buffer still holds the hidden gradient of f2out)
+      const int ng = last ? 0 : NT;
+      if (np == 0 && !last) {    // no pair inside the cutoff: dL/dh = 0 (the buffer still holds the hidden gradient of f2out)
         for (int s = tid; s < 32 * 32; s += 512) *(f32x4*)(sGh + (s >> 5) * ML_LD + 4 * (s & 31)) = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();         // (uniform over the workgroup)
+      }
       while (true) {
         int k = 0;
         if (lane == 0) k = atomicAdd(&sCnt[0], 1);
         k = __builtin_amdgcn_readfirstlane(k);
-        if (k >= nder + nrow) break;
+        if (k >= nder + nrow + ng) break;
+        if (k >= nder + nrow) {
+          // ---- G, channel tile t: gx[:, 32 t : 32 t + 32] += gh W_in (weights requested before the wait for the row sums)
+          const int t = k - nder - nrow;
+          f32x4 avA[8], avB[8];
+          ml_dense_load8(avA, P.in2f_t, t, lane, 0);
+          ml_dense_load8(avB, P.in2f_t, t, lane, 1);
+          if (nrow > 0) {
+            while (__hip_atomic_load(&sCnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nrow) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          }
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          acc = ml_dense_mma8(avA, sGh, lane, 0, acc);
+          acc = ml_dense_mma8(avB, sGh, lane, 1, acc);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float* xp = sGx + el * ML_LD + 32 * t + 8 * q + 4 * hi;
+            f32x4 xv = *(const f32x4*)xp;
+            xv.x += acc[4 * q]; xv.y += acc[4 * q + 1]; xv.z += acc[4 * q + 2]; xv.w += acc[4 * q + 3];
+            if (el >= na) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)xp = xv;
+            if (l == 0 && el < na) ml_st<f32x4>(a.gx0 + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4), xv);
+          }
+          continue;
+        }
         if (k >= nder) {
           // ---- gh[a][c] = sum over the row of a of gy[b][c] g[pair][c] f_c
           ml_row_sums4<10>(sGh, sGy, g_g, sEb, sRow, k - nder, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) atomicAdd(&sCnt[1], 1);
           continue;
         }
         const int tile = k >> 1, tp = k & 1;
@@ -1020,29 +1054,6 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
       ML_STAMP(36 + 6 * (Ltop - l));
       if (last) break;
 
-      // ================= G: gx += gh W_in
-      if (wv < NT) {
-        const int t = wv;
-        f32x4 avA[8], avB[8];
-        ml_dense_load8(avA, P.in2f_t, t, lane, 0);
-        ml_dense_load8(avB, P.in2f_t, t, lane, 1);
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = ml_dense_mma8(avA, sGh, lane, 0, acc);
-        acc = ml_dense_mma8(avB, sGh, lane, 1, acc);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float* xp = sGx + el * ML_LD + 32 * t + 8 * q + 4 * hi;
-          f32x4 xv = *(const f32x4*)xp;
-          xv.x += acc[4 * q]; xv.y += acc[4 * q + 1]; xv.z += acc[4 * q + 2]; xv.w += acc[4 * q + 3];
-          if (el >= na) xv = f32x4{0.f, 0.f, 0.f, 0.f};
-          *(f32x4*)xp = xv;
-          if (l == 0 && el < na) ml_st<f32x4>(a.gx0 + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4), xv);
-        }
-      }
-      __syncthreads();
-      ML_STAMP(37 + 6 * (Ltop - l));
     }
 
     // ---- dL/dr of both directions of every pair, once for all interactions (pairs beyond the cutoff: zero); with gR the pair's

@@ -40,8 +40,8 @@ print("bwd per-block cycles min/median/max %d %d %d; duration us min/median/max 
     cyc.min(), np.median(cyc), cyc.max(), dur.min(), np.median(dur), dur.max(), np.median(cyc / dur) / 1e3))
 slow = np.argsort(-blk[:, 1])[:8]
 print("latest blocks:", [(int(b), round((blk[b, 0] - t0) / 100, 1), round((blk[b, 1] - t0) / 100, 1), int(cyc[b])) for b in slow])
-sub = {64: "task start", 65: "rbf done", 66: "gemm1 + act done", 67: "gemm2 done", 68: "stores issued"}
-print("first filter task of wave 0:")
+sub = {64: "task start", 65: "loads issued + rbf done", 66: "gemm1 + act done", 67: "gemm2' tt=0 done", 68: "products tt=0 done", 69: "gemm2' tt=1 done", 70: "products tt=1 done", 71: "task end"}
+print("first derivative task of wave 0 (backward, top interaction):")
 prev = st[64]
 for k in sorted(sub):
     if st[k]:
