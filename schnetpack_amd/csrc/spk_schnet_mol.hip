@@ -380,7 +380,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
     }
     const int np = ml_pair_records(sP, nullptr, sScan, a.half, a.rij, a.R, a.offsets, a.idx_i, a.idx_j, p0, np_list, a0, a.rb.cutoff, a.compact != 0, tid);
     const int ntile = (np + 31) / 32;
-    ml_stage_packed<512, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
+    // (W2 of the first interaction -- first read by GEMM 2 of the first tile -- is staged by team 0 behind its first hidden tile,
+    // while team 1 is still busy with in2f)
     ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[0].w1, a.rb.n_rbf, KPB, tid);
     if (tid < NF) { sb1[tid] = a.L[0].b1[tid]; sb2[tid] = a.L[0].b2[tid]; }
 
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
             *(f32x4*)(zbuf + el * ML_LD + 32 * t + 8 * q + 4 * hi) =
                 f32x4{spk_fast_ssp(zc[4 * q]), spk_fast_ssp(zc[4 * q + 1]), spk_fast_ssp(zc[4 * q + 2]), spk_fast_ssp(zc[4 * q + 3])};
         }
+        if (l == 0 && it == 0 && team == 0) ml_stage_packed<256, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
         __syncthreads();     // the team's hidden tile (and, in the first round, h) is complete
         if (active) {
           // ---- GEMM 2, operands swapped (rows = pairs, columns = channels 32 t + el): g = W2 z + b2, A operand from LDS
@@ -576,15 +578,24 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           for (int w = 0; w < HT; ++w) y += sH[w * 32 + lane];
           if (lane >= na) y = 0.f;
         }
-        const long long prev = __shfl_up(my_mol, 1, 64);
-        const bool head_of_run = lane < na && (lane == 0 || prev != my_mol);
-        float sum = 0.f;
-        for (int b = 0; b < 32; ++b) {                 // runs are contiguous: every head walks forward while the id matches
-          const float yb = spk_readlane_f(y, b);
-          const long long mb = __shfl(my_mol, b, 64);
-          if (head_of_run && b >= lane && b < na && mb == my_mol) sum += yb;
+        const long long first_mol = __shfl(my_mol, 0, 64);
+        if (__all(lane >= na || my_mol == first_mol)) {
+          // the whole group is one molecule (the usual case): a butterfly over the 32 atom lanes (y is 0 beyond na)
+          float sum = y;
+#pragma unroll
+          for (int m = 16; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+          if (lane == 0 && na > 0) { if (Hd.direct_store) Hd.E[my_mol] = sum; else unsafeAtomicAdd(Hd.E + my_mol, sum); }
+        } else {
+          const long long prev = __shfl_up(my_mol, 1, 64);
+          const bool head_of_run = lane < na && (lane == 0 || prev != my_mol);
+          float sum = 0.f;
+          for (int b = 0; b < 32; ++b) {               // runs are contiguous: every head walks forward while the id matches
+            const float yb = spk_readlane_f(y, b);
+            const long long mb = __shfl(my_mol, b, 64);
+            if (head_of_run && b >= lane && b < na && mb == my_mol) sum += yb;
+          }
+          if (head_of_run) { if (Hd.direct_store) Hd.E[my_mol] = sum; else unsafeAtomicAdd(Hd.E + my_mol, sum); }
         }
-        if (head_of_run) { if (Hd.direct_store) Hd.E[my_mol] = sum; else unsafeAtomicAdd(Hd.E + my_mol, sum); }
       }
     }
     ML_STAMP(31);
