@@ -494,6 +494,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       ML_STAMP(4 + 5 * l);
 
       // ================= phase C1: pre3 = (y0 + y1) W3^T + b3 (saved), hidden = ssp(pre3) -> sH; the other team stages weights
+      f32x4 avC[8];        // team 0: first half of the weight tile of phase C2, requested BEFORE the stores of pre3 -- loads and
+                           // stores share one in-order counter, a load issued behind a store cannot be waited for without it
       if (team == 0) {
         f32x4 avA[8], avB[8];
         ml_dense_load8(avA, P.o1_p, t, lane, 0);
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
         for (int r = 0; r < 16; ++r) acc[r] = P.o1_b[32 * t + ml_row(r, hi)];
         acc = ml_dense_mma8_sum(avA, sY, sT, lane, 0, acc);
         acc = ml_dense_mma8_sum(avB, sY, sT, lane, 1, acc);
+        ml_dense_load8(avC, P.o2_p, t, lane, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -520,13 +523,12 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
 
       // ================= phase C2: x += hidden W4^T + b4
       if (team == 0) {
-        f32x4 avA[8], avB[8];
-        ml_dense_load8(avA, P.o2_p, t, lane, 0);
+        f32x4 avB[8];
         ml_dense_load8(avB, P.o2_p, t, lane, 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = P.o2_b[32 * t + ml_row(r, hi)];
-        acc = ml_dense_mma8(avA, sH, lane, 0, acc);
+        acc = ml_dense_mma8(avC, sH, lane, 0, acc);
         acc = ml_dense_mma8(avB, sH, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -547,27 +549,28 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       long long my_mol = -1;
       if (wv == 1 && lane < 32) my_mol = lane < na ? Hd.idx_m[a0 + lane] : -2;      // wave 1: molecule id of atom `lane`
       __syncthreads();                    // x_L is complete
-      if (wv < HT) {
+      const int hw = wv;
+      if (hw < HT) {
         f32x4 av[16];                     // (requested after the barrier: register arrays that live across one get spilled)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) av[u] = ml_ld<f32x4>(Hd.w1 + (size_t)(32 * wv) * NF, (unsigned)((el * NF + 8 * u + 4 * hi) * 4));
+        for (int u = 0; u < 16; ++u) av[u] = ml_ld<f32x4>(Hd.w1 + (size_t)(32 * hw) * NF, (unsigned)((el * NF + 8 * u + 4 * hi) * 4));
         f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = Hd.b1[32 * wv + ml_row(r, hi)];
+        for (int r = 0; r < 16; ++r) acc[r] = Hd.b1[32 * hw + ml_row(r, hi)];
         acc = ml_dense_mma(av, sX, lane, acc);
         float part = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-          if (el < na) ml_st<f32x4>(Hd.pre_h + (size_t)a0 * Hd.H + 32 * wv, (unsigned)((el * Hd.H + 8 * q + 4 * hi) * 4), pv);
-          const f32x4 wv2 = *(const f32x4*)(Hd.w2 + 32 * wv + 8 * q + 4 * hi);
+          if (el < na) ml_st<f32x4>(Hd.pre_h + (size_t)a0 * Hd.H + 32 * hw, (unsigned)((el * Hd.H + 8 * q + 4 * hi) * 4), pv);
+          const f32x4 wv2 = *(const f32x4*)(Hd.w2 + 32 * hw + 8 * q + 4 * hi);
           if (Hd.act == SPK_ACT_SILU)
             part += pv.x * spk_sigmoid(pv.x) * wv2.x + pv.y * spk_sigmoid(pv.y) * wv2.y + pv.z * spk_sigmoid(pv.z) * wv2.z + pv.w * spk_sigmoid(pv.w) * wv2.w;
           else
             part += spk_ssp(pv.x) * wv2.x + spk_ssp(pv.y) * wv2.y + spk_ssp(pv.z) * wv2.z + spk_ssp(pv.w) * wv2.w;
         }
         part += __shfl_xor(part, 32, 64);
-        if (hi == 0) sH[wv * 32 + el] = part;          // (sH: the hidden tile of the last f2out is no longer needed)
+        if (hi == 0) sH[hw * 32 + el] = part;          // (sH: the hidden tile of the last f2out is no longer needed)
       }
       __syncthreads();
       // wave 1 holds the molecule id of atom (lane) in my_mol: segment heads add their run, one atomic per (group, molecule)
