@@ -988,36 +988,62 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) ml_rbf(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, 8 * u + 4 * hi + v, pr.d, phi[u][v], dphi[u][v]);
         // ---- GEMM 1, value and derivative (rows = hidden channels, columns = pairs): z' = sigmoid(W1 phi + b1) * (W1 phi')
+        // Software-pipelined by hand: a wave issues in order, so an activation block placed between two MFMA groups leaves the
+        // matrix pipe idle for its whole length.  The MFMAs of hidden tile c + 1 are therefore interleaved with the activations
+        // of tile c (one or two of its 16 accumulator rows per MFMA pair): the VALU work runs in the shadow of the MFMAs.
         f32x16 zp[NT];
         {
+          constexpr int NSTEP = 4 * KPB;
           f32x4 wq = *(const f32x4*)(sW1 + lane * 4);
+          f32x16 zc, zq;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { zc[r] = sb1[ml_row(r, hi)]; zq[r] = 0.f; }
+#pragma unroll
+          for (int u = 0; u < KPB; ++u) {
+            f32x4 wn = wq;
+            if (u + 1 < NT * KPB) wn = *(const f32x4*)(sW1 + ((u + 1) * 64 + lane) * 4);
+            zc = ML_MFMA(wq.x, phi[u][0], zc); zq = ML_MFMA(wq.x, dphi[u][0], zq);
+            zc = ML_MFMA(wq.y, phi[u][1], zc); zq = ML_MFMA(wq.y, dphi[u][1], zq);
+            zc = ML_MFMA(wq.z, phi[u][2], zc); zq = ML_MFMA(wq.z, dphi[u][2], zq);
+            zc = ML_MFMA(wq.w, phi[u][3], zc); zq = ML_MFMA(wq.w, dphi[u][3], zq);
+            wq = wn;
+          }
 #pragma unroll
           for (int c = 0; c < NT; ++c) {
-            f32x16 zc, zq;
+            f32x16 zcn = zc, zqn = zq;
+            if (c + 1 < NT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { zc[r] = sb1[32 * c + ml_row(r, hi)]; zq[r] = 0.f; }
+              for (int r = 0; r < 16; ++r) { zcn[r] = sb1[32 * (c + 1) + ml_row(r, hi)]; zqn[r] = 0.f; }
 #pragma unroll
-            for (int u = 0; u < KPB; ++u) {
-              const int nxt = c * KPB + u + 1;
-              f32x4 wn = wq;
-              if (nxt < NT * KPB) wn = *(const f32x4*)(sW1 + (nxt * 64 + lane) * 4);
-              zc = ML_MFMA(wq.x, phi[u][0], zc);
-              zc = ML_MFMA(wq.y, phi[u][1], zc);
-              zc = ML_MFMA(wq.z, phi[u][2], zc);
-              zc = ML_MFMA(wq.w, phi[u][3], zc);
-              zq = ML_MFMA(wq.x, dphi[u][0], zq);
-              zq = ML_MFMA(wq.y, dphi[u][1], zq);
-              zq = ML_MFMA(wq.z, dphi[u][2], zq);
-              zq = ML_MFMA(wq.w, dphi[u][3], zq);
-              wq = wn;
-            }
+              for (int u = 0; u < KPB; ++u) {
+                const int nxt = (c + 1) * KPB + u + 1;
+                f32x4 wn = wq;
+                if (nxt < NT * KPB) wn = *(const f32x4*)(sW1 + (nxt * 64 + lane) * 4);
+                const float wv4[4] = {wq.x, wq.y, wq.z, wq.w};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              float sp, sg;
-              spk_fast_softplus_sigmoid(zc[r], sp, sg);
-              zq[r] *= sg;
+                for (int v = 0; v < 4; ++v) {
+                  zcn = ML_MFMA(wv4[v], phi[u][v], zcn);
+                  zqn = ML_MFMA(wv4[v], dphi[u][v], zqn);
+                  const int st = 4 * u + v;
+#pragma unroll
+                  for (int r = (16 * st) / NSTEP; r < (16 * (st + 1)) / NSTEP; ++r) {
+                    float sp, sg;
+                    spk_fast_softplus_sigmoid(zc[r], sp, sg);
+                    zq[r] *= sg;
+                  }
+                }
+                wq = wn;
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float sp, sg;
+                spk_fast_softplus_sigmoid(zc[r], sp, sg);
+                zq[r] *= sg;
+              }
             }
             zp[c] = zq;
+            zc = zcn; zq = zqn;
           }
         }
         // ---- GEMM 2' per channel tile (rows = channels 32 t + ml_row(r, hi), columns = pairs): g' = W2 z'
