@@ -28,7 +28,6 @@ for base in (0, 32):
         if k >= base and k < base + 32 and st[k]:
             print("  %-36s %8d  (+%d)" % (names[k], st[k] - st[base], st[k] - prev)); prev = st[k]
 import numpy as np
-print("fwd L0 phase A iteration stamps (cycles from L0 staged):", [st[k] - st[1] for k in range(100, 110) if st[k]])
 print("bwd set-up of block 0 (cycles from the first instruction):", {k: st[k] - st[130] for k in (120, 121, 122, 123, 124, 32) if st[k]})
 blk = np.array(st[128:128 + 4 * 256]).reshape(256, 4)
 t0 = blk[:, 0].min()
@@ -40,12 +39,6 @@ print("bwd per-block cycles min/median/max %d %d %d; duration us min/median/max 
     cyc.min(), np.median(cyc), cyc.max(), dur.min(), np.median(dur), dur.max(), np.median(cyc / dur) / 1e3))
 slow = np.argsort(-blk[:, 1])[:8]
 print("latest blocks:", [(int(b), round((blk[b, 0] - t0) / 100, 1), round((blk[b, 1] - t0) / 100, 1), int(cyc[b])) for b in slow])
-sub = {64: "task start", 65: "loads issued + rbf done", 66: "gemm1 + act done", 67: "gemm2' tt=0 done", 68: "products tt=0 done", 69: "gemm2' tt=1 done", 70: "products tt=1 done", 71: "task end"}
-print("first derivative task of wave 0 (backward, top interaction):")
-prev = st[64]
-for k in sorted(sub):
-    if st[k]:
-        print("  %-36s %8d  (+%d)" % (sub[k], st[k] - st[64], st[k] - prev)); prev = st[k]
 _lib.profile_enable(True); _lib.profile_report()
 for _ in range(20):
     m(dict(inp))
