@@ -636,6 +636,17 @@ def main():
         except Exception as exc:  # pragma: no cover
             sweep = {"error": str(exc)[:200]}
 
+    # context for `roofline` (which, per contract, is about the dominant launch): all MFMA-bound launches of one force call over the
+    # wall time of the call (cfg 2: the two molecule-resident launches and the gaps between them)
+    if roofline is not None and roofline.get("bound") == "mfma":
+        try:
+            tot = sum(algo[t][1] * kernels[t]["launches_per_step"] for t in kernels if t in algo and algo[t][0] == "mfma")
+            sec = dt / args.steps
+            roofline["force_call"] = {"algorithmic_flop": tot, "achieved": round(tot / sec / 1e12, 3), "unit": "TFLOP/s",
+                                      "frac": round(tot / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                      "note": "algorithmic FLOP of every MFMA-bound launch of one force call / wall time of the call"}
+        except Exception:  # pragma: no cover
+            pass
     info = _lib.device_info()
     line = {
         "metric": "M edge-messages/s (eval force call, %s, %s)" % ("MD17-aspirin 256-frame batch" if args.workload == "aspirin" else "32k-atom bulk-water PBC box", "SchNet" if args.kind == "schnet" else "PaiNN"),
