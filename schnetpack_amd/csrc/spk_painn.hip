@@ -696,6 +696,143 @@ __global__ __launch_bounds__(256, MINB) void k_painn_mixing_fwd(MixFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same forward with EIGHT wavefronts per 16-atom tile: wave w owns the 16 features [16 w, 16 w + 16) in every stage, i.e. one
+// 16x16 accumulator where the four-wave form has a pair.  Half the accumulators and half the weight registers per wave: the kernel
+// fits the 256-register budget of two waves per SIMD without scratch, so the serial stages of a tile are walked by two waves per
+// SIMD (one fills the other's load / LDS / barrier gaps) and a tile finishes in about half the time -- which is what the
+// 336-tiles-on-256-CUs launch of configs[2] is bound by (one tile per workgroup, two rounds).
+// ------------------------------------------------------------------------------------------
+// A operands of the 16-feature tile (pair p, half k) for u-steps [u0, u0 + 4)
+__device__ __forceinline__ void mix_load_a16(f32x4 (&av)[4], const float* __restrict__ w, int KB, int p, int k, int u0, int el, int h) {
+  const char* base = (const char*)w + (((int64_t)p * KB + 2 * u0) * 64) * 16 + k * 256;
+  const uint32_t off = (uint32_t)(((h >> 1) * 64 + (h & 1) * 32 + el) * 16);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) av[u] = *(const f32x4*)(base + off + u * 2048);
+}
+__device__ __forceinline__ void mix_mfma4_16(const f32x4 (&av)[4], const f32x4 (&bv)[4], f32x4& acc) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+  }
+}
+
+template <int F>
+__global__ __launch_bounds__(512, 2) void k_painn_mixing_fwd8(MixFwdArgs a) {
+  static_assert(F == 128, "the weight stream below is written out for n_atom_basis = 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDA = F + 4, LDC = 2 * F + 4, LDH = F + 4;
+  constexpr int KB1 = F / 8, KB2 = 2 * F / 8;
+  constexpr int PW = F / 32;          // weight pairs per F output features
+  float* sMu = smem;                 // [3][16][LDA]
+  float* sCt = sMu + 48 * LDA;       // [16][LDC]
+  float* sHd = sCt + 16 * LDC;       // [16][LDH]
+  const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pw = w8 >> 1, kw = w8 & 1;             // this wave's pair and half inside a block of F output features
+  const int h = lane >> 4, el = lane & 15;
+  const int f0 = 16 * w8 + 4 * h;                  // this lane's four features
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t ntiles = (a.N + 15) / 16;
+  f32x4 wa[4], wb[4];
+  if ((int64_t)blockIdx.x < ntiles) mix_load_a16(wa, a.wmix, KB1, pw, kw, 0, el, h);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t m0 = tile * 16;
+    const int64_t m = m0 + el;
+    const bool valid = m < a.N;
+    constexpr int Q4 = F / 4;
+    for (int s = threadIdx.x; s < 48 * Q4; s += 512) {
+      const int row = s / Q4, c4 = s - row * Q4;
+      const int x = row >> 4, n = row & 15;
+      int64_t mm = m0 + n;
+      if (mm >= a.N) mm = a.N - 1;
+      *(f32x4*)(sMu + row * LDA + 4 * c4) = *(const f32x4*)(a.mu1 + (mm * 3 + x) * F + 4 * c4);
+    }
+    for (int s = threadIdx.x; s < 16 * Q4; s += 512) {
+      const int n = s / Q4, c4 = s - n * Q4;
+      int64_t mm = m0 + n;
+      if (mm >= a.N) mm = a.N - 1;
+      *(f32x4*)(sCt + n * LDC + 4 * c4) = *(const f32x4*)(a.q1 + mm * F + 4 * c4);
+    }
+    __syncthreads();
+    // ---- stage 1: channel mix
+    f32x4 V[3], W[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { V[x] = z4; W[x] = z4; }
+    f32x4 bv[4];
+#define MIX8_X3(WSET, C, ACC)                                                                     \
+    _Pragma("unroll") for (int x = 0; x < 3; ++x) {                                               \
+      mix_load_b(bv, sMu + (16 * x + el) * LDA, C, h);                                            \
+      mix_mfma4_16(WSET, bv, ACC[x]);                                                             \
+    }
+    mix_load_a16(wb, a.wmix, KB1, pw, kw, 4, el, h);          MIX8_X3(wa, 0, V) __builtin_amdgcn_sched_barrier(0);
+    mix_load_a16(wa, a.wmix, KB1, pw + PW, kw, 0, el, h);     MIX8_X3(wb, 1, V) __builtin_amdgcn_sched_barrier(0);
+    mix_load_a16(wb, a.wmix, KB1, pw + PW, kw, 4, el, h);     MIX8_X3(wa, 0, W) __builtin_amdgcn_sched_barrier(0);
+    mix_load_a16(wa, a.w1, KB2, pw, kw, 0, el, h);            MIX8_X3(wb, 1, W) __builtin_amdgcn_sched_barrier(0);
+#undef MIX8_X3
+    f32x4 sVW = z4;
+    {
+      f32x4 n2 = {a.eps, a.eps, a.eps, a.eps};
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        n2 += V[x] * V[x];
+        sVW += V[x] * W[x];
+        if (valid) {
+          *(f32x4*)(a.mix + (m * 3 + x) * 2 * F + f0) = V[x];
+          *(f32x4*)(a.mix + (m * 3 + x) * 2 * F + F + f0) = W[x];
+        }
+      }
+      f32x4 vn;
+      vn.x = sqrtf(n2.x); vn.y = sqrtf(n2.y); vn.z = sqrtf(n2.z); vn.w = sqrtf(n2.w);
+      *(f32x4*)(sCt + el * LDC + F + f0) = vn;
+    }
+    __syncthreads();
+    // ---- stage 2: hidden = silu([q | |V|] W1^T + b1)
+    {
+      f32x4 acc = a.b1 ? *(const f32x4*)(a.b1 + f0) : z4;
+      const float* brow = sCt + el * LDC;
+      mix_load_a16(wb, a.w1, KB2, pw, kw, 4, el, h);   mix_load_b(bv, brow, 0, h); mix_mfma4_16(wa, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wa, a.w1, KB2, pw, kw, 8, el, h);   mix_load_b(bv, brow, 1, h); mix_mfma4_16(wb, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wb, a.w1, KB2, pw, kw, 12, el, h);  mix_load_b(bv, brow, 2, h); mix_mfma4_16(wa, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wa, a.w2, KB1, pw, kw, 0, el, h);   mix_load_b(bv, brow, 3, h); mix_mfma4_16(wb, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      f32x4 o = acc;
+      if (valid) *(f32x4*)(a.preB + m * F + f0) = o;
+      o.x = o.x * spk_sigmoid(o.x); o.y = o.y * spk_sigmoid(o.y); o.z = o.z * spk_sigmoid(o.z); o.w = o.w * spk_sigmoid(o.w);
+      *(f32x4*)(sHd + el * LDH + f0) = o;
+    }
+    __syncthreads();
+    // ---- stage 3: a = hidden W2^T + b2, parts (q | mu | q mu)
+    f32x4 A[3];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) A[part] = a.b2 ? *(const f32x4*)(a.b2 + part * F + f0) : z4;
+    {
+      const float* brow = sHd + el * LDH;
+      const bool more = tile + gridDim.x < ntiles;
+      mix_load_a16(wb, a.w2, KB1, pw, kw, 4, el, h);             mix_load_b(bv, brow, 0, h); mix_mfma4_16(wa, bv, A[0]); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wa, a.w2, KB1, pw + PW, kw, 0, el, h);        mix_load_b(bv, brow, 1, h); mix_mfma4_16(wb, bv, A[0]); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wb, a.w2, KB1, pw + PW, kw, 4, el, h);        mix_load_b(bv, brow, 0, h); mix_mfma4_16(wa, bv, A[1]); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wa, a.w2, KB1, pw + 2 * PW, kw, 0, el, h);    mix_load_b(bv, brow, 1, h); mix_mfma4_16(wb, bv, A[1]); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wb, a.w2, KB1, pw + 2 * PW, kw, 4, el, h);    mix_load_b(bv, brow, 0, h); mix_mfma4_16(wa, bv, A[2]); __builtin_amdgcn_sched_barrier(0);
+      if (more) mix_load_a16(wa, a.wmix, KB1, pw, kw, 0, el, h); mix_load_b(bv, brow, 1, h); mix_mfma4_16(wb, bv, A[2]); __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- stage 4: q += a_q + a_qmu sum_x V W ;  mu += a_mu W
+    if (valid) {
+#pragma unroll
+      for (int part = 0; part < 3; ++part) *(f32x4*)(a.a + m * 3 * F + part * F + f0) = A[part];
+      const f32x4 q = *(const f32x4*)(sCt + el * LDC + f0);
+      *(f32x4*)(a.q_out + m * F + f0) = q + A[0] + A[2] * sVW;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const f32x4 mu = *(const f32x4*)(sMu + (16 * x + el) * LDA + f0);
+        *(f32x4*)(a.mu_out + (m * 3 + x) * F + f0) = mu + A[1] * W[x];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused first half of the PaiNNMixing backward (n_atom_basis = 128): gradient of the update w.r.t. the context
 // output a and the mixed tensor (k_mix_update_bwd), the two transposed Dense layers of the intra-atomic context net,
 // and the gradient of the [q | |V|] context input (k_mix_ctx_bwd) in ONE launch -- 3 launches before.  Same
@@ -801,12 +938,102 @@ __global__ __launch_bounds__(256, MINB) void k_painn_mixing_bwd(MixBwdArgs a) {
   }
 }
 
+// The same backward with eight wavefronts per tile (see k_painn_mixing_fwd8): wave w owns the features [16 w, 16 w + 16).
+template <int F>
+__global__ __launch_bounds__(512, 2) void k_painn_mixing_bwd8(MixBwdArgs a) {
+  static_assert(F == 128, "the weight stream below is written out for n_atom_basis = 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDG = 3 * F + 4, LDT = F + 4;
+  constexpr int KB3 = 3 * F / 8, KB1 = F / 8;
+  constexpr int PW = F / 32;
+  float* sGa = smem;                 // [16][LDG]  dL/da  (q | mu | q mu)
+  float* sT = sGa + 16 * LDG;        // [16][LDT]  dL/d hidden pre-activation
+  const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pw = w8 >> 1, kw = w8 & 1;
+  const int h = lane >> 4, el = lane & 15;
+  const int f0 = 16 * w8 + 4 * h;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t ntiles = (a.N + 15) / 16;
+  f32x4 wa[4], wb[4], bv[4];
+  if ((int64_t)blockIdx.x < ntiles) mix_load_a16(wa, a.w2t, KB3, pw, kw, 0, el, h);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t m0 = tile * 16;
+    int64_t m = m0 + el;
+    const bool valid = m < a.N;
+    if (!valid) m = a.N - 1;
+    // ---- stage 0: gradient of the update (painn.py:111-116) for this wave's features
+    f32x4 V[3], gV[3], gq4, invn;
+    {
+      const f32x4 amu = *(const f32x4*)(a.a + m * 3 * F + F + f0), aqm = *(const f32x4*)(a.a + m * 3 * F + 2 * F + f0);
+      gq4 = *(const f32x4*)(a.gq + m * F + f0);
+      f32x4 s = z4, gam = z4, n2 = {a.eps, a.eps, a.eps, a.eps};
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const f32x4 v = *(const f32x4*)(a.mix + (m * 3 + x) * 2 * F + f0);
+        const f32x4 w = *(const f32x4*)(a.mix + (m * 3 + x) * 2 * F + F + f0);
+        const f32x4 gm = *(const f32x4*)(a.gmu + (m * 3 + x) * F + f0);
+        V[x] = v;
+        s += v * w; gam += gm * w; n2 += v * v;
+        gV[x] = gq4 * aqm * w;                                         // dL/dV, the norm term follows in stage 2
+        if (valid) *(f32x4*)(a.gmix + (m * 3 + x) * 2 * F + F + f0) = gq4 * aqm * v + gm * amu;   // dL/dW
+      }
+      invn.x = 1.0f / sqrtf(n2.x); invn.y = 1.0f / sqrtf(n2.y); invn.z = 1.0f / sqrtf(n2.z); invn.w = 1.0f / sqrtf(n2.w);
+      *(f32x4*)(sGa + el * LDG + f0) = gq4;
+      *(f32x4*)(sGa + el * LDG + F + f0) = gam;
+      *(f32x4*)(sGa + el * LDG + 2 * F + f0) = gq4 * s;
+    }
+    __syncthreads();
+    // ---- stage 1: t = (ga W2) * silu'(preB), contraction 3F = 6 chunks
+    {
+      f32x4 acc = z4;
+      const float* brow = sGa + el * LDG;
+      mix_load_a16(wb, a.w2t, KB3, pw, kw, 4, el, h);   mix_load_b(bv, brow, 0, h); mix_mfma4_16(wa, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wa, a.w2t, KB3, pw, kw, 8, el, h);   mix_load_b(bv, brow, 1, h); mix_mfma4_16(wb, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wb, a.w2t, KB3, pw, kw, 12, el, h);  mix_load_b(bv, brow, 2, h); mix_mfma4_16(wa, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wa, a.w2t, KB3, pw, kw, 16, el, h);  mix_load_b(bv, brow, 3, h); mix_mfma4_16(wb, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wb, a.w2t, KB3, pw, kw, 20, el, h);  mix_load_b(bv, brow, 4, h); mix_mfma4_16(wa, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wa, a.w1t, KB1, pw, kw, 0, el, h);   mix_load_b(bv, brow, 5, h); mix_mfma4_16(wb, bv, acc); __builtin_amdgcn_sched_barrier(0);
+      const f32x4 pb = *(const f32x4*)(a.preB + m * F + f0);
+      f32x4 o = acc;
+      o.x *= spk_act_grad<SPK_ACT_SILU>(pb.x); o.y *= spk_act_grad<SPK_ACT_SILU>(pb.y);
+      o.z *= spk_act_grad<SPK_ACT_SILU>(pb.z); o.w *= spk_act_grad<SPK_ACT_SILU>(pb.w);
+      *(f32x4*)(sT + el * LDT + f0) = o;
+    }
+    __syncthreads();
+    // ---- stage 2: g_ctx = t W1: the q part feeds dL/dq, the |V| part the norm term of dL/dV
+    {
+      f32x4 q0 = z4, n0 = z4;
+      const float* brow = sT + el * LDT;
+      const bool more = tile + gridDim.x < ntiles;
+      mix_load_a16(wb, a.w1t, KB1, pw, kw, 4, el, h);             mix_load_b(bv, brow, 0, h); mix_mfma4_16(wa, bv, q0); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wa, a.w1t, KB1, pw + PW, kw, 0, el, h);        mix_load_b(bv, brow, 1, h); mix_mfma4_16(wb, bv, q0); __builtin_amdgcn_sched_barrier(0);
+      mix_load_a16(wb, a.w1t, KB1, pw + PW, kw, 4, el, h);        mix_load_b(bv, brow, 0, h); mix_mfma4_16(wa, bv, n0); __builtin_amdgcn_sched_barrier(0);
+      if (more) mix_load_a16(wa, a.w2t, KB3, pw, kw, 0, el, h);   mix_load_b(bv, brow, 1, h); mix_mfma4_16(wb, bv, n0); __builtin_amdgcn_sched_barrier(0);
+      if (valid) {
+        *(f32x4*)(a.gq1 + m * F + f0) = gq4 + q0;
+        const f32x4 sc = n0 * invn;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) *(f32x4*)(a.gmix + (m * 3 + x) * 2 * F + f0) = gV[x] + sc * V[x];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Measured (profiles/README.md, round 2): the spill-free variant wins at every size tried (cfg 3: forward 45.9 -> 42.9 us,
 // backward 34.3 -> 29.7 us; 32 k-atom box: 185 -> 166 us and 151 -> 130 us).  SPK_MIX_OCC=2 selects the two-workgroup form.
 static bool mix_one_block_per_cu(int64_t ntiles) {
   static const char* env = getenv("SPK_MIX_OCC");
   (void)ntiles;
   return !(env && env[0] == '2');
+}
+
+// Eight waves per tile is the default at every size measured (cfg 3: forward 42.3 -> 38.9 us, backward 29.5 -> 26.8 us; 32 k-atom
+// box: 167.6 -> 148.3 us and 128.3 -> 117.5 us); SPK_MIX_OCC = 1 / 2 select the four-wave forms (one / two workgroups per CU).
+static bool mix_eight_waves(int64_t ntiles) {
+  static const char* env = getenv("SPK_MIX_OCC");
+  (void)ntiles;
+  return !(env && (env[0] == '1' || env[0] == '2'));
 }
 
 static int launch_painn_mixing_bwd(const MixBwdArgs& a, int F, hipStream_t stream) {
@@ -816,7 +1043,8 @@ static int launch_painn_mixing_bwd(const MixBwdArgs& a, int F, hipStream_t strea
   const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
   SpkProfScope prof("painn_mixing_bwd", stream);
   // few tiles per CU (molecule batches): one workgroup per CU, no scratch; many tiles per CU: two resident workgroups
-  if (mix_one_block_per_cu(ntiles)) hipLaunchKernelGGL((k_painn_mixing_bwd<128, 1>), dim3(grid), dim3(256), lds, stream, a);
+  if (mix_eight_waves(ntiles)) hipLaunchKernelGGL((k_painn_mixing_bwd8<128>), dim3(grid), dim3(512), lds, stream, a);
+  else if (mix_one_block_per_cu(ntiles)) hipLaunchKernelGGL((k_painn_mixing_bwd<128, 1>), dim3(grid), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL((k_painn_mixing_bwd<128, 2>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
@@ -828,7 +1056,8 @@ static int launch_painn_mixing_fwd(const MixFwdArgs& a, int F, hipStream_t strea
   const int64_t ntiles = (a.N + 15) / 16;
   const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
   SpkProfScope prof("painn_mixing_fwd", stream);
-  if (mix_one_block_per_cu(ntiles)) hipLaunchKernelGGL((k_painn_mixing_fwd<128, 1>), dim3(grid), dim3(256), lds, stream, a);
+  if (mix_eight_waves(ntiles)) hipLaunchKernelGGL((k_painn_mixing_fwd8<128>), dim3(grid), dim3(512), lds, stream, a);
+  else if (mix_one_block_per_cu(ntiles)) hipLaunchKernelGGL((k_painn_mixing_fwd<128, 1>), dim3(grid), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL((k_painn_mixing_fwd<128, 2>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
