@@ -19,8 +19,8 @@
 // of a chunk are issued before its 32 MFMAs, and the next chunk is requested before the current one
 // is consumed (two register sets), so a wave pays the memory latency once instead of per k-block.
 #define DCH 8
-template <bool TRANS, int PRO>
-__device__ __forceinline__ void dense_load_chunk(f32x4 (&av)[DCH], f32x4 (&bv)[DCH], int c, int nug,
+template <bool TRANS, int PRO, int CH>
+__device__ __forceinline__ void dense_load_chunk(f32x4 (&av)[CH], f32x4 (&bv)[CH], int c, int nug,
                                                  const float* __restrict__ inrow,
                                                  const float* __restrict__ prow,
                                                  const float* __restrict__ w, int KC, int NW, int t,
@@ -28,8 +28,8 @@ __device__ __forceinline__ void dense_load_chunk(f32x4 (&av)[DCH], f32x4 (&bv)[D
   // KC and NW are multiples of 4 (not necessarily of 8 / 32): contraction groups past KC and weight rows past NW read as 0
   const bool rin = 32 * t + el < NW;
 #pragma unroll
-  for (int u = 0; u < DCH; ++u) {
-    const int ug = c * DCH + u;
+  for (int u = 0; u < CH; ++u) {
+    const int ug = c * CH + u;
     if (ug < nug) {
       const int kk0 = 8 * ug + 4 * hi;
       const bool kin = kk0 < KC;
@@ -55,11 +55,12 @@ __device__ __forceinline__ void dense_load_chunk(f32x4 (&av)[DCH], f32x4 (&bv)[D
   }
 }
 
-__device__ __forceinline__ f32x16 dense_mfma_chunk(const f32x4 (&av)[DCH], const f32x4 (&bv)[DCH], int c,
+template <int CH>
+__device__ __forceinline__ f32x16 dense_mfma_chunk(const f32x4 (&av)[CH], const f32x4 (&bv)[CH], int c,
                                                    int nug, f32x16 acc) {
 #pragma unroll
-  for (int u = 0; u < DCH; ++u) {
-    if (c * DCH + u < nug) {
+  for (int u = 0; u < CH; ++u) {
+    if (c * CH + u < nug) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
@@ -77,9 +78,13 @@ __device__ __forceinline__ void dense_tiles(
     float* __restrict__ pre_out, int64_t M, int KC, int NW, int64_t ntasks, int64_t first, int64_t stride) {
   const int lane = threadIdx.x & 63;
   const int hi = lane >> 5, el = lane & 31;
+  // chunk of k-blocks per register set: the transposed form gathers its A operand with four strided scalar loads per k-block --
+  // eight blocks per set kept 32 loads and their addresses in flight twice over and pushed the kernels into scratch (k_gemm_pair)
+  // or to one wave per SIMD (k_dense_mfma); four blocks per set fit
+  constexpr int CH = TRANS ? 4 : DCH;
   const int tcount = (NW + 31) / 32;
   const int nug = (KC + 7) / 8;
-  const int nch = (nug + DCH - 1) / DCH;
+  const int nch = (nug + CH - 1) / CH;
   for (int64_t task = first; task < ntasks; task += stride) {
     const int64_t mt = task / tcount;
     const int t = (int)(task % tcount);
@@ -88,7 +93,7 @@ __device__ __forceinline__ void dense_tiles(
     const int64_t mc = valid ? m : (M - 1);
     const float* inrow = in + mc * KC;
     const float* prow = PRO != SPK_ACT_NONE ? pre_in + mc * KC : nullptr;
-    f32x4 a0[DCH], b0[DCH], a1[DCH], b1[DCH];
+    f32x4 a0[CH], b0[CH], a1[CH], b1[CH];
     dense_load_chunk<TRANS, PRO>(a0, b0, 0, nug, inrow, prow, w, KC, NW, t, el, hi);
     f32x4 rv[4];  // residual rows, requested ahead of the MFMAs
 #pragma unroll
