@@ -79,7 +79,7 @@ struct MolFwdArgs {
   int64_t gsz, N;
   RadialDev rb;
   int compact;              // drop the pairs beyond the cutoff from the tiles (lists with a skin); the backward does the same
-  long long* dbg;           // tuning aid: cycle stamps of thread 0 of workgroup 0 (null in production)
+  long long* dbg;           // tuning aid: cycle stamps, see spk_schnet_mol_set_debug_buffer (null in production)
 };
 #define ML_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -607,7 +607,9 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
 
 // ------------------------------------------------------------------------------------------ host side
 static long long* g_mol_dbg = nullptr;
-// tuning aid: device buffer of >= 64 int64 that receives cycle stamps of thread 0 / workgroup 0 (NULL: off)
+// tuning aid (scripts/mol_timing.py; not declared in include/spk_hip.h): device buffer of int64 that receives cycle stamps -- entries
+// [0, 128): phases of thread 0 of workgroup 0; [128 + 4 b, 128 + 4 b + 4): real-time and cycle stamps at the start / end of workgroup b
+// of the backward launch, so the buffer must hold 128 + 4 * (number of groups) entries.  NULL: off (production)
 extern "C" void spk_schnet_mol_set_debug_buffer(void* p) { g_mol_dbg = (long long*)p; }
 
 static size_t mol_fwd_lds(int kpb) {
