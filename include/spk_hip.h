@@ -408,8 +408,9 @@ int spk_schnet_potential_forces_f32(const spk_schnet_t* m, const spk_head_t* hea
                                     float* E, float* F, float* pre_h, float* saved, void* stream);
 
 /* Kernel-tuning aid of the molecule-resident SchNet kernels (spk_schnet_mol.hip: block-diagonal lists with <= 32 atoms per
- * block run every interaction inside one workgroup): device buffer (>= 64 int64) receiving cycle stamps of workgroup 0 at
- * the phase boundaries; NULL disables it (default). */
+ * block run every interaction inside one workgroup): device buffer of int64 receiving cycle stamps -- entries [0, 128): thread 0
+ * of workgroup 0 at the phase boundaries; [128 + 4 b, 128 + 4 b + 4): start / end of workgroup b of the backward launch (real time and
+ * shader clock) -- so it must hold 128 + 4 * (number of groups) entries; NULL disables it (default). */
 void spk_schnet_mol_set_debug_buffer(void* device_buffer);
 
 /* ------------------------------------------------------------------ representation/painn.py:31-67

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
 
 // ------------------------------------------------------------------------------------------ host side
 static long long* g_mol_dbg = nullptr;
-// tuning aid (scripts/mol_timing.py; not declared in include/spk_hip.h): device buffer of int64 that receives cycle stamps -- entries
+// tuning aid (scripts/mol_timing.py; include/spk_hip.h): device buffer of int64 that receives cycle stamps -- entries
 // [0, 128): phases of thread 0 of workgroup 0; [128 + 4 b, 128 + 4 b + 4): real-time and cycle stamps at the start / end of workgroup b
 // of the backward launch, so the buffer must hold 128 + 4 * (number of groups) entries.  NULL: off (production)
 extern "C" void spk_schnet_mol_set_debug_buffer(void* p) { g_mol_dbg = (long long*)p; }
