@@ -56,6 +56,16 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="do not collect the HBM counters of the dominant kernel in this run")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the few eager force calls rocprofv3 --pmc wraps
     ap.add_argument("--md-steps", type=int, default=200)
+    ap.add_argument("--thermostat", default="auto", choices=["auto", "none", "pile"],
+                    help="--mode md --beads B: PILE-L NVT (300 K, tau = 100 fs; md_configs/dynamics/thermostat/pile_local.yaml).  auto = pile for ring polymers")
+    ap.add_argument("--bead-parallel", nargs="?", const="state", default=None, choices=["state", "forces"],
+                    help="--mode md --beads B --gpus N: ONE ring polymer of B beads spread over the N ranks (B / N beads each) instead of N "
+                         "independent replicas.  state: ranks hold only their beads, all-gather of (q, p) in the main step + one of p per "
+                         "thermostat application; forces: integrator state replicated, the one all-gather of a step carries the forces")
+    ap.add_argument("--no-painn", action="store_true", help="skip the `painn` sub-object (configs[2]) of the default line")
+    ap.add_argument("--no-train", action="store_true", help="skip the `train` sub-object (configs[3] per-GPU share) of the default line")
+    ap.add_argument("--no-pimd", action="store_true", help="skip `md.water_pimd` (configs[4]: PaiNN, 8 beads, RPMD + PILE-L) of the default line")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the `drop_in` sub-object (the reference's own NeuralNetworkPotential after install())")
     ap.add_argument("--dry-run", action="store_true", help="rank wiring only (launcher, process group, barrier, max-over-ranks reduction), no device work: for the CPU test of --gpus N")
     return ap.parse_args()
 
@@ -136,7 +146,7 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
-def collect_pmc(args, timeout_s=170):
+def collect_pmc(args, kind, workload, timeout_s=170):
     """HBM-side traffic per launch of every hot kernel, measured IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE and
     WRITE_SIZE do not share a pass on gfx950; kernel-trace only) over a child of this script that runs three eager force
     calls of the same workload.  Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: KiB per
@@ -156,7 +166,7 @@ def collect_pmc(args, timeout_s=170):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", out, "-o", "p", "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--kind", args.kind, "--workload", args.workload,
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--kind", kind, "--workload", workload,
                    "--frames", str(args.frames), "--water-side", str(args.water_side), "--variant", args.variant]
             env = dict(os.environ, TMPDIR="/tmp")
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -262,6 +272,354 @@ def sweep_measure(model, dev, kind, n_atoms=16384, degrees=(16, 32, 64), reps=10
     return {"kind": kind, "what": "representation forward + backward w.r.t. r_ij on fixed-degree graphs, eager launches, per GPU", "rows": rows}
 
 
+_WATER = {}
+
+
+def cached_water_box(n_side, seed):
+    """The synthetic bulk-water box (host-side construction takes seconds: built once per run)."""
+    from schnetpack_amd import synthetic as S
+    if (n_side, seed) not in _WATER:
+        _WATER[(n_side, seed)] = S.water_box(n_side=n_side, seed=seed)
+    return _WATER[(n_side, seed)]
+
+
+def algorithmic_work(kind, E, N, n_mol, F, n_int, n_rbf):
+    """tag -> (bound, ALGORITHMIC work per launch, executed share of it, perfect-reuse lower bound of the HBM bytes or None).
+    SURVEY.md section 8(d) per-unit figures x units per launch: cfconv forward E * 2 (n_rbf nf + nf^2)
+    FLOP per directed edge-message, backward 2x; PaiNN message forward E * 3100 + N * 4096 B (no-reuse gather convention),
+    backward 2x.  The pair kernels EXECUTE half of the forward figure (one filter per undirected pair) and the saved-filter
+    backward 352/608 of that.  B_min (section 8(d), perfect reuse): every atom row read / written once + 28 B of geometry and
+    indices per edge -- SchNet cfconv N * 2 * 4F + E * 28, PaiNN message N * (4096 + 2 * 12F) + E * 28."""
+    nf = F
+    flop_fwd = 2.0 * E * (n_rbf * nf + nf * nf)
+    msg_bytes = E * 3100.0 + N * 4096.0
+    bmin_cf = N * 8.0 * F + E * 28.0
+    bmin_msg = N * (4096.0 + 24.0 * F) + E * 28.0
+    bmin_msg0 = N * (4096.0 + 12.0 * F) + E * 28.0
+    flop_dense = 2.0 * N * 3 * F * F
+    # molecule-resident launches: per pair tile of 32 undirected pairs: hidden layer once (4 x 4 KPB MFMAs), GEMM 2 (4 x 64),
+    # incidence accumulation (4 x 32); per molecule and interaction three Dense layers on a 32-row tile (3 x 4 x 64); 1 MFMA = 4096 FLOP
+    tiles_mol = (E // 2 + 31 * n_mol) // 32
+    kpb = (n_rbf + 7) // 8
+    exec_mol = n_int * 4096.0 * (tiles_mol * 4 * (4 * kpb + 64 + 32) + n_mol * 3 * 4 * 64)
+    exec_mol_bwd = n_int * 4096.0 * (tiles_mol * 2 * (8 * kpb + 128) + n_mol * 3 * 4 * 64)
+    mol_f, mol_b = n_int * (flop_fwd + flop_dense), n_int * (2 * flop_fwd + flop_dense)
+    gs = 0.5 * 352.0 / 608.0
+    return {
+        "schnet_mol_fwd": ("mfma", mol_f, exec_mol / mol_f, n_int * bmin_cf), "schnet_mol_bwd": ("mfma", mol_b, exec_mol_bwd / mol_b, 2 * n_int * bmin_cf),
+        "cfconv_fwd_mfma": ("mfma", flop_fwd, 1.0, bmin_cf), "cfconv_fwd_simple": ("mfma", flop_fwd, 1.0, bmin_cf),
+        "cfconv_fwd_pair": ("mfma", flop_fwd, 0.5, bmin_cf),
+        "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd, 1.0, 2 * bmin_cf), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd, 1.0, 2 * bmin_cf),
+        "cfconv_bwd_simple": ("mfma", 2 * flop_fwd, 1.0, 2 * bmin_cf), "cfconv_bwd_pair": ("mfma", 2 * flop_fwd, 0.5, 2 * bmin_cf),
+        "cfconv_bwd_pair_gs": ("mfma", 2 * flop_fwd, gs, 2 * bmin_cf), "cfconv_bwd_pair_gs_geom": ("mfma", 2 * flop_fwd, gs, 2 * bmin_cf),
+        "painn_msg_fwd_row": ("hbm", msg_bytes, 1.0, bmin_msg), "painn_msg_fwd_simple": ("hbm", msg_bytes, 1.0, bmin_msg),
+        "painn_msg_bwd_row": ("hbm", 2 * msg_bytes, 1.0, 2 * bmin_msg), "painn_msg_bwd_simple": ("hbm", 2 * msg_bytes, 1.0, 2 * bmin_msg),
+        "painn_msg_fwd_tile": ("hbm", msg_bytes, 1.0, bmin_msg),
+        # first-interaction variants: mu == 0 (its 3F floats per neighbour are not gathered); geometry-only backward
+        # (c and mu of the neighbour: the forward's bytes; with mu == 0 only c)
+        "painn_msg_fwd_row_mu0": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0), "painn_msg_fwd_tile_mu0": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0),
+        "painn_msg_bwd_row_geom": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0), "painn_msg_bwd_tile_geom": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0),
+        "painn_msg_bwd_tile": ("hbm", 2 * msg_bytes, 1.0, 2 * bmin_msg),
+    }
+
+
+def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist, steps, warmup, with_pmc=True, with_cpu=True, cpu_reps=15):
+    """One eval-mode force-call measurement (the headline leg, and the `painn` sub-object of the default line): timed
+    graph replays bracketed by barriers, per-kernel HIP-event pass, roofline of the dominant kernel (+ in-run PMC traffic),
+    the reference on the host cores with the parity of this very batch.  Returns a dict; rank != 0 gets only the timing."""
+    from schnetpack_amd import _lib, model as M, synthetic as S
+    from schnetpack_amd.parallel import shard_frames
+    n_int, F, n_rbf, cutoff = 3, 128, 20, 5.0
+    # weak scaling: rank r owns frames [r*frames, (r+1)*frames) of one global seeded trajectory
+    lo, hi = shard_frames(args.frames * world, rank, world)
+    if workload == "water":
+        batch = cached_water_box(args.water_side, rank)   # one replica (bead) per rank
+    else:
+        batch = S.molecule_batch("aspirin", hi - lo, seed=1000 + rank if world > 1 else 0)
+    E = int(batch["idx_i"].shape[0])
+    N = int(batch["Z"].shape[0])
+    inp = M.batch_to_inputs(batch, dev)
+
+    def force_call():
+        out = model(dict(inp))
+        # detach: a live autograd graph from an earlier (default-stream) call would be pulled into
+        # the HIP-graph capture through the AccumulateGrad node of the positions
+        return out["energy"].detach(), out["forces"].detach()
+
+    if args.pmc_child:          # wrapped by `rocprofv3 --pmc` from collect_pmc(): a few eager calls, no output
+        for _ in range(3):
+            force_call()
+        torch.cuda.synchronize()
+        return None
+
+    for _ in range(max(warmup, 3)):
+        e_ref, f_ref = force_call()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    force_call()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                ge, gf = force_call()
+            g.replay()
+            torch.cuda.synchronize()
+            err = float((gf - f_ref).abs().max() / f_ref.abs().max())
+            if not (err < 1e-5):
+                raise RuntimeError("graph replay deviates from eager: %g" % err)
+            graph = g
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            sys.stderr.write("[bench] HIP graph capture unavailable (%s); running eager\n" % exc)
+            graph = None
+            torch.cuda.synchronize()
+
+    step = graph.replay if graph is not None else force_call
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if graph is not None:   # the LAST timed replay must still reproduce the eager result (not only the first one)
+        err = float((gf - f_ref).abs().max() / f_ref.abs().max())
+        if not (err < 1e-5):
+            raise RuntimeError("graph replay deviates from eager after the timed loop: %g" % err)
+    E_total = E
+    if dist is not None:
+        rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        et = torch.tensor([E], device=rdev, dtype=torch.float64)
+        dist.all_reduce(et, op=dist.ReduceOp.SUM)
+        E_total = int(et.item())
+    value = E_total * n_int * steps / dt / 1e6
+    res = {"value": value, "dt": dt, "steps": steps, "E": E, "N": N, "frames": hi - lo, "graph": graph is not None, "batch": batch, "inp": inp,
+           "e_ref": e_ref, "f_ref": f_ref, "n_int": n_int, "F": F, "n_rbf": n_rbf, "cutoff": cutoff}
+    if rank != 0:
+        return res
+
+    # ---------------- per-kernel timing (separate eager pass, HIP events on the launch stream)
+    _lib.profile_enable(True)
+    _lib.profile_report()
+    psteps = min(steps, 20)
+    for _ in range(psteps):
+        force_call()
+    prof = _lib.profile_report()
+    _lib.profile_enable(False)
+    n_mol = int(batch["n_mol"])
+    algo = algorithmic_work(kind, E, N, n_mol, F, n_int, n_rbf)
+    kernels = {}
+    for tag, (cnt, ms) in prof.items():
+        kernels[tag] = {"launches_per_step": cnt / psteps, "avg_us": 1e3 * ms / max(cnt, 1), "us_per_step": 1e3 * ms / psteps}
+    # every kernel with an algorithmic-work model also carries its own fraction of the peak (the N-sized PaiNN kernels: SURVEY.md
+    # section 8(d): mixing N * 360 kFLOP per interaction forward, 2x backward -- the backward launch leaves the channel-mix
+    # transpose to a chain launch, so its own share is the two transposed context layers + the products: N * 2 * 2 (2F F + F 3F))
+    mix_flop = N * 2.0 * (3 * F * 2 * F + 2 * F * F + F * 3 * F)
+    algo_n = {"painn_mixing_fwd": mix_flop, "painn_mixing_bwd": N * 4.0 * (2 * F * F + F * 3 * F)}
+    FLAG = "exceeds 1: the algorithmic convention of SURVEY.md 8(d) books more work than this kernel issues (one filter per undirected pair, saved filters, cache-resident gathers); read executed_frac_of_peak / traffic instead"
+    for tag, kd in kernels.items():
+        if tag in algo:
+            bound, work, executed, bmin = algo[tag]
+            peak = MFMA_F32_PEAK_TFLOPS * 1e12 if bound == "mfma" else HBM_PEAK_GBS * 1e9
+            kd["frac_of_peak"] = round(work / (kd["avg_us"] * 1e-6) / peak, 4)
+            kd["executed_frac_of_peak"] = round(executed * kd["frac_of_peak"], 4)
+            kd["bound"] = bound
+            if kd["frac_of_peak"] > 1.0:
+                kd["frac_flag"] = FLAG
+        elif tag in algo_n:
+            kd["frac_of_peak"] = round(algo_n[tag] / (kd["avg_us"] * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
+            kd["bound"] = "mfma"
+    cand = [t for t in kernels if t in algo]
+    roofline = None
+    if cand:
+        # dominant kernel: compile-time variants of one kernel (the first-interaction forms "_geom" / "_mu0") count as
+        # one family when ranking; the family's main member is the one reported
+        fam = lambda t: t.replace("_geom", "").replace("_mu0", "")
+        fam_time = {}
+        for t in cand:
+            fam_time[fam(t)] = fam_time.get(fam(t), 0.0) + kernels[t]["us_per_step"]
+        top = max(fam_time, key=fam_time.get)
+        dom = max([t for t in cand if fam(t) == top], key=lambda t: kernels[t]["us_per_step"])
+        bound, work, executed, bmin = algo[dom]
+        sec = kernels[dom]["avg_us"] * 1e-6
+        if bound == "mfma":
+            ach, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "avg_launch_us": round(kernels[dom]["avg_us"], 2), "algorithmic_per_launch": work,
+                    "executed_frac_of_peak": round(executed * ach / peak, 4),
+                    "B_min_bytes_per_launch": bmin,
+                    "B_min_note": "perfect-reuse lower bound of the HBM bytes of this launch (SURVEY.md 8(d)): every atom row once + 28 B per edge; "
+                                  "time at the HBM peak = %.2f us" % (bmin / (HBM_PEAK_GBS * 1e9) * 1e6),
+                    "note": "achieved = algorithmic work / HIP-event time of the launch; executed_frac_of_peak counts only the "
+                            "work the kernel really issues (pair kernels evaluate one filter per undirected edge)"}
+        if roofline["frac"] > 1.0:
+            roofline["frac_flag"] = FLAG
+
+    # HBM traffic of the dominant kernel, measured in THIS run (collect_pmc: two `rocprofv3 --pmc` passes over a child of
+    # this script); the committed record of an earlier run is only the fallback, and says which kernel revision it is from
+    pmc = None
+    if roofline is not None and world == 1 and with_pmc and not args.no_pmc:
+        pmc = collect_pmc(args, kind, workload)
+    if roofline is not None and pmc is not None and roofline["kernel"] in pmc and "read_bytes" in pmc[roofline["kernel"]] and "write_bytes" in pmc[roofline["kernel"]]:
+        c = pmc[roofline["kernel"]]
+        roofline["traffic"] = c["read_bytes"] + c["write_bytes"]
+        roofline["traffic_over_B_min"] = round(roofline["traffic"] / bmin, 2) if bmin else None
+        roofline["traffic_frac_of_hbm_peak"] = round(roofline["traffic"] / (kernels[roofline["kernel"]]["avg_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
+        roofline["traffic_detail"] = {"read_bytes": c["read_bytes"], "write_bytes": c["write_bytes"], "kernel_name": c["kernel_name"],
+                                      "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over 3 eager "
+                                                "force calls of this workload; KiB per dispatch, FETCH_SIZE x 2 (gfx950); Infinity-Cache hits are counted",
+                                      "csrc_digest": csrc_digest(),
+                                      "all_kernels": {t: {"read_bytes": v.get("read_bytes"), "write_bytes": v.get("write_bytes")} for t, v in pmc.items()}}
+    else:
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_%s_%s.json" % (kind, workload))
+        if roofline is not None and os.path.exists(pmc_file):
+            try:
+                rec = json.load(open(pmc_file))
+                c = rec["counters"].get(roofline["kernel"])
+                if c and "FETCH_SIZE_raw_per_launch" in c and "WRITE_SIZE_raw_per_launch" in c:
+                    rd = 2.0 * 1024.0 * c["FETCH_SIZE_raw_per_launch"]
+                    wr = 1024.0 * c["WRITE_SIZE_raw_per_launch"]
+                    roofline["traffic"] = rd + wr
+                    roofline["traffic_detail"] = {"read_bytes": rd, "write_bytes": wr, "source": os.path.relpath(pmc_file, ROOT) + " (committed record of an earlier run)",
+                                                  "record_csrc_digest": rec.get("csrc_digest"), "csrc_digest": csrc_digest(),
+                                                  "record_is_current": rec.get("csrc_digest") == csrc_digest()}
+            except Exception as exc:  # pragma: no cover
+                sys.stderr.write("[bench] could not read %s: %s\n" % (pmc_file, exc))
+
+    # context for `roofline` (which, per contract, is about the dominant launch): every launch of one force call with an algorithmic-work
+    # model over the wall time of the call
+    if roofline is not None:
+        try:
+            b = roofline["bound"]
+            tot = sum(algo[t][1] * kernels[t]["launches_per_step"] for t in kernels if t in algo and algo[t][0] == b)
+            sec = dt / steps
+            if b == "mfma":
+                roofline["force_call"] = {"algorithmic_flop": tot, "achieved": round(tot / sec / 1e12, 3), "unit": "TFLOP/s",
+                                          "frac": round(tot / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                          "note": "algorithmic FLOP of every MFMA-bound launch of one force call / wall time of the call"}
+            else:
+                whole = 3.0 * n_int * (E * 3100.0 + 2 * N * 4096.0)       # SURVEY.md 8(d): B_force = 3 sum_layers (message + mixing) forward bytes
+                roofline["force_call"] = {"algorithmic_bytes": whole, "achieved": round(whole / sec / 1e9, 1), "unit": "GB/s",
+                                          "frac": round(whole / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                          "note": "SURVEY.md 8(d) B_force = 3 x sum over interactions of (message + mixing) forward bytes / wall time of the call"}
+        except Exception:  # pragma: no cover
+            pass
+
+    # ---------------- CPU baseline: the reference's own modules on the host cores (SURVEY.md section 8(d)), same batch, same
+    # weights; the oracle restatement ("port") only where the reference is not available
+    cpu = None
+    if world == 1 and with_cpu and not args.no_cpu_baseline:
+        # torch's intra-op pool stops scaling (and then degrades) on these small per-op sizes well before
+        # the 100+ cores of a GPU host; 16 threads is the bounded, stated sample configuration
+        ncores = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(ncores)
+        ref_model = reference_model(kind, rep_p, head_p, F, n_int, n_rbf, cutoff)
+        if ref_model is not None:
+            def cpu_call():
+                o = ref_model(reference_inputs(batch))     # fresh tensors per call: the model writes into the dict
+                return {"energy": o["energy"].detach(), "forces": o["forces"].detach()}
+            kind_ = "reference"
+        else:
+            from oracle import spk_oracle as O          # test infrastructure: the CPU restatement, timed as the baseline
+            cpu_call = lambda: O.energy_and_forces(kind, rep_p, head_p, batch, n_int)
+            kind_ = "port"
+        c0 = time.perf_counter()
+        oc = cpu_call()
+        first = time.perf_counter() - c0
+        reps = max(1, min(cpu_reps, int(20.0 / max(first, 1e-3))))      # bounded sample: about 20 s of CPU work at most
+        ts = []
+        for _ in range(reps):
+            c0 = time.perf_counter()
+            oc = cpu_call()
+            ts.append(time.perf_counter() - c0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        df = (f_ref.cpu() - oc["forces"]).double()
+        cpu = {"value": round(E * n_int / med / 1e6, 4), "unit": "M edge-messages/s", "cores": ncores, "kind": kind_,
+               "sample": "same %s, median of %d force calls (%.2f s each) of %s, torch %s fp32 CPU" % (
+                   "%d-frame batch" % (hi - lo) if workload == "aspirin" else "%d-atom box" % N, reps, med,
+                   "the reference's NeuralNetworkPotential (PairwiseDistances + representation + Atomwise + Forces) via oracle/refshim.py" if kind_ == "reference" else "the oracle restatement",
+                   torch.__version__),
+               "parity_rel_forces": float(df.abs().max() / oc["forces"].abs().max()),
+               "parity_rms_forces": float(df.pow(2).mean().sqrt() / oc["forces"].double().pow(2).mean().sqrt()),
+               "parity_rel_energy": float((e_ref.cpu() - oc["energy"]).abs().max() / oc["energy"].abs().max())}
+    res.update({"kernels": kernels, "roofline": roofline, "cpu": cpu})
+    return res
+
+
+def drop_in_measure(args, dev, rep_p, head_p, batch, f_hip, steps=50):
+    """north_star's "callers stay untouched": the REFERENCE's own NeuralNetworkPotential / Atomwise / Forces code (from
+    oracle/_ref resp. /root/reference -- the callers, not a result oracle) around the HIP classes after
+    schnetpack_amd.install.install(), eager and through the opt-in ``fused_potential`` route that hands the standard potential
+    to the two-launch operator.  Returns edge-messages/s of both and the agreement with the mirror model's forces."""
+    from oracle import refshim
+    if not refshim.available():
+        return None
+    import schnetpack_amd.install as inst
+    ns = refshim.load()
+    import numpy as np
+    sys.modules["ase.data"].atomic_masses = np.ones(119)
+    E = int(batch["idx_i"].shape[0])
+    out = {"what": "the reference's NeuralNetworkPotential(+ its Atomwise, Forces) on cuda:0 after schnetpack_amd.install.install(): the representation, "
+                   "PairwiseDistances, Dense and scatter_add underneath are the HIP classes; same batch, same weights, eager calls (the reference "
+                   "model allocates its outputs per call), median-free mean over %d calls" % steps}
+    try:
+        for label, kw in (("module_by_module", {}), ("fused_potential", {"fused_head": True, "fused_potential": True})):
+            inst.install(sys.modules["schnetpack"], **kw)
+            try:
+                spk = sys.modules["schnetpack"]
+                rb, cf = spk.nn.GaussianRBF(20, 5.0), spk.nn.CosineCutoff(5.0)
+                rep = sys.modules["schnetpack.representation.schnet"].SchNet(128, 3, rb, cf)
+                aw = sys.modules["schnetpack.atomistic.atomwise"].Atomwise(n_in=128, output_key="energy")
+                pd = sys.modules["schnetpack.atomistic.distances"].PairwiseDistances()
+                m = ns.model.NeuralNetworkPotential(rep, input_modules=[pd], output_modules=[aw, ns.response.Forces()])
+                m.representation.load_state_dict(rep_p)
+                m.output_modules[0].load_state_dict(head_p)
+                m = m.to(dev).eval()
+                ri = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in reference_inputs(batch).items()}
+
+                def call():
+                    d = dict(ri)
+                    d["_positions"] = ri["_positions"].detach().clone()
+                    o = m(d)
+                    return o["forces"].detach()
+                for _ in range(5):
+                    f = call()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    f = call()
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - t0) / steps
+                out[label] = {"ms_per_call": round(ms, 4), "M_edge_messages_per_s": round(E * 3 / ms / 1e3, 1),
+                              "model_class": type(m).__module__ + "." + type(m).__name__,
+                              "rel_diff_forces_vs_mirror_model": float((f - f_hip).abs().max() / f_hip.abs().max())}
+            finally:
+                inst.uninstall()
+    except Exception as exc:  # pragma: no cover
+        out["error"] = str(exc)[:300]
+    return out
+
+
 def main():
     import faulthandler
     faulthandler.enable()
@@ -294,229 +652,52 @@ def main():
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from schnetpack_amd import _lib, model as M, synthetic as S
-    from schnetpack_amd.parallel import shard_frames
 
     _lib.set_variant({"auto": _lib.VARIANT_AUTO, "simple": _lib.VARIANT_SIMPLE, "mfma": _lib.VARIANT_MFMA,
                       "directed": _lib.VARIANT_MFMA_DIRECTED, "pair": _lib.VARIANT_MFMA_PAIR, "mol": _lib.VARIANT_MFMA_MOL}[args.variant])
     if os.environ.get("SPK_CHAIN_ROWS"):      # tuning hook: force the row-tile height of the fused Dense chains
         _lib.lib().spk_chain_set_rows(int(os.environ["SPK_CHAIN_ROWS"]))
     n_int, F, n_rbf, cutoff = 3, 128, 20, 5.0
-    # random-init weights of the named architecture (seeded; the package's own initialisation, which follows the
-    # reference's: xavier_uniform Dense weights, zero biases, N(0, 1) embedding).  Host copies with the reference's
-    # state_dict keys are kept for the cpu_baseline leg -- the only place the oracle is imported.
-    torch.manual_seed(0)
-    model = M.build_model(args.kind, F, n_int, n_rbf, cutoff)
-    rep_p = {k: v.detach().clone() for k, v in model.representation.state_dict().items()}
-    head_p = {k: v.detach().clone() for k, v in model.output_modules[0].state_dict().items()}
-    model = model.to(dev).eval()
+
+    def make_model(kind):
+        # random-init weights of the named architecture (seeded; the package's own initialisation, which follows the
+        # reference's: xavier_uniform Dense weights, zero biases, N(0, 1) embedding).  Host copies with the reference's
+        # state_dict keys are kept for the cpu_baseline leg -- the only place the oracle is imported.
+        torch.manual_seed(0)
+        m = M.build_model(kind, F, n_int, n_rbf, cutoff)
+        rp = {k: v.detach().clone() for k, v in m.representation.state_dict().items()}
+        hp = {k: v.detach().clone() for k, v in m.output_modules[0].state_dict().items()}
+        return m.to(dev).eval(), rp, hp
+
+    model, rep_p, head_p = make_model(args.kind)
 
     if args.mode == "train":
-        return train_main(args, rank, world, dev, dist, model, rep_p, head_p)
+        line = train_measure(args, args.kind, rank, world, dev, dist, model, rep_p, head_p, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps(line))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.mode == "md":
         return md_main(args, rank, world, dev, dist, model)
 
-    # weak scaling: rank r owns frames [r*frames, (r+1)*frames) of one global seeded trajectory
-    lo, hi = shard_frames(args.frames * world, rank, world)
-    if args.workload == "water":
-        batch = S.water_box(n_side=args.water_side, seed=rank)   # one replica (bead) per rank
-    else:
-        batch = S.molecule_batch("aspirin", hi - lo, seed=1000 + rank if world > 1 else 0)
-    E = int(batch["idx_i"].shape[0])
-    N = int(batch["Z"].shape[0])
-    inp = M.batch_to_inputs(batch, dev)
-
-    def force_call():
-        out = model(dict(inp))
-        # detach: a live autograd graph from an earlier (default-stream) call would be pulled into
-        # the HIP-graph capture through the AccumulateGrad node of the positions
-        return out["energy"].detach(), out["forces"].detach()
-
-    if args.pmc_child:          # wrapped by `rocprofv3 --pmc` from collect_pmc(): a few eager calls, no output
-        for _ in range(3):
-            force_call()
-        torch.cuda.synchronize()
+    r = eval_leg(args, args.kind, args.workload, model, rep_p, head_p, rank, world, dev, dist, args.steps, args.warmup, cpu_reps=args.cpu_reps)
+    if r is None:       # --pmc-child
         return
-
-    for _ in range(max(args.warmup, 3)):
-        e_ref, f_ref = force_call()
-    torch.cuda.synchronize()
-
-    graph = None
-    if not args.no_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    force_call()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                ge, gf = force_call()
-            g.replay()
-            torch.cuda.synchronize()
-            err = float((gf - f_ref).abs().max() / f_ref.abs().max())
-            if not (err < 1e-5):
-                raise RuntimeError("graph replay deviates from eager: %g" % err)
-            graph = g
-        except Exception as exc:  # pragma: no cover - depends on the runtime
-            sys.stderr.write("[bench] HIP graph capture unavailable (%s); running eager\n" % exc)
-            graph = None
-            torch.cuda.synchronize()
-
-    step = graph.replay if graph is not None else force_call
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if graph is not None:   # the LAST timed replay must still reproduce the eager result (not only the first one)
-        err = float((gf - f_ref).abs().max() / f_ref.abs().max())
-        if not (err < 1e-5):
-            raise RuntimeError("graph replay deviates from eager after the timed loop: %g" % err)
-    E_total = E
-    if dist is not None:
-        rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        et = torch.tensor([E], device=rdev, dtype=torch.float64)
-        dist.all_reduce(et, op=dist.ReduceOp.SUM)
-        E_total = int(et.item())
-    value = E_total * n_int * args.steps / dt / 1e6
-
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-
-    # ---------------- per-kernel timing (separate eager pass, HIP events on the launch stream)
-    _lib.profile_enable(True)
-    _lib.profile_report()
-    psteps = min(args.steps, 20)
-    for _ in range(psteps):
-        force_call()
-    prof = _lib.profile_report()
-    _lib.profile_enable(False)
-    nf = F
-    # ALGORITHMIC work per launch (SURVEY.md section 8(d) per-unit figures x units per launch; DESIGN.md
-    # section 5): forward E * 2 (n_rbf nf + nf^2) FLOP per directed edge-message, backward 2x.  The
-    # pair kernels EXECUTE half of the forward figure (one filter per undirected pair) and the
-    # saved-filter backward executes 352/304 of the (halved) forward figure.
-    flop_fwd = 2.0 * E * (n_rbf * nf + nf * nf)
-    msg_bytes = E * 3100.0 + N * 4096.0
-    # molecule-resident forward (all interactions in one launch): the filter GEMMs of every interaction + the three Dense
-    # layers per interaction; executed = pair-shared filters, GEMM 1 repeated per channel tile, atom rows padded to 32
-    flop_dense = 2.0 * N * 3 * F * F
-    n_mol = int(batch["n_mol"])
-    # per pair tile of 32 undirected pairs: hidden layer once (4 x 4 KPB MFMAs), GEMM 2 (4 x 64), incidence accumulation (4 x 32);
-    # per molecule and interaction three Dense layers on a 32-row tile (3 x 4 x 64); one MFMA = 4096 FLOP
-    tiles_mol = (E // 2 + 31 * n_mol) // 32
-    exec_mol = n_int * 4096.0 * (tiles_mol * 4 * (4 * ((n_rbf + 7) // 8) + 64 + 32) + n_mol * 3 * 4 * 64)
-    exec_mol_bwd = n_int * 4096.0 * (tiles_mol * 2 * (8 * ((n_rbf + 7) // 8) + 128) + n_mol * 3 * 4 * 64)
-    algo = {
-        "schnet_mol_fwd": ("mfma", n_int * (flop_fwd + flop_dense), exec_mol / (n_int * (flop_fwd + flop_dense))),
-        # backward: value + derivative through the filter MLP (2x the forward figure, section 8(d)) + the three transposed Dense layers
-        "schnet_mol_bwd": ("mfma", n_int * (2 * flop_fwd + flop_dense), exec_mol_bwd / (n_int * (2 * flop_fwd + flop_dense))),
-        "cfconv_fwd_mfma": ("mfma", flop_fwd, 1.0), "cfconv_fwd_simple": ("mfma", flop_fwd, 1.0),
-        "cfconv_fwd_pair": ("mfma", flop_fwd, 0.5),
-        "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd, 1.0), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd, 1.0),
-        "cfconv_bwd_simple": ("mfma", 2 * flop_fwd, 1.0), "cfconv_bwd_pair": ("mfma", 2 * flop_fwd, 0.5),
-        "cfconv_bwd_pair_gs": ("mfma", 2 * flop_fwd, 0.5 * 352.0 / 608.0), "cfconv_bwd_pair_gs_geom": ("mfma", 2 * flop_fwd, 0.5 * 352.0 / 608.0),
-        "painn_msg_fwd_row": ("hbm", msg_bytes, 1.0), "painn_msg_fwd_simple": ("hbm", msg_bytes, 1.0),
-        "painn_msg_bwd_row": ("hbm", 2 * msg_bytes, 1.0), "painn_msg_bwd_simple": ("hbm", 2 * msg_bytes, 1.0),
-        "painn_msg_fwd_tile": ("hbm", msg_bytes, 1.0),
-        # first-interaction variants: mu == 0 (its 3F floats per neighbour are not gathered); geometry-only backward
-        # (c and mu of the neighbour: the forward's bytes; with mu == 0 only c)
-        "painn_msg_fwd_row_mu0": ("hbm", E * 1564.0 + N * 4096.0, 1.0), "painn_msg_fwd_tile_mu0": ("hbm", E * 1564.0 + N * 4096.0, 1.0),
-        "painn_msg_bwd_row_geom": ("hbm", E * 1564.0 + N * 4096.0, 1.0), "painn_msg_bwd_tile_geom": ("hbm", E * 1564.0 + N * 4096.0, 1.0),
-        "painn_msg_bwd_tile": ("hbm", 2 * msg_bytes, 1.0),
-    }
-    kernels = {}
-    for tag, (cnt, ms) in prof.items():
-        kernels[tag] = {"launches_per_step": cnt / psteps, "avg_us": 1e3 * ms / max(cnt, 1), "us_per_step": 1e3 * ms / psteps}
-    # every kernel with an algorithmic-work model also carries its own fraction of the peak (the N-sized PaiNN kernels: SURVEY.md
-    # section 8(d): mixing N * 360 kFLOP per interaction forward, 2x backward -- the backward launch leaves the channel-mix
-    # transpose to a chain launch, so its own share is the two transposed context layers + the products: N * 2 * 2 (2F F + F 3F))
-    mix_flop = N * 2.0 * (3 * F * 2 * F + 2 * F * F + F * 3 * F)
-    algo_n = {"painn_mixing_fwd": mix_flop, "painn_mixing_bwd": N * 4.0 * (2 * F * F + F * 3 * F)}
-    for tag, kd in kernels.items():
-        if tag in algo:
-            bound, work, _ = algo[tag]
-            kd["frac_of_peak"] = round(work / (kd["avg_us"] * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12 if bound == "mfma" else HBM_PEAK_GBS * 1e9), 4)
-            kd["bound"] = bound
-        elif tag in algo_n:
-            kd["frac_of_peak"] = round(algo_n[tag] / (kd["avg_us"] * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
-            kd["bound"] = "mfma"
-    cand = [t for t in kernels if t in algo]
-    roofline = None
-    if cand:
-        # dominant kernel: compile-time variants of one kernel (the first-interaction forms "_geom" / "_mu0") count as
-        # one family when ranking; the family's main member is the one reported
-        fam = lambda t: t.replace("_geom", "").replace("_mu0", "")
-        fam_time = {}
-        for t in cand:
-            fam_time[fam(t)] = fam_time.get(fam(t), 0.0) + kernels[t]["us_per_step"]
-        top = max(fam_time, key=fam_time.get)
-        dom = max([t for t in cand if fam(t) == top], key=lambda t: kernels[t]["us_per_step"])
-        bound, work, executed = algo[dom]
-        sec = kernels[dom]["avg_us"] * 1e-6
-        if bound == "mfma":
-            ach, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-        else:
-            ach, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
-        roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": None,
-                    "avg_launch_us": round(kernels[dom]["avg_us"], 2), "algorithmic_per_launch": work,
-                    "executed_frac_of_peak": round(executed * ach / peak, 4),
-                    "note": "achieved = algorithmic work / HIP-event time of the launch; executed_frac_of_peak counts only the "
-                            "work the kernel really issues (pair kernels evaluate one filter per undirected edge)"}
-
-    # HBM traffic of the dominant kernel, measured in THIS run (collect_pmc: two `rocprofv3 --pmc` passes over a child of
-    # this script); the committed record of an earlier run is only the fallback, and says which kernel revision it is from
-    pmc = None
-    if roofline is not None and world == 1 and not args.no_pmc:
-        pmc = collect_pmc(args)
-    if roofline is not None and pmc is not None and roofline["kernel"] in pmc and "read_bytes" in pmc[roofline["kernel"]] and "write_bytes" in pmc[roofline["kernel"]]:
-        c = pmc[roofline["kernel"]]
-        roofline["traffic"] = c["read_bytes"] + c["write_bytes"]
-        roofline["traffic_detail"] = {"read_bytes": c["read_bytes"], "write_bytes": c["write_bytes"], "kernel_name": c["kernel_name"],
-                                      "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over 3 eager "
-                                                "force calls of this workload; KiB per dispatch, FETCH_SIZE x 2 (gfx950); Infinity-Cache hits are counted",
-                                      "csrc_digest": csrc_digest(),
-                                      "all_kernels": {t: {"read_bytes": v.get("read_bytes"), "write_bytes": v.get("write_bytes")} for t, v in pmc.items()}}
-    else:
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_%s_%s.json" % (args.kind, args.workload))
-        if roofline is not None and os.path.exists(pmc_file):
-            try:
-                rec = json.load(open(pmc_file))
-                c = rec["counters"].get(roofline["kernel"])
-                if c and "FETCH_SIZE_raw_per_launch" in c and "WRITE_SIZE_raw_per_launch" in c:
-                    rd = 2.0 * 1024.0 * c["FETCH_SIZE_raw_per_launch"]
-                    wr = 1024.0 * c["WRITE_SIZE_raw_per_launch"]
-                    roofline["traffic"] = rd + wr
-                    roofline["traffic_detail"] = {"read_bytes": rd, "write_bytes": wr, "source": os.path.relpath(pmc_file, ROOT) + " (committed record of an earlier run)",
-                                                  "record_csrc_digest": rec.get("csrc_digest"), "csrc_digest": csrc_digest(),
-                                                  "record_is_current": rec.get("csrc_digest") == csrc_digest()}
-            except Exception as exc:  # pragma: no cover
-                sys.stderr.write("[bench] could not read %s: %s\n" % (pmc_file, exc))
+    value, dt, E, N, batch, inp = r["value"], r["dt"], r["E"], r["N"], r["batch"], r["inp"]
+    kernels, roofline, cpu = r["kernels"], r["roofline"], r["cpu"]
+    default_line = world == 1 and args.kind == "schnet" and args.workload == "aspirin"
 
     # ---------------- scatter_add op alone (north_star: HBM roofline of the segmented sum) and the measured copy
     # bandwidth of this box beside it (fraction of nominal AND of measured copy bandwidth).
     # Both are timed as 50 launches inside ONE HIP graph (no host launch gaps), with events around the replay.
-    from schnetpack_amd import ops
     xs = torch.randn(E, F, device=dev)
     idx = inp["_idx_i"]
+    from schnetpack_amd import ops
     rp = ops.segment_rowptr(idx, N)
     src = torch.empty(64 * 1024 * 1024, device=dev)     # 256 MB: beyond the Infinity Cache together with dst
     dst = torch.empty_like(src)
@@ -569,44 +750,6 @@ def main():
     nbl = {"pairs": int(nl["_idx_i"].shape[0]), "matches_input_list": int(nl["_idx_i"].shape[0]) == E,
            "build_ms": round(1e3 * t_nl[len(t_nl) // 2], 4), "M_pairs_per_s": round(E / t_nl[len(t_nl) // 2] / 1e6, 1),
            "note": "count + fill incl. allocation and the one D2H of the pair count (wall clock, median of 5)"}
-
-    # ---------------- CPU baseline: the reference's own modules on the host cores, same batch, same
-    # weights; the oracle restatement ("port") only where the reference is not available
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        # torch's intra-op pool stops scaling (and then degrades) on these small per-op sizes well before
-        # the 100+ cores of a GPU host; 16 threads is the bounded, stated sample configuration
-        ncores = min(os.cpu_count() or 1, 16)
-        torch.set_num_threads(ncores)
-        ref_model = reference_model(args.kind, rep_p, head_p, F, n_int, n_rbf, cutoff)
-        if ref_model is not None:
-            def cpu_call():
-                o = ref_model(reference_inputs(batch))     # fresh tensors per call: the model writes into the dict
-                return {"energy": o["energy"].detach(), "forces": o["forces"].detach()}
-            kind_ = "reference"
-        else:
-            from oracle import spk_oracle as O          # test infrastructure: the CPU restatement, timed as the baseline
-            cpu_call = lambda: O.energy_and_forces(args.kind, rep_p, head_p, batch, n_int)
-            kind_ = "port"
-        c0 = time.perf_counter()
-        oc = cpu_call()
-        first = time.perf_counter() - c0
-        reps = max(1, min(args.cpu_reps, int(20.0 / max(first, 1e-3))))      # bounded sample: about 20 s of CPU work
-        ts = []
-        for _ in range(reps):
-            c0 = time.perf_counter()
-            oc = cpu_call()
-            ts.append(time.perf_counter() - c0)
-        ts.sort()
-        med = ts[len(ts) // 2]
-        cpu = {"value": round(E * n_int / med / 1e6, 4), "unit": "M edge-messages/s", "cores": ncores, "kind": kind_,
-               "sample": "same %s, median of %d force calls (%.2f s each) of %s, torch %s fp32 CPU" % (
-                   "%d-frame batch" % (hi - lo) if args.workload == "aspirin" else "%d-atom box" % N, reps, med,
-                   "the reference's NeuralNetworkPotential (PairwiseDistances + representation + Atomwise + Forces) via oracle/refshim.py" if kind_ == "reference" else "the oracle restatement",
-                   torch.__version__),
-               "parity_rel_forces": float((f_ref.cpu() - oc["forces"]).abs().max() / oc["forces"].abs().max()),
-               "parity_rel_energy": float((e_ref.cpu() - oc["energy"]).abs().max() / oc["energy"].abs().max())}
-
     if cpu is not None and args.workload == "aspirin":
         # the reference's per-molecule TorchNeighborList loop, restated (oracle/nbl_oracle.py), same batch
         from oracle import nbl_oracle as NB
@@ -615,74 +758,123 @@ def main():
         nbl["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - c0), 2)
         nbl["cpu_oracle_pairs"] = int(oi.shape[0])
 
+    # ---------------- configs[2]: the same 256-frame batch through PaiNN (default line only)
+    painn = None
+    painn_model = None
+    if default_line and not args.no_painn:
+        try:
+            painn_model, p_rep, p_head = make_model("painn")
+            pr = eval_leg(args, "painn", "aspirin", painn_model, p_rep, p_head, 0, 1, dev, None, min(args.steps, 100), min(args.warmup, 10), cpu_reps=3)
+            painn = {"metric": "M edge-messages/s (eval force call, MD17-aspirin 256-frame batch, PaiNN)", "value": round(pr["value"], 2),
+                     "unit": "M edge-messages/s", "ms_per_step": round(1e3 * pr["dt"] / pr["steps"], 4), "steps": pr["steps"], "hip_graph": pr["graph"],
+                     "config": {"workload": "configs[2]: MD17 aspirin x %d frames, PaiNN(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0) + Atomwise + Forces; "
+                                            "N=%d atoms, E=%d directed edges" % (pr["frames"], pr["N"], pr["E"])},
+                     "roofline": pr["roofline"], "cpu_baseline": pr["cpu"], "kernels": pr["kernels"]}
+        except Exception as exc:  # pragma: no cover
+            painn = {"error": str(exc)[:300]}
+
+    # ---------------- configs[3] per-GPU share: one AdamW step of the force-matching loss, PaiNN and SchNet
+    train = None
+    if default_line and not args.no_train:
+        train = {}
+        for k in ("painn", "schnet"):
+            try:
+                tm, t_rep, t_head = make_model(k)
+                tl = train_measure(args, k, 0, 1, dev, None, tm, t_rep, t_head, steps=100, warmup=8)
+                train[k] = {kk: tl[kk] for kk in ("metric", "value", "unit", "ms_per_step", "steps", "config", "cpu_baseline", "launches_per_step", "roofline")}
+                del tm
+            except Exception as exc:  # pragma: no cover
+                train[k] = {"error": str(exc)[:300]}
+        torch.cuda.empty_cache()
+
     # ---------------- the other half of BASELINE's metric: MD ns/day (on-device NVE loop, rows f1-f3), aspirin x 256 and the
-    # 32k-atom water box, same model kind; and north_star's padded-neighbour sweep
+    # 32k-atom water box, same model kind; configs[4] as stated: PaiNN, 8 beads, RPMD 0.2 fs + PILE-L NVT on the full box
     md = None
     if world == 1 and not args.no_md:
         md = {}
+        keys = ("ns_per_day", "ms_per_step", "n_atoms", "pairs_in_list", "trajectories", "rebuilds", "fraction_in_rebuilds", "dt_fs", "steps", "hip_graph")
         for wl in ("aspirin", "water"):
             try:
-                r = md_run(args, model, dev, wl, 0, 1, None, steps=args.md_steps if wl == "aspirin" else max(args.md_steps // 4, 20), warmup=10)
-                md[wl] = {k: r[k] for k in ("ns_per_day", "ms_per_step", "n_atoms", "pairs_in_list", "trajectories", "rebuilds", "fraction_in_rebuilds", "dt_fs", "steps", "hip_graph")}
+                rr = md_run(args, model, dev, wl, 0, 1, None, steps=args.md_steps if wl == "aspirin" else max(args.md_steps // 4, 20), warmup=10)
+                md[wl] = {k: rr[k] for k in keys}
             except Exception as exc:  # pragma: no cover
                 md[wl] = {"error": str(exc)[:200]}
         md["note"] = ("NVE velocity Verlet, 0.5 fs, one HIP-graph replay per step; ns/day per trajectory.  Water box: device neighbour list with a "
                       "%.1f A skin.  Aspirin batch: isolated molecules of <= 28 atoms keep the COMPLETE intramolecular list (an infinite skin: no "
                       "rebuilds, no host synchronisation; pairs beyond the cutoff get no tile in the kernels)" % args.md_shell)
+        if default_line and not args.no_pimd:
+            try:
+                if painn_model is None:
+                    painn_model, _, _ = make_model("painn")
+                torch.cuda.empty_cache()
+                rr = md_run(args, painn_model, dev, "water", 0, 1, None, steps=30, warmup=6, beads=8, thermostat="pile")
+                md["water_pimd"] = {k: rr[k] for k in keys + ("beads", "thermostat", "ms_per_rebuild", "kinetic_temperature_K", "collectives_per_step")}
+                md["water_pimd"]["what"] = ("configs[4] on ONE GPU: 31 944-atom bulk-water PBC box, PaiNN(128, 3, 20, 5.0), ring-polymer MD with 8 beads folded into "
+                                            "the batch (8 x 31 944 atoms per force call), 0.2 fs, PILE-L thermostat (300 K, tau = 100 fs) at step begin and end = NVT; "
+                                            "units A / Dalton / ps; ns/day of the ring polymer")
+            except Exception as exc:  # pragma: no cover
+                md["water_pimd"] = {"error": str(exc)[:300]}
     sweep = None
     if world == 1 and not args.no_sweep:
         try:
             sweep = sweep_measure(model, dev, args.kind)
         except Exception as exc:  # pragma: no cover
             sweep = {"error": str(exc)[:200]}
+    drop_in = None
+    if default_line and not args.no_drop_in and not args.no_cpu_baseline:
+        drop_in = drop_in_measure(args, dev, rep_p, head_p, batch, r["f_ref"])
 
-    # context for `roofline` (which, per contract, is about the dominant launch): all MFMA-bound launches of one force call over the
-    # wall time of the call (cfg 2: the two molecule-resident launches and the gaps between them)
-    if roofline is not None and roofline.get("bound") == "mfma":
-        try:
-            tot = sum(algo[t][1] * kernels[t]["launches_per_step"] for t in kernels if t in algo and algo[t][0] == "mfma")
-            sec = dt / args.steps
-            roofline["force_call"] = {"algorithmic_flop": tot, "achieved": round(tot / sec / 1e12, 3), "unit": "TFLOP/s",
-                                      "frac": round(tot / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                                      "note": "algorithmic FLOP of every MFMA-bound launch of one force call / wall time of the call"}
-        except Exception:  # pragma: no cover
-            pass
     info = _lib.device_info()
+    hi_lo = r["frames"]
     line = {
         "metric": "M edge-messages/s (eval force call, %s, %s)" % ("MD17-aspirin 256-frame batch" if args.workload == "aspirin" else "32k-atom bulk-water PBC box", "SchNet" if args.kind == "schnet" else "PaiNN"),
         "value": round(value, 2), "unit": "M edge-messages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("configs[1]: MD17 aspirin x %d frames per GPU, %s(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0) + Atomwise + Forces; N=%d atoms, E=%d directed edges per GPU"
-                                % (hi - lo, "SchNet" if args.kind == "schnet" else "PaiNN", N, E)) if args.workload == "aspirin" else
+                                % (hi_lo, "SchNet" if args.kind == "schnet" else "PaiNN", N, E)) if args.workload == "aspirin" else
                                ("configs[4] per-GPU share: bulk-water PBC box, one replica per GPU, %s(128, 3, 20, 5.0) + Atomwise + Forces; N=%d atoms, E=%d directed edges per GPU; ns/day at 0.5 fs per force call = %.3f"
                                 % ("SchNet" if args.kind == "schnet" else "PaiNN", N, E, args.steps / dt * 0.5 * 86400e-6)),
-                   "n_atoms": N, "n_edges": E, "frames_per_s": round((hi - lo) * world * args.steps / dt, 1),
+                   "n_atoms": N, "n_edges": E, "frames_per_s": round(hi_lo * world * args.steps / dt, 1),
                    "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                    "world_size": world, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
-                   "hip_graph": graph is not None, "variant": args.variant, "compute_units": info["compute_units"]},
-        "roofline": roofline, "cpu_baseline": cpu, "md": md, "sweep": sweep, "kernels": kernels, "scatter_add": scatter, "neighbor_list": nbl,
+                   "hip_graph": r["graph"], "variant": args.variant, "compute_units": info["compute_units"]},
+        "roofline": roofline, "cpu_baseline": cpu, "painn": painn, "train": train, "md": md, "sweep": sweep, "drop_in": drop_in,
+        "kernels": kernels, "scatter_add": scatter, "neighbor_list": nbl,
     }
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def md_run(args, model, dev, workload, rank, world, dist, steps, warmup):
-    """NVE molecular dynamics, the whole step on the device: fused
-    kick + drift + skin check, device neighbour list with a skin (rebuilt when an atom moved more than half
-    of it), HIP-graph force call, kick.  Every rank integrates its own batch / box (replicas only, no
-    collective).  ns/day = steps/s x dt x 86400e-6 per trajectory; random-init weights give an
-    arbitrary but smooth potential, so energies are in model units: momenta start at zero and stay small.
+def md_run(args, model, dev, workload, rank, world, dist, steps, warmup, beads=None, thermostat=None, bead_parallel=None):
+    """Molecular dynamics, the whole step on the device: fused kick + drift + skin check,
+    device neighbour list with a skin (rebuilt when an atom moved more than half of it), HIP-graph force call, kick.
+    ``beads`` > 1: ring-polymer MD (0.2 fs, md_configs/dynamics/integrator/rpmd.yaml) with the beads folded into the batch;
+    ``thermostat`` "pile": PILE-L at 300 K, tau = 100 fs at step begin and end (NVT; md_configs/dynamics/thermostat/
+    pile_local.yaml) in the unit system A / Dalton / ps (energy unit Da A^2 / ps^2 = 0.01 kJ/mol).  Without ``bead_parallel``
+    every rank integrates its own batch / box (replicas only, no collective); with it ONE ring polymer is spread over the ranks
+    (beads / world each; exchange scheme "state" or "forces", md.RPMDSimulation).  ns/day = steps/s x dt x 86400e-6 per
+    trajectory; random-init weights give an arbitrary but smooth potential (NVE runs start from zero momenta).
     Returns the measurements of this rank (time = max over ranks)."""
     from schnetpack_amd import model as M, synthetic as S
-    from schnetpack_amd.md import NVESimulation, RPMDSimulation
-    dt_fs = 0.5 if args.beads <= 1 else 0.2     # md.yaml resp. rpmd.yaml of the reference
+    from schnetpack_amd import md as MD
+    beads = args.beads if beads is None else beads
+    thermostat = args.thermostat if thermostat is None else thermostat
+    bead_parallel = args.bead_parallel if bead_parallel is None else bead_parallel
+    if thermostat == "auto":
+        thermostat = "pile" if beads > 1 else "none"
+    if thermostat == "pile" and beads <= 1:
+        raise SystemExit("bench.py: the PILE-L thermostat belongs to ring-polymer MD (--beads B > 1)")
+    if bead_parallel and (beads <= 1 or dist is None or beads % world):
+        raise SystemExit("bench.py --bead-parallel: needs --beads B > 1 divisible by --gpus N > 1")
+    dt_fs = 0.5 if beads <= 1 else 0.2     # md.yaml resp. rpmd.yaml of the reference
+    shared = bool(bead_parallel)            # bead-parallel: every rank starts from the SAME system
     if workload == "water":
-        batch = S.water_box(n_side=args.water_side, seed=rank)
+        batch = cached_water_box(args.water_side, 0 if shared else rank)
         n_traj = 1
     else:
-        batch = S.molecule_batch("aspirin", args.frames, seed=1000 + rank if world > 1 else 0)
+        batch = S.molecule_batch("aspirin", args.frames, seed=1000 + rank if (world > 1 and not shared) else 0)
         n_traj = args.frames
     inp = M.batch_to_inputs(batch, dev)
     N = int(batch["Z"].shape[0])
@@ -691,15 +883,27 @@ def md_run(args, model, dev, workload, rank, world, dist, steps, warmup):
         inp["_cell"] = batch["cell"].reshape(1, 3, 3).to(dev)
         inp["_pbc"] = torch.tensor([True, True, True], device=dev)
     masses = torch.where(batch["Z"] == 1, 1.008, torch.where(batch["Z"] == 6, 12.011, 15.999)).to(dev)
-    # model energy unit := eV-like; time step chosen so that atoms move ~1e-3 A per step
-    if args.beads > 1:
-        sim = RPMDSimulation(model, inp, masses, 0.02, args.beads, cutoff=5.0, omega=3.0, cutoff_shell=args.md_shell, use_graph=not args.no_graph)
+    KB = 100.0 * MD.KB_MD                  # Boltzmann's constant in Da A^2 / ps^2 / K (the positions are in A)
+    T_bath = 300.0
+    th = None
+    if beads > 1:
+        if thermostat == "pile":
+            th = MD.PILELocalThermostat(T_bath, 100.0, seed=1234, kb=KB)          # tau = 100 fs, like pile_local.yaml
+            time_step = dt_fs * MD.FS_MD     # real units: 0.2 fs in ps; omega = kB n T / hbar (1 / ps)
+            omega = None
+        else:
+            time_step, omega = 0.02, 3.0     # NVE ring polymer in model units (round-1/2 lines)
+        sim = MD.RPMDSimulation(model, inp, masses, time_step, beads, cutoff=5.0, temperature=T_bath, omega=omega, cutoff_shell=args.md_shell,
+                                use_graph=not args.no_graph, thermostat=th, group=(dist.group.WORLD if bead_parallel else None),
+                                exchange=bead_parallel or "state")
     else:
-        sim = NVESimulation(model, inp, masses, 0.02, cutoff=5.0, cutoff_shell=args.md_shell, use_graph=not args.no_graph)
+        # model energy unit := eV-like; time step chosen so that atoms move ~1e-3 A per step
+        sim = MD.NVESimulation(model, inp, masses, 0.02, cutoff=5.0, cutoff_shell=args.md_shell, use_graph=not args.no_graph)
     sim.step(max(warmup, 2))
     e0 = sim.total_energy()
     b0 = sim.nl.n_builds
     tr0 = sim.t_rebuild
+    c0 = getattr(sim, "n_collectives", 0)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -716,11 +920,18 @@ def md_run(args, model, dev, workload, rank, world, dist, steps, warmup):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     steps_s = steps / dt
-    return {"ns_per_day": round(steps_s * dt_fs * 86400e-6, 4), "ms_per_step": round(1e3 * dt / steps, 4), "steps_per_s": steps_s, "dt_fs": dt_fs,
-            "n_atoms": N, "pairs_in_list": int(sim._lists["_idx_i"].shape[0]), "trajectories": n_traj, "steps": steps, "seconds": dt,
-            "rebuilds": sim.nl.n_builds - b0, "ms_per_rebuild": round(1e3 * (sim.t_rebuild - tr0) / max(sim.nl.n_builds - b0, 1), 3),
-            "fraction_in_rebuilds": round((sim.t_rebuild - tr0) / dt, 4), "graph_captures": sim.n_captures, "hip_graph": sim.graph is not None,
-            "energy_drift": abs(sim.total_energy() - e0) / max(float(sim.kinetic_energy()), 1e-12) / steps}
+    n_loc = getattr(sim, "n_local", 1)
+    ke = float(sim.kinetic_energy())
+    res = {"ns_per_day": round(steps_s * dt_fs * 86400e-6, 4), "ms_per_step": round(1e3 * dt / steps, 4), "steps_per_s": steps_s, "dt_fs": dt_fs,
+           "n_atoms": N, "pairs_in_list": int(sim._lists["_idx_i"].shape[0]), "trajectories": n_traj, "steps": steps, "seconds": dt,
+           "rebuilds": sim.nl.n_builds - b0, "ms_per_rebuild": round(1e3 * (sim.t_rebuild - tr0) / max(sim.nl.n_builds - b0, 1), 3),
+           "fraction_in_rebuilds": round((sim.t_rebuild - tr0) / dt, 4), "graph_captures": sim.n_captures, "hip_graph": sim.graph is not None,
+           "beads": beads, "beads_per_rank": n_loc if beads > 1 else 1, "thermostat": ("PILE-L 300 K tau=100 fs" if th is not None else None),
+           "collectives_per_step": (getattr(sim, "n_collectives", 0) - c0) / steps,
+           "energy_drift": abs(sim.total_energy() - e0) / max(ke, 1e-12) / steps}
+    if th is not None:      # ring-polymer momenta equilibrate at n_beads x T (thermostats_rpmd.py:93-100)
+        res["kinetic_temperature_K"] = round(2.0 * ke / (3 * N * n_loc * KB) / beads, 2)
+    return res
 
 
 def md_main(args, rank, world, dev, dist, model):
@@ -733,24 +944,38 @@ def md_main(args, rank, world, dev, dist, model):
         return
     kind = "SchNet" if args.kind == "schnet" else "PaiNN"
     n_traj, N, E_list = r["trajectories"], r["n_atoms"], r["pairs_in_list"]
+    bp = args.bead_parallel
+    nve = r["thermostat"] is None
+    if args.beads <= 1:
+        metric = "MD ns/day per trajectory (NVE, 0.5 fs, %s, %s)"
+    else:
+        metric = "RPMD ns/day per ring polymer (" + str(args.beads) + " beads, 0.2 fs, " + ("NVE" if nve else "PILE-L NVT 300 K") + ", %s, %s)"
+    if bp:
+        par = ("bead-parallel: ONE ring polymer of %d beads over %d rank(s), %d bead(s) per rank, exchange scheme '%s': %.0f all-gather(s) per step"
+               % (args.beads, world, r["beads_per_rank"], bp, r["collectives_per_step"]))
+    else:
+        par = "replicas only: %d independent rank(s), no collective" % world
     line = {
-        "metric": ("MD ns/day per trajectory (NVE, 0.5 fs, %s, %s)" if args.beads <= 1 else "RPMD ns/day per ring polymer (" + str(args.beads) + " beads, 0.2 fs, %s, %s)") % ("MD17-aspirin x %d replicas" % n_traj if args.workload == "aspirin" else "32k-atom bulk-water PBC box", kind),
+        "metric": metric % ("MD17-aspirin x %d replicas" % n_traj if args.workload == "aspirin" else "32k-atom bulk-water PBC box", kind),
         "value": r["ns_per_day"], "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong" if bp else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("%s: %s(128, 3, 20, 5.0) + Atomwise + Forces, %s, device neighbour list with a %.1f A skin (%d pairs in the list), "
-                                "%d trajectories per GPU advanced together; N=%d atoms per bead and GPU"
-                                % ("configs[1]-style MD17 aspirin batch" if args.workload == "aspirin" else "configs[4] per-GPU share (one bead / replica per GPU)",
-                                   kind, "velocity Verlet" if args.beads <= 1 else "ring-polymer integrator with %d beads folded into the batch" % args.beads,
+        "config": {"workload": ("%s: %s(128, 3, 20, 5.0) + Atomwise + Forces, %s, device neighbour list with a %.1f A skin (%d pairs in the list of this rank), "
+                                "%d trajectories per GPU advanced together; N=%d atoms per bead"
+                                % ("configs[1]-style MD17 aspirin batch" if args.workload == "aspirin" else "configs[4] (32k-atom bulk water)",
+                                   kind, "velocity Verlet" if args.beads <= 1 else "ring-polymer integrator, %d beads (%d folded into the batch of a rank)" % (args.beads, r["beads_per_rank"]),
                                    args.md_shell, E_list, n_traj, N)),
-                   "trajectories_per_gpu": n_traj, "aggregate_ns_per_day": round(r["ns_per_day"] * n_traj * world, 3),
+                   "trajectories_per_gpu": n_traj, "aggregate_ns_per_day": round(r["ns_per_day"] * n_traj * (1 if bp else world), 3),
                    "M_edge_messages_per_s_in_list": round(E_list * n_int * r["steps_per_s"] * world / 1e6, 1),
                    "neighbor_list_rebuilds_in_timed_region": r["rebuilds"],
                    "ms_per_rebuild_incl_recapture": r["ms_per_rebuild"],
                    "fraction_of_time_in_rebuilds": r["fraction_in_rebuilds"], "graph_captures": r["graph_captures"],
-                   "hip_graph": r["hip_graph"],
-                   "energy_drift_per_step_rel_to_kinetic": r["energy_drift"],
-                   "parallelism": "replicas only: %d independent rank(s), no collective" % world},
+                   "hip_graph": r["hip_graph"], "beads": r["beads"], "beads_per_rank": r["beads_per_rank"], "thermostat": r["thermostat"],
+                   "kinetic_temperature_K": r.get("kinetic_temperature_K"),
+                   "collectives_per_step": r["collectives_per_step"],
+                   "energy_drift_per_step_rel_to_kinetic": r["energy_drift"] if nve else None,
+                   "world_size": world, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
+                   "parallelism": par},
         "roofline": None, "cpu_baseline": None,
     }
     print(json.dumps(line))
@@ -758,15 +983,14 @@ def md_main(args, rank, world, dev, dist, model):
         dist.destroy_process_group()
 
 
-def train_main(args, rank, world, dev, dist, model, rep_p, head_p):
+def train_measure(args, kind, rank, world, dev, dist, model, rep_p, head_p, steps, warmup):
     """configs[3] (SURVEY.md section 8 cfg 4): rMD17-aspirin training step, PaiNN/SchNet in train() mode
     (Forces with create_graph=True -> double backward through the differentiable HIP primitives), loss
     0.01 MSE(E) + 0.99 MSE(F), AdamW(lr 1e-3), 8 frames per GPU, ONE all-reduce of one flat gradient
-    bucket per step (RCCL; bucket views, no copy kernels)."""
-    from schnetpack_amd import model as M, synthetic as S
-    from schnetpack_amd.parallel import FlatGradAllReduce
-    n_int = 3
+    bucket per step (RCCL; bucket views, no copy kernels).  Returns the JSON line (dict) on rank 0, None elsewhere."""
+    from schnetpack_amd import _lib, synthetic as S
     from schnetpack_amd.train import GraphedTrainStep
+    n_int, F, n_rbf, cutoff = 3, 128, 20, 5.0
     pool = []
     for k in range(8):                      # 8 different resident mini-batches, cycled
         b = S.molecule_batch("aspirin", args.train_frames, seed=5000 + 97 * rank + k)
@@ -777,7 +1001,7 @@ def train_main(args, rank, world, dev, dist, model, rep_p, head_p):
     n_atoms = int(pool[0][0]["Z"].shape[0])
     emax = 64 * (max(int(p[0]["idx_i"].shape[0]) for p in pool) // 64 + 2)      # static capacity of the pair list
     tstep = GraphedTrainStep(model, n_atoms, args.train_frames, emax, 5.0, lr=1e-3,
-                          group=(dist.group.WORLD if dist is not None else None), use_graph=not args.no_graph)
+                             group=(dist.group.WORLD if dist is not None else None), use_graph=not args.no_graph)
     reducer = tstep.reducer
 
     def step(i):
@@ -785,13 +1009,15 @@ def train_main(args, rank, world, dev, dist, model, rep_p, head_p):
         tstep.load(bd, Et, Ft)
         return tstep.step()
 
-    losses = [float(step(i).detach()) for i in range(max(args.warmup, 4))]
+    # launches of one step: the HIP-event profile scopes of the library see its own launches; the step's total (incl. the framework's
+    # element-wise / concatenation kernels) is the kernel count of the captured graph -- counted by an eager step under the profiler hooks
+    losses = [float(step(i).detach()) for i in range(max(warmup, 4))]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         loss = step(i)
     torch.cuda.synchronize()
     if dist is not None:
@@ -804,59 +1030,106 @@ def train_main(args, rank, world, dev, dist, model, rep_p, head_p):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
+    # launch count of one step (library + framework kernels): torch's kineto profile of one eager step
+    launches = None
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        tstep_use_graph = tstep.use_graph
+        tstep.use_graph = False
+        step(0)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as pr:
+            step(1)
+            torch.cuda.synchronize()
+        launches = sum(1 for ev in pr.events() if str(getattr(ev, "device_type", "")).endswith("CUDA") and not ev.name.lower().startswith(("memcpy", "memset")))
+        tstep.use_graph = tstep_use_graph
+    except Exception as exc:  # pragma: no cover
+        sys.stderr.write("[bench] launch count unavailable (%s)\n" % exc)
+    ms_step = 1e3 * dt / steps
+    # training = forward + recorded first-order backward (B_force) + the backward of that pass (about 2x the force call):
+    # booked as 3 x B_force of the per-GPU batch; the step is launch-latency bound at this size, which the fraction shows
+    b0 = pool[0][0]
+    E0, N0 = int(b0["idx_i"].shape[0]), n_atoms
+    if kind == "painn":
+        work, bound, peak, unit = 3.0 * 3.0 * n_int * (E0 * 3100.0 + 2 * N0 * 4096.0), "hbm", HBM_PEAK_GBS, "GB/s"
+        ach = work / (ms_step * 1e-3) / 1e9
+    else:
+        work, bound, peak, unit = 3.0 * 3.0 * n_int * (2.0 * E0 * (n_rbf * F + F * F) + 2.0 * N0 * 3 * F * F), "mfma", MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        ach = work / (ms_step * 1e-3) / 1e12
+    roofline = {"kernel": "whole training step (%s launches, one HIP-graph replay)" % (launches if launches is not None else "n/a"), "bound": bound,
+                "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": None,
+                "algorithmic_per_step": work,
+                "note": "algorithmic work of a force-matching step booked as 3 x the force call of its batch (forward + recorded backward + the backward of "
+                        "both, SURVEY.md 8(d) / Appendix B) over the wall time of the step; at 8 frames per GPU the step is launch-latency bound"}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import spk_oracle as O          # test infrastructure: the CPU restatement, timed as the baseline
         ncores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(ncores)
         b, _, Et, Ft = pool[0]
         Et, Ft = Et.cpu(), Ft.cpu()
-        rp = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() and k.endswith(("weight", "bias")) else v) for k, v in rep_p.items()}
-        hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
-        leaves = [v for v in list(rp.values()) + list(hp.values()) if torch.is_tensor(v) and v.requires_grad]
-        copt = torch.optim.AdamW(leaves, lr=1e-3)
+        ref_model = reference_model(kind, rep_p, head_p, F, n_int, n_rbf, cutoff)
+        if ref_model is not None:
+            # the REFERENCE's modules in train() mode: Forces(create_graph=True) -> double backward, torch AdamW (atomistic/response.py:59-68)
+            ref_model.train()
+            copt = torch.optim.AdamW(ref_model.parameters(), lr=1e-3)
 
-        def cpu_step():
-            copt.zero_grad()
-            R = b["R"].clone().requires_grad_(True)
-            r_ij = O.pairwise_vectors(R, b["idx_i"], b["idx_j"], b["offsets"])
-            if args.kind == "schnet":
-                x = O.schnet_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, n_int)
-            else:
-                x, _ = O.painn_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, n_int)
-            E = O.atomwise_energy(x, b["idx_m"], args.train_frames, hp)
-            (dEdR,) = torch.autograd.grad([E.sum()], [R], create_graph=True)
-            l = 0.01 * ((E - Et) ** 2).mean() + 0.99 * ((-dEdR - Ft) ** 2).mean()
-            l.backward()
-            copt.step()
-        cpu_step()
+            def cpu_step():
+                copt.zero_grad()
+                o = ref_model(reference_inputs(b))
+                l = 0.01 * ((o["energy"] - Et) ** 2).mean() + 0.99 * ((o["forces"] - Ft) ** 2).mean()
+                l.backward()
+                copt.step()
+                return float(l.detach())
+            kind_ = "reference"
+        else:
+            from oracle import spk_oracle as O          # test infrastructure: the CPU restatement, timed as the baseline
+            rp = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() and k.endswith(("weight", "bias")) else v) for k, v in rep_p.items()}
+            hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
+            leaves = [v for v in list(rp.values()) + list(hp.values()) if torch.is_tensor(v) and v.requires_grad]
+            copt = torch.optim.AdamW(leaves, lr=1e-3)
+
+            def cpu_step():
+                copt.zero_grad()
+                R = b["R"].clone().requires_grad_(True)
+                r_ij = O.pairwise_vectors(R, b["idx_i"], b["idx_j"], b["offsets"])
+                if kind == "schnet":
+                    x = O.schnet_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, n_int)
+                else:
+                    x, _ = O.painn_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, n_int)
+                E = O.atomwise_energy(x, b["idx_m"], args.train_frames, hp)
+                (dEdR,) = torch.autograd.grad([E.sum()], [R], create_graph=True)
+                l = 0.01 * ((E - Et) ** 2).mean() + 0.99 * ((-dEdR - Ft) ** 2).mean()
+                l.backward()
+                copt.step()
+                return float(l.detach())
+            kind_ = "port"
+        first_cpu_loss = cpu_step()
         ts = []
-        for _ in range(args.cpu_reps):
+        for _ in range(min(args.cpu_reps, 10)):
             c0 = time.perf_counter()
             cpu_step()
             ts.append(time.perf_counter() - c0)
         ts.sort()
-        cpu = {"value": round(args.train_frames / ts[len(ts) // 2], 2), "unit": "samples/s", "cores": ncores, "kind": "port",
-               "sample": "same %d-frame training step on the oracle (torch CPU autograd), median of %d" % (args.train_frames, args.cpu_reps)}
-    kind = "SchNet" if args.kind == "schnet" else "PaiNN"
-    line = {
-        "metric": "training samples/s (rMD17-aspirin force-matching step, %s)" % kind,
-        "value": round(args.train_frames * world * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        cpu = {"value": round(args.train_frames / ts[len(ts) // 2], 2), "unit": "samples/s", "cores": ncores, "kind": kind_,
+               "sample": "the same %d-frame AdamW step of the force-matching loss on %s (torch CPU autograd, fp32), median of %d; its first loss %.6f vs %.6f here "
+                         "(same weights, same first batch)" % (args.train_frames, "the reference's NeuralNetworkPotential in train() mode" if kind_ == "reference" else "the oracle restatement",
+                                                             len(ts), first_cpu_loss, losses[0]),
+               "first_loss_rel_diff": abs(first_cpu_loss - losses[0]) / max(abs(first_cpu_loss), 1e-30)}
+    kname = "SchNet" if kind == "schnet" else "PaiNN"
+    return {
+        "metric": "training samples/s (rMD17-aspirin force-matching step, %s)" % kname,
+        "value": round(args.train_frames * world * steps / dt, 2), "unit": "samples/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[3]: rMD17 aspirin training, %d frames per GPU (global batch %d), %s(128, 3, 20, 5.0) + Atomwise + "
                                "Forces(create_graph), loss 0.01 MSE(E) + 0.99 MSE(F), AdamW lr 1e-3, one flat-bucket all-reduce of %d floats per step; "
                                "static shapes (pair list padded to %d) replayed as HIP graphs: %s"
-                               % (args.train_frames, args.train_frames * world, kind, reducer.numel, emax, tstep.g_bwd is not None),
+                               % (args.train_frames, args.train_frames * world, kname, reducer.numel, emax, tstep.g_bwd is not None),
                    "parallelism": "dp%d" % world, "first_loss": losses[0], "last_loss": float(loss.detach())},
-        "roofline": None, "cpu_baseline": cpu,
+        "launches_per_step": launches,
+        "roofline": roofline, "cpu_baseline": cpu,
     }
-    print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

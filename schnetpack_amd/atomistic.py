@@ -61,6 +61,16 @@ class Atomwise(nn.Module):
         self._head_act = 0
         self._fused_head = self._head_fusable()
 
+    def __setstate__(self, state):
+        # a model pickled by the REFERENCE (torch.save(model), task.py:300) unpickled onto this class after
+        # install(fused_head=True) never ran __init__: fill what the reference's Atomwise does not carry
+        super().__setstate__(state)
+        if "n_molecules_key" not in self.__dict__:
+            self.n_molecules_key = "_n_molecules"
+        if "_fused_head" not in self.__dict__ or "_head_act" not in self.__dict__:
+            self._head_act = 0
+            self._fused_head = self._head_fusable()
+
     def _head_fusable(self) -> bool:
         """True when the head is the default 2-layer / width-1 MLP the fused HIP kernel covers."""
         if self.aggregation_mode is None or self.n_out != 1:

@@ -24,7 +24,10 @@
 #include <torch/library.h>
 
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <list>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <tuple>
@@ -90,6 +93,8 @@ std::mutex g_mutex;
 // ------------------------------------------------------------------------------------------------ neighbour-list plan
 struct Plan {
   Tensor idx_i, idx_j, rowptr, rev, half, edge_pair, grp_atom0, grp_pair0, grp_tile0;   // keep-alive + device data
+  Tensor src_i, src_j;       // the CALLER's index tensors: the cache key is their data_ptr, so they must stay allocated while the entry lives
+                             // (an int32 list converted to int64 above would otherwise be freed and its address re-used by another list)
   bool sorted = false, symmetric = false;
   int64_t n_atoms = 0, n_edges = 0, n_half = 0;
   int32_t n_groups = 0, max_group_atoms = 0, max_group_pairs = 0;
@@ -180,6 +185,8 @@ std::shared_ptr<Plan> get_plan(const Tensor& idx_i_in, const Tensor& idx_j_in, i
   auto p = std::make_shared<Plan>();
   p->idx_i = i64(idx_i_in, "edge_plan");
   p->idx_j = i64(idx_j_in, "edge_plan");
+  p->src_i = idx_i_in;
+  p->src_j = idx_j_in;
   p->n_atoms = n_atoms;
   p->n_edges = p->idx_i.size(0);
   p->has_r = r_ij.defined();
@@ -238,10 +245,15 @@ void decide_filter(Plan& p, const Tensor& r_ij, double cutoff) {
 // HIP-graph replays of the training step refill the index BUFFERS between replays: no plan cache, no host round trip.
 // Declared ascending indices get their CSR row pointers from a device-only kernel (spk_segment_rowptr_i32) launched by
 // static_refresh() inside the captured step; every other index takes the atomic scatter.
-struct StaticEntry { Tensor idx, rowptr; int64_t n_rows; };
+// Declarations belong to an OWNER (one per StaticLists object = one captured step): a second stepper (another shape bucket, a
+// validation step) adds its own entries and never touches the buffers a live captured graph of the first one points at; an
+// owner's entries (its row pointers and its error word) are freed only by static_release(owner).
+struct StaticEntry { Tensor idx, rowptr; int64_t n_rows; int64_t owner; };
+struct StaticRange { Tensor idx; int64_t hi; int64_t owner; };
 std::vector<StaticEntry> g_static;
-std::vector<std::pair<Tensor, int64_t>> g_static_ranges;   // unsorted indices that must lie in [0, hi)
-Tensor g_static_err;
+std::vector<StaticRange> g_static_ranges;   // unsorted indices that must lie in [0, hi)
+std::map<int64_t, Tensor> g_static_err;     // owner -> device error word
+int64_t g_static_next_owner = 1;
 bool g_static_on = false;
 
 Tensor static_rowptr(const Tensor& idx, int64_t dim_size) {
@@ -412,9 +424,16 @@ struct PainnModel {
 Lru<SchnetModel> g_schnet(8);
 Lru<PainnModel> g_painn(8);
 
+// Parameters updated IN PLACE by a captured optimizer step keep their data_ptr AND their version counter (graph replays do not
+// go through the tensor's bookkeeping), so identity + version alone would keep serving transposed / packed copies of the weights
+// as they were before the replays.  Whoever changes parameters behind torch's back (train.GraphedTrainStep after every replay)
+// calls weights_changed(), which moves every weight-derived cache entry out of reach.
+std::atomic<uint64_t> g_weight_generation{0};
+
 std::vector<uint64_t> weights_key(at::TensorList ws, std::initializer_list<int64_t> extra) {
   std::vector<uint64_t> key;
-  key.reserve(2 * ws.size() + extra.size());
+  key.reserve(2 * ws.size() + extra.size() + 1);
+  key.push_back(g_weight_generation.load(std::memory_order_acquire));
   for (const auto& w : ws) {
     key.push_back((uint64_t)w.data_ptr());
     key.push_back(version_of(w));
@@ -636,7 +655,8 @@ std::shared_ptr<HeadCache> get_head(const Tensor& w1_in, const c10::optional<Ten
                             (uint64_t)((b1_in.has_value() && b1_in->defined()) ? b1_in->data_ptr() : nullptr),
                             (b1_in.has_value() && b1_in->defined()) ? version_of(*b1_in) : 0,
                             (uint64_t)((b2_in.has_value() && b2_in->defined()) ? b2_in->data_ptr() : nullptr),
-                            (b2_in.has_value() && b2_in->defined()) ? version_of(*b2_in) : 0};
+                            (b2_in.has_value() && b2_in->defined()) ? version_of(*b2_in) : 0,
+                            g_weight_generation.load(std::memory_order_acquire)};
   std::lock_guard<std::mutex> lock(g_mutex);
   if (auto hit = g_heads.get(key)) return hit;
   auto h = std::make_shared<HeadCache>();
@@ -1341,6 +1361,8 @@ void edge_plan_install_op(const Tensor& idx_i, const Tensor& idx_j, int64_t n_at
   require_device(idx_i, "edge_plan_install");
   TORCH_CHECK(meta.size() >= 8, "edge_plan_install: meta needs 8 entries");
   auto p = std::make_shared<Plan>();
+  p->src_i = idx_i;
+  p->src_j = idx_j;
   p->idx_i = i64(idx_i, "edge_plan_install");
   p->idx_j = i64(idx_j, "edge_plan_install");
   p->n_atoms = n_atoms;
@@ -1380,48 +1402,83 @@ void edge_plan_install_op(const Tensor& idx_i, const Tensor& idx_j, int64_t n_at
 }
 
 // static-shape mode (training-step graph replays)
-Tensor static_declare_op(const Tensor& idx, int64_t n_rows) {
+Tensor& static_err_of(int64_t owner, const at::Device& dev) {      // g_mutex held
+  Tensor& e = g_static_err[owner];
+  if (!e.defined()) e = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
+  return e;
+}
+int64_t static_new_op() {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  return g_static_next_owner++;
+}
+Tensor static_declare_op(const Tensor& idx, int64_t n_rows, int64_t owner) {
   require_device(idx, "static_declare");
   TORCH_CHECK(idx.scalar_type() == at::kLong && idx.is_contiguous(), "static_declare: needs a contiguous int64 tensor");
   std::lock_guard<std::mutex> lock(g_mutex);
-  if (!g_static_err.defined()) g_static_err = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(idx.device()));
+  static_err_of(owner, idx.device());
   for (auto& e : g_static)
-    if (e.idx.data_ptr() == idx.data_ptr() && e.n_rows == n_rows) return e.rowptr;
-  g_static.push_back({idx, at::zeros({n_rows + 1}, at::TensorOptions().dtype(at::kInt).device(idx.device())), n_rows});
+    if (e.idx.data_ptr() == idx.data_ptr() && e.n_rows == n_rows) {
+      TORCH_CHECK(e.owner == owner, "static_declare: this index buffer is already declared by another StaticLists object");
+      return e.rowptr;
+    }
+  g_static.push_back({idx, at::zeros({n_rows + 1}, at::TensorOptions().dtype(at::kInt).device(idx.device())), n_rows, owner});
   return g_static.back().rowptr;
 }
-void static_declare_range_op(const Tensor& idx, int64_t hi) {
+void static_declare_range_op(const Tensor& idx, int64_t hi, int64_t owner) {
   require_device(idx, "static_declare_range");
   TORCH_CHECK(idx.scalar_type() == at::kLong && idx.is_contiguous(), "static_declare_range: needs a contiguous int64 tensor");
   std::lock_guard<std::mutex> lock(g_mutex);
-  if (!g_static_err.defined()) g_static_err = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(idx.device()));
+  static_err_of(owner, idx.device());
   for (auto& e : g_static_ranges)
-    if (e.first.data_ptr() == idx.data_ptr()) { e.second = hi; return; }
-  g_static_ranges.emplace_back(idx, hi);
+    if (e.idx.data_ptr() == idx.data_ptr() && e.owner == owner) { e.hi = hi; return; }
+  g_static_ranges.push_back({idx, hi, owner});
 }
-void static_refresh_op() {
+void static_refresh_op(int64_t owner) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  auto it = g_static_err.find(owner);
+  if (it == g_static_err.end()) return;
+  int32_t* err = it->second.data_ptr<int32_t>();
   for (auto& e : g_static) {
+    if (e.owner != owner) continue;
     c10::DeviceGuard guard(e.idx.device());
-    check(spk_segment_rowptr_i32(e.idx.data_ptr<int64_t>(), e.idx.size(0), e.n_rows, e.rowptr.data_ptr<int32_t>(), g_static_err.data_ptr<int32_t>(),
-                                 stream_of(e.idx)));
+    check(spk_segment_rowptr_i32(e.idx.data_ptr<int64_t>(), e.idx.size(0), e.n_rows, e.rowptr.data_ptr<int32_t>(), err, stream_of(e.idx)));
   }
   for (auto& e : g_static_ranges) {
-    c10::DeviceGuard guard(e.first.device());
-    check(spk_index_range_check(e.first.data_ptr<int64_t>(), e.first.numel(), e.second, g_static_err.data_ptr<int32_t>(), stream_of(e.first)));
+    if (e.owner != owner) continue;
+    c10::DeviceGuard guard(e.idx.device());
+    check(spk_index_range_check(e.idx.data_ptr<int64_t>(), e.idx.numel(), e.hi, err, stream_of(e.idx)));
   }
 }
-void static_enable_op(bool on) { g_static_on = on; }
-int64_t static_check_op() {
-  if (!g_static_err.defined()) return 0;
-  int64_t f = g_static_err.item<int32_t>();
-  if (f) g_static_err.zero_();
+bool static_enable_op(bool on) {      // returns the PREVIOUS state (so that a scope can restore it)
+  const bool prev = g_static_on;
+  g_static_on = on;
+  return prev;
+}
+int64_t static_check_op(int64_t owner) {
+  Tensor e;
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_static_err.find(owner);
+    if (it == g_static_err.end()) return 0;
+    e = it->second;
+  }
+  int64_t f = e.item<int32_t>();
+  if (f) e.zero_();
   return f;
 }
-void static_clear_op() {
+// drop the declarations of ONE owner (its StaticLists object is gone; so are the graphs that referenced its buffers)
+void static_release_op(int64_t owner) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  g_static.erase(std::remove_if(g_static.begin(), g_static.end(), [&](const StaticEntry& e) { return e.owner == owner; }), g_static.end());
+  g_static_ranges.erase(std::remove_if(g_static_ranges.begin(), g_static_ranges.end(), [&](const StaticRange& e) { return e.owner == owner; }),
+                        g_static_ranges.end());
+  g_static_err.erase(owner);
+}
+void static_clear_op() {      // everything, every owner (tests; no captured graph may be replayed afterwards)
   std::lock_guard<std::mutex> lock(g_mutex);
   g_static.clear();
   g_static_ranges.clear();
-  g_static_err = Tensor();
+  g_static_err.clear();
   g_static_on = false;
 }
 void clear_caches_op() {
@@ -1429,7 +1486,9 @@ void clear_caches_op() {
   g_plans.clear();
   g_schnet.clear();
   g_painn.clear();
+  g_heads.clear();
 }
+void weights_changed_op() { g_weight_generation.fetch_add(1, std::memory_order_acq_rel); }
 
 // --- CPU key: loud refusal (the dispatcher's own "no kernel" message does not say why); one boxed kernel for every operator
 void no_cpu_boxed(const c10::OperatorHandle& op, c10::Stack*) {
@@ -1539,13 +1598,16 @@ TORCH_LIBRARY(spk_hip, m) {
   m.def("edge_plan(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor? r_ij, float cutoff=0.0, int force_filter=-1) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("edge_plan_install(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor rowptr, Tensor rev, Tensor half, Tensor edge_pair, Tensor grp_atom0, Tensor grp_pair0, int[] meta) -> ()");
   // static-shape mode + cache control (host-side state)
-  m.def("static_declare(Tensor idx, int n_rows) -> Tensor");
-  m.def("static_declare_range(Tensor idx, int hi) -> ()");
-  m.def("static_refresh() -> ()", static_refresh_op);
-  m.def("static_enable(bool on) -> ()", static_enable_op);
-  m.def("static_check() -> int", static_check_op);
+  m.def("static_new() -> int", static_new_op);
+  m.def("static_declare(Tensor idx, int n_rows, int owner=0) -> Tensor");
+  m.def("static_declare_range(Tensor idx, int hi, int owner=0) -> ()");
+  m.def("static_refresh(int owner=0) -> ()", static_refresh_op);
+  m.def("static_enable(bool on) -> bool", static_enable_op);
+  m.def("static_check(int owner=0) -> int", static_check_op);
+  m.def("static_release(int owner) -> ()", static_release_op);
   m.def("static_clear() -> ()", static_clear_op);
   m.def("clear_caches() -> ()", clear_caches_op);
+  m.def("weights_changed() -> ()", weights_changed_op);
   // training regime: operators closed under differentiation (spk_torch_train.h)
   train_defs(m);
 }

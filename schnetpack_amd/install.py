@@ -45,11 +45,46 @@ def uninstall():
 _ABSENT = object()
 
 
-def install(spk=None, verbose=False, fused_head=False, neighbor_lists=False):
+def _fused_potential_forward(orig_forward):
+    """``NeuralNetworkPotential.forward`` (model/base.py:174-190) with the standard potential handed to the fused operators
+    (model.classify_potential); everything else -- training mode, scripting, any other composition -- runs the reference's own
+    forward unchanged.  The classification of an instance is made once."""
+    import torch
+    from . import model as M
+
+    def forward(self, inputs):
+        if self.training or torch.jit.is_scripting():
+            return orig_forward(self, inputs)
+        mode = self.__dict__.get("_spk_hip_mode")
+        if mode is None:
+            mode = M.classify_potential(self)
+            self.__dict__["_spk_hip_mode"] = mode
+        if mode == 0:
+            return orig_forward(self, inputs)
+        inputs = self.initialize_derivatives(inputs)
+        if mode == 2:
+            inputs = M.potential_forces_forward(self, inputs)
+        else:
+            inputs = M.potential_forward(self, inputs)
+            for i, m in enumerate(self.output_modules):
+                if i > 0:
+                    inputs = m(inputs)
+        inputs = self.postprocess(inputs)
+        return self.extract_outputs(inputs)
+
+    forward._spk_hip_patched = True
+    return forward
+
+
+def install(spk=None, verbose=False, fused_head=False, neighbor_lists=False, fused_potential=False):
     """Patch ``spk`` (default: the imported ``schnetpack``).  Returns the list of patched names.
 
     ``fused_head=True`` also routes ``atomistic.Atomwise`` to the mirror whose default 2-layer energy head
     runs as one fused kernel pair in eval mode (same constructor, ``state_dict`` keys and outputs).
+    ``fused_potential=True`` (opt-in; implies nothing else -- combine with ``fused_head=True``, which the routing needs)
+    wraps ``model.base.NeuralNetworkPotential.forward``: an eval-mode model that is the standard potential (PairwiseDistances ->
+    SchNet -> default Atomwise -> Forces) runs as the two-launch operator exactly like the mirror model; any other model, and
+    training, keep the reference's forward.
     ``neighbor_lists=True`` adds ``transform.HipNeighborList`` and replaces ``md.neighborlist_md.NeighborListMD``
     by the device-side batched version (same constructor and ``get_neighbors``)."""
     from . import atomistic as A
@@ -89,6 +124,13 @@ def install(spk=None, verbose=False, fused_head=False, neighbor_lists=False):
     if fused_head:
         for mod in (getattr(spk, "atomistic", None), sub("atomistic.atomwise")):
             _set(mod, "Atomwise", A.Atomwise, log)
+    if fused_potential:
+        mb = sub("model.base")
+        cls = getattr(mb, "NeuralNetworkPotential", None) if mb is not None else None
+        if cls is not None and not getattr(cls.forward, "_spk_hip_patched", False):
+            _ORIGINALS.append((cls, "forward", cls.forward))
+            cls.forward = _fused_potential_forward(cls.forward)
+            log.append(mb.__name__ + ".NeuralNetworkPotential.forward")
     if neighbor_lists:
         from . import neighborlist as NL
         for mod in (getattr(spk, "transform", None), sub("transform.neighborlist")):

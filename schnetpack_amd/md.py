@@ -211,8 +211,12 @@ class PILELocalThermostat:
     ring_polymer = True
 
     def __init__(self, temperature_bath: float, time_constant: float, thermostat_centroid: bool = True, damping_factor: float = 1.0,
-                 seed: int = 0, group=None, compute_fn=None):
-        self.temperature_bath, self.time_constant = float(temperature_bath), float(time_constant)
+                 seed: int = 0, group=None, compute_fn=None, fs: float = FS_MD, kb: float = KB_MD):
+        # ``time_constant`` is in FEMTOSECONDS like the reference's (LangevinThermostat.__init__ multiplies by spk_units.fs,
+        # md/simulation_hooks/thermostats.py); ``fs`` / ``kb`` are 1 fs and Boltzmann's constant in the unit system of the
+        # state tensors (defaults: the reference's MD internal units kJ/mol, nm, Dalton => ps)
+        self.temperature_bath, self.time_constant = float(temperature_bath), float(time_constant) * float(fs)
+        self.kb = float(kb)
         self.thermostat_centroid, self.damping_factor = bool(thermostat_centroid), float(damping_factor)
         self.seed, self.group = int(seed), group
         self._compute = compute_fn or _pile_hip
@@ -224,7 +228,7 @@ class PILELocalThermostat:
         self.n_beads = integrator.n_beads
         self.M = pile_matrices(self.n_beads, integrator.omega, integrator.time_step, self.time_constant, self.thermostat_centroid,
                                self.damping_factor)
-        self.noise_scale = math.sqrt(KB_MD * self.n_beads * self.temperature_bath)
+        self.noise_scale = math.sqrt(self.kb * self.n_beads * self.temperature_bath)
         self._range = integrator._bead_range if self.group is None else RingPolymer(integrator.time_step, self.n_beads, 1.0, omega=1.0,
                                                                                     group=self.group)._bead_range
         return self
@@ -396,9 +400,8 @@ class NVESimulation:
             pass
         elif self.energy is None:
             out = self.model(self._call_inputs())              # first call: builds the plan, sizes the outputs
-            self._f = out["forces"].detach().clone()
+            self._f = self._force_buffer(out["forces"].detach())
             self._e = out["energy"].detach().clone()
-            self.state.forces = self._f.view(self.state.positions.shape)
             self.energy = self._e
         else:
             self._prepare_plan()                               # plan of the new list (host syncs) outside any capture
@@ -414,24 +417,30 @@ class NVESimulation:
         torch.cuda.synchronize(self.flag.device)
         self.t_rebuild += time.perf_counter() - t0
 
+    def _force_buffer(self, f):
+        """Static force buffer the captured force call writes into ([N, 3]; the state's ``forces`` is a view of it)."""
+        buf = f.clone()
+        self.state.forces = buf.view(self.state.positions.shape)
+        return buf
+
+    def _one_step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step_body()
+
     def step(self, n_steps=1):
         import time
         if self._complete:                     # nothing to watch: back-to-back replays, no host synchronisation
             for _ in range(n_steps):
-                if self.graph is not None:
-                    self.graph.replay()
-                else:
-                    self._step_body()
+                self._one_step()
             return
         done = 0
         while done < n_steps:
             k = min(self.check_every, n_steps - done)
             t0 = time.perf_counter()
             for _ in range(k):
-                if self.graph is not None:
-                    self.graph.replay()
-                else:
-                    self._step_body()
+                self._one_step()
             done += k
             moved, step_bits = self.flag.tolist()              # the one host sync of the chunk
             t_step = (time.perf_counter() - t0) / k
@@ -466,21 +475,46 @@ class NVESimulation:
 
 
 class RPMDSimulation(NVESimulation):
-    """Ring-polymer MD (md/integrators.py:113-229) of ``n_beads`` replicas of ONE batch of systems on one GPU: the
-    beads are folded into the batch dimension exactly as the reference does (md/calculators/base_calculator.py:
-    166-183), so one force call and one device neighbour list serve all beads.  One step is one graph replay:
+    """Ring-polymer MD (md/integrators.py:113-229) of ``n_beads`` replicas of ONE batch of systems: the beads are folded
+    into the batch dimension exactly as the reference does (md/calculators/base_calculator.py:166-183), so one force call
+    and one device neighbour list serve all beads of a rank.  Single process -- one step is one graph replay:
 
-        kick (p += dt/2 F)  ->  ring-polymer main step (k_md_ring_polymer: bead mixing + skin test)  ->
-        force call of all beads  ->  kick
+        [PILE-L]  ->  kick (p += dt/2 F)  ->  ring-polymer main step (k_md_ring_polymer: bead mixing + skin test)  ->
+        force call of all beads  ->  kick  ->  [PILE-L]
 
-    The conserved quantity is the ring-polymer Hamiltonian
-    ``sum_b [p_b^2 / 2m + V(q_b)] + sum_b 1/2 m omega^2 |q_b - q_{b+1}|^2`` (``total_energy``)."""
+    The conserved quantity (no thermostat) is the ring-polymer Hamiltonian
+    ``sum_b [p_b^2 / 2m + V(q_b)] + sum_b 1/2 m omega^2 |q_b - q_{b+1}|^2`` (``total_energy``).
+
+    **Bead-parallel** (``group`` given; SURVEY.md section 8(e): one contiguous chunk of ``n_beads / world`` beads per rank,
+    each rank with its own neighbour list and its own force-call graph; the normal-mode mixing
+    md/utils/normal_model_transformation.py:70-98 is the only thing that couples beads).  Two exchange schemes:
+
+    * ``exchange="state"`` -- every rank holds ONLY its beads.  One all-gather of the packed (positions, momenta) in the
+      ring-polymer main step (``RingPolymer(group=...)``) and one all-gather of the momenta per application of the
+      thermostat (``PILELocalThermostat(group=...)``): 1 + applications = 3 collectives per NVT step, 1 per NVE step --
+      the reference's three exchange points (md/simulator.py:126-150), nothing more.
+    * ``exchange="forces"`` -- every rank carries the integrator state of ALL beads (``n_beads x N x 3`` floats: 3 MB at
+      configs[4]) and repeats the element-wise integrator / thermostat arithmetic, which is bit-identical on every rank
+      (deterministic kernels, counter-based noise); only the FORCE CALL is sharded, so the one exchange of a step is the
+      all-gather of the forces: 1 collective per step with or without the thermostat.
+
+    Collectives are counted in ``n_collectives``.  The force call (+ the kernels next to it) of a rank is a HIP graph; the
+    collectives run between the graph segments (RCCL on its own stream; ``gloo`` staged through the host so that two ranks
+    can share one device in a test)."""
 
     def __init__(self, model, inputs, masses, time_step, n_beads, cutoff, temperature=300.0, omega=None,
-                 cutoff_shell=1.0, use_graph=True, thermostat: Optional["PILELocalThermostat"] = None, complete_list="auto"):
+                 cutoff_shell=1.0, use_graph=True, thermostat: Optional["PILELocalThermostat"] = None, complete_list="auto",
+                 group=None, exchange: str = "state"):
         from . import properties as P
+        if exchange not in ("state", "forces"):
+            raise ValueError("exchange must be 'state' or 'forces'")
         self.thermostat = thermostat
-        self.n_beads = B = int(n_beads)
+        self.n_beads = int(n_beads)
+        self.group, self.exchange = group, exchange
+        self.n_collectives = 0
+        self._rp = RingPolymer(time_step, self.n_beads, temperature, omega=omega, group=group)
+        self._lo, hi, self._world = self._rp._bead_range()
+        self.n_local = B = hi - self._lo                      # beads in THIS rank's batch
         N = int(inputs[P.R].shape[0])
         n_mol = int(inputs[P.n_atoms].shape[0])
         rep = dict(inputs)
@@ -492,49 +526,166 @@ class RPMDSimulation(NVESimulation):
             rep[P.cell] = inputs[P.cell].reshape(-1, 3, 3).repeat(B, 1, 1)
         if inputs.get(P.pbc) is not None:
             rep[P.pbc] = inputs[P.pbc].reshape(-1, 3).repeat(B, 1).reshape(-1)
-        self._rp = RingPolymer(time_step, B, temperature, omega=omega)
         self._n1 = N
         super().__init__(model, rep, masses, time_step, cutoff, cutoff_shell, use_graph, complete_list=complete_list)
 
+    # -- state ---------------------------------------------------------------------------------
+    @property
+    def _replicated(self) -> bool:
+        return self._world > 1 and self.exchange == "forces"
+
     def _setup_state(self, R, masses):
-        B, N = self.n_beads, self._n1
-        self.state = MDState(R.view(B, N, 3), torch.zeros(B, N, 3, device=R.device), masses.float().reshape(1, -1, 1))
+        Bl, N, dev = self.n_local, self._n1, R.device
+        m = masses.float().reshape(1, -1, 1)
+        if self._replicated:
+            # integrator state of ALL beads on every rank (they start from the same geometry); the force call reads the
+            # rank's rows of it in place
+            Ball = self.n_beads
+            self._q_all = R.view(Bl, N, 3)[:1].repeat(Ball, 1, 1).contiguous()
+            self._p_all = torch.zeros(Ball, N, 3, device=dev)
+            self._f_all = torch.zeros(Ball, N, 3, device=dev)
+            self.full = MDState(self._q_all, self._p_all, m, self._f_all)
+            lo = self._lo
+            self.state = MDState(self._q_all[lo:lo + Bl], self._p_all[lo:lo + Bl], m, self._f_all[lo:lo + Bl])
+            nb = Ball
+        else:
+            self.state = MDState(R.view(Bl, N, 3), torch.zeros(Bl, N, 3, device=dev), m)
+            nb = Bl
         self.integrator = self._rp
-        self._qt = torch.empty_like(self.state.positions)
-        self._pt = torch.empty_like(self.state.positions)
-        self._A = self._rp.A.to(R.device)
+        self._m_rep = m.reshape(-1).repeat(Bl).contiguous()
+        self._qt = torch.empty(nb, N, 3, device=dev)
+        self._pt = torch.empty(nb, N, 3, device=dev)
+        self._A = self._rp.A.to(dev)
+        if self._world > 1 and not self._replicated:
+            self._pack = torch.empty(2, Bl, N, 3, device=dev)                    # (q, p) of the rank, one message
+            self._gath = torch.empty(self._world, 2, Bl, N, 3, device=dev)
+            self._pgath = torch.empty(self._world, Bl, N, 3, device=dev)
         if self.thermostat is not None:          # NVT: PILE-L at step begin and end (md/simulator.py:126-150)
             self.thermostat.init(self._rp)
-            self._M = self.thermostat.M.to(R.device)
-            self._stepc = torch.zeros(1, dtype=torch.int64, device=R.device)      # step counter on the device: fresh noise per graph replay
+            self._M = self.thermostat.M.to(dev)
+            self._stepc = torch.zeros(1, dtype=torch.int64, device=dev)      # step counter on the device: fresh noise per graph replay
 
+    def _force_buffer(self, f):
+        if not self._replicated:
+            return super()._force_buffer(f)
+        buf = self.state.forces.view(-1, 3)        # the rank's rows of the all-bead force tensor, written in place
+        buf.copy_(f)
+        return buf
+
+    # -- the one collective primitive ------------------------------------------------------------
+    def _all_gather(self, out: torch.Tensor, local: torch.Tensor):
+        """``out[r] = local of rank r`` (contiguous buffers).  RCCL directly on the device buffers; other back-ends (gloo in
+        the tests: it has no device all-gather) through pinned host staging."""
+        import torch.distributed as dist
+        self.n_collectives += 1
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out.view(-1), local.view(-1), group=self.group)
+            return
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out.view(-1), local.detach().cpu().view(-1), group=self.group)
+        out.copy_(h_out)
+
+    # -- pieces of a step --------------------------------------------------------------------------
     def _thermostat(self, which):
-        th, st = self.thermostat, self.state
-        _pile_hip(st.momenta, st.masses, self._M, th.noise_scale, th.seed, 0, self._stepc, which, 0, self.n_beads, self._pt)
+        th = self.thermostat
+        if self._replicated:                       # all beads, every rank, same counter-based noise: no exchange
+            st = self.full
+            _pile_hip(st.momenta, st.masses, self._M, th.noise_scale, th.seed, 0, self._stepc, which, 0, self.n_beads, self._pt)
+        elif self._world > 1:                      # the rank's beads from everybody's momenta: ONE all-gather
+            st = self.state
+            self._all_gather(self._pgath, st.momenta)
+            _pile_hip(self._pgath.view(self.n_beads, self._n1, 3), st.masses, self._M, th.noise_scale, th.seed, 0, self._stepc, which,
+                      self._lo, self.n_local, self._pt)
+        else:
+            st = self.state
+            _pile_hip(st.momenta, st.masses, self._M, th.noise_scale, th.seed, 0, self._stepc, which, 0, self.n_beads, self._pt)
         with torch.no_grad():
             st.momenta.copy_(self._pt)
 
-    def _step_body(self):
+    def _skin(self):
         thr = max(0.5 * self.nl.cutoff_shell - self.margin, 0.0)
-        st = self.state
-        if self.thermostat is not None:
-            self._thermostat(0)
-        self.integrator.half_step(st)
         ref = None if self._complete else self.nl.previous_positions       # complete lists: nothing to watch
-        _ring_polymer_hip(st.positions, st.momenta, st.masses, self._A, 0, self.n_beads, self._qt, self._pt,
-                          ref, thr, None if self._complete else self.flag)
+        return ref, thr, (None if self._complete else self.flag)
+
+    def _mix(self):
+        """kick + ring-polymer main step of the beads this rank integrates (skin test on the beads of its list)."""
+        ref, thr, flag = self._skin()
+        if self._replicated:
+            st = self.full
+            self.integrator.half_step(st)
+            _ring_polymer_hip(st.positions, st.momenta, st.masses, self._A, 0, self.n_beads, self._qt, self._pt)
+            with torch.no_grad():
+                st.positions.copy_(self._qt)
+                st.momenta.copy_(self._pt)
+            if ref is not None:                    # skin criterion of the rank's own beads (a drift of zero length: test only)
+                loc = self.state
+                with torch.cuda.device(loc.positions.device):
+                    check(lib().spk_md_kick_drift_f32(fptr(loc.positions), fptr(loc.momenta), None, fptr(self._m_rep), 0.0,
+                                                      loc.positions.numel() // 3, fptr(ref), float(thr) ** 2,
+                                                      _lib.iptr(flag, torch.int32), stream()))
+            return
+        st = self.state
+        self.integrator.half_step(st)
+        if self._world > 1:
+            with torch.no_grad():
+                self._pack[0].copy_(st.positions)
+                self._pack[1].copy_(st.momenta)
+            self._all_gather(self._gath, self._pack)
+            q_all = self._gath[:, 0].reshape(self.n_beads, self._n1, 3)          # [world, n_local] -> beads (copy: strided)
+            p_all = self._gath[:, 1].reshape(self.n_beads, self._n1, 3)
+        else:
+            q_all, p_all = st.positions, st.momenta
+        _ring_polymer_hip(q_all, p_all, st.masses, self._A, self._lo, self.n_local, self._qt, self._pt, ref, thr, flag)
         with torch.no_grad():
             st.positions.copy_(self._qt)
             st.momenta.copy_(self._pt)
-        self._force_eval()
-        self.integrator.half_step(st)
+
+    def _finish(self):
+        """forces of the new positions -> second kick (-> thermostat, step counter)."""
+        if self._replicated:
+            self._all_gather(self._f_all.view(self._world, -1), self.state.forces)
+            self.integrator.half_step(self.full)
+        else:
+            self.integrator.half_step(self.state)
         if self.thermostat is not None:
             self._thermostat(1)
             with torch.no_grad():
                 self._stepc.add_(1)
 
+    def _step_body(self):
+        """single process: the whole step (one graph).  Bead-parallel: only the force evaluation (the graph segment between
+        the collectives); ``_one_step`` adds the rest."""
+        if self._world > 1:
+            self._force_eval()
+            return
+        if self.thermostat is not None:
+            self._thermostat(0)
+        self._mix()
+        self._force_eval()
+        self._finish()
+
+    def _one_step(self):
+        if self._world == 1:
+            return super()._one_step()
+        if self.thermostat is not None:
+            self._thermostat(0)
+        self._mix()
+        super()._one_step()                        # force call of the rank's beads: graph replay
+        self._finish()
+
+    @property
+    def collectives_per_step(self) -> int:
+        if self._world == 1:
+            return 0
+        if self._replicated:
+            return 1
+        return 1 + (2 if self.thermostat is not None else 0)
+
     def spring_energy(self):
-        q, m = self.state.positions, self.state.masses.reshape(1, -1, 1)
+        """Spring energy of the beads this process holds (all of them unless ``exchange="state"`` over several ranks, where
+        the links to the neighbouring ranks' beads are not visible locally)."""
+        st = self.full if self._replicated else self.state
+        q, m = st.positions, st.masses.reshape(1, -1, 1)
         d = q - torch.roll(q, -1, 0)
         return 0.5 * self._rp.omega ** 2 * (m * d * d).sum()
 

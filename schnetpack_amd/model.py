@@ -13,6 +13,80 @@ from .representation import PaiNN, SchNet
 __all__ = ["NeuralNetworkPotential", "build_model", "batch_to_inputs"]
 
 
+def _is_forces(m) -> bool:
+    """The mirror's ``Forces`` or the reference's own (atomistic/response.py:14-92; same attributes) -- not a subclass that may
+    have changed what the module computes."""
+    if type(m) is Forces:
+        return True
+    t = type(m)
+    return (t.__name__ == "Forces" and t.__module__ == "schnetpack.atomistic.response"
+            and all(hasattr(m, a) for a in ("calc_forces", "calc_stress", "energy_key", "force_key")))
+
+
+def classify_potential(model) -> int:
+    """0: module-by-module.  1: the standard potential -- ``PairwiseDistances`` -> fused ``SchNet`` -> ``Atomwise`` (default
+    head, summed or averaged over the molecule) -> ``Forces`` without stress: representation + head are ONE operator.
+    2: ... and the only other output is Forces' -dE/dR of a summed energy: energies AND forces from the two launches.
+    Works on any model with the reference's ``NeuralNetworkPotential`` layout (model/base.py:132-190), i.e. also on the
+    reference's own class around the HIP modules."""
+    rep, ins, outs = model.representation, list(model.input_modules), list(model.output_modules)
+    if not (isinstance(rep, SchNet) and rep._fused and len(rep.interactions) > 0):
+        return 0
+    if not (len(ins) == 1 and type(ins[0]) is PairwiseDistances and len(outs) >= 1):
+        return 0
+    head = outs[0]
+    if not (isinstance(head, Atomwise) and head._fused_head and head.per_atom_output_key is None
+            and head.aggregation_mode in ("sum", "avg")):
+        return 0
+    if not all(_is_forces(m) and not m.calc_stress for m in outs[1:]):
+        return 0
+    if (len(outs) == 2 and outs[1].calc_forces and outs[1].energy_key == head.output_key and head.aggregation_mode == "sum"):
+        return 2
+    return 1
+
+
+def potential_forward(model, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Standard potential, differentiable form: ``torch.ops.spk_hip.schnet_potential`` (pair vectors, representation and
+    energy head in one launch each way); the ``Forces`` module that follows triggers the one-launch backward."""
+    rep, head = model.representation, model.output_modules[0]
+    idx_m = inputs[properties.idx_m]
+    n_mol = head._n_molecules(inputs, idx_m)
+    kind, p0, p1 = rep.radial_basis.kernel_params()
+    l0, l1 = head.outnet[0], head.outnet[1]
+    E, x = torch.ops.spk_hip.schnet_potential(
+        rep.embed(inputs), inputs[properties.R], inputs.get(properties.offsets), inputs[properties.idx_i], inputs[properties.idx_j], idx_m,
+        n_mol, rep.interaction_weights(), [l0.weight, l0.bias, l1.weight, l1.bias], rep.n_filters, kind, p0, p1,
+        rep.cutoff_fn.cutoff_value(), head._head_act)
+    if head.aggregation_mode == "avg":
+        E = E / inputs[properties.n_atoms]
+    inputs["scalar_representation"] = x
+    inputs[head.output_key] = E
+    return inputs
+
+
+def potential_forces_forward(model, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Energies and forces straight from the two launches (no autograd node: eval only; the embedding rows are looked up
+    inside the forward launch when the nuclear embedding is a plain table)."""
+    rep, head, frc = model.representation, model.output_modules[0], model.output_modules[1]
+    idx_m = inputs[properties.idx_m]
+    kind, p0, p1 = rep.radial_basis.kernel_params()
+    l0, l1 = head.outnet[0], head.outnet[1]
+    plain = type(rep.embedding) is nn.Embedding and len(rep.electronic_embeddings) == 0
+    with torch.no_grad():
+        x0 = None if plain else rep.embed(inputs)
+        E, F, x = torch.ops.spk_hip.schnet_potential_forces(
+            x0, rep.embedding.weight if plain else None, inputs[properties.Z], inputs[properties.R], inputs.get(properties.offsets),
+            inputs[properties.idx_i], inputs[properties.idx_j], idx_m, head._n_molecules(inputs, idx_m), rep.interaction_weights(),
+            [l0.weight, l0.bias, l1.weight, l1.bias], rep.n_filters, kind, p0, p1, rep.cutoff_fn.cutoff_value(), head._head_act)
+    if torch.is_grad_enabled():      # a backward pass into this eval-mode model gets the eval-only message, not silence
+        guard = [l0.weight]
+        E, F = torch.ops.spk_hip.eval_guard(E, guard), torch.ops.spk_hip.eval_guard(F, guard)
+    inputs["scalar_representation"] = x
+    inputs[head.output_key] = E
+    inputs[frc.force_key] = F
+    return inputs
+
+
 class NeuralNetworkPotential(nn.Module):
     """input_modules -> representation -> output_modules (dict in, dict out); TorchScript-able like the reference's
     (src/scripts/spkdeploy:16-40 scripts the whole model).
@@ -21,7 +95,8 @@ class NeuralNetworkPotential(nn.Module):
     the molecule) -> ``Forces`` without stress -- runs in eval mode as ONE operator, ``torch.ops.spk_hip.schnet_potential``:
     on batches of small molecules the pair vectors, the representation and the energy head are one launch and the backward
     that ``Forces`` triggers (dE/dE -> head -> representation -> dE/dR) is one launch; on every other list the operator runs
-    the same three stages through their own kernels.  Any other composition takes the module-by-module path below."""
+    the same three stages through their own kernels.  Any other composition takes the module-by-module path below.
+    (``install(fused_potential=True)`` gives the reference's own ``NeuralNetworkPotential`` the same routing.)"""
 
     required_derivatives: List[str]
     model_outputs: List[str]
@@ -45,63 +120,18 @@ class NeuralNetworkPotential(nn.Module):
                 if k not in outs:
                     outs.append(k)
         self.model_outputs = outs
-        self._potential = self._is_standard_potential()
+        mode = classify_potential(self)
+        self._potential = mode >= 1
         # ... and when the only other output is Forces' -dE/dR, energies AND forces come from the two launches directly
-        outs_l = list(self.output_modules)
-        self._potential_forces = (self._potential and len(outs_l) == 2 and outs_l[1].calc_forces
-                                  and outs_l[1].energy_key == outs_l[0].output_key and outs_l[0].aggregation_mode == "sum")
-
-    def _is_standard_potential(self) -> bool:
-        rep, ins, outs = self.representation, list(self.input_modules), list(self.output_modules)
-        if not (isinstance(rep, SchNet) and rep._fused and len(rep.interactions) > 0):
-            return False
-        if not (len(ins) == 1 and type(ins[0]) is PairwiseDistances and len(outs) >= 1):
-            return False
-        head = outs[0]
-        if not (isinstance(head, Atomwise) and head._fused_head and head.per_atom_output_key is None
-                and head.aggregation_mode in ("sum", "avg")):
-            return False
-        return all(type(m) is Forces and not m.calc_stress for m in outs[1:])
+        self._potential_forces = mode == 2
 
     @torch.jit.unused
     def _potential_forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        rep, head = self.representation, self.output_modules[0]
-        idx_m = inputs[properties.idx_m]
-        n_mol = head._n_molecules(inputs, idx_m)
-        kind, p0, p1 = rep.radial_basis.kernel_params()
-        l0, l1 = head.outnet[0], head.outnet[1]
-        E, x = torch.ops.spk_hip.schnet_potential(
-            rep.embed(inputs), inputs[properties.R], inputs.get(properties.offsets), inputs[properties.idx_i], inputs[properties.idx_j], idx_m,
-            n_mol, rep.interaction_weights(), [l0.weight, l0.bias, l1.weight, l1.bias], rep.n_filters, kind, p0, p1,
-            rep.cutoff_fn.cutoff_value(), head._head_act)
-        if head.aggregation_mode == "avg":
-            E = E / inputs[properties.n_atoms]
-        inputs["scalar_representation"] = x
-        inputs[head.output_key] = E
-        return inputs
+        return potential_forward(self, inputs)
 
     @torch.jit.unused
     def _potential_forces_forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """Energies and forces straight from the two launches (no autograd node: eval only; the embedding rows are looked up
-        inside the forward launch when the nuclear embedding is a plain table)."""
-        rep, head, frc = self.representation, self.output_modules[0], self.output_modules[1]
-        idx_m = inputs[properties.idx_m]
-        kind, p0, p1 = rep.radial_basis.kernel_params()
-        l0, l1 = head.outnet[0], head.outnet[1]
-        plain = type(rep.embedding) is nn.Embedding and len(rep.electronic_embeddings) == 0
-        with torch.no_grad():
-            x0 = None if plain else rep.embed(inputs)
-            E, F, x = torch.ops.spk_hip.schnet_potential_forces(
-                x0, rep.embedding.weight if plain else None, inputs[properties.Z], inputs[properties.R], inputs.get(properties.offsets),
-                inputs[properties.idx_i], inputs[properties.idx_j], idx_m, head._n_molecules(inputs, idx_m), rep.interaction_weights(),
-                [l0.weight, l0.bias, l1.weight, l1.bias], rep.n_filters, kind, p0, p1, rep.cutoff_fn.cutoff_value(), head._head_act)
-        if torch.is_grad_enabled():      # a backward pass into this eval-mode model gets the eval-only message, not silence
-            guard = [l0.weight]
-            E, F = torch.ops.spk_hip.eval_guard(E, guard), torch.ops.spk_hip.eval_guard(F, guard)
-        inputs["scalar_representation"] = x
-        inputs[head.output_key] = E
-        inputs[frc.force_key] = F
-        return inputs
+        return potential_forces_forward(self, inputs)
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         for p in self.required_derivatives:

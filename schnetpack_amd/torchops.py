@@ -41,7 +41,7 @@ ops = load()
 
 OPERATORS = ["scatter_add", "gather", "pairwise", "pairwise_backward", "dense", "radial_cutoff", "schnet", "painn", "atomwise",
              "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
-             "painn_backward", "atomwise_forward", "atomwise_backward", "schnet_potential", "schnet_potential_forward", "schnet_potential_backward", "schnet_potential_forces", "eval_guard", "potential_plan", "edge_plan", "edge_plan_install", "static_declare", "static_declare_range", "static_refresh", "static_enable",
+             "painn_backward", "atomwise_forward", "atomwise_backward", "schnet_potential", "schnet_potential_forward", "schnet_potential_backward", "schnet_potential_forces", "eval_guard", "potential_plan", "edge_plan", "edge_plan_install", "static_new", "static_release", "weights_changed", "static_declare", "static_declare_range", "static_refresh", "static_enable",
              "static_check", "static_clear", "clear_caches",
              # training regime: operators closed under differentiation (csrc/spk_torch_train.h)
              "act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm", "vec3", "gemm_pair"]
@@ -63,27 +63,42 @@ class StaticLists:
     (``declare_range`` adds unsorted indices -- ``idx_j``, atomic numbers -- to that check)."""
 
     def __init__(self):
-        ops.static_clear()
+        # declarations are owned by THIS object: another StaticLists (a second shape bucket, a validation stepper) never frees
+        # or re-purposes the row-pointer / error buffers a captured graph of this one points at (round-2 ADVICE)
+        self._owner = int(ops.static_new())
+        self._prev = []
 
     def declare_sorted(self, idx, n_rows):
-        return ops.static_declare(idx, int(n_rows))
+        return ops.static_declare(idx, int(n_rows), self._owner)
 
     def declare_range(self, idx, hi):
         """``idx`` (any order) must lie in [0, hi): checked on the device by every ``refresh()``."""
-        ops.static_declare_range(idx, int(hi))
+        ops.static_declare_range(idx, int(hi), self._owner)
 
     def refresh(self):
-        ops.static_refresh()
+        ops.static_refresh(self._owner)
 
     def check(self):
-        f = int(ops.static_check())
+        f = int(ops.static_check(self._owner))
         if f:
             raise SpkHipError("StaticLists: a declared index was %s" % ("not ascending" if f & 1 else "out of range"))
 
+    def release(self):
+        """Drop this object's declarations and buffers (no graph that refreshed them may be replayed afterwards)."""
+        if self._owner:
+            ops.static_release(self._owner)
+            self._owner = 0
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:      # interpreter shutdown
+            pass
+
     def __enter__(self):
-        ops.static_enable(True)
+        self._prev.append(bool(ops.static_enable(True)))
         return self
 
     def __exit__(self, *exc):
-        ops.static_enable(False)
+        ops.static_enable(self._prev.pop() if self._prev else False)      # restore, do not just switch off: scopes nest
         return False

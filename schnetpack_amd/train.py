@@ -149,6 +149,9 @@ class GraphedTrainStep:
         if self.g_opt is not None:
             self.reducer(self.group)
             self.g_opt.replay()
+        # the captured optimizer updates the parameters in place WITHOUT moving their version counters: tell the operator
+        # library that every transposed / packed weight copy it caches (eval-mode forwards, e.g. validation) is stale
+        torch.ops.spk_hip.weights_changed()
         return self.loss
 
     def check(self):

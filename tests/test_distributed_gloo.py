@@ -200,7 +200,7 @@ def _pile_worker(rank, world, port, q):
         return res[bead0:bead0 + n_local].float()
 
     rp = RingPolymer(5e-4, 4, 300.0, omega=55.0, group=dist.group.WORLD, compute_fn=lambda *a, **k: None)
-    th = PILELocalThermostat(300.0, 0.1, seed=99, group=dist.group.WORLD, compute_fn=compute).init(rp)
+    th = PILELocalThermostat(300.0, 100.0, seed=99, group=dist.group.WORLD, compute_fn=compute).init(rp)
     lo, hi = 2 * rank, 2 * rank + 2
     st = MDState(Q[lo:hi].clone(), P[lo:hi].clone(), M)
     th.apply(st, step=5, which=0)

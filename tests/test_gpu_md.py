@@ -327,7 +327,7 @@ def test_rpmd_nvt_loop_with_pile_thermostat_thermalises(dev):
     inp = M.batch_to_inputs(b, dev)
     inp["_n_atoms"] = torch.bincount(b["idx_m"], minlength=4).to(dev)
     masses = torch.where(b["Z"] == 1, 1.008, torch.where(b["Z"] == 6, 12.011, 15.999)).to(dev)
-    th = MD.PILELocalThermostat(300.0, 0.01, seed=3)
+    th = MD.PILELocalThermostat(300.0, 10.0, seed=3)        # time constant in fs, like the reference's
     sim = MD.RPMDSimulation(model, inp, masses, 2e-4, 4, cutoff=5.0, omega=30.0, cutoff_shell=2.0, thermostat=th)
     assert float(sim.kinetic_energy()) == 0.0
     sim.step(300)

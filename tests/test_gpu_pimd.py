@@ -1,0 +1,267 @@
+"""configs[4] as stated (BASELINE.json: bulk water PBC, PaiNN, ring-polymer MD with 8 beads, PILE-L NVT; SURVEY.md section 8
+cfg 5) on the device:
+
+* a few NVT steps of an 8-bead PaiNN water box -- thermostat at step begin and end (md/simulator.py:126-150,
+  md/simulation_hooks/thermostats_rpmd.py:33-119), ring-polymer main step (md/integrators.py:204-229), force call of all beads
+  folded into the batch (md/calculators/base_calculator.py:166-183) -- against a float64 integration with ``oracle/md_oracle.py``
+  fed the SAME counter-based noise and oracle forces on exact per-bead periodic lists;
+* the forces of the 8-bead batch against the REFERENCE's own modules (oracle/refshim.py) at 1e-5, with an RMS criterion
+  beside the max-norm one;
+* the full-size system (8 x 31 944 atoms, ~13.7 M directed edges in one force call): every bead of the batch gets the forces
+  of that bead evaluated alone (size-independent property), and a few graph-replayed NVT steps run and thermalise;
+* the bead-parallel form of the same step (one bead chunk per rank, ``RPMDSimulation(group=...)``): two gloo ranks sharing the
+  one device reproduce the single-process trajectory with 1 + applications (exchange="state") resp. 1 (exchange="forces")
+  collectives per step.
+"""
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import rel_err
+from oracle import md_oracle as MDO
+from oracle import nbl_oracle as NB
+from oracle import refshim
+from oracle import spk_oracle as O
+from schnetpack_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _masses(Z):
+    return torch.where(Z == 1, 1.008, torch.where(Z == 6, 12.011, 15.999))
+
+
+def _water_inputs(b, dev):
+    from schnetpack_amd import model as M
+    inp = M.batch_to_inputs(b, dev)
+    inp["_n_atoms"] = torch.tensor([b["Z"].shape[0]], device=dev)
+    inp["_cell"] = b["cell"].reshape(1, 3, 3).to(dev)
+    inp["_pbc"] = torch.tensor([True, True, True], device=dev)
+    return inp
+
+
+def _painn(dev, rep_p, head_p):
+    from schnetpack_amd import model as M
+    m = M.build_model("painn")
+    M.load_reference_params(m, rep_p, head_p)
+    return m.to(dev).eval()
+
+
+KB = 0.8314462618          # Da A^2 / ps^2 / K  (positions in A, time in ps)
+DT, T_BATH, TAU_FS, SEED = 2.0e-4, 300.0, 100.0, 77
+
+
+def _sim(model, b, dev, n_beads, shell=1.0, **kw):
+    from schnetpack_amd import md as MD
+    th = MD.PILELocalThermostat(T_BATH, TAU_FS, seed=SEED, kb=KB)
+    return MD.RPMDSimulation(model, _water_inputs(b, dev), _masses(b["Z"]).to(dev), DT, n_beads, cutoff=5.0, temperature=T_BATH,
+                             cutoff_shell=shell, thermostat=th, **kw)
+
+
+def test_pimd_nvt_steps_follow_the_oracle_fed_the_same_noise(dev):
+    from schnetpack_amd import md as MD
+    rep_p, head_p = O.init_painn_params(), O.init_atomwise_params(128, seed=1)
+    # amplify the (random-init) potential so that the forces matter next to the 300 K noise: head output x 400
+    head_p = {k: (v * 400.0 if k.startswith("outnet.1") else v) for k, v in head_p.items()}
+    model = _painn(dev, rep_p, head_p)
+    b = S.water_box(n_side=5, seed=3)          # 375 atoms, L = 15.5 A
+    N, B = int(b["Z"].shape[0]), 8
+    sim = _sim(model, b, dev, B)
+    g = torch.Generator().manual_seed(11)
+    q0 = b["R"][None].repeat(B, 1, 1) + 0.02 * torch.randn(B, N, 3, generator=g)
+    masses = _masses(b["Z"])
+    p0 = torch.randn(B, N, 3, generator=g) * (masses[None, :, None] * KB * T_BATH).sqrt()
+    sim.state.positions.copy_(q0.to(dev))
+    sim.state.momenta.copy_(p0.to(dev))
+    sim._rebuild(True)
+    sim._force_eval()
+
+    cell, pbc = b["cell"].reshape(1, 3, 3), torch.tensor([[True, True, True]])
+
+    def oracle_forces(q):
+        out = []
+        for k in range(B):
+            i, j, _, off = NB.batch_neighbor_list(q[k].float(), b["idx_m"], cell, pbc, 5.0)
+            bb = dict(b, R=q[k], idx_i=i, idx_j=j, offsets=off.double())
+            out.append(O.energy_and_forces("painn", rep_p, head_p, bb, 3, dtype=torch.float64)["forces"])
+        return torch.stack(out)
+
+    omega = MD.KB_MD * B * T_BATH / MD.HBAR_MD                 # kB n T / hbar in 1 / ps (a ratio: unit system independent)
+    assert abs(sim._rp.omega - omega) < 1e-9 * omega
+    C = MDO.normal_mode_matrix(B)
+    _, prop = MDO.ring_polymer_propagator(B, omega, DT)
+    c1, c2 = MDO.pile_coefficients(B, omega, DT, TAU_FS * 1e-3)
+    kT = KB * B * T_BATH
+    q, p, m = q0.double(), p0.double(), masses.double()[None, :, None]
+    F = oracle_forces(q)
+    assert rel_err(sim.state.forces.cpu(), F) < TOL
+    n_steps = 4
+    for step in range(n_steps):
+        p = MDO.pile_apply(p, m, C, c1, c2, kT, MDO.pile_noise(B, N, SEED, step, 0))
+        p = MDO.half_step(p, F, DT)
+        q, p = MDO.ring_polymer_main_step(q, p, m, C, prop)
+        F = oracle_forces(q)
+        p = MDO.half_step(p, F, DT)
+        p = MDO.pile_apply(p, m, C, c1, c2, kT, MDO.pile_noise(B, N, SEED, step, 1))
+    sim.step(n_steps)
+    assert int(sim._stepc.item()) == n_steps
+    dq = (sim.state.positions.cpu().double() - q0.double())
+    assert rel_err(dq, q - q0.double()) < 2e-4, "displacements over the steps"       # displacements ~ 1e-2 A: fp32 positions resolve 1e-6 A
+    assert rel_err(sim.state.positions.cpu(), q) < 1e-6
+    assert rel_err(sim.state.momenta.cpu(), p) < 1e-4
+    assert rel_err(sim.state.forces.cpu(), F) < 5e-5          # forces at the END of the trajectory (positions differ by fp32 rounding)
+    # the force kicks were not negligible in this trajectory (otherwise the comparison would not see the force call)
+    assert float((F.abs().max() * DT) / p.abs().mean()) > 1e-3
+
+
+@pytest.mark.skipif(not refshim.available(), reason="neither /root/reference nor oracle/_ref present")
+def test_eight_bead_batch_forces_match_the_reference_modules(dev):
+    """Forces of the folded 8-bead periodic batch vs the reference's NeuralNetworkPotential (its PairwiseDistances, PaiNN,
+    Atomwise, Forces) on the host: max-norm AND rms, per component."""
+    ns = refshim.load()
+    rep_p, head_p = O.init_painn_params(), O.init_atomwise_params(128, seed=1)
+    model = _painn(dev, rep_p, head_p)
+    b = S.water_box(n_side=6, seed=5)          # 648 atoms
+    N, B = int(b["Z"].shape[0]), 8
+    sim = _sim(model, b, dev, B, shell=0.5)
+    g = torch.Generator().manual_seed(2)
+    q0 = b["R"][None].repeat(B, 1, 1) + 0.03 * torch.randn(B, N, 3, generator=g)
+    sim.state.positions.copy_(q0.to(dev))
+    sim._rebuild(True)
+    sim._force_eval()
+    Fg = sim.state.forces.cpu()
+
+    rb, cf = ns.nn.GaussianRBF(20, 5.0), ns.nn.CosineCutoff(5.0)
+    ref = ns.model.NeuralNetworkPotential(ns.painn.PaiNN(128, 3, rb, cf), input_modules=[ns.distances.PairwiseDistances()],
+                                          output_modules=[ns.atomwise.Atomwise(n_in=128, output_key="energy"), ns.response.Forces()])
+    ref.representation.load_state_dict(rep_p)
+    ref.output_modules[0].load_state_dict(head_p)
+    ref.eval()
+    cell, pbc = b["cell"].reshape(1, 3, 3), torch.tensor([[True, True, True]])
+    worst, num, den = 0.0, 0.0, 0.0
+    for k in range(B):
+        i, j, _, off = NB.batch_neighbor_list(q0[k], b["idx_m"], cell, pbc, 5.0)
+        out = ref({"_atomic_numbers": b["Z"], "_positions": q0[k].clone(), "_idx_i": i, "_idx_j": j, "_offsets": off.float(),
+                   "_idx_m": b["idx_m"], "_cell": cell, "_pbc": pbc.reshape(-1), "_n_atoms": torch.tensor([N])})
+        Fr = out["forces"].detach()
+        worst = max(worst, float((Fg[k] - Fr).abs().max() / Fr.abs().max()))
+        num += float((Fg[k].double() - Fr.double()).pow(2).sum())
+        den += float(Fr.double().pow(2).sum())
+    assert worst < TOL, worst
+    assert math.sqrt(num / den) < 3e-6, math.sqrt(num / den)
+
+
+def test_full_size_eight_bead_batch_is_bead_independent_and_runs_nvt(dev):
+    """8 x 31 944 atoms in ONE force call (configs[4] folded onto one GPU): bead b of the batch gets exactly the forces of bead
+    b evaluated alone (batch independence, the size-independent property at the full size), and the graph-replayed NVT loop
+    (PILE-L both ends, device step counter) advances and heats the cold ring polymer."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40e9:
+        pytest.skip("needs ~30 GB of device memory")
+    from schnetpack_amd import model as M
+    rep_p, head_p = O.init_painn_params(), O.init_atomwise_params(128, seed=1)
+    model = _painn(dev, rep_p, head_p)
+    b = S.water_box(n_side=22, seed=0)
+    N, B = int(b["Z"].shape[0]), 8
+    assert N == 31944
+    sim = _sim(model, b, dev, B, shell=2.0)
+    g = torch.Generator().manual_seed(4)
+    q0 = b["R"][None].repeat(B, 1, 1) + 0.02 * torch.randn(B, N, 3, generator=g)
+    sim.state.positions.copy_(q0.to(dev))
+    sim._rebuild(True)
+    sim._force_eval()
+    F8 = sim.state.forces.clone()
+    assert int(sim._lists["_idx_i"].shape[0]) > 8 * 1.7e6
+    one = _water_inputs(b, dev)
+    from schnetpack_amd import neighborlist as NL
+    for k in (0, 5):
+        inp = dict(one)
+        inp["_positions"] = q0[k].to(dev)
+        nl = NL.neighbor_list(inp["_positions"], 5.0, idx_m=inp["_idx_m"], cell=inp["_cell"], pbc=inp["_pbc"], n_systems=1)
+        inp.update({"_idx_i": nl["_idx_i"], "_idx_j": nl["_idx_j"], "_offsets": nl["_offsets"]})
+        F1 = model(inp)["forces"].detach()
+        assert rel_err(F8[k], F1) < 2e-6
+        rms = float((F8[k] - F1).double().pow(2).mean().sqrt() / F1.double().pow(2).mean().sqrt())
+        assert rms < 1e-6, rms
+    assert float(sim.kinetic_energy()) == 0.0
+    sim.step(6)
+    torch.cuda.synchronize()
+    assert int(sim._stepc.item()) == 6 and sim.graph is not None
+    ke = float(sim.kinetic_energy())
+    assert math.isfinite(ke) and ke > 0.0
+    assert torch.isfinite(sim.state.positions).all()
+
+
+# ----------------------------------------------------------------------------- bead-parallel (two gloo ranks, one device)
+def _free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _bp_worker(rank, world, port, exchange, n_steps, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    rep_p, head_p = O.init_painn_params(), O.init_atomwise_params(128, seed=1)
+    head_p = {k: (v * 400.0 if k.startswith("outnet.1") else v) for k, v in head_p.items()}
+    model = _painn(dev, rep_p, head_p)
+    b = S.water_box(n_side=5, seed=3)
+    sim = _sim(model, b, dev, 4, group=dist.group.WORLD, exchange=exchange)
+    sim.step(n_steps)
+    torch.cuda.synchronize()
+    lo = sim._lo
+    q.put((rank, lo, sim.state.positions.cpu().tolist(), sim.state.momenta.cpu().tolist(), sim.n_collectives, sim.collectives_per_step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["state", "forces"])
+def test_bead_parallel_pimd_two_ranks_equal_single_process(dev, exchange):
+    """4 beads over 2 ranks (2 per rank; both ranks on the one device of the box, gloo staged through the host) == 4 beads in one
+    process: same counter-based noise, same deterministic kernels.  Collectives per NVT step: 3 = 1 + applications for
+    exchange="state", 1 for exchange="forces" (md/utils/normal_model_transformation.py:70-98 is the only coupling of beads)."""
+    n_steps = 5
+    rep_p, head_p = O.init_painn_params(), O.init_atomwise_params(128, seed=1)
+    head_p = {k: (v * 400.0 if k.startswith("outnet.1") else v) for k, v in head_p.items()}
+    model = _painn(dev, rep_p, head_p)
+    b = S.water_box(n_side=5, seed=3)
+    ref = _sim(model, b, dev, 4)
+    ref.step(n_steps)
+    q_ref, p_ref = ref.state.positions.cpu(), ref.state.momenta.cpu()
+    assert ref.collectives_per_step == 0
+
+    ctx = mp.get_context("spawn")
+    qu = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bp_worker, args=(r, 2, port, exchange, n_steps, qu)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = {}
+    for _ in range(2):
+        rank, lo, qq, pp, ncoll, cps = qu.get(timeout=600)
+        res[rank] = (lo, torch.tensor(qq), torch.tensor(pp), ncoll, cps)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    for rank in (0, 1):
+        lo, qq, pp, ncoll, cps = res[rank]
+        assert lo == 2 * rank and qq.shape[0] == 2
+        assert cps == (3 if exchange == "state" else 1)
+        assert ncoll == cps * n_steps
+        assert rel_err(qq, q_ref[lo:lo + 2]) < 1e-6
+        assert rel_err(pp, p_ref[lo:lo + 2]) < 2e-5

@@ -143,3 +143,57 @@ def test_reference_callers_training_mode_weight_gradients(dev, ns):
         assert p.grad is not None, k
         worst = max(worst, rel_err(p.grad.cpu(), gr[k].grad))
     assert worst < 2e-4, worst     # fp32 second-order accumulations against the fp64 reference
+
+
+def test_unpickled_model_with_fused_head_install(dev, ns):
+    """Round-2 ADVICE: after install(fused_head=True) a reference-pickled model maps its Atomwise onto the mirror class without
+    running __init__ -- __setstate__ has to supply `_fused_head`, `_head_act`, `n_molecules_key`."""
+    import schnetpack_amd.install as inst
+    from schnetpack_amd import atomistic as A
+    path = build_ref.data_path("lammps_aspirin_best_model")
+    load_model = sys.modules["schnetpack.utils"].load_model if hasattr(sys.modules["schnetpack.utils"], "load_model") \
+        else __import__("schnetpack.utils.compatibility", fromlist=["load_model"]).load_model
+    b = S.molecule_batch("aspirin", 3, seed=5, jitter=0.03)
+    out_ref = load_model(path).eval()(_ref_inputs(b))
+    inst.install(sys.modules["schnetpack"], fused_head=True)
+    m_hip = load_model(path)
+    head = m_hip.output_modules[0]
+    assert isinstance(head, A.Atomwise) and head._fused_head and head.n_molecules_key == "_n_molecules"
+    out = m_hip.to(dev).eval()(_ref_inputs(b, dev))
+    assert rel_err(out["forces"].cpu(), out_ref["forces"]) < TOL
+
+
+def test_fused_potential_install_routes_the_reference_model_to_the_two_launch_operator(dev, ns):
+    """install(fused_head=True, fused_potential=True): the REFERENCE's NeuralNetworkPotential.forward hands the standard
+    potential (PairwiseDistances -> SchNet -> Atomwise -> Forces) to the fused operators in eval mode -- same energies and forces
+    as the reference on the CPU, exactly two profiled launches per call -- and keeps its own forward for everything else
+    (training mode, PaiNN)."""
+    import schnetpack_amd.install as inst
+    from schnetpack_amd import _lib
+    b = S.molecule_batch("aspirin", 6, seed=21)
+    m_ref = _build_reference_model(ns, "schnet").eval()
+    out_ref = m_ref(_ref_inputs(b))
+    inst.install(sys.modules["schnetpack"], fused_head=True, fused_potential=True)
+    m = _build_reference_model(ns, "schnet").to(dev).eval()
+    assert type(m) is ns.model.NeuralNetworkPotential and getattr(type(m).forward, "_spk_hip_patched", False)
+    out = m(_ref_inputs(b, dev))            # first call: plan
+    _lib.profile_enable(True)
+    _lib.profile_report()
+    out = m(_ref_inputs(b, dev))
+    prof = _lib.profile_report()
+    _lib.profile_enable(False)
+    assert m.__dict__["_spk_hip_mode"] == 2
+    assert set(prof) == {"schnet_mol_fwd", "schnet_mol_bwd"}, prof
+    assert set(out) == set(out_ref)
+    assert rel_err(out["energy"].cpu(), out_ref["energy"]) < TOL
+    assert rel_err(out["forces"].cpu(), out_ref["forces"]) < TOL
+    # training mode: the reference's forward (differentiable primitives, create_graph)
+    m.train()
+    o = m(_ref_inputs(b, dev))
+    assert o["forces"].requires_grad
+    # another architecture is left alone
+    mp_ = _build_reference_model(ns, "painn").to(dev).eval()
+    op = mp_(_ref_inputs(b, dev))
+    assert mp_.__dict__["_spk_hip_mode"] == 0 and torch.isfinite(op["forces"]).all()
+    inst.uninstall()
+    assert not getattr(ns.model.NeuralNetworkPotential.forward, "_spk_hip_patched", False)

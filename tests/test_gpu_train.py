@@ -123,3 +123,75 @@ def test_malformed_batch_is_flagged_on_the_device_and_reads_nothing_out_of_bound
     torch.cuda.synchronize()
     with pytest.raises(SpkHipError, match="out of range"):
         ts.check()
+
+
+def test_two_graphed_steppers_coexist(dev):
+    """Round-2 ADVICE: the static-shape declarations are owned by their StaticLists object.  A second stepper (another shape
+    bucket / a validation stepper) built and run while the first one's captured graph is alive must neither wipe the first
+    one's row pointers / error word nor disturb its trajectory: stepper A interleaved with stepper B walks the trajectory
+    of stepper A alone."""
+    from schnetpack_amd.train import GraphedTrainStep
+    frames, steps = 4, 8
+    data = _batches(steps, frames)
+    N = data[0][0]["Z"].shape[0]
+    emax = max(int(b["idx_i"].shape[0]) for b, _, _ in data) + 10
+
+    alone = GraphedTrainStep(_model("schnet", dev), N, frames, emax, 5.0, lr=1e-3)
+    ref_losses = []
+    for b, Et, Ft in data:
+        alone.load(b, Et, Ft)
+        ref_losses.append(float(alone.step()))
+    del alone
+
+    a = GraphedTrainStep(_model("schnet", dev), N, frames, emax, 5.0, lr=1e-3)
+    losses = []
+    other = _batches(3, 2)
+    bstep = None
+    for k, (b, Et, Ft) in enumerate(data):
+        a.load(b, Et, Ft)
+        losses.append(float(a.step()))
+        if k == 3:          # A's graph is captured by now: build B (different shapes: 2 frames, other capacity) and run it
+            bstep = GraphedTrainStep(_model("painn", dev), other[0][0]["Z"].shape[0], 2, max(int(x[0]["idx_i"].shape[0]) for x in other) + 7, 5.0)
+        if bstep is not None:
+            ob, oE, oF = other[k % 3]
+            bstep.load(ob, oE, oF)
+            assert torch.isfinite(bstep.step())
+    a.check()
+    bstep.check()
+    assert a.g_bwd is not None and bstep.g_bwd is not None
+    assert a.lists._owner != bstep.lists._owner
+    assert max(abs(x - y) / abs(y) for x, y in zip(losses, ref_losses)) < 1e-6, (losses, ref_losses)
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_eval_forward_after_graph_replays_sees_the_updated_weights(dev, kind):
+    """Round-2 ADVICE: a captured AdamW step updates the parameters in place without moving their version counters; the
+    operator library's transposed / packed weight copies (eval-mode forwards: validation) must not survive it.  Validation after
+    replays == a fresh model that was handed the trained parameters."""
+    from schnetpack_amd import model as M
+    from schnetpack_amd.train import GraphedTrainStep
+    frames = 4
+    data = _batches(7, frames)
+    N = data[0][0]["Z"].shape[0]
+    emax = max(int(b["idx_i"].shape[0]) for b, _, _ in data) + 10
+    model = _model(kind, dev)
+    ts = GraphedTrainStep(model, N, frames, emax, 5.0, lr=1e-2)
+    vb = S.molecule_batch("aspirin", 3, seed=900)
+    outs = []
+    for k, (b, Et, Ft) in enumerate(data):
+        ts.load(b, Et, Ft)
+        ts.step()
+        if k >= 2:          # validation between replays: fills the weight caches again and again
+            model.eval()
+            o = model(M.batch_to_inputs(vb, dev))
+            outs.append((o["energy"].detach().clone(), o["forces"].detach().clone()))
+            model.train()
+    assert ts.g_bwd is not None
+    fresh = M.build_model(kind).to(dev)
+    fresh.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()})
+    fresh.eval()
+    o = fresh(M.batch_to_inputs(vb, dev))
+    assert rel_err(outs[-1][0], o["energy"].detach()) < 1e-6
+    assert rel_err(outs[-1][1], o["forces"].detach()) < 1e-6
+    # and the validation outputs really moved with the training (a stale cache would have frozen part of them)
+    assert rel_err(outs[0][1], outs[-1][1]) > 1e-4
