@@ -132,6 +132,7 @@ _PROTOS = {
     "spk_schnet_cfconv_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
     "spk_cfconv_set_debug_buffer": (None, [c_f]),
     "spk_schnet_mol_set_debug_buffer": (None, [c_f]),
+    "spk_painn_mol_set_debug_buffer": (None, [c_f]),
     "spk_schnet_saved_floats": (c_i64, [P(SchnetT), c_i64]),
     "spk_schnet_saved_floats_graph": (c_i64, [P(SchnetT), P(GraphT), P(RadialT)]),
     "spk_schnet_scratch_floats": (c_i64, [P(SchnetT), c_i64]),

@@ -1154,6 +1154,11 @@ static spk_chain_layer_t mk_fwd(const float* w, const float* wT, const float* b,
             : mk_layer(w, b, nullptr, out, pre_out, nullptr, k, n_out, act, 0, 0);
 }
 
+// molecule-resident forward (spk_painn_mol.hip): block-diagonal lists with <= 32 atoms per block, F = 128
+bool spk_painn_mol_eligible(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb);
+int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
+                          const float* r_ij, float* q_out, float* mu_out, float* saved, hipStream_t stream);
+
 // per layer saved for backward: preA [F] | c [3F] | mu_in [3F] | mix [6F] | preB [F] | a [3F]
 static inline int64_t painn_saved_per_atom(int F) { return 17 * (int64_t)F; }
 
@@ -1184,6 +1189,8 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
     { int _zr = spk_zero_async(mu_out, 3 * nf * sizeof(float), stream); if (_zr) return _zr; }
     return SPK_OK;
   }
+  if (ptab.base && r_ij && spk_painn_mol_eligible(m, g, rb))      // batches of small molecules: the whole forward is ONE launch
+    return spk_painn_mol_forward(m, g, rb, ptab, q0, r_ij, q_out, mu_out, saved, stream);
   float* c1 = scratch;            // [N,F]
   float* q1 = c1 + nf;            // [N,F]
   float* mu1 = q1 + nf;           // [N,3F]

@@ -1,0 +1,621 @@
+// Molecule-resident PaiNN representation (representation/painn.py:207-256) for BATCHES OF SMALL MOLECULES.
+//
+// A batch produced by the reference's collate function (data/loader.py:35-46) is block diagonal: no edge leaves a molecule.
+// With <= 32 atoms per block the whole representation of a block -- every interaction: inter-atomic context net, equivariant
+// message, channel mix + intra-atomic context net + update (painn.py:31-67, :92-117) -- is local to ONE workgroup: q [32 x F],
+// mu [3 x 32 x F] and the context rows c [3 x 32 x F] live in LDS for the whole kernel, the 2 x 3 x 512-byte neighbour gathers of
+// the message never leave the compute unit, and nothing but the saved-for-backward tensors goes to memory.  One launch replaces
+// the 3 L launches of the general driver (spk_painn.hip: context chain, message, mixing per interaction).
+//
+// Workgroup = 8 wavefronts, one group of atoms (a block, or several small blocks, <= 32 atoms, <= 768 directed edges).
+// Per interaction (B = workgroup barrier):
+//   P1  pre_a = W_a1 q + b          (T-GEMM, 4 feature tiles)             -> saved, silu -> sH                     B
+//   P2  c = W_a2 silu(pre_a) + b    (12 feature tiles over the 8 waves)   -> saved, LDS planes (q | R | mu part)   B
+//   P3  message: one wavefront per centre atom walks its CSR row; a lane owns two channels; the filter slice
+//       Phi_e = (phi(d_e) W_f^T + b_f) f_c(d_e) is recomputed per edge from register-resident weights; c_j / mu_j come from LDS;
+//       the row sums stay in registers                                                                             B, write, B
+//   P4  (V | W) = mu W_mix^T for the three components (wave t: feature tile t of V and of W, so |V|, sum_x V W and the
+//       update are register-local), |V| -> LDS, mix -> saved                                                       B
+//   P5  pre_b = W_b1 [q | |V|] + b  (K = 256)                              -> saved, silu -> sH                     B
+//   P6  a = W_b2 silu(pre_b) + b -> saved;  q += a_q + a_qmu sum_x V W;  mu += a_mu W                               B
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout: 1e-5 parity with the reference rules out bf16.  Deterministic: no atomics.
+// The saved tensors have exactly the layout of the general driver (spk_painn_saved_floats), so either backward can follow.
+#include "spk_common.h"
+#include "spk_pack.h"
+
+#define PM_MAXL 6
+#define PM_LD 132                 // row stride (floats) of the [32][128] tiles in LDS: conflict-free 16-byte accesses
+#define PM_TILE (32 * PM_LD)
+#define PM_MAXEDGES 768           // directed edges per group (= 2 x 384 pairs, the plan's bound)
+#define PM_NRBF 20                // register-resident filter weights: n_rbf <= 20
+#define PM_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
+
+typedef float pm_f2 __attribute__((ext_vector_type(2)));
+
+struct PmLayerDev {
+  const float *ctx1_p, *ctx1_b;   // packed forward image of interatomic_context_net.0.weight [F, F], bias
+  const float *ctx2_p, *ctx2_b;   // ... .1.weight [3F, F]
+  const float* mix_p;             // mixing.mu_channel_mix.weight [2F, F]
+  const float *ic1_p, *ic1_b;     // intraatomic_context_net.0.weight [F, 2F]
+  const float *ic2_p, *ic2_b;     // ... .1.weight [3F, F]
+  const float *wf, *bf;           // filter_net rows of this interaction, raw [3F, n_rbf], [3F]
+};
+
+struct PmFwdArgs {
+  PmLayerDev L[PM_MAXL];
+  int n_layers;
+  const float* q0;          // [N, 128]
+  float* q_out;             // [N, 128]
+  float* mu_out;            // [N, 3, 128]
+  const float* rij;         // [E, 3]
+  const int64_t* idx_j;
+  const int32_t* rowptr;    // CSR of idx_i
+  const int32_t* grp_atom0; // [G+1]
+  int n_groups;
+  float* saved;             // per interaction: preA [N,F] | c [N,3F] | mu_in [N,3F] | mix [N,6F] | preB [N,F] | a [N,3F]
+  int64_t N;
+  float eps;
+  RadialDev rb;
+  long long* dbg;           // tuning aid: cycle stamps of thread 0 of workgroup 0 (spk_painn_mol_set_debug_buffer; null in production)
+};
+#define PM_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
+
+// per directed edge of a group: local neighbour, unit vector, distance, cutoff value -- computed once per group
+struct __attribute__((aligned(8))) PmEdge { int jl; float ux, uy, uz, d, fc; };
+
+template <class T>
+__device__ __forceinline__ T pm_ld(const void* sbase, unsigned voff) { return *(const T*)((const char*)sbase + voff); }
+template <class T>
+__device__ __forceinline__ void pm_st(void* sbase, unsigned voff, T v) { *(T*)((char*)sbase + voff) = v; }
+// register r of the half hi of a 32x32 accumulator holds row (r & 3) + 8 (r >> 2) + 4 hi
+__device__ __forceinline__ int pm_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---- T-GEMM pieces (convention of spk_dense.hip): A = packed weights straight from L2, B = activations [32][PM_LD] in LDS;
+// accumulator rows = output features 32 t + pm_row(r, hi), columns = atoms (lane & 31).
+// Packed image: P[((t * KB + ug) * 64 + lane) * 4 + v] = W[32 t + (lane & 31)][8 ug + 4 (lane >> 5) + v]; one k-block = 1024 bytes.
+__device__ __forceinline__ void pm_load8(f32x4 (&av)[8], const char* sb /* wave-uniform */, int lane) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) av[u] = pm_ld<f32x4>(sb, (unsigned)(lane * 16 + u * 1024));
+}
+// (all eight B operands are requested before the first MFMA: left alone the compiler issues each ds_read right in front of the
+//  four MFMAs that need it -- zero prefetch distance, the matrix pipe waits ~100 cycles per group of four)
+__device__ __forceinline__ f32x16 pm_mma8(const f32x4 (&av)[8], const float* __restrict__ brow, f32x16 acc) {
+  f32x4 bv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) bv[u] = *(const f32x4*)(brow + 8 * u);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    acc = PM_MFMA(av[u].x, bv[u].x, acc);
+    acc = PM_MFMA(av[u].y, bv[u].y, acc);
+    acc = PM_MFMA(av[u].z, bv[u].z, acc);
+    acc = PM_MFMA(av[u].w, bv[u].w, acc);
+  }
+  return acc;
+}
+// 16 k-blocks (K = 128 of the image's row, starting at k-block kb0) against ONE LDS tile
+__device__ __forceinline__ f32x16 pm_tile16(const float* __restrict__ wp, int KB, int t /* wave-uniform */, int kb0, const float* __restrict__ sB, int lane,
+                                            f32x16 acc) {
+  const char* sb = (const char*)wp + ((size_t)t * KB + kb0) * 1024;
+  const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
+  f32x4 a0[8], a1[8];
+  pm_load8(a0, sb, lane);
+  pm_load8(a1, sb + 8 * 1024, lane);
+  acc = pm_mma8(a0, brow, acc);
+  acc = pm_mma8(a1, brow + 64, acc);
+  return acc;
+}
+// the same weights against the THREE component planes of mu (A operand shared: 96 MFMAs per 8 k-blocks)
+__device__ __forceinline__ void pm_tile16x3(const float* __restrict__ wp, int t, const float* __restrict__ sB, int lane, f32x16& c0, f32x16& c1, f32x16& c2) {
+  const char* sb = (const char*)wp + (size_t)t * 16 * 1024;
+  const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
+  f32x4 a0[8], a1[8];
+  pm_load8(a0, sb, lane);
+  pm_load8(a1, sb + 8 * 1024, lane);
+  c0 = pm_mma8(a0, brow, c0);
+  c1 = pm_mma8(a0, brow + PM_TILE, c1);
+  c2 = pm_mma8(a0, brow + 2 * PM_TILE, c2);
+  c0 = pm_mma8(a1, brow + 64, c0);
+  c1 = pm_mma8(a1, brow + PM_TILE + 64, c1);
+  c2 = pm_mma8(a1, brow + 2 * PM_TILE + 64, c2);
+}
+__device__ __forceinline__ f32x16 pm_bias_acc(const float* __restrict__ b, int t, int hi) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = b[32 * t + pm_row(r, hi)];
+  return acc;
+}
+__device__ __forceinline__ float pm_silu(float x) { return x * spk_sigmoid(x); }
+
+// phi_k(d) for the lane's own k (nn/radial.py:11-15 gaussian, :105-110 bessel), parameters preloaded
+__device__ __forceinline__ float pm_phi(int kind, float p0k, float p1k, float d) {
+  if (kind == SPK_RBF_GAUSSIAN) {
+    const float c = -0.5f / (p1k * p1k);
+    const float t = d - p0k;
+    return expf(c * t * t);
+  }
+  const float s = sinf(p0k * d);
+  return d == 0.0f ? s : s / d;
+}
+
+// Workgroup barrier that waits for the LDS traffic of the wave only (like ck's block_sync_lds): __syncthreads() also drains
+// vmcnt, i.e. waits until the saved-for-backward STORES of the phase have been acknowledged by L2 (~5 k cycles each time) and
+// until the weight tiles prefetched for the next phase have arrived -- neither is needed at the barrier.
+#define PM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// one feature tile of packed weights (16 k-blocks = K 128) on its way from L2 + the bias of its rows
+struct PmW { f32x4 a0[8], a1[8]; };
+__device__ __forceinline__ void pm_wload(PmW& W, const float* __restrict__ wp, int KB, int t /* wave-uniform */, int kb0, int lane) {
+  const char* sb = (const char*)wp + ((size_t)t * KB + kb0) * 1024;
+  pm_load8(W.a0, sb, lane);
+  pm_load8(W.a1, sb + 8 * 1024, lane);
+}
+__device__ __forceinline__ f32x16 pm_wmma(const PmW& W, const float* __restrict__ sB, int lane, f32x16 acc) {
+  const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
+  acc = pm_mma8(W.a0, brow, acc);
+  acc = pm_mma8(W.a1, brow + 64, acc);
+  return acc;
+}
+__device__ __forceinline__ void pm_wmma3(const PmW& W, const float* __restrict__ sB, int lane, f32x16& c0, f32x16& c1, f32x16& c2) {
+  const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
+  c0 = pm_mma8(W.a0, brow, c0);
+  c1 = pm_mma8(W.a0, brow + PM_TILE, c1);
+  c2 = pm_mma8(W.a0, brow + 2 * PM_TILE, c2);
+  c0 = pm_mma8(W.a1, brow + 64, c0);
+  c1 = pm_mma8(W.a1, brow + PM_TILE + 64, c1);
+  c2 = pm_mma8(W.a1, brow + 2 * PM_TILE + 64, c2);
+}
+
+// filter rows 2 lane, 2 lane + 1 of the three parts (q | R | mu) of the filter net as they lie in memory: K consecutive floats per
+// row, [part][row][chunk of 4 k]
+template <int K>
+struct PmFilt { f32x4 w[3][2][K / 4]; };
+template <int K>
+__device__ __forceinline__ void pm_filt_load(PmFilt<K>& Wf, const float* __restrict__ wf, int lane, bool mu0) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const float* r0 = wf + (size_t)(p * 128 + 2 * lane) * K;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int c = 0; c < K / 4; ++c) Wf.w[p][ch][c] = !(mu0 && p == 2) ? *(const f32x4*)(r0 + ch * K + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// Phi = W phi + b for the lane's two channels of one part: products over PAIRS of k (the pair (w[k], w[k+1]) is adjacent in the
+// loaded row chunk, the pair (phi[k], phi[k+1]) in the broadcast LDS read: v_pk_fma_f32 without any repacking), the two partial
+// sums of a channel meet at the end
+template <int K>
+__device__ __forceinline__ pm_f2 pm_filter2(const f32x4 (&w0)[K / 4], const f32x4 (&w1)[K / 4], const f32x4 (&ph)[K / 4], pm_f2 bias) {
+  pm_f2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < K / 4; ++c) {
+    s0 = pm_f2{w0[c].x, w0[c].y} * pm_f2{ph[c].x, ph[c].y} + s0;
+    s1 = pm_f2{w1[c].x, w1[c].y} * pm_f2{ph[c].x, ph[c].y} + s1;
+    s0 = pm_f2{w0[c].z, w0[c].w} * pm_f2{ph[c].z, ph[c].w} + s0;
+    s1 = pm_f2{w1[c].z, w1[c].w} * pm_f2{ph[c].z, ph[c].w} + s1;
+  }
+  return pm_f2{s0.x + s0.y, s1.x + s1.y} + bias;
+}
+
+// P3: message (painn.py:43-66): a wavefront per centre atom (the atoms of the wave: sAsg), lane = channels 2 lane, 2 lane + 1; two
+// edges of the row per step -- lanes 0..31 evaluate the radial basis of the first, lanes 32..63 of the second, the values reach
+// all lanes through a 256-byte LDS slot of the wave (broadcast reads).  q is updated in place (no other atom's message reads
+// it); the new mu rows stay in registers (rm) until every wave has read its neighbours' rows.
+template <int K>
+__device__ __forceinline__ void pm_message(const PmFilt<K>& Wf, const float* __restrict__ bf, float* __restrict__ sQ, const float* __restrict__ sMu,
+                                           const float* __restrict__ sC, const PmEdge* __restrict__ sE, const int* __restrict__ sRow,
+                                           const int* __restrict__ myAsg, float* __restrict__ myPhi, int rbf_kind, float p0k, float p1k, float cutoff,
+                                           bool mu0, int lane, pm_f2 (&rm)[4][3]) {
+  const int hi = lane >> 5;
+  pm_f2 bias[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) bias[p] = *(const pm_f2*)(bf + p * 128 + 2 * lane);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int at = myAsg[it];
+    pm_f2 accq = {0.f, 0.f}, av0 = {0.f, 0.f}, av1 = {0.f, 0.f}, av2 = {0.f, 0.f};
+    if (at >= 0) {
+      const int rs = sRow[at], re = sRow[at + 1];
+      for (int le = rs; le < re; le += 2) {
+        const bool two = le + 1 < re;
+        const PmEdge eA = sE[le], eB = sE[two ? le + 1 : le];
+        const float fA = eA.d < cutoff ? eA.fc : 0.f, fB = (two && eB.d < cutoff) ? eB.fc : 0.f;
+        if (fA == 0.f && fB == 0.f) continue;          // skin pairs contribute exactly zero
+        myPhi[lane] = pm_phi(rbf_kind, p0k, p1k, hi ? eB.d : eA.d);
+        const int jA = eA.jl * PM_LD + 2 * lane, jB = eB.jl * PM_LD + 2 * lane;
+        f32x4 pa[K / 4], pb[K / 4];
+#pragma unroll
+        for (int c = 0; c < K / 4; ++c) { pa[c] = *(const f32x4*)(myPhi + 4 * c); pb[c] = *(const f32x4*)(myPhi + 32 + 4 * c); }
+        {
+          const pm_f2 PqA = pm_filter2<K>(Wf.w[0][0], Wf.w[0][1], pa, bias[0]), PqB = pm_filter2<K>(Wf.w[0][0], Wf.w[0][1], pb, bias[0]);
+          accq += PqA * fA * *(const pm_f2*)(sC + jA) + PqB * fB * *(const pm_f2*)(sC + jB);
+        }
+        {
+          const pm_f2 PRA = pm_filter2<K>(Wf.w[1][0], Wf.w[1][1], pa, bias[1]), PRB = pm_filter2<K>(Wf.w[1][0], Wf.w[1][1], pb, bias[1]);
+          const pm_f2 mRA = PRA * fA * *(const pm_f2*)(sC + PM_TILE + jA), mRB = PRB * fB * *(const pm_f2*)(sC + PM_TILE + jB);
+          av0 += mRA * eA.ux + mRB * eB.ux; av1 += mRA * eA.uy + mRB * eB.uy; av2 += mRA * eA.uz + mRB * eB.uz;
+        }
+        if (!mu0) {
+          const pm_f2 PmA = pm_filter2<K>(Wf.w[2][0], Wf.w[2][1], pa, bias[2]), PmB = pm_filter2<K>(Wf.w[2][0], Wf.w[2][1], pb, bias[2]);
+          const pm_f2 mmA = PmA * fA * *(const pm_f2*)(sC + 2 * PM_TILE + jA), mmB = PmB * fB * *(const pm_f2*)(sC + 2 * PM_TILE + jB);
+          av0 += mmA * *(const pm_f2*)(sMu + jA) + mmB * *(const pm_f2*)(sMu + jB);
+          av1 += mmA * *(const pm_f2*)(sMu + PM_TILE + jA) + mmB * *(const pm_f2*)(sMu + PM_TILE + jB);
+          av2 += mmA * *(const pm_f2*)(sMu + 2 * PM_TILE + jA) + mmB * *(const pm_f2*)(sMu + 2 * PM_TILE + jB);
+        }
+      }
+      const int io = at * PM_LD + 2 * lane;
+      *(pm_f2*)(sQ + io) += accq;
+      av0 += *(const pm_f2*)(sMu + io); av1 += *(const pm_f2*)(sMu + PM_TILE + io); av2 += *(const pm_f2*)(sMu + 2 * PM_TILE + io);
+    }
+    rm[it][0] = av0; rm[it][1] = av1; rm[it][2] = av2;
+  }
+}
+__device__ __forceinline__ void pm_message_write(float* __restrict__ sMu, const int* __restrict__ myAsg, int lane, const pm_f2 (&rm)[4][3]) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int at = myAsg[it];
+    if (at >= 0) {
+      const int io = at * PM_LD + 2 * lane;
+      *(pm_f2*)(sMu + io) = rm[it][0]; *(pm_f2*)(sMu + PM_TILE + io) = rm[it][1]; *(pm_f2*)(sMu + 2 * PM_TILE + io) = rm[it][2];
+    }
+  }
+}
+
+// Every weight tile is requested one step AHEAD of its use -- right after the MFMAs of the previous tile and BEFORE that tile's
+// epilogue: loads and stores share one in-order counter on this architecture, so a load issued behind the saved-tensor stores of
+// an epilogue could not be waited for before those stores were acknowledged.
+// The two teams of four waves (wave t of a team = SIMD t) run DIFFERENT code paths with the same sequence of barriers: the register
+// allocation of a path then only sees what that team keeps alive (team 0: V / W / sum V W across P4-P6; team 1: the K = 256 tile).
+template <int K>      // n_rbf (a multiple of 4, <= PM_NRBF): compile-time so that the register-resident filter weights are indexed statically
+__global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
+  constexpr int F = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sQ = smem;                          // [32][LD]     q
+  float* sMu = sQ + PM_TILE;                 // [3][32][LD]  mu, component planes
+  float* sC = sMu + 3 * PM_TILE;             // [3][32][LD]  c planes (q | R | mu part) during P2-P3; plane 0 = |V| during P4-P5
+  float* sH = sC + 3 * PM_TILE;              // [32][LD]     hidden layer of the two context nets
+  PmEdge* sE = (PmEdge*)(sH + PM_TILE);      // [PM_MAXEDGES]
+  float* sPhi = (float*)(sE + PM_MAXEDGES);  // [8 waves][64] radial basis of the two edges a wave is working on
+  int* sRow = (int*)(sPhi + 8 * 64);         // [33] local CSR
+  int* sAsg = sRow + 36;                     // [8 waves][4] atoms of a wave in the message phase (balanced by row length), -1 = none
+  float* sN = sC;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, el = lane & 31;
+  const int team = wv >> 2, t = wv & 3;
+  const float p0k = (el < K && a.rb.p0) ? a.rb.p0[el] : 0.f;      // lanes 0..31 and 32..63: the basis of edge A resp. B
+  const float p1k = (el < K && a.rb.p1) ? a.rb.p1[el] : 1.f;
+  const float cutoff = a.rb.cutoff;
+  const int64_t nf = a.N * (int64_t)F;
+  const int64_t per = 17 * nf;
+  float* myPhi = sPhi + wv * 64;
+  const int* myAsg = sAsg + wv * 4;
+
+  for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+    const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
+    const int e0 = a.rowptr[a0], ne = a.rowptr[a0 + na] - e0;
+    PM_BARRIER();      // the previous group is done with every LDS buffer
+    PM_STAMP(0);
+
+    // ---- group set-up: q rows, mu = 0 (painn.py:246), local CSR, edge geometry (shared by all interactions)
+    for (int s = tid; s < 32 * 32; s += 512) {
+      const int row = s >> 5, c4 = s & 31;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < na) v = pm_ld<f32x4>(a.q0 + (size_t)a0 * F, (unsigned)(s * 16));
+      *(f32x4*)(sQ + row * PM_LD + 4 * c4) = v;
+    }
+    for (int s = tid; s < 3 * PM_TILE / 4; s += 512) *(f32x4*)(sMu + 4 * s) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int le = tid; le < ne; le += 512) {
+      const int64_t e = (int64_t)e0 + le;
+      const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+      PmEdge ed;
+      ed.d = sqrtf(rx * rx + ry * ry + rz * rz);
+      const float inv = 1.0f / ed.d;
+      ed.ux = rx * inv; ed.uy = ry * inv; ed.uz = rz * inv;
+      float dfc;
+      spk_cutoff_eval(cutoff, ed.d, ed.fc, dfc);
+      ed.jl = (int)(a.idx_j[e] - a0);
+      sE[le] = ed;
+    }
+    if (wv == 7) {
+      // local CSR + the atoms of every wave in the message phase: rows ranked by length (longest first), dealt out in snake order
+      int r0 = 0;
+      if (lane <= 32) r0 = a.rowptr[a0 + (lane < na ? lane : na)] - e0;
+      const int r1 = __shfl_down(r0, 1, 64);
+      if (lane <= 32) sRow[lane] = r0;
+      const int deg = lane < na ? r1 - r0 : -1;
+      int rank = 0;
+      for (int b = 0; b < 32; ++b) {
+        const int db = __builtin_amdgcn_readlane(deg, b);
+        rank += (db > deg || (db == deg && b < lane)) ? 1 : 0;
+      }
+      if (lane < 32) sAsg[lane] = -1;
+      if (lane < na) {
+        const int rnd = rank >> 3, pos = rank & 7;
+        sAsg[((rnd & 1) ? 7 - pos : pos) * 4 + rnd] = lane;
+      }
+    }
+    // mu entering the first interaction is zero: the backward reads it from the saved block
+    for (int s = tid; s < na * 96; s += 512) pm_st<f32x4>(a.saved + 4 * nf + (size_t)a0 * 3 * F, (unsigned)(s * 16), f32x4{0.f, 0.f, 0.f, 0.f});
+
+    if (team == 0) {
+      // ======================================================================== team 0
+      PmW Wt;            // the weight tile this wave needs next
+      f32x16 bz;         // ... and its bias
+      pm_wload(Wt, a.L[0].ctx1_p, 16, t, 0, lane); bz = pm_bias_acc(a.L[0].ctx1_b, t, hi);
+      for (int l = 0; l < a.n_layers; ++l) {
+        const PmLayerDev& P = a.L[l];
+        float* S = a.saved + (int64_t)l * per;
+        const bool last = (l + 1 == a.n_layers);
+        float* mu_next_g = last ? a.mu_out : (a.saved + (int64_t)(l + 1) * per + 4 * nf);
+        PM_BARRIER();
+        PM_STAMP(1 + 8 * l);
+        // ---- P1: pre_a = W_a1 q + b (saved), silu -> sH
+        {
+          f32x16 acc = pm_wmma(Wt, sQ, lane, bz);
+          pm_wload(Wt, P.ctx2_p, 16, t, 0, lane); bz = pm_bias_acc(P.ctx2_b, t, hi);
+          float* preA_g = S;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *(f32x4*)(sH + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{pm_silu(pv.x), pm_silu(pv.y), pm_silu(pv.z), pm_silu(pv.w)};
+            if (el < na) pm_st<f32x4>(preA_g + (size_t)a0 * F + 32 * t, (unsigned)((el * F + 8 * q + 4 * hi) * 4), pv);
+          }
+        }
+        PM_BARRIER();
+        PM_STAMP(2 + 8 * l);
+        // ---- P2: c = W_a2 silu(pre_a) + b, tiles t and 8 + t (saved, LDS planes)
+        PmFilt<K> Wf;
+        {
+          float* c_g = S + nf;
+          f32x16 acc = pm_wmma(Wt, sH, lane, bz);
+          pm_wload(Wt, P.ctx2_p, 16, 8 + t, 0, lane); bz = pm_bias_acc(P.ctx2_b, 8 + t, hi);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *(f32x4*)(sC + el * PM_LD + 32 * t + 8 * q + 4 * hi) = cv;
+            if (el < na) pm_st<f32x4>(c_g + (size_t)a0 * 3 * F + 32 * t, (unsigned)((el * 3 * F + 8 * q + 4 * hi) * 4), cv);
+          }
+          acc = pm_wmma(Wt, sH, lane, bz);
+          pm_filt_load<K>(Wf, P.wf, lane, l == 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *(f32x4*)(sC + 2 * PM_TILE + el * PM_LD + 32 * t + 8 * q + 4 * hi) = cv;
+            if (el < na) pm_st<f32x4>(c_g + (size_t)a0 * 3 * F + 32 * (8 + t), (unsigned)((el * 3 * F + 8 * q + 4 * hi) * 4), cv);
+          }
+        }
+        PM_BARRIER();
+        PM_STAMP(3 + 8 * l);
+        // ---- P3: message
+        {
+          pm_f2 rm[4][3];
+          pm_message<K>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, l == 0, lane, rm);
+          pm_wload(Wt, P.mix_p, 16, t, 0, lane);
+          PM_STAMP(4 + 8 * l);
+          PM_BARRIER();       // every wave has read its neighbours' rows: mu can be replaced
+          pm_message_write(sMu, myAsg, lane, rm);
+        }
+        PM_BARRIER();
+        PM_STAMP(5 + 8 * l);
+        // ---- P4: V = mu W_mix^T[:F] for the three components (feature tile t); |V| -> LDS (read by team 1 in P5); V saved
+        f32x16 W0, W1, W2, sVW;
+        f32x16 V0, V1, V2;
+        {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { V0[r] = 0.f; V1[r] = 0.f; V2[r] = 0.f; W0[r] = 0.f; W1[r] = 0.f; W2[r] = 0.f; }
+          pm_wmma3(Wt, sMu, lane, V0, V1, V2);
+          pm_wload(Wt, P.mix_p, 16, 4 + t, 0, lane);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 nv;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int r = 4 * q + v;
+              nv[v] = sqrtf(V0[r] * V0[r] + V1[r] * V1[r] + V2[r] * V2[r] + a.eps);
+            }
+            *(f32x4*)(sN + el * PM_LD + 32 * t + 8 * q + 4 * hi) = nv;
+          }
+        }
+        PM_BARRIER();
+        PM_STAMP(6 + 8 * l);
+        // ---- P5: W = mu W_mix^T[F:] (beside team 1's pre_b on the same SIMD); sum_x V W; mix saved
+        {
+          pm_wmma3(Wt, sMu, lane, W0, W1, W2);
+          pm_wload(Wt, P.ic2_p, 16, 8 + t, 0, lane); bz = pm_bias_acc(P.ic2_b, 8 + t, hi);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sVW[r] = V0[r] * W0[r] + V1[r] * W1[r] + V2[r] * W2[r];
+          if (el < na) {
+            float* mg = S + 7 * nf + (size_t)a0 * 6 * F + 32 * t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned o = (unsigned)((el * 6 * F + 8 * q + 4 * hi) * 4);
+              pm_st<f32x4>(mg, o, f32x4{V0[4 * q], V0[4 * q + 1], V0[4 * q + 2], V0[4 * q + 3]});
+              pm_st<f32x4>(mg, o + 2 * F * 4, f32x4{V1[4 * q], V1[4 * q + 1], V1[4 * q + 2], V1[4 * q + 3]});
+              pm_st<f32x4>(mg, o + 4 * F * 4, f32x4{V2[4 * q], V2[4 * q + 1], V2[4 * q + 2], V2[4 * q + 3]});
+              pm_st<f32x4>(mg, o + F * 4, f32x4{W0[4 * q], W0[4 * q + 1], W0[4 * q + 2], W0[4 * q + 3]});
+              pm_st<f32x4>(mg, o + 3 * F * 4, f32x4{W1[4 * q], W1[4 * q + 1], W1[4 * q + 2], W1[4 * q + 3]});
+              pm_st<f32x4>(mg, o + 5 * F * 4, f32x4{W2[4 * q], W2[4 * q + 1], W2[4 * q + 2], W2[4 * q + 3]});
+            }
+          }
+        }
+        PM_BARRIER();
+        PM_STAMP(7 + 8 * l);
+        // ---- P6: a = W_b2 silu(pre_b) + b (saved);  q += a_q + a_qmu sum_x V W;  mu += a_mu W      (painn.py:110-116)
+        {
+          float* ag = S + 14 * nf + (size_t)a0 * 3 * F + 32 * t;
+          f32x16 tq = pm_wmma(Wt, sH, lane, bz);                       // a_qmu
+          pm_wload(Wt, P.ic2_p, 16, t, 0, lane); bz = pm_bias_acc(P.ic2_b, t, hi);
+          if (el < na) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              pm_st<f32x4>(ag, (unsigned)((el * 3 * F + 2 * F + 8 * q + 4 * hi) * 4), f32x4{tq[4 * q], tq[4 * q + 1], tq[4 * q + 2], tq[4 * q + 3]});
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tq[r] *= sVW[r];
+          f32x16 aq = pm_wmma(Wt, sH, lane, bz);                       // a_q
+          pm_wload(Wt, P.ic2_p, 16, 4 + t, 0, lane); bz = pm_bias_acc(P.ic2_b, 4 + t, hi);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float* qp = sQ + el * PM_LD + 32 * t + 8 * q + 4 * hi;
+            f32x4 qv = *(const f32x4*)qp;
+            const f32x4 av = {aq[4 * q], aq[4 * q + 1], aq[4 * q + 2], aq[4 * q + 3]};
+            qv.x += av.x + tq[4 * q]; qv.y += av.y + tq[4 * q + 1]; qv.z += av.z + tq[4 * q + 2]; qv.w += av.w + tq[4 * q + 3];
+            if (el >= na) qv = f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)qp = qv;
+            if (el < na) {
+              pm_st<f32x4>(ag, (unsigned)((el * 3 * F + 8 * q + 4 * hi) * 4), av);
+              if (last) pm_st<f32x4>(a.q_out + (size_t)a0 * F + 32 * t, (unsigned)((el * F + 8 * q + 4 * hi) * 4), qv);
+            }
+          }
+          f32x16 am = pm_wmma(Wt, sH, lane, bz);                       // a_mu
+          if (!last) { pm_wload(Wt, a.L[l + 1].ctx1_p, 16, t, 0, lane); bz = pm_bias_acc(a.L[l + 1].ctx1_b, t, hi); }
+          float* mn = mu_next_g + (size_t)a0 * 3 * F + 32 * t;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 av = {am[4 * q], am[4 * q + 1], am[4 * q + 2], am[4 * q + 3]};
+            float* mp = sMu + el * PM_LD + 32 * t + 8 * q + 4 * hi;
+            f32x4 m0 = *(const f32x4*)mp, m1 = *(const f32x4*)(mp + PM_TILE), m2 = *(const f32x4*)(mp + 2 * PM_TILE);
+            m0.x += av.x * W0[4 * q]; m0.y += av.y * W0[4 * q + 1]; m0.z += av.z * W0[4 * q + 2]; m0.w += av.w * W0[4 * q + 3];
+            m1.x += av.x * W1[4 * q]; m1.y += av.y * W1[4 * q + 1]; m1.z += av.z * W1[4 * q + 2]; m1.w += av.w * W1[4 * q + 3];
+            m2.x += av.x * W2[4 * q]; m2.y += av.y * W2[4 * q + 1]; m2.z += av.z * W2[4 * q + 2]; m2.w += av.w * W2[4 * q + 3];
+            if (el >= na) { m0 = f32x4{0.f, 0.f, 0.f, 0.f}; m1 = m0; m2 = m0; }
+            *(f32x4*)mp = m0; *(f32x4*)(mp + PM_TILE) = m1; *(f32x4*)(mp + 2 * PM_TILE) = m2;
+            if (el < na) {
+              const unsigned o = (unsigned)((el * 3 * F + 8 * q + 4 * hi) * 4);
+              pm_st<f32x4>(ag, (unsigned)((el * 3 * F + F + 8 * q + 4 * hi) * 4), av);
+              pm_st<f32x4>(mn, o, m0);
+              pm_st<f32x4>(mn, o + F * 4, m1);
+              pm_st<f32x4>(mn, o + 2 * F * 4, m2);
+            }
+          }
+        }
+        PM_STAMP(8 + 8 * l);
+        // (the barrier at the top of the next interaction / group closes this phase)
+      }
+    } else {
+      // ======================================================================== team 1
+      for (int l = 0; l < a.n_layers; ++l) {
+        const PmLayerDev& P = a.L[l];
+        float* S = a.saved + (int64_t)l * per;
+        PmW Wt;
+        f32x16 bz;
+        PM_BARRIER();
+        // ---- P1: (team 0: pre_a) -- request the tile of P2
+        pm_wload(Wt, P.ctx2_p, 16, 4 + t, 0, lane); bz = pm_bias_acc(P.ctx2_b, 4 + t, hi);
+        PM_BARRIER();
+        // ---- P2: c tile 4 + t (the R part)
+        PmFilt<K> Wf;
+        {
+          float* c_g = S + nf;
+          f32x16 acc = pm_wmma(Wt, sH, lane, bz);
+          pm_filt_load<K>(Wf, P.wf, lane, l == 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *(f32x4*)(sC + PM_TILE + el * PM_LD + 32 * t + 8 * q + 4 * hi) = cv;
+            if (el < na) pm_st<f32x4>(c_g + (size_t)a0 * 3 * F + 32 * (4 + t), (unsigned)((el * 3 * F + 8 * q + 4 * hi) * 4), cv);
+          }
+        }
+        PM_BARRIER();
+        // ---- P3: message
+        {
+          pm_f2 rm[4][3];
+          pm_message<K>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, l == 0, lane, rm);
+          PM_BARRIER();
+          pm_message_write(sMu, myAsg, lane, rm);
+        }
+        PM_BARRIER();
+        // ---- P4: (team 0: channel mix) -- request the K = 256 tile of P5
+        PmW Wu;
+        pm_wload(Wt, P.ic1_p, 32, t, 0, lane);
+        pm_wload(Wu, P.ic1_p, 32, t, 16, lane);
+        bz = pm_bias_acc(P.ic1_b, t, hi);
+        PM_BARRIER();
+        // ---- P5: pre_b = W_b1 [q | |V|] + b (K = 256; saved), silu -> sH
+        {
+          float* preB_g = S + 13 * nf;
+          f32x16 acc = pm_wmma(Wt, sQ, lane, bz);
+          acc = pm_wmma(Wu, sN, lane, acc);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *(f32x4*)(sH + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{pm_silu(pv.x), pm_silu(pv.y), pm_silu(pv.z), pm_silu(pv.w)};
+            if (el < na) pm_st<f32x4>(preB_g + (size_t)a0 * F + 32 * t, (unsigned)((el * F + 8 * q + 4 * hi) * 4), pv);
+          }
+        }
+        PM_BARRIER();
+        // ---- P6: (team 0: update)
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static long long* g_pm_dbg = nullptr;
+// tuning aid (scripts/painn_mol_timing.py): device buffer of >= 64 int64 receiving cycle stamps of thread 0 of workgroup 0 at the
+// phase boundaries of the forward (entry 0: group start; 1 + 8 l ... 8 + 8 l: P1 .. end of interaction l).  NULL: off (production)
+extern "C" void spk_painn_mol_set_debug_buffer(void* p) { g_pm_dbg = (long long*)p; }
+static size_t painn_mol_fwd_lds() { return (size_t)(8 * PM_TILE + 8 * 64) * sizeof(float) + PM_MAXEDGES * sizeof(PmEdge) + (36 + 32) * sizeof(int); }
+
+// Shapes / lists the molecule-resident forward covers (everything else runs the general driver of spk_painn.hip)
+bool spk_painn_mol_eligible(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb) {
+  const int variant = spk_get_variant();
+  if (variant != SPK_VARIANT_AUTO && variant != SPK_VARIANT_MFMA_PAIR && variant != SPK_VARIANT_MFMA) return false;
+  if (getenv("SPK_NO_MOL") || getenv("SPK_NO_PAINN_MOL")) return false;
+  if (m->n_atom_basis != 128 || m->n_interactions < 1 || m->n_interactions > PM_MAXL || !m->wpack) return false;
+  if (rb->n_rbf != 20 && rb->n_rbf != 16 && rb->n_rbf != 12 && rb->n_rbf != 8) return false;      // instances (filter rows are fetched as 16-byte vectors)
+  if (!(g->sorted && g->rowptr && g->idx_j)) return false;
+  if (g->n_groups <= 0 || !g->grp_atom0 || g->max_group_atoms > 32) return false;
+  if (g->max_group_pairs <= 0 || 2 * g->max_group_pairs > PM_MAXEDGES) return false;
+  return true;
+}
+
+template <int K>
+static int launch_painn_mol_fwd(const PmFwdArgs& a, hipStream_t stream) {
+  const size_t lds = painn_mol_fwd_lds();
+  auto kern = k_painn_mol_fwd<K>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  int grid = a.n_groups;
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  SpkProfScope prof("painn_mol_fwd", stream);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
+                          const float* r_ij, float* q_out, float* mu_out, float* saved, hipStream_t stream) {
+  PmFwdArgs a;
+  a.n_layers = m->n_interactions;
+  for (int l = 0; l < m->n_interactions; ++l) {
+    const spk_painn_layer_t& P = m->layers[l];
+    PmLayerDev& D = a.L[l];
+    D.ctx1_p = spk_packed_of(ptab, P.ctx_w1, 0); D.ctx1_b = P.ctx_b1;
+    D.ctx2_p = spk_packed_of(ptab, P.ctx_w2, 0); D.ctx2_b = P.ctx_b2;
+    D.mix_p = spk_packed_of(ptab, P.mix_w, 0);
+    D.ic1_p = spk_packed_of(ptab, P.ictx_w1, 0); D.ic1_b = P.ictx_b1;
+    D.ic2_p = spk_packed_of(ptab, P.ictx_w2, 0); D.ic2_b = P.ictx_b2;
+    D.wf = P.filt_w; D.bf = P.filt_b;
+    SPK_CHECK_ARG(D.ctx1_p && D.ctx2_p && D.mix_p && D.ic1_p && D.ic2_p, "spk_painn_mol_forward: packed weight image missing");
+    SPK_CHECK_ARG(D.ctx1_b && D.ctx2_b && D.ic1_b && D.ic2_b && D.wf && D.bf, "spk_painn_mol_forward: null bias / filter weights");
+  }
+  a.q0 = q0; a.q_out = q_out; a.mu_out = mu_out; a.rij = r_ij;
+  a.idx_j = g->idx_j; a.rowptr = g->rowptr; a.grp_atom0 = g->grp_atom0; a.n_groups = g->n_groups;
+  a.saved = saved; a.N = g->n_atoms; a.eps = m->epsilon; a.rb = spk_radial_dev(rb); a.dbg = g_pm_dbg;
+  switch (rb->n_rbf) {
+    case 20: return launch_painn_mol_fwd<20>(a, stream);
+    case 16: return launch_painn_mol_fwd<16>(a, stream);
+    case 12: return launch_painn_mol_fwd<12>(a, stream);
+    case 8: return launch_painn_mol_fwd<8>(a, stream);
+    default: break;
+  }
+  SPK_CHECK_ARG(false, "spk_painn_mol_forward: n_rbf = %d has no instance (see spk_painn_mol_eligible)", rb->n_rbf);
+  return SPK_OK;
+}

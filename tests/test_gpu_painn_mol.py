@@ -1,0 +1,106 @@
+"""Molecule-resident PaiNN kernels (schnetpack_amd/csrc/spk_painn_mol.hip): batches of small molecules are block diagonal
+(data/loader.py:35-46), so a group of <= 32 atoms runs all interactions (painn.py:207-256) inside one workgroup with q / mu / context
+rows in LDS.  Checked against the CPU oracle in float64 and against the general driver (``SPK_NO_PAINN_MOL`` disables the molecule
+path; the profile tags assert which path ran).  Tolerance 1e-5 relative (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import spk_oracle as O
+from schnetpack_amd import synthetic as S
+from test_gpu_mol import _mixed_batch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _run(batch, dev, n_int=3, n_rbf=20, radial="gaussian", general=False, **rep_kw):
+    from schnetpack_amd import _lib, model as M
+    rep = O.init_painn_params(128, n_int, n_rbf, 5.0, radial=radial, **rep_kw)
+    head = O.init_atomwise_params(128, seed=1)
+    m = M.build_model("painn", 128, n_int, n_rbf, 5.0, radial, **rep_kw)
+    M.load_reference_params(m, rep, head)
+    m = m.to(dev).eval()
+    if general:
+        os.environ["SPK_NO_PAINN_MOL"] = "1"
+    try:
+        _lib.profile_enable(True)
+        _lib.profile_report()
+        inp = M.batch_to_inputs(batch, dev)
+        out = m(inp)
+        res = (out["energy"].detach().cpu(), out["forces"].detach().cpu(), inp["scalar_representation"].detach().cpu(),
+               inp["vector_representation"].detach().cpu())
+        tags = _lib.profile_report()
+    finally:
+        _lib.profile_enable(False)
+        os.environ.pop("SPK_NO_PAINN_MOL", None)
+    return res, tags, (rep, head)
+
+
+@pytest.mark.parametrize("sizes,n_int,n_rbf,radial,rep_kw", [
+    (["aspirin"] * 7, 3, 20, "gaussian", {}),
+    (["ethanol", "aspirin", "atom", "ethanol", "dimer", "ethanol", "ethanol", "aspirin", "atom", "atom"], 3, 20, "gaussian", {}),
+    (["ethanol"] * 40, 2, 16, "bessel", {}),
+    (["aspirin", "dimer"] * 3, 1, 8, "gaussian", {}),
+    (["aspirin"] * 300, 3, 20, "gaussian", {}),          # more groups than compute units: the workgroups loop
+    (["aspirin"] * 5, 2, 20, "bessel", {"shared_filters": True}),
+])
+def test_molecule_resident_painn_matches_oracle_and_general_driver(dev, sizes, n_int, n_rbf, radial, rep_kw):
+    b = _mixed_batch(3, sizes)
+    (e, f, x, v), tags, (rep, head) = _run(b, dev, n_int, n_rbf, radial, **rep_kw)
+    assert "painn_mol_fwd" in tags and not any(t.startswith(("painn_msg_fwd", "painn_mixing_fwd")) for t in tags), tags      # the path under test ran
+    ref = O.energy_and_forces("painn", rep, head, b, n_int, need_rep=True, dtype=torch.float64, shared_filters=bool(rep_kw.get("shared_filters")))
+    assert rel_err(x, ref["scalar_representation"]) < TOL
+    assert rel_err(v, ref["vector_representation"]) < TOL
+    assert rel_err(e, ref["energy"]) < TOL and rel_err(f, ref["forces"]) < TOL
+    (e2, f2, x2, v2), tags2, _ = _run(b, dev, n_int, n_rbf, radial, general=True, **rep_kw)
+    assert "painn_mol_fwd" not in tags2 and any(t.startswith("painn_msg_fwd") for t in tags2), tags2
+    assert rel_err(x, x2) < 2e-6 and rel_err(v, v2) < 2e-6 and rel_err(f, f2) < 5e-6
+
+
+def test_molecule_resident_painn_is_deterministic(dev):
+    b = S.molecule_batch("aspirin", 64, seed=9)
+    (e1, f1, x1, v1), tags, _ = _run(b, dev)
+    (e2, f2, x2, v2), _, _ = _run(b, dev)
+    assert "painn_mol_fwd" in tags
+    assert torch.equal(x1, x2) and torch.equal(v1, v2)
+
+
+def test_skin_list_pairs_beyond_the_cutoff_contribute_nothing(dev):
+    """An MD list with a 2 A skin holds pairs with f_c = 0: same representation and forces as the exact list."""
+    rng = np.random.RandomState(1)
+    systems_skin, systems_exact = [], []
+    for _ in range(6):
+        R = np.asarray(S.ASPIRIN_R) + 0.05 * rng.randn(21, 3)
+        for lst, rc in ((systems_skin, 7.0), (systems_exact, 5.0)):
+            ii, jj = S.neighbor_pairs_open(R, rc)
+            lst.append({"Z": S.ASPIRIN_Z, "R": R, "idx_i": ii, "idx_j": jj})
+    bs, be = S.collate(systems_skin), S.collate(systems_exact)
+    assert bs["idx_i"].shape[0] > be["idx_i"].shape[0]
+    (e, f, x, v), tags, (rep, head) = _run(bs, dev)
+    assert "painn_mol_fwd" in tags
+    ref = O.energy_and_forces("painn", rep, head, be, 3, need_rep=True, dtype=torch.float64)
+    assert rel_err(x, ref["scalar_representation"]) < TOL and rel_err(f, ref["forces"]) < TOL
+
+
+def test_large_molecules_and_wide_bases_fall_back_to_the_general_driver(dev):
+    rng = np.random.RandomState(0)
+    R = np.concatenate([np.asarray(S.ASPIRIN_R), np.asarray(S.ASPIRIN_R) + np.array([4.0, 0.0, 0.0])]) + 0.05 * rng.randn(42, 3)
+    ii, jj = S.neighbor_pairs_open(R, 5.0)
+    b = S.collate([{"Z": S.ASPIRIN_Z * 2, "R": R, "idx_i": ii, "idx_j": jj}] * 3)
+    (e, f, x, v), tags, (rep, head) = _run(b, dev)
+    assert "painn_mol_fwd" not in tags
+    assert rel_err(f, O.energy_and_forces("painn", rep, head, b, 3)["forces"]) < TOL
+    b2 = _mixed_batch(2, ["aspirin"] * 4)
+    (e, f, x, v), tags, (rep, head) = _run(b2, dev, 3, 32)      # n_rbf = 32 > 20: filter weights do not fit the registers
+    assert "painn_mol_fwd" not in tags
+    assert rel_err(f, O.energy_and_forces("painn", rep, head, b2, 3)["forces"]) < TOL
