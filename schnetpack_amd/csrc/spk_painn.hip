@@ -1158,6 +1158,9 @@ static spk_chain_layer_t mk_fwd(const float* w, const float* wT, const float* b,
 bool spk_painn_mol_eligible(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb);
 int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
                           const float* r_ij, float* q_out, float* mu_out, float* saved, hipStream_t stream);
+bool spk_painn_mol_bwd_eligible(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb);
+int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
+                           const float* gmu_out, const float* r_ij, const float* saved, float* gc_scratch, float* gr, float* gq0, hipStream_t stream);
 
 // per layer saved for backward: preA [F] | c [3F] | mu_in [3F] | mix [6F] | preB [F] | a [3F]
 static inline int64_t painn_saved_per_atom(int F) { return 17 * (int64_t)F; }
@@ -1189,7 +1192,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
     { int _zr = spk_zero_async(mu_out, 3 * nf * sizeof(float), stream); if (_zr) return _zr; }
     return SPK_OK;
   }
-  if (ptab.base && r_ij && spk_painn_mol_eligible(m, g, rb))      // batches of small molecules: the whole forward is ONE launch
+  if (ptab.base && r_ij && !getenv("SPK_NO_PAINN_MOL_FWD") && spk_painn_mol_eligible(m, g, rb))      // batches of small molecules: the whole forward is ONE launch
     return spk_painn_mol_forward(m, g, rb, ptab, q0, r_ij, q_out, mu_out, saved, stream);
   float* c1 = scratch;            // [N,F]
   float* q1 = c1 + nf;            // [N,F]
@@ -1256,6 +1259,8 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
   const SpkPackTable ptab = (m->wpack && painn_pack_shapes_ok(m)) ? painn_pack_table(m) : SpkPackTable();
   const int64_t N = g->n_atoms, E = g->n_edges;
   const int F = m->n_atom_basis, L = m->n_interactions;
+  if (N > 0 && E > 0 && L > 0 && gr && r_ij && saved && scratch && (gq_out || gmu_out) && ptab.base && spk_painn_mol_bwd_eligible(m, g, rb))
+    return spk_painn_mol_backward(m, g, rb, ptab, gq_out, gmu_out, r_ij, saved, scratch, gr, gq0, stream);      // ONE launch, every gr entry written once
   if (E > 0) {
     SPK_CHECK_ARG(gr != nullptr, "%s: null gr", who);
     { int _zr = spk_zero_async(gr, (size_t)E * 3 * sizeof(float), stream); if (_zr) return _zr; }

@@ -552,6 +552,490 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
   }
 }
 
+// =====================================================================================================================
+// Backward: dL/dr_ij (and dL/dq0 on request) from dL/dq_L, dL/dmu_L and the saved tensors of the forward, one launch.
+// LDS: running gradients gq [32][LD], gmu [3][32][LD]; four work tiles X0..X3; per-edge gradient sums sG (written to gr once).
+// Per interaction, last to first (B = barrier):
+//   M1  element-wise: ga_mu = sum_x gmu_x W_x, ga_qmu = gq sum_x V_x W_x, U = gq a_qmu                              (painn.py:110-116 transposed)
+//   M2  g_hid = ([gq | ga_mu | ga_qmu] W_b2) * silu'(pre_b)      K = 384 split over the two teams, partial sums through LDS
+//   M3  [gq += | g_nv =] g_hid W_b1                              8 feature tiles over the 8 waves
+//   M4  per component x: gV = U W_x + g_nv V_x / |V|, gW = U V_x + gmu_x a_mu;  gmu_x += [gV | gW] W_mix (K = 256 split over the teams)
+//   message: (A) the transposed sums of the centre atom through the reverse edge (symmetric lists: Phi_ij = Phi_ji, u_ji = -u_ij)
+//            -> gc, new gmu;  (B) the geometry gradient of every edge of the row -> sG.  One wavefront per centre atom, a lane owns
+//            two channels, gq / gmu / mu rows of the neighbours from LDS, its context rows c_j from L2 (requested one edge ahead)
+//   ctx  gq += ((gc W_a2) * silu'(pre_a)) W_a1
+// The first interaction of an eval-mode backward (nobody asks for dL/dq0) forms the geometry gradient only.
+struct PmLayerBwd {
+  const float* ic2T_p;    // packed image of A = ictx_w2^T  (rows F,  K = 3F)
+  const float* ic1T_p;    // A = ictx_w1^T  (rows 2F, K = F)
+  const float* mixT_p;    // A = mix_w^T    (rows F,  K = 2F)
+  const float* ctx2T_p;   // A = ctx_w2^T   (rows F,  K = 3F)
+  const float* ctx1T_p;   // A = ctx_w1^T   (rows F,  K = F)
+  const float *wf, *bf;
+};
+struct PmBwdArgs {
+  PmLayerBwd L[PM_MAXL];
+  int n_layers;
+  const float* gq_out;      // [N, F] or null (zeros)
+  const float* gmu_out;     // [N, 3, F] or null (zeros)
+  const float* rij;
+  const int64_t* idx_j;
+  const int32_t* rowptr;
+  const int32_t* grp_atom0;
+  int n_groups;
+  const float* saved;
+  float* gc_scratch;        // [N, 3F]
+  float* gr;                // [E, 3], every entry written once
+  float* gq0;               // [N, F] or null
+  int64_t N;
+  float eps;
+  RadialDev rb;
+  long long* dbg;
+};
+#define PM_BSTAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[64 + (n)] = (long long)__builtin_readcyclecounter(); } while (0)
+
+__device__ __forceinline__ float pm_silu_grad(float x) {
+  const float sg = spk_sigmoid(x);
+  return sg * (1.0f + x * (1.0f - sg));
+}
+// sum over the 64 lanes, result in every lane (four DPP adds per row of 16 + four v_readlane), as spk_painn.hip
+__device__ __forceinline__ float pm_wave_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return (spk_readlane_f(v, 15) + spk_readlane_f(v, 31)) + (spk_readlane_f(v, 47) + spk_readlane_f(v, 63));
+}
+// phi_k(d), phi_k'(d) for the lane's own k, parameters preloaded
+__device__ __forceinline__ void pm_phi_d(int kind, float p0k, float p1k, float d, float& phi, float& dphi) {
+  if (kind == SPK_RBF_GAUSSIAN) {
+    const float c = -0.5f / (p1k * p1k);
+    const float t = d - p0k;
+    phi = expf(c * t * t);
+    dphi = 2.0f * c * t * phi;
+  } else {
+    float sn, co;
+    sincosf(p0k * d, &sn, &co);
+    if (d == 0.0f) { phi = sn; dphi = 0.f; }
+    else { const float inv = 1.0f / d; phi = sn * inv; dphi = (p0k * co - phi) * inv; }
+  }
+}
+
+struct PmW3 { f32x4 a[3][8]; };        // 24 k-blocks of one feature tile
+__device__ __forceinline__ void pm_w3load(PmW3& W, const float* __restrict__ wp, int KB, int t, int kb0, int lane) {
+  const char* sb = (const char*)wp + ((size_t)t * KB + kb0) * 1024;
+  pm_load8(W.a[0], sb, lane);
+  pm_load8(W.a[1], sb + 8 * 1024, lane);
+  pm_load8(W.a[2], sb + 16 * 1024, lane);
+}
+
+// message backward of the atoms of one wave (see the header comment of this section); rm = the new gmu rows (written by the
+// caller after the barrier), gc -> global scratch, geometry gradients -> sG
+template <int K>
+__device__ __forceinline__ void pm_message_bwd(const PmFilt<K>& Wf, const float* __restrict__ bf, const float* __restrict__ sGq, const float* __restrict__ sGmu,
+                                               const float* __restrict__ sMuIn, const float* __restrict__ c_g, float* __restrict__ gc_g,
+                                               const f32x4* __restrict__ sEa, const float* __restrict__ sEd, float* __restrict__ sG,
+                                               const int* __restrict__ sRow, const int* __restrict__ myAsg, float* __restrict__ myPhi, float* __restrict__ myFc,
+                                               int rbf_kind, float p0k, float p1k, float cutoff, bool mu0, bool geom, int lane, pm_f2 (&rm)[4][3]) {
+  const int hi = lane >> 5;
+  pm_f2 bias[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) bias[p] = *(const pm_f2*)(bf + p * 128 + 2 * lane);
+  const pm_f2 zero2 = {0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int at = myAsg[it];
+    pm_f2 accq = zero2, accR = zero2, av0 = zero2, av1 = zero2, av2 = zero2;
+    pm_f2 gma0 = zero2, gma1 = zero2, gma2 = zero2;
+    if (at >= 0) {
+      const int rs = sRow[at], re = sRow[at + 1];
+      // cutoff value and slope of the edges of the row: lanes = edges
+      {
+        float fc = 0.f, dfc = 0.f;
+        if (rs + lane < re) spk_cutoff_eval(cutoff, sEd[rs + lane], fc, dfc);
+        myFc[lane] = fc; myFc[64 + lane] = dfc;
+      }
+      const int io = at * PM_LD + 2 * lane;
+      const pm_f2 gqa = *(const pm_f2*)(sGq + io);
+      gma0 = *(const pm_f2*)(sGmu + io); gma1 = *(const pm_f2*)(sGmu + PM_TILE + io); gma2 = *(const pm_f2*)(sGmu + 2 * PM_TILE + io);
+      pm_f2 cn0 = zero2, cn1 = zero2, cn2 = zero2;          // context rows of the NEXT edge's neighbour (from L2)
+      if (rs < re) {
+        const float* cp = c_g + (size_t)__float_as_int(sEa[rs].x) * 384 + 2 * lane;
+        cn0 = *(const pm_f2*)cp; cn1 = *(const pm_f2*)(cp + 128); cn2 = *(const pm_f2*)(cp + 256);
+      }
+      for (int le = rs; le < re; ++le) {
+        const pm_f2 cq = cn0, cR = cn1, cm = cn2;
+        if (le + 1 < re) {
+          const float* cp = c_g + (size_t)__float_as_int(sEa[le + 1].x) * 384 + 2 * lane;
+          cn0 = *(const pm_f2*)cp; cn1 = *(const pm_f2*)(cp + 128); cn2 = *(const pm_f2*)(cp + 256);
+        }
+        const float fc = myFc[le - rs], dfc = myFc[64 + le - rs];
+        if (fc == 0.f && dfc == 0.f) continue;          // pairs at / beyond the cutoff contribute exactly zero
+        const f32x4 ea = sEa[le];
+        const int jl = __float_as_int(ea.x);
+        const float ux = ea.y, uy = ea.z, uz = ea.w, d = sEd[le];
+        {
+          float ph, dph;
+          pm_phi_d(rbf_kind, p0k, p1k, d, ph, dph);
+          myPhi[lane] = hi ? dph : ph;
+        }
+        const int jo = jl * PM_LD + 2 * lane;
+        f32x4 pa[K / 4], pd[K / 4];
+#pragma unroll
+        for (int c = 0; c < K / 4; ++c) { pa[c] = *(const f32x4*)(myPhi + 4 * c); pd[c] = *(const f32x4*)(myPhi + 32 + 4 * c); }
+        const pm_f2 gu = gma0 * ux + gma1 * uy + gma2 * uz;
+        pm_f2 ddv, mR;
+        {   // q part
+          const pm_f2 P = pm_filter2<K>(Wf.w[0][0], Wf.w[0][1], pa, bias[0]), Pd = pm_filter2<K>(Wf.w[0][0], Wf.w[0][1], pd, zero2);
+          if (!geom) accq += P * fc * *(const pm_f2*)(sGq + jo);
+          ddv = cq * gqa * (Pd * fc + P * dfc);
+        }
+        {   // R part
+          const pm_f2 P = pm_filter2<K>(Wf.w[1][0], Wf.w[1][1], pa, bias[1]), Pd = pm_filter2<K>(Wf.w[1][0], Wf.w[1][1], pd, zero2);
+          const pm_f2 FR = P * fc;
+          if (!geom) {
+            const pm_f2 gb0 = *(const pm_f2*)(sGmu + jo), gb1 = *(const pm_f2*)(sGmu + PM_TILE + jo), gb2 = *(const pm_f2*)(sGmu + 2 * PM_TILE + jo);
+            accR -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
+          }
+          ddv += cR * gu * (Pd * fc + P * dfc);
+          mR = FR * cR;
+        }
+        if (!mu0) {   // mu part
+          const pm_f2 P = pm_filter2<K>(Wf.w[2][0], Wf.w[2][1], pa, bias[2]), Pd = pm_filter2<K>(Wf.w[2][0], Wf.w[2][1], pd, zero2);
+          const pm_f2 Fm = P * fc;
+          if (!geom) {
+            av0 += Fm * *(const pm_f2*)(sGmu + jo); av1 += Fm * *(const pm_f2*)(sGmu + PM_TILE + jo); av2 += Fm * *(const pm_f2*)(sGmu + 2 * PM_TILE + jo);
+          }
+          const pm_f2 gm = gma0 * *(const pm_f2*)(sMuIn + jo) + gma1 * *(const pm_f2*)(sMuIn + PM_TILE + jo) + gma2 * *(const pm_f2*)(sMuIn + 2 * PM_TILE + jo);
+          ddv += cm * gm * (Pd * fc + P * dfc);
+        }
+        const pm_f2 t0 = gma0 * mR, t1 = gma1 * mR, t2 = gma2 * mR;
+        const float dd = pm_wave_sum(ddv.x + ddv.y), tux = pm_wave_sum(t0.x + t0.y), tuy = pm_wave_sum(t1.x + t1.y), tuz = pm_wave_sum(t2.x + t2.y);
+        if (lane == 0 && d > 0.f) {
+          const float dot = tux * ux + tuy * uy + tuz * uz;
+          const float invd = 1.0f / d;
+          sG[3 * le] += dd * ux + (tux - dot * ux) * invd;
+          sG[3 * le + 1] += dd * uy + (tuy - dot * uy) * invd;
+          sG[3 * le + 2] += dd * uz + (tuz - dot * uz) * invd;
+        }
+      }
+      if (!geom) {
+        // gc_i = (acc_q, acc_R, sum_x mu_i[x] acc_v[x]);  gmu_i[x] = gmu1_i[x] + c_i^mu acc_v[x]
+        pm_f2 gcm = zero2, cma = zero2;
+        if (!mu0) {
+          gcm = *(const pm_f2*)(sMuIn + io) * av0 + *(const pm_f2*)(sMuIn + PM_TILE + io) * av1 + *(const pm_f2*)(sMuIn + 2 * PM_TILE + io) * av2;
+          cma = *(const pm_f2*)(c_g + (size_t)at * 384 + 256 + 2 * lane);
+        }
+        float* gp = gc_g + (size_t)at * 384 + 2 * lane;
+        *(pm_f2*)gp = accq; *(pm_f2*)(gp + 128) = accR; *(pm_f2*)(gp + 256) = gcm;
+        gma0 += cma * av0; gma1 += cma * av1; gma2 += cma * av2;
+      }
+    }
+    rm[it][0] = gma0; rm[it][1] = gma1; rm[it][2] = gma2;
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
+  constexpr int F = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sGq = smem;                         // [32][LD]    running dL/dq
+  float* sGmu = sGq + PM_TILE;               // [3][32][LD] running dL/dmu
+  float* X0 = sGmu + 3 * PM_TILE;            // work tiles
+  float* X1 = X0 + PM_TILE;
+  float* X2 = X1 + PM_TILE;
+  float* X3 = X2 + PM_TILE;
+  float* sG = X3 + PM_TILE;                  // [PM_MAXEDGES][3] geometry gradient of every directed edge of the group
+  float* sPhi = sG + 3 * PM_MAXEDGES;        // [8][64]
+  float* sFc = sPhi + 8 * 64;                // [8][128] cutoff value | slope of the edges of the row a wave works on
+  int* sRow = (int*)(sFc + 8 * 128);         // [33]
+  int* sAsg = sRow + 36;                     // [8][4]
+  // during the message phase: X0..X2 = mu entering the interaction (component planes), X3 = edge records
+  f32x4* sEa = (f32x4*)X3;                   // [PM_MAXEDGES] (local neighbour, unit vector)
+  float* sEd = X3 + 4 * PM_MAXEDGES;         // [PM_MAXEDGES] distance
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, el = lane & 31;
+  const int team = wv >> 2, t = wv & 3;
+  const float p0k = (el < K && a.rb.p0) ? a.rb.p0[el] : 0.f;
+  const float p1k = (el < K && a.rb.p1) ? a.rb.p1[el] : 1.f;
+  const float cutoff = a.rb.cutoff;
+  const int64_t nf = a.N * (int64_t)F;
+  const int64_t per = 17 * nf;
+  float* myPhi = sPhi + wv * 64;
+  float* myFc = sFc + wv * 128;
+  const int* myAsg = sAsg + wv * 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+  for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+    const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
+    const int e0 = a.rowptr[a0], ne = a.rowptr[a0 + na] - e0;
+    PM_BARRIER();
+    PM_BSTAMP(0);
+    // ---- group set-up: incoming gradients, per-edge sums, local CSR and the wave -> atoms map of the message phase
+    for (int s = tid; s < 4 * 32 * 32; s += 512) {
+      const int pl = s >> 10, row = (s >> 5) & 31, c4 = s & 31;      // pl 0: gq, 1..3: gmu components
+      f32x4 v = z4;
+      if (row < na) {
+        if (pl == 0) { if (a.gq_out) v = *(const f32x4*)(a.gq_out + (size_t)(a0 + row) * F + 4 * c4); }
+        else if (a.gmu_out) v = *(const f32x4*)(a.gmu_out + ((size_t)(a0 + row) * 3 + (pl - 1)) * F + 4 * c4);
+      }
+      *(f32x4*)(sGq + pl * PM_TILE + row * PM_LD + 4 * c4) = v;
+    }
+    for (int s = tid; s < 3 * PM_MAXEDGES; s += 512) sG[s] = 0.f;
+    if (wv == 7) {
+      int r0 = 0;
+      if (lane <= 32) r0 = a.rowptr[a0 + (lane < na ? lane : na)] - e0;
+      const int r1 = __shfl_down(r0, 1, 64);
+      if (lane <= 32) sRow[lane] = r0;
+      const int deg = lane < na ? r1 - r0 : -1;
+      int rank = 0;
+      for (int b = 0; b < 32; ++b) {
+        const int db = __builtin_amdgcn_readlane(deg, b);
+        rank += (db > deg || (db == deg && b < lane)) ? 1 : 0;
+      }
+      if (lane < 32) sAsg[lane] = -1;
+      if (lane < na) {
+        const int rnd = rank >> 3, pos = rank & 7;
+        sAsg[((rnd & 1) ? 7 - pos : pos) * 4 + rnd] = lane;
+      }
+    }
+
+    for (int l = a.n_layers - 1; l >= 0; --l) {
+      const PmLayerBwd& P = a.L[l];
+      const float* S = a.saved + (int64_t)l * per;
+      const float* preA_g = S + (size_t)a0 * F;
+      const float* c_g = S + nf + (size_t)a0 * 3 * F;
+      const float* muin_g = S + 4 * nf + (size_t)a0 * 3 * F;
+      const float* mix_g = S + 7 * nf + (size_t)a0 * 6 * F;
+      const float* preB_g = S + 13 * nf + (size_t)a0 * F;
+      const float* a_g = S + 14 * nf + (size_t)a0 * 3 * F;
+      const bool mu0 = (l == 0);
+      const bool geom = (l == 0 && a.gq0 == nullptr);
+      PM_BARRIER();
+      PM_BSTAMP(1 + 12 * (a.n_layers - 1 - l));
+
+      // ================= M1: ga_mu -> X0, ga_qmu -> X1, U = gq a_qmu -> X3                 (weights of M2 requested meanwhile)
+      PmW3 W3;
+      pm_w3load(W3, P.ic2T_p, 48, t, 24 * team, lane);
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const int s = tid + 512 * rep, row = s >> 5, c4 = s & 31;
+        f32x4 gam = z4, gaq = z4, U = z4;
+        if (row < na) {
+          const f32x4 gq = *(const f32x4*)(sGq + row * PM_LD + 4 * c4);
+          const float* mp = mix_g + (size_t)row * 6 * F + 4 * c4;
+          f32x4 Ssum = z4;
+#pragma unroll
+          for (int x = 0; x < 3; ++x) {
+            const f32x4 V = *(const f32x4*)(mp + x * 2 * F), W = *(const f32x4*)(mp + x * 2 * F + F);
+            const f32x4 gm = *(const f32x4*)(sGmu + x * PM_TILE + row * PM_LD + 4 * c4);
+            Ssum += V * W;
+            gam += gm * W;
+          }
+          const f32x4 aqm = *(const f32x4*)(a_g + (size_t)row * 3 * F + 2 * F + 4 * c4);
+          gaq = gq * Ssum;
+          U = gq * aqm;
+        }
+        *(f32x4*)(X0 + row * PM_LD + 4 * c4) = gam;
+        *(f32x4*)(X1 + row * PM_LD + 4 * c4) = gaq;
+        *(f32x4*)(X3 + row * PM_LD + 4 * c4) = U;
+      }
+      PM_BARRIER();
+      PM_BSTAMP(2 + 12 * (a.n_layers - 1 - l));
+
+      // ================= M2: g_hid = ([gq | ga_mu | ga_qmu] W_b2) silu'(pre_b) -> X2; team 0: k-blocks 0..23, team 1: 24..47
+      PmW Wn;       // weights of M3 (tile 4 team + t of A = W_b1^T)
+      {
+        const float* b0 = team ? X0 + 64 : sGq;
+        const float* b1 = team ? X1 : sGq + 64;
+        const float* b2 = team ? X1 + 64 : X0;
+        const size_t bo = (size_t)((lane & 31) * PM_LD + 4 * (lane >> 5));
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = pm_mma8(W3.a[0], b0 + bo, acc);
+        acc = pm_mma8(W3.a[1], b1 + bo, acc);
+        acc = pm_mma8(W3.a[2], b2 + bo, acc);
+        pm_wload(Wn, P.ic1T_p, 16, 4 * team + t, 0, lane);
+        if (team == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *(f32x4*)(X2 + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        }
+        PM_BARRIER();
+        if (team == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float* xp = X2 + el * PM_LD + 32 * t + 8 * q + 4 * hi;
+            const f32x4 part = *(const f32x4*)xp;
+            f32x4 pb = z4;
+            if (el < na) pb = pm_ld<f32x4>(preB_g + 32 * t, (unsigned)((el * F + 8 * q + 4 * hi) * 4));
+            *(f32x4*)xp = f32x4{(acc[4 * q] + part.x) * pm_silu_grad(pb.x), (acc[4 * q + 1] + part.y) * pm_silu_grad(pb.y),
+                                (acc[4 * q + 2] + part.z) * pm_silu_grad(pb.z), (acc[4 * q + 3] + part.w) * pm_silu_grad(pb.w)};
+          }
+        }
+      }
+      PM_BARRIER();
+      PM_BSTAMP(3 + 12 * (a.n_layers - 1 - l));
+
+      // ================= M3: g_ctx = g_hid W_b1: tiles 0..3 (q part, team 0): gq += ; tiles 4..7 (|V| part, team 1): g_nv -> X0
+      PmW Wm;       // weights of M4: A = W_mix^T, k-blocks 16 team .. 16 team + 15 (the gV resp. gW half of the contraction)
+      {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = pm_wmma(Wn, X2, lane, acc);
+        pm_wload(Wm, P.mixT_p, 32, t, 16 * team, lane);
+        float* dst = team ? X0 : sGq;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float* xp = dst + el * PM_LD + 32 * t + 8 * q + 4 * hi;
+          f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          if (team == 0) v += *(const f32x4*)xp;
+          *(f32x4*)xp = v;
+        }
+      }
+      PM_BARRIER();
+      PM_BSTAMP(4 + 12 * (a.n_layers - 1 - l));
+
+      // ================= M4: per component x: gV -> X1, gW -> X2; gmu_x += [gV | gW] W_mix  (team 1 adds its half first)
+      for (int x = 0; x < 3; ++x) {
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+          const int s = tid + 512 * rep, row = s >> 5, c4 = s & 31;
+          f32x4 gV = z4, gW = z4;
+          if (row < na) {
+            const float* mp = mix_g + (size_t)row * 6 * F + 4 * c4;
+            const f32x4 V0 = *(const f32x4*)mp, V1 = *(const f32x4*)(mp + 2 * F), V2 = *(const f32x4*)(mp + 4 * F);
+            const f32x4 Vx = *(const f32x4*)(mp + x * 2 * F), Wx = *(const f32x4*)(mp + x * 2 * F + F);
+            const f32x4 am = *(const f32x4*)(a_g + (size_t)row * 3 * F + F + 4 * c4);
+            const f32x4 U = *(const f32x4*)(X3 + row * PM_LD + 4 * c4), gnv = *(const f32x4*)(X0 + row * PM_LD + 4 * c4);
+            const f32x4 gm = *(const f32x4*)(sGmu + x * PM_TILE + row * PM_LD + 4 * c4);
+            f32x4 nv;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) nv[v] = sqrtf(V0[v] * V0[v] + V1[v] * V1[v] + V2[v] * V2[v] + a.eps);
+            gV = U * Wx + gnv * Vx / nv;
+            gW = U * Vx + gm * am;
+          }
+          *(f32x4*)(X1 + row * PM_LD + 4 * c4) = gV;
+          *(f32x4*)(X2 + row * PM_LD + 4 * c4) = gW;
+        }
+        PM_BARRIER();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = pm_wmma(Wm, team ? X2 : X1, lane, acc);
+        float* gp = sGmu + x * PM_TILE + el * PM_LD + 32 * t + 4 * hi;
+        if (team == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *(f32x4*)(gp + 8 * q) += f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        }
+        PM_BARRIER();
+        if (team == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *(f32x4*)(gp + 8 * q) += f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        }
+      }
+      PM_BARRIER();
+      PM_BSTAMP(5 + 12 * (a.n_layers - 1 - l));
+
+      // ================= message backward: mu entering the interaction -> X0..X2, edge records -> X3
+      PmFilt<K> Wf;
+      pm_filt_load<K>(Wf, P.wf, lane, mu0);
+      if (!mu0) {
+        for (int s = tid; s < 3 * 32 * 32; s += 512) {
+          const int x = s >> 10, row = (s >> 5) & 31, c4 = s & 31;
+          f32x4 v = z4;
+          if (row < na) v = *(const f32x4*)(muin_g + ((size_t)row * 3 + x) * F + 4 * c4);
+          *(f32x4*)(X0 + x * PM_TILE + row * PM_LD + 4 * c4) = v;
+        }
+      }
+      for (int le = tid; le < ne; le += 512) {
+        const int64_t e = (int64_t)e0 + le;
+        const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+        const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float inv = 1.0f / d;
+        sEa[le] = f32x4{__int_as_float((int)(a.idx_j[e] - a0)), rx * inv, ry * inv, rz * inv};
+        sEd[le] = d;
+      }
+      PM_BARRIER();
+      PM_BSTAMP(6 + 12 * (a.n_layers - 1 - l));
+      {
+        pm_f2 rm[4][3];
+        pm_message_bwd<K>(Wf, P.bf, sGq, sGmu, X0, c_g, a.gc_scratch + (size_t)a0 * 3 * F, sEa, sEd, sG, sRow, myAsg, myPhi, myFc, a.rb.kind, p0k, p1k,
+                          cutoff, mu0, geom, lane, rm);
+        PM_BSTAMP(7 + 12 * (a.n_layers - 1 - l));
+        if (geom) break;          // (uniform over the workgroup: the first interaction of an eval-mode backward ends here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the gc rows of this wave have reached L2
+        PM_BARRIER();
+        pm_message_write(sGmu, myAsg, lane, rm);
+      }
+      // ================= context net backward: gc -> X0..X2 (part planes), gq += ((gc W_a2) silu'(pre_a)) W_a1
+      pm_w3load(W3, P.ctx2T_p, 48, t, 24 * team, lane);
+      {
+        const float* gcs = a.gc_scratch + (size_t)a0 * 3 * F;
+        for (int s = tid; s < 3 * 32 * 32; s += 512) {
+          const int p = s >> 10, row = (s >> 5) & 31, c4 = s & 31;
+          f32x4 v = z4;
+          if (row < na) v = __builtin_nontemporal_load((const f32x4*)(gcs + (size_t)row * 3 * F + p * F + 4 * c4));
+          *(f32x4*)(X0 + p * PM_TILE + row * PM_LD + 4 * c4) = v;
+        }
+      }
+      PM_BARRIER();
+      PM_BSTAMP(8 + 12 * (a.n_layers - 1 - l));
+      {
+        const float* b0 = team ? X1 + 64 : X0;
+        const float* b1 = team ? X2 : X0 + 64;
+        const float* b2 = team ? X2 + 64 : X1;
+        const size_t bo = (size_t)((lane & 31) * PM_LD + 4 * (lane >> 5));
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = pm_mma8(W3.a[0], b0 + bo, acc);
+        acc = pm_mma8(W3.a[1], b1 + bo, acc);
+        acc = pm_mma8(W3.a[2], b2 + bo, acc);
+        if (team == 0) pm_wload(Wn, P.ctx1T_p, 16, t, 0, lane);
+        if (team == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *(f32x4*)(X3 + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        }
+        PM_BARRIER();
+        if (team == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float* xp = X3 + el * PM_LD + 32 * t + 8 * q + 4 * hi;
+            const f32x4 part = *(const f32x4*)xp;
+            f32x4 pa = z4;
+            if (el < na) pa = pm_ld<f32x4>(preA_g + 32 * t, (unsigned)((el * F + 8 * q + 4 * hi) * 4));
+            *(f32x4*)xp = f32x4{(acc[4 * q] + part.x) * pm_silu_grad(pa.x), (acc[4 * q + 1] + part.y) * pm_silu_grad(pa.y),
+                                (acc[4 * q + 2] + part.z) * pm_silu_grad(pa.z), (acc[4 * q + 3] + part.w) * pm_silu_grad(pa.w)};
+          }
+        }
+      }
+      PM_BARRIER();
+      PM_BSTAMP(9 + 12 * (a.n_layers - 1 - l));
+      if (team == 0) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = pm_wmma(Wn, X3, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float* xp = sGq + el * PM_LD + 32 * t + 8 * q + 4 * hi;
+          f32x4 v = *(const f32x4*)xp;
+          v += f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          *(f32x4*)xp = v;
+          if (l == 0 && a.gq0 && el < na) pm_st<f32x4>(a.gq0 + (size_t)a0 * F + 32 * t, (unsigned)((el * F + 8 * q + 4 * hi) * 4), v);
+        }
+      }
+      PM_BSTAMP(10 + 12 * (a.n_layers - 1 - l));
+    }
+    // ---- the geometry gradient of every edge of the group, written exactly once
+    PM_BARRIER();
+    for (int s = tid; s < 3 * ne; s += 512) a.gr[3 * (int64_t)e0 + s] = sG[s];
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static long long* g_pm_dbg = nullptr;
 // tuning aid (scripts/painn_mol_timing.py): device buffer of >= 64 int64 receiving cycle stamps of thread 0 of workgroup 0 at the
@@ -617,5 +1101,63 @@ int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_
     default: break;
   }
   SPK_CHECK_ARG(false, "spk_painn_mol_forward: n_rbf = %d has no instance (see spk_painn_mol_eligible)", rb->n_rbf);
+  return SPK_OK;
+}
+
+static size_t painn_mol_bwd_lds() {
+  return (size_t)(8 * PM_TILE + 3 * PM_MAXEDGES + 8 * 64 + 8 * 128) * sizeof(float) + (36 + 32) * sizeof(int);
+}
+// the backward additionally needs a symmetric list (the transposed sums run through the reverse edge)
+bool spk_painn_mol_bwd_eligible(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb) {
+  if (!spk_painn_mol_eligible(m, g, rb)) return false;
+  if (getenv("SPK_NO_PAINN_MOL_BWD")) return false;
+  return g->symmetric != 0;
+}
+
+template <int K>
+static int launch_painn_mol_bwd(const PmBwdArgs& a, hipStream_t stream) {
+  const size_t lds = painn_mol_bwd_lds();
+  auto kern = k_painn_mol_bwd<K>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  int grid = a.n_groups;
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  SpkProfScope prof("painn_mol_bwd", stream);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// gq_out / gmu_out may be null (zeros); gr [E, 3] is overwritten (no clearing needed); gq0 may be null; gc_scratch: [N, 3F] floats
+int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
+                           const float* gmu_out, const float* r_ij, const float* saved, float* gc_scratch, float* gr, float* gq0, hipStream_t stream) {
+  PmBwdArgs a;
+  a.n_layers = m->n_interactions;
+  for (int l = 0; l < m->n_interactions; ++l) {
+    const spk_painn_layer_t& P = m->layers[l];
+    PmLayerBwd& D = a.L[l];
+    D.ic2T_p = spk_packed_of(ptab, P.ictx_w2, 1);
+    D.ic1T_p = spk_packed_of(ptab, P.ictx_w1, 1);
+    D.mixT_p = spk_packed_of(ptab, P.mix_w, 1);
+    D.ctx2T_p = spk_packed_of(ptab, P.ctx_w2, 1);
+    D.ctx1T_p = spk_packed_of(ptab, P.ctx_w1, 1);
+    D.wf = P.filt_w; D.bf = P.filt_b;
+    SPK_CHECK_ARG(D.ic2T_p && D.ic1T_p && D.mixT_p && D.ctx2T_p && D.ctx1T_p && D.wf && D.bf, "spk_painn_mol_backward: packed weight image missing");
+  }
+  a.gq_out = gq_out; a.gmu_out = gmu_out; a.rij = r_ij; a.idx_j = g->idx_j; a.rowptr = g->rowptr; a.grp_atom0 = g->grp_atom0;
+  a.n_groups = g->n_groups; a.saved = saved; a.gc_scratch = gc_scratch; a.gr = gr; a.gq0 = gq0; a.N = g->n_atoms; a.eps = m->epsilon;
+  a.rb = spk_radial_dev(rb); a.dbg = g_pm_dbg;
+  switch (rb->n_rbf) {
+    case 20: return launch_painn_mol_bwd<20>(a, stream);
+    case 16: return launch_painn_mol_bwd<16>(a, stream);
+    case 12: return launch_painn_mol_bwd<12>(a, stream);
+    case 8: return launch_painn_mol_bwd<8>(a, stream);
+    default: break;
+  }
+  SPK_CHECK_ARG(false, "spk_painn_mol_backward: n_rbf = %d has no instance", rb->n_rbf);
   return SPK_OK;
 }

@@ -58,6 +58,7 @@ def test_molecule_resident_painn_matches_oracle_and_general_driver(dev, sizes, n
     b = _mixed_batch(3, sizes)
     (e, f, x, v), tags, (rep, head) = _run(b, dev, n_int, n_rbf, radial, **rep_kw)
     assert "painn_mol_fwd" in tags and not any(t.startswith(("painn_msg_fwd", "painn_mixing_fwd")) for t in tags), tags      # the path under test ran
+    assert "painn_mol_bwd" in tags and not any(t.startswith(("painn_msg_bwd", "painn_mixing_bwd", "chain")) for t in tags), tags
     ref = O.energy_and_forces("painn", rep, head, b, n_int, need_rep=True, dtype=torch.float64, shared_filters=bool(rep_kw.get("shared_filters")))
     assert rel_err(x, ref["scalar_representation"]) < TOL
     assert rel_err(v, ref["vector_representation"]) < TOL
@@ -68,11 +69,64 @@ def test_molecule_resident_painn_matches_oracle_and_general_driver(dev, sizes, n
 
 
 def test_molecule_resident_painn_is_deterministic(dev):
+    """No atomics anywhere in the two launches: representation AND forces are bit-reproducible."""
     b = S.molecule_batch("aspirin", 64, seed=9)
     (e1, f1, x1, v1), tags, _ = _run(b, dev)
     (e2, f2, x2, v2), _, _ = _run(b, dev)
-    assert "painn_mol_fwd" in tags
+    assert "painn_mol_fwd" in tags and "painn_mol_bwd" in tags
     assert torch.equal(x1, x2) and torch.equal(v1, v2)
+    assert torch.equal(f1, f2)
+
+
+@pytest.mark.parametrize("which", ["forward_only", "backward_only"])
+def test_either_half_combines_with_the_general_driver(dev, which):
+    """The saved tensors have the layout of the general driver: molecule-resident forward + general backward and general forward +
+    molecule-resident backward give the same forces."""
+    b = _mixed_batch(11, ["aspirin", "ethanol", "aspirin", "dimer", "atom", "aspirin"])
+    env = "SPK_NO_PAINN_MOL_BWD" if which == "forward_only" else "SPK_NO_PAINN_MOL_FWD"
+    os.environ[env] = "1"
+    try:
+        (e, f, x, v), tags, (rep, head) = _run(b, dev)
+    finally:
+        os.environ.pop(env, None)
+    assert ("painn_mol_fwd" in tags) == (which == "forward_only") and ("painn_mol_bwd" in tags) == (which == "backward_only"), tags
+    ref = O.energy_and_forces("painn", rep, head, b, 3, dtype=torch.float64)
+    assert rel_err(f, ref["forces"]) < TOL
+
+
+def test_gradient_of_a_vector_readout_and_of_the_embedding(dev):
+    """The backward launch with dL/dmu_L != 0 and dL/dq0 wanted (not the eval force path): gradients of
+    sum(w_q . q) + sum(w_mu . mu) w.r.t. r_ij and the embedding rows against torch autograd of the oracle in float64."""
+    from schnetpack_amd import _lib, model as M
+    b = _mixed_batch(5, ["aspirin", "ethanol", "aspirin"])
+    rep_p = O.init_painn_params(128, 2, 20, 5.0)
+    m = M.build_model("painn", 128, 2, 20, 5.0)
+    M.load_reference_params(m, rep_p, O.init_atomwise_params(128, seed=1))
+    rep = m.representation.to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    N = b["Z"].shape[0]
+    wq, wm = torch.randn(N, 128, generator=g), torch.randn(N, 3, 128, generator=g)
+    r = (b["R"][b["idx_j"]] - b["R"][b["idx_i"]] + b["offsets"]).float()
+    # oracle, float64
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in rep_p.items()}
+    r64 = r.double().requires_grad_(True)
+    emb = p64["embedding.weight"].clone().requires_grad_(True)
+    q, mu = O.painn_representation(b["Z"], r64, b["idx_i"], b["idx_j"], dict(p64, **{"embedding.weight": emb}), 2)
+    (gr_ref, gemb_ref) = torch.autograd.grad([(q * wq.double()).sum() + (mu * wm.double()).sum()], [r64, emb])
+    # device: the fused eval operator, gradient w.r.t. r_ij and the embedding table
+    rd = r.to(dev).requires_grad_(True)
+    rep.embedding.weight.requires_grad_(True)
+    _lib.profile_enable(True); _lib.profile_report()
+    try:
+        out = rep({"_atomic_numbers": b["Z"].to(dev), "_Rij": rd, "_idx_i": b["idx_i"].to(dev), "_idx_j": b["idx_j"].to(dev)})
+        loss = (out["scalar_representation"] * wq.to(dev)).sum() + (out["vector_representation"] * wm.to(dev)).sum()
+        gr, gemb = torch.autograd.grad([loss], [rd, rep.embedding.weight])
+        tags = _lib.profile_report()
+    finally:
+        _lib.profile_enable(False)
+    assert "painn_mol_bwd" in tags, tags
+    assert rel_err(gr.cpu(), gr_ref) < TOL
+    assert rel_err(gemb.cpu(), gemb_ref) < TOL
 
 
 def test_skin_list_pairs_beyond_the_cutoff_contribute_nothing(dev):
