@@ -77,12 +77,12 @@ __device__ __forceinline__ void pm_load8(f32x4 (&av)[8], const char* sb /* wave-
 #pragma unroll
   for (int u = 0; u < 8; ++u) av[u] = pm_ld<f32x4>(sb, (unsigned)(lane * 16 + u * 1024));
 }
-// (all eight B operands are requested before the first MFMA: left alone the compiler issues each ds_read right in front of the
-//  four MFMAs that need it -- zero prefetch distance, the matrix pipe waits ~100 cycles per group of four)
+// (B operands are requested four groups ahead: left alone the compiler issues each ds_read right in front of the four MFMAs
+//  that need it -- zero prefetch distance, the matrix pipe waits ~100 cycles per group of four)
 __device__ __forceinline__ f32x16 pm_mma8(const f32x4 (&av)[8], const float* __restrict__ brow, f32x16 acc) {
   f32x4 bv[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) bv[u] = *(const f32x4*)(brow + 8 * u);
+  for (int u = 0; u < 4; ++u) bv[u] = *(const f32x4*)(brow + 8 * u);
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -90,6 +90,10 @@ __device__ __forceinline__ f32x16 pm_mma8(const f32x4 (&av)[8], const float* __r
     acc = PM_MFMA(av[u].y, bv[u].y, acc);
     acc = PM_MFMA(av[u].z, bv[u].z, acc);
     acc = PM_MFMA(av[u].w, bv[u].w, acc);
+    if (u + 4 < 8) {
+      bv[u + 4] = *(const f32x4*)(brow + 8 * (u + 4));
+      asm volatile("" ::: "memory");
+    }
   }
   return acc;
 }
@@ -143,59 +147,120 @@ __device__ __forceinline__ float pm_phi(int kind, float p0k, float p1k, float d)
 // until the weight tiles prefetched for the next phase have arrived -- neither is needed at the barrier.
 #define PM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// one feature tile of packed weights (16 k-blocks = K 128) on its way from L2 + the bias of its rows
-struct PmW { f32x4 a0[8], a1[8]; };
+// A feature tile of packed weights on its way from L2.  Only the FIRST eight k-blocks travel across a phase boundary (32
+// registers); the following chunks are requested when the tile is used, each one chunk (32 MFMAs = 2 k cycles) ahead of its use.
+// (Whole tiles held across a barrier -- 64 to 96 registers next to the accumulators -- were spilled by the register allocator
+// RIGHT BEHIND their loads: load, wait, store to scratch, one L2 round trip after the other.)
+struct PmW { f32x4 a0[8]; const char* sb; };
 __device__ __forceinline__ void pm_wload(PmW& W, const float* __restrict__ wp, int KB, int t /* wave-uniform */, int kb0, int lane) {
+  W.sb = (const char*)wp + ((size_t)t * KB + kb0) * 1024;
+  pm_load8(W.a0, W.sb, lane);
+}
+// 16 k-blocks against one LDS tile
+__device__ __forceinline__ f32x16 pm_wmma(const PmW& W, const float* __restrict__ sB, int lane, f32x16 acc) {
+  const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
+  f32x4 a1[8];
+  pm_load8(a1, W.sb + 8 * 1024, lane);
+  acc = pm_mma8(W.a0, brow, acc);
+  acc = pm_mma8(a1, brow + 64, acc);
+  return acc;
+}
+// 16 k-blocks, the same weights against the three component planes of an LDS tensor
+__device__ __forceinline__ void pm_wmma3(const PmW& W, const float* __restrict__ sB, int lane, f32x16& c0, f32x16& c1, f32x16& c2) {
+  const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
+  f32x4 a1[8];
+  pm_load8(a1, W.sb + 8 * 1024, lane);
+  c0 = pm_mma8(W.a0, brow, c0);
+  c1 = pm_mma8(W.a0, brow + PM_TILE, c1);
+  c2 = pm_mma8(W.a0, brow + 2 * PM_TILE, c2);
+  c0 = pm_mma8(a1, brow + 64, c0);
+  c1 = pm_mma8(a1, brow + PM_TILE + 64, c1);
+  c2 = pm_mma8(a1, brow + 2 * PM_TILE + 64, c2);
+}
+// 24 k-blocks against three half tiles (b0, b1, b2: LDS addresses of the lane's row, k offset included)
+__device__ __forceinline__ f32x16 pm_wmma_3chunks(const PmW& W, const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2, int lane,
+                                                  f32x16 acc) {
+  f32x4 a1[8], a2[8];
+  pm_load8(a1, W.sb + 8 * 1024, lane);
+  acc = pm_mma8(W.a0, b0, acc);
+  pm_load8(a2, W.sb + 16 * 1024, lane);
+  acc = pm_mma8(a1, b1, acc);
+  acc = pm_mma8(a2, b2, acc);
+  return acc;
+}
+// a whole tile in registers (the W_mix^T half tile that serves the three components of M4)
+struct PmWF { f32x4 a0[8], a1[8]; };
+__device__ __forceinline__ void pm_wfload(PmWF& W, const float* __restrict__ wp, int KB, int t, int kb0, int lane) {
   const char* sb = (const char*)wp + ((size_t)t * KB + kb0) * 1024;
   pm_load8(W.a0, sb, lane);
   pm_load8(W.a1, sb + 8 * 1024, lane);
 }
-__device__ __forceinline__ f32x16 pm_wmma(const PmW& W, const float* __restrict__ sB, int lane, f32x16 acc) {
+__device__ __forceinline__ f32x16 pm_wfmma(const PmWF& W, const float* __restrict__ sB, int lane, f32x16 acc) {
   const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
   acc = pm_mma8(W.a0, brow, acc);
   acc = pm_mma8(W.a1, brow + 64, acc);
   return acc;
 }
-__device__ __forceinline__ void pm_wmma3(const PmW& W, const float* __restrict__ sB, int lane, f32x16& c0, f32x16& c1, f32x16& c2) {
-  const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
-  c0 = pm_mma8(W.a0, brow, c0);
-  c1 = pm_mma8(W.a0, brow + PM_TILE, c1);
-  c2 = pm_mma8(W.a0, brow + 2 * PM_TILE, c2);
-  c0 = pm_mma8(W.a1, brow + 64, c0);
-  c1 = pm_mma8(W.a1, brow + PM_TILE + 64, c1);
-  c2 = pm_mma8(W.a1, brow + 2 * PM_TILE + 64, c2);
-}
 
 // filter rows 2 lane, 2 lane + 1 of the three parts (q | R | mu) of the filter net as they lie in memory: K consecutive floats per
-// row, [part][row][chunk of 4 k]
+// row, [part][row][chunk of 4 k]; one more chunk holds (bias, 0, 0, 0): the bias is the weight of an extra basis function whose
+// value is f_c(d), so that  Phi f_c = sum_k w_k (f_c phi_k) + b f_c  is ONE contraction (no separate multiplications by f_c)
 template <int K>
-struct PmFilt { f32x4 w[3][2][K / 4]; };
+struct PmFilt { f32x4 w[3][2][K / 4 + 1]; };
 template <int K>
-__device__ __forceinline__ void pm_filt_load(PmFilt<K>& Wf, const float* __restrict__ wf, int lane, bool mu0) {
+__device__ __forceinline__ void pm_filt_load(PmFilt<K>& Wf, const float* __restrict__ wf, const float* __restrict__ bf, int lane, bool mu0) {
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
     const float* r0 = wf + (size_t)(p * 128 + 2 * lane) * K;
+    const bool off = mu0 && p == 2;
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
+    for (int ch = 0; ch < 2; ++ch) {
 #pragma unroll
-      for (int c = 0; c < K / 4; ++c) Wf.w[p][ch][c] = !(mu0 && p == 2) ? *(const f32x4*)(r0 + ch * K + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < K / 4; ++c) Wf.w[p][ch][c] = !off ? *(const f32x4*)(r0 + ch * K + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      Wf.w[p][ch][K / 4] = f32x4{off ? 0.f : bf[p * 128 + 2 * lane + ch], 0.f, 0.f, 0.f};
+    }
   }
 }
 
-// Phi = W phi + b for the lane's two channels of one part: products over PAIRS of k (the pair (w[k], w[k+1]) is adjacent in the
-// loaded row chunk, the pair (phi[k], phi[k+1]) in the broadcast LDS read: v_pk_fma_f32 without any repacking), the two partial
-// sums of a channel meet at the end
-template <int K>
-__device__ __forceinline__ pm_f2 pm_filter2(const f32x4 (&w0)[K / 4], const f32x4 (&w1)[K / 4], const f32x4 (&ph)[K / 4], pm_f2 bias) {
+// F = sum over the K + 4 slots of w * basis for the lane's two channels of one part: products over PAIRS of slots (the pair
+// (w[k], w[k+1]) is adjacent in the loaded row chunk, the pair of basis values in the broadcast LDS read: v_pk_fma_f32 without
+// any repacking), the two partial sums of a channel meet at the end
+template <int NC>
+__device__ __forceinline__ pm_f2 pm_filter2(const f32x4 (&w0)[NC], const f32x4 (&w1)[NC], const f32x4 (&ph)[NC]) {
   pm_f2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < K / 4; ++c) {
+  for (int c = 0; c < NC; ++c) {
     s0 = pm_f2{w0[c].x, w0[c].y} * pm_f2{ph[c].x, ph[c].y} + s0;
     s1 = pm_f2{w1[c].x, w1[c].y} * pm_f2{ph[c].x, ph[c].y} + s1;
-    s0 = pm_f2{w0[c].z, w0[c].w} * pm_f2{ph[c].z, ph[c].w} + s0;
-    s1 = pm_f2{w1[c].z, w1[c].w} * pm_f2{ph[c].z, ph[c].w} + s1;
+    if (c + 1 < NC) {          // (the last chunk is (bias, 0, 0, 0))
+      s0 = pm_f2{w0[c].z, w0[c].w} * pm_f2{ph[c].z, ph[c].w} + s0;
+      s1 = pm_f2{w1[c].z, w1[c].w} * pm_f2{ph[c].z, ph[c].w} + s1;
+    }
   }
-  return pm_f2{s0.x + s0.y, s1.x + s1.y} + bias;
+  return pm_f2{s0.x + s0.y, s1.x + s1.y};
+}
+
+// basis slot `k` (= lane & 31) of an edge at distance d with cutoff value fc / slope dfc:
+//   k <  K : fc phi_k(d)                     |  d/dd: fc phi_k' + dfc phi_k
+//   k == K : fc (the bias slot)              |  dfc
+//   else 0                                                                       (nn/radial.py:11-15 gaussian, :105-110 bessel)
+// Gaussian: exp through v_exp_f32 (exp2 of a non-positive argument, 1 ulp); Bessel: the accurate sincosf.
+template <int K>
+__device__ __forceinline__ void pm_basis(int kind, int k, float p0k, float p1k, float d, float fc, float dfc, float& b, float& db) {
+  float phi, dphi;
+  if (kind == SPK_RBF_GAUSSIAN) {
+    const float c = -0.5f / (p1k * p1k);
+    const float t = d - p0k;
+    phi = __builtin_amdgcn_exp2f(1.4426950408889634f * c * t * t);
+    dphi = 2.0f * c * t * phi;
+  } else {
+    float sn, co;
+    sincosf(p0k * d, &sn, &co);
+    if (d == 0.0f) { phi = sn; dphi = 0.f; }
+    else { const float inv = 1.0f / d; phi = sn * inv; dphi = (p0k * co - phi) * inv; }
+  }
+  b = k < K ? fc * phi : (k == K ? fc : 0.f);
+  db = k < K ? fc * dphi + dfc * phi : (k == K ? dfc : 0.f);
 }
 
 // P3: message (painn.py:43-66): a wavefront per centre atom (the atoms of the wave: sAsg), lane = channels 2 lane, 2 lane + 1; two
@@ -208,9 +273,7 @@ __device__ __forceinline__ void pm_message(const PmFilt<K>& Wf, const float* __r
                                            const int* __restrict__ myAsg, float* __restrict__ myPhi, int rbf_kind, float p0k, float p1k, float cutoff,
                                            bool mu0, int lane, pm_f2 (&rm)[4][3]) {
   const int hi = lane >> 5;
-  pm_f2 bias[3];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) bias[p] = *(const pm_f2*)(bf + p * 128 + 2 * lane);
+  (void)bf;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int at = myAsg[it];
@@ -222,23 +285,27 @@ __device__ __forceinline__ void pm_message(const PmFilt<K>& Wf, const float* __r
         const PmEdge eA = sE[le], eB = sE[two ? le + 1 : le];
         const float fA = eA.d < cutoff ? eA.fc : 0.f, fB = (two && eB.d < cutoff) ? eB.fc : 0.f;
         if (fA == 0.f && fB == 0.f) continue;          // skin pairs contribute exactly zero
-        myPhi[lane] = pm_phi(rbf_kind, p0k, p1k, hi ? eB.d : eA.d);
-        const int jA = eA.jl * PM_LD + 2 * lane, jB = eB.jl * PM_LD + 2 * lane;
-        f32x4 pa[K / 4], pb[K / 4];
-#pragma unroll
-        for (int c = 0; c < K / 4; ++c) { pa[c] = *(const f32x4*)(myPhi + 4 * c); pb[c] = *(const f32x4*)(myPhi + 32 + 4 * c); }
         {
-          const pm_f2 PqA = pm_filter2<K>(Wf.w[0][0], Wf.w[0][1], pa, bias[0]), PqB = pm_filter2<K>(Wf.w[0][0], Wf.w[0][1], pb, bias[0]);
-          accq += PqA * fA * *(const pm_f2*)(sC + jA) + PqB * fB * *(const pm_f2*)(sC + jB);
+          float bs, dbs;
+          pm_basis<K>(rbf_kind, lane & 31, p0k, p1k, hi ? eB.d : eA.d, hi ? fB : fA, 0.f, bs, dbs);
+          myPhi[lane] = bs;
+        }
+        const int jA = eA.jl * PM_LD + 2 * lane, jB = eB.jl * PM_LD + 2 * lane;
+        f32x4 pa[K / 4 + 1], pb[K / 4 + 1];
+#pragma unroll
+        for (int c = 0; c < K / 4 + 1; ++c) { pa[c] = *(const f32x4*)(myPhi + 4 * c); pb[c] = *(const f32x4*)(myPhi + 32 + 4 * c); }
+        {
+          const pm_f2 FqA = pm_filter2<K / 4 + 1>(Wf.w[0][0], Wf.w[0][1], pa), FqB = pm_filter2<K / 4 + 1>(Wf.w[0][0], Wf.w[0][1], pb);
+          accq += FqA * *(const pm_f2*)(sC + jA) + FqB * *(const pm_f2*)(sC + jB);
         }
         {
-          const pm_f2 PRA = pm_filter2<K>(Wf.w[1][0], Wf.w[1][1], pa, bias[1]), PRB = pm_filter2<K>(Wf.w[1][0], Wf.w[1][1], pb, bias[1]);
-          const pm_f2 mRA = PRA * fA * *(const pm_f2*)(sC + PM_TILE + jA), mRB = PRB * fB * *(const pm_f2*)(sC + PM_TILE + jB);
+          const pm_f2 FRA = pm_filter2<K / 4 + 1>(Wf.w[1][0], Wf.w[1][1], pa), FRB = pm_filter2<K / 4 + 1>(Wf.w[1][0], Wf.w[1][1], pb);
+          const pm_f2 mRA = FRA * *(const pm_f2*)(sC + PM_TILE + jA), mRB = FRB * *(const pm_f2*)(sC + PM_TILE + jB);
           av0 += mRA * eA.ux + mRB * eB.ux; av1 += mRA * eA.uy + mRB * eB.uy; av2 += mRA * eA.uz + mRB * eB.uz;
         }
         if (!mu0) {
-          const pm_f2 PmA = pm_filter2<K>(Wf.w[2][0], Wf.w[2][1], pa, bias[2]), PmB = pm_filter2<K>(Wf.w[2][0], Wf.w[2][1], pb, bias[2]);
-          const pm_f2 mmA = PmA * fA * *(const pm_f2*)(sC + 2 * PM_TILE + jA), mmB = PmB * fB * *(const pm_f2*)(sC + 2 * PM_TILE + jB);
+          const pm_f2 FmA = pm_filter2<K / 4 + 1>(Wf.w[2][0], Wf.w[2][1], pa), FmB = pm_filter2<K / 4 + 1>(Wf.w[2][0], Wf.w[2][1], pb);
+          const pm_f2 mmA = FmA * *(const pm_f2*)(sC + 2 * PM_TILE + jA), mmB = FmB * *(const pm_f2*)(sC + 2 * PM_TILE + jB);
           av0 += mmA * *(const pm_f2*)(sMu + jA) + mmB * *(const pm_f2*)(sMu + jB);
           av1 += mmA * *(const pm_f2*)(sMu + PM_TILE + jA) + mmB * *(const pm_f2*)(sMu + PM_TILE + jB);
           av2 += mmA * *(const pm_f2*)(sMu + 2 * PM_TILE + jA) + mmB * *(const pm_f2*)(sMu + 2 * PM_TILE + jB);
@@ -378,7 +445,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
             if (el < na) pm_st<f32x4>(c_g + (size_t)a0 * 3 * F + 32 * t, (unsigned)((el * 3 * F + 8 * q + 4 * hi) * 4), cv);
           }
           acc = pm_wmma(Wt, sH, lane, bz);
-          pm_filt_load<K>(Wf, P.wf, lane, l == 0);
+          pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -510,7 +577,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         {
           float* c_g = S + nf;
           f32x16 acc = pm_wmma(Wt, sH, lane, bz);
-          pm_filt_load<K>(Wf, P.wf, lane, l == 0);
+          pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -598,13 +665,30 @@ __device__ __forceinline__ float pm_silu_grad(float x) {
   const float sg = spk_sigmoid(x);
   return sg * (1.0f + x * (1.0f - sg));
 }
-// sum over the 64 lanes, result in every lane (four DPP adds per row of 16 + four v_readlane), as spk_painn.hip
-__device__ __forceinline__ float pm_wave_sum(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
-  return (spk_readlane_f(v, 15) + spk_readlane_f(v, 31)) + (spk_readlane_f(v, 47) + spk_readlane_f(v, 63));
+// FOUR sums over the 64 lanes at once (the per-edge scalars of the geometry gradient): two select-and-add steps inside the quads
+// leave lane r (mod 4) with value r summed over its quad, two row rotations by 4 and 8 lanes sum the rows of 16, a swizzle and a
+// half-wave exchange sum the four rows -- 13 lane-crossing operations instead of 4 x (4 DPP + 4 v_readlane)
+__device__ __forceinline__ float pm_dpp_add(float keep, float send, int ctrl_sel) {
+  // keep + (send of the partner lane); the four DPP patterns used below
+  float o;
+  switch (ctrl_sel) {
+    case 0: o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true)); break;    // quad_perm [1,0,3,2]
+    case 1: o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true)); break;    // quad_perm [2,3,0,1]
+    case 2: o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x124, 0xF, 0xF, true)); break;   // row_ror:4
+    default: o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xF, 0xF, true)); break;  // row_ror:8
+  }
+  return keep + o;
+}
+__device__ __forceinline__ void pm_wave_sum4(float& a, float& b, float& c, float& d, int lane) {
+  const bool o1 = lane & 1, o2 = lane & 2;
+  const float ab = pm_dpp_add(o1 ? b : a, o1 ? a : b, 0);
+  const float cd = pm_dpp_add(o1 ? d : c, o1 ? c : d, 0);
+  float v = pm_dpp_add(o2 ? cd : ab, o2 ? ab : cd, 1);      // lane & 3 == 0: a, 1: b, 2: c, 3: d, summed over the quad
+  v = pm_dpp_add(v, v, 2);
+  v = pm_dpp_add(v, v, 3);                                  // ... over the row of 16
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));      // lane ^ 16
+  v += __shfl_xor(v, 32, 64);
+  a = spk_readlane_f(v, 0); b = spk_readlane_f(v, 1); c = spk_readlane_f(v, 2); d = spk_readlane_f(v, 3);
 }
 // phi_k(d), phi_k'(d) for the lane's own k, parameters preloaded
 __device__ __forceinline__ void pm_phi_d(int kind, float p0k, float p1k, float d, float& phi, float& dphi) {
@@ -621,13 +705,6 @@ __device__ __forceinline__ void pm_phi_d(int kind, float p0k, float p1k, float d
   }
 }
 
-struct PmW3 { f32x4 a[3][8]; };        // 24 k-blocks of one feature tile
-__device__ __forceinline__ void pm_w3load(PmW3& W, const float* __restrict__ wp, int KB, int t, int kb0, int lane) {
-  const char* sb = (const char*)wp + ((size_t)t * KB + kb0) * 1024;
-  pm_load8(W.a[0], sb, lane);
-  pm_load8(W.a[1], sb + 8 * 1024, lane);
-  pm_load8(W.a[2], sb + 16 * 1024, lane);
-}
 
 // message backward of the atoms of one wave (see the header comment of this section); rm = the new gmu rows (written by the
 // caller after the barrier), gc -> global scratch, geometry gradients -> sG
@@ -638,9 +715,7 @@ __device__ __forceinline__ void pm_message_bwd(const PmFilt<K>& Wf, const float*
                                                const int* __restrict__ sRow, const int* __restrict__ myAsg, float* __restrict__ myPhi, float* __restrict__ myFc,
                                                int rbf_kind, float p0k, float p1k, float cutoff, bool mu0, bool geom, int lane, pm_f2 (&rm)[4][3]) {
   const int hi = lane >> 5;
-  pm_f2 bias[3];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) bias[p] = *(const pm_f2*)(bf + p * 128 + 2 * lane);
+  (void)bf;
   const pm_f2 zero2 = {0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -675,42 +750,41 @@ __device__ __forceinline__ void pm_message_bwd(const PmFilt<K>& Wf, const float*
         const int jl = __float_as_int(ea.x);
         const float ux = ea.y, uy = ea.z, uz = ea.w, d = sEd[le];
         {
-          float ph, dph;
-          pm_phi_d(rbf_kind, p0k, p1k, d, ph, dph);
-          myPhi[lane] = hi ? dph : ph;
+          float bs, dbs;
+          pm_basis<K>(rbf_kind, lane & 31, p0k, p1k, d, fc, dfc, bs, dbs);
+          myPhi[lane] = hi ? dbs : bs;
         }
         const int jo = jl * PM_LD + 2 * lane;
-        f32x4 pa[K / 4], pd[K / 4];
+        f32x4 pa[K / 4 + 1], pd[K / 4 + 1];
 #pragma unroll
-        for (int c = 0; c < K / 4; ++c) { pa[c] = *(const f32x4*)(myPhi + 4 * c); pd[c] = *(const f32x4*)(myPhi + 32 + 4 * c); }
+        for (int c = 0; c < K / 4 + 1; ++c) { pa[c] = *(const f32x4*)(myPhi + 4 * c); pd[c] = *(const f32x4*)(myPhi + 32 + 4 * c); }
         const pm_f2 gu = gma0 * ux + gma1 * uy + gma2 * uz;
         pm_f2 ddv, mR;
         {   // q part
-          const pm_f2 P = pm_filter2<K>(Wf.w[0][0], Wf.w[0][1], pa, bias[0]), Pd = pm_filter2<K>(Wf.w[0][0], Wf.w[0][1], pd, zero2);
-          if (!geom) accq += P * fc * *(const pm_f2*)(sGq + jo);
-          ddv = cq * gqa * (Pd * fc + P * dfc);
+          const pm_f2 Fq = pm_filter2<K / 4 + 1>(Wf.w[0][0], Wf.w[0][1], pa), dFq = pm_filter2<K / 4 + 1>(Wf.w[0][0], Wf.w[0][1], pd);
+          if (!geom) accq += Fq * *(const pm_f2*)(sGq + jo);
+          ddv = cq * gqa * dFq;
         }
         {   // R part
-          const pm_f2 P = pm_filter2<K>(Wf.w[1][0], Wf.w[1][1], pa, bias[1]), Pd = pm_filter2<K>(Wf.w[1][0], Wf.w[1][1], pd, zero2);
-          const pm_f2 FR = P * fc;
+          const pm_f2 FR = pm_filter2<K / 4 + 1>(Wf.w[1][0], Wf.w[1][1], pa), dFR = pm_filter2<K / 4 + 1>(Wf.w[1][0], Wf.w[1][1], pd);
           if (!geom) {
             const pm_f2 gb0 = *(const pm_f2*)(sGmu + jo), gb1 = *(const pm_f2*)(sGmu + PM_TILE + jo), gb2 = *(const pm_f2*)(sGmu + 2 * PM_TILE + jo);
             accR -= FR * (gb0 * ux + gb1 * uy + gb2 * uz);
           }
-          ddv += cR * gu * (Pd * fc + P * dfc);
+          ddv += cR * gu * dFR;
           mR = FR * cR;
         }
         if (!mu0) {   // mu part
-          const pm_f2 P = pm_filter2<K>(Wf.w[2][0], Wf.w[2][1], pa, bias[2]), Pd = pm_filter2<K>(Wf.w[2][0], Wf.w[2][1], pd, zero2);
-          const pm_f2 Fm = P * fc;
+          const pm_f2 Fm = pm_filter2<K / 4 + 1>(Wf.w[2][0], Wf.w[2][1], pa), dFm = pm_filter2<K / 4 + 1>(Wf.w[2][0], Wf.w[2][1], pd);
           if (!geom) {
             av0 += Fm * *(const pm_f2*)(sGmu + jo); av1 += Fm * *(const pm_f2*)(sGmu + PM_TILE + jo); av2 += Fm * *(const pm_f2*)(sGmu + 2 * PM_TILE + jo);
           }
           const pm_f2 gm = gma0 * *(const pm_f2*)(sMuIn + jo) + gma1 * *(const pm_f2*)(sMuIn + PM_TILE + jo) + gma2 * *(const pm_f2*)(sMuIn + 2 * PM_TILE + jo);
-          ddv += cm * gm * (Pd * fc + P * dfc);
+          ddv += cm * gm * dFm;
         }
         const pm_f2 t0 = gma0 * mR, t1 = gma1 * mR, t2 = gma2 * mR;
-        const float dd = pm_wave_sum(ddv.x + ddv.y), tux = pm_wave_sum(t0.x + t0.y), tuy = pm_wave_sum(t1.x + t1.y), tuz = pm_wave_sum(t2.x + t2.y);
+        float dd = ddv.x + ddv.y, tux = t0.x + t0.y, tuy = t1.x + t1.y, tuz = t2.x + t2.y;
+        pm_wave_sum4(dd, tux, tuy, tuz, lane);
         if (lane == 0 && d > 0.f) {
           const float dot = tux * ux + tuy * uy + tuz * uz;
           const float invd = 1.0f / d;
@@ -816,8 +890,9 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
       PM_BSTAMP(1 + 12 * (a.n_layers - 1 - l));
 
       // ================= M1: ga_mu -> X0, ga_qmu -> X1, U = gq a_qmu -> X3                 (weights of M2 requested meanwhile)
-      PmW3 W3;
-      pm_w3load(W3, P.ic2T_p, 48, t, 24 * team, lane);
+      PmW W3;
+      pm_wload(W3, P.ic2T_p, 48, t, 24 * team, lane);
+      if (a.dbg && blockIdx.x == 0 && lane == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(W3.a0[7].x)); a.dbg[64 + 52 + wv] = (long long)__builtin_readcyclecounter(); }
 #pragma unroll
       for (int rep = 0; rep < 2; ++rep) {
         const int s = tid + 512 * rep, row = s >> 5, c4 = s & 31;
@@ -854,15 +929,16 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = pm_mma8(W3.a[0], b0 + bo, acc);
-        acc = pm_mma8(W3.a[1], b1 + bo, acc);
-        acc = pm_mma8(W3.a[2], b2 + bo, acc);
+        acc = pm_wmma_3chunks(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
+        if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(acc[0])); a.dbg[64 + 40] = (long long)__builtin_readcyclecounter(); }
+        if (a.dbg && blockIdx.x == 0 && lane == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(acc[0])); a.dbg[64 + 44 + wv] = (long long)__builtin_readcyclecounter(); }
         pm_wload(Wn, P.ic1T_p, 16, 4 * team + t, 0, lane);
         if (team == 1) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) *(f32x4*)(X2 + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
         }
         PM_BARRIER();
+        if (l == a.n_layers - 1) PM_BSTAMP(41);
         if (team == 0) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -875,17 +951,18 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
           }
         }
       }
+      if (l == a.n_layers - 1) PM_BSTAMP(42);
       PM_BARRIER();
       PM_BSTAMP(3 + 12 * (a.n_layers - 1 - l));
 
       // ================= M3: g_ctx = g_hid W_b1: tiles 0..3 (q part, team 0): gq += ; tiles 4..7 (|V| part, team 1): g_nv -> X0
-      PmW Wm;       // weights of M4: A = W_mix^T, k-blocks 16 team .. 16 team + 15 (the gV resp. gW half of the contraction)
+      PmWF Wm;      // weights of M4: A = W_mix^T, k-blocks 16 team .. 16 team + 15 (the gV resp. gW half of the contraction)
       {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         acc = pm_wmma(Wn, X2, lane, acc);
-        pm_wload(Wm, P.mixT_p, 32, t, 16 * team, lane);
+        pm_wfload(Wm, P.mixT_p, 32, t, 16 * team, lane);
         float* dst = team ? X0 : sGq;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -924,7 +1001,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = pm_wmma(Wm, team ? X2 : X1, lane, acc);
+        acc = pm_wfmma(Wm, team ? X2 : X1, lane, acc);
         float* gp = sGmu + x * PM_TILE + el * PM_LD + 32 * t + 4 * hi;
         if (team == 1) {
 #pragma unroll
@@ -941,7 +1018,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
 
       // ================= message backward: mu entering the interaction -> X0..X2, edge records -> X3
       PmFilt<K> Wf;
-      pm_filt_load<K>(Wf, P.wf, lane, mu0);
+      pm_filt_load<K>(Wf, P.wf, P.bf, lane, mu0);
       if (!mu0) {
         for (int s = tid; s < 3 * 32 * 32; s += 512) {
           const int x = s >> 10, row = (s >> 5) & 31, c4 = s & 31;
@@ -971,7 +1048,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         pm_message_write(sGmu, myAsg, lane, rm);
       }
       // ================= context net backward: gc -> X0..X2 (part planes), gq += ((gc W_a2) silu'(pre_a)) W_a1
-      pm_w3load(W3, P.ctx2T_p, 48, t, 24 * team, lane);
+      pm_wload(W3, P.ctx2T_p, 48, t, 24 * team, lane);
       {
         const float* gcs = a.gc_scratch + (size_t)a0 * 3 * F;
         for (int s = tid; s < 3 * 32 * 32; s += 512) {
@@ -991,9 +1068,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = pm_mma8(W3.a[0], b0 + bo, acc);
-        acc = pm_mma8(W3.a[1], b1 + bo, acc);
-        acc = pm_mma8(W3.a[2], b2 + bo, acc);
+        acc = pm_wmma_3chunks(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
         if (team == 0) pm_wload(Wn, P.ctx1T_p, 16, t, 0, lane);
         if (team == 1) {
 #pragma unroll

@@ -27,6 +27,8 @@ for base in (0, 64):
         kk = k + base
         if kk < len(st) and st[kk]:
             print("  %-36s %8d  (+%d)" % (names[k] if base == 0 else "bwd " + str(k), st[kk] - st[base], st[kk] - prev)); prev = st[kk]
+print("bwd M2 detail (top layer): phase start -> MFMAs retired %d, -> partial barrier %d, -> epilogue done %d" % (st[64 + 40] - st[64 + 2], st[64 + 41] - st[64 + 2], st[64 + 42] - st[64 + 2]))
+print("   per wave: weights arrived (rel. to M1 start)", [st[64 + 52 + w] - st[64 + 1] for w in range(8)], " MFMAs retired (rel. to M2 start)", [st[64 + 44 + w] - st[64 + 2] for w in range(8)])
 print("HW_ID per wave (simd = bits 4-5):", [(hex(x), (x >> 4) & 3) for x in st[200:208]])
 _lib.profile_enable(True); _lib.profile_report()
 for _ in range(20):
