@@ -120,6 +120,7 @@ def self_spawn(args):
 # rocprofv3 kernel-name patterns of the profile tags (spk_profile_report) -- used to attribute PMC counters
 PMC_TAGS = [
     ("schnet_mol_fwd", r"k_schnet_mol_fwd<"), ("schnet_mol_bwd", r"k_schnet_mol_bwd<"),
+    ("painn_mol_fwd", r"k_painn_mol_fwd<"), ("painn_mol_bwd", r"k_painn_mol_bwd<"),
     ("cfconv_fwd_pair", r"k_cfconv_pair<[^>]*false, false, false>"), ("cfconv_bwd_pair_gs_geom", r"k_cfconv_pair_t<[^>]*true, true, true>"),
     ("cfconv_bwd_pair_gs", r"k_cfconv_pair_t<[^>]*true, true, false>"), ("cfconv_bwd_pair", r"k_cfconv_pair_t<[^>]*true, false"),
     ("cfconv_fwd_mol", r"k_cfconv_mol<[^>]*false>"), ("cfconv_bwd_mol", r"k_cfconv_mol<[^>]*true>"),
@@ -305,7 +306,12 @@ def algorithmic_work(kind, E, N, n_mol, F, n_int, n_rbf):
     exec_mol_bwd = n_int * 4096.0 * (tiles_mol * 2 * (8 * kpb + 128) + n_mol * 3 * 4 * 64)
     mol_f, mol_b = n_int * (flop_fwd + flop_dense), n_int * (2 * flop_fwd + flop_dense)
     gs = 0.5 * 352.0 / 608.0
+    # molecule-resident PaiNN launches: every interaction's message AND mixing / context nets in one launch -- booked, like the
+    # kernels they replace, by the no-reuse gather convention: forward sum over interactions of (message + mixing) bytes, backward 2x
+    pmol = n_int * (msg_bytes + N * 4096.0)
+    pmol_min = n_int * (bmin_msg + N * 4096.0)
     return {
+        "painn_mol_fwd": ("hbm", pmol, 1.0, pmol_min), "painn_mol_bwd": ("hbm", 2 * pmol, 1.0, 2 * pmol_min),
         "schnet_mol_fwd": ("mfma", mol_f, exec_mol / mol_f, n_int * bmin_cf), "schnet_mol_bwd": ("mfma", mol_b, exec_mol_bwd / mol_b, 2 * n_int * bmin_cf),
         "cfconv_fwd_mfma": ("mfma", flop_fwd, 1.0, bmin_cf), "cfconv_fwd_simple": ("mfma", flop_fwd, 1.0, bmin_cf),
         "cfconv_fwd_pair": ("mfma", flop_fwd, 0.5, bmin_cf),
@@ -432,6 +438,10 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
     # transpose to a chain launch, so its own share is the two transposed context layers + the products: N * 2 * 2 (2F F + F 3F))
     mix_flop = N * 2.0 * (3 * F * 2 * F + 2 * F * F + F * 3 * F)
     algo_n = {"painn_mixing_fwd": mix_flop, "painn_mixing_bwd": N * 4.0 * (2 * F * F + F * 3 * F)}
+    # the Dense share of the molecule-resident PaiNN launches (context net N * 2 (F F + F 3F) + mixing N * 360 k per interaction; backward
+    # 2x) against the fp32 matrix peak, beside their HBM-convention fraction
+    pm_dense = n_int * (N * 2.0 * (F * F + 3 * F * F) + mix_flop)
+    algo_mfma_view = {"painn_mol_fwd": pm_dense, "painn_mol_bwd": 2 * pm_dense}
     FLAG = "exceeds 1: the algorithmic convention of SURVEY.md 8(d) books more work than this kernel issues (one filter per undirected pair, saved filters, cache-resident gathers); read executed_frac_of_peak / traffic instead"
     for tag, kd in kernels.items():
         if tag in algo:
@@ -442,6 +452,8 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
             kd["bound"] = bound
             if kd["frac_of_peak"] > 1.0:
                 kd["frac_flag"] = FLAG
+            if tag in algo_mfma_view:
+                kd["dense_flop_frac_of_mfma_peak"] = round(algo_mfma_view[tag] / (kd["avg_us"] * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
         elif tag in algo_n:
             kd["frac_of_peak"] = round(algo_n[tag] / (kd["avg_us"] * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
             kd["bound"] = "mfma"

@@ -321,8 +321,33 @@ def deploy_goldens(ns):
     print("wrote deploy_painn.npz")
 
 
+def deep_model_goldens(ns):
+    """The reference's DEFAULT depth (configs/model/representation/schnet.yaml:5-9: n_interactions = 6; PaiNN with six blocks
+    beside it): twice the interactions of the bench configuration -- twice the error accumulation of the fp32 kernels (round-2
+    review: pin a 6-interaction golden).  Molecule batch and the periodic 192-atom water box."""
+    nn = ns.nn
+    head = O.init_atomwise_params(128, seed=1)
+    wb = S.water_box(n_side=4, seed=0)
+    for name, kind, b in (("schnet6_aspirin4", "schnet", S.molecule_batch("aspirin", 4, seed=11)), ("schnet6_water192", "schnet", wb),
+                          ("painn6_aspirin4", "painn", S.molecule_batch("aspirin", 4, seed=11)), ("painn6_water192", "painn", wb)):
+        rb = nn.GaussianRBF(20, 5.0)
+        torch.manual_seed(0)
+        if kind == "schnet":
+            rep = ns.schnet.SchNet(128, 6, rb, nn.CosineCutoff(5.0))
+            p = O.init_schnet_params(n_interactions=6)
+        else:
+            rep = ns.painn.PaiNN(128, 6, rb, nn.CosineCutoff(5.0))
+            p = O.init_painn_params(n_interactions=6)
+        sd = rep.state_dict()
+        assert all(torch.equal(sd[k], p[k].to(sd[k].dtype)) for k in sd), name
+        res = run_reference(ns, rep, head, b)
+        save(name + ".npz", b, res, weights_checksum=checksum(p), kind=kind, cutoff=5.0, radial="gaussian", n_interactions=6)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "md":
+    if len(sys.argv) > 1 and sys.argv[1] == "deep":
+        deep_model_goldens(refshim.load())
+    elif len(sys.argv) > 1 and sys.argv[1] == "md":
         ring_polymer_goldens()
     elif len(sys.argv) > 1 and sys.argv[1] == "nbl":
         neighbor_list_goldens(refshim.load())
@@ -333,3 +358,4 @@ if __name__ == "__main__":
         neighbor_list_goldens(refshim.load())
         ring_polymer_goldens()
         deploy_goldens(refshim.load())
+        deep_model_goldens(refshim.load())

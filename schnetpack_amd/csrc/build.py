@@ -62,6 +62,7 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd)
     build_native_example(force, verbose)
     build_torch_ops(force, verbose)
+    build_jit_client(force, verbose)
     return LIB
 
 
@@ -103,6 +104,31 @@ def build_native_example(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return RUN_BIN
+
+
+JIT_SRC = os.path.join(HERE, "..", "..", "examples", "native", "spk_jit_client.cpp")
+JIT_BIN = os.path.join(HERE, "spk_jit_client")
+
+
+def build_jit_client(force=False, verbose=True):
+    """C++ libtorch client of a deployed TorchScript archive (examples/native/spk_jit_client.cpp): what LAMMPS' pair style does
+    (interfaces/lammps/pair_schnetpack.cpp:125-131, :285-328) -- torch::jit::load + forward, no Python -- after dlopen of the two
+    operator libraries.  Links libtorch only; the spk_hip libraries are given at run time."""
+    if not os.path.exists(JIT_SRC):
+        return None
+    if not (force or _stale(JIT_BIN, [JIT_SRC])):
+        return JIT_BIN
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [os.environ.get("CXX", "g++"), "-O1", "-std=c++17", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + p for p in ce.include_paths()] + ["-I/opt/rocm/include", JIT_SRC, "-o", JIT_BIN, "-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10",
+            "-ltorch_hip", "-lc10_hip", "-ldl", "-Wl,--no-as-needed", "-Wl,-rpath," + tlib, "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return JIT_BIN
 
 
 if __name__ == "__main__":

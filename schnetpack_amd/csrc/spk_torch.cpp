@@ -1353,6 +1353,21 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> edge_plan_op(const Tensor& idx_i, con
   return {p->rowptr, p->rev, p->half.defined() ? p->half : at::empty({0}, iopt), flags};
 }
 
+// Every array of the plan of a list (for raw C-ABI callers and tests: they wrap these tensors in a spk_graph_t instead of
+// re-deriving them): (rowptr, rev, half, edge_pair, grp_atom0, grp_pair0, grp_tile0, meta) with meta = [sorted, symmetric,
+// n_half, n_groups, max_group_atoms, max_group_pairs, filter_pairs (-1 undecided), n_tiles_grouped] (int64, host).
+std::vector<Tensor> edge_plan_arrays_op(const Tensor& idx_i, const Tensor& idx_j, int64_t n_atoms, const c10::optional<Tensor>& r_ij) {
+  require_device(idx_i, "edge_plan_arrays");
+  Tensor r = (r_ij.has_value() && r_ij->defined()) ? *r_ij : Tensor();
+  auto p = get_plan(idx_i, idx_j, n_atoms, r);
+  auto iopt = at::TensorOptions().dtype(at::kInt).device(idx_i.device());
+  auto or_empty = [&](const Tensor& t) { return t.defined() ? t : at::empty({0}, iopt); };
+  Tensor meta = at::tensor(std::vector<int64_t>{p->sorted, p->symmetric, p->n_half, p->n_groups, p->max_group_atoms, p->max_group_pairs,
+                                                p->filter_pairs, p->n_tiles_grouped}, at::TensorOptions().dtype(at::kLong));
+  return {p->rowptr, p->rev, or_empty(p->half), or_empty(p->edge_pair), or_empty(p->grp_atom0), or_empty(p->grp_pair0), or_empty(p->grp_tile0), meta,
+          p->idx_i, p->idx_j};
+}
+
 // Plan made on the host by the collate function (schnetpack_amd/data.py, DataLoader workers): put it into the cache under the
 // key of the device index tensors -- no kernel, no device-to-host copy.  meta = [sorted, symmetric, n_half, n_groups,
 // max_group_atoms, max_group_pairs, filter_pairs (-1 unknown), n_tiles_grouped].
@@ -1596,6 +1611,7 @@ TORCH_LIBRARY(spk_hip, m) {
   m.def("atomwise_forward(Tensor x, Tensor w1, Tensor? b1, Tensor w2, Tensor? b2, Tensor idx_m, int n_mol, int act) -> (Tensor, Tensor, Tensor)");
   m.def("atomwise_backward(Tensor? gE, Tensor? gy_atom, Tensor pre, Tensor w1, Tensor w2, Tensor idx_m, int n_mol, int act) -> Tensor");
   m.def("edge_plan(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor? r_ij, float cutoff=0.0, int force_filter=-1) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("edge_plan_arrays(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor? r_ij) -> Tensor[]");
   m.def("edge_plan_install(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor rowptr, Tensor rev, Tensor half, Tensor edge_pair, Tensor grp_atom0, Tensor grp_pair0, int[] meta) -> ()");
   // static-shape mode + cache control (host-side state)
   m.def("static_new() -> int", static_new_op);
@@ -1638,6 +1654,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm d
   m.impl("atomwise_forward", atomwise_forward_raw);
   m.impl("atomwise_backward", atomwise_backward_op);
   m.impl("edge_plan", edge_plan_op);
+  m.impl("edge_plan_arrays", edge_plan_arrays_op);
   m.impl("static_declare", static_declare_op);
   m.impl("static_declare_range", static_declare_range_op);
   m.impl("edge_plan_install", edge_plan_install_op);

@@ -47,7 +47,7 @@ def golden_params(meta):
         rep = {k[4:]: v for k, v in meta["weights"].items() if k.startswith("rep.")}
         head = {k[5:]: v for k, v in meta["weights"].items() if k.startswith("head.")}
         return rep, head
-    kw = dict(cutoff=float(meta["cutoff"]), radial=str(meta["radial"]))
+    kw = dict(cutoff=float(meta["cutoff"]), radial=str(meta["radial"]), n_interactions=int(meta.get("n_interactions", 3)))
     if str(meta["kind"]) == "schnet":
         rep = O.init_schnet_params(**kw)
     else:
@@ -58,7 +58,9 @@ def golden_params(meta):
 MODEL_CASES = ["schnet_ethanol.npz", "schnet_aspirin8.npz", "painn_ethanol.npz",
                "painn_aspirin8.npz", "schnet_bessel_aspirin2.npz", "painn_bessel_aspirin2.npz",
                "schnet_skin_aspirin2.npz", "painn_skin_aspirin2.npz",
-               "painn_aspirin_pretrained.npz", "schnet_water192.npz", "painn_water192.npz"]
+               "painn_aspirin_pretrained.npz", "schnet_water192.npz", "painn_water192.npz",
+               # the reference's default depth (6 interactions): twice the error accumulation of the bench configuration
+               "schnet6_aspirin4.npz", "schnet6_water192.npz", "painn6_aspirin4.npz", "painn6_water192.npz"]
 
 
 def rel_err(a, b):

@@ -152,3 +152,46 @@ def test_eval_operator_autograd_contract_on_device(dev, kind):
         O.painn_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, 3)[0]
     (go,) = torch.autograd.grad((xo * w.cpu().double()).sum(), [rp["embedding.weight"]])
     assert rel_err(g_emb, go) < TOL
+
+
+def _write_system_bin(path, g, t):
+    """LAMMPS-style single system (golden fixture `t`) in the little-endian layout examples/native/spk_jit_client.cpp reads."""
+    n, E = int(g[t + "Z"].shape[0]), int(g[t + "idx_i"].shape[0])
+    with open(path, "wb") as f:
+        f.write(np.asarray([n, E], dtype="<i8").tobytes())
+        f.write(np.asarray(g[t + "Z"], dtype="<i8").tobytes())
+        f.write(np.asarray(g[t + "R"], dtype="<f4").tobytes())
+        f.write(np.asarray(g[t + "idx_i"], dtype="<i8").tobytes())
+        f.write(np.asarray(g[t + "idx_j"], dtype="<i8").tobytes())
+        f.write(np.asarray(g[t + "offsets"], dtype="<f4").tobytes())
+        f.write(np.asarray(g[t + "cell"], dtype="<f4").reshape(9).tobytes())
+
+
+def test_cpp_libtorch_client_loads_the_archives_like_lammps(dev, tmp_path):
+    """The actual contract of interfaces/lammps/pair_schnetpack.cpp:125-131, :328: a C++ process -- no Python, no `import
+    schnetpack_amd` -- dlopens the two operator libraries, torch::jit::load(path, device, {"cutoff": ""}), forward on the dict of
+    one system, and reproduces the reference-generated fixtures (free molecule and periodic cell, both shipped PaiNN models)."""
+    import subprocess
+    from schnetpack_amd.csrc import build as B
+    exe = B.JIT_BIN
+    if not os.path.exists(exe):
+        pytest.skip("spk_jit_client not built")
+    paths = {n: build_ref.deployed_path(n) for n in build_ref.DEPLOYED}
+    if not all(os.path.exists(p) for p in paths.values()):
+        pytest.skip("oracle/_ref/deployed/*.pt not built (needs /root/reference at build time)")
+    g = load_npz("deploy_painn.npz")
+    for name, p in paths.items():
+        for tag in ("free", "pbc"):
+            t = "%s_%s_" % (name, tag)
+            sysf = str(tmp_path / (t + "system.bin"))
+            _write_system_bin(sysf, g, t)
+            r = subprocess.run([exe, p, sysf, B.LIB, B.TORCH_LIB, "cuda:0"], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            lines = r.stdout.strip().splitlines()
+            assert lines[0].startswith("cutoff") and float(lines[0].split()[1]) == pytest.approx(float(g[name + "_cutoff"]))
+            E = float(lines[1].split()[1])
+            F = np.array([[float(x) for x in ln.split()] for ln in lines[2:]])
+            Er, Fr = np.asarray(g[t + "energy"]).reshape(-1), np.asarray(g[t + "forces"])
+            assert F.shape == Fr.shape
+            assert np.abs(F - Fr).max() / np.abs(Fr).max() < TOL, t
+            assert abs(E - float(Er[0])) <= 0.07, t

@@ -91,14 +91,14 @@ def test_graphed_training_step_equals_eager_loop(dev, kind):
 
 
 def test_static_lists_flag_unsorted_index(dev):
-    from schnetpack_amd import ops
+    from schnetpack_amd import torchops
     from schnetpack_amd._lib import SpkHipError
-    sl = ops.StaticLists()
+    sl = torchops.StaticLists()
     idx = torch.tensor([0, 0, 1, 3, 3, 5], device=dev)
-    sl.declare_sorted(idx, 7)
+    rowptr = sl.declare_sorted(idx, 7)
     sl.refresh()
     sl.check()
-    assert sl.rowptr(idx, 7).cpu().tolist() == [0, 2, 3, 3, 5, 5, 6, 6]
+    assert rowptr.cpu().tolist() == [0, 2, 3, 3, 5, 5, 6, 6]
     idx.copy_(torch.tensor([0, 2, 1, 3, 3, 5], device=dev))
     sl.refresh()
     with pytest.raises(SpkHipError):

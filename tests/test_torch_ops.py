@@ -145,3 +145,33 @@ def test_reference_model_with_installed_hip_classes_scripts_like_spkdeploy(tmp_p
         assert "spk_hip::painn" in str(jm.representation.graph)
         assert "spk_hip::pairwise" in str(getattr(jm.input_modules, "0").graph)
         assert type(jm).__name__ == "RecursiveScriptModule" and jm.original_name == "NeuralNetworkPotential"
+
+
+def test_cpp_libtorch_client_builds_loads_the_archive_and_refuses_the_cpu(tmp_path):
+    """examples/native/spk_jit_client.cpp (the C++ side of interfaces/lammps/pair_schnetpack.cpp:125-131, :328) on the build box:
+    it builds against libtorch, dlopens the two operator libraries, loads a `spkdeploy` archive with its cutoff metadata -- and,
+    with no ROCm device here, the first operator refuses the CPU tensors loudly (rc 1, the no-fallback message)."""
+    import os
+    import subprocess
+    import numpy as np
+    from oracle import build_ref
+    from schnetpack_amd.csrc import build as B
+    exe = B.build_jit_client(verbose=False)
+    assert exe and os.path.exists(exe)
+    p = build_ref.deployed_path(build_ref.DEPLOYED[0] if isinstance(build_ref.DEPLOYED, (list, tuple)) else sorted(build_ref.DEPLOYED)[0])
+    if not os.path.exists(p):
+        import pytest
+        pytest.skip("oracle/_ref/deployed/*.pt not built")
+    sysf = str(tmp_path / "system.bin")
+    n, E = 3, 6
+    with open(sysf, "wb") as f:
+        f.write(np.asarray([n, E], dtype="<i8").tobytes())
+        f.write(np.asarray([8, 1, 1], dtype="<i8").tobytes())
+        f.write(np.asarray([[0, 0, 0], [0.96, 0, 0], [-0.24, 0.93, 0]], dtype="<f4").tobytes())
+        f.write(np.asarray([0, 0, 1, 1, 2, 2], dtype="<i8").tobytes())
+        f.write(np.asarray([1, 2, 0, 2, 0, 1], dtype="<i8").tobytes())
+        f.write(np.zeros((E, 3), dtype="<f4").tobytes())
+        f.write(np.zeros(9, dtype="<f4").tobytes())
+    r = subprocess.run([exe, p, sysf, B.LIB, B.TORCH_LIB, "cpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stdout, r.stderr)
+    assert "no CPU fallback" in r.stderr or "ROCm" in r.stderr, r.stderr[-1500:]
