@@ -407,6 +407,13 @@ int spk_schnet_potential_forces_f32(const spk_schnet_t* m, const spk_head_t* hea
                                     const float* offsets, const int64_t* idx_m, int64_t n_mol, int32_t all_inside, float* x_out,
                                     float* E, float* F, float* pre_h, float* saved, void* stream);
 
+/* EXPERIMENT (eval only, not on any default path; scripts/tab_filter_experiment.py): continuous-filter convolution
+ * (representation/schnet.py:60-67) with the filter W_l(d) f_c(d) read from a cubic-Hermite table instead of the filter network:
+ *   y[i, c] = sum_{e in row(i)} h[idx_j[e], c] * T_c(|r_e|),  table [n_knots, 128, 2] = (value, slope * step) at d = n d_max / (n_knots - 1),
+ * zero at and beyond the cutoff.  Sorted list (g->rowptr), nf = 128; y [N, 128] is overwritten. */
+int spk_cfconv_tab_f32(const spk_graph_t* g, const float* r_ij, const float* h, const float* table, int32_t n_knots, float d_max,
+                       float cutoff, int32_t nf, float* y, void* stream);
+
 /* Kernel-tuning aid of the molecule-resident SchNet kernels (spk_schnet_mol.hip: block-diagonal lists with <= 32 atoms per
  * block run every interaction inside one workgroup): device buffer of int64 receiving cycle stamps -- entries [0, 128): thread 0
  * of workgroup 0 at the phase boundaries; [128 + 4 b, 128 + 4 b + 4): start / end of workgroup b of the backward launch (real time and

@@ -412,6 +412,12 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
       f32x16 bz;         // ... and its bias
       pm_wload(Wt, a.L[0].ctx1_p, 16, t, 0, lane); bz = pm_bias_acc(a.L[0].ctx1_b, t, hi);
       for (int l = 0; l < a.n_layers; ++l) {
+        // (lane-derived LDS / global offsets are re-derived inside every interaction: hoisted out of the loop by the compiler they
+        //  fill the prologue with dozens of live registers -- and their spills)
+        int lane_o_ = lane, tid_o_ = tid;
+        asm volatile("" : "+v"(lane_o_), "+v"(tid_o_));
+        const int lane = lane_o_, tid = tid_o_, hi = lane >> 5, el = lane & 31;
+        (void)tid; (void)hi; (void)el;
         const PmLayerDev& P = a.L[l];
         float* S = a.saved + (int64_t)l * per;
         const bool last = (l + 1 == a.n_layers);
@@ -564,6 +570,12 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
     } else {
       // ======================================================================== team 1
       for (int l = 0; l < a.n_layers; ++l) {
+        // (lane-derived LDS / global offsets are re-derived inside every interaction: hoisted out of the loop by the compiler they
+        //  fill the prologue with dozens of live registers -- and their spills)
+        int lane_o_ = lane, tid_o_ = tid;
+        asm volatile("" : "+v"(lane_o_), "+v"(tid_o_));
+        const int lane = lane_o_, tid = tid_o_, hi = lane >> 5, el = lane & 31;
+        (void)tid; (void)hi; (void)el;
         const PmLayerDev& P = a.L[l];
         float* S = a.saved + (int64_t)l * per;
         PmW Wt;
@@ -876,6 +888,12 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
     }
 
     for (int l = a.n_layers - 1; l >= 0; --l) {
+      // (lane-derived LDS / global offsets are re-derived inside every interaction: hoisted out of the loop by the compiler they
+      //  fill the prologue with dozens of live registers -- and their spills)
+      int lane_o_ = lane, tid_o_ = tid;
+      asm volatile("" : "+v"(lane_o_), "+v"(tid_o_));
+      const int lane = lane_o_, tid = tid_o_, hi = lane >> 5, el = lane & 31;
+      (void)tid; (void)hi; (void)el;
       const PmLayerBwd& P = a.L[l];
       const float* S = a.saved + (int64_t)l * per;
       const float* preA_g = S + (size_t)a0 * F;

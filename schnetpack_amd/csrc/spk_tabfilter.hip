@@ -1,0 +1,70 @@
+// EXPERIMENT (round 3, SURVEY.md section 8(d): "cfconv as a whole is MFMA-bound unless the filter MLP is tabulated"):
+// continuous-filter convolution (representation/schnet.py:60-67) with the filter  W_l(d) f_c(d)  read from a TABLE instead of
+// being evaluated by the filter network.  The filter is a smooth function of ONE variable per channel, so a cubic-Hermite spline
+// over n_knots equidistant knots (value + slope, built in float64 from the weights whenever they change) replaces the
+// 2 (n_rbf nf + nf nf) = 37.9 kFLOP per edge-message of the MLP by ~10 FLOP and two 1-KB table rows per edge.  Eval-only, default
+// OFF: the fp32 MFMA kernels stay the contract path; scripts/tab_filter_experiment.py measures time and error of this kernel
+// beside them (profiles/r03_tabulated_filter_experiment.json).
+//
+//   y[i, c] = sum_{e in row(i)} h[j(e), c] * T_c(d_e),   T_c(d) = Hermite(table[n], table[n + 1], t),  n = floor(d / step), t = frac
+//
+// table: [n_knots][nf][2] floats = (value, slope * step) at d_n = n * step; entries beyond the cutoff are zero.  One wavefront per
+// centre atom (CSR row, sorted idx_i), a lane owns two channels: a table row is one coalesced 1-KB burst, the neighbour row
+// 512 bytes; no atomics; row sums in registers.  Bound: L2 / HBM gather bandwidth (2.5 KB per edge).
+#include "spk_common.h"
+
+typedef float tf2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_cfconv_tab(const float* __restrict__ h, const float* __restrict__ rij, const int64_t* __restrict__ idx_j,
+                                                    const int32_t* __restrict__ rowptr, const float* __restrict__ table, int n_knots, float inv_step,
+                                                    float cutoff, int64_t N, float* __restrict__ y, float* __restrict__ dy_dd /* [E] or null */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int64_t atom = (int64_t)blockIdx.x * 4 + wv; atom < N; atom += (int64_t)gridDim.x * 4) {
+    const int32_t e0 = rowptr[atom], e1 = rowptr[atom + 1];
+    tf2 acc = {0.f, 0.f};
+    for (int32_t cs = e0; cs < e1; cs += 64) {
+      // lanes = edges: geometry of up to 64 edges of the row at once
+      const int32_t em = cs + lane;
+      const bool ev = em < e1;
+      const int32_t emc = ev ? em : (e1 - 1);
+      const int jl = (int)idx_j[emc];
+      const float rx = rij[3 * (int64_t)emc], ry = rij[3 * (int64_t)emc + 1], rz = rij[3 * (int64_t)emc + 2];
+      const float dl = sqrtf(rx * rx + ry * ry + rz * rz);
+      uint64_t live = __ballot(ev && dl < cutoff);
+      while (live) {
+        const int t = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        const int64_t j = __builtin_amdgcn_readlane(jl, t);
+        const float d = spk_readlane_f(dl, t);
+        const float u = d * inv_step;
+        int n = (int)u;
+        n = n < n_knots - 2 ? n : n_knots - 2;
+        const float s = u - (float)n;
+        const f32x4 k0 = *(const f32x4*)(table + ((size_t)n * 128 + 2 * lane) * 2);          // (v, m) of channels 2 lane, 2 lane + 1
+        const f32x4 k1 = *(const f32x4*)(table + ((size_t)(n + 1) * 128 + 2 * lane) * 2);
+        const tf2 hj = *(const tf2*)(h + j * 128 + 2 * lane);
+        const float s2 = s * s, s3 = s2 * s;
+        const float h00 = 2.f * s3 - 3.f * s2 + 1.f, h10 = s3 - 2.f * s2 + s, h01 = -2.f * s3 + 3.f * s2, h11 = s3 - s2;
+        const tf2 W = {h00 * k0.x + h10 * k0.y + h01 * k1.x + h11 * k1.y, h00 * k0.z + h10 * k0.w + h01 * k1.z + h11 * k1.w};
+        acc += W * hj;
+      }
+    }
+    *(tf2*)(y + atom * 128 + 2 * lane) = acc;
+  }
+}
+
+// table: [n_knots, 128, 2]; the list must be sorted (rowptr given); nf = 128 only (experiment).  y [N, 128] is overwritten.
+extern "C" int spk_cfconv_tab_f32(const spk_graph_t* g, const float* r_ij, const float* h, const float* table, int32_t n_knots, float d_max,
+                                  float cutoff, int32_t nf, float* y, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(g && g->sorted && g->rowptr && g->idx_j, "spk_cfconv_tab_f32: needs a sorted list with row pointers");
+  SPK_CHECK_ARG(nf == 128 && n_knots >= 2 && d_max > 0.f, "spk_cfconv_tab_f32: nf = 128, n_knots >= 2 (experiment)");
+  if (g->n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(r_ij && h && table && y, "spk_cfconv_tab_f32: null pointer");
+  const float inv_step = (float)(n_knots - 1) / d_max;
+  SpkProfScope prof("cfconv_tab_fwd", stream);
+  hipLaunchKernelGGL(k_cfconv_tab, dim3(spk_grid_for(g->n_atoms, 4, spk_num_cus() * 8)), dim3(256), 0, stream, h, r_ij, g->idx_j, g->rowptr, table, n_knots,
+                     inv_step, cutoff, g->n_atoms, y, nullptr);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

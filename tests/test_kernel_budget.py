@@ -20,6 +20,10 @@ BUDGET = {
     # the two molecule-resident launches sit AT the 256-register limit of two waves per SIMD; the metadata reports a small
     # private segment although no scratch instruction is on a hot path
     "spk_schnet_mol.hip": {"k_schnet_mol_fwdILi3E": (128, 2), "k_schnet_mol_bwdILi3E": (128, 2)},
+    # molecule-resident PaiNN (round 3): both launches at the 256-register limit; what is left in scratch are values parked in the
+    # prologue and a handful of reloads in the message loops -- when whole prefetched weight tiles were being spilled behind their
+    # loads the figures were 2 176 / 652 B per lane and every Dense phase waited for a chain of L2 round trips
+    "spk_painn_mol.hip": {"k_painn_mol_fwdILi20E": (256, 2), "k_painn_mol_bwdILi20E": (448, 2)},
 }
 
 
