@@ -413,6 +413,11 @@ int spk_schnet_potential_forces_f32(const spk_schnet_t* m, const spk_head_t* hea
  * zero at and beyond the cutoff.  Sorted list (g->rowptr), nf = 128; y [N, 128] is overwritten. */
 int spk_cfconv_tab_f32(const spk_graph_t* g, const float* r_ij, const float* h, const float* table, int32_t n_knots, float d_max,
                        float cutoff, int32_t nf, float* y, void* stream);
+/* Attach a table to the interaction whose filter_network.1.weight lies at device address `key` (table == NULL detaches it):
+ * spk_schnet_forward_f32 / _backward_f32 then run that interaction's convolution (and its first-order backward, on symmetric
+ * sorted lists) through the table kernels.  The caller rebuilds the tables when the weights change.  Not used by default. */
+int spk_filter_table_set(const float* key, const float* table, int32_t n_knots, float d_max);
+void spk_filter_table_clear(void);
 
 /* Kernel-tuning aid of the molecule-resident SchNet kernels (spk_schnet_mol.hip: block-diagonal lists with <= 32 atoms per
  * block run every interaction inside one workgroup): device buffer of int64 receiving cycle stamps -- entries [0, 128): thread 0

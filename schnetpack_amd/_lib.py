@@ -108,6 +108,8 @@ _PROTOS = {
     "spk_atomwise_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "spk_atomwise_fwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i64, c_f, c_f, c_f, c_f]),
     "spk_atomwise_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i64, c_f, c_f]),
+    "spk_filter_table_set": (ctypes.c_int, [c_f, c_f, c_i32, ctypes.c_float]),
+    "spk_filter_table_clear": (None, []),
     "spk_cfconv_tab_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i32, ctypes.c_float, ctypes.c_float, c_i32, c_f, c_f]),
     "spk_segment_rowptr_i32": (ctypes.c_int, [c_f, c_i64, c_i64, c_f, c_f, c_f]),
     "spk_index_range_check": (ctypes.c_int, [c_f, c_i64, c_i64, c_f, c_f]),

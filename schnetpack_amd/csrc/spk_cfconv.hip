@@ -1101,11 +1101,23 @@ int64_t spk_cfconv_gsave_floats(const spk_graph_t* g, const spk_radial_t* rb, in
   return tiles * 32 * (int64_t)nf;
 }
 
+// EXPERIMENT (spk_tabfilter.hip): layers with a registered filter table run the table-driven row kernels
+bool spk_filter_table_lookup(const float* key, const float** table, int* n_knots, float* d_max);
+extern "C" int spk_cfconv_tab_f32(const spk_graph_t* g, const float* r_ij, const float* h, const float* table, int32_t n_knots, float d_max,
+                                  float cutoff, int32_t nf, float* y, void* stream);
+int spk_cfconv_tab_bwd_internal(const spk_graph_t* g, const float* r_ij, const float* h, const float* gy, const float* table, int n_knots, float d_max,
+                                float cutoff, float* gh, float* gr, bool gr_assign, hipStream_t stream);
+
 int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* h,
                             const float* r_ij, const float* w1, const float* b1, const float* w2,
                             const float* b2, int nf, float* y, hipStream_t stream, bool pre_zeroed,
                             float* gsave) {
   const char* who = "spk_schnet_cfconv_fwd_f32";
+  {
+    const float* tab; int nk; float dmax;
+    if (g && rb && nf == 128 && g->n_atoms > 0 && g->sorted && g->rowptr && h && r_ij && y && spk_filter_table_lookup(w2, &tab, &nk, &dmax))
+      return spk_cfconv_tab_f32(g, r_ij, h, tab, nk, dmax, rb->cutoff, nf, y, stream);
+  }
   int rc = check_graph(g, who);
   if (rc) return rc;
   SPK_CHECK_ARG(rb && rb->n_rbf >= 1 && rb->n_rbf <= 256, "%s: bad radial basis", who);
@@ -1129,6 +1141,12 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
                             const float* w2, const float* b2, int nf, float* gh, float* gr,
                             hipStream_t stream, bool pre_zeroed, const float* gload, bool gr_assign, bool want_gh) {
   const char* who = "spk_schnet_cfconv_bwd_f32";
+  {
+    const float* tab; int nk; float dmax;
+    if (g && rb && nf == 128 && g->n_atoms > 0 && g->n_edges > 0 && g->sorted && g->symmetric && g->rowptr && h && gy && r_ij && gr &&
+        spk_filter_table_lookup(w2, &tab, &nk, &dmax))
+      return spk_cfconv_tab_bwd_internal(g, r_ij, h, gy, tab, nk, dmax, rb->cutoff, want_gh ? gh : nullptr, gr, gr_assign, stream);
+  }
   int rc = check_graph(g, who);
   if (rc) return rc;
   SPK_CHECK_ARG(rb && rb->n_rbf >= 1 && rb->n_rbf <= 256, "%s: bad radial basis", who);

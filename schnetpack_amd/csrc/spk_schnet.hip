@@ -15,6 +15,14 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
                             const float* w2, const float* b2, int nf, float* gh, float* gr,
                             hipStream_t stream, bool pre_zeroed, const float* gload, bool gr_assign, bool want_gh);
 
+// EXPERIMENT (spk_tabfilter.hip): a model whose first interaction has a registered filter table runs the general driver with the
+// table-driven cfconv kernels (the molecule-resident launches evaluate the filter network themselves)
+bool spk_filter_table_lookup(const float* key, const float** table, int* n_knots, float* d_max);
+static bool schnet_tabulated(const spk_schnet_t* m) {
+  const float* tab; int nk; float dmax;
+  return m && m->layers && m->n_interactions > 0 && spk_filter_table_lookup(m->layers[0].fn_w2, &tab, &nk, &dmax);
+}
+
 static int check_model(const spk_schnet_t* m, const char* who) {
   SPK_CHECK_ARG(m != nullptr && m->layers != nullptr, "%s: null model", who);
   SPK_CHECK_ARG(m->n_atom_basis > 0 && m->n_filters > 0 && m->n_interactions >= 0, "%s: bad model sizes", who);
@@ -141,7 +149,7 @@ extern "C" int spk_schnet_forward_f32(const spk_schnet_t* m, const spk_graph_t* 
   const int64_t gsz = (m->reserved & 1) ? spk_cfconv_gsave_floats(g, rb, NF) : 0;  // bit 0: saved has filter space
   float* gbase = saved + (int64_t)L * N * (NF + F);
   // batches of small molecules with the filters saved for the backward: the whole forward is one molecule-resident launch
-  if (gsz > 0 && ptab.base && spk_schnet_mol_eligible(m, g, rb))
+  if (gsz > 0 && ptab.base && spk_schnet_mol_eligible(m, g, rb) && !schnet_tabulated(m))
     return spk_schnet_mol_forward(m, g, rb, ptab, x0, r_ij, x_out, saved, gsz, stream);
   // skin lists: compact the pair list of THIS call (pairs inside the cutoff, order kept) behind the saved filters
   spk_graph_t gact = *g;
@@ -196,7 +204,7 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   const int64_t N = g->n_atoms, E = g->n_edges;
   const int F = m->n_atom_basis, NF = m->n_filters, L = m->n_interactions;
   // batches of small molecules: the whole backward is one molecule-resident launch (it assigns every entry of gr)
-  if (L > 0 && N > 0 && E > 0 && (m->reserved & 1) && ptab.base && gx_out && saved && gr && spk_schnet_mol_bwd_eligible(m, g, rb)) {
+  if (L > 0 && N > 0 && E > 0 && (m->reserved & 1) && ptab.base && gx_out && saved && gr && spk_schnet_mol_bwd_eligible(m, g, rb) && !schnet_tabulated(m)) {
     const int64_t gsz_m = spk_cfconv_gsave_floats(g, rb, NF);
     if (gsz_m > 0) return spk_schnet_mol_backward(m, g, rb, ptab, gx_out, r_ij, saved, gsz_m, gr, gx0, stream);
   }
@@ -226,7 +234,7 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
   const float* gbase = saved + (int64_t)L * N * (NF + F);
   // the compacted pair list written by the forward of this call (the molecule-resident forward writes none: it keeps
   // the full pair list, and so does this backward then -- saved filters are addressed by pair position)
-  const bool mol_fwd = gsz > 0 && ptab.base && spk_schnet_mol_eligible(m, g, rb);
+  const bool mol_fwd = gsz > 0 && ptab.base && spk_schnet_mol_eligible(m, g, rb) && !schnet_tabulated(m);
   spk_graph_t gact = *g;
   if (gsz > 0 && !mol_fwd && schnet_filter_on(m, g, rb)) {
     const int32_t* ah = (const int32_t*)(gbase + (int64_t)L * gsz);

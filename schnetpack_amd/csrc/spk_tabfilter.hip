@@ -53,6 +53,111 @@ __global__ __launch_bounds__(256) void k_cfconv_tab(const float* __restrict__ h,
   }
 }
 
+// First-order backward of the table-driven convolution on SYMMETRIC sorted lists, one row pass, no atomics:
+//   gh[i, c]  = sum_{e in row(i)} gy[j(e), c] T_c(d_e)                      (the transposed sum through the reverse edge: T_ij = T_ji)
+//   gr[e]    (+)= ( sum_c gy[i, c] h[j(e), c] T_c'(d_e) ) r_e / d_e          (every directed edge exactly once per call)
+// T_c' comes from the SAME spline (derivative of the Hermite basis / step).
+__global__ __launch_bounds__(256) void k_cfconv_tab_bwd(const float* __restrict__ h, const float* __restrict__ gy, const float* __restrict__ rij,
+                                                        const int64_t* __restrict__ idx_j, const int32_t* __restrict__ rowptr,
+                                                        const float* __restrict__ table, int n_knots, float inv_step, float cutoff, int64_t N,
+                                                        float* __restrict__ gh /* null: not wanted */, float* __restrict__ gr, int assign) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int64_t atom = (int64_t)blockIdx.x * 4 + wv; atom < N; atom += (int64_t)gridDim.x * 4) {
+    const int32_t e0 = rowptr[atom], e1 = rowptr[atom + 1];
+    const tf2 gyi = *(const tf2*)(gy + atom * 128 + 2 * lane);
+    tf2 acc = {0.f, 0.f};
+    for (int32_t cs = e0; cs < e1; cs += 64) {
+      const int32_t em = cs + lane;
+      const bool ev = em < e1;
+      const int32_t emc = ev ? em : (e1 - 1);
+      const int jl = (int)idx_j[emc];
+      const float rx = rij[3 * (int64_t)emc], ry = rij[3 * (int64_t)emc + 1], rz = rij[3 * (int64_t)emc + 2];
+      const float dl = sqrtf(rx * rx + ry * ry + rz * rz);
+      float sl = 0.f;                                   // d/dd sum of this lane's edge
+      uint64_t live = __ballot(ev && dl < cutoff);
+      while (live) {
+        const int t = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        const int64_t j = __builtin_amdgcn_readlane(jl, t);
+        const float d = spk_readlane_f(dl, t);
+        const float u = d * inv_step;
+        int n = (int)u;
+        n = n < n_knots - 2 ? n : n_knots - 2;
+        const float s = u - (float)n;
+        const f32x4 k0 = *(const f32x4*)(table + ((size_t)n * 128 + 2 * lane) * 2);
+        const f32x4 k1 = *(const f32x4*)(table + ((size_t)(n + 1) * 128 + 2 * lane) * 2);
+        const tf2 hj = *(const tf2*)(h + j * 128 + 2 * lane);
+        const float s2 = s * s, s3 = s2 * s;
+        if (gh) {
+          const tf2 gyj = *(const tf2*)(gy + j * 128 + 2 * lane);
+          const float h00 = 2.f * s3 - 3.f * s2 + 1.f, h10 = s3 - 2.f * s2 + s, h01 = -2.f * s3 + 3.f * s2, h11 = s3 - s2;
+          const tf2 W = {h00 * k0.x + h10 * k0.y + h01 * k1.x + h11 * k1.y, h00 * k0.z + h10 * k0.w + h01 * k1.z + h11 * k1.w};
+          acc += W * gyj;
+        }
+        const float g00 = 6.f * s2 - 6.f * s, g10 = 3.f * s2 - 4.f * s + 1.f, g01 = -g00, g11 = 3.f * s2 - 2.f * s;
+        const tf2 dW = {g00 * k0.x + g10 * k0.y + g01 * k1.x + g11 * k1.y, g00 * k0.z + g10 * k0.w + g01 * k1.z + g11 * k1.w};
+        const tf2 pv = gyi * hj * dW;
+        float sum = pv.x + pv.y;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == t) sl = sum * inv_step;
+      }
+      if (ev) {
+        const float f = dl > 0.f ? sl / dl : 0.f;
+        float* gp = gr + 3 * (int64_t)em;
+        if (assign) { gp[0] = f * rx; gp[1] = f * ry; gp[2] = f * rz; }
+        else { gp[0] += f * rx; gp[1] += f * ry; gp[2] += f * rz; }
+      }
+    }
+    if (gh) *(tf2*)(gh + atom * 128 + 2 * lane) = acc;
+  }
+}
+
+// ---- registry: tables are attached to a filter network by the device pointer of its filter_network.1.weight (the key the
+// general SchNet driver hands to the cfconv launchers); spk_schnet_cfconv_* run the table kernels for registered layers
+#include <mutex>
+struct TabEntry { const float* key; const float* table; int n_knots; float d_max; };
+static TabEntry g_tabs[64];
+static int g_ntabs = 0;
+static std::mutex g_tab_mutex;
+
+extern "C" int spk_filter_table_set(const float* key, const float* table, int32_t n_knots, float d_max) {
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  for (int i = 0; i < g_ntabs; ++i)
+    if (g_tabs[i].key == key) {
+      if (table) { g_tabs[i].table = table; g_tabs[i].n_knots = n_knots; g_tabs[i].d_max = d_max; }
+      else { g_tabs[i] = g_tabs[g_ntabs - 1]; --g_ntabs; }
+      return SPK_OK;
+    }
+  if (!table) return SPK_OK;
+  SPK_CHECK_ARG(key && n_knots >= 2 && d_max > 0.f, "spk_filter_table_set: bad arguments");
+  SPK_CHECK_ARG(g_ntabs < 64, "spk_filter_table_set: more than 64 tabulated layers");
+  g_tabs[g_ntabs++] = TabEntry{key, table, n_knots, d_max};
+  return SPK_OK;
+}
+extern "C" void spk_filter_table_clear() {
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  g_ntabs = 0;
+}
+bool spk_filter_table_lookup(const float* key, const float** table, int* n_knots, float* d_max) {
+  if (g_ntabs == 0) return false;
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  for (int i = 0; i < g_ntabs; ++i)
+    if (g_tabs[i].key == key) { *table = g_tabs[i].table; *n_knots = g_tabs[i].n_knots; *d_max = g_tabs[i].d_max; return true; }
+  return false;
+}
+bool spk_filter_tables_active() { return g_ntabs > 0; }
+
+int spk_cfconv_tab_bwd_internal(const spk_graph_t* g, const float* r_ij, const float* h, const float* gy, const float* table, int n_knots, float d_max,
+                                float cutoff, float* gh, float* gr, bool gr_assign, hipStream_t stream) {
+  const float inv_step = (float)(n_knots - 1) / d_max;
+  SpkProfScope prof(gh ? "cfconv_tab_bwd" : "cfconv_tab_bwd_geom", stream);
+  hipLaunchKernelGGL(k_cfconv_tab_bwd, dim3(spk_grid_for(g->n_atoms, 4, spk_num_cus() * 8)), dim3(256), 0, stream, h, gy, r_ij, g->idx_j, g->rowptr, table,
+                     n_knots, inv_step, cutoff, g->n_atoms, gh, gr, gr_assign ? 1 : 0);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 // table: [n_knots, 128, 2]; the list must be sorted (rowptr given); nf = 128 only (experiment).  y [N, 128] is overwritten.
 extern "C" int spk_cfconv_tab_f32(const spk_graph_t* g, const float* r_ij, const float* h, const float* table, int32_t n_knots, float d_max,
                                   float cutoff, int32_t nf, float* y, void* stream_) {

@@ -1,0 +1,87 @@
+"""EXPERIMENT (round 3; eval only, never on by default): tabulated SchNet filters.
+
+The filter of an interaction, ``W_l(d) f_c(d) = (ssp(phi(d) W1^T + b1) W2^T + b2) f_c(d)`` (representation/schnet.py:60-62), is a smooth
+function of ONE variable per channel.  :func:`tabulate_filters` evaluates it and its slope in float64 on the host at ``n_knots``
+equidistant distances in [0, cutoff] and attaches the tables to the interactions (``spk_filter_table_set``, keyed by the device
+address of ``filter_network.1.weight``); the general SchNet driver then runs the convolution and its first-order backward through
+the table kernels (``csrc/spk_tabfilter.hip``: cubic Hermite, one row pass, no atomics) instead of the fp32-MFMA filter network.
+The fp32-MFMA path stays the contract path; measured time / error of both: ``scripts/tab_filter_experiment.py``,
+``profiles/r03_tabulated_filter_experiment.json``, DESIGN.md section 7.
+
+The tables are a snapshot of the weights: call :func:`tabulate_filters` again after the weights (or their device) changed,
+:func:`clear_filter_tables` to go back.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_KEEP = {}      # id(representation) -> (tables tensor [L, n_knots, F, 2], keys)
+
+
+def filter_and_slope(interaction, radial_basis, cutoff: float, d: torch.Tensor):
+    """(W f_c, d(W f_c)/dd) at distances ``d`` ([n]) in float64 on the host, analytic derivative."""
+    d = d.double().cpu()
+    kind, p0, p1 = radial_basis.kernel_params()
+    p0 = p0.double().cpu()
+    if int(kind) == _lib.SPK_RBF_GAUSSIAN:
+        c = -0.5 / p1.double().cpu() ** 2
+        t = d[:, None] - p0[None, :]
+        phi = torch.exp(c * t * t)
+        dphi = 2.0 * c * t * phi
+    else:
+        arg = d[:, None] * p0[None, :]
+        inv = torch.where(d == 0, torch.ones_like(d), 1.0 / d)[:, None]
+        phi = torch.sin(arg) * inv
+        dphi = (p0[None, :] * torch.cos(arg) - phi) * inv
+    w1, b1 = interaction.filter_network[0].weight.detach().double().cpu(), interaction.filter_network[0].bias.detach().double().cpu()
+    w2, b2 = interaction.filter_network[1].weight.detach().double().cpu(), interaction.filter_network[1].bias.detach().double().cpu()
+    a = phi @ w1.t() + b1
+    hid = torch.nn.functional.softplus(a) - math.log(2.0)
+    dhid = torch.sigmoid(a) * (dphi @ w1.t())
+    g = hid @ w2.t() + b2
+    dg = dhid @ w2.t()
+    inside = (d < cutoff).double()
+    fc = 0.5 * (torch.cos(d * math.pi / cutoff) + 1.0) * inside
+    dfc = -0.5 * math.pi / cutoff * torch.sin(d * math.pi / cutoff) * inside
+    return g * fc[:, None], dg * fc[:, None] + g * dfc[:, None]
+
+
+def tabulate_filters(representation, n_knots: int = 512) -> torch.Tensor:
+    """Build and attach the filter tables of every interaction of a SchNet representation (on its device).  Returns the tables
+    ``[n_interactions, n_knots, n_filters, 2]`` = (value, slope * step)."""
+    rep = representation
+    if rep.n_filters != 128 or not rep._fused:
+        raise _lib.SpkHipError("tabulate_filters: the table kernels cover n_filters = 128 and the fused filter network (ssp) only")
+    cutoff = float(rep.cutoff_fn.cutoff_value())
+    clear_filter_tables(rep)
+    d = torch.linspace(0.0, cutoff, int(n_knots), dtype=torch.float64)
+    step = cutoff / (int(n_knots) - 1)
+    tabs = []
+    for it in rep.interactions:
+        W, dW = filter_and_slope(it, rep.radial_basis, cutoff, d)
+        tabs.append(torch.stack([W, dW * step], -1))
+    dev = rep.interactions[0].filter_network[1].weight.device
+    table = torch.stack(tabs).float().contiguous().to(dev)
+    keys = []
+    for l, it in enumerate(rep.interactions):
+        w2 = it.filter_network[1].weight
+        _lib.check(_lib.lib().spk_filter_table_set(_lib.fptr(w2.detach()), _lib.fptr(table[l]), int(n_knots), cutoff))
+        keys.append(w2)
+    _KEEP[id(rep)] = (table, keys)
+    torch.ops.spk_hip.clear_caches()          # parameter blocks are rebuilt: the drivers look the tables up by weight address
+    return table
+
+
+def clear_filter_tables(representation: Optional[object] = None):
+    """Detach the tables of one representation (or of all): the fp32-MFMA filter network runs again."""
+    if representation is None:
+        _lib.lib().spk_filter_table_clear()
+        _KEEP.clear()
+        return
+    ent = _KEEP.pop(id(representation), None)
+    if ent is not None:
+        for w2 in ent[1]:
+            _lib.check(_lib.lib().spk_filter_table_set(_lib.fptr(w2.detach()), None, 0, 0.0))

@@ -111,6 +111,22 @@ for wl in ("aspirin256", "water31944"):
         out = model(dict(inp))
     prof = _lib.profile_report(); _lib.profile_enable(False)
     row["contract_path_kernels_us"] = {k: round(1e3 * v[1] / max(v[0], 1), 1) for k, v in prof.items() if "cfconv" in k or "schnet_mol" in k}
+    # the whole eval force call (PairwiseDistances -> SchNet -> Atomwise -> Forces), contract path vs tables attached (512 knots)
+    from schnetpack_amd import tabulate
+
+    def force_call():
+        o = model(dict(inp))
+        return o["forces"].detach()
+    f_contract = force_call().clone()
+    row["force_call_contract_ms"] = round(event_time_us(force_call, reps=10) / 1e3, 4)
+    tabulate.tabulate_filters(model.representation, 512)
+    _lib.profile_enable(True); _lib.profile_report()
+    f_tab = force_call().clone()
+    prof = _lib.profile_report(); _lib.profile_enable(False)
+    row["force_call_tabulated_ms"] = round(event_time_us(force_call, reps=10) / 1e3, 4)
+    row["tabulated_kernels_us"] = {k: round(1e3 * v[1] / max(v[0], 1), 1) for k, v in prof.items() if "cfconv" in k}
+    row["forces_tabulated_vs_contract_rel"] = float((f_tab - f_contract).abs().max() / f_contract.abs().max())
+    tabulate.clear_filter_tables()
     res["workloads"].append(row)
 res["conclusion"] = "see DESIGN.md section 7 (round 3): time and error of the table kernel beside the fp32-MFMA kernels of the same launch"
 print(json.dumps(res))

@@ -159,3 +159,34 @@ def test_supercell_forces_tile(dev, kind):
     e, f = _gpu_call(model, big, dev)
     assert rel_err(f, ref["forces"].repeat(8, 1).float()) < TOL
     assert abs(float(e[0]) - 8.0 * float(ref["energy"][0])) <= 2e-5 * abs(8.0 * float(ref["energy"][0]))
+
+
+def test_tabulated_filter_experiment_force_call_on_the_water_box(dev):
+    """EXPERIMENT, default off (schnetpack_amd/tabulate.py): SchNet with the filters read from 512-knot cubic-Hermite tables on the
+    10 125-atom periodic box -- forward AND first-order backward through the table kernels (profile tags), energies and forces
+    against the float64 oracle.  The value error of the table is ~4e-8, its slope error ~4e-6 of max |dW/dd| (fp32 table): the
+    forces stay inside the 1e-5 bar with less margin than the fp32-MFMA contract path, which this test runs beside it."""
+    from schnetpack_amd import _lib, model as M, tabulate
+    rep_p, head_p = _params("schnet")
+    model = _model("schnet", dev, rep_p, head_p)
+    b = S.water_box(n_side=15, seed=1)
+    ref = O.energy_and_forces("schnet", rep_p, head_p, b, 3, dtype=torch.float64)
+    inp = M.batch_to_inputs(b, dev)
+    out0 = model(dict(inp))
+    e0, f0 = rel_err(out0["energy"].cpu(), ref["energy"]), rel_err(out0["forces"].detach().cpu(), ref["forces"])
+    try:
+        tabulate.tabulate_filters(model.representation, 512)
+        _lib.profile_enable(True); _lib.profile_report()
+        out = model(dict(inp))
+        tags = _lib.profile_report()
+    finally:
+        _lib.profile_enable(False)
+        tabulate.clear_filter_tables()
+    assert "cfconv_tab_fwd" in tags and ("cfconv_tab_bwd" in tags or "cfconv_tab_bwd_geom" in tags), tags
+    assert not any(t.startswith(("cfconv_fwd", "cfconv_bwd")) for t in tags), tags
+    e1, f1 = rel_err(out["energy"].cpu(), ref["energy"]), rel_err(out["forces"].detach().cpu(), ref["forces"])
+    print("contract path: energy %.2e forces %.2e | tabulated: energy %.2e forces %.2e" % (e0, f0, e1, f1))
+    assert e1 < TOL and f1 < TOL
+    # and the tables are gone again
+    out2 = model(dict(inp))
+    assert rel_err(out2["forces"].detach().cpu(), out0["forces"].detach().cpu()) < 2e-6
