@@ -832,6 +832,45 @@ def main():
             sweep = sweep_measure(model, dev, args.kind)
         except Exception as exc:  # pragma: no cover
             sweep = {"error": str(exc)[:200]}
+    # ---------------- experiment, default OFF in the product: tabulated SchNet filters (schnetpack_amd/tabulate.py) beside the fp32-MFMA
+    # contract path on the 32k-atom water box -- time of the eval force call and agreement of the forces
+    experiments = None
+    if default_line and not args.no_md:
+        try:
+            from schnetpack_amd import tabulate
+            wb = cached_water_box(args.water_side, 0)
+            winp = M.batch_to_inputs(wb, dev)
+
+            def wcall():
+                return model(dict(winp))["forces"].detach()
+
+            def wtime(reps=8):
+                for _ in range(2):
+                    wcall()
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                for _ in range(reps):
+                    wcall()
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - c0) / reps
+            f_c = wcall().clone()
+            ms_c = wtime()
+            tabulate.tabulate_filters(model.representation, 512)
+            try:
+                f_t = wcall().clone()
+                ms_t = wtime()
+            finally:
+                tabulate.clear_filter_tables()
+            Ew = int(wb["idx_i"].shape[0])
+            experiments = {"tabulated_filters": {
+                "what": "EXPERIMENT (opt-in, eval only): W_l(d) f_c(d) from 512-knot cubic-Hermite tables (value + slope, float64 build) instead of the filter "
+                        "network; eval force call of SchNet(128, 3, 20, 5.0) on the %d-atom water box (E = %d), eager launches" % (int(wb["Z"].shape[0]), Ew),
+                "contract_path_ms": round(ms_c, 4), "tabulated_ms": round(ms_t, 4),
+                "contract_M_edge_messages_per_s": round(Ew * 3 / ms_c / 1e3, 1), "tabulated_M_edge_messages_per_s": round(Ew * 3 / ms_t / 1e3, 1),
+                "forces_rel_diff_tabulated_vs_contract": float((f_t - f_c).abs().max() / f_c.abs().max()),
+                "note": "the contract (fp32 MFMA) path is what every headline number of this line runs; table error: value ~4e-8, slope ~4e-6 of max |dW/dd| (fp32 table)"}}
+        except Exception as exc:  # pragma: no cover
+            experiments = {"tabulated_filters": {"error": str(exc)[:300]}}
     drop_in = None
     if default_line and not args.no_drop_in and not args.no_cpu_baseline:
         drop_in = drop_in_measure(args, dev, rep_p, head_p, batch, r["f_ref"])
@@ -851,7 +890,7 @@ def main():
                    "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                    "world_size": world, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
                    "hip_graph": r["graph"], "variant": args.variant, "compute_units": info["compute_units"]},
-        "roofline": roofline, "cpu_baseline": cpu, "painn": painn, "train": train, "md": md, "sweep": sweep, "drop_in": drop_in,
+        "roofline": roofline, "cpu_baseline": cpu, "painn": painn, "train": train, "md": md, "sweep": sweep, "drop_in": drop_in, "experiments": experiments,
         "kernels": kernels, "scatter_add": scatter, "neighbor_list": nbl,
     }
     print(json.dumps(line))

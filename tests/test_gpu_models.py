@@ -432,3 +432,26 @@ def test_dense_cluster_rows_longer_than_a_wavefront(dev, kind):
     ref = O.energy_and_forces(kind, rep_p, head_p, b, 3)
     assert rel_err(out["energy"].detach().cpu(), ref["energy"]) < TOL
     assert rel_err(out["forces"].detach().cpu(), ref["forces"]) < 2 * TOL
+
+
+@pytest.mark.parametrize("case", [c for c in MODEL_CASES if c.startswith("schnet")])
+def test_tabulated_filter_experiment_matches_reference_goldens(dev, case):
+    """EXPERIMENT, default off (schnetpack_amd/tabulate.py): every SchNet fixture generated from the reference -- Gaussian and Bessel
+    bases, a list with pairs beyond the cutoff, the periodic box, 3 and 6 interactions -- through the table-driven convolution
+    kernels (512 knots): energies, forces and representation inside the 1e-5 bar, the table kernels ran (profile tags)."""
+    from schnetpack_amd import _lib, tabulate
+    batch, ref, meta = load_golden(case)
+    rep_p, head_p = golden_params(meta)
+    model = _build(meta, dev, rep_p, head_p).eval()
+    try:
+        tabulate.tabulate_filters(model.representation, 512)
+        _lib.profile_enable(True); _lib.profile_report()
+        out = _force_call(model, batch, dev)
+        tags = _lib.profile_report()
+    finally:
+        _lib.profile_enable(False)
+        tabulate.clear_filter_tables()
+    assert "cfconv_tab_fwd" in tags and not any(t.startswith(("cfconv_fwd", "cfconv_bwd", "schnet_mol")) for t in tags), tags
+    assert rel_err(out["energy"], ref["energy"]) < TOL
+    assert rel_err(out["forces"], ref["forces"]) < TOL
+    assert rel_err(out["scalar_representation"], ref["scalar_representation"]) < TOL
