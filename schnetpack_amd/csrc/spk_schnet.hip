@@ -286,6 +286,7 @@ extern "C" int spk_schnet_backward_f32(const spk_schnet_t* m, const spk_graph_t*
 // (atomistic/distances.py:14-26, representation/schnet.py:147-173, atomistic/atomwise.py:69-88, atomistic/response.py:59-76).
 static bool potential_ok(const spk_schnet_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb) {
   if (!m || !head || !g || !rb || !m->layers || m->n_interactions <= 0 || !(m->reserved & 1)) return false;
+  if (schnet_tabulated(m)) return false;          // (experiment) registered filter tables: the stage-by-stage path runs the table kernels
   if (!m->wpack || !schnet_pack_shapes_ok(m)) return false;
   if (!head->w1 || !head->w1t || !head->b1 || !head->w2 || head->n_hidden < 32 || head->n_hidden > 128 || head->n_hidden % 32) return false;
   if (head->act != SPK_ACT_SSP && head->act != SPK_ACT_SILU) return false;
