@@ -57,7 +57,9 @@ template <> struct MsgVec<2> {
 
 // GEOM (backward only): form the geometry gradient gr alone -- no neighbour gradients are gathered, no gc / gmu
 // MU0: mu == 0 everywhere (first interaction): the mu rows of the neighbours are not gathered
-template <int VPL, int NRBF, bool BWD, bool GEOM = false, bool MU0 = false>
+// TAB (experiment, opt-in): the raw filter and its slope come from a cubic-Hermite table (two 16-byte reads per part and
+// knot for the lane's two channels) instead of NRBF FMAs per channel from register-resident weights (which are then not loaded)
+template <int VPL, int NRBF, bool BWD, bool GEOM = false, bool MU0 = false, bool TAB = false>
 __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
   typedef MsgVec<VPL> MV;
   typedef typename MV::T VT;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
   // [3F, K] is read once per workgroup with coalesced loads into a transposed, padded LDS image
   // (conflict-free writes), from which every lane picks its rows.
   extern __shared__ __attribute__((aligned(16))) float swf[];   // [K][3F + 1]
-  {
+  if (!TAB) {
     const int ld = 3 * F + 1;
     for (int s = threadIdx.x; s < 3 * F * K; s += 256) {
       const int row = s / K, k = s - row * K;
@@ -76,10 +78,10 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
     }
     __syncthreads();
   }
-  VT w[3][NRBF];
+  VT w[3][TAB ? 1 : NRBF];
   VT bias[3];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
+  for (int p = 0; p < 3 && !TAB; ++p) {
     float tb[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) tb[v] = a.bf[p * F + VPL * lane + v];
@@ -154,13 +156,37 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
             const float d = spk_readlane_f(dl, t);
             const float ux = spk_readlane_f(uxl, t), uy = spk_readlane_f(uyl, t), uz = spk_readlane_f(uzl, t);
             const float fc = spk_readlane_f(fcl, t), dfc = spk_readlane_f(dfcl, t);
+            VT P[3], Pd[3] = {MV::zero(), MV::zero(), MV::zero()};
+            if (TAB) {
+              // raw filter and slope of the lane's channels from the table: knots n, n + 1 of [n_knots][3F][2]
+              const float u = d * a.tab_inv_step;
+              int n = (int)u;
+              n = n < a.tab_knots - 2 ? n : a.tab_knots - 2;
+              const float sx = u - (float)n, s2 = sx * sx, s3 = s2 * sx;
+              const float h00 = 2.f * s3 - 3.f * s2 + 1.f, h10 = s3 - 2.f * s2 + sx, h01 = -2.f * s3 + 3.f * s2, h11 = s3 - s2;
+              const float g00 = (6.f * s2 - 6.f * sx) * a.tab_inv_step, g10 = (3.f * s2 - 4.f * sx + 1.f) * a.tab_inv_step, g01 = -g00,
+                          g11 = (3.f * s2 - 2.f * sx) * a.tab_inv_step;
+              const float* t0 = a.tab + ((size_t)n * 3 * F + fo) * 2;
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                if (MU0 && p == 2) { P[p] = MV::zero(); continue; }
+                float pv[VPL], pdv[VPL];
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                  const f32x2 k0 = *(const f32x2*)(t0 + (size_t)(p * F + v) * 2), k1 = *(const f32x2*)(t0 + ((size_t)3 * F + p * F + v) * 2);
+                  pv[v] = h00 * k0.x + h10 * k0.y + h01 * k1.x + h11 * k1.y;
+                  pdv[v] = g00 * k0.x + g10 * k0.y + g01 * k1.x + g11 * k1.y;
+                }
+                P[p] = MV::load(pv);
+                if (BWD) Pd[p] = MV::load(pdv);
+              }
+            } else {
             // lane k evaluates phi_k(d)
             float pl, dpl;
             spk_rbf_eval(a.rb, lane, d, pl, dpl);
-            VT P[3] = {bias[0], bias[1], bias[2]};
-            VT Pd[3] = {MV::zero(), MV::zero(), MV::zero()};
+            P[0] = bias[0]; P[1] = bias[1]; P[2] = bias[2];
 #pragma unroll
-            for (int k = 0; k < NRBF; ++k) {
+            for (int k = 0; k < (TAB ? 1 : NRBF); ++k) {
               const float s = spk_readlane_f(pl, k);
               const float sd = BWD ? spk_readlane_f(dpl, k) : 0.f;
 #pragma unroll
@@ -168,6 +194,7 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
                 P[p] = w[p][k] * s + P[p];
                 if (BWD) Pd[p] = w[p][k] * sd + Pd[p];
               }
+            }
             }
             if (!BWD) {
               const VT mq = P[0] * fc * cjr[par][0];
@@ -329,11 +356,29 @@ static int check_msg(const spk_graph_t* g, const spk_radial_t* rb, int F, const 
   return SPK_OK;
 }
 
+// EXPERIMENT (spk_tabfilter.hip): filter tables attached to an interaction by the address of its filter rows
+bool spk_filter_table_lookup(const float* key, const float** table, int* n_knots, float* d_max);
+
 template <bool BWD>
-static int msg_dispatch(const MsgArgs& a, bool row_ok, hipStream_t stream, const char* who) {
+static int msg_dispatch(const MsgArgs& a_in, bool row_ok, hipStream_t stream, const char* who) {
   const int variant = spk_get_variant();
+  MsgArgs a = a_in;
   const int F = a.F, K = a.rb.n_rbf;
   const bool shape_ok = row_ok && (F == 64 || F == 128) && K <= 32;
+  {
+    const float* tab; int nk; float dmax;
+    if (shape_ok && F == 128 && variant != SPK_VARIANT_SIMPLE && spk_filter_table_lookup(a.wf, &tab, &nk, &dmax)) {
+      a.tab = tab; a.tab_knots = nk; a.tab_inv_step = (float)(nk - 1) / dmax;
+      const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 4);
+      SpkProfScope prof(BWD ? (a.geom_only ? "painn_msg_bwd_tab_geom" : "painn_msg_bwd_tab") : (a.mu_zero ? "painn_msg_fwd_tab_mu0" : "painn_msg_fwd_tab"), stream);
+      if (BWD && a.geom_only && a.mu_zero) hipLaunchKernelGGL((k_painn_msg_row<2, 20, BWD, BWD, true, true>), dim3(grid), dim3(256), 0, stream, a);
+      else if (BWD && a.geom_only) hipLaunchKernelGGL((k_painn_msg_row<2, 20, BWD, BWD, false, true>), dim3(grid), dim3(256), 0, stream, a);
+      else if (!BWD && a.mu_zero) hipLaunchKernelGGL((k_painn_msg_row<2, 20, BWD, false, !BWD, true>), dim3(grid), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((k_painn_msg_row<2, 20, BWD, false, false, true>), dim3(grid), dim3(256), 0, stream, a);
+      SPK_LAUNCH_CHECK();
+      return SPK_OK;
+    }
+  }
   SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || shape_ok, "%s: shape F=%d n_rbf=%d (or unsorted/asymmetric list) not supported by the row kernel", who, F, K);
   if (!BWD && shape_ok && variant != SPK_VARIANT_SIMPLE && spk_painn_msg_tile_ok(a)) {
     // forward on large lists: filter GEMM on the matrix cores, 32-edge tiles (spk_painn_tile.hip); the profile scope
@@ -1162,6 +1207,11 @@ bool spk_painn_mol_bwd_eligible(const spk_painn_t* m, const spk_graph_t* g, cons
 int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
                            const float* gmu_out, const float* r_ij, const float* saved, float* gc_scratch, float* gr, float* gq0, hipStream_t stream);
 
+static bool painn_tabulated(const spk_painn_t* m) {
+  const float* tab; int nk; float dmax;
+  return m && m->layers && m->n_interactions > 0 && spk_filter_table_lookup(m->layers[0].filt_w, &tab, &nk, &dmax);
+}
+
 // per layer saved for backward: preA [F] | c [3F] | mu_in [3F] | mix [6F] | preB [F] | a [3F]
 static inline int64_t painn_saved_per_atom(int F) { return 17 * (int64_t)F; }
 
@@ -1192,7 +1242,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
     { int _zr = spk_zero_async(mu_out, 3 * nf * sizeof(float), stream); if (_zr) return _zr; }
     return SPK_OK;
   }
-  if (ptab.base && r_ij && !getenv("SPK_NO_PAINN_MOL_FWD") && spk_painn_mol_eligible(m, g, rb))      // batches of small molecules: the whole forward is ONE launch
+  if (ptab.base && r_ij && !getenv("SPK_NO_PAINN_MOL_FWD") && !painn_tabulated(m) && spk_painn_mol_eligible(m, g, rb))      // batches of small molecules: the whole forward is ONE launch
     return spk_painn_mol_forward(m, g, rb, ptab, q0, r_ij, q_out, mu_out, saved, stream);
   float* c1 = scratch;            // [N,F]
   float* q1 = c1 + nf;            // [N,F]
@@ -1259,7 +1309,7 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
   const SpkPackTable ptab = (m->wpack && painn_pack_shapes_ok(m)) ? painn_pack_table(m) : SpkPackTable();
   const int64_t N = g->n_atoms, E = g->n_edges;
   const int F = m->n_atom_basis, L = m->n_interactions;
-  if (N > 0 && E > 0 && L > 0 && gr && r_ij && saved && scratch && (gq_out || gmu_out) && ptab.base && spk_painn_mol_bwd_eligible(m, g, rb))
+  if (N > 0 && E > 0 && L > 0 && gr && r_ij && saved && scratch && (gq_out || gmu_out) && ptab.base && !painn_tabulated(m) && spk_painn_mol_bwd_eligible(m, g, rb))
     return spk_painn_mol_backward(m, g, rb, ptab, gq_out, gmu_out, r_ij, saved, scratch, gr, gq0, stream);      // ONE launch, every gr entry written once
   if (E > 0) {
     SPK_CHECK_ARG(gr != nullptr, "%s: null gr", who);

@@ -27,6 +27,11 @@ struct MsgArgs {
   int mu_zero;        // mu is known to be all zeros (first interaction, painn.py:246): its rows are not gathered
   int geom_only;      // bwd: only gr is wanted (first interaction of an eval-mode backward): gc / gmu are not formed
   RadialDev rb;
+  // EXPERIMENT (spk_tabfilter.hip, opt-in): the raw filter phi(d) W_f^T + b_f of this interaction from a cubic-Hermite table
+  // [n_knots][3F][2] = (value, slope * step) instead of the n_rbf FMAs per channel; null = off
+  const float* tab;
+  int tab_knots;
+  float tab_inv_step;
 };
 
 // MFMA tile kernel of the forward message (spk_painn_tile.hip): true if it should run for this shape / list

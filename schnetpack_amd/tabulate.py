@@ -49,14 +49,60 @@ def filter_and_slope(interaction, radial_basis, cutoff: float, d: torch.Tensor):
     return g * fc[:, None], dg * fc[:, None] + g * dfc[:, None]
 
 
+def _basis(radial_basis, d: torch.Tensor):
+    kind, p0, p1 = radial_basis.kernel_params()
+    p0 = p0.double().cpu()
+    if int(kind) == _lib.SPK_RBF_GAUSSIAN:
+        c = -0.5 / p1.double().cpu() ** 2
+        t = d[:, None] - p0[None, :]
+        phi = torch.exp(c * t * t)
+        return phi, 2.0 * c * t * phi
+    arg = d[:, None] * p0[None, :]
+    inv = torch.where(d == 0, torch.ones_like(d), 1.0 / d)[:, None]
+    phi = torch.sin(arg) * inv
+    return phi, (p0[None, :] * torch.cos(arg) - phi) * inv
+
+
+def _tabulate_painn(rep, n_knots: int) -> torch.Tensor:
+    """PaiNN (painn.py:232-236): the RAW filter of an interaction, phi(d) W_f^T + b_f over its 3F rows (the cutoff stays in the
+    kernels), attached to the address of those rows of ``filter_net.weight``."""
+    F = rep.n_atom_basis
+    if F != 128 or not getattr(rep, "_fused", False):
+        raise _lib.SpkHipError("tabulate_filters: the table kernels cover n_atom_basis = 128 and the fused PaiNN path only")
+    cutoff = float(rep.cutoff_fn.cutoff_value())
+    d = torch.linspace(0.0, cutoff, int(n_knots), dtype=torch.float64)
+    step = cutoff / (int(n_knots) - 1)
+    phi, dphi = _basis(rep.radial_basis, d)
+    w, b = rep.filter_net.weight.detach().double().cpu(), rep.filter_net.bias.detach().double().cpu()
+    L = len(rep.interactions)
+    shared = w.shape[0] == 3 * F
+    tabs = []
+    for l in range(L):
+        rows = slice(0, 3 * F) if shared else slice(3 * F * l, 3 * F * (l + 1))
+        tabs.append(torch.stack([phi @ w[rows].t() + b[rows], (dphi @ w[rows].t()) * step], -1))
+    dev = rep.filter_net.weight.device
+    table = torch.stack(tabs).float().contiguous().to(dev)
+    keys = []
+    for l in range(L):
+        rows = slice(0, 3 * F) if shared else slice(3 * F * l, 3 * F * (l + 1))
+        key = rep.filter_net.weight.detach()[rows]
+        _lib.check(_lib.lib().spk_filter_table_set(_lib.fptr(key), _lib.fptr(table[l]), int(n_knots), cutoff))
+        keys.append(key)
+    _KEEP[id(rep)] = (table, keys)
+    torch.ops.spk_hip.clear_caches()
+    return table
+
+
 def tabulate_filters(representation, n_knots: int = 512) -> torch.Tensor:
-    """Build and attach the filter tables of every interaction of a SchNet representation (on its device).  Returns the tables
-    ``[n_interactions, n_knots, n_filters, 2]`` = (value, slope * step)."""
+    """Build and attach the filter tables of every interaction of a SchNet or PaiNN representation (on its device).  Returns the
+    tables ``[n_interactions, n_knots, n_filters (3 n_atom_basis for PaiNN), 2]`` = (value, slope * step)."""
     rep = representation
+    clear_filter_tables(rep)
+    if hasattr(rep, "filter_net"):
+        return _tabulate_painn(rep, n_knots)
     if rep.n_filters != 128 or not rep._fused:
         raise _lib.SpkHipError("tabulate_filters: the table kernels cover n_filters = 128 and the fused filter network (ssp) only")
     cutoff = float(rep.cutoff_fn.cutoff_value())
-    clear_filter_tables(rep)
     d = torch.linspace(0.0, cutoff, int(n_knots), dtype=torch.float64)
     step = cutoff / (int(n_knots) - 1)
     tabs = []

@@ -434,7 +434,7 @@ def test_dense_cluster_rows_longer_than_a_wavefront(dev, kind):
     assert rel_err(out["forces"].detach().cpu(), ref["forces"]) < 2 * TOL
 
 
-@pytest.mark.parametrize("case", [c for c in MODEL_CASES if c.startswith("schnet")])
+@pytest.mark.parametrize("case", [c for c in MODEL_CASES if c != "painn_aspirin_pretrained.npz"] + ["painn_aspirin_pretrained.npz"])
 def test_tabulated_filter_experiment_matches_reference_goldens(dev, case):
     """EXPERIMENT, default off (schnetpack_amd/tabulate.py): every SchNet fixture generated from the reference -- Gaussian and Bessel
     bases, a list with pairs beyond the cutoff, the periodic box, 3 and 6 interactions -- through the table-driven convolution
@@ -451,7 +451,13 @@ def test_tabulated_filter_experiment_matches_reference_goldens(dev, case):
     finally:
         _lib.profile_enable(False)
         tabulate.clear_filter_tables()
-    assert "cfconv_tab_fwd" in tags and not any(t.startswith(("cfconv_fwd", "cfconv_bwd", "schnet_mol")) for t in tags), tags
+    if str(meta["kind"]) == "schnet":
+        assert "cfconv_tab_fwd" in tags and not any(t.startswith(("cfconv_fwd", "cfconv_bwd", "schnet_mol")) for t in tags), tags
+    else:
+        assert any(t.startswith("painn_msg_fwd_tab") for t in tags) and any(t.startswith("painn_msg_bwd_tab") for t in tags), tags
+        assert not any(t.startswith(("painn_msg_fwd_row", "painn_msg_bwd_row", "painn_msg_fwd_tile", "painn_msg_bwd_tile", "painn_mol")) for t in tags), tags
     assert rel_err(out["energy"], ref["energy"]) < TOL
     assert rel_err(out["forces"], ref["forces"]) < TOL
     assert rel_err(out["scalar_representation"], ref["scalar_representation"]) < TOL
+    if "vector_representation" in ref:
+        assert rel_err(out["vector_representation"], ref["vector_representation"]) < TOL
