@@ -261,16 +261,23 @@ __device__ __forceinline__ void ml_dense_load(f32x4 (&av)[16], const float* __re
 #pragma unroll
   for (int u = 0; u < 16; ++u) av[u] = ml_ld<f32x4>(sb, (unsigned)(lane * 16 + u * 1024));
 }
+// (B operands are requested four k-blocks ahead of their MFMAs and pinned there: left alone the compiler issues every ds_read
+//  right in front of the four MFMAs that need it and the matrix pipe waits ~100 cycles per group -- round 3, found on spk_painn_mol.hip)
+#define ML_PIN() asm volatile("" ::: "memory")
 __device__ __forceinline__ f32x16 ml_dense_mma(const f32x4 (&av)[16], const float* __restrict__ sIn, int lane, f32x16 acc) {
   const int hi = lane >> 5, el = lane & 31;
   const float* brow = sIn + el * ML_LD + 4 * hi;
+  f32x4 bv[16];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) bv[u] = *(const f32x4*)(brow + 8 * u);
+  ML_PIN();
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
-    const f32x4 bv = *(const f32x4*)(brow + 8 * u);
-    acc = ML_MFMA(av[u].x, bv.x, acc);
-    acc = ML_MFMA(av[u].y, bv.y, acc);
-    acc = ML_MFMA(av[u].z, bv.z, acc);
-    acc = ML_MFMA(av[u].w, bv.w, acc);
+    acc = ML_MFMA(av[u].x, bv[u].x, acc);
+    acc = ML_MFMA(av[u].y, bv[u].y, acc);
+    acc = ML_MFMA(av[u].z, bv[u].z, acc);
+    acc = ML_MFMA(av[u].w, bv[u].w, acc);
+    if (u + 4 < 16) { bv[u + 4] = *(const f32x4*)(brow + 8 * (u + 4)); ML_PIN(); }
   }
   return acc;
 }
@@ -284,13 +291,17 @@ __device__ __forceinline__ void ml_dense_load8(f32x4 (&av)[8], const float* __re
 __device__ __forceinline__ f32x16 ml_dense_mma8(const f32x4 (&av)[8], const float* __restrict__ sIn, int lane, int half, f32x16 acc) {
   const int hi = lane >> 5, el = lane & 31;
   const float* brow = sIn + el * ML_LD + 4 * hi + 64 * half;
+  f32x4 bv[8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) bv[u] = *(const f32x4*)(brow + 8 * u);
+  ML_PIN();
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const f32x4 bv = *(const f32x4*)(brow + 8 * u);
-    acc = ML_MFMA(av[u].x, bv.x, acc);
-    acc = ML_MFMA(av[u].y, bv.y, acc);
-    acc = ML_MFMA(av[u].z, bv.z, acc);
-    acc = ML_MFMA(av[u].w, bv.w, acc);
+    acc = ML_MFMA(av[u].x, bv[u].x, acc);
+    acc = ML_MFMA(av[u].y, bv[u].y, acc);
+    acc = ML_MFMA(av[u].z, bv[u].z, acc);
+    acc = ML_MFMA(av[u].w, bv[u].w, acc);
+    if (u + 4 < 8) { bv[u + 4] = *(const f32x4*)(brow + 8 * (u + 4)); ML_PIN(); }
   }
   return acc;
 }
@@ -298,16 +309,8 @@ __device__ __forceinline__ f32x16 ml_dense_tile(const float* __restrict__ wp, co
   const int hi = lane >> 5, el = lane & 31;
   f32x4 av[16];
   ml_dense_load(av, wp, t, lane);
-  const float* brow = sIn + el * ML_LD + 4 * hi;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const f32x4 bv = *(const f32x4*)(brow + 8 * u);
-    acc = ML_MFMA(av[u].x, bv.x, acc);
-    acc = ML_MFMA(av[u].y, bv.y, acc);
-    acc = ML_MFMA(av[u].z, bv.z, acc);
-    acc = ML_MFMA(av[u].w, bv.w, acc);
-  }
-  return acc;
+  (void)hi; (void)el;
+  return ml_dense_mma(av, sIn, lane, acc);
 }
 
 // B operand of a Dense half-tile that is the SUM of two LDS tiles (the two teams' partial cfconv outputs)
@@ -315,13 +318,17 @@ __device__ __forceinline__ f32x16 ml_dense_mma8_sum(const f32x4 (&av)[8], const 
                                                     f32x16 acc) {
   const int hi = lane >> 5, el = lane & 31;
   const int off = el * ML_LD + 4 * hi + 64 * half;
+  f32x4 b0[8], b1[8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { b0[u] = *(const f32x4*)(sIn0 + off + 8 * u); b1[u] = *(const f32x4*)(sIn1 + off + 8 * u); }
+  ML_PIN();
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const f32x4 b0 = *(const f32x4*)(sIn0 + off + 8 * u), b1 = *(const f32x4*)(sIn1 + off + 8 * u);
-    acc = ML_MFMA(av[u].x, b0.x + b1.x, acc);
-    acc = ML_MFMA(av[u].y, b0.y + b1.y, acc);
-    acc = ML_MFMA(av[u].z, b0.z + b1.z, acc);
-    acc = ML_MFMA(av[u].w, b0.w + b1.w, acc);
+    acc = ML_MFMA(av[u].x, b0[u].x + b1[u].x, acc);
+    acc = ML_MFMA(av[u].y, b0[u].y + b1[u].y, acc);
+    acc = ML_MFMA(av[u].z, b0[u].z + b1[u].z, acc);
+    acc = ML_MFMA(av[u].w, b0[u].w + b1[u].w, acc);
+    if (u + 4 < 8) { b0[u + 4] = *(const f32x4*)(sIn0 + off + 8 * (u + 4)); b1[u + 4] = *(const f32x4*)(sIn1 + off + 8 * (u + 4)); ML_PIN(); }
   }
   return acc;
 }
