@@ -462,17 +462,20 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           {
             const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
             const float* zrow = zbuf + el * ML_LD + 4 * hi;
-            f32x4 wq = *(const f32x4*)wbase;
-            f32x4 zq = *(const f32x4*)zrow;
+            // both operands come from LDS: requested THREE k-blocks ahead and pinned there (the one-ahead form written here
+            // before was collapsed by the compiler to "two ds_reads, wait for both, four MFMAs": the LDS round trip of every
+            // k-block sat in the MFMA chain)
+            f32x4 wb[KB2], zb[KB2];
+#pragma unroll
+            for (int ug = 0; ug < 3; ++ug) { wb[ug] = *(const f32x4*)(wbase + ug * 256); zb[ug] = *(const f32x4*)(zrow + 8 * ug); }
+            ML_PIN();
 #pragma unroll
             for (int ug = 0; ug < KB2; ++ug) {
-              f32x4 wn = wq, zn = zq;
-              if (ug + 1 < KB2) { wn = *(const f32x4*)(wbase + (ug + 1) * 256); zn = *(const f32x4*)(zrow + 8 * (ug + 1)); }
-              g = ML_MFMA(zq.x, wq.x, g);
-              g = ML_MFMA(zq.y, wq.y, g);
-              g = ML_MFMA(zq.z, wq.z, g);
-              g = ML_MFMA(zq.w, wq.w, g);
-              wq = wn; zq = zn;
+              if (ug + 3 < KB2) { wb[ug + 3] = *(const f32x4*)(wbase + (ug + 3) * 256); zb[ug + 3] = *(const f32x4*)(zrow + 8 * (ug + 3)); ML_PIN(); }
+              g = ML_MFMA(zb[ug].x, wb[ug].x, g);
+              g = ML_MFMA(zb[ug].y, wb[ug].y, g);
+              g = ML_MFMA(zb[ug].z, wb[ug].z, g);
+              g = ML_MFMA(zb[ug].w, wb[ug].w, g);
             }
           }
           // raw filter outputs for the backward (row = position of the pair in the list, 128-byte row segments per half wave)
@@ -1068,18 +1071,21 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) gp[r] = 0.f;
           {
+            // weights from LDS, requested three k-blocks ahead and pinned there (the one-ahead form was collapsed by the compiler
+            // to "ds_read, wait, four MFMAs": a derivative task alone on its SIMD then waits out the LDS round trip of every k-block)
             const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
-            f32x4 wq = *(const f32x4*)wbase;
+            f32x4 wb[KB2];
+#pragma unroll
+            for (int ug = 0; ug < 3; ++ug) wb[ug] = *(const f32x4*)(wbase + ug * 256);
+            ML_PIN();
 #pragma unroll
             for (int ug = 0; ug < KB2; ++ug) {
               const int c = ug >> 2, q = ug & 3;
-              f32x4 wn = wq;
-              if (ug + 1 < KB2) wn = *(const f32x4*)(wbase + (ug + 1) * 256);
-              gp = ML_MFMA(wq.x, zp[c][4 * q + 0], gp);
-              gp = ML_MFMA(wq.y, zp[c][4 * q + 1], gp);
-              gp = ML_MFMA(wq.z, zp[c][4 * q + 2], gp);
-              gp = ML_MFMA(wq.w, zp[c][4 * q + 3], gp);
-              wq = wn;
+              if (ug + 3 < KB2) { wb[ug + 3] = *(const f32x4*)(wbase + (ug + 3) * 256); ML_PIN(); }
+              gp = ML_MFMA(wb[ug].x, zp[c][4 * q + 0], gp);
+              gp = ML_MFMA(wb[ug].y, zp[c][4 * q + 1], gp);
+              gp = ML_MFMA(wb[ug].z, zp[c][4 * q + 2], gp);
+              gp = ML_MFMA(wb[ug].w, zp[c][4 * q + 3], gp);
             }
           }
 #pragma unroll
