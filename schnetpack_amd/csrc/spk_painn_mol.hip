@@ -663,7 +663,7 @@ struct PmBwdArgs {
   const int32_t* grp_atom0;
   int n_groups;
   const float* saved;
-  float* gc_scratch;        // [N, 3F]
+  float* gc_scratch;        // [2][N, 3F]: gc rows | new gmu rows of the message backward
   float* gr;                // [E, 3], every entry written once
   float* gq0;               // [N, F] or null
   int64_t N;
@@ -725,7 +725,9 @@ __device__ __forceinline__ void pm_message_bwd(const PmFilt<K>& Wf, const float*
                                                const float* __restrict__ sMuIn, const float* __restrict__ c_g, float* __restrict__ gc_g,
                                                const f32x4* __restrict__ sEa, const float* __restrict__ sEd, float* __restrict__ sG,
                                                const int* __restrict__ sRow, const int* __restrict__ myAsg, float* __restrict__ myPhi, float* __restrict__ myFc,
-                                               int rbf_kind, float p0k, float p1k, float cutoff, bool mu0, bool geom, int lane, pm_f2 (&rm)[4][3]) {
+                                               int rbf_kind, float p0k, float p1k, float cutoff, bool mu0, bool geom, int lane, float* __restrict__ gmu_g) {
+  // gmu_g: global scratch [n, 3, F] receiving the new gmu rows (the LDS rows are still being read by other waves; kept in
+  // registers across the row loops instead, the 24 values pushed the loop into scratch reloads on every edge)
   const int hi = lane >> 5;
   (void)bf;
   const pm_f2 zero2 = {0.f, 0.f};
@@ -815,9 +817,10 @@ __device__ __forceinline__ void pm_message_bwd(const PmFilt<K>& Wf, const float*
         float* gp = gc_g + (size_t)at * 384 + 2 * lane;
         *(pm_f2*)gp = accq; *(pm_f2*)(gp + 128) = accR; *(pm_f2*)(gp + 256) = gcm;
         gma0 += cma * av0; gma1 += cma * av1; gma2 += cma * av2;
+        float* mp = gmu_g + (size_t)at * 384 + 2 * lane;
+        *(pm_f2*)mp = gma0; *(pm_f2*)(mp + 128) = gma1; *(pm_f2*)(mp + 256) = gma2;
       }
     }
-    rm[it][0] = gma0; rm[it][1] = gma1; rm[it][2] = gma2;
   }
 }
 
@@ -950,7 +953,6 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         acc = pm_wmma_3chunks(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
         if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(acc[0])); a.dbg[64 + 40] = (long long)__builtin_readcyclecounter(); }
         if (a.dbg && blockIdx.x == 0 && lane == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(acc[0])); a.dbg[64 + 44 + wv] = (long long)__builtin_readcyclecounter(); }
-        pm_wload(Wn, P.ic1T_p, 16, 4 * team + t, 0, lane);
         if (team == 1) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) *(f32x4*)(X2 + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -976,11 +978,13 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
       // ================= M3: g_ctx = g_hid W_b1: tiles 0..3 (q part, team 0): gq += ; tiles 4..7 (|V| part, team 1): g_nv -> X0
       PmWF Wm;      // weights of M4: A = W_mix^T, k-blocks 16 team .. 16 team + 15 (the gV resp. gW half of the contraction)
       {
+        // (in this kernel a weight chunk held across a barrier is spilled right behind its load by the register allocator -- a
+        //  chain of L2 round trips; requested at the start of the phase that uses it the chunk costs one exposed round trip)
+        pm_wload(Wn, P.ic1T_p, 16, 4 * team + t, 0, lane);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         acc = pm_wmma(Wn, X2, lane, acc);
-        pm_wfload(Wm, P.mixT_p, 32, t, 16 * team, lane);
         float* dst = team ? X0 : sGq;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -994,6 +998,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
       PM_BSTAMP(4 + 12 * (a.n_layers - 1 - l));
 
       // ================= M4: per component x: gV -> X1, gW -> X2; gmu_x += [gV | gW] W_mix  (team 1 adds its half first)
+      pm_wfload(Wm, P.mixT_p, 32, t, 16 * team, lane);
       for (int x = 0; x < 3; ++x) {
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
@@ -1056,24 +1061,27 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
       PM_BARRIER();
       PM_BSTAMP(6 + 12 * (a.n_layers - 1 - l));
       {
-        pm_f2 rm[4][3];
         pm_message_bwd<K>(Wf, P.bf, sGq, sGmu, X0, c_g, a.gc_scratch + (size_t)a0 * 3 * F, sEa, sEd, sG, sRow, myAsg, myPhi, myFc, a.rb.kind, p0k, p1k,
-                          cutoff, mu0, geom, lane, rm);
+                          cutoff, mu0, geom, lane, a.gc_scratch + 3 * nf + (size_t)a0 * 3 * F);
         PM_BSTAMP(7 + 12 * (a.n_layers - 1 - l));
         if (geom) break;          // (uniform over the workgroup: the first interaction of an eval-mode backward ends here)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the gc rows of this wave have reached L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the gc / gmu rows of this wave have reached L2
         PM_BARRIER();
-        pm_message_write(sGmu, myAsg, lane, rm);
       }
       // ================= context net backward: gc -> X0..X2 (part planes), gq += ((gc W_a2) silu'(pre_a)) W_a1
       pm_wload(W3, P.ctx2T_p, 48, t, 24 * team, lane);
       {
         const float* gcs = a.gc_scratch + (size_t)a0 * 3 * F;
+        const float* gms = a.gc_scratch + 3 * nf + (size_t)a0 * 3 * F;
         for (int s = tid; s < 3 * 32 * 32; s += 512) {
           const int p = s >> 10, row = (s >> 5) & 31, c4 = s & 31;
-          f32x4 v = z4;
-          if (row < na) v = __builtin_nontemporal_load((const f32x4*)(gcs + (size_t)row * 3 * F + p * F + 4 * c4));
+          f32x4 v = z4, w = z4;
+          if (row < na) {
+            v = __builtin_nontemporal_load((const f32x4*)(gcs + (size_t)row * 3 * F + p * F + 4 * c4));
+            w = __builtin_nontemporal_load((const f32x4*)(gms + (size_t)row * 3 * F + p * F + 4 * c4));
+          }
           *(f32x4*)(X0 + p * PM_TILE + row * PM_LD + 4 * c4) = v;
+          *(f32x4*)(sGmu + p * PM_TILE + row * PM_LD + 4 * c4) = w;
         }
       }
       PM_BARRIER();
@@ -1087,7 +1095,6 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         acc = pm_wmma_3chunks(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
-        if (team == 0) pm_wload(Wn, P.ctx1T_p, 16, t, 0, lane);
         if (team == 1) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) *(f32x4*)(X3 + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -1108,6 +1115,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
       PM_BARRIER();
       PM_BSTAMP(9 + 12 * (a.n_layers - 1 - l));
       if (team == 0) {
+        pm_wload(Wn, P.ctx1T_p, 16, t, 0, lane);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1225,7 +1233,7 @@ static int launch_painn_mol_bwd(const PmBwdArgs& a, hipStream_t stream) {
   return SPK_OK;
 }
 
-// gq_out / gmu_out may be null (zeros); gr [E, 3] is overwritten (no clearing needed); gq0 may be null; gc_scratch: [N, 3F] floats
+// gq_out / gmu_out may be null (zeros); gr [E, 3] is overwritten (no clearing needed); gq0 may be null; gc_scratch: 2 x [N, 3F] floats
 int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
                            const float* gmu_out, const float* r_ij, const float* saved, float* gc_scratch, float* gr, float* gq0, hipStream_t stream) {
   PmBwdArgs a;
