@@ -267,11 +267,12 @@ __device__ __forceinline__ void pm_basis(int kind, int k, float p0k, float p1k, 
 // edges of the row per step -- lanes 0..31 evaluate the radial basis of the first, lanes 32..63 of the second, the values reach
 // all lanes through a 256-byte LDS slot of the wave (broadcast reads).  q is updated in place (no other atom's message reads
 // it); the new mu rows stay in registers (rm) until every wave has read its neighbours' rows.
-template <int K>
+template <int K, bool MU0>
 __device__ __forceinline__ void pm_message(const PmFilt<K>& Wf, const float* __restrict__ bf, float* __restrict__ sQ, const float* __restrict__ sMu,
                                            const float* __restrict__ sC, const PmEdge* __restrict__ sE, const int* __restrict__ sRow,
                                            const int* __restrict__ myAsg, float* __restrict__ myPhi, int rbf_kind, float p0k, float p1k, float cutoff,
-                                           bool mu0, int lane, pm_f2 (&rm)[4][3]) {
+                                           int lane, pm_f2 (&rm)[4][3]) {
+  constexpr bool mu0 = MU0;
   const int hi = lane >> 5;
   (void)bf;
 #pragma unroll
@@ -464,7 +465,8 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         // ---- P3: message
         {
           pm_f2 rm[4][3];
-          pm_message<K>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, l == 0, lane, rm);
+          if (l == 0) pm_message<K, true>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm);
+          else pm_message<K, false>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm);
           pm_wload(Wt, P.mix_p, 16, t, 0, lane);
           PM_STAMP(4 + 8 * l);
           PM_BARRIER();       // every wave has read its neighbours' rows: mu can be replaced
@@ -601,7 +603,8 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         // ---- P3: message
         {
           pm_f2 rm[4][3];
-          pm_message<K>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, l == 0, lane, rm);
+          if (l == 0) pm_message<K, true>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm);
+          else pm_message<K, false>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm);
           PM_BARRIER();
           pm_message_write(sMu, myAsg, lane, rm);
         }
@@ -720,12 +723,14 @@ __device__ __forceinline__ void pm_phi_d(int kind, float p0k, float p1k, float d
 
 // message backward of the atoms of one wave (see the header comment of this section); rm = the new gmu rows (written by the
 // caller after the barrier), gc -> global scratch, geometry gradients -> sG
-template <int K>
+// MU0 / GEOM as template parameters: as run-time flags the compiler turned the small guarded blocks into per-component selects
+template <int K, bool MU0, bool GEOM>
 __device__ __forceinline__ void pm_message_bwd(const PmFilt<K>& Wf, const float* __restrict__ bf, const float* __restrict__ sGq, const float* __restrict__ sGmu,
                                                const float* __restrict__ sMuIn, const float* __restrict__ c_g, float* __restrict__ gc_g,
                                                const f32x4* __restrict__ sEa, const float* __restrict__ sEd, float* __restrict__ sG,
                                                const int* __restrict__ sRow, const int* __restrict__ myAsg, float* __restrict__ myPhi, float* __restrict__ myFc,
-                                               int rbf_kind, float p0k, float p1k, float cutoff, bool mu0, bool geom, int lane, float* __restrict__ gmu_g) {
+                                               int rbf_kind, float p0k, float p1k, float cutoff, int lane, float* __restrict__ gmu_g) {
+  constexpr bool mu0 = MU0, geom = GEOM;
   // gmu_g: global scratch [n, 3, F] receiving the new gmu rows (the LDS rows are still being read by other waves; kept in
   // registers across the row loops instead, the 24 values pushed the loop into scratch reloads on every edge)
   const int hi = lane >> 5;
@@ -1061,8 +1066,10 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
       PM_BARRIER();
       PM_BSTAMP(6 + 12 * (a.n_layers - 1 - l));
       {
-        pm_message_bwd<K>(Wf, P.bf, sGq, sGmu, X0, c_g, a.gc_scratch + (size_t)a0 * 3 * F, sEa, sEd, sG, sRow, myAsg, myPhi, myFc, a.rb.kind, p0k, p1k,
-                          cutoff, mu0, geom, lane, a.gc_scratch + 3 * nf + (size_t)a0 * 3 * F);
+        float* gcs_w = a.gc_scratch + (size_t)a0 * 3 * F;
+        if (geom) pm_message_bwd<K, true, true>(Wf, P.bf, sGq, sGmu, X0, c_g, gcs_w, sEa, sEd, sG, sRow, myAsg, myPhi, myFc, a.rb.kind, p0k, p1k, cutoff, lane, gcs_w + 3 * nf);
+        else if (mu0) pm_message_bwd<K, true, false>(Wf, P.bf, sGq, sGmu, X0, c_g, gcs_w, sEa, sEd, sG, sRow, myAsg, myPhi, myFc, a.rb.kind, p0k, p1k, cutoff, lane, gcs_w + 3 * nf);
+        else pm_message_bwd<K, false, false>(Wf, P.bf, sGq, sGmu, X0, c_g, gcs_w, sEa, sEd, sG, sRow, myAsg, myPhi, myFc, a.rb.kind, p0k, p1k, cutoff, lane, gcs_w + 3 * nf);
         PM_BSTAMP(7 + 12 * (a.n_layers - 1 - l));
         if (geom) break;          // (uniform over the workgroup: the first interaction of an eval-mode backward ends here)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the gc / gmu rows of this wave have reached L2
