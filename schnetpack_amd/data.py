@@ -153,17 +153,53 @@ class WireCollate:
         return out
 
 
-def install_plan(inputs: Dict[str, torch.Tensor]) -> bool:
-    """Hand the host-made plan of a batch (already on the device) to the operator library: the plan cache entry of
+def to_device(batch: Dict[str, torch.Tensor], device, non_blocking: bool = True) -> Dict[str, torch.Tensor]:
+    """Move a collated batch to ``device``.  ``_spk_plan_meta`` (eight scalars that the HOST reads when the plan is installed)
+    stays where the collate function put it: on the device it would cost a blocking device-to-host copy per batch."""
+    return {k: (v if k == PLAN_KEYS[6] else v.to(device, non_blocking=non_blocking)) for k, v in batch.items()}
+
+
+def _validate_plan(inputs, meta):
+    """Debug check of an installed plan (synchronises): the library only checks the SIZES of the arrays it is handed."""
+    E = int(inputs[structure.idx_i].shape[0])
+    N = int(inputs[structure.Z].shape[0])
+    rowptr, rev, half, edge_pair, ga, gp = (inputs[k] for k in PLAN_KEYS[:6])
+
+    def in_range(t, lo, hi, what):
+        if t.numel() and (int(t.min()) < lo or int(t.max()) >= hi):
+            raise ValueError("install_plan: %s outside [%d, %d)" % (what, lo, hi))
+
+    in_range(rowptr, 0, E + 1, "rowptr")
+    if bool((rowptr[1:] < rowptr[:-1]).any()) or int(rowptr[-1]) != E:
+        raise ValueError("install_plan: rowptr is not a CSR row pointer of the list")
+    if meta[1] and E:
+        in_range(rev[:E], 0, E, "rev")
+        in_range(half, 0, E, "half")
+        in_range(edge_pair, 0, meta[2], "edge_pair")
+        if meta[3] > 0:
+            in_range(ga, 0, N + 1, "grp_atom0")
+            in_range(gp, 0, meta[2] + 1, "grp_pair0")
+
+
+def install_plan(inputs: Dict[str, torch.Tensor], validate: bool = False) -> bool:
+    """Hand the host-made plan of a batch (arrays already on the device) to the operator library: the plan cache entry of
     ``(inputs["_idx_i"], inputs["_idx_j"])`` is created from the ``_spk_*`` tensors without a kernel launch or a sync.
-    Returns False when the batch carries no plan (then the device derives it on first use)."""
+    ``_spk_plan_meta`` must still be a HOST tensor (move batches with :func:`to_device`): the host reads its eight scalars here,
+    and from the device that would be a blocking copy per batch -- refused instead of paid silently.  ``validate=True`` range-checks
+    the arrays first (debug; synchronises).  Returns False when the batch carries no plan (then the device derives it on first use)."""
     if PLAN_KEYS[0] not in inputs:
         return False
     from . import torchops  # noqa: F401
     meta = inputs[PLAN_KEYS[6]]
+    if meta.device.type != "cpu":
+        raise ValueError("install_plan: '_spk_plan_meta' is on %s; keep it on the host (schnetpack_amd.data.to_device moves "
+                         "everything else) -- reading it back would synchronise every batch" % meta.device)
+    meta = [int(v) for v in meta.tolist()]
+    if validate:
+        _validate_plan(inputs, meta)
     torch.ops.spk_hip.edge_plan_install(inputs[structure.idx_i], inputs[structure.idx_j], int(inputs[structure.Z].shape[0]),
                                         inputs[PLAN_KEYS[0]], inputs[PLAN_KEYS[1]], inputs[PLAN_KEYS[2]], inputs[PLAN_KEYS[3]],
-                                        inputs[PLAN_KEYS[4]], inputs[PLAN_KEYS[5]], [int(v) for v in meta.tolist()])
+                                        inputs[PLAN_KEYS[4]], inputs[PLAN_KEYS[5]], meta)
     return True
 
 

@@ -99,8 +99,15 @@ def test_installed_host_plan_equals_device_plan_and_force_call():
     batch = D.WireCollate(model_cutoff=5.0)(_systems(3, ("aspirin", "ethanol", "aspirin", "aspirin", "ethanol", "ethanol")))
     torch.manual_seed(0)
     model = M.build_model("schnet").to(dev).eval()
-    inp = {k: v.to(dev) for k, v in batch.items() if k not in ("energy",) and "triples" not in k and not k.endswith("_local")}
-    assert D.install_plan(inp)
+    inp = D.to_device({k: v for k, v in batch.items() if k not in ("energy",) and "triples" not in k and not k.endswith("_local")}, dev)
+    assert inp["_spk_plan_meta"].device.type == "cpu"          # the host reads it: no device-to-host copy per batch
+    with pytest.raises(ValueError, match="keep it on the host"):
+        D.install_plan({k: v.to(dev) for k, v in inp.items()})
+    bad = dict(inp)
+    bad["_spk_rev"] = inp["_spk_rev"] + 10 ** 6
+    with pytest.raises(ValueError, match="rev outside"):
+        D.install_plan(bad, validate=True)
+    assert D.install_plan(inp, validate=True)
     N = int(inp["_atomic_numbers"].shape[0])
     out = model({k: v for k, v in inp.items() if not k.startswith("_spk")})
     r = inp["_positions"][inp["_idx_j"]] - inp["_positions"][inp["_idx_i"]] + inp["_offsets"]
