@@ -425,8 +425,9 @@ void spk_filter_table_clear(void);
  * shader clock) -- so it must hold 128 + 4 * (number of groups) entries; NULL disables it (default). */
 void spk_schnet_mol_set_debug_buffer(void* device_buffer);
 /* The same for the molecule-resident PaiNN kernels (spk_painn_mol.hip; representation/painn.py:207-256 with q / mu / context rows
- * of a <= 32-atom block in LDS, all interactions in one launch): >= 128 int64; entry 0 = group start, 1 + 8 l .. 8 + 8 l = phase
- * boundaries of interaction l of the forward (thread 0 of workgroup 0); entries 64.. the backward.  NULL disables it (default). */
+ * of a <= 32-atom block in LDS, all interactions in one launch): >= 256 int64; entry 0 = group start, 1 + 8 l .. 8 + 8 l = phase
+ * boundaries of interaction l of the forward (thread 0 of workgroup 0); entries 64.. the backward, 128 + 16 w .. the message phase
+ * of wave w in its top interaction.  NULL disables it (default). */
 void spk_painn_mol_set_debug_buffer(void* device_buffer);
 
 /* ------------------------------------------------------------------ representation/painn.py:31-67

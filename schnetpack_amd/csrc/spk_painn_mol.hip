@@ -57,6 +57,7 @@ struct PmFwdArgs {
   float eps;
   RadialDev rb;
   long long* dbg;           // tuning aid: cycle stamps of thread 0 of workgroup 0 (spk_painn_mol_set_debug_buffer; null in production)
+  int assign;               // tuning: 0 = dynamic (default), 1 = snake over the waves, >= 20: static greedy with this cost per edge of the younger wave
 };
 #define PM_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -267,17 +268,66 @@ __device__ __forceinline__ void pm_basis(int kind, int k, float p0k, float p1k, 
 // edges of the row per step -- lanes 0..31 evaluate the radial basis of the first, lanes 32..63 of the second, the values reach
 // all lanes through a 256-byte LDS slot of the wave (broadcast reads).  q is updated in place (no other atom's message reads
 // it); the new mu rows stay in registers (rm) until every wave has read its neighbours' rows.
+// Atoms of the group -> waves of the message phases (sAsg[wave][slot], -1 = none; run by ONE wave, lane = atom, deg = row length or
+// -1 beyond the group).  Waves w and w + 4 share a SIMD and the phases are VALU-bound; per-wave stamps show the OLDER wave of a SIMD
+// (w < 4) getting the larger share of the issue slots -- 2.2 k cycles per edge of the backward against 3.0 k for its partner -- and a
+// wave left alone on its SIMD running at 1.6 k per edge, i.e. less than twice as fast: the phase is shortest when all eight waves
+// finish together.  Rows are dealt longest first to the wave that would finish it earliest, (edges so far + row) x the cost per edge
+// of that wave (22 : 30), at most 4 atoms per wave.  mode 1 = the snake over the waves used until round 3 (for A/B runs).
+__device__ __forceinline__ void pm_assign_atoms(int deg, int na, int lane, int* __restrict__ sAsg, int mode) {
+  int rank = 0;
+  for (int b = 0; b < 32; ++b) {
+    const int db = __builtin_amdgcn_readlane(deg, b);
+    rank += (db > deg || (db == deg && b < lane)) ? 1 : 0;
+  }
+  if (lane < 32) sAsg[lane] = -1;
+  if (mode == 0) {          // dynamic (default): sAsg = the atoms by falling row length; the waves take the next one when they are free
+    if (lane < na) sAsg[rank] = lane;
+    return;
+  }
+  if (mode == 1) {
+    if (lane < na) {
+      const int rnd = rank >> 3, pos = rank & 7;
+      sAsg[((rnd & 1) ? 7 - pos : pos) * 4 + rnd] = lane;
+    }
+    return;
+  }
+  int myload = 0, mycnt = 0;          // lanes 0..7: edges (+ 1 per atom) and atoms given to wave `lane`
+  const int cost = mode >= 20 ? mode : (lane < 4 ? 22 : 30);
+  for (int r = 0; r < na; ++r) {
+    const unsigned long long m = __ballot(rank == r && lane < na);
+    const int at = (int)__ffsll((long long)m) - 1;
+    const int d = __builtin_amdgcn_readlane(deg, at) + 1;
+    const int key = (lane < 8 && mycnt < 4) ? (myload + d) * (lane < 4 ? 22 : cost) * 8 + lane : 0x7fffffff;
+    int best = 0x7fffffff;
+    for (int w = 0; w < 8; ++w) { const int kw = __builtin_amdgcn_readlane(key, w); best = kw < best ? kw : best; }
+    const int w = best & 7;
+    if (lane == w) { sAsg[w * 4 + mycnt] = at; mycnt += 1; myload += d; }
+  }
+}
+
+// the next atom of a wave in a message phase: dynamic (asg = the 32-entry order, *ctr = atoms taken so far in this phase) or static
+// (asg = the four slots of the wave)
+__device__ __forceinline__ int pm_next_atom(const int* __restrict__ asg, int* __restrict__ ctr, int na, int it, int lane, bool dyn) {
+  if (!dyn) return it < 4 ? asg[it] : -1;
+  int r = 0;
+  if (lane == 0) r = atomicAdd(ctr, 1);
+  r = __builtin_amdgcn_readfirstlane(r);
+  return r < na ? asg[r] : -1;
+}
+
 template <int K, bool MU0>
 __device__ __forceinline__ void pm_message(const PmFilt<K>& Wf, const float* __restrict__ bf, float* __restrict__ sQ, const float* __restrict__ sMu,
                                            const float* __restrict__ sC, const PmEdge* __restrict__ sE, const int* __restrict__ sRow,
                                            const int* __restrict__ myAsg, float* __restrict__ myPhi, int rbf_kind, float p0k, float p1k, float cutoff,
-                                           int lane, pm_f2 (&rm)[4][3]) {
+                                           int lane, pm_f2 (&rm)[4][3], int (&ats)[4], int* __restrict__ ctr, int na, bool dyn) {
   constexpr bool mu0 = MU0;
   const int hi = lane >> 5;
   (void)bf;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int at = myAsg[it];
+    const int at = pm_next_atom(myAsg, ctr, na, it, lane, dyn);
+    ats[it] = at;
     pm_f2 accq = {0.f, 0.f}, av0 = {0.f, 0.f}, av1 = {0.f, 0.f}, av2 = {0.f, 0.f};
     if (at >= 0) {
       const int rs = sRow[at], re = sRow[at + 1];
@@ -319,10 +369,10 @@ __device__ __forceinline__ void pm_message(const PmFilt<K>& Wf, const float* __r
     rm[it][0] = av0; rm[it][1] = av1; rm[it][2] = av2;
   }
 }
-__device__ __forceinline__ void pm_message_write(float* __restrict__ sMu, const int* __restrict__ myAsg, int lane, const pm_f2 (&rm)[4][3]) {
+__device__ __forceinline__ void pm_message_write(float* __restrict__ sMu, const int (&ats)[4], int lane, const pm_f2 (&rm)[4][3]) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int at = myAsg[it];
+    const int at = ats[it];
     if (at >= 0) {
       const int io = at * PM_LD + 2 * lane;
       *(pm_f2*)(sMu + io) = rm[it][0]; *(pm_f2*)(sMu + PM_TILE + io) = rm[it][1]; *(pm_f2*)(sMu + 2 * PM_TILE + io) = rm[it][2];
@@ -359,6 +409,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
   const int64_t per = 17 * nf;
   float* myPhi = sPhi + wv * 64;
   const int* myAsg = sAsg + wv * 4;
+  const bool dyn = (a.assign == 0);
 
   for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
     const int a0 = a.grp_atom0[grp], na = a.grp_atom0[grp + 1] - a0;
@@ -387,22 +438,13 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
       sE[le] = ed;
     }
     if (wv == 7) {
-      // local CSR + the atoms of every wave in the message phase: rows ranked by length (longest first), dealt out in snake order
+      // local CSR + the atoms of every wave in the message phase (pm_assign_atoms: edges balanced per SIMD)
       int r0 = 0;
       if (lane <= 32) r0 = a.rowptr[a0 + (lane < na ? lane : na)] - e0;
       const int r1 = __shfl_down(r0, 1, 64);
       if (lane <= 32) sRow[lane] = r0;
-      const int deg = lane < na ? r1 - r0 : -1;
-      int rank = 0;
-      for (int b = 0; b < 32; ++b) {
-        const int db = __builtin_amdgcn_readlane(deg, b);
-        rank += (db > deg || (db == deg && b < lane)) ? 1 : 0;
-      }
-      if (lane < 32) sAsg[lane] = -1;
-      if (lane < na) {
-        const int rnd = rank >> 3, pos = rank & 7;
-        sAsg[((rnd & 1) ? 7 - pos : pos) * 4 + rnd] = lane;
-      }
+      pm_assign_atoms(lane < na ? r1 - r0 : -1, na, lane, sAsg, a.assign);
+      if (lane == 0) { sRow[34] = 0; sRow[35] = 0; }
     }
     // mu entering the first interaction is zero: the backward reads it from the saved block
     for (int s = tid; s < na * 96; s += 512) pm_st<f32x4>(a.saved + 4 * nf + (size_t)a0 * 3 * F, (unsigned)(s * 16), f32x4{0.f, 0.f, 0.f, 0.f});
@@ -465,12 +507,15 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         // ---- P3: message
         {
           pm_f2 rm[4][3];
-          if (l == 0) pm_message<K, true>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm);
-          else pm_message<K, false>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm);
+          int ats[4];
+          int* ctr = sRow + 34 + (l & 1);
+          if (tid == 0) sRow[34 + ((l + 1) & 1)] = 0;          // (the counter of the next interaction; everybody left it a barrier ago)
+          if (l == 0) pm_message<K, true>(Wf, P.bf, sQ, sMu, sC, sE, sRow, dyn ? sAsg : myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm, ats, ctr, na, dyn);
+          else pm_message<K, false>(Wf, P.bf, sQ, sMu, sC, sE, sRow, dyn ? sAsg : myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm, ats, ctr, na, dyn);
           pm_wload(Wt, P.mix_p, 16, t, 0, lane);
           PM_STAMP(4 + 8 * l);
           PM_BARRIER();       // every wave has read its neighbours' rows: mu can be replaced
-          pm_message_write(sMu, myAsg, lane, rm);
+          pm_message_write(sMu, ats, lane, rm);
         }
         PM_BARRIER();
         PM_STAMP(5 + 8 * l);
@@ -603,10 +648,13 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         // ---- P3: message
         {
           pm_f2 rm[4][3];
-          if (l == 0) pm_message<K, true>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm);
-          else pm_message<K, false>(Wf, P.bf, sQ, sMu, sC, sE, sRow, myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm);
+          int ats[4];
+          int* ctr = sRow + 34 + (l & 1);
+          if (tid == 0) sRow[34 + ((l + 1) & 1)] = 0;          // (the counter of the next interaction; everybody left it a barrier ago)
+          if (l == 0) pm_message<K, true>(Wf, P.bf, sQ, sMu, sC, sE, sRow, dyn ? sAsg : myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm, ats, ctr, na, dyn);
+          else pm_message<K, false>(Wf, P.bf, sQ, sMu, sC, sE, sRow, dyn ? sAsg : myAsg, myPhi, a.rb.kind, p0k, p1k, cutoff, lane, rm, ats, ctr, na, dyn);
           PM_BARRIER();
-          pm_message_write(sMu, myAsg, lane, rm);
+          pm_message_write(sMu, ats, lane, rm);
         }
         PM_BARRIER();
         // ---- P4: (team 0: channel mix) -- request the K = 256 tile of P5
@@ -673,6 +721,7 @@ struct PmBwdArgs {
   float eps;
   RadialDev rb;
   long long* dbg;
+  int assign;
 };
 #define PM_BSTAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[64 + (n)] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -724,24 +773,59 @@ __device__ __forceinline__ void pm_phi_d(int kind, float p0k, float p1k, float d
 // message backward of the atoms of one wave (see the header comment of this section); rm = the new gmu rows (written by the
 // caller after the barrier), gc -> global scratch, geometry gradients -> sG
 // MU0 / GEOM as template parameters: as run-time flags the compiler turned the small guarded blocks into per-component selects
+// NIT x 512 threads x 16 bytes from global rows into LDS tiles: element `it` of a thread = (plane it >> 1, row (tid >> 5) + 16 (it & 1),
+// float4 column tid & 31).  Branch-free (rows >= na read row 0 and store zeros) so that ALL loads are in flight before the first LDS
+// store: a `for (s = tid; ...; s += 512) if (row < na) ...` loop is compiled into one exposed memory round trip PER ITERATION.
+template <int NIT, bool NT, class SrcFn>
+__device__ __forceinline__ void pm_fill_tiles(float* dst0 /* LDS plane 0, planes PM_TILE apart */, int tid, int na, SrcFn src /* (plane, row) -> row base */) {
+  f32x4 v[NIT];
+  const int r0 = tid >> 5, c4 = tid & 31;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = r0 + 16 * (it & 1), rr = row < na ? row : 0;
+    const f32x4* p = (const f32x4*)(src(it >> 1, rr)) + c4;
+    if (NT) v[it] = __builtin_nontemporal_load(p);
+    else v[it] = *p;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = r0 + 16 * (it & 1);
+    *(f32x4*)(dst0 + (it >> 1) * PM_TILE + row * PM_LD + 4 * c4) = row < na ? v[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 template <int K, bool MU0, bool GEOM>
 __device__ __forceinline__ void pm_message_bwd(const PmFilt<K>& Wf, const float* __restrict__ bf, const float* __restrict__ sGq, const float* __restrict__ sGmu,
                                                const float* __restrict__ sMuIn, const float* __restrict__ c_g, float* __restrict__ gc_g,
                                                const f32x4* __restrict__ sEa, const float* __restrict__ sEd, float* __restrict__ sG,
                                                const int* __restrict__ sRow, const int* __restrict__ myAsg, float* __restrict__ myPhi, float* __restrict__ myFc,
-                                               int rbf_kind, float p0k, float p1k, float cutoff, int lane, float* __restrict__ gmu_g) {
+                                               int rbf_kind, float p0k, float p1k, float cutoff, int lane, float* __restrict__ gmu_g, long long* dbgw /* tuning: 16 stamps of this wave, or null */,
+                                               int* __restrict__ ctr, int na, bool dyn) {
   constexpr bool mu0 = MU0, geom = GEOM;
+#define PM_MSTAMP(n) do { if (dbgw && lane == 0) dbgw[n] = (long long)__builtin_readcyclecounter(); } while (0)
+  PM_MSTAMP(0);
   // gmu_g: global scratch [n, 3, F] receiving the new gmu rows (the LDS rows are still being read by other waves; kept in
   // registers across the row loops instead, the 24 values pushed the loop into scratch reloads on every edge)
   const int hi = lane >> 5;
   (void)bf;
   const pm_f2 zero2 = {0.f, 0.f};
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int at = myAsg[it];
+  // global rows are addressed as (wave-uniform base, 32-bit lane offset): 64-bit per-lane addresses cost register pairs, and a
+  // spilled one is reloaded from scratch between the result stores of an atom -- a wait for their acknowledgement (loads, stores
+  // and scratch reloads share one in-order counter)
+  const unsigned lo = (unsigned)(8 * lane);
+  pm_f2 cn0 = zero2, cn1 = zero2, cn2 = zero2;          // context rows of the NEXT edge's neighbour (from L2)
+  int at = pm_next_atom(myAsg, ctr, na, 0, lane, dyn);
+  if (at >= 0 && sRow[at] < sRow[at + 1]) {
+    const unsigned co = (unsigned)__float_as_int(sEa[sRow[at]].x) * 1536u + lo;
+    cn0 = pm_ld<pm_f2>(c_g, co); cn1 = pm_ld<pm_f2>(c_g, co + 512u); cn2 = pm_ld<pm_f2>(c_g, co + 1024u);
+  }
+  // (a plain loop: one copy of the row code per instance instead of four -- and in the dynamic mode a wave may take more than four atoms)
+  for (int it = 0; at >= 0; ++it) {
     pm_f2 accq = zero2, accR = zero2, av0 = zero2, av1 = zero2, av2 = zero2;
     pm_f2 gma0 = zero2, gma1 = zero2, gma2 = zero2;
-    if (at >= 0) {
+    int at_next = -1;
+    {
+      PM_MSTAMP(1 + 3 * (it < 4 ? it : 3));
       const int rs = sRow[at], re = sRow[at + 1];
       // cutoff value and slope of the edges of the row: lanes = edges
       {
@@ -752,16 +836,11 @@ __device__ __forceinline__ void pm_message_bwd(const PmFilt<K>& Wf, const float*
       const int io = at * PM_LD + 2 * lane;
       const pm_f2 gqa = *(const pm_f2*)(sGq + io);
       gma0 = *(const pm_f2*)(sGmu + io); gma1 = *(const pm_f2*)(sGmu + PM_TILE + io); gma2 = *(const pm_f2*)(sGmu + 2 * PM_TILE + io);
-      pm_f2 cn0 = zero2, cn1 = zero2, cn2 = zero2;          // context rows of the NEXT edge's neighbour (from L2)
-      if (rs < re) {
-        const float* cp = c_g + (size_t)__float_as_int(sEa[rs].x) * 384 + 2 * lane;
-        cn0 = *(const pm_f2*)cp; cn1 = *(const pm_f2*)(cp + 128); cn2 = *(const pm_f2*)(cp + 256);
-      }
       for (int le = rs; le < re; ++le) {
         const pm_f2 cq = cn0, cR = cn1, cm = cn2;
         if (le + 1 < re) {
-          const float* cp = c_g + (size_t)__float_as_int(sEa[le + 1].x) * 384 + 2 * lane;
-          cn0 = *(const pm_f2*)cp; cn1 = *(const pm_f2*)(cp + 128); cn2 = *(const pm_f2*)(cp + 256);
+          const unsigned co = (unsigned)__float_as_int(sEa[le + 1].x) * 1536u + lo;
+          cn0 = pm_ld<pm_f2>(c_g, co); cn1 = pm_ld<pm_f2>(c_g, co + 512u); cn2 = pm_ld<pm_f2>(c_g, co + 1024u);
         }
         const float fc = myFc[le - rs], dfc = myFc[64 + le - rs];
         if (fc == 0.f && dfc == 0.f) continue;          // pairs at / beyond the cutoff contribute exactly zero
@@ -812,20 +891,62 @@ __device__ __forceinline__ void pm_message_bwd(const PmFilt<K>& Wf, const float*
           sG[3 * le + 2] += dd * uz + (tuz - dot * uz) * invd;
         }
       }
+      PM_MSTAMP(2 + 3 * (it < 4 ? it : 3));
+      // the first context row of the wave's NEXT atom is requested BEFORE the result rows of this one are stored: behind the stores
+      // the wait for it is a wait for their acknowledgement by L2
+      pm_f2 cma = zero2;
+      if (!geom && !mu0) cma = pm_ld<pm_f2>(c_g, (unsigned)at * 1536u + 1024u + lo);
+      {
+        at_next = pm_next_atom(myAsg, ctr, na, it + 1, lane, dyn);
+        if (at_next >= 0 && sRow[at_next] < sRow[at_next + 1]) {
+          const unsigned co = (unsigned)__float_as_int(sEa[sRow[at_next]].x) * 1536u + lo;
+          cn0 = pm_ld<pm_f2>(c_g, co); cn1 = pm_ld<pm_f2>(c_g, co + 512u); cn2 = pm_ld<pm_f2>(c_g, co + 1024u);
+        }
+      }
       if (!geom) {
         // gc_i = (acc_q, acc_R, sum_x mu_i[x] acc_v[x]);  gmu_i[x] = gmu1_i[x] + c_i^mu acc_v[x]
-        pm_f2 gcm = zero2, cma = zero2;
-        if (!mu0) {
-          gcm = *(const pm_f2*)(sMuIn + io) * av0 + *(const pm_f2*)(sMuIn + PM_TILE + io) * av1 + *(const pm_f2*)(sMuIn + 2 * PM_TILE + io) * av2;
-          cma = *(const pm_f2*)(c_g + (size_t)at * 384 + 256 + 2 * lane);
-        }
-        float* gp = gc_g + (size_t)at * 384 + 2 * lane;
-        *(pm_f2*)gp = accq; *(pm_f2*)(gp + 128) = accR; *(pm_f2*)(gp + 256) = gcm;
+        pm_f2 gcm = zero2;
+        if (!mu0) gcm = *(const pm_f2*)(sMuIn + io) * av0 + *(const pm_f2*)(sMuIn + PM_TILE + io) * av1 + *(const pm_f2*)(sMuIn + 2 * PM_TILE + io) * av2;
+        const unsigned go = (unsigned)at * 1536u + lo;
+        pm_st<pm_f2>(gc_g, go, accq); pm_st<pm_f2>(gc_g, go + 512u, accR); pm_st<pm_f2>(gc_g, go + 1024u, gcm);
         gma0 += cma * av0; gma1 += cma * av1; gma2 += cma * av2;
-        float* mp = gmu_g + (size_t)at * 384 + 2 * lane;
-        *(pm_f2*)mp = gma0; *(pm_f2*)(mp + 128) = gma1; *(pm_f2*)(mp + 256) = gma2;
+        pm_st<pm_f2>(gmu_g, go, gma0); pm_st<pm_f2>(gmu_g, go + 512u, gma1); pm_st<pm_f2>(gmu_g, go + 1024u, gma2);
       }
+      PM_MSTAMP(3 + 3 * (it < 4 ? it : 3));
     }
+    at = at_next;
+  }
+  PM_MSTAMP(13);
+#undef PM_MSTAMP
+}
+
+// K-split GEMM epilogue shared by the two teams: wave t of either team holds a partial accumulator of output tile t.  Each team
+// finishes HALF of the tile (team 0 the channel groups q = 0, 1, team 1 q = 2, 3): it hands the other half of its partial sums
+// to the partner through the output tile, and after the barrier adds the partner's half to its own, applies silu'(pre) and writes
+// the result in place.  (One team finishing the whole tile took 5 k cycles with the other idle.)
+template <int Q0>
+__device__ __forceinline__ void pm_split_send(float* __restrict__ X, const f32x16& acc, int el, int t, int hi) {
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    const int q = 2 - Q0 + qq;
+    *(f32x4*)(X + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  }
+}
+template <int Q0>
+__device__ __forceinline__ void pm_split_load_pre(f32x4 (&pre)[2], const float* __restrict__ pre_g /* + 32 t */, int el, int na, int hi) {
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) pre[qq] = pm_ld<f32x4>(pre_g, (unsigned)(((el < na ? el : 0) * 128 + 8 * (Q0 + qq) + 4 * hi) * 4));
+}
+template <int Q0>
+__device__ __forceinline__ void pm_split_finish(float* __restrict__ X, const f32x16& acc, const f32x4 (&pre)[2], int el, int na, int t, int hi) {
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    const int q = Q0 + qq;
+    float* xp = X + el * PM_LD + 32 * t + 8 * q + 4 * hi;
+    const f32x4 part = *(const f32x4*)xp;
+    const f32x4 pv = el < na ? pre[qq] : f32x4{0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)xp = f32x4{(acc[4 * q] + part.x) * pm_silu_grad(pv.x), (acc[4 * q + 1] + part.y) * pm_silu_grad(pv.y),
+                        (acc[4 * q + 2] + part.z) * pm_silu_grad(pv.z), (acc[4 * q + 3] + part.w) * pm_silu_grad(pv.w)};
   }
 }
 
@@ -859,6 +980,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
   float* myPhi = sPhi + wv * 64;
   float* myFc = sFc + wv * 128;
   const int* myAsg = sAsg + wv * 4;
+  const bool dyn = (a.assign == 0);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
   for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
@@ -867,32 +989,18 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
     PM_BARRIER();
     PM_BSTAMP(0);
     // ---- group set-up: incoming gradients, per-edge sums, local CSR and the wave -> atoms map of the message phase
-    for (int s = tid; s < 4 * 32 * 32; s += 512) {
-      const int pl = s >> 10, row = (s >> 5) & 31, c4 = s & 31;      // pl 0: gq, 1..3: gmu components
-      f32x4 v = z4;
-      if (row < na) {
-        if (pl == 0) { if (a.gq_out) v = *(const f32x4*)(a.gq_out + (size_t)(a0 + row) * F + 4 * c4); }
-        else if (a.gmu_out) v = *(const f32x4*)(a.gmu_out + ((size_t)(a0 + row) * 3 + (pl - 1)) * F + 4 * c4);
-      }
-      *(f32x4*)(sGq + pl * PM_TILE + row * PM_LD + 4 * c4) = v;
-    }
+    if (a.gq_out) pm_fill_tiles<2, false>(sGq, tid, na, [&](int, int r) { return a.gq_out + (size_t)(a0 + r) * F; });
+    else for (int s = tid; s < 32 * 32; s += 512) *(f32x4*)(sGq + (s >> 5) * PM_LD + 4 * (s & 31)) = z4;
+    if (a.gmu_out) pm_fill_tiles<6, false>(sGmu, tid, na, [&](int x, int r) { return a.gmu_out + ((size_t)(a0 + r) * 3 + x) * F; });
+    else for (int s = tid; s < 3 * 32 * 32; s += 512) *(f32x4*)(sGmu + (s >> 10) * PM_TILE + ((s >> 5) & 31) * PM_LD + 4 * (s & 31)) = z4;
     for (int s = tid; s < 3 * PM_MAXEDGES; s += 512) sG[s] = 0.f;
     if (wv == 7) {
       int r0 = 0;
       if (lane <= 32) r0 = a.rowptr[a0 + (lane < na ? lane : na)] - e0;
       const int r1 = __shfl_down(r0, 1, 64);
       if (lane <= 32) sRow[lane] = r0;
-      const int deg = lane < na ? r1 - r0 : -1;
-      int rank = 0;
-      for (int b = 0; b < 32; ++b) {
-        const int db = __builtin_amdgcn_readlane(deg, b);
-        rank += (db > deg || (db == deg && b < lane)) ? 1 : 0;
-      }
-      if (lane < 32) sAsg[lane] = -1;
-      if (lane < na) {
-        const int rnd = rank >> 3, pos = rank & 7;
-        sAsg[((rnd & 1) ? 7 - pos : pos) * 4 + rnd] = lane;
-      }
+      pm_assign_atoms(lane < na ? r1 - r0 : -1, na, lane, sAsg, a.assign);
+      if (lane == 0) { sRow[34] = 0; sRow[35] = 0; }
     }
 
     for (int l = a.n_layers - 1; l >= 0; --l) {
@@ -919,28 +1027,34 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
       PmW W3;
       pm_wload(W3, P.ic2T_p, 48, t, 24 * team, lane);
       if (a.dbg && blockIdx.x == 0 && lane == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(W3.a0[7].x)); a.dbg[64 + 52 + wv] = (long long)__builtin_readcyclecounter(); }
+      {
+        // (both row halves of a thread: 14 loads in flight, then the arithmetic -- branch-free, rows >= na read row 0 and store zeros)
+        f32x4 mV[2][3], mW[2][3], aqm[2];
+        const int r0 = tid >> 5, c4 = tid & 31;
 #pragma unroll
-      for (int rep = 0; rep < 2; ++rep) {
-        const int s = tid + 512 * rep, row = s >> 5, c4 = s & 31;
-        f32x4 gam = z4, gaq = z4, U = z4;
-        if (row < na) {
+        for (int rep = 0; rep < 2; ++rep) {
+          const int row = r0 + 16 * rep, rr = row < na ? row : 0;
+          const float* mp = mix_g + (size_t)rr * 6 * F + 4 * c4;
+#pragma unroll
+          for (int x = 0; x < 3; ++x) { mV[rep][x] = *(const f32x4*)(mp + x * 2 * F); mW[rep][x] = *(const f32x4*)(mp + x * 2 * F + F); }
+          aqm[rep] = *(const f32x4*)(a_g + (size_t)rr * 3 * F + 2 * F + 4 * c4);
+        }
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+          const int row = r0 + 16 * rep;
           const f32x4 gq = *(const f32x4*)(sGq + row * PM_LD + 4 * c4);
-          const float* mp = mix_g + (size_t)row * 6 * F + 4 * c4;
-          f32x4 Ssum = z4;
+          f32x4 Ssum = z4, gam = z4;
 #pragma unroll
           for (int x = 0; x < 3; ++x) {
-            const f32x4 V = *(const f32x4*)(mp + x * 2 * F), W = *(const f32x4*)(mp + x * 2 * F + F);
             const f32x4 gm = *(const f32x4*)(sGmu + x * PM_TILE + row * PM_LD + 4 * c4);
-            Ssum += V * W;
-            gam += gm * W;
+            Ssum += mV[rep][x] * mW[rep][x];
+            gam += gm * mW[rep][x];
           }
-          const f32x4 aqm = *(const f32x4*)(a_g + (size_t)row * 3 * F + 2 * F + 4 * c4);
-          gaq = gq * Ssum;
-          U = gq * aqm;
+          const bool live = row < na;
+          *(f32x4*)(X0 + row * PM_LD + 4 * c4) = live ? gam : z4;
+          *(f32x4*)(X1 + row * PM_LD + 4 * c4) = live ? gq * Ssum : z4;
+          *(f32x4*)(X3 + row * PM_LD + 4 * c4) = live ? gq * aqm[rep] : z4;
         }
-        *(f32x4*)(X0 + row * PM_LD + 4 * c4) = gam;
-        *(f32x4*)(X1 + row * PM_LD + 4 * c4) = gaq;
-        *(f32x4*)(X3 + row * PM_LD + 4 * c4) = U;
       }
       PM_BARRIER();
       PM_BSTAMP(2 + 12 * (a.n_layers - 1 - l));
@@ -952,29 +1066,21 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         const float* b1 = team ? X1 : sGq + 64;
         const float* b2 = team ? X1 + 64 : X0;
         const size_t bo = (size_t)((lane & 31) * PM_LD + 4 * (lane >> 5));
+        f32x4 pb[2];      // pre_b of this team's half of the epilogue, requested before the MFMAs (rows >= na: row 0, never used)
+        if (team == 0) pm_split_load_pre<0>(pb, preB_g + 32 * t, el, na, hi);
+        else pm_split_load_pre<2>(pb, preB_g + 32 * t, el, na, hi);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         acc = pm_wmma_3chunks(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
         if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(acc[0])); a.dbg[64 + 40] = (long long)__builtin_readcyclecounter(); }
         if (a.dbg && blockIdx.x == 0 && lane == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(acc[0])); a.dbg[64 + 44 + wv] = (long long)__builtin_readcyclecounter(); }
-        if (team == 1) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) *(f32x4*)(X2 + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        }
+        if (team == 0) pm_split_send<0>(X2, acc, el, t, hi);
+        else pm_split_send<2>(X2, acc, el, t, hi);
         PM_BARRIER();
         if (l == a.n_layers - 1) PM_BSTAMP(41);
-        if (team == 0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float* xp = X2 + el * PM_LD + 32 * t + 8 * q + 4 * hi;
-            const f32x4 part = *(const f32x4*)xp;
-            f32x4 pb = z4;
-            if (el < na) pb = pm_ld<f32x4>(preB_g + 32 * t, (unsigned)((el * F + 8 * q + 4 * hi) * 4));
-            *(f32x4*)xp = f32x4{(acc[4 * q] + part.x) * pm_silu_grad(pb.x), (acc[4 * q + 1] + part.y) * pm_silu_grad(pb.y),
-                                (acc[4 * q + 2] + part.z) * pm_silu_grad(pb.z), (acc[4 * q + 3] + part.w) * pm_silu_grad(pb.w)};
-          }
-        }
+        if (team == 0) pm_split_finish<0>(X2, acc, pb, el, na, t, hi);
+        else pm_split_finish<2>(X2, acc, pb, el, na, t, hi);
       }
       if (l == a.n_layers - 1) PM_BSTAMP(42);
       PM_BARRIER();
@@ -1002,59 +1108,80 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
       PM_BARRIER();
       PM_BSTAMP(4 + 12 * (a.n_layers - 1 - l));
 
-      // ================= M4: per component x: gV -> X1, gW -> X2; gmu_x += [gV | gW] W_mix  (team 1 adds its half first)
+      // ================= M4: per component x: gV -> X1, gW -> X2; gmu_x += [gV | gW] W_mix  (K = 256 split over the teams)
       pm_wfload(Wm, P.mixT_p, 32, t, 16 * team, lane);
-      for (int x = 0; x < 3; ++x) {
+      // (the saved rows are read ONCE per thread where possible: g_nv / |V| and a_mu before the loop, V_x / W_x of the next component
+      //  requested while the MFMAs of this one run -- a global round trip per component sat in front of every barrier before)
+      f32x4 cV[2], cW[2], Gn[2], am[2];
+      {
+        f32x4 V1[2], V2[2];
+        const int r0 = tid >> 5, c4 = tid & 31;
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
-          const int s = tid + 512 * rep, row = s >> 5, c4 = s & 31;
-          f32x4 gV = z4, gW = z4;
-          if (row < na) {
-            const float* mp = mix_g + (size_t)row * 6 * F + 4 * c4;
-            const f32x4 V0 = *(const f32x4*)mp, V1 = *(const f32x4*)(mp + 2 * F), V2 = *(const f32x4*)(mp + 4 * F);
-            const f32x4 Vx = *(const f32x4*)(mp + x * 2 * F), Wx = *(const f32x4*)(mp + x * 2 * F + F);
-            const f32x4 am = *(const f32x4*)(a_g + (size_t)row * 3 * F + F + 4 * c4);
-            const f32x4 U = *(const f32x4*)(X3 + row * PM_LD + 4 * c4), gnv = *(const f32x4*)(X0 + row * PM_LD + 4 * c4);
-            const f32x4 gm = *(const f32x4*)(sGmu + x * PM_TILE + row * PM_LD + 4 * c4);
-            f32x4 nv;
+          const int row = r0 + 16 * rep, rr = row < na ? row : 0;
+          const float* mp = mix_g + (size_t)rr * 6 * F + 4 * c4;
+          cV[rep] = *(const f32x4*)mp; V1[rep] = *(const f32x4*)(mp + 2 * F); V2[rep] = *(const f32x4*)(mp + 4 * F);
+          cW[rep] = *(const f32x4*)(mp + F);
+          am[rep] = *(const f32x4*)(a_g + (size_t)rr * 3 * F + F + 4 * c4);
+        }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) nv[v] = sqrtf(V0[v] * V0[v] + V1[v] * V1[v] + V2[v] * V2[v] + a.eps);
-            gV = U * Wx + gnv * Vx / nv;
-            gW = U * Vx + gm * am;
+        for (int rep = 0; rep < 2; ++rep) {
+          const int row = r0 + 16 * rep;
+          const f32x4 gnv = *(const f32x4*)(X0 + row * PM_LD + 4 * c4);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Gn[rep][v] = gnv[v] / sqrtf(cV[rep][v] * cV[rep][v] + V1[rep][v] * V1[rep][v] + V2[rep][v] * V2[rep][v] + a.eps);
+        }
+      }
+      for (int x = 0; x < 3; ++x) {
+        f32x4 nV[2], nW[2];
+        {
+          const int r0 = tid >> 5, c4 = tid & 31;
+#pragma unroll
+          for (int rep = 0; rep < 2; ++rep) {
+            const int row = r0 + 16 * rep;
+            const f32x4 U = *(const f32x4*)(X3 + row * PM_LD + 4 * c4);
+            const f32x4 gm = *(const f32x4*)(sGmu + x * PM_TILE + row * PM_LD + 4 * c4);
+            const bool live = row < na;
+            *(f32x4*)(X1 + row * PM_LD + 4 * c4) = live ? U * cW[rep] + Gn[rep] * cV[rep] : z4;
+            *(f32x4*)(X2 + row * PM_LD + 4 * c4) = live ? U * cV[rep] + gm * am[rep] : z4;
           }
-          *(f32x4*)(X1 + row * PM_LD + 4 * c4) = gV;
-          *(f32x4*)(X2 + row * PM_LD + 4 * c4) = gW;
+          const int xn = x < 2 ? x + 1 : 2;
+#pragma unroll
+          for (int rep = 0; rep < 2; ++rep) {
+            const int row = r0 + 16 * rep, rr = row < na ? row : 0;
+            const float* mp = mix_g + (size_t)rr * 6 * F + 4 * c4 + xn * 2 * F;
+            nV[rep] = *(const f32x4*)mp; nW[rep] = *(const f32x4*)(mp + F);
+          }
         }
         PM_BARRIER();
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         acc = pm_wfmma(Wm, team ? X2 : X1, lane, acc);
-        float* gp = sGmu + x * PM_TILE + el * PM_LD + 32 * t + 4 * hi;
-        if (team == 1) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) *(f32x4*)(gp + 8 * q) += f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        }
+        // (the two K halves meet through X0 -- g_nv is in registers by now: each team hands the partner half a tile and adds the other
+        //  half into gmu_x; two barriers per component instead of three, nobody idle in the epilogue)
+        if (team == 0) pm_split_send<0>(X0, acc, el, t, hi);
+        else pm_split_send<2>(X0, acc, el, t, hi);
         PM_BARRIER();
-        if (team == 0) {
+        {
+          float* gp = sGmu + x * PM_TILE + el * PM_LD + 32 * t + 4 * hi;
+          const float* pp = X0 + el * PM_LD + 32 * t + 4 * hi;
+          if (team == 0) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) *(f32x4*)(gp + 8 * q) += f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            for (int q = 0; q < 2; ++q) *(f32x4*)(gp + 8 * q) += *(const f32x4*)(pp + 8 * q) + f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          } else {
+#pragma unroll
+            for (int q = 2; q < 4; ++q) *(f32x4*)(gp + 8 * q) += *(const f32x4*)(pp + 8 * q) + f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          }
         }
+        cV[0] = nV[0]; cV[1] = nV[1]; cW[0] = nW[0]; cW[1] = nW[1];
       }
       PM_BARRIER();
       PM_BSTAMP(5 + 12 * (a.n_layers - 1 - l));
 
       // ================= message backward: mu entering the interaction -> X0..X2, edge records -> X3
       PmFilt<K> Wf;
-      pm_filt_load<K>(Wf, P.wf, P.bf, lane, mu0);
-      if (!mu0) {
-        for (int s = tid; s < 3 * 32 * 32; s += 512) {
-          const int x = s >> 10, row = (s >> 5) & 31, c4 = s & 31;
-          f32x4 v = z4;
-          if (row < na) v = *(const f32x4*)(muin_g + ((size_t)row * 3 + x) * F + 4 * c4);
-          *(f32x4*)(X0 + x * PM_TILE + row * PM_LD + 4 * c4) = v;
-        }
-      }
+      if (!mu0) pm_fill_tiles<6, false>(X0, tid, na, [&](int x, int r) { return muin_g + ((size_t)r * 3 + x) * F; });
       for (int le = tid; le < ne; le += 512) {
         const int64_t e = (int64_t)e0 + le;
         const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
@@ -1063,32 +1190,42 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         sEa[le] = f32x4{__int_as_float((int)(a.idx_j[e] - a0)), rx * inv, ry * inv, rz * inv};
         sEd[le] = d;
       }
+      pm_filt_load<K>(Wf, P.wf, P.bf, lane, mu0);      // (requested before the tile fill the 120 registers pushed the message loop into scratch reloads)
       PM_BARRIER();
       PM_BSTAMP(6 + 12 * (a.n_layers - 1 - l));
       {
         float* gcs_w = a.gc_scratch + (size_t)a0 * 3 * F;
-        if (geom) pm_message_bwd<K, true, true>(Wf, P.bf, sGq, sGmu, X0, c_g, gcs_w, sEa, sEd, sG, sRow, myAsg, myPhi, myFc, a.rb.kind, p0k, p1k, cutoff, lane, gcs_w + 3 * nf);
-        else if (mu0) pm_message_bwd<K, true, false>(Wf, P.bf, sGq, sGmu, X0, c_g, gcs_w, sEa, sEd, sG, sRow, myAsg, myPhi, myFc, a.rb.kind, p0k, p1k, cutoff, lane, gcs_w + 3 * nf);
-        else pm_message_bwd<K, false, false>(Wf, P.bf, sGq, sGmu, X0, c_g, gcs_w, sEa, sEd, sG, sRow, myAsg, myPhi, myFc, a.rb.kind, p0k, p1k, cutoff, lane, gcs_w + 3 * nf);
+        long long* dbgw = (a.dbg && blockIdx.x == 0 && l == a.n_layers - 1) ? a.dbg + 128 + 16 * wv : nullptr;
+        int* ctr = sRow + 34 + (l & 1);
+        if (tid == 0) sRow[34 + ((l + 1) & 1)] = 0;
+        const int* asg = dyn ? sAsg : myAsg;
+        if (geom) pm_message_bwd<K, true, true>(Wf, P.bf, sGq, sGmu, X0, c_g, gcs_w, sEa, sEd, sG, sRow, asg, myPhi, myFc, a.rb.kind, p0k, p1k, cutoff, lane, gcs_w + 3 * nf, dbgw, ctr, na, dyn);
+        else if (mu0) pm_message_bwd<K, true, false>(Wf, P.bf, sGq, sGmu, X0, c_g, gcs_w, sEa, sEd, sG, sRow, asg, myPhi, myFc, a.rb.kind, p0k, p1k, cutoff, lane, gcs_w + 3 * nf, dbgw, ctr, na, dyn);
+        else pm_message_bwd<K, false, false>(Wf, P.bf, sGq, sGmu, X0, c_g, gcs_w, sEa, sEd, sG, sRow, asg, myPhi, myFc, a.rb.kind, p0k, p1k, cutoff, lane, gcs_w + 3 * nf, dbgw, ctr, na, dyn);
         PM_BSTAMP(7 + 12 * (a.n_layers - 1 - l));
         if (geom) break;          // (uniform over the workgroup: the first interaction of an eval-mode backward ends here)
+        pm_wload(W3, P.ctx2T_p, 48, t, 24 * team, lane);      // (weights of the context GEMM: they arrive while the wave waits for the others)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the gc / gmu rows of this wave have reached L2
         PM_BARRIER();
       }
       // ================= context net backward: gc -> X0..X2 (part planes), gq += ((gc W_a2) silu'(pre_a)) W_a1
-      pm_wload(W3, P.ctx2T_p, 48, t, 24 * team, lane);
       {
         const float* gcs = a.gc_scratch + (size_t)a0 * 3 * F;
         const float* gms = a.gc_scratch + 3 * nf + (size_t)a0 * 3 * F;
-        for (int s = tid; s < 3 * 32 * 32; s += 512) {
-          const int p = s >> 10, row = (s >> 5) & 31, c4 = s & 31;
-          f32x4 v = z4, w = z4;
-          if (row < na) {
-            v = __builtin_nontemporal_load((const f32x4*)(gcs + (size_t)row * 3 * F + p * F + 4 * c4));
-            w = __builtin_nontemporal_load((const f32x4*)(gms + (size_t)row * 3 * F + p * F + 4 * c4));
-          }
-          *(f32x4*)(X0 + p * PM_TILE + row * PM_LD + 4 * c4) = v;
-          *(f32x4*)(sGmu + p * PM_TILE + row * PM_LD + 4 * c4) = w;
+        // (twelve 16-byte loads per thread in flight: one L2 round trip)
+        f32x4 vg[6], vm[6];
+        const int r0 = tid >> 5, c4 = tid & 31;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+          const int row = r0 + 16 * (it & 1), rr = row < na ? row : 0;
+          vg[it] = __builtin_nontemporal_load((const f32x4*)(gcs + (size_t)rr * 3 * F + (it >> 1) * F + 4 * c4));
+          vm[it] = __builtin_nontemporal_load((const f32x4*)(gms + (size_t)rr * 3 * F + (it >> 1) * F + 4 * c4));
+        }
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+          const int row = r0 + 16 * (it & 1);
+          *(f32x4*)(X0 + (it >> 1) * PM_TILE + row * PM_LD + 4 * c4) = row < na ? vg[it] : z4;
+          *(f32x4*)(sGmu + (it >> 1) * PM_TILE + row * PM_LD + 4 * c4) = row < na ? vm[it] : z4;
         }
       }
       PM_BARRIER();
@@ -1098,26 +1235,18 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         const float* b1 = team ? X2 : X0 + 64;
         const float* b2 = team ? X2 + 64 : X1;
         const size_t bo = (size_t)((lane & 31) * PM_LD + 4 * (lane >> 5));
+        f32x4 pa[2];
+        if (team == 0) pm_split_load_pre<0>(pa, preA_g + 32 * t, el, na, hi);
+        else pm_split_load_pre<2>(pa, preA_g + 32 * t, el, na, hi);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         acc = pm_wmma_3chunks(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
-        if (team == 1) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) *(f32x4*)(X3 + el * PM_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        }
+        if (team == 0) pm_split_send<0>(X3, acc, el, t, hi);
+        else pm_split_send<2>(X3, acc, el, t, hi);
         PM_BARRIER();
-        if (team == 0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float* xp = X3 + el * PM_LD + 32 * t + 8 * q + 4 * hi;
-            const f32x4 part = *(const f32x4*)xp;
-            f32x4 pa = z4;
-            if (el < na) pa = pm_ld<f32x4>(preA_g + 32 * t, (unsigned)((el * F + 8 * q + 4 * hi) * 4));
-            *(f32x4*)xp = f32x4{(acc[4 * q] + part.x) * pm_silu_grad(pa.x), (acc[4 * q + 1] + part.y) * pm_silu_grad(pa.y),
-                                (acc[4 * q + 2] + part.z) * pm_silu_grad(pa.z), (acc[4 * q + 3] + part.w) * pm_silu_grad(pa.w)};
-          }
-        }
+        if (team == 0) pm_split_finish<0>(X3, acc, pa, el, na, t, hi);
+        else pm_split_finish<2>(X3, acc, pa, el, na, t, hi);
       }
       PM_BARRIER();
       PM_BSTAMP(9 + 12 * (a.n_layers - 1 - l));
@@ -1146,7 +1275,12 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
 
 // ------------------------------------------------------------------------------------------ host side
 static long long* g_pm_dbg = nullptr;
-// tuning aid (scripts/painn_mol_timing.py): device buffer of >= 64 int64 receiving cycle stamps of thread 0 of workgroup 0 at the
+static int pm_assign_mode() {      // tuning: default 0 = dynamic; SPK_PM_ASSIGN=snake (1), or the cost per edge (>= 20) of the younger wave of a SIMD against 22 of the older (static greedy)
+  const char* e = getenv("SPK_PM_ASSIGN");
+  if (!e || e[0] == 'd') return 0;
+  return e[0] == 's' ? 1 : atoi(e);
+}
+// tuning aid (scripts/painn_mol_timing.py): device buffer of >= 256 int64 receiving cycle stamps of thread 0 of workgroup 0 at the
 // phase boundaries of the forward (entry 0: group start; 1 + 8 l ... 8 + 8 l: P1 .. end of interaction l).  NULL: off (production)
 extern "C" void spk_painn_mol_set_debug_buffer(void* p) { g_pm_dbg = (long long*)p; }
 static size_t painn_mol_fwd_lds() { return (size_t)(8 * PM_TILE + 8 * 64) * sizeof(float) + PM_MAXEDGES * sizeof(PmEdge) + (36 + 32) * sizeof(int); }
@@ -1200,7 +1334,7 @@ int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_
   }
   a.q0 = q0; a.q_out = q_out; a.mu_out = mu_out; a.rij = r_ij;
   a.idx_j = g->idx_j; a.rowptr = g->rowptr; a.grp_atom0 = g->grp_atom0; a.n_groups = g->n_groups;
-  a.saved = saved; a.N = g->n_atoms; a.eps = m->epsilon; a.rb = spk_radial_dev(rb); a.dbg = g_pm_dbg;
+  a.saved = saved; a.N = g->n_atoms; a.eps = m->epsilon; a.rb = spk_radial_dev(rb); a.dbg = g_pm_dbg; a.assign = pm_assign_mode();
   switch (rb->n_rbf) {
     case 20: return launch_painn_mol_fwd<20>(a, stream);
     case 16: return launch_painn_mol_fwd<16>(a, stream);
@@ -1258,7 +1392,7 @@ int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk
   }
   a.gq_out = gq_out; a.gmu_out = gmu_out; a.rij = r_ij; a.idx_j = g->idx_j; a.rowptr = g->rowptr; a.grp_atom0 = g->grp_atom0;
   a.n_groups = g->n_groups; a.saved = saved; a.gc_scratch = gc_scratch; a.gr = gr; a.gq0 = gq0; a.N = g->n_atoms; a.eps = m->epsilon;
-  a.rb = spk_radial_dev(rb); a.dbg = g_pm_dbg;
+  a.rb = spk_radial_dev(rb); a.dbg = g_pm_dbg; a.assign = pm_assign_mode();
   switch (rb->n_rbf) {
     case 20: return launch_painn_mol_bwd<20>(a, stream);
     case 16: return launch_painn_mol_bwd<16>(a, stream);
