@@ -58,6 +58,7 @@ struct PmFwdArgs {
   RadialDev rb;
   long long* dbg;           // tuning aid: cycle stamps of thread 0 of workgroup 0 (spk_painn_mol_set_debug_buffer; null in production)
   int assign;               // tuning: 0 = dynamic (default), 1 = snake over the waves, >= 20: static greedy with this cost per edge of the younger wave
+  int tiled;                // host side: 1 = launch the instance with the message on the matrix core (Gaussian bases; SPK_PM_TILED=0: row form)
 };
 #define PM_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -380,12 +381,221 @@ __device__ __forceinline__ void pm_message_write(float* __restrict__ sMu, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// P3 on the matrix core ("tiled" message; Gaussian bases; a group has at most 32 edge tiles = 16 per wave).  The filter of an edge is a contraction of n_rbf + 1 basis
+// values with the filter rows -- per edge and channel 21 FMAs that the row form above issues as packed VALU math, 62 % of its
+// instructions.  Here a TILE of 32 edge slots x 32 channels x 3 parts is three small GEMMs on v_mfma_f32_32x32x2_f32:
+//   F_p[slot, ch] = sum_k  A[slot, k] B_p[k, ch],   A = f_c(d) phi_k(d) (k < n_rbf), f_c(d) (k = n_rbf: the bias slot), 0 beyond,
+// A evaluated in registers by the lane that owns (slot = lane & 31, k = 2 kb + (lane >> 5)), B_p = the filter rows of the wave's
+// 32-channel group (33 registers per interaction).  In the accumulator a lane holds ONE channel (lane & 31) of 16 slots, and the 16
+// slots of a lane half belong to ONE centre atom (a tile = the rows of two atoms with <= 16 edges each, or one longer row split
+// over the halves): the products with the neighbour rows (LDS, conflict-free: 32 consecutive channels) are summed over the edges
+// IN THE LANE -- no lane-crossing reduction, no atomics, fixed order.  Wave (team, cg) works on channel group cg of the tiles
+// team, team + 2, ...: the MFMAs of one wave of a SIMD were meant to run beside the VALU / LDS work of the other.
+// MEASURED (round 3, cfg 3): correct -- and slower than the row form.  A tile costs 33 MFMAs (2.1 k cycles) + ~470 VALU / LDS
+// instructions per wave; per SIMD 13 tiles take 52 k cycles = the SUM of the two, not their maximum (row form: 45 k): with two
+// waves per SIMD in the same phase of the same loop the matrix pipe idles while both waves wait on the LDS round trips of the
+// products (six per pair of slots before the reads were pipelined by hand, 60 k) and both queue for it afterwards.  Kept behind
+// SPK_PM_TILED=1 (default off) with its parity tests; what it would need is a third and fourth wave per SIMD (128 registers
+// each: the accumulators alone are 48) or the products themselves as a second GEMM.
+#define PM_KB(K) (((K) + 2) / 2)
+#define PM_TILE_INTS 256          // sPhi as ints: [0, 256) the tile list (32 tiles x 8), then as floats [256, 280) centres, [280, 304) exponents
+typedef float pm_f8 __attribute__((ext_vector_type(8)));
+template <int K>
+struct PmTW { float b[3][PM_KB(K)]; };
+template <int K>
+__device__ __forceinline__ void pm_tw_load(PmTW<K>& W, const float* __restrict__ wf, const float* __restrict__ bf, int cg, int lane, bool mu0) {
+  const int hi = lane >> 5, ch = cg * 32 + (lane & 31);
+#pragma unroll
+  for (int kb = 0; kb < PM_KB(K); ++kb) {
+    const int k = 2 * kb + hi;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      float v = 0.f;
+      if (!(mu0 && p == 2)) {
+        if (k < K) v = wf[(size_t)(p * 128 + ch) * K + k];
+        else if (k == K) v = bf[p * 128 + ch];
+      }
+      W.b[p][kb] = v;
+    }
+  }
+}
+// tiles of a group (run by one wave, lane = atom): rows of more than 16 edges own a tile (first 16 edges in half A, the rest in half
+// B), the others are paired in atom order.  sTile[8 u + ...] = atom A, first edge A, edges A, atom B, first edge B, edges B.
+// Also the table of the Gaussian basis: centres and -log2(e) / (2 width^2) per k (0 beyond n_rbf).  Returns the number of tiles.
+template <int K>
+__device__ __forceinline__ int pm_build_tiles(const int* __restrict__ sRow, int na, int lane, const RadialDev& rb, int* __restrict__ sTile) {
+  const int rs = lane < na ? sRow[lane] : 0, dg = lane < na ? sRow[lane + 1] - rs : 0;
+  const bool lng = dg > 16, sht = dg > 0 && !lng;
+  const unsigned long long ml = __ballot(lng), ms = __ballot(sht);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int n_long = __popcll(ml), n_short = __popcll(ms);
+  if (lng) {
+    int* T = sTile + 8 * __popcll(ml & below);
+    T[0] = lane; T[1] = rs; T[2] = 16; T[3] = lane; T[4] = rs + 16; T[5] = dg - 16;
+  } else if (sht) {
+    const int r = __popcll(ms & below);
+    int* T = sTile + 8 * (n_long + (r >> 1));
+    if (r & 1) { T[3] = lane; T[4] = rs; T[5] = dg; }
+    else {
+      T[0] = lane; T[1] = rs; T[2] = dg;
+      if (r == n_short - 1) { T[3] = lane; T[4] = rs; T[5] = 0; }          // (no partner: an empty half B)
+    }
+  }
+  if (lane < 24) {
+    float* tb = (float*)(sTile + PM_TILE_INTS);
+    const float wd = (lane < K && rb.p1) ? rb.p1[lane] : 1.f;
+    tb[lane] = (lane < K && rb.p0) ? rb.p0[lane] : 0.f;
+    tb[24 + lane] = lane < K ? -0.5f * 1.4426950408889634f / (wd * wd) : 0.f;
+  }
+  return n_long + ((n_short + 1) >> 1);
+}
+// edge records of the tiled form: arrays of PM_ME entries each (structure of arrays: the values of two consecutive slots land in
+// adjacent registers = operands of packed math), 16 zero records behind the last edge (slots beyond a row's end read the following
+// rows' records -- finite values times a filter that is exactly 0)
+#define PM_ME (PM_MAXEDGES + 16)
+struct PmEdgeT { const int* jo; const float *ux, *uy, *uz, *d, *fc; };
+__device__ __forceinline__ PmEdgeT pm_edge_arrays(const void* base) {
+  const float* f = (const float*)base;
+  return PmEdgeT{(const int*)f, f + PM_ME, f + 2 * PM_ME, f + 3 * PM_ME, f + 4 * PM_ME, f + 5 * PM_ME};
+}
+template <int K, bool MU0>
+__device__ __forceinline__ void pm_message_tiled(const PmTW<K>& W, float* __restrict__ sQ, const float* __restrict__ sMu, const float* __restrict__ sC,
+                                                 const PmEdgeT E, const int* __restrict__ sTile, int nT, int team, int cg,
+                                                 float cutoff, int lane, pm_f8 (&dm)[3], float* __restrict__ ovf /* [na, 3, 128] global: slots beyond 8 */) {
+  constexpr int KB = PM_KB(K);
+  const int hi = lane >> 5, m = lane & 31;
+  const int hA = (m >> 2) & 1, rA = (m & 3) + 4 * (m >> 3);      // the slot this lane evaluates the basis of: (half, index in the half)
+  const int ch = cg * 32 + m;
+  const float* tb = (const float*)(sTile + PM_TILE_INTS) + hi;
+  const pm_f2 z2 = {0.f, 0.f};
+  const unsigned chb = 4u * (unsigned)ch;
+  const unsigned c_base = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)sC;
+  const unsigned mu_base = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)sMu;
+  int s = 0;
+#pragma nounroll
+  for (int u = team; u < nT; u += 2, ++s) {
+    const int* T = sTile + 8 * u;
+    const int iA = T[0], fA = T[1], nA = T[2], iB = T[3], fB = T[4], nB = T[5];
+    // ---- A operand (Gaussian bases; the Bessel models keep the row form: eleven inlined sines per instance)
+    float A[KB];
+    {
+      const int cnt = hA ? nB : nA;
+      const bool valid = rA < cnt;
+      const int e = (hA ? fB : fA) + rA;
+      const float d = E.d[e];
+      const float fc = (valid && d < cutoff) ? E.fc[e] : 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int k = 2 * kb + hi;
+        const float tt = d - tb[2 * kb];
+        const float g = fc * __builtin_amdgcn_exp2f(tb[24 + 2 * kb] * tt * tt);
+        A[kb] = (2 * kb + 1 < K || k < K) ? g : (k == K ? fc : 0.f);
+      }
+    }
+    // ---- the three filters of the tile for this wave's channel group
+    f32x16 F0, F1, F2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { F0[r] = 0.f; F1[r] = 0.f; F2[r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      F0 = PM_MFMA(A[kb], W.b[0][kb], F0);
+      F1 = PM_MFMA(A[kb], W.b[1][kb], F1);
+      if (!MU0) F2 = PM_MFMA(A[kb], W.b[2][kb], F2);
+    }
+    // ---- products with the neighbour rows, summed over the 16 slots of the lane's half (= one centre atom), two slots per step.
+    // Software-pipelined by hand: the LDS reads of step p + 1 are issued before the arithmetic of step p and PINNED there (left
+    // alone the compiler puts every read right in front of its use: six exposed LDS round trips per step, 6 k cycles per tile --
+    // three times the MFMA time of the tile)
+    const int fh = hi ? fB : fA;
+    // (explicit 32-bit LDS addresses: row offset of the neighbour [bytes, from the edge record] + channel + plane base, the three
+    //  planes of mu resp. c as immediate offsets of the reads -- as generic pointer arithmetic every read cost two or three adds)
+    typedef const __attribute__((address_space(3))) float* lds_cf;
+    unsigned jo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) jo[r] = (unsigned)E.jo[fh + r] * 4u + chb;
+    pm_f2 q2 = z2, m0 = z2, m1 = z2, m2 = z2;
+    struct Stage { pm_f2 ux, uy, uz, cq, cR, cM, ma, mb, mc; };
+    auto issue = [&](int r, Stage& S) {
+      const int e = fh + r;
+      S.ux = pm_f2{E.ux[e], E.ux[e + 1]}; S.uy = pm_f2{E.uy[e], E.uy[e + 1]}; S.uz = pm_f2{E.uz[e], E.uz[e + 1]};
+      lds_cf c0 = (lds_cf)(size_t)(jo[r] + c_base), c1 = (lds_cf)(size_t)(jo[r + 1] + c_base);
+      S.cq = pm_f2{c0[0], c1[0]}; S.cR = pm_f2{c0[PM_TILE], c1[PM_TILE]};
+      if (!MU0) {
+        lds_cf u0 = (lds_cf)(size_t)(jo[r] + mu_base), u1 = (lds_cf)(size_t)(jo[r + 1] + mu_base);
+        S.cM = pm_f2{c0[2 * PM_TILE], c1[2 * PM_TILE]};
+        S.ma = pm_f2{u0[0], u1[0]}; S.mb = pm_f2{u0[PM_TILE], u1[PM_TILE]}; S.mc = pm_f2{u0[2 * PM_TILE], u1[2 * PM_TILE]};
+      }
+    };
+    auto compute = [&](int r, const Stage& S) {
+      q2 += pm_f2{F0[r], F0[r + 1]} * S.cq;
+      const pm_f2 tR = pm_f2{F1[r], F1[r + 1]} * S.cR;
+      m0 += tR * S.ux; m1 += tR * S.uy; m2 += tR * S.uz;
+      if (!MU0) {
+        const pm_f2 tM = pm_f2{F2[r], F2[r + 1]} * S.cM;
+        m0 += tM * S.ma; m1 += tM * S.mb; m2 += tM * S.mc;
+      }
+    };
+    Stage S0, S1;
+    issue(0, S0);
+#pragma unroll
+    for (int r = 0; r < 16; r += 4) {
+      issue(r + 2, S1);
+      asm volatile("" ::: "memory");
+      compute(r, S0);
+      if (r + 4 < 16) issue(r + 4, S0);
+      asm volatile("" ::: "memory");
+      compute(r + 2, S1);
+    }
+    float dq = q2.x + q2.y, d0 = m0.x + m0.y, d1 = m1.x + m1.y, d2 = m2.x + m2.y;
+    const bool longrow = (iA == iB) && nB > 0;
+    if (longrow) { dq += __shfl_xor(dq, 32, 64); d0 += __shfl_xor(d0, 32, 64); d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64); }
+    const bool owner = hi ? (nB > 0 && !longrow) : (nA > 0);
+    const int ic = hi ? iB : iA;
+    if (owner) sQ[ic * PM_LD + ch] += dq;         // q in place: nobody's message reads q
+    // the new mu rows wait for the barrier (the old ones are still being read): slot s of the wave, selected without indexed
+    // registers; groups of more than 16 tiles park the slots beyond 8 in global memory
+    if (s < 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const bool me = (s == j); dm[0][j] = me ? d0 : dm[0][j]; dm[1][j] = me ? d1 : dm[1][j]; dm[2][j] = me ? d2 : dm[2][j]; }
+    } else if (owner) {
+      float* o = ovf + (size_t)ic * 384 + ch;
+      o[0] = d0; o[128] = d1; o[256] = d2;
+    }
+  }
+}
+__device__ __forceinline__ void pm_message_tiled_write(float* __restrict__ sMu, const int* __restrict__ sTile, int nT, int team, int cg, int lane, const pm_f8 (&dm)[3],
+                                                       const float* __restrict__ ovf) {
+  const int hi = lane >> 5, ch = cg * 32 + (lane & 31);
+  int s = 0;
+#pragma nounroll
+  for (int u = team; u < nT; u += 2, ++s) {
+    const int* T = sTile + 8 * u;
+    const int iA = T[0], nA = T[2], iB = T[3], nB = T[5];
+    const bool longrow = (iA == iB) && nB > 0;
+    const bool owner = hi ? (nB > 0 && !longrow) : (nA > 0);
+    if (owner) {
+      const int ic = hi ? iB : iA;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (s < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const bool me = (s == j); v0 = me ? dm[0][j] : v0; v1 = me ? dm[1][j] : v1; v2 = me ? dm[2][j] : v2; }
+      } else {
+        const float* o = ovf + (size_t)ic * 384 + ch;
+        v0 = o[0]; v1 = o[128]; v2 = o[256];
+      }
+      const int io = ic * PM_LD + ch;
+      sMu[io] += v0; sMu[PM_TILE + io] += v1; sMu[2 * PM_TILE + io] += v2;
+    }
+  }
+}
+
 // Every weight tile is requested one step AHEAD of its use -- right after the MFMAs of the previous tile and BEFORE that tile's
 // epilogue: loads and stores share one in-order counter on this architecture, so a load issued behind the saved-tensor stores of
 // an epilogue could not be waited for before those stores were acknowledged.
 // The two teams of four waves (wave t of a team = SIMD t) run DIFFERENT code paths with the same sequence of barriers: the register
 // allocation of a path then only sees what that team keeps alive (team 0: V / W / sum V W across P4-P6; team 1: the K = 256 tile).
-template <int K>      // n_rbf (a multiple of 4, <= PM_NRBF): compile-time so that the register-resident filter weights are indexed statically
+template <int K, bool TILED>      // K = n_rbf (a multiple of 4, <= PM_NRBF): the register-resident filter weights are indexed statically; TILED: message on the matrix core (Gaussian bases)
 __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
   constexpr int F = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -394,7 +604,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
   float* sC = sMu + 3 * PM_TILE;             // [3][32][LD]  c planes (q | R | mu part) during P2-P3; plane 0 = |V| during P4-P5
   float* sH = sC + 3 * PM_TILE;              // [32][LD]     hidden layer of the two context nets
   PmEdge* sE = (PmEdge*)(sH + PM_TILE);      // [PM_MAXEDGES]
-  float* sPhi = (float*)(sE + PM_MAXEDGES);  // [8 waves][64] radial basis of the two edges a wave is working on
+  float* sPhi = (float*)(sE + PM_MAXEDGES + 16);  // [8 waves][64] radial basis of the two edges a wave is working on (tiled form: tile list + basis table)
   int* sRow = (int*)(sPhi + 8 * 64);         // [33] local CSR
   int* sAsg = sRow + 36;                     // [8 waves][4] atoms of a wave in the message phase (balanced by row length), -1 = none
   float* sN = sC;
@@ -425,17 +635,22 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
       *(f32x4*)(sQ + row * PM_LD + 4 * c4) = v;
     }
     for (int s = tid; s < 3 * PM_TILE / 4; s += 512) *(f32x4*)(sMu + 4 * s) = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int le = tid; le < ne; le += 512) {
-      const int64_t e = (int64_t)e0 + le;
-      const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
-      PmEdge ed;
-      ed.d = sqrtf(rx * rx + ry * ry + rz * rz);
-      const float inv = 1.0f / ed.d;
-      ed.ux = rx * inv; ed.uy = ry * inv; ed.uz = rz * inv;
-      float dfc;
-      spk_cutoff_eval(cutoff, ed.d, ed.fc, dfc);
-      ed.jl = (int)(a.idx_j[e] - a0);
-      sE[le] = ed;
+    for (int le = tid; le < ne + (TILED ? 16 : 0); le += 512) {
+      PmEdge ed = {0, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (le < ne) {
+        const int64_t e = (int64_t)e0 + le;
+        const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+        ed.d = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float inv = 1.0f / ed.d;
+        ed.ux = rx * inv; ed.uy = ry * inv; ed.uz = rz * inv;
+        float dfc;
+        spk_cutoff_eval(cutoff, ed.d, ed.fc, dfc);
+        ed.jl = (int)(a.idx_j[e] - a0);
+      }
+      if (TILED) {          // structure of arrays, the neighbour as its row offset (pm_message_tiled)
+        float* f = (float*)sE;
+        ((int*)f)[le] = ed.jl * PM_LD; f[PM_ME + le] = ed.ux; f[2 * PM_ME + le] = ed.uy; f[3 * PM_ME + le] = ed.uz; f[4 * PM_ME + le] = ed.d; f[5 * PM_ME + le] = ed.fc;
+      } else sE[le] = ed;
     }
     if (wv == 7) {
       // local CSR + the atoms of every wave in the message phase (pm_assign_atoms: edges balanced per SIMD)
@@ -445,6 +660,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
       if (lane <= 32) sRow[lane] = r0;
       pm_assign_atoms(lane < na ? r1 - r0 : -1, na, lane, sAsg, a.assign);
       if (lane == 0) { sRow[34] = 0; sRow[35] = 0; }
+      if (TILED) { const int n = pm_build_tiles<K>(sRow, na, lane, a.rb, (int*)sPhi); if (lane == 0) sRow[33] = n; }      // (the row form uses sPhi per edge; the two are exclusive)
     }
     // mu entering the first interaction is zero: the backward reads it from the saved block
     for (int s = tid; s < na * 96; s += 512) pm_st<f32x4>(a.saved + 4 * nf + (size_t)a0 * 3 * F, (unsigned)(s * 16), f32x4{0.f, 0.f, 0.f, 0.f});
@@ -467,6 +683,9 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         float* mu_next_g = last ? a.mu_out : (a.saved + (int64_t)(l + 1) * per + 4 * nf);
         PM_BARRIER();
         PM_STAMP(1 + 8 * l);
+        const int nT = sRow[33];
+        constexpr bool tiled = TILED;
+        const int* sTile = (const int*)sPhi;
         // ---- P1: pre_a = W_a1 q + b (saved), silu -> sH
         {
           f32x16 acc = pm_wmma(Wt, sQ, lane, bz);
@@ -483,6 +702,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         PM_STAMP(2 + 8 * l);
         // ---- P2: c = W_a2 silu(pre_a) + b, tiles t and 8 + t (saved, LDS planes)
         PmFilt<K> Wf;
+        PmTW<K> TW;
         {
           float* c_g = S + nf;
           f32x16 acc = pm_wmma(Wt, sH, lane, bz);
@@ -494,7 +714,8 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
             if (el < na) pm_st<f32x4>(c_g + (size_t)a0 * 3 * F + 32 * t, (unsigned)((el * 3 * F + 8 * q + 4 * hi) * 4), cv);
           }
           acc = pm_wmma(Wt, sH, lane, bz);
-          pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);
+          if (tiled) pm_tw_load<K>(TW, P.wf, P.bf, t, lane, l == 0);
+          else pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -505,7 +726,16 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         PM_BARRIER();
         PM_STAMP(3 + 8 * l);
         // ---- P3: message
-        {
+        if (tiled) {
+          pm_f8 dm[3];
+          float* ovf = a.mu_out + (size_t)a0 * 3 * F;          // (written for good in P6 of the last interaction: free until then)
+          if (l == 0) pm_message_tiled<K, true>(TW, sQ, sMu, sC, pm_edge_arrays(sE), sTile, nT, 0, t, cutoff, lane, dm, ovf);
+          else pm_message_tiled<K, false>(TW, sQ, sMu, sC, pm_edge_arrays(sE), sTile, nT, 0, t, cutoff, lane, dm, ovf);
+          pm_wload(Wt, P.mix_p, 16, t, 0, lane);
+          PM_STAMP(4 + 8 * l);
+          PM_BARRIER();       // every wave has read its neighbours' rows: mu can be replaced
+          pm_message_tiled_write(sMu, sTile, nT, 0, t, lane, dm, ovf);
+        } else {
           pm_f2 rm[4][3];
           int ats[4];
           int* ctr = sRow + 34 + (l & 1);
@@ -628,15 +858,20 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         PmW Wt;
         f32x16 bz;
         PM_BARRIER();
+        const int nT = sRow[33];
+        constexpr bool tiled = TILED;
+        const int* sTile = (const int*)sPhi;
         // ---- P1: (team 0: pre_a) -- request the tile of P2
         pm_wload(Wt, P.ctx2_p, 16, 4 + t, 0, lane); bz = pm_bias_acc(P.ctx2_b, 4 + t, hi);
         PM_BARRIER();
         // ---- P2: c tile 4 + t (the R part)
         PmFilt<K> Wf;
+        PmTW<K> TW;
         {
           float* c_g = S + nf;
           f32x16 acc = pm_wmma(Wt, sH, lane, bz);
-          pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);
+          if (tiled) pm_tw_load<K>(TW, P.wf, P.bf, t, lane, l == 0);
+          else pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -646,7 +881,14 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         }
         PM_BARRIER();
         // ---- P3: message
-        {
+        if (tiled) {
+          pm_f8 dm[3];
+          float* ovf = a.mu_out + (size_t)a0 * 3 * F;          // (written for good in P6 of the last interaction: free until then)
+          if (l == 0) pm_message_tiled<K, true>(TW, sQ, sMu, sC, pm_edge_arrays(sE), sTile, nT, 1, t, cutoff, lane, dm, ovf);
+          else pm_message_tiled<K, false>(TW, sQ, sMu, sC, pm_edge_arrays(sE), sTile, nT, 1, t, cutoff, lane, dm, ovf);
+          PM_BARRIER();
+          pm_message_tiled_write(sMu, sTile, nT, 1, t, lane, dm, ovf);
+        } else {
           pm_f2 rm[4][3];
           int ats[4];
           int* ctr = sRow + 34 + (l & 1);
@@ -1283,7 +1525,7 @@ static int pm_assign_mode() {      // tuning: default 0 = dynamic; SPK_PM_ASSIGN
 // tuning aid (scripts/painn_mol_timing.py): device buffer of >= 256 int64 receiving cycle stamps of thread 0 of workgroup 0 at the
 // phase boundaries of the forward (entry 0: group start; 1 + 8 l ... 8 + 8 l: P1 .. end of interaction l).  NULL: off (production)
 extern "C" void spk_painn_mol_set_debug_buffer(void* p) { g_pm_dbg = (long long*)p; }
-static size_t painn_mol_fwd_lds() { return (size_t)(8 * PM_TILE + 8 * 64) * sizeof(float) + PM_MAXEDGES * sizeof(PmEdge) + (36 + 32) * sizeof(int); }
+static size_t painn_mol_fwd_lds() { return (size_t)(8 * PM_TILE + 8 * 64) * sizeof(float) + (PM_MAXEDGES + 16) * sizeof(PmEdge) + (36 + 32) * sizeof(int); }
 
 // Shapes / lists the molecule-resident forward covers (everything else runs the general driver of spk_painn.hip)
 bool spk_painn_mol_eligible(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb) {
@@ -1298,10 +1540,10 @@ bool spk_painn_mol_eligible(const spk_painn_t* m, const spk_graph_t* g, const sp
   return true;
 }
 
-template <int K>
-static int launch_painn_mol_fwd(const PmFwdArgs& a, hipStream_t stream) {
+template <int K, bool TILED>
+static int launch_painn_mol_fwd_t(const PmFwdArgs& a, hipStream_t stream) {
   const size_t lds = painn_mol_fwd_lds();
-  auto kern = k_painn_mol_fwd<K>;
+  auto kern = k_painn_mol_fwd<K, TILED>;
   static bool attr_set = false;
   if (!attr_set) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1314,6 +1556,10 @@ static int launch_painn_mol_fwd(const PmFwdArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
+}
+template <int K>
+static int launch_painn_mol_fwd(const PmFwdArgs& a, hipStream_t stream) {
+  return a.tiled ? launch_painn_mol_fwd_t<K, true>(a, stream) : launch_painn_mol_fwd_t<K, false>(a, stream);
 }
 
 int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
@@ -1335,6 +1581,9 @@ int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_
   a.q0 = q0; a.q_out = q_out; a.mu_out = mu_out; a.rij = r_ij;
   a.idx_j = g->idx_j; a.rowptr = g->rowptr; a.grp_atom0 = g->grp_atom0; a.n_groups = g->n_groups;
   a.saved = saved; a.N = g->n_atoms; a.eps = m->epsilon; a.rb = spk_radial_dev(rb); a.dbg = g_pm_dbg; a.assign = pm_assign_mode();
+  // the matrix-core form of the message is an EXPERIMENT, off by default (SPK_PM_TILED=1): correct (the parity tests run it), but
+  // 214 us against 197 us of the row form at cfg 3 -- see the comment at pm_message_tiled and DESIGN.md 4.3a
+  { const char* e = getenv("SPK_PM_TILED"); a.tiled = (e && e[0] == '1' && rb->kind == SPK_RBF_GAUSSIAN) ? 1 : 0; }
   switch (rb->n_rbf) {
     case 20: return launch_painn_mol_fwd<20>(a, stream);
     case 16: return launch_painn_mol_fwd<16>(a, stream);

@@ -68,6 +68,34 @@ def test_molecule_resident_painn_matches_oracle_and_general_driver(dev, sizes, n
     assert rel_err(x, x2) < 2e-6 and rel_err(v, v2) < 2e-6 and rel_err(f, f2) < 5e-6
 
 
+@pytest.mark.parametrize("sizes,n_int,n_rbf", [
+    (["aspirin"] * 7, 3, 20),
+    (["ethanol", "aspirin", "atom", "ethanol", "dimer", "ethanol", "ethanol", "aspirin", "atom", "atom"], 2, 16),
+    (["aspirin"] * 300, 3, 20),
+])
+@pytest.mark.parametrize("assign", ["snake", "30"])
+def test_tuning_switches_keep_parity(dev, sizes, n_int, n_rbf, assign):
+    """The switches of the tuning runs stay correct code: the message on the matrix core (SPK_PM_TILED=1, an experiment that is off
+    by default: DESIGN.md 4.3a) and the static atom -> wave assignments (SPK_PM_ASSIGN) against the float64 oracle and, bit for bit
+    where the summation order is the same, against the default path."""
+    b = _mixed_batch(5, sizes)
+    (e0, f0, x0, v0), _, (rep, head) = _run(b, dev, n_int, n_rbf)
+    ref = O.energy_and_forces("painn", rep, head, b, n_int, need_rep=True, dtype=torch.float64)
+    os.environ["SPK_PM_ASSIGN"] = assign
+    try:
+        (e1, f1, x1, v1), tags, _ = _run(b, dev, n_int, n_rbf)
+        os.environ["SPK_PM_TILED"] = "1"
+        (e2, f2, x2, v2), tags2, _ = _run(b, dev, n_int, n_rbf)
+    finally:
+        os.environ.pop("SPK_PM_ASSIGN", None)
+        os.environ.pop("SPK_PM_TILED", None)
+    assert "painn_mol_fwd" in tags and "painn_mol_fwd" in tags2
+    assert torch.equal(x0, x1) and torch.equal(v0, v1) and torch.equal(f0, f1)          # which wave takes a row does not change the row
+    assert rel_err(x2, ref["scalar_representation"]) < TOL and rel_err(v2, ref["vector_representation"]) < TOL
+    assert rel_err(e2, ref["energy"]) < TOL and rel_err(f2, ref["forces"]) < TOL
+    assert not torch.equal(v0, v2)                                                         # (the tiled form really ran: another summation order)
+
+
 def test_molecule_resident_painn_is_deterministic(dev):
     """No atomics anywhere in the two launches: representation AND forces are bit-reproducible."""
     b = S.molecule_batch("aspirin", 64, seed=9)
