@@ -523,6 +523,19 @@ int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g, const spk
                            const float* saved, float* scratch, float* gr, float* gq0,
                            void* stream);
 
+/* The standard potential in two launches (see spk_schnet_potential_forces_f32) for PaiNN (representation/painn.py:207-256; head with n_hidden = 64, i.e. the default build_mlp(128, 1, n_layers = 2)):
+ * pair vectors from the positions, rows of the embedding table (q0 == NULL), every interaction and the energy head in the forward
+ * launch; head gradient, every interaction and the forces (fixed summation order over each atom's edges and their reverse edges:
+ * bit-reproducible, no atomics) in the backward launch.  Lists: as spk_painn_forward_f32's molecule-resident path (block-diagonal,
+ * symmetric, <= 32 atoms and <= 384 pairs per block), g->idx_i and g->rev given.  q_out [N,F], mu_out [N,3,F], E [n_mol], F [N,3],
+ * pre_h [N,64], saved = spk_painn_saved_floats(), scratch = spk_painn_scratch_floats() floats. */
+int spk_painn_potential_supported(const spk_painn_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb);
+int spk_painn_potential_forces_f32(const spk_painn_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb,
+                                   const float* q0, const float* emb, const int64_t* Z, int32_t n_types, const float* R,
+                                   const float* offsets, const int64_t* idx_m, int64_t n_mol, int32_t all_inside, float* q_out,
+                                   float* mu_out, float* E, float* F, float* pre_h, float* saved, float* scratch, void* stream);
+
+
 /* ------------------------------------------------------------------ deployment runtime
  * Torch-free replacement of the deployed-model path: src/scripts/spkdeploy:16-40 writes a TorchScript archive
  * (+ "cutoff" metadata), interfaces/lammps/pair_schnetpack.cpp:128 loads it with torch::jit::load and :328 calls

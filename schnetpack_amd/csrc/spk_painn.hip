@@ -1199,13 +1199,8 @@ static spk_chain_layer_t mk_fwd(const float* w, const float* wT, const float* b,
             : mk_layer(w, b, nullptr, out, pre_out, nullptr, k, n_out, act, 0, 0);
 }
 
-// molecule-resident forward (spk_painn_mol.hip): block-diagonal lists with <= 32 atoms per block, F = 128
-bool spk_painn_mol_eligible(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb);
-int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
-                          const float* r_ij, float* q_out, float* mu_out, float* saved, hipStream_t stream);
-bool spk_painn_mol_bwd_eligible(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb);
-int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
-                           const float* gmu_out, const float* r_ij, const float* saved, float* gc_scratch, float* gr, float* gq0, hipStream_t stream);
+// molecule-resident kernels (spk_painn_mol.hip): block-diagonal lists with <= 32 atoms per block, F = 128
+#include "spk_painn_mol.h"
 
 static bool painn_tabulated(const spk_painn_t* m) {
   const float* tab; int nk; float dmax;
@@ -1384,4 +1379,50 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
     }
   }
   return SPK_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The standard potential  PairwiseDistances -> PaiNN -> Atomwise(sum) -> Forces  on batches of small molecules: TWO launches
+// (atomistic/distances.py:14-26, representation/painn.py:207-256, atomistic/atomwise.py:69-88, atomistic/response.py:59-76).
+static bool painn_potential_ok(const spk_painn_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb) {
+  if (!m || !head || !g || !rb || !m->layers || m->n_interactions <= 0) return false;
+  if (painn_tabulated(m)) return false;          // (experiment) registered filter tables: the stage-by-stage path runs the table kernels
+  if (!m->wpack || !painn_pack_shapes_ok(m)) return false;
+  if (!head->w1 || !head->w1t || !head->b1 || !head->w2 || head->n_hidden != 64) return false;
+  if (head->act != SPK_ACT_SSP && head->act != SPK_ACT_SILU) return false;
+  if (getenv("SPK_NO_POTENTIAL") || getenv("SPK_NO_PAINN_MOL_FWD") || !g->idx_i || !g->rev) return false;
+  return spk_painn_mol_eligible(m, g, rb) && spk_painn_mol_bwd_eligible(m, g, rb);
+}
+extern "C" int spk_painn_potential_supported(const spk_painn_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb) {
+  return painn_potential_ok(m, head, g, rb) ? 1 : 0;
+}
+
+// Energies and FORCES (= -dE/dR of the summed energy) in the two launches, nothing else: q0 may be NULL (the rows of the nuclear
+// embedding table `emb` [n_types, F] are looked up by Z inside the forward launch).  all_inside != 0: the caller guarantees that every
+// molecule's atoms lie inside ONE group of the plan and that every molecule has an atom -- the energies are then stored, not
+// accumulated, and E needs no clearing launch.  scratch: spk_painn_scratch_floats() floats.
+extern "C" int spk_painn_potential_forces_f32(const spk_painn_t* m, const spk_head_t* head, const spk_graph_t* g, const spk_radial_t* rb,
+                                              const float* q0, const float* emb, const int64_t* Z, int32_t n_types, const float* R,
+                                              const float* offsets, const int64_t* idx_m, int64_t n_mol, int32_t all_inside, float* q_out,
+                                              float* mu_out, float* E, float* F, float* pre_h, float* saved, float* scratch, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const char* who = "spk_painn_potential_forces_f32";
+  SPK_CHECK_ARG(painn_potential_ok(m, head, g, rb), "%s: model / list not covered by the fused potential (see spk_painn_potential_supported)", who);
+  SPK_CHECK_ARG(n_mol >= 0 && (n_mol == 0 || E), "%s: null energy buffer", who);
+  SPK_CHECK_ARG(q0 || (emb && Z && n_types > 0), "%s: neither features nor an embedding table", who);
+  if (n_mol > 0 && !all_inside) { int zr = spk_zero_async(E, (size_t)n_mol * sizeof(float), stream); if (zr) return zr; }
+  if (g->n_atoms == 0) return SPK_OK;
+  SPK_CHECK_ARG(R && idx_m && q_out && mu_out && F && pre_h && saved && scratch, "%s: null buffer", who);
+  PmHeadDev h;
+  h.w1 = head->w1; h.w1t = head->w1t; h.b1 = head->b1; h.w2 = head->w2; h.b2 = head->b2; h.H = head->n_hidden; h.act = head->act;
+  h.idx_m = idx_m; h.E = E; h.pre_h = pre_h; h.direct_store = all_inside ? 1 : 0;
+  const SpkPackTable ptab = painn_pack_table(m);
+  // scratch: [2][N, 3F] rows of the message backward, then the pair vectors [E, 3] (3 E <= 93 N floats of the 18 N F left)
+  //          and dE/dq_L [N, F], the gradient of the summed energy through the head -- both written by the forward launch
+  const size_t nf = (size_t)g->n_atoms * m->n_atom_basis;
+  float* rij = scratch + 6 * nf;
+  float* gq = scratch + 7 * nf;
+  SPK_TRY(spk_painn_mol_forward_ex(m, g, rb, ptab, q0, nullptr, R, offsets, q0 ? nullptr : emb, Z, &h, rij, gq, q_out, mu_out, saved, stream));
+  return spk_painn_mol_backward_ex(m, g, rb, ptab, gq, nullptr, rij, saved, scratch, nullptr, nullptr, F, stream);
 }

@@ -22,6 +22,7 @@
 // The saved tensors have exactly the layout of the general driver (spk_painn_saved_floats), so either backward can follow.
 #include "spk_common.h"
 #include "spk_pack.h"
+#include "spk_painn_mol.h"
 
 #define PM_MAXL 6
 #define PM_LD 132                 // row stride (floats) of the [32][128] tiles in LDS: conflict-free 16-byte accesses
@@ -48,6 +49,13 @@ struct PmFwdArgs {
   float* q_out;             // [N, 128]
   float* mu_out;            // [N, 3, 128]
   const float* rij;         // [E, 3]
+  const float *R, *offsets; // POT: positions [N, 3] (+ offsets [E, 3] or null) instead of rij
+  float* rij_out;           // POT: [E, 3] the pair vectors, for the backward launch
+  float* gq_out;            // POT: [N, 128] dE/dq_L = the gradient of the summed energy through the head, for the backward launch
+  const int64_t* idx_i;     // POT
+  const float* emb;         // POT with q0 == null: rows of the nuclear embedding table [n_types, 128] ...
+  const int64_t* Z;         // ... by atomic number [N]
+  PmHeadDev head;           // POT
   const int64_t* idx_j;
   const int32_t* rowptr;    // CSR of idx_i
   const int32_t* grp_atom0; // [G+1]
@@ -132,6 +140,7 @@ __device__ __forceinline__ f32x16 pm_bias_acc(const float* __restrict__ b, int t
   return acc;
 }
 __device__ __forceinline__ float pm_silu(float x) { return x * spk_sigmoid(x); }
+__device__ __forceinline__ float pm_silu_grad(float x);
 
 // phi_k(d) for the lane's own k (nn/radial.py:11-15 gaussian, :105-110 bessel), parameters preloaded
 __device__ __forceinline__ float pm_phi(int kind, float p0k, float p1k, float d) {
@@ -595,7 +604,7 @@ __device__ __forceinline__ void pm_message_tiled_write(float* __restrict__ sMu, 
 // an epilogue could not be waited for before those stores were acknowledged.
 // The two teams of four waves (wave t of a team = SIMD t) run DIFFERENT code paths with the same sequence of barriers: the register
 // allocation of a path then only sees what that team keeps alive (team 0: V / W / sum V W across P4-P6; team 1: the K = 256 tile).
-template <int K, bool TILED>      // K = n_rbf (a multiple of 4, <= PM_NRBF): the register-resident filter weights are indexed statically; TILED: message on the matrix core (Gaussian bases)
+template <int K, bool TILED, bool POT>      // K = n_rbf (a multiple of 4, <= PM_NRBF): the register-resident filter weights are indexed statically; TILED: message on the matrix core (Gaussian bases); POT: the standard potential
 __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
   constexpr int F = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -631,7 +640,10 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
     for (int s = tid; s < 32 * 32; s += 512) {
       const int row = s >> 5, c4 = s & 31;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < na) v = pm_ld<f32x4>(a.q0 + (size_t)a0 * F, (unsigned)(s * 16));
+      if (row < na) {
+        if (POT && !a.q0) v = *(const f32x4*)(a.emb + (size_t)a.Z[a0 + row] * F + 4 * c4);
+        else v = pm_ld<f32x4>(a.q0 + (size_t)a0 * F, (unsigned)(s * 16));
+      }
       *(f32x4*)(sQ + row * PM_LD + 4 * c4) = v;
     }
     for (int s = tid; s < 3 * PM_TILE / 4; s += 512) *(f32x4*)(sMu + 4 * s) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -639,7 +651,13 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
       PmEdge ed = {0, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (le < ne) {
         const int64_t e = (int64_t)e0 + le;
-        const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+        float rx, ry, rz;
+        if (POT) {          // r_ij = R_j - R_i (+ offset): atomistic/distances.py:14-26
+          const int64_t i3 = 3 * a.idx_i[e], j3 = 3 * a.idx_j[e];
+          rx = a.R[j3] - a.R[i3]; ry = a.R[j3 + 1] - a.R[i3 + 1]; rz = a.R[j3 + 2] - a.R[i3 + 2];
+          if (a.offsets) { rx += a.offsets[3 * e]; ry += a.offsets[3 * e + 1]; rz += a.offsets[3 * e + 2]; }
+          a.rij_out[3 * e] = rx; a.rij_out[3 * e + 1] = ry; a.rij_out[3 * e + 2] = rz;
+        } else { rx = a.rij[3 * e]; ry = a.rij[3 * e + 1]; rz = a.rij[3 * e + 2]; }
         ed.d = sqrtf(rx * rx + ry * ry + rz * rz);
         const float inv = 1.0f / ed.d;
         ed.ux = rx * inv; ed.uy = ry * inv; ed.uz = rz * inv;
@@ -921,6 +939,92 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         // ---- P6: (team 0: update)
       }
     }
+    if (POT) {
+      // ================= energy head on the atom tile that is still in LDS: y = w2 . act(W1 q + b1) + b2, E[mol] += sum_atoms y
+      const PmHeadDev& Hd = a.head;
+      long long my_mol = -1;
+      if (wv == 1 && lane < 32) my_mol = lane < na ? Hd.idx_m[a0 + lane] : -2;      // wave 1: molecule id of atom `lane`
+      PM_BARRIER();                    // q_L is complete
+      if (wv < 2) {                    // H = 64: two hidden tiles
+        f32x4 av[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) av[u] = pm_ld<f32x4>(Hd.w1 + (size_t)(32 * wv) * F, (unsigned)((el * F + 8 * u + 4 * hi) * 4));
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = Hd.b1[32 * wv + pm_row(r, hi)];
+        const float* brow = sQ + el * PM_LD + 4 * hi;
+        {
+          f32x4 a0v[8], a1v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { a0v[u] = av[u]; a1v[u] = av[8 + u]; }
+          acc = pm_mma8(a0v, brow, acc);
+          acc = pm_mma8(a1v, brow + 64, acc);
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          if (el < na) pm_st<f32x4>(Hd.pre_h + (size_t)a0 * 64 + 32 * wv, (unsigned)((el * 64 + 8 * q + 4 * hi) * 4), pv);
+          const f32x4 wv2 = *(const f32x4*)(Hd.w2 + 32 * wv + 8 * q + 4 * hi);
+          if (Hd.act == SPK_ACT_SILU) part += pm_silu(pv.x) * wv2.x + pm_silu(pv.y) * wv2.y + pm_silu(pv.z) * wv2.z + pm_silu(pv.w) * wv2.w;
+          else part += spk_ssp(pv.x) * wv2.x + spk_ssp(pv.y) * wv2.y + spk_ssp(pv.z) * wv2.z + spk_ssp(pv.w) * wv2.w;
+        }
+        part += __shfl_xor(part, 32, 64);
+        if (hi == 0) sH[wv * 32 + el] = part;          // (sH: the hidden tile of the last context net is no longer needed)
+        // hidden gradient of the summed energy, w2 . act'(pre) -> sC plane 1 [atom][64] (B operand of the GEMM below)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 wv2 = *(const f32x4*)(Hd.w2 + 32 * wv + 8 * q + 4 * hi);
+          f32x4 gh;
+          if (Hd.act == SPK_ACT_SILU) gh = f32x4{wv2.x * pm_silu_grad(acc[4 * q]), wv2.y * pm_silu_grad(acc[4 * q + 1]), wv2.z * pm_silu_grad(acc[4 * q + 2]), wv2.w * pm_silu_grad(acc[4 * q + 3])};
+          else gh = f32x4{wv2.x * spk_sigmoid(acc[4 * q]), wv2.y * spk_sigmoid(acc[4 * q + 1]), wv2.z * spk_sigmoid(acc[4 * q + 2]), wv2.w * spk_sigmoid(acc[4 * q + 3])};      // ssp' = sigmoid
+          if (el >= na) gh = f32x4{0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)(sC + PM_TILE + el * PM_LD + 32 * wv + 8 * q + 4 * hi) = gh;
+        }
+      }
+      PM_BARRIER();
+      // dE/dq_L = gh W1 (feature tile wv - 4 on waves 4..7, K = 64) -> global: the backward launch starts from it
+      if (wv >= 4) {
+        const int ft = wv - 4;
+        f32x4 av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = pm_ld<f32x4>(Hd.w1t + (size_t)(32 * ft) * 64, (unsigned)((el * 64 + 8 * u + 4 * hi) * 4));
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = pm_mma8(av, sC + PM_TILE + el * PM_LD + 4 * hi, acc);
+        if (el < na) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            pm_st<f32x4>(a.gq_out + (size_t)a0 * F + 32 * ft, (unsigned)((el * F + 8 * q + 4 * hi) * 4), f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+        }
+      }
+      // wave 1 holds the molecule id of atom (lane) in my_mol: segment heads add their run, one atomic per (group, molecule)
+      if (wv == 1) {
+        float y = 0.f;
+        if (lane < 32) {
+          y = (Hd.b2 ? Hd.b2[0] : 0.f) + sH[lane] + sH[32 + lane];
+          if (lane >= na) y = 0.f;
+        }
+        const long long first_mol = __shfl(my_mol, 0, 64);
+        if (__all(lane >= na || my_mol == first_mol)) {
+          float sum = y;          // the whole group is one molecule (the usual case): a butterfly over the 32 atom lanes
+#pragma unroll
+          for (int mk = 16; mk >= 1; mk >>= 1) sum += __shfl_xor(sum, mk, 64);
+          if (lane == 0 && na > 0) { if (Hd.direct_store) Hd.E[my_mol] = sum; else unsafeAtomicAdd(Hd.E + my_mol, sum); }
+        } else {
+          const long long prev = __shfl_up(my_mol, 1, 64);
+          const bool head_of_run = lane < na && (lane == 0 || prev != my_mol);
+          float sum = 0.f;
+          for (int b = 0; b < 32; ++b) {               // runs are contiguous: every head walks forward while the id matches
+            const float yb = spk_readlane_f(y, b);
+            const long long mb = __shfl(my_mol, b, 64);
+            if (head_of_run && b >= lane && b < na && mb == my_mol) sum += yb;
+          }
+          if (head_of_run) { if (Hd.direct_store) Hd.E[my_mol] = sum; else unsafeAtomicAdd(Hd.E + my_mol, sum); }
+        }
+      }
+    }
   }
 }
 
@@ -951,6 +1055,8 @@ struct PmBwdArgs {
   const float* gq_out;      // [N, F] or null (zeros)
   const float* gmu_out;     // [N, 3, F] or null (zeros)
   const float* rij;
+  const int32_t* rev;       // POT: reverse edge of every edge (symmetric list); rij, gq_out = pair vectors and dL/dq_L written by the forward launch
+  float* forces;            // POT: [N, 3] = -dE/dR, written instead of gr
   const int64_t* idx_j;
   const int32_t* rowptr;
   const int32_t* grp_atom0;
@@ -1192,7 +1298,18 @@ __device__ __forceinline__ void pm_split_finish(float* __restrict__ X, const f32
   }
 }
 
-template <int K>
+// forces = -dE/dR: r_ij = R_j - R_i, so atom i collects -gr of its own edges and +gr of their reverse edges (symmetric list: the
+// reverse of a row's edge ends at the row's atom) -- one thread per (atom, component), fixed order, no atomics
+__device__ __forceinline__ void pm_pot_forces(const float* sG, const int* sRow, const int* sRev, float* __restrict__ forces, int a0, int na) {
+  for (int s = threadIdx.x; s < 3 * na; s += 512) {
+    const int at = s / 3, c = s - 3 * at;
+    float acc = 0.f;
+    for (int le = sRow[at]; le < sRow[at + 1]; ++le) acc += sG[3 * le + c] - sG[3 * sRev[le] + c];
+    forces[3 * (size_t)(a0 + at) + c] = acc;
+  }
+}
+
+template <int K, bool POT>
 __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
   constexpr int F = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1207,6 +1324,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
   float* sFc = sPhi + 8 * 64;                // [8][128] cutoff value | slope of the edges of the row a wave works on
   int* sRow = (int*)(sFc + 8 * 128);         // [33]
   int* sAsg = sRow + 36;                     // [8][4]
+  int* sRev = sAsg + 32;                     // POT: [PM_MAXEDGES] local index of the reverse edge
   // during the message phase: X0..X2 = mu entering the interaction (component planes), X3 = edge records
   f32x4* sEa = (f32x4*)X3;                   // [PM_MAXEDGES] (local neighbour, unit vector)
   float* sEd = X3 + 4 * PM_MAXEDGES;         // [PM_MAXEDGES] distance
@@ -1236,6 +1354,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
     if (a.gmu_out) pm_fill_tiles<6, false>(sGmu, tid, na, [&](int x, int r) { return a.gmu_out + ((size_t)(a0 + r) * 3 + x) * F; });
     else for (int s = tid; s < 3 * 32 * 32; s += 512) *(f32x4*)(sGmu + (s >> 10) * PM_TILE + ((s >> 5) & 31) * PM_LD + 4 * (s & 31)) = z4;
     for (int s = tid; s < 3 * PM_MAXEDGES; s += 512) sG[s] = 0.f;
+    if (POT) for (int le = tid; le < ne; le += 512) sRev[le] = a.rev[e0 + le] - e0;
     if (wv == 7) {
       int r0 = 0;
       if (lane <= 32) r0 = a.rowptr[a0 + (lane < na ? lane : na)] - e0;
@@ -1244,7 +1363,6 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
       pm_assign_atoms(lane < na ? r1 - r0 : -1, na, lane, sAsg, a.assign);
       if (lane == 0) { sRow[34] = 0; sRow[35] = 0; }
     }
-
     for (int l = a.n_layers - 1; l >= 0; --l) {
       // (lane-derived LDS / global offsets are re-derived inside every interaction: hoisted out of the loop by the compiler they
       //  fill the prologue with dozens of live registers -- and their spills)
@@ -1511,7 +1629,11 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
     }
     // ---- the geometry gradient of every edge of the group, written exactly once
     PM_BARRIER();
-    for (int s = tid; s < 3 * ne; s += 512) a.gr[3 * (int64_t)e0 + s] = sG[s];
+    if (POT) {
+      pm_pot_forces(sG, sRow, sRev, a.forces, a0, na);
+    } else {
+      for (int s = tid; s < 3 * ne; s += 512) a.gr[3 * (int64_t)e0 + s] = sG[s];
+    }
   }
 }
 
@@ -1540,10 +1662,10 @@ bool spk_painn_mol_eligible(const spk_painn_t* m, const spk_graph_t* g, const sp
   return true;
 }
 
-template <int K, bool TILED>
+template <int K, bool TILED, bool POT>
 static int launch_painn_mol_fwd_t(const PmFwdArgs& a, hipStream_t stream) {
   const size_t lds = painn_mol_fwd_lds();
-  auto kern = k_painn_mol_fwd<K, TILED>;
+  auto kern = k_painn_mol_fwd<K, TILED, POT>;
   static bool attr_set = false;
   if (!attr_set) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1559,12 +1681,20 @@ static int launch_painn_mol_fwd_t(const PmFwdArgs& a, hipStream_t stream) {
 }
 template <int K>
 static int launch_painn_mol_fwd(const PmFwdArgs& a, hipStream_t stream) {
-  return a.tiled ? launch_painn_mol_fwd_t<K, true>(a, stream) : launch_painn_mol_fwd_t<K, false>(a, stream);
+  if (a.R) return launch_painn_mol_fwd_t<K, false, true>(a, stream);          // the standard potential
+  return a.tiled ? launch_painn_mol_fwd_t<K, true, false>(a, stream) : launch_painn_mol_fwd_t<K, false, false>(a, stream);
 }
 
-int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
-                          const float* r_ij, float* q_out, float* mu_out, float* saved, hipStream_t stream) {
+// r_ij, or (potential mode) R + offsets + head: pair vectors from the positions, q0 == null: rows of `emb` by Z, energies through the head
+int spk_painn_mol_forward_ex(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
+                             const float* r_ij, const float* R, const float* offsets, const float* emb, const int64_t* Z, const PmHeadDev* head,
+                             float* rij_out, float* gq_head_out, float* q_out, float* mu_out, float* saved, hipStream_t stream) {
   PmFwdArgs a;
+  a.R = R; a.offsets = offsets; a.idx_i = g->idx_i; a.emb = emb; a.Z = Z; a.rij_out = rij_out; a.gq_out = gq_head_out;
+  SPK_CHECK_ARG(!R || (rij_out && gq_head_out && head->w1t), "spk_painn_mol_forward: no buffers for the pair vectors / the head gradient");
+  if (head) a.head = *head; else { a.head = PmHeadDev(); }
+  SPK_CHECK_ARG((R != nullptr) == (head != nullptr), "spk_painn_mol_forward: positions and head go together");
+  SPK_CHECK_ARG(!R || (head->H == 64 && head->w1 && head->b1 && head->w2 && head->idx_m && head->E && head->pre_h && (q0 || (emb && Z))), "spk_painn_mol_forward: incomplete potential arguments");
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_painn_layer_t& P = m->layers[l];
@@ -1594,9 +1724,13 @@ int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_
   SPK_CHECK_ARG(false, "spk_painn_mol_forward: n_rbf = %d has no instance (see spk_painn_mol_eligible)", rb->n_rbf);
   return SPK_OK;
 }
+int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
+                          const float* r_ij, float* q_out, float* mu_out, float* saved, hipStream_t stream) {
+  return spk_painn_mol_forward_ex(m, g, rb, ptab, q0, r_ij, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, q_out, mu_out, saved, stream);
+}
 
 static size_t painn_mol_bwd_lds() {
-  return (size_t)(8 * PM_TILE + 3 * PM_MAXEDGES + 8 * 64 + 8 * 128) * sizeof(float) + (36 + 32) * sizeof(int);
+  return (size_t)(8 * PM_TILE + 3 * PM_MAXEDGES + 8 * 64 + 8 * 128) * sizeof(float) + (36 + 32 + PM_MAXEDGES) * sizeof(int);
 }
 // the backward additionally needs a symmetric list (the transposed sums run through the reverse edge)
 bool spk_painn_mol_bwd_eligible(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb) {
@@ -1605,10 +1739,10 @@ bool spk_painn_mol_bwd_eligible(const spk_painn_t* m, const spk_graph_t* g, cons
   return g->symmetric != 0;
 }
 
-template <int K>
-static int launch_painn_mol_bwd(const PmBwdArgs& a, hipStream_t stream) {
+template <int K, bool POT>
+static int launch_painn_mol_bwd_t(const PmBwdArgs& a, hipStream_t stream) {
   const size_t lds = painn_mol_bwd_lds();
-  auto kern = k_painn_mol_bwd<K>;
+  auto kern = k_painn_mol_bwd<K, POT>;
   static bool attr_set = false;
   if (!attr_set) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1623,10 +1757,20 @@ static int launch_painn_mol_bwd(const PmBwdArgs& a, hipStream_t stream) {
   return SPK_OK;
 }
 
-// gq_out / gmu_out may be null (zeros); gr [E, 3] is overwritten (no clearing needed); gq0 may be null; gc_scratch: 2 x [N, 3F] floats
-int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
-                           const float* gmu_out, const float* r_ij, const float* saved, float* gc_scratch, float* gr, float* gq0, hipStream_t stream) {
+template <int K>
+static int launch_painn_mol_bwd(const PmBwdArgs& a, hipStream_t stream) {
+  return a.forces ? launch_painn_mol_bwd_t<K, true>(a, stream) : launch_painn_mol_bwd_t<K, false>(a, stream);
+}
+
+// gq_out / gmu_out may be null (zeros); gr [E, 3] is overwritten (no clearing needed); gq0 may be null; gc_scratch: 2 x [N, 3F] floats.
+// Potential mode (forces given; r_ij, gq_out = the pair vectors and dL/dq_L = head gradient written by the forward launch; gr / gq0
+// null): forces [N, 3] = -dE/dR are written instead of gr.
+int spk_painn_mol_backward_ex(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
+                              const float* gmu_out, const float* r_ij, const float* saved,
+                              float* gc_scratch, float* gr, float* gq0, float* forces, hipStream_t stream) {
   PmBwdArgs a;
+  a.rev = g->rev; a.forces = forces;
+  SPK_CHECK_ARG(!forces || (g->rev && r_ij && gq_out && !gr && !gq0), "spk_painn_mol_backward: incomplete potential arguments");
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_painn_layer_t& P = m->layers[l];
@@ -1651,4 +1795,8 @@ int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk
   }
   SPK_CHECK_ARG(false, "spk_painn_mol_backward: n_rbf = %d has no instance", rb->n_rbf);
   return SPK_OK;
+}
+int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
+                           const float* gmu_out, const float* r_ij, const float* saved, float* gc_scratch, float* gr, float* gq0, hipStream_t stream) {
+  return spk_painn_mol_backward_ex(m, g, rb, ptab, gq_out, gmu_out, r_ij, saved, gc_scratch, gr, gq0, nullptr, stream);
 }

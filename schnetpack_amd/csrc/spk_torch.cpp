@@ -841,6 +841,64 @@ std::tuple<Tensor, Tensor, Tensor> schnet_potential_forces_raw(const c10::option
   return {std::get<0>(fw), at::neg(std::get<0>(bw)), std::get<1>(fw)};
 }
 
+// The same for PaiNN: (E, F = -dE/dR, scalar_representation, vector_representation), eval only, no autograd node.  Batches of small
+// molecules: TWO launches (spk_painn_potential_forces_f32); every other list runs the same stages through their own kernels.
+std::tuple<Tensor, Tensor, Tensor, Tensor> painn_potential_forces_raw(const c10::optional<Tensor>& q0_in, const c10::optional<Tensor>& emb_in, const Tensor& Z_in,
+                                                                      const Tensor& R_in, const c10::optional<Tensor>& offsets_in, const Tensor& idx_i,
+                                                                      const Tensor& idx_j, const Tensor& idx_m_in, int64_t n_mol, at::TensorList ws,
+                                                                      at::TensorList head, bool shared_filters, double eps, int64_t rbf_kind,
+                                                                      const Tensor& p0_in, const c10::optional<Tensor>& p1_in, double cutoff, int64_t head_act) {
+  const char* who = "painn_potential_forces";
+  const bool has_q0 = q0_in.has_value() && q0_in->defined();
+  TORCH_CHECK(has_q0 || (emb_in.has_value() && emb_in->defined()), who, ": neither features nor an embedding table");
+  TORCH_CHECK(head.size() == 4, who, ": head = [outnet.0.weight, outnet.0.bias, outnet.1.weight, outnet.1.bias]");
+  Tensor R = f32(R_in.detach(), who);
+  Tensor off = opt_f32(offsets_in, who);
+  Tensor idx_m = i64(idx_m_in, who), Z = i64(Z_in, who);
+  Tensor q0 = has_q0 ? f32(q0_in->detach(), who) : Tensor();
+  Tensor emb = has_q0 ? Tensor() : f32(emb_in->detach(), who);
+  const int64_t N = R.size(0), F = has_q0 ? q0.size(1) : emb.size(1);
+  c10::DeviceGuard guard(R.device());
+  c10::optional<Tensor> off_d = off.defined() ? c10::optional<Tensor>(off) : c10::optional<Tensor>();
+  auto plan = find_plan(idx_i, idx_j, N);
+  if (!plan || plan->filter_pairs < 0) {       // first call on this list: the plan needs the geometry once
+    Tensor r = pairwise_raw(R, idx_i, idx_j, off_d);
+    plan = get_plan(idx_i, idx_j, N, r);
+    decide_filter(*plan, r, cutoff);
+  }
+  auto M = get_painn(ws, F, shared_filters, eps);
+  auto H = get_head(head[0], head[1], head[2], head[3]);
+  Tensor p0 = f32(p0_in, who), p1 = opt_f32(p1_in, who);
+  spk_graph_t g = plan->graph();
+  spk_radial_t rb = radial_of(rbf_kind, p0, p1, cutoff);
+  spk_head_t hd;
+  hd.w1 = fp(H->w1); hd.w1t = fp(H->w1t); hd.b1 = fp(H->b1); hd.w2 = fp(H->w2); hd.b2 = fp(H->b2);
+  hd.n_hidden = (int32_t)H->w1.size(0); hd.act = (int32_t)head_act;
+  const bool fused = H->w1.dim() == 2 && H->w1.size(1) == F && H->w2.numel() == H->w1.size(0) && H->b1.defined() &&
+                     spk_painn_potential_supported(&M->m, &hd, &g, &rb) != 0;
+  if (fused) {
+    const bool inside = molecules_inside_groups(*plan, idx_m, n_mol);
+    Tensor q = at::empty({N, F}, R.options()), mu = at::empty({N, 3, F}, R.options());
+    Tensor E = at::empty({n_mol}, R.options()), Fo = at::empty({N, 3}, R.options());
+    Tensor pre_h = at::empty({N, (int64_t)hd.n_hidden}, R.options());
+    Tensor saved = at::empty({std::max<int64_t>(1, spk_painn_saved_floats(&M->m, N))}, R.options());
+    Tensor scratch = at::empty({std::max<int64_t>(1, spk_painn_scratch_floats(&M->m, N))}, R.options());
+    check(spk_painn_potential_forces_f32(&M->m, &hd, &g, &rb, fp(q0), fp(emb), Z.data_ptr<int64_t>(), emb.defined() ? (int32_t)emb.size(0) : 0, fp(R), fp(off),
+                                         idx_m.data_ptr<int64_t>(), n_mol, inside ? 1 : 0, fpm(q), fpm(mu), fpm(E), fpm(Fo), fpm(pre_h), fpm(saved), fpm(scratch),
+                                         stream_of(R)));
+    return {E, Fo, q, mu};
+  }
+  if (!has_q0) q0 = emb.index_select(0, Z);
+  Tensor r = pairwise_raw(R, idx_i, idx_j, off_d);
+  std::shared_ptr<Plan> pl;
+  auto fw = painn_forward_raw(q0, r, idx_i, idx_j, ws, shared_filters, eps, rbf_kind, p0, p1_in, cutoff, &pl);
+  auto hdf = atomwise_forward_raw(std::get<0>(fw), head[0], head[1], head[2], head[3], idx_m, n_mol, head_act);
+  Tensor gq = atomwise_backward_raw(at::ones({n_mol}, R.options()), Tensor(), std::get<2>(hdf), head[0], head[2], idx_m, n_mol, head_act);
+  auto bw = painn_backward_raw(gq, Tensor(), r, std::get<2>(fw), std::get<3>(fw), *pl, ws, F, shared_filters, eps, rbf_kind, p0, p1_in, cutoff, false);
+  Tensor gR = pairwise_bwd_raw(std::get<0>(bw), idx_i, idx_j, N);
+  return {std::get<0>(hdf), at::neg(gR), std::get<0>(fw), std::get<1>(fw)};
+}
+
 // ------------------------------------------------------------------------------------------------ dispatcher handles
 template <class Sig>
 c10::TypedOperatorHandle<Sig> op_handle(const char* name) {
@@ -1157,7 +1215,7 @@ struct EvalGuardFn : public torch::autograd::Function<EvalGuardFn> {
     return y.alias();
   }
   static variable_list backward(AutogradContext* ctx, variable_list) {
-    TORCH_CHECK(false, "spk_hip::schnet_potential_forces", kEvalOnly);
+    TORCH_CHECK(false, "spk_hip::schnet_potential_forces / painn_potential_forces", kEvalOnly);
     return variable_list((size_t)ctx->saved_data["n"].toInt() + 1);
   }
 };
@@ -1257,6 +1315,13 @@ std::tuple<Tensor, Tensor, Tensor> schnet_potential_forces_meta(const c10::optio
                                                                 double, int64_t) {
   const int64_t F = (x0.has_value() && x0->defined()) ? x0->size(1) : emb->size(1);
   return {at::empty({n_mol}, R.options()), at::empty_like(R), at::empty({R.size(0), F}, R.options())};
+}
+std::tuple<Tensor, Tensor, Tensor, Tensor> painn_potential_forces_meta(const c10::optional<Tensor>& q0, const c10::optional<Tensor>& emb, const Tensor&, const Tensor& R,
+                                                                       const c10::optional<Tensor>&, const Tensor&, const Tensor&, const Tensor&, int64_t n_mol,
+                                                                       at::TensorList, at::TensorList, bool, double, int64_t, const Tensor&,
+                                                                       const c10::optional<Tensor>&, double, int64_t) {
+  const int64_t F = (q0.has_value() && q0->defined()) ? q0->size(1) : emb->size(1);
+  return {at::empty({n_mol}, R.options()), at::empty_like(R), at::empty({R.size(0), F}, R.options()), at::empty({R.size(0), 3, F}, R.options())};
 }
 std::tuple<Tensor, Tensor, Tensor, Tensor> schnet_potential_forward_meta(const Tensor& x0, const Tensor&, const c10::optional<Tensor>&, const Tensor& idx_i,
                                                                          const Tensor&, const Tensor&, int64_t n_mol, at::TensorList ws, at::TensorList head,
@@ -1596,6 +1661,7 @@ TORCH_LIBRARY(spk_hip, m) {
   // PairwiseDistances -> SchNet -> Atomwise(sum): (energy, scalar_representation); two launches where the list allows it
   m.def("schnet_potential(Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor)");
   m.def("schnet_potential_forces(Tensor? x0, Tensor? embedding, Tensor Z, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor, Tensor)");  // eval: (E, forces, scalar_representation), no autograd
+  m.def("painn_potential_forces(Tensor? q0, Tensor? embedding, Tensor Z, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, bool shared_filters, float epsilon, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor, Tensor, Tensor)");  // eval: (E, forces, scalar_representation, vector_representation), no autograd
   m.def("potential_plan(Tensor idx_i, Tensor idx_j, int n_atoms, Tensor idx_m, int n_mol) -> int");
   m.def("eval_guard(Tensor(a) y, Tensor[] params) -> Tensor(a)");      // alias of y whose backward raises the eval-only message
   m.def("schnet_potential_forward(Tensor x0, Tensor R, Tensor? offsets, Tensor idx_i, Tensor idx_j, Tensor idx_m, int n_mol, Tensor[] weights, Tensor[] head, int n_filters, int rbf_kind, Tensor rbf_p0, Tensor? rbf_p1, float cutoff, int head_act) -> (Tensor, Tensor, Tensor, Tensor)");
@@ -1641,6 +1707,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm d
   m.impl("schnet_potential", schnet_potential_dev);
   m.impl("schnet_potential_forward", schnet_potential_forward_raw);
   m.impl("schnet_potential_forces", schnet_potential_forces_raw);
+  m.impl("painn_potential_forces", painn_potential_forces_raw);
   m.impl("eval_guard", eval_guard_dev);
   m.impl("potential_plan", potential_plan_op);
   m.impl("schnet_potential_backward", schnet_potential_backward_raw);
@@ -1680,7 +1747,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CPU, m) {
   for (const char* name : {"scatter_add", "gather", "pairwise", "pairwise_backward", "dense", "radial_cutoff", "schnet", "painn", "atomwise",
                            "dense_forward", "dense_backward_input", "radial_cutoff_backward", "schnet_forward", "schnet_backward", "painn_forward",
                            "painn_backward", "atomwise_forward", "atomwise_backward", "edge_plan", "static_declare", "static_declare_range", "schnet_potential",
-                           "schnet_potential_forward", "schnet_potential_backward", "schnet_potential_forces", "potential_plan"})
+                           "schnet_potential_forward", "schnet_potential_backward", "schnet_potential_forces", "painn_potential_forces", "potential_plan"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
   for (const char* name : kTrainOps) m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }
@@ -1707,6 +1774,7 @@ TORCH_LIBRARY_IMPL(spk_hip, Meta, m) {
   m.impl("schnet_potential", schnet_potential_meta);
   m.impl("schnet_potential_forward", schnet_potential_forward_meta);
   m.impl("schnet_potential_forces", schnet_potential_forces_meta);
+  m.impl("painn_potential_forces", painn_potential_forces_meta);
   m.impl("eval_guard", eval_guard_dev);
   m.impl("schnet_potential_backward", schnet_potential_backward_meta);
   train_impl_meta(m);

@@ -30,7 +30,8 @@ def classify_potential(model) -> int:
     Works on any model with the reference's ``NeuralNetworkPotential`` layout (model/base.py:132-190), i.e. also on the
     reference's own class around the HIP modules."""
     rep, ins, outs = model.representation, list(model.input_modules), list(model.output_modules)
-    if not (isinstance(rep, SchNet) and rep._fused and len(rep.interactions) > 0):
+    is_painn = isinstance(rep, PaiNN)
+    if not (isinstance(rep, (SchNet, PaiNN)) and rep._fused and len(rep.interactions) > 0):
         return 0
     if not (len(ins) == 1 and type(ins[0]) is PairwiseDistances and len(outs) >= 1):
         return 0
@@ -42,7 +43,7 @@ def classify_potential(model) -> int:
         return 0
     if (len(outs) == 2 and outs[1].calc_forces and outs[1].energy_key == head.output_key and head.aggregation_mode == "sum"):
         return 2
-    return 1
+    return 0 if is_painn else 1          # (PaiNN: only the energies-and-forces form is one operator)
 
 
 def potential_forward(model, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -72,6 +73,21 @@ def potential_forces_forward(model, inputs: Dict[str, torch.Tensor]) -> Dict[str
     kind, p0, p1 = rep.radial_basis.kernel_params()
     l0, l1 = head.outnet[0], head.outnet[1]
     plain = type(rep.embedding) is nn.Embedding and len(rep.electronic_embeddings) == 0
+    if isinstance(rep, PaiNN):
+        with torch.no_grad():
+            E, F, x, mu = torch.ops.spk_hip.painn_potential_forces(
+                None if plain else rep.embed(inputs), rep.embedding.weight if plain else None, inputs[properties.Z], inputs[properties.R],
+                inputs.get(properties.offsets), inputs[properties.idx_i], inputs[properties.idx_j], idx_m, head._n_molecules(inputs, idx_m),
+                rep.interaction_weights(), [l0.weight, l0.bias, l1.weight, l1.bias], rep.share_filters, rep.epsilon, kind, p0, p1,
+                rep.cutoff_fn.cutoff_value(), head._head_act)
+        if torch.is_grad_enabled():
+            guard = [l0.weight]
+            E, F = torch.ops.spk_hip.eval_guard(E, guard), torch.ops.spk_hip.eval_guard(F, guard)
+        inputs["scalar_representation"] = x
+        inputs["vector_representation"] = mu
+        inputs[head.output_key] = E
+        inputs[frc.force_key] = F
+        return inputs
     with torch.no_grad():
         x0 = None if plain else rep.embed(inputs)
         E, F, x = torch.ops.spk_hip.schnet_potential_forces(

@@ -152,6 +152,24 @@ class PaiNN(nn.Module):
                 and hasattr(self.cutoff_fn, "cutoff_value")
                 and self.n_atom_basis <= 1024 and 1 <= n_rbf <= 256)
 
+    def interaction_weights(self) -> List[torch.Tensor]:
+        """Nine tensors per interaction in the order of spk_painn_layer_t (include/spk_hip.h), then filter_net.{weight, bias}."""
+        ws: List[torch.Tensor] = []
+        for interaction, mixing in zip(self.interactions, self.mixing):
+            ws += interaction.fused_weights()
+            ws += mixing.fused_weights()
+        fb = self.filter_net.bias
+        assert fb is not None
+        ws.append(self.filter_net.weight)
+        ws.append(fb)
+        return ws
+
+    def embed(self, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
+        q = self.embedding(inputs[properties.Z])
+        for embedding in self.electronic_embeddings:
+            q = q + embedding(q, inputs)
+        return q
+
     def forward(self, inputs: Dict[str, torch.Tensor]):
         atomic_numbers = inputs[properties.Z]
         r_ij = inputs[properties.Rij]
@@ -164,15 +182,7 @@ class PaiNN(nn.Module):
             q = q + embedding(q, inputs)
 
         if self._fused and not self.training:
-            # nine tensors per interaction in the order of spk_painn_layer_t (include/spk_hip.h), then filter_net.{weight, bias}
-            ws: List[torch.Tensor] = []
-            for interaction, mixing in zip(self.interactions, self.mixing):
-                ws += interaction.fused_weights()
-                ws += mixing.fused_weights()
-            fb = self.filter_net.bias
-            assert fb is not None
-            ws.append(self.filter_net.weight)
-            ws.append(fb)
+            ws = self.interaction_weights()
             kind, p0, p1 = self.radial_basis.kernel_params()
             q, mu = torch.ops.spk_hip.painn(q, r_ij, idx_i, idx_j, ws, self.share_filters, self.epsilon, kind, p0, p1,
                                             self.cutoff_fn.cutoff_value())

@@ -23,7 +23,9 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _run(batch, dev, n_int=3, n_rbf=20, radial="gaussian", general=False, **rep_kw):
+def _run(batch, dev, n_int=3, n_rbf=20, radial="gaussian", general=False, potential=False, **rep_kw):
+    """potential=False: representation operator + head + Forces (the kernels' plain instances); True: the standard potential as ONE
+    operator (pair vectors, embedding rows, head and forces inside the two launches)."""
     from schnetpack_amd import _lib, model as M
     rep = O.init_painn_params(128, n_int, n_rbf, 5.0, radial=radial, **rep_kw)
     head = O.init_atomwise_params(128, seed=1)
@@ -32,6 +34,8 @@ def _run(batch, dev, n_int=3, n_rbf=20, radial="gaussian", general=False, **rep_
     m = m.to(dev).eval()
     if general:
         os.environ["SPK_NO_PAINN_MOL"] = "1"
+    if not potential:
+        os.environ["SPK_NO_POTENTIAL"] = "1"
     try:
         _lib.profile_enable(True)
         _lib.profile_report()
@@ -43,6 +47,7 @@ def _run(batch, dev, n_int=3, n_rbf=20, radial="gaussian", general=False, **rep_
     finally:
         _lib.profile_enable(False)
         os.environ.pop("SPK_NO_PAINN_MOL", None)
+        os.environ.pop("SPK_NO_POTENTIAL", None)
     return res, tags, (rep, head)
 
 
@@ -94,6 +99,28 @@ def test_tuning_switches_keep_parity(dev, sizes, n_int, n_rbf, assign):
     assert rel_err(x2, ref["scalar_representation"]) < TOL and rel_err(v2, ref["vector_representation"]) < TOL
     assert rel_err(e2, ref["energy"]) < TOL and rel_err(f2, ref["forces"]) < TOL
     assert not torch.equal(v0, v2)                                                         # (the tiled form really ran: another summation order)
+
+
+@pytest.mark.parametrize("sizes,n_int,n_rbf,radial", [
+    (["aspirin"] * 7, 3, 20, "gaussian"),
+    (["ethanol", "aspirin", "atom", "ethanol", "dimer", "ethanol", "ethanol", "aspirin", "atom", "atom"], 3, 20, "gaussian"),
+    (["ethanol"] * 40, 2, 16, "bessel"),
+    (["aspirin"] * 300, 3, 20, "gaussian"),
+])
+def test_standard_potential_in_two_launches(dev, sizes, n_int, n_rbf, radial):
+    """PairwiseDistances -> PaiNN -> Atomwise -> Forces as ONE operator (torch.ops.spk_hip.painn_potential_forces): exactly the two
+    molecule kernels run, energies / forces / representations match the float64 oracle and the operator-by-operator path."""
+    b = _mixed_batch(7, sizes)
+    (e, f, x, v), tags, (rep, head) = _run(b, dev, n_int, n_rbf, radial, potential=True)
+    assert set(tags) == {"painn_mol_fwd", "painn_mol_bwd"}, tags
+    ref = O.energy_and_forces("painn", rep, head, b, n_int, need_rep=True, dtype=torch.float64)
+    assert rel_err(x, ref["scalar_representation"]) < TOL and rel_err(v, ref["vector_representation"]) < TOL
+    assert rel_err(e, ref["energy"]) < TOL and rel_err(f, ref["forces"]) < TOL
+    (e2, f2, x2, v2), tags2, _ = _run(b, dev, n_int, n_rbf, radial, potential=False)
+    assert len(tags2) > 2
+    assert rel_err(e, e2) < 2e-6 and rel_err(f, f2) < 5e-6 and rel_err(x, x2) < 2e-6 and rel_err(v, v2) < 2e-6
+    (e3, f3, _, _), _, _ = _run(b, dev, n_int, n_rbf, radial, potential=True)
+    assert torch.equal(f, f3) and torch.equal(e, e3)                  # no atomics on the way to the forces
 
 
 def test_molecule_resident_painn_is_deterministic(dev):

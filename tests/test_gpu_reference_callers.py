@@ -166,13 +166,14 @@ def test_unpickled_model_with_fused_head_install(dev, ns):
 def test_fused_potential_install_routes_the_reference_model_to_the_two_launch_operator(dev, ns):
     """install(fused_head=True, fused_potential=True): the REFERENCE's NeuralNetworkPotential.forward hands the standard
     potential (PairwiseDistances -> SchNet -> Atomwise -> Forces) to the fused operators in eval mode -- same energies and forces
-    as the reference on the CPU, exactly two profiled launches per call -- and keeps its own forward for everything else
-    (training mode, PaiNN)."""
+    as the reference on the CPU, exactly two profiled launches per call, SchNet and PaiNN -- and keeps its own forward for
+    everything else (training mode, other compositions)."""
     import schnetpack_amd.install as inst
     from schnetpack_amd import _lib
     b = S.molecule_batch("aspirin", 6, seed=21)
     m_ref = _build_reference_model(ns, "schnet").eval()
     out_ref = m_ref(_ref_inputs(b))
+    out_pref = _build_reference_model(ns, "painn").eval()(_ref_inputs(b))
     inst.install(sys.modules["schnetpack"], fused_head=True, fused_potential=True)
     m = _build_reference_model(ns, "schnet").to(dev).eval()
     assert type(m) is ns.model.NeuralNetworkPotential and getattr(type(m).forward, "_spk_hip_patched", False)
@@ -191,9 +192,20 @@ def test_fused_potential_install_routes_the_reference_model_to_the_two_launch_op
     m.train()
     o = m(_ref_inputs(b, dev))
     assert o["forces"].requires_grad
-    # another architecture is left alone
+    # the PaiNN standard potential is routed the same way (torch.ops.spk_hip.painn_potential_forces) ...
     mp_ = _build_reference_model(ns, "painn").to(dev).eval()
     op = mp_(_ref_inputs(b, dev))
-    assert mp_.__dict__["_spk_hip_mode"] == 0 and torch.isfinite(op["forces"]).all()
+    _lib.profile_enable(True)
+    _lib.profile_report()
+    op = mp_(_ref_inputs(b, dev))
+    prof_p = _lib.profile_report()
+    _lib.profile_enable(False)
+    assert mp_.__dict__["_spk_hip_mode"] == 2 and set(prof_p) == {"painn_mol_fwd", "painn_mol_bwd"}, prof_p
+    assert rel_err(op["energy"].cpu(), out_pref["energy"]) < TOL and rel_err(op["forces"].cpu(), out_pref["forces"]) < TOL
+    # ... and a model that is not the standard potential (stress requested) is left alone
+    ms = _build_reference_model(ns, "schnet").to(dev).eval()
+    ms.output_modules[1].calc_stress = True
+    from schnetpack_amd import model as M
+    assert M.classify_potential(ms) == 0
     inst.uninstall()
     assert not getattr(ns.model.NeuralNetworkPotential.forward, "_spk_hip_patched", False)
