@@ -145,6 +145,8 @@ _PROTOS = {
     "spk_schnet_potential_forward_f32": (ctypes.c_int, [P(SchnetT), P(HeadT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_f, c_f]),
     "spk_schnet_potential_forces_f32": (ctypes.c_int, [P(SchnetT), P(HeadT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_i64, c_i32, c_f, c_f, c_f, c_f, c_f, c_f]),
     "spk_schnet_potential_backward_f32": (ctypes.c_int, [P(SchnetT), P(HeadT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "spk_painn_potential_supported": (ctypes.c_int, [P(PainnT), P(HeadT), P(GraphT), P(RadialT)]),
+    "spk_painn_potential_forces_f32": (ctypes.c_int, [P(PainnT), P(HeadT), P(GraphT), P(RadialT), c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_i64, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "spk_painn_message_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
     "spk_painn_message_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_f]),
     "spk_painn_set_tile": (None, [c_i32]),

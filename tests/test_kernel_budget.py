@@ -23,7 +23,10 @@ BUDGET = {
     # molecule-resident PaiNN (round 3): both launches at the 256-register limit; what is left in scratch are values parked in the
     # prologue and a handful of reloads in the message loops -- when whole prefetched weight tiles were being spilled behind their
     # loads the figures were 2 176 / 652 B per lane and every Dense phase waited for a chain of L2 round trips
-    "spk_painn_mol.hip": {"k_painn_mol_fwdILi20E": (256, 2), "k_painn_mol_bwdILi20E": (448, 2)},
+    # instances <n_rbf, tiled, potential> / <n_rbf, potential>: the row form (default) with and without the two-launch potential; the
+    # tile-form experiment (SPK_PM_TILED=1) is not a budgeted path
+    "spk_painn_mol.hip": {"k_painn_mol_fwdILi20ELb0ELb0E": (256, 2), "k_painn_mol_fwdILi20ELb0ELb1E": (320, 2),
+                          "k_painn_mol_bwdILi20ELb0E": (448, 2), "k_painn_mol_bwdILi20ELb1E": (448, 2)},
 }
 
 
