@@ -868,7 +868,7 @@ def main():
                 "contract_path_ms": round(ms_c, 4), "tabulated_ms": round(ms_t, 4),
                 "contract_M_edge_messages_per_s": round(Ew * 3 / ms_c / 1e3, 1), "tabulated_M_edge_messages_per_s": round(Ew * 3 / ms_t / 1e3, 1),
                 "forces_rel_diff_tabulated_vs_contract": float((f_t - f_c).abs().max() / f_c.abs().max()),
-                "note": "the contract (fp32 MFMA) path is what every headline number of this line runs; table error: value ~4e-8, slope ~4e-6 of max |dW/dd| (fp32 table)"}}
+                "note": "the contract (fp32 MFMA) path is what every headline number of this line runs; table error: value ~4e-8, slope ~1.6e-6 of max |dW/dd| at 512 knots (2e-7 at 1024)"}}
         except Exception as exc:  # pragma: no cover
             experiments = {"tabulated_filters": {"error": str(exc)[:300]}}
     drop_in = None

@@ -409,7 +409,7 @@ int spk_schnet_potential_forces_f32(const spk_schnet_t* m, const spk_head_t* hea
 
 /* EXPERIMENT (eval only, not on any default path; scripts/tab_filter_experiment.py): continuous-filter convolution
  * (representation/schnet.py:60-67) with the filter W_l(d) f_c(d) read from a cubic-Hermite table instead of the filter network:
- *   y[i, c] = sum_{e in row(i)} h[idx_j[e], c] * T_c(|r_e|),  table [n_knots, 128, 2] = (value, slope * step) at d = n d_max / (n_knots - 1),
+ *   y[i, c] = sum_{e in row(i)} h[idx_j[e], c] * T_c(|r_e|),  table [n_knots, 128, 4] = (value, slope * step, next value - value, next slope * step) at d = n d_max / (n_knots - 1),
  * zero at and beyond the cutoff.  Sorted list (g->rowptr), nf = 128; y [N, 128] is overwritten. */
 int spk_cfconv_tab_f32(const spk_graph_t* g, const float* r_ij, const float* h, const float* table, int32_t n_knots, float d_max,
                        float cutoff, int32_t nf, float* y, void* stream);

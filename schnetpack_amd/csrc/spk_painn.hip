@@ -57,7 +57,8 @@ template <> struct MsgVec<2> {
 
 // GEOM (backward only): form the geometry gradient gr alone -- no neighbour gradients are gathered, no gc / gmu
 // MU0: mu == 0 everywhere (first interaction): the mu rows of the neighbours are not gathered
-// TAB (experiment, opt-in): the raw filter and its slope come from a cubic-Hermite table (two 16-byte reads per part and
+// TAB (experiment, opt-in): the raw filter and its slope come from a cubic-Hermite table (one 16-byte read per part and channel: knot
+// value, slope, difference to the next knot, next slope;
 // knot for the lane's two channels) instead of NRBF FMAs per channel from register-resident weights (which are then not loaded)
 template <int VPL, int NRBF, bool BWD, bool GEOM = false, bool MU0 = false, bool TAB = false>
 __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
@@ -158,24 +159,24 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
             const float fc = spk_readlane_f(fcl, t), dfc = spk_readlane_f(dfcl, t);
             VT P[3], Pd[3] = {MV::zero(), MV::zero(), MV::zero()};
             if (TAB) {
-              // raw filter and slope of the lane's channels from the table: knots n, n + 1 of [n_knots][3F][2]
+              // raw filter and slope of the lane's channels from the table: interval n of [n_knots][3F][4]
               const float u = d * a.tab_inv_step;
               int n = (int)u;
               n = n < a.tab_knots - 2 ? n : a.tab_knots - 2;
               const float sx = u - (float)n, s2 = sx * sx, s3 = s2 * sx;
-              const float h00 = 2.f * s3 - 3.f * s2 + 1.f, h10 = s3 - 2.f * s2 + sx, h01 = -2.f * s3 + 3.f * s2, h11 = s3 - s2;
-              const float g00 = (6.f * s2 - 6.f * sx) * a.tab_inv_step, g10 = (3.f * s2 - 4.f * sx + 1.f) * a.tab_inv_step, g01 = -g00,
+              const float h10 = s3 - 2.f * s2 + sx, h01 = -2.f * s3 + 3.f * s2, h11 = s3 - s2;
+              const float g10 = (3.f * s2 - 4.f * sx + 1.f) * a.tab_inv_step, g01 = (6.f * sx - 6.f * s2) * a.tab_inv_step,
                           g11 = (3.f * s2 - 2.f * sx) * a.tab_inv_step;
-              const float* t0 = a.tab + ((size_t)n * 3 * F + fo) * 2;
+              const float* t0 = a.tab + ((size_t)n * 3 * F + fo) * 4;
 #pragma unroll
               for (int p = 0; p < 3; ++p) {
                 if (MU0 && p == 2) { P[p] = MV::zero(); continue; }
                 float pv[VPL], pdv[VPL];
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) {
-                  const f32x2 k0 = *(const f32x2*)(t0 + (size_t)(p * F + v) * 2), k1 = *(const f32x2*)(t0 + ((size_t)3 * F + p * F + v) * 2);
-                  pv[v] = h00 * k0.x + h10 * k0.y + h01 * k1.x + h11 * k1.y;
-                  pdv[v] = g00 * k0.x + g10 * k0.y + g01 * k1.x + g11 * k1.y;
+                  const f32x4 kk = *(const f32x4*)(t0 + (size_t)(p * F + v) * 4);          // (v_n, m_n, v_n+1 - v_n, m_n+1)
+                  pv[v] = kk.x + h10 * kk.y + h01 * kk.z + h11 * kk.w;
+                  pdv[v] = g10 * kk.y + g01 * kk.z + g11 * kk.w;
                 }
                 P[p] = MV::load(pv);
                 if (BWD) Pd[p] = MV::load(pdv);

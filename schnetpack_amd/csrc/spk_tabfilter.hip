@@ -2,13 +2,14 @@
 // continuous-filter convolution (representation/schnet.py:60-67) with the filter  W_l(d) f_c(d)  read from a TABLE instead of
 // being evaluated by the filter network.  The filter is a smooth function of ONE variable per channel, so a cubic-Hermite spline
 // over n_knots equidistant knots (value + slope, built in float64 from the weights whenever they change) replaces the
-// 2 (n_rbf nf + nf nf) = 37.9 kFLOP per edge-message of the MLP by ~10 FLOP and two 1-KB table rows per edge.  Eval-only, default
+// 2 (n_rbf nf + nf nf) = 37.9 kFLOP per edge-message of the MLP by ~10 FLOP and one 2-KB table row per edge.  Eval-only, default
 // OFF: the fp32 MFMA kernels stay the contract path; scripts/tab_filter_experiment.py measures time and error of this kernel
 // beside them (profiles/r03_tabulated_filter_experiment.json).
 //
 //   y[i, c] = sum_{e in row(i)} h[j(e), c] * T_c(d_e),   T_c(d) = Hermite(table[n], table[n + 1], t),  n = floor(d / step), t = frac
 //
-// table: [n_knots][nf][2] floats = (value, slope * step) at d_n = n * step; entries beyond the cutoff are zero.  One wavefront per
+// table: [n_knots][nf][4] floats = (value, slope * step, value of the next knot - value [formed in float64], slope * step of the
+// next knot) at d_n = n * step -- one 16-byte read per channel and interval; entries beyond the cutoff are zero.  One wavefront per
 // centre atom (CSR row, sorted idx_i), a lane owns two channels: a table row is one coalesced 1-KB burst, the neighbour row
 // 512 bytes; no atomics; row sums in registers.  Bound: L2 / HBM gather bandwidth (2.5 KB per edge).
 #include "spk_common.h"
@@ -40,12 +41,12 @@ __global__ __launch_bounds__(256) void k_cfconv_tab(const float* __restrict__ h,
         int n = (int)u;
         n = n < n_knots - 2 ? n : n_knots - 2;
         const float s = u - (float)n;
-        const f32x4 k0 = *(const f32x4*)(table + ((size_t)n * 128 + 2 * lane) * 2);          // (v, m) of channels 2 lane, 2 lane + 1
-        const f32x4 k1 = *(const f32x4*)(table + ((size_t)(n + 1) * 128 + 2 * lane) * 2);
+        const f32x4 ka = *(const f32x4*)(table + ((size_t)n * 128 + 2 * lane) * 4);          // (v_n, m_n, v_n+1 - v_n, m_n+1) of channel 2 lane
+        const f32x4 kb = *(const f32x4*)(table + ((size_t)n * 128 + 2 * lane + 1) * 4);      // ... of channel 2 lane + 1
         const tf2 hj = *(const tf2*)(h + j * 128 + 2 * lane);
         const float s2 = s * s, s3 = s2 * s;
-        const float h00 = 2.f * s3 - 3.f * s2 + 1.f, h10 = s3 - 2.f * s2 + s, h01 = -2.f * s3 + 3.f * s2, h11 = s3 - s2;
-        const tf2 W = {h00 * k0.x + h10 * k0.y + h01 * k1.x + h11 * k1.y, h00 * k0.z + h10 * k0.w + h01 * k1.z + h11 * k1.w};
+        const float h10 = s3 - 2.f * s2 + s, h01 = -2.f * s3 + 3.f * s2, h11 = s3 - s2;
+        const tf2 W = {ka.x + h10 * ka.y + h01 * ka.z + h11 * ka.w, kb.x + h10 * kb.y + h01 * kb.z + h11 * kb.w};
         acc += W * hj;
       }
     }
@@ -84,18 +85,18 @@ __global__ __launch_bounds__(256) void k_cfconv_tab_bwd(const float* __restrict_
         int n = (int)u;
         n = n < n_knots - 2 ? n : n_knots - 2;
         const float s = u - (float)n;
-        const f32x4 k0 = *(const f32x4*)(table + ((size_t)n * 128 + 2 * lane) * 2);
-        const f32x4 k1 = *(const f32x4*)(table + ((size_t)(n + 1) * 128 + 2 * lane) * 2);
+        const f32x4 ka = *(const f32x4*)(table + ((size_t)n * 128 + 2 * lane) * 4);
+        const f32x4 kb = *(const f32x4*)(table + ((size_t)n * 128 + 2 * lane + 1) * 4);
         const tf2 hj = *(const tf2*)(h + j * 128 + 2 * lane);
         const float s2 = s * s, s3 = s2 * s;
         if (gh) {
           const tf2 gyj = *(const tf2*)(gy + j * 128 + 2 * lane);
-          const float h00 = 2.f * s3 - 3.f * s2 + 1.f, h10 = s3 - 2.f * s2 + s, h01 = -2.f * s3 + 3.f * s2, h11 = s3 - s2;
-          const tf2 W = {h00 * k0.x + h10 * k0.y + h01 * k1.x + h11 * k1.y, h00 * k0.z + h10 * k0.w + h01 * k1.z + h11 * k1.w};
+          const float h10 = s3 - 2.f * s2 + s, h01 = -2.f * s3 + 3.f * s2, h11 = s3 - s2;
+          const tf2 W = {ka.x + h10 * ka.y + h01 * ka.z + h11 * ka.w, kb.x + h10 * kb.y + h01 * kb.z + h11 * kb.w};
           acc += W * gyj;
         }
-        const float g00 = 6.f * s2 - 6.f * s, g10 = 3.f * s2 - 4.f * s + 1.f, g01 = -g00, g11 = 3.f * s2 - 2.f * s;
-        const tf2 dW = {g00 * k0.x + g10 * k0.y + g01 * k1.x + g11 * k1.y, g00 * k0.z + g10 * k0.w + g01 * k1.z + g11 * k1.w};
+        const float g10 = 3.f * s2 - 4.f * s + 1.f, g01 = 6.f * s - 6.f * s2, g11 = 3.f * s2 - 2.f * s;
+        const tf2 dW = {g10 * ka.y + g01 * ka.z + g11 * ka.w, g10 * kb.y + g01 * kb.z + g11 * kb.w};
         const tf2 pv = gyi * hj * dW;
         float sum = pv.x + pv.y;
 #pragma unroll
@@ -158,7 +159,7 @@ int spk_cfconv_tab_bwd_internal(const spk_graph_t* g, const float* r_ij, const f
   return SPK_OK;
 }
 
-// table: [n_knots, 128, 2]; the list must be sorted (rowptr given); nf = 128 only (experiment).  y [N, 128] is overwritten.
+// table: [n_knots, 128, 4]; the list must be sorted (rowptr given); nf = 128 only (experiment).  y [N, 128] is overwritten.
 extern "C" int spk_cfconv_tab_f32(const spk_graph_t* g, const float* r_ij, const float* h, const float* table, int32_t n_knots, float d_max,
                                   float cutoff, int32_t nf, float* y, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

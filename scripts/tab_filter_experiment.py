@@ -8,7 +8,7 @@ in float64 from the model's weights at n_knots equidistant points of [0, cutoff]
 import ctypes, json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from schnetpack_amd import _lib, model as M, ops, synthetic as S
+from schnetpack_amd import _lib, model as M, ops, synthetic as S, tabulate
 
 dev = torch.device("cuda:0")
 L = _lib.lib()
@@ -33,7 +33,7 @@ def build_table(inter, rb, n_knots):
     d = torch.linspace(0.0, cutoff, n_knots, dtype=torch.float64)
     W, dW = filter_fp64(inter, rb, d)
     step = cutoff / (n_knots - 1)
-    return torch.stack([W, dW * step], -1).float().contiguous()          # [n_knots, F, 2]
+    return tabulate.pack_knots(W, dW * step).float().contiguous()          # [n_knots, F, 4] = (v_n, m_n, v_n+1 - v_n, m_n+1)
 
 
 def hermite(table, d, step):
@@ -41,11 +41,11 @@ def hermite(table, d, step):
     u = d.double() / step
     n = u.floor().clamp(max=table.shape[0] - 2).long()
     s = (u - n)[:, None]
-    k0, k1 = table[n].double(), table[n + 1].double()
-    h00, h10, h01, h11 = 2 * s ** 3 - 3 * s ** 2 + 1, s ** 3 - 2 * s ** 2 + s, -2 * s ** 3 + 3 * s ** 2, s ** 3 - s ** 2
-    W = h00 * k0[..., 0] + h10 * k0[..., 1] + h01 * k1[..., 0] + h11 * k1[..., 1]
-    dh00, dh10, dh01, dh11 = 6 * s ** 2 - 6 * s, 3 * s ** 2 - 4 * s + 1, -6 * s ** 2 + 6 * s, 3 * s ** 2 - 2 * s
-    dW = (dh00 * k0[..., 0] + dh10 * k0[..., 1] + dh01 * k1[..., 0] + dh11 * k1[..., 1]) / step
+    k = table[n].double()
+    h10, h01, h11 = s ** 3 - 2 * s ** 2 + s, -2 * s ** 3 + 3 * s ** 2, s ** 3 - s ** 2
+    W = k[..., 0] + h10 * k[..., 1] + h01 * k[..., 2] + h11 * k[..., 3]
+    dh10, dh01, dh11 = 3 * s ** 2 - 4 * s + 1, -6 * s ** 2 + 6 * s, 3 * s ** 2 - 2 * s
+    dW = (dh10 * k[..., 1] + dh01 * k[..., 2] + dh11 * k[..., 3]) / step
     return W, dW
 
 
