@@ -123,6 +123,37 @@ def test_standard_potential_in_two_launches(dev, sizes, n_int, n_rbf, radial):
     assert torch.equal(f, f3) and torch.equal(e, e3)                  # no atomics on the way to the forces
 
 
+@pytest.mark.parametrize("kind", ["painn", "schnet"])
+def test_two_launch_potential_on_small_periodic_cells(dev, kind):
+    """Batches of SMALL PERIODIC systems (24-atom water cells, cutoff 2.8 A: 40 % of the pairs cross a cell face, some atom pairs are
+    neighbours through two images) are block-diagonal too: the two-launch potential forms r_ij = R_j - R_i + offset inside the
+    forward launch and returns forces through the reverse-edge map -- against the float64 oracle."""
+    from schnetpack_amd import _lib, model as M
+    cutoff = 2.8
+    systems = []
+    for k in range(5):
+        w = S.water_box(n_side=2, cutoff=cutoff, seed=30 + k)
+        systems.append({"Z": w["Z"], "R": np.asarray(w["R"]), "idx_i": np.asarray(w["idx_i"]), "idx_j": np.asarray(w["idx_j"]), "offsets": np.asarray(w["offsets"])})
+    b = S.collate(systems)
+    assert float(b["offsets"].abs().sum()) > 0
+    rep = (O.init_painn_params if kind == "painn" else O.init_schnet_params)(128, 3, 20, cutoff)
+    head = O.init_atomwise_params(128, seed=1)
+    m = M.build_model(kind, 128, 3, 20, cutoff)
+    M.load_reference_params(m, rep, head)
+    m = m.to(dev).eval()
+    _lib.profile_enable(True)
+    _lib.profile_report()
+    try:
+        inp = M.batch_to_inputs(b, dev)
+        out = m(inp)
+        tags = set(_lib.profile_report())
+    finally:
+        _lib.profile_enable(False)
+    assert tags == {kind + "_mol_fwd", kind + "_mol_bwd"}, tags
+    ref = O.energy_and_forces(kind, rep, head, b, 3, dtype=torch.float64)
+    assert rel_err(out["energy"].detach().cpu(), ref["energy"]) < TOL and rel_err(out["forces"].detach().cpu(), ref["forces"]) < TOL
+
+
 def test_molecule_resident_painn_is_deterministic(dev):
     """No atomics anywhere in the two launches: representation AND forces are bit-reproducible."""
     b = S.molecule_batch("aspirin", 64, seed=9)

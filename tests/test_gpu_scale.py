@@ -165,7 +165,7 @@ def test_tabulated_filter_experiment_force_call_on_the_water_box(dev):
     """EXPERIMENT, default off (schnetpack_amd/tabulate.py): SchNet with the filters read from 512-knot cubic-Hermite tables on the
     10 125-atom periodic box -- forward AND first-order backward through the table kernels (profile tags), energies and forces
     against the float64 oracle.  The value error of the table is ~4e-8, its slope error ~1.6e-6 of max |dW/dd| (512 knots; knot differences formed in float64): the
-    forces stay inside the 1e-5 bar with less margin than the fp32-MFMA contract path, which this test runs beside it."""
+    forces stay inside the 1e-5 bar with the margin of the fp32-MFMA contract path, which this test runs beside it."""
     from schnetpack_amd import _lib, model as M, tabulate
     rep_p, head_p = _params("schnet")
     model = _model("schnet", dev, rep_p, head_p)
