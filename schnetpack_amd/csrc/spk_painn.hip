@@ -1422,6 +1422,7 @@ extern "C" int spk_painn_potential_forces_f32(const spk_painn_t* m, const spk_he
   // scratch: [2][N, 3F] rows of the message backward, then the pair vectors [E, 3] (3 E <= 93 N floats of the 18 N F left)
   //          and dE/dq_L [N, F], the gradient of the summed energy through the head -- both written by the forward launch
   const size_t nf = (size_t)g->n_atoms * m->n_atom_basis;
+  SPK_CHECK_ARG(3 * (size_t)g->n_edges <= nf, "%s: more than n_atom_basis / 3 neighbours per atom on average", who);
   float* rij = scratch + 6 * nf;
   float* gq = scratch + 7 * nf;
   SPK_TRY(spk_painn_mol_forward_ex(m, g, rb, ptab, q0, nullptr, R, offsets, q0 ? nullptr : emb, Z, &h, rij, gq, q_out, mu_out, saved, stream));
