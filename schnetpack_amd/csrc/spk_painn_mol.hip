@@ -731,9 +731,9 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
             *(f32x4*)(sC + el * PM_LD + 32 * t + 8 * q + 4 * hi) = cv;
             if (el < na) pm_st<f32x4>(c_g + (size_t)a0 * 3 * F + 32 * t, (unsigned)((el * 3 * F + 8 * q + 4 * hi) * 4), cv);
           }
-          acc = pm_wmma(Wt, sH, lane, bz);
           if (tiled) pm_tw_load<K>(TW, P.wf, P.bf, t, lane, l == 0);
           else pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);
+          acc = pm_wmma(Wt, sH, lane, bz);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -887,9 +887,9 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         PmTW<K> TW;
         {
           float* c_g = S + nf;
-          f32x16 acc = pm_wmma(Wt, sH, lane, bz);
           if (tiled) pm_tw_load<K>(TW, P.wf, P.bf, t, lane, l == 0);
-          else pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);
+          else pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);          // (requested before the MFMAs of the tile: they arrive meanwhile)
+          f32x16 acc = pm_wmma(Wt, sH, lane, bz);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
