@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0          # same guide, HBM3E spec peak
+RAMP_S = 0.15                  # untimed clock ramp in front of the warm-up steps of the eval legs (seconds of replays)
 
 
 def parse():
@@ -387,6 +388,16 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
             torch.cuda.synchronize()
 
     step = graph.replay if graph is not None else force_call
+    # clock ramp, untimed and BEFORE the W warm-up steps: a freshly started process reaches its sustained clocks only after some
+    # tens of milliseconds of work -- with the driver's --steps 20 --warmup 5 the whole measurement is 6 ms long and came out 8 %
+    # below the same binary at --steps 200 (one box, alternating runs).  Bounded: RAMP_S seconds of replays, reported in `config`
+    t_r = time.perf_counter()
+    n_ramp = 0
+    while time.perf_counter() - t_r < RAMP_S:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        n_ramp += 20
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -415,7 +426,7 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
         dist.all_reduce(et, op=dist.ReduceOp.SUM)
         E_total = int(et.item())
     value = E_total * n_int * steps / dt / 1e6
-    res = {"value": value, "dt": dt, "steps": steps, "E": E, "N": N, "frames": hi - lo, "graph": graph is not None, "batch": batch, "inp": inp,
+    res = {"value": value, "dt": dt, "steps": steps, "E": E, "N": N, "frames": hi - lo, "graph": graph is not None, "batch": batch, "inp": inp, "n_ramp": n_ramp,
            "e_ref": e_ref, "f_ref": f_ref, "n_int": n_int, "F": F, "n_rbf": n_rbf, "cutoff": cutoff}
     if rank != 0:
         return res
@@ -896,7 +907,8 @@ def main():
                    "n_atoms": N, "n_edges": E, "frames_per_s": round(hi_lo * world * args.steps / dt, 1),
                    "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                    "world_size": world, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
-                   "hip_graph": r["graph"], "variant": args.variant, "compute_units": info["compute_units"]},
+                   "hip_graph": r["graph"], "variant": args.variant, "compute_units": info["compute_units"],
+                   "preconditioning": "%d untimed replays (%.2f s clock ramp) before the %d warm-up steps; the timed region is exactly %d steps" % (r["n_ramp"], RAMP_S, args.warmup, r["steps"])},
         "roofline": roofline, "cpu_baseline": cpu, "painn": painn, "train": train, "md": md, "sweep": sweep, "drop_in": drop_in, "experiments": experiments,
         "kernels": kernels, "scatter_add": scatter, "neighbor_list": nbl,
     }
