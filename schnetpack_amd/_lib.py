@@ -127,6 +127,8 @@ _PROTOS = {
     "spk_radial_c_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, P(RadialT), c_i32, c_f, c_f]),
     "spk_rowscale_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_f, c_f]),
     "spk_rowdot_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_f, c_f]),
+    "spk_fm_loss_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_f, c_f, c_i64, ctypes.c_float, ctypes.c_float, c_f, c_f, c_f]),
+    "spk_fm_loss_bwd_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_f, c_i64, c_f, c_f]),
     "spk_vec3_f32": (ctypes.c_int, [c_i32, c_f, c_i64, c_f, c_i64, c_i64, c_i32, c_f, c_f]),
     "spk_dense_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
     "spk_dense_bwd_input_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),

@@ -281,6 +281,22 @@ Tensor call_rowscale(const Tensor& W, const Tensor& s) {
   static auto op = op_handle<Tensor(const Tensor&, const Tensor&)>("spk_hip::rowscale");
   return op.call(W, s);
 }
+// loss = wE mean((E - E_t)^2) + wF mean((F - F_t)^2) -> (loss [], gE, gF): value and gradients in one launch
+std::tuple<Tensor, Tensor, Tensor> fm_loss_raw(const Tensor& E_in, const Tensor& Et_in, const Tensor& F_in, const Tensor& Ft_in, double wE, double wF) {
+  Tensor E = f32(E_in, "fm_loss"), Et = f32(Et_in, "fm_loss"), F = f32(F_in, "fm_loss"), Ft = f32(Ft_in, "fm_loss");
+  TORCH_CHECK(E.sizes() == Et.sizes() && F.sizes() == Ft.sizes(), "fm_loss: predictions and targets differ in shape");
+  c10::DeviceGuard guard(E.device());
+  Tensor loss = at::empty({}, E.options()), gE = at::empty_like(E), gF = at::empty_like(F);
+  check(spk_fm_loss_f32(fp(E), fp(Et), E.numel(), fp(F), fp(Ft), F.numel(), (float)wE, (float)wF, fpm(loss), fpm(gE), fpm(gF), stream_of(E)));
+  return {loss, gE, gF};
+}
+std::tuple<Tensor, Tensor> fm_loss_backward_raw(const Tensor& g_in, const Tensor& gE, const Tensor& gF) {
+  Tensor g = f32(g_in, "fm_loss backward").reshape({1});
+  c10::DeviceGuard guard(gE.device());
+  Tensor oE = at::empty_like(gE), oF = at::empty_like(gF);
+  check(spk_fm_loss_bwd_f32(fp(g), fp(gE), gE.numel(), fp(gF), gF.numel(), fpm(oE), fpm(oF), stream_of(gE)));
+  return {oE, oF};
+}
 Tensor call_rowdot(const Tensor& a, const Tensor& b) {
   static auto op = op_handle<Tensor(const Tensor&, const Tensor&)>("spk_hip::rowdot");
   return op.call(a, b);
@@ -579,6 +595,26 @@ Tensor radial_c_ad(const Tensor& G, const Tensor& d, const OptT& a, int64_t kind
   return RadialCFn::apply(G, d, p0, a, p1, kind, cutoff, order);
 }
 Tensor rowscale_ad(const Tensor& W, const Tensor& s) { return RowscaleFn::apply(W, s); }
+// First order only: the gradient of the loss w.r.t. the forces flows on into the recorded force graph (that is where the second
+// order of force matching lives); the loss node itself is not differentiated twice.
+struct FmLossFn : public torch::autograd::Function<FmLossFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& E, const Tensor& Et, const Tensor& F, const Tensor& Ft, double wE, double wF) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = op_handle<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, double, double)>("spk_hip::fm_loss_forward");
+    auto r = op.call(E, Et, F, Ft, wE, wF);
+    ctx->save_for_backward({std::get<1>(r), std::get<2>(r)});
+    return std::get<0>(r);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    static auto op = op_handle<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&)>("spk_hip::fm_loss_backward");
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto r = op.call(g[0], sv[0], sv[1]);
+    return {std::get<0>(r), Tensor(), std::get<1>(r), Tensor(), Tensor(), Tensor()};
+  }
+};
+Tensor fm_loss_ad(const Tensor& E, const Tensor& Et, const Tensor& F, const Tensor& Ft, double wE, double wF) { return FmLossFn::apply(E, Et, F, Ft, wE, wF); }
+Tensor fm_loss_dev(const Tensor& E, const Tensor& Et, const Tensor& F, const Tensor& Ft, double wE, double wF) { return std::get<0>(fm_loss_raw(E, Et, F, Ft, wE, wF)); }
 Tensor rowdot_ad(const Tensor& a, const Tensor& b) { return RowdotFn::apply(a, b); }
 Tensor edge_norm_ad(const Tensor& r) { return EdgeNormFn::apply(r); }
 
@@ -628,9 +664,14 @@ Tensor rowdot_meta(const Tensor& a, const Tensor&) {
   return at::empty(shape, a.options());
 }
 Tensor edge_norm_meta(const Tensor& r) { return at::empty({r.size(0)}, r.options()); }
+Tensor fm_loss_meta(const Tensor& E, const Tensor&, const Tensor&, const Tensor&, double, double) { return at::empty({}, E.options()); }
+std::tuple<Tensor, Tensor, Tensor> fm_loss_forward_meta(const Tensor& E, const Tensor&, const Tensor& F, const Tensor&, double, double) {
+  return {at::empty({}, E.options()), at::empty_like(E), at::empty_like(F)};
+}
+std::tuple<Tensor, Tensor> fm_loss_backward_meta(const Tensor&, const Tensor& gE, const Tensor& gF) { return {at::empty_like(gE), at::empty_like(gF)}; }
 
 // ------------------------------------------------------------------------------------------------ registration
-const char* const kTrainOps[] = {"act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm", "vec3", "gemm_pair"};
+const char* const kTrainOps[] = {"act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm", "vec3", "gemm_pair", "fm_loss", "fm_loss_forward", "fm_loss_backward"};
 
 void train_defs(torch::Library& m) {
   m.def("act_mul(Tensor? a, Tensor z, int act, int order, Tensor? c=None) -> Tensor");                   // a . act^(order)(z) + c
@@ -646,6 +687,9 @@ void train_defs(torch::Library& m) {
   m.def("rowscale(Tensor W, Tensor s) -> Tensor");                                                        // Wij * rcut_ij[:, None], schnet.py:61
   m.def("rowdot(Tensor a, Tensor b) -> Tensor");
   m.def("edge_norm(Tensor r_ij) -> Tensor");                                                              // torch.norm(r_ij, dim=1), schnet.py:156
+  m.def("fm_loss(Tensor E, Tensor E_t, Tensor F, Tensor F_t, float w_e, float w_f) -> Tensor");           // w_e MSE(E) + w_f MSE(F): the loss of a force-matching step (task.py:120-135)
+  m.def("fm_loss_forward(Tensor E, Tensor E_t, Tensor F, Tensor F_t, float w_e, float w_f) -> (Tensor, Tensor, Tensor)");
+  m.def("fm_loss_backward(Tensor g, Tensor gE, Tensor gF) -> (Tensor, Tensor)");
 }
 void train_impl_device(torch::Library& m) {
   m.impl("act_mul", act_mul_raw);
@@ -661,6 +705,9 @@ void train_impl_device(torch::Library& m) {
   m.impl("rowscale", rowscale_raw);
   m.impl("rowdot", rowdot_raw);
   m.impl("edge_norm", edge_norm_raw);
+  m.impl("fm_loss", fm_loss_dev);
+  m.impl("fm_loss_forward", fm_loss_raw);
+  m.impl("fm_loss_backward", fm_loss_backward_raw);
 }
 void train_impl_autograd(torch::Library& m) {
   m.impl("act_mul", act_mul_ad);
@@ -675,6 +722,7 @@ void train_impl_autograd(torch::Library& m) {
   m.impl("rowscale", rowscale_ad);
   m.impl("rowdot", rowdot_ad);
   m.impl("edge_norm", edge_norm_ad);
+  m.impl("fm_loss", fm_loss_ad);
 }
 void train_impl_meta(torch::Library& m) {
   m.impl("act_mul", act_mul_meta);
@@ -690,4 +738,7 @@ void train_impl_meta(torch::Library& m) {
   m.impl("rowscale", rowscale_meta);
   m.impl("rowdot", rowdot_meta);
   m.impl("edge_norm", edge_norm_meta);
+  m.impl("fm_loss", fm_loss_meta);
+  m.impl("fm_loss_forward", fm_loss_forward_meta);
+  m.impl("fm_loss_backward", fm_loss_backward_meta);
 }

@@ -369,6 +369,53 @@ extern "C" int spk_rowdot_f32(const float* a, const float* b, int64_t rows, int3
   return SPK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ force-matching loss
+// loss = wE mean((E - E_t)^2) + wF mean((F - F_t)^2)  (the reference's task block: two MSE terms, task.py:166-185 with the weights of
+// the example configs) and its gradients w.r.t. E and F in ONE launch -- as framework arithmetic the two terms and their backward are
+// 19 launches of a training step that is launch-latency bound.  One workgroup (the operands are N * 3 + M numbers).
+__global__ __launch_bounds__(256) void k_fm_loss(const float* __restrict__ E, const float* __restrict__ Et, int64_t M, const float* __restrict__ F,
+                                                  const float* __restrict__ Ft, int64_t n3, float wE, float wF, float* __restrict__ loss,
+                                                  float* __restrict__ gE, float* __restrict__ gF) {
+  __shared__ float red[256];
+  const float cE = M > 0 ? wE / (float)M : 0.f, cF = n3 > 0 ? wF / (float)n3 : 0.f;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < M; i += 256) { const float d = E[i] - Et[i]; acc += cE * d * d; gE[i] = 2.f * cE * d; }
+  for (int64_t i = threadIdx.x; i < n3; i += 256) { const float d = F[i] - Ft[i]; acc += cF * d * d; gF[i] = 2.f * cF * d; }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) loss[0] = red[0];
+}
+// (gE, gF) * g[0] -> (outE, outF): the backward of the node, one launch for both operands
+__global__ void k_fm_loss_bwd(const float* __restrict__ g, const float* __restrict__ gE, int64_t M, const float* __restrict__ gF, int64_t n3,
+                              float* __restrict__ outE, float* __restrict__ outF) {
+  const float s = g[0];
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < M + n3; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t < M) outE[t] = s * gE[t];
+    else outF[t - M] = s * gF[t - M];
+  }
+}
+extern "C" int spk_fm_loss_f32(const float* E, const float* Et, int64_t M, const float* F, const float* Ft, int64_t n3, float wE, float wF,
+                               float* loss, float* gE, float* gF, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(M >= 0 && n3 >= 0 && loss, "spk_fm_loss_f32: bad sizes / null loss");
+  SPK_CHECK_ARG((M == 0 || (E && Et && gE)) && (n3 == 0 || (F && Ft && gF)), "spk_fm_loss_f32: null pointer");
+  SpkProfScope prof("fm_loss", stream);
+  hipLaunchKernelGGL(k_fm_loss, dim3(1), dim3(256), 0, stream, E, Et, M, F, Ft, n3, wE, wF, loss, gE, gF);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+extern "C" int spk_fm_loss_bwd_f32(const float* g, const float* gE, int64_t M, const float* gF, int64_t n3, float* outE, float* outF, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(M >= 0 && n3 >= 0, "spk_fm_loss_bwd_f32: bad sizes");
+  if (M + n3 == 0) return SPK_OK;
+  SPK_CHECK_ARG(g && (M == 0 || (gE && outE)) && (n3 == 0 || (gF && outF)), "spk_fm_loss_bwd_f32: null pointer");
+  SpkProfScope prof("fm_loss_bwd", stream);
+  hipLaunchKernelGGL(k_fm_loss_bwd, dim3(spk_grid_for(M + n3, 256, 64)), dim3(256), 0, stream, g, gE, M, gF, n3, outE, outF);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ 3-vector algebra (PaiNN, painn.py:55-66, 99-117)
 // V-type operands are [M, 3, F] (Cartesian component in the middle), s-type [M, F], u-type [M, 3]; every V / s operand comes with a
 // row stride (ld) so that the halves of a split tensor are read in place.  Five kernels, closed under differentiation:

@@ -44,7 +44,8 @@ OPERATORS = ["scatter_add", "gather", "pairwise", "pairwise_backward", "dense", 
              "painn_backward", "atomwise_forward", "atomwise_backward", "schnet_potential", "schnet_potential_forward", "schnet_potential_backward", "schnet_potential_forces", "painn_potential_forces", "eval_guard", "potential_plan", "edge_plan", "edge_plan_install", "static_new", "static_release", "weights_changed", "static_declare", "static_declare_range", "static_refresh", "static_enable",
              "static_check", "static_clear", "clear_caches",
              # training regime: operators closed under differentiation (csrc/spk_torch_train.h)
-             "act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm", "vec3", "gemm_pair"]
+             "act_mul", "linear", "matmul_nn", "matmul_tn", "cfconv", "edge_mul", "radial_d", "radial_c", "rowscale", "rowdot", "edge_norm", "vec3", "gemm_pair",
+             "fm_loss", "fm_loss_forward", "fm_loss_backward"]
 
 
 # operation codes of torch.ops.spk_hip.vec3 (include/spk_hip.h: SPK_VEC3_*)

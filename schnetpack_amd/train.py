@@ -112,7 +112,8 @@ class GraphedTrainStep:
         inputs[properties.R] = self.buf[properties.R].detach().requires_grad_(False)
         inputs["_n_molecules"] = self.M
         out = self.model(inputs)
-        loss = self.wE * ((out["energy"] - self.E_t) ** 2).mean() + self.wF * ((out["forces"] - self.F_t) ** 2).mean()
+        # w_E MSE(E) + w_F MSE(F) and both gradients as ONE launch (the framework arithmetic of the two terms and their backward: 19)
+        loss = torch.ops.spk_hip.fm_loss(out["energy"], self.E_t, out["forces"], self.F_t, float(self.wE), float(self.wF))
         loss.backward()
         self.reducer.pack()
         self.loss.copy_(loss.detach())

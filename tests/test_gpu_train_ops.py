@@ -215,3 +215,20 @@ def test_training_operators_refuse_malformed_input(dev):
         ops.rowdot(x.double(), x.double())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.vec3(0, torch.zeros(2, 3, 4), torch.zeros(2, 4))
+
+
+def test_force_matching_loss_value_and_gradients(dev):
+    """torch.ops.spk_hip.fm_loss = w_E MSE(E) + w_F MSE(F) (one launch) and its first-order gradients (one launch) against the
+    framework arithmetic it replaces in GraphedTrainStep."""
+    torch.manual_seed(3)
+    E = torch.randn(8, device=dev, requires_grad=True)
+    F = torch.randn(168, 3, device=dev, requires_grad=True)
+    Et, Ft = torch.randn(8, device=dev), torch.randn(168, 3, device=dev)
+    wE, wF = 0.01, 0.99
+    ref = wE * ((E - Et) ** 2).mean() + wF * ((F - Ft) ** 2).mean()
+    gE_ref, gF_ref = torch.autograd.grad(ref * 1.7, (E, F))
+    got = torch.ops.spk_hip.fm_loss(E, Et, F, Ft, wE, wF)
+    gE, gF = torch.autograd.grad(got * 1.7, (E, F))
+    assert got.shape == () and abs(float(got) - float(ref)) < 1e-6 * abs(float(ref))
+    assert float((gE - gE_ref).abs().max()) < 1e-6 * float(gE_ref.abs().max())
+    assert float((gF - gF_ref).abs().max()) < 1e-6 * float(gF_ref.abs().max())
