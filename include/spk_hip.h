@@ -635,7 +635,7 @@ int spk_vec3_f32(int32_t op, const float* A, int64_t ldA, const float* B, int64_
 int spk_rowdot_f32(const float* a, const float* b, int64_t rows, int32_t F, float* out, void* stream);
 
 /* Force-matching loss of a training step, loss = wE mean((E - E_t)^2) + wF mean((F - F_t)^2) (AtomisticTask.loss_fn with two MSE
- * outputs, task.py:120-135), and its gradients gE [M], gF [n3] w.r.t. E and F in one launch; spk_fm_loss_bwd_f32 scales them by the
+ * outputs, task.py:59-66, 142-146), and its gradients gE [M], gF [n3] w.r.t. E and F in one launch; spk_fm_loss_bwd_f32 scales them by the
  * incoming gradient g[0] (device scalar).  loss [1]. */
 int spk_fm_loss_f32(const float* E, const float* E_t, int64_t M, const float* F, const float* F_t, int64_t n3, float wE, float wF,
                     float* loss, float* gE, float* gF, void* stream);

@@ -687,7 +687,7 @@ void train_defs(torch::Library& m) {
   m.def("rowscale(Tensor W, Tensor s) -> Tensor");                                                        // Wij * rcut_ij[:, None], schnet.py:61
   m.def("rowdot(Tensor a, Tensor b) -> Tensor");
   m.def("edge_norm(Tensor r_ij) -> Tensor");                                                              // torch.norm(r_ij, dim=1), schnet.py:156
-  m.def("fm_loss(Tensor E, Tensor E_t, Tensor F, Tensor F_t, float w_e, float w_f) -> Tensor");           // w_e MSE(E) + w_f MSE(F): the loss of a force-matching step (task.py:120-135)
+  m.def("fm_loss(Tensor E, Tensor E_t, Tensor F, Tensor F_t, float w_e, float w_f) -> Tensor");           // w_e MSE(E) + w_f MSE(F): the loss of a force-matching step (task.py:59-66, 142-146)
   m.def("fm_loss_forward(Tensor E, Tensor E_t, Tensor F, Tensor F_t, float w_e, float w_f) -> (Tensor, Tensor, Tensor)");
   m.def("fm_loss_backward(Tensor g, Tensor gE, Tensor gF) -> (Tensor, Tensor)");
 }

@@ -370,7 +370,7 @@ extern "C" int spk_rowdot_f32(const float* a, const float* b, int64_t rows, int3
 }
 
 // ------------------------------------------------------------------------------------------------ force-matching loss
-// loss = wE mean((E - E_t)^2) + wF mean((F - F_t)^2)  (the reference's task block: two MSE terms, task.py:166-185 with the weights of
+// loss = wE mean((E - E_t)^2) + wF mean((F - F_t)^2)  (ModelOutput.calculate_loss + AtomisticTask.loss_fn, task.py:59-66, 142-146, with two MSE outputs and the weights of
 // the example configs) and its gradients w.r.t. E and F in ONE launch -- as framework arithmetic the two terms and their backward are
 // 19 launches of a training step that is launch-latency bound.  One workgroup (the operands are N * 3 + M numbers).
 __global__ __launch_bounds__(256) void k_fm_loss(const float* __restrict__ E, const float* __restrict__ Et, int64_t M, const float* __restrict__ F,
