@@ -106,10 +106,14 @@ def _tabulate_painn(rep, n_knots: int) -> torch.Tensor:
     return table
 
 
-def tabulate_filters(representation, n_knots: int = 512) -> torch.Tensor:
+def tabulate_filters(representation, n_knots: Optional[int] = None) -> torch.Tensor:
     """Build and attach the filter tables of every interaction of a SchNet or PaiNN representation (on its device).  Returns the
-    tables ``[n_interactions, n_knots, n_filters (3 n_atom_basis for PaiNN), 4]`` (:func:`pack_knots`)."""
+    tables ``[n_interactions, n_knots, n_filters (3 n_atom_basis for PaiNN), 4]`` (:func:`pack_knots`).  ``n_knots=None``: 512 for Gaussian
+    bases, 1024 for Bessel bases."""
     rep = representation
+    if n_knots is None:          # Bessel filters oscillate faster: 512 knots leave 1.5e-5 of max |dW/dd| in the slope, 1024 knots 1.6e-6
+        kind = int(rep.radial_basis.kernel_params()[0])
+        n_knots = 512 if kind == _lib.SPK_RBF_GAUSSIAN else 1024
     clear_filter_tables(rep)
     if hasattr(rep, "filter_net"):
         return _tabulate_painn(rep, n_knots)
