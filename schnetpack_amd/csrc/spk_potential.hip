@@ -319,7 +319,7 @@ int run_model(spk_potential* p, int64_t N, int64_t E, int64_t M, bool new_list, 
   rc = spk_atomwise_fwd_f32(p->xo.as<float>(), p->t.at("head_w1"), p->t.at("head_b1"), p->t.at("head_w2"), p->t.at("head_b2"), p->idxm.as<int64_t>(),
                             N, F, H, h.head_act, M, p->pre.as<float>(), nullptr, p->E.as<float>(), s);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_fill_f32, dim3(spk_grid_for(M, 256, 1024)), dim3(256), 0, s, p->gE.as<float>(), 1.0f, M);   // grad_outputs = ones (response.py:63)
+  hipLaunchKernelGGL(k_fill_f32, dim3(spk_grid_for(M, 256, 1024)), dim3(256), 0, s, p->gE.as<float>(), 1.0f, M);   // grad_outputs = ones (atomistic/response.py:63)
   SPK_LAUNCH_CHECK();
   rc = spk_atomwise_bwd_f32(p->gE.as<float>(), nullptr, p->pre.as<float>(), p->t.at("head_w1"), p->t.at("head_w2"), p->idxm.as<int64_t>(), N, F, H,
                             h.head_act, M, p->gx.as<float>(), s);
@@ -337,7 +337,7 @@ int run_model(spk_potential* p, int64_t N, int64_t E, int64_t M, bool new_list, 
   SPK_HIP_TRY(hipMemcpyAsync(p->hE.data(), p->E.p, (size_t)M * 4, hipMemcpyDeviceToHost, s));
   SPK_HIP_TRY(hipMemcpyAsync(p->hF.data(), p->gR.p, (size_t)N * 12, hipMemcpyDeviceToHost, s));
   SPK_HIP_TRY(hipStreamSynchronize(s));
-  for (int64_t k = 0; k < 3 * N; ++k) host_forces[k] = -p->hF[k];          // forces = -dE/dR (response.py:76)
+  for (int64_t k = 0; k < 3 * N; ++k) host_forces[k] = -p->hF[k];          // forces = -dE/dR (atomistic/response.py:76)
   // AddOffsets (transform/atomistic.py:300-324), fp32 like the deployed reference model (spkdeploy:24-26)
   std::vector<float> n_at((size_t)M, 0.f), y0((size_t)M, 0.f);
   for (int64_t a = 0; a < N; ++a) {

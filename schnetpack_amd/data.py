@@ -1,5 +1,5 @@
 """Collate-side wire format (second half): mirror of ``schnetpack.data.loader``
-(data/loader.py:13-90) whose collate function -- running in the DataLoader WORKERS -- also produces what the device
+(data/loader.py:13-86) whose collate function -- running in the DataLoader WORKERS -- also produces what the device
 kernels otherwise derive per neighbour list with ``spk_edge_plan`` and its host round trips:
 
 * CSR row pointers of ``_idx_i`` (int32), the reverse-edge map, the canonical edge of every undirected pair, the pair of
@@ -204,7 +204,7 @@ def install_plan(inputs: Dict[str, torch.Tensor], validate: bool = False) -> boo
 
 
 class AtomsLoader(DataLoader):
-    """Mirror of ``schnetpack.data.AtomsLoader`` (data/loader.py:61-90); ``collate_fn`` defaults to the wire-format collate."""
+    """Mirror of ``schnetpack.data.AtomsLoader`` (data/loader.py:61-86); ``collate_fn`` defaults to the wire-format collate."""
 
     def __init__(self, dataset: Dataset, batch_size: Optional[int] = 1, shuffle: bool = False, sampler: Optional[Sampler] = None,
                  batch_sampler: Optional[Sampler[Sequence[int]]] = None, num_workers: int = 0, collate_fn=None,

@@ -93,7 +93,7 @@ def test_spkdeploy_archives_load_like_lammps_and_match_reference_fixtures(dev):
 @pytest.mark.skipif(not refshim.available(), reason="neither /root/reference nor oracle/_ref present")
 @pytest.mark.parametrize("kind", ["schnet", "painn"])
 def test_stress_through_reference_strain_module(dev, kind):
-    """Strain (response.py:434-464) makes positions, cell and OFFSETS functions of a strain tensor; Forces(calc_stress=True)
+    """Strain (atomistic/response.py:434-464) makes positions, cell and OFFSETS functions of a strain tensor; Forces(calc_stress=True)
     differentiates the energy w.r.t. it: exercises d r_ij / d offsets of the HIP PairwiseDistances."""
     import schnetpack_amd.install as inst
     ns = refshim.load()

@@ -85,7 +85,7 @@ def test_eval_mode_parameter_gradients_raise_and_training_mode_has_them(kind):
     out = m(_meta_inputs())
     with pytest.raises(RuntimeError, match="training mode"):
         out["energy"].sum().backward()
-    # ... while Forces' own first-order gradient w.r.t. the positions (autograd.grad, response.py:63-68) is served
+    # ... while Forces' own first-order gradient w.r.t. the positions (autograd.grad, atomistic/response.py:63-68) is served
     assert out["forces"].shape == (12, 3)
     # second order in eval mode (create_graph) is refused as well instead of silently dropping terms
     inp = _meta_inputs()
