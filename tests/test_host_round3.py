@@ -60,3 +60,43 @@ def test_bench_books_every_modelled_kernel_with_a_lower_bound():
             assert bmin is None or 0 < bmin, tag
     assert any(t.startswith("painn_mol") for t in B.algorithmic_work("painn", 77944, 5376, 256, 128, 3, 20))
     assert 0.05 <= B.RAMP_S <= 0.5          # the untimed clock ramp stays a bounded fraction of a second
+
+
+def test_documented_second_order_of_the_filter_node():
+    """DESIGN.md 4.12 writes down the first and second derivative of the SchNet filter node (schnet.py:60-62) for the fused training
+    node that is not built yet: the formulas, restated in float64, against torch autograd."""
+    import math
+    torch.manual_seed(0)
+    E, K, nf, rc, dt = 9, 6, 8, 5.0, torch.float64
+    d = (0.5 + 3 * torch.rand(E, dtype=dt)).requires_grad_(True)
+    mu, c = torch.linspace(0, 4, K, dtype=dt), -0.5 / 0.3 ** 2
+    W1, b1 = torch.randn(nf, K, dtype=dt, requires_grad=True), torch.randn(nf, dtype=dt, requires_grad=True)
+    W2, b2 = torch.randn(nf, nf, dtype=dt, requires_grad=True), torch.randn(nf, dtype=dt, requires_grad=True)
+    G, h = torch.randn(E, nf, dtype=dt, requires_grad=True), torch.randn(E, dtype=dt)
+    t = d[:, None] - mu[None]
+    phi = torch.exp(c * t * t)
+    dphi = 2 * c * t * phi
+    ddphi = 2 * c * phi + 2 * c * t * dphi
+    fc = 0.5 * (torch.cos(d * math.pi / rc) + 1)
+    dfc = -0.5 * math.pi / rc * torch.sin(d * math.pi / rc)
+    ddfc = -0.5 * (math.pi / rc) ** 2 * torch.cos(d * math.pi / rc)
+    a = phi @ W1.t() + b1
+    z = torch.nn.functional.softplus(a) - math.log(2.0)
+    g = z @ W2.t() + b2
+    W = g * fc[:, None]
+    gd_auto, = torch.autograd.grad(W, d, G, create_graph=True)
+    sig = torch.sigmoid(a)
+    ap, app = dphi @ W1.t(), ddphi @ W1.t()
+    gp = (sig * ap) @ W2.t()
+    assert torch.allclose((G * (fc[:, None] * gp + dfc[:, None] * g)).sum(1), gd_auto, rtol=1e-12, atol=1e-12)
+    auto = torch.autograd.grad((h * gd_auto).sum(), (G, d, W1, b1, W2, b2))
+    sigp = sig * (1 - sig)
+    gpp = (sigp * ap * ap + sig * app) @ W2.t()
+    u, v = h[:, None] * fc[:, None] * G, h[:, None] * dfc[:, None] * G
+    ub, vb = u @ W2, v @ W2
+    ab, pb = vb * sig + ub * sigp * ap, ub * sig
+    mine = (h[:, None] * (fc[:, None] * gp + dfc[:, None] * g),
+            h * (G * (fc[:, None] * gpp + 2 * dfc[:, None] * gp + ddfc[:, None] * g)).sum(1),
+            ab.t() @ phi + pb.t() @ dphi, ab.sum(0), u.t() @ (sig * ap) + v.t() @ z, v.sum(0))
+    for x, y in zip(mine, auto):
+        assert torch.allclose(x.detach(), y, rtol=1e-10, atol=1e-12)
