@@ -596,6 +596,10 @@ int spk_act_mul_f32(const float* a, const float* z, const float* c, int64_t n, i
 int spk_gemm_tn_plan(int64_t n, int32_t O, int32_t K, int32_t* n_slices, int64_t* ws_floats, int32_t* n_tiles);
 int spk_gemm_tn_f32(const float* U, const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, float* ws,
                     uint32_t* tickets, void* stream);
+/* the same with the bias gradient restricted to the rows [0, n_bias) of U ([value rows ; tangent rows]-stacked operands of the
+ * force-matching engine below carry a bias on the value rows only) */
+int spk_gemm_tn_nb_f32(const float* U, const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, int64_t n_bias,
+                       float* ws, uint32_t* tickets, void* stream);
 /* The two independent products of a Dense backward in ONE launch: out = a w (trans = 1: a [m, n_out], w [n_out, k] -> [m, k]) or
  * a w^T (trans = 0: a [m, k] -> [m, n_out]), and (G, gb) as spk_gemm_tn_f32.  Widths of the first product must be multiples of 4. */
 int spk_gemm_pair_f32(const float* a, const float* w, int32_t trans, int64_t m, int32_t k, int32_t n_out, float* out,
@@ -640,6 +644,53 @@ int spk_rowdot_f32(const float* a, const float* b, int64_t rows, int32_t F, floa
 int spk_fm_loss_f32(const float* E, const float* E_t, int64_t M, const float* F, const float* F_t, int64_t n3, float wE, float wF,
                     float* loss, float* gE, float* gF, void* stream);
 int spk_fm_loss_bwd_f32(const float* g, const float* gE, int64_t M, const float* gF, int64_t n3, float* outE, float* outF, void* stream);
+
+/* ------------------------------------------------------------------ force-matching gradients by forward-over-reverse
+ * Replaces what the reference obtains from autograd with create_graph = True: Forces (atomistic/response.py:59-68) builds the
+ * graph of -dE/dR, the task differentiates loss(E, F) through it (task.py:166-185) -- reverse over reverse, several hundred
+ * framework nodes per step.  For a loss L(E, F) with gE = dL/dE [n_mol] and gF = dL/dF [N,3] held fixed,
+ *     dL/dtheta = d/dtheta [ sum_m gE_m E_m + D_t E_tot ],   t = -gF   (directional derivative of the total energy along t),
+ * i.e. one dual-number forward pass along t and ONE reverse pass (oracle/fm_oracle.py, pinned against autograd; spk_fm_engine.h):
+ *   spk_*_fm_forward_f32    values (kept in `workspace`) + reverse w.r.t. the positions -> E [n_mol], F [N,3] (F may be NULL)
+ *   spk_*_fm_backward_f32   tangents + reverse of the dual graph -> `grads`, ONE flat fp32 buffer:
+ *        SchNet: per interaction the nine tensors of spk_schnet_layer_t in that order | head w1, b1, w2, b2 | embedding [n_types, F]
+ *        PaiNN:  per interaction the nine tensors of spk_painn_layer_t in that order (filt_* excluded) | filter_net.weight, .bias
+ *                (all rows) | head w1, b1, w2, b2 | embedding
+ *     (every entry is written; a weight shared by several interactions gets one slot per interaction -- the caller sums).
+ * The model covers PairwiseDistances -> SchNet / PaiNN -> Atomwise (default two-layer head, summed per molecule) -> Forces without
+ * stress; any F, n_filters, n_rbf, Gaussian / Bessel basis; idx_i ASCENDING (err |= 1 otherwise), idx_j in any order, the list need
+ * not be symmetric (the transposed sums run over a by-neighbour CSR built on the device per call).  Only raw state_dict weights are
+ * read (no transposed / packed copies: the weights change every step).  No host synchronisation: both calls can be captured in a
+ * HIP graph.  The SAME workspace (and batch) must be passed to the backward call; spk_*_fm_workspace_bytes sizes it. */
+typedef struct {
+  int64_t n_atoms, n_edges, n_mol;
+  const int64_t* Z;        /* [N] atomic numbers (rows of `embedding`; out of range -> zero row) */
+  const int64_t* idx_i;    /* [E] ascending */
+  const int64_t* idx_j;    /* [E] */
+  const int64_t* idx_m;    /* [N] ascending molecule index */
+  const float* R;          /* [N,3] */
+  const float* offsets;    /* [E,3] or NULL */
+  const float* embedding;  /* [n_types, F] nuclear embedding table (representation/schnet.py:126-128) */
+  int32_t n_types;
+  int32_t reserved;
+} spk_fm_batch_t;
+int64_t spk_schnet_fm_workspace_bytes(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t n_atoms, int64_t n_edges, int64_t n_mol);
+int64_t spk_schnet_fm_grad_floats(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int32_t n_types);
+int spk_schnet_fm_forward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
+                              float* E, float* F, int32_t* err, void* stream);
+int spk_schnet_fm_backward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
+                               const float* gE, const float* gF, float* grads, void* stream);
+int64_t spk_painn_fm_workspace_bytes(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t n_atoms, int64_t n_edges, int64_t n_mol);
+int64_t spk_painn_fm_grad_floats(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int32_t n_types);
+int spk_painn_fm_forward_f32(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
+                             float* E, float* F, int32_t* err, void* stream);
+int spk_painn_fm_backward_f32(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
+                              const float* gE, const float* gF, float* grads, void* stream);
+/* By-neighbour CSR of a pair list on the device (the transpose permutation of SURVEY.md section 7 step 4): perm [E] = the pairs
+ * ordered by idx_j (stable: ascending pair index inside a column), colptr [N + 2] (column N collects out-of-range neighbours).
+ * tmp: spk_transpose_plan_bytes(E, N) bytes.  No host synchronisation. */
+int64_t spk_transpose_plan_bytes(int64_t n_edges, int64_t n_atoms);
+int spk_transpose_plan(const int64_t* idx_j, int64_t n_edges, int64_t n_atoms, int32_t* colptr, int32_t* perm, void* tmp, void* stream);
 
 #ifdef __cplusplus
 }

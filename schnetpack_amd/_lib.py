@@ -70,6 +70,11 @@ class PainnLayerT(ctypes.Structure):
                                    "ctx_w1T", "ctx_w2T", "mix_wT", "ictx_w1T", "ictx_w2T")]
 
 
+class FmBatchT(ctypes.Structure):
+    _fields_ = [("n_atoms", c_i64), ("n_edges", c_i64), ("n_mol", c_i64), ("Z", c_f), ("idx_i", c_f), ("idx_j", c_f), ("idx_m", c_f), ("R", c_f),
+                ("offsets", c_f), ("embedding", c_f), ("n_types", c_i32), ("reserved", c_i32)]
+
+
 class PainnT(ctypes.Structure):
     _fields_ = [("n_atom_basis", c_i32), ("n_interactions", c_i32), ("epsilon", ctypes.c_float),
                 ("reserved", c_i32), ("layers", ctypes.POINTER(PainnLayerT)), ("wpack", c_f)]
@@ -120,6 +125,7 @@ _PROTOS = {
     "spk_act_mul_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i32, c_i32, c_f, c_f]),
     "spk_gemm_tn_plan": (ctypes.c_int, [c_i64, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]),
     "spk_gemm_tn_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f]),
+    "spk_gemm_tn_nb_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_i32, c_f, c_f, c_i64, c_f, c_f, c_f]),
     "spk_gemm_pair_f32": (ctypes.c_int, [c_f, c_f, c_i32, c_i64, c_i32, c_i32, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f]),
     "spk_cfconv_edge_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i32, c_f, c_f]),
     "spk_edge_mul_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i32, c_f, c_f]),
@@ -129,6 +135,16 @@ _PROTOS = {
     "spk_rowdot_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_f, c_f]),
     "spk_fm_loss_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_f, c_f, c_i64, ctypes.c_float, ctypes.c_float, c_f, c_f, c_f]),
     "spk_fm_loss_bwd_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_f, c_i64, c_f, c_f]),
+    "spk_schnet_fm_workspace_bytes": (c_i64, [P(SchnetT), P(HeadT), P(RadialT), c_i64, c_i64, c_i64]),
+    "spk_schnet_fm_grad_floats": (c_i64, [P(SchnetT), P(HeadT), P(RadialT), c_i32]),
+    "spk_schnet_fm_forward_f32": (ctypes.c_int, [P(SchnetT), P(HeadT), P(RadialT), P(FmBatchT), c_f, c_f, c_f, c_f, c_f]),
+    "spk_schnet_fm_backward_f32": (ctypes.c_int, [P(SchnetT), P(HeadT), P(RadialT), P(FmBatchT), c_f, c_f, c_f, c_f, c_f]),
+    "spk_painn_fm_workspace_bytes": (c_i64, [P(PainnT), P(HeadT), P(RadialT), c_i64, c_i64, c_i64]),
+    "spk_painn_fm_grad_floats": (c_i64, [P(PainnT), P(HeadT), P(RadialT), c_i32]),
+    "spk_painn_fm_forward_f32": (ctypes.c_int, [P(PainnT), P(HeadT), P(RadialT), P(FmBatchT), c_f, c_f, c_f, c_f, c_f]),
+    "spk_painn_fm_backward_f32": (ctypes.c_int, [P(PainnT), P(HeadT), P(RadialT), P(FmBatchT), c_f, c_f, c_f, c_f, c_f]),
+    "spk_transpose_plan_bytes": (c_i64, [c_i64, c_i64]),
+    "spk_transpose_plan": (ctypes.c_int, [c_f, c_i64, c_i64, c_f, c_f, c_f, c_f]),
     "spk_vec3_f32": (ctypes.c_int, [c_i32, c_f, c_i64, c_f, c_i64, c_i64, c_i32, c_f, c_f]),
     "spk_dense_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
     "spk_dense_bwd_input_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),

@@ -10,8 +10,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_schnet_mol.hip", "spk_painn.hip", "spk_painn_tile.hip", "spk_painn_mol.hip", "spk_tabfilter.hip", "spk_nbl.hip", "spk_md.hip", "spk_potential.hip", "spk_train.hip"]
-HEADERS = ["spk_common.h", "spk_painn_msg.h", "spk_painn_mol.h", "spk_pack.h", "spk_gemm_tn.h", os.path.join("..", "..", "include", "spk_hip.h")]
+SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_schnet_mol.hip", "spk_painn.hip", "spk_painn_tile.hip", "spk_painn_mol.hip", "spk_tabfilter.hip", "spk_nbl.hip", "spk_md.hip", "spk_potential.hip", "spk_train.hip", "spk_fm.hip"]
+HEADERS = ["spk_common.h", "spk_painn_msg.h", "spk_painn_mol.h", "spk_pack.h", "spk_gemm_tn.h", "spk_fm_engine.h", "spk_fm_kernels.h", os.path.join("..", "..", "include", "spk_hip.h")]
 LIB = os.path.join(HERE, "libspk_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-mcode-object-version=5", "-Wall", "-Wno-unused-function"]
@@ -73,7 +73,7 @@ TORCH_LIB = os.path.join(HERE, "libspk_torch.so")
 def build_torch_ops(force=False, verbose=True):
     """libspk_torch.so: the TORCH_LIBRARY(spk_hip) operator registrations (spk_torch.cpp; host C++ only, every operator
     calls into libspk_hip.so), compiled against the installed PyTorch-ROCm headers and linked next to libspk_hip.so."""
-    if not (force or _stale(TORCH_LIB, [TORCH_SRC, os.path.join(HERE, "spk_torch_train.h"), LIB, os.path.join(HERE, HEADERS[-1])])):
+    if not (force or _stale(TORCH_LIB, [TORCH_SRC, os.path.join(HERE, "spk_torch_train.h"), os.path.join(HERE, "spk_torch_fm.h"), LIB, os.path.join(HERE, HEADERS[-1])])):
         return TORCH_LIB
     import torch
     from torch.utils import cpp_extension as ce

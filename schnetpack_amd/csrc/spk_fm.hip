@@ -1,0 +1,255 @@
+// Force-matching gradient engine on the device: the HIP instantiation of spk_fm_engine.h (host orchestration of the four passes)
+// and spk_fm_kernels.h (their element-wise / row kernels), with
+//   Dense / input-gradient GEMMs    spk_dense_f32 / spk_dense_bwd_input_f32 (fp32 MFMA, spk_dense.hip) on [value ; tangent]-stacked rows
+//   weight-gradient GEMMs           spk_gemm_tn_nb_f32 (v_mfma_f32_32x32x2_f32 over the stacked sample dimension, spk_gemm_tn.h)
+//   by-neighbour CSR                 stable rocPRIM radix sort of (idx_j, pair id)
+// Replaces the second-order autograd graph of the reference's training step (atomistic/response.py:59-68, task.py:166-185).
+#include <string.h>
+#include <vector>
+#include "spk_common.h"
+#include <rocprim/rocprim.hpp>
+#include "spk_fm_engine.h"
+
+// ------------------------------------------------------------------------------------------------ by-neighbour CSR
+__global__ void k_tp_keys(const int64_t* __restrict__ jj, int64_t E, int64_t N, int* __restrict__ keys, int* __restrict__ vals) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = jj[e];
+    keys[e] = (uint64_t)j < (uint64_t)N ? (int)j : (int)N;
+    vals[e] = (int)e;
+  }
+}
+// colptr [rows + 1] of ascending int keys in [0, rows)
+__global__ void k_tp_colptr(const int* __restrict__ keys, int64_t E, int64_t rows, int* __restrict__ colptr) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e <= E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t prev = e > 0 ? keys[e - 1] : -1;
+    const int64_t cur = e < E ? keys[e] : rows;
+    for (int64_t r = prev + 1; r <= cur; ++r) colptr[r] = (int)e;
+  }
+}
+static size_t tp_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t tp_sort_tmp_bytes(int64_t n) {
+  static size_t cached[64] = {0};
+  int b = 0;
+  while (((int64_t)1 << b) < n && b < 62) ++b;
+  if (cached[b] == 0) {
+    size_t bytes = 0;
+    int* k = nullptr;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)1 << b, 0, 32, (hipStream_t)0);
+    if (e != hipSuccess || bytes == 0) bytes = ((size_t)32 << b) + (1 << 20);     // no device to ask (build box): a generous bound
+    cached[b] = bytes;
+  }
+  return cached[b];
+}
+extern "C" int64_t spk_transpose_plan_bytes(int64_t E, int64_t N) {
+  (void)N;
+  if (E < 1) E = 1;
+  return (int64_t)(3 * tp_align((size_t)E * 4) + tp_align(tp_sort_tmp_bytes(E)));
+}
+extern "C" int spk_transpose_plan(const int64_t* idx_j, int64_t E, int64_t N, int32_t* colptr, int32_t* perm, void* tmp, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(E >= 0 && N >= 0 && E < (1ll << 31) && N < (1ll << 31) - 1 && colptr && (E == 0 || (idx_j && perm && tmp)), "spk_transpose_plan: bad arguments");
+  SpkProfScope prof("transpose_plan", stream);
+  char* p = (char*)tmp;
+  int* keys = (int*)p;
+  int* keys_s = (int*)(p + tp_align((size_t)(E > 0 ? E : 1) * 4));
+  int* vals = (int*)(p + 2 * tp_align((size_t)(E > 0 ? E : 1) * 4));
+  void* sort_tmp = p + 3 * tp_align((size_t)(E > 0 ? E : 1) * 4);
+  if (E > 0) {
+    hipLaunchKernelGGL(k_tp_keys, dim3(spk_grid_for(E, 256, 4096)), dim3(256), 0, stream, idx_j, E, N, keys, vals);
+    size_t bytes = tp_sort_tmp_bytes(E);
+    int bits = 1;
+    while (((int64_t)1 << bits) <= N && bits < 31) ++bits;
+    SPK_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, bytes, keys, keys_s, vals, perm, (size_t)E, 0, bits, stream));
+  }
+  hipLaunchKernelGGL(k_tp_colptr, dim3(spk_grid_for(E + 1, 256, 4096)), dim3(256), 0, stream, keys_s, E, N + 1, colptr);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ device backend of the engine
+struct FmDeviceBackend {
+  hipStream_t stream;
+  float* gws = nullptr;
+  uint32_t* tickets = nullptr;
+  int max_blocks;
+  explicit FmDeviceBackend(hipStream_t s) : stream(s), max_blocks(spk_num_cus() * 32) {}
+  void set_gemm_ws(float* w, uint32_t* t) { gws = w; tickets = t; }
+  int64_t gemm_tn_ws_floats(int64_t n, int O, int K) {
+    int32_t S, tiles;
+    int64_t wsf = 0;
+    if (spk_gemm_tn_plan(n, O, K, &S, &wsf, &tiles)) return 0;
+    return wsf;
+  }
+  size_t transpose_tmp_bytes(int64_t E, int64_t N) { return (size_t)spk_transpose_plan_bytes(E, N); }
+  int zero_u32(uint32_t* p, int64_t n) { return spk_zero_async(p, (size_t)n * 4, stream); }
+  int rowptr(const int64_t* idx, int64_t n, int64_t rows, int32_t* out, int32_t* err) { return spk_segment_rowptr_i32(idx, n, rows, out, err, stream); }
+  int transpose_plan(const int64_t* jj, int64_t E, int64_t N, int32_t* colptr, int32_t* perm, void* tmp) { return spk_transpose_plan(jj, E, N, colptr, perm, tmp, stream); }
+  int dense(const float* x, const float* w, const float* b, const float* res, float* y, float* pre, int64_t m, int k, int n_out, int act) {
+    return spk_dense_f32(x, w, b, res, y, pre, m, k, n_out, act, stream);
+  }
+  int dense_bwd_input(const float* dy, const float* pre, const float* w, const float* res, float* dx, int64_t m, int k, int n_out, int act) {
+    return spk_dense_bwd_input_f32(dy, pre, w, res, dx, m, k, n_out, act, stream);
+  }
+  int gemm_tn(const float* U, const float* X, int64_t n, int O, int K, float* G, float* gb, int64_t n_bias) {
+    return spk_gemm_tn_nb_f32(U, X, n, O, K, G, gb, n_bias, gws, tickets, stream);
+  }
+  template <class... KA, class... A>
+  void flat(const char* tag, void (*k)(KA...), int64_t total, A... a) {
+    if (total <= 0) return;
+    SpkProfScope prof(tag, stream);
+    hipLaunchKernelGGL(k, dim3(spk_grid_for(total, 256, max_blocks)), dim3(256), 0, stream, static_cast<KA>(a)...);
+  }
+  template <class... KA, class... A>
+  void rows(const char* tag, void (*k)(KA...), int64_t n_rows, A... a) {      // one wavefront per row, four per workgroup
+    if (n_rows <= 0) return;
+    SpkProfScope prof(tag, stream);
+    hipLaunchKernelGGL(k, dim3(spk_grid_for(n_rows, 4, max_blocks)), dim3(256), 0, stream, static_cast<KA>(a)...);
+  }
+};
+typedef FmEngine<float, FmDeviceBackend> FmDev;
+
+// ------------------------------------------------------------------------------------------------ C ABI -> engine descriptions
+static int fm_common_check(const spk_head_t* head, const spk_radial_t* rb, const char* who) {
+  SPK_CHECK_ARG(head && rb, "%s: null head / radial description", who);
+  SPK_CHECK_ARG(head->w1 && head->w2 && head->n_hidden >= 1 && (head->act == SPK_ACT_SSP || head->act == SPK_ACT_SILU), "%s: bad head description", who);
+  SPK_CHECK_ARG((rb->kind == SPK_RBF_GAUSSIAN || rb->kind == SPK_RBF_BESSEL) && rb->n_rbf >= 1 && rb->n_rbf <= 1024 && rb->p0 &&
+                (rb->kind == SPK_RBF_BESSEL || rb->p1) && rb->cutoff > 0.f, "%s: bad radial description", who);
+  return SPK_OK;
+}
+static int fm_batch_check(const spk_fm_batch_t* b, const char* who) {
+  SPK_CHECK_ARG(b != nullptr, "%s: null batch", who);
+  SPK_CHECK_ARG(b->n_atoms >= 1 && b->n_edges >= 0 && b->n_mol >= 1 && b->n_edges < (1ll << 31) && b->n_atoms < (1ll << 31) - 2, "%s: bad batch sizes", who);
+  SPK_CHECK_ARG(b->Z && b->idx_m && b->R && b->embedding && b->n_types >= 1 && (b->n_edges == 0 || (b->idx_i && b->idx_j)), "%s: null batch pointer", who);
+  return SPK_OK;
+}
+static FmHead<float> fm_head(const spk_head_t* h) { return FmHead<float>{h->w1, h->b1, h->w2, h->b2, h->n_hidden, h->act}; }
+static FmRadial<float> fm_radial(const spk_radial_t* rb) { return FmRadial<float>{rb->kind, rb->n_rbf, rb->p0, rb->p1, rb->cutoff}; }
+static FmBatch<float> fm_batch(const spk_fm_batch_t* b) {
+  return FmBatch<float>{b->n_atoms, b->n_edges, b->n_mol, b->Z, b->idx_i, b->idx_j, b->idx_m, b->R, b->offsets, b->embedding, b->n_types};
+}
+
+static int fm_schnet_model(const spk_schnet_t* m, std::vector<FmSchnetLayer<float>>& lay, FmSchnetModel<float>& out, const char* who) {
+  SPK_CHECK_ARG(m && m->n_atom_basis >= 1 && m->n_filters >= 1 && m->n_interactions >= 0 && (m->n_interactions == 0 || m->layers), "%s: bad model description", who);
+  lay.resize((size_t)m->n_interactions);
+  for (int l = 0; l < m->n_interactions; ++l) {
+    const spk_schnet_layer_t& P = m->layers[l];
+    SPK_CHECK_ARG(P.in2f_w && P.fn_w1 && P.fn_b1 && P.fn_w2 && P.fn_b2 && P.f2out_w1 && P.f2out_b1 && P.f2out_w2 && P.f2out_b2, "%s: null weight in interaction %d", who, l);
+    lay[(size_t)l] = FmSchnetLayer<float>{P.in2f_w, P.fn_w1, P.fn_b1, P.fn_w2, P.fn_b2, P.f2out_w1, P.f2out_b1, P.f2out_w2, P.f2out_b2};
+  }
+  out = FmSchnetModel<float>{m->n_atom_basis, m->n_filters, m->n_interactions, lay.data()};
+  return SPK_OK;
+}
+static int fm_painn_model(const spk_painn_t* m, const spk_radial_t* rb, std::vector<FmPainnLayer<float>>& lay, FmPainnModel<float>& out, const char* who) {
+  SPK_CHECK_ARG(m && m->n_atom_basis >= 1 && m->n_interactions >= 1 && m->layers, "%s: bad model description", who);
+  const int L = m->n_interactions, F = m->n_atom_basis;
+  lay.resize((size_t)L);
+  const bool shared = L > 1 && m->layers[1].filt_w == m->layers[0].filt_w;
+  for (int l = 0; l < L; ++l) {
+    const spk_painn_layer_t& P = m->layers[l];
+    SPK_CHECK_ARG(P.ctx_w1 && P.ctx_b1 && P.ctx_w2 && P.ctx_b2 && P.mix_w && P.ictx_w1 && P.ictx_b1 && P.ictx_w2 && P.ictx_b2 && P.filt_w && P.filt_b,
+                  "%s: null weight in interaction %d", who, l);
+    // the filter rows of all interactions must be ONE matrix (filter_net.weight, painn.py:179-189): slices in interaction order, or one shared slice
+    const int64_t row0 = shared ? 0 : 3ll * F * l;
+    SPK_CHECK_ARG(P.filt_w == m->layers[0].filt_w + row0 * rb->n_rbf && P.filt_b == m->layers[0].filt_b + row0, "%s: filter_net rows of interaction %d are not slice %d of one matrix",
+                  who, l, l);
+    lay[(size_t)l] = FmPainnLayer<float>{P.ctx_w1, P.ctx_b1, P.ctx_w2, P.ctx_b2, P.mix_w, P.ictx_w1, P.ictx_b1, P.ictx_w2, P.ictx_b2};
+  }
+  out = FmPainnModel<float>{F, L, shared ? 1 : 0, m->epsilon, lay.data(), m->layers[0].filt_w, m->layers[0].filt_b};
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ SchNet
+extern "C" int64_t spk_schnet_fm_workspace_bytes(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t N, int64_t E, int64_t M) {
+  if (!m || !head || !rb || N < 1 || E < 0 || M < 1) return -1;
+  FmDeviceBackend be(nullptr);
+  FmDev eng(be);
+  FmDev::SchnetWs w;
+  FmSchnetModel<float> mm{m->n_atom_basis, m->n_filters, m->n_interactions, nullptr};
+  eng.schnet_carve(nullptr, mm, rb->n_rbf, head->n_hidden, N, E, M, w);
+  return (int64_t)w.bytes;
+}
+extern "C" int64_t spk_schnet_fm_grad_floats(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int32_t n_types) {
+  if (!m || !head || !rb) return -1;
+  return fm_schnet_grad_floats(m->n_atom_basis, m->n_filters, m->n_interactions, rb->n_rbf, head->n_hidden, n_types);
+}
+extern "C" int spk_schnet_fm_forward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace, float* E,
+                                         float* F, int32_t* err, void* stream_) {
+  int rc = fm_common_check(head, rb, "spk_schnet_fm_forward_f32");
+  if (rc) return rc;
+  if ((rc = fm_batch_check(batch, "spk_schnet_fm_forward_f32"))) return rc;
+  SPK_CHECK_ARG(workspace && E, "spk_schnet_fm_forward_f32: null workspace / output");
+  std::vector<FmSchnetLayer<float>> lay;
+  FmSchnetModel<float> mm;
+  if ((rc = fm_schnet_model(m, lay, mm, "spk_schnet_fm_forward_f32"))) return rc;
+  FmDeviceBackend be((hipStream_t)stream_);
+  FmDev eng(be);
+  rc = eng.schnet_forward(mm, fm_head(head), fm_radial(rb), fm_batch(batch), workspace, E, F, err);
+  if (rc) return rc;
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+extern "C" int spk_schnet_fm_backward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
+                                          const float* gE, const float* gF, float* grads, void* stream_) {
+  int rc = fm_common_check(head, rb, "spk_schnet_fm_backward_f32");
+  if (rc) return rc;
+  if ((rc = fm_batch_check(batch, "spk_schnet_fm_backward_f32"))) return rc;
+  SPK_CHECK_ARG(workspace && gE && gF && grads, "spk_schnet_fm_backward_f32: null pointer");
+  std::vector<FmSchnetLayer<float>> lay;
+  FmSchnetModel<float> mm;
+  if ((rc = fm_schnet_model(m, lay, mm, "spk_schnet_fm_backward_f32"))) return rc;
+  FmDeviceBackend be((hipStream_t)stream_);
+  FmDev eng(be);
+  rc = eng.schnet_backward(mm, fm_head(head), fm_radial(rb), fm_batch(batch), workspace, gE, gF, grads);
+  if (rc) return rc;
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ PaiNN
+extern "C" int64_t spk_painn_fm_workspace_bytes(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t N, int64_t E, int64_t M) {
+  if (!m || !head || !rb || N < 1 || E < 0 || M < 1 || m->n_interactions < 1 || !m->layers) return -1;
+  FmDeviceBackend be(nullptr);
+  FmDev eng(be);
+  FmDev::PainnWs w;
+  const bool shared = m->n_interactions > 1 && m->layers[1].filt_w == m->layers[0].filt_w;
+  FmPainnModel<float> mm{m->n_atom_basis, m->n_interactions, shared ? 1 : 0, m->epsilon, nullptr, nullptr, nullptr};
+  eng.painn_carve(nullptr, mm, rb->n_rbf, head->n_hidden, N, E, M, w);
+  return (int64_t)w.bytes;
+}
+extern "C" int64_t spk_painn_fm_grad_floats(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int32_t n_types) {
+  if (!m || !head || !rb || m->n_interactions < 1 || !m->layers) return -1;
+  const bool shared = m->n_interactions > 1 && m->layers[1].filt_w == m->layers[0].filt_w;
+  return fm_painn_grad_floats(m->n_atom_basis, m->n_interactions, rb->n_rbf, head->n_hidden, n_types, shared ? 1 : 0);
+}
+extern "C" int spk_painn_fm_forward_f32(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace, float* E,
+                                        float* F, int32_t* err, void* stream_) {
+  int rc = fm_common_check(head, rb, "spk_painn_fm_forward_f32");
+  if (rc) return rc;
+  if ((rc = fm_batch_check(batch, "spk_painn_fm_forward_f32"))) return rc;
+  SPK_CHECK_ARG(workspace && E, "spk_painn_fm_forward_f32: null workspace / output");
+  std::vector<FmPainnLayer<float>> lay;
+  FmPainnModel<float> mm;
+  if ((rc = fm_painn_model(m, rb, lay, mm, "spk_painn_fm_forward_f32"))) return rc;
+  FmDeviceBackend be((hipStream_t)stream_);
+  FmDev eng(be);
+  rc = eng.painn_forward(mm, fm_head(head), fm_radial(rb), fm_batch(batch), workspace, E, F, err);
+  if (rc) return rc;
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+extern "C" int spk_painn_fm_backward_f32(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
+                                         const float* gE, const float* gF, float* grads, void* stream_) {
+  int rc = fm_common_check(head, rb, "spk_painn_fm_backward_f32");
+  if (rc) return rc;
+  if ((rc = fm_batch_check(batch, "spk_painn_fm_backward_f32"))) return rc;
+  SPK_CHECK_ARG(workspace && gE && gF && grads, "spk_painn_fm_backward_f32: null pointer");
+  std::vector<FmPainnLayer<float>> lay;
+  FmPainnModel<float> mm;
+  if ((rc = fm_painn_model(m, rb, lay, mm, "spk_painn_fm_backward_f32"))) return rc;
+  FmDeviceBackend be((hipStream_t)stream_);
+  FmDev eng(be);
+  rc = eng.painn_backward(mm, fm_head(head), fm_radial(rb), fm_batch(batch), workspace, gE, gF, grads);
+  if (rc) return rc;
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

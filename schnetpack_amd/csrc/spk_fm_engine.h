@@ -1,0 +1,455 @@
+// Force-matching gradient engine: host orchestration of the four passes (see spk_fm_kernels.h and oracle/fm_oracle.py)
+//   forward  = A (values) + B (reverse w.r.t. the positions)                    -> energies, forces
+//   backward = C (tangents along t = -dL/dF) + D (reverse of the dual graph)    -> the gradient of L w.r.t. every weight
+// for a loss L(E, F) given gE = dL/dE, gF = dL/dF: what the reference gets from autograd with create_graph=True
+// (atomistic/response.py:59-68, task.py:166-185) as a second-order graph of several hundred nodes is here ~100 launches of
+// Dense / weight-gradient GEMMs on [value ; tangent]-stacked rows and of the element-wise / row kernels of spk_fm_kernels.h.
+//
+// The code is a template over a BACKEND that provides the Dense GEMMs, the transposed (weight-gradient) GEMM, CSR helpers and
+// the kernel launcher: spk_fm.hip instantiates it on the device (T = float; spk_dense_f32 / spk_gemm_tn on the fp32 MFMA,
+// rocPRIM for the by-neighbour CSR), tests/fm_emu instantiates it with serial loops in float64 / float32 on the build box
+// (test infrastructure: the orchestration is identical, so a wrong buffer, stride or formula is caught without a GPU).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include "spk_fm_kernels.h"
+
+template <class T>
+struct FmSchnetLayer { const T *in2f_w, *fn_w1, *fn_b1, *fn_w2, *fn_b2, *f2out_w1, *f2out_b1, *f2out_w2, *f2out_b2; };
+template <class T>
+struct FmPainnLayer { const T *ctx_w1, *ctx_b1, *ctx_w2, *ctx_b2, *mix_w, *ictx_w1, *ictx_b1, *ictx_w2, *ictx_b2; };
+template <class T>
+struct FmHead { const T *w1, *b1, *w2, *b2; int n_hidden, act; };
+template <class T>
+struct FmBatch {
+  int64_t N, E, M;
+  const int64_t *Z, *ii, *jj, *idx_m;   // atomic numbers, pair indices (ii ascending), molecule index (ascending)
+  const T *R, *off;                     // positions [N,3], pair offsets [E,3] or NULL
+  const T* emb;                         // nuclear embedding table [n_types, F]
+  int n_types;
+};
+template <class T>
+struct FmSchnetModel { int F, nf, L; const FmSchnetLayer<T>* layers; };
+template <class T>
+struct FmPainnModel { int F, L, shared_filters; T eps; const FmPainnLayer<T>* layers; const T *filt_w, *filt_b; };   // filter_net.{weight, bias}, all rows
+
+// ---------------------------------------------------------------------------------------------------------------- workspace arena
+// One pass over the same carving code computes the size (base == NULL) or binds the pointers.
+struct FmArena {
+  char* base;
+  size_t off;
+  explicit FmArena(void* b) : base((char*)b), off(0) {}
+  template <class U>
+  U* take(int64_t n) {
+    U* r = base ? (U*)(base + off) : nullptr;
+    off += ((size_t)(n > 0 ? n : 1) * sizeof(U) + 255) & ~(size_t)255;
+    return r;
+  }
+};
+
+template <class T>
+struct FmCommonWs {
+  int32_t *rowptr, *rowptr_m, *colptr, *perm, *csrc, *e_act;
+  void* plan_tmp;
+  T *d, *u, *fc, *fc1, *phi2, *dt, *ut, *gd, *gu, *gr;
+  T *preh2, *th2, *e_atom, *gt2, *gpre2, *gEa2;
+  T* gemm_ws;
+  uint32_t* tickets;
+};
+
+// flat gradient layouts (floats): SchNet  [per interaction: the nine tensors of spk_schnet_layer_t] | head w1 b1 w2 b2 | embedding
+//                                 PaiNN   [per interaction: the nine tensors of spk_painn_layer_t] | filter_net w, b | head | embedding
+static inline int64_t fm_schnet_layer_grad_floats(int F, int nf, int K) { return (int64_t)nf * F + (int64_t)nf * K + nf + (int64_t)nf * nf + nf + (int64_t)F * nf + F + (int64_t)F * F + F; }
+static inline int64_t fm_painn_layer_grad_floats(int F) { return (int64_t)F * F + F + 3ll * F * F + 3 * F + 2ll * F * F + 2ll * F * F + F + 3ll * F * F + 3 * F; }
+static inline int64_t fm_head_grad_floats(int F, int H) { return (int64_t)H * F + H + H + 1; }
+static inline int64_t fm_schnet_grad_floats(int F, int nf, int L, int K, int H, int n_types) {
+  return L * fm_schnet_layer_grad_floats(F, nf, K) + fm_head_grad_floats(F, H) + (int64_t)n_types * F;
+}
+static inline int64_t fm_painn_grad_floats(int F, int L, int K, int H, int n_types, int shared) {
+  const int Lf = shared ? 1 : L;
+  return L * fm_painn_layer_grad_floats(F) + 3ll * F * Lf * K + 3ll * F * Lf + fm_head_grad_floats(F, H) + (int64_t)n_types * F;
+}
+
+template <class T, class B>
+struct FmEngine {
+  B& be;
+  explicit FmEngine(B& b) : be(b) {}
+
+  // ------------------------------------------------------------------------------------------------ shared pieces
+  void carve_common(FmArena& a, FmCommonWs<T>& w, int64_t N, int64_t E, int64_t M, int K, int H, bool painn, int64_t gemm_ws_floats) {
+    w.tickets = a.take<uint32_t>(4096 + 64);              // [4096] ticket counters of the weight-gradient GEMM | [64] e_act (zeroed together)
+    w.e_act = (int32_t*)(w.tickets ? w.tickets + 4096 : nullptr);
+    w.rowptr = a.take<int32_t>(N + 1);
+    w.rowptr_m = a.take<int32_t>(M + 1);
+    w.colptr = a.take<int32_t>(N + 2);
+    w.perm = a.take<int32_t>(E);
+    w.csrc = a.take<int32_t>(E);
+    w.gr = a.take<T>(3 * E);
+    w.plan_tmp = a.take<char>((int64_t)be.transpose_tmp_bytes(E, N));
+    w.d = a.take<T>(E); w.u = a.take<T>(3 * E); w.fc = a.take<T>(E); w.fc1 = a.take<T>(E);
+    w.phi2 = a.take<T>(2 * E * K);
+    w.dt = a.take<T>(E); w.gd = a.take<T>(E);
+    w.ut = painn ? a.take<T>(3 * E) : nullptr;
+    w.gu = painn ? a.take<T>(3 * E) : nullptr;
+    w.preh2 = a.take<T>(2 * N * H); w.th2 = a.take<T>(2 * N * H); w.e_atom = a.take<T>(N);
+    w.gt2 = a.take<T>(2 * N * H); w.gpre2 = a.take<T>(2 * N * H); w.gEa2 = a.take<T>(2 * N);
+    w.gemm_ws = a.take<T>(gemm_ws_floats);
+  }
+
+  int prepare(const FmBatch<T>& b, const FmRadial<T>& rb, FmCommonWs<T>& w, int32_t* err) {
+    int rc;
+    if ((rc = be.zero_u32(w.tickets, 4096 + 64))) return rc;
+    if ((rc = be.rowptr(b.ii, b.E, b.N, w.rowptr, err))) return rc;
+    if ((rc = be.rowptr(b.idx_m, b.N, b.M, w.rowptr_m, err))) return rc;
+    if ((rc = be.transpose_plan(b.jj, b.E, b.N, w.colptr, w.perm, w.plan_tmp))) return rc;
+    be.flat("fm_colsrc", k_fm_colsrc<T>, b.E, w.perm, b.ii, b.E, b.N, w.csrc, (T*)nullptr);
+    be.flat("fm_geom", k_fm_geom<T>, b.E, b.R, b.off, b.ii, b.jj, b.E, b.N, rb, w.d, w.u, w.fc, w.fc1, w.phi2, w.e_act);
+    return 0;
+  }
+
+  // energy head on x [N, F] (atomistic/atomwise.py:69-88): pre_h, th = act(pre_h), e_i, E_m
+  int head_forward(const FmBatch<T>& b, const FmHead<T>& hd, int F, const T* x, FmCommonWs<T>& w, T* E_out, const int32_t* err) {
+    const int H = hd.n_hidden;
+    int rc;
+    if ((rc = be.dense(x, hd.w1, hd.b1, nullptr, w.th2, w.preh2, b.N, F, H, hd.act))) return rc;
+    be.rows("fm_head_e", k_fm_rowdot_bias<T>, b.N, w.th2, hd.w2, hd.b2, b.N, H, w.e_atom);
+    be.rows("fm_head_E", k_fm_segsum1<T>, b.M, w.e_atom, w.rowptr_m, b.M, err, E_out);
+    return 0;
+  }
+  // dE_tot/dx -> gx [N, F]
+  int head_backward_R(const FmBatch<T>& b, const FmHead<T>& hd, int F, FmCommonWs<T>& w, T* gx) {
+    const int H = hd.n_hidden;
+    be.flat("fm_bcast", k_fm_bcast_rows<T>, b.N * H, hd.w2, (const T*)nullptr, (const int64_t*)nullptr, b.N, H, (int64_t)0, w.gt2);
+    return be.dense_bwd_input(w.gt2, w.preh2, hd.w1, nullptr, gx, b.N, F, H, hd.act);
+  }
+  int head_tangent(const FmBatch<T>& b, const FmHead<T>& hd, int F, const T* xt, FmCommonWs<T>& w) {
+    const int H = hd.n_hidden;
+    int rc;
+    if ((rc = be.dense(xt, hd.w1, nullptr, nullptr, w.preh2 + b.N * H, nullptr, b.N, F, H, FM_ACT_NONE))) return rc;
+    be.flat("fm_act_t", k_fm_act_tangent<T>, b.N * H, w.preh2, w.preh2 + b.N * H, b.N * H, hd.act, w.th2 + b.N * H);
+    return 0;
+  }
+  // reverse of the dual head: S = sum_i gE_i e_i + sum_i et_i; x2 = [x ; xt]; -> gx2 = [gx ; hx] [2N, F] and the head's gradients
+  int head_dual_backward(const FmBatch<T>& b, const FmHead<T>& hd, int F, const T* x2, const T* gE, FmCommonWs<T>& w, T* gx2, T* g_head) {
+    const int H = hd.n_hidden;
+    const int64_t N = b.N;
+    T* g_w1 = g_head;
+    T* g_b1 = g_w1 + (int64_t)H * F;
+    T* g_w2 = g_b1 + H;
+    T* g_b2 = g_w2 + H;
+    int rc;
+    be.flat("fm_gather1", k_fm_gather1<T>, N, gE, b.idx_m, N, b.M, w.gEa2, w.gEa2 + N);
+    if ((rc = be.gemm_tn(w.gEa2, w.th2, 2 * N, 1, H, g_w2, g_b2, N))) return rc;
+    be.flat("fm_bcast", k_fm_bcast_rows<T>, N * H, hd.w2, (const T*)w.gEa2, (const int64_t*)nullptr, N, H, N, w.gt2);
+    be.flat("fm_bcast", k_fm_bcast_rows<T>, N * H, hd.w2, (const T*)nullptr, (const int64_t*)nullptr, N, H, (int64_t)0, w.gt2 + N * H);
+    be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, N * H, w.gt2, w.preh2, N * H, hd.act, w.gpre2);
+    if ((rc = be.gemm_tn(w.gpre2, x2, 2 * N, H, F, g_w1, g_b1, N))) return rc;
+    return be.dense_bwd_input(w.gpre2, nullptr, hd.w1, nullptr, gx2, 2 * N, F, H, FM_ACT_NONE);
+  }
+
+  // ================================================================================================ SchNet
+  struct SchnetWs {
+    FmCommonWs<T> c;
+    std::vector<T*> X2, h2, a2, z2, Wf2, y2, p32, s2;
+    T *gxa, *gxb, *gs2, *gp2, *gy2, *gh2, *gg2, *gz2, *ga2;
+    size_t bytes;
+  };
+  void schnet_carve(void* base, const FmSchnetModel<T>& m, int K, int H, int64_t N, int64_t E, int64_t M, SchnetWs& w) {
+    FmArena a(base);
+    const int F = m.F, nf = m.nf, L = m.L;
+    int64_t gw = 0;
+    auto need = [&](int64_t n, int O, int Kk) { const int64_t v = be.gemm_tn_ws_floats(n, O, Kk); if (v > gw) gw = v; };
+    need(2 * N, 1, H); need(2 * N, H, F); need(2 * N, F, F); need(2 * N, F, nf); need(2 * E, nf, nf); need(2 * E, nf, K); need(2 * N, nf, F);
+    carve_common(a, w.c, N, E, M, K, H, false, gw);
+    w.X2.resize(L + 1);
+    for (int l = 0; l <= L; ++l) w.X2[l] = a.take<T>(2 * N * F);
+    w.h2.resize(L); w.a2.resize(L); w.z2.resize(L); w.Wf2.resize(L); w.y2.resize(L); w.p32.resize(L); w.s2.resize(L);
+    for (int l = 0; l < L; ++l) {
+      w.h2[l] = a.take<T>(2 * N * nf); w.a2[l] = a.take<T>(2 * E * nf); w.z2[l] = a.take<T>(2 * E * nf); w.Wf2[l] = a.take<T>(2 * E * nf);
+      w.y2[l] = a.take<T>(2 * N * nf); w.p32[l] = a.take<T>(2 * N * F); w.s2[l] = a.take<T>(2 * N * F);
+    }
+    w.gxa = a.take<T>(2 * N * F); w.gxb = a.take<T>(2 * N * F); w.gs2 = a.take<T>(2 * N * F); w.gp2 = a.take<T>(2 * N * F);
+    w.gy2 = a.take<T>(2 * N * nf); w.gh2 = a.take<T>(2 * N * nf);
+    w.gg2 = a.take<T>(2 * E * nf); w.gz2 = a.take<T>(2 * E * nf); w.ga2 = a.take<T>(2 * E * nf);
+    w.bytes = a.off;
+  }
+
+  // passes A + B
+  int schnet_forward(const FmSchnetModel<T>& m, const FmHead<T>& hd, const FmRadial<T>& rb, const FmBatch<T>& b, void* ws, T* E_out, T* F_out, int32_t* err) {
+    SchnetWs w;
+    const int F = m.F, nf = m.nf, L = m.L, K = rb.n_rbf;
+    const int64_t N = b.N, E = b.E;
+    schnet_carve(ws, m, K, hd.n_hidden, N, E, b.M, w);
+    be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
+    int rc;
+    if ((rc = prepare(b, rb, w.c, err))) return rc;
+    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.X2[0]);
+    for (int l = 0; l < L; ++l) {                                            // ---- pass A
+      const FmSchnetLayer<T>& P = m.layers[l];
+      T *a2 = w.a2[l], *z2 = w.z2[l], *Wf2 = w.Wf2[l];
+      // filter network, value and d-derivative (schnet.py:61): a = phi W1^T + b1, a1 = phi1 W1^T; z = ssp(a), z1 = ssp'(a) a1; g = z W2^T + b2, g1 = z1 W2^T
+      if ((rc = be.dense(w.c.phi2, P.fn_w1, P.fn_b1, nullptr, z2, a2, E, K, nf, FM_ACT_SSP))) return rc;
+      if ((rc = be.dense(w.c.phi2 + E * K, P.fn_w1, nullptr, nullptr, a2 + E * nf, nullptr, E, K, nf, FM_ACT_NONE))) return rc;
+      be.flat("fm_act_t", k_fm_act_tangent<T>, E * nf, a2, a2 + E * nf, E * nf, FM_ACT_SSP, z2 + E * nf);
+      if ((rc = be.dense(z2, P.fn_w2, P.fn_b2, nullptr, Wf2, nullptr, E, nf, nf, FM_ACT_NONE))) return rc;
+      if ((rc = be.dense(z2 + E * nf, P.fn_w2, nullptr, nullptr, Wf2 + E * nf, nullptr, E, nf, nf, FM_ACT_NONE))) return rc;
+      be.flat("fm_filter_fc", k_fm_filter_fc<T>, E * nf, Wf2, w.c.fc, w.c.fc1, E, nf);
+      if ((rc = be.dense(w.X2[l], P.in2f_w, nullptr, nullptr, w.h2[l], nullptr, N, F, nf, FM_ACT_NONE))) return rc;
+      be.flat("fm_cfconv", k_fm_cfconv<T>, N * nf, w.h2[l], Wf2, w.c.rowptr, b.jj, w.c.e_act, N, nf, w.y2[l]);
+      if ((rc = be.dense(w.y2[l], P.f2out_w1, P.f2out_b1, nullptr, w.s2[l], w.p32[l], N, nf, F, FM_ACT_SSP))) return rc;
+      if ((rc = be.dense(w.s2[l], P.f2out_w2, P.f2out_b2, w.X2[l], w.X2[l + 1], nullptr, N, F, F, FM_ACT_NONE))) return rc;
+    }
+    if ((rc = head_forward(b, hd, F, w.X2[L], w.c, E_out, err))) return rc;
+    if (!F_out) return 0;
+    if ((rc = head_backward_R(b, hd, F, w.c, w.gxa))) return rc;            // ---- pass B
+    be.flat("fm_zero", k_fm_zero<T>, E, w.c.gd, E);
+    for (int l = L - 1; l >= 0; --l) {
+      const FmSchnetLayer<T>& P = m.layers[l];
+      if ((rc = be.dense_bwd_input(w.gxa, nullptr, P.f2out_w2, nullptr, w.gs2, N, F, F, FM_ACT_NONE))) return rc;
+      if ((rc = be.dense_bwd_input(w.gs2, w.p32[l], P.f2out_w1, nullptr, w.gy2, N, nf, F, FM_ACT_SSP))) return rc;
+      be.rows("fm_cfconv_gd", k_fm_cfconv_gd<T>, E, w.gy2, w.h2[l], w.Wf2[l] + E * nf, b.ii, b.jj, E, N, nf, w.c.gd);
+      if (l > 0) {
+        be.flat("fm_cfconv_T", k_fm_cfconv_T<T>, N * nf, w.gy2, w.Wf2[l], w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, nf, w.gh2);
+        if ((rc = be.dense_bwd_input(w.gh2, nullptr, P.in2f_w, w.gxa, w.gxb, N, F, nf, FM_ACT_NONE))) return rc;
+        T* t = w.gxa; w.gxa = w.gxb; w.gxb = t;
+      }
+    }
+    be.flat("fm_gr", k_fm_gr<T>, E, w.c.gd, (const T*)nullptr, w.c.u, w.c.d, E, w.c.gr);
+    be.flat("fm_force", k_fm_force<T>, N * 3, w.c.gr, w.c.rowptr, w.c.colptr, w.c.perm, w.c.e_act, N, F_out);
+    return 0;
+  }
+
+  // passes C + D; `grads` in the flat layout of fm_schnet_grad_floats(); the workspace must be the one the forward call filled
+  int schnet_backward(const FmSchnetModel<T>& m, const FmHead<T>& hd, const FmRadial<T>& rb, const FmBatch<T>& b, void* ws, const T* gE, const T* gF, T* grads) {
+    SchnetWs w;
+    const int F = m.F, nf = m.nf, L = m.L, K = rb.n_rbf, H = hd.n_hidden;
+    const int64_t N = b.N, E = b.E;
+    schnet_carve(ws, m, K, H, N, E, b.M, w);
+    be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
+    int rc;
+    be.flat("fm_tgeom", k_fm_tgeom<T>, E, gF, b.ii, b.jj, w.c.d, w.c.u, E, N, w.c.dt, (T*)nullptr);
+    for (int l = 0; l < L; ++l) {                                            // ---- pass C
+      const FmSchnetLayer<T>& P = m.layers[l];
+      T* ht = l > 0 ? w.h2[l] + N * nf : nullptr;
+      if (l > 0 && (rc = be.dense(w.X2[l] + N * F, P.in2f_w, nullptr, nullptr, ht, nullptr, N, F, nf, FM_ACT_NONE))) return rc;
+      be.flat("fm_cfconv_t", k_fm_cfconv_t<T>, N * nf, w.h2[l], (const T*)ht, w.Wf2[l], w.Wf2[l] + E * nf, w.c.dt, w.c.rowptr, b.jj, w.c.e_act, N, nf, w.y2[l] + N * nf);
+      if ((rc = be.dense(w.y2[l] + N * nf, P.f2out_w1, nullptr, nullptr, w.p32[l] + N * F, nullptr, N, nf, F, FM_ACT_NONE))) return rc;
+      be.flat("fm_act_t", k_fm_act_tangent<T>, N * F, w.p32[l], w.p32[l] + N * F, N * F, FM_ACT_SSP, w.s2[l] + N * F);
+      if ((rc = be.dense(w.s2[l] + N * F, P.f2out_w2, nullptr, l > 0 ? w.X2[l] + N * F : nullptr, w.X2[l + 1] + N * F, nullptr, N, F, F, FM_ACT_NONE))) return rc;
+    }
+    if ((rc = head_tangent(b, hd, F, w.X2[L] + N * F, w.c))) return rc;
+    const int64_t lg = fm_schnet_layer_grad_floats(F, nf, K);
+    T* g_head = grads + L * lg;
+    T* g_emb = g_head + fm_head_grad_floats(F, H);
+    if ((rc = head_dual_backward(b, hd, F, w.X2[L], gE, w.c, w.gxa, g_head))) return rc;
+    for (int l = L - 1; l >= 0; --l) {                                       // ---- pass D
+      const FmSchnetLayer<T>& P = m.layers[l];
+      T* g = grads + l * lg;
+      T* g_in2f = g; g += (int64_t)nf * F;
+      T* g_w1 = g; g += (int64_t)nf * K;
+      T* g_b1 = g; g += nf;
+      T* g_w2 = g; g += (int64_t)nf * nf;
+      T* g_b2 = g; g += nf;
+      T* g_o1 = g; g += (int64_t)F * nf;
+      T* g_ob1 = g; g += F;
+      T* g_o2 = g; g += (int64_t)F * F;
+      T* g_ob2 = g;
+      const int64_t nr = l > 0 ? 2 * N : N;      // rows that carry a tangent partner at the INPUT of this interaction (xt_0 = 0)
+      if ((rc = be.gemm_tn(w.gxa, w.s2[l], 2 * N, F, F, g_o2, g_ob2, N))) return rc;
+      if ((rc = be.dense_bwd_input(w.gxa, nullptr, P.f2out_w2, nullptr, w.gs2, 2 * N, F, F, FM_ACT_NONE))) return rc;
+      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, N * F, w.gs2, w.p32[l], N * F, FM_ACT_SSP, w.gp2);
+      if ((rc = be.gemm_tn(w.gp2, w.y2[l], 2 * N, F, nf, g_o1, g_ob1, N))) return rc;
+      if ((rc = be.dense_bwd_input(w.gp2, nullptr, P.f2out_w1, nullptr, w.gy2, 2 * N, nf, F, FM_ACT_NONE))) return rc;
+      be.flat("fm_cfconv_T_dual", k_fm_cfconv_T_dual<T>, N * nf, w.gy2, w.Wf2[l], w.c.dt, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, E, nf, w.gh2);
+      be.flat("fm_filter_cot", k_fm_filter_cot<T>, E * nf, w.gy2, w.h2[l], (const T*)(l > 0 ? w.h2[l] + N * nf : nullptr), w.c.dt, w.c.fc, w.c.fc1, b.ii, b.jj, N, E,
+              nf, w.gg2);
+      if ((rc = be.gemm_tn(w.gg2, w.z2[l], 2 * E, nf, nf, g_w2, g_b2, E))) return rc;
+      if ((rc = be.dense_bwd_input(w.gg2, nullptr, P.fn_w2, nullptr, w.gz2, 2 * E, nf, nf, FM_ACT_NONE))) return rc;
+      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, E * nf, w.gz2, w.a2[l], E * nf, FM_ACT_SSP, w.ga2);
+      if ((rc = be.gemm_tn(w.ga2, w.c.phi2, 2 * E, nf, K, g_w1, g_b1, E))) return rc;
+      if ((rc = be.gemm_tn(w.gh2, w.X2[l], nr, nf, F, g_in2f, nullptr, nr))) return rc;
+      if ((rc = be.dense_bwd_input(w.gh2, nullptr, P.in2f_w, w.gxa, w.gxb, nr, F, nf, FM_ACT_NONE))) return rc;
+      T* t = w.gxa; w.gxa = w.gxb; w.gxb = t;
+    }
+    be.flat("fm_embed_grad", k_fm_embed_grad<T>, (int64_t)b.n_types * F, w.gxa, b.Z, N, F, b.n_types, g_emb);
+    return 0;
+  }
+
+  // ================================================================================================ PaiNN
+  struct PainnWs {
+    FmCommonWs<T> c;
+    T* Phi2;
+    std::vector<T*> Q2, MU2, pa2, sa2, c2, q1_2, mu1_2, VW2, n2, svw2, ctx2, pb2, sb2, a2;
+    T *gq_a, *gq_b, *gmu_a, *gmu_b, *ga2, *gsb2, *gpb2, *gctx2, *gVW2, *gq1_2, *gmu1_2, *gc2, *gsa2, *gpa2, *gP2, *gtmp;
+    size_t bytes;
+  };
+  void painn_carve(void* base, const FmPainnModel<T>& m, int K, int H, int64_t N, int64_t E, int64_t M, PainnWs& w) {
+    FmArena a(base);
+    const int F = m.F, L = m.L;
+    const int64_t ld = 3ll * F * (m.shared_filters ? 1 : L);
+    int64_t gw = 0;
+    auto need = [&](int64_t n, int O, int Kk) { const int64_t v = be.gemm_tn_ws_floats(n, O, Kk); if (v > gw) gw = v; };
+    need(2 * N, 1, H); need(2 * N, H, F); need(2 * N, 3 * F, F); need(2 * N, F, 2 * F); need(6 * N, 2 * F, F); need(2 * E, 3 * F, K); need(2 * N, F, F);
+    carve_common(a, w.c, N, E, M, K, H, true, gw);
+    w.Phi2 = a.take<T>(2 * E * ld);
+    auto vec = [&](std::vector<T*>& v, int n, int64_t floats) { v.resize(n); for (int l = 0; l < n; ++l) v[l] = a.take<T>(floats); };
+    vec(w.Q2, L + 1, 2 * N * F);
+    vec(w.MU2, L + 1, 6 * N * F);
+    vec(w.pa2, L, 2 * N * F); vec(w.sa2, L, 2 * N * F); vec(w.c2, L, 6 * N * F); vec(w.q1_2, L, 2 * N * F); vec(w.mu1_2, L, 6 * N * F);
+    vec(w.VW2, L, 12 * N * F); vec(w.n2, L, 2 * N * F); vec(w.svw2, L, 2 * N * F); vec(w.ctx2, L, 4 * N * F); vec(w.pb2, L, 2 * N * F);
+    vec(w.sb2, L, 2 * N * F); vec(w.a2, L, 6 * N * F);
+    w.gq_a = a.take<T>(2 * N * F); w.gq_b = a.take<T>(2 * N * F); w.gmu_a = a.take<T>(6 * N * F); w.gmu_b = a.take<T>(6 * N * F);
+    w.ga2 = a.take<T>(6 * N * F); w.gsb2 = a.take<T>(2 * N * F); w.gpb2 = a.take<T>(2 * N * F); w.gctx2 = a.take<T>(4 * N * F);
+    w.gVW2 = a.take<T>(12 * N * F); w.gq1_2 = a.take<T>(2 * N * F); w.gmu1_2 = a.take<T>(6 * N * F); w.gc2 = a.take<T>(6 * N * F);
+    w.gsa2 = a.take<T>(2 * N * F); w.gpa2 = a.take<T>(2 * N * F); w.gP2 = a.take<T>(6 * E * F);
+    w.gtmp = a.take<T>(m.shared_filters ? 3ll * F * K + 3 * F : 1);
+    w.bytes = a.off;
+  }
+
+  int painn_forward(const FmPainnModel<T>& m, const FmHead<T>& hd, const FmRadial<T>& rb, const FmBatch<T>& b, void* ws, T* E_out, T* F_out, int32_t* err) {
+    PainnWs w;
+    const int F = m.F, L = m.L, K = rb.n_rbf;
+    const int64_t N = b.N, E = b.E;
+    const int ld = 3 * F * (m.shared_filters ? 1 : L);
+    painn_carve(ws, m, K, hd.n_hidden, N, E, b.M, w);
+    be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
+    int rc;
+    if ((rc = prepare(b, rb, w.c, err))) return rc;
+    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.Q2[0]);
+    // every interaction's filter rows at once (painn.py:232-236): Phi = (phi Wf^T + bf) f_c, with the d-derivative beside it
+    if ((rc = be.dense(w.c.phi2, m.filt_w, m.filt_b, nullptr, w.Phi2, nullptr, E, K, ld, FM_ACT_NONE))) return rc;
+    if ((rc = be.dense(w.c.phi2 + E * K, m.filt_w, nullptr, nullptr, w.Phi2 + E * (int64_t)ld, nullptr, E, K, ld, FM_ACT_NONE))) return rc;
+    be.flat("fm_filter_fc", k_fm_filter_fc<T>, E * (int64_t)ld, w.Phi2, w.c.fc, w.c.fc1, E, ld);
+    for (int l = 0; l < L; ++l) {                                            // ---- pass A
+      const FmPainnLayer<T>& P = m.layers[l];
+      const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);
+      const T* mu = l > 0 ? w.MU2[l] : nullptr;
+      if ((rc = be.dense(w.Q2[l], P.ctx_w1, P.ctx_b1, nullptr, w.sa2[l], w.pa2[l], N, F, F, FM_ACT_SILU))) return rc;
+      if ((rc = be.dense(w.sa2[l], P.ctx_w2, P.ctx_b2, nullptr, w.c2[l], nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_msg", k_fm_painn_msg<T>, N * F, w.Q2[l], mu, w.c2[l], Phi, ld, w.c.u, w.c.rowptr, b.jj, w.c.e_act, N, F, w.q1_2[l], w.mu1_2[l]);
+      if ((rc = be.dense(w.mu1_2[l], P.mix_w, nullptr, nullptr, w.VW2[l], nullptr, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_mix", k_fm_painn_mix<T>, N * F, w.q1_2[l], w.VW2[l], m.eps, N, F, w.n2[l], w.svw2[l], w.ctx2[l]);
+      if ((rc = be.dense(w.ctx2[l], P.ictx_w1, P.ictx_b1, nullptr, w.sb2[l], w.pb2[l], N, 2 * F, F, FM_ACT_SILU))) return rc;
+      if ((rc = be.dense(w.sb2[l], P.ictx_w2, P.ictx_b2, nullptr, w.a2[l], nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_update", k_fm_painn_update<T>, N * F, w.q1_2[l], w.mu1_2[l], w.VW2[l], w.a2[l], w.svw2[l], N, F, w.Q2[l + 1], w.MU2[l + 1]);
+    }
+    if ((rc = head_forward(b, hd, F, w.Q2[L], w.c, E_out, err))) return rc;
+    if (!F_out) return 0;
+    if ((rc = head_backward_R(b, hd, F, w.c, w.gq_a))) return rc;           // ---- pass B
+    be.flat("fm_zero", k_fm_zero<T>, E, w.c.gd, E);
+    be.flat("fm_zero", k_fm_zero<T>, 3 * E, w.c.gu, 3 * E);
+    const T* gmu = nullptr;                                                  // the head does not read the vector representation
+    for (int l = L - 1; l >= 0; --l) {
+      const FmPainnLayer<T>& P = m.layers[l];
+      const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);
+      const T* mu = l > 0 ? w.MU2[l] : nullptr;
+      be.flat("fm_painn_update_bwd", k_fm_painn_update_bwd<T>, N * F, w.gq_a, gmu, w.VW2[l], w.a2[l], w.svw2[l], N, F, w.ga2, w.gVW2);
+      if ((rc = be.dense_bwd_input(w.ga2, nullptr, P.ictx_w2, nullptr, w.gsb2, N, F, 3 * F, FM_ACT_NONE))) return rc;
+      if ((rc = be.dense_bwd_input(w.gsb2, w.pb2[l], P.ictx_w1, nullptr, w.gctx2, N, 2 * F, F, FM_ACT_SILU))) return rc;
+      be.flat("fm_painn_mix_bwd", k_fm_painn_mix_bwd<T>, N * F, w.gq_a, w.gctx2, w.VW2[l], w.n2[l], N, F, w.gq1_2, w.gVW2);
+      if ((rc = be.dense_bwd_input(w.gVW2, nullptr, P.mix_w, gmu, w.gmu1_2, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
+      be.rows("fm_painn_msg_gd", k_fm_painn_msg_gd<T>, E, w.gq1_2, w.gmu1_2, w.c2[l], mu, Phi, ld, w.c.u, b.ii, b.jj, E, N, F, w.c.gd, w.c.gu);
+      if (l > 0) {
+        be.flat("fm_painn_msg_T", k_fm_painn_msg_T<T>, N * F, w.gq1_2, w.gmu1_2, w.c2[l], mu, Phi, ld, w.c.u, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, F, w.gc2, w.gmu_a);
+        if ((rc = be.dense_bwd_input(w.gc2, nullptr, P.ctx_w2, nullptr, w.gsa2, N, F, 3 * F, FM_ACT_NONE))) return rc;
+        if ((rc = be.dense_bwd_input(w.gsa2, w.pa2[l], P.ctx_w1, w.gq1_2, w.gq_a, N, F, F, FM_ACT_SILU))) return rc;
+        gmu = w.gmu_a;
+        T* t = w.gmu_a; w.gmu_a = w.gmu_b; w.gmu_b = t;
+      }
+    }
+    be.flat("fm_gr", k_fm_gr<T>, E, w.c.gd, (const T*)w.c.gu, w.c.u, w.c.d, E, w.c.gr);
+    be.flat("fm_force", k_fm_force<T>, N * 3, w.c.gr, w.c.rowptr, w.c.colptr, w.c.perm, w.c.e_act, N, F_out);
+    return 0;
+  }
+
+  // `grads` in the flat layout of fm_painn_grad_floats()
+  int painn_backward(const FmPainnModel<T>& m, const FmHead<T>& hd, const FmRadial<T>& rb, const FmBatch<T>& b, void* ws, const T* gE, const T* gF, T* grads) {
+    PainnWs w;
+    const int F = m.F, L = m.L, K = rb.n_rbf, H = hd.n_hidden;
+    const int64_t N = b.N, E = b.E;
+    const int Lf = m.shared_filters ? 1 : L;
+    const int ld = 3 * F * Lf;
+    painn_carve(ws, m, K, H, N, E, b.M, w);
+    be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
+    int rc;
+    be.flat("fm_tgeom", k_fm_tgeom<T>, E, gF, b.ii, b.jj, w.c.d, w.c.u, E, N, w.c.dt, w.c.ut);
+    const int64_t NF = N * F;
+    for (int l = 0; l < L; ++l) {                                            // ---- pass C
+      const FmPainnLayer<T>& P = m.layers[l];
+      const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);
+      const int first = l == 0;
+      if (!first) {
+        if ((rc = be.dense(w.Q2[l] + NF, P.ctx_w1, nullptr, nullptr, w.pa2[l] + NF, nullptr, N, F, F, FM_ACT_NONE))) return rc;
+        be.flat("fm_act_t", k_fm_act_tangent<T>, NF, w.pa2[l], w.pa2[l] + NF, NF, FM_ACT_SILU, w.sa2[l] + NF);
+        if ((rc = be.dense(w.sa2[l] + NF, P.ctx_w2, nullptr, nullptr, w.c2[l] + 3 * NF, nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
+      }
+      be.flat("fm_painn_msg_t", k_fm_painn_msg_t<T>, NF, (const T*)(first ? nullptr : w.Q2[l] + NF), w.c2[l], (const T*)(first ? nullptr : w.MU2[l]), Phi, ld, E, w.c.dt,
+              w.c.u, w.c.ut, w.c.rowptr, b.jj, w.c.e_act, N, F, first, w.q1_2[l] + NF, w.mu1_2[l] + 3 * NF);
+      if ((rc = be.dense(w.mu1_2[l] + 3 * NF, P.mix_w, nullptr, nullptr, w.VW2[l] + 6 * NF, nullptr, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_mix_t", k_fm_painn_mix_t<T>, NF, w.q1_2[l] + NF, w.VW2[l], w.VW2[l] + 6 * NF, w.n2[l], N, F, w.n2[l] + NF, w.svw2[l] + NF, w.ctx2[l] + 2 * NF);
+      if ((rc = be.dense(w.ctx2[l] + 2 * NF, P.ictx_w1, nullptr, nullptr, w.pb2[l] + NF, nullptr, N, 2 * F, F, FM_ACT_NONE))) return rc;
+      be.flat("fm_act_t", k_fm_act_tangent<T>, NF, w.pb2[l], w.pb2[l] + NF, NF, FM_ACT_SILU, w.sb2[l] + NF);
+      if ((rc = be.dense(w.sb2[l] + NF, P.ictx_w2, nullptr, nullptr, w.a2[l] + 3 * NF, nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_update_t", k_fm_painn_update_t<T>, NF, w.q1_2[l] + NF, w.mu1_2[l] + 3 * NF, w.VW2[l], w.VW2[l] + 6 * NF, w.a2[l], w.a2[l] + 3 * NF, w.svw2[l],
+              w.svw2[l] + NF, N, F, w.Q2[l + 1] + NF, w.MU2[l + 1] + 3 * NF);
+    }
+    if ((rc = head_tangent(b, hd, F, w.Q2[L] + NF, w.c))) return rc;
+    const int64_t lg = fm_painn_layer_grad_floats(F);
+    T* g_fw = grads + L * lg;
+    T* g_fb = g_fw + 3ll * F * Lf * K;
+    T* g_head = g_fb + 3ll * F * Lf;
+    T* g_emb = g_head + fm_head_grad_floats(F, H);
+    if ((rc = head_dual_backward(b, hd, F, w.Q2[L], gE, w.c, w.gq_a, g_head))) return rc;
+    const T* gmu2 = nullptr;
+    for (int l = L - 1; l >= 0; --l) {                                       // ---- pass D
+      const FmPainnLayer<T>& P = m.layers[l];
+      const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);
+      const int first = l == 0;
+      T* g = grads + l * lg;
+      T* g_cw1 = g; g += (int64_t)F * F;
+      T* g_cb1 = g; g += F;
+      T* g_cw2 = g; g += 3ll * F * F;
+      T* g_cb2 = g; g += 3 * F;
+      T* g_mix = g; g += 2ll * F * F;
+      T* g_iw1 = g; g += 2ll * F * F;
+      T* g_ib1 = g; g += F;
+      T* g_iw2 = g; g += 3ll * F * F;
+      T* g_ib2 = g;
+      // mixing (painn.py:99-116)
+      be.flat("fm_painn_update_dual_bwd", k_fm_painn_update_dual_bwd<T>, NF, w.gq_a, gmu2, w.VW2[l], w.a2[l], w.svw2[l], N, F, w.ga2, w.gVW2);
+      if ((rc = be.gemm_tn(w.ga2, w.sb2[l], 2 * N, 3 * F, F, g_iw2, g_ib2, N))) return rc;
+      if ((rc = be.dense_bwd_input(w.ga2, nullptr, P.ictx_w2, nullptr, w.gsb2, 2 * N, F, 3 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, NF, w.gsb2, w.pb2[l], NF, FM_ACT_SILU, w.gpb2);
+      if ((rc = be.gemm_tn(w.gpb2, w.ctx2[l], 2 * N, F, 2 * F, g_iw1, g_ib1, N))) return rc;
+      if ((rc = be.dense_bwd_input(w.gpb2, nullptr, P.ictx_w1, nullptr, w.gctx2, 2 * N, 2 * F, F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_mix_dual_bwd", k_fm_painn_mix_dual_bwd<T>, NF, w.gq_a, w.gctx2, w.VW2[l], w.n2[l], N, F, w.gq1_2, w.gVW2);
+      if ((rc = be.gemm_tn(w.gVW2, w.mu1_2[l], 6 * N, 2 * F, F, g_mix, nullptr, 6 * N))) return rc;
+      if ((rc = be.dense_bwd_input(w.gVW2, nullptr, P.mix_w, gmu2, w.gmu1_2, 6 * N, F, 2 * F, FM_ACT_NONE))) return rc;
+      // message (painn.py:50-66)
+      const T* mu2 = first ? nullptr : w.MU2[l];
+      be.flat("fm_painn_filter_cot", k_fm_painn_filter_cot<T>, E * F, w.gq1_2, w.gmu1_2, w.c2[l], mu2, w.c.dt, w.c.u, w.c.ut, w.c.fc, w.c.fc1, b.ii, b.jj, N, E, F, first,
+              w.gP2);
+      if (m.shared_filters && l != L - 1) {
+        if ((rc = be.gemm_tn(w.gP2, w.c.phi2, 2 * E, 3 * F, K, w.gtmp, w.gtmp + 3ll * F * K, E))) return rc;
+        be.flat("fm_axpy", k_fm_axpy<T>, 3ll * F * K + 3 * F, w.gtmp, 3ll * F * K + 3 * F, g_fw);   // (g_fw and g_fb are adjacent when Lf == 1)
+      } else {
+        const int64_t row0 = m.shared_filters ? 0 : 3ll * F * l;
+        if ((rc = be.gemm_tn(w.gP2, w.c.phi2, 2 * E, 3 * F, K, g_fw + row0 * K, g_fb + row0, E))) return rc;
+      }
+      be.flat("fm_painn_msg_T_dual", k_fm_painn_msg_T_dual<T>, NF, w.gq1_2, w.gmu1_2, w.c2[l], mu2, Phi, ld, E, w.c.dt, w.c.u, w.c.ut, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, F,
+              first, w.gc2, w.gmu_a);
+      const int64_t nr = first ? N : 2 * N;
+      if ((rc = be.gemm_tn(w.gc2, w.sa2[l], nr, 3 * F, F, g_cw2, g_cb2, N))) return rc;
+      if ((rc = be.dense_bwd_input(w.gc2, nullptr, P.ctx_w2, nullptr, w.gsa2, nr, F, 3 * F, FM_ACT_NONE))) return rc;
+      if (first) be.flat("fm_act_t", k_fm_act_tangent<T>, NF, w.pa2[l], w.gsa2, NF, FM_ACT_SILU, w.gpa2);
+      else be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, NF, w.gsa2, w.pa2[l], NF, FM_ACT_SILU, w.gpa2);
+      if ((rc = be.gemm_tn(w.gpa2, w.Q2[l], nr, F, F, g_cw1, g_cb1, N))) return rc;
+      if ((rc = be.dense_bwd_input(w.gpa2, nullptr, P.ctx_w1, w.gq1_2, w.gq_a, nr, F, F, FM_ACT_NONE))) return rc;
+      gmu2 = w.gmu_a;
+      T* t = w.gmu_a; w.gmu_a = w.gmu_b; w.gmu_b = t;
+    }
+    be.flat("fm_embed_grad", k_fm_embed_grad<T>, (int64_t)b.n_types * F, w.gq_a, b.Z, N, F, b.n_types, g_emb);
+    return 0;
+  }
+};

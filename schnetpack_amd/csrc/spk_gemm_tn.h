@@ -7,12 +7,13 @@
 #define TN_ROWS_PER_BLOCK 512
 struct GemmTnArgs {
   const float* U; const float* X; int64_t n; int O, K, tiles_k, S, n_tiles; int64_t rows_per_slice, rows_per_wave;
+  int64_t nb;   // the column sums of U (bias gradient) run over rows [0, nb) only: [value ; tangent]-stacked operands carry a bias on the value rows
   float* G; float* gb; float* ws; float* wsb; unsigned* tickets;
 };
 // one workgroup of 64 * TN_WAVES threads = (tile, slice s); n_tiles = number of output tiles (the grid width of the stand-alone launch)
 __device__ __forceinline__ void gemm_tn_block(const GemmTnArgs& a, int tile, int s) {
   const float* __restrict__ U = a.U; const float* __restrict__ X = a.X;
-  const int64_t n = a.n, rows_per_slice = a.rows_per_slice, rows_per_wave = a.rows_per_wave;
+  const int64_t n = a.n, rows_per_slice = a.rows_per_slice, rows_per_wave = a.rows_per_wave, nb = a.nb;
   const int O = a.O, K = a.K, tiles_k = a.tiles_k, S = a.S, NT_ = a.n_tiles;
   float* __restrict__ G = a.G; float* __restrict__ gb = a.gb; float* __restrict__ ws = a.ws; float* __restrict__ wsb = a.wsb;
   unsigned* __restrict__ tickets = a.tickets;
@@ -44,7 +45,7 @@ __device__ __forceinline__ void gemm_tn_block(const GemmTnArgs& a, int tile, int
 #pragma unroll
     for (int q = 0; q < TN_BATCH; ++q) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
-      usum += av[q];
+      usum += (rb + 2 * q + hi < nb) ? av[q] : 0.f;
     }
   }
   usum += __shfl_xor(usum, 32, 64);
@@ -99,7 +100,7 @@ static inline GemmTnArgs spk_gemm_tn_args(const float* U, const float* X, int64_
   rpw += rpw & 1;                                                       // whole MFMA steps per wave
   if (rpw < 2) rpw = 2;
   GemmTnArgs a;
-  a.U = U; a.X = X; a.n = n; a.O = O; a.K = K; a.tiles_k = (K + 31) / 32; a.S = S; a.n_tiles = tiles;
+  a.U = U; a.X = X; a.n = n; a.nb = n; a.O = O; a.K = K; a.tiles_k = (K + 31) / 32; a.S = S; a.n_tiles = tiles;
   a.rows_per_slice = rpw * TN_WAVES; a.rows_per_wave = rpw;
   a.G = G; a.gb = gb; a.ws = ws; a.wsb = ws ? ws + (int64_t)S * tiles * 1024 : nullptr; a.tickets = (unsigned*)tickets;
   return a;

@@ -1000,6 +1000,7 @@ const char* kEvalOnly =
     "training path is differentiable to any order in all parameters.";
 
 #include "spk_torch_train.h"
+#include "spk_torch_fm.h"
 
 // ------------------------------------------------------------------------------------------------ autograd: primitives
 // scatter_add <-> gather are each other's transposes; both backward passes call the differentiable operator again, so the
@@ -1692,6 +1693,7 @@ TORCH_LIBRARY(spk_hip, m) {
   m.def("weights_changed() -> ()", weights_changed_op);
   // training regime: operators closed under differentiation (spk_torch_train.h)
   train_defs(m);
+  fm_defs(m);
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm devices in PyTorch-ROCm
@@ -1726,6 +1728,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CUDA, m) {   // "CUDA" is the dispatch key of ROCm d
   m.impl("static_declare_range", static_declare_range_op);
   m.impl("edge_plan_install", edge_plan_install_op);
   train_impl_device(m);
+  fm_impl_device(m);
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, Autograd, m) {
@@ -1741,6 +1744,7 @@ TORCH_LIBRARY_IMPL(spk_hip, Autograd, m) {
   m.impl("schnet_potential", schnet_potential_ad);
   m.impl("eval_guard", eval_guard_ad);
   train_impl_autograd(m);
+  fm_impl_autograd(m);
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, CPU, m) {
@@ -1750,6 +1754,7 @@ TORCH_LIBRARY_IMPL(spk_hip, CPU, m) {
                            "schnet_potential_forward", "schnet_potential_backward", "schnet_potential_forces", "painn_potential_forces", "potential_plan"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
   for (const char* name : kTrainOps) m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
+  for (const char* name : kFmOps) m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }
 
 TORCH_LIBRARY_IMPL(spk_hip, Meta, m) {
@@ -1778,4 +1783,5 @@ TORCH_LIBRARY_IMPL(spk_hip, Meta, m) {
   m.impl("eval_guard", eval_guard_dev);
   m.impl("schnet_potential_backward", schnet_potential_backward_meta);
   train_impl_meta(m);
+  fm_impl_meta(m);
 }

@@ -606,6 +606,8 @@ struct FmLossFn : public torch::autograd::Function<FmLossFn> {
     return std::get<0>(r);
   }
   static variable_list backward(AutogradContext* ctx, variable_list g) {
+    TORCH_CHECK(!at::GradMode::is_enabled(), "spk_hip::fm_loss: the backward of the loss node is not recorded (create_graph=True through the loss itself would silently "
+                "drop d(dL/dE)/dE and d(dL/dF)/dF); write the loss with torch arithmetic if it has to be differentiated twice");
     auto sv = ctx->get_saved_variables();
     static auto op = op_handle<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&)>("spk_hip::fm_loss_backward");
     at::AutoDispatchBelowADInplaceOrView guard;

@@ -90,7 +90,15 @@ extern "C" int spk_gemm_tn_plan(int64_t n, int32_t O, int32_t K, int32_t* n_slic
 
 extern "C" int spk_gemm_tn_f32(const float* U, const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, float* ws, uint32_t* tickets,
                                void* stream_) {
+  return spk_gemm_tn_nb_f32(U, X, n, O, K, G, gb, n, ws, tickets, stream_);
+}
+
+// the same with the bias gradient (column sums of U) restricted to the rows [0, n_bias): operands stacked as [value rows ; tangent rows]
+// carry a bias on the value rows only (force-matching engine, spk_fm_engine.h)
+extern "C" int spk_gemm_tn_nb_f32(const float* U, const float* X, int64_t n, int32_t O, int32_t K, float* G, float* gb, int64_t n_bias, float* ws,
+                                  uint32_t* tickets, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(n_bias >= 0 && n_bias <= n, "spk_gemm_tn_nb_f32: n_bias outside [0, n]");
   int32_t S, tiles;
   int64_t wsf;
   int rc = spk_gemm_tn_plan(n, O, K, &S, &wsf, &tiles);
@@ -100,6 +108,7 @@ extern "C" int spk_gemm_tn_f32(const float* U, const float* X, int64_t n, int32_
   SPK_CHECK_ARG(tiles <= 4096, "spk_gemm_tn_f32: %d output tiles (max 4096)", tiles);
   SpkProfScope prof("gemm_tn", stream);
   GemmTnArgs a = spk_gemm_tn_args(U, X, n, O, K, S, tiles, G, gb, ws, tickets);
+  a.nb = n_bias;
   hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(64 * TN_WAVES), 0, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;

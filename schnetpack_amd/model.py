@@ -103,6 +103,57 @@ def potential_forces_forward(model, inputs: Dict[str, torch.Tensor]) -> Dict[str
     return inputs
 
 
+def potential_fm_forward(model, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """TRAINING mode of the standard potential: ``torch.ops.spk_hip.schnet_fm`` / ``painn_fm`` -- energies and forces from one
+    operator whose backward is the forward-over-reverse engine (csrc/spk_fm.hip): the gradient of any loss(E, F) w.r.t. every
+    weight in ~100 launches, where ``Forces(create_graph=True)`` (atomistic/response.py:59-68) records a second-order graph of
+    several hundred nodes.  The positions enter detached: the operator differentiates w.r.t. the weights only."""
+    rep, head, frc = model.representation, model.output_modules[0], model.output_modules[1]
+    idx_m = inputs[properties.idx_m]
+    kind, p0, p1 = rep.radial_basis.kernel_params()
+    l0, l1 = head.outnet[0], head.outnet[1]
+    common = (rep.embedding.weight, inputs[properties.Z], inputs[properties.R].detach(), inputs.get(properties.offsets), inputs[properties.idx_i],
+              inputs[properties.idx_j], idx_m, head._n_molecules(inputs, idx_m), rep.interaction_weights(), [l0.weight, l0.bias, l1.weight, l1.bias])
+    if isinstance(rep, PaiNN):
+        E, F = torch.ops.spk_hip.painn_fm(*common, rep.share_filters, rep._eps(), kind, p0, p1, rep.cutoff_fn.cutoff_value(), model._fm_head_act)
+    else:
+        E, F = torch.ops.spk_hip.schnet_fm(*common, rep.n_filters, kind, p0, p1, rep.cutoff_fn.cutoff_value(), model._fm_head_act)
+    inputs[head.output_key] = E
+    inputs[frc.force_key] = F
+    return inputs
+
+
+def classify_fm(model) -> int:
+    """Activation id of the energy head (> 0) when the force-matching engine covers the model, else 0: ``PairwiseDistances`` -> fused-able
+    ``SchNet`` / ``PaiNN`` with a plain nuclear embedding table -> ``Atomwise`` (two Dense layers, width-1 output, summed per molecule; ANY
+    hidden width) -> ``Forces`` of that energy without stress.  Looser than :func:`classify_potential`: the engine's Dense layers take any
+    width, so e.g. n_atom_basis = 32 (head width 16) trains through it although the fused eval head does not cover it."""
+    from . import _lib
+    from .nn import Dense
+    from .nn.base import activation_id
+    rep, ins, outs = model.representation, list(model.input_modules), list(model.output_modules)
+    if not (isinstance(rep, (SchNet, PaiNN)) and rep._fused and len(rep.interactions) > 0):
+        return 0
+    if not (type(rep.embedding) is nn.Embedding and len(rep.electronic_embeddings) == 0):
+        return 0
+    if not (len(ins) == 1 and type(ins[0]) is PairwiseDistances and len(outs) == 2):
+        return 0
+    head, frc = outs
+    if not (isinstance(head, Atomwise) and head.per_atom_output_key is None and head.aggregation_mode == "sum" and head.n_out == 1):
+        return 0
+    net = head.outnet
+    if not (isinstance(net, nn.Sequential) and len(net) == 2 and all(isinstance(l, Dense) for l in net)):
+        return 0
+    act = activation_id(net[0].activation)
+    if act not in (_lib.SPK_ACT_SSP, _lib.SPK_ACT_SILU) or activation_id(net[1].activation) != _lib.SPK_ACT_NONE:
+        return 0
+    if net[1].out_features != 1 or net[0].bias is None or net[1].bias is None:
+        return 0
+    if not (_is_forces(frc) and frc.calc_forces and not frc.calc_stress and frc.energy_key == head.output_key):
+        return 0
+    return int(act)
+
+
 class NeuralNetworkPotential(nn.Module):
     """input_modules -> representation -> output_modules (dict in, dict out); TorchScript-able like the reference's
     (src/scripts/spkdeploy:16-40 scripts the whole model).
@@ -118,6 +169,10 @@ class NeuralNetworkPotential(nn.Module):
     model_outputs: List[str]
     _potential: Final[bool]
     _potential_forces: Final[bool]
+    #: training mode of the standard potential through the force-matching engine (``spk_hip::schnet_fm`` / ``painn_fm``: weight
+    #: gradients of a loss(E, F) by forward-over-reverse).  Set to False for the operator-by-operator path (any-order autograd).
+    fm_engine: bool
+    _fm_head_act: int
 
     def __init__(self, representation: nn.Module, input_modules: List[nn.Module] = None,
                  output_modules: List[nn.Module] = None):
@@ -140,6 +195,12 @@ class NeuralNetworkPotential(nn.Module):
         self._potential = mode >= 1
         # ... and when the only other output is Forces' -dE/dR, energies AND forces come from the two launches directly
         self._potential_forces = mode == 2
+        self._fm_head_act = classify_fm(self)
+        self.fm_engine = self._fm_head_act > 0
+
+    @torch.jit.unused
+    def _potential_fm_forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        return potential_fm_forward(self, inputs)
 
     @torch.jit.unused
     def _potential_forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -155,6 +216,9 @@ class NeuralNetworkPotential(nn.Module):
                 inputs[p].requires_grad_()
         if self._potential_forces and not self.training and not torch.jit.is_scripting():
             inputs = self._potential_forces_forward(inputs)
+            return {k: inputs[k] for k in self.model_outputs}
+        if self.training and self.fm_engine and not torch.jit.is_scripting():
+            inputs = self._potential_fm_forward(inputs)
             return {k: inputs[k] for k in self.model_outputs}
         if self._potential and not self.training and not torch.jit.is_scripting():
             inputs = self._potential_forward(inputs)
