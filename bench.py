@@ -1074,9 +1074,11 @@ def train_measure(args, kind, rank, world, dev, dist, model, rep_p, head_p, step
                              group=(dist.group.WORLD if dist is not None else None), use_graph=not args.no_graph)
     reducer = tstep.reducer
 
+    # resident batches in the packed layout of the step's two static buffers (what a collate worker hands over): two copies per load
+    packed = [tstep.pack(p[0], p[2], p[3], device=dev) for p in pool]
+
     def step(i):
-        _, bd, Et, Ft = pool[i % len(pool)]
-        tstep.load(bd, Et, Ft)
+        tstep.load_packed(*packed[i % len(packed)])
         return tstep.step()
 
     # launches of one step: the HIP-event profile scopes of the library see its own launches; the step's total (incl. the framework's

@@ -199,6 +199,85 @@ __global__ __launch_bounds__(256) void k_dense_mfma_splitk(const float* __restri
   }
 }
 
+// Few output tiles (small batches: a training step has 168 - 336 rows per Dense layer): one tile per WORKGROUP, the four waves split the
+// contraction chunk-wise (K = 128 -> one chunk of four k-blocks each: ONE memory round trip per wave instead of a chain of them), the partial
+// tiles meet in LDS in wave order (deterministic), wave 0 runs the epilogue of dense_tiles (bias, pre-activation store, activation, residual).
+// Same operand conventions and template switches as k_dense_mfma.
+template <int ACT, bool TRANS, int PRO, int CH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_dense_mfma_sk(const float* __restrict__ in, const float* __restrict__ pre_in, const float* __restrict__ w,
+                                                       const float* __restrict__ b, const float* res, float* out, float* __restrict__ pre_out, int64_t M, int KC,
+                                                       int NW) {
+  __shared__ float red[WAVES - 1][32][33];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  const int tcount = (NW + 31) / 32;
+  const int nug = (KC + 7) / 8;
+  const int nch = (nug + CH - 1) / CH;
+  const int64_t task = blockIdx.x;
+  const int64_t mt = task / tcount;
+  const int t = (int)(task % tcount);
+  const int64_t m = mt * 32 + el;
+  const bool valid = m < M;
+  const int64_t mc = valid ? m : (M - 1);
+  const float* inrow = in + mc * KC;
+  const float* prow = PRO != SPK_ACT_NONE ? pre_in + mc * KC : nullptr;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32x4 a0[CH], b0[CH], a1[CH], b1[CH];
+  if (wv < nch) dense_load_chunk<TRANS, PRO>(a0, b0, wv, nug, inrow, prow, w, KC, NW, t, el, hi);
+  f32x4 rv[4];
+  if (wv == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      rv[q] = (res && valid && 32 * t + 8 * q + 4 * hi < NW) ? *(const f32x4*)(res + m * NW + 32 * t + 8 * q + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int c = wv; c < nch; c += 2 * WAVES) {
+    if (c + WAVES < nch) dense_load_chunk<TRANS, PRO>(a1, b1, c + WAVES, nug, inrow, prow, w, KC, NW, t, el, hi);
+    acc = dense_mfma_chunk(a0, b0, c, nug, acc);
+    if (c + 2 * WAVES < nch) dense_load_chunk<TRANS, PRO>(a0, b0, c + 2 * WAVES, nug, inrow, prow, w, KC, NW, t, el, hi);
+    if (c + WAVES < nch) acc = dense_mfma_chunk(a1, b1, c + WAVES, nug, acc);
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv - 1][(r & 3) + 8 * (r >> 2) + 4 * hi][el] = acc[r];
+  }
+  __syncthreads();
+  if (wv == 0 && valid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = 32 * t + 8 * q + 4 * hi;
+      if (col >= NW) continue;
+      const int64_t off = m * NW + col;
+      f32x4 o;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 4 * q + v, rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float sum = acc[r];
+#pragma unroll
+        for (int q2 = 0; q2 < WAVES - 1; ++q2) sum += red[q2][rr][el];
+        o[v] = sum + (b ? b[col + v] : 0.f);
+      }
+      if (pre_out) *(f32x4*)(pre_out + off) = o;
+      o.x = spk_act<ACT>(o.x); o.y = spk_act<ACT>(o.y); o.z = spk_act<ACT>(o.z); o.w = spk_act<ACT>(o.w);
+      if (res) o += rv[q];
+      *(f32x4*)(out + off) = o;
+    }
+  }
+}
+
+template <int ACT, bool TRANS, int PRO>
+static void dense_sk_launch(int KC, unsigned ntasks, hipStream_t stream, const float* in, const float* pre_in, const float* w, const float* b, const float* res, float* out,
+                            float* pre_out, int64_t M, int NW) {
+  // chunk = 2 / 4 k-blocks over four waves up to K = 128 (every wave gets one chunk: one memory round trip), eight waves with chunks of 4 beyond
+  const int nug = (KC + 7) / 8;
+#define SPK_SK(CH, WV) hipLaunchKernelGGL((k_dense_mfma_sk<ACT, TRANS, PRO, CH, WV>), dim3(ntasks), dim3(64 * WV), 0, stream, in, pre_in, w, b, res, out, pre_out, M, KC, NW)
+  if (nug <= 8) SPK_SK(2, 4);
+  else if (nug <= 16) SPK_SK(4, 4);
+  else SPK_SK(4, 8);
+#undef SPK_SK
+}
+
 // Straightforward kernel for any shape: one thread per output element.
 __global__ void k_dense_simple(const float* __restrict__ in, const float* __restrict__ pre_in,
                                const float* __restrict__ w, const float* __restrict__ b,
@@ -247,7 +326,29 @@ static int dense_dispatch(const float* in, const float* pre_in, const float* w, 
   const bool mfma_combo = (pro == SPK_ACT_NONE) || (act == SPK_ACT_NONE && trans);
   if (shape_ok && mfma_combo && variant != SPK_VARIANT_SIMPLE) {
     const int64_t ntasks = ((M + 31) / 32) * ((NW + 31) / 32);
-    if (KC >= 256 && ntasks <= 2 * (int64_t)spk_num_cus() && act == SPK_ACT_NONE && pro == SPK_ACT_NONE && !res && !pre_out) {
+    if (ntasks <= 4 * (int64_t)spk_num_cus() && KC >= 16 && !getenv("SPK_DENSE_NO_SK")) {
+      // few tiles: one tile per workgroup, the contraction split over its waves
+      const unsigned nt = (unsigned)ntasks;
+#define SPK_SKL(A, T, P) dense_sk_launch<A, T, P>(KC, nt, stream, in, pre_in, w, b, res, out, pre_out, M, NW)
+      if (pro == SPK_ACT_NONE) {
+        if (!trans) {
+          if (act == SPK_ACT_NONE) SPK_SKL(SPK_ACT_NONE, false, SPK_ACT_NONE);
+          else if (act == SPK_ACT_SSP) SPK_SKL(SPK_ACT_SSP, false, SPK_ACT_NONE);
+          else SPK_SKL(SPK_ACT_SILU, false, SPK_ACT_NONE);
+        } else {
+          if (act == SPK_ACT_NONE) SPK_SKL(SPK_ACT_NONE, true, SPK_ACT_NONE);
+          else if (act == SPK_ACT_SSP) SPK_SKL(SPK_ACT_SSP, true, SPK_ACT_NONE);
+          else SPK_SKL(SPK_ACT_SILU, true, SPK_ACT_NONE);
+        }
+      } else {
+        if (pro == SPK_ACT_SSP) SPK_SKL(SPK_ACT_NONE, true, SPK_ACT_SSP);
+        else SPK_SKL(SPK_ACT_NONE, true, SPK_ACT_SILU);
+      }
+#undef SPK_SKL
+      SPK_LAUNCH_CHECK();
+      return SPK_OK;
+    }
+    if (getenv("SPK_DENSE_NO_SK") && KC >= 256 && ntasks <= 2 * (int64_t)spk_num_cus() && act == SPK_ACT_NONE && pro == SPK_ACT_NONE && !res && !pre_out) {
       if (trans) hipLaunchKernelGGL((k_dense_mfma_splitk<true>), dim3((unsigned)ntasks), dim3(256), 0, stream, in, w, b, out, M, KC, NW);
       else hipLaunchKernelGGL((k_dense_mfma_splitk<false>), dim3((unsigned)ntasks), dim3(256), 0, stream, in, w, b, out, M, KC, NW);
       SPK_LAUNCH_CHECK();

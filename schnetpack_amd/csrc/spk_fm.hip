@@ -66,18 +66,71 @@ extern "C" int spk_transpose_plan(const int64_t* idx_j, int64_t E, int64_t N, in
   return SPK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ batched weight-gradient GEMMs
+// Every weight gradient of a pass is G = U^T X over [value ; tangent]-stacked rows (spk_gemm_tn.h).  The ~20 problems of a step are
+// independent of each other and of the rest of pass D, and each is tiny (a few hundred rows): as separate launches they cost ~19 us
+// apiece (latency), together they fill the chip once.  Descriptors travel as kernel arguments (< 4 KB), so nothing is staged in memory.
+#include "spk_gemm_tn.h"
+#define FM_TN_MAX 24
+struct GemmTnBatch {
+  int n;
+  int prefix[FM_TN_MAX + 1];   // first workgroup of every problem
+  GemmTnArgs a[FM_TN_MAX];
+};
+__global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_tn_batched(GemmTnBatch b_) {
+  // The problem index is dynamic: indexing the by-value argument would make the compiler copy all of it (2.8 KB) into scratch per lane
+  // (first version: 227 us for what is 15 us of work).  Read the descriptor of this workgroup's problem from the kernel-argument segment
+  // itself -- constant memory, uniform address, scalar loads.
+  typedef const __attribute__((address_space(4))) GemmTnBatch* BatchPtr;      // keep the constant address space: uniform index => s_load
+  BatchPtr b = (BatchPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)b_;
+  int p = 0;
+  const int n = b->n;
+  while (p + 1 < n && (int)blockIdx.x >= b->prefix[p + 1]) ++p;
+  const int local = (int)blockIdx.x - b->prefix[p];
+  GemmTnArgs a;
+  a.U = b->a[p].U; a.X = b->a[p].X; a.n = b->a[p].n; a.O = b->a[p].O; a.K = b->a[p].K; a.tiles_k = b->a[p].tiles_k; a.S = b->a[p].S; a.n_tiles = b->a[p].n_tiles;
+  a.rows_per_slice = b->a[p].rows_per_slice; a.rows_per_wave = b->a[p].rows_per_wave; a.nb = b->a[p].nb;
+  a.G = b->a[p].G; a.gb = b->a[p].gb; a.ws = b->a[p].ws; a.wsb = b->a[p].wsb; a.tickets = b->a[p].tickets;
+  gemm_tn_block(a, local % a.n_tiles, local / a.n_tiles);
+}
+
 // ------------------------------------------------------------------------------------------------ device backend of the engine
 struct FmDeviceBackend {
   hipStream_t stream;
   float* gws = nullptr;
   uint32_t* tickets = nullptr;
   int max_blocks;
-  explicit FmDeviceBackend(hipStream_t s) : stream(s), max_blocks(spk_num_cus() * 32) {}
+  GemmTnBatch batch;
+  int64_t ws_used = 0;
+  int tickets_used = 0;
+  explicit FmDeviceBackend(hipStream_t s) : stream(s), max_blocks(spk_num_cus() * 32) { batch.n = 0; batch.prefix[0] = 0; }
   void set_gemm_ws(float* w, uint32_t* t) { gws = w; tickets = t; }
+  int gemm_flush() {
+    if (batch.n == 0) return SPK_OK;
+    SpkProfScope prof("gemm_tn_batched", stream);
+    hipLaunchKernelGGL(k_gemm_tn_batched, dim3(batch.prefix[batch.n]), dim3(64 * TN_WAVES), 0, stream, batch);
+    batch.n = 0;
+    ws_used = 0;
+    tickets_used = 0;
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
+  // Slices of one problem meet through memory behind __threadfence() -- on this part an agent-scope release writes the XCD's L2 back, tens of
+  // microseconds when a few hundred workgroups do it (first batched version: 167 us for 15 us of work).  The batch as a whole already
+  // fills the chip, so a problem is cut into slices only when a slice still has >= 4096 rows: training-step sizes run with S = 1 (no fence).
+  static void tn_plan(int64_t n, int O, int K, int32_t* S, int64_t* wsf, int32_t* tiles) {
+    *tiles = ((O + 31) / 32) * ((K + 31) / 32);
+    int64_t s = n / 4096;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    *S = (int32_t)s;
+    *wsf = s > 1 ? s * (int64_t)*tiles * (1024 + 32) : 0;
+  }
   int64_t gemm_tn_ws_floats(int64_t n, int O, int K) {
     int32_t S, tiles;
     int64_t wsf = 0;
-    if (spk_gemm_tn_plan(n, O, K, &S, &wsf, &tiles)) return 0;
+    tn_plan(n, O, K, &S, &wsf, &tiles);
     return wsf;
   }
   size_t transpose_tmp_bytes(int64_t E, int64_t N) { return (size_t)spk_transpose_plan_bytes(E, N); }
@@ -90,8 +143,24 @@ struct FmDeviceBackend {
   int dense_bwd_input(const float* dy, const float* pre, const float* w, const float* res, float* dx, int64_t m, int k, int n_out, int act) {
     return spk_dense_bwd_input_f32(dy, pre, w, res, dx, m, k, n_out, act, stream);
   }
+  // deferred: the problem joins the batch that gemm_flush() launches (the engine keeps U and X intact until then)
   int gemm_tn(const float* U, const float* X, int64_t n, int O, int K, float* G, float* gb, int64_t n_bias) {
-    return spk_gemm_tn_nb_f32(U, X, n, O, K, G, gb, n_bias, gws, tickets, stream);
+    int32_t S, tiles;
+    int64_t wsf;
+    int rc;
+    tn_plan(n, O, K, &S, &wsf, &tiles);
+    SPK_CHECK_ARG(tiles <= 4096 && U && X && G && n_bias <= n, "fm engine: bad weight-gradient problem");
+    if (batch.n == FM_TN_MAX || tickets_used + tiles > 4096) {
+      if ((rc = gemm_flush())) return rc;
+    }
+    GemmTnArgs a = spk_gemm_tn_args(U, X, n, O, K, S, tiles, G, gb, gws ? gws + ws_used : nullptr, tickets + tickets_used);
+    a.nb = n_bias;
+    batch.a[batch.n] = a;
+    batch.prefix[batch.n + 1] = batch.prefix[batch.n] + tiles * S;
+    ++batch.n;
+    ws_used += wsf;
+    tickets_used += tiles;
+    return SPK_OK;
   }
   template <class... KA, class... A>
   void flat(const char* tag, void (*k)(KA...), int64_t total, A... a) {
@@ -129,7 +198,7 @@ static FmBatch<float> fm_batch(const spk_fm_batch_t* b) {
 }
 
 static int fm_schnet_model(const spk_schnet_t* m, std::vector<FmSchnetLayer<float>>& lay, FmSchnetModel<float>& out, const char* who) {
-  SPK_CHECK_ARG(m && m->n_atom_basis >= 1 && m->n_filters >= 1 && m->n_interactions >= 0 && (m->n_interactions == 0 || m->layers), "%s: bad model description", who);
+  SPK_CHECK_ARG(m && m->n_atom_basis >= 1 && m->n_filters >= 1 && m->n_interactions >= 1 && m->layers, "%s: bad model description (at least one interaction)", who);
   lay.resize((size_t)m->n_interactions);
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_schnet_layer_t& P = m->layers[l];

@@ -152,15 +152,16 @@ struct FmEngine {
   struct SchnetWs {
     FmCommonWs<T> c;
     std::vector<T*> X2, h2, a2, z2, Wf2, y2, p32, s2;
-    T *gxa, *gxb, *gs2, *gp2, *gy2, *gh2, *gg2, *gz2, *ga2;
+    std::vector<T*> GX, gp2, gh2, gg2, ga2;     // per interaction: operands of the weight-gradient GEMMs, which run as ONE batched launch at the end of pass D
+    T *gs2, *gy2, *gz2;
     size_t bytes;
   };
   void schnet_carve(void* base, const FmSchnetModel<T>& m, int K, int H, int64_t N, int64_t E, int64_t M, SchnetWs& w) {
     FmArena a(base);
     const int F = m.F, nf = m.nf, L = m.L;
-    int64_t gw = 0;
-    auto need = [&](int64_t n, int O, int Kk) { const int64_t v = be.gemm_tn_ws_floats(n, O, Kk); if (v > gw) gw = v; };
-    need(2 * N, 1, H); need(2 * N, H, F); need(2 * N, F, F); need(2 * N, F, nf); need(2 * E, nf, nf); need(2 * E, nf, K); need(2 * N, nf, F);
+    int64_t gw = 0;      // the weight-gradient GEMMs of a pass run concurrently (one batched launch): their slice workspaces add up
+    auto need = [&](int64_t n, int O, int Kk, int times) { gw += times * be.gemm_tn_ws_floats(n, O, Kk); };
+    need(2 * N, 1, H, 1); need(2 * N, H, F, 1); need(2 * N, F, F, L); need(2 * N, F, nf, L); need(2 * E, nf, nf, L); need(2 * E, nf, K, L); need(2 * N, nf, F, L);
     carve_common(a, w.c, N, E, M, K, H, false, gw);
     w.X2.resize(L + 1);
     for (int l = 0; l <= L; ++l) w.X2[l] = a.take<T>(2 * N * F);
@@ -169,9 +170,13 @@ struct FmEngine {
       w.h2[l] = a.take<T>(2 * N * nf); w.a2[l] = a.take<T>(2 * E * nf); w.z2[l] = a.take<T>(2 * E * nf); w.Wf2[l] = a.take<T>(2 * E * nf);
       w.y2[l] = a.take<T>(2 * N * nf); w.p32[l] = a.take<T>(2 * N * F); w.s2[l] = a.take<T>(2 * N * F);
     }
-    w.gxa = a.take<T>(2 * N * F); w.gxb = a.take<T>(2 * N * F); w.gs2 = a.take<T>(2 * N * F); w.gp2 = a.take<T>(2 * N * F);
-    w.gy2 = a.take<T>(2 * N * nf); w.gh2 = a.take<T>(2 * N * nf);
-    w.gg2 = a.take<T>(2 * E * nf); w.gz2 = a.take<T>(2 * E * nf); w.ga2 = a.take<T>(2 * E * nf);
+    w.GX.resize(L + 1);
+    for (int l = 0; l <= L; ++l) w.GX[l] = a.take<T>(2 * N * F);
+    w.gp2.resize(L); w.gh2.resize(L); w.gg2.resize(L); w.ga2.resize(L);
+    for (int l = 0; l < L; ++l) {
+      w.gp2[l] = a.take<T>(2 * N * F); w.gh2[l] = a.take<T>(2 * N * nf); w.gg2[l] = a.take<T>(2 * E * nf); w.ga2[l] = a.take<T>(2 * E * nf);
+    }
+    w.gs2 = a.take<T>(2 * N * F); w.gy2 = a.take<T>(2 * N * nf); w.gz2 = a.take<T>(2 * E * nf);
     w.bytes = a.off;
   }
 
@@ -202,17 +207,18 @@ struct FmEngine {
     }
     if ((rc = head_forward(b, hd, F, w.X2[L], w.c, E_out, err))) return rc;
     if (!F_out) return 0;
-    if ((rc = head_backward_R(b, hd, F, w.c, w.gxa))) return rc;            // ---- pass B
+    T *gxa = w.GX[L], *gxb = w.GX[0], *ghb = w.gh2[0];                      // pass B borrows pass-D buffers (it ends before D starts)
+    if ((rc = head_backward_R(b, hd, F, w.c, gxa))) return rc;              // ---- pass B
     be.flat("fm_zero", k_fm_zero<T>, E, w.c.gd, E);
     for (int l = L - 1; l >= 0; --l) {
       const FmSchnetLayer<T>& P = m.layers[l];
-      if ((rc = be.dense_bwd_input(w.gxa, nullptr, P.f2out_w2, nullptr, w.gs2, N, F, F, FM_ACT_NONE))) return rc;
+      if ((rc = be.dense_bwd_input(gxa, nullptr, P.f2out_w2, nullptr, w.gs2, N, F, F, FM_ACT_NONE))) return rc;
       if ((rc = be.dense_bwd_input(w.gs2, w.p32[l], P.f2out_w1, nullptr, w.gy2, N, nf, F, FM_ACT_SSP))) return rc;
       be.rows("fm_cfconv_gd", k_fm_cfconv_gd<T>, E, w.gy2, w.h2[l], w.Wf2[l] + E * nf, b.ii, b.jj, E, N, nf, w.c.gd);
       if (l > 0) {
-        be.flat("fm_cfconv_T", k_fm_cfconv_T<T>, N * nf, w.gy2, w.Wf2[l], w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, nf, w.gh2);
-        if ((rc = be.dense_bwd_input(w.gh2, nullptr, P.in2f_w, w.gxa, w.gxb, N, F, nf, FM_ACT_NONE))) return rc;
-        T* t = w.gxa; w.gxa = w.gxb; w.gxb = t;
+        be.flat("fm_cfconv_T", k_fm_cfconv_T<T>, N * nf, w.gy2, w.Wf2[l], w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, nf, ghb);
+        if ((rc = be.dense_bwd_input(ghb, nullptr, P.in2f_w, gxa, gxb, N, F, nf, FM_ACT_NONE))) return rc;
+        T* t = gxa; gxa = gxb; gxb = t;
       }
     }
     be.flat("fm_gr", k_fm_gr<T>, E, w.c.gd, (const T*)nullptr, w.c.u, w.c.d, E, w.c.gr);
@@ -242,7 +248,7 @@ struct FmEngine {
     const int64_t lg = fm_schnet_layer_grad_floats(F, nf, K);
     T* g_head = grads + L * lg;
     T* g_emb = g_head + fm_head_grad_floats(F, H);
-    if ((rc = head_dual_backward(b, hd, F, w.X2[L], gE, w.c, w.gxa, g_head))) return rc;
+    if ((rc = head_dual_backward(b, hd, F, w.X2[L], gE, w.c, w.GX[L], g_head))) return rc;
     for (int l = L - 1; l >= 0; --l) {                                       // ---- pass D
       const FmSchnetLayer<T>& P = m.layers[l];
       T* g = grads + l * lg;
@@ -255,24 +261,25 @@ struct FmEngine {
       T* g_ob1 = g; g += F;
       T* g_o2 = g; g += (int64_t)F * F;
       T* g_ob2 = g;
+      T *gx = w.GX[l + 1], *gp2 = w.gp2[l], *gh2 = w.gh2[l], *gg2 = w.gg2[l], *ga2 = w.ga2[l];
       const int64_t nr = l > 0 ? 2 * N : N;      // rows that carry a tangent partner at the INPUT of this interaction (xt_0 = 0)
-      if ((rc = be.gemm_tn(w.gxa, w.s2[l], 2 * N, F, F, g_o2, g_ob2, N))) return rc;
-      if ((rc = be.dense_bwd_input(w.gxa, nullptr, P.f2out_w2, nullptr, w.gs2, 2 * N, F, F, FM_ACT_NONE))) return rc;
-      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, N * F, w.gs2, w.p32[l], N * F, FM_ACT_SSP, w.gp2);
-      if ((rc = be.gemm_tn(w.gp2, w.y2[l], 2 * N, F, nf, g_o1, g_ob1, N))) return rc;
-      if ((rc = be.dense_bwd_input(w.gp2, nullptr, P.f2out_w1, nullptr, w.gy2, 2 * N, nf, F, FM_ACT_NONE))) return rc;
-      be.flat("fm_cfconv_T_dual", k_fm_cfconv_T_dual<T>, N * nf, w.gy2, w.Wf2[l], w.c.dt, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, E, nf, w.gh2);
+      if ((rc = be.gemm_tn(gx, w.s2[l], 2 * N, F, F, g_o2, g_ob2, N))) return rc;
+      if ((rc = be.dense_bwd_input(gx, nullptr, P.f2out_w2, nullptr, w.gs2, 2 * N, F, F, FM_ACT_NONE))) return rc;
+      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, N * F, w.gs2, w.p32[l], N * F, FM_ACT_SSP, gp2);
+      if ((rc = be.gemm_tn(gp2, w.y2[l], 2 * N, F, nf, g_o1, g_ob1, N))) return rc;
+      if ((rc = be.dense_bwd_input(gp2, nullptr, P.f2out_w1, nullptr, w.gy2, 2 * N, nf, F, FM_ACT_NONE))) return rc;
+      be.flat("fm_cfconv_T_dual", k_fm_cfconv_T_dual<T>, N * nf, w.gy2, w.Wf2[l], w.c.dt, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, E, nf, gh2);
       be.flat("fm_filter_cot", k_fm_filter_cot<T>, E * nf, w.gy2, w.h2[l], (const T*)(l > 0 ? w.h2[l] + N * nf : nullptr), w.c.dt, w.c.fc, w.c.fc1, b.ii, b.jj, N, E,
-              nf, w.gg2);
-      if ((rc = be.gemm_tn(w.gg2, w.z2[l], 2 * E, nf, nf, g_w2, g_b2, E))) return rc;
-      if ((rc = be.dense_bwd_input(w.gg2, nullptr, P.fn_w2, nullptr, w.gz2, 2 * E, nf, nf, FM_ACT_NONE))) return rc;
-      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, E * nf, w.gz2, w.a2[l], E * nf, FM_ACT_SSP, w.ga2);
-      if ((rc = be.gemm_tn(w.ga2, w.c.phi2, 2 * E, nf, K, g_w1, g_b1, E))) return rc;
-      if ((rc = be.gemm_tn(w.gh2, w.X2[l], nr, nf, F, g_in2f, nullptr, nr))) return rc;
-      if ((rc = be.dense_bwd_input(w.gh2, nullptr, P.in2f_w, w.gxa, w.gxb, nr, F, nf, FM_ACT_NONE))) return rc;
-      T* t = w.gxa; w.gxa = w.gxb; w.gxb = t;
+              nf, gg2);
+      if ((rc = be.gemm_tn(gg2, w.z2[l], 2 * E, nf, nf, g_w2, g_b2, E))) return rc;
+      if ((rc = be.dense_bwd_input(gg2, nullptr, P.fn_w2, nullptr, w.gz2, 2 * E, nf, nf, FM_ACT_NONE))) return rc;
+      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, E * nf, w.gz2, w.a2[l], E * nf, FM_ACT_SSP, ga2);
+      if ((rc = be.gemm_tn(ga2, w.c.phi2, 2 * E, nf, K, g_w1, g_b1, E))) return rc;
+      if ((rc = be.gemm_tn(gh2, w.X2[l], nr, nf, F, g_in2f, nullptr, nr))) return rc;
+      if ((rc = be.dense_bwd_input(gh2, nullptr, P.in2f_w, gx, w.GX[l], nr, F, nf, FM_ACT_NONE))) return rc;
     }
-    be.flat("fm_embed_grad", k_fm_embed_grad<T>, (int64_t)b.n_types * F, w.gxa, b.Z, N, F, b.n_types, g_emb);
+    if ((rc = be.gemm_flush())) return rc;
+    be.flat("fm_embed_grad", k_fm_embed_grad<T>, (int64_t)b.n_types * F, w.GX[0], b.Z, N, F, b.n_types, g_emb);
     return 0;
   }
 
@@ -281,7 +288,8 @@ struct FmEngine {
     FmCommonWs<T> c;
     T* Phi2;
     std::vector<T*> Q2, MU2, pa2, sa2, c2, q1_2, mu1_2, VW2, n2, svw2, ctx2, pb2, sb2, a2;
-    T *gq_a, *gq_b, *gmu_a, *gmu_b, *ga2, *gsb2, *gpb2, *gctx2, *gVW2, *gq1_2, *gmu1_2, *gc2, *gsa2, *gpa2, *gP2, *gtmp;
+    std::vector<T*> ga2, gpb2, gVW2, gP2, gc2, gpa2;     // per interaction: operands of the weight-gradient GEMMs (one batched launch at the end of pass D)
+    T *gq_a, *gq_b, *gmu_a, *gmu_b, *gsb2, *gctx2, *gq1_2, *gmu1_2, *gsa2, *gtmp;
     size_t bytes;
   };
   void painn_carve(void* base, const FmPainnModel<T>& m, int K, int H, int64_t N, int64_t E, int64_t M, PainnWs& w) {
@@ -289,8 +297,8 @@ struct FmEngine {
     const int F = m.F, L = m.L;
     const int64_t ld = 3ll * F * (m.shared_filters ? 1 : L);
     int64_t gw = 0;
-    auto need = [&](int64_t n, int O, int Kk) { const int64_t v = be.gemm_tn_ws_floats(n, O, Kk); if (v > gw) gw = v; };
-    need(2 * N, 1, H); need(2 * N, H, F); need(2 * N, 3 * F, F); need(2 * N, F, 2 * F); need(6 * N, 2 * F, F); need(2 * E, 3 * F, K); need(2 * N, F, F);
+    auto need = [&](int64_t n, int O, int Kk, int times) { gw += times * be.gemm_tn_ws_floats(n, O, Kk); };
+    need(2 * N, 1, H, 1); need(2 * N, H, F, 1); need(2 * N, 3 * F, F, 2 * L); need(2 * N, F, 2 * F, L); need(6 * N, 2 * F, F, L); need(2 * E, 3 * F, K, L); need(2 * N, F, F, L);
     carve_common(a, w.c, N, E, M, K, H, true, gw);
     w.Phi2 = a.take<T>(2 * E * ld);
     auto vec = [&](std::vector<T*>& v, int n, int64_t floats) { v.resize(n); for (int l = 0; l < n; ++l) v[l] = a.take<T>(floats); };
@@ -300,10 +308,10 @@ struct FmEngine {
     vec(w.VW2, L, 12 * N * F); vec(w.n2, L, 2 * N * F); vec(w.svw2, L, 2 * N * F); vec(w.ctx2, L, 4 * N * F); vec(w.pb2, L, 2 * N * F);
     vec(w.sb2, L, 2 * N * F); vec(w.a2, L, 6 * N * F);
     w.gq_a = a.take<T>(2 * N * F); w.gq_b = a.take<T>(2 * N * F); w.gmu_a = a.take<T>(6 * N * F); w.gmu_b = a.take<T>(6 * N * F);
-    w.ga2 = a.take<T>(6 * N * F); w.gsb2 = a.take<T>(2 * N * F); w.gpb2 = a.take<T>(2 * N * F); w.gctx2 = a.take<T>(4 * N * F);
-    w.gVW2 = a.take<T>(12 * N * F); w.gq1_2 = a.take<T>(2 * N * F); w.gmu1_2 = a.take<T>(6 * N * F); w.gc2 = a.take<T>(6 * N * F);
-    w.gsa2 = a.take<T>(2 * N * F); w.gpa2 = a.take<T>(2 * N * F); w.gP2 = a.take<T>(6 * E * F);
-    w.gtmp = a.take<T>(m.shared_filters ? 3ll * F * K + 3 * F : 1);
+    vec(w.ga2, L, 6 * N * F); vec(w.gpb2, L, 2 * N * F); vec(w.gVW2, L, 12 * N * F); vec(w.gP2, L, 6 * E * F); vec(w.gc2, L, 6 * N * F); vec(w.gpa2, L, 2 * N * F);
+    w.gsb2 = a.take<T>(2 * N * F); w.gctx2 = a.take<T>(4 * N * F); w.gq1_2 = a.take<T>(2 * N * F); w.gmu1_2 = a.take<T>(6 * N * F);
+    w.gsa2 = a.take<T>(2 * N * F);
+    w.gtmp = a.take<T>(m.shared_filters ? (int64_t)L * (3ll * F * K + 3 * F) : 1);
     w.bytes = a.off;
   }
 
@@ -340,19 +348,20 @@ struct FmEngine {
     be.flat("fm_zero", k_fm_zero<T>, E, w.c.gd, E);
     be.flat("fm_zero", k_fm_zero<T>, 3 * E, w.c.gu, 3 * E);
     const T* gmu = nullptr;                                                  // the head does not read the vector representation
+    T *ga = w.ga2[0], *gVW = w.gVW2[0], *gc = w.gc2[0];                      // pass B borrows pass-D buffers (it ends before D starts)
     for (int l = L - 1; l >= 0; --l) {
       const FmPainnLayer<T>& P = m.layers[l];
       const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);
       const T* mu = l > 0 ? w.MU2[l] : nullptr;
-      be.flat("fm_painn_update_bwd", k_fm_painn_update_bwd<T>, N * F, w.gq_a, gmu, w.VW2[l], w.a2[l], w.svw2[l], N, F, w.ga2, w.gVW2);
-      if ((rc = be.dense_bwd_input(w.ga2, nullptr, P.ictx_w2, nullptr, w.gsb2, N, F, 3 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_update_bwd", k_fm_painn_update_bwd<T>, N * F, w.gq_a, gmu, w.VW2[l], w.a2[l], w.svw2[l], N, F, ga, gVW);
+      if ((rc = be.dense_bwd_input(ga, nullptr, P.ictx_w2, nullptr, w.gsb2, N, F, 3 * F, FM_ACT_NONE))) return rc;
       if ((rc = be.dense_bwd_input(w.gsb2, w.pb2[l], P.ictx_w1, nullptr, w.gctx2, N, 2 * F, F, FM_ACT_SILU))) return rc;
-      be.flat("fm_painn_mix_bwd", k_fm_painn_mix_bwd<T>, N * F, w.gq_a, w.gctx2, w.VW2[l], w.n2[l], N, F, w.gq1_2, w.gVW2);
-      if ((rc = be.dense_bwd_input(w.gVW2, nullptr, P.mix_w, gmu, w.gmu1_2, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_mix_bwd", k_fm_painn_mix_bwd<T>, N * F, w.gq_a, w.gctx2, w.VW2[l], w.n2[l], N, F, w.gq1_2, gVW);
+      if ((rc = be.dense_bwd_input(gVW, nullptr, P.mix_w, gmu, w.gmu1_2, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
       be.rows("fm_painn_msg_gd", k_fm_painn_msg_gd<T>, E, w.gq1_2, w.gmu1_2, w.c2[l], mu, Phi, ld, w.c.u, b.ii, b.jj, E, N, F, w.c.gd, w.c.gu);
       if (l > 0) {
-        be.flat("fm_painn_msg_T", k_fm_painn_msg_T<T>, N * F, w.gq1_2, w.gmu1_2, w.c2[l], mu, Phi, ld, w.c.u, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, F, w.gc2, w.gmu_a);
-        if ((rc = be.dense_bwd_input(w.gc2, nullptr, P.ctx_w2, nullptr, w.gsa2, N, F, 3 * F, FM_ACT_NONE))) return rc;
+        be.flat("fm_painn_msg_T", k_fm_painn_msg_T<T>, N * F, w.gq1_2, w.gmu1_2, w.c2[l], mu, Phi, ld, w.c.u, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, F, gc, w.gmu_a);
+        if ((rc = be.dense_bwd_input(gc, nullptr, P.ctx_w2, nullptr, w.gsa2, N, F, 3 * F, FM_ACT_NONE))) return rc;
         if ((rc = be.dense_bwd_input(w.gsa2, w.pa2[l], P.ctx_w1, w.gq1_2, w.gq_a, N, F, F, FM_ACT_SILU))) return rc;
         gmu = w.gmu_a;
         T* t = w.gmu_a; w.gmu_a = w.gmu_b; w.gmu_b = t;
@@ -416,39 +425,45 @@ struct FmEngine {
       T* g_ib1 = g; g += F;
       T* g_iw2 = g; g += 3ll * F * F;
       T* g_ib2 = g;
+      T *ga2 = w.ga2[l], *gpb2 = w.gpb2[l], *gVW2 = w.gVW2[l], *gP2 = w.gP2[l], *gc2 = w.gc2[l], *gpa2 = w.gpa2[l];
       // mixing (painn.py:99-116)
-      be.flat("fm_painn_update_dual_bwd", k_fm_painn_update_dual_bwd<T>, NF, w.gq_a, gmu2, w.VW2[l], w.a2[l], w.svw2[l], N, F, w.ga2, w.gVW2);
-      if ((rc = be.gemm_tn(w.ga2, w.sb2[l], 2 * N, 3 * F, F, g_iw2, g_ib2, N))) return rc;
-      if ((rc = be.dense_bwd_input(w.ga2, nullptr, P.ictx_w2, nullptr, w.gsb2, 2 * N, F, 3 * F, FM_ACT_NONE))) return rc;
-      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, NF, w.gsb2, w.pb2[l], NF, FM_ACT_SILU, w.gpb2);
-      if ((rc = be.gemm_tn(w.gpb2, w.ctx2[l], 2 * N, F, 2 * F, g_iw1, g_ib1, N))) return rc;
-      if ((rc = be.dense_bwd_input(w.gpb2, nullptr, P.ictx_w1, nullptr, w.gctx2, 2 * N, 2 * F, F, FM_ACT_NONE))) return rc;
-      be.flat("fm_painn_mix_dual_bwd", k_fm_painn_mix_dual_bwd<T>, NF, w.gq_a, w.gctx2, w.VW2[l], w.n2[l], N, F, w.gq1_2, w.gVW2);
-      if ((rc = be.gemm_tn(w.gVW2, w.mu1_2[l], 6 * N, 2 * F, F, g_mix, nullptr, 6 * N))) return rc;
-      if ((rc = be.dense_bwd_input(w.gVW2, nullptr, P.mix_w, gmu2, w.gmu1_2, 6 * N, F, 2 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_update_dual_bwd", k_fm_painn_update_dual_bwd<T>, NF, w.gq_a, gmu2, w.VW2[l], w.a2[l], w.svw2[l], N, F, ga2, gVW2);
+      if ((rc = be.gemm_tn(ga2, w.sb2[l], 2 * N, 3 * F, F, g_iw2, g_ib2, N))) return rc;
+      if ((rc = be.dense_bwd_input(ga2, nullptr, P.ictx_w2, nullptr, w.gsb2, 2 * N, F, 3 * F, FM_ACT_NONE))) return rc;
+      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, NF, w.gsb2, w.pb2[l], NF, FM_ACT_SILU, gpb2);
+      if ((rc = be.gemm_tn(gpb2, w.ctx2[l], 2 * N, F, 2 * F, g_iw1, g_ib1, N))) return rc;
+      if ((rc = be.dense_bwd_input(gpb2, nullptr, P.ictx_w1, nullptr, w.gctx2, 2 * N, 2 * F, F, FM_ACT_NONE))) return rc;
+      be.flat("fm_painn_mix_dual_bwd", k_fm_painn_mix_dual_bwd<T>, NF, w.gq_a, w.gctx2, w.VW2[l], w.n2[l], N, F, w.gq1_2, gVW2);
+      if ((rc = be.gemm_tn(gVW2, w.mu1_2[l], 6 * N, 2 * F, F, g_mix, nullptr, 6 * N))) return rc;
+      if ((rc = be.dense_bwd_input(gVW2, nullptr, P.mix_w, gmu2, w.gmu1_2, 6 * N, F, 2 * F, FM_ACT_NONE))) return rc;
       // message (painn.py:50-66)
       const T* mu2 = first ? nullptr : w.MU2[l];
       be.flat("fm_painn_filter_cot", k_fm_painn_filter_cot<T>, E * F, w.gq1_2, w.gmu1_2, w.c2[l], mu2, w.c.dt, w.c.u, w.c.ut, w.c.fc, w.c.fc1, b.ii, b.jj, N, E, F, first,
-              w.gP2);
+              gP2);
       if (m.shared_filters && l != L - 1) {
-        if ((rc = be.gemm_tn(w.gP2, w.c.phi2, 2 * E, 3 * F, K, w.gtmp, w.gtmp + 3ll * F * K, E))) return rc;
-        be.flat("fm_axpy", k_fm_axpy<T>, 3ll * F * K + 3 * F, w.gtmp, 3ll * F * K + 3 * F, g_fw);   // (g_fw and g_fb are adjacent when Lf == 1)
+        // one filter slice shared by all interactions: the slots of the interactions are added up after the batched launch
+        T* slot = w.gtmp + (int64_t)l * (3ll * F * K + 3 * F);
+        if ((rc = be.gemm_tn(gP2, w.c.phi2, 2 * E, 3 * F, K, slot, slot + 3ll * F * K, E))) return rc;
       } else {
         const int64_t row0 = m.shared_filters ? 0 : 3ll * F * l;
-        if ((rc = be.gemm_tn(w.gP2, w.c.phi2, 2 * E, 3 * F, K, g_fw + row0 * K, g_fb + row0, E))) return rc;
+        if ((rc = be.gemm_tn(gP2, w.c.phi2, 2 * E, 3 * F, K, g_fw + row0 * K, g_fb + row0, E))) return rc;
       }
-      be.flat("fm_painn_msg_T_dual", k_fm_painn_msg_T_dual<T>, NF, w.gq1_2, w.gmu1_2, w.c2[l], mu2, Phi, ld, E, w.c.dt, w.c.u, w.c.ut, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, F,
-              first, w.gc2, w.gmu_a);
+      be.flat("fm_painn_msg_T_dual", k_fm_painn_msg_T_dual<T>, NF, w.gq1_2, w.gmu1_2, w.c2[l], mu2, Phi, ld, E, w.c.dt, w.c.u, w.c.ut, w.c.colptr, w.c.perm, w.c.csrc,
+              w.c.e_act, N, F, first, gc2, w.gmu_a);
       const int64_t nr = first ? N : 2 * N;
-      if ((rc = be.gemm_tn(w.gc2, w.sa2[l], nr, 3 * F, F, g_cw2, g_cb2, N))) return rc;
-      if ((rc = be.dense_bwd_input(w.gc2, nullptr, P.ctx_w2, nullptr, w.gsa2, nr, F, 3 * F, FM_ACT_NONE))) return rc;
-      if (first) be.flat("fm_act_t", k_fm_act_tangent<T>, NF, w.pa2[l], w.gsa2, NF, FM_ACT_SILU, w.gpa2);
-      else be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, NF, w.gsa2, w.pa2[l], NF, FM_ACT_SILU, w.gpa2);
-      if ((rc = be.gemm_tn(w.gpa2, w.Q2[l], nr, F, F, g_cw1, g_cb1, N))) return rc;
-      if ((rc = be.dense_bwd_input(w.gpa2, nullptr, P.ctx_w1, w.gq1_2, w.gq_a, nr, F, F, FM_ACT_NONE))) return rc;
+      if ((rc = be.gemm_tn(gc2, w.sa2[l], nr, 3 * F, F, g_cw2, g_cb2, N))) return rc;
+      if ((rc = be.dense_bwd_input(gc2, nullptr, P.ctx_w2, nullptr, w.gsa2, nr, F, 3 * F, FM_ACT_NONE))) return rc;
+      if (first) be.flat("fm_act_t", k_fm_act_tangent<T>, NF, w.pa2[l], w.gsa2, NF, FM_ACT_SILU, gpa2);
+      else be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, NF, w.gsa2, w.pa2[l], NF, FM_ACT_SILU, gpa2);
+      if ((rc = be.gemm_tn(gpa2, w.Q2[l], nr, F, F, g_cw1, g_cb1, N))) return rc;
+      if ((rc = be.dense_bwd_input(gpa2, nullptr, P.ctx_w1, w.gq1_2, w.gq_a, nr, F, F, FM_ACT_NONE))) return rc;
       gmu2 = w.gmu_a;
       T* t = w.gmu_a; w.gmu_a = w.gmu_b; w.gmu_b = t;
     }
+    if ((rc = be.gemm_flush())) return rc;
+    if (m.shared_filters)
+      for (int l = 0; l < L - 1; ++l)
+        be.flat("fm_axpy", k_fm_axpy<T>, 3ll * F * K + 3 * F, w.gtmp + (int64_t)l * (3ll * F * K + 3 * F), 3ll * F * K + 3 * F, g_fw);   // (g_fw and g_fb are adjacent when Lf == 1)
     be.flat("fm_embed_grad", k_fm_embed_grad<T>, (int64_t)b.n_types * F, w.gq_a, b.Z, N, F, b.n_types, g_emb);
     return 0;
   }

@@ -25,7 +25,7 @@
 #define FM_WAVE_SUM(x) (x)
 #define FM_IF_LANE0
 #else
-#define FM_KERNEL __global__
+#define FM_KERNEL __global__ __launch_bounds__(256)
 #define FM_HD __device__ __forceinline__
 #define FM_UNROLL _Pragma("unroll")
 #define FM_R __restrict__

@@ -33,21 +33,26 @@ __device__ __forceinline__ void gemm_tn_block(const GemmTnArgs& a, int tile, int
   float usum = 0.f;
   const float* up = U + (o_ok ? o : 0);
   const float* xp = X + (k_ok ? k : 0);
-  for (int64_t rb = r0; rb < r1; rb += 2 * TN_BATCH) {
-    float av[TN_BATCH], bv[TN_BATCH];
-#pragma unroll
-    for (int q = 0; q < TN_BATCH; ++q) {
-      const int64_t row = rb + 2 * q + hi;
-      const bool ok = row < r1;
-      av[q] = (ok && o_ok) ? up[row * O] : 0.f;
-      bv[q] = (ok && k_ok) ? xp[row * K] : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < TN_BATCH; ++q) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
-      usum += (rb + 2 * q + hi < nb) ? av[q] : 0.f;
-    }
+  // The bias gradient (column sums of U) runs over the rows [0, nb) only.  The wave's row range is cut at nb and walked as two loops -- the
+  // first adds to the column sums, the second does not: a per-element select inside one loop cost 30 registers and pushed the kernel into scratch.
+  const int64_t rmid = nb < r0 ? r0 : (nb > r1 ? r1 : nb);
+#define SPK_TN_LOOP(RBEG, REND, WITH_BIAS)                                                  \
+  for (int64_t rb = (RBEG); rb < (REND); rb += 2 * TN_BATCH) {                              \
+    float av[TN_BATCH], bv[TN_BATCH];                                                       \
+    _Pragma("unroll") for (int q = 0; q < TN_BATCH; ++q) {                                  \
+      const int64_t row = rb + 2 * q + hi;                                                  \
+      const bool ok = row < (REND);                                                         \
+      av[q] = (ok && o_ok) ? up[row * O] : 0.f;                                             \
+      bv[q] = (ok && k_ok) ? xp[row * K] : 0.f;                                             \
+    }                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < TN_BATCH; ++q) {                                  \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);               \
+      if (WITH_BIAS) usum += av[q];                                                         \
+    }                                                                                       \
   }
+  SPK_TN_LOOP(r0, rmid, true)
+  SPK_TN_LOOP(rmid, r1, false)
+#undef SPK_TN_LOOP
   usum += __shfl_xor(usum, 32, 64);
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wv][(r & 3) + 8 * (r >> 2) + 4 * hi][el] = acc[r];

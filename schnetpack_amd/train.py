@@ -56,12 +56,18 @@ class GraphedTrainStep:
         self.wE, self.wF = loss_weights
         self.group, self.use_graph, self.warmup_steps = group, use_graph, warmup_steps
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        # the static inputs of the step are views of TWO buffers (all indices | all floats): a batch that arrives packed
+        # (:meth:`pack`, e.g. from a DataLoader worker) is loaded with two copies instead of eleven
+        N, Em, M = self.N, self.Emax, self.M
+        self._ibuf = z(2 * N + 2 * Em, dt=torch.int64)
+        self._fbuf = z(3 * N + 3 * Em + M + 3 * N)
         self.buf = {
-            properties.Z: z(self.N, dt=torch.int64), properties.R: z(self.N, 3),
-            properties.idx_i: z(self.Emax, dt=torch.int64), properties.idx_j: z(self.Emax, dt=torch.int64),
-            properties.offsets: z(self.Emax, 3), properties.idx_m: z(self.N, dt=torch.int64),
+            properties.Z: self._ibuf[:N], properties.idx_m: self._ibuf[N:2 * N],
+            properties.idx_i: self._ibuf[2 * N:2 * N + Em], properties.idx_j: self._ibuf[2 * N + Em:],
+            properties.R: self._fbuf[:3 * N].view(N, 3), properties.offsets: self._fbuf[3 * N:3 * N + 3 * Em].view(Em, 3),
         }
-        self.E_t, self.F_t = z(self.M), z(self.N, 3)
+        self.E_t = self._fbuf[3 * N + 3 * Em:3 * N + 3 * Em + M]
+        self.F_t = self._fbuf[3 * N + 3 * Em + M:].view(N, 3)
         self.loss = z(())
         self.lists = torchops.StaticLists()
         self.lists.declare_sorted(self.buf[properties.idx_i], self.N)
@@ -103,6 +109,29 @@ class GraphedTrainStep:
                 b[properties.offsets][E:].copy_(self._pad_offsets[E:])
             self.E_t.copy_(E_target, non_blocking=True)
             self.F_t.copy_(F_target, non_blocking=True)
+
+    def pack(self, batch: Dict[str, torch.Tensor], E_target: torch.Tensor, F_target: torch.Tensor, device=None):
+        """The batch in the layout of the two static buffers -- (indices [2 N + 2 E_max] int64, floats [6 N + 3 E_max + M]) -- with the pair
+        list already padded to the capacity (:func:`pad_edges`).  Host-side work (collate / DataLoader worker); :meth:`load_packed` then
+        moves a batch with two copies."""
+        if int(batch["Z"].shape[0]) != self.N:
+            raise ValueError("batch has %d atoms, the step was built for %d" % (batch["Z"].shape[0], self.N))
+        cpu = lambda t, dt: t.detach().to("cpu", dt)
+        ii, jj, off = pad_edges(cpu(batch["idx_i"], torch.int64), cpu(batch["idx_j"], torch.int64), cpu(batch["offsets"], torch.float32), self.N,
+                                self.Emax, self.cutoff)
+        ip = torch.cat([cpu(batch["Z"], torch.int64), cpu(batch["idx_m"], torch.int64), ii, jj])
+        fp = torch.cat([cpu(batch["R"], torch.float32).reshape(-1), off.reshape(-1), cpu(E_target, torch.float32).reshape(-1),
+                        cpu(F_target, torch.float32).reshape(-1)])
+        if ip.numel() != self._ibuf.numel() or fp.numel() != self._fbuf.numel():
+            raise ValueError("packed batch does not match the static buffers (n_molecules / capacity)")
+        if device is not None:
+            return ip.to(device), fp.to(device)
+        return ip, fp
+
+    def load_packed(self, ipack: torch.Tensor, fpack: torch.Tensor):
+        with torch.no_grad():
+            self._ibuf.copy_(ipack, non_blocking=True)
+            self._fbuf.copy_(fpack, non_blocking=True)
 
     # ---------------------------------------------------------------- the step
     def _forward_backward(self):

@@ -62,8 +62,21 @@ struct EmuBackend {
     }
     return 0;
   }
-  // G [O, K] = U^T X over n rows; gb [O] = column sums of the first n_bias rows of U
+  // the weight-gradient GEMMs are DEFERRED to gemm_flush() exactly like on the device (one batched launch at the end of a pass): an operand
+  // buffer that the engine overwrites before the flush would give wrong gradients here too
+  struct Tn { const T* U; const T* X; int64_t n; int O, K; T* G; T* gb; int64_t nb; };
+  std::vector<Tn> pending;
   int gemm_tn(const T* U, const T* X, int64_t n, int O, int K, T* G, T* gb, int64_t n_bias) {
+    pending.push_back(Tn{U, X, n, O, K, G, gb, n_bias});
+    return 0;
+  }
+  int gemm_flush() {
+    for (const Tn& t : pending) gemm_tn_now(t.U, t.X, t.n, t.O, t.K, t.G, t.gb, t.nb);
+    pending.clear();
+    return 0;
+  }
+  // G [O, K] = U^T X over n rows; gb [O] = column sums of the first n_bias rows of U
+  int gemm_tn_now(const T* U, const T* X, int64_t n, int O, int K, T* G, T* gb, int64_t n_bias) {
     for (int o = 0; o < O; ++o) {
       for (int c = 0; c < K; ++c) {
         T acc = 0;

@@ -195,3 +195,19 @@ def test_eval_forward_after_graph_replays_sees_the_updated_weights(dev, kind):
     assert rel_err(outs[-1][1], o["forces"].detach()) < 1e-6
     # and the validation outputs really moved with the training (a stale cache would have frozen part of them)
     assert rel_err(outs[0][1], outs[-1][1]) > 1e-4
+
+
+def test_packed_load_fills_the_static_buffers_like_load(dev):
+    """``pack`` + ``load_packed`` (two copies) leave exactly what ``load`` (eleven copies) leaves in the static inputs of the step."""
+    from schnetpack_amd.train import GraphedTrainStep
+    (b, Et, Ft), = _batches(1, 3)
+    N, E = b["Z"].shape[0], b["idx_i"].shape[0]
+    a = GraphedTrainStep(_model("schnet", dev), N, 3, E + 50, 5.0, use_graph=False)
+    c = GraphedTrainStep(_model("schnet", dev), N, 3, E + 50, 5.0, use_graph=False)
+    a.load(b, Et, Ft)
+    c.load_packed(*c.pack(b, Et, Ft, device=dev))
+    for k in a.buf:
+        assert torch.equal(a.buf[k], c.buf[k]), k
+    assert torch.equal(a.E_t, c.E_t) and torch.equal(a.F_t, c.F_t)
+    with pytest.raises(ValueError):
+        c.pack(dict(b, Z=b["Z"][:-1]), Et, Ft)

@@ -61,14 +61,16 @@ def test_matmul_tn(dev, n, o, k):
 @pytest.mark.parametrize("m,k,o,trans", [(2560, 128, 128, True), (2560, 128, 128, False), (168, 64, 128, True), (2432, 20, 128, True), (504, 128, 256, False),
                                           (70, 6, 10, True)])
 def test_gemm_pair_is_both_products_of_a_dense_backward(dev, m, k, o, trans):
-    """out = a w (trans) | a w^T and (u^T x, column sums of u) from ONE launch equal the two separate operators bit for bit
+    """out = a w (trans) | a w^T and (u^T x, column sums of u) from ONE launch equal the two separate operators (the weight-gradient half bit for bit)
     (widths that are not multiples of 4 take the two launches inside the operator)."""
     w, u, x = rnd(o, k, seed=1) / k ** 0.5, rnd(m, o, seed=2), rnd(m, k, seed=3)
     a = u if trans else x
     out, G, cs = ops.gemm_pair(a.to(dev), w.to(dev), trans, u.to(dev), x.to(dev))
     ref_out = ops.matmul_nn(a.to(dev), w.to(dev)) if trans else ops.linear(a.to(dev), w.to(dev), None)
     G2, cs2 = ops.matmul_tn(u.to(dev), x.to(dev))
-    assert torch.equal(out, ref_out) and torch.equal(G, G2) and torch.equal(cs, cs2)
+    # (the stand-alone Dense launch of a small problem splits the contraction over the waves of a workgroup -- k_dense_mfma_sk -- so its sums
+    #  associate differently from the one-wave-per-tile walk inside the pair kernel: equal to fp32 rounding, not bit for bit)
+    assert rel_err(out.cpu(), ref_out.cpu()) < 1e-6 and torch.equal(G, G2) and torch.equal(cs, cs2)
     assert rel_err(out.cpu(), (a.double() @ w.double()) if trans else (a.double() @ w.double().t())) < TOL
     assert rel_err(G.cpu(), u.double().t() @ x.double()) < TOL
 
