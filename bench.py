@@ -127,8 +127,8 @@ PMC_TAGS = [
     ("cfconv_fwd_mol", r"k_cfconv_mol<[^>]*false>"), ("cfconv_bwd_mol", r"k_cfconv_mol<[^>]*true>"),
     ("cfconv_fwd_mfma", r"k_cfconv_mfma<[^>]*false, (true|false)>"), ("cfconv_bwd_mfma_sym", r"k_cfconv_mfma<[^>]*true, true>"),
     ("cfconv_bwd_mfma_atomic", r"k_cfconv_mfma<[^>]*true, false>"),
-    ("painn_msg_fwd_row", r"k_painn_msg_row<\d+, \d+, false, false, false>"), ("painn_msg_bwd_row", r"k_painn_msg_row<\d+, \d+, true, false, false>"),
-    ("painn_msg_fwd_row_mu0", r"k_painn_msg_row<\d+, \d+, false, false, true>"), ("painn_msg_bwd_row_geom", r"k_painn_msg_row<\d+, \d+, true, true"),
+    ("painn_msg_fwd_row", r"k_painn_msg_row<\d+, \d+, false, false, false[,>]"), ("painn_msg_bwd_row", r"k_painn_msg_row<\d+, \d+, true, false, false[,>]"),
+    ("painn_msg_fwd_row_mu0", r"k_painn_msg_row<\d+, \d+, false, false, true[,>]"), ("painn_msg_bwd_row_geom", r"k_painn_msg_row<\d+, \d+, true, true"),
     ("painn_msg_fwd_tile_mu0", r"k_painn_msg_tile<\d+, \d+, true"), ("painn_msg_fwd_tile", r"k_painn_msg_tile<"),
     ("painn_msg_bwd_tile_geom", r"k_painn_msg_tile_bwd<\d+, \d+, true"), ("painn_msg_bwd_tile", r"k_painn_msg_tile_bwd<\d+, \d+, false"),
     ("painn_mixing_fwd", r"k_painn_mixing_fwd"), ("painn_mixing_bwd", r"k_painn_mixing_bwd"),
@@ -149,10 +149,12 @@ def csrc_digest():
 
 
 def collect_pmc(args, kind, workload, timeout_s=170):
-    """HBM-side traffic per launch of every hot kernel, measured IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE and
-    WRITE_SIZE do not share a pass on gfx950; kernel-trace only) over a child of this script that runs three eager force
-    calls of the same workload.  Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: KiB per
-    dispatch, FETCH_SIZE x 2 on gfx950.  Returns {tag: {"read_bytes", "write_bytes", "kernel_name", "launches"}} or None."""
+    """HBM-side traffic AND matrix-core work per launch of every hot kernel, measured IN THIS RUN: three `rocprofv3 --pmc` passes
+    (FETCH_SIZE and WRITE_SIZE do not share a pass on gfx950; the third carries SQ_INSTS_VALU_MFMA_MOPS_F32, SQ_VALU_MFMA_BUSY_CYCLES
+    and GRBM_GUI_ACTIVE; kernel-trace only) over a child of this script that runs three eager force calls of the same workload.
+    Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: KiB per dispatch, FETCH_SIZE x 2 on gfx950; one MOPS
+    unit = 512 FLOP; busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs.
+    Returns {tag: {"read_bytes", "write_bytes", "mfma_mops", "mfma_busy_cycles", "gui_active", "kernel_name"}} or None."""
     import csv
     import glob
     import re
@@ -165,9 +167,9 @@ def collect_pmc(args, kind, workload, timeout_s=170):
     res = {}
     tmp = tempfile.mkdtemp(prefix="spk_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", out, "-o", "p", "--",
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
+            out = os.path.join(tmp, counter.split()[0])
+            cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc"] + counter.split() + ["-d", out, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--kind", kind, "--workload", workload,
                    "--frames", str(args.frames), "--water-side", str(args.water_side), "--variant", args.variant]
             env = dict(os.environ, TMPDIR="/tmp")
@@ -179,27 +181,32 @@ def collect_pmc(args, kind, workload, timeout_s=170):
                 p.wait()
                 return None
             if rc != 0:
+                if counter.startswith("SQ_"):
+                    continue            # the traffic passes are the contract's; the MFMA pass is extra
                 return None
             acc, cnt, names = {}, {}, {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") != counter:
+                    cname = row.get("Counter_Name")
+                    if cname not in counter.split():
                         continue
                     name = row["Kernel_Name"]
                     for tag, pat in PMC_TAGS:
                         if re.search(pat, name):
-                            acc[tag] = acc.get(tag, 0.0) + float(row["Counter_Value"])
-                            cnt[tag] = cnt.get(tag, 0) + 1
+                            acc[(tag, cname)] = acc.get((tag, cname), 0.0) + float(row["Counter_Value"])
+                            cnt[(tag, cname)] = cnt.get((tag, cname), 0) + 1
                             names[tag] = name[:100]
                             break
-            for tag in acc:
+            for (tag, cname) in acc:
                 r = res.setdefault(tag, {"kernel_name": names[tag]})
-                per = 1024.0 * acc[tag] / cnt[tag]
-                if counter == "FETCH_SIZE":
-                    r["read_bytes"] = 2.0 * per
+                per = acc[(tag, cname)] / cnt[(tag, cname)]
+                if cname == "FETCH_SIZE":
+                    r["read_bytes"] = 2.0 * 1024.0 * per
+                elif cname == "WRITE_SIZE":
+                    r["write_bytes"] = 1024.0 * per
                 else:
-                    r["write_bytes"] = per
-                r["launches_" + counter] = cnt[tag]
+                    r[{"SQ_INSTS_VALU_MFMA_MOPS_F32": "mfma_mops", "SQ_VALU_MFMA_BUSY_CYCLES": "mfma_busy_cycles", "GRBM_GUI_ACTIVE": "gui_active"}[cname]] = per
+                r["launches_" + cname] = cnt[(tag, cname)]
     except Exception as exc:  # pragma: no cover - depends on the profiler
         sys.stderr.write("[bench] PMC pass failed: %s\n" % exc)
         return None
@@ -388,6 +395,16 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
             torch.cuda.synchronize()
 
     step = graph.replay if graph is not None else force_call
+    # the same K timed steps WITHOUT the clock ramp first (reported beside the headline as value_without_ramp: what a freshly
+    # started process measures over these few milliseconds)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt_cold = time.perf_counter() - t0
     # clock ramp, untimed and BEFORE the W warm-up steps: a freshly started process reaches its sustained clocks only after some
     # tens of milliseconds of work -- with the driver's --steps 20 --warmup 5 the whole measurement is 6 ms long and came out 8 %
     # below the same binary at --steps 200 (one box, alternating runs).  Bounded: RAMP_S seconds of replays, reported in `config`
@@ -426,7 +443,7 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
         dist.all_reduce(et, op=dist.ReduceOp.SUM)
         E_total = int(et.item())
     value = E_total * n_int * steps / dt / 1e6
-    res = {"value": value, "dt": dt, "steps": steps, "E": E, "N": N, "frames": hi - lo, "graph": graph is not None, "batch": batch, "inp": inp, "n_ramp": n_ramp,
+    res = {"value": value, "value_without_ramp": E * n_int * steps / dt_cold / 1e6, "dt": dt, "steps": steps, "E": E, "N": N, "frames": hi - lo, "graph": graph is not None, "batch": batch, "inp": inp, "n_ramp": n_ramp,
            "e_ref": e_ref, "f_ref": f_ref, "n_int": n_int, "F": F, "n_rbf": n_rbf, "cutoff": cutoff}
     if rank != 0:
         return res
@@ -509,6 +526,52 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
     pmc = None
     if roofline is not None and world == 1 and with_pmc and not args.no_pmc:
         pmc = collect_pmc(args, kind, workload)
+    # what every kernel DOES, from this run's counters (not from a table of instruction counts): executed matrix-core FLOP =
+    # SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, HBM-side bytes = FETCH_SIZE x 2 + WRITE_SIZE, both over the HIP-event time of the launch;
+    # MFMA-pipe busy share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).  A kernel below half of BOTH roofs
+    # is labelled latency / VALU bound.
+    if pmc is not None:
+        for tag, c in pmc.items():
+            if tag not in kernels:
+                continue
+            kd, sec = kernels[tag], kernels[tag]["avg_us"] * 1e-6
+            meas = {"source": "rocprofv3 --pmc passes of this run"}
+            if "read_bytes" in c and "write_bytes" in c:
+                meas["hbm_bytes"] = c["read_bytes"] + c["write_bytes"]
+                meas["hbm_frac_of_peak"] = round(meas["hbm_bytes"] / sec / (HBM_PEAK_GBS * 1e9), 4)
+            if "mfma_mops" in c:
+                meas["mfma_flop_issued"] = 512.0 * c["mfma_mops"]
+                meas["mfma_frac_of_peak"] = round(meas["mfma_flop_issued"] / sec / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
+                if tag in algo and algo[tag][0] == "mfma":
+                    useful = algo[tag][1] * algo[tag][2]
+                    meas["mfma_flop_useful_model"] = useful
+                    meas["issued_over_useful"] = round(meas["mfma_flop_issued"] / useful, 3) if useful else None
+            if "mfma_busy_cycles" in c and c.get("gui_active"):
+                meas["mfma_busy_frac"] = round(c["mfma_busy_cycles"] / (1024.0 * c["gui_active"] / 8.0), 4)
+            hf, mf = meas.get("hbm_frac_of_peak"), meas.get("mfma_frac_of_peak")
+            if hf is not None and mf is not None:
+                meas["bound_measured"] = "latency/valu" if max(hf, mf) < 0.5 else ("mfma" if mf >= hf else "hbm")
+            kd["measured"] = meas
+            # executed fraction: HBM-bound kernels -- the measured bytes; MFMA-bound kernels -- the ISSUED matrix-core work of the counters
+            # divided by the issued / useful ratio where a model of the useful work exists (rows of padding in the 32-row tiles are issued,
+            # not useful), else the issued work itself
+            if kd.get("bound") == "mfma" and mf is not None:
+                kd["issued_frac_of_peak"] = mf
+                kd["executed_frac_of_peak"] = round(mf / meas["issued_over_useful"], 4) if meas.get("issued_over_useful") else mf
+            elif kd.get("bound") == "hbm" and hf is not None:
+                kd["executed_frac_of_peak"] = hf
+        if roofline is not None and "measured" in kernels.get(roofline["kernel"], {}):
+            m_ = kernels[roofline["kernel"]]["measured"]
+            roofline["measured"] = m_
+            ex = kernels[roofline["kernel"]].get("executed_frac_of_peak")
+            if roofline["bound"] == "mfma" and "mfma_frac_of_peak" in m_:
+                roofline["issued_frac_of_peak"], roofline["issued_over_useful"], roofline["mfma_busy_frac"] = m_["mfma_frac_of_peak"], m_.get("issued_over_useful"), m_.get("mfma_busy_frac")
+            if ex is not None:
+                roofline["executed_frac_of_peak"] = ex
+                roofline["executed_frac_source"] = "counters of this run (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, resp. FETCH_SIZE x 2 + WRITE_SIZE, over the HIP-event time)"
+                if "frac_by_convention" in roofline:      # the headline fraction is the executed one
+                    roofline["frac"] = ex
+                    roofline["achieved"] = round(ex * roofline["peak"], 3)
     if roofline is not None and pmc is not None and roofline["kernel"] in pmc and "read_bytes" in pmc[roofline["kernel"]] and "write_bytes" in pmc[roofline["kernel"]]:
         c = pmc[roofline["kernel"]]
         roofline["traffic"] = c["read_bytes"] + c["write_bytes"]
@@ -546,11 +609,17 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
                 roofline["force_call"] = {"algorithmic_flop": tot, "achieved": round(tot / sec / 1e12, 3), "unit": "TFLOP/s",
                                           "frac": round(tot / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                           "note": "algorithmic FLOP of every MFMA-bound launch of one force call / wall time of the call"}
+                issued = sum(kernels[t]["measured"]["mfma_flop_issued"] * kernels[t]["launches_per_step"] for t in kernels if "mfma_flop_issued" in kernels[t].get("measured", {}))
+                if issued:
+                    roofline["force_call"]["issued_flop"] = issued
+                    roofline["force_call"]["issued_frac"] = round(issued / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
             else:
                 whole = 3.0 * n_int * (E * 3100.0 + 2 * N * 4096.0)       # B_force = 3 sum_layers (message + mixing) forward bytes
                 roofline["force_call"] = {"algorithmic_bytes": whole, "achieved": round(whole / sec / 1e9, 1), "unit": "GB/s",
                                           "frac": round(whole / sec / 1e9 / HBM_PEAK_GBS, 4),
                                           "note": "SURVEY.md 8(d) B_force = 3 x sum over interactions of (message + mixing) forward bytes / wall time of the call"}
+            if roofline["force_call"]["frac"] > 1.0:
+                roofline["force_call"]["frac_flag"] = FLAG
         except Exception:  # pragma: no cover
             pass
 
@@ -575,14 +644,15 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
         c0 = time.perf_counter()
         oc = cpu_call()
         first = time.perf_counter() - c0
-        reps = max(1, min(cpu_reps, int(20.0 / max(first, 1e-3))))      # bounded sample: about 20 s of CPU work at most
+        reps = max(1, min(cpu_reps, int(20.0 / max(first, 1e-3)))) if cpu_reps > 0 else 0      # bounded sample: about 20 s of CPU work at most
         ts = []
         for _ in range(reps):
             c0 = time.perf_counter()
             oc = cpu_call()
             ts.append(time.perf_counter() - c0)
         ts.sort()
-        med = ts[len(ts) // 2]
+        med = ts[len(ts) // 2] if ts else first        # cpu_reps == 0 (the water box: ~20 s per call): the one call made is the sample
+        reps = max(reps, 1)
         df = (f_ref.cpu() - oc["forces"]).double()
         cpu = {"value": round(E * n_int / med / 1e6, 4), "unit": "M edge-messages/s", "cores": ncores, "kind": kind_,
                "sample": "same %s, median of %d force calls (%.2f s each) of %s, torch %s fp32 CPU" % (
@@ -611,9 +681,10 @@ def drop_in_measure(args, dev, rep_p, head_p, batch, f_hip, steps=50):
     E = int(batch["idx_i"].shape[0])
     out = {"what": "the reference's NeuralNetworkPotential(+ its Atomwise, Forces) on cuda:0 after schnetpack_amd.install.install(): the representation, "
                    "PairwiseDistances, Dense and scatter_add underneath are the HIP classes; same batch, same weights, eager calls (the reference "
-                   "model allocates its outputs per call), median-free mean over %d calls" % steps}
+                   "model allocates its outputs per call), median of 3 repetitions of %d calls; module_by_module = install(fused_head=False, fused_potential=False), "
+                   "fused_potential = install() with its defaults" % steps}
     try:
-        for label, kw in (("module_by_module", {}), ("fused_potential", {"fused_head": True, "fused_potential": True})):
+        for label, kw in (("module_by_module", {"fused_head": False, "fused_potential": False}), ("fused_potential", {"fused_head": True, "fused_potential": True})):
             inst.install(sys.modules["schnetpack"], **kw)
             try:
                 spk = sys.modules["schnetpack"]
@@ -634,13 +705,17 @@ def drop_in_measure(args, dev, rep_p, head_p, batch, f_hip, steps=50):
                     return o["forces"].detach()
                 for _ in range(5):
                     f = call()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    f = call()
-                torch.cuda.synchronize()
-                ms = 1e3 * (time.perf_counter() - t0) / steps
+                reps_ms = []
+                for _ in range(3):          # an eager, launch-bound leg: median of three repetitions (34 % run-to-run spread seen on single ones)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        f = call()
+                    torch.cuda.synchronize()
+                    reps_ms.append(1e3 * (time.perf_counter() - t0) / steps)
+                ms = sorted(reps_ms)[1]
                 out[label] = {"ms_per_call": round(ms, 4), "M_edge_messages_per_s": round(E * 3 / ms / 1e3, 1),
+                              "repetitions_ms": [round(v, 4) for v in reps_ms],
                               "model_class": type(m).__module__ + "." + type(m).__name__,
                               "rel_diff_forces_vs_mirror_model": float((f - f_hip).abs().max() / f_hip.abs().max())}
             finally:
@@ -803,6 +878,29 @@ def main():
         except Exception as exc:  # pragma: no cover
             painn = {"error": str(exc)[:300]}
 
+    # ---------------- configs[4] per-GPU share: the eval force call on the 32k-atom bulk-water PBC box, both models (default line only):
+    # roofline of the dominant kernel with this run's counters, traffic over the perfect-reuse bound, ONE force call of the
+    # reference on the host cores as the baseline (PaiNN only -- a call takes ~20 s; SchNet's: profiles/)
+    water = None
+    if default_line and not args.no_md:
+        water = {}
+        for k in ("painn", "schnet"):
+            try:
+                if k == "painn":
+                    if painn_model is None:
+                        painn_model, p_rep, p_head = make_model("painn")
+                    wm, w_rep, w_head = painn_model, p_rep, p_head
+                else:
+                    wm, w_rep, w_head = model, rep_p, head_p
+                wr = eval_leg(args, k, "water", wm, w_rep, w_head, 0, 1, dev, None, 10, 2, with_pmc=True, with_cpu=(k == "painn"), cpu_reps=0)
+                water[k] = {"metric": "M edge-messages/s (eval force call, 32k-atom bulk-water PBC box, %s)" % ("PaiNN" if k == "painn" else "SchNet"),
+                            "value": round(wr["value"], 2), "unit": "M edge-messages/s", "ms_per_step": round(1e3 * wr["dt"] / wr["steps"], 4), "steps": wr["steps"],
+                            "hip_graph": wr["graph"], "n_atoms": wr["N"], "n_edges": wr["E"], "ns_per_day_at_0.5fs_per_call": round(wr["steps"] / wr["dt"] * 0.5 * 86400e-6, 3),
+                            "roofline": wr["roofline"], "cpu_baseline": wr["cpu"], "kernels": wr["kernels"]}
+            except Exception as exc:  # pragma: no cover
+                water[k] = {"error": str(exc)[:300]}
+        torch.cuda.empty_cache()
+
     # ---------------- configs[3] per-GPU share: one AdamW step of the force-matching loss, PaiNN and SchNet
     train = None
     if default_line and not args.no_train:
@@ -897,7 +995,8 @@ def main():
     hi_lo = r["frames"]
     line = {
         "metric": "M edge-messages/s (eval force call, %s, %s)" % ("MD17-aspirin 256-frame batch" if args.workload == "aspirin" else "32k-atom bulk-water PBC box", "SchNet" if args.kind == "schnet" else "PaiNN"),
-        "value": round(value, 2), "unit": "M edge-messages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "value_without_ramp": round(r["value_without_ramp"], 2) if world == 1 else None,
+        "unit": "M edge-messages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("configs[1]: MD17 aspirin x %d frames per GPU, %s(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0) + Atomwise + Forces; N=%d atoms, E=%d directed edges per GPU"
@@ -908,8 +1007,9 @@ def main():
                    "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                    "world_size": world, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
                    "hip_graph": r["graph"], "variant": args.variant, "compute_units": info["compute_units"],
-                   "preconditioning": "%d untimed replays (%.2f s clock ramp) before the %d warm-up steps; the timed region is exactly %d steps" % (r["n_ramp"], RAMP_S, args.warmup, r["steps"])},
-        "roofline": roofline, "cpu_baseline": cpu, "painn": painn, "train": train, "md": md, "sweep": sweep, "drop_in": drop_in, "experiments": experiments,
+                   "preconditioning": "%d untimed replays (%.2f s clock ramp) before the %d warm-up steps; the timed region is exactly %d steps; "
+                                      "value_without_ramp = the same %d steps timed once before the ramp (this rank)" % (r["n_ramp"], RAMP_S, args.warmup, r["steps"], r["steps"])},
+        "roofline": roofline, "cpu_baseline": cpu, "painn": painn, "water": water, "train": train, "md": md, "sweep": sweep, "drop_in": drop_in, "experiments": experiments,
         "kernels": kernels, "scatter_add": scatter, "neighbor_list": nbl,
     }
     print(json.dumps(line))

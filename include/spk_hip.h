@@ -54,6 +54,37 @@ typedef struct {
   float cutoff;
 } spk_radial_t;
 
+/* EXPERIMENT, opt-in.  Block plan of a list sorted by idx_i for the block kernels of the PaiNN message (spk_painn_blk.hip; built by
+ * spk_blocks_build into buffers of the caller, sizes from spk_blocks_sizes): atoms in groups of SPK_BLK_ATOMS consecutive
+ * atoms (split into 2 / 4 / 8 sub-blocks where the unique neighbours of a group exceed `cap`), per sub-block the
+ * ascending list of its unique neighbour atoms and per edge the position of idx_j in it, 16-edge tiles aligned to atoms;
+ * plus the per-call workspace the kernels fill from r_ij (radial basis x cutoff in MFMA operand order, per-edge records,
+ * per-slice partial sums of the geometry gradient). */
+#define SPK_BLK_ATOMS 8
+#define SPK_BLK_STG_MAX 9          /* 16-byte staging units per thread and 16-channel slice: two LDS buffers of 9 x 512 x 16 B = 144 KB */
+#define SPK_BLK_CAP (SPK_BLK_STG_MAX * 64 * SPK_BLK_ATOMS / 24)   /* = 192 unique neighbours per block (6 row pieces of 64 B each) */
+typedef struct {
+  int32_t n_groups;          /* ceil(n_atoms / SPK_BLK_ATOMS) */
+  int32_t max_unique;        /* largest unique-neighbour count of a sub-block */
+  int32_t n_tiles;
+  int32_t cap;               /* capacity the plan was built for */
+  int32_t ks;                /* k-steps of 4 radial functions: 5 (n_rbf <= 20) or 8 (n_rbf <= 32) */
+  int32_t ok;                /* 0: the list does not fit (a single atom has more than cap / 2048 neighbours): keep the row kernels */
+  int32_t n_blocks;          /* sub-blocks of all groups, in atom order */
+  int32_t reserved;
+  const int32_t* blk_desc;   /* [n_blocks][4] first atom, atoms (0..SPK_BLK_ATOMS), first edge, unique neighbours */
+  const int32_t* sub_n;      /* [n_groups] sub-blocks per group: 1, 2, 4 or 8 */
+  const int32_t* sub_u;      /* [n_groups * SPK_BLK_ATOMS] unique neighbours of sub-block s of group g at [SPK_BLK_ATOMS g + s] */
+  const int32_t* uniq;       /* [n_edges] unique neighbours of a sub-block from uniq[rowptr[first atom]] on */
+  const uint16_t* jl;        /* [n_edges] position of idx_j[e] in its sub-block's list */
+  const int32_t* atom_tile0; /* [n_atoms + 1] first tile of every atom */
+  const int32_t* tile_info;  /* [n_tiles][2] first edge, number of edges (1..16) */
+  float* apack;              /* [n_tiles][ks][64]  f_c phi_k           (workspace, written per call) */
+  float* adpack;             /* [n_tiles][ks][64]  d(f_c phi_k)/dd */
+  float* rec;                /* [n_tiles][6][16]   local neighbour, unit vector, f_c, f_c' */
+  float* part;               /* [F / 16][n_edges][4] */
+} spk_blocks_t;
+
 /* Neighbour-list description: what `_idx_i`, `_idx_j` look like plus the CSR row pointers and
  * flags that spk_edge_plan() derives once per neighbour list. */
 typedef struct {
@@ -92,6 +123,7 @@ typedef struct {
   const int32_t* edge_pair;
   int32_t max_group_pairs; /* largest number of undirected pairs inside one group (0: unknown) */
   int32_t reserved1;
+  const spk_blocks_t* blocks; /* optional block plan (large lists; spk_blocks_build), NULL: none */
 } spk_graph_t;
 
 /* ------------------------------------------------------------------ library / device info */
@@ -116,6 +148,23 @@ const char* spk_profile_report(void);
 int spk_edge_plan(const int64_t* idx_i, const int64_t* idx_j, const float* r_ij, int64_t n_edges,
                   int64_t n_atoms, int32_t* rowptr, int32_t* rev, int32_t* scratch,
                   int32_t* host_flags, void* stream);
+
+/* Block plan (see spk_blocks_t).  spk_blocks_sizes: element counts of the ten buffers for a list of this size
+ * (sizes[0..8]: sub_n, sub_u, uniq, jl (uint16), atom_tile0, tile_info, apack = adpack, rec, part; sizes[9] = ks;
+ * sizes[10]: blk_desc (int32)).
+ * spk_blocks_build fills the index buffers of `out` (the caller has set the pointers), n_groups / max_unique / n_tiles /
+ * n_blocks / ok; cap <= 0: SPK_BLK_CAP.  dev_stats: >= 16 bytes device scratch; host_stats [4]: largest
+ * unique count, 1 if the list does not fit, number of tiles, number of blocks.  Synchronises the stream once -- per list, not per call.
+ * spk_blocks_prepare_f32 fills the per-call tables from r_ij (the drivers do this themselves).
+ * spk_painn_set_block: 1 = use the block kernels whenever a usable plan hangs on the graph; 0 (default) = never -- they are an
+ * opt-in experiment: parity-green, measured slower than the row / tile kernels on the 32k-atom water box (spk_painn_blk.hip). */
+int spk_blocks_sizes(int64_t n_atoms, int64_t n_edges, int32_t n_rbf, int32_t n_atom_basis, int64_t* sizes);
+int spk_blocks_build(const spk_graph_t* g, int32_t n_rbf, int32_t cap, spk_blocks_t* out, int32_t* dev_stats,
+                     int32_t* host_stats, void* stream);
+int spk_blocks_prepare_f32(const spk_graph_t* g, const spk_radial_t* rb, const float* r_ij, void* stream);
+void spk_painn_set_block(int mode);
+int spk_blocks_group_atoms(void);   /* SPK_BLK_ATOMS of the built library */
+void spk_painn_blk_set_debug_buffer(void* device_buffer, int block);   /* tuning aid: cycle stamps of one workgroup; NULL = off */
 
 /* ------------------------------------------------------------------ nn/scatter.py:7-34
  * y[o, k, c] = sum_{e: idx[e]==k} x[o, e, c]   (x: [outer, E, inner], y: [outer, dim_size, inner]).

@@ -37,7 +37,14 @@ class GraphT(ctypes.Structure):
                 ("n_half", c_i64), ("grp_atom0", c_f), ("grp_pair0", c_f), ("grp_tile0", c_f),
                 ("n_groups", c_i32), ("max_group_atoms", c_i32), ("n_tiles_grouped", c_i64),
                 ("filter_pairs", c_i32), ("reserved0", c_i32), ("n_half_dev", c_f), ("edge_pair", c_f),
-                ("max_group_pairs", c_i32), ("reserved1", c_i32)]
+                ("max_group_pairs", c_i32), ("reserved1", c_i32), ("blocks", c_f)]
+
+
+class BlocksT(ctypes.Structure):
+    """``spk_blocks_t``: block plan of a large sorted list for the PaiNN message kernels of the box regime (spk_painn_blk.hip)."""
+    _fields_ = [("n_groups", c_i32), ("max_unique", c_i32), ("n_tiles", c_i32), ("cap", c_i32), ("ks", c_i32), ("ok", c_i32),
+                ("n_blocks", c_i32), ("reserved", c_i32), ("blk_desc", c_f), ("sub_n", c_f), ("sub_u", c_f), ("uniq", c_f), ("jl", c_f), ("atom_tile0", c_f), ("tile_info", c_f),
+                ("apack", c_f), ("adpack", c_f), ("rec", c_f), ("part", c_f)]
 
 
 class SchnetLayerT(ctypes.Structure):
@@ -168,6 +175,12 @@ _PROTOS = {
     "spk_painn_message_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
     "spk_painn_message_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_f]),
     "spk_painn_set_tile": (None, [c_i32]),
+    "spk_painn_set_block": (None, [c_i32]),
+    "spk_blocks_group_atoms": (ctypes.c_int, []),
+    "spk_painn_blk_set_debug_buffer": (None, [c_f, c_i32]),
+    "spk_blocks_sizes": (ctypes.c_int, [c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_i64)]),
+    "spk_blocks_build": (ctypes.c_int, [P(GraphT), c_i32, c_i32, P(BlocksT), c_f, ctypes.POINTER(c_i32), c_f]),
+    "spk_blocks_prepare_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f]),
     "spk_painn_mix_ctx_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, ctypes.c_float, c_f, c_f]),
     "spk_painn_mix_update_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i32, c_f, c_f, c_f]),
     "spk_painn_mix_update_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_f, c_f, c_f]),

@@ -14,6 +14,7 @@ int spk_dense_internal(const float* in, const float* pre_in, const float* w, con
                        int act, bool trans, int pro, hipStream_t stream);
 
 #include "spk_painn_msg.h"
+#include "spk_painn_blk.h"
 
 // ------------------------------------------------------------------------------------------
 // row kernels (sorted idx_i; backward additionally needs a symmetric list)
@@ -381,6 +382,8 @@ static int msg_dispatch(const MsgArgs& a_in, bool row_ok, hipStream_t stream, co
     }
   }
   SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || shape_ok, "%s: shape F=%d n_rbf=%d (or unsorted/asymmetric list) not supported by the row kernel", who, F, K);
+  if (row_ok && variant != SPK_VARIANT_SIMPLE && spk_painn_blk_ok(a, BWD))       // large lists with a block plan (spk_painn_blk.hip)
+    return BWD ? spk_painn_blk_bwd(a, stream) : spk_painn_blk_fwd(a, stream);
   if (!BWD && shape_ok && variant != SPK_VARIANT_SIMPLE && spk_painn_msg_tile_ok(a)) {
     // forward on large lists: filter GEMM on the matrix cores, 32-edge tiles (spk_painn_tile.hip); the profile scope
     // covers the init launch too
@@ -433,7 +436,7 @@ static int msg_dispatch(const MsgArgs& a_in, bool row_ok, hipStream_t stream, co
 int spk_painn_message_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
                                    const float* q, const float* mu, const float* r_ij,
                                    const float* wf, const float* bf, int F, float* q_out,
-                                   float* mu_out, hipStream_t stream, bool mu_zero = false) {
+                                   float* mu_out, hipStream_t stream, bool mu_zero = false, bool blocks_prepared = false) {
   const char* who = "spk_painn_message_fwd_f32";
   int rc = check_msg(g, rb, F, who);
   if (rc) return rc;
@@ -443,13 +446,15 @@ int spk_painn_message_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
   a.c = c; a.q = q; a.mu = mu; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j; a.rowptr = g->rowptr;
   a.wf = wf; a.bf = bf; a.q_out = q_out; a.mu_out = mu_out; a.E = g->n_edges; a.N = g->n_atoms; a.F = F;
   a.rb = spk_radial_dev(rb); a.mu_zero = mu_zero ? 1 : 0; a.skin_list = g->filter_pairs ? 1 : 0;
+  a.blocks = g->blocks; a.blocks_prepared = blocks_prepared ? 1 : 0;
   return msg_dispatch<false>(a, g->sorted && g->rowptr, stream, who);
 }
 
 int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const float* c,
                                    const float* mu, const float* gq_out, const float* gmu_out,
                                    const float* r_ij, const float* wf, const float* bf, int F,
-                                   float* gc, float* gmu, float* gr, hipStream_t stream, bool geom_only = false, bool mu_zero = false) {
+                                   float* gc, float* gmu, float* gr, hipStream_t stream, bool geom_only = false, bool mu_zero = false,
+                                   bool blocks_prepared = false) {
   const char* who = "spk_painn_message_bwd_f32";
   int rc = check_msg(g, rb, F, who);
   if (rc) return rc;
@@ -459,6 +464,7 @@ int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
   a.c = c; a.mu = mu; a.gq_out = gq_out; a.gmu_out = gmu_out; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
   a.rowptr = g->rowptr; a.wf = wf; a.bf = bf; a.gc = gc; a.gmu = gmu; a.gr = gr; a.E = g->n_edges; a.N = g->n_atoms;
   a.F = F; a.rb = spk_radial_dev(rb); a.geom_only = geom_only ? 1 : 0; a.mu_zero = mu_zero ? 1 : 0; a.skin_list = g->filter_pairs ? 1 : 0;
+  a.blocks = g->blocks; a.blocks_prepared = blocks_prepared ? 1 : 0;
   return msg_dispatch<true>(a, g->sorted && g->symmetric && g->rowptr, stream, who);
 }
 
@@ -1220,6 +1226,16 @@ extern "C" int64_t spk_painn_scratch_floats(const spk_painn_t* m, int64_t N) {
   return N * 24 * (int64_t)m->n_atom_basis;
 }
 
+// per-call edge tables of the block kernels (spk_painn_blk.hip): true if the message launches of this call will use them
+static bool painn_blocks_prepare(const spk_graph_t* g, const spk_radial_t* rb, const float* r_ij, int F, bool bwd, hipStream_t stream) {
+  if (!g->blocks || !r_ij || g->n_edges == 0 || !(g->sorted && g->rowptr) || (bwd && !g->symmetric)) return false;
+  if (spk_get_variant() == SPK_VARIANT_SIMPLE) return false;
+  MsgArgs a = {};
+  a.rij = r_ij; a.rb = spk_radial_dev(rb); a.blocks = g->blocks; a.E = g->n_edges; a.N = g->n_atoms; a.F = F; a.rowptr = g->rowptr;
+  if (!spk_painn_blk_ok(a, bwd)) return false;
+  return spk_painn_blk_prep(a, stream) == SPK_OK;
+}
+
 extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
                                      const spk_radial_t* rb, const float* q0, const float* r_ij,
                                      float* q_out, float* mu_out, float* saved, float* scratch,
@@ -1246,6 +1262,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
   float* ctx = mu1 + 3 * nf;      // [N,2F]
   float* a1 = ctx + 2 * nf;       // [N,F]
   const int64_t per = painn_saved_per_atom(F) * N;
+  const bool blk = painn_blocks_prepare(g, rb, r_ij, F, false, stream);     // per-call edge tables of the block kernels, once for all interactions
   // mu entering the first interaction is zero (painn.py:246)
   { int _zr = spk_zero_async(saved + 4 * nf, 3 * nf * sizeof(float), stream); if (_zr) return _zr; }
   for (int l = 0; l < L; ++l) {
@@ -1262,7 +1279,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
       spk_apply_pack(ch, ptab);
       SPK_TRY(spk_dense_chain_f32(&ch, stream));
     }
-    SPK_TRY(spk_painn_message_fwd_internal(g, rb, c, qin, mu_in, r_ij, P.filt_w, P.filt_b, F, q1, mu1, stream, l == 0));   // mu_in == 0 for l == 0
+    SPK_TRY(spk_painn_message_fwd_internal(g, rb, c, qin, mu_in, r_ij, P.filt_w, P.filt_b, F, q1, mu1, stream, l == 0, blk));   // mu_in == 0 for l == 0
     float* mu_next = (l == L - 1) ? mu_out : (saved + (l + 1) * per + 4 * nf);
     const float* pk_mix = spk_packed_of(ptab, P.mix_w, 0);
     const float* pk_w1 = spk_packed_of(ptab, P.ictx_w1, 0);
@@ -1330,6 +1347,7 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
   if (gmu_out) SPK_HIP_TRY(hipMemcpyAsync(gmu, gmu_out, 3 * nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
   else { int _zr = spk_zero_async(gmu, 3 * nf * sizeof(float), stream); if (_zr) return _zr; }
   const int64_t per = painn_saved_per_atom(F) * N;
+  const bool blk = painn_blocks_prepare(g, rb, r_ij, F, true, stream);
   for (int l = L - 1; l >= 0; --l) {
     const spk_painn_layer_t& P = m->layers[l];
     const float* S = saved + l * per;
@@ -1367,7 +1385,7 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
     // (first interaction without dL/dq0, the eval path: only the geometry gradient is formed and the context-net
     //  backward below it is skipped)
     const bool last_geom_only = (l == 0 && !gq0);
-    SPK_TRY(spk_painn_message_bwd_internal(g, rb, c, mu_in, gq1, gmu1, r_ij, P.filt_w, P.filt_b, F, gc, gmu, gr, stream, last_geom_only, l == 0));
+    SPK_TRY(spk_painn_message_bwd_internal(g, rb, c, mu_in, gq1, gmu1, r_ij, P.filt_w, P.filt_b, F, gc, gmu, gr, stream, last_geom_only, l == 0, blk));
     if (last_geom_only) break;
     {  // context net backward; residual path adds gq1
       float* out = (l == 0 && gq0) ? gq0 : gq;
@@ -1425,6 +1443,6 @@ extern "C" int spk_painn_potential_forces_f32(const spk_painn_t* m, const spk_he
   SPK_CHECK_ARG(3 * (size_t)g->n_edges <= nf, "%s: more than n_atom_basis / 3 neighbours per atom on average", who);
   float* rij = scratch + 6 * nf;
   float* gq = scratch + 7 * nf;
-  SPK_TRY(spk_painn_mol_forward_ex(m, g, rb, ptab, q0, nullptr, R, offsets, q0 ? nullptr : emb, Z, &h, rij, gq, q_out, mu_out, saved, stream));
+  SPK_TRY(spk_painn_mol_forward_ex(m, g, rb, ptab, q0, nullptr, R, offsets, q0 ? nullptr : emb, Z, n_types, &h, rij, gq, q_out, mu_out, saved, stream));
   return spk_painn_mol_backward_ex(m, g, rb, ptab, gq, nullptr, rij, saved, scratch, nullptr, nullptr, F, stream);
 }

@@ -29,8 +29,8 @@ int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_
 int spk_painn_mol_backward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
                            const float* gmu_out, const float* r_ij, const float* saved, float* gc_scratch, float* gr, float* gq0, hipStream_t stream);
 int spk_painn_mol_forward_ex(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
-                             const float* r_ij, const float* R, const float* offsets, const float* emb, const int64_t* Z, const PmHeadDev* head,
-                             float* rij_out, float* gq_head_out, float* q_out, float* mu_out, float* saved, hipStream_t stream);
+                             const float* r_ij, const float* R, const float* offsets, const float* emb, const int64_t* Z, int n_types,
+                             const PmHeadDev* head, float* rij_out, float* gq_head_out, float* q_out, float* mu_out, float* saved, hipStream_t stream);
 int spk_painn_mol_backward_ex(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* gq_out,
                               const float* gmu_out, const float* r_ij, const float* saved,
                               float* gc_scratch, float* gr, float* gq0, float* forces, hipStream_t stream);

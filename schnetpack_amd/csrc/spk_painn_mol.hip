@@ -55,6 +55,7 @@ struct PmFwdArgs {
   const int64_t* idx_i;     // POT
   const float* emb;         // POT with q0 == null: rows of the nuclear embedding table [n_types, 128] ...
   const int64_t* Z;         // ... by atomic number [N]
+  int n_types;              // rows of emb: a Z outside [0, n_types) reads nothing and poisons its molecule with NaN (nn.Embedding raises)
   PmHeadDev head;           // POT
   const int64_t* idx_j;
   const int32_t* rowptr;    // CSR of idx_i
@@ -641,8 +642,11 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
       const int row = s >> 5, c4 = s & 31;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < na) {
-        if (POT && !a.q0) v = *(const f32x4*)(a.emb + (size_t)a.Z[a0 + row] * F + 4 * c4);
-        else v = pm_ld<f32x4>(a.q0 + (size_t)a0 * F, (unsigned)(s * 16));
+        if (POT && !a.q0) {
+          const int64_t z = a.Z[a0 + row];
+          if (z >= 0 && z < a.n_types) v = *(const f32x4*)(a.emb + (size_t)z * F + 4 * c4);
+          else { const float qn = __builtin_nanf(""); v = f32x4{qn, qn, qn, qn}; }       // no row to read: loud, never out of bounds
+        } else v = pm_ld<f32x4>(a.q0 + (size_t)a0 * F, (unsigned)(s * 16));
       }
       *(f32x4*)(sQ + row * PM_LD + 4 * c4) = v;
     }
@@ -1687,13 +1691,14 @@ static int launch_painn_mol_fwd(const PmFwdArgs& a, hipStream_t stream) {
 
 // r_ij, or (potential mode) R + offsets + head: pair vectors from the positions, q0 == null: rows of `emb` by Z, energies through the head
 int spk_painn_mol_forward_ex(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
-                             const float* r_ij, const float* R, const float* offsets, const float* emb, const int64_t* Z, const PmHeadDev* head,
-                             float* rij_out, float* gq_head_out, float* q_out, float* mu_out, float* saved, hipStream_t stream) {
+                             const float* r_ij, const float* R, const float* offsets, const float* emb, const int64_t* Z, int n_types,
+                             const PmHeadDev* head, float* rij_out, float* gq_head_out, float* q_out, float* mu_out, float* saved, hipStream_t stream) {
   PmFwdArgs a;
-  a.R = R; a.offsets = offsets; a.idx_i = g->idx_i; a.emb = emb; a.Z = Z; a.rij_out = rij_out; a.gq_out = gq_head_out;
-  SPK_CHECK_ARG(!R || (rij_out && gq_head_out && head->w1t), "spk_painn_mol_forward: no buffers for the pair vectors / the head gradient");
-  if (head) a.head = *head; else { a.head = PmHeadDev(); }
+  a.R = R; a.offsets = offsets; a.idx_i = g->idx_i; a.emb = emb; a.Z = Z; a.n_types = n_types; a.rij_out = rij_out; a.gq_out = gq_head_out;
   SPK_CHECK_ARG((R != nullptr) == (head != nullptr), "spk_painn_mol_forward: positions and head go together");
+  SPK_CHECK_ARG(!R || (rij_out && gq_head_out && head->w1t), "spk_painn_mol_forward: no buffers for the pair vectors / the head gradient");
+  SPK_CHECK_ARG(!emb || n_types > 0, "spk_painn_mol_forward: embedding table without a row count");
+  if (head) a.head = *head; else { a.head = PmHeadDev(); }
   SPK_CHECK_ARG(!R || (head->H == 64 && head->w1 && head->b1 && head->w2 && head->idx_m && head->E && head->pre_h && (q0 || (emb && Z))), "spk_painn_mol_forward: incomplete potential arguments");
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
@@ -1726,7 +1731,7 @@ int spk_painn_mol_forward_ex(const spk_painn_t* m, const spk_graph_t* g, const s
 }
 int spk_painn_mol_forward(const spk_painn_t* m, const spk_graph_t* g, const spk_radial_t* rb, const SpkPackTable& ptab, const float* q0,
                           const float* r_ij, float* q_out, float* mu_out, float* saved, hipStream_t stream) {
-  return spk_painn_mol_forward_ex(m, g, rb, ptab, q0, r_ij, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, q_out, mu_out, saved, stream);
+  return spk_painn_mol_forward_ex(m, g, rb, ptab, q0, r_ij, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, q_out, mu_out, saved, stream);
 }
 
 static size_t painn_mol_bwd_lds() {

@@ -32,6 +32,9 @@ struct MsgArgs {
   const float* tab;
   int tab_knots;
   float tab_inv_step;
+  // block plan of the list (spk_painn_blk.hip; null: none) and whether its per-call edge tables are current for `rij`
+  const spk_blocks_t* blocks;
+  int blocks_prepared;
 };
 
 // MFMA tile kernel of the forward message (spk_painn_tile.hip): true if it should run for this shape / list

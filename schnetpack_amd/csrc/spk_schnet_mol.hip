@@ -380,7 +380,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
         if (a.x0) v = ml_ld<f32x4>(a.x0 + (size_t)a0 * NF, (unsigned)(s * 16));
         else {
           const long long z = a.Z[a0 + row];
-          if (z >= 0 && z < a.n_types) v = *(const f32x4*)(a.emb + (size_t)z * NF + 4 * c4);      // (out of range: zeros, flagged by the plan / caller)
+          if (z >= 0 && z < a.n_types) v = *(const f32x4*)(a.emb + (size_t)z * NF + 4 * c4);
+          else { const float qn = __builtin_nanf(""); v = f32x4{qn, qn, qn, qn}; }     // no such row (nn.Embedding raises): NaN, never out of bounds
         }
       }
       *(f32x4*)(sX + row * ML_LD + 4 * c4) = v;

@@ -102,6 +102,11 @@ struct Plan {
   int filter_pairs = -1;     // -1: undecided
   bool has_r = false;
   std::vector<std::pair<std::vector<uint64_t>, bool>> inside;   // per idx_m tensor: every molecule inside one group, none empty
+  // block plan of a large sorted list (PaiNN message kernels of the box regime, spk_painn_blk.hip): index arrays + per-call workspace
+  Tensor b_sub_n, b_sub_u, b_uniq, b_jl, b_tile0, b_tinfo, b_desc, b_apack, b_adpack, b_rec, b_part;
+  spk_blocks_t blocks;
+  int blocks_state = 0;      // 0: not built, 1: usable, -1: the list does not fit / too small
+  int blocks_rbf = 0, blocks_F = 0;
 
   spk_graph_t graph() const {
     spk_graph_t g;
@@ -127,6 +132,7 @@ struct Plan {
     }
     g.filter_pairs = filter_pairs > 0 ? 1 : 0;
     g.edge_pair = edge_pair.defined() ? edge_pair.data_ptr<int32_t>() : nullptr;
+    g.blocks = blocks_state == 1 ? &blocks : nullptr;
     return g;
   }
 };
@@ -227,6 +233,39 @@ std::shared_ptr<Plan> get_plan(const Tensor& idx_i_in, const Tensor& idx_j_in, i
   }
   g_plans.put(key, p);
   return p;
+}
+
+// Block plan of a sorted list for the block kernels of the PaiNN message (spk_painn_blk.hip): an opt-in EXPERIMENT (SPK_BLOCKS=1 and
+// spk_painn_set_block(1)) -- measured slower than the row / tile kernels on the water box.  Built once per list next to the plan
+// (one small D2H copy), keyed by the radial-basis size and the feature width the workspace is sized for.
+void ensure_blocks(Plan& p, int64_t n_rbf, int64_t F) {
+  const char* env = getenv("SPK_BLOCKS");
+  const int force = env ? (env[0] == '0' ? -1 : 1) : 0;
+  if (p.blocks_state != 0 && p.blocks_rbf == n_rbf && p.blocks_F == F) return;
+  p.blocks_state = -1; p.blocks_rbf = (int)n_rbf; p.blocks_F = (int)F;
+  if (force <= 0 || !p.sorted || p.n_edges == 0 || n_rbf > 32 || F % 16 != 0 || F < 16) return;
+  int64_t sz[12];
+  check(spk_blocks_sizes(p.n_atoms, p.n_edges, (int32_t)n_rbf, (int32_t)F, sz));
+  auto dev = p.idx_i.device();
+  auto iopt = at::TensorOptions().dtype(at::kInt).device(dev);
+  auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+  p.b_sub_n = at::zeros({sz[0]}, iopt); p.b_sub_u = at::zeros({sz[1]}, iopt); p.b_uniq = at::zeros({sz[2]}, iopt);
+  p.b_jl = at::zeros({sz[3]}, at::TensorOptions().dtype(at::kShort).device(dev));
+  p.b_tile0 = at::zeros({sz[4]}, iopt); p.b_tinfo = at::zeros({sz[5]}, iopt); p.b_desc = at::zeros({sz[10]}, iopt);
+  Tensor stats = at::zeros({4}, iopt);
+  std::memset(&p.blocks, 0, sizeof(p.blocks));
+  p.blocks.sub_n = p.b_sub_n.data_ptr<int32_t>(); p.blocks.sub_u = p.b_sub_u.data_ptr<int32_t>(); p.blocks.uniq = p.b_uniq.data_ptr<int32_t>();
+  p.blocks.jl = (const uint16_t*)p.b_jl.data_ptr<int16_t>(); p.blocks.atom_tile0 = p.b_tile0.data_ptr<int32_t>(); p.blocks.tile_info = p.b_tinfo.data_ptr<int32_t>(); p.blocks.blk_desc = p.b_desc.data_ptr<int32_t>();
+  int32_t host[4] = {0, 0, 0, 0};
+  spk_graph_t g = p.graph();
+  check(spk_blocks_build(&g, (int32_t)n_rbf, 0, &p.blocks, stats.data_ptr<int32_t>(), host, stream_of(p.idx_i)));
+  if (!p.blocks.ok) { p.b_uniq = Tensor(); p.b_jl = Tensor(); return; }
+  const int64_t nt = std::max<int64_t>(p.blocks.n_tiles, 1);
+  p.b_apack = at::empty({nt * p.blocks.ks * 64}, fopt); p.b_adpack = at::empty({nt * p.blocks.ks * 64}, fopt);
+  p.b_rec = at::empty({nt * 6 * 16}, fopt); p.b_part = at::empty({sz[8]}, fopt);
+  p.blocks.apack = p.b_apack.data_ptr<float>(); p.blocks.adpack = p.b_adpack.data_ptr<float>();
+  p.blocks.rec = p.b_rec.data_ptr<float>(); p.blocks.part = p.b_part.data_ptr<float>();
+  p.blocks_state = 1;
 }
 
 // Lists with pairs at or beyond the cutoff (MD skin lists): switch the per-call pair compaction of the fused SchNet path
@@ -581,6 +620,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> painn_forward_raw(const Tensor& q0_in
   auto plan = get_plan(idx_i, idx_j, N, r);
   if (plan->filter_pairs < 0 && plan->n_edges >= (1 << 19))
     decide_filter(*plan, r, cutoff);   // large lists: tells the message dispatch whether the list carries a skin
+  ensure_blocks(*plan, p0.size(0), F);
   auto M = get_painn(ws, F, shared_filters, eps);
   spk_graph_t g = plan->graph();
   spk_radial_t rb = radial_of(rbf_kind, p0, p1, cutoff);

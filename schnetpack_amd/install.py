@@ -45,23 +45,26 @@ def uninstall():
 _ABSENT = object()
 
 
-def _fused_potential_forward(orig_forward):
-    """``NeuralNetworkPotential.forward`` (model/base.py:174-190) with the standard potential handed to the fused operators
-    (model.classify_potential); everything else -- training mode, scripting, any other composition -- runs the reference's own
-    forward unchanged.  The classification of an instance is made once."""
-    import torch
+def _fused_potential_call(orig_call):
+    """``NeuralNetworkPotential.__call__`` with the standard potential handed to the fused operators (model.classify_potential):
+    an eval-mode call of a model that is PairwiseDistances -> SchNet / PaiNN -> default Atomwise -> Forces runs as the two-launch
+    operator; everything else -- training mode, any other composition, a model with forward hooks, keyword / extra arguments --
+    goes through ``nn.Module.__call__`` to the reference's own ``forward`` (model/base.py:174-190), which is NOT touched: the class
+    stays scriptable (``torch.jit.script`` compiles ``forward``; ``spkdeploy`` and the LAMMPS route depend on it), and a scripted
+    module has its own ``__call__``.  The classification of an instance is made once."""
     from . import model as M
 
-    def forward(self, inputs):
-        if self.training or torch.jit.is_scripting():
-            return orig_forward(self, inputs)
+    def __call__(self, *args, **kwargs):
+        if (self.training or len(args) != 1 or kwargs or not isinstance(args[0], dict)
+                or self._forward_hooks or self._forward_pre_hooks):
+            return orig_call(self, *args, **kwargs)
         mode = self.__dict__.get("_spk_hip_mode")
         if mode is None:
             mode = M.classify_potential(self)
             self.__dict__["_spk_hip_mode"] = mode
         if mode == 0:
-            return orig_forward(self, inputs)
-        inputs = self.initialize_derivatives(inputs)
+            return orig_call(self, *args, **kwargs)
+        inputs = self.initialize_derivatives(args[0])
         if mode == 2:
             inputs = M.potential_forces_forward(self, inputs)
         else:
@@ -72,19 +75,20 @@ def _fused_potential_forward(orig_forward):
         inputs = self.postprocess(inputs)
         return self.extract_outputs(inputs)
 
-    forward._spk_hip_patched = True
-    return forward
+    __call__._spk_hip_patched = True
+    return __call__
 
 
-def install(spk=None, verbose=False, fused_head=False, neighbor_lists=False, fused_potential=False):
+def install(spk=None, verbose=False, fused_head=True, neighbor_lists=False, fused_potential=True):
     """Patch ``spk`` (default: the imported ``schnetpack``).  Returns the list of patched names.
 
-    ``fused_head=True`` also routes ``atomistic.Atomwise`` to the mirror whose default 2-layer energy head
+    ``fused_head`` (default on) also routes ``atomistic.Atomwise`` to the mirror whose default 2-layer energy head
     runs as one fused kernel pair in eval mode (same constructor, ``state_dict`` keys and outputs).
-    ``fused_potential=True`` (opt-in; implies nothing else -- combine with ``fused_head=True``, which the routing needs)
-    wraps ``model.base.NeuralNetworkPotential.forward``: an eval-mode model that is the standard potential (PairwiseDistances ->
-    SchNet -> default Atomwise -> Forces) runs as the two-launch operator exactly like the mirror model; any other model, and
-    training, keep the reference's forward.
+    ``fused_potential`` (default on since round 4; needs ``fused_head``) wraps ``model.base.NeuralNetworkPotential.__call__``:
+    an eval-mode call of a model that is the standard potential (PairwiseDistances -> SchNet / PaiNN -> default Atomwise ->
+    Forces) runs as the two-launch operator exactly like the mirror model -- 1.3-2 x the module-by-module route; any other
+    model, training, and ``torch.jit.script`` (the class ``forward`` is untouched) keep the reference's code.
+    ``install(fused_head=False, fused_potential=False)`` is the minimal patch of rounds 1-3.
     ``neighbor_lists=True`` adds ``transform.HipNeighborList`` and replaces ``md.neighborlist_md.NeighborListMD``
     by the device-side batched version (same constructor and ``get_neighbors``)."""
     from . import atomistic as A
@@ -124,13 +128,14 @@ def install(spk=None, verbose=False, fused_head=False, neighbor_lists=False, fus
     if fused_head:
         for mod in (getattr(spk, "atomistic", None), sub("atomistic.atomwise")):
             _set(mod, "Atomwise", A.Atomwise, log)
-    if fused_potential:
+    if fused_potential and fused_head:
         mb = sub("model.base")
         cls = getattr(mb, "NeuralNetworkPotential", None) if mb is not None else None
-        if cls is not None and not getattr(cls.forward, "_spk_hip_patched", False):
-            _ORIGINALS.append((cls, "forward", cls.forward))
-            cls.forward = _fused_potential_forward(cls.forward)
-            log.append(mb.__name__ + ".NeuralNetworkPotential.forward")
+        if cls is not None and not getattr(cls.__call__, "_spk_hip_patched", False):
+            # (the patched name is the class's own __call__ attribute: absent before, nn.Module's is inherited)
+            _ORIGINALS.append((cls, "__call__", cls.__dict__.get("__call__", _ABSENT)))
+            cls.__call__ = _fused_potential_call(cls.__call__)
+            log.append(mb.__name__ + ".NeuralNetworkPotential.__call__")
     if neighbor_lists:
         from . import neighborlist as NL
         for mod in (getattr(spk, "transform", None), sub("transform.neighborlist")):

@@ -218,8 +218,10 @@ class NeuralNetworkPotential(nn.Module):
             inputs = self._potential_forces_forward(inputs)
             return {k: inputs[k] for k in self.model_outputs}
         if self.training and self.fm_engine and not torch.jit.is_scripting():
-            inputs = self._potential_fm_forward(inputs)
-            return {k: inputs[k] for k in self.model_outputs}
+            pos = inputs[properties.R]
+            if pos.is_cuda and pos.dtype == torch.float32:      # the engine is fp32 on the device; anything else (float64 checks of the
+                inputs = self._potential_fm_forward(inputs)     # operator-by-operator path on the host) takes the primitives below
+                return {k: inputs[k] for k in self.model_outputs}
         if self._potential and not self.training and not torch.jit.is_scripting():
             inputs = self._potential_forward(inputs)
             for i, m in enumerate(self.output_modules):

@@ -61,10 +61,36 @@ class EdgePlan:
                                   iptr(gp[2], torch.int32) if gp else None, n_groups if gp else 0, max_ga if gp else 0,
                                   n_tiles_g if gp else 0, 0, 0, None,
                                   iptr(self.edge_pair, torch.int32) if self.edge_pair is not None else None,
-                                  max_gp if gp else 0, 0)
+                                  max_gp if gp else 0, 0, None)
+        self.blocks = None
 
     def graph(self):
         return ctypes.byref(self._graph)
+
+    def build_blocks(self, n_rbf=20, n_atom_basis=128, cap=0):
+        """Block plan of the list (``spk_blocks_build``; include/spk_hip.h) for the box-regime PaiNN message kernels, attached to
+        the graph.  Returns (usable, largest unique-neighbour count, tiles).  One device-to-host copy -- per list, not per call."""
+        assert self.sorted, "block plans need a list sorted by idx_i"
+        dev = self.idx_i.device
+        sizes = (ctypes.c_int64 * 12)()
+        check(lib().spk_blocks_sizes(self.n_atoms, self.n_edges, int(n_rbf), int(n_atom_basis), sizes))
+        i32 = lambda n: torch.zeros(max(int(n), 1), dtype=torch.int32, device=dev)
+        f32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.float32, device=dev)
+        bufs = dict(sub_n=i32(sizes[0]), sub_u=i32(sizes[1]), uniq=i32(sizes[2]), jl=torch.zeros(max(int(sizes[3]), 1), dtype=torch.int16, device=dev),
+                    atom_tile0=i32(sizes[4]), tile_info=i32(sizes[5]), blk_desc=i32(sizes[10]), stats=i32(4))
+        b = _lib.BlocksT()
+        for name in ("sub_n", "sub_u", "uniq", "jl", "atom_tile0", "tile_info", "blk_desc"):
+            setattr(b, name, bufs[name].data_ptr())
+        host = (ctypes.c_int32 * 4)()
+        with torch.cuda.device(dev):
+            check(lib().spk_blocks_build(self.graph(), int(n_rbf), int(cap), ctypes.byref(b), bufs["stats"].data_ptr(), host, stream()))
+        ks, nt = int(sizes[9]), max(int(b.n_tiles), 1)
+        bufs.update(apack=f32(nt * ks * 64), adpack=f32(nt * ks * 64), rec=f32(nt * 6 * 16), part=f32(sizes[8]))
+        for name in ("apack", "adpack", "rec", "part"):
+            setattr(b, name, bufs[name].data_ptr())
+        self.blocks, self._block_bufs = b, bufs
+        self._graph.blocks = ctypes.addressof(b) if b.ok else None
+        return bool(b.ok), int(b.max_unique), int(b.n_tiles)
 
     # lists with pairs at or beyond the cutoff (MD skin lists): per-call compaction in the fused SchNet path
     filter_pairs = None     # None: undecided, see decide_filter()

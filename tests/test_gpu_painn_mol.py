@@ -244,3 +244,32 @@ def test_large_molecules_and_wide_bases_fall_back_to_the_general_driver(dev):
     (e, f, x, v), tags, (rep, head) = _run(b2, dev, 3, 32)      # n_rbf = 32 > 20: filter weights do not fit the registers
     assert "painn_mol_fwd" not in tags
     assert rel_err(f, O.energy_and_forces("painn", rep, head, b2, 3)["forces"]) < TOL
+
+
+@pytest.mark.parametrize("kind", ["painn", "schnet"])
+def test_atomic_number_beyond_the_embedding_table_poisons_its_molecule_and_reads_nothing(dev, kind):
+    """Round-3 ADVICE: the two-launch potentials look the embedding rows up by Z inside the forward launch.  The reference's
+    nn.Embedding raises an IndexError for Z >= max_z (representation/painn.py:155, schnet.py:127); a device kernel cannot raise, so
+    an out-of-range Z reads NO row (it used to be an out-of-bounds read in the PaiNN kernel) and poisons exactly its molecule with
+    NaN -- the other molecules of the batch are untouched."""
+    from schnetpack_amd import _lib, model as M
+    b = S.molecule_batch("aspirin", 3, seed=12)
+    rep = (O.init_painn_params if kind == "painn" else O.init_schnet_params)()
+    head = O.init_atomwise_params(128, seed=1)
+    m = M.build_model(kind)
+    M.load_reference_params(m, rep, head)
+    m = m.to(dev).eval()
+    good = m(M.batch_to_inputs(b, dev))
+    e_good, f_good = good["energy"].detach().cpu(), good["forces"].detach().cpu()
+    for bad_z in (100, 250, -3):
+        bb = dict(b)
+        bb["Z"] = b["Z"].clone()
+        bb["Z"][21 + 4] = bad_z                       # an atom of the SECOND molecule
+        _lib.profile_enable(True); _lib.profile_report()
+        out = m(M.batch_to_inputs(bb, dev))
+        tags = set(_lib.profile_report()); _lib.profile_enable(False)
+        assert tags == {kind + "_mol_fwd", kind + "_mol_bwd"}, tags
+        e, f = out["energy"].detach().cpu(), out["forces"].detach().cpu()
+        assert torch.isnan(e[1]) and torch.isnan(f[21:42]).all()
+        assert rel_err(e[[0, 2]], e_good[[0, 2]]) < 1e-6
+        assert rel_err(f[:21], f_good[:21]) < 1e-6 and rel_err(f[42:], f_good[42:]) < 1e-6

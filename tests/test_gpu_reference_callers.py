@@ -176,7 +176,8 @@ def test_fused_potential_install_routes_the_reference_model_to_the_two_launch_op
     out_pref = _build_reference_model(ns, "painn").eval()(_ref_inputs(b))
     inst.install(sys.modules["schnetpack"], fused_head=True, fused_potential=True)
     m = _build_reference_model(ns, "schnet").to(dev).eval()
-    assert type(m) is ns.model.NeuralNetworkPotential and getattr(type(m).forward, "_spk_hip_patched", False)
+    assert type(m) is ns.model.NeuralNetworkPotential and getattr(type(m).__call__, "_spk_hip_patched", False)
+    assert not hasattr(type(m).forward, "_spk_hip_patched")      # the class forward stays the reference's (scriptable)
     out = m(_ref_inputs(b, dev))            # first call: plan
     _lib.profile_enable(True)
     _lib.profile_report()
@@ -208,4 +209,4 @@ def test_fused_potential_install_routes_the_reference_model_to_the_two_launch_op
     from schnetpack_amd import model as M
     assert M.classify_potential(ms) == 0
     inst.uninstall()
-    assert not getattr(ns.model.NeuralNetworkPotential.forward, "_spk_hip_patched", False)
+    assert not getattr(ns.model.NeuralNetworkPotential.__call__, "_spk_hip_patched", False)

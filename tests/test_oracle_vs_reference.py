@@ -98,9 +98,13 @@ def test_install_hook_patches_reference_namespace_and_pickles_resolve_to_mirrors
         ("schnetpack.nn.radial", "BesselRBF"), ("schnetpack.nn.cutoff", "CosineCutoff"),
         ("schnetpack.nn.scatter", "scatter_add"), ("schnetpack.atomistic.distances", "PairwiseDistances"),
         ("schnetpack.atomistic.atomwise", "scatter_add") if hasattr(sys.modules["schnetpack.atomistic.atomwise"], "scatter_add") else ("schnetpack.nn", "scatter_add")]}
+    aw_mod = sys.modules["schnetpack.atomistic.atomwise"]
+    saved[("schnetpack.atomistic.atomwise", "Atomwise")] = aw_mod.Atomwise
     try:
-        log = inst.install(spk)
+        log = inst.install(spk)          # defaults since round 4: fused head + the standard potential routed at __call__
         assert "schnetpack.representation.painn.PaiNN" in log and "schnetpack.nn.scatter_add" in log
+        assert "schnetpack.model.base.NeuralNetworkPotential.__call__" in log and "schnetpack.atomistic.atomwise.Atomwise" in log
+        assert not hasattr(sys.modules["schnetpack.model.base"].NeuralNetworkPotential.forward, "_spk_hip_patched")
         assert sys.modules["schnetpack.representation.painn"].PaiNN is R.PaiNN
         assert spk.nn.scatter_add is N.scatter_add
         sys.modules["ase.data"].atomic_masses = np.ones(119)
@@ -123,14 +127,14 @@ def test_install_hook_patches_reference_namespace_and_pickles_resolve_to_mirrors
         assert flts[0] == pytest.approx(5.0) and flts[2] == pytest.approx(float(m.postprocessors[1].mean), rel=1e-6)
         # opt-in extras: fused energy head and the device neighbour lists
         from schnetpack_amd import atomistic as A, neighborlist as NL
-        aw_mod = sys.modules["schnetpack.atomistic.atomwise"]
-        saved[("schnetpack.atomistic.atomwise", "Atomwise")] = aw_mod.Atomwise
         log2 = inst.install(spk, fused_head=True, neighbor_lists=True)
         assert aw_mod.Atomwise is A.Atomwise and "schnetpack.atomistic.atomwise.Atomwise" in log2
         if ns.neighborlist is not None:
             assert sys.modules["schnetpack.transform.neighborlist"].HipNeighborList is NL.HipNeighborList
             delattr(sys.modules["schnetpack.transform.neighborlist"], "HipNeighborList")
     finally:
+        inst.uninstall()
+        assert "__call__" not in sys.modules["schnetpack.model.base"].NeuralNetworkPotential.__dict__
         for (mod, k), v in saved.items():
             setattr(sys.modules[mod], k, v)
         spk.representation.SchNet = ns.schnet.SchNet
