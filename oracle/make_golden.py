@@ -344,9 +344,34 @@ def deep_model_goldens(ns):
         save(name + ".npz", b, res, weights_checksum=checksum(p), kind=kind, cutoff=5.0, radial="gaussian", n_interactions=6)
 
 
+def deep_bessel_goldens(ns):
+    """Six interactions x BesselRBF (round-3 review): the molecule kernels evaluate sin / cos with the hardware transcendentals, and
+    depth multiplies whatever error they leave -- the least-margin combination gets its own reference fixtures, on a molecule batch
+    and on the periodic 192-atom water box."""
+    nn = ns.nn
+    head = O.init_atomwise_params(128, seed=1)
+    wb = S.water_box(n_side=4, seed=0)
+    for name, kind, b in (("schnet6_bessel_aspirin4", "schnet", S.molecule_batch("aspirin", 4, seed=11)), ("schnet6_bessel_water192", "schnet", wb),
+                          ("painn6_bessel_aspirin4", "painn", S.molecule_batch("aspirin", 4, seed=11)), ("painn6_bessel_water192", "painn", wb)):
+        rb = nn.BesselRBF(20, 5.0)
+        torch.manual_seed(0)
+        if kind == "schnet":
+            rep = ns.schnet.SchNet(128, 6, rb, nn.CosineCutoff(5.0))
+            p = O.init_schnet_params(n_interactions=6, radial="bessel")
+        else:
+            rep = ns.painn.PaiNN(128, 6, rb, nn.CosineCutoff(5.0))
+            p = O.init_painn_params(n_interactions=6, radial="bessel")
+        sd = rep.state_dict()
+        assert all(torch.equal(sd[k], p[k].to(sd[k].dtype)) for k in sd), name
+        res = run_reference(ns, rep, head, b)
+        save(name + ".npz", b, res, weights_checksum=checksum(p), kind=kind, cutoff=5.0, radial="bessel", n_interactions=6)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "deep":
         deep_model_goldens(refshim.load())
+    elif len(sys.argv) > 1 and sys.argv[1] == "deep_bessel":
+        deep_bessel_goldens(refshim.load())
     elif len(sys.argv) > 1 and sys.argv[1] == "md":
         ring_polymer_goldens()
     elif len(sys.argv) > 1 and sys.argv[1] == "nbl":
@@ -359,3 +384,4 @@ if __name__ == "__main__":
         ring_polymer_goldens()
         deploy_goldens(refshim.load())
         deep_model_goldens(refshim.load())
+        deep_bessel_goldens(refshim.load())

@@ -470,9 +470,31 @@ struct Vec3Fn : public torch::autograd::Function<Vec3Fn> {
   }
 };
 
-void check_fixed_basis(const Tensor& p0, const OptT& p1, const char* who) {
+// Trainable radial parameters (nn/radial.py:36-45: GaussianRBF(trainable=True) makes `offsets` / `widths` nn.Parameters): the Gaussian
+// family is closed under differentiation w.r.t. them as well.  With t = d - mu_k and phi_k^(n) the n-th derivative in d,
+//   d phi_k^(n) / d mu_k = - phi_k^(n+1),      d phi_k^(n) / d w_k = - (n phi_k^(n) + t phi_k^(n+1)) / w_k      (phi(t; w) = g(t / w)),
+// so the gradients are column sums over the pairs of the SAME products the d-gradients are made of -- expressed through the
+// operators themselves (spk_hip::radial_d at order n, n + 1), hence differentiable again: the second order of force matching
+// (atomistic/response.py:59-68) needs d/d(mu, w) of the recorded dE/dd nodes.  Bessel frequencies are buffers in the reference.
+void check_fixed_basis(int64_t kind, const Tensor& p0, const OptT& p1, const char* who) {
+  if (kind == 0) return;
   TORCH_CHECK(!p0.requires_grad() && !(p1.has_value() && p1->defined() && p1->requires_grad()), who,
-              ": the radial parameters are constants of this operator; trainable bases take the formula path of the module");
+              ": only the Gaussian basis has trainable parameters (offsets, widths); kind ", kind, " takes constants");
+}
+// column sums over every leading dimension: X [..., K] -> [K]
+Tensor colsum_k(const Tensor& X) { return X.reshape({-1, X.size(-1)}).sum(0); }
+// (g_mu, g_w) of  out = a phi^(n)(d)  contracted with `g` ([..., K]); Dn / Dn1 = a phi^(n) / a phi^(n+1) with the SAME a
+std::pair<Tensor, Tensor> gaussian_param_grads(const Tensor& g, const Tensor& Dn, const Tensor& Dn1, const Tensor& d, const Tensor& mu, const Tensor& w,
+                                               int64_t n, bool want_mu, bool want_w) {
+  Tensor gmu, gw;
+  const Tensor s1 = colsum_k(at::mul(g, Dn1));
+  if (want_mu) gmu = at::neg(s1);
+  if (want_w) {
+    Tensor acc = at::sub(colsum_k(at::mul(at::mul(g, Dn1), d.unsqueeze(-1))), at::mul(mu, s1));
+    if (n > 0) acc = at::add(acc, colsum_k(at::mul(g, Dn)), (double)n);
+    gw = at::neg(at::div(acc, w));
+  }
+  return {gmu, gw};
 }
 
 // out = a phi^(k)(d)
@@ -501,7 +523,15 @@ struct RadialDFn : public torch::autograd::Function<RadialDFn> {
       if (ctx->needs_input_grad(0)) gd = call_radial_c(g[0], d, opt_of(a), kind, p0, p1, cutoff, k + 1);
       if (has_a && ctx->needs_input_grad(2)) ga = call_radial_c(g[0], d, c10::nullopt, kind, p0, p1, cutoff, k);
     }
-    return {gd, Tensor(), ga, Tensor(), Tensor(), Tensor(), Tensor()};
+    Tensor gp0, gp1;
+    // (needs_input_grad indexes the TENSOR inputs that were passed: an absent optional has no edge, so p1 follows a only if a is there)
+    const size_t e_p1 = has_a ? 3 : 2;
+    if (kind == 0 && sv[3].defined() && (ctx->needs_input_grad(1) || ctx->needs_input_grad(e_p1))) {
+      TORCH_CHECK(k + 1 <= 3, "spk_hip::radial_d: parameter gradients of derivative order ", k, " are not provided");
+      const Tensor Dn = call_radial_d(d, opt_of(a), kind, p0, p1, cutoff, k), Dn1 = call_radial_d(d, opt_of(a), kind, p0, p1, cutoff, k + 1);
+      std::tie(gp0, gp1) = gaussian_param_grads(g[0], Dn, Dn1, d, p0, sv[3], k, ctx->needs_input_grad(1), ctx->needs_input_grad(e_p1));
+    }
+    return {gd, gp0, ga, gp1, Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -529,7 +559,15 @@ struct RadialCFn : public torch::autograd::Function<RadialCFn> {
     if (ctx->needs_input_grad(0)) gG = call_radial_d(d, ag, kind, p0, p1, cutoff, k);
     if (ctx->needs_input_grad(1)) gd = call_radial_c(G, d, ag, kind, p0, p1, cutoff, k + 1);
     if (has_a && ctx->needs_input_grad(3)) ga = call_radial_c(G, d, g[0], kind, p0, p1, cutoff, k);
-    return {gG, gd, Tensor(), ga, Tensor(), Tensor(), Tensor(), Tensor()};
+    Tensor gp0, gp1;
+    const size_t e_p1 = has_a ? 4 : 3;
+    if (kind == 0 && sv[4].defined() && (ctx->needs_input_grad(2) || ctx->needs_input_grad(e_p1))) {
+      // out_e = (a g)_e sum_k G_ek phi_k^(n)(d_e): the same column sums with G in the place of the incoming gradient
+      TORCH_CHECK(k + 1 <= 3, "spk_hip::radial_c: parameter gradients of derivative order ", k, " are not provided");
+      const Tensor Dn = call_radial_d(d, ag, kind, p0, p1, cutoff, k), Dn1 = call_radial_d(d, ag, kind, p0, p1, cutoff, k + 1);
+      std::tie(gp0, gp1) = gaussian_param_grads(G, Dn, Dn1, d, p0, sv[4], k, ctx->needs_input_grad(2), ctx->needs_input_grad(e_p1));
+    }
+    return {gG, gd, gp0, ga, gp1, Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -587,11 +625,11 @@ Tensor cfconv_ad(const Tensor& x, const Tensor& W, const OptT& io, const OptT& i
 Tensor edge_mul_ad(const Tensor& a, const Tensor& b, const OptT& ia, const OptT& ib) { return EdgeMulFn::apply(a, b, ia, ib); }
 Tensor vec3_ad(int64_t op, const Tensor& A, const Tensor& B) { return Vec3Fn::apply(A, B, op); }
 Tensor radial_d_ad(const Tensor& d, const OptT& a, int64_t kind, const Tensor& p0, const OptT& p1, double cutoff, int64_t order) {
-  check_fixed_basis(p0, p1, "spk_hip::radial_d");
+  check_fixed_basis(kind, p0, p1, "spk_hip::radial_d");
   return RadialDFn::apply(d, p0, a, p1, kind, cutoff, order);
 }
 Tensor radial_c_ad(const Tensor& G, const Tensor& d, const OptT& a, int64_t kind, const Tensor& p0, const OptT& p1, double cutoff, int64_t order) {
-  check_fixed_basis(p0, p1, "spk_hip::radial_c");
+  check_fixed_basis(kind, p0, p1, "spk_hip::radial_c");
   return RadialCFn::apply(G, d, p0, a, p1, kind, cutoff, order);
 }
 Tensor rowscale_ad(const Tensor& W, const Tensor& s) { return RowscaleFn::apply(W, s); }

@@ -136,6 +136,8 @@ def classify_fm(model) -> int:
         return 0
     if not (type(rep.embedding) is nn.Embedding and len(rep.electronic_embeddings) == 0):
         return 0
+    if getattr(rep.radial_basis, "trainable", False):      # the engine has no gradient w.r.t. offsets / widths: the closed operators do
+        return 0
     if not (len(ins) == 1 and type(ins[0]) is PairwiseDistances and len(outs) == 2):
         return 0
     head, frc = outs
@@ -237,10 +239,10 @@ class NeuralNetworkPotential(nn.Module):
 
 
 def build_model(kind: str = "schnet", n_atom_basis: int = 128, n_interactions: int = 3,
-                n_rbf: int = 20, cutoff: float = 5.0, radial: str = "gaussian", **rep_kw):
+                n_rbf: int = 20, cutoff: float = 5.0, radial: str = "gaussian", trainable_rbf: bool = False, **rep_kw):
     """SchNet / PaiNN + Atomwise energy head + Forces, assembled like
     configs/model/nnp.yaml:4-8 + experiment/md17.yaml:30-38."""
-    rb = GaussianRBF(n_rbf, cutoff) if radial == "gaussian" else BesselRBF(n_rbf, cutoff)
+    rb = GaussianRBF(n_rbf, cutoff, trainable=trainable_rbf) if radial == "gaussian" else BesselRBF(n_rbf, cutoff)
     cf = CosineCutoff(cutoff)
     if kind == "schnet":
         rep = SchNet(n_atom_basis, n_interactions, rb, cf, **rep_kw)

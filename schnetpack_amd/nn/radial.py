@@ -47,9 +47,9 @@ class GaussianRBF(nn.Module):
         return 0, self.offsets, self.widths
 
     def forward(self, inputs: torch.Tensor):
-        if self.trainable:
-            return gaussian_rbf(inputs, self.offsets, self.widths)
-        if self.training and torch.is_grad_enabled() and inputs.requires_grad:
+        # training-mode graphs (any order in d; with ``trainable=True`` also the gradients w.r.t. offsets / widths, nn/radial.py:40-45)
+        # run the closed operator family spk_hip::radial_d / radial_c; plain evaluation the fused radial + cutoff kernel
+        if torch.is_grad_enabled() and ((self.training and inputs.requires_grad) or (self.trainable and self.offsets.requires_grad)):
             return torch.ops.spk_hip.radial_d(inputs, None, 0, self.offsets, self.widths, 1.0, 0)
         return torch.ops.spk_hip.radial_cutoff(inputs, 0, self.offsets, self.widths, 1.0, True, False)[0]
 

@@ -140,7 +140,7 @@ class PaiNN(nn.Module):
         return float(self.epsilon)
 
     def _fusable(self) -> bool:
-        """The one-operator eval path covers SiLU context nets, the mirrored radial bases (not trainable) and cosine
+        """The one-operator eval path covers SiLU context nets, the mirrored radial bases (trainable or not: in eval mode their parameters are plain operands) and cosine
         cutoff within the kernels' shape limits (spk_painn.hip: n_atom_basis <= 1024, n_rbf <= 256)."""
         if len(self.interactions) == 0:
             return False
@@ -148,7 +148,6 @@ class PaiNN(nn.Module):
         n_rbf = int(getattr(self.radial_basis, "n_rbf", 0))
         return (all(activation_id(a) == _lib.SPK_ACT_SILU for a in acts)
                 and hasattr(self.radial_basis, "kernel_params")
-                and not getattr(self.radial_basis, "trainable", False)
                 and hasattr(self.cutoff_fn, "cutoff_value")
                 and self.n_atom_basis <= 1024 and 1 <= n_rbf <= 256)
 

@@ -97,7 +97,7 @@ class SchNet(nn.Module):
             self._fused = self._fusable()
 
     def _fusable(self) -> bool:
-        """The one-operator eval path covers ssp filters / output nets, the mirrored radial bases (not trainable) and
+        """The one-operator eval path covers ssp filters / output nets, the mirrored radial bases (trainable or not: in eval mode their parameters are plain operands) and
         cosine cutoff, within the kernels' shape limits (spk_cfconv.hip: n_filters % 4, n_rbf <= 256)."""
         if len(self.interactions) == 0:
             return True
@@ -106,7 +106,6 @@ class SchNet(nn.Module):
         n_rbf = int(getattr(self.radial_basis, "n_rbf", 0))
         return (all(activation_id(a) == _lib.SPK_ACT_SSP for a in acts)
                 and hasattr(self.radial_basis, "kernel_params")
-                and not getattr(self.radial_basis, "trainable", False)
                 and hasattr(self.cutoff_fn, "cutoff_value")
                 and self.n_filters % 4 == 0 and self.n_filters <= 1024 and 1 <= n_rbf <= 256)
 

@@ -60,7 +60,9 @@ MODEL_CASES = ["schnet_ethanol.npz", "schnet_aspirin8.npz", "painn_ethanol.npz",
                "schnet_skin_aspirin2.npz", "painn_skin_aspirin2.npz",
                "painn_aspirin_pretrained.npz", "schnet_water192.npz", "painn_water192.npz",
                # the reference's default depth (6 interactions): twice the error accumulation of the bench configuration
-               "schnet6_aspirin4.npz", "schnet6_water192.npz", "painn6_aspirin4.npz", "painn6_water192.npz"]
+               "schnet6_aspirin4.npz", "schnet6_water192.npz", "painn6_aspirin4.npz", "painn6_water192.npz",
+               # six interactions x BesselRBF: hardware sin / cos in the molecule kernels x depth, the least-margin combination (round-3 review)
+               "schnet6_bessel_aspirin4.npz", "schnet6_bessel_water192.npz", "painn6_bessel_aspirin4.npz", "painn6_bessel_water192.npz"]
 
 
 def rel_err(a, b):

@@ -238,3 +238,145 @@ def test_bead_parallel_pile_thermostat_world2_equals_single_process_oracle():
     p2 = MDO.pile_apply(p1, M.double(), C, c1, c2, kT, MDO.pile_noise(4, 6, 99, 5, 1))
     got = torch.cat([res[0], res[1]])
     assert torch.allclose(got.double(), p2, rtol=1e-5, atol=1e-5 * float(p2.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ GraphedTrainStep: the two-graph split
+class _FakeGraph:
+    """Stands in for torch.cuda.CUDAGraph on the build box: 'capture' records which of the step's pieces were issued inside it
+    (nothing executes, as under a real capture); replay runs them (the control flow is the product's, the graphs are not)."""
+    log = None           # the run log of the process
+    current = None
+
+    def __init__(self):
+        self.pieces = []
+
+    def pool(self):
+        return None
+
+    def replay(self):
+        for name, fn in self.pieces:
+            _FakeGraph.log.append(name)
+            fn()
+
+
+class _fake_graph_ctx:
+    def __init__(self, g, pool=None):
+        self.g = g
+
+    def __enter__(self):
+        _FakeGraph.current = self.g
+
+    def __exit__(self, *exc):
+        _FakeGraph.current = None
+        return False
+
+
+class _NullLists:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _graphed_step_worker(rank, world, port, q):
+    """GraphedTrainStep.step() with world size `world`: capture decision (one graph / backward + optimizer graphs), the order
+    backward-graph -> flat-bucket all-reduce -> optimizer-graph, and the averaged update.  The model's forward / backward and the
+    optimizer are stand-ins (a quadratic loss with rank-dependent data, plain SGD): what is under test is train.py's control flow."""
+    import torch.distributed as dist
+    from schnetpack_amd import train as T
+    from schnetpack_amd.parallel import FlatGradAllReduce
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.zeros(4))
+    target = torch.arange(4.0) * (rank + 1)          # rank-dependent data: the averaged gradient differs from either local one
+    st = object.__new__(T.GraphedTrainStep)
+    st.dev, st.group, st.use_graph, st.warmup_steps, st.n_steps = torch.device("cpu"), None, True, 0, 0
+    st.g_bwd = st.g_opt = None
+    st.lists = _NullLists()
+    st.loss = torch.zeros(())
+    st.reducer = FlatGradAllReduce([w], as_views=True)
+    _FakeGraph.log = log = []
+
+    def forward_backward():
+        def body():
+            st.reducer.release()
+            loss = 0.5 * ((w - target) ** 2).sum()
+            loss.backward()
+            st.reducer.pack()
+            st.loss.copy_(loss.detach())
+        if _FakeGraph.current is not None:           # under capture nothing executes: the work is recorded
+            _FakeGraph.current.pieces.append(("fb", body))
+        else:
+            body()
+
+    class Opt:
+        def step(self_inner):
+            def body():
+                with torch.no_grad():
+                    w.sub_(0.5 * w.grad)
+            if _FakeGraph.current is not None:
+                _FakeGraph.current.pieces.append(("opt", body))
+            else:
+                body()
+    st._forward_backward = forward_backward
+    st.opt = Opt()
+    real_reducer = st.reducer
+
+    class LoggedReducer:
+        def __call__(self_inner, group=None):
+            log.append("reduce")
+            return real_reducer(group)
+
+        def __getattr__(self_inner, name):
+            return getattr(real_reducer, name)
+    st.reducer = LoggedReducer()
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.CUDAGraph = _FakeGraph
+    torch.cuda.graph = _fake_graph_ctx
+    torch.ops.spk_hip.weights_changed = lambda: None if False else None
+    T.torch.ops.spk_hip.weights_changed()          # (exists on the host: no tensors involved)
+    st.step()                                      # capture + first replay
+    captured = ([n for n, _ in st.g_bwd.pieces], None if st.g_opt is None else [n for n, _ in st.g_opt.pieces])
+    del log[:]
+    st.step()
+    q.put((rank, captured, list(log), w.detach().tolist()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_graphed_train_step_two_graph_split(world):
+    """Round-3 review: `GraphedTrainStep._capture` decides at capture time whether the optimizer goes into the backward graph (one
+    rank) or into a second graph behind the gradient all-reduce (several ranks) -- exercised here with world size 1 and 2 on gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graphed_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, captured, log, wv = q.get(timeout=180)
+        res[rank] = (captured, log, wv)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        captured, log, wv = res[rank]
+        if world == 1:
+            assert captured == (["fb", "opt"], None) and log == ["fb", "opt"]
+        else:
+            assert captured == (["fb"], ["opt"]) and log == ["fb", "reduce", "opt"]
+    # the trajectory: SGD with lr 0.5 on 0.5 |w - t|^2, two applications of the update (two replays), with the rank-AVERAGED
+    # target when there are two ranks: w <- w + 0.5 (t_mean - w)
+    t_mean = torch.arange(4.0) * (1.5 if world == 2 else 1.0)
+    want = torch.zeros(4)
+    for _ in range(2):
+        want = want + 0.5 * (t_mean - want)
+    for rank in range(world):
+        assert torch.allclose(torch.tensor(res[rank][2]), want, atol=1e-6), (rank, res[rank][2], want.tolist())

@@ -123,6 +123,63 @@ def test_training_mode_double_backward_matches_oracle(dev, kind, F, n_rbf, radia
 
 
 @pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_trainable_gaussian_basis_trains_on_the_hip_operators(dev, kind):
+    """GaussianRBF(trainable=True) (nn/radial.py:36-48): a force-matching step in training mode runs the closed operators
+    spk_hip::radial_d / radial_c (no ATen formula of the basis on the path -- the profile shows the kernels) and yields the gradients
+    w.r.t. offsets and widths next to those of every weight, fp32 on the device against the float64 oracle; the same model in eval
+    mode keeps the fused two-launch potential."""
+    from schnetpack_amd import _lib, model as M
+    F, n_rbf = 128, 20
+    b = S.molecule_batch("aspirin", 3, seed=12)
+    rep_p = O.init_schnet_params(F, 3, n_rbf, 5.0) if kind == "schnet" else O.init_painn_params(F, 3, n_rbf, 5.0)
+    head_p = O.init_atomwise_params(F, seed=1)
+    g = torch.Generator().manual_seed(0)
+    Et = torch.randn(3, generator=g)
+    Ft = torch.randn(b["Z"].shape[0], 3, generator=g)
+    trained = ("weight", "bias", "radial_basis.offsets", "radial_basis.widths")
+    rp = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and k.endswith(trained) else
+              (v.double() if v.is_floating_point() else v)) for k, v in rep_p.items()}
+    hp = {k: v.clone().double().requires_grad_(True) for k, v in head_p.items()}
+    R = b["R"].clone().double().requires_grad_(True)
+    r_ij = O.pairwise_vectors(R, b["idx_i"], b["idx_j"], b["offsets"].double())
+    if kind == "schnet":
+        x = O.schnet_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, 3)
+    else:
+        x, _ = O.painn_representation(b["Z"], r_ij, b["idx_i"], b["idx_j"], rp, 3)
+    E = O.atomwise_energy(x, b["idx_m"], 3, hp)
+    (dEdR,) = torch.autograd.grad([E.sum()], [R], create_graph=True)
+    loss_o = 0.01 * ((E - Et.double()) ** 2).mean() + 0.99 * ((-dEdR - Ft.double()) ** 2).mean()
+    names = [k for k, v in rp.items() if torch.is_tensor(v) and v.requires_grad]
+    go = dict(zip(names, torch.autograd.grad(loss_o, [rp[k] for k in names], allow_unused=True)))
+
+    model = M.build_model(kind, F, 3, n_rbf, 5.0, "gaussian", trainable_rbf=True)
+    assert not model.fm_engine and model.representation._fused
+    M.load_reference_params(model, rep_p, head_p)
+    model = model.to(dev).train()
+    assert isinstance(model.representation.radial_basis.offsets, torch.nn.Parameter)
+    _lib.profile_enable(True); _lib.profile_report()
+    out = model(M.batch_to_inputs(b, dev))
+    loss = 0.01 * ((out["energy"] - Et.to(dev)) ** 2).mean() + 0.99 * ((out["forces"] - Ft.to(dev)) ** 2).mean()
+    loss.backward()
+    tags = set(_lib.profile_report()); _lib.profile_enable(False)
+    assert {"radial_d", "radial_c"} <= tags, tags
+    assert abs(float(loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach())) < 1e-5
+    got = dict(model.representation.named_parameters())
+    for k in ("radial_basis.offsets", "radial_basis.widths"):
+        assert got[k].grad is not None and rel_err(got[k].grad.cpu(), go[k]) < 1e-4, (k, rel_err(got[k].grad.cpu(), go[k]))
+    worst = max(rel_err(got[k].grad.cpu(), go[k]) for k in names if go[k] is not None)
+    assert worst < 1e-4, worst
+    # eval mode: the parameters are plain operands of the fused potential
+    model.eval()
+    _lib.profile_enable(True); _lib.profile_report()
+    oe = model(M.batch_to_inputs(b, dev))
+    tags = set(_lib.profile_report()); _lib.profile_enable(False)
+    assert tags == {kind + "_mol_fwd", kind + "_mol_bwd"}, tags
+    ref = O.energy_and_forces(kind, rep_p, head_p, b, 3, dtype=torch.float64)
+    assert rel_err(oe["forces"].detach().cpu(), ref["forces"]) < TOL
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
 def test_bench_scale_properties(dev, kind):
     """cfg 2/3 sizes (256 aspirin frames, N=5376, E~77.9k): (i) equals the CPU oracle on a
     16-frame subset; (ii) total force on every molecule vanishes (translation invariance);

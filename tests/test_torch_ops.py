@@ -120,11 +120,13 @@ def test_representations_script_like_the_reference(rep_cls, radial, kw):
     assert again(dict(inp))["scalar_representation"].shape == (12, 128)
 
 
-def test_trainable_rbf_takes_the_differentiable_path_and_still_scripts():
+def test_trainable_rbf_keeps_the_fused_eval_path_and_still_scripts():
+    """GaussianRBF(trainable=True) (nn/radial.py:40-45): in eval mode offsets / widths are plain operands of the fused operator; in
+    training mode the closed operators spk_hip::radial_d / radial_c carry their gradients (tests/test_train_autograd.py)."""
     rep = SchNet(64, 2, GaussianRBF(16, 5.0, trainable=True), CosineCutoff(5.0)).to("meta").eval()
-    assert rep._fused is False
+    assert rep._fused is True and isinstance(rep.radial_basis.offsets, torch.nn.Parameter)
     srep = torch.jit.script(rep)
-    assert "spk_hip::schnet(" not in str(srep.graph)
+    assert "spk_hip::schnet(" in str(srep.graph) and "spk_hip::radial_d" in str(srep.radial_basis.graph)
     inp = _meta_inputs()
     inp["_Rij"] = torch.zeros(40, 3, device="meta")
     assert srep(inp)["scalar_representation"].shape == (12, 64)

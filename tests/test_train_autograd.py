@@ -44,6 +44,15 @@ def _cases():
         "radial_d gaussian": (lambda d, a: ops.radial_d(d, a, 0, p0, p1, 5.0, 0), (d, T(E))),
         "radial_d gaussian' without a": (lambda d: ops.radial_d(d, None, 0, p0, p1, 5.0, 1), (d,)),
         "radial_d bessel": (lambda d, a: ops.radial_d(d, a, 1, fr, None, 5.0, 0), (d, T(E))),
+        # GaussianRBF(trainable=True), nn/radial.py:40-45: offsets and widths are operands with gradients, to second order
+        "radial_d gaussian, trainable offsets / widths": (lambda d, a, mu, w: ops.radial_d(d, a, 0, mu, w, 5.0, 0),
+                                                          (d, T(E), p0.clone().requires_grad_(), p1.clone().requires_grad_())),
+        "radial_d gaussian', trainable, [E, 1] distances": (lambda d1, mu, w: ops.radial_d(d1, None, 0, mu, w, 5.0, 1),
+                                                            (d.detach().unsqueeze(1).requires_grad_(), p0.clone().requires_grad_(), p1.clone().requires_grad_())),
+        "radial_c gaussian, trainable": (lambda G, d, a, mu, w: ops.radial_c(G, d, a, 0, mu, w, 5.0, 0),
+                                         (T(E, R), d, T(E), p0.clone().requires_grad_(), p1.clone().requires_grad_())),
+        "radial_c gaussian', trainable": (lambda G, d, mu, w: ops.radial_c(G, d, None, 0, mu, w, 5.0, 1),
+                                          (T(E, R), d, p0.clone().requires_grad_(), p1.clone().requires_grad_())),
         "radial_d cutoff": (lambda d, a: ops.radial_d(d, a, 2, p0, None, 5.0, 0), (d, T(E))),
         "radial_d cutoff without a": (lambda d: ops.radial_d(d, None, 2, p0, None, 5.0, 0), (d,)),
         "radial_c gaussian": (lambda G, d, a: ops.radial_c(G, d, a, 0, p0, p1, 5.0, 0), (T(E, R), d, T(E))),
@@ -88,23 +97,34 @@ def test_refusal_is_back_after_the_context():
         ops.rowdot(torch.ones(2, 2), torch.ones(2, 2))
 
 
-def test_radial_parameters_that_require_grad_are_refused():
+def test_only_the_gaussian_basis_has_trainable_parameters():
+    """Bessel frequencies are buffers in the reference (nn/radial.py:99-103): a frequency tensor that requires grad is refused."""
+    fr = (torch.arange(1, 7, dtype=D) * 0.6).requires_grad_()
+    with crk.reference_kernels(), pytest.raises(RuntimeError, match="only the Gaussian basis"):
+        ops.radial_d(torch.rand(4, dtype=D), None, 1, fr, None, 5.0, 0)
     p0 = torch.linspace(0.5, 4.0, 6, dtype=D, requires_grad=True)
-    with crk.reference_kernels(), pytest.raises(RuntimeError, match="constants of this operator"):
-        ops.radial_d(torch.rand(4, dtype=D), None, 0, p0, torch.ones(6, dtype=D), 5.0, 0)
+    with crk.reference_kernels():
+        out = ops.radial_d(torch.rand(4, dtype=D), None, 0, p0, torch.ones(6, dtype=D), 5.0, 0)
+        out.sum().backward()
+    assert p0.grad is not None and torch.isfinite(p0.grad).all()
 
 
-@pytest.mark.parametrize("kind,radial", [("schnet", "gaussian"), ("schnet", "bessel"), ("painn", "gaussian"), ("painn", "bessel")])
+@pytest.mark.parametrize("kind,radial", [("schnet", "gaussian"), ("schnet", "bessel"), ("painn", "gaussian"), ("painn", "bessel"),
+                                         ("schnet", "gaussian_trainable"), ("painn", "gaussian_trainable")])
 def test_force_matching_step_matches_the_oracle(kind, radial):
-    """energy -> forces (create_graph) -> loss -> weight gradients, whole model in training mode, float64."""
+    """energy -> forces (create_graph) -> loss -> weight gradients, whole model in training mode, float64.  `gaussian_trainable`:
+    GaussianRBF(trainable=True) -- the gradients w.r.t. offsets and widths come from the same closed operators."""
     F, n_rbf = 32, 8
+    trainable = radial.endswith("_trainable")
+    radial = radial.split("_")[0]
     b = S.molecule_batch("aspirin", 3, seed=12)
     rep_p = O.init_schnet_params(F, 3, n_rbf, 5.0, radial=radial) if kind == "schnet" else O.init_painn_params(F, 3, n_rbf, 5.0, radial=radial)
     head_p = O.init_atomwise_params(F, seed=1)
     g = torch.Generator().manual_seed(0)
     Et = torch.randn(3, generator=g).double()
     Ft = torch.randn(b["Z"].shape[0], 3, generator=g).double()
-    rp = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and k.endswith(("weight", "bias")) else
+    trained = ("weight", "bias", "radial_basis.offsets", "radial_basis.widths") if trainable else ("weight", "bias")
+    rp = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and k.endswith(trained) else
               (v.double() if v.is_floating_point() else v)) for k, v in rep_p.items()}
     hp = {k: v.clone().double().requires_grad_(True) for k, v in head_p.items()}
     R = b["R"].clone().double().requires_grad_(True)
@@ -118,8 +138,11 @@ def test_force_matching_step_matches_the_oracle(kind, radial):
     loss_o = 0.01 * ((E - Et) ** 2).mean() + 0.99 * ((-dEdR - Ft) ** 2).mean()
     names = [k for k, v in rp.items() if torch.is_tensor(v) and v.requires_grad]
     go = dict(zip(names, torch.autograd.grad(loss_o, [rp[k] for k in names], allow_unused=True)))
+    if trainable:
+        assert go["radial_basis.offsets"] is not None and float(go["radial_basis.offsets"].abs().max()) > 0 and float(go["radial_basis.widths"].abs().max()) > 0
 
-    model = M.build_model(kind, F, 3, n_rbf, 5.0, radial)
+    model = M.build_model(kind, F, 3, n_rbf, 5.0, radial, trainable_rbf=trainable)
+    assert model.fm_engine == (not trainable) and model.representation._fused      # trainable bases: closed operators in training, fused kernels in eval
     M.load_reference_params(model, rep_p, head_p)
     model = model.double().train()
     inp = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in M.batch_to_inputs(b, torch.device("cpu")).items()}
@@ -146,7 +169,7 @@ def test_force_matching_step_matches_the_oracle(kind, radial):
             assert float((got[k].grad - go[k]).abs().max()) <= 1e-10 * float(go[k].abs().max()), k
     # the whole step is a few hundred operator calls of the HIP family (SchNet: Dense 5 x 3 + head, each forward / backward /
     # twice-backward = linear, matmul_nn, matmul_tn, act_mul; no torch matmul in between)
-    if kind == "schnet":
+    if kind == "schnet" and not trainable:
         assert sum(calls.values()) <= 190, dict(calls)
         # weight gradients ride with the input gradient of the same layer in one launch wherever a pass needs both
         assert calls["gemm_pair"] >= 25 and calls["matmul_tn"] + calls["gemm_pair"] >= 30 and calls["cfconv"] >= 12, dict(calls)
