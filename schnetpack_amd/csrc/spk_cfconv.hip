@@ -49,6 +49,7 @@ struct CfArgs {
   const int32_t* grp_tile0;  // [G+1] first (group-aligned) tile of the group
   int n_groups;
   int max_group_atoms;
+  int xcd_walk;        // persistent tile loops: XCD-contiguous walk (spk_xcd_tile; set by the launchers when gridDim.x % 8 == 0 on large lists)
   RadialDev rb;
 };
 
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_mfma(CfArgs a) {
     int nidx = 0;
     if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
     nidx = __builtin_amdgcn_readfirstlane(nidx);
-    const int64_t tile = (int64_t)blockIdx.x + (int64_t)nidx * gridDim.x;
+    const int64_t tile = a.xcd_walk ? spk_xcd_tile(nidx, ntiles) : (int64_t)blockIdx.x + (int64_t)nidx * gridDim.x;
     if (tile >= ntiles) break;
 
     const int64_t e = tile * 32 + el;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair(CfArgs a) {
       if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
       nidx = __builtin_amdgcn_readfirstlane(nidx);
       // MOL: the group's tiles; otherwise tiles blockIdx.x + n * gridDim.x of the whole list
-      const int ltile = MOL ? nidx : (int)blockIdx.x + nidx * (int)gridDim.x;
+      const int ltile = MOL ? nidx : (a.xcd_walk ? (int)spk_xcd_tile(nidx, gtiles) : (int)blockIdx.x + nidx * (int)gridDim.x);
       if (ltile >= gtiles) break;
       const int64_t gtile = (int64_t)gt0 + ltile;        // addresses the saved filters
 
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_t(CfArgs a) {
     int nidx = 0;
     if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
     nidx = __builtin_amdgcn_readfirstlane(nidx);
-    const int64_t tile = (int64_t)blockIdx.x + (int64_t)nidx * gridDim.x;
+    const int64_t tile = a.xcd_walk ? spk_xcd_tile(nidx, ntiles) : (int64_t)blockIdx.x + (int64_t)nidx * gridDim.x;
     if (tile >= ntiles) break;
 
     const int64_t hidx = tile * 32 + el;
@@ -936,7 +937,9 @@ static int launch_mfma(const CfArgs& a, hipStream_t stream) {
   if (grid > maxg) grid = maxg;
   if (grid < 1) grid = 1;
   SpkProfScope prof(BWD ? (SYM ? "cfconv_bwd_mfma_sym" : "cfconv_bwd_mfma_atomic") : "cfconv_fwd_mfma", stream);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+  CfArgs ax = a;
+  ax.xcd_walk = (spk_xcd_walk_default() && grid % 8 == 0 && ntiles >= 16 * (int64_t)grid) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, ax);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -961,7 +964,9 @@ static int launch_pair(const CfArgs& a, hipStream_t stream) {
   if (grid < 1) grid = 1;
   SpkProfScope prof(BWD ? (GS ? (MOL ? "cfconv_bwd_mol_gs" : "cfconv_bwd_pair_gs") : (MOL ? "cfconv_bwd_mol" : "cfconv_bwd_pair"))
                         : (MOL ? "cfconv_fwd_mol" : "cfconv_fwd_pair"), stream);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+  CfArgs ax = a;
+  ax.xcd_walk = (!MOL && spk_xcd_walk_default() && grid % 8 == 0 && (a.n_half + 31) / 32 >= 16 * (int64_t)grid) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, ax);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -983,7 +988,9 @@ static int launch_pair_t_bwd_gs(const CfArgs& a, hipStream_t stream) {
   if (grid > maxg) grid = maxg;
   if (grid < 1) grid = 1;
   SpkProfScope prof(a.skip_gh ? "cfconv_bwd_pair_gs_geom" : "cfconv_bwd_pair_gs", stream);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+  CfArgs ax = a;
+  ax.xcd_walk = (spk_xcd_walk_default() && grid % 8 == 0 && ntiles >= 16 * (int64_t)grid) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, ax);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

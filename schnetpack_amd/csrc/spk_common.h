@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "../../include/spk_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -182,6 +183,22 @@ __device__ __forceinline__ void spk_cutoff_eval_fast(float rc, float d, float& f
     f = 0.5f * (__builtin_amdgcn_cosf(rev) + 1.0f);
     df = -0.5f * SPK_PI_F * inv * __builtin_amdgcn_sinf(rev);
   } else { f = 0.f; df = 0.f; }
+}
+
+// XCD-contiguous walk of `ntiles` work items by persistent workgroups (needs gridDim.x % 8 == 0).  Workgroups are handed round-robin to
+// the 8 XCDs, each with its own 4 MiB L2: with tile = blockIdx.x + n gridDim.x every XCD sees every 8th tile of the window the chip is
+// working on, so the rows that neighbouring tiles gather are fetched into up to 8 L2s; here the workgroups of XCD x walk the eighth
+// [x per, (x + 1) per) of the tiles.  Returns ntiles when the workgroup has run out.  Measured on the 32k-atom water box
+// (profiles/r04_tile_experiments.txt): PaiNN tile forward 666 -> 630 us, row forward 859 -> 821 us.
+__device__ __forceinline__ int64_t spk_xcd_tile(int nidx, int64_t ntiles) {
+  const int64_t per = (ntiles + 7) / 8;
+  const int64_t tl = (int64_t)(blockIdx.x >> 3) + (int64_t)nidx * (gridDim.x >> 3);
+  const int64_t t = (int64_t)(blockIdx.x & 7) * per + tl;
+  return (tl < per && t < ntiles) ? t : ntiles;
+}
+static inline int spk_xcd_walk_default() {
+  static const int v = [] { const char* e = getenv("SPK_XCD_WALK"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
 }
 
 __device__ __forceinline__ float spk_wave_sum(float v) {

@@ -97,7 +97,15 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
     }
   }
 
-  for (int64_t atom = (int64_t)blockIdx.x * 4 + wv; atom < a.N; atom += (int64_t)gridDim.x * 4) {
+  // Workgroups go round-robin over the 8 XCDs: with xcd_map the workgroups of one XCD walk a CONTIGUOUS eighth of the atoms (their
+  // neighbours' rows are then shared inside that XCD's L2) instead of every 8th group of four (spk_painn_tile.hip measured +8 % for
+  // the tile forward on the water box with the same walk)
+  const int64_t per_xcd = a.xcd_map ? (a.N + 7) / 8 : a.N;
+  const int64_t a_lo = a.xcd_map ? (int64_t)(blockIdx.x & 7) * per_xcd : 0;
+  const int64_t a_hi = a.xcd_map ? (a_lo + per_xcd < a.N ? a_lo + per_xcd : a.N) : a.N;
+  const int64_t a_first = a.xcd_map ? a_lo + (int64_t)(blockIdx.x >> 3) * 4 + wv : (int64_t)blockIdx.x * 4 + wv;
+  const int64_t a_step = a.xcd_map ? (int64_t)((gridDim.x + 7) >> 3) * 4 : (int64_t)gridDim.x * 4;
+  for (int64_t atom = a_first; atom < a_hi; atom += a_step) {
     const int32_t e0 = a.rowptr[atom], e1 = a.rowptr[atom + 1];
     const int64_t fo = (int64_t)VPL * lane;  // first channel of this lane
     VT accq = MV::zero(), accR = MV::zero();                                   // fwd: dq ; bwd: gc_q, gc_R
@@ -397,7 +405,8 @@ static int msg_dispatch(const MsgArgs& a_in, bool row_ok, hipStream_t stream, co
   }
   if (shape_ok && variant != SPK_VARIANT_SIMPLE) {
     // persistent waves: every wave walks several CSR rows, so the per-wave weight set-up is amortised
-    const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 2);
+    a.xcd_map = (spk_xcd_walk_default() && a.N >= (1 << 14)) ? 1 : 0;        // large lists only: a molecule batch fits every L2
+    const int grid = a.xcd_map ? (spk_grid_for(a.N, 4, spk_num_cus() * 2) + 7) / 8 * 8 : spk_grid_for(a.N, 4, spk_num_cus() * 2);
     const size_t lds = (size_t)K * (3 * F + 1) * sizeof(float);
     // the first-interaction specialisations are timed under their own tags (they move fewer bytes)
     SpkProfScope prof(BWD ? (a.geom_only ? "painn_msg_bwd_row_geom" : "painn_msg_bwd_row") : (a.mu_zero ? "painn_msg_fwd_row_mu0" : "painn_msg_fwd_row"), stream);

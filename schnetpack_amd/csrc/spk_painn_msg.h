@@ -25,6 +25,7 @@ struct MsgArgs {
   int skin_list;      // the list holds a sizeable share of pairs beyond the cutoff (spk_graph_t.filter_pairs): the row kernel drops them before
                       // their rows are fetched, the tile kernel would pay the filter GEMM for them
   int mu_zero;        // mu is known to be all zeros (first interaction, painn.py:246): its rows are not gathered
+  int xcd_map;        // row kernels: the workgroups of an XCD walk a contiguous eighth of the atoms (set by the launcher)
   int geom_only;      // bwd: only gr is wanted (first interaction of an eval-mode backward): gc / gmu are not formed
   RadialDev rb;
   // EXPERIMENT (spk_tabfilter.hip, opt-in): the raw filter phi(d) W_f^T + b_f of this interaction from a cubic-Hermite table

@@ -69,8 +69,11 @@ __device__ __forceinline__ float quad_sum(float v) {
 __device__ __forceinline__ int slot_of_row(int el) { return 16 * ((el >> 2) & 1) + (el & 3) + 4 * (el >> 3); }
 
 // MU0: mu == 0 (first interaction): the mu part of the filter and the mu rows are skipped
-template <int F, int KPB, bool MU0>
-__global__ __launch_bounds__(256, 2) void k_painn_msg_tile(MsgArgs a, int ntiles) {
+// MINW: waves per SIMD the register allocation is held to (2: up to 256 VGPRs; 4: up to 128 -- tuning experiment SPK_TILE_WAVES=4).
+// xcd_map != 0: workgroup w (XCD w % 8) walks a CONTIGUOUS eighth of the tiles instead of every gridDim-th tile, so the rows its
+// neighbours on the same XCD gather are the ones it gathers (default; SPK_XCD_WALK=0 switches it off)
+template <int F, int KPB, bool MU0, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void k_painn_msg_tile(MsgArgs a, int ntiles, int xcd_map) {
   constexpr int NT = F / 32;          // channel blocks per part
   constexpr int NB = 3 * NT;          // column blocks of the filter GEMM
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -89,11 +92,16 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_tile(MsgArgs a, int ntiles
   const int slot = slot_of_row(el);
   constexpr unsigned F3 = 3u * F;
 
+  const int per_xcd = (ntiles + 7) / 8, wg_per_xcd = ((int)gridDim.x + 7) / 8;
   while (true) {
     int nidx = 0;
     if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
     nidx = __builtin_amdgcn_readfirstlane(nidx);
-    const int tile = (int)blockIdx.x + nidx * (int)gridDim.x;
+    int tile = (int)blockIdx.x + nidx * (int)gridDim.x;
+    if (xcd_map) {
+      const int tl = ((int)blockIdx.x >> 3) + nidx * wg_per_xcd;
+      tile = tl < per_xcd ? ((int)blockIdx.x & 7) * per_xcd + tl : ntiles;
+    }
     if (tile >= ntiles) break;
 
     // ---- geometry of this lane's edge slot (lanes 32..63 mirror lanes 0..31)
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_tile(MsgArgs a, int ntiles
 // One workgroup per CU (launch bounds 256, 1): the wave may use the whole 512-entry register file (VGPR + AGPR), so the
 // gathers of a whole part are in flight behind the part's GEMMs.
 template <int F, int KPB, bool GEOM, bool MU0>
-__global__ __launch_bounds__(256, 1) void k_painn_msg_tile_bwd(MsgArgs a, int ntiles) {
+__global__ __launch_bounds__(256, 1) void k_painn_msg_tile_bwd(MsgArgs a, int ntiles, int xcd_map) {
   constexpr int NT = F / 32;
   constexpr int NB = 3 * NT;
   constexpr int RSTR = 9;             // [32 edges][8 quad partials + 1 pad] per quantity
@@ -226,7 +234,11 @@ __global__ __launch_bounds__(256, 1) void k_painn_msg_tile_bwd(MsgArgs a, int nt
     int nidx = 0;
     if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
     nidx = __builtin_amdgcn_readfirstlane(nidx);
-    const int tile = (int)blockIdx.x + nidx * (int)gridDim.x;
+    int tile = (int)blockIdx.x + nidx * (int)gridDim.x;
+    if (xcd_map) {      // the workgroups of one XCD walk a contiguous eighth of the tiles (see k_painn_msg_tile)
+      const int per_xcd = (ntiles + 7) / 8, tl = ((int)blockIdx.x >> 3) + nidx * (((int)gridDim.x + 7) / 8);
+      tile = tl < per_xcd ? ((int)blockIdx.x & 7) * per_xcd + tl : ntiles;
+    }
     if (tile >= ntiles) break;
 
     const int64_t e_first = (int64_t)tile * 32;
@@ -431,8 +443,24 @@ int launch_tile(const MsgArgs& a, hipStream_t stream) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile<F, KPB, MU0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  const int grid = spk_grid_for(nt, 4, spk_num_cus() * 2);
-  hipLaunchKernelGGL((k_painn_msg_tile<F, KPB, MU0>), dim3(grid), dim3(256), lds, stream, a, (int)nt);
+    // XCD-contiguous walk: 680 -> 625 us on the 32k-atom water box (profiles/r04_tile_experiments.txt)
+  const int xcd_map = spk_xcd_walk_default();     // SPK_XCD_WALK=0 switches it off
+  static const int wavesN = [] { const char* e = getenv("SPK_TILE_WAVES"); return (e && (e[0] == '3' || e[0] == '4')) ? e[0] - '0' : 0; }();
+  if (wavesN) {
+    static bool attrN = false;
+    if (!attrN) {
+      SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile<F, KPB, MU0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile<F, KPB, MU0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attrN = true;
+    }
+    const int gridN = (spk_grid_for(nt, 4, spk_num_cus() * wavesN) + 7) / 8 * 8;
+    if (wavesN == 3) hipLaunchKernelGGL((k_painn_msg_tile<F, KPB, MU0, 3>), dim3(gridN), dim3(256), lds, stream, a, (int)nt, xcd_map);
+    else hipLaunchKernelGGL((k_painn_msg_tile<F, KPB, MU0, 4>), dim3(gridN), dim3(256), lds, stream, a, (int)nt, xcd_map);
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
+  const int grid = xcd_map ? (spk_grid_for(nt, 4, spk_num_cus() * 2) + 7) / 8 * 8 : spk_grid_for(nt, 4, spk_num_cus() * 2);
+  hipLaunchKernelGGL((k_painn_msg_tile<F, KPB, MU0>), dim3(grid), dim3(256), lds, stream, a, (int)nt, xcd_map);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -446,8 +474,9 @@ int launch_tile_bwd(const MsgArgs& a, hipStream_t stream) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile_bwd<F, KPB, GEOM, MU0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  const int grid = spk_grid_for(nt, 4, spk_num_cus());
-  hipLaunchKernelGGL((k_painn_msg_tile_bwd<F, KPB, GEOM, MU0>), dim3(grid), dim3(256), lds, stream, a, (int)nt);
+  const int xcd_map = spk_xcd_walk_default();
+  const int grid = xcd_map ? (spk_grid_for(nt, 4, spk_num_cus()) + 7) / 8 * 8 : spk_grid_for(nt, 4, spk_num_cus());
+  hipLaunchKernelGGL((k_painn_msg_tile_bwd<F, KPB, GEOM, MU0>), dim3(grid), dim3(256), lds, stream, a, (int)nt, xcd_map);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

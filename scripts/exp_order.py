@@ -66,6 +66,8 @@ for name, perm in orders():            # perm[new] = old
         row[mname + "_fwd_us"] = round(timeit(fwd), 1); row[mname + "_bwd_us"] = round(timeit(bwd), 1)
     L.spk_painn_set_tile(0)
     # block kernels (spk_painn_blk.hip): per-tag HIP-event times of prep / forward / backward passes
+    if os.environ.get("EXP_NO_BLOCKS"):
+        res[name] = row; print(name, row, flush=True); continue
     okb, max_u, n_tiles = plan.build_blocks(K, F)
     row["blk_plan"] = {"ok": okb, "max_unique": max_u, "tiles": n_tiles, "sub_n_hist": torch.bincount(plan._block_bufs["sub_n"].cpu()).tolist()}
     if okb:
