@@ -504,6 +504,9 @@ int spk_painn_message_bwd_f32(const spk_graph_t* g, const spk_radial_t* rb, cons
  * 16 <= n_rbf <= 39 forward / <= 31 backward, sorted (+ symmetric) list), -1 = never.  All compute the same function; the
  * tests run each family against the oracle and the reference fixtures. */
 void spk_painn_set_tile(int32_t mode);
+/* row kernels of the PaiNN message with the radial values of a 64-edge chunk in a wave-private LDS table (F = 128, n_rbf <= 20):
+ * -1 = on large lists (default), 0 = never, 1 = whenever the shape has the instance */
+void spk_painn_set_row_table(int32_t mode);
 
 /* representation/painn.py:92-117 -- the elementwise parts of PaiNNMixing around its three
  * Dense layers.  mix [N,3,2F] = mu_channel_mix(mu) = (V | W).

@@ -175,6 +175,7 @@ _PROTOS = {
     "spk_painn_message_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),
     "spk_painn_message_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_f]),
     "spk_painn_set_tile": (None, [c_i32]),
+    "spk_painn_set_row_table": (None, [c_i32]),
     "spk_painn_set_block": (None, [c_i32]),
     "spk_blocks_group_atoms": (ctypes.c_int, []),
     "spk_painn_blk_set_debug_buffer": (None, [c_f, c_i32]),

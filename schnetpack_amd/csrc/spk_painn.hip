@@ -61,7 +61,12 @@ template <> struct MsgVec<2> {
 // TAB (experiment, opt-in): the raw filter and its slope come from a cubic-Hermite table (one 16-byte read per part and channel: knot
 // value, slope, difference to the next knot, next slope;
 // knot for the lane's two channels) instead of NRBF FMAs per channel from register-resident weights (which are then not loaded)
-template <int VPL, int NRBF, bool BWD, bool GEOM = false, bool MU0 = false, bool TAB = false>
+// LT (round 4; F = 128, n_rbf <= 20): the radial values phi_k(d), phi_k'(d) of the 64 edges of a chunk are evaluated with lanes = EDGES
+// (n_rbf full-precision evaluations per lane and chunk instead of one per lane and EDGE) into a wave-private LDS table and read back
+// per edge as 5 + 5 broadcast ds_read_b128 -- instead of one evaluation by lane k and 2 n_rbf v_readlane broadcasts per edge.  The
+// SQ counters said this kernel is VALU-issue bound (330 instructions per edge and wavefront in the backward, 66 % busy): the
+// broadcasts and the per-edge evaluation were 70 of them, and LDS reads issue beside the VALU.
+template <int VPL, int NRBF, bool BWD, bool GEOM = false, bool MU0 = false, bool TAB = false, bool LT = false>
 __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
   typedef MsgVec<VPL> MV;
   typedef typename MV::T VT;
@@ -96,6 +101,8 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       w[p][k] = MV::load(tw);
     }
   }
+  float* tabw = swf + wv * (64 * 2 * NRBF);      // LT: this wave's [64 edges][phi_0.. | phi'_0..] table (aliases the weight image, which is dead now)
+  if (LT) __syncthreads();
 
   // Workgroups go round-robin over the 8 XCDs: with xcd_map the workgroups of one XCD walk a CONTIGUOUS eighth of the atoms (their
   // neighbours' rows are then shared inside that XCD's L2) instead of every 8th group of four (spk_painn_tile.hip measured +8 % for
@@ -130,6 +137,22 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
       float fcl, dfcl;
       spk_cutoff_eval(a.rb.cutoff, dl, fcl, dfcl);
       float grx = 0.f, gry = 0.f, grz = 0.f;  // bwd: geometry gradient of this lane's edge
+      if (LT) {
+        spk_wave_lds_sync();      // the previous chunk's reads are done
+#pragma unroll
+        for (int k4 = 0; k4 < NRBF / 4; ++k4) {
+          f32x4 pv, dv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float p_, dp_;
+            spk_rbf_eval(a.rb, 4 * k4 + q, dl, p_, dp_);        // 0 for k >= n_rbf
+            pv[q] = p_; dv[q] = dp_;
+          }
+          *(f32x4*)(tabw + lane * (2 * NRBF) + 4 * k4) = pv;
+          if (BWD) *(f32x4*)(tabw + lane * (2 * NRBF) + NRBF + 4 * k4) = dv;
+        }
+        spk_wave_lds_sync();
+      }
       // neighbour rows are requested one edge ahead (explicit double buffer): the row kernel is
       // bound by the latency of these dependent gathers, not by their bandwidth
       constexpr bool PF = true;
@@ -189,6 +212,22 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
                 }
                 P[p] = MV::load(pv);
                 if (BWD) Pd[p] = MV::load(pdv);
+              }
+            } else if (LT) {
+              const float* te = tabw + t * (2 * NRBF);          // wave-uniform address: broadcast reads
+              P[0] = bias[0]; P[1] = bias[1]; P[2] = bias[2];
+#pragma unroll
+              for (int k4 = 0; k4 < NRBF / 4; ++k4) {
+                const f32x4 s4 = *(const f32x4*)(te + 4 * k4);
+                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                if (BWD) d4 = *(const f32x4*)(te + NRBF + 4 * k4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                  for (int p = 0; p < 3; ++p) {
+                    P[p] = w[p][4 * k4 + q] * s4[q] + P[p];
+                    if (BWD) Pd[p] = w[p][4 * k4 + q] * d4[q] + Pd[p];
+                  }
               }
             } else {
             // lane k evaluates phi_k(d)
@@ -369,6 +408,9 @@ static int check_msg(const spk_graph_t* g, const spk_radial_t* rb, int F, const 
 // EXPERIMENT (spk_tabfilter.hip): filter tables attached to an interaction by the address of its filter rows
 bool spk_filter_table_lookup(const float* key, const float** table, int* n_knots, float* d_max);
 
+static int g_row_table = -1;     // -1: rule (large lists), 0 / 1: never / whenever the shape has the instance
+extern "C" void spk_painn_set_row_table(int32_t mode) { g_row_table = mode; }
+
 template <bool BWD>
 static int msg_dispatch(const MsgArgs& a_in, bool row_ok, hipStream_t stream, const char* who) {
   const int variant = spk_get_variant();
@@ -407,7 +449,14 @@ static int msg_dispatch(const MsgArgs& a_in, bool row_ok, hipStream_t stream, co
     // persistent waves: every wave walks several CSR rows, so the per-wave weight set-up is amortised
     a.xcd_map = (spk_xcd_walk_default() && a.N >= (1 << 14)) ? 1 : 0;        // large lists only: a molecule batch fits every L2
     const int grid = a.xcd_map ? (spk_grid_for(a.N, 4, spk_num_cus() * 2) + 7) / 8 * 8 : spk_grid_for(a.N, 4, spk_num_cus() * 2);
-    const size_t lds = (size_t)K * (3 * F + 1) * sizeof(float);
+    size_t lds = (size_t)K * (3 * F + 1) * sizeof(float);
+    // LDS radial table (LT) where it pays: F = 128, n_rbf <= 20, large lists (the instruction-bound regime); SPK_ROW_LT=0 / 1 forces
+    static const int lt_env = [] { const char* e = getenv("SPK_ROW_LT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const int lt_mode = g_row_table >= 0 ? g_row_table : lt_env;
+    // measured on the 32k-atom water box (profiles/r04_tile_experiments.txt): forward 824 -> 643 us, backward 1 423 -> 1 597 us (at
+    // 255 VGPRs the backward's schedule loses more than the table saves) => the rule switches it on for the forward only
+    const bool lt = F == 128 && K <= 20 && (lt_mode >= 0 ? lt_mode == 1 : (!BWD && a.N >= (1 << 14)));
+    if (lt && lds < 4 * 64 * 2 * 20 * sizeof(float)) lds = 4 * 64 * 2 * 20 * sizeof(float);
     // the first-interaction specialisations are timed under their own tags (they move fewer bytes)
     SpkProfScope prof(BWD ? (a.geom_only ? "painn_msg_bwd_row_geom" : "painn_msg_bwd_row") : (a.mu_zero ? "painn_msg_fwd_row_mu0" : "painn_msg_fwd_row"), stream);
 #define SPK_MSG_CASE(VPLv, NRBFv)                                                                                             \
@@ -417,7 +466,13 @@ static int msg_dispatch(const MsgArgs& a_in, bool row_ok, hipStream_t stream, co
     else if (!BWD && a.mu_zero) hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, false, !BWD>), dim3(grid), dim3(256), lds, stream, a);      \
     else hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, BWD, false, false>), dim3(grid), dim3(256), lds, stream, a);                           \
   } while (0)
-    if (F == 64) { if (K <= 20) SPK_MSG_CASE(1, 20); else SPK_MSG_CASE(1, 32); }
+    if (lt) {
+      if (BWD && a.geom_only && a.mu_zero) hipLaunchKernelGGL((k_painn_msg_row<2, 20, BWD, BWD, true, false, true>), dim3(grid), dim3(256), lds, stream, a);
+      else if (BWD && a.geom_only) hipLaunchKernelGGL((k_painn_msg_row<2, 20, BWD, BWD, false, false, true>), dim3(grid), dim3(256), lds, stream, a);
+      else if (!BWD && a.mu_zero) hipLaunchKernelGGL((k_painn_msg_row<2, 20, BWD, false, !BWD, false, true>), dim3(grid), dim3(256), lds, stream, a);
+      else hipLaunchKernelGGL((k_painn_msg_row<2, 20, BWD, false, false, false, true>), dim3(grid), dim3(256), lds, stream, a);
+    }
+    else if (F == 64) { if (K <= 20) SPK_MSG_CASE(1, 20); else SPK_MSG_CASE(1, 32); }
     else { if (K <= 20) SPK_MSG_CASE(2, 20); else SPK_MSG_CASE(2, 32); }
 #undef SPK_MSG_CASE
     SPK_LAUNCH_CHECK();

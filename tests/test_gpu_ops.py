@@ -438,8 +438,9 @@ def test_painn_message_forward_backward(dev, variant, graph, F, n_rbf):
     # forward through both kernel families: row kernel (-1) and the MFMA tile kernel (1: whenever the shape has one;
     # shapes / lists without one fall through to the row or simple kernel)
     try:
-        for mode in (-1, 1):
-            L.spk_painn_set_tile(mode)
+        for mode in (-1, -2, 1):       # row kernel, row kernel with the LDS radial table (where the shape has it), MFMA tile kernel
+            L.spk_painn_set_tile(-1 if mode == -2 else mode)
+            L.spk_painn_set_row_table(1 if mode == -2 else 0)
             q_out.fill_(float("nan")); mu_out.fill_(float("nan"))
             _lib.check(L.spk_painn_message_fwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(qd), _lib.fptr(mud), _lib.fptr(rd),
                                                    _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(q_out), _lib.fptr(mu_out), _lib.stream()))
@@ -447,11 +448,13 @@ def test_painn_message_forward_backward(dev, variant, graph, F, n_rbf):
             assert rel_err(mu_out.cpu(), muo) < TOL, mode
     finally:
         L.spk_painn_set_tile(0)
+        L.spk_painn_set_row_table(-1)
     gc = torch.empty(N, 3 * F, device=dev)
     gmu_in = torch.empty(N, 3, F, device=dev)
     try:
-        for mode in (-1, 1):     # row kernel, MFMA tile kernel (where the shape / list has one)
-            L.spk_painn_set_tile(mode)
+        for mode in (-1, -2, 1):     # row kernel, row kernel + LDS radial table, MFMA tile kernel (where the shape / list has one)
+            L.spk_painn_set_tile(-1 if mode == -2 else mode)
+            L.spk_painn_set_row_table(1 if mode == -2 else 0)
             gc.fill_(float("nan")); gmu_in.fill_(float("nan"))
             gr = torch.zeros(r.shape[0], 3, device=dev)
             _lib.check(L.spk_painn_message_bwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(mud), _lib.fptr(gqd), _lib.fptr(gmud),
@@ -462,6 +465,7 @@ def test_painn_message_forward_backward(dev, variant, graph, F, n_rbf):
             assert rel_err(gr.cpu(), gro) < TOL, mode
     finally:
         L.spk_painn_set_tile(0)
+        L.spk_painn_set_row_table(-1)
 
 
 def test_painn_mixing_elementwise(dev):
