@@ -85,6 +85,18 @@ typedef struct {
   float* part;               /* [F / 16][n_edges][4] */
 } spk_blocks_t;
 
+/* The list sorted by NEIGHBOUR (spk_transposed_build): for lists that are sorted by idx_i but not symmetric (half lists, one-sided
+ * lists of external back-ends; transform/neighborlist.py:446-456 and interfaces/lammps/pair_schnetpack.cpp:240-267 need not deliver
+ * both directions) the "scatter over idx_j" of every backward runs as a ROW pass over this transposed list -- the forward kernel
+ * with (idx_i, idx_j) exchanged -- instead of float atomics. */
+typedef struct {
+  const int64_t* idx_i;   /* [E] = idx_j[perm], ascending */
+  const int64_t* idx_j;   /* [E] = idx_i[perm] */
+  const int32_t* rowptr;  /* [N + 2] CSR of the above (row N collects out-of-range neighbours: empty on a valid list) */
+  const int32_t* perm;    /* [E] pair k of the transposed list is pair perm[k] of the list (stable sort by idx_j) */
+  float* r_perm;          /* [E, 3] workspace: r_ij[perm], refilled per call */
+} spk_transposed_t;
+
 /* Neighbour-list description: what `_idx_i`, `_idx_j` look like plus the CSR row pointers and
  * flags that spk_edge_plan() derives once per neighbour list. */
 typedef struct {
@@ -124,6 +136,7 @@ typedef struct {
   int32_t max_group_pairs; /* largest number of undirected pairs inside one group (0: unknown) */
   int32_t reserved1;
   const spk_blocks_t* blocks; /* optional block plan (large lists; spk_blocks_build), NULL: none */
+  const spk_transposed_t* transposed; /* optional: the list sorted by neighbour (asymmetric lists; spk_transposed_build), NULL: none */
 } spk_graph_t;
 
 /* ------------------------------------------------------------------ library / device info */
@@ -741,6 +754,10 @@ int spk_painn_fm_backward_f32(const spk_painn_t* m, const spk_head_t* head, cons
 /* By-neighbour CSR of a pair list on the device (the transpose permutation of SURVEY.md section 7 step 4): perm [E] = the pairs
  * ordered by idx_j (stable: ascending pair index inside a column), colptr [N + 2] (column N collects out-of-range neighbours).
  * tmp: spk_transpose_plan_bytes(E, N) bytes.  No host synchronisation. */
+/* spk_transposed_build: the arrays of spk_transposed_t from the plan above (t_idx_i, t_idx_j [E] int64; rowptr [N + 2]; perm [E]);
+ * tmp as for spk_transpose_plan.  No host synchronisation. */
+int spk_transposed_build(const int64_t* idx_i, const int64_t* idx_j, int64_t n_edges, int64_t n_atoms, int64_t* t_idx_i, int64_t* t_idx_j,
+                         int32_t* rowptr, int32_t* perm, void* tmp, void* stream);
 int64_t spk_transpose_plan_bytes(int64_t n_edges, int64_t n_atoms);
 int spk_transpose_plan(const int64_t* idx_j, int64_t n_edges, int64_t n_atoms, int32_t* colptr, int32_t* perm, void* tmp, void* stream);
 

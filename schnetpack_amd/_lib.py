@@ -37,7 +37,12 @@ class GraphT(ctypes.Structure):
                 ("n_half", c_i64), ("grp_atom0", c_f), ("grp_pair0", c_f), ("grp_tile0", c_f),
                 ("n_groups", c_i32), ("max_group_atoms", c_i32), ("n_tiles_grouped", c_i64),
                 ("filter_pairs", c_i32), ("reserved0", c_i32), ("n_half_dev", c_f), ("edge_pair", c_f),
-                ("max_group_pairs", c_i32), ("reserved1", c_i32), ("blocks", c_f)]
+                ("max_group_pairs", c_i32), ("reserved1", c_i32), ("blocks", c_f), ("transposed", c_f)]
+
+
+class TransposedT(ctypes.Structure):
+    """``spk_transposed_t``: the list sorted by neighbour (asymmetric lists: transposed sums as row passes instead of atomics)."""
+    _fields_ = [("idx_i", c_f), ("idx_j", c_f), ("rowptr", c_f), ("perm", c_f), ("r_perm", c_f)]
 
 
 class BlocksT(ctypes.Structure):
@@ -177,6 +182,8 @@ _PROTOS = {
     "spk_painn_set_tile": (None, [c_i32]),
     "spk_painn_set_row_table": (None, [c_i32]),
     "spk_painn_set_block": (None, [c_i32]),
+    "spk_transpose_plan_bytes": (c_i64, [c_i64, c_i64]),
+    "spk_transposed_build": (ctypes.c_int, [c_f, c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_f]),
     "spk_blocks_group_atoms": (ctypes.c_int, []),
     "spk_painn_blk_set_debug_buffer": (None, [c_f, c_i32]),
     "spk_blocks_sizes": (ctypes.c_int, [c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_i64)]),

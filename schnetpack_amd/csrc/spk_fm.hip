@@ -66,6 +66,24 @@ extern "C" int spk_transpose_plan(const int64_t* idx_j, int64_t E, int64_t N, in
   return SPK_OK;
 }
 
+__global__ void k_tp_fill(const int64_t* __restrict__ idx_i, const int64_t* __restrict__ idx_j, const int* __restrict__ perm, int64_t E,
+                          int64_t* __restrict__ ti, int64_t* __restrict__ tj) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < E; k += (int64_t)gridDim.x * blockDim.x) {
+    const int e = perm[k];
+    ti[k] = idx_j[e];
+    tj[k] = idx_i[e];
+  }
+}
+extern "C" int spk_transposed_build(const int64_t* idx_i, const int64_t* idx_j, int64_t E, int64_t N, int64_t* t_idx_i, int64_t* t_idx_j, int32_t* rowptr,
+                                    int32_t* perm, void* tmp, void* stream_) {
+  SPK_CHECK_ARG(E == 0 || (idx_i && t_idx_i && t_idx_j), "spk_transposed_build: null argument");
+  int rc = spk_transpose_plan(idx_j, E, N, rowptr, perm, tmp, stream_);
+  if (rc || E == 0) return rc;
+  hipLaunchKernelGGL(k_tp_fill, dim3(spk_grid_for(E, 256, 4096)), dim3(256), 0, (hipStream_t)stream_, idx_i, idx_j, perm, E, t_idx_i, t_idx_j);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ batched weight-gradient GEMMs
 // Every weight gradient of a pass is G = U^T X over [value ; tangent]-stacked rows (spk_gemm_tn.h).  The ~20 problems of a step are
 // independent of each other and of the rest of pass D, and each is tiny (a few hundred rows): as separate launches they cost ~19 us

@@ -106,6 +106,10 @@ struct Plan {
   Tensor b_sub_n, b_sub_u, b_uniq, b_jl, b_tile0, b_tinfo, b_desc, b_apack, b_adpack, b_rec, b_part;
   spk_blocks_t blocks;
   int blocks_state = 0;      // 0: not built, 1: usable, -1: the list does not fit / too small
+  // the list sorted by neighbour (sorted, asymmetric lists: transposed sums of the backward as row passes, spk_transposed_t)
+  Tensor t_idx_i, t_idx_j, t_rowptr, t_perm, t_rperm;
+  spk_transposed_t transposed;
+  bool has_transposed = false;
   int blocks_rbf = 0, blocks_F = 0;
 
   spk_graph_t graph() const {
@@ -133,6 +137,7 @@ struct Plan {
     g.filter_pairs = filter_pairs > 0 ? 1 : 0;
     g.edge_pair = edge_pair.defined() ? edge_pair.data_ptr<int32_t>() : nullptr;
     g.blocks = blocks_state == 1 ? &blocks : nullptr;
+    g.transposed = has_transposed ? &transposed : nullptr;
     return g;
   }
 };
@@ -221,6 +226,21 @@ std::shared_ptr<Plan> get_plan(const Tensor& idx_i_in, const Tensor& idx_j_in, i
       p->half = Tensor();
       p->n_half = 0;
     }
+  }
+  if (p->sorted && !p->symmetric && r_ij.defined() && p->n_edges >= 4096) {
+    // asymmetric list: its by-neighbour copy, so that the backward's scatter over idx_j runs as a row pass (no host sync)
+    auto lopt = at::TensorOptions().dtype(at::kLong).device(dev);
+    p->t_idx_i = at::empty({p->n_edges}, lopt); p->t_idx_j = at::empty({p->n_edges}, lopt);
+    p->t_rowptr = at::zeros({n_atoms + 2}, iopt); p->t_perm = at::empty({p->n_edges}, iopt);
+    p->t_rperm = at::empty({p->n_edges, 3}, at::TensorOptions().dtype(at::kFloat).device(dev));
+    Tensor tmp = at::empty({std::max<int64_t>(spk_transpose_plan_bytes(p->n_edges, n_atoms), 16)}, at::TensorOptions().dtype(at::kByte).device(dev));
+    check(spk_transposed_build(p->idx_i.data_ptr<int64_t>(), p->idx_j.data_ptr<int64_t>(), p->n_edges, n_atoms, p->t_idx_i.data_ptr<int64_t>(),
+                               p->t_idx_j.data_ptr<int64_t>(), p->t_rowptr.data_ptr<int32_t>(), p->t_perm.data_ptr<int32_t>(), tmp.data_ptr(),
+                               stream_of(p->idx_i)));
+    p->transposed.idx_i = p->t_idx_i.data_ptr<int64_t>(); p->transposed.idx_j = p->t_idx_j.data_ptr<int64_t>();
+    p->transposed.rowptr = p->t_rowptr.data_ptr<int32_t>(); p->transposed.perm = p->t_perm.data_ptr<int32_t>();
+    p->transposed.r_perm = p->t_rperm.data_ptr<float>();
+    p->has_transposed = true;
   }
   if (p->symmetric && p->n_half > 0) {
     // position in `half` of the pair of every directed edge (molecule-resident SchNet kernels)
@@ -1445,7 +1465,7 @@ Tensor atomwise_backward_op(const c10::optional<Tensor>& gE, const c10::optional
   return atomwise_backward_raw((gE.has_value() && gE->defined()) ? *gE : Tensor(), (gy.has_value() && gy->defined()) ? *gy : Tensor(), pre, w1, w2, idx_m, n_mol, act);
 }
 
-// (rowptr, rev, half, flags[sorted, symmetric, n_half, filter_pairs]) of a list; also warms the cache outside a graph capture
+// (rowptr, rev, half, flags[sorted, symmetric, n_half, filter_pairs, by-neighbour copy built]) of a list; also warms the cache outside a graph capture
 // force_filter: -1 = decide from the geometry (cutoff > 0), 0 / 1 = switch the per-call pair compaction off / on for this list
 std::tuple<Tensor, Tensor, Tensor, Tensor> edge_plan_op(const Tensor& idx_i, const Tensor& idx_j, int64_t n_atoms, const c10::optional<Tensor>& r_ij,
                                                         double cutoff, int64_t force_filter) {
@@ -1454,7 +1474,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> edge_plan_op(const Tensor& idx_i, con
   auto p = get_plan(idx_i, idx_j, n_atoms, r);
   if (force_filter >= 0) p->filter_pairs = (force_filter != 0 && p->symmetric && p->n_edges > 0) ? 1 : 0;
   else if (r.defined() && cutoff > 0) decide_filter(*p, r, cutoff);
-  Tensor flags = at::tensor(std::vector<int64_t>{p->sorted, p->symmetric, p->n_half, p->filter_pairs}, at::TensorOptions().dtype(at::kLong));
+  Tensor flags = at::tensor(std::vector<int64_t>{p->sorted, p->symmetric, p->n_half, p->filter_pairs, p->has_transposed ? 1 : 0}, at::TensorOptions().dtype(at::kLong));
   auto iopt = at::TensorOptions().dtype(at::kInt).device(idx_i.device());
   return {p->rowptr, p->rev, p->half.defined() ? p->half : at::empty({0}, iopt), flags};
 }

@@ -61,11 +61,29 @@ class EdgePlan:
                                   iptr(gp[2], torch.int32) if gp else None, n_groups if gp else 0, max_ga if gp else 0,
                                   n_tiles_g if gp else 0, 0, 0, None,
                                   iptr(self.edge_pair, torch.int32) if self.edge_pair is not None else None,
-                                  max_gp if gp else 0, 0, None)
+                                  max_gp if gp else 0, 0, None, None)
         self.blocks = None
+        self.transposed = None
 
     def graph(self):
         return ctypes.byref(self._graph)
+
+    def build_transposed(self):
+        """The list sorted by neighbour (``spk_transposed_build``), attached to the graph: asymmetric sorted lists then run their
+        transposed sums as row passes.  No host synchronisation."""
+        dev = self.idx_i.device
+        E, N = self.n_edges, self.n_atoms
+        bufs = dict(idx_i=torch.empty(max(E, 1), dtype=torch.int64, device=dev), idx_j=torch.empty(max(E, 1), dtype=torch.int64, device=dev),
+                    rowptr=torch.zeros(N + 2, dtype=torch.int32, device=dev), perm=torch.empty(max(E, 1), dtype=torch.int32, device=dev),
+                    r_perm=torch.empty(max(E, 1), 3, dtype=torch.float32, device=dev),
+                    tmp=torch.empty(max(int(lib().spk_transpose_plan_bytes(E, N)), 16), dtype=torch.uint8, device=dev))
+        with torch.cuda.device(dev):
+            check(lib().spk_transposed_build(iptr(self.idx_i), iptr(self.idx_j), E, N, bufs["idx_i"].data_ptr(), bufs["idx_j"].data_ptr(),
+                                             bufs["rowptr"].data_ptr(), bufs["perm"].data_ptr(), bufs["tmp"].data_ptr(), stream()))
+        t = _lib.TransposedT(bufs["idx_i"].data_ptr(), bufs["idx_j"].data_ptr(), bufs["rowptr"].data_ptr(), bufs["perm"].data_ptr(), bufs["r_perm"].data_ptr())
+        self.transposed, self._transposed_bufs = t, bufs
+        self._graph.transposed = ctypes.addressof(t)
+        return t
 
     def build_blocks(self, n_rbf=20, n_atom_basis=128, cap=0):
         """Block plan of the list (``spk_blocks_build``; include/spk_hip.h) for the box-regime PaiNN message kernels, attached to

@@ -289,9 +289,11 @@ def _cfconv_oracle(h, r, idx_i, idx_j, p, n_atoms, kind, gy):
     return y.detach(), gh, gr
 
 
-def _cfconv_hip(dev, h, r, idx_i, idx_j, p, n_atoms, kind, gy):
+def _cfconv_hip(dev, h, r, idx_i, idx_j, p, n_atoms, kind, gy, transposed=False):
     from schnetpack_amd import _lib, ops
     plan = ops.EdgePlan(idx_i.to(dev), idx_j.to(dev), n_atoms, r.to(dev))
+    if transposed:
+        plan.build_transposed()
     if kind == "gaussian":
         off, w = O.gaussian_rbf_params(p["n_rbf"], 5.0)
         keep = (off.to(dev), w.to(dev))  # device buffers must outlive the raw C calls
@@ -347,6 +349,35 @@ def test_cfconv_forward_backward(dev, variant, graph, nf, n_rbf, kind):
     assert rel_err(y, yo) < TOL
     assert rel_err(gh, gho) < TOL
     assert rel_err(gr, gro) < TOL
+
+
+@pytest.mark.parametrize("nf,n_rbf,kind", [(128, 20, "gaussian"), (64, 16, "bessel")])
+def test_cfconv_backward_through_the_by_neighbour_list(dev, nf, n_rbf, kind):
+    """Sorted but ASYMMETRIC lists (one-sided / half lists of external back-ends): with the list's by-neighbour copy on the graph
+    (spk_transposed_build) the backward's scatter over idx_j runs as the forward kernel over the transposed list + a directed backward
+    without atomics on gh -- same results as the oracle and as the atomic path; the transposed arrays against their definition."""
+    from schnetpack_amd import _lib
+    g = torch.Generator().manual_seed(13)
+    rb = S.random_graph_batch(300, 24, seed=7, sort=True)
+    r, idx_i, idx_j, n_atoms = rb["r_ij"], rb["idx_i"], rb["idx_j"], rb["Z"].shape[0]
+    p = _filter_params(nf, n_rbf, 3)
+    h = torch.randn(n_atoms, nf, generator=g); gy = torch.randn(n_atoms, nf, generator=g)
+    yo, gho, gro = _cfconv_oracle(h, r, idx_i, idx_j, p, n_atoms, kind, gy)
+    _lib.profile_enable(True); _lib.profile_report()
+    y, gh, gr, plan = _cfconv_hip(dev, h, r, idx_i, idx_j, p, n_atoms, kind, gy, transposed=True)
+    tags = _lib.profile_report(); _lib.profile_enable(False)
+    assert not plan.symmetric and plan.sorted
+    assert tags["cfconv_fwd_mfma"][0] == 2 and tags["cfconv_bwd_mfma_atomic"][0] == 1, tags       # forward, transposed forward, directed backward
+    assert rel_err(y, yo) < TOL and rel_err(gh, gho) < TOL and rel_err(gr, gro) < TOL
+    y2, gh2, gr2, _ = _cfconv_hip(dev, h, r, idx_i, idx_j, p, n_atoms, kind, gy, transposed=False)
+    assert rel_err(gh, gh2) < 2e-6 and rel_err(gr, gr2) < 2e-6
+    # definition of the transposed arrays: a stable sort of the pairs by neighbour
+    order = torch.sort(idx_j, stable=True).indices
+    tb = plan._transposed_bufs
+    assert torch.equal(tb["perm"].cpu().long(), order)
+    assert torch.equal(tb["idx_i"].cpu(), idx_j[order]) and torch.equal(tb["idx_j"].cpu(), idx_i[order])
+    want_rp = torch.searchsorted(idx_j[order].contiguous(), torch.arange(n_atoms + 2))
+    assert torch.equal(tb["rowptr"].cpu().long(), want_rp)
 
 
 def test_cfconv_empty_and_isolated(dev, variant):
