@@ -114,18 +114,78 @@ __global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_tn_batched(GemmTnBatch b
 }
 
 // ------------------------------------------------------------------------------------------------ device backend of the engine
+// Side streams of the engine -- EXPERIMENT, off by default (SPK_FM_STREAMS=1).  Launches of a training step are latency bound (~100
+// launches of 2-5 us of work each) and some chains are independent (the filter networks of the interactions depend on the geometry
+// only), so they were put on side streams beside the atom chain; inside a stream capture the event record / wait pairs become graph
+// edges, i.e. the captured step gets parallel branches.  MEASURED (scripts/gpu_fm_streams_ab.sh, one box, alternating runs, identical
+// losses): SchNet 0.610 -> 0.851 ms per step, PaiNN 0.891 -> 1.062 ms -- every cross-queue dependency of a replayed HIP graph costs
+// more than the short launch it lets overlap.  The switch stays for re-measurement on other runtimes; per device, created at the first
+// EAGER call (a captured training step is preceded by eager warm-up steps).
+struct FmSideStreams {
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t fork_ev[2] = {nullptr, nullptr};
+  hipEvent_t done_ev[16] = {};
+  bool ok = false;
+};
+static FmSideStreams* fm_side_streams(hipStream_t main) {
+  static FmSideStreams per_dev[64];
+  static const bool on = [] { const char* e = getenv("SPK_FM_STREAMS"); return e && e[0] == '1'; }();
+  if (!on) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  FmSideStreams& s = per_dev[dev];
+  if (!s.ok) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;     // never create inside a capture
+    for (int k = 0; k < 2; ++k) {
+      if (hipStreamCreateWithFlags(&s.side[k], hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&s.fork_ev[k], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    for (int k = 0; k < 16; ++k)
+      if (hipEventCreateWithFlags(&s.done_ev[k], hipEventDisableTiming) != hipSuccess) return nullptr;
+    s.ok = true;
+  }
+  return &s;
+}
+
 struct FmDeviceBackend {
   hipStream_t stream;
+  hipStream_t main_stream;
+  FmSideStreams* ss = nullptr;
   float* gws = nullptr;
   uint32_t* tickets = nullptr;
   int max_blocks;
   GemmTnBatch batch;
   int64_t ws_used = 0;
   int tickets_used = 0;
-  explicit FmDeviceBackend(hipStream_t s) : stream(s), max_blocks(spk_num_cus() * 32) { batch.n = 0; batch.prefix[0] = 0; }
+  explicit FmDeviceBackend(hipStream_t s) : stream(s), main_stream(s), max_blocks(spk_num_cus() * 32) { batch.n = 0; batch.prefix[0] = 0; }
+  // fork(s): later launches go to side stream s (which first waits for everything issued on the main stream so far); back(k): record
+  // "done" event k there and return to the main stream; wait(k): the main stream waits for event k.  Without side streams all three are
+  // no-ops and the work stays in issue order on the main stream.
+  bool can_fork(int n_events) { if (!ss) ss = fm_side_streams(main_stream); return ss != nullptr && n_events <= 16; }
+  void fork(int s) {
+    if (!ss) return;
+    (void)hipEventRecord(ss->fork_ev[s], main_stream);
+    (void)hipStreamWaitEvent(ss->side[s], ss->fork_ev[s], 0);
+    stream = ss->side[s];
+  }
+  void back(int k) {
+    if (!ss) return;
+    (void)hipEventRecord(ss->done_ev[k], stream);
+    stream = main_stream;
+    pending |= 1u << k;
+  }
+  void wait(int k) {
+    if (!ss || !(pending & (1u << k))) return;
+    (void)hipStreamWaitEvent(main_stream, ss->done_ev[k], 0);
+    pending &= ~(1u << k);
+  }
   void set_gemm_ws(float* w, uint32_t* t) { gws = w; tickets = t; }
+  unsigned pending = 0;      // "done" events recorded on a side stream and not yet waited for by the main stream
   int gemm_flush() {
     if (batch.n == 0) return SPK_OK;
+    for (int k = 0; k < 16; ++k)       // the batch reads operands that side streams may still be producing
+      if (pending & (1u << k)) wait(k);
     SpkProfScope prof("gemm_tn_batched", stream);
     hipLaunchKernelGGL(k_gemm_tn_batched, dim3(batch.prefix[batch.n]), dim3(64 * TN_WAVES), 0, stream, batch);
     batch.n = 0;

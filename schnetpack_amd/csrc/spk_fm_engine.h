@@ -190,9 +190,13 @@ struct FmEngine {
     int rc;
     if ((rc = prepare(b, rb, w.c, err))) return rc;
     be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.X2[0]);
-    for (int l = 0; l < L; ++l) {                                            // ---- pass A
+    // ---- pass A.  The filter networks depend on the geometry only: they are issued first, on two side streams (interactions alternate),
+    // and the atom chain on the main stream waits for interaction l's filters in front of its convolution.
+    const bool par = be.can_fork(L);
+    for (int l = 0; l < L; ++l) {
       const FmSchnetLayer<T>& P = m.layers[l];
       T *a2 = w.a2[l], *z2 = w.z2[l], *Wf2 = w.Wf2[l];
+      if (par) be.fork(l & 1);
       // filter network, value and d-derivative (schnet.py:61): a = phi W1^T + b1, a1 = phi1 W1^T; z = ssp(a), z1 = ssp'(a) a1; g = z W2^T + b2, g1 = z1 W2^T
       if ((rc = be.dense(w.c.phi2, P.fn_w1, P.fn_b1, nullptr, z2, a2, E, K, nf, FM_ACT_SSP))) return rc;
       if ((rc = be.dense(w.c.phi2 + E * K, P.fn_w1, nullptr, nullptr, a2 + E * nf, nullptr, E, K, nf, FM_ACT_NONE))) return rc;
@@ -200,7 +204,13 @@ struct FmEngine {
       if ((rc = be.dense(z2, P.fn_w2, P.fn_b2, nullptr, Wf2, nullptr, E, nf, nf, FM_ACT_NONE))) return rc;
       if ((rc = be.dense(z2 + E * nf, P.fn_w2, nullptr, nullptr, Wf2 + E * nf, nullptr, E, nf, nf, FM_ACT_NONE))) return rc;
       be.flat("fm_filter_fc", k_fm_filter_fc<T>, E * nf, Wf2, w.c.fc, w.c.fc1, E, nf);
+      if (par) be.back(l);
+    }
+    for (int l = 0; l < L; ++l) {
+      const FmSchnetLayer<T>& P = m.layers[l];
+      T* Wf2 = w.Wf2[l];
       if ((rc = be.dense(w.X2[l], P.in2f_w, nullptr, nullptr, w.h2[l], nullptr, N, F, nf, FM_ACT_NONE))) return rc;
+      if (par) be.wait(l);
       be.flat("fm_cfconv", k_fm_cfconv<T>, N * nf, w.h2[l], Wf2, w.c.rowptr, b.jj, w.c.e_act, N, nf, w.y2[l]);
       if ((rc = be.dense(w.y2[l], P.f2out_w1, P.f2out_b1, nullptr, w.s2[l], w.p32[l], N, nf, F, FM_ACT_SSP))) return rc;
       if ((rc = be.dense(w.s2[l], P.f2out_w2, P.f2out_b2, w.X2[l], w.X2[l + 1], nullptr, N, F, F, FM_ACT_NONE))) return rc;
@@ -249,6 +259,7 @@ struct FmEngine {
     T* g_head = grads + L * lg;
     T* g_emb = g_head + fm_head_grad_floats(F, H);
     if ((rc = head_dual_backward(b, hd, F, w.X2[L], gE, w.c, w.GX[L], g_head))) return rc;
+    const bool parD = be.can_fork(L);
     for (int l = L - 1; l >= 0; --l) {                                       // ---- pass D
       const FmSchnetLayer<T>& P = m.layers[l];
       T* g = grads + l * lg;
@@ -272,12 +283,17 @@ struct FmEngine {
       be.flat("fm_filter_cot", k_fm_filter_cot<T>, E * nf, w.gy2, w.h2[l], (const T*)(l > 0 ? w.h2[l] + N * nf : nullptr), w.c.dt, w.c.fc, w.c.fc1, b.ii, b.jj, N, E,
               nf, gg2);
       if ((rc = be.gemm_tn(gg2, w.z2[l], 2 * E, nf, nf, g_w2, g_b2, E))) return rc;
+      // the reverse of the filter network feeds only weight gradients (deferred to the batched launch): off the atom chain, on ONE side
+      // stream for all interactions (they share the scratch gz2)
+      if (parD) be.fork(0);
       if ((rc = be.dense_bwd_input(gg2, nullptr, P.fn_w2, nullptr, w.gz2, 2 * E, nf, nf, FM_ACT_NONE))) return rc;
       be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, E * nf, w.gz2, w.a2[l], E * nf, FM_ACT_SSP, ga2);
+      if (parD) be.back(l);
       if ((rc = be.gemm_tn(ga2, w.c.phi2, 2 * E, nf, K, g_w1, g_b1, E))) return rc;
       if ((rc = be.gemm_tn(gh2, w.X2[l], nr, nf, F, g_in2f, nullptr, nr))) return rc;
       if ((rc = be.dense_bwd_input(gh2, nullptr, P.in2f_w, gx, w.GX[l], nr, F, nf, FM_ACT_NONE))) return rc;
     }
+    if (parD) for (int l = 0; l < L; ++l) be.wait(l);
     if ((rc = be.gemm_flush())) return rc;
     be.flat("fm_embed_grad", k_fm_embed_grad<T>, (int64_t)b.n_types * F, w.GX[0], b.Z, N, F, b.n_types, g_emb);
     return 0;
@@ -324,17 +340,22 @@ struct FmEngine {
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
     if ((rc = prepare(b, rb, w.c, err))) return rc;
-    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.Q2[0]);
-    // every interaction's filter rows at once (painn.py:232-236): Phi = (phi Wf^T + bf) f_c, with the d-derivative beside it
+    // every interaction's filter rows at once (painn.py:232-236): Phi = (phi Wf^T + bf) f_c, with the d-derivative beside it -- on a side
+    // stream, beside the embedding and the first context net (they meet in front of the first message)
+    const bool par = be.can_fork(1);
+    if (par) be.fork(0);
     if ((rc = be.dense(w.c.phi2, m.filt_w, m.filt_b, nullptr, w.Phi2, nullptr, E, K, ld, FM_ACT_NONE))) return rc;
     if ((rc = be.dense(w.c.phi2 + E * K, m.filt_w, nullptr, nullptr, w.Phi2 + E * (int64_t)ld, nullptr, E, K, ld, FM_ACT_NONE))) return rc;
     be.flat("fm_filter_fc", k_fm_filter_fc<T>, E * (int64_t)ld, w.Phi2, w.c.fc, w.c.fc1, E, ld);
+    if (par) be.back(0);
+    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.Q2[0]);
     for (int l = 0; l < L; ++l) {                                            // ---- pass A
       const FmPainnLayer<T>& P = m.layers[l];
       const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);
       const T* mu = l > 0 ? w.MU2[l] : nullptr;
       if ((rc = be.dense(w.Q2[l], P.ctx_w1, P.ctx_b1, nullptr, w.sa2[l], w.pa2[l], N, F, F, FM_ACT_SILU))) return rc;
       if ((rc = be.dense(w.sa2[l], P.ctx_w2, P.ctx_b2, nullptr, w.c2[l], nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
+      if (par && l == 0) be.wait(0);
       be.flat("fm_painn_msg", k_fm_painn_msg<T>, N * F, w.Q2[l], mu, w.c2[l], Phi, ld, w.c.u, w.c.rowptr, b.jj, w.c.e_act, N, F, w.q1_2[l], w.mu1_2[l]);
       if ((rc = be.dense(w.mu1_2[l], P.mix_w, nullptr, nullptr, w.VW2[l], nullptr, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
       be.flat("fm_painn_mix", k_fm_painn_mix<T>, N * F, w.q1_2[l], w.VW2[l], m.eps, N, F, w.n2[l], w.svw2[l], w.ctx2[l]);

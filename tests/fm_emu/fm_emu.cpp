@@ -10,6 +10,10 @@
 
 template <class T>
 struct EmuBackend {
+  bool can_fork(int) { return true; }       // (the emulation runs everything in issue order: the fork / back / wait calls of the engine are exercised as calls)
+  void fork(int) {}
+  void back(int) {}
+  void wait(int) {}
   void set_gemm_ws(T*, uint32_t*) {}
   int64_t gemm_tn_ws_floats(int64_t, int, int) { return 0; }
   size_t transpose_tmp_bytes(int64_t, int64_t) { return 0; }
