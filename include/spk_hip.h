@@ -315,6 +315,32 @@ int spk_dense_bwd_input_f32(const float* dy, const float* pre, const float* w, c
                             float* dx, int64_t m, int32_t k, int32_t n_out, int32_t act,
                             void* stream);
 
+/* A Dense layer on a (value, tangent) PAIR of activations in ONE launch -- the unit of the force-matching engine (spk_*_fm_*), where
+ * every activation of nn/base.py:52-55 travels with its directional derivative along t = -dL/dF (atomistic/response.py:59-68 under
+ * create_graph=True).  p = x w^T (trans = 0, w [n_out, k_in]) or x w (trans = 1, w [k_in, n_out]) for both members, then
+ *   SPK_DD_FWD       p_v += b;  y_v = act(p_v) + res_v,  y_t = act'(p_v) p_t + res_t;  with fc (act NONE): y_v = p_v fc[m], y_t = p_t fc[m] + p_v fc1[m]
+ *                    (the cutoff product of schnet.py:62 / painn.py:232-236 with its d-derivative);  pre_v / pre_t (optional) receive p_v, p_t
+ *   SPK_DD_TANGENT   x_v == NULL:  y_t = act'(pre_v_in) p_t + res_t;  pre_t (optional) receives p_t
+ *   SPK_DD_DUAL_BWD  (p_v, p_t) = (g_z, h_z), the cotangents of z = act(a), z_t = act'(a) a_t with a = pre_v_in, a_t = pre_t_in (NULL = 0):
+ *                    y_v = g_z act'(a) + h_z act''(a) a_t,  y_t = h_z act'(a)
+ * All row-major [m, .]; every pointer 16-byte aligned; k_in % 4 == 0, n_out % 4 == 0 and at most 4 tiles of 32 x 32 per compute unit
+ * (spk_dense_dual_supported): one workgroup per tile -- larger problems are two spk_dense_f32 launches and an element-wise one. */
+#define SPK_DD_FWD 0
+#define SPK_DD_TANGENT 1
+#define SPK_DD_DUAL_BWD 2
+typedef struct {
+  const float *x_v, *x_t;             /* [m, k_in] */
+  const float *w, *b;
+  const float *res_v, *res_t;         /* [m, n_out] or NULL */
+  const float *pre_v_in, *pre_t_in;   /* [m, n_out] saved pre-activations (TANGENT, DUAL_BWD) */
+  const float *fc, *fc1;              /* [m] or NULL */
+  float *y_v, *y_t, *pre_v, *pre_t;   /* [m, n_out] */
+  int64_t m;
+  int32_t k_in, n_out, act, mode, trans;
+} spk_dense_dual_t;
+int spk_dense_dual_supported(int64_t m, int32_t k_in, int32_t n_out);
+int spk_dense_dual_f32(const spk_dense_dual_t* d, void* stream);
+
 /* Chain of up to 3 Dense layers in ONE launch (e.g. f2out.0 -> f2out.1 (+residual) -> next in2f of
  * representation/schnet.py:33-36,60,69,168, or the input-gradient transposes of such a chain).  The
  * activations of a 32-row tile stay in LDS between layers.  Layer l maps [m, k_l] -> [m, n_out_l] with
@@ -710,6 +736,21 @@ int spk_fm_loss_f32(const float* E, const float* E_t, int64_t M, const float* F,
                     float* loss, float* gE, float* gF, void* stream);
 int spk_fm_loss_bwd_f32(const float* g, const float* gE, int64_t M, const float* gF, int64_t n3, float* outE, float* outF, void* stream);
 
+/* AdamW (torch.optim.AdamW arithmetic: decoupled weight decay, bias corrections, eps outside the corrected root -- the optimizer of the
+ * reference's training configs, task.py:187-199) for ALL parameters in one launch.  grads / exp_avg / exp_avg_sq are flat buffers of one
+ * layout; chunk c updates param[poffset .. poffset + n) from the flat range [offset, offset + n), n <= SPK_ADAMW_CHUNK (one workgroup per
+ * chunk; the table lives on the device).  step [1] is the device-side step count (float, starts at 0; the launch reads it, uses count + 1
+ * and stores it); ticket [1] must be zero before the first call. */
+#define SPK_ADAMW_CHUNK 2048
+typedef struct {
+  void* param;       /* base of the parameter tensor (float32) */
+  int64_t poffset;   /* first element of the chunk inside the parameter */
+  int64_t offset;    /* first element of the chunk inside the flat buffers */
+  int64_t n;
+} spk_adamw_chunk_t;
+int spk_adamw_f32(const spk_adamw_chunk_t* chunks, int64_t n_chunks, const float* grads, float* exp_avg, float* exp_avg_sq, float* step,
+                  uint32_t* ticket, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* ------------------------------------------------------------------ force-matching gradients by forward-over-reverse
  * Replaces what the reference obtains from autograd with create_graph = True: Forces (atomistic/response.py:59-68) builds the
  * graph of -dE/dR, the task differentiates loss(E, F) through it (task.py:166-185) -- reverse over reverse, several hundred
@@ -726,7 +767,8 @@ int spk_fm_loss_bwd_f32(const float* g, const float* gE, int64_t M, const float*
  * stress; any F, n_filters, n_rbf, Gaussian / Bessel basis; idx_i ASCENDING (err |= 1 otherwise), idx_j in any order, the list need
  * not be symmetric (the transposed sums run over a by-neighbour CSR built on the device per call).  Only raw state_dict weights are
  * read (no transposed / packed copies: the weights change every step).  No host synchronisation: both calls can be captured in a
- * HIP graph.  The SAME workspace (and batch) must be passed to the backward call; spk_*_fm_workspace_bytes sizes it. */
+ * HIP graph.  The SAME workspace (and batch) must be passed to the backward call; spk_*_fm_workspace_bytes sizes it (n_types = rows of the
+ * embedding table of the batch description: the workspace holds the one-hot rows of Z, the operand of the table's gradient). */
 typedef struct {
   int64_t n_atoms, n_edges, n_mol;
   const int64_t* Z;        /* [N] atomic numbers (rows of `embedding`; out of range -> zero row) */
@@ -739,13 +781,15 @@ typedef struct {
   int32_t n_types;
   int32_t reserved;
 } spk_fm_batch_t;
-int64_t spk_schnet_fm_workspace_bytes(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t n_atoms, int64_t n_edges, int64_t n_mol);
+int64_t spk_schnet_fm_workspace_bytes(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t n_atoms, int64_t n_edges, int64_t n_mol,
+                                      int32_t n_types);
 int64_t spk_schnet_fm_grad_floats(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int32_t n_types);
 int spk_schnet_fm_forward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
                               float* E, float* F, int32_t* err, void* stream);
 int spk_schnet_fm_backward_f32(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
                                const float* gE, const float* gF, float* grads, void* stream);
-int64_t spk_painn_fm_workspace_bytes(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t n_atoms, int64_t n_edges, int64_t n_mol);
+int64_t spk_painn_fm_workspace_bytes(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t n_atoms, int64_t n_edges, int64_t n_mol,
+                                     int32_t n_types);
 int64_t spk_painn_fm_grad_floats(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int32_t n_types);
 int spk_painn_fm_forward_f32(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
                              float* E, float* F, int32_t* err, void* stream);

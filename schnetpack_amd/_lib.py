@@ -76,6 +76,12 @@ class ChainT(ctypes.Structure):
                 ("zero_ptr", c_f), ("zero_count", c_i64), ("tmp", c_f * 2), ("layers", ChainLayerT * 3)]
 
 
+class DenseDualT(ctypes.Structure):
+    """spk_dense_dual_t: a Dense layer on a (value, tangent) pair of activations (include/spk_hip.h)."""
+    _fields_ = [(n, c_f) for n in ("x_v", "x_t", "w", "b", "res_v", "res_t", "pre_v_in", "pre_t_in", "fc", "fc1", "y_v", "y_t", "pre_v", "pre_t")] + \
+               [("m", c_i64), ("k_in", c_i32), ("n_out", c_i32), ("act", c_i32), ("mode", c_i32), ("trans", c_i32)]
+
+
 class PainnLayerT(ctypes.Structure):
     _fields_ = [(n, c_f) for n in ("ctx_w1", "ctx_b1", "ctx_w2", "ctx_b2", "filt_w", "filt_b",
                                    "mix_w", "ictx_w1", "ictx_b1", "ictx_w2", "ictx_b2",
@@ -147,11 +153,11 @@ _PROTOS = {
     "spk_rowdot_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_i32, c_f, c_f]),
     "spk_fm_loss_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_f, c_f, c_i64, ctypes.c_float, ctypes.c_float, c_f, c_f, c_f]),
     "spk_fm_loss_bwd_f32": (ctypes.c_int, [c_f, c_f, c_i64, c_f, c_i64, c_f, c_f]),
-    "spk_schnet_fm_workspace_bytes": (c_i64, [P(SchnetT), P(HeadT), P(RadialT), c_i64, c_i64, c_i64]),
+    "spk_schnet_fm_workspace_bytes": (c_i64, [P(SchnetT), P(HeadT), P(RadialT), c_i64, c_i64, c_i64, c_i32]),
     "spk_schnet_fm_grad_floats": (c_i64, [P(SchnetT), P(HeadT), P(RadialT), c_i32]),
     "spk_schnet_fm_forward_f32": (ctypes.c_int, [P(SchnetT), P(HeadT), P(RadialT), P(FmBatchT), c_f, c_f, c_f, c_f, c_f]),
     "spk_schnet_fm_backward_f32": (ctypes.c_int, [P(SchnetT), P(HeadT), P(RadialT), P(FmBatchT), c_f, c_f, c_f, c_f, c_f]),
-    "spk_painn_fm_workspace_bytes": (c_i64, [P(PainnT), P(HeadT), P(RadialT), c_i64, c_i64, c_i64]),
+    "spk_painn_fm_workspace_bytes": (c_i64, [P(PainnT), P(HeadT), P(RadialT), c_i64, c_i64, c_i64, c_i32]),
     "spk_painn_fm_grad_floats": (c_i64, [P(PainnT), P(HeadT), P(RadialT), c_i32]),
     "spk_painn_fm_forward_f32": (ctypes.c_int, [P(PainnT), P(HeadT), P(RadialT), P(FmBatchT), c_f, c_f, c_f, c_f, c_f]),
     "spk_painn_fm_backward_f32": (ctypes.c_int, [P(PainnT), P(HeadT), P(RadialT), P(FmBatchT), c_f, c_f, c_f, c_f, c_f]),
@@ -160,6 +166,9 @@ _PROTOS = {
     "spk_vec3_f32": (ctypes.c_int, [c_i32, c_f, c_i64, c_f, c_i64, c_i64, c_i32, c_f, c_f]),
     "spk_dense_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
     "spk_dense_bwd_input_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
+    "spk_adamw_f32": (ctypes.c_int, [c_f, c_i64, c_f, c_f, c_f, c_f, c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f]),
+    "spk_dense_dual_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),
+    "spk_dense_dual_f32": (ctypes.c_int, [P(DenseDualT), c_f]),
     "spk_dense_chain_f32": (ctypes.c_int, [P(ChainT), c_f]),
     "spk_schnet_cfconv_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f]),
     "spk_schnet_cfconv_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f]),

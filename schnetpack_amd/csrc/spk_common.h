@@ -196,6 +196,14 @@ __device__ __forceinline__ int64_t spk_xcd_tile(int nidx, int64_t ntiles) {
   const int64_t t = (int64_t)(blockIdx.x & 7) * per + tl;
   return (tl < per && t < ntiles) ? t : ntiles;
 }
+// a pointer the caller knows to be the same on every lane of the wavefront, moved to scalar registers (loads through it take the
+// "scalar base + 32-bit lane offset" form)
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* spk_uniform_ptr(const T* p) {      // (typed as global memory: a plain pointer rebuilt from integers loads as "flat")
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const __attribute__((address_space(1))) T*)(((uint64_t)hi << 32) | lo);
+}
 static inline int spk_xcd_walk_default() {
   static const int v = [] { const char* e = getenv("SPK_XCD_WALK"); return (e && e[0] == '0') ? 0 : 1; }();
   return v;

@@ -201,13 +201,13 @@ __global__ __launch_bounds__(256) void k_dense_mfma_splitk(const float* __restri
 
 // Few output tiles (small batches: a training step has 168 - 336 rows per Dense layer): one tile per WORKGROUP, the four waves split the
 // contraction chunk-wise (K = 128 -> one chunk of four k-blocks each: ONE memory round trip per wave instead of a chain of them), the partial
-// tiles meet in LDS in wave order (deterministic), wave 0 runs the epilogue of dense_tiles (bias, pre-activation store, activation, residual).
+// tiles meet in LDS in wave order (deterministic), waves 0 .. 3 share the epilogue of dense_tiles (bias, pre-activation store, activation, residual).
 // Same operand conventions and template switches as k_dense_mfma.
 template <int ACT, bool TRANS, int PRO, int CH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_dense_mfma_sk(const float* __restrict__ in, const float* __restrict__ pre_in, const float* __restrict__ w,
                                                        const float* __restrict__ b, const float* res, float* out, float* __restrict__ pre_out, int64_t M, int KC,
                                                        int NW) {
-  __shared__ float red[WAVES - 1][32][33];
+  __shared__ float red[WAVES][32][33];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int hi = lane >> 5, el = lane & 31;
   const int tcount = (NW + 31) / 32;
@@ -226,44 +226,37 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_mfma_sk(const float* __res
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   f32x4 a0[CH], b0[CH], a1[CH], b1[CH];
   if (wv < nch) dense_load_chunk<TRANS, PRO>(a0, b0, wv, nug, inrow, prow, w, KC, NW, t, el, hi);
-  f32x4 rv[4];
-  if (wv == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      rv[q] = (res && valid && 32 * t + 8 * q + 4 * hi < NW) ? *(const f32x4*)(res + m * NW + 32 * t + 8 * q + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  // the epilogue is shared by waves 0 .. 3: wave q finishes the column group q (8 of the 32 output features); its operands are requested ahead
+  const int col = 32 * t + 8 * wv + 4 * hi;
+  const bool fin = valid && wv < 4 && col < NW;
+  const int64_t off = m * NW + col;
+  const f32x4 z4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 rv = (res && fin) ? *(const f32x4*)(res + off) : z4;
+  f32x4 bq = z4;      // (scalar loads: a bias may be any 4-byte aligned view of a flat parameter buffer)
+  if (b && fin) { bq.x = b[col]; bq.y = b[col + 1]; bq.z = b[col + 2]; bq.w = b[col + 3]; }
   for (int c = wv; c < nch; c += 2 * WAVES) {
     if (c + WAVES < nch) dense_load_chunk<TRANS, PRO>(a1, b1, c + WAVES, nug, inrow, prow, w, KC, NW, t, el, hi);
     acc = dense_mfma_chunk(a0, b0, c, nug, acc);
     if (c + 2 * WAVES < nch) dense_load_chunk<TRANS, PRO>(a0, b0, c + 2 * WAVES, nug, inrow, prow, w, KC, NW, t, el, hi);
     if (c + WAVES < nch) acc = dense_mfma_chunk(a1, b1, c + WAVES, nug, acc);
   }
-  if (wv > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wv - 1][(r & 3) + 8 * (r >> 2) + 4 * hi][el] = acc[r];
-  }
+  for (int r = 0; r < 16; ++r) red[wv][(r & 3) + 8 * (r >> 2) + 4 * hi][el] = acc[r];
   __syncthreads();
-  if (wv == 0 && valid) {
+  if (!fin) return;
+  f32x4 o;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = 32 * t + 8 * q + 4 * hi;
-      if (col >= NW) continue;
-      const int64_t off = m * NW + col;
-      f32x4 o;
+  for (int v = 0; v < 4; ++v) {
+    const int rr = 8 * wv + 4 * hi + v;
+    float sum = red[0][rr][el];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = 4 * q + v, rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float sum = acc[r];
-#pragma unroll
-        for (int q2 = 0; q2 < WAVES - 1; ++q2) sum += red[q2][rr][el];
-        o[v] = sum + (b ? b[col + v] : 0.f);
-      }
-      if (pre_out) *(f32x4*)(pre_out + off) = o;
-      o.x = spk_act<ACT>(o.x); o.y = spk_act<ACT>(o.y); o.z = spk_act<ACT>(o.z); o.w = spk_act<ACT>(o.w);
-      if (res) o += rv[q];
-      *(f32x4*)(out + off) = o;
-    }
+    for (int q2 = 1; q2 < WAVES; ++q2) sum += red[q2][rr][el];      // wave order: deterministic
+    o[v] = sum + bq[v];
   }
+  if (pre_out) *(f32x4*)(pre_out + off) = o;
+  o.x = spk_act<ACT>(o.x); o.y = spk_act<ACT>(o.y); o.z = spk_act<ACT>(o.z); o.w = spk_act<ACT>(o.w);
+  o += rv;
+  *(f32x4*)(out + off) = o;
 }
 
 template <int ACT, bool TRANS, int PRO>
@@ -760,4 +753,218 @@ int spk_dense_internal(const float* in, const float* pre_in, const float* w, con
                        int act, bool trans, int pro, hipStream_t stream) {
   return dense_dispatch(in, pre_in, w, b, res, out, pre_out, M, KC, NW, act, trans, pro, stream,
                         "spk_dense");
+}
+
+// ---------------------------------------------------------------- Dense layers on (value, tangent) pairs
+// The force-matching engine (spk_fm_engine.h) carries every activation as a pair (value, tangent along t = -dL/dF).  A Dense layer acts
+// on both with the same weights, and the activation couples them element by element (tangent: act'(a) a_t; reverse of the pair:
+// g_a = g_z act'(a) + h_z act''(a) a_t, h_a = h_z act'(a)).  As separate launches that is two Dense launches and an element-wise one per
+// layer, each a few microseconds of latency at training sizes (168 - 2 500 rows).  Here ONE workgroup owns the 32 x 32 tile of both
+// members: the weight operand is fetched once, the two accumulators meet in the epilogue.
+struct DenseDualArgs {
+  const float *in_v, *in_t;       // [M, KC]; in_v == NULL: tangent member only
+  const float *w, *b;
+  const float *res_v, *res_t;     // [M, NW] or NULL
+  const float *epre_v, *epre_t;   // [M, NW] saved pre-activations (modes TANGENT / DUAL_BWD)
+  const float *fc, *fc1;          // [M] row scale of mode FWD: y_v = p_v fc, y_t = p_t fc + p_v fc'
+  float *out_v, *out_t, *pre_v, *pre_t;
+  int64_t M;
+  int KC, NW, act, mode;
+};
+
+__device__ __forceinline__ float dd_act(int act, int order, float z) {
+  if (act == SPK_ACT_NONE) return order == 0 ? z : (order == 1 ? 1.f : 0.f);
+  const float s = spk_sigmoid(z);
+  if (act == SPK_ACT_SSP) {
+    if (order == 0) return spk_ssp(z);
+    return order == 1 ? s : s * (1.f - s);
+  }
+  if (order == 0) return z * s;
+  if (order == 1) return s * (1.f + z * (1.f - s));
+  return s * (1.f - s) * (2.f + z * (1.f - 2.f * s));
+}
+
+template <bool TRANS, int CH>
+__device__ __forceinline__ void dd_load_chunk(f32x4 (&av)[CH], f32x4 (&bt)[CH], f32x4 (&bvv)[CH], int c, int nug, const float* __restrict__ row_t,
+                                              const float* __restrict__ row_v, bool dual, const float* __restrict__ w, int KC, int NW, int t, int el, int hi) {
+  const bool rin = 32 * t + el < NW;
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    const int ug = c * CH + u;
+    if (ug < nug) {
+      const int kk0 = 8 * ug + 4 * hi;
+      const bool kin = kk0 < KC;
+      f32x4 x{0.f, 0.f, 0.f, 0.f}, y{0.f, 0.f, 0.f, 0.f}, a4{0.f, 0.f, 0.f, 0.f};
+      if (kin) x = *(const f32x4*)(row_t + kk0);
+      if (kin && dual) y = *(const f32x4*)(row_v + kk0);
+      if (kin && rin) {
+        if (!TRANS) {
+          a4 = *(const f32x4*)(w + (int64_t)(32 * t + el) * KC + kk0);
+        } else {
+          const float* wp = w + (int64_t)kk0 * NW + 32 * t + el;
+          a4.x = wp[0]; a4.y = wp[NW]; a4.z = wp[2 * (int64_t)NW]; a4.w = wp[3 * (int64_t)NW];
+        }
+      }
+      bt[u] = x; bvv[u] = y; av[u] = a4;
+    }
+  }
+}
+
+// Four waves: wave w contracts the chunks w, w + 4, ... of the tile; all partial tiles go through LDS, and wave w finishes the column
+// group q = w (8 of the 32 output features) -- the epilogue (up to three transcendental activations per element) runs on all four waves
+// instead of one (first version, epilogue on wave 0 only: 10 - 13 us per launch against 5 - 6 us of the plain kernel).
+// Long contractions (K > 128) run with eight waves: waves 4 .. 7 hand their partial tiles to waves 0 .. 3 through the same LDS buffer first.
+template <bool TRANS, int CH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_dense_dual_sk(DenseDualArgs a) {
+  __shared__ float red[2][4][32][33];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  const int KC = a.KC, NW = a.NW;
+  const int tcount = (NW + 31) / 32;
+  const int nug = (KC + 7) / 8;
+  const int nch = (nug + CH - 1) / CH;
+  const int64_t task = blockIdx.x;
+  const int64_t mt = task / tcount;
+  const int t = (int)(task % tcount);
+  const int64_t m = mt * 32 + el;
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : (a.M - 1);
+  const bool dual = a.in_v != nullptr;
+  const float* row_t = a.in_t + mc * KC;
+  const float* row_v = dual ? a.in_v + mc * KC : row_t;
+  f32x16 acc_v, acc_t;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc_v[r] = 0.f; acc_t[r] = 0.f; }
+  f32x4 a0[CH], t0[CH], v0[CH], a1[CH], t1[CH], v1[CH];
+  if (wv < nch) dd_load_chunk<TRANS, CH>(a0, t0, v0, wv, nug, row_t, row_v, dual, a.w, KC, NW, t, el, hi);
+  // epilogue operands of the wave's column group, requested ahead of the contraction
+  const int col = 32 * t + 8 * wv + 4 * hi;
+  const bool fin = valid && wv < 4 && col < NW;
+  const int64_t off = m * NW + col;
+  const f32x4 z4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 ev = (a.epre_v && fin) ? *(const f32x4*)(a.epre_v + off) : z4;
+  const f32x4 et = (a.epre_t && fin) ? *(const f32x4*)(a.epre_t + off) : z4;
+  const f32x4 rv = (a.res_v && fin) ? *(const f32x4*)(a.res_v + off) : z4;
+  const f32x4 rt = (a.res_t && fin) ? *(const f32x4*)(a.res_t + off) : z4;
+  f32x4 bq = z4;
+  if (a.b && fin) { bq.x = a.b[col]; bq.y = a.b[col + 1]; bq.z = a.b[col + 2]; bq.w = a.b[col + 3]; }
+  float fcm = 0.f, fc1m = 0.f;
+  if (a.fc && valid) { fcm = a.fc[m]; fc1m = a.fc1[m]; }
+  for (int c = wv; c < nch; c += 2 * WAVES) {
+    if (c + WAVES < nch) dd_load_chunk<TRANS, CH>(a1, t1, v1, c + WAVES, nug, row_t, row_v, dual, a.w, KC, NW, t, el, hi);
+    acc_t = dense_mfma_chunk(a0, t0, c, nug, acc_t);
+    if (dual) acc_v = dense_mfma_chunk(a0, v0, c, nug, acc_v);
+    if (c + 2 * WAVES < nch) dd_load_chunk<TRANS, CH>(a0, t0, v0, c + 2 * WAVES, nug, row_t, row_v, dual, a.w, KC, NW, t, el, hi);
+    if (c + WAVES < nch) {
+      acc_t = dense_mfma_chunk(a1, t1, c + WAVES, nug, acc_t);
+      if (dual) acc_v = dense_mfma_chunk(a1, v1, c + WAVES, nug, acc_v);
+    }
+  }
+  if (WAVES == 8) {
+    if (wv >= 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        red[0][wv - 4][rr][el] = acc_t[r];
+        if (dual) red[1][wv - 4][rr][el] = acc_v[r];
+      }
+    }
+    __syncthreads();
+    if (wv < 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        acc_t[r] += red[0][wv][rr][el];
+        if (dual) acc_v[r] += red[1][wv][rr][el];
+      }
+    }
+    __syncthreads();
+  }
+  if (wv < 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      red[0][wv][rr][el] = acc_t[r];
+      if (dual) red[1][wv][rr][el] = acc_v[r];
+    }
+  }
+  __syncthreads();
+  if (!fin) return;
+  const int act = a.act, mode = a.mode;
+  f32x4 ov, ot, pv, pt;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int rr = 8 * wv + 4 * hi + v;
+    float st = 0.f, sv = 0.f;
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {      // wave order: deterministic
+      st += red[0][q2][rr][el];
+      if (dual) sv += red[1][q2][rr][el];
+    }
+    if (mode == SPK_DD_FWD) {
+      sv += bq[v];
+      pv[v] = sv; pt[v] = st;
+      if (a.fc) { ov[v] = sv * fcm; ot[v] = st * fcm + sv * fc1m; }
+      else { ov[v] = dd_act(act, 0, sv); ot[v] = dd_act(act, 1, sv) * st; }
+    } else if (mode == SPK_DD_TANGENT) {
+      pt[v] = st; pv[v] = 0.f; ov[v] = 0.f;
+      ot[v] = dd_act(act, 1, ev[v]) * st;
+    } else {      // SPK_DD_DUAL_BWD: (sv, st) = (g_z, h_z)
+      const float p = ev[v], a1v = dd_act(act, 1, p);
+      pv[v] = sv; pt[v] = st;
+      ov[v] = sv * a1v + st * dd_act(act, 2, p) * et[v];
+      ot[v] = st * a1v;
+    }
+  }
+  if (a.pre_v && dual) *(f32x4*)(a.pre_v + off) = pv;
+  if (a.pre_t) *(f32x4*)(a.pre_t + off) = pt;
+  if (dual) { ov += rv; *(f32x4*)(a.out_v + off) = ov; }
+  ot += rt;
+  *(f32x4*)(a.out_t + off) = ot;
+}
+
+extern "C" int spk_dense_dual_supported(int64_t m, int32_t k_in, int32_t n_out) {
+  if (m <= 0 || k_in <= 0 || n_out <= 0 || k_in % 4 || n_out % 4) return 0;
+  const int64_t ntasks = ((m + 31) / 32) * ((n_out + 31) / 32);
+  return ntasks <= 4 * (int64_t)spk_num_cus() && spk_get_variant() != SPK_VARIANT_SIMPLE;      // (the bound of the one-tile-per-workgroup Dense kernel)
+}
+
+extern "C" int spk_dense_dual_f32(const spk_dense_dual_t* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPK_CHECK_ARG(d != nullptr, "spk_dense_dual_f32: null description");
+  SPK_CHECK_ARG(d->m >= 0 && d->k_in > 0 && d->n_out > 0, "spk_dense_dual_f32: bad sizes");
+  if (d->m == 0) return SPK_OK;
+  SPK_CHECK_ARG(spk_dense_dual_supported(d->m, d->k_in, d->n_out), "spk_dense_dual_f32: shape m=%lld k=%d n=%d outside the pair kernel (see spk_dense_dual_supported)",
+                (long long)d->m, d->k_in, d->n_out);
+  SPK_CHECK_ARG(d->mode == SPK_DD_FWD || d->mode == SPK_DD_TANGENT || d->mode == SPK_DD_DUAL_BWD, "spk_dense_dual_f32: unknown mode %d", d->mode);
+  SPK_CHECK_ARG(d->act == SPK_ACT_NONE || d->act == SPK_ACT_SSP || d->act == SPK_ACT_SILU, "spk_dense_dual_f32: unknown activation %d", d->act);
+  SPK_CHECK_ARG(d->x_t && d->w && d->y_t, "spk_dense_dual_f32: null pointer");
+  SPK_CHECK_ARG((d->mode == SPK_DD_TANGENT) == (d->x_v == nullptr), "spk_dense_dual_f32: x_v is given in every mode but TANGENT");
+  SPK_CHECK_ARG(d->x_v == nullptr || d->y_v != nullptr, "spk_dense_dual_f32: y_v missing");
+  SPK_CHECK_ARG(d->mode == SPK_DD_FWD || d->pre_v_in != nullptr, "spk_dense_dual_f32: the saved pre-activation is missing");
+  SPK_CHECK_ARG(d->mode == SPK_DD_FWD || (!d->b && !d->fc), "spk_dense_dual_f32: bias / row scale belong to mode FWD");
+  SPK_CHECK_ARG(!d->fc || (d->fc1 && d->act == SPK_ACT_NONE), "spk_dense_dual_f32: the row scale needs fc1 and a linear layer");
+  SPK_CHECK_ARG(aligned16(d->x_v) && aligned16(d->x_t) && aligned16(d->w) && aligned16(d->res_v) && aligned16(d->res_t) && aligned16(d->pre_v_in) &&
+                    aligned16(d->pre_t_in) && aligned16(d->y_v) && aligned16(d->y_t) && aligned16(d->pre_v) && aligned16(d->pre_t),
+                "spk_dense_dual_f32: 16-byte alignment required");
+  DenseDualArgs a;
+  a.in_v = d->x_v; a.in_t = d->x_t; a.w = d->w; a.b = d->b; a.res_v = d->res_v; a.res_t = d->res_t; a.epre_v = d->pre_v_in; a.epre_t = d->pre_t_in;
+  a.fc = d->fc; a.fc1 = d->fc1; a.out_v = d->y_v; a.out_t = d->y_t; a.pre_v = d->pre_v; a.pre_t = d->pre_t;
+  a.M = d->m; a.KC = d->k_in; a.NW = d->n_out; a.act = d->act; a.mode = d->mode;
+  SpkProfScope prof(d->mode == SPK_DD_FWD ? "dense_dual_fwd" : (d->mode == SPK_DD_TANGENT ? "dense_tangent" : "dense_dual_bwd"), stream);
+  const unsigned nt = (unsigned)(((d->m + 31) / 32) * ((d->n_out + 31) / 32));
+  const int nug = (d->k_in + 7) / 8;
+#define SPK_DDL(T, CH, WV) hipLaunchKernelGGL((k_dense_dual_sk<T, CH, WV>), dim3(nt), dim3(64 * WV), 0, stream, a)
+  if (d->trans) {
+    if (nug <= 8) SPK_DDL(true, 2, 4);
+    else if (nug <= 16) SPK_DDL(true, 4, 4);
+    else SPK_DDL(true, 4, 8);
+  } else {
+    if (nug <= 8) SPK_DDL(false, 2, 4);
+    else if (nug <= 16) SPK_DDL(false, 4, 4);
+    else SPK_DDL(false, 4, 8);
+  }
+#undef SPK_DDL
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
 }

@@ -109,8 +109,21 @@ __global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_tn_batched(GemmTnBatch b
   GemmTnArgs a;
   a.U = b->a[p].U; a.X = b->a[p].X; a.n = b->a[p].n; a.O = b->a[p].O; a.K = b->a[p].K; a.tiles_k = b->a[p].tiles_k; a.S = b->a[p].S; a.n_tiles = b->a[p].n_tiles;
   a.rows_per_slice = b->a[p].rows_per_slice; a.rows_per_wave = b->a[p].rows_per_wave; a.nb = b->a[p].nb;
-  a.G = b->a[p].G; a.gb = b->a[p].gb; a.ws = b->a[p].ws; a.wsb = b->a[p].wsb; a.tickets = b->a[p].tickets;
+  a.G = b->a[p].G; a.gb = b->a[p].gb; a.ws = b->a[p].ws; a.wsb = b->a[p].wsb; a.tickets = b->a[p].tickets; a.defer = b->a[p].defer;
   gemm_tn_block(a, local % a.n_tiles, local / a.n_tiles);
+}
+// the sliced problems of a batch (S > 1, deferred): one workgroup per output tile adds the partial tiles up; prefix[] counts tiles here
+__global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_tn_batched_reduce(GemmTnBatch b_) {
+  typedef const __attribute__((address_space(4))) GemmTnBatch* BatchPtr;
+  BatchPtr b = (BatchPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)b_;
+  int p = 0;
+  const int n = b->n;
+  while (p + 1 < n && (int)blockIdx.x >= b->prefix[p + 1]) ++p;
+  GemmTnArgs a;
+  a.O = b->a[p].O; a.K = b->a[p].K; a.tiles_k = b->a[p].tiles_k; a.S = b->a[p].S; a.n_tiles = b->a[p].n_tiles;
+  a.G = b->a[p].G; a.gb = b->a[p].gb; a.ws = b->a[p].ws; a.wsb = b->a[p].wsb;
+  gemm_tn_reduce_block(a, (int)blockIdx.x - b->prefix[p]);
 }
 
 // ------------------------------------------------------------------------------------------------ device backend of the engine
@@ -155,7 +168,7 @@ struct FmDeviceBackend {
   float* gws = nullptr;
   uint32_t* tickets = nullptr;
   int max_blocks;
-  GemmTnBatch batch;
+  GemmTnBatch batch, rbatch;
   int64_t ws_used = 0;
   int tickets_used = 0;
   explicit FmDeviceBackend(hipStream_t s) : stream(s), main_stream(s), max_blocks(spk_num_cus() * 32) { batch.n = 0; batch.prefix[0] = 0; }
@@ -186,20 +199,36 @@ struct FmDeviceBackend {
     if (batch.n == 0) return SPK_OK;
     for (int k = 0; k < 16; ++k)       // the batch reads operands that side streams may still be producing
       if (pending & (1u << k)) wait(k);
-    SpkProfScope prof("gemm_tn_batched", stream);
-    hipLaunchKernelGGL(k_gemm_tn_batched, dim3(batch.prefix[batch.n]), dim3(64 * TN_WAVES), 0, stream, batch);
+    {
+      SpkProfScope prof("gemm_tn_batched", stream);
+      hipLaunchKernelGGL(k_gemm_tn_batched, dim3(batch.prefix[batch.n]), dim3(64 * TN_WAVES), 0, stream, batch);
+    }
+    rbatch.n = 0;
+    rbatch.prefix[0] = 0;
+    for (int p = 0; p < batch.n; ++p)
+      if (batch.a[p].S > 1) {
+        rbatch.a[rbatch.n] = batch.a[p];
+        rbatch.prefix[rbatch.n + 1] = rbatch.prefix[rbatch.n] + batch.a[p].n_tiles;
+        ++rbatch.n;
+      }
+    if (rbatch.n > 0) {
+      SpkProfScope prof("gemm_tn_batched_reduce", stream);
+      hipLaunchKernelGGL(k_gemm_tn_batched_reduce, dim3(rbatch.prefix[rbatch.n]), dim3(64 * TN_WAVES), 0, stream, rbatch);
+    }
     batch.n = 0;
     ws_used = 0;
     tickets_used = 0;
     SPK_LAUNCH_CHECK();
     return SPK_OK;
   }
-  // Slices of one problem meet through memory behind __threadfence() -- on this part an agent-scope release writes the XCD's L2 back, tens of
-  // microseconds when a few hundred workgroups do it (first batched version: 167 us for 15 us of work).  The batch as a whole already
-  // fills the chip, so a problem is cut into slices only when a slice still has >= 4096 rows: training-step sizes run with S = 1 (no fence).
+  // A workgroup walks its rows in batches of 32 per wave, one exposed memory round trip after the other: the pair-row problems of a step
+  // (5 120 rows, 20 batches per wave) took 45 us while the atom-row problems of the same launch were done after 5.  Rows are therefore cut
+  // into slices of ~1 024; the partial tiles of the slices are added up by a SECOND launch (k_gemm_tn_batched_reduce), not inside the first:
+  // meeting through memory behind __threadfence() costs an L2 write-back per workgroup on this part (first batched version: 167 us for
+  // 15 us of work), a kernel boundary costs ~4 us once.
   static void tn_plan(int64_t n, int O, int K, int32_t* S, int64_t* wsf, int32_t* tiles) {
     *tiles = ((O + 31) / 32) * ((K + 31) / 32);
-    int64_t s = n / 4096;
+    int64_t s = (n + 512) / 1024;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     *S = (int32_t)s;
@@ -221,6 +250,70 @@ struct FmDeviceBackend {
   int dense_bwd_input(const float* dy, const float* pre, const float* w, const float* res, float* dx, int64_t m, int k, int n_out, int act) {
     return spk_dense_bwd_input_f32(dy, pre, w, res, dx, m, k, n_out, act, stream);
   }
+  // Dense layers on (value, tangent) pairs: ONE launch each (spk_dense_dual_f32) at training sizes; problems beyond the pair kernel's tile
+  // budget (and SPK_FM_NO_DUAL=1, the A/B switch) run as the two Dense launches and the element-wise launch they replace.
+  // MEASURED per use (scripts/gpu_fm_mask.sh, 8-frame aspirin step, SPK_FM_DUAL_MASK): the forward pair pays (SchNet 0.529 -> 0.507 ms:
+  // three launches of which two are Dense become one); the tangent alone is neutral (a Dense launch absorbs a ~1.5 us element-wise one);
+  // the reverse of the pair LOSES (SchNet +3 us, PaiNN +18 us per step: its epilogue evaluates act' and act'' behind the transposed-weight
+  // loads, longer than the Dense launch plus the short element-wise launch it replaces) -- default mask 3, the reverse stays separate.
+  static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+  bool dual_ok(int64_t M, int KC, int NW, int kind = 1) const {      // kind: 1 forward pair, 2 tangent alone, 4 reverse of the pair (SPK_FM_DUAL_MASK: tuning)
+    static const int mask = [] {
+      const char* e = getenv("SPK_FM_NO_DUAL");
+      if (e && e[0] == '1') return 0;
+      const char* m = getenv("SPK_FM_DUAL_MASK");
+      return m ? atoi(m) : 3;
+    }();
+    return (mask & kind) && spk_dense_dual_supported(M, KC, NW);
+  }
+  int dense_dual(const float* x2, const float* w, const float* b, float* y2, float* pre2, int64_t M, int k, int n_out, int act, const float* fc, const float* fc1) {
+    const float* xt = x2 + M * k;
+    float* yt = y2 + M * n_out;
+    float* pt = pre2 ? pre2 + M * n_out : nullptr;
+    if (dual_ok(M, k, n_out) && al16(xt) && al16(yt) && al16(pt)) {
+      spk_dense_dual_t d = {};
+      d.x_v = x2; d.x_t = xt; d.w = w; d.b = b; d.fc = fc; d.fc1 = fc1; d.y_v = y2; d.y_t = yt; d.pre_v = pre2; d.pre_t = pt;
+      d.m = M; d.k_in = k; d.n_out = n_out; d.act = act; d.mode = SPK_DD_FWD; d.trans = 0;
+      return spk_dense_dual_f32(&d, stream);
+    }
+    int rc;
+    if (fc) {
+      if ((rc = dense(x2, w, b, nullptr, y2, nullptr, M, k, n_out, FM_ACT_NONE))) return rc;
+      if ((rc = dense(xt, w, nullptr, nullptr, yt, nullptr, M, k, n_out, FM_ACT_NONE))) return rc;
+      flat("fm_filter_fc", k_fm_filter_fc<float>, M * n_out, y2, fc, fc1, M, n_out);
+      return SPK_OK;
+    }
+    SPK_CHECK_ARG(pre2 || act == FM_ACT_NONE, "fm engine: a Dense pair with an activation keeps its pre-activations");
+    if ((rc = dense(x2, w, b, nullptr, y2, pre2, M, k, n_out, act))) return rc;
+    if (act == FM_ACT_NONE) return dense(xt, w, nullptr, nullptr, yt, pt, M, k, n_out, FM_ACT_NONE);
+    if ((rc = dense(xt, w, nullptr, nullptr, pt, nullptr, M, k, n_out, FM_ACT_NONE))) return rc;
+    flat("fm_act_t", k_fm_act_tangent<float>, M * n_out, (const float*)pre2, (const float*)pt, M * n_out, act, yt);
+    return SPK_OK;
+  }
+  int dense_tangent(const float* xt, const float* w, const float* pre_v, float* yt, float* pre_t, int64_t M, int KC, int NW, int act, bool trans) {
+    if (dual_ok(M, KC, NW, 2) && al16(xt) && al16(pre_v) && al16(yt) && al16(pre_t)) {
+      spk_dense_dual_t d = {};
+      d.x_t = xt; d.w = w; d.pre_v_in = pre_v; d.y_t = yt; d.pre_t = pre_t;
+      d.m = M; d.k_in = KC; d.n_out = NW; d.act = act; d.mode = SPK_DD_TANGENT; d.trans = trans ? 1 : 0;
+      return spk_dense_dual_f32(&d, stream);
+    }
+    int rc = trans ? dense_bwd_input(xt, nullptr, w, nullptr, pre_t, M, NW, KC, FM_ACT_NONE) : dense(xt, w, nullptr, nullptr, pre_t, nullptr, M, KC, NW, FM_ACT_NONE);
+    if (rc) return rc;
+    flat("fm_act_t", k_fm_act_tangent<float>, M * NW, pre_v, (const float*)pre_t, M * NW, act, yt);
+    return SPK_OK;
+  }
+  int dense_dual_bwd(const float* g2, const float* w, const float* pre2, float* gx2, float* tmp2, int64_t M, int k, int n_out, int act) {
+    if (dual_ok(M, n_out, k, 4) && al16(g2 + M * n_out) && al16(pre2 + M * k) && al16(gx2 + M * k)) {
+      spk_dense_dual_t d = {};
+      d.x_v = g2; d.x_t = g2 + M * n_out; d.w = w; d.pre_v_in = pre2; d.pre_t_in = pre2 + M * k; d.y_v = gx2; d.y_t = gx2 + M * k;
+      d.m = M; d.k_in = n_out; d.n_out = k; d.act = act; d.mode = SPK_DD_DUAL_BWD; d.trans = 1;
+      return spk_dense_dual_f32(&d, stream);
+    }
+    int rc = dense_bwd_input(g2, nullptr, w, nullptr, tmp2, 2 * M, k, n_out, FM_ACT_NONE);
+    if (rc) return rc;
+    flat("fm_act_dual_bwd", k_fm_act_dual_bwd<float>, M * k, (const float*)tmp2, pre2, M * k, act, gx2);
+    return SPK_OK;
+  }
   // deferred: the problem joins the batch that gemm_flush() launches (the engine keeps U and X intact until then)
   int gemm_tn(const float* U, const float* X, int64_t n, int O, int K, float* G, float* gb, int64_t n_bias) {
     int32_t S, tiles;
@@ -233,6 +326,7 @@ struct FmDeviceBackend {
     }
     GemmTnArgs a = spk_gemm_tn_args(U, X, n, O, K, S, tiles, G, gb, gws ? gws + ws_used : nullptr, tickets + tickets_used);
     a.nb = n_bias;
+    a.defer = 1;
     batch.a[batch.n] = a;
     batch.prefix[batch.n + 1] = batch.prefix[batch.n] + tiles * S;
     ++batch.n;
@@ -306,13 +400,13 @@ static int fm_painn_model(const spk_painn_t* m, const spk_radial_t* rb, std::vec
 }
 
 // ------------------------------------------------------------------------------------------------ SchNet
-extern "C" int64_t spk_schnet_fm_workspace_bytes(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t N, int64_t E, int64_t M) {
-  if (!m || !head || !rb || N < 1 || E < 0 || M < 1) return -1;
+extern "C" int64_t spk_schnet_fm_workspace_bytes(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t N, int64_t E, int64_t M, int32_t n_types) {
+  if (!m || !head || !rb || N < 1 || E < 0 || M < 1 || n_types < 1) return -1;
   FmDeviceBackend be(nullptr);
   FmDev eng(be);
   FmDev::SchnetWs w;
   FmSchnetModel<float> mm{m->n_atom_basis, m->n_filters, m->n_interactions, nullptr};
-  eng.schnet_carve(nullptr, mm, rb->n_rbf, head->n_hidden, N, E, M, w);
+  eng.schnet_carve(nullptr, mm, rb->n_rbf, head->n_hidden, N, E, M, n_types, w);
   return (int64_t)w.bytes;
 }
 extern "C" int64_t spk_schnet_fm_grad_floats(const spk_schnet_t* m, const spk_head_t* head, const spk_radial_t* rb, int32_t n_types) {
@@ -353,14 +447,14 @@ extern "C" int spk_schnet_fm_backward_f32(const spk_schnet_t* m, const spk_head_
 }
 
 // ------------------------------------------------------------------------------------------------ PaiNN
-extern "C" int64_t spk_painn_fm_workspace_bytes(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t N, int64_t E, int64_t M) {
-  if (!m || !head || !rb || N < 1 || E < 0 || M < 1 || m->n_interactions < 1 || !m->layers) return -1;
+extern "C" int64_t spk_painn_fm_workspace_bytes(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int64_t N, int64_t E, int64_t M, int32_t n_types) {
+  if (!m || !head || !rb || N < 1 || E < 0 || M < 1 || n_types < 1 || m->n_interactions < 1 || !m->layers) return -1;
   FmDeviceBackend be(nullptr);
   FmDev eng(be);
   FmDev::PainnWs w;
   const bool shared = m->n_interactions > 1 && m->layers[1].filt_w == m->layers[0].filt_w;
   FmPainnModel<float> mm{m->n_atom_basis, m->n_interactions, shared ? 1 : 0, m->epsilon, nullptr, nullptr, nullptr};
-  eng.painn_carve(nullptr, mm, rb->n_rbf, head->n_hidden, N, E, M, w);
+  eng.painn_carve(nullptr, mm, rb->n_rbf, head->n_hidden, N, E, M, n_types, w);
   return (int64_t)w.bytes;
 }
 extern "C" int64_t spk_painn_fm_grad_floats(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, int32_t n_types) {

@@ -54,8 +54,10 @@ struct FmCommonWs {
   void* plan_tmp;
   T *d, *u, *fc, *fc1, *phi2, *dt, *ut, *gd, *gu, *gr;
   T *preh2, *th2, *e_atom, *gt2, *gpre2, *gEa2;
+  T* onehot;      // [N, n_types] one-hot rows of Z: operand of the embedding table's gradient
   T* gemm_ws;
   uint32_t* tickets;
+  int64_t zero_words;
 };
 
 // flat gradient layouts (floats): SchNet  [per interaction: the nine tensors of spk_schnet_layer_t] | head w1 b1 w2 b2 | embedding
@@ -77,9 +79,14 @@ struct FmEngine {
   explicit FmEngine(B& b) : be(b) {}
 
   // ------------------------------------------------------------------------------------------------ shared pieces
-  void carve_common(FmArena& a, FmCommonWs<T>& w, int64_t N, int64_t E, int64_t M, int K, int H, bool painn, int64_t gemm_ws_floats) {
-    w.tickets = a.take<uint32_t>(4096 + 64);              // [4096] ticket counters of the weight-gradient GEMM | [64] e_act (zeroed together)
+  void carve_common(FmArena& a, FmCommonWs<T>& w, int64_t N, int64_t E, int64_t M, int K, int H, int n_types, bool painn, int64_t gemm_ws_floats) {
+    // zeroed together by ONE launch in prepare(): [4096] ticket counters of the weight-gradient GEMM | [64] e_act | gd [E] | gu [3 E] (pass B accumulates into them)
+    const size_t z0 = a.off;
+    w.tickets = a.take<uint32_t>(4096 + 64);
     w.e_act = (int32_t*)(w.tickets ? w.tickets + 4096 : nullptr);
+    w.gd = a.take<T>(E);
+    w.gu = painn ? a.take<T>(3 * E) : nullptr;
+    w.zero_words = (int64_t)((a.off - z0) / 4);
     w.rowptr = a.take<int32_t>(N + 1);
     w.rowptr_m = a.take<int32_t>(M + 1);
     w.colptr = a.take<int32_t>(N + 2);
@@ -89,22 +96,22 @@ struct FmEngine {
     w.plan_tmp = a.take<char>((int64_t)be.transpose_tmp_bytes(E, N));
     w.d = a.take<T>(E); w.u = a.take<T>(3 * E); w.fc = a.take<T>(E); w.fc1 = a.take<T>(E);
     w.phi2 = a.take<T>(2 * E * K);
-    w.dt = a.take<T>(E); w.gd = a.take<T>(E);
+    w.dt = a.take<T>(E);
     w.ut = painn ? a.take<T>(3 * E) : nullptr;
-    w.gu = painn ? a.take<T>(3 * E) : nullptr;
     w.preh2 = a.take<T>(2 * N * H); w.th2 = a.take<T>(2 * N * H); w.e_atom = a.take<T>(N);
     w.gt2 = a.take<T>(2 * N * H); w.gpre2 = a.take<T>(2 * N * H); w.gEa2 = a.take<T>(2 * N);
+    w.onehot = a.take<T>(N * (int64_t)n_types);
     w.gemm_ws = a.take<T>(gemm_ws_floats);
   }
 
   int prepare(const FmBatch<T>& b, const FmRadial<T>& rb, FmCommonWs<T>& w, int32_t* err) {
     int rc;
-    if ((rc = be.zero_u32(w.tickets, 4096 + 64))) return rc;
+    if ((rc = be.zero_u32(w.tickets, w.zero_words))) return rc;
     if ((rc = be.rowptr(b.ii, b.E, b.N, w.rowptr, err))) return rc;
     if ((rc = be.rowptr(b.idx_m, b.N, b.M, w.rowptr_m, err))) return rc;
     if ((rc = be.transpose_plan(b.jj, b.E, b.N, w.colptr, w.perm, w.plan_tmp))) return rc;
     be.flat("fm_colsrc", k_fm_colsrc<T>, b.E, w.perm, b.ii, b.E, b.N, w.csrc, (T*)nullptr);
-    be.flat("fm_geom", k_fm_geom<T>, b.E, b.R, b.off, b.ii, b.jj, b.E, b.N, rb, w.d, w.u, w.fc, w.fc1, w.phi2, w.e_act);
+    be.flat("fm_geom", k_fm_geom<T>, b.E * rb.n_rbf, b.R, b.off, b.ii, b.jj, b.E, b.N, rb, w.d, w.u, w.fc, w.fc1, w.phi2, w.e_act);
     return 0;
   }
 
@@ -125,10 +132,7 @@ struct FmEngine {
   }
   int head_tangent(const FmBatch<T>& b, const FmHead<T>& hd, int F, const T* xt, FmCommonWs<T>& w) {
     const int H = hd.n_hidden;
-    int rc;
-    if ((rc = be.dense(xt, hd.w1, nullptr, nullptr, w.preh2 + b.N * H, nullptr, b.N, F, H, FM_ACT_NONE))) return rc;
-    be.flat("fm_act_t", k_fm_act_tangent<T>, b.N * H, w.preh2, w.preh2 + b.N * H, b.N * H, hd.act, w.th2 + b.N * H);
-    return 0;
+    return be.dense_tangent(xt, hd.w1, w.preh2, w.th2 + b.N * H, w.preh2 + b.N * H, b.N, F, H, hd.act, false);
   }
   // reverse of the dual head: S = sum_i gE_i e_i + sum_i et_i; x2 = [x ; xt]; -> gx2 = [gx ; hx] [2N, F] and the head's gradients
   int head_dual_backward(const FmBatch<T>& b, const FmHead<T>& hd, int F, const T* x2, const T* gE, FmCommonWs<T>& w, T* gx2, T* g_head) {
@@ -141,9 +145,7 @@ struct FmEngine {
     int rc;
     be.flat("fm_gather1", k_fm_gather1<T>, N, gE, b.idx_m, N, b.M, w.gEa2, w.gEa2 + N);
     if ((rc = be.gemm_tn(w.gEa2, w.th2, 2 * N, 1, H, g_w2, g_b2, N))) return rc;
-    be.flat("fm_bcast", k_fm_bcast_rows<T>, N * H, hd.w2, (const T*)w.gEa2, (const int64_t*)nullptr, N, H, N, w.gt2);
-    be.flat("fm_bcast", k_fm_bcast_rows<T>, N * H, hd.w2, (const T*)nullptr, (const int64_t*)nullptr, N, H, (int64_t)0, w.gt2 + N * H);
-    be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, N * H, w.gt2, w.preh2, N * H, hd.act, w.gpre2);
+    be.flat("fm_head_dual_cot", k_fm_head_dual_cot<T>, N * H, hd.w2, (const T*)w.gEa2, (const T*)w.preh2, N, H, hd.act, w.gpre2);
     if ((rc = be.gemm_tn(w.gpre2, x2, 2 * N, H, F, g_w1, g_b1, N))) return rc;
     return be.dense_bwd_input(w.gpre2, nullptr, hd.w1, nullptr, gx2, 2 * N, F, H, FM_ACT_NONE);
   }
@@ -156,13 +158,13 @@ struct FmEngine {
     T *gs2, *gy2, *gz2;
     size_t bytes;
   };
-  void schnet_carve(void* base, const FmSchnetModel<T>& m, int K, int H, int64_t N, int64_t E, int64_t M, SchnetWs& w) {
+  void schnet_carve(void* base, const FmSchnetModel<T>& m, int K, int H, int64_t N, int64_t E, int64_t M, int n_types, SchnetWs& w) {
     FmArena a(base);
     const int F = m.F, nf = m.nf, L = m.L;
     int64_t gw = 0;      // the weight-gradient GEMMs of a pass run concurrently (one batched launch): their slice workspaces add up
     auto need = [&](int64_t n, int O, int Kk, int times) { gw += times * be.gemm_tn_ws_floats(n, O, Kk); };
-    need(2 * N, 1, H, 1); need(2 * N, H, F, 1); need(2 * N, F, F, L); need(2 * N, F, nf, L); need(2 * E, nf, nf, L); need(2 * E, nf, K, L); need(2 * N, nf, F, L);
-    carve_common(a, w.c, N, E, M, K, H, false, gw);
+    need(N, n_types, F, 1); need(2 * N, 1, H, 1); need(2 * N, H, F, 1); need(2 * N, F, F, L); need(2 * N, F, nf, L); need(2 * E, nf, nf, L); need(2 * E, nf, K, L); need(2 * N, nf, F, L);
+    carve_common(a, w.c, N, E, M, K, H, n_types, false, gw);
     w.X2.resize(L + 1);
     for (int l = 0; l <= L; ++l) w.X2[l] = a.take<T>(2 * N * F);
     w.h2.resize(L); w.a2.resize(L); w.z2.resize(L); w.Wf2.resize(L); w.y2.resize(L); w.p32.resize(L); w.s2.resize(L);
@@ -185,11 +187,11 @@ struct FmEngine {
     SchnetWs w;
     const int F = m.F, nf = m.nf, L = m.L, K = rb.n_rbf;
     const int64_t N = b.N, E = b.E;
-    schnet_carve(ws, m, K, hd.n_hidden, N, E, b.M, w);
+    schnet_carve(ws, m, K, hd.n_hidden, N, E, b.M, b.n_types, w);
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
     if ((rc = prepare(b, rb, w.c, err))) return rc;
-    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.X2[0]);
+    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.X2[0], w.c.onehot);
     // ---- pass A.  The filter networks depend on the geometry only: they are issued first, on two side streams (interactions alternate),
     // and the atom chain on the main stream waits for interaction l's filters in front of its convolution.
     const bool par = be.can_fork(L);
@@ -198,12 +200,9 @@ struct FmEngine {
       T *a2 = w.a2[l], *z2 = w.z2[l], *Wf2 = w.Wf2[l];
       if (par) be.fork(l & 1);
       // filter network, value and d-derivative (schnet.py:61): a = phi W1^T + b1, a1 = phi1 W1^T; z = ssp(a), z1 = ssp'(a) a1; g = z W2^T + b2, g1 = z1 W2^T
-      if ((rc = be.dense(w.c.phi2, P.fn_w1, P.fn_b1, nullptr, z2, a2, E, K, nf, FM_ACT_SSP))) return rc;
-      if ((rc = be.dense(w.c.phi2 + E * K, P.fn_w1, nullptr, nullptr, a2 + E * nf, nullptr, E, K, nf, FM_ACT_NONE))) return rc;
-      be.flat("fm_act_t", k_fm_act_tangent<T>, E * nf, a2, a2 + E * nf, E * nf, FM_ACT_SSP, z2 + E * nf);
-      if ((rc = be.dense(z2, P.fn_w2, P.fn_b2, nullptr, Wf2, nullptr, E, nf, nf, FM_ACT_NONE))) return rc;
-      if ((rc = be.dense(z2 + E * nf, P.fn_w2, nullptr, nullptr, Wf2 + E * nf, nullptr, E, nf, nf, FM_ACT_NONE))) return rc;
-      be.flat("fm_filter_fc", k_fm_filter_fc<T>, E * nf, Wf2, w.c.fc, w.c.fc1, E, nf);
+      // (each a Dense layer on the (value, d-derivative) pair: one launch, the activation / cutoff product in its epilogue)
+      if ((rc = be.dense_dual(w.c.phi2, P.fn_w1, P.fn_b1, z2, a2, E, K, nf, FM_ACT_SSP, nullptr, nullptr))) return rc;
+      if ((rc = be.dense_dual(z2, P.fn_w2, P.fn_b2, Wf2, nullptr, E, nf, nf, FM_ACT_NONE, w.c.fc, w.c.fc1))) return rc;
       if (par) be.back(l);
     }
     for (int l = 0; l < L; ++l) {
@@ -219,7 +218,6 @@ struct FmEngine {
     if (!F_out) return 0;
     T *gxa = w.GX[L], *gxb = w.GX[0], *ghb = w.gh2[0];                      // pass B borrows pass-D buffers (it ends before D starts)
     if ((rc = head_backward_R(b, hd, F, w.c, gxa))) return rc;              // ---- pass B
-    be.flat("fm_zero", k_fm_zero<T>, E, w.c.gd, E);
     for (int l = L - 1; l >= 0; --l) {
       const FmSchnetLayer<T>& P = m.layers[l];
       if ((rc = be.dense_bwd_input(gxa, nullptr, P.f2out_w2, nullptr, w.gs2, N, F, F, FM_ACT_NONE))) return rc;
@@ -241,7 +239,7 @@ struct FmEngine {
     SchnetWs w;
     const int F = m.F, nf = m.nf, L = m.L, K = rb.n_rbf, H = hd.n_hidden;
     const int64_t N = b.N, E = b.E;
-    schnet_carve(ws, m, K, H, N, E, b.M, w);
+    schnet_carve(ws, m, K, H, N, E, b.M, b.n_types, w);
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
     be.flat("fm_tgeom", k_fm_tgeom<T>, E, gF, b.ii, b.jj, w.c.d, w.c.u, E, N, w.c.dt, (T*)nullptr);
@@ -250,8 +248,7 @@ struct FmEngine {
       T* ht = l > 0 ? w.h2[l] + N * nf : nullptr;
       if (l > 0 && (rc = be.dense(w.X2[l] + N * F, P.in2f_w, nullptr, nullptr, ht, nullptr, N, F, nf, FM_ACT_NONE))) return rc;
       be.flat("fm_cfconv_t", k_fm_cfconv_t<T>, N * nf, w.h2[l], (const T*)ht, w.Wf2[l], w.Wf2[l] + E * nf, w.c.dt, w.c.rowptr, b.jj, w.c.e_act, N, nf, w.y2[l] + N * nf);
-      if ((rc = be.dense(w.y2[l] + N * nf, P.f2out_w1, nullptr, nullptr, w.p32[l] + N * F, nullptr, N, nf, F, FM_ACT_NONE))) return rc;
-      be.flat("fm_act_t", k_fm_act_tangent<T>, N * F, w.p32[l], w.p32[l] + N * F, N * F, FM_ACT_SSP, w.s2[l] + N * F);
+      if ((rc = be.dense_tangent(w.y2[l] + N * nf, P.f2out_w1, w.p32[l], w.s2[l] + N * F, w.p32[l] + N * F, N, nf, F, FM_ACT_SSP, false))) return rc;
       if ((rc = be.dense(w.s2[l] + N * F, P.f2out_w2, nullptr, l > 0 ? w.X2[l] + N * F : nullptr, w.X2[l + 1] + N * F, nullptr, N, F, F, FM_ACT_NONE))) return rc;
     }
     if ((rc = head_tangent(b, hd, F, w.X2[L] + N * F, w.c))) return rc;
@@ -275,8 +272,7 @@ struct FmEngine {
       T *gx = w.GX[l + 1], *gp2 = w.gp2[l], *gh2 = w.gh2[l], *gg2 = w.gg2[l], *ga2 = w.ga2[l];
       const int64_t nr = l > 0 ? 2 * N : N;      // rows that carry a tangent partner at the INPUT of this interaction (xt_0 = 0)
       if ((rc = be.gemm_tn(gx, w.s2[l], 2 * N, F, F, g_o2, g_ob2, N))) return rc;
-      if ((rc = be.dense_bwd_input(gx, nullptr, P.f2out_w2, nullptr, w.gs2, 2 * N, F, F, FM_ACT_NONE))) return rc;
-      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, N * F, w.gs2, w.p32[l], N * F, FM_ACT_SSP, gp2);
+      if ((rc = be.dense_dual_bwd(gx, P.f2out_w2, w.p32[l], gp2, w.gs2, N, F, F, FM_ACT_SSP))) return rc;
       if ((rc = be.gemm_tn(gp2, w.y2[l], 2 * N, F, nf, g_o1, g_ob1, N))) return rc;
       if ((rc = be.dense_bwd_input(gp2, nullptr, P.f2out_w1, nullptr, w.gy2, 2 * N, nf, F, FM_ACT_NONE))) return rc;
       be.flat("fm_cfconv_T_dual", k_fm_cfconv_T_dual<T>, N * nf, w.gy2, w.Wf2[l], w.c.dt, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, E, nf, gh2);
@@ -286,17 +282,15 @@ struct FmEngine {
       // the reverse of the filter network feeds only weight gradients (deferred to the batched launch): off the atom chain, on ONE side
       // stream for all interactions (they share the scratch gz2)
       if (parD) be.fork(0);
-      if ((rc = be.dense_bwd_input(gg2, nullptr, P.fn_w2, nullptr, w.gz2, 2 * E, nf, nf, FM_ACT_NONE))) return rc;
-      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, E * nf, w.gz2, w.a2[l], E * nf, FM_ACT_SSP, ga2);
+      if ((rc = be.dense_dual_bwd(gg2, P.fn_w2, w.a2[l], ga2, w.gz2, E, nf, nf, FM_ACT_SSP))) return rc;
       if (parD) be.back(l);
       if ((rc = be.gemm_tn(ga2, w.c.phi2, 2 * E, nf, K, g_w1, g_b1, E))) return rc;
       if ((rc = be.gemm_tn(gh2, w.X2[l], nr, nf, F, g_in2f, nullptr, nr))) return rc;
       if ((rc = be.dense_bwd_input(gh2, nullptr, P.in2f_w, gx, w.GX[l], nr, F, nf, FM_ACT_NONE))) return rc;
     }
     if (parD) for (int l = 0; l < L; ++l) be.wait(l);
-    if ((rc = be.gemm_flush())) return rc;
-    be.flat("fm_embed_grad", k_fm_embed_grad<T>, (int64_t)b.n_types * F, w.GX[0], b.Z, N, F, b.n_types, g_emb);
-    return 0;
+    if ((rc = be.gemm_tn(w.c.onehot, w.GX[0], N, b.n_types, F, g_emb, nullptr, N))) return rc;      // embedding table: onehot(Z)^T gx_0
+    return be.gemm_flush();
   }
 
   // ================================================================================================ PaiNN
@@ -308,14 +302,14 @@ struct FmEngine {
     T *gq_a, *gq_b, *gmu_a, *gmu_b, *gsb2, *gctx2, *gq1_2, *gmu1_2, *gsa2, *gtmp;
     size_t bytes;
   };
-  void painn_carve(void* base, const FmPainnModel<T>& m, int K, int H, int64_t N, int64_t E, int64_t M, PainnWs& w) {
+  void painn_carve(void* base, const FmPainnModel<T>& m, int K, int H, int64_t N, int64_t E, int64_t M, int n_types, PainnWs& w) {
     FmArena a(base);
     const int F = m.F, L = m.L;
     const int64_t ld = 3ll * F * (m.shared_filters ? 1 : L);
     int64_t gw = 0;
     auto need = [&](int64_t n, int O, int Kk, int times) { gw += times * be.gemm_tn_ws_floats(n, O, Kk); };
-    need(2 * N, 1, H, 1); need(2 * N, H, F, 1); need(2 * N, 3 * F, F, 2 * L); need(2 * N, F, 2 * F, L); need(6 * N, 2 * F, F, L); need(2 * E, 3 * F, K, L); need(2 * N, F, F, L);
-    carve_common(a, w.c, N, E, M, K, H, true, gw);
+    need(N, n_types, F, 1); need(2 * N, 1, H, 1); need(2 * N, H, F, 1); need(2 * N, 3 * F, F, 2 * L); need(2 * N, F, 2 * F, L); need(6 * N, 2 * F, F, L); need(2 * E, 3 * F, K, L); need(2 * N, F, F, L);
+    carve_common(a, w.c, N, E, M, K, H, n_types, true, gw);
     w.Phi2 = a.take<T>(2 * E * ld);
     auto vec = [&](std::vector<T*>& v, int n, int64_t floats) { v.resize(n); for (int l = 0; l < n; ++l) v[l] = a.take<T>(floats); };
     vec(w.Q2, L + 1, 2 * N * F);
@@ -336,7 +330,7 @@ struct FmEngine {
     const int F = m.F, L = m.L, K = rb.n_rbf;
     const int64_t N = b.N, E = b.E;
     const int ld = 3 * F * (m.shared_filters ? 1 : L);
-    painn_carve(ws, m, K, hd.n_hidden, N, E, b.M, w);
+    painn_carve(ws, m, K, hd.n_hidden, N, E, b.M, b.n_types, w);
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
     if ((rc = prepare(b, rb, w.c, err))) return rc;
@@ -344,11 +338,9 @@ struct FmEngine {
     // stream, beside the embedding and the first context net (they meet in front of the first message)
     const bool par = be.can_fork(1);
     if (par) be.fork(0);
-    if ((rc = be.dense(w.c.phi2, m.filt_w, m.filt_b, nullptr, w.Phi2, nullptr, E, K, ld, FM_ACT_NONE))) return rc;
-    if ((rc = be.dense(w.c.phi2 + E * K, m.filt_w, nullptr, nullptr, w.Phi2 + E * (int64_t)ld, nullptr, E, K, ld, FM_ACT_NONE))) return rc;
-    be.flat("fm_filter_fc", k_fm_filter_fc<T>, E * (int64_t)ld, w.Phi2, w.c.fc, w.c.fc1, E, ld);
+    if ((rc = be.dense_dual(w.c.phi2, m.filt_w, m.filt_b, w.Phi2, nullptr, E, K, ld, FM_ACT_NONE, w.c.fc, w.c.fc1))) return rc;
     if (par) be.back(0);
-    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.Q2[0]);
+    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.Q2[0], w.c.onehot);
     for (int l = 0; l < L; ++l) {                                            // ---- pass A
       const FmPainnLayer<T>& P = m.layers[l];
       const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);
@@ -366,8 +358,6 @@ struct FmEngine {
     if ((rc = head_forward(b, hd, F, w.Q2[L], w.c, E_out, err))) return rc;
     if (!F_out) return 0;
     if ((rc = head_backward_R(b, hd, F, w.c, w.gq_a))) return rc;           // ---- pass B
-    be.flat("fm_zero", k_fm_zero<T>, E, w.c.gd, E);
-    be.flat("fm_zero", k_fm_zero<T>, 3 * E, w.c.gu, 3 * E);
     const T* gmu = nullptr;                                                  // the head does not read the vector representation
     T *ga = w.ga2[0], *gVW = w.gVW2[0], *gc = w.gc2[0];                      // pass B borrows pass-D buffers (it ends before D starts)
     for (int l = L - 1; l >= 0; --l) {
@@ -400,7 +390,7 @@ struct FmEngine {
     const int64_t N = b.N, E = b.E;
     const int Lf = m.shared_filters ? 1 : L;
     const int ld = 3 * F * Lf;
-    painn_carve(ws, m, K, H, N, E, b.M, w);
+    painn_carve(ws, m, K, H, N, E, b.M, b.n_types, w);
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
     be.flat("fm_tgeom", k_fm_tgeom<T>, E, gF, b.ii, b.jj, w.c.d, w.c.u, E, N, w.c.dt, w.c.ut);
@@ -410,16 +400,14 @@ struct FmEngine {
       const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);
       const int first = l == 0;
       if (!first) {
-        if ((rc = be.dense(w.Q2[l] + NF, P.ctx_w1, nullptr, nullptr, w.pa2[l] + NF, nullptr, N, F, F, FM_ACT_NONE))) return rc;
-        be.flat("fm_act_t", k_fm_act_tangent<T>, NF, w.pa2[l], w.pa2[l] + NF, NF, FM_ACT_SILU, w.sa2[l] + NF);
+        if ((rc = be.dense_tangent(w.Q2[l] + NF, P.ctx_w1, w.pa2[l], w.sa2[l] + NF, w.pa2[l] + NF, N, F, F, FM_ACT_SILU, false))) return rc;
         if ((rc = be.dense(w.sa2[l] + NF, P.ctx_w2, nullptr, nullptr, w.c2[l] + 3 * NF, nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
       }
       be.flat("fm_painn_msg_t", k_fm_painn_msg_t<T>, NF, (const T*)(first ? nullptr : w.Q2[l] + NF), w.c2[l], (const T*)(first ? nullptr : w.MU2[l]), Phi, ld, E, w.c.dt,
               w.c.u, w.c.ut, w.c.rowptr, b.jj, w.c.e_act, N, F, first, w.q1_2[l] + NF, w.mu1_2[l] + 3 * NF);
       if ((rc = be.dense(w.mu1_2[l] + 3 * NF, P.mix_w, nullptr, nullptr, w.VW2[l] + 6 * NF, nullptr, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
       be.flat("fm_painn_mix_t", k_fm_painn_mix_t<T>, NF, w.q1_2[l] + NF, w.VW2[l], w.VW2[l] + 6 * NF, w.n2[l], N, F, w.n2[l] + NF, w.svw2[l] + NF, w.ctx2[l] + 2 * NF);
-      if ((rc = be.dense(w.ctx2[l] + 2 * NF, P.ictx_w1, nullptr, nullptr, w.pb2[l] + NF, nullptr, N, 2 * F, F, FM_ACT_NONE))) return rc;
-      be.flat("fm_act_t", k_fm_act_tangent<T>, NF, w.pb2[l], w.pb2[l] + NF, NF, FM_ACT_SILU, w.sb2[l] + NF);
+      if ((rc = be.dense_tangent(w.ctx2[l] + 2 * NF, P.ictx_w1, w.pb2[l], w.sb2[l] + NF, w.pb2[l] + NF, N, 2 * F, F, FM_ACT_SILU, false))) return rc;
       if ((rc = be.dense(w.sb2[l] + NF, P.ictx_w2, nullptr, nullptr, w.a2[l] + 3 * NF, nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
       be.flat("fm_painn_update_t", k_fm_painn_update_t<T>, NF, w.q1_2[l] + NF, w.mu1_2[l] + 3 * NF, w.VW2[l], w.VW2[l] + 6 * NF, w.a2[l], w.a2[l] + 3 * NF, w.svw2[l],
               w.svw2[l] + NF, N, F, w.Q2[l + 1] + NF, w.MU2[l + 1] + 3 * NF);
@@ -450,8 +438,7 @@ struct FmEngine {
       // mixing (painn.py:99-116)
       be.flat("fm_painn_update_dual_bwd", k_fm_painn_update_dual_bwd<T>, NF, w.gq_a, gmu2, w.VW2[l], w.a2[l], w.svw2[l], N, F, ga2, gVW2);
       if ((rc = be.gemm_tn(ga2, w.sb2[l], 2 * N, 3 * F, F, g_iw2, g_ib2, N))) return rc;
-      if ((rc = be.dense_bwd_input(ga2, nullptr, P.ictx_w2, nullptr, w.gsb2, 2 * N, F, 3 * F, FM_ACT_NONE))) return rc;
-      be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, NF, w.gsb2, w.pb2[l], NF, FM_ACT_SILU, gpb2);
+      if ((rc = be.dense_dual_bwd(ga2, P.ictx_w2, w.pb2[l], gpb2, w.gsb2, N, F, 3 * F, FM_ACT_SILU))) return rc;
       if ((rc = be.gemm_tn(gpb2, w.ctx2[l], 2 * N, F, 2 * F, g_iw1, g_ib1, N))) return rc;
       if ((rc = be.dense_bwd_input(gpb2, nullptr, P.ictx_w1, nullptr, w.gctx2, 2 * N, 2 * F, F, FM_ACT_NONE))) return rc;
       be.flat("fm_painn_mix_dual_bwd", k_fm_painn_mix_dual_bwd<T>, NF, w.gq_a, w.gctx2, w.VW2[l], w.n2[l], N, F, w.gq1_2, gVW2);
@@ -473,19 +460,19 @@ struct FmEngine {
               w.c.e_act, N, F, first, gc2, w.gmu_a);
       const int64_t nr = first ? N : 2 * N;
       if ((rc = be.gemm_tn(gc2, w.sa2[l], nr, 3 * F, F, g_cw2, g_cb2, N))) return rc;
-      if ((rc = be.dense_bwd_input(gc2, nullptr, P.ctx_w2, nullptr, w.gsa2, nr, F, 3 * F, FM_ACT_NONE))) return rc;
-      if (first) be.flat("fm_act_t", k_fm_act_tangent<T>, NF, w.pa2[l], w.gsa2, NF, FM_ACT_SILU, gpa2);
-      else be.flat("fm_act_dual_bwd", k_fm_act_dual_bwd<T>, NF, w.gsa2, w.pa2[l], NF, FM_ACT_SILU, gpa2);
+      // (the first interaction has no tangent at its input: only the value cotangent flows, g_a = act'(a) g_s)
+      if (first) { if ((rc = be.dense_tangent(gc2, P.ctx_w2, w.pa2[l], gpa2, w.gsa2, N, 3 * F, F, FM_ACT_SILU, true))) return rc; }
+      else if ((rc = be.dense_dual_bwd(gc2, P.ctx_w2, w.pa2[l], gpa2, w.gsa2, N, F, 3 * F, FM_ACT_SILU))) return rc;
       if ((rc = be.gemm_tn(gpa2, w.Q2[l], nr, F, F, g_cw1, g_cb1, N))) return rc;
       if ((rc = be.dense_bwd_input(gpa2, nullptr, P.ctx_w1, w.gq1_2, w.gq_a, nr, F, F, FM_ACT_NONE))) return rc;
       gmu2 = w.gmu_a;
       T* t = w.gmu_a; w.gmu_a = w.gmu_b; w.gmu_b = t;
     }
+    if ((rc = be.gemm_tn(w.c.onehot, w.gq_a, N, b.n_types, F, g_emb, nullptr, N))) return rc;      // embedding table: onehot(Z)^T gq_0
     if ((rc = be.gemm_flush())) return rc;
     if (m.shared_filters)
       for (int l = 0; l < L - 1; ++l)
         be.flat("fm_axpy", k_fm_axpy<T>, 3ll * F * K + 3 * F, w.gtmp + (int64_t)l * (3ll * F * K + 3 * F), 3ll * F * K + 3 * F, g_fw);   // (g_fw and g_fb are adjacent when Lf == 1)
-    be.flat("fm_embed_grad", k_fm_embed_grad<T>, (int64_t)b.n_types * F, w.gq_a, b.Z, N, F, b.n_types, g_emb);
     return 0;
   }
 };

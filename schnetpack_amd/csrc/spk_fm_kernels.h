@@ -24,6 +24,7 @@
 #define FM_FOR_LANES(f, F) for (int f = 0; f < (int)(F); ++f)
 #define FM_WAVE_SUM(x) (x)
 #define FM_IF_LANE0
+#define FM_LAST_LANE_WITH(cond) (cond)
 #else
 #define FM_KERNEL __global__ __launch_bounds__(256)
 #define FM_HD __device__ __forceinline__
@@ -35,6 +36,13 @@
 #define FM_FOR_LANES(f, F) for (int f = threadIdx.x & 63; f < (int)(F); f += 64)
 #define FM_WAVE_SUM(x) fm_wave_sum(x)
 #define FM_IF_LANE0 if ((threadIdx.x & 63) == 0)
+// true on the highest active lane of the wavefront on which `cond` holds (one atomic per wavefront instead of one per lane: 2 560 atomic
+// maxima on ONE address cost k_fm_geom ~10 of its 14 us -- they serialise at the L2)
+#define FM_LAST_LANE_WITH(cond) fm_last_lane_with(cond)
+__device__ __forceinline__ bool fm_last_lane_with(bool cond) {
+  const unsigned long long m = __ballot(cond);
+  return cond && (int)(threadIdx.x & 63) == 63 - __builtin_clzll(m);
+}
 __device__ __forceinline__ float fm_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -91,8 +99,10 @@ struct FmRadial {   // nn/radial.py:18-48 (Gaussian: p0 = offsets, p1 = widths),
 // ------------------------------------------------------------------------------------------------ geometry
 // d, u = r / d, f_c, f_c', phi2 = [phi ; phi'] for every pair (atomistic/distances.py:14-26, nn/radial.py, nn/cutoff.py)
 template <class T>
-FM_KERNEL void k_fm_geom(const T* R, const T* off, const int64_t* ii, const int64_t* jj, int64_t E, int64_t N, FmRadial<T> rb, T* d_out, T* u_out, T* fc_out,
-                         T* fc1_out, T* phi2, int32_t* e_act) {
+FM_KERNEL void k_fm_geom(const T* FM_R R, const T* FM_R off, const int64_t* FM_R ii, const int64_t* FM_R jj, int64_t E, int64_t N, FmRadial<T> rb, T* FM_R d_out,
+                         T* FM_R u_out, T* FM_R fc_out, T* FM_R fc1_out, T* FM_R phi2, int32_t* e_act) {
+  const T* FM_R p0 = rb.p0;
+  const T* FM_R p1 = rb.p1;
   FM_FOR(e, E) {
     int64_t i = ii[e], j = jj[e];
     const bool ok = (uint64_t)i < (uint64_t)N && (uint64_t)j < (uint64_t)N;
@@ -119,26 +129,39 @@ FM_KERNEL void k_fm_geom(const T* R, const T* off, const int64_t* ii, const int6
     fc1_out[e] = f1;
     // e_act = 1 + the last pair inside the cutoff: the row / column loops stop there (pairs behind it -- the inert tail that pads a
     // static-shape batch, train.pad_edges -- contribute exactly zero and would otherwise make the last atom's row hundreds of pairs long)
-    if (ok && d < rb.cutoff) FM_ATOMIC_MAX(e_act, (int32_t)(e + 1));
-    const int K = rb.n_rbf;
-    for (int k = 0; k < K; ++k) {
-      T phi, phi1;
-      if (rb.kind == 0) {
-        const T w = rb.p1[k];
-        const T c = -T(0.5) / (w * w);
-        const T t = d - rb.p0[k];
-        phi = fm_exp(c * t * t);
-        phi1 = T(2) * c * t * phi;
-      } else {
-        const T fr = rb.p0[k];
-        T s, c;
-        fm_sincos(fr * d, s, c);
-        if (d == 0) { phi = s; phi1 = 0; }
-        else { phi = s * inv; phi1 = (fr * c - phi) * inv; }
-      }
-      phi2[e * K + k] = phi;
-      phi2[(E + e) * K + k] = phi1;
+    if (FM_LAST_LANE_WITH(ok && d < rb.cutoff)) FM_ATOMIC_MAX(e_act, (int32_t)(e + 1));      // (pair indices ascend with the lane)
+  }
+  // basis values and d-derivatives: one thread per (pair, k) -- with the basis loop inside the per-pair thread the 2 560 pairs of a training
+  // batch were 40 wavefronts walking 20 exponentials and 40 strided stores each (12.6 us); d is recomputed here from cached loads
+  const int K = rb.n_rbf;
+  FM_FOR(t, E * K) {
+    const int64_t e = t / K;
+    const int k = (int)(t % K);
+    int64_t i = ii[e], j = jj[e];
+    if (!((uint64_t)i < (uint64_t)N && (uint64_t)j < (uint64_t)N)) { i = 0; j = 0; }
+    T d2 = 0;
+    for (int x = 0; x < 3; ++x) {
+      const T r = R[j * 3 + x] - R[i * 3 + x] + (off ? off[e * 3 + x] : T(0));
+      d2 += r * r;
     }
+    const T d = fm_sqrt(d2);
+    const T inv = d > 0 ? T(1) / d : T(0);
+    T phi, phi1;
+    if (rb.kind == 0) {
+      const T w = p1[k];
+      const T c = -T(0.5) / (w * w);
+      const T tt = d - p0[k];
+      phi = fm_exp(c * tt * tt);
+      phi1 = T(2) * c * tt * phi;
+    } else {
+      const T fr = p0[k];
+      T s, c;
+      fm_sincos(fr * d, s, c);
+      if (d == 0) { phi = s; phi1 = 0; }
+      else { phi = s * inv; phi1 = (fr * c - phi) * inv; }
+    }
+    phi2[t] = phi;
+    phi2[E * K + t] = phi1;
   }
 }
 
@@ -259,6 +282,18 @@ FM_KERNEL void k_fm_bcast_rows(const T* w, const T* s, const int64_t* idx, int64
     out[t] = w[t % H] * sc;
   }
 }
+// reverse of the dual head's last layer and activation in one pass: S = sum_i gE_i e_i + sum_i et_i gives the cotangents g_th = w2 gEa_i,
+// h_th = w2 of (th, th_t); through th = act(a), th_t = act'(a) a_t (k_fm_act_dual_bwd):  [g_a ; h_a] stacked [2 n H]
+template <class T>
+FM_KERNEL void k_fm_head_dual_cot(const T* w2, const T* gEa, const T* pre2, int64_t n, int H, int act, T* gpre2) {
+  FM_FOR(t, n * H) {
+    const T hz = w2[t % H], gz = hz * gEa[t / H];
+    const T a = pre2[t], at = pre2[n * H + t];
+    const T a1 = fm_act(act, 1, a);
+    gpre2[t] = gz * a1 + hz * fm_act(act, 2, a) * at;
+    gpre2[n * H + t] = hz * a1;
+  }
+}
 template <class T>
 FM_KERNEL void k_fm_gather1(const T* s, const int64_t* idx, int64_t n, int64_t n_s, T* out, T* ones) {
   FM_FOR(i, n) {
@@ -295,28 +330,17 @@ FM_KERNEL void k_fm_segsum1(const T* e_atom, const int32_t* rowptr_m, int64_t M,
 }
 
 // ------------------------------------------------------------------------------------------------ embedding
+// x = table[Z], and the one-hot rows of Z beside it ([N, n_types]): the gradient of the table, gtable[z, :] = sum_{i: Z_i = z} gx[i, :], is then
+// onehot^T gx -- one more problem of the batched weight-gradient launch instead of a kernel in which every (z, f) thread walks all atoms
+// (14.6 us for 168 atoms).  A number outside [0, n_types) reads nothing and its one-hot row is zero.
 template <class T>
-FM_KERNEL void k_fm_embed(const T* table, const int64_t* Z, int64_t N, int F, int n_types, T* x) {
+FM_KERNEL void k_fm_embed(const T* table, const int64_t* Z, int64_t N, int F, int n_types, T* x, T* onehot) {
   FM_FOR(t, N * F) {
     const int64_t z = Z[t / F];
     x[t] = (uint64_t)z < (uint64_t)n_types ? table[z * F + t % F] : T(0);
   }
-}
-// gtable[z, :] = sum_{i: Z_i = z} gx[i, :]   (fixed order: deterministic; the comparison is uniform over a wavefront)
-template <class T>
-FM_KERNEL void k_fm_embed_grad(const T* FM_R gx, const int64_t* FM_R Z, int64_t N, int F, int n_types, T* FM_R gtable) {
-  FM_FOR(t, (int64_t)n_types * F) {
-    const int64_t z = t / F;
-    const int f = (int)(t % F);
-    T acc = 0;
-    for (int64_t ib = 0; ib < N; ib += FM_CH) {
-      int64_t zz[FM_CH];
-      T v[FM_CH];
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) zz[q] = ib + q < N ? Z[ib + q] : -1;
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) v[q] = zz[q] == z ? gx[(ib + q) * F + f] : T(0);
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) acc += v[q];
-    }
-    gtable[t] = acc;
+  if (onehot) {
+    FM_FOR(t, N * n_types) onehot[t] = Z[t / n_types] == (int64_t)(t % n_types) ? T(1) : T(0);
   }
 }
 

@@ -91,8 +91,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> fm_forward_raw(bool painn, const Tens
   FmCall c;
   fm_setup(c, painn, emb, Z, R, off, ii, jj, im, n_mol, ws, head, n_filters, shared_filters, eps, rbf_kind, p0, p1, cutoff, head_act, who);
   c10::DeviceGuard guard(c.R.device());
-  const int64_t bytes = painn ? spk_painn_fm_workspace_bytes(&c.pm, &c.head, &c.rb, c.b.n_atoms, c.b.n_edges, n_mol)
-                              : spk_schnet_fm_workspace_bytes(&c.sm, &c.head, &c.rb, c.b.n_atoms, c.b.n_edges, n_mol);
+  const int64_t bytes = painn ? spk_painn_fm_workspace_bytes(&c.pm, &c.head, &c.rb, c.b.n_atoms, c.b.n_edges, n_mol, c.b.n_types)
+                              : spk_schnet_fm_workspace_bytes(&c.sm, &c.head, &c.rb, c.b.n_atoms, c.b.n_edges, n_mol, c.b.n_types);
   TORCH_CHECK(bytes > 0, who, ": bad sizes");
   Tensor wsb = at::empty({bytes}, c.R.options().dtype(at::kByte));
   Tensor Eo = at::empty({n_mol}, c.R.options()), Fo = at::empty({c.b.n_atoms, 3}, c.R.options());

@@ -66,6 +66,53 @@ struct EmuBackend {
     }
     return 0;
   }
+  // Dense on a (value, tangent) pair, rows stacked [2M] (the device runs these as one launch, spk_dense_dual_f32)
+  int dense_dual(const T* x2, const T* w, const T* b, T* y2, T* pre2, int64_t M, int k, int n_out, int act, const T* fc, const T* fc1) {
+    for (int64_t r = 0; r < M; ++r)
+      for (int o = 0; o < n_out; ++o) {
+        T pv = b ? b[o] : T(0), pt = 0;
+        for (int c = 0; c < k; ++c) {
+          pv += x2[r * k + c] * w[(int64_t)o * k + c];
+          pt += x2[(M + r) * k + c] * w[(int64_t)o * k + c];
+        }
+        if (pre2) { pre2[r * n_out + o] = pv; pre2[(M + r) * n_out + o] = pt; }
+        if (fc) {
+          y2[r * n_out + o] = pv * fc[r];
+          y2[(M + r) * n_out + o] = pt * fc[r] + pv * fc1[r];
+        } else {
+          y2[r * n_out + o] = fm_act(act, 0, pv);
+          y2[(M + r) * n_out + o] = fm_act(act, 1, pv) * pt;
+        }
+      }
+    return 0;
+  }
+  // yt = act'(pre_v) (xt W^T)  (trans: xt W with W [KC, NW]);  pre_t receives the product
+  int dense_tangent(const T* xt, const T* w, const T* pre_v, T* yt, T* pre_t, int64_t M, int KC, int NW, int act, bool trans) {
+    for (int64_t r = 0; r < M; ++r)
+      for (int o = 0; o < NW; ++o) {
+        T pt = 0;
+        for (int c = 0; c < KC; ++c) pt += xt[r * KC + c] * (trans ? w[(int64_t)c * NW + o] : w[(int64_t)o * KC + c]);
+        pre_t[r * NW + o] = pt;
+        yt[r * NW + o] = fm_act(act, 1, pre_v[r * NW + o]) * pt;
+      }
+    return 0;
+  }
+  // [g_z ; h_z] = g2 W  (g2 [2M, n_out], W [n_out, k]), then the reverse of the activation pair at pre2 = [a ; a_t] ([2M, k])
+  int dense_dual_bwd(const T* g2, const T* w, const T* pre2, T* gx2, T* tmp2, int64_t M, int k, int n_out, int act) {
+    (void)tmp2;
+    for (int64_t r = 0; r < M; ++r)
+      for (int c = 0; c < k; ++c) {
+        T gz = 0, hz = 0;
+        for (int o = 0; o < n_out; ++o) {
+          gz += g2[r * n_out + o] * w[(int64_t)o * k + c];
+          hz += g2[(M + r) * n_out + o] * w[(int64_t)o * k + c];
+        }
+        const T a = pre2[r * k + c], at = pre2[(M + r) * k + c], a1 = fm_act(act, 1, a);
+        gx2[r * k + c] = gz * a1 + hz * fm_act(act, 2, a) * at;
+        gx2[(M + r) * k + c] = hz * a1;
+      }
+    return 0;
+  }
   // the weight-gradient GEMMs are DEFERRED to gemm_flush() exactly like on the device (one batched launch at the end of a pass): an operand
   // buffer that the engine overwrites before the flush would give wrong gradients here too
   struct Tn { const T* U; const T* X; int64_t n; int O, K; T* G; T* gb; int64_t nb; };
@@ -158,12 +205,12 @@ static int64_t ws_bytes(const EmuDesc* d) {
   if (d->kind == 0) {
     typename FmEngine<T, EmuBackend<T>>::SchnetWs w;
     FmSchnetModel<T> m{d->F, d->nf, d->L, nullptr};
-    eng.schnet_carve(nullptr, m, d->K, d->H, d->N, d->E, d->M, w);
+    eng.schnet_carve(nullptr, m, d->K, d->H, d->N, d->E, d->M, d->n_types, w);
     return (int64_t)w.bytes;
   }
   typename FmEngine<T, EmuBackend<T>>::PainnWs w;
   FmPainnModel<T> m{d->F, d->L, d->shared, (T)d->eps, nullptr, nullptr, nullptr};
-  eng.painn_carve(nullptr, m, d->K, d->H, d->N, d->E, d->M, w);
+  eng.painn_carve(nullptr, m, d->K, d->H, d->N, d->E, d->M, d->n_types, w);
   return (int64_t)w.bytes;
 }
 

@@ -255,6 +255,84 @@ def test_dense_forward_backward(dev, variant, m, k, n, act):
     assert rel_err(gx.cpu(), gxo) < TOL
 
 
+@pytest.mark.parametrize("m,k,n,act", [(168, 128, 128, "ssp"), (2436, 20, 128, "ssp"), (2436, 128, 128, None), (168, 256, 128, "silu"),
+                                       (45, 128, 384, "silu"), (640, 20, 1152, None), (168, 128, 64, "ssp"), (1, 64, 32, "silu")])
+def test_dense_on_value_tangent_pairs(dev, m, k, n, act):
+    """spk_dense_dual_f32 (one launch per Dense layer of the force-matching engine's (value, tangent) pairs) in its three modes against
+    float64 formulas: forward pair (activation or cutoff row scale), tangent alone, reverse of the pair -- nn/base.py:52-55 under the
+    double differentiation of atomistic/response.py:59-68."""
+    from schnetpack_amd import _lib, ops
+    L = _lib.lib()
+    assert L.spk_dense_dual_supported(m, k, n)
+    g = torch.Generator().manual_seed(11)
+    xv = torch.randn(m, k, generator=g); xt = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g) * 0.1
+    fc = torch.rand(m, generator=g); fc1 = torch.randn(m, generator=g)
+    a = ops._ACT_IDS[act]
+    D = lambda t: t.to(dev).contiguous()
+    f0 = {None: lambda z: z, "ssp": O.shifted_softplus, "silu": O.silu}[act]
+
+    def derivs(z):      # act', act'' in float64 by autograd
+        z = z.clone().requires_grad_(True)
+        (d1,) = torch.autograd.grad(f0(z).sum(), [z], create_graph=True)
+        if act is None:
+            return torch.ones_like(z), torch.zeros_like(z)
+        (d2,) = torch.autograd.grad(d1.sum(), [z])
+        return d1.detach(), d2
+
+    xvd, xtd, wd, bd, fcd, fc1d = map(D, (xv, xt, w, b, fc, fc1))
+    pv_o = xv.double() @ w.double().T + b.double(); pt_o = xt.double() @ w.double().T
+    d1, _ = derivs(pv_o)
+
+    def run(**kw):
+        d = _lib.DenseDualT()
+        keep = []
+        for key, val in kw.items():
+            if isinstance(val, torch.Tensor):
+                keep.append(val)
+                setattr(d, key, _lib.fptr(val))
+            else:
+                setattr(d, key, val)
+        _lib.check(L.spk_dense_dual_f32(ctypes.byref(d), _lib.stream()))
+        torch.cuda.synchronize()
+
+    new = lambda *shape: torch.full(shape, float("nan"), device=dev)
+    # forward pair with the activation
+    yv, yt, pv, pt = new(m, n), new(m, n), new(m, n), new(m, n)
+    run(x_v=xvd, x_t=xtd, w=wd, b=bd, y_v=yv, y_t=yt, pre_v=pv, pre_t=pt, m=m, k_in=k, n_out=n, act=a, mode=0, trans=0)
+    assert rel_err(pv.cpu(), pv_o) < TOL and rel_err(pt.cpu(), pt_o) < TOL
+    assert rel_err(yv.cpu(), f0(pv_o)) < TOL and rel_err(yt.cpu(), d1 * pt_o) < TOL
+    if act is None:      # cutoff row scale with its derivative (linear layers)
+        yv, yt = new(m, n), new(m, n)
+        run(x_v=xvd, x_t=xtd, w=wd, b=bd, fc=fcd, fc1=fc1d, y_v=yv, y_t=yt, m=m, k_in=k, n_out=n, act=a, mode=0, trans=0)
+        assert rel_err(yv.cpu(), pv_o * fc.double()[:, None]) < TOL
+        assert rel_err(yt.cpu(), pt_o * fc.double()[:, None] + pv_o * fc1.double()[:, None]) < TOL
+    # tangent alone, at saved pre-activations
+    sv = torch.randn(m, n, generator=g); svd = D(sv)
+    s1, s2 = derivs(sv.double())
+    yt, pt = new(m, n), new(m, n)
+    run(x_t=xtd, w=wd, pre_v_in=svd, y_t=yt, pre_t=pt, m=m, k_in=k, n_out=n, act=a, mode=1, trans=0)
+    assert rel_err(pt.cpu(), pt_o) < TOL and rel_err(yt.cpu(), s1 * pt_o) < TOL
+    # the transposed product (input-gradient form: x [m, n] times w [n, k]) in tangent mode and as the reverse of the pair
+    gz = torch.randn(m, n, generator=g); hz = torch.randn(m, n, generator=g)
+    av = torch.randn(m, k, generator=g); at = torch.randn(m, k, generator=g)
+    gzd, hzd, avd, atd = map(D, (gz, hz, av, at))
+    a1, a2 = derivs(av.double())
+    Gz = gz.double() @ w.double(); Hz = hz.double() @ w.double()
+    yt = new(m, k)
+    run(x_t=gzd, w=wd, pre_v_in=avd, y_t=yt, m=m, k_in=n, n_out=k, act=a, mode=1, trans=1)
+    assert rel_err(yt.cpu(), a1 * Gz) < TOL
+    yv, yt = new(m, k), new(m, k)
+    run(x_v=gzd, x_t=hzd, w=wd, pre_v_in=avd, pre_t_in=atd, y_v=yv, y_t=yt, m=m, k_in=n, n_out=k, act=a, mode=2, trans=1)
+    assert rel_err(yv.cpu(), Gz * a1 + Hz * a2 * at.double()) < TOL and rel_err(yt.cpu(), Hz * a1) < TOL
+    # refused: shapes outside the MFMA tiles, a missing saved pre-activation
+    bad = _lib.DenseDualT()
+    bad.x_t = _lib.fptr(xtd); bad.w = _lib.fptr(wd); bad.y_t = _lib.fptr(yt); bad.m = m; bad.k_in = k; bad.n_out = n; bad.mode = 1
+    assert L.spk_dense_dual_f32(ctypes.byref(bad), _lib.stream()) != 0
+    assert not L.spk_dense_dual_supported(m, 18, n)
+
+
 def test_dense_residual_and_preactivation(dev, variant):
     from schnetpack_amd import ops, _lib
     g = torch.Generator().manual_seed(8)

@@ -90,6 +90,45 @@ def test_graphed_training_step_equals_eager_loop(dev, kind):
     assert worst < 1e-3, worst
 
 
+def test_flat_adamw_walks_the_trajectory_of_torch_adamw(dev):
+    """FlatAdamW (spk_adamw_f32: one launch over the flat gradient bucket, step count on the device) against torch.optim.AdamW on the
+    same parameters and gradients for 20 steps -- eager and as a replayed graph (task.py:187-199: the reference's optimizer)."""
+    from schnetpack_amd.parallel import FlatGradAllReduce
+    from schnetpack_amd.train import FlatAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 20), (128,), (3, 128, 128), (5000,), (1,), (2049,)]
+    mine = [torch.nn.Parameter(torch.randn(*sh, generator=g).to(dev)) for sh in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    red = FlatGradAllReduce(mine, as_views=True)
+    opt = FlatAdamW(red, lr=3e-3, weight_decay=0.05)
+    topt = torch.optim.AdamW(ref, lr=3e-3, weight_decay=0.05)
+    grads = [[torch.randn(*sh, generator=g).to(dev) * (0.1 + k) for sh in shapes] for k in range(20)]
+
+    def load(k):
+        for p, q, gr in zip(mine, ref, grads[k]):
+            p.grad.copy_(gr)
+            q.grad = gr.clone()
+
+    for k in range(10):
+        load(k)
+        opt.step()
+        topt.step()
+    graph = torch.cuda.CUDAGraph()
+    load(10)
+    with torch.cuda.graph(graph):      # (recorded, not executed)
+        opt.step()
+    graph.replay()
+    topt.step()
+    for k in range(11, 20):
+        load(k)
+        graph.replay()
+        topt.step()
+    torch.cuda.synchronize()
+    assert float(opt.step_count) == 20.0
+    for p, q in zip(mine, ref):
+        assert rel_err(p.detach().cpu(), q.detach().cpu()) < 2e-6
+
+
 def test_static_lists_flag_unsorted_index(dev):
     from schnetpack_amd import torchops
     from schnetpack_amd._lib import SpkHipError
