@@ -8,6 +8,7 @@
 #include <vector>
 #include "spk_common.h"
 #include <rocprim/rocprim.hpp>
+#define SPK_FM_PAINN_UNCOND 1
 #include "spk_fm_engine.h"
 
 // ------------------------------------------------------------------------------------------------ by-neighbour CSR

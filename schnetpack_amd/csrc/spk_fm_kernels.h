@@ -50,6 +50,40 @@ __device__ __forceinline__ float fm_wave_sum(float v) {
 }
 #endif
 
+// Gathers of the chunked loops: the address is made valid (index 0 when the pair does not count) and the LOAD IS UNCONDITIONAL, the
+// value is selected afterwards.  Written as `ok ? p[i] : 0` the compiler guards every load with its own branch and waits for memory inside
+// them: the gathers of a chunk then leave one after the other (k_fm_cfconv_T_dual: 10.7 us for four chunks of three dependent stages).
+template <class T, class I>
+FM_HD T fm_ld(bool ok, const T* p, I idx) {
+  const T v = p[ok ? idx : I(0)];
+  return ok ? v : T(0);
+}
+template <class T, class I, class D>
+FM_HD T fm_ldi(bool ok, const T* p, I idx, D dflt) {
+  const T v = p[ok ? idx : I(0)];
+  return ok ? v : (T)dflt;
+}
+#define FM_LD(ok, p, idx) fm_ld((ok), (p), (idx))
+// p may be NULL (uniform over the launch): the load then goes to `alt` (any non-NULL array of T) and is masked -- a pointer SELECT, not a
+// branch around the load (twelve uniform branches inside a chunk cost the PaiNN message kernels a factor of two)
+#define FM_LDN(ok, p, idx, alt) fm_ld((ok) && (p) != nullptr, (p) ? (p) : (alt), (idx))
+#define FM_LDI(ok, p, idx, dflt) fm_ldi((ok), (p), (idx), (dflt))
+// The PaiNN message kernels gather ~100 values per chunk.  There the unconditional form ALONE made the scheduler interleave loads and uses
+// to bound the live ranges (waits with one or two loads in flight: k_fm_painn_msg_T_dual 17 -> 34 us); with a scheduling fence between the
+// gathers of a chunk and their uses the ~46 loads leave together (PaiNN step 0.767 -> 0.743 ms).  SPK_FM_PAINN_UNCOND (set by spk_fm.hip)
+// selects that form; without it these kernels keep the plain conditional loads.
+#if defined(SPK_FM_EMU) || !defined(SPK_FM_PAINN_UNCOND)
+#define FM_LDC(ok, p, idx) ((ok) ? (p)[idx] : T(0))
+#define FM_LDNC(ok, p, idx) ((ok) && (p) ? (p)[idx] : T(0))
+#define FM_LDIC(ok, p, idx, dflt) ((ok) ? (p)[idx] : (dflt))
+#define FM_FENCE()
+#else
+#define FM_LDC(ok, p, idx) fm_ld((ok), (p), (idx))
+#define FM_LDNC(ok, p, idx) fm_ld((ok) && (p) != nullptr, (p) ? (p) : (const T*)gathers_alt, (idx))
+#define FM_LDIC(ok, p, idx, dflt) fm_ldi((ok), (p), (idx), (dflt))
+#define FM_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // Row / column loops keep FM_CH (light kernels) or FM_CH4 (PaiNN message) pairs in flight: index loads, then every gather of the chunk, then
 // the sums IN PAIR ORDER (the result does not depend on the chunking).  At training sizes (~15 pairs per atom, everything L2 resident)
 // a loop with one dependent gather per iteration is a chain of ~0.5 us round trips; chunked, a row costs two or three.
@@ -211,8 +245,8 @@ FM_KERNEL void k_fm_force(const T* FM_R gr, const int32_t* FM_R rowptr, const in
     for (int kb = colptr[a]; kb < k1; kb += FM_CH) {
       int e[FM_CH];
       T v[FM_CH];
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) e[q] = kb + q < k1 ? perm[kb + q] : ea;
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) v[q] = e[q] < ea ? gr[(int64_t)e[q] * 3 + x] : T(0);
+      FM_UNROLL for (int q = 0; q < FM_CH; ++q) e[q] = FM_LDI(kb + q < k1, perm, kb + q, ea);
+      FM_UNROLL for (int q = 0; q < FM_CH; ++q) v[q] = FM_LD(e[q] < ea, gr, (int64_t)e[q] * 3 + x);
       FM_UNROLL for (int q = 0; q < FM_CH; ++q) acc += v[q];
       if (e[FM_CH - 1] >= ea) break;
     }
@@ -220,7 +254,7 @@ FM_KERNEL void k_fm_force(const T* FM_R gr, const int32_t* FM_R rowptr, const in
     if (e1 > ea) e1 = ea;
     for (int eb = rowptr[a]; eb < e1; eb += FM_CH) {
       T v[FM_CH];
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) v[q] = eb + q < e1 ? gr[(int64_t)(eb + q) * 3 + x] : T(0);
+      FM_UNROLL for (int q = 0; q < FM_CH; ++q) v[q] = FM_LD(eb + q < e1, gr, (int64_t)(eb + q) * 3 + x);
       FM_UNROLL for (int q = 0; q < FM_CH; ++q) acc -= v[q];
     }
     Fo[t] = -acc;
@@ -359,11 +393,11 @@ FM_KERNEL void k_fm_cfconv(const T* FM_R h, const T* FM_R Wf, const int32_t* FM_
     for (int eb = rowptr[i]; eb < e1; eb += FM_CH) {
       int64_t j[FM_CH];
       T a[FM_CH], b[FM_CH];
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) j[q] = eb + q < e1 ? jj[eb + q] : -1;
+      FM_UNROLL for (int q = 0; q < FM_CH; ++q) j[q] = FM_LDI(eb + q < e1, jj, eb + q, -1);
       FM_UNROLL for (int q = 0; q < FM_CH; ++q) {
         const bool ok = (uint64_t)j[q] < (uint64_t)N;
-        a[q] = ok ? h[j[q] * nf + c] : T(0);
-        b[q] = ok ? Wf[(int64_t)(eb + q) * nf + c] : T(0);
+        a[q] = FM_LD(ok, h, j[q] * nf + c);
+        b[q] = FM_LD(ok, Wf, (int64_t)(eb + q) * nf + c);
       }
       FM_UNROLL for (int q = 0; q < FM_CH; ++q) acc += a[q] * b[q];
     }
@@ -384,15 +418,15 @@ FM_KERNEL void k_fm_cfconv_t(const T* FM_R h, const T* FM_R ht, const T* FM_R Wf
     for (int eb = rowptr[i]; eb < e1; eb += FM_CH4) {
       int64_t j[FM_CH4];
       T a[FM_CH4], a1[FM_CH4], b[FM_CH4], b1[FM_CH4], de[FM_CH4];
-      FM_UNROLL for (int q = 0; q < FM_CH4; ++q) j[q] = eb + q < e1 ? jj[eb + q] : -1;
+      FM_UNROLL for (int q = 0; q < FM_CH4; ++q) j[q] = FM_LDI(eb + q < e1, jj, eb + q, -1);
       FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
         const bool ok = (uint64_t)j[q] < (uint64_t)N;
         const int64_t e = eb + q;
-        a[q] = ok ? h[j[q] * nf + c] : T(0);
-        a1[q] = ok && ht ? ht[j[q] * nf + c] : T(0);
-        b[q] = ok && ht ? Wf[e * nf + c] : T(0);
-        b1[q] = ok ? Wf1[e * nf + c] : T(0);
-        de[q] = ok ? dt[e] : T(0);
+        a[q] = FM_LD(ok, h, j[q] * nf + c);
+        a1[q] = FM_LDN(ok, ht, j[q] * nf + c, h);
+        b[q] = FM_LD(ok && ht != nullptr, Wf, e * nf + c);
+        b1[q] = FM_LD(ok, Wf1, e * nf + c);
+        de[q] = FM_LD(ok, dt, e);
       }
       FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
         acc += a[q] * b1[q] * de[q];
@@ -428,13 +462,13 @@ FM_KERNEL void k_fm_cfconv_T(const T* FM_R gy, const T* FM_R Wf, const int32_t* 
       int e[FM_CH], i[FM_CH];
       T a[FM_CH], b[FM_CH];
       FM_UNROLL for (int q = 0; q < FM_CH; ++q) {
-        e[q] = kb + q < k1 ? perm[kb + q] : ea;
-        i[q] = kb + q < k1 ? csrc[kb + q] : -1;
+        e[q] = FM_LDI(kb + q < k1, perm, kb + q, ea);
+        i[q] = FM_LDI(kb + q < k1, csrc, kb + q, -1);
       }
       FM_UNROLL for (int q = 0; q < FM_CH; ++q) {
         const bool ok = e[q] < ea && i[q] >= 0;
-        a[q] = ok ? gy[(int64_t)i[q] * nf + c] : T(0);
-        b[q] = ok ? Wf[(int64_t)e[q] * nf + c] : T(0);
+        a[q] = FM_LD(ok, gy, (int64_t)i[q] * nf + c);
+        b[q] = FM_LD(ok, Wf, (int64_t)e[q] * nf + c);
       }
       FM_UNROLL for (int q = 0; q < FM_CH; ++q) acc += a[q] * b[q];
       if (e[FM_CH - 1] >= ea) break;
@@ -456,16 +490,16 @@ FM_KERNEL void k_fm_cfconv_T_dual(const T* FM_R gy2, const T* FM_R Wf2, const T*
       int e[FM_CH4], i[FM_CH4];
       T g[FM_CH4], hh[FM_CH4], w[FM_CH4], w1[FM_CH4], de[FM_CH4];
       FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
-        e[q] = kb + q < k1 ? perm[kb + q] : ea;
-        i[q] = kb + q < k1 ? csrc[kb + q] : -1;
+        e[q] = FM_LDI(kb + q < k1, perm, kb + q, ea);
+        i[q] = FM_LDI(kb + q < k1, csrc, kb + q, -1);
       }
       FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
         const bool ok = e[q] < ea && i[q] >= 0;
-        g[q] = ok ? gy2[(int64_t)i[q] * nf + c] : T(0);
-        hh[q] = ok ? gy2[(N + i[q]) * nf + c] : T(0);
-        w[q] = ok ? Wf2[(int64_t)e[q] * nf + c] : T(0);
-        w1[q] = ok ? Wf2[(E + e[q]) * nf + c] : T(0);
-        de[q] = ok ? dt[e[q]] : T(0);
+        g[q] = FM_LD(ok, gy2, (int64_t)i[q] * nf + c);
+        hh[q] = FM_LD(ok, gy2, (N + i[q]) * nf + c);
+        w[q] = FM_LD(ok, Wf2, (int64_t)e[q] * nf + c);
+        w1[q] = FM_LD(ok, Wf2, (E + e[q]) * nf + c);
+        de[q] = FM_LD(ok, dt, e[q]);
       }
       FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
         ag += g[q] * w[q] + hh[q] * w1[q] * de[q];
@@ -504,6 +538,7 @@ FM_KERNEL void k_fm_filter_cot(const T* gy2, const T* h, const T* ht, const T* d
 template <class T>
 FM_KERNEL void k_fm_painn_msg(const T* FM_R q, const T* FM_R mu, const T* FM_R c, const T* FM_R Phi, int ld, const T* FM_R u, const int32_t* FM_R rowptr,
                               const int64_t* FM_R jj, const int32_t* FM_R e_act, int64_t N, int F, T* FM_R q1, T* FM_R mu1) {
+  const T* gathers_alt = c; (void)gathers_alt;
   const int ea = *e_act;
   FM_FOR(t, N * F) {
     const int64_t i = t / F;
@@ -514,17 +549,18 @@ FM_KERNEL void k_fm_painn_msg(const T* FM_R q, const T* FM_R mu, const T* FM_R c
     for (int eb = rowptr[i]; eb < e1; eb += FM_CH4) {
       int64_t j[FM_CH4];
       T P[FM_CH4][3], cj[FM_CH4][3], uu[FM_CH4][3], mj[FM_CH4][3];
-      FM_UNROLL for (int k = 0; k < FM_CH4; ++k) j[k] = eb + k < e1 ? jj[eb + k] : -1;
+      FM_UNROLL for (int k = 0; k < FM_CH4; ++k) j[k] = FM_LDIC(eb + k < e1, jj, eb + k, -1);
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
         const bool ok = (uint64_t)j[k] < (uint64_t)N;
         const int64_t e = eb + k;
         FM_UNROLL for (int p = 0; p < 3; ++p) {
-          P[k][p] = ok ? Phi[e * ld + p * F + f] : T(0);
-          cj[k][p] = ok ? c[j[k] * 3 * F + p * F + f] : T(0);
-          uu[k][p] = ok ? u[e * 3 + p] : T(0);
-          mj[k][p] = ok && mu ? mu[(j[k] * 3 + p) * F + f] : T(0);
+          P[k][p] = FM_LDC(ok, Phi, e * ld + p * F + f);
+          cj[k][p] = FM_LDC(ok, c, j[k] * 3 * F + p * F + f);
+          uu[k][p] = FM_LDC(ok, u, e * 3 + p);
+          mj[k][p] = FM_LDNC(ok, mu, (j[k] * 3 + p) * F + f);
         }
       }
+      FM_FENCE();
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
         dq += P[k][0] * cj[k][0];
         const T mR = P[k][1] * cj[k][1], mm = P[k][2] * cj[k][2];
@@ -540,6 +576,7 @@ template <class T>
 FM_KERNEL void k_fm_painn_msg_t(const T* FM_R qt, const T* FM_R c2, const T* FM_R mu2, const T* FM_R Phi, int ld, int64_t E, const T* FM_R dt, const T* FM_R u,
                                 const T* FM_R ut, const int32_t* FM_R rowptr, const int64_t* FM_R jj, const int32_t* FM_R e_act, int64_t N, int F, int first,
                                 T* FM_R q1t, T* FM_R mu1t) {
+  const T* gathers_alt = c2; (void)gathers_alt;
   const int ea = *e_act;
   FM_FOR(t, N * F) {
     const int64_t i = t / F;
@@ -550,23 +587,24 @@ FM_KERNEL void k_fm_painn_msg_t(const T* FM_R qt, const T* FM_R c2, const T* FM_
     for (int eb = rowptr[i]; eb < e1; eb += FM_CH4) {
       int64_t j[FM_CH4];
       T P[FM_CH4][3], P1[FM_CH4][3], cj[FM_CH4][3], tj[FM_CH4][3], uu[FM_CH4][3], uv[FM_CH4][3], mj[FM_CH4][3], mtj[FM_CH4][3], de[FM_CH4];
-      FM_UNROLL for (int k = 0; k < FM_CH4; ++k) j[k] = eb + k < e1 ? jj[eb + k] : -1;
+      FM_UNROLL for (int k = 0; k < FM_CH4; ++k) j[k] = FM_LDIC(eb + k < e1, jj, eb + k, -1);
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
         const bool ok = (uint64_t)j[k] < (uint64_t)N;
         const bool ok2 = ok && !first;
         const int64_t e = eb + k;
-        de[k] = ok ? dt[e] : T(0);
+        de[k] = FM_LDC(ok, dt, e);
         FM_UNROLL for (int p = 0; p < 3; ++p) {
-          P[k][p] = ok ? Phi[e * ld + p * F + f] : T(0);
-          P1[k][p] = ok ? Phi[(E + e) * ld + p * F + f] : T(0);
-          cj[k][p] = ok ? c2[j[k] * 3 * F + p * F + f] : T(0);
-          tj[k][p] = ok2 ? c2[(N + j[k]) * 3 * F + p * F + f] : T(0);
-          uu[k][p] = ok ? u[e * 3 + p] : T(0);
-          uv[k][p] = ok ? ut[e * 3 + p] : T(0);
-          mj[k][p] = ok2 ? mu2[(j[k] * 3 + p) * F + f] : T(0);
-          mtj[k][p] = ok2 ? mu2[((N + j[k]) * 3 + p) * F + f] : T(0);
+          P[k][p] = FM_LDC(ok, Phi, e * ld + p * F + f);
+          P1[k][p] = FM_LDC(ok, Phi, (E + e) * ld + p * F + f);
+          cj[k][p] = FM_LDC(ok, c2, j[k] * 3 * F + p * F + f);
+          tj[k][p] = FM_LDC(ok2, c2, (N + j[k]) * 3 * F + p * F + f);
+          uu[k][p] = FM_LDC(ok, u, e * 3 + p);
+          uv[k][p] = FM_LDC(ok, ut, e * 3 + p);
+          mj[k][p] = FM_LDNC(ok2, mu2, (j[k] * 3 + p) * F + f);
+          mtj[k][p] = FM_LDNC(ok2, mu2, ((N + j[k]) * 3 + p) * F + f);
         }
       }
+      FM_FENCE();
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
         dq += P1[k][0] * de[k] * cj[k][0] + P[k][0] * tj[k][0];
         const T mR = P[k][1] * cj[k][1], mRt = P1[k][1] * de[k] * cj[k][1] + P[k][1] * tj[k][1];
@@ -616,6 +654,7 @@ template <class T>
 FM_KERNEL void k_fm_painn_msg_T(const T* FM_R gq1, const T* FM_R gmu1, const T* FM_R c, const T* FM_R mu, const T* FM_R Phi, int ld, const T* FM_R u,
                                 const int32_t* FM_R colptr, const int32_t* FM_R perm, const int32_t* FM_R csrc, const int32_t* FM_R e_act, int64_t N, int F,
                                 T* FM_R gc, T* FM_R gmu) {
+  const T* gathers_alt = gq1; (void)gathers_alt;
   const int ea = *e_act;
   FM_FOR(t, N * F) {
     const int64_t j = t / F;
@@ -628,18 +667,19 @@ FM_KERNEL void k_fm_painn_msg_T(const T* FM_R gq1, const T* FM_R gmu1, const T* 
       int e[FM_CH4], i[FM_CH4];
       T P[FM_CH4][3], g1[FM_CH4][3], uu[FM_CH4][3], gq[FM_CH4];
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
-        e[k] = kb + k < k1 ? perm[kb + k] : ea;
-        i[k] = kb + k < k1 ? csrc[kb + k] : -1;
+        e[k] = FM_LDIC(kb + k < k1, perm, kb + k, ea);
+        i[k] = FM_LDIC(kb + k < k1, csrc, kb + k, -1);
       }
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
         const bool ok = e[k] < ea && i[k] >= 0;
-        gq[k] = ok ? gq1[(int64_t)i[k] * F + f] : T(0);
+        gq[k] = FM_LDC(ok, gq1, (int64_t)i[k] * F + f);
         FM_UNROLL for (int p = 0; p < 3; ++p) {
-          P[k][p] = ok ? Phi[(int64_t)e[k] * ld + p * F + f] : T(0);
-          g1[k][p] = ok && gmu1 ? gmu1[((int64_t)i[k] * 3 + p) * F + f] : T(0);
-          uu[k][p] = ok ? u[(int64_t)e[k] * 3 + p] : T(0);
+          P[k][p] = FM_LDC(ok, Phi, (int64_t)e[k] * ld + p * F + f);
+          g1[k][p] = FM_LDNC(ok, gmu1, ((int64_t)i[k] * 3 + p) * F + f);
+          uu[k][p] = FM_LDC(ok, u, (int64_t)e[k] * 3 + p);
         }
       }
+      FM_FENCE();
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
         T gmR = 0, gmm = 0;
         FM_UNROLL for (int x = 0; x < 3; ++x) {
@@ -703,24 +743,25 @@ FM_KERNEL void k_fm_painn_msg_T_dual(const T* FM_R gq1_2, const T* FM_R gmu1_2, 
       int e[FM_CH4], i[FM_CH4];
       T P[FM_CH4][3], P1[FM_CH4][3], g1[FM_CH4][3], h1[FM_CH4][3], uu[FM_CH4][3], uv[FM_CH4][3], gq[FM_CH4], hq[FM_CH4], de[FM_CH4];
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
-        e[k] = kb + k < k1 ? perm[kb + k] : ea;
-        i[k] = kb + k < k1 ? csrc[kb + k] : -1;
+        e[k] = FM_LDIC(kb + k < k1, perm, kb + k, ea);
+        i[k] = FM_LDIC(kb + k < k1, csrc, kb + k, -1);
       }
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
         const bool ok = e[k] < ea && i[k] >= 0;
         const int64_t ee = e[k], iv = i[k];
-        gq[k] = ok ? gq1_2[iv * F + f] : T(0);
-        hq[k] = ok ? gq1_2[(N + iv) * F + f] : T(0);
-        de[k] = ok ? dt[ee] : T(0);
+        gq[k] = FM_LDC(ok, gq1_2, iv * F + f);
+        hq[k] = FM_LDC(ok, gq1_2, (N + iv) * F + f);
+        de[k] = FM_LDC(ok, dt, ee);
         FM_UNROLL for (int p = 0; p < 3; ++p) {
-          P[k][p] = ok ? Phi[ee * ld + p * F + f] : T(0);
-          P1[k][p] = ok ? Phi[(E + ee) * ld + p * F + f] : T(0);
-          g1[k][p] = ok ? gmu1_2[(iv * 3 + p) * F + f] : T(0);
-          h1[k][p] = ok ? gmu1_2[((N + iv) * 3 + p) * F + f] : T(0);
-          uu[k][p] = ok ? u[ee * 3 + p] : T(0);
-          uv[k][p] = ok ? ut[ee * 3 + p] : T(0);
+          P[k][p] = FM_LDC(ok, Phi, ee * ld + p * F + f);
+          P1[k][p] = FM_LDC(ok, Phi, (E + ee) * ld + p * F + f);
+          g1[k][p] = FM_LDC(ok, gmu1_2, (iv * 3 + p) * F + f);
+          h1[k][p] = FM_LDC(ok, gmu1_2, ((N + iv) * 3 + p) * F + f);
+          uu[k][p] = FM_LDC(ok, u, ee * 3 + p);
+          uv[k][p] = FM_LDC(ok, ut, ee * 3 + p);
         }
       }
+      FM_FENCE();
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
         T gm[3], hm[3];
         gm[0] = gq[k]; hm[0] = hq[k];
