@@ -506,6 +506,11 @@ int spk_cfconv_tab_f32(const spk_graph_t* g, const float* r_ij, const float* h, 
  * sorted lists) through the table kernels.  The caller rebuilds the tables when the weights change.  Not used by default. */
 int spk_filter_table_set(const float* key, const float* table, int32_t n_knots, float d_max);
 void spk_filter_table_clear(void);
+/* A table is a snapshot of the weights: set_stamp records the version of the weights it was built from (any non-zero number the caller
+ * can reproduce, e.g. the tensor's version counter + 1); drop_if_stale(key, stamp) detaches the table when its recorded stamp differs
+ * (returns 1), so that changed weights run the exact filter network instead of a stale table. */
+int spk_filter_table_set_stamp(const float* key, uint64_t stamp);
+int spk_filter_table_drop_if_stale(const float* key, uint64_t stamp);
 
 /* Kernel-tuning aid of the molecule-resident SchNet kernels (spk_schnet_mol.hip: block-diagonal lists with <= 32 atoms per
  * block run every interaction inside one workgroup): device buffer of int64 receiving cycle stamps -- entries [0, 128): thread 0

@@ -925,10 +925,11 @@ static int launch_mfma(const CfArgs& a, hipStream_t stream) {
   constexpr int NWAVES = BWD ? 4 : 8;
   const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + NWAVES * 32 * TP2) * sizeof(float) + 4 * sizeof(int);
   auto kern = k_cfconv_mfma<NF, KPB, NWAVES, BWD, SYM>;
-  static bool attr_set = false;  // once per instantiation (not a stream operation; keep it out of graph capture)
-  if (!attr_set) {
+  static SpkPerDevice attr_set;  // once per instantiation (not a stream operation; keep it out of graph capture)
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_dev);
   }
   const int64_t ntiles = (a.E + 31) / 32;
   // one persistent workgroup per CU; small problems use fewer, fuller workgroups
@@ -951,10 +952,11 @@ static int launch_pair(const CfArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + (BWD ? NWAVES * 2 * 32 * 33 : 0) + (MOL ? (size_t)a.max_group_atoms * NF : 0)) * sizeof(float) +
                      (size_t)NWAVES * 32 * sizeof(EdgeRec) + 4 * sizeof(int);
   auto kern = k_cfconv_pair<NF, KPB, NWAVES, BWD, GS, MOL>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SpkPerDevice attr_set;
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_set.mark(attr_dev);
   }
   int grid;
   if (MOL) grid = a.n_groups;
@@ -976,11 +978,12 @@ static int launch_pair_t_bwd_gs(const CfArgs& a, hipStream_t stream) {
   constexpr int NWAVES = 8;
   const size_t lds = (size_t)(NF * NF + NF * KPB * 8 + 2 * NF + NWAVES * 32 * TP2) * sizeof(float) + 4 * sizeof(int);
   auto kern = a.skip_gh ? k_cfconv_pair_t<NF, KPB, NWAVES, true, true, true> : k_cfconv_pair_t<NF, KPB, NWAVES, true, true, false>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SpkPerDevice attr_set;
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_cfconv_pair_t<NF, KPB, NWAVES, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_cfconv_pair_t<NF, KPB, NWAVES, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_dev);
   }
   const int64_t ntiles = (a.n_half + 31) / 32;
   int grid = (int)((ntiles + NWAVES - 1) / NWAVES);

@@ -459,12 +459,13 @@ extern "C" int spk_dense_chain_f32(const spk_chain_t* c, void* stream_) {
     int w0 = c->layers[0].k, w1 = c->n_layers > 1 ? c->layers[0].n_out : 0;
     if (c->n_layers > 2 && c->layers[1].n_out > w0) w0 = c->layers[1].n_out;
     const int ld0 = w0 + 4, ld1 = w1 + 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static SpkPerDevice attr_done;
+    int attr_done_dev;
+    if (attr_done.pending(&attr_done_dev)) {
       const int max_lds = (int)(2 * 32 * (CH_MAXW + 4) * sizeof(float));
       SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_dense_chain, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
       SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_dense_chain16, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-      attr_done = true;
+      attr_done.mark(attr_done_dev);
     }
     // 16-row tiles while 32-row tiles would leave CUs idle or alone with one workgroup
     const int64_t ntiles32 = (c->m + 31) / 32;

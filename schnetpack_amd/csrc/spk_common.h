@@ -1,5 +1,6 @@
 // Shared device/host helpers for the gfx950 kernels.  Wavefront = 64 lanes everywhere.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -196,6 +197,18 @@ __device__ __forceinline__ int64_t spk_xcd_tile(int nidx, int64_t ntiles) {
   const int64_t t = (int64_t)(blockIdx.x & 7) * per + tl;
   return (tl < per && t < ntiles) ? t : ntiles;
 }
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a function ON ONE DEVICE: a launcher keeps one static SpkPerDevice per kernel
+// and sets the attribute the first time it runs on each device (a process that drives several GPUs -- bead-parallel MD, one process per
+// node in tests -- would otherwise fail its first large-LDS launch on the second one).  Host side, not a stream operation.
+struct SpkPerDevice {
+  std::atomic<uint64_t> word[4];      // bit d of word d / 64 (static storage: zero)
+  bool pending(int* dev) {
+    if (hipGetDevice(dev) != hipSuccess || *dev < 0) *dev = 0;
+    return !(word[(*dev >> 6) & 3].load(std::memory_order_acquire) & (1ull << (*dev & 63)));
+  }
+  void mark(int dev) { word[(dev >> 6) & 3].fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
+
 // a pointer the caller knows to be the same on every lane of the wavefront, moved to scalar registers (loads through it take the
 // "scalar base + 32-bit lane offset" form)
 template <class T>

@@ -342,6 +342,12 @@ struct FmDeviceBackend {
     hipLaunchKernelGGL(k, dim3(spk_grid_for(total, 256, max_blocks)), dim3(256), 0, stream, static_cast<KA>(a)...);
   }
   template <class... KA, class... A>
+  void slotted(const char* tag, void (*k)(KA...), int64_t total, A... a) {      // FM_FOR_SLOTTED kernels: 64 items per workgroup, four waves share each item's row
+    if (total <= 0) return;
+    SpkProfScope prof(tag, stream);
+    hipLaunchKernelGGL(k, dim3(spk_grid_for(total, 64, max_blocks)), dim3(256), 0, stream, static_cast<KA>(a)...);
+  }
+  template <class... KA, class... A>
   void rows(const char* tag, void (*k)(KA...), int64_t n_rows, A... a) {      // one wavefront per row, four per workgroup
     if (n_rows <= 0) return;
     SpkProfScope prof(tag, stream);

@@ -210,7 +210,7 @@ struct FmEngine {
       T* Wf2 = w.Wf2[l];
       if ((rc = be.dense(w.X2[l], P.in2f_w, nullptr, nullptr, w.h2[l], nullptr, N, F, nf, FM_ACT_NONE))) return rc;
       if (par) be.wait(l);
-      be.flat("fm_cfconv", k_fm_cfconv<T>, N * nf, w.h2[l], Wf2, w.c.rowptr, b.jj, w.c.e_act, N, nf, w.y2[l]);
+      be.slotted("fm_cfconv", k_fm_cfconv<T>, N * nf, w.h2[l], Wf2, w.c.rowptr, b.jj, w.c.e_act, N, nf, w.y2[l]);
       if ((rc = be.dense(w.y2[l], P.f2out_w1, P.f2out_b1, nullptr, w.s2[l], w.p32[l], N, nf, F, FM_ACT_SSP))) return rc;
       if ((rc = be.dense(w.s2[l], P.f2out_w2, P.f2out_b2, w.X2[l], w.X2[l + 1], nullptr, N, F, F, FM_ACT_NONE))) return rc;
     }
@@ -224,7 +224,7 @@ struct FmEngine {
       if ((rc = be.dense_bwd_input(w.gs2, w.p32[l], P.f2out_w1, nullptr, w.gy2, N, nf, F, FM_ACT_SSP))) return rc;
       be.rows("fm_cfconv_gd", k_fm_cfconv_gd<T>, E, w.gy2, w.h2[l], w.Wf2[l] + E * nf, b.ii, b.jj, E, N, nf, w.c.gd);
       if (l > 0) {
-        be.flat("fm_cfconv_T", k_fm_cfconv_T<T>, N * nf, w.gy2, w.Wf2[l], w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, nf, ghb);
+        be.slotted("fm_cfconv_T", k_fm_cfconv_T<T>, N * nf, w.gy2, w.Wf2[l], w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, nf, ghb);
         if ((rc = be.dense_bwd_input(ghb, nullptr, P.in2f_w, gxa, gxb, N, F, nf, FM_ACT_NONE))) return rc;
         T* t = gxa; gxa = gxb; gxb = t;
       }
@@ -247,7 +247,7 @@ struct FmEngine {
       const FmSchnetLayer<T>& P = m.layers[l];
       T* ht = l > 0 ? w.h2[l] + N * nf : nullptr;
       if (l > 0 && (rc = be.dense(w.X2[l] + N * F, P.in2f_w, nullptr, nullptr, ht, nullptr, N, F, nf, FM_ACT_NONE))) return rc;
-      be.flat("fm_cfconv_t", k_fm_cfconv_t<T>, N * nf, w.h2[l], (const T*)ht, w.Wf2[l], w.Wf2[l] + E * nf, w.c.dt, w.c.rowptr, b.jj, w.c.e_act, N, nf, w.y2[l] + N * nf);
+      be.slotted("fm_cfconv_t", k_fm_cfconv_t<T>, N * nf, w.h2[l], (const T*)ht, w.Wf2[l], w.Wf2[l] + E * nf, w.c.dt, w.c.rowptr, b.jj, w.c.e_act, N, nf, w.y2[l] + N * nf);
       if ((rc = be.dense_tangent(w.y2[l] + N * nf, P.f2out_w1, w.p32[l], w.s2[l] + N * F, w.p32[l] + N * F, N, nf, F, FM_ACT_SSP, false))) return rc;
       if ((rc = be.dense(w.s2[l] + N * F, P.f2out_w2, nullptr, l > 0 ? w.X2[l] + N * F : nullptr, w.X2[l + 1] + N * F, nullptr, N, F, F, FM_ACT_NONE))) return rc;
     }
@@ -275,7 +275,7 @@ struct FmEngine {
       if ((rc = be.dense_dual_bwd(gx, P.f2out_w2, w.p32[l], gp2, w.gs2, N, F, F, FM_ACT_SSP))) return rc;
       if ((rc = be.gemm_tn(gp2, w.y2[l], 2 * N, F, nf, g_o1, g_ob1, N))) return rc;
       if ((rc = be.dense_bwd_input(gp2, nullptr, P.f2out_w1, nullptr, w.gy2, 2 * N, nf, F, FM_ACT_NONE))) return rc;
-      be.flat("fm_cfconv_T_dual", k_fm_cfconv_T_dual<T>, N * nf, w.gy2, w.Wf2[l], w.c.dt, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, E, nf, gh2);
+      be.slotted("fm_cfconv_T_dual", k_fm_cfconv_T_dual<T>, N * nf, w.gy2, w.Wf2[l], w.c.dt, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, E, nf, gh2);
       be.flat("fm_filter_cot", k_fm_filter_cot<T>, E * nf, w.gy2, w.h2[l], (const T*)(l > 0 ? w.h2[l] + N * nf : nullptr), w.c.dt, w.c.fc, w.c.fc1, b.ii, b.jj, N, E,
               nf, gg2);
       if ((rc = be.gemm_tn(gg2, w.z2[l], 2 * E, nf, nf, g_w2, g_b2, E))) return rc;
@@ -348,7 +348,7 @@ struct FmEngine {
       if ((rc = be.dense(w.Q2[l], P.ctx_w1, P.ctx_b1, nullptr, w.sa2[l], w.pa2[l], N, F, F, FM_ACT_SILU))) return rc;
       if ((rc = be.dense(w.sa2[l], P.ctx_w2, P.ctx_b2, nullptr, w.c2[l], nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
       if (par && l == 0) be.wait(0);
-      be.flat("fm_painn_msg", k_fm_painn_msg<T>, N * F, w.Q2[l], mu, w.c2[l], Phi, ld, w.c.u, w.c.rowptr, b.jj, w.c.e_act, N, F, w.q1_2[l], w.mu1_2[l]);
+      be.slotted("fm_painn_msg", k_fm_painn_msg<T>, N * F, w.Q2[l], mu, w.c2[l], Phi, ld, w.c.u, w.c.rowptr, b.jj, w.c.e_act, N, F, w.q1_2[l], w.mu1_2[l]);
       if ((rc = be.dense(w.mu1_2[l], P.mix_w, nullptr, nullptr, w.VW2[l], nullptr, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
       be.flat("fm_painn_mix", k_fm_painn_mix<T>, N * F, w.q1_2[l], w.VW2[l], m.eps, N, F, w.n2[l], w.svw2[l], w.ctx2[l]);
       if ((rc = be.dense(w.ctx2[l], P.ictx_w1, P.ictx_b1, nullptr, w.sb2[l], w.pb2[l], N, 2 * F, F, FM_ACT_SILU))) return rc;
@@ -371,7 +371,7 @@ struct FmEngine {
       if ((rc = be.dense_bwd_input(gVW, nullptr, P.mix_w, gmu, w.gmu1_2, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
       be.rows("fm_painn_msg_gd", k_fm_painn_msg_gd<T>, E, w.gq1_2, w.gmu1_2, w.c2[l], mu, Phi, ld, w.c.u, b.ii, b.jj, E, N, F, w.c.gd, w.c.gu);
       if (l > 0) {
-        be.flat("fm_painn_msg_T", k_fm_painn_msg_T<T>, N * F, w.gq1_2, w.gmu1_2, w.c2[l], mu, Phi, ld, w.c.u, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, F, gc, w.gmu_a);
+        be.slotted("fm_painn_msg_T", k_fm_painn_msg_T<T>, N * F, w.gq1_2, w.gmu1_2, w.c2[l], mu, Phi, ld, w.c.u, w.c.colptr, w.c.perm, w.c.csrc, w.c.e_act, N, F, gc, w.gmu_a);
         if ((rc = be.dense_bwd_input(gc, nullptr, P.ctx_w2, nullptr, w.gsa2, N, F, 3 * F, FM_ACT_NONE))) return rc;
         if ((rc = be.dense_bwd_input(w.gsa2, w.pa2[l], P.ctx_w1, w.gq1_2, w.gq_a, N, F, F, FM_ACT_SILU))) return rc;
         gmu = w.gmu_a;
@@ -403,7 +403,7 @@ struct FmEngine {
         if ((rc = be.dense_tangent(w.Q2[l] + NF, P.ctx_w1, w.pa2[l], w.sa2[l] + NF, w.pa2[l] + NF, N, F, F, FM_ACT_SILU, false))) return rc;
         if ((rc = be.dense(w.sa2[l] + NF, P.ctx_w2, nullptr, nullptr, w.c2[l] + 3 * NF, nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
       }
-      be.flat("fm_painn_msg_t", k_fm_painn_msg_t<T>, NF, (const T*)(first ? nullptr : w.Q2[l] + NF), w.c2[l], (const T*)(first ? nullptr : w.MU2[l]), Phi, ld, E, w.c.dt,
+      be.slotted("fm_painn_msg_t", k_fm_painn_msg_t<T>, NF, (const T*)(first ? nullptr : w.Q2[l] + NF), w.c2[l], (const T*)(first ? nullptr : w.MU2[l]), Phi, ld, E, w.c.dt,
               w.c.u, w.c.ut, w.c.rowptr, b.jj, w.c.e_act, N, F, first, w.q1_2[l] + NF, w.mu1_2[l] + 3 * NF);
       if ((rc = be.dense(w.mu1_2[l] + 3 * NF, P.mix_w, nullptr, nullptr, w.VW2[l] + 6 * NF, nullptr, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
       be.flat("fm_painn_mix_t", k_fm_painn_mix_t<T>, NF, w.q1_2[l] + NF, w.VW2[l], w.VW2[l] + 6 * NF, w.n2[l], N, F, w.n2[l] + NF, w.svw2[l] + NF, w.ctx2[l] + 2 * NF);
@@ -456,7 +456,7 @@ struct FmEngine {
         const int64_t row0 = m.shared_filters ? 0 : 3ll * F * l;
         if ((rc = be.gemm_tn(gP2, w.c.phi2, 2 * E, 3 * F, K, g_fw + row0 * K, g_fb + row0, E))) return rc;
       }
-      be.flat("fm_painn_msg_T_dual", k_fm_painn_msg_T_dual<T>, NF, w.gq1_2, w.gmu1_2, w.c2[l], mu2, Phi, ld, E, w.c.dt, w.c.u, w.c.ut, w.c.colptr, w.c.perm, w.c.csrc,
+      be.slotted("fm_painn_msg_T_dual", k_fm_painn_msg_T_dual<T>, NF, w.gq1_2, w.gmu1_2, w.c2[l], mu2, Phi, ld, E, w.c.dt, w.c.u, w.c.ut, w.c.colptr, w.c.perm, w.c.csrc,
               w.c.e_act, N, F, first, gc2, w.gmu_a);
       const int64_t nr = first ? N : 2 * N;
       if ((rc = be.gemm_tn(gc2, w.sa2[l], nr, 3 * F, F, g_cw2, g_cb2, N))) return rc;

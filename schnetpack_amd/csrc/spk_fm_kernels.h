@@ -25,6 +25,12 @@
 #define FM_WAVE_SUM(x) (x)
 #define FM_IF_LANE0
 #define FM_LAST_LANE_WITH(cond) (cond)
+// slotted row loops (see the device definitions): the emulation has one slot
+#define FM_NSLOT 1
+#define FM_SLOT 0
+#define FM_FOR_SLOTTED(t, total) for (int64_t t = 0, fm_ok = 1; t < (int64_t)(total); ++t)
+#define FM_SLOT_SUM(arr, n)
+#define FM_SLOT_OWNER (fm_ok != 0)
 #else
 #define FM_KERNEL __global__ __launch_bounds__(256)
 #define FM_HD __device__ __forceinline__
@@ -39,6 +45,28 @@
 // true on the highest active lane of the wavefront on which `cond` holds (one atomic per wavefront instead of one per lane: 2 560 atomic
 // maxima on ONE address cost k_fm_geom ~10 of its 14 us -- they serialise at the L2)
 #define FM_LAST_LANE_WITH(cond) fm_last_lane_with(cond)
+// Slotted row loops: the pairs of a CSR row are shared by FM_NSLOT threads -- the four waves of a workgroup; lane l of every wave works on
+// item 64 * block + l, wave w takes the chunks w, w + 4, ... of the item's row, the partial sums meet in LDS in slot order (deterministic)
+// and wave 0 writes.  An 8-frame training batch has ~15 pairs per atom: with one thread per (atom, channel) the PaiNN message kernels were
+// 84 workgroups each walking four chunks of ~25 dependent-stage gathers (10 - 17 us a launch); slotted they are 336 workgroups with one
+// chunk per thread.  Items past the end are clamped to the last one (every thread reaches the barriers) and do not write.
+#define FM_NSLOT 4
+#define FM_SLOT ((int)(threadIdx.x >> 6))
+#define FM_FOR_SLOTTED(t, total)                                                                                                       \
+  for (int64_t fm_base = (int64_t)blockIdx.x * 64; fm_base < (int64_t)(total); fm_base += (int64_t)gridDim.x * 64)                    \
+    for (int64_t fm_t = fm_base + (threadIdx.x & 63), fm_ok = fm_t < (int64_t)(total), t = fm_ok ? fm_t : (int64_t)(total) - 1, fm_once = 1; fm_once; fm_once = 0)
+#define FM_SLOT_MAXV 12
+#define FM_SLOT_SUM(arr, n)                                                                                                            \
+  do {                                                                                                                                 \
+    __shared__ float fm_red[FM_SLOT_MAXV][FM_NSLOT][64];                                                                               \
+    const int fm_w = threadIdx.x >> 6, fm_l = threadIdx.x & 63;                                                                        \
+    _Pragma("unroll") for (int fm_q = 0; fm_q < (n); ++fm_q) fm_red[fm_q][fm_w][fm_l] = (arr)[fm_q];                                 \
+    __syncthreads();                                                                                                                   \
+    _Pragma("unroll") for (int fm_q = 0; fm_q < (n); ++fm_q)                                                                          \
+      (arr)[fm_q] = ((fm_red[fm_q][0][fm_l] + fm_red[fm_q][1][fm_l]) + fm_red[fm_q][2][fm_l]) + fm_red[fm_q][3][fm_l];              \
+    __syncthreads();                                                                                                                   \
+  } while (0)
+#define FM_SLOT_OWNER (fm_ok != 0 && (threadIdx.x >> 6) == 0)
 __device__ __forceinline__ bool fm_last_lane_with(bool cond) {
   const unsigned long long m = __ballot(cond);
   return cond && (int)(threadIdx.x & 63) == 63 - __builtin_clzll(m);
@@ -384,24 +412,25 @@ template <class T>
 FM_KERNEL void k_fm_cfconv(const T* FM_R h, const T* FM_R Wf, const int32_t* FM_R rowptr, const int64_t* FM_R jj, const int32_t* FM_R e_act, int64_t N, int nf,
                            T* FM_R y) {
   const int ea = *e_act;
-  FM_FOR(t, N * nf) {
+  FM_FOR_SLOTTED(t, N * nf) {
     const int64_t i = t / nf;
     const int c = (int)(t % nf);
     int e1 = rowptr[i + 1];
     if (e1 > ea) e1 = ea;
-    T acc = 0;
-    for (int eb = rowptr[i]; eb < e1; eb += FM_CH) {
-      int64_t j[FM_CH];
-      T a[FM_CH], b[FM_CH];
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) j[q] = FM_LDI(eb + q < e1, jj, eb + q, -1);
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) {
+    T acc[1] = {0};
+    for (int eb = rowptr[i] + FM_SLOT * FM_CH4; eb < e1; eb += FM_NSLOT * FM_CH4) {
+      int64_t j[FM_CH4];
+      T a[FM_CH4], b[FM_CH4];
+      FM_UNROLL for (int q = 0; q < FM_CH4; ++q) j[q] = FM_LDI(eb + q < e1, jj, eb + q, -1);
+      FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
         const bool ok = (uint64_t)j[q] < (uint64_t)N;
         a[q] = FM_LD(ok, h, j[q] * nf + c);
         b[q] = FM_LD(ok, Wf, (int64_t)(eb + q) * nf + c);
       }
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) acc += a[q] * b[q];
+      FM_UNROLL for (int q = 0; q < FM_CH4; ++q) acc[0] += a[q] * b[q];
     }
-    y[t] = acc;
+    FM_SLOT_SUM(acc, 1);
+    if (FM_SLOT_OWNER) y[t] = acc[0];
   }
 }
 // yt_i = sum_e (ht_j Wf_e + h_j Wf1_e dt_e)      (ht may be NULL: first interaction)
@@ -409,13 +438,13 @@ template <class T>
 FM_KERNEL void k_fm_cfconv_t(const T* FM_R h, const T* FM_R ht, const T* FM_R Wf, const T* FM_R Wf1, const T* FM_R dt, const int32_t* FM_R rowptr,
                              const int64_t* FM_R jj, const int32_t* FM_R e_act, int64_t N, int nf, T* FM_R yt) {
   const int ea = *e_act;
-  FM_FOR(t, N * nf) {
+  FM_FOR_SLOTTED(t, N * nf) {
     const int64_t i = t / nf;
     const int c = (int)(t % nf);
     int e1 = rowptr[i + 1];
     if (e1 > ea) e1 = ea;
-    T acc = 0;
-    for (int eb = rowptr[i]; eb < e1; eb += FM_CH4) {
+    T acc[1] = {0};
+    for (int eb = rowptr[i] + FM_SLOT * FM_CH4; eb < e1; eb += FM_NSLOT * FM_CH4) {
       int64_t j[FM_CH4];
       T a[FM_CH4], a1[FM_CH4], b[FM_CH4], b1[FM_CH4], de[FM_CH4];
       FM_UNROLL for (int q = 0; q < FM_CH4; ++q) j[q] = FM_LDI(eb + q < e1, jj, eb + q, -1);
@@ -429,11 +458,12 @@ FM_KERNEL void k_fm_cfconv_t(const T* FM_R h, const T* FM_R ht, const T* FM_R Wf
         de[q] = FM_LD(ok, dt, e);
       }
       FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
-        acc += a[q] * b1[q] * de[q];
-        if (ht) acc += a1[q] * b[q];
+        acc[0] += a[q] * b1[q] * de[q];
+        if (ht) acc[0] += a1[q] * b[q];
       }
     }
-    yt[t] = acc;
+    FM_SLOT_SUM(acc, 1);
+    if (FM_SLOT_OWNER) yt[t] = acc[0];
   }
 }
 // pass B: gd_e += sum_c gy_i h_j Wf1_e   (one wavefront per pair)
@@ -453,27 +483,28 @@ template <class T>
 FM_KERNEL void k_fm_cfconv_T(const T* FM_R gy, const T* FM_R Wf, const int32_t* FM_R colptr, const int32_t* FM_R perm, const int32_t* FM_R csrc,
                              const int32_t* FM_R e_act, int64_t N, int nf, T* FM_R gh) {
   const int ea = *e_act;
-  FM_FOR(t, N * nf) {
+  FM_FOR_SLOTTED(t, N * nf) {
     const int64_t j = t / nf;
     const int c = (int)(t % nf);
-    T acc = 0;
+    T acc[1] = {0};
     const int k1 = colptr[j + 1];
-    for (int kb = colptr[j]; kb < k1; kb += FM_CH) {
-      int e[FM_CH], i[FM_CH];
-      T a[FM_CH], b[FM_CH];
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) {
+    for (int kb = colptr[j] + FM_SLOT * FM_CH4; kb < k1; kb += FM_NSLOT * FM_CH4) {
+      int e[FM_CH4], i[FM_CH4];
+      T a[FM_CH4], b[FM_CH4];
+      FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
         e[q] = FM_LDI(kb + q < k1, perm, kb + q, ea);
         i[q] = FM_LDI(kb + q < k1, csrc, kb + q, -1);
       }
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) {
+      FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
         const bool ok = e[q] < ea && i[q] >= 0;
         a[q] = FM_LD(ok, gy, (int64_t)i[q] * nf + c);
         b[q] = FM_LD(ok, Wf, (int64_t)e[q] * nf + c);
       }
-      FM_UNROLL for (int q = 0; q < FM_CH; ++q) acc += a[q] * b[q];
-      if (e[FM_CH - 1] >= ea) break;
+      FM_UNROLL for (int q = 0; q < FM_CH4; ++q) acc[0] += a[q] * b[q];
+      if (e[FM_CH4 - 1] >= ea) break;
     }
-    gh[t] = acc;
+    FM_SLOT_SUM(acc, 1);
+    if (FM_SLOT_OWNER) gh[t] = acc[0];
   }
 }
 // pass D: gh_j = sum (gy_i Wf_e + hy_i Wf1_e dt_e),  hh_j = sum hy_i Wf_e ;  gy2 = [gy ; hy] [2N, nf], Wf2 = [Wf ; Wf1] [2E, nf]
@@ -481,12 +512,12 @@ template <class T>
 FM_KERNEL void k_fm_cfconv_T_dual(const T* FM_R gy2, const T* FM_R Wf2, const T* FM_R dt, const int32_t* FM_R colptr, const int32_t* FM_R perm,
                                   const int32_t* FM_R csrc, const int32_t* FM_R e_act, int64_t N, int64_t E, int nf, T* FM_R gh2) {
   const int ea = *e_act;
-  FM_FOR(t, N * nf) {
+  FM_FOR_SLOTTED(t, N * nf) {
     const int64_t j = t / nf;
     const int c = (int)(t % nf);
-    T ag = 0, ah = 0;
+    T acc[2] = {0, 0};      // ag, ah
     const int k1 = colptr[j + 1];
-    for (int kb = colptr[j]; kb < k1; kb += FM_CH4) {
+    for (int kb = colptr[j] + FM_SLOT * FM_CH4; kb < k1; kb += FM_NSLOT * FM_CH4) {
       int e[FM_CH4], i[FM_CH4];
       T g[FM_CH4], hh[FM_CH4], w[FM_CH4], w1[FM_CH4], de[FM_CH4];
       FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
@@ -502,13 +533,16 @@ FM_KERNEL void k_fm_cfconv_T_dual(const T* FM_R gy2, const T* FM_R Wf2, const T*
         de[q] = FM_LD(ok, dt, e[q]);
       }
       FM_UNROLL for (int q = 0; q < FM_CH4; ++q) {
-        ag += g[q] * w[q] + hh[q] * w1[q] * de[q];
-        ah += hh[q] * w[q];
+        acc[0] += g[q] * w[q] + hh[q] * w1[q] * de[q];
+        acc[1] += hh[q] * w[q];
       }
       if (e[FM_CH4 - 1] >= ea) break;
     }
-    gh2[t] = ag;
-    gh2[N * nf + t] = ah;
+    FM_SLOT_SUM(acc, 2);
+    if (FM_SLOT_OWNER) {
+      gh2[t] = acc[0];
+      gh2[N * nf + t] = acc[1];
+    }
   }
 }
 // pass D, per pair and channel: cotangents of the raw filter outputs (g, g1):
@@ -540,13 +574,13 @@ FM_KERNEL void k_fm_painn_msg(const T* FM_R q, const T* FM_R mu, const T* FM_R c
                               const int64_t* FM_R jj, const int32_t* FM_R e_act, int64_t N, int F, T* FM_R q1, T* FM_R mu1) {
   const T* gathers_alt = c; (void)gathers_alt;
   const int ea = *e_act;
-  FM_FOR(t, N * F) {
+  FM_FOR_SLOTTED(t, N * F) {
     const int64_t i = t / F;
     const int f = (int)(t % F);
-    T dq = 0, dm[3] = {0, 0, 0};
+    T acc[4] = {0, 0, 0, 0};      // dq, dm[3]
     int e1 = rowptr[i + 1];
     if (e1 > ea) e1 = ea;
-    for (int eb = rowptr[i]; eb < e1; eb += FM_CH4) {
+    for (int eb = rowptr[i] + FM_SLOT * FM_CH4; eb < e1; eb += FM_NSLOT * FM_CH4) {
       int64_t j[FM_CH4];
       T P[FM_CH4][3], cj[FM_CH4][3], uu[FM_CH4][3], mj[FM_CH4][3];
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) j[k] = FM_LDIC(eb + k < e1, jj, eb + k, -1);
@@ -562,13 +596,16 @@ FM_KERNEL void k_fm_painn_msg(const T* FM_R q, const T* FM_R mu, const T* FM_R c
       }
       FM_FENCE();
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
-        dq += P[k][0] * cj[k][0];
+        acc[0] += P[k][0] * cj[k][0];
         const T mR = P[k][1] * cj[k][1], mm = P[k][2] * cj[k][2];
-        FM_UNROLL for (int x = 0; x < 3; ++x) dm[x] += mR * uu[k][x] + mm * mj[k][x];
+        FM_UNROLL for (int x = 0; x < 3; ++x) acc[1 + x] += mR * uu[k][x] + mm * mj[k][x];
       }
     }
-    q1[t] = q[t] + dq;
-    for (int x = 0; x < 3; ++x) mu1[(i * 3 + x) * F + f] = (mu ? mu[(i * 3 + x) * F + f] : T(0)) + dm[x];
+    FM_SLOT_SUM(acc, 4);
+    if (FM_SLOT_OWNER) {
+      q1[t] = q[t] + acc[0];
+      for (int x = 0; x < 3; ++x) mu1[(i * 3 + x) * F + f] = (mu ? mu[(i * 3 + x) * F + f] : T(0)) + acc[1 + x];
+    }
   }
 }
 // tangent of the message; c2 = [c ; ct] [2N, 3F], mu2 = [mu ; mut] [2 * 3N, F] (NULL: first interaction, then ct = 0 too), qt NULL = 0
@@ -578,13 +615,13 @@ FM_KERNEL void k_fm_painn_msg_t(const T* FM_R qt, const T* FM_R c2, const T* FM_
                                 T* FM_R q1t, T* FM_R mu1t) {
   const T* gathers_alt = c2; (void)gathers_alt;
   const int ea = *e_act;
-  FM_FOR(t, N * F) {
+  FM_FOR_SLOTTED(t, N * F) {
     const int64_t i = t / F;
     const int f = (int)(t % F);
-    T dq = 0, dm[3] = {0, 0, 0};
+    T acc[4] = {0, 0, 0, 0};      // dq, dm[3]
     int e1 = rowptr[i + 1];
     if (e1 > ea) e1 = ea;
-    for (int eb = rowptr[i]; eb < e1; eb += FM_CH4) {
+    for (int eb = rowptr[i] + FM_SLOT * FM_CH4; eb < e1; eb += FM_NSLOT * FM_CH4) {
       int64_t j[FM_CH4];
       T P[FM_CH4][3], P1[FM_CH4][3], cj[FM_CH4][3], tj[FM_CH4][3], uu[FM_CH4][3], uv[FM_CH4][3], mj[FM_CH4][3], mtj[FM_CH4][3], de[FM_CH4];
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) j[k] = FM_LDIC(eb + k < e1, jj, eb + k, -1);
@@ -606,14 +643,17 @@ FM_KERNEL void k_fm_painn_msg_t(const T* FM_R qt, const T* FM_R c2, const T* FM_
       }
       FM_FENCE();
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
-        dq += P1[k][0] * de[k] * cj[k][0] + P[k][0] * tj[k][0];
+        acc[0] += P1[k][0] * de[k] * cj[k][0] + P[k][0] * tj[k][0];
         const T mR = P[k][1] * cj[k][1], mRt = P1[k][1] * de[k] * cj[k][1] + P[k][1] * tj[k][1];
         const T mm = P[k][2] * cj[k][2], mmt = P1[k][2] * de[k] * cj[k][2] + P[k][2] * tj[k][2];
-        FM_UNROLL for (int x = 0; x < 3; ++x) dm[x] += mRt * uu[k][x] + mR * uv[k][x] + mmt * mj[k][x] + mm * mtj[k][x];
+        FM_UNROLL for (int x = 0; x < 3; ++x) acc[1 + x] += mRt * uu[k][x] + mR * uv[k][x] + mmt * mj[k][x] + mm * mtj[k][x];
       }
     }
-    q1t[t] = (first ? T(0) : qt[t]) + dq;
-    for (int x = 0; x < 3; ++x) mu1t[(i * 3 + x) * F + f] = (first ? T(0) : mu2[((N + i) * 3 + x) * F + f]) + dm[x];
+    FM_SLOT_SUM(acc, 4);
+    if (FM_SLOT_OWNER) {
+      q1t[t] = (first ? T(0) : qt[t]) + acc[0];
+      for (int x = 0; x < 3; ++x) mu1t[(i * 3 + x) * F + f] = (first ? T(0) : mu2[((N + i) * 3 + x) * F + f]) + acc[1 + x];
+    }
   }
 }
 // pass B, per pair (one wavefront): gd_e += sum gm c_j Phi1,  gu_e[x] += sum_f gmu1_i[x] mR     (gmu1 NULL = 0)
@@ -656,14 +696,14 @@ FM_KERNEL void k_fm_painn_msg_T(const T* FM_R gq1, const T* FM_R gmu1, const T* 
                                 T* FM_R gc, T* FM_R gmu) {
   const T* gathers_alt = gq1; (void)gathers_alt;
   const int ea = *e_act;
-  FM_FOR(t, N * F) {
+  FM_FOR_SLOTTED(t, N * F) {
     const int64_t j = t / F;
     const int f = (int)(t % F);
-    T aq = 0, aR = 0, am = 0, ag[3] = {0, 0, 0}, mj[3];
+    T acc[6] = {0, 0, 0, 0, 0, 0}, mj[3];      // aq, aR, am, ag[3]
     const T cm = c[j * 3 * F + 2 * F + f];
     for (int x = 0; x < 3; ++x) mj[x] = mu ? mu[(j * 3 + x) * F + f] : T(0);
     const int k1 = colptr[j + 1];
-    for (int kb = colptr[j]; kb < k1; kb += FM_CH4) {
+    for (int kb = colptr[j] + FM_SLOT * FM_CH4; kb < k1; kb += FM_NSLOT * FM_CH4) {
       int e[FM_CH4], i[FM_CH4];
       T P[FM_CH4][3], g1[FM_CH4][3], uu[FM_CH4][3], gq[FM_CH4];
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
@@ -686,18 +726,21 @@ FM_KERNEL void k_fm_painn_msg_T(const T* FM_R gq1, const T* FM_R gmu1, const T* 
           gmR += g1[k][x] * uu[k][x];
           gmm += g1[k][x] * mj[x];
         }
-        aq += P[k][0] * gq[k];
-        aR += P[k][1] * gmR;
-        am += P[k][2] * gmm;
+        acc[0] += P[k][0] * gq[k];
+        acc[1] += P[k][1] * gmR;
+        acc[2] += P[k][2] * gmm;
         const T mm = P[k][2] * cm;
-        FM_UNROLL for (int x = 0; x < 3; ++x) ag[x] += mm * g1[k][x];
+        FM_UNROLL for (int x = 0; x < 3; ++x) acc[3 + x] += mm * g1[k][x];
       }
       if (e[FM_CH4 - 1] >= ea) break;
     }
-    gc[j * 3 * F + f] = aq;
-    gc[j * 3 * F + F + f] = aR;
-    gc[j * 3 * F + 2 * F + f] = am;
-    for (int x = 0; x < 3; ++x) gmu[(j * 3 + x) * F + f] = (gmu1 ? gmu1[(j * 3 + x) * F + f] : T(0)) + ag[x];
+    FM_SLOT_SUM(acc, 6);
+    if (FM_SLOT_OWNER) {
+      gc[j * 3 * F + f] = acc[0];
+      gc[j * 3 * F + F + f] = acc[1];
+      gc[j * 3 * F + 2 * F + f] = acc[2];
+      for (int x = 0; x < 3; ++x) gmu[(j * 3 + x) * F + f] = (gmu1 ? gmu1[(j * 3 + x) * F + f] : T(0)) + acc[3 + x];
+    }
   }
 }
 // per-pair cotangents of the message, shared by the two pass-D kernels below
@@ -729,17 +772,17 @@ FM_KERNEL void k_fm_painn_msg_T_dual(const T* FM_R gq1_2, const T* FM_R gmu1_2, 
                                      const T* FM_R dt, const T* FM_R u, const T* FM_R ut, const int32_t* FM_R colptr, const int32_t* FM_R perm,
                                      const int32_t* FM_R csrc, const int32_t* FM_R e_act, int64_t N, int F, int first, T* FM_R gc2, T* FM_R gmu2) {
   const int ea = *e_act;
-  FM_FOR(t, N * F) {
+  FM_FOR_SLOTTED(t, N * F) {
     const int64_t j = t / F;
     const int f = (int)(t % F);
-    T ag[3] = {0, 0, 0}, ah[3] = {0, 0, 0}, mg[3] = {0, 0, 0}, mh[3] = {0, 0, 0}, mj[3], mtj[3];
+    T acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mj[3], mtj[3];      // ag[3], ah[3], mg[3], mh[3]
     const T cm = c2[j * 3 * F + 2 * F + f], ctm = first ? T(0) : c2[(N + j) * 3 * F + 2 * F + f];
     for (int x = 0; x < 3; ++x) {
       mj[x] = first ? T(0) : mu2[(j * 3 + x) * F + f];
       mtj[x] = first ? T(0) : mu2[((N + j) * 3 + x) * F + f];
     }
     const int k1 = colptr[j + 1];
-    for (int kb = colptr[j]; kb < k1; kb += FM_CH4) {
+    for (int kb = colptr[j] + FM_SLOT * FM_CH4; kb < k1; kb += FM_NSLOT * FM_CH4) {
       int e[FM_CH4], i[FM_CH4];
       T P[FM_CH4][3], P1[FM_CH4][3], g1[FM_CH4][3], h1[FM_CH4][3], uu[FM_CH4][3], uv[FM_CH4][3], gq[FM_CH4], hq[FM_CH4], de[FM_CH4];
       FM_UNROLL for (int k = 0; k < FM_CH4; ++k) {
@@ -773,24 +816,27 @@ FM_KERNEL void k_fm_painn_msg_T_dual(const T* FM_R gq1_2, const T* FM_R gmu1_2, 
           hm[2] += h1[k][x] * mj[x];
         }
         FM_UNROLL for (int p = 0; p < 3; ++p) {
-          ag[p] += gm[p] * P[k][p] + hm[p] * P1[k][p] * de[k];
-          ah[p] += hm[p] * P[k][p];
+          acc[p] += gm[p] * P[k][p] + hm[p] * P1[k][p] * de[k];
+          acc[3 + p] += hm[p] * P[k][p];
         }
         const T mm = P[k][2] * cm, mmt = P1[k][2] * de[k] * cm + P[k][2] * ctm;
         FM_UNROLL for (int x = 0; x < 3; ++x) {
-          mg[x] += g1[k][x] * mm + h1[k][x] * mmt;
-          mh[x] += h1[k][x] * mm;
+          acc[6 + x] += g1[k][x] * mm + h1[k][x] * mmt;
+          acc[9 + x] += h1[k][x] * mm;
         }
       }
       if (e[FM_CH4 - 1] >= ea) break;
     }
-    for (int p = 0; p < 3; ++p) {
-      gc2[j * 3 * F + p * F + f] = ag[p];
-      gc2[(N + j) * 3 * F + p * F + f] = ah[p];
-    }
-    for (int x = 0; x < 3; ++x) {
-      gmu2[(j * 3 + x) * F + f] = gmu1_2[(j * 3 + x) * F + f] + mg[x];
-      gmu2[((N + j) * 3 + x) * F + f] = gmu1_2[((N + j) * 3 + x) * F + f] + mh[x];
+    FM_SLOT_SUM(acc, 12);
+    if (FM_SLOT_OWNER) {
+      for (int p = 0; p < 3; ++p) {
+        gc2[j * 3 * F + p * F + f] = acc[p];
+        gc2[(N + j) * 3 * F + p * F + f] = acc[3 + p];
+      }
+      for (int x = 0; x < 3; ++x) {
+        gmu2[(j * 3 + x) * F + f] = gmu1_2[(j * 3 + x) * F + f] + acc[6 + x];
+        gmu2[((N + j) * 3 + x) * F + f] = gmu1_2[((N + j) * 3 + x) * F + f] + acc[9 + x];
+      }
     }
   }
 }

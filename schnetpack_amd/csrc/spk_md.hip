@@ -129,14 +129,11 @@ extern "C" int spk_md_ring_polymer_step_f32(const float* q_all, const float* p_a
   SPK_CHECK_ARG(n_beads >= 1 && n_beads <= 96 && n_atoms >= 0, "spk_md_ring_polymer_step_f32: bad sizes (n_beads <= 96)");
   if (n_beads > 64) {   // 16 B^2 bytes of dynamic LDS: above 64 KB the launch needs the attribute -- a property of the function ON ONE
                         // DEVICE, so it is tracked per device (once each, not a stream operation)
-    static std::atomic<uint64_t> attr_set[4];            // bit d of word d / 64
-    int dev = 0;
-    SPK_HIP_TRY(hipGetDevice(&dev));
-    const uint64_t bit = 1ull << (dev & 63);
-    std::atomic<uint64_t>& word = attr_set[(dev >> 6) & 3];
-    if (!(word.load(std::memory_order_acquire) & bit)) {
+    static SpkPerDevice attr_set;
+    int attr_dev;
+    if (attr_set.pending(&attr_dev)) {
       SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_md_ring_polymer, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 96 * 96));
-      word.fetch_or(bit, std::memory_order_release);
+      attr_set.mark(attr_dev);
     }
   }
   SPK_CHECK_ARG(bead0 >= 0 && n_local >= 0 && bead0 + n_local <= n_beads, "spk_md_ring_polymer_step_f32: bead range outside [0, n_beads)");

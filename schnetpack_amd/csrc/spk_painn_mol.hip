@@ -1670,10 +1670,11 @@ template <int K, bool TILED, bool POT>
 static int launch_painn_mol_fwd_t(const PmFwdArgs& a, hipStream_t stream) {
   const size_t lds = painn_mol_fwd_lds();
   auto kern = k_painn_mol_fwd<K, TILED, POT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SpkPerDevice attr_set;
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_dev);
   }
   int grid = a.n_groups;
   const int maxg = spk_num_cus();
@@ -1748,10 +1749,11 @@ template <int K, bool POT>
 static int launch_painn_mol_bwd_t(const PmBwdArgs& a, hipStream_t stream) {
   const size_t lds = painn_mol_bwd_lds();
   auto kern = k_painn_mol_bwd<K, POT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SpkPerDevice attr_set;
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_dev);
   }
   int grid = a.n_groups;
   const int maxg = spk_num_cus();

@@ -438,20 +438,22 @@ template <int F, int KPB, bool MU0>
 int launch_tile(const MsgArgs& a, hipStream_t stream) {
   const int64_t nt = (a.E + 31) / 32;
   const size_t lds = (size_t)(3 * (F / 32) * KPB * 256) * sizeof(float) + 4 * 32 * sizeof(TileRec) + 16;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SpkPerDevice attr_done;
+  int attr_done_dev;
+  if (attr_done.pending(&attr_done_dev)) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile<F, KPB, MU0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    attr_done.mark(attr_done_dev);
   }
     // XCD-contiguous walk: 680 -> 625 us on the 32k-atom water box (profiles/r04_tile_experiments.txt)
   const int xcd_map = spk_xcd_walk_default();     // SPK_XCD_WALK=0 switches it off
   static const int wavesN = [] { const char* e = getenv("SPK_TILE_WAVES"); return (e && (e[0] == '3' || e[0] == '4')) ? e[0] - '0' : 0; }();
   if (wavesN) {
-    static bool attrN = false;
-    if (!attrN) {
+    static SpkPerDevice attrN;
+    int attrN_dev;
+    if (attrN.pending(&attrN_dev)) {
       SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile<F, KPB, MU0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile<F, KPB, MU0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attrN = true;
+      attrN.mark(attrN_dev);
     }
     const int gridN = (spk_grid_for(nt, 4, spk_num_cus() * wavesN) + 7) / 8 * 8;
     if (wavesN == 3) hipLaunchKernelGGL((k_painn_msg_tile<F, KPB, MU0, 3>), dim3(gridN), dim3(256), lds, stream, a, (int)nt, xcd_map);
@@ -469,10 +471,11 @@ template <int F, int KPB, bool GEOM, bool MU0>
 int launch_tile_bwd(const MsgArgs& a, hipStream_t stream) {
   const int64_t nt = (a.E + 31) / 32;
   const size_t lds = (size_t)(3 * (F / 32) * KPB * 256) * sizeof(float) + 4 * 32 * sizeof(TileRec) + 4 * 4 * 32 * 9 * sizeof(float) + 16;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SpkPerDevice attr_done;
+  int attr_done_dev;
+  if (attr_done.pending(&attr_done_dev)) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_tile_bwd<F, KPB, GEOM, MU0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    attr_done.mark(attr_done_dev);
   }
   const int xcd_map = spk_xcd_walk_default();
   const int grid = xcd_map ? (spk_grid_for(nt, 4, spk_num_cus()) + 7) / 8 * 8 : spk_grid_for(nt, 4, spk_num_cus());

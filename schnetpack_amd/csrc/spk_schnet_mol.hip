@@ -647,10 +647,11 @@ template <int KPB>
 static int launch_mol_fwd(const MolFwdArgs& a, hipStream_t stream) {
   const size_t lds = mol_fwd_lds(KPB);
   auto kern = k_schnet_mol_fwd<KPB>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SpkPerDevice attr_set;
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_dev);
   }
   int grid = a.n_groups;
   const int maxg = spk_num_cus();
@@ -1173,10 +1174,11 @@ template <int KPB>
 static int launch_mol_bwd(const MolBwdArgs& a, hipStream_t stream) {
   const size_t lds = mol_bwd_lds(KPB);
   auto kern = k_schnet_mol_bwd<KPB>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SpkPerDevice attr_set;
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
     SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_dev);
   }
   int grid = a.n_groups;
   const int maxg = spk_num_cus();

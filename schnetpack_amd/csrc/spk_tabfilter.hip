@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_cfconv_tab_bwd(const float* __restrict_
 // ---- registry: tables are attached to a filter network by the device pointer of its filter_network.1.weight (the key the
 // general SchNet driver hands to the cfconv launchers); spk_schnet_cfconv_* run the table kernels for registered layers
 #include <mutex>
-struct TabEntry { const float* key; const float* table; int n_knots; float d_max; };
+struct TabEntry { const float* key; const float* table; int n_knots; float d_max; uint64_t stamp; };      // stamp: version of the weights the table was built from (0 = untracked)
 static TabEntry g_tabs[64];
 static int g_ntabs = 0;
 static std::mutex g_tab_mutex;
@@ -126,15 +126,36 @@ extern "C" int spk_filter_table_set(const float* key, const float* table, int32_
   std::lock_guard<std::mutex> lock(g_tab_mutex);
   for (int i = 0; i < g_ntabs; ++i)
     if (g_tabs[i].key == key) {
-      if (table) { g_tabs[i].table = table; g_tabs[i].n_knots = n_knots; g_tabs[i].d_max = d_max; }
+      if (table) { g_tabs[i].table = table; g_tabs[i].n_knots = n_knots; g_tabs[i].d_max = d_max; g_tabs[i].stamp = 0; }
       else { g_tabs[i] = g_tabs[g_ntabs - 1]; --g_ntabs; }
       return SPK_OK;
     }
   if (!table) return SPK_OK;
   SPK_CHECK_ARG(key && n_knots >= 2 && d_max > 0.f, "spk_filter_table_set: bad arguments");
   SPK_CHECK_ARG(g_ntabs < 64, "spk_filter_table_set: more than 64 tabulated layers");
-  g_tabs[g_ntabs++] = TabEntry{key, table, n_knots, d_max};
+  g_tabs[g_ntabs++] = TabEntry{key, table, n_knots, d_max, 0};
   return SPK_OK;
+}
+// A table is a SNAPSHOT of the weights.  The caller that owns the weights records their version beside it (stamp) and asks, whenever
+// it sees the weights again with a version of its own, whether the snapshot is still theirs: a stale table is dropped (the exact
+// filter network runs again) instead of being served silently.  Returns 1 when an entry was dropped.
+extern "C" int spk_filter_table_set_stamp(const float* key, uint64_t stamp) {
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  for (int i = 0; i < g_ntabs; ++i)
+    if (g_tabs[i].key == key) { g_tabs[i].stamp = stamp; return SPK_OK; }
+  return SPK_ERR_ARG;
+}
+extern "C" int spk_filter_table_drop_if_stale(const float* key, uint64_t stamp) {
+  if (g_ntabs == 0) return 0;
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  for (int i = 0; i < g_ntabs; ++i)
+    if (g_tabs[i].key == key) {
+      if (g_tabs[i].stamp == 0 || g_tabs[i].stamp == stamp) return 0;
+      g_tabs[i] = g_tabs[g_ntabs - 1];
+      --g_ntabs;
+      return 1;
+    }
+  return 0;
 }
 extern "C" void spk_filter_table_clear() {
   std::lock_guard<std::mutex> lock(g_tab_mutex);

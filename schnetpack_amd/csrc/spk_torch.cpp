@@ -522,6 +522,8 @@ std::shared_ptr<SchnetModel> get_schnet(at::TensorList ws, int64_t F, int64_t nf
     P.in2f_w = fp(t[0]); P.fn_w1 = fp(t[1]); P.fn_b1 = fp(t[2]); P.fn_w2 = fp(t[3]); P.fn_b2 = fp(t[4]);
     P.f2out_w1 = fp(t[5]); P.f2out_b1 = fp(t[6]); P.f2out_w2 = fp(t[7]); P.f2out_b2 = fp(t[8]);
     P.in2f_wT = fp(in2fT); P.f2out_w1T = fp(w1T); P.f2out_w2T = fp(w2T);
+    if (spk_filter_table_drop_if_stale(P.fn_w2, 1 + version_of(t[1]) + version_of(t[2]) + version_of(t[3]) + version_of(t[4])))      // (versions only grow: their sum names the state of the four filter-network tensors)
+      TORCH_WARN("spk_hip: the filter table of a SchNet interaction was built from other weights (version changed); dropped -- the exact filter network runs");
   }
   M->m.n_atom_basis = (int32_t)F; M->m.n_filters = (int32_t)nf; M->m.n_interactions = (int32_t)L; M->m.reserved = 0;
   M->m.layers = M->layers.data(); M->m.wpack = nullptr;
@@ -569,6 +571,8 @@ std::shared_ptr<PainnModel> get_painn(at::TensorList ws, int64_t F, bool shared_
     const int64_t row0 = shared_filters ? 0 : 3 * F * l;
     P.filt_w = fp(fw) + row0 * n_rbf;
     P.filt_b = fp(fb) + row0;
+    if (spk_filter_table_drop_if_stale(P.filt_w, 1 + version_of(fw) + version_of(fb)))
+      TORCH_WARN("spk_hip: the filter table of a PaiNN interaction was built from other weights (version changed); dropped -- the exact filter runs");
   }
   M->m.n_atom_basis = (int32_t)F; M->m.n_interactions = (int32_t)L; M->m.epsilon = epsf; M->m.reserved = 0;
   M->m.layers = M->layers.data(); M->m.wpack = nullptr;
@@ -1629,7 +1633,10 @@ void clear_caches_op() {
   g_painn.clear();
   g_heads.clear();
 }
-void weights_changed_op() { g_weight_generation.fetch_add(1, std::memory_order_acq_rel); }
+void weights_changed_op() {
+  g_weight_generation.fetch_add(1, std::memory_order_acq_rel);
+  spk_filter_table_clear();      // tabulated filters (opt-in experiment) are snapshots of the weights: all stale now
+}
 
 // --- CPU key: loud refusal (the dispatcher's own "no kernel" message does not say why); one boxed kernel for every operator
 void no_cpu_boxed(const c10::OperatorHandle& op, c10::Stack*) {

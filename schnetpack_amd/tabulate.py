@@ -12,13 +12,31 @@ The tables are a snapshot of the weights: call :func:`tabulate_filters` again af
 :func:`clear_filter_tables` to go back.
 """
 import math
+import weakref
 from typing import Optional
 
 import torch
 
 from . import _lib
 
-_KEEP = {}      # id(representation) -> (tables tensor [L, n_knots, F, 4], keys)
+# representation (weak) -> (tables tensor [L, n_knots, F, 4], device addresses the tables are registered under).  The addresses are kept as
+# numbers: a model moved with .to() / re-allocated weights is detached by the addresses it WAS registered under, and a collected
+# representation takes its entries with it (weakref finalizer) -- no stale address stays behind for a later allocation to alias.  The version
+# of the weights travels with each table (spk_filter_table_set_stamp): the operator library drops a table whose weights changed in place.
+_KEEP = weakref.WeakKeyDictionary()
+
+
+def _detach(addresses):
+    import ctypes
+    for a in addresses:
+        _lib.lib().spk_filter_table_set(ctypes.c_void_p(a), None, 0, 0.0)
+
+
+def _remember(rep, table, addresses):
+    _KEEP[rep] = (table, list(addresses))
+    weakref.finalize(rep, _detach, list(addresses))
+
+
 
 
 def pack_knots(v: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
@@ -100,8 +118,9 @@ def _tabulate_painn(rep, n_knots: int) -> torch.Tensor:
         rows = slice(0, 3 * F) if shared else slice(3 * F * l, 3 * F * (l + 1))
         key = rep.filter_net.weight.detach()[rows]
         _lib.check(_lib.lib().spk_filter_table_set(_lib.fptr(key), _lib.fptr(table[l]), int(n_knots), cutoff))
-        keys.append(key)
-    _KEEP[id(rep)] = (table, keys)
+        _lib.check(_lib.lib().spk_filter_table_set_stamp(_lib.fptr(key), 1 + rep.filter_net.weight._version + rep.filter_net.bias._version))
+        keys.append(key.data_ptr())
+    _remember(rep, table, keys)
     torch.ops.spk_hip.clear_caches()
     return table
 
@@ -132,8 +151,10 @@ def tabulate_filters(representation, n_knots: Optional[int] = None) -> torch.Ten
     for l, it in enumerate(rep.interactions):
         w2 = it.filter_network[1].weight
         _lib.check(_lib.lib().spk_filter_table_set(_lib.fptr(w2.detach()), _lib.fptr(table[l]), int(n_knots), cutoff))
-        keys.append(w2)
-    _KEEP[id(rep)] = (table, keys)
+        fn = it.filter_network
+        _lib.check(_lib.lib().spk_filter_table_set_stamp(_lib.fptr(w2.detach()), 1 + fn[0].weight._version + fn[0].bias._version + w2._version + fn[1].bias._version))
+        keys.append(w2.data_ptr())
+    _remember(rep, table, keys)
     torch.ops.spk_hip.clear_caches()          # parameter blocks are rebuilt: the drivers look the tables up by weight address
     return table
 
@@ -144,7 +165,6 @@ def clear_filter_tables(representation: Optional[object] = None):
         _lib.lib().spk_filter_table_clear()
         _KEEP.clear()
         return
-    ent = _KEEP.pop(id(representation), None)
+    ent = _KEEP.pop(representation, None)
     if ent is not None:
-        for w2 in ent[1]:
-            _lib.check(_lib.lib().spk_filter_table_set(_lib.fptr(w2.detach()), None, 0, 0.0))
+        _detach(ent[1])

@@ -146,6 +146,8 @@ struct EmuBackend {
   void flat(const char*, void (*k)(KA...), int64_t, A... a) { k(static_cast<KA>(a)...); }
   template <class... KA, class... A>
   void rows(const char*, void (*k)(KA...), int64_t, A... a) { k(static_cast<KA>(a)...); }
+  template <class... KA, class... A>
+  void slotted(const char*, void (*k)(KA...), int64_t, A... a) { k(static_cast<KA>(a)...); }
 };
 
 extern "C" {

@@ -518,3 +518,34 @@ def test_tabulated_filter_experiment_matches_reference_goldens(dev, case):
     assert rel_err(out["scalar_representation"], ref["scalar_representation"]) < TOL
     if "vector_representation" in ref:
         assert rel_err(out["vector_representation"], ref["vector_representation"]) < TOL
+
+
+@pytest.mark.parametrize("case", ["schnet_aspirin8.npz", "painn_aspirin8.npz"])
+def test_filter_tables_are_dropped_when_their_weights_change(dev, case):
+    """A filter table is a snapshot of the weights (schnetpack_amd/tabulate.py, opt-in): after an in-place change of a filter weight the
+    operator library must not keep serving it -- the next call runs the exact filter network on the new weights (round-3 advice)."""
+    import warnings
+    from schnetpack_amd import _lib, tabulate
+    batch, ref, meta = load_golden(case)
+    rep_p, head_p = golden_params(meta)
+    model = _build(meta, dev, rep_p, head_p).eval()
+    rep = model.representation
+    try:
+        tabulate.tabulate_filters(rep, 512)
+        _force_call(model, batch, dev)
+        with torch.no_grad():
+            w = rep.interactions[0].filter_network[1].weight if str(meta["kind"]) == "schnet" else rep.filter_net.weight
+            w.mul_(1.25)
+        _lib.profile_enable(True); _lib.profile_report()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = _force_call(model, batch, dev)
+        tags = _lib.profile_report()
+    finally:
+        _lib.profile_enable(False)
+        tabulate.clear_filter_tables()
+    exact = _force_call(model, batch, dev)          # no tables at all: the same (changed) weights through the default kernels
+    assert rel_err(out["forces"], exact["forces"]) < 1e-6 and rel_err(out["energy"], exact["energy"]) < 1e-6
+    assert rel_err(out["forces"], ref["forces"]) > 1e-3          # (the weights did change)
+    if str(meta["kind"]) == "painn":
+        assert not any(t.startswith("painn_msg_fwd_tab") for t in tags), tags      # one shared filter_net: every interaction's table was stale
