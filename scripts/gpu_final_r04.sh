@@ -9,8 +9,10 @@ cd $ROOT
 export TMPDIR=/tmp
 echo "== default bench"; SECONDS=0
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "rc=$? wall=${SECONDS}s" | tee $OUT/bench_default.wall; cut -c1-300 $OUT/bench_default.json
+if [ -z "$SKIP_DRIVER_LINE" ]; then
 echo "== driver command"; SECONDS=0
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_command.json 2> $OUT/bench_driver.err; echo "rc=$? wall=${SECONDS}s" | tee $OUT/bench_driver.wall; cut -c1-200 $OUT/bench_driver_command.json
+fi
 for KIND in schnet painn; do
   echo "== bench water $KIND"
   timeout 600 python bench.py --kind $KIND --workload water --steps 30 --warmup 5 --no-md --no-sweep --cpu-reps 1 > $OUT/bench_water_$KIND.json 2> $OUT/bench_water_$KIND.err; echo "rc=$?"; cut -c1-200 $OUT/bench_water_$KIND.json
@@ -32,5 +34,5 @@ for k in schnet painn; do
   f=$(find /tmp/prof_$k -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" $OUT/train_${k}_kernel_stats.csv
 done
-echo "== kernel resources"; timeout 600 python scripts/kernel_resources.py > $OUT/kernel_resources.md 2>/dev/null; tail -3 $OUT/kernel_resources.md
+if [ -z "$SKIP_RESOURCES" ]; then echo "== kernel resources"; timeout 600 python scripts/kernel_resources.py > $OUT/kernel_resources.md 2>/dev/null; tail -3 $OUT/kernel_resources.md; fi
 du -sh $OUT
