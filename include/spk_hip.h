@@ -324,7 +324,8 @@ int spk_dense_bwd_input_f32(const float* dy, const float* pre, const float* w, c
  *   SPK_DD_DUAL_BWD  (p_v, p_t) = (g_z, h_z), the cotangents of z = act(a), z_t = act'(a) a_t with a = pre_v_in, a_t = pre_t_in (NULL = 0):
  *                    y_v = g_z act'(a) + h_z act''(a) a_t,  y_t = h_z act'(a)
  * All row-major [m, .]; every pointer 16-byte aligned; k_in % 4 == 0, n_out % 4 == 0 and at most 4 tiles of 32 x 32 per compute unit
- * (spk_dense_dual_supported): one workgroup per tile -- larger problems are two spk_dense_f32 launches and an element-wise one. */
+ * (spk_dense_dual_supported): one workgroup per tile; the forward pair (FWD, trans = 0) also runs at any size on a grid-stride kernel
+ * (spk_dense_dual_fwd_supported) -- other modes of larger problems are two spk_dense_f32 launches and an element-wise one. */
 #define SPK_DD_FWD 0
 #define SPK_DD_TANGENT 1
 #define SPK_DD_DUAL_BWD 2
@@ -339,6 +340,7 @@ typedef struct {
   int32_t k_in, n_out, act, mode, trans;
 } spk_dense_dual_t;
 int spk_dense_dual_supported(int64_t m, int32_t k_in, int32_t n_out);
+int spk_dense_dual_fwd_supported(int64_t m, int32_t k_in, int32_t n_out);   /* mode FWD with trans = 0: any number of tiles (grid-stride kernel) */
 int spk_dense_dual_f32(const spk_dense_dual_t* d, void* stream);
 
 /* Chain of up to 3 Dense layers in ONE launch (e.g. f2out.0 -> f2out.1 (+residual) -> next in2f of

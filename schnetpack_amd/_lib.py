@@ -170,6 +170,7 @@ _PROTOS = {
     "spk_filter_table_set_stamp": (ctypes.c_int, [c_f, ctypes.c_uint64]),
     "spk_filter_table_drop_if_stale": (ctypes.c_int, [c_f, ctypes.c_uint64]),
     "spk_dense_dual_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),
+    "spk_dense_dual_fwd_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),
     "spk_dense_dual_f32": (ctypes.c_int, [P(DenseDualT), c_f]),
     "spk_dense_chain_f32": (ctypes.c_int, [P(ChainT), c_f]),
     "spk_schnet_cfconv_fwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f]),

@@ -923,10 +923,80 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dual_sk(DenseDualArgs a) {
   *(f32x4*)(a.out_t + off) = ot;
 }
 
+// Many tiles (pair rows of larger batches: the filter networks of a 128-frame training step have 40 k rows): the forward pair on the
+// grid-stride form of k_dense_mfma -- one wave walks 32 x 32 tiles, whole contraction, both accumulators, epilogue in the wave.  At this
+// size the separate route is two Dense launches plus an element-wise pass over 2 x [rows, n_out] that is pure memory traffic (PaiNN's
+// cutoff product: 150 us of a 2.5 ms step).
+__global__ __launch_bounds__(256) void k_dense_dual_tiles(DenseDualArgs a, int64_t ntasks) {
+  constexpr int CH = 4;
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 5, el = lane & 31;
+  const int KC = a.KC, NW = a.NW;
+  const int tcount = (NW + 31) / 32;
+  const int nug = (KC + 7) / 8;
+  const int nch = (nug + CH - 1) / CH;
+  const int act = a.act;
+  for (int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntasks; task += (int64_t)gridDim.x * 4) {
+    const int64_t mt = task / tcount;
+    const int t = (int)(task % tcount);
+    const int64_t m = mt * 32 + el;
+    const bool valid = m < a.M;
+    const int64_t mc = valid ? m : (a.M - 1);
+    const float* row_t = a.in_t + mc * KC;
+    const float* row_v = a.in_v + mc * KC;
+    f32x4 a0[CH], t0[CH], v0[CH], a1[CH], t1[CH], v1[CH];
+    dd_load_chunk<false, CH>(a0, t0, v0, 0, nug, row_t, row_v, true, a.w, KC, NW, t, el, hi);
+    float fcm = 0.f, fc1m = 0.f;
+    if (a.fc && valid) { fcm = a.fc[m]; fc1m = a.fc1[m]; }
+    f32x16 acc_v, acc_t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      acc_v[r] = (a.b && col < NW) ? a.b[col] : 0.f;
+      acc_t[r] = 0.f;
+    }
+    for (int c = 0; c < nch; c += 2) {
+      if (c + 1 < nch) dd_load_chunk<false, CH>(a1, t1, v1, c + 1, nug, row_t, row_v, true, a.w, KC, NW, t, el, hi);
+      acc_v = dense_mfma_chunk(a0, v0, c, nug, acc_v);
+      acc_t = dense_mfma_chunk(a0, t0, c, nug, acc_t);
+      if (c + 2 < nch) dd_load_chunk<false, CH>(a0, t0, v0, c + 2, nug, row_t, row_v, true, a.w, KC, NW, t, el, hi);
+      if (c + 1 < nch) {
+        acc_v = dense_mfma_chunk(a1, v1, c + 1, nug, acc_v);
+        acc_t = dense_mfma_chunk(a1, t1, c + 1, nug, acc_t);
+      }
+    }
+    if (!valid) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = 32 * t + 8 * q + 4 * hi;
+      if (col >= NW) continue;
+      const int64_t off = m * NW + col;
+      f32x4 pv, pt, ov, ot;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float sv = acc_v[4 * q + v], st = acc_t[4 * q + v];
+        pv[v] = sv; pt[v] = st;
+        if (a.fc) { ov[v] = sv * fcm; ot[v] = st * fcm + sv * fc1m; }
+        else { ov[v] = dd_act(act, 0, sv); ot[v] = dd_act(act, 1, sv) * st; }
+      }
+      if (a.pre_v) *(f32x4*)(a.pre_v + off) = pv;
+      if (a.pre_t) *(f32x4*)(a.pre_t + off) = pt;
+      if (a.res_v) ov += *(const f32x4*)(a.res_v + off);
+      if (a.res_t) ot += *(const f32x4*)(a.res_t + off);
+      *(f32x4*)(a.out_v + off) = ov;
+      *(f32x4*)(a.out_t + off) = ot;
+    }
+  }
+}
+
 extern "C" int spk_dense_dual_supported(int64_t m, int32_t k_in, int32_t n_out) {
   if (m <= 0 || k_in <= 0 || n_out <= 0 || k_in % 4 || n_out % 4) return 0;
   const int64_t ntasks = ((m + 31) / 32) * ((n_out + 31) / 32);
   return ntasks <= 4 * (int64_t)spk_num_cus() && spk_get_variant() != SPK_VARIANT_SIMPLE;      // (the bound of the one-tile-per-workgroup Dense kernel)
+}
+// the forward pair (mode FWD, trans = 0) has a second kernel for any number of tiles
+extern "C" int spk_dense_dual_fwd_supported(int64_t m, int32_t k_in, int32_t n_out) {
+  return m > 0 && k_in > 0 && n_out > 0 && k_in % 4 == 0 && n_out % 4 == 0 && spk_get_variant() != SPK_VARIANT_SIMPLE;
 }
 
 extern "C" int spk_dense_dual_f32(const spk_dense_dual_t* d, void* stream_) {
@@ -934,7 +1004,9 @@ extern "C" int spk_dense_dual_f32(const spk_dense_dual_t* d, void* stream_) {
   SPK_CHECK_ARG(d != nullptr, "spk_dense_dual_f32: null description");
   SPK_CHECK_ARG(d->m >= 0 && d->k_in > 0 && d->n_out > 0, "spk_dense_dual_f32: bad sizes");
   if (d->m == 0) return SPK_OK;
-  SPK_CHECK_ARG(spk_dense_dual_supported(d->m, d->k_in, d->n_out), "spk_dense_dual_f32: shape m=%lld k=%d n=%d outside the pair kernel (see spk_dense_dual_supported)",
+  const bool small = spk_dense_dual_supported(d->m, d->k_in, d->n_out) != 0;
+  const bool big_fwd = !small && d->mode == SPK_DD_FWD && !d->trans && spk_dense_dual_fwd_supported(d->m, d->k_in, d->n_out);
+  SPK_CHECK_ARG(small || big_fwd, "spk_dense_dual_f32: shape m=%lld k=%d n=%d outside the pair kernels (see spk_dense_dual_supported / _fwd_supported)",
                 (long long)d->m, d->k_in, d->n_out);
   SPK_CHECK_ARG(d->mode == SPK_DD_FWD || d->mode == SPK_DD_TANGENT || d->mode == SPK_DD_DUAL_BWD, "spk_dense_dual_f32: unknown mode %d", d->mode);
   SPK_CHECK_ARG(d->act == SPK_ACT_NONE || d->act == SPK_ACT_SSP || d->act == SPK_ACT_SILU, "spk_dense_dual_f32: unknown activation %d", d->act);
@@ -952,6 +1024,12 @@ extern "C" int spk_dense_dual_f32(const spk_dense_dual_t* d, void* stream_) {
   a.fc = d->fc; a.fc1 = d->fc1; a.out_v = d->y_v; a.out_t = d->y_t; a.pre_v = d->pre_v; a.pre_t = d->pre_t;
   a.M = d->m; a.KC = d->k_in; a.NW = d->n_out; a.act = d->act; a.mode = d->mode;
   SpkProfScope prof(d->mode == SPK_DD_FWD ? "dense_dual_fwd" : (d->mode == SPK_DD_TANGENT ? "dense_tangent" : "dense_dual_bwd"), stream);
+  if (big_fwd) {
+    const int64_t ntasks = ((d->m + 31) / 32) * ((d->n_out + 31) / 32);
+    hipLaunchKernelGGL(k_dense_dual_tiles, dim3(spk_grid_for(ntasks, 4, spk_num_cus() * 8)), dim3(256), 0, stream, a, ntasks);
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
   const unsigned nt = (unsigned)(((d->m + 31) / 32) * ((d->n_out + 31) / 32));
   const int nug = (d->k_in + 7) / 8;
 #define SPK_DDL(T, CH, WV) hipLaunchKernelGGL((k_dense_dual_sk<T, CH, WV>), dim3(nt), dim3(64 * WV), 0, stream, a)

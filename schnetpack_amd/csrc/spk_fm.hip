@@ -258,20 +258,21 @@ struct FmDeviceBackend {
   // the reverse of the pair LOSES (SchNet +3 us, PaiNN +18 us per step: its epilogue evaluates act' and act'' behind the transposed-weight
   // loads, longer than the Dense launch plus the short element-wise launch it replaces) -- default mask 3, the reverse stays separate.
   static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-  bool dual_ok(int64_t M, int KC, int NW, int kind = 1) const {      // kind: 1 forward pair, 2 tangent alone, 4 reverse of the pair (SPK_FM_DUAL_MASK: tuning)
+  static bool dual_enabled(int kind) {      // kind: 1 forward pair, 2 tangent alone, 4 reverse of the pair (SPK_FM_DUAL_MASK: tuning)
     static const int mask = [] {
       const char* e = getenv("SPK_FM_NO_DUAL");
       if (e && e[0] == '1') return 0;
       const char* m = getenv("SPK_FM_DUAL_MASK");
       return m ? atoi(m) : 3;
     }();
-    return (mask & kind) && spk_dense_dual_supported(M, KC, NW);
+    return (mask & kind) != 0;
   }
+  bool dual_ok(int64_t M, int KC, int NW, int kind = 1) const { return dual_enabled(kind) && spk_dense_dual_supported(M, KC, NW); }
   int dense_dual(const float* x2, const float* w, const float* b, float* y2, float* pre2, int64_t M, int k, int n_out, int act, const float* fc, const float* fc1) {
     const float* xt = x2 + M * k;
     float* yt = y2 + M * n_out;
     float* pt = pre2 ? pre2 + M * n_out : nullptr;
-    if (dual_ok(M, k, n_out) && al16(xt) && al16(yt) && al16(pt)) {
+    if (dual_enabled(1) && spk_dense_dual_fwd_supported(M, k, n_out) && al16(xt) && al16(yt) && al16(pt)) {      // (one-tile-per-workgroup kernel up to 4 tiles per CU, grid-stride kernel beyond)
       spk_dense_dual_t d = {};
       d.x_v = x2; d.x_t = xt; d.w = w; d.b = b; d.fc = fc; d.fc1 = fc1; d.y_v = y2; d.y_t = yt; d.pre_v = pre2; d.pre_t = pt;
       d.m = M; d.k_in = k; d.n_out = n_out; d.act = act; d.mode = SPK_DD_FWD; d.trans = 0;

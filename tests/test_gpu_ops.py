@@ -326,6 +326,21 @@ def test_dense_on_value_tangent_pairs(dev, m, k, n, act):
     yv, yt = new(m, k), new(m, k)
     run(x_v=gzd, x_t=hzd, w=wd, pre_v_in=avd, pre_t_in=atd, y_v=yv, y_t=yt, m=m, k_in=n, n_out=k, act=a, mode=2, trans=1)
     assert rel_err(yv.cpu(), Gz * a1 + Hz * a2 * at.double()) < TOL and rel_err(yt.cpu(), Hz * a1) < TOL
+    # the forward pair beyond the one-tile-per-workgroup budget: grid-stride kernel (pair rows of larger batches), a partial last row tile
+    mb = (40000 if n <= 384 else 8000) + 7
+    assert not L.spk_dense_dual_supported(mb, k, n) and L.spk_dense_dual_fwd_supported(mb, k, n)
+    xb = torch.randn(2, mb, k, generator=g); fcb = torch.rand(mb, generator=g); fc1b = torch.randn(mb, generator=g)
+    xbd, fcbd, fc1bd = D(xb), D(fcb), D(fc1b)
+    pvb = xb[0].double() @ w.double().T + b.double(); ptb = xb[1].double() @ w.double().T
+    yv, yt, pv, pt = new(mb, n), new(mb, n), new(mb, n), new(mb, n)
+    run(x_v=xbd[0], x_t=xbd[1], w=wd, b=bd, y_v=yv, y_t=yt, pre_v=pv, pre_t=pt, m=mb, k_in=k, n_out=n, act=a, mode=0, trans=0)
+    d1b, _ = derivs(pvb)
+    assert rel_err(pv.cpu(), pvb) < TOL and rel_err(pt.cpu(), ptb) < TOL and rel_err(yv.cpu(), f0(pvb)) < TOL and rel_err(yt.cpu(), d1b * ptb) < TOL
+    if act is None:
+        yv, yt = new(mb, n), new(mb, n)
+        run(x_v=xbd[0], x_t=xbd[1], w=wd, b=bd, fc=fcbd, fc1=fc1bd, y_v=yv, y_t=yt, m=mb, k_in=k, n_out=n, act=a, mode=0, trans=0)
+        assert rel_err(yv.cpu(), pvb * fcb.double()[:, None]) < TOL
+        assert rel_err(yt.cpu(), ptb * fcb.double()[:, None] + pvb * fc1b.double()[:, None]) < TOL
     # refused: shapes outside the MFMA tiles, a missing saved pre-activation
     bad = _lib.DenseDualT()
     bad.x_t = _lib.fptr(xtd); bad.w = _lib.fptr(wd); bad.y_t = _lib.fptr(yt); bad.m = m; bad.k_in = k; bad.n_out = n; bad.mode = 1
