@@ -71,3 +71,31 @@ def test_block_plan_size_table_and_exports():
     assert L.spk_blocks_sizes(-1, 0, 20, 128, sizes) != 0
     for name in ("spk_blocks_build", "spk_blocks_prepare_f32", "spk_painn_set_block", "spk_painn_blk_set_debug_buffer"):
         assert hasattr(L, name)
+
+
+def test_flat_adamw_chunk_table_and_cpu_refusal():
+    """train.FlatAdamW: the chunk table covers every parameter element exactly once in bucket order (chunks of at most 2048), and the
+    optimizer has no CPU route -- stepping on host tensors fails loudly (the product path never falls back)."""
+    import pytest
+    import torch
+    from schnetpack_amd._lib import SpkHipError
+    from schnetpack_amd.parallel import FlatGradAllReduce
+    from schnetpack_amd.train import FlatAdamW
+    shapes = [(128, 20), (128,), (3, 50, 50), (1,), (2049,)]
+    params = [torch.nn.Parameter(torch.randn(*sh)) for sh in shapes]
+    red = FlatGradAllReduce(params, as_views=True)
+    opt = FlatAdamW(red, lr=1e-3)
+    rows = opt.chunks.tolist()
+    assert opt.numel == sum(p.numel() for p in params) == red.flat.numel()
+    flat_off = 0
+    for p in params:
+        mine = [r for r in rows if r[0] == p.data_ptr()]
+        assert [r[1] for r in mine] == list(range(0, p.numel(), FlatAdamW.CHUNK))          # offsets inside the parameter
+        assert [r[2] for r in mine] == [flat_off + c for c in range(0, p.numel(), FlatAdamW.CHUNK)]   # offsets inside the bucket
+        assert sum(r[3] for r in mine) == p.numel() and all(0 < r[3] <= FlatAdamW.CHUNK for r in mine)
+        flat_off += p.numel()
+    assert len(rows) == sum((p.numel() + FlatAdamW.CHUNK - 1) // FlatAdamW.CHUNK for p in params)
+    with pytest.raises(SpkHipError):
+        opt.step()
+    with pytest.raises(ValueError):
+        FlatAdamW(FlatGradAllReduce([torch.nn.Parameter(torch.zeros(4, dtype=torch.float64))], as_views=False))
