@@ -557,7 +557,9 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
             # not useful), else the issued work itself
             if kd.get("bound") == "mfma" and mf is not None:
                 kd["issued_frac_of_peak"] = mf
-                kd["executed_frac_of_peak"] = round(mf / meas["issued_over_useful"], 4) if meas.get("issued_over_useful") else mf
+                # (never above the issued work: where the model of the useful work books MORE than the counters saw issued -- one filter per
+                #  undirected pair against the convention's per-direction count -- the issued work is the executed work)
+                kd["executed_frac_of_peak"] = round(mf / max(1.0, meas["issued_over_useful"]), 4) if meas.get("issued_over_useful") else mf
             elif kd.get("bound") == "hbm" and hf is not None:
                 kd["executed_frac_of_peak"] = hf
         if roofline is not None and "measured" in kernels.get(roofline["kernel"], {}):
@@ -569,6 +571,11 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
             if ex is not None:
                 roofline["executed_frac_of_peak"] = ex
                 roofline["executed_frac_source"] = "counters of this run (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, resp. FETCH_SIZE x 2 + WRITE_SIZE, over the HIP-event time)"
+                if roofline["bound"] == "mfma" and "frac_by_convention" not in roofline and roofline["frac"] > m_.get("mfma_frac_of_peak", 1.0):
+                    # the convention books more matrix-core work than the counters of this run saw ISSUED: same treatment as a fraction above 1
+                    roofline["achieved_by_convention"], roofline["frac_by_convention"] = roofline["achieved"], roofline["frac"]
+                    roofline["frac_flag"] = ("frac_by_convention exceeds the issued matrix-core work of this run's counters (the algorithmic convention of SURVEY.md 8(d) books "
+                                             "more than the kernel issues: one filter per undirected pair); `achieved` and `frac` of this object are the executed work")
                 if "frac_by_convention" in roofline:      # the headline fraction is the executed one
                     roofline["frac"] = ex
                     roofline["achieved"] = round(ex * roofline["peak"], 3)
