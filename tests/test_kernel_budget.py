@@ -15,7 +15,11 @@ from schnetpack_amd.csrc import build as B
 
 # mangled-name fragment -> (max scratch bytes per lane, min waves per SIMD)
 BUDGET = {
-    "spk_dense.hip": {"k_gemm_pairILb1E": (0, 2), "k_gemm_pairILb0E": (0, 2), "k_dense_mfmaILi0ELb1ELi0E": (0, 2), "k_dense_mfmaILi0ELb0ELi0E": (0, 2)},
+    # (round 4: the pair Dense kernels of the training step and the double-buffered weight-gradient loop -- at 32 row pairs per batch the
+    #  latter went 940 B/lane into scratch with its 64-bit lane addresses; it stays at 16)
+    "spk_dense.hip": {"k_gemm_pairILb1E": (0, 2), "k_gemm_pairILb0E": (0, 2), "k_dense_mfmaILi0ELb1ELi0E": (0, 2), "k_dense_mfmaILi0ELb0ELi0E": (0, 2),
+                      "k_dense_dual_sk": (0, 2), "k_dense_dual_tiles": (0, 2), "k_dense_mfma_skILi0ELb0ELi0ELi4ELi4E": (0, 4)},
+    "spk_fm.hip": {"k_gemm_tn_batched11GemmTnBatch": (0, 2), "k_fm_painn_msg_T_dualIfE": (0, 2), "k_fm_painn_msg_tIfE": (0, 2), "k_fm_cfconv_T_dualIfE": (0, 4)},
     "spk_painn.hip": {"k_painn_mixing_fwd8ILi128E": (0, 2), "k_painn_mixing_bwd8ILi128E": (0, 2)},
     # the two molecule-resident launches sit AT the 256-register limit of two waves per SIMD; the metadata reports a small
     # private segment although no scratch instruction is on a hot path
