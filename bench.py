@@ -215,6 +215,56 @@ def collect_pmc(args, kind, workload, timeout_s=170):
     return res or None
 
 
+PMC_TRAIN_STEPS = 4
+
+
+def collect_train_pmc(args, kind, timeout_s=120):
+    """HBM-side bytes of ONE training step, measured in this run: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only)
+    over a child of this script that runs PMC_TRAIN_STEPS eager steps of the same configuration; every dispatch of the child is summed
+    (library and framework kernels alike) and divided by the number of steps.  KiB per dispatch, FETCH_SIZE x 2 on gfx950
+    (/opt/skills/guides/MI355X_MICROARCH.md).  Returns {"read_bytes", "write_bytes", "dispatches_per_step"} or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="spk_pmc_train_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--mode", "train", "--kind", kind, "--train-frames", str(args.train_frames)]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)
+                p.wait()
+                return None
+            if rc != 0:
+                return None
+            total, n = 0.0, 0
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter:
+                        total += float(row["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return None
+            res["read_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = (2.0 if counter == "FETCH_SIZE" else 1.0) * 1024.0 * total / PMC_TRAIN_STEPS
+            res["dispatches_per_step"] = round(n / PMC_TRAIN_STEPS, 1)
+    except Exception as exc:  # pragma: no cover - depends on the profiler
+        sys.stderr.write("[bench] training PMC pass failed: %s\n" % exc)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 def reference_model(kind, rep_p, head_p, F, n_int, n_rbf, cutoff):
     """The REFERENCE's own modules (NeuralNetworkPotential + PairwiseDistances + SchNet/PaiNN + Atomwise + Forces,
     configs/model/nnp.yaml) through oracle/refshim.py (from /root/reference, or its byte-compiled build oracle/_ref on
@@ -784,8 +834,8 @@ def main():
     model, rep_p, head_p = make_model(args.kind)
 
     if args.mode == "train":
-        line = train_measure(args, args.kind, rank, world, dev, dist, model, rep_p, head_p, args.steps, args.warmup)
-        if rank == 0:
+        line = train_measure(args, args.kind, rank, world, dev, dist, model, rep_p, head_p, args.steps, args.warmup, with_pmc=True)
+        if rank == 0 and line is not None:
             print(json.dumps(line))
         if dist is not None:
             dist.destroy_process_group()
@@ -1160,7 +1210,7 @@ def md_main(args, rank, world, dev, dist, model):
         dist.destroy_process_group()
 
 
-def train_measure(args, kind, rank, world, dev, dist, model, rep_p, head_p, steps, warmup):
+def train_measure(args, kind, rank, world, dev, dist, model, rep_p, head_p, steps, warmup, with_pmc=False):
     """configs[3] (SURVEY.md section 8 cfg 4): rMD17-aspirin training step, PaiNN/SchNet in train() mode
     (Forces with create_graph=True -> double backward through the differentiable HIP primitives), loss
     0.01 MSE(E) + 0.99 MSE(F), AdamW(lr 1e-3), 8 frames per GPU, ONE all-reduce of one flat gradient
@@ -1187,6 +1237,13 @@ def train_measure(args, kind, rank, world, dev, dist, model, rep_p, head_p, step
     def step(i):
         tstep.load_packed(*packed[i % len(packed)])
         return tstep.step()
+
+    if args.pmc_child:          # wrapped by `rocprofv3 --pmc` from collect_train_pmc(): PMC_TRAIN_STEPS eager steps, no output
+        tstep.use_graph = False
+        for i in range(PMC_TRAIN_STEPS):
+            step(i)
+        torch.cuda.synchronize()
+        return None
 
     # launches of one step: the HIP-event profile scopes of the library see its own launches; the step's total (incl. the framework's
     # element-wise / concatenation kernels) is the kernel count of the captured graph -- counted by an eager step under the profiler hooks
@@ -1241,6 +1298,14 @@ def train_measure(args, kind, rank, world, dev, dist, model, rep_p, head_p, step
                 "algorithmic_per_step": work,
                 "note": "algorithmic work of a force-matching step booked as 3 x the force call of its batch (forward + recorded backward + the backward of "
                         "both, SURVEY.md 8(d) / Appendix B) over the wall time of the step; at 8 frames per GPU the step is launch-latency bound"}
+    if world == 1 and with_pmc and not args.no_pmc:      # (the `--mode train` line; the default line's embedded training legs skip the two profiler passes)
+        tp = collect_train_pmc(args, kind)
+        if tp is not None and "read_bytes" in tp and "write_bytes" in tp:
+            roofline["traffic"] = tp["read_bytes"] + tp["write_bytes"]
+            roofline["traffic_detail"] = dict(tp, source="measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) summed over every "
+                                              "dispatch of %d eager steps of this configuration / %d; KiB per dispatch, FETCH_SIZE x 2 (gfx950); includes the moments and "
+                                              "parameters of the optimizer, the saved activations of all four passes and the framework's copies" % (PMC_TRAIN_STEPS, PMC_TRAIN_STEPS))
+            roofline["traffic_frac_of_hbm_peak"] = round(roofline["traffic"] / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         ncores = min(os.cpu_count() or 1, 16)
