@@ -192,3 +192,39 @@ def test_transpose_plan_is_a_stable_sort_by_neighbour(dev):
     assert torch.equal(perm.cpu().long(), ref)
     cp = torch.searchsorted(key[ref].contiguous(), torch.arange(N + 2))
     assert torch.equal(colptr.cpu().long(), cp)
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_large_batch_gradients_are_the_mean_of_its_two_halves(dev, kind):
+    """Size-independent property at a size the float64 oracle does not reach: 320 aspirin frames (6 720 atoms, 860 k (atom, channel) items --
+    the slotted row kernels walk their grid-stride loop twice, the Dense layers of the pair rows take the many-tile kernels, every
+    weight-gradient problem is cut into row slices) against the SAME weights on the two halves of the batch.  Both MSE terms are means over
+    molecules / atoms, so loss_full = (loss_a + loss_b) / 2 and every gradient likewise (task.py:142-146)."""
+    n = 320
+    full = S.molecule_batch("aspirin", n, seed=12)
+    na = full["Z"].shape[0] // 2
+    g = torch.Generator().manual_seed(4)
+    Et, Ft = torch.randn(n, generator=g), torch.randn(full["Z"].shape[0], 3, generator=g)
+
+    def half(lo):
+        atoms = slice(lo * na, (lo + 1) * na)
+        keep = (full["idx_i"] >= lo * na) & (full["idx_i"] < (lo + 1) * na)
+        b = {"Z": full["Z"][atoms], "R": full["R"][atoms], "idx_m": full["idx_m"][atoms] - lo * (n // 2),
+             "idx_i": full["idx_i"][keep] - lo * na, "idx_j": full["idx_j"][keep] - lo * na, "offsets": full["offsets"][keep], "n_mol": n // 2}
+        return b, Et[lo * (n // 2):(lo + 1) * (n // 2)], Ft[atoms]
+
+    rep_p, head_p = _params(kind)
+    E, F, gr, loss = _device_step(kind, rep_p, head_p, full, 3, Et, Ft, dev)
+    parts = []
+    for lo in (0, 1):
+        b, et, ft = half(lo)
+        parts.append(_device_step(kind, rep_p, head_p, b, 3, et, ft, dev))
+    assert rel_err(E, torch.cat([p[0] for p in parts])) < 1e-6 and rel_err(F, torch.cat([p[1] for p in parts])) < 1e-6
+    assert abs(loss - 0.5 * (parts[0][3] + parts[1][3])) / abs(loss) < 1e-5
+    worst = ("", 0.0)
+    for k, v in gr.items():
+        r = 0.5 * (parts[0][2][k] + parts[1][2][k])
+        e = float((v - r).abs().max()) / (float(r.abs().max()) + 1e-300)
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 5e-5, worst
