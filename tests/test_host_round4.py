@@ -99,3 +99,26 @@ def test_flat_adamw_chunk_table_and_cpu_refusal():
         opt.step()
     with pytest.raises(ValueError):
         FlatAdamW(FlatGradAllReduce([torch.nn.Parameter(torch.zeros(4, dtype=torch.float64))], as_views=False))
+
+
+def test_filter_table_registry_stamps():
+    """Host side of the tabulated-filter registry (spk_filter_table_set / _set_stamp / _drop_if_stale; pointers are only stored, nothing is
+    launched): a table whose recorded weight version differs from the caller's is dropped, an untracked or matching one stays."""
+    import ctypes
+    from schnetpack_amd import _lib
+    L = _lib.lib()
+    key, tab = ctypes.c_void_p(0x7000_0000_1000), ctypes.c_void_p(0x7000_0000_2000)
+    L.spk_filter_table_clear()
+    try:
+        assert L.spk_filter_table_set_stamp(key, 5) != 0                      # nothing registered under this key
+        _lib.check(L.spk_filter_table_set(key, tab, 512, 5.0))
+        assert L.spk_filter_table_drop_if_stale(key, 123) == 0                # untracked (stamp 0): never dropped
+        _lib.check(L.spk_filter_table_set_stamp(key, 7))
+        assert L.spk_filter_table_drop_if_stale(key, 7) == 0                  # same version: stays
+        assert L.spk_filter_table_drop_if_stale(ctypes.c_void_p(0x7000_0000_3000), 9) == 0      # other key: untouched
+        assert L.spk_filter_table_drop_if_stale(key, 8) == 1                  # the weights moved on: dropped
+        assert L.spk_filter_table_drop_if_stale(key, 8) == 0                  # ... and gone
+        _lib.check(L.spk_filter_table_set(key, tab, 512, 5.0))                # re-registering resets the stamp
+        assert L.spk_filter_table_drop_if_stale(key, 99) == 0
+    finally:
+        L.spk_filter_table_clear()
