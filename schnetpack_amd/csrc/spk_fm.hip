@@ -93,6 +93,7 @@ extern "C" int spk_transposed_build(const int64_t* idx_i, const int64_t* idx_j, 
 #define FM_TN_MAX 24
 struct GemmTnBatch {
   int n;
+  int xcd_walk;                // 1: XCD-contiguous (slice, tile) order inside a problem (SPK_XCD_WALK=0 switches it off)
   int prefix[FM_TN_MAX + 1];   // first workgroup of every problem
   GemmTnArgs a[FM_TN_MAX];
 };
@@ -111,7 +112,14 @@ __global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_tn_batched(GemmTnBatch b
   a.U = b->a[p].U; a.X = b->a[p].X; a.n = b->a[p].n; a.O = b->a[p].O; a.K = b->a[p].K; a.tiles_k = b->a[p].tiles_k; a.S = b->a[p].S; a.n_tiles = b->a[p].n_tiles;
   a.rows_per_slice = b->a[p].rows_per_slice; a.rows_per_wave = b->a[p].rows_per_wave; a.nb = b->a[p].nb;
   a.G = b->a[p].G; a.gb = b->a[p].gb; a.ws = b->a[p].ws; a.wsb = b->a[p].wsb; a.tickets = b->a[p].tickets; a.defer = b->a[p].defer;
-  gemm_tn_block(a, local % a.n_tiles, local / a.n_tiles);
+  // Which (tile, slice) this workgroup takes.  Workgroups go to the XCDs round robin (blockIdx % 8), and every tile of one slice reads the
+  // same rows of U / X (1 024 rows x (O + K) floats: ~1 MB for 128 x 128) -- in plain order the 16 tiles of a slice sit on 8 different L2s
+  // and the operands (2 x 42 MB at 128 frames: far beyond a 4 MB L2) are fetched from the memory side four times over.  With the pairs
+  // enumerated so that one XCD gets a CONTIGUOUS range of (slice, tile) pairs, all tiles of a slice share one L2.
+  int pair = local;
+  const int total = a.n_tiles * a.S;
+  if (a.S > 1 && total % 8 == 0 && b->xcd_walk) pair = (local & 7) * (total >> 3) + (local >> 3);
+  gemm_tn_block(a, pair % a.n_tiles, pair / a.n_tiles);
 }
 // the sliced problems of a batch (S > 1, deferred): one workgroup per output tile adds the partial tiles up; prefix[] counts tiles here
 __global__ __launch_bounds__(64 * TN_WAVES) void k_gemm_tn_batched_reduce(GemmTnBatch b_) {
@@ -200,6 +208,7 @@ struct FmDeviceBackend {
     if (batch.n == 0) return SPK_OK;
     for (int k = 0; k < 16; ++k)       // the batch reads operands that side streams may still be producing
       if (pending & (1u << k)) wait(k);
+    batch.xcd_walk = spk_xcd_walk_default();
     {
       SpkProfScope prof("gemm_tn_batched", stream);
       hipLaunchKernelGGL(k_gemm_tn_batched, dim3(batch.prefix[batch.n]), dim3(64 * TN_WAVES), 0, stream, batch);
