@@ -300,9 +300,6 @@ FM_KERNEL void k_fm_colsrc(const int32_t* FM_R perm, const int64_t* FM_R ii, int
 
 // ------------------------------------------------------------------------------------------------ generic element-wise
 template <class T>
-FM_KERNEL void k_fm_zero(T* p, int64_t n) { FM_FOR(t, n) p[t] = 0; }
-
-template <class T>
 FM_KERNEL void k_fm_axpy(const T* x, int64_t n, T* y) { FM_FOR(t, n) y[t] += x[t]; }
 
 // out_t = act'(pre) pre_t  (tangent through an activation)
