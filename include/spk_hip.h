@@ -757,6 +757,10 @@ typedef struct {
 } spk_adamw_chunk_t;
 int spk_adamw_f32(const spk_adamw_chunk_t* chunks, int64_t n_chunks, const float* grads, float* exp_avg, float* exp_avg_sq, float* step,
                   uint32_t* ticket, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* The same launch with the learning rate read from device memory (lr_dev [1]): a step captured in a HIP graph follows a schedule
+ * (the reference attaches torch lr schedulers to its optimizer, task.py:253-275) by a host-to-device copy between replays. */
+int spk_adamw_devlr_f32(const spk_adamw_chunk_t* chunks, int64_t n_chunks, const float* grads, float* exp_avg, float* exp_avg_sq, float* step,
+                        uint32_t* ticket, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* ------------------------------------------------------------------ force-matching gradients by forward-over-reverse
  * Replaces what the reference obtains from autograd with create_graph = True: Forces (atomistic/response.py:59-68) builds the

@@ -167,6 +167,7 @@ _PROTOS = {
     "spk_dense_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
     "spk_dense_bwd_input_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f]),
     "spk_adamw_f32": (ctypes.c_int, [c_f, c_i64, c_f, c_f, c_f, c_f, c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f]),
+    "spk_adamw_devlr_f32": (ctypes.c_int, [c_f, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f]),
     "spk_filter_table_set_stamp": (ctypes.c_int, [c_f, ctypes.c_uint64]),
     "spk_filter_table_drop_if_stale": (ctypes.c_int, [c_f, ctypes.c_uint64]),
     "spk_dense_dual_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),

@@ -191,7 +191,7 @@ struct FmEngine {
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
     if ((rc = prepare(b, rb, w.c, err))) return rc;
-    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.X2[0], w.c.onehot);
+    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.X2[0], w.c.onehot, err);
     // ---- pass A.  The filter networks depend on the geometry only: they are issued first, on two side streams (interactions alternate),
     // and the atom chain on the main stream waits for interaction l's filters in front of its convolution.
     const bool par = be.can_fork(L);
@@ -340,7 +340,7 @@ struct FmEngine {
     if (par) be.fork(0);
     if ((rc = be.dense_dual(w.c.phi2, m.filt_w, m.filt_b, w.Phi2, nullptr, E, K, ld, FM_ACT_NONE, w.c.fc, w.c.fc1))) return rc;
     if (par) be.back(0);
-    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.Q2[0], w.c.onehot);
+    be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.Q2[0], w.c.onehot, err);
     for (int l = 0; l < L; ++l) {                                            // ---- pass A
       const FmPainnLayer<T>& P = m.layers[l];
       const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);

@@ -19,6 +19,7 @@
 #define FM_UNROLL
 #define FM_R
 #define FM_ATOMIC_MAX(p, v) do { if (*(p) < (v)) *(p) = (v); } while (0)
+#define FM_ATOMIC_OR(p, v) do { *(p) |= (v); } while (0)
 #define FM_FOR(t, total) for (int64_t t = 0; t < (int64_t)(total); ++t)
 #define FM_FOR_ROWS(row, rows) for (int64_t row = 0; row < (int64_t)(rows); ++row)
 #define FM_FOR_LANES(f, F) for (int f = 0; f < (int)(F); ++f)
@@ -37,6 +38,7 @@
 #define FM_UNROLL _Pragma("unroll")
 #define FM_R __restrict__
 #define FM_ATOMIC_MAX(p, v) atomicMax((p), (v))
+#define FM_ATOMIC_OR(p, v) atomicOr((p), (v))
 #define FM_FOR(t, total) for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < (int64_t)(total); t += (int64_t)gridDim.x * blockDim.x)
 #define FM_FOR_ROWS(row, rows) for (int64_t row = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6); row < (int64_t)(rows); row += (int64_t)gridDim.x * (blockDim.x >> 6))
 #define FM_FOR_LANES(f, F) for (int f = threadIdx.x & 63; f < (int)(F); f += 64)
@@ -391,12 +393,15 @@ FM_KERNEL void k_fm_segsum1(const T* e_atom, const int32_t* rowptr_m, int64_t M,
 // ------------------------------------------------------------------------------------------------ embedding
 // x = table[Z], and the one-hot rows of Z beside it ([N, n_types]): the gradient of the table, gtable[z, :] = sum_{i: Z_i = z} gx[i, :], is then
 // onehot^T gx -- one more problem of the batched weight-gradient launch instead of a kernel in which every (z, f) thread walks all atoms
-// (14.6 us for 168 atoms).  A number outside [0, n_types) reads nothing and its one-hot row is zero.
+// (14.6 us for 168 atoms).  A number outside [0, n_types) is an error, never an out-of-bounds read: its row is NaN (like the eval kernels:
+// the energies of its molecule come out NaN), its one-hot row is zero and bit 1 of the validity flag is raised.
 template <class T>
-FM_KERNEL void k_fm_embed(const T* table, const int64_t* Z, int64_t N, int F, int n_types, T* x, T* onehot) {
+FM_KERNEL void k_fm_embed(const T* table, const int64_t* Z, int64_t N, int F, int n_types, T* x, T* onehot, int32_t* err) {
   FM_FOR(t, N * F) {
     const int64_t z = Z[t / F];
-    x[t] = (uint64_t)z < (uint64_t)n_types ? table[z * F + t % F] : T(0);
+    const bool ok = (uint64_t)z < (uint64_t)n_types;
+    x[t] = ok ? table[z * F + t % F] : (T)NAN;
+    if (!ok && err && t % F == 0) FM_ATOMIC_OR(err, 2);
   }
   if (onehot) {
     FM_FOR(t, N * n_types) onehot[t] = Z[t / n_types] == (int64_t)(t % n_types) ? T(1) : T(0);

@@ -20,6 +20,7 @@
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 #include <torch/autograd.h>
 #include <torch/library.h>
 

@@ -150,6 +150,7 @@ constexpr const char* kFmFirstOrder =
     "a recorded backward (create_graph=True) or a gradient w.r.t. the positions is not provided -- set `model.fm_engine = False` to run the operator-by-operator "
     "training path, which is differentiable to any order";
 
+// (capture status of the current stream)
 struct PotentialFmFn : public torch::autograd::Function<PotentialFmFn> {
   // argument slots: 0 emb | 1 Z | 2 R | 3 idx_i | 4 idx_j | 5 idx_m | 6 p0 | 7 offsets | 8 p1 | ws... | head... | 8 scalars
   static variable_list forward(AutogradContext* ctx, const Tensor& emb, const Tensor& Z, const Tensor& R, const Tensor& idx_i, const Tensor& idx_j, const Tensor& idx_m,
@@ -185,6 +186,19 @@ struct PotentialFmFn : public torch::autograd::Function<PotentialFmFn> {
     const char* who = painn ? "spk_hip::painn_fm" : "spk_hip::schnet_fm";
     TORCH_CHECK(!at::GradMode::is_enabled(), who, kFmFirstOrder);
     TORCH_CHECK(!ctx->needs_input_grad(2), who, kFmFirstOrder);
+    {
+      // the forward's validity flag (bit 0: idx_i / idx_m not ascending -- the engine's row kernels need the list sorted by centre atom, the
+      // energies are NaN then; bit 1: an atomic number outside the embedding table): surfaced here, at the first point the caller waits for
+      // the device anyway.  Not inside a stream capture (no host read there: static-shape steps poll StaticLists.check() instead).
+      const Tensor err = ctx->saved_data["err"].toTensor();
+      if (err.defined() && err.numel() == 1 && c10::hip::currentStreamCaptureStatusMayInitCtx() == c10::hip::CaptureStatus::None) {
+        const int flag = err.item<int>();
+        TORCH_CHECK((flag & 1) == 0, who, ": idx_i / idx_m are not sorted ascending. The force-matching engine walks the pair list by centre atom "
+                    "(every neighbour list of the reference is sorted this way; CountNeighbors(sorted=False)-style lists are not) -- sort the list, or set "
+                    "`model.fm_engine = False` to train through the operator-by-operator path, which takes any pair order");
+        TORCH_CHECK((flag & 2) == 0, who, ": an atomic number lies outside the embedding table (max_z)");
+      }
+    }
     auto sv = ctx->get_saved_variables();
     const size_t n_ws = (size_t)cfg[6], n_head = (size_t)cfg[7];
     std::vector<Tensor> ws(sv.begin() + 10, sv.begin() + 10 + n_ws), head(sv.begin() + 10 + n_ws, sv.begin() + 10 + n_ws + n_head);

@@ -433,11 +433,12 @@ extern "C" int spk_fm_loss_bwd_f32(const float* g, const float* gE, int64_t M, c
 // Arithmetic of torch.optim.AdamW (decoupled weight decay, bias corrections from the step count, eps outside the corrected root).
 // The step count lives on the device (graph replays): every workgroup reads it, the LAST one to finish writes count + 1.
 __global__ __launch_bounds__(256) void k_adamw(const spk_adamw_chunk_t* __restrict__ chunks, const float* __restrict__ g, float* __restrict__ m,
-                                               float* __restrict__ v, float* step, unsigned* ticket, float lr, float b1, float b2, float eps, float wd) {
+                                               float* __restrict__ v, float* step, unsigned* ticket, float lr, const float* __restrict__ lr_dev, float b1, float b2, float eps, float wd) {
   __shared__ float s_t;
   if (threadIdx.x == 0) s_t = *(volatile float*)step + 1.0f;
   __syncthreads();
   const float t = s_t;
+  if (lr_dev) lr = *lr_dev;     // learning rate of a schedule: read from the device so that a captured step follows it
   const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
   const float step_size = lr / bc1, decay = 1.0f - lr * wd;
   const spk_adamw_chunk_t c = chunks[blockIdx.x];
@@ -458,18 +459,26 @@ __global__ __launch_bounds__(256) void k_adamw(const spk_adamw_chunk_t* __restri
     *step = t;
   }
 }
-extern "C" int spk_adamw_f32(const spk_adamw_chunk_t* chunks, int64_t n_chunks, const float* grads, float* exp_avg, float* exp_avg_sq, float* step,
-                             uint32_t* ticket, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int adamw_launch(const spk_adamw_chunk_t* chunks, int64_t n_chunks, const float* grads, float* exp_avg, float* exp_avg_sq, float* step, uint32_t* ticket, float lr,
+                        const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, hipStream_t stream) {
   SPK_CHECK_ARG(n_chunks >= 0 && n_chunks < (1ll << 31), "spk_adamw_f32: bad chunk count");
   if (n_chunks == 0) return SPK_OK;
   SPK_CHECK_ARG(chunks && grads && exp_avg && exp_avg_sq && step && ticket, "spk_adamw_f32: null pointer");
   SPK_CHECK_ARG(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && weight_decay >= 0.f, "spk_adamw_f32: bad hyper-parameters");
   SpkProfScope prof("adamw", stream);
-  hipLaunchKernelGGL(k_adamw, dim3((unsigned)n_chunks), dim3(256), 0, stream, chunks, grads, exp_avg, exp_avg_sq, step, (unsigned*)ticket, lr, beta1, beta2, eps,
+  hipLaunchKernelGGL(k_adamw, dim3((unsigned)n_chunks), dim3(256), 0, stream, chunks, grads, exp_avg, exp_avg_sq, step, (unsigned*)ticket, lr, lr_dev, beta1, beta2, eps,
                      weight_decay);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
+}
+extern "C" int spk_adamw_f32(const spk_adamw_chunk_t* chunks, int64_t n_chunks, const float* grads, float* exp_avg, float* exp_avg_sq, float* step,
+                             uint32_t* ticket, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream_) {
+  return adamw_launch(chunks, n_chunks, grads, exp_avg, exp_avg_sq, step, ticket, lr, nullptr, beta1, beta2, eps, weight_decay, (hipStream_t)stream_);
+}
+extern "C" int spk_adamw_devlr_f32(const spk_adamw_chunk_t* chunks, int64_t n_chunks, const float* grads, float* exp_avg, float* exp_avg_sq, float* step,
+                                   uint32_t* ticket, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, void* stream_) {
+  SPK_CHECK_ARG(lr_dev != nullptr, "spk_adamw_devlr_f32: null learning-rate pointer");
+  return adamw_launch(chunks, n_chunks, grads, exp_avg, exp_avg_sq, step, ticket, 0.f, lr_dev, beta1, beta2, eps, weight_decay, (hipStream_t)stream_);
 }
 
 // ------------------------------------------------------------------------------------------------ 3-vector algebra (PaiNN, painn.py:55-66, 99-117)

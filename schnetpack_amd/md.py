@@ -7,6 +7,7 @@ of the tensors handed in (the reference's MD internal units are kJ/mol, nm, Dalt
 ``masses`` ([1, n_atoms, 1] or [n_atoms]) attributes -- what ``schnetpack.md.System`` has.
 """
 import math
+import os
 import struct
 from typing import Optional
 
@@ -514,6 +515,9 @@ class RPMDSimulation(NVESimulation):
         self.n_collectives = 0
         self._rp = RingPolymer(time_step, self.n_beads, temperature, omega=omega, group=group)
         self._lo, hi, self._world = self._rp._bead_range()
+        # the distributed code path: several ranks -- or ONE rank with a group when SPK_MD_FORCE_COLLECTIVES=1 (the RCCL smoke test of a one-GPU
+        # box: every all-gather then executes, as an identity, on the real back-end)
+        self._dist = self._world > 1 or (group is not None and os.environ.get("SPK_MD_FORCE_COLLECTIVES") == "1")
         self.n_local = B = hi - self._lo                      # beads in THIS rank's batch
         N = int(inputs[P.R].shape[0])
         n_mol = int(inputs[P.n_atoms].shape[0])
@@ -532,7 +536,7 @@ class RPMDSimulation(NVESimulation):
     # -- state ---------------------------------------------------------------------------------
     @property
     def _replicated(self) -> bool:
-        return self._world > 1 and self.exchange == "forces"
+        return self._dist and self.exchange == "forces"
 
     def _setup_state(self, R, masses):
         Bl, N, dev = self.n_local, self._n1, R.device
@@ -556,7 +560,7 @@ class RPMDSimulation(NVESimulation):
         self._qt = torch.empty(nb, N, 3, device=dev)
         self._pt = torch.empty(nb, N, 3, device=dev)
         self._A = self._rp.A.to(dev)
-        if self._world > 1 and not self._replicated:
+        if self._dist and not self._replicated:
             self._pack = torch.empty(2, Bl, N, 3, device=dev)                    # (q, p) of the rank, one message
             self._gath = torch.empty(self._world, 2, Bl, N, 3, device=dev)
             self._pgath = torch.empty(self._world, Bl, N, 3, device=dev)
@@ -591,7 +595,7 @@ class RPMDSimulation(NVESimulation):
         if self._replicated:                       # all beads, every rank, same counter-based noise: no exchange
             st = self.full
             _pile_hip(st.momenta, st.masses, self._M, th.noise_scale, th.seed, 0, self._stepc, which, 0, self.n_beads, self._pt)
-        elif self._world > 1:                      # the rank's beads from everybody's momenta: ONE all-gather
+        elif self._dist:                      # the rank's beads from everybody's momenta: ONE all-gather
             st = self.state
             self._all_gather(self._pgath, st.momenta)
             _pile_hip(self._pgath.view(self.n_beads, self._n1, 3), st.masses, self._M, th.noise_scale, th.seed, 0, self._stepc, which,
@@ -626,7 +630,7 @@ class RPMDSimulation(NVESimulation):
             return
         st = self.state
         self.integrator.half_step(st)
-        if self._world > 1:
+        if self._dist:
             with torch.no_grad():
                 self._pack[0].copy_(st.positions)
                 self._pack[1].copy_(st.momenta)
@@ -655,7 +659,7 @@ class RPMDSimulation(NVESimulation):
     def _step_body(self):
         """single process: the whole step (one graph).  Bead-parallel: only the force evaluation (the graph segment between
         the collectives); ``_one_step`` adds the rest."""
-        if self._world > 1:
+        if self._dist:
             self._force_eval()
             return
         if self.thermostat is not None:
@@ -665,7 +669,7 @@ class RPMDSimulation(NVESimulation):
         self._finish()
 
     def _one_step(self):
-        if self._world == 1:
+        if not self._dist:
             return super()._one_step()
         if self.thermostat is not None:
             self._thermostat(0)
@@ -675,7 +679,7 @@ class RPMDSimulation(NVESimulation):
 
     @property
     def collectives_per_step(self) -> int:
-        if self._world == 1:
+        if not self._dist:
             return 0
         if self._replicated:
             return 1

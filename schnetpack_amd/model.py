@@ -107,7 +107,10 @@ def potential_fm_forward(model, inputs: Dict[str, torch.Tensor]) -> Dict[str, to
     """TRAINING mode of the standard potential: ``torch.ops.spk_hip.schnet_fm`` / ``painn_fm`` -- energies and forces from one
     operator whose backward is the forward-over-reverse engine (csrc/spk_fm.hip): the gradient of any loss(E, F) w.r.t. every
     weight in ~100 launches, where ``Forces(create_graph=True)`` (atomistic/response.py:59-68) records a second-order graph of
-    several hundred nodes.  The positions enter detached: the operator differentiates w.r.t. the weights only."""
+    several hundred nodes.  The positions enter detached: the operator differentiates w.r.t. the weights only, the forces it
+    returns ARE -dE/dR.  Consequence (documented, not detected: ``forward`` itself marks the positions as requiring grad, like the
+    reference's, so a request cannot be told from the default): in train mode the outputs carry no graph to the positions --
+    ``autograd.grad(E, R)`` reports an unused input; use ``model.fm_engine = False`` for position derivatives of any order."""
     rep, head, frc = model.representation, model.output_modules[0], model.output_modules[1]
     idx_m = inputs[properties.idx_m]
     kind, p0, p1 = rep.radial_basis.kernel_params()
@@ -221,8 +224,11 @@ class NeuralNetworkPotential(nn.Module):
             return {k: inputs[k] for k in self.model_outputs}
         if self.training and self.fm_engine and not torch.jit.is_scripting():
             pos = inputs[properties.R]
-            if pos.is_cuda and pos.dtype == torch.float32:      # the engine is fp32 on the device; anything else (float64 checks of the
-                inputs = self._potential_fm_forward(inputs)     # operator-by-operator path on the host) takes the primitives below
+            w0 = self.representation.embedding.weight
+            # the engine is fp32 on the device, for positions AND parameters; anything else (float64 checks of the operator-by-operator path on
+            # the host, float64 weights) takes the primitives below
+            if pos.is_cuda and pos.dtype == torch.float32 and w0.is_cuda and w0.dtype == torch.float32:
+                inputs = self._potential_fm_forward(inputs)
                 return {k: inputs[k] for k in self.model_outputs}
         if self._potential and not self.training and not torch.jit.is_scripting():
             inputs = self._potential_forward(inputs)

@@ -33,8 +33,20 @@ def _detach(addresses):
 
 
 def _remember(rep, table, addresses):
-    _KEEP[rep] = (table, list(addresses))
-    weakref.finalize(rep, _detach, list(addresses))
+    """One live finalizer per representation: the handle is kept with the entry and detached (cancelled) when the entry is replaced or
+    cleared -- a finalizer of an EARLIER registration would otherwise fire at collection time with addresses the allocator may since have
+    handed to another model's weights, and silently drop that model's tables."""
+    old = _KEEP.pop(rep, None)
+    if old is not None and len(old) > 2:
+        old[2].detach()
+    fin = weakref.finalize(rep, _detach, list(addresses))
+    _KEEP[rep] = (table, list(addresses), fin)
+
+
+def _refuse_trainable(rep):
+    if getattr(rep.radial_basis, "trainable", False):
+        raise _lib.SpkHipError("tabulate_filters: the radial basis is trainable -- the tables are a snapshot keyed on the versions of the filter-network weights "
+                               "only, offsets / widths that change under them would leave a stale table; tabulate a model with a fixed basis")
 
 
 
@@ -133,6 +145,7 @@ def tabulate_filters(representation, n_knots: Optional[int] = None) -> torch.Ten
     if n_knots is None:          # Bessel filters oscillate faster: 512 knots leave 1.5e-5 of max |dW/dd| in the slope, 1024 knots 1.6e-6
         kind = int(rep.radial_basis.kernel_params()[0])
         n_knots = 512 if kind == _lib.SPK_RBF_GAUSSIAN else 1024
+    _refuse_trainable(rep)
     clear_filter_tables(rep)
     if hasattr(rep, "filter_net"):
         return _tabulate_painn(rep, n_knots)
@@ -163,8 +176,13 @@ def clear_filter_tables(representation: Optional[object] = None):
     """Detach the tables of one representation (or of all): the fp32-MFMA filter network runs again."""
     if representation is None:
         _lib.lib().spk_filter_table_clear()
+        for ent in list(_KEEP.values()):
+            if len(ent) > 2:
+                ent[2].detach()
         _KEEP.clear()
         return
     ent = _KEEP.pop(representation, None)
     if ent is not None:
+        if len(ent) > 2:
+            ent[2].detach()
         _detach(ent[1])

@@ -46,10 +46,18 @@ def pad_edges(idx_i, idx_j, offsets, n_atoms: int, max_edges: int, cutoff: float
 
 
 class FlatAdamW:
-    """``torch.optim.AdamW`` arithmetic (the optimizer of the reference's training configs, task.py:187-199) as ONE launch for all
+    """``torch.optim.AdamW`` arithmetic (the optimizer of the reference's training configs, task.py:253-275) as ONE launch for all
     parameters: the gradients are the flat bucket of a :class:`FlatGradAllReduce` (``reducer.flat``), the moments are flat buffers of the
-    same layout, the parameters stay the model's own tensors (``spk_adamw_f32`` reaches them through a chunk table).  The step count lives
-    on the device, so a captured step replays.  State: ``exp_avg``, ``exp_avg_sq``, ``step_count``."""
+    same layout, the parameters stay the model's own tensors (``spk_adamw_devlr_f32`` reaches them through a chunk table).  The step count
+    AND the learning rate live on the device, so a captured step replays and follows a schedule (``opt.lr = ...`` between replays is one
+    4-byte copy).  State: ``exp_avg``, ``exp_avg_sq``, ``step_count``, ``lr`` (:meth:`state_dict` / :meth:`load_state_dict`).
+
+    Differences from ``torch.optim.AdamW``, all deliberate: one parameter group; no ``amsgrad`` / ``maximize``; a parameter the backward
+    never reached is treated as a zero gradient (torch skips it, so its weight decay is skipped there too); the parameters are written
+    through raw pointers, so their autograd version counters do not move -- every eager :meth:`step` therefore tells the operator
+    library that its cached weight images are stale (``spk_hip::weights_changed``; a captured step cannot, the owner of the graph
+    does it after the replay, see :meth:`GraphedTrainStep.step`); the float32 step count saturates at 2**24, where both bias corrections
+    have long been 1."""
 
     CHUNK = 2048
 
@@ -57,7 +65,7 @@ class FlatAdamW:
         from . import _lib
         self._lib = _lib
         self.reducer = reducer
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.betas, self.eps, self.weight_decay = (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         params = reducer.params
         if not params:
             raise ValueError("no trainable parameters")
@@ -78,6 +86,52 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros(off, device=dev)
         self.step_count = torch.zeros(1, device=dev)
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._lr = float(lr)
+        self._lr_dev = torch.full((1,), float(lr), device=dev)
+        # the face a learning-rate schedule needs (torch schedulers read and write param_groups[0]["lr"]; call sync_lr() after scheduler.step())
+        self.param_groups = [{"params": self._params, "lr": float(lr), "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}]
+
+    # ------------------------------------------------------------ learning rate (host mirror + device scalar)
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float):
+        value = float(value)
+        if value < 0.0:
+            raise ValueError("FlatAdamW: negative learning rate")
+        if value != self._lr:
+            self._lr = value
+            self._lr_dev.fill_(value)          # outside any capture: the next replay reads the new value
+        self.param_groups[0]["lr"] = value
+
+    def sync_lr(self):
+        """Adopt ``param_groups[0]["lr"]`` (what a torch-style scheduler wrote)."""
+        self.lr = self.param_groups[0]["lr"]
+
+    # ------------------------------------------------------------ checkpointing (task checkpoints carry the optimizer state)
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(), "step_count": self.step_count.detach().clone(),
+                "lr": self._lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "numel": self.numel}
+
+    def load_state_dict(self, state):
+        if int(state["numel"]) != self.numel:
+            raise ValueError("FlatAdamW: state of %d elements, optimizer of %d" % (int(state["numel"]), self.numel))
+        with torch.no_grad():
+            self.exp_avg.copy_(state["exp_avg"])
+            self.exp_avg_sq.copy_(state["exp_avg_sq"])
+            self.step_count.copy_(state["step_count"])
+        # betas / eps / weight_decay are launch arguments baked into a captured graph: a different value needs a re-capture, so it is refused here
+        for k, have in (("betas", self.betas), ("eps", self.eps), ("weight_decay", self.weight_decay)):
+            want = tuple(float(v) for v in state[k]) if k == "betas" else float(state[k])
+            if want != have:
+                raise ValueError("FlatAdamW.load_state_dict: %s = %r differs from this optimizer's %r" % (k, want, have))
+        self.lr = state["lr"]
+
+    def zero_grad(self, set_to_none: bool = True):
+        """The gradients are the views of the reducer's bucket: released (the next backward re-creates them)."""
+        self.reducer.release()
 
     def step(self):
         flat = self.reducer.flat
@@ -86,9 +140,13 @@ class FlatAdamW:
         if any(p.data_ptr() != q for p, q in zip(self._params, self._ptrs)):
             raise RuntimeError("FlatAdamW: a parameter was re-allocated after the optimizer was built")
         L, c = self._lib, ctypes.c_void_p
-        L.check(L.lib().spk_adamw_f32(c(self.chunks.data_ptr()), int(self.chunks.shape[0]), L.fptr(flat), L.fptr(self.exp_avg), L.fptr(self.exp_avg_sq),
-                                      L.fptr(self.step_count), c(self._ticket.data_ptr()), self.lr, self.betas[0], self.betas[1], self.eps,
-                                      self.weight_decay, L.stream()))
+        L.check(L.lib().spk_adamw_devlr_f32(c(self.chunks.data_ptr()), int(self.chunks.shape[0]), L.fptr(flat), L.fptr(self.exp_avg), L.fptr(self.exp_avg_sq),
+                                            L.fptr(self.step_count), c(self._ticket.data_ptr()), L.fptr(self._lr_dev), self.betas[0], self.betas[1], self.eps,
+                                            self.weight_decay, L.stream()))
+        # the parameters changed behind torch's back (no version bump): every cached transposed / packed weight image of the operator library and
+        # every filter table is stale now.  (Inside a capture the call would only run once, at capture time: the graph's owner repeats it per replay.)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.ops.spk_hip.weights_changed()
 
 
 class GraphedTrainStep:

@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, env_extra=None, timeout=900):
+def _run(args, env_extra=None, timeout=900, with_detail=False):
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="spk_bench_"), "detail.json")
+    args = list(args) + ["--detail", detail]
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -21,7 +24,11 @@ def _run(args, env_extra=None, timeout=900):
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, res.stdout[-2000:]
-    return json.loads(lines[0])
+    assert res.stdout.strip().splitlines()[-1] == lines[0]          # the LAST stdout line is the JSON line ...
+    assert len(lines[0]) < 8192                                     # ... and fits the driver's 8 KB tail
+    line = json.loads(lines[0])
+    assert line["detail"] == detail
+    return (line, json.load(open(detail))) if with_detail else line
 
 
 def test_gpus_2_runs_two_ranks():
@@ -35,7 +42,7 @@ def test_gpus_2_runs_two_ranks():
 
 
 def test_default_line_has_both_halves_of_the_metric():
-    line = _run(["--steps", "10", "--warmup", "3", "--md-steps", "40", "--water-side", "10", "--no-pmc", "--cpu-reps", "2"])
+    line, detail = _run(["--steps", "10", "--warmup", "3", "--md-steps", "40", "--water-side", "10", "--no-pmc", "--cpu-reps", "2"], with_detail=True)
     assert line["n_gpus"] == 1 and line["dtype"] == "f32" and line["value"] > 0
     rf = line["roofline"]
     assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] <= 1.0 and rf["peak"] > 0
@@ -43,7 +50,17 @@ def test_default_line_has_both_halves_of_the_metric():
     assert cpu["kind"] in ("reference", "port") and cpu["value"] > 0 and cpu["parity_rel_forces"] < 1e-5
     md = line["md"]
     assert md["aspirin"]["ns_per_day"] > 0 and md["water"]["ns_per_day"] > 0 and md["aspirin"]["trajectories"] == 256
-    assert any("frac_of_peak" in v for v in line["kernels"].values())      # every modelled kernel carries its own roofline fraction
-    rows = line["sweep"]["rows"]
-    assert [r["k"] for r in rows if r["list"] == "symmetric"] == [16, 32, 64]
+    assert any("frac_of_peak" in v for v in detail["kernels"].values())      # every modelled kernel carries its own roofline fraction (detail file)
+    rows = detail["sweep"]["rows"]
+    for model in ("schnet", "painn"):
+        assert [r["k"] for r in rows if r["list"] == "symmetric" and r["model"] == model] == [16, 32, 64]
+        assert [r["k"] for r in rows if r["list"] == "asymmetric" and r["model"] == model] == [32]
     assert all(r["M_edge_messages_per_s"] > 0 and r["E"] == r["N"] * r["k"] for r in rows)
+    assert len(line["sweep"]["rows"]) == len(rows) and "columns" in line["sweep"]
+    # the scatter_add roofline distinguishes the Infinity-Cache-resident replay from the DRAM-streaming cases
+    sc = line["scatter_add"]
+    assert sc["cache_resident"]["frac"] > 0 and sc["dram_rotating"]["working_set_MB"] > 512 and sc["frac_dram"] == min(
+        v["frac"] for k, v in sc.items() if k.startswith("dram_"))
+    assert sc["dram_rotating"]["frac_of_measured_copy"] <= 1.05
+    # the edge of the molecule regime is a row of the line
+    assert {r[1] for r in line["molecule_cliff"]["rows"]} == {21, 29, 42, 60}

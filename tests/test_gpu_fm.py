@@ -166,6 +166,25 @@ def test_refusals_and_flags(dev):
     bad["offsets"] = torch.flip(b["offsets"], [0])
     out = model(M.batch_to_inputs(bad, dev))
     assert bool(torch.isnan(out["energy"]).all())
+    # ... and the backward SAYS so instead of handing a NaN loss to the optimizer: the message names the way out
+    with pytest.raises(RuntimeError, match="not sorted ascending.*fm_engine = False"):
+        (out["energy"] ** 2).sum().backward()
+    # an atomic number outside the embedding table: NaN energies of its molecule (like the eval kernels), flagged in the backward
+    badz = dict(b)
+    badz["Z"] = b["Z"].clone()
+    badz["Z"][3] = 100000
+    model.zero_grad()
+    out = model(M.batch_to_inputs(badz, dev))
+    assert bool(torch.isnan(out["energy"][0])) and not bool(torch.isnan(out["energy"][1]))
+    with pytest.raises(RuntimeError, match="outside the embedding table"):
+        (out["forces"] ** 2).sum().backward()
+    # the operator-by-operator path takes the unsorted list (the documented way out)
+    model.fm_engine = False
+    model.zero_grad()
+    o1 = model(M.batch_to_inputs(bad, dev))
+    o2 = model(M.batch_to_inputs(b, dev))
+    assert rel_err(o1["energy"].detach().cpu(), o2["energy"].detach().cpu()) < 1e-5
+    assert rel_err(o1["forces"].detach().cpu(), o2["forces"].detach().cpu()) < 1e-5
 
 
 def test_transpose_plan_is_a_stable_sort_by_neighbour(dev):

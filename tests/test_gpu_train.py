@@ -250,3 +250,93 @@ def test_packed_load_fills_the_static_buffers_like_load(dev):
     assert torch.equal(a.E_t, c.E_t) and torch.equal(a.F_t, c.F_t)
     with pytest.raises(ValueError):
         c.pack(dict(b, Z=b["Z"][:-1]), Et, Ft)
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_eval_after_eager_flat_adamw_steps_sees_the_new_weights(dev, kind):
+    """FlatAdamW writes the parameters through raw pointers -- their version counters never move -- and the eval-mode
+    caches of the operator library (transposed / packed weight images keyed on generation + data_ptr + _version) would keep hitting after EAGER
+    steps.  Eval forward, N eager steps (use_graph=False: every step is eager), eval forward again: must equal a fresh model that was loaded
+    with the updated weights (and must differ from the first eval)."""
+    from schnetpack_amd import model as M
+    from schnetpack_amd.train import GraphedTrainStep, FlatAdamW
+    frames = 4
+    data = _batches(3, frames)
+    b0 = data[0][0]
+    N = b0["Z"].shape[0]
+    emax = max(int(b["idx_i"].shape[0]) for b, _, _ in data) + 10
+    model = _model(kind, dev)
+    model.eval()
+    out0 = model(M.batch_to_inputs(b0, dev))
+    f0, e0 = out0["forces"].detach().clone(), out0["energy"].detach().clone()
+    ts = GraphedTrainStep(model, N, frames, emax, 5.0, lr=3e-3, use_graph=False)
+    assert isinstance(ts.opt, FlatAdamW)
+    for b, Et, Ft in data:
+        ts.load(b, Et, Ft)
+        ts.step()
+    ts.check()
+    model.eval()
+    out1 = model(M.batch_to_inputs(b0, dev))
+    fresh = M.build_model(kind).to(dev)
+    fresh.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()})
+    fresh.eval()
+    out2 = fresh(M.batch_to_inputs(b0, dev))
+    assert rel_err(out1["forces"].detach().cpu(), out2["forces"].detach().cpu()) < 1e-6
+    assert rel_err(out1["energy"].detach().cpu(), out2["energy"].detach().cpu()) < 1e-6
+    assert rel_err(out1["forces"].detach().cpu(), f0.cpu()) > 1e-4 and rel_err(out1["energy"].detach().cpu(), e0.cpu()) > 1e-6      # the weights did move
+
+
+def test_flat_adamw_state_dict_and_device_learning_rate(dev):
+    """Checkpoint / resume and a learning-rate schedule under a captured step: exp_avg / exp_avg_sq / step_count
+    round-trip; the learning rate lives on the device, so ONE captured launch follows `opt.lr = ...` between replays like torch.optim.AdamW
+    with a scheduler (task.py:253-275)."""
+    from schnetpack_amd.parallel import FlatGradAllReduce
+    from schnetpack_amd.train import FlatAdamW
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 20), (64,), (4100,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(*sh, generator=torch.Generator().manual_seed(5)).to(dev)) for sh in shapes]
+    mine, ref = mk(), mk()
+    red = FlatGradAllReduce(mine, as_views=True)
+    opt = FlatAdamW(red, lr=1e-2)
+    topt = torch.optim.AdamW(ref, lr=1e-2)
+    sched = torch.optim.lr_scheduler.StepLR(topt, step_size=3, gamma=0.5)
+    grads = [[torch.randn(*sh, generator=g).to(dev) for sh in shapes] for _ in range(12)]
+
+    def load(k, params, bind_views):
+        for p, gr in zip(params, grads[k]):
+            if bind_views:
+                p.grad.copy_(gr)
+            else:
+                p.grad = gr.clone()
+
+    load(0, mine, True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.step()
+    for k in range(6):
+        load(k, mine, True); load(k, ref, False)
+        graph.replay()
+        topt.step(); sched.step()
+        opt.lr = sched.get_last_lr()[0]                # (a torch scheduler writing param_groups[0]["lr"] + opt.sync_lr() does the same)
+    torch.cuda.synchronize()
+    for p, q in zip(mine, ref):
+        assert rel_err(p.detach().cpu(), q.detach().cpu()) < 2e-6
+    assert abs(opt.lr - 1e-2 * 0.25) < 1e-12
+
+    # resume: a second optimizer over copies of the parameters, loaded from the state, continues the same trajectory
+    state = opt.state_dict()
+    mine2 = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    red2 = FlatGradAllReduce(mine2, as_views=True)
+    opt2 = FlatAdamW(red2, lr=123.0)
+    opt2.load_state_dict(state)
+    assert float(opt2.step_count) == 6.0 and opt2.lr == opt.lr
+    for k in range(6, 12):
+        load(k, mine, True); load(k, mine2, True)
+        opt.step(); opt2.step()
+    for p, q in zip(mine, mine2):
+        assert torch.equal(p.detach(), q.detach())
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(dict(state, weight_decay=0.5))
+    opt.param_groups[0]["lr"] = 7e-4
+    opt.sync_lr()
+    assert opt.lr == 7e-4 and abs(float(opt._lr_dev) - 7e-4) < 1e-10
