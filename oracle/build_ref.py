@@ -30,6 +30,11 @@ DATA = [
     ("interfaces/lammps/examples/aspirin/aspirin.data", "data/aspirin.data"),
     ("tests/testdata/md_ethanol.model", "data/md_ethanol.model"),
     ("tests/testdata/md_ethanol.xyz", "data/md_ethanol.xyz"),
+] + [
+    # the five PaiNN models trained on rMD17 ethanol that ship with the reference: real, TRAINED weights (a wider dynamic
+    # range than any seeded initialisation) -- data artefacts of the reference, copied like the models above; the outputs of the reference on
+    # them are committed as tests/golden/painn_rmd17_ethanol_trained.npz (oracle/make_golden.py)
+    ("examples/trained_models/rmd17_ethanol/painn_%d/best_model" % k, "data/rmd17_ethanol_painn_%d.model" % k) for k in range(1, 6)
 ]
 STAMP = os.path.join(OUT, "BUILD_INFO")
 

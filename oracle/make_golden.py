@@ -149,6 +149,30 @@ def main():
          radial="gaussian", n_interactions=int(rep.n_interactions), **w)
 
 
+def trained_model_goldens(ns):
+    """The reference's five trained rMD17-ethanol PaiNN models (examples/trained_models/rmd17_ethanol/painn_{1..5}/best_model: PaiNN(128, 3,
+    20 Gaussians, 5 A) + Atomwise + Forces -- configs[3]'s architecture with TRAINED weights): representation + energy head (no
+    postprocessors, like every other fixture) on six jittered ethanol frames.  The weights are not stored (12 MB): the tests load them from
+    the same model files (oracle/build_ref.py copies them into oracle/_ref/data) and check them against the checksum stored here."""
+    from oracle import build_ref
+    sys.modules["ase.data"].atomic_masses = np.ones(119)
+    b = S.molecule_batch("ethanol", 6, seed=17, jitter=0.06)
+    arrs = {"in_" + k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in b.items() if k != "cell"}
+    for k in range(1, 6):
+        m = torch.load(build_ref.data_path("rmd17_ethanol_painn_%d.model" % k), map_location="cpu", weights_only=False)
+        m.eval()
+        rep, head_sd = m.representation, m.output_modules[0].state_dict()
+        res = run_reference(ns, rep, head_sd, b)
+        for q, v in res.items():
+            arrs["ref%d_%s" % (k, q)] = v
+        arrs["weights_checksum_%d" % k] = checksum({**rep.state_dict(), **{"head." + kk: v for kk, v in head_sd.items()}})
+        w = torch.cat([v.flatten().double() for v in rep.state_dict().values() if v.is_floating_point()])
+        arrs["weights_absmax_%d" % k] = float(w.abs().max())
+    arrs.update(kind="painn", cutoff=5.0, radial="gaussian", n_interactions=3, n_models=5)
+    np.savez_compressed(os.path.join(OUT, "painn_rmd17_ethanol_trained.npz"), **arrs)
+    print("wrote painn_rmd17_ethanol_trained.npz", {k: getattr(v, "shape", v) for k, v in arrs.items() if not k.startswith("ref")})
+
+
 def neighbor_list_goldens(ns):
     """(1) the reference's own precomputed Argon vectors (tests/conftest.py:192-447), lifted out of the
     fixture functions; (2) TorchNeighborList outputs (transform/neighborlist.py:438-553) on seeded
@@ -378,6 +402,8 @@ if __name__ == "__main__":
         neighbor_list_goldens(refshim.load())
     elif len(sys.argv) > 1 and sys.argv[1] == "deploy":
         deploy_goldens(refshim.load())
+    elif len(sys.argv) > 1 and sys.argv[1] == "trained":
+        trained_model_goldens(refshim.load())
     else:
         main()
         neighbor_list_goldens(refshim.load())
@@ -385,3 +411,4 @@ if __name__ == "__main__":
         deploy_goldens(refshim.load())
         deep_model_goldens(refshim.load())
         deep_bessel_goldens(refshim.load())
+        trained_model_goldens(refshim.load())

@@ -138,3 +138,20 @@ def test_md_oracle_reproduces_reference_ring_polymer_step():
         q2, p2 = MD.ring_polymer_main_step(q, p, m, C, P)
         assert torch.allclose(q2, torch.from_numpy(g[t + "q_out"]), atol=1e-13)
         assert torch.allclose(p2, torch.from_numpy(g[t + "p_out"]), atol=1e-12)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5])
+def test_oracle_on_the_references_trained_rmd17_models(k):
+    """The oracle restatement with TRAINED weights (examples/trained_models/rmd17_ethanol/painn_k/best_model) against the
+    outputs the reference itself produced for them (tests/golden/painn_rmd17_ethanol_trained.npz, oracle/make_golden.py)."""
+    from conftest import trained_checksum, trained_rmd17_params
+    z = load_npz("painn_rmd17_ethanol_trained.npz")
+    got = trained_rmd17_params(k)
+    if got is None:
+        pytest.skip("the reference's model files are not available (neither /root/reference nor oracle/_ref/data)")
+    rep_p, head_p = got
+    assert abs(trained_checksum(rep_p, head_p) - z["weights_checksum_%d" % k]) < 1e-6 * z["weights_checksum_%d" % k]
+    batch = {kk[3:]: (int(v) if np.ndim(v) == 0 else torch.from_numpy(v)) for kk, v in z.items() if kk.startswith("in_")}
+    out = O.energy_and_forces("painn", rep_p, head_p, batch, 3)
+    assert rel_err(out["energy"], torch.from_numpy(z["ref%d_energy" % k])) < 2e-6
+    assert rel_err(out["forces"], torch.from_numpy(z["ref%d_forces" % k])) < 2e-6
