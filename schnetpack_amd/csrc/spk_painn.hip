@@ -66,7 +66,11 @@ template <> struct MsgVec<2> {
 // per edge as 5 + 5 broadcast ds_read_b128 -- instead of one evaluation by lane k and 2 n_rbf v_readlane broadcasts per edge.  The
 // SQ counters said this kernel is VALU-issue bound (330 instructions per edge and wavefront in the backward, 66 % busy): the
 // broadcasts and the per-edge evaluation were 70 of them, and LDS reads issue beside the VALU.
-template <int VPL, int NRBF, bool BWD, bool GEOM = false, bool MU0 = false, bool TAB = false, bool LT = false>
+// TS (backward only; round 5): the TRANSPOSED SUMS alone -- gc and the new gmu of the row atom, no geometry gradient: the slope of the filter is
+// not formed and the neighbours' c / mu rows are not gathered.  Run over the by-neighbour copy of an asymmetric list (spk_transposed_t; rows =
+// neighbour atoms j, entries = the pairs that point at j, pair vectors negated) it is the scatter over idx_j of painn.py:54-66's backward as a
+// row pass: no atomics, fixed order.  The geometry gradient of such a list is the GEOM form over the list itself.
+template <int VPL, int NRBF, bool BWD, bool GEOM = false, bool MU0 = false, bool TAB = false, bool LT = false, bool TS = false>
 __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
   typedef MsgVec<VPL> MV;
   typedef typename MV::T VT;
@@ -149,20 +153,20 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
             pv[q] = p_; dv[q] = dp_;
           }
           *(f32x4*)(tabw + lane * (2 * NRBF) + 4 * k4) = pv;
-          if (BWD) *(f32x4*)(tabw + lane * (2 * NRBF) + NRBF + 4 * k4) = dv;
+          if (BWD && !TS) *(f32x4*)(tabw + lane * (2 * NRBF) + NRBF + 4 * k4) = dv;
         }
         spk_wave_lds_sync();
       }
       // neighbour rows are requested one edge ahead (explicit double buffer): the row kernel is
       // bound by the latency of these dependent gathers, not by their bandwidth
       constexpr bool PF = true;
-      VT cjr[PF ? 2 : 1][3], mujr[PF ? 2 : 1][3] = {}, gqbr[PF ? 2 : 1] = {}, gmbr[PF ? 2 : 1][3] = {};
+      VT cjr[PF ? 2 : 1][3] = {}, mujr[PF ? 2 : 1][3] = {}, gqbr[PF ? 2 : 1] = {}, gmbr[PF ? 2 : 1][3] = {};
       auto load_rows = [&](int slot, int t) {
         const int64_t jj = __builtin_amdgcn_readlane(jl, t);
         const float* cj = a.c + jj * 3 * F + fo;
         const float* muj = a.mu + jj * 3 * F + fo;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { cjr[slot][p] = MV::load(cj + p * F); if (!MU0) mujr[slot][p] = MV::load(muj + p * F); }
+        for (int p = 0; p < 3 && !TS; ++p) { cjr[slot][p] = MV::load(cj + p * F); if (!MU0) mujr[slot][p] = MV::load(muj + p * F); }
         if (BWD && !GEOM) {
           gqbr[slot] = MV::load(a.gq_out + jj * F + fo);
 #pragma unroll
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
                   pdv[v] = g10 * kk.y + g01 * kk.z + g11 * kk.w;
                 }
                 P[p] = MV::load(pv);
-                if (BWD) Pd[p] = MV::load(pdv);
+                if (BWD && !TS) Pd[p] = MV::load(pdv);
               }
             } else if (LT) {
               const float* te = tabw + t * (2 * NRBF);          // wave-uniform address: broadcast reads
@@ -220,13 +224,13 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
               for (int k4 = 0; k4 < NRBF / 4; ++k4) {
                 const f32x4 s4 = *(const f32x4*)(te + 4 * k4);
                 f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-                if (BWD) d4 = *(const f32x4*)(te + NRBF + 4 * k4);
+                if (BWD && !TS) d4 = *(const f32x4*)(te + NRBF + 4 * k4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                   for (int p = 0; p < 3; ++p) {
                     P[p] = w[p][4 * k4 + q] * s4[q] + P[p];
-                    if (BWD) Pd[p] = w[p][4 * k4 + q] * d4[q] + Pd[p];
+                    if (BWD && !TS) Pd[p] = w[p][4 * k4 + q] * d4[q] + Pd[p];
                   }
               }
             } else {
@@ -237,11 +241,11 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
 #pragma unroll
             for (int k = 0; k < (TAB ? 1 : NRBF); ++k) {
               const float s = spk_readlane_f(pl, k);
-              const float sd = BWD ? spk_readlane_f(dpl, k) : 0.f;
+              const float sd = (BWD && !TS) ? spk_readlane_f(dpl, k) : 0.f;
 #pragma unroll
               for (int p = 0; p < 3; ++p) {
                 P[p] = w[p][k] * s + P[p];
-                if (BWD) Pd[p] = w[p][k] * sd + Pd[p];
+                if (BWD && !TS) Pd[p] = w[p][k] * sd + Pd[p];
               }
             }
             }
@@ -268,6 +272,7 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
                 accv[0] += Fm * gb0; accv[1] += Fm * gb1; accv[2] += Fm * gb2;
               }
               // (2) geometry gradient of edge (atom <- b)
+              if (!TS) {
               const VT gu = gma[0] * ux + gma[1] * uy + gma[2] * uz;
               const VT gm = gma[0] * mb0 + gma[1] * mb1 + gma[2] * mb2;
               const VT ddv = cq * gqa * dFq + cR * gu * dFR + cm * gm * dFm;
@@ -281,11 +286,12 @@ __global__ __launch_bounds__(256) void k_painn_msg_row(MsgArgs a) {
                 gry = dd * uy + (tuy - dot * uy) * invd;
                 grz = dd * uz + (tuz - dot * uz) * invd;
               }
+              }
             }
           }
         }
       }
-      if (BWD && ev && dl > 0.f) {
+      if (BWD && !TS && ev && dl > 0.f) {
         a.gr[3 * (int64_t)em] += grx; a.gr[3 * (int64_t)em + 1] += gry; a.gr[3 * (int64_t)em + 2] += grz;
       }
     }
@@ -390,6 +396,14 @@ __global__ void k_painn_msg_simple(MsgArgs a) {
         a.gr[3 * e + 2] += D * uz + (Z - dot * uz) * inv;
       }
     }
+  }
+}
+
+// out[k] = -r[perm[k]]: the pair vectors of the by-neighbour copy of a list, seen from the neighbour (R_i - R_j)
+__global__ void k_gather_rows3_neg(const float* __restrict__ r, const int32_t* __restrict__ perm, int64_t E, float* __restrict__ out) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < E; k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = perm[k];
+    out[3 * k] = -r[3 * e]; out[3 * k + 1] = -r[3 * e + 1]; out[3 * k + 2] = -r[3 * e + 2];
   }
 }
 
@@ -529,6 +543,46 @@ int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
   a.rowptr = g->rowptr; a.wf = wf; a.bf = bf; a.gc = gc; a.gmu = gmu; a.gr = gr; a.E = g->n_edges; a.N = g->n_atoms;
   a.F = F; a.rb = spk_radial_dev(rb); a.geom_only = geom_only ? 1 : 0; a.mu_zero = mu_zero ? 1 : 0; a.skin_list = g->filter_pairs ? 1 : 0;
   a.blocks = g->blocks; a.blocks_prepared = blocks_prepared ? 1 : 0;
+  // Sorted but ASYMMETRIC list that carries its by-neighbour copy (spk_transposed_t; LAMMPS-ordered and vesin lists,
+  // interfaces/lammps/pair_schnetpack.cpp:240-267, transform/neighborlist.py:446-456): two row passes instead of the edge-parallel kernel
+  // with its 7 F float atomics per pair -- (1) the transposed sums as the TS row form over the by-neighbour list, (2) the geometry gradient
+  // as the GEOM row form over the list itself.  No atomics, fixed summation order: bit-reproducible.
+  if (g->sorted && !g->symmetric && g->rowptr && g->transposed && g->transposed->r_perm && spk_get_variant() == SPK_VARIANT_AUTO && (F == 128 || F == 64) &&
+      rb->n_rbf <= 32 && g->n_edges > 0 && !getenv("SPK_NO_TRANSPOSED")) {
+    const spk_transposed_t* T = g->transposed;
+    const int K = rb->n_rbf;
+    const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 2);
+    const size_t lds = (size_t)K * (3 * F + 1) * sizeof(float);
+    if (!geom_only) {
+      hipLaunchKernelGGL(k_gather_rows3_neg, dim3(spk_grid_for(a.E, 256, spk_num_cus() * 8)), dim3(256), 0, stream, r_ij, T->perm, a.E, T->r_perm);
+      SPK_LAUNCH_CHECK();
+      MsgArgs t = a;
+      t.idx_i = T->idx_i; t.idx_j = T->idx_j; t.rowptr = T->rowptr; t.rij = T->r_perm; t.gr = nullptr; t.blocks = nullptr; t.geom_only = 0;
+      SpkProfScope prof("painn_msg_bwd_row_tsum", stream);
+#define SPK_TS_CASE(VPLv, NRBFv)                                                                                                               \
+  do {                                                                                                                                         \
+    if (t.mu_zero) hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, true, false, true, false, false, true>), dim3(grid), dim3(256), lds, stream, t);  \
+    else hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, true, false, false, false, false, true>), dim3(grid), dim3(256), lds, stream, t);         \
+  } while (0)
+      if (F == 64) { if (K <= 20) SPK_TS_CASE(1, 20); else SPK_TS_CASE(1, 32); }
+      else { if (K <= 20) SPK_TS_CASE(2, 20); else SPK_TS_CASE(2, 32); }
+#undef SPK_TS_CASE
+      SPK_LAUNCH_CHECK();
+    }
+    MsgArgs gm = a;
+    gm.geom_only = 1; gm.blocks = nullptr;
+    SpkProfScope prof("painn_msg_bwd_row_geom", stream);
+#define SPK_GM_CASE(VPLv, NRBFv)                                                                                                               \
+  do {                                                                                                                                         \
+    if (gm.mu_zero) hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, true, true, true>), dim3(grid), dim3(256), lds, stream, gm);               \
+    else hipLaunchKernelGGL((k_painn_msg_row<VPLv, NRBFv, true, true, false>), dim3(grid), dim3(256), lds, stream, gm);                         \
+  } while (0)
+    if (F == 64) { if (K <= 20) SPK_GM_CASE(1, 20); else SPK_GM_CASE(1, 32); }
+    else { if (K <= 20) SPK_GM_CASE(2, 20); else SPK_GM_CASE(2, 32); }
+#undef SPK_GM_CASE
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
   return msg_dispatch<true>(a, g->sorted && g->symmetric && g->rowptr, stream, who);
 }
 

@@ -90,6 +90,48 @@ def test_force_call_on_the_references_trained_rmd17_models(dev, variant, k):
         assert record_parity("rmd17_ethanol_trained_painn_%d" % k, variant, q, out[q], torch.from_numpy(z["ref%d_%s" % (k, q)]), TOL) < TOL, q
 
 
+@pytest.mark.parametrize("kind", ["painn", "schnet"])
+def test_representation_backward_on_a_sorted_asymmetric_list(dev, kind):
+    """A sorted, ASYMMETRIC pair list (LAMMPS order, vesin: transform/neighborlist.py:446-456) through the module API: representation forward and
+    the gradient w.r.t. r_ij (what a force call asks of the hot path) against the float64 oracle.  The plan carries the by-neighbour copy of the list: the scatter over idx_j
+    runs as row passes (SchNet: round 4; PaiNN: round 5 -- no atomic kernel in the call, bit-reproducible)."""
+    from schnetpack_amd import _lib, model as M
+    rep_p = O.init_schnet_params() if kind == "schnet" else O.init_painn_params()
+    model = M.build_model(kind)
+    M.load_reference_params(model, rep_p, O.init_atomwise_params(128, seed=1))
+    rep = model.representation.to(dev).eval()
+    b = S.random_graph_batch(600, 24, seed=11, sort=True)
+    E = b["idx_i"].shape[0]
+    assert E >= 4096
+    gsel = torch.randn(600, 128, generator=torch.Generator().manual_seed(1))
+    r64 = b["r_ij"].double().requires_grad_(True)
+    p64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in rep_p.items()}
+    if kind == "schnet":
+        x_o = O.schnet_representation(b["Z"], r64, b["idx_i"], b["idx_j"], p64, 3)
+    else:
+        x_o, _ = O.painn_representation(b["Z"], r64, b["idx_i"], b["idx_j"], p64, 3)
+    (g_o,) = torch.autograd.grad((x_o * gsel.double()).sum(), [r64])
+
+    def call():
+        r = b["r_ij"].to(dev).requires_grad_(True)
+        d = {"_atomic_numbers": b["Z"].to(dev), "_idx_i": b["idx_i"].to(dev), "_idx_j": b["idx_j"].to(dev), "_Rij": r}
+        x = rep(d)["scalar_representation"]
+        (g,) = torch.autograd.grad([(x * gsel.to(dev)).sum()], [r])
+        return x.detach(), g
+    call()
+    _lib.profile_enable(True); _lib.profile_report()
+    x1, g1 = call()
+    tags = set(_lib.profile_report()); _lib.profile_enable(False)
+    x2, g2 = call()
+    assert record_parity("asymmetric_sorted_600x24_" + kind, "auto", "scalar_representation", x1.cpu(), x_o.detach(), TOL) < TOL
+    assert record_parity("asymmetric_sorted_600x24_" + kind, "auto", "grad_r_ij", g1.cpu(), g_o, TOL) < TOL
+    if kind == "painn":      # (SchNet's by-neighbour pass keeps one float atomic per run and channel in the forward-type kernel: not bit-stable)
+        assert not any("simple" in t or "atomic" in t for t in tags), tags
+        assert "painn_msg_bwd_row_tsum" in tags and torch.equal(g1, g2) and torch.equal(x1, x2)
+    else:
+        assert rel_err(g2.cpu(), g1.cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("kind", ["schnet", "painn"])
 def test_full_bench_batch_against_the_live_reference(dev, kind):
     """configs[1] / configs[2] AT THE STATED SIZE -- all 256 aspirin frames (N = 5 376, E = 77 944), the weights bench.py uses -- against the

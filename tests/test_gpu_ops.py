@@ -592,6 +592,55 @@ def test_painn_message_forward_backward(dev, variant, graph, F, n_rbf):
         L.spk_painn_set_row_table(-1)
 
 
+@pytest.mark.parametrize("F,n_rbf,mu_zero", [(128, 20, False), (64, 20, False), (128, 32, False), (128, 20, True)])
+def test_painn_message_backward_on_asymmetric_lists_without_atomics(dev, F, n_rbf, mu_zero):
+    """Sorted but ASYMMETRIC list (what the LAMMPS interface and vesin hand over, interfaces/lammps/pair_schnetpack.cpp:240-267,
+    transform/neighborlist.py:446-456) with its by-neighbour copy attached (spk_transposed_build): the backward runs as two row passes --
+    transposed sums over the by-neighbour list (TS), geometry gradient over the list (GEOM) -- equal to the oracle, equal to the
+    edge-parallel atomic kernel it replaces, and BIT-reproducible (the atomic kernel is not)."""
+    import os
+    from schnetpack_amd import _lib, ops
+    g = torch.Generator().manual_seed(77)
+    rb_ = S.random_graph_batch(700, 24, seed=3, sort=True)
+    r, idx_i, idx_j, N = rb_["r_ij"], rb_["idx_i"], rb_["idx_j"], rb_["Z"].shape[0]
+    c = torch.randn(N, 3 * F, generator=g)
+    q = torch.randn(N, F, generator=g)
+    mu = torch.zeros(N, 3, F) if mu_zero else torch.randn(N, 3, F, generator=g)
+    wf = torch.randn(3 * F, n_rbf, generator=g) * 0.3
+    bf = torch.randn(3 * F, generator=g) * 0.1
+    gq = torch.randn(N, F, generator=g)
+    gmu = torch.randn(N, 3, F, generator=g)
+    _, _, gco, gmuo, gro = _msg_oracle(c, q, mu, r, idx_i, idx_j, wf, bf, N, F, gq, gmu)
+    plan = ops.EdgePlan(idx_i.to(dev), idx_j.to(dev), N, r.to(dev))
+    assert plan.sorted and not plan.symmetric
+    off, w = O.gaussian_rbf_params(n_rbf, 5.0)
+    offd, wd = off.to(dev), w.to(dev)
+    rb = ops.radial_struct(_lib.SPK_RBF_GAUSSIAN, n_rbf, offd, wd, 5.0)
+    D = lambda t: t.to(dev).contiguous()
+    cd, mud, rd, wfd, bfd, gqd, gmud = map(D, (c, mu, r, wf, bf, gq, gmu))
+    L = _lib.lib()
+
+    def run():
+        gc = torch.full((N, 3 * F), float("nan"), device=dev)
+        gmu_in = torch.full((N, 3, F), float("nan"), device=dev)
+        gr = torch.zeros(r.shape[0], 3, device=dev)
+        _lib.profile_enable(True); _lib.profile_report()
+        _lib.check(L.spk_painn_message_bwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(mud), _lib.fptr(gqd), _lib.fptr(gmud),
+                                               _lib.fptr(rd), _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(gc), _lib.fptr(gmu_in), _lib.fptr(gr), _lib.stream()))
+        tags = set(_lib.profile_report()); _lib.profile_enable(False)
+        return gc, gmu_in, gr, tags
+
+    a0 = run()                                  # no by-neighbour copy yet: the edge-parallel kernel with float atomics
+    assert "painn_msg_bwd_simple" in a0[3]
+    plan.build_transposed()
+    a1, a2 = run(), run()
+    assert a1[3] == {"painn_msg_bwd_row_tsum", "painn_msg_bwd_row_geom"}, a1[3]
+    for got in (a0, a1):
+        assert rel_err(got[0].cpu(), gco) < TOL and rel_err(got[1].cpu(), gmuo) < TOL and rel_err(got[2].cpu(), gro) < TOL
+    for x, y in zip(a1[:3], a2[:3]):
+        assert torch.equal(x, y)                # fixed summation order
+
+
 def test_painn_mixing_elementwise(dev):
     from schnetpack_amd import _lib
     g = torch.Generator().manual_seed(31)
