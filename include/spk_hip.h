@@ -806,6 +806,13 @@ int spk_painn_fm_forward_f32(const spk_painn_t* m, const spk_head_t* head, const
                              float* E, float* F, int32_t* err, void* stream);
 int spk_painn_fm_backward_f32(const spk_painn_t* m, const spk_head_t* head, const spk_radial_t* rb, const spk_fm_batch_t* batch, void* workspace,
                               const float* gE, const float* gF, float* grads, void* stream);
+/* EXPERIMENT (round 5, default off): row chains of the force-matching engine (csrc/spk_fm_chain.h) -- consecutive atom-local launches of a
+ * pass recorded as stages of ONE launch (one workgroup per four atoms, fp32 products on v_mfma_f32_4x4x1).  Same results, 137 -> 62
+ * launches per PaiNN step -- and slower (0.69 -> 0.93 ms at 8 frames): what a small launch costs is the chain of dependent memory round trips
+ * inside it, not the launch (profiles/r05_row_chains.md).  mode 1: record chains; 0 or -1: launch by launch (default).  SPK_FM_CHAIN gives
+ * the initial value. */
+void spk_fm_set_chain(int32_t mode);
+
 /* By-neighbour CSR of a pair list on the device (the transpose permutation of SURVEY.md section 7 step 4): perm [E] = the pairs
  * ordered by idx_j (stable: ascending pair index inside a column), colptr [N + 2] (column N collects out-of-range neighbours).
  * tmp: spk_transpose_plan_bytes(E, N) bytes.  No host synchronisation. */

@@ -90,6 +90,7 @@ extern "C" int spk_transposed_build(const int64_t* idx_i, const int64_t* idx_j, 
 // independent of each other and of the rest of pass D, and each is tiny (a few hundred rows): as separate launches they cost ~19 us
 // apiece (latency), together they fill the chip once.  Descriptors travel as kernel arguments (< 4 KB), so nothing is staged in memory.
 #include "spk_gemm_tn.h"
+#include "spk_fm_chain.h"
 #define FM_TN_MAX 24
 struct GemmTnBatch {
   int n;
@@ -170,6 +171,10 @@ static FmSideStreams* fm_side_streams(hipStream_t main) {
   return &s;
 }
 
+// row chains (experiment): 1 = record them, 0 / -1 = launch by launch (the default); SPK_FM_CHAIN sets the initial value
+static int g_fm_chain_mode = [] { const char* e = getenv("SPK_FM_CHAIN"); return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1; }();
+extern "C" void spk_fm_set_chain(int32_t mode) { g_fm_chain_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
+
 struct FmDeviceBackend {
   hipStream_t stream;
   hipStream_t main_stream;
@@ -180,31 +185,190 @@ struct FmDeviceBackend {
   GemmTnBatch batch, rbatch;
   int64_t ws_used = 0;
   int tickets_used = 0;
-  explicit FmDeviceBackend(hipStream_t s) : stream(s), main_stream(s), max_blocks(spk_num_cus() * 32) { batch.n = 0; batch.prefix[0] = 0; }
+  explicit FmDeviceBackend(hipStream_t s) : stream(s), main_stream(s), max_blocks(spk_num_cus() * 32) { batch.n = 0; batch.prefix[0] = 0; chain.n_stages = 0; }
+  // ---- row chains (spk_fm_chain.h): between chain_begin() and chain_end() the atom-local launches are RECORDED as stages and leave as one
+  // launch; anything else that launches flushes the recorded stages first, so the issue order of the engine is kept.  SPK_FM_CHAIN=0 / 1
+  // switches the recording off / on for every size (default: batches of at most FM_CHAIN_MAX_ATOMS atoms).
+  FmChainDesc chain;
+  bool recording = false;
+  int chain_max_k = 0, chain_max_nw = 0, chain_max_r = 0;
+  static int chain_mode() { return g_fm_chain_mode; }
+  void chain_begin(int64_t N) {
+    const int m = chain_mode();
+    // EXPERIMENT, default OFF (measured slower: profiles/r05_row_chains.md): recorded only on request (SPK_FM_CHAIN=1 / spk_fm_set_chain(1))
+    recording = m == 1 && N > 0;
+    chain.n_stages = 0; chain.N = N; chain_max_k = chain_max_nw = chain_max_r = 0;
+  }
+  int chain_end() { const int rc = chain_flush(); recording = false; return rc; }
+  int chain_flush() {
+    if (chain.n_stages == 0) return SPK_OK;
+    const int n = chain.n_stages;
+    chain.n_stages = 0;                       // (first: the launch below must not re-enter through pre_launch)
+    FmChainDesc d = chain;
+    d.n_stages = n;
+    // per stage: the split of K over the waves, and whether Y is handed to the next stage through LDS (Dense -> Dense on the same rows)
+    const int nwaves = FM_CHAIN_THREADS / 64;
+    int buf = 0;
+    for (int i = 0; i < n; ++i) {
+      if (d.st[i].is_ew) continue;
+      FmGemmStage& g = d.st[i].g;
+      const int n_cg = (g.NW + 63) / 64;
+      int ks = 1;
+      while (n_cg * ks * 2 <= nwaves && (g.K % (ks * 2 * FM_CHAIN_CHUNK)) == 0) ks *= 2;
+      g.ks = ks;
+      g.keep_y = 0;
+      g.x_from_lds = 0;
+      const int ns_in = g.mode == FM_G_TANGENT ? 1 : g.ns;
+      const int R = ns_in * g.rpa * FM_CHAIN_ATOMS;
+      const int need_x = R * (g.K + 4), need_p = ks * R * (g.NW + 4);
+      if (need_x > buf) buf = need_x;
+      if (need_p > buf) buf = need_p;
+    }
+    for (int i = 0; i + 1 < n; ++i) {
+      if (d.st[i].is_ew || d.st[i + 1].is_ew) continue;
+      FmGemmStage &a = d.st[i].g, &b = d.st[i + 1].g;
+      const int a_ns_out = a.mode == FM_G_TANGENT ? 1 : a.ns, b_ns_in = b.mode == FM_G_TANGENT ? 1 : b.ns;
+      const bool prologue = b.mode == FM_G_BWD_INPUT && b.pre_in != nullptr;
+      if (b.X == a.Y && b.K == a.NW && a.rpa == b.rpa && a_ns_out == b_ns_in && !prologue) { a.keep_y = 1; b.x_from_lds = 1; }
+    }
+    // operands that an earlier stage of this chain writes (any overlap of the address ranges is enough to call it internal)
+    for (int i = 0; i < n; ++i) {
+      if (d.st[i].is_ew) continue;
+      FmGemmStage& g = d.st[i].g;
+      auto internal = [&](const float* p) {
+        if (!p) return true;
+        for (int j = 0; j < i; ++j) {
+          if (d.st[j].is_ew) { for (int q = 0; q < 3; ++q) if (d.st[j].e.out[q] && chain_near(d.st[j].e.out[q], p)) return true; }
+          else if (chain_near(d.st[j].g.Y, p) || (d.st[j].g.pre_out && chain_near(d.st[j].g.pre_out, p))) return true;
+        }
+        return false;
+      };
+      g.ext = (internal(g.X) ? 0 : 1) | (internal(g.res) ? 0 : 2) | (internal(g.pre_in) ? 0 : 4);
+    }
+    d.buf_floats = (buf + 3) & ~3;
+    static const bool dbg = getenv("SPK_FM_CHAIN_DEBUG") != nullptr;
+    if (dbg) {
+      fprintf(stderr, "[fm_chain] N=%lld stages=%d lds=%d B:", (long long)chain.N, n, 2 * d.buf_floats * 4);
+      for (int i = 0; i < n; ++i) {
+        if (d.st[i].is_ew) fprintf(stderr, " ew%d", d.st[i].e.kind);
+        else fprintf(stderr, " g(m%d %dx%d R%d ks%d%s%s%s)", d.st[i].g.mode, d.st[i].g.K, d.st[i].g.NW, (d.st[i].g.mode == FM_G_TANGENT ? 1 : d.st[i].g.ns) * d.st[i].g.rpa * FM_CHAIN_ATOMS,
+                     d.st[i].g.ks, d.st[i].g.trans ? " T" : "", d.st[i].g.x_from_lds ? " <lds" : "", d.st[i].g.keep_y ? " >lds" : "");
+      }
+      fprintf(stderr, "\n");
+    }
+    const size_t lds = (size_t)2 * d.buf_floats * sizeof(float);
+    static SpkPerDevice lds_set;
+    int dev_;
+    if (lds_set.pending(&dev_)) {
+      SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_fm_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      lds_set.mark(dev_);
+    }
+    SPK_CHECK_ARG(lds <= 160 * 1024, "fm engine: row chain needs %zu bytes of LDS", lds);
+    const int64_t blocks = (chain.N + FM_CHAIN_ATOMS - 1) / FM_CHAIN_ATOMS;
+    static const bool stamps = getenv("SPK_FM_CHAIN_STAMPS") != nullptr;       // debugging aid: cycle stamps of workgroup 0, printed per launch (synchronises!)
+    static unsigned long long* dbg_dev = nullptr;
+    d.dbg = nullptr;
+    if (stamps) {
+      if (!dbg_dev) SPK_HIP_TRY(hipMalloc((void**)&dbg_dev, 128 * sizeof(unsigned long long)));
+      SPK_HIP_TRY(hipMemsetAsync(dbg_dev, 0, 128 * sizeof(unsigned long long), stream));
+      d.dbg = dbg_dev;
+    }
+    {
+      SpkProfScope prof("fm_chain", stream);
+      hipLaunchKernelGGL(k_fm_chain, dim3((unsigned)blocks), dim3(FM_CHAIN_THREADS), lds, stream, d);
+    }
+    if (stamps) {
+      unsigned long long h[128];
+      SPK_HIP_TRY(hipStreamSynchronize(stream));
+      SPK_HIP_TRY(hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[fm_chain stamps] warm %llu |", h[1] - h[0]);
+      unsigned long long prev = h[1];
+      for (int i = 0; i < n; ++i) {
+        const unsigned long long* q = h + 2 + 8 * i;
+        if (d.st[i].is_ew) { fprintf(stderr, " ew:%llu |", q[6] - prev); prev = q[6]; }
+        else {
+          fprintf(stderr, " g[x %llu bar %llu mm %llu bar %llu ld %llu st %llu bar %llu] |", q[0] - prev, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5]);
+          prev = q[6];
+        }
+      }
+      fprintf(stderr, " total %llu\n", prev - h[0]);
+    }
+    chain_max_k = chain_max_nw = chain_max_r = 0;
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
+  // p lies inside (or right behind: stacked halves are addressed as base + offset) the tensor that starts at `base`: tensors of a workspace are at
+  // most 12 N F floats long
+  bool chain_near(const float* base, const float* p) const {
+    const int64_t span = 12ll * chain.N * FM_CHAIN_MAX_W;
+    return p >= base && p < base + span;
+  }
+  void pre_launch() { if (recording && chain.n_stages) (void)chain_flush(); }
+  // a Dense-type stage joins the chain when the shapes fit (rows = 1, 2, 3 or 6 per atom; widths multiples of 4 up to FM_CHAIN_MAX_W; 16-byte aligned rows)
+  bool chain_gemm(int mode, const float* X, const float* W, const float* b, const float* res, const float* pre_in, float* Y, float* pre_out, int64_t m_rows, int K, int NW,
+                  int act, int trans, int ns_hint) {
+    if (!recording || chain.N <= 0 || m_rows % chain.N) return false;
+    const int64_t mpa = m_rows / chain.N;                 // rows per atom over all stacks of X
+    int ns, rpa;
+    if (ns_hint == 2) { if (mpa != 2 && mpa != 6) return false; ns = 2; rpa = (int)mpa / 2; }
+    else if (mpa == 1 || mpa == 3) { ns = 1; rpa = (int)mpa; }
+    else if (mpa == 2 || mpa == 6) { ns = 2; rpa = (int)mpa / 2; }
+    else return false;
+    if (mode == FM_G_TANGENT && ns != 1) return false;
+    if (K < FM_CHAIN_CHUNK || NW < 4 || (K % FM_CHAIN_CHUNK) || (NW & 3) || K > FM_CHAIN_MAX_W || NW > FM_CHAIN_MC * FM_CHAIN_CW) return false;
+    if (!al16(X) || !al16(W) || !al16(Y) || !al16(pre_in) || !al16(pre_out) || !al16(res)) return false;
+    if (chain.n_stages == FM_CHAIN_MAX_STAGES && chain_flush()) return false;
+    FmChainStage& st = chain.st[chain.n_stages++];
+    st.is_ew = 0;
+    st.g.X = X; st.g.W = W; st.g.b = b; st.g.res = res; st.g.pre_in = pre_in; st.g.Y = Y; st.g.pre_out = pre_out;
+    st.g.K = K; st.g.NW = NW; st.g.act = act; st.g.mode = mode; st.g.trans = trans; st.g.ns = ns; st.g.rpa = rpa;
+    const int R = ns * rpa * FM_CHAIN_ATOMS;
+    if (K > chain_max_k) chain_max_k = K;
+    if (NW > chain_max_nw) chain_max_nw = NW;
+    if (R > chain_max_r) chain_max_r = R;
+    return true;
+  }
+  // the atom-local element-wise kernels of the PaiNN mixing block (FmEwArgs): a stage of the chain, or one generic launch
+  void ew(const FmEwArgs<float>& a) {
+    if (recording && a.N == chain.N) {
+      if (chain.n_stages == FM_CHAIN_MAX_STAGES) (void)chain_flush();
+      FmChainStage& st = chain.st[chain.n_stages++];
+      st.is_ew = 1;
+      st.e = a;
+      return;
+    }
+    static const char* const tags[FM_EW_KINDS] = {"fm_painn_mix", "fm_painn_mix_t", "fm_painn_update", "fm_painn_update_t", "fm_painn_update_bwd", "fm_painn_mix_bwd",
+                                                  "fm_painn_update_dual_bwd", "fm_painn_mix_dual_bwd"};
+    flat(tags[a.kind], k_fm_ew<float>, a.N * a.F, a);
+  }
   // fork(s): later launches go to side stream s (which first waits for everything issued on the main stream so far); back(k): record
   // "done" event k there and return to the main stream; wait(k): the main stream waits for event k.  Without side streams all three are
   // no-ops and the work stays in issue order on the main stream.
   bool can_fork(int n_events) { if (!ss) ss = fm_side_streams(main_stream); return ss != nullptr && n_events <= 16; }
   void fork(int s) {
     if (!ss) return;
+    pre_launch();
     (void)hipEventRecord(ss->fork_ev[s], main_stream);
     (void)hipStreamWaitEvent(ss->side[s], ss->fork_ev[s], 0);
     stream = ss->side[s];
   }
   void back(int k) {
     if (!ss) return;
+    pre_launch();
     (void)hipEventRecord(ss->done_ev[k], stream);
     stream = main_stream;
     pending |= 1u << k;
   }
   void wait(int k) {
     if (!ss || !(pending & (1u << k))) return;
+    pre_launch();
     (void)hipStreamWaitEvent(main_stream, ss->done_ev[k], 0);
     pending &= ~(1u << k);
   }
   void set_gemm_ws(float* w, uint32_t* t) { gws = w; tickets = t; }
   unsigned pending = 0;      // "done" events recorded on a side stream and not yet waited for by the main stream
   int gemm_flush() {
+    pre_launch();
     if (batch.n == 0) return SPK_OK;
     for (int k = 0; k < 16; ++k)       // the batch reads operands that side streams may still be producing
       if (pending & (1u << k)) wait(k);
@@ -251,13 +415,17 @@ struct FmDeviceBackend {
     return wsf;
   }
   size_t transpose_tmp_bytes(int64_t E, int64_t N) { return (size_t)spk_transpose_plan_bytes(E, N); }
-  int zero_u32(uint32_t* p, int64_t n) { return spk_zero_async(p, (size_t)n * 4, stream); }
-  int rowptr(const int64_t* idx, int64_t n, int64_t rows, int32_t* out, int32_t* err) { return spk_segment_rowptr_i32(idx, n, rows, out, err, stream); }
-  int transpose_plan(const int64_t* jj, int64_t E, int64_t N, int32_t* colptr, int32_t* perm, void* tmp) { return spk_transpose_plan(jj, E, N, colptr, perm, tmp, stream); }
+  int zero_u32(uint32_t* p, int64_t n) { pre_launch(); return spk_zero_async(p, (size_t)n * 4, stream); }
+  int rowptr(const int64_t* idx, int64_t n, int64_t rows, int32_t* out, int32_t* err) { pre_launch(); return spk_segment_rowptr_i32(idx, n, rows, out, err, stream); }
+  int transpose_plan(const int64_t* jj, int64_t E, int64_t N, int32_t* colptr, int32_t* perm, void* tmp) { pre_launch(); return spk_transpose_plan(jj, E, N, colptr, perm, tmp, stream); }
   int dense(const float* x, const float* w, const float* b, const float* res, float* y, float* pre, int64_t m, int k, int n_out, int act) {
+    if (chain_gemm(FM_G_DENSE, x, w, b, res, nullptr, y, pre, m, k, n_out, act, 0, 0)) return SPK_OK;
+    pre_launch();
     return spk_dense_f32(x, w, b, res, y, pre, m, k, n_out, act, stream);
   }
   int dense_bwd_input(const float* dy, const float* pre, const float* w, const float* res, float* dx, int64_t m, int k, int n_out, int act) {
+    if ((pre || act == FM_ACT_NONE) && chain_gemm(FM_G_BWD_INPUT, dy, w, nullptr, res, pre, dx, nullptr, m, n_out, k, act, 1, 0)) return SPK_OK;
+    pre_launch();
     return spk_dense_bwd_input_f32(dy, pre, w, res, dx, m, k, n_out, act, stream);
   }
   // Dense layers on (value, tangent) pairs: ONE launch each (spk_dense_dual_f32) at training sizes; problems beyond the pair kernel's tile
@@ -281,6 +449,8 @@ struct FmDeviceBackend {
     const float* xt = x2 + M * k;
     float* yt = y2 + M * n_out;
     float* pt = pre2 ? pre2 + M * n_out : nullptr;
+    if (!fc && chain_gemm(FM_G_DUAL_FWD, x2, w, b, nullptr, nullptr, y2, pre2, 2 * M, k, n_out, act, 0, 2)) return SPK_OK;
+    pre_launch();
     if (dual_enabled(1) && spk_dense_dual_fwd_supported(M, k, n_out) && al16(xt) && al16(yt) && al16(pt)) {      // (one-tile-per-workgroup kernel up to 4 tiles per CU, grid-stride kernel beyond)
       spk_dense_dual_t d = {};
       d.x_v = x2; d.x_t = xt; d.w = w; d.b = b; d.fc = fc; d.fc1 = fc1; d.y_v = y2; d.y_t = yt; d.pre_v = pre2; d.pre_t = pt;
@@ -302,6 +472,8 @@ struct FmDeviceBackend {
     return SPK_OK;
   }
   int dense_tangent(const float* xt, const float* w, const float* pre_v, float* yt, float* pre_t, int64_t M, int KC, int NW, int act, bool trans) {
+    if (chain_gemm(FM_G_TANGENT, xt, w, nullptr, nullptr, pre_v, yt, pre_t, M, KC, NW, act, trans ? 1 : 0, 1)) return SPK_OK;
+    pre_launch();
     if (dual_ok(M, KC, NW, 2) && al16(xt) && al16(pre_v) && al16(yt) && al16(pre_t)) {
       spk_dense_dual_t d = {};
       d.x_t = xt; d.w = w; d.pre_v_in = pre_v; d.y_t = yt; d.pre_t = pre_t;
@@ -314,6 +486,8 @@ struct FmDeviceBackend {
     return SPK_OK;
   }
   int dense_dual_bwd(const float* g2, const float* w, const float* pre2, float* gx2, float* tmp2, int64_t M, int k, int n_out, int act) {
+    if (chain_gemm(FM_G_DUAL_BWD, g2, w, nullptr, nullptr, pre2, gx2, nullptr, 2 * M, n_out, k, act, 1, 2)) return SPK_OK;
+    pre_launch();
     if (dual_ok(M, n_out, k, 4) && al16(g2 + M * n_out) && al16(pre2 + M * k) && al16(gx2 + M * k)) {
       spk_dense_dual_t d = {};
       d.x_v = g2; d.x_t = g2 + M * n_out; d.w = w; d.pre_v_in = pre2; d.pre_t_in = pre2 + M * k; d.y_v = gx2; d.y_t = gx2 + M * k;
@@ -348,18 +522,21 @@ struct FmDeviceBackend {
   template <class... KA, class... A>
   void flat(const char* tag, void (*k)(KA...), int64_t total, A... a) {
     if (total <= 0) return;
+    pre_launch();
     SpkProfScope prof(tag, stream);
     hipLaunchKernelGGL(k, dim3(spk_grid_for(total, 256, max_blocks)), dim3(256), 0, stream, static_cast<KA>(a)...);
   }
   template <class... KA, class... A>
   void slotted(const char* tag, void (*k)(KA...), int64_t total, A... a) {      // FM_FOR_SLOTTED kernels: 64 items per workgroup, four waves share each item's row
     if (total <= 0) return;
+    pre_launch();
     SpkProfScope prof(tag, stream);
     hipLaunchKernelGGL(k, dim3(spk_grid_for(total, 64, max_blocks)), dim3(256), 0, stream, static_cast<KA>(a)...);
   }
   template <class... KA, class... A>
   void rows(const char* tag, void (*k)(KA...), int64_t n_rows, A... a) {      // one wavefront per row, four per workgroup
     if (n_rows <= 0) return;
+    pre_launch();
     SpkProfScope prof(tag, stream);
     hipLaunchKernelGGL(k, dim3(spk_grid_for(n_rows, 4, max_blocks)), dim3(256), 0, stream, static_cast<KA>(a)...);
   }

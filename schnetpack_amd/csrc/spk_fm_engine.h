@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <vector>
+#include <initializer_list>
 #include "spk_fm_kernels.h"
 
 template <class T>
@@ -77,6 +78,19 @@ template <class T, class B>
 struct FmEngine {
   B& be;
   explicit FmEngine(B& b) : be(b) {}
+
+  // the atom-local element-wise kernels of PaiNN's mixing block through one descriptor (a stage of a row chain on the device, spk_fm_chain.h)
+  void ew(int kind, int64_t N, int F, T eps, std::initializer_list<const T*> in, std::initializer_list<T*> out) {
+    FmEwArgs<T> a;
+    a.kind = kind; a.F = F; a.N = N; a.eps = eps;
+    for (int q = 0; q < 8; ++q) a.in[q] = nullptr;
+    for (int q = 0; q < 3; ++q) a.out[q] = nullptr;
+    int q = 0;
+    for (const T* p : in) a.in[q++] = p;
+    q = 0;
+    for (T* p : out) a.out[q++] = p;
+    be.ew(a);
+  }
 
   // ------------------------------------------------------------------------------------------------ shared pieces
   void carve_common(FmArena& a, FmCommonWs<T>& w, int64_t N, int64_t E, int64_t M, int K, int H, int n_types, bool painn, int64_t gemm_ws_floats) {
@@ -191,6 +205,7 @@ struct FmEngine {
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
     if ((rc = prepare(b, rb, w.c, err))) return rc;
+    be.chain_begin(N);      // atom-local launches from here on may leave as row chains (device backend, small batches)
     be.flat("fm_embed", k_fm_embed<T>, N * F, b.emb, b.Z, N, F, b.n_types, w.X2[0], w.c.onehot, err);
     // ---- pass A.  The filter networks depend on the geometry only: they are issued first, on two side streams (interactions alternate),
     // and the atom chain on the main stream waits for interaction l's filters in front of its convolution.
@@ -215,7 +230,7 @@ struct FmEngine {
       if ((rc = be.dense(w.s2[l], P.f2out_w2, P.f2out_b2, w.X2[l], w.X2[l + 1], nullptr, N, F, F, FM_ACT_NONE))) return rc;
     }
     if ((rc = head_forward(b, hd, F, w.X2[L], w.c, E_out, err))) return rc;
-    if (!F_out) return 0;
+    if (!F_out) return be.chain_end();
     T *gxa = w.GX[L], *gxb = w.GX[0], *ghb = w.gh2[0];                      // pass B borrows pass-D buffers (it ends before D starts)
     if ((rc = head_backward_R(b, hd, F, w.c, gxa))) return rc;              // ---- pass B
     for (int l = L - 1; l >= 0; --l) {
@@ -231,7 +246,7 @@ struct FmEngine {
     }
     be.flat("fm_gr", k_fm_gr<T>, E, w.c.gd, (const T*)nullptr, w.c.u, w.c.d, E, w.c.gr);
     be.flat("fm_force", k_fm_force<T>, N * 3, w.c.gr, w.c.rowptr, w.c.colptr, w.c.perm, w.c.e_act, N, F_out);
-    return 0;
+    return be.chain_end();
   }
 
   // passes C + D; `grads` in the flat layout of fm_schnet_grad_floats(); the workspace must be the one the forward call filled
@@ -242,6 +257,7 @@ struct FmEngine {
     schnet_carve(ws, m, K, H, N, E, b.M, b.n_types, w);
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
+    be.chain_begin(N);
     be.flat("fm_tgeom", k_fm_tgeom<T>, E, gF, b.ii, b.jj, w.c.d, w.c.u, E, N, w.c.dt, (T*)nullptr);
     for (int l = 0; l < L; ++l) {                                            // ---- pass C
       const FmSchnetLayer<T>& P = m.layers[l];
@@ -290,6 +306,7 @@ struct FmEngine {
     }
     if (parD) for (int l = 0; l < L; ++l) be.wait(l);
     if ((rc = be.gemm_tn(w.c.onehot, w.GX[0], N, b.n_types, F, g_emb, nullptr, N))) return rc;      // embedding table: onehot(Z)^T gx_0
+    if ((rc = be.chain_end())) return rc;
     return be.gemm_flush();
   }
 
@@ -334,6 +351,7 @@ struct FmEngine {
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
     if ((rc = prepare(b, rb, w.c, err))) return rc;
+    be.chain_begin(N);
     // every interaction's filter rows at once (painn.py:232-236): Phi = (phi Wf^T + bf) f_c, with the d-derivative beside it -- on a side
     // stream, beside the embedding and the first context net (they meet in front of the first message)
     const bool par = be.can_fork(1);
@@ -350,13 +368,13 @@ struct FmEngine {
       if (par && l == 0) be.wait(0);
       be.slotted("fm_painn_msg", k_fm_painn_msg<T>, N * F, w.Q2[l], mu, w.c2[l], Phi, ld, w.c.u, w.c.rowptr, b.jj, w.c.e_act, N, F, w.q1_2[l], w.mu1_2[l]);
       if ((rc = be.dense(w.mu1_2[l], P.mix_w, nullptr, nullptr, w.VW2[l], nullptr, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
-      be.flat("fm_painn_mix", k_fm_painn_mix<T>, N * F, w.q1_2[l], w.VW2[l], m.eps, N, F, w.n2[l], w.svw2[l], w.ctx2[l]);
+      ew(FM_EW_MIX, N, F, m.eps, {w.q1_2[l], w.VW2[l]}, {w.n2[l], w.svw2[l], w.ctx2[l]});
       if ((rc = be.dense(w.ctx2[l], P.ictx_w1, P.ictx_b1, nullptr, w.sb2[l], w.pb2[l], N, 2 * F, F, FM_ACT_SILU))) return rc;
       if ((rc = be.dense(w.sb2[l], P.ictx_w2, P.ictx_b2, nullptr, w.a2[l], nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
-      be.flat("fm_painn_update", k_fm_painn_update<T>, N * F, w.q1_2[l], w.mu1_2[l], w.VW2[l], w.a2[l], w.svw2[l], N, F, w.Q2[l + 1], w.MU2[l + 1]);
+      ew(FM_EW_UPDATE, N, F, T(0), {w.q1_2[l], w.mu1_2[l], w.VW2[l], w.a2[l], w.svw2[l]}, {w.Q2[l + 1], w.MU2[l + 1]});
     }
     if ((rc = head_forward(b, hd, F, w.Q2[L], w.c, E_out, err))) return rc;
-    if (!F_out) return 0;
+    if (!F_out) return be.chain_end();
     if ((rc = head_backward_R(b, hd, F, w.c, w.gq_a))) return rc;           // ---- pass B
     const T* gmu = nullptr;                                                  // the head does not read the vector representation
     T *ga = w.ga2[0], *gVW = w.gVW2[0], *gc = w.gc2[0];                      // pass B borrows pass-D buffers (it ends before D starts)
@@ -364,10 +382,10 @@ struct FmEngine {
       const FmPainnLayer<T>& P = m.layers[l];
       const T* Phi = w.Phi2 + (m.shared_filters ? 0 : 3 * F * l);
       const T* mu = l > 0 ? w.MU2[l] : nullptr;
-      be.flat("fm_painn_update_bwd", k_fm_painn_update_bwd<T>, N * F, w.gq_a, gmu, w.VW2[l], w.a2[l], w.svw2[l], N, F, ga, gVW);
+      ew(FM_EW_UPDATE_BWD, N, F, T(0), {w.gq_a, gmu, w.VW2[l], w.a2[l], w.svw2[l]}, {ga, gVW});
       if ((rc = be.dense_bwd_input(ga, nullptr, P.ictx_w2, nullptr, w.gsb2, N, F, 3 * F, FM_ACT_NONE))) return rc;
       if ((rc = be.dense_bwd_input(w.gsb2, w.pb2[l], P.ictx_w1, nullptr, w.gctx2, N, 2 * F, F, FM_ACT_SILU))) return rc;
-      be.flat("fm_painn_mix_bwd", k_fm_painn_mix_bwd<T>, N * F, w.gq_a, w.gctx2, w.VW2[l], w.n2[l], N, F, w.gq1_2, gVW);
+      ew(FM_EW_MIX_BWD, N, F, T(0), {w.gq_a, w.gctx2, w.VW2[l], w.n2[l]}, {w.gq1_2, gVW});
       if ((rc = be.dense_bwd_input(gVW, nullptr, P.mix_w, gmu, w.gmu1_2, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
       be.rows("fm_painn_msg_gd", k_fm_painn_msg_gd<T>, E, w.gq1_2, w.gmu1_2, w.c2[l], mu, Phi, ld, w.c.u, b.ii, b.jj, E, N, F, w.c.gd, w.c.gu);
       if (l > 0) {
@@ -380,7 +398,7 @@ struct FmEngine {
     }
     be.flat("fm_gr", k_fm_gr<T>, E, w.c.gd, (const T*)w.c.gu, w.c.u, w.c.d, E, w.c.gr);
     be.flat("fm_force", k_fm_force<T>, N * 3, w.c.gr, w.c.rowptr, w.c.colptr, w.c.perm, w.c.e_act, N, F_out);
-    return 0;
+    return be.chain_end();
   }
 
   // `grads` in the flat layout of fm_painn_grad_floats()
@@ -393,6 +411,7 @@ struct FmEngine {
     painn_carve(ws, m, K, H, N, E, b.M, b.n_types, w);
     be.set_gemm_ws(w.c.gemm_ws, w.c.tickets);
     int rc;
+    be.chain_begin(N);
     be.flat("fm_tgeom", k_fm_tgeom<T>, E, gF, b.ii, b.jj, w.c.d, w.c.u, E, N, w.c.dt, w.c.ut);
     const int64_t NF = N * F;
     for (int l = 0; l < L; ++l) {                                            // ---- pass C
@@ -406,11 +425,11 @@ struct FmEngine {
       be.slotted("fm_painn_msg_t", k_fm_painn_msg_t<T>, NF, (const T*)(first ? nullptr : w.Q2[l] + NF), w.c2[l], (const T*)(first ? nullptr : w.MU2[l]), Phi, ld, E, w.c.dt,
               w.c.u, w.c.ut, w.c.rowptr, b.jj, w.c.e_act, N, F, first, w.q1_2[l] + NF, w.mu1_2[l] + 3 * NF);
       if ((rc = be.dense(w.mu1_2[l] + 3 * NF, P.mix_w, nullptr, nullptr, w.VW2[l] + 6 * NF, nullptr, 3 * N, F, 2 * F, FM_ACT_NONE))) return rc;
-      be.flat("fm_painn_mix_t", k_fm_painn_mix_t<T>, NF, w.q1_2[l] + NF, w.VW2[l], w.VW2[l] + 6 * NF, w.n2[l], N, F, w.n2[l] + NF, w.svw2[l] + NF, w.ctx2[l] + 2 * NF);
+      ew(FM_EW_MIX_T, N, F, T(0), {w.q1_2[l] + NF, w.VW2[l], w.VW2[l] + 6 * NF, w.n2[l]}, {w.n2[l] + NF, w.svw2[l] + NF, w.ctx2[l] + 2 * NF});
       if ((rc = be.dense_tangent(w.ctx2[l] + 2 * NF, P.ictx_w1, w.pb2[l], w.sb2[l] + NF, w.pb2[l] + NF, N, 2 * F, F, FM_ACT_SILU, false))) return rc;
       if ((rc = be.dense(w.sb2[l] + NF, P.ictx_w2, nullptr, nullptr, w.a2[l] + 3 * NF, nullptr, N, F, 3 * F, FM_ACT_NONE))) return rc;
-      be.flat("fm_painn_update_t", k_fm_painn_update_t<T>, NF, w.q1_2[l] + NF, w.mu1_2[l] + 3 * NF, w.VW2[l], w.VW2[l] + 6 * NF, w.a2[l], w.a2[l] + 3 * NF, w.svw2[l],
-              w.svw2[l] + NF, N, F, w.Q2[l + 1] + NF, w.MU2[l + 1] + 3 * NF);
+      ew(FM_EW_UPDATE_T, N, F, T(0), {w.q1_2[l] + NF, w.mu1_2[l] + 3 * NF, w.VW2[l], w.VW2[l] + 6 * NF, w.a2[l], w.a2[l] + 3 * NF, w.svw2[l], w.svw2[l] + NF},
+         {w.Q2[l + 1] + NF, w.MU2[l + 1] + 3 * NF});
     }
     if ((rc = head_tangent(b, hd, F, w.Q2[L] + NF, w.c))) return rc;
     const int64_t lg = fm_painn_layer_grad_floats(F);
@@ -436,12 +455,12 @@ struct FmEngine {
       T* g_ib2 = g;
       T *ga2 = w.ga2[l], *gpb2 = w.gpb2[l], *gVW2 = w.gVW2[l], *gP2 = w.gP2[l], *gc2 = w.gc2[l], *gpa2 = w.gpa2[l];
       // mixing (painn.py:99-116)
-      be.flat("fm_painn_update_dual_bwd", k_fm_painn_update_dual_bwd<T>, NF, w.gq_a, gmu2, w.VW2[l], w.a2[l], w.svw2[l], N, F, ga2, gVW2);
+      ew(FM_EW_UPDATE_DUAL_BWD, N, F, T(0), {w.gq_a, gmu2, w.VW2[l], w.a2[l], w.svw2[l]}, {ga2, gVW2});
       if ((rc = be.gemm_tn(ga2, w.sb2[l], 2 * N, 3 * F, F, g_iw2, g_ib2, N))) return rc;
       if ((rc = be.dense_dual_bwd(ga2, P.ictx_w2, w.pb2[l], gpb2, w.gsb2, N, F, 3 * F, FM_ACT_SILU))) return rc;
       if ((rc = be.gemm_tn(gpb2, w.ctx2[l], 2 * N, F, 2 * F, g_iw1, g_ib1, N))) return rc;
       if ((rc = be.dense_bwd_input(gpb2, nullptr, P.ictx_w1, nullptr, w.gctx2, 2 * N, 2 * F, F, FM_ACT_NONE))) return rc;
-      be.flat("fm_painn_mix_dual_bwd", k_fm_painn_mix_dual_bwd<T>, NF, w.gq_a, w.gctx2, w.VW2[l], w.n2[l], N, F, w.gq1_2, gVW2);
+      ew(FM_EW_MIX_DUAL_BWD, N, F, T(0), {w.gq_a, w.gctx2, w.VW2[l], w.n2[l]}, {w.gq1_2, gVW2});
       if ((rc = be.gemm_tn(gVW2, w.mu1_2[l], 6 * N, 2 * F, F, g_mix, nullptr, 6 * N))) return rc;
       if ((rc = be.dense_bwd_input(gVW2, nullptr, P.mix_w, gmu2, w.gmu1_2, 6 * N, F, 2 * F, FM_ACT_NONE))) return rc;
       // message (painn.py:50-66)
@@ -469,6 +488,7 @@ struct FmEngine {
       T* t = w.gmu_a; w.gmu_a = w.gmu_b; w.gmu_b = t;
     }
     if ((rc = be.gemm_tn(w.c.onehot, w.gq_a, N, b.n_types, F, g_emb, nullptr, N))) return rc;      // embedding table: onehot(Z)^T gq_0
+    if ((rc = be.chain_end())) return rc;
     if ((rc = be.gemm_flush())) return rc;
     if (m.shared_filters)
       for (int l = 0; l < L - 1; ++l)

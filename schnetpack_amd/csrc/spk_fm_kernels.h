@@ -870,148 +870,197 @@ FM_KERNEL void k_fm_painn_filter_cot(const T* gq1_2, const T* gmu1_2, const T* c
 }
 
 // ================================================================================================ PaiNN mixing (painn.py:99-116)
+// The eight element-wise kernels of the mixing block are ATOM-LOCAL: item t = (atom i, channel f) reads and writes rows of atom i only.  Each is
+// written as a per-item function `fm_painn_*_at(t, ...)`; the kernels below run it over all N F items, the row-chain kernel of spk_fm_chain.h runs
+// it over the items of a workgroup's own atoms between two Dense stages (one launch for what is a chain of launches otherwise).
 // n = sqrt(sum_x V^2 + eps), svw = sum_x V W, ctx = [q1 | n]
 template <class T>
-FM_KERNEL void k_fm_painn_mix(const T* q1, const T* VW, T eps, int64_t N, int F, T* n, T* svw, T* ctx) {
-  FM_FOR(t, N * F) {
-    const int64_t i = t / F;
-    const int f = (int)(t % F);
-    T s2 = 0, sv = 0;
-    for (int x = 0; x < 3; ++x) {
-      const T V = VW[(i * 3 + x) * 2 * F + f], W = VW[(i * 3 + x) * 2 * F + F + f];
-      s2 += V * V;
-      sv += V * W;
-    }
-    const T nn = fm_sqrt(s2 + eps);
-    n[t] = nn;
-    svw[t] = sv;
-    ctx[i * 2 * F + f] = q1[t];
-    ctx[i * 2 * F + F + f] = nn;
+FM_HD void fm_painn_mix_at(int64_t t, const T* q1, const T* VW, T eps, int64_t N, int F, T* n, T* svw, T* ctx) {
+  const int64_t i = t / F;
+  const int f = (int)(t % F);
+  T s2 = 0, sv = 0;
+  for (int x = 0; x < 3; ++x) {
+    const T V = VW[(i * 3 + x) * 2 * F + f], W = VW[(i * 3 + x) * 2 * F + F + f];
+    s2 += V * V;
+    sv += V * W;
   }
+  const T nn = fm_sqrt(s2 + eps);
+  n[t] = nn;
+  svw[t] = sv;
+  ctx[i * 2 * F + f] = q1[t];
+  ctx[i * 2 * F + F + f] = nn;
 }
 template <class T>
-FM_KERNEL void k_fm_painn_mix_t(const T* q1t, const T* VW, const T* VWt, const T* n, int64_t N, int F, T* nt, T* svwt, T* ctxt) {
-  FM_FOR(t, N * F) {
-    const int64_t i = t / F;
-    const int f = (int)(t % F);
-    T a = 0, sv = 0;
-    for (int x = 0; x < 3; ++x) {
-      const int64_t o = (i * 3 + x) * 2 * F + f;
-      a += VW[o] * VWt[o];
-      sv += VWt[o] * VW[o + F] + VW[o] * VWt[o + F];
-    }
-    const T v = a / n[t];
-    nt[t] = v;
-    svwt[t] = sv;
-    ctxt[i * 2 * F + f] = q1t[t];
-    ctxt[i * 2 * F + F + f] = v;
+FM_HD void fm_painn_mix_t_at(int64_t t, const T* q1t, const T* VW, const T* VWt, const T* n, int64_t N, int F, T* nt, T* svwt, T* ctxt) {
+  const int64_t i = t / F;
+  const int f = (int)(t % F);
+  T a = 0, sv = 0;
+  for (int x = 0; x < 3; ++x) {
+    const int64_t o = (i * 3 + x) * 2 * F + f;
+    a += VW[o] * VWt[o];
+    sv += VWt[o] * VW[o + F] + VW[o] * VWt[o + F];
   }
+  const T v = a / n[t];
+  nt[t] = v;
+  svwt[t] = sv;
+  ctxt[i * 2 * F + f] = q1t[t];
+  ctxt[i * 2 * F + F + f] = v;
 }
 // q2 = q1 + a_q + a_qmu svw,  mu2 = mu1 + a_mu W
+// (every function below requests ALL its operands before its first store: inside a row chain a load issued behind a store waits until that
+//  store has been acknowledged -- loads and stores share one in-order counter -- and a workgroup alone on its compute unit has nobody to hide
+//  ~2 us of that behind)
 template <class T>
-FM_KERNEL void k_fm_painn_update(const T* q1, const T* mu1, const T* VW, const T* a, const T* svw, int64_t N, int F, T* q2, T* mu2) {
-  FM_FOR(t, N * F) {
-    const int64_t i = t / F;
-    const int f = (int)(t % F);
-    q2[t] = q1[t] + a[i * 3 * F + f] + a[i * 3 * F + 2 * F + f] * svw[t];
-    const T am = a[i * 3 * F + F + f];
-    for (int x = 0; x < 3; ++x) mu2[(i * 3 + x) * F + f] = mu1[(i * 3 + x) * F + f] + am * VW[(i * 3 + x) * 2 * F + F + f];
-  }
+FM_HD void fm_painn_update_at(int64_t t, const T* q1, const T* mu1, const T* VW, const T* a, const T* svw, int64_t N, int F, T* q2, T* mu2) {
+  const int64_t i = t / F;
+  const int f = (int)(t % F);
+  const T am = a[i * 3 * F + F + f];
+  const T q = q1[t] + a[i * 3 * F + f] + a[i * 3 * F + 2 * F + f] * svw[t];
+  T m[3];
+  for (int x = 0; x < 3; ++x) m[x] = mu1[(i * 3 + x) * F + f] + am * VW[(i * 3 + x) * 2 * F + F + f];
+  q2[t] = q;
+  for (int x = 0; x < 3; ++x) mu2[(i * 3 + x) * F + f] = m[x];
 }
 template <class T>
-FM_KERNEL void k_fm_painn_update_t(const T* q1t, const T* mu1t, const T* VW, const T* VWt, const T* a, const T* at, const T* svw, const T* svwt, int64_t N,
-                                   int F, T* q2t, T* mu2t) {
-  FM_FOR(t, N * F) {
-    const int64_t i = t / F;
-    const int f = (int)(t % F);
-    q2t[t] = q1t[t] + at[i * 3 * F + f] + at[i * 3 * F + 2 * F + f] * svw[t] + a[i * 3 * F + 2 * F + f] * svwt[t];
-    const T am = a[i * 3 * F + F + f], amt = at[i * 3 * F + F + f];
-    for (int x = 0; x < 3; ++x) {
-      const int64_t o = (i * 3 + x) * 2 * F + F + f;
-      mu2t[(i * 3 + x) * F + f] = mu1t[(i * 3 + x) * F + f] + amt * VW[o] + am * VWt[o];
-    }
+FM_HD void fm_painn_update_t_at(int64_t t, const T* q1t, const T* mu1t, const T* VW, const T* VWt, const T* a, const T* at, const T* svw, const T* svwt, int64_t N,
+                                int F, T* q2t, T* mu2t) {
+  const int64_t i = t / F;
+  const int f = (int)(t % F);
+  const T q = q1t[t] + at[i * 3 * F + f] + at[i * 3 * F + 2 * F + f] * svw[t] + a[i * 3 * F + 2 * F + f] * svwt[t];
+  const T am = a[i * 3 * F + F + f], amt = at[i * 3 * F + F + f];
+  T m[3];
+  for (int x = 0; x < 3; ++x) {
+    const int64_t o = (i * 3 + x) * 2 * F + F + f;
+    m[x] = mu1t[(i * 3 + x) * F + f] + amt * VW[o] + am * VWt[o];
   }
+  q2t[t] = q;
+  for (int x = 0; x < 3; ++x) mu2t[(i * 3 + x) * F + f] = m[x];
 }
 // pass B: ga = (gq | sum gmu W | gq svw);  gs = gq a_qmu;  gV = gs W;  gW = gmu a_mu + gs V      (gmu NULL = 0)
 template <class T>
-FM_KERNEL void k_fm_painn_update_bwd(const T* gq, const T* gmu, const T* VW, const T* a, const T* svw, int64_t N, int F, T* ga, T* gVW) {
-  FM_FOR(t, N * F) {
-    const int64_t i = t / F;
-    const int f = (int)(t % F);
-    const T g = gq[t], am = a[i * 3 * F + F + f], gs = g * a[i * 3 * F + 2 * F + f];
-    T s = 0;
-    for (int x = 0; x < 3; ++x) {
-      const int64_t o = (i * 3 + x) * 2 * F + f;
-      const T gm = gmu ? gmu[(i * 3 + x) * F + f] : T(0);
-      s += gm * VW[o + F];
-      gVW[o] = gs * VW[o + F];
-      gVW[o + F] = gm * am + gs * VW[o];
-    }
-    ga[i * 3 * F + f] = g;
-    ga[i * 3 * F + F + f] = s;
-    ga[i * 3 * F + 2 * F + f] = g * svw[t];
+FM_HD void fm_painn_update_bwd_at(int64_t t, const T* gq, const T* gmu, const T* VW, const T* a, const T* svw, int64_t N, int F, T* ga, T* gVW) {
+  const int64_t i = t / F;
+  const int f = (int)(t % F);
+  const T g = gq[t], am = a[i * 3 * F + F + f], gs = g * a[i * 3 * F + 2 * F + f], sv = svw[t];
+  T s = 0, gV[3], gW[3];
+  for (int x = 0; x < 3; ++x) {
+    const int64_t o = (i * 3 + x) * 2 * F + f;
+    const T gm = gmu ? gmu[(i * 3 + x) * F + f] : T(0);
+    const T V = VW[o], W = VW[o + F];
+    s += gm * W;
+    gV[x] = gs * W;
+    gW[x] = gm * am + gs * V;
   }
+  for (int x = 0; x < 3; ++x) {
+    const int64_t o = (i * 3 + x) * 2 * F + f;
+    gVW[o] = gV[x];
+    gVW[o + F] = gW[x];
+  }
+  ga[i * 3 * F + f] = g;
+  ga[i * 3 * F + F + f] = s;
+  ga[i * 3 * F + 2 * F + f] = g * sv;
 }
 // pass B: gq1 = gq + gctx[:, :F];  gV += (gctx[:, F:] / n) V
 template <class T>
-FM_KERNEL void k_fm_painn_mix_bwd(const T* gq, const T* gctx, const T* VW, const T* n, int64_t N, int F, T* gq1, T* gVW) {
-  FM_FOR(t, N * F) {
-    const int64_t i = t / F;
-    const int f = (int)(t % F);
-    gq1[t] = gq[t] + gctx[i * 2 * F + f];
-    const T s = gctx[i * 2 * F + F + f] / n[t];
-    for (int x = 0; x < 3; ++x) {
-      const int64_t o = (i * 3 + x) * 2 * F + f;
-      gVW[o] += s * VW[o];
-    }
+FM_HD void fm_painn_mix_bwd_at(int64_t t, const T* gq, const T* gctx, const T* VW, const T* n, int64_t N, int F, T* gq1, T* gVW) {
+  const int64_t i = t / F;
+  const int f = (int)(t % F);
+  const T q = gq[t] + gctx[i * 2 * F + f];
+  const T s = gctx[i * 2 * F + F + f] / n[t];
+  T v[3];
+  for (int x = 0; x < 3; ++x) {
+    const int64_t o = (i * 3 + x) * 2 * F + f;
+    v[x] = gVW[o] + s * VW[o];
   }
+  gq1[t] = q;
+  for (int x = 0; x < 3; ++x) gVW[(i * 3 + x) * 2 * F + f] = v[x];
 }
 // pass D: stacked cotangents in (gq2 = [gq ; hq], gmu2 = [gmu ; hmu] or NULL), values VW2 = [VW ; VWt], a2 = [a ; at], svw2 = [svw ; svwt]
 //   -> ga2 = [ga ; ha] [2N, 3F], gVW2 = [gVW ; hVW] [2 * 3N, 2F]       (equations (1)-(6) of oracle/fm_oracle.py)
 template <class T>
-FM_KERNEL void k_fm_painn_update_dual_bwd(const T* gq2, const T* gmu2, const T* VW2, const T* a2, const T* svw2, int64_t N, int F, T* ga2, T* gVW2) {
-  FM_FOR(t, N * F) {
-    const int64_t i = t / F;
-    const int f = (int)(t % F);
-    const T gq = gq2[t], hq = gq2[N * F + t];
-    const T am = a2[i * 3 * F + F + f], aqm = a2[i * 3 * F + 2 * F + f];
-    const T amt = a2[(N + i) * 3 * F + F + f], aqmt = a2[(N + i) * 3 * F + 2 * F + f];
-    const T gs = gq * aqm + hq * aqmt, hs = hq * aqm;
-    T sg = 0, sh = 0;
-    for (int x = 0; x < 3; ++x) {
-      const int64_t o = (i * 3 + x) * 2 * F + f, ot = ((N + i) * 3 + x) * 2 * F + f;
-      const T V = VW2[o], W = VW2[o + F], Vt = VW2[ot], Wt = VW2[ot + F];
-      const T gm = gmu2 ? gmu2[(i * 3 + x) * F + f] : T(0), hm = gmu2 ? gmu2[((N + i) * 3 + x) * F + f] : T(0);
-      sg += gm * W + hm * Wt;
-      sh += hm * W;
-      gVW2[o] = gs * W + hs * Wt;                       // gV
-      gVW2[o + F] = gm * am + hm * amt + gs * V + hs * Vt;  // gW
-      gVW2[ot] = hs * W;                                // hV
-      gVW2[ot + F] = hm * am + hs * V;                  // hW
-    }
-    ga2[i * 3 * F + f] = gq;
-    ga2[i * 3 * F + F + f] = sg;
-    ga2[i * 3 * F + 2 * F + f] = gq * svw2[t] + hq * svw2[N * F + t];
-    ga2[(N + i) * 3 * F + f] = hq;
-    ga2[(N + i) * 3 * F + F + f] = sh;
-    ga2[(N + i) * 3 * F + 2 * F + f] = hq * svw2[t];
+FM_HD void fm_painn_update_dual_bwd_at(int64_t t, const T* gq2, const T* gmu2, const T* VW2, const T* a2, const T* svw2, int64_t N, int F, T* ga2, T* gVW2) {
+  const int64_t i = t / F;
+  const int f = (int)(t % F);
+  const T gq = gq2[t], hq = gq2[N * F + t];
+  const T am = a2[i * 3 * F + F + f], aqm = a2[i * 3 * F + 2 * F + f];
+  const T amt = a2[(N + i) * 3 * F + F + f], aqmt = a2[(N + i) * 3 * F + 2 * F + f];
+  const T sv = svw2[t], svt = svw2[N * F + t];
+  const T gs = gq * aqm + hq * aqmt, hs = hq * aqm;
+  T sg = 0, sh = 0, oV[3], oW[3], oVt[3], oWt[3];
+  for (int x = 0; x < 3; ++x) {
+    const int64_t o = (i * 3 + x) * 2 * F + f, ot = ((N + i) * 3 + x) * 2 * F + f;
+    const T V = VW2[o], W = VW2[o + F], Vt = VW2[ot], Wt = VW2[ot + F];
+    const T gm = gmu2 ? gmu2[(i * 3 + x) * F + f] : T(0), hm = gmu2 ? gmu2[((N + i) * 3 + x) * F + f] : T(0);
+    sg += gm * W + hm * Wt;
+    sh += hm * W;
+    oV[x] = gs * W + hs * Wt;                       // gV
+    oW[x] = gm * am + hm * amt + gs * V + hs * Vt;  // gW
+    oVt[x] = hs * W;                                // hV
+    oWt[x] = hm * am + hs * V;                      // hW
   }
+  for (int x = 0; x < 3; ++x) {
+    const int64_t o = (i * 3 + x) * 2 * F + f, ot = ((N + i) * 3 + x) * 2 * F + f;
+    gVW2[o] = oV[x];
+    gVW2[o + F] = oW[x];
+    gVW2[ot] = oVt[x];
+    gVW2[ot + F] = oWt[x];
+  }
+  ga2[i * 3 * F + f] = gq;
+  ga2[i * 3 * F + F + f] = sg;
+  ga2[i * 3 * F + 2 * F + f] = gq * sv + hq * svt;
+  ga2[(N + i) * 3 * F + f] = hq;
+  ga2[(N + i) * 3 * F + F + f] = sh;
+  ga2[(N + i) * 3 * F + 2 * F + f] = hq * sv;
 }
 // pass D: gq1 = gq + gctx[:, :F], hq1 = hq + hctx[:, :F];  gV += gn/n V + hn/n (Vt - nt/n V),  hV += hn/n V      (equations (7), (8))
 template <class T>
-FM_KERNEL void k_fm_painn_mix_dual_bwd(const T* gq2, const T* gctx2, const T* VW2, const T* n2, int64_t N, int F, T* gq1_2, T* gVW2) {
-  FM_FOR(t, N * F) {
-    const int64_t i = t / F;
-    const int f = (int)(t % F);
-    gq1_2[t] = gq2[t] + gctx2[i * 2 * F + f];
-    gq1_2[N * F + t] = gq2[N * F + t] + gctx2[(N + i) * 2 * F + f];
-    const T n = n2[t], nt = n2[N * F + t];
-    const T gn = gctx2[i * 2 * F + F + f] / n, hn = gctx2[(N + i) * 2 * F + F + f] / n;
-    for (int x = 0; x < 3; ++x) {
-      const int64_t o = (i * 3 + x) * 2 * F + f, ot = ((N + i) * 3 + x) * 2 * F + f;
-      const T V = VW2[o], Vt = VW2[ot];
-      gVW2[o] += gn * V + hn * (Vt - nt / n * V);
-      gVW2[ot] += hn * V;
-    }
+FM_HD void fm_painn_mix_dual_bwd_at(int64_t t, const T* gq2, const T* gctx2, const T* VW2, const T* n2, int64_t N, int F, T* gq1_2, T* gVW2) {
+  const int64_t i = t / F;
+  const int f = (int)(t % F);
+  const T q = gq2[t] + gctx2[i * 2 * F + f];
+  const T qt = gq2[N * F + t] + gctx2[(N + i) * 2 * F + f];
+  const T n = n2[t], nt = n2[N * F + t];
+  const T gn = gctx2[i * 2 * F + F + f] / n, hn = gctx2[(N + i) * 2 * F + F + f] / n;
+  T v[3], vt[3];
+  for (int x = 0; x < 3; ++x) {
+    const int64_t o = (i * 3 + x) * 2 * F + f, ot = ((N + i) * 3 + x) * 2 * F + f;
+    const T V = VW2[o], Vt = VW2[ot];
+    v[x] = gVW2[o] + gn * V + hn * (Vt - nt / n * V);
+    vt[x] = gVW2[ot] + hn * V;
+  }
+  gq1_2[t] = q;
+  gq1_2[N * F + t] = qt;
+  for (int x = 0; x < 3; ++x) {
+    gVW2[(i * 3 + x) * 2 * F + f] = v[x];
+    gVW2[((N + i) * 3 + x) * 2 * F + f] = vt[x];
   }
 }
+
+// One descriptor for the eight: kind + up to eight inputs and two outputs (the order of each function's arguments above), so that the engine's
+// backends can record them as stages of a row chain (spk_fm_chain.h) or run them as one generic launch.
+enum { FM_EW_MIX = 0, FM_EW_MIX_T, FM_EW_UPDATE, FM_EW_UPDATE_T, FM_EW_UPDATE_BWD, FM_EW_MIX_BWD, FM_EW_UPDATE_DUAL_BWD, FM_EW_MIX_DUAL_BWD, FM_EW_KINDS };
+template <class T>
+struct FmEwArgs {
+  int kind, F;
+  int64_t N;
+  T eps;
+  const T* in[8];
+  T* out[3];
+};
+template <class T>
+FM_HD void fm_ew_at(const FmEwArgs<T>& a, int64_t t) {
+  const T* const* i = a.in;
+  T* const* o = a.out;
+  switch (a.kind) {
+    case FM_EW_MIX: fm_painn_mix_at<T>(t, i[0], i[1], a.eps, a.N, a.F, o[0], o[1], o[2]); break;
+    case FM_EW_MIX_T: fm_painn_mix_t_at<T>(t, i[0], i[1], i[2], i[3], a.N, a.F, o[0], o[1], o[2]); break;
+    case FM_EW_UPDATE: fm_painn_update_at<T>(t, i[0], i[1], i[2], i[3], i[4], a.N, a.F, o[0], o[1]); break;
+    case FM_EW_UPDATE_T: fm_painn_update_t_at<T>(t, i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], a.N, a.F, o[0], o[1]); break;
+    case FM_EW_UPDATE_BWD: fm_painn_update_bwd_at<T>(t, i[0], i[1], i[2], i[3], i[4], a.N, a.F, o[0], o[1]); break;
+    case FM_EW_MIX_BWD: fm_painn_mix_bwd_at<T>(t, i[0], i[1], i[2], i[3], a.N, a.F, o[0], o[1]); break;
+    case FM_EW_UPDATE_DUAL_BWD: fm_painn_update_dual_bwd_at<T>(t, i[0], i[1], i[2], i[3], i[4], a.N, a.F, o[0], o[1]); break;
+    default: fm_painn_mix_dual_bwd_at<T>(t, i[0], i[1], i[2], i[3], a.N, a.F, o[0], o[1]); break;
+  }
+}
+template <class T>
+FM_KERNEL void k_fm_ew(FmEwArgs<T> a) { FM_FOR(t, a.N * a.F) fm_ew_at<T>(a, t); }

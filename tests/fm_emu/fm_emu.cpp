@@ -15,6 +15,10 @@ struct EmuBackend {
   void back(int) {}
   void wait(int) {}
   void set_gemm_ws(T*, uint32_t*) {}
+  // row chains are a launch-count device of the HIP backend: here every stage runs at once, in issue order
+  void chain_begin(int64_t) {}
+  int chain_end() { return 0; }
+  void ew(const FmEwArgs<T>& a) { for (int64_t t = 0; t < a.N * a.F; ++t) fm_ew_at<T>(a, t); }
   int64_t gemm_tn_ws_floats(int64_t, int, int) { return 0; }
   size_t transpose_tmp_bytes(int64_t, int64_t) { return 0; }
   int zero_u32(uint32_t* p, int64_t n) { std::memset(p, 0, (size_t)n * 4); return 0; }

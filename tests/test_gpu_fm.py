@@ -247,3 +247,35 @@ def test_large_batch_gradients_are_the_mean_of_its_two_halves(dev, kind):
         if e > worst[1]:
             worst = (k, e)
     assert worst[1] < 5e-5, worst
+
+
+@pytest.mark.parametrize("kind,frames", [("schnet", 8), ("painn", 8), ("painn", 3), ("schnet", 5)])
+def test_row_chains_equal_the_launch_by_launch_step(dev, kind, frames):
+    """Round 5 EXPERIMENT (opt-in, spk_fm_set_chain(1)): the atom-local launches of a pass recorded as row chains (csrc/spk_fm_chain.h: one
+    workgroup per 4 atoms walks Dense / element-wise stages on v_mfma_f32_4x4x1) against the same step launch by launch: energies, forces and
+    every weight gradient agree to fp32 rounding, the chained step takes far fewer launches (and, measured, more time:
+    profiles/r05_row_chains.md -- which is why it is off by default).  The chained step is also held against the float64 oracle.
+    frames = 3 / 5: the last workgroup owns fewer than four atoms (63 = 15 x 4 + 3; 105 = 26 x 4 + 1)."""
+    from schnetpack_amd import _lib
+    b = S.molecule_batch("aspirin", frames, seed=21)
+    g = torch.Generator().manual_seed(5)
+    Et, Ft = torch.randn(frames, generator=g), torch.randn(b["Z"].shape[0], 3, generator=g)
+    rep_p, head_p = _params(kind)
+    res, launches = {}, {}
+    try:
+        for mode in (0, 1):
+            _lib.lib().spk_fm_set_chain(mode)
+            _lib.profile_enable(True); _lib.profile_report()
+            res[mode] = _device_step(kind, rep_p, head_p, b, 3, Et, Ft, dev)
+            prof = _lib.profile_report(); _lib.profile_enable(False)
+            launches[mode] = sum(c for c, _ in prof.values())
+            if mode == 1:
+                assert "fm_chain" in prof
+    finally:
+        _lib.lib().spk_fm_set_chain(-1)
+    _compare(res[1], _oracle(kind, rep_p, head_p, b, 3, Et, Ft))
+    a, c = res[0], res[1]
+    assert rel_err(c[0], a[0]) < 2e-6 and rel_err(c[1], a[1]) < 2e-6 and abs(c[3] - a[3]) / abs(a[3]) < 2e-6
+    for k in a[2]:
+        assert float((c[2][k] - a[2][k]).abs().max()) / (float(a[2][k].abs().max()) + 1e-300) < 5e-6, k
+    assert launches[1] < 0.75 * launches[0], launches
