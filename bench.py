@@ -273,7 +273,7 @@ PMC_TAGS = [
     ("painn_msg_fwd_tile_mu0", r"k_painn_msg_tile<\d+, \d+, true"), ("painn_msg_fwd_tile", r"k_painn_msg_tile<"),
     ("painn_msg_bwd_tile_geom", r"k_painn_msg_tile_bwd<\d+, \d+, true"), ("painn_msg_bwd_tile", r"k_painn_msg_tile_bwd<\d+, \d+, false"),
     ("painn_mixing_fwd", r"k_painn_mixing_fwd"), ("painn_mixing_bwd", r"k_painn_mixing_bwd"),
-    ("dense_chain", r"k_dense_chain"), ("scatter_add_segsum", r"k_segsum<4>"),
+    ("dense_chain", r"k_dense_chain"), ("scatter_add_segsum", r"k_segsum<4, \d+>"),
 ]
 
 

@@ -227,7 +227,10 @@ extern "C" int spk_edge_plan(const int64_t* idx_i, const int64_t* idx_j, const f
 // ---------------------------------------------------------------- scatter_add (nn/scatter.py)
 // Segmented sum over CSR rows: one thread per (outer, row, VEC-chunk of inner); consecutive
 // threads read consecutive addresses of every edge row (coalesced), y written exactly once.
-template <int VEC>
+// UNR entries of the segment are in flight per thread, the tail as one more PREDICATED batch (clamped address, value masked) -- never a loop
+// of single dependent loads; the sums run in entry order whatever UNR is, so the result does not depend on it.  Streaming from DRAM the kernel is
+// bound by the loads it keeps outstanding (round 5: SPK_SEGSUM_UNROLL = 4 / 8 / 16 selects the instance for A/B runs; default 8).
+template <int VEC, int UNR>
 __global__ void k_segsum(const float* __restrict__ x, const int32_t* __restrict__ rowptr,
                          int64_t outer, int64_t E, int64_t inner, int64_t N,
                          float* __restrict__ y) {
@@ -243,24 +246,19 @@ __global__ void k_segsum(const float* __restrict__ x, const int32_t* __restrict_
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-    int32_t e = e0;
-    for (; e + 4 <= e1; e += 4) {
-      float tmp[4][VEC];
+    for (int32_t e = e0; e < e1; e += UNR) {
+      float tmp[UNR][VEC];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* p = xp + (int64_t)(e + u) * inner;
-        if (VEC == 4) { f32x4 q = *(const f32x4*)p; tmp[u][0] = q.x; tmp[u][1 % VEC] = q.y; tmp[u][2 % VEC] = q.z; tmp[u][3 % VEC] = q.w; }
-        else { tmp[u][0] = p[0]; }
+      for (int u = 0; u < UNR; ++u) {
+        const bool ok = e + u < e1;
+        const float* p = xp + (int64_t)(ok ? e + u : e1 - 1) * inner;
+        if (VEC == 4) { f32x4 q = *(const f32x4*)p; tmp[u][0] = ok ? q.x : 0.f; tmp[u][1 % VEC] = ok ? q.y : 0.f; tmp[u][2 % VEC] = ok ? q.z : 0.f; tmp[u][3 % VEC] = ok ? q.w : 0.f; }
+        else { tmp[u][0] = ok ? p[0] : 0.f; }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < UNR; ++u)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] += tmp[u][v];
-    }
-    for (; e < e1; ++e) {
-      const float* p = xp + (int64_t)e * inner;
-      if (VEC == 4) { f32x4 q = *(const f32x4*)p; acc[0] += q.x; acc[1 % VEC] += q.y; acc[2 % VEC] += q.z; acc[3 % VEC] += q.w; }
-      else { acc[0] += p[0]; }
     }
     float* yp = y + (o * N + k) * inner + c * VEC;
     if (VEC == 4) { f32x4 q; q.x = acc[0]; q.y = acc[1 % VEC]; q.z = acc[2 % VEC]; q.w = acc[3 % VEC]; *(f32x4*)yp = q; }
@@ -318,11 +316,14 @@ extern "C" int spk_scatter_add_f32(const float* x, const int64_t* idx, const int
       hipLaunchKernelGGL(k_segsum_wave, dim3(spk_grid_for(outer * N * inner * 64, 256, maxb)), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
     } else if (vec4) {
       int grid = spk_grid_for(outer * N * (inner / 4), 256, maxb);
+      static const int unr = [] { const char* e = getenv("SPK_SEGSUM_UNROLL"); const int v = e ? atoi(e) : 8; return v == 4 || v == 16 ? v : 8; }();
       SpkProfScope prof("scatter_add_segsum", stream);
-      hipLaunchKernelGGL(k_segsum<4>, dim3(grid), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
+      if (unr == 4) hipLaunchKernelGGL((k_segsum<4, 4>), dim3(grid), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
+      else if (unr == 16) hipLaunchKernelGGL((k_segsum<4, 16>), dim3(grid), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
+      else hipLaunchKernelGGL((k_segsum<4, 8>), dim3(grid), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
     } else {
       int grid = spk_grid_for(outer * N * inner, 256, maxb);
-      hipLaunchKernelGGL(k_segsum<1>, dim3(grid), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
+      hipLaunchKernelGGL((k_segsum<1, 8>), dim3(grid), dim3(256), 0, stream, x, rowptr, outer, E, inner, N, y);
     }
     SPK_LAUNCH_CHECK();
   } else {
