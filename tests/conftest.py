@@ -86,6 +86,13 @@ def record_parity(fixture, variant, quantity, got, ref, tol):
     return e
 
 
+def record_value(fixture, variant, quantity, err, tol):
+    """Ledger entry for a comparison whose error was computed by the test itself (e.g. the worst weight-gradient tensor of a training step)."""
+    _LEDGER.append({"fixture": str(fixture), "variant": str(variant), "quantity": str(quantity), "max_rel": float(err), "rms_rel": None,
+                    "tolerance": float(tol), "margin_x": (float(tol) / float(err)) if err > 0 else None})
+    return err
+
+
 def pytest_sessionfinish(session, exitstatus):
     if not _LEDGER:
         return

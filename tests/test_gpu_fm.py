@@ -6,7 +6,7 @@ arithmetic in a different summation order than float64; the CPU emulation of the
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import record_value, rel_err
 from oracle import fm_oracle as FM
 from oracle import spk_oracle as O
 from schnetpack_amd import synthetic as S
@@ -75,6 +75,8 @@ def _compare(got, ref, tol_g=2e-5):
         e = float((g[k].reshape(r.shape) - r).abs().max()) / (float(r.abs().max()) + 1e-300)
         if e > worst[1]:
             worst = (k, e)
+    record_value("fm_engine_step", "engine", "weight_gradient_worst_tensor", worst[1], tol_g)
+    record_value("fm_engine_step", "engine", "forces", rel_err(F, F_o), 1e-5)
     assert worst[1] < tol_g, worst
     return worst
 

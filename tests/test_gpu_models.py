@@ -212,6 +212,8 @@ def test_training_mode_double_backward_matches_oracle(dev, kind, F, n_rbf, radia
         worst = max(worst, rel_err(gh.cpu(), go[k]))
     # weight gradients of the force-matching loss (second order of the hot path), fp32 on the device against the fp64 oracle,
     # relative to the largest entry of each gradient tensor
+    from conftest import record_value
+    record_value("operator_by_operator_training_%s_F%d_%s" % (kind, F, radial), "primitives", "weight_gradient_worst_tensor", worst, 1e-4)
     assert worst < 1e-4, worst
 
 
