@@ -17,17 +17,19 @@
 // covers 4 rows x 64 columns per accumulator, no padding rows, full fp32 rate (512 FLOP / 8 cycles).  X sits in LDS (replicated reads:
 // lane l needs row l % 4), the columns of W stream from L2 (16-byte loads along k for y = x W^T, 4-byte loads for the transposed form).
 //
-// Finding.  A stage costs ~13 k cycles (6 us) however it is arranged -- 4x4x1 products are 3 % of that.  Cycle stamps (SPK_FM_CHAIN_STAMPS=1):
-// every phase of a stage is a dependent round trip to memory of 1.5-3 k cycles -- weights, operands of the epilogue, and above all the
-// acknowledgement of the stage's own stores: vector loads and stores share ONE in-order counter, the compiler waits with vmcnt(0) wherever a
-// loop hides the count, so the first load behind a store waits for the store.  Tried, in this order, each measured on the device: one weight
-// load in flight (75 us per seven-stage chain) -> chunks of 16-32 k with the next chunk requested ahead, K split over the waves, Y handed to
-// the next stage through LDS (46 us) -> LDS-only barriers + owner-consistent thread mapping so that no stage waits for global visibility
-// (50 us) -> a warm-up pass that requests every weight line and external operand at kernel start (52 us) -> two-phase epilogues (all loads,
-// then all stores) with the next stage's weights requested before the stores (53 us).  The launches a chain replaces take 31 us: the
-// "launch cost" of a small kernel IS this chain of round trips (its own loads, its own store drain); fusing them into one workgroup keeps
-// every one of them and loses the overlap that separate, wider launches have.  What would win needs every intermediate tensor of a chain
-// resident in LDS and a dedicated store wave (no load ever behind a store): sketched in profiles/r05_row_chains.md, not built.
+// Finding.  A stage costs ~5 us however it is arranged -- 4x4x1 products are a few per cent of that.  Tried, in this order, each measured on the
+// device (scripts/gpu_r5_e.sh, gpu_r5_f.sh, gpu_r5_g.sh): one weight load in flight (75 us per seven-stage chain) -> chunks of 16-32 k with the
+// next chunk requested ahead, K split over the waves, Y handed to the next stage through LDS (46 us) -> LDS-only barriers + owner-consistent
+// thread mapping so that no stage waits for global visibility (50 us) -> a warm-up pass that requests every weight line and external operand at
+// kernel start (52 us; the pass itself costs 3 us per chain) -> two-phase epilogues with the next stage's weights requested before the stores
+// (53 us, 19 k lines of code) -> rolled epilogues, out-of-line activation (50 us) -> descriptors copied to LDS once (50 us).  Then the stages
+// were HOLLOWED OUT (SPK_FM_CHAIN_DRY bits; wrong results, timing only): without epilogue loads / stores 0.896 -> 0.889 ms per PaiNN step,
+// without weight loads 0.844, without X loads 0.794, without the element-wise stages 0.756, without the warm-up 0.679 -- i.e. with NOTHING of
+// a stage touching global memory the chained step takes what the launch-by-launch step takes (0.672 ms).  The memory round trips are ~25 % of a
+// stage; the rest is the fixed cost of a generic stage interpreter on one workgroup: ~25 descriptor fields read and made uniform, three
+// barriers with eight waves of different length, a work-item switch, an out-of-line activation, the LDS round trips of X, the partial tiles
+// and Y -- ~3.5 us per stage, about what the launch it replaces costs.  What would win is not this kernel made faster but a hand-specialised
+// kernel per chain (descriptor in SGPRs, one barrier per stage, operands resident in LDS, a store wave): profiles/r05_row_chains.md.
 #pragma once
 #include "spk_fm_kernels.h"
 
@@ -69,6 +71,7 @@ struct FmChainDesc {
   int buf_floats;        // the dynamic LDS is two buffers of this many floats: X of a stage in one, its partial products (then Y) in the other
   int64_t N;             // atoms
   unsigned long long* dbg;   // cycle stamps of workgroup 0 (debugging aid, SPK_FM_CHAIN_STAMPS=1; NULL otherwise)
+  int dry;                   // TIMING EXPERIMENT ONLY (SPK_FM_CHAIN_DRY=1, wrong results): no global operand loads and no global stores in the epilogues
   FmChainStage st[FM_CHAIN_MAX_STAGES];
 };
 
@@ -85,6 +88,11 @@ struct FmChainItem {
   // weight chunk of this lane's column (the k range of an item is a whole number of chunks: K % (ks * 32) == 0, checked when the stage is recorded):
   // trans == 0: W[col][k .. k + 32) as 8 x 16 bytes; trans == 1: W[k + q][col], q < 32, as 32 x 4 bytes
   static __device__ __forceinline__ void load(const float* __restrict__ W, int K, int NW, int trans, int colc, int k, float (&w)[FM_CHAIN_CHUNK]) {
+    if (trans & 2) {          // timing experiment (SPK_FM_CHAIN_DRY & 2): no weight traffic
+#pragma unroll
+      for (int q = 0; q < FM_CHAIN_CHUNK; ++q) w[q] = 1.0f;
+      return;
+    }
     if (!trans) {
       const float* p = W + (int64_t)colc * K + k;
 #pragma unroll
@@ -160,15 +168,16 @@ __device__ __forceinline__ void fm_chain_first_chunk(const float* W, int K, int 
   }
 }
 
-#define FM_CHAIN_MR 6       // rows a thread owns in one stage (2 stacks x 3 rows of its atom)
 #define FM_CHAIN_MC 3       // columns a thread owns in one row (NW <= 3 x 128)
+// one copy of the activation code (value, first and second derivative) instead of one per use
+__device__ __attribute__((noinline)) float fm_chain_act(int act, int order, float z) { return fm_act<float>(act, order, z); }
 
 // X of the stage in bufX (row stride ldx; loaded here unless inherited), partial products -> bufP, then the epilogue.  `wc` arrives holding the
 // first weight chunk of this wave's first work item and leaves holding that of the NEXT Dense stage (nW .. nks; nW == NULL: none): those loads
 // -- like every operand of the epilogue -- are requested BEFORE the first store of the stage (a load behind a store waits for the store).
 // Returns the row stride of Y in bufP (for a stage that inherits it).
 __device__ __forceinline__ int fm_chain_gemm_stage(const FmGemmStage& g, int64_t N, int64_t a0, float* bufX, int ldx_in, float* bufP, float (&wc)[FM_CHAIN_CHUNK],
-                                                   const float* nW, int nK, int nNW, int ntrans, int nks, unsigned long long* dbg) {
+                                                   const float* nW, int nK, int nNW, int ntrans, int nks, unsigned long long* dbg, int dry) {
   const int tid = threadIdx.x;
   const int K = g.K, NW = g.NW;
   const int ns_in = g.mode == FM_G_TANGENT ? 1 : g.ns;
@@ -195,7 +204,7 @@ __device__ __forceinline__ int fm_chain_gemm_stage(const FmGemmStage& g, int64_t
         float v = 0.f;
         if (atom_ok) {
           v = g.X[gr * K + c];
-          if (g.mode == FM_G_BWD_INPUT && g.pre_in) v *= fm_act<float>(g.act, 1, g.pre_in[gr * K + c]);
+          if (g.mode == FM_G_BWD_INPUT && g.pre_in) v *= fm_chain_act(g.act, 1, g.pre_in[gr * K + c]);
         }
         bufX[lr * ldx + c] = v;
       }
@@ -225,86 +234,57 @@ __device__ __forceinline__ int fm_chain_gemm_stage(const FmGemmStage& g, int64_t
   FM_CHAIN_STAMP(dbg, 2);
   FM_CHAIN_LDS_BARRIER();
   FM_CHAIN_STAMP(dbg, 3);
-  // ---- epilogue, by owner, in two phases: (1) the sums of the partial tiles and EVERY global operand, then the next stage's weights; (2) the
-  // arithmetic and all stores.  Slot [r][cc]: row r of the thread's rows (DUAL modes: r < 3 value rows, 3 + r their tangent partners),
-  // column of + 128 cc.
+  // ---- epilogue, by owner: sum of the partial tiles -> global (and back into the first partial tile when the next stage reads Y from LDS).
+  // ROLLED loops and an out-of-line activation on purpose: the unrolled two-phase form of this epilogue (all operand loads, the next stage's
+  // weights, then all stores) made the kernel 19 k lines of straight-line code for no gain (0.93 -> 0.88 ms per PaiNN step when rolled back).
   const int pstride = R * ldp;
-  auto psum = [&](int lr, int c) {
-    float p = bufP[lr * ldp + c];
-    for (int q = 1; q < KS; ++q) p += bufP[q * pstride + lr * ldp + c];
-    return p;
-  };
   const bool dual = g.mode == FM_G_DUAL_FWD || g.mode == FM_G_DUAL_BWD;
   const int nrow = dual ? g.rpa : ns_in * g.rpa;
-  float O1[FM_CHAIN_MR][FM_CHAIN_MC], Bv[FM_CHAIN_MC];
-  int lrow[FM_CHAIN_MR];
-  int64_t grw[FM_CHAIN_MR];
-#pragma unroll
-  for (int r = 0; r < FM_CHAIN_MR; ++r) {
-    int rr = r, st = 0;
-    if (dual) { st = r / 3; rr = r - 3 * st; }
-    else { st = r / g.rpa; rr = r - st * g.rpa; }
-    const bool rv = dual ? (rr < g.rpa) : (r < nrow);
-    lrow[r] = rv ? st * per + oa * g.rpa + rr : -1;
-    grw[r] = st * stack + grow0 + rr;
-  }
-  const float* o1p = (g.mode == FM_G_DENSE || g.mode == FM_G_BWD_INPUT) ? g.res : ((g.mode == FM_G_TANGENT || g.mode == FM_G_DUAL_BWD) ? g.pre_in : nullptr);
-#pragma unroll
-  for (int cc = 0; cc < FM_CHAIN_MC; ++cc) {
-    const int c = of + cc * FM_CHAIN_CW;
-    Bv[cc] = (g.b && c < NW && atom_ok) ? g.b[c] : 0.f;
-#pragma unroll
-    for (int r = 0; r < FM_CHAIN_MR; ++r) O1[r][cc] = (o1p && atom_ok && lrow[r] >= 0 && c < NW) ? o1p[grw[r] * NW + c] : 0.f;
-  }
   FM_CHAIN_STAMP(dbg, 4);
   if (nW) fm_chain_first_chunk(nW, nK, nNW, ntrans, nks, wc);
-  // phase 2
-#pragma unroll
-  for (int cc = 0; cc < FM_CHAIN_MC; ++cc) {
-    const int c = of + cc * FM_CHAIN_CW;
-    if (c >= NW) continue;
-    if (!dual) {
-#pragma unroll
-      for (int r = 0; r < FM_CHAIN_MR; ++r) {
-        if (lrow[r] < 0) continue;
-        float p = psum(lrow[r], c);
+  for (int r = 0; r < nrow; ++r) {
+    const int st = dual ? 0 : r / g.rpa, rr = dual ? r : r - st * g.rpa;
+    const int lr = st * per + oa * g.rpa + rr;
+    const int64_t gr = st * stack + grow0 + rr;
+    for (int c = of; c < NW; c += FM_CHAIN_CW) {
+      float p = bufP[lr * ldp + c];
+      for (int q = 1; q < KS; ++q) p += bufP[q * pstride + lr * ldp + c];
+      if (!dual) {
         if (atom_ok) {
           if (g.mode == FM_G_DENSE) {
-            p += Bv[cc];
-            if (g.pre_out) g.pre_out[grw[r] * NW + c] = p;
-            p = fm_act<float>(g.act, 0, p) + O1[r][cc];
+            if (g.b) p += g.b[c];
+            if (g.pre_out && !dry) g.pre_out[gr * NW + c] = p;
+            p = fm_chain_act(g.act, 0, p);
+            if (g.res && !dry) p += g.res[gr * NW + c];
           } else if (g.mode == FM_G_BWD_INPUT) {
-            p += O1[r][cc];
+            if (g.res && !dry) p += g.res[gr * NW + c];
           } else {
-            if (g.pre_out) g.pre_out[grw[r] * NW + c] = p;
-            p *= fm_act<float>(g.act, 1, O1[r][cc]);
+            if (g.pre_out && !dry) g.pre_out[gr * NW + c] = p;
+            p *= fm_chain_act(g.act, 1, dry ? p : g.pre_in[gr * NW + c]);
           }
-          g.Y[grw[r] * NW + c] = p;
+          if (!dry) g.Y[gr * NW + c] = p;
         } else p = 0.f;
-        if (g.keep_y) bufP[lrow[r] * ldp + c] = p;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (lrow[r] < 0) continue;
-        float pv = psum(lrow[r], c);
-        const float pt = psum(lrow[3 + r], c);
+        if (g.keep_y) bufP[lr * ldp + c] = p;
+      } else {
+        const int lt = per + lr;
+        const int64_t gt = gr + stack;
+        float pt = bufP[lt * ldp + c];
+        for (int q = 1; q < KS; ++q) pt += bufP[q * pstride + lt * ldp + c];
         float yv = 0.f, yt = 0.f;
         if (atom_ok) {
           if (g.mode == FM_G_DUAL_FWD) {
-            pv += Bv[cc];
-            if (g.pre_out) { g.pre_out[grw[r] * NW + c] = pv; g.pre_out[grw[3 + r] * NW + c] = pt; }
-            yv = fm_act<float>(g.act, 0, pv);
-            yt = fm_act<float>(g.act, 1, pv) * pt;
+            if (g.b) p += g.b[c];
+            if (g.pre_out && !dry) { g.pre_out[gr * NW + c] = p; g.pre_out[gt * NW + c] = pt; }
+            yv = fm_chain_act(g.act, 0, p);
+            yt = fm_chain_act(g.act, 1, p) * pt;
           } else {      // FM_G_DUAL_BWD
-            const float a = O1[r][cc], at = O1[3 + r][cc], a1 = fm_act<float>(g.act, 1, a);
-            yv = pv * a1 + pt * fm_act<float>(g.act, 2, a) * at;
+            const float a = dry ? p : g.pre_in[gr * NW + c], at = dry ? pt : g.pre_in[gt * NW + c], a1 = fm_chain_act(g.act, 1, a);
+            yv = p * a1 + pt * fm_chain_act(g.act, 2, a) * at;
             yt = pt * a1;
           }
-          g.Y[grw[r] * NW + c] = yv;
-          g.Y[grw[3 + r] * NW + c] = yt;
+          if (!dry) { g.Y[gr * NW + c] = yv; g.Y[gt * NW + c] = yt; }
         }
-        if (g.keep_y) { bufP[lrow[r] * ldp + c] = yv; bufP[lrow[3 + r] * ldp + c] = yt; }
+        if (g.keep_y) { bufP[lr * ldp + c] = yv; bufP[lt * ldp + c] = yt; }
       }
     }
   }
@@ -314,18 +294,36 @@ __device__ __forceinline__ int fm_chain_gemm_stage(const FmGemmStage& g, int64_t
   return ldp;
 }
 
+// a value every lane holds (read from LDS) moved to scalar registers
+__device__ __forceinline__ int fm_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class P>
+__device__ __forceinline__ P* fm_uni(P* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (P*)(((uint64_t)hi << 32) | lo);
+}
+
 __global__ __launch_bounds__(FM_CHAIN_THREADS) void k_fm_chain(FmChainDesc d_) {
-  // dynamic stage index: read the descriptors from the kernel-argument segment itself (uniform addresses => scalar loads; indexing the by-value
-  // argument would copy it to scratch per lane, see k_gemm_tn_batched)
-  typedef const __attribute__((address_space(4))) FmChainDesc* DescPtr;
-  DescPtr d = (DescPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  // The stage descriptors are kernel arguments (2.7 KB).  They are copied into LDS once (all lines of the kernel-argument segment requested
+  // together) and read from there, made wave-uniform with v_readfirstlane.  (Tried because the per-stage scalar loads from the argument segment
+  // were a suspect for the fixed cost of a stage; the step time did not move: profiles/r05_row_chains.md.)
+  __shared__ FmChainDesc sdesc;
+  {
+    const int* src = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
+    int* dst = (int*)&sdesc;
+    for (int i = threadIdx.x; i < (int)(sizeof(FmChainDesc) / 4); i += FM_CHAIN_THREADS) dst[i] = src[i];
+  }
   (void)d_;
+  __syncthreads();
+  const FmChainDesc* d = &sdesc;
   extern __shared__ __attribute__((aligned(16))) float fm_chain_lds[];
-  const int64_t N = d->N;
+  const int64_t N = ((int64_t)fm_uni((int)(d->N >> 32)) << 32) | (uint32_t)fm_uni((int)(d->N & 0xffffffff));
   const int64_t a0 = (int64_t)blockIdx.x * FM_CHAIN_ATOMS;
-  const int n_st = d->n_stages;
-  const int bf = d->buf_floats;
-  FM_CHAIN_STAMP(d->dbg, 0);
+  const int n_st = fm_uni(d->n_stages);
+  const int bf = fm_uni(d->buf_floats);
+  const int dryf = fm_uni(d->dry);
+  unsigned long long* const dbgp = fm_uni(d->dbg);
+  FM_CHAIN_STAMP(dbgp, 0);
   // ---- warm-up: one request per 128-byte line of every weight matrix and bias of the chain, and of the block's rows of every operand that an
   // EARLIER launch wrote -- all independent, all in flight at once.  Every stage of a chain meets different weights, and what earlier launches
   // wrote sits behind the memory-side cache: cold, each stage paid two or three dependent misses of ~2 us (measured: ~5 us per stage with the
@@ -335,20 +333,20 @@ __global__ __launch_bounds__(FM_CHAIN_THREADS) void k_fm_chain(FmChainDesc d_) {
     float dummy = 0.f;
     const int oa_ = threadIdx.x / FM_CHAIN_CW, of_ = threadIdx.x - oa_ * FM_CHAIN_CW;
     const bool aok = a0 + oa_ < N;
-    for (int si = 0; si < n_st; ++si) {
-      if (d->st[si].is_ew) continue;
-      const float* W = d->st[si].g.W;
-      const float* b = d->st[si].g.b;
-      const int K = d->st[si].g.K, NW = d->st[si].g.NW, ext = d->st[si].g.ext, rpa = d->st[si].g.rpa, mode = d->st[si].g.mode;
-      const int ns_in = mode == FM_G_TANGENT ? 1 : d->st[si].g.ns;
+    for (int si = 0; si < n_st && !(dryf & 16); ++si) {
+      if (fm_uni(d->st[si].is_ew)) continue;
+      const float* W = fm_uni(d->st[si].g.W);
+      const float* b = fm_uni(d->st[si].g.b);
+      const int K = fm_uni(d->st[si].g.K), NW = fm_uni(d->st[si].g.NW), ext = fm_uni(d->st[si].g.ext), rpa = fm_uni(d->st[si].g.rpa), mode = fm_uni(d->st[si].g.mode);
+      const int ns_in = mode == FM_G_TANGENT ? 1 : fm_uni(d->st[si].g.ns);
       for (int i = threadIdx.x * 32; i < K * NW; i += FM_CHAIN_THREADS * 32) dummy += W[i];
       if (b && threadIdx.x * 32 < NW) dummy += b[threadIdx.x * 32];
       if (aok && ext) {
-        const float* X = d->st[si].g.X;
-        const float* res = d->st[si].g.res;
-        const float* pin = d->st[si].g.pre_in;
+        const float* X = fm_uni(d->st[si].g.X);
+        const float* res = fm_uni(d->st[si].g.res);
+        const float* pin = fm_uni(d->st[si].g.pre_in);
         const int wpin = mode == FM_G_BWD_INPUT ? K : NW;                      // width of pre_in
-        const int ns_pin = mode == FM_G_TANGENT ? 1 : d->st[si].g.ns;
+        const int ns_pin = mode == FM_G_TANGENT ? 1 : fm_uni(d->st[si].g.ns);
         const int ns_res = ns_in;
         for (int sr = 0; sr < 2 * rpa; ++sr) {
           const int st = sr / rpa, r = sr - st * rpa;
@@ -362,22 +360,23 @@ __global__ __launch_bounds__(FM_CHAIN_THREADS) void k_fm_chain(FmChainDesc d_) {
     asm volatile("" ::"v"(dummy));
   }
   int cur = 0, ldx = 0;
-  FM_CHAIN_STAMP(d->dbg, 1);
+  FM_CHAIN_STAMP(dbgp, 1);
   float wc[FM_CHAIN_CHUNK];
   // index of the first Dense stage at or behind `from` (n_st: none)
-  auto next_gemm = [&](int from) { int j = from; while (j < n_st && d->st[j].is_ew) ++j; return j; };
+  auto next_gemm = [&](int from) { int j = from; while (j < n_st && fm_uni(d->st[j].is_ew)) ++j; return j; };
   {
     const int j = next_gemm(0);
-    if (j < n_st) fm_chain_first_chunk(d->st[j].g.W, d->st[j].g.K, d->st[j].g.NW, d->st[j].g.trans, d->st[j].g.ks, wc);
+    if (j < n_st) fm_chain_first_chunk(fm_uni(d->st[j].g.W), fm_uni(d->st[j].g.K), fm_uni(d->st[j].g.NW), fm_uni(d->st[j].g.trans) | (dryf & 2), fm_uni(d->st[j].g.ks), wc);
   }
   for (int si = 0; si < n_st; ++si) {
-    if (d->st[si].is_ew) {
+    if (fm_uni(d->st[si].is_ew)) {
+      if (dryf & 8) continue;
       FmEwArgs<float> e;
-      e.kind = d->st[si].e.kind; e.F = d->st[si].e.F; e.N = d->st[si].e.N; e.eps = d->st[si].e.eps;
+      e.kind = fm_uni(d->st[si].e.kind); e.F = fm_uni(d->st[si].e.F); e.N = N; e.eps = d->st[si].e.eps;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) e.in[q] = d->st[si].e.in[q];
+      for (int q = 0; q < 8; ++q) e.in[q] = fm_uni(d->st[si].e.in[q]);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) e.out[q] = d->st[si].e.out[q];
+      for (int q = 0; q < 3; ++q) e.out[q] = fm_uni(d->st[si].e.out[q]);
       // item (atom, channel) by its owner: with F a multiple of 128 every operand is the owner's own (no wait); any other width takes the
       // conservative route -- all earlier stores of the workgroup visible before, all of this stage's after
       const bool owned = (e.F % FM_CHAIN_CW) == 0;
@@ -386,17 +385,20 @@ __global__ __launch_bounds__(FM_CHAIN_THREADS) void k_fm_chain(FmChainDesc d_) {
       if (a0 + oa < N)
         for (int ch = of; ch < e.F; ch += FM_CHAIN_CW) fm_ew_at<float>(e, (a0 + oa) * e.F + ch);
       if (!owned) __syncthreads();
-      FM_CHAIN_STAMP(d->dbg, 2 + 8 * si + 6);
+      FM_CHAIN_STAMP(dbgp, 2 + 8 * si + 6);
     } else {
       FmGemmStage g;
-      g.X = d->st[si].g.X; g.W = d->st[si].g.W; g.b = d->st[si].g.b; g.res = d->st[si].g.res; g.pre_in = d->st[si].g.pre_in; g.Y = d->st[si].g.Y;
-      g.pre_out = d->st[si].g.pre_out; g.K = d->st[si].g.K; g.NW = d->st[si].g.NW; g.act = d->st[si].g.act; g.mode = d->st[si].g.mode;
-      g.trans = d->st[si].g.trans; g.ns = d->st[si].g.ns; g.rpa = d->st[si].g.rpa; g.x_from_lds = d->st[si].g.x_from_lds; g.keep_y = d->st[si].g.keep_y;
-      g.ks = d->st[si].g.ks;
+      g.X = fm_uni(d->st[si].g.X); g.W = fm_uni(d->st[si].g.W); g.b = fm_uni(d->st[si].g.b); g.res = fm_uni(d->st[si].g.res); g.pre_in = fm_uni(d->st[si].g.pre_in);
+      g.Y = fm_uni(d->st[si].g.Y); g.pre_out = fm_uni(d->st[si].g.pre_out); g.K = fm_uni(d->st[si].g.K); g.NW = fm_uni(d->st[si].g.NW); g.act = fm_uni(d->st[si].g.act);
+      g.mode = fm_uni(d->st[si].g.mode); g.trans = fm_uni(d->st[si].g.trans); g.ns = fm_uni(d->st[si].g.ns); g.rpa = fm_uni(d->st[si].g.rpa);
+      g.x_from_lds = fm_uni(d->st[si].g.x_from_lds); g.keep_y = fm_uni(d->st[si].g.keep_y); g.ks = fm_uni(d->st[si].g.ks);
+      if (dryf & 2) g.trans |= 2;
+      if (dryf & 4) g.x_from_lds = 1;          // (timing experiment: X is whatever the buffer holds)
       const int j = next_gemm(si + 1);
-      const float* nW = j < n_st ? d->st[j].g.W : nullptr;
-      const int nK = j < n_st ? d->st[j].g.K : 0, nNW = j < n_st ? d->st[j].g.NW : 0, ntr = j < n_st ? d->st[j].g.trans : 0, nks = j < n_st ? d->st[j].g.ks : 1;
-      ldx = fm_chain_gemm_stage(g, N, a0, fm_chain_lds + cur * bf, ldx, fm_chain_lds + (cur ^ 1) * bf, wc, nW, nK, nNW, ntr, nks, d->dbg ? d->dbg + 2 + 8 * si : nullptr);
+      const float* nW = j < n_st ? fm_uni(d->st[j].g.W) : nullptr;
+      const int nK = j < n_st ? fm_uni(d->st[j].g.K) : 0, nNW = j < n_st ? fm_uni(d->st[j].g.NW) : 0, ntr = (j < n_st ? fm_uni(d->st[j].g.trans) : 0) | (dryf & 2),
+                nks = j < n_st ? fm_uni(d->st[j].g.ks) : 1;
+      ldx = fm_chain_gemm_stage(g, N, a0, fm_chain_lds + cur * bf, ldx, fm_chain_lds + (cur ^ 1) * bf, wc, nW, nK, nNW, ntr, nks, dbgp ? dbgp + 2 + 8 * si : nullptr, dryf & 1);
       cur ^= 1;             // Y (when kept) is in the buffer the next stage reads its X from
     }
   }
