@@ -808,8 +808,8 @@ int spk_painn_fm_backward_f32(const spk_painn_t* m, const spk_head_t* head, cons
                               const float* gE, const float* gF, float* grads, void* stream);
 /* EXPERIMENT (round 5, default off): row chains of the force-matching engine (csrc/spk_fm_chain.h) -- consecutive atom-local launches of a
  * pass recorded as stages of ONE launch (one workgroup per four atoms, fp32 products on v_mfma_f32_4x4x1).  Same results, 137 -> 62
- * launches per PaiNN step -- and slower (0.69 -> 0.93 ms at 8 frames): what a small launch costs is the chain of dependent memory round trips
- * inside it, not the launch (profiles/r05_row_chains.md).  mode 1: record chains; 0 or -1: launch by launch (default).  SPK_FM_CHAIN gives
+ * launches per PaiNN step -- and slower (0.67 -> 0.89 ms at 8 frames): a stage of the generic chain kernel has about the fixed cost of the launch
+ * it replaces (profiles/r05_row_chains.md).  mode 1: record chains; 0 or -1: launch by launch (default).  SPK_FM_CHAIN gives
  * the initial value. */
 void spk_fm_set_chain(int32_t mode);
 
