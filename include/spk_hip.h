@@ -813,6 +813,18 @@ int spk_painn_fm_backward_f32(const spk_painn_t* m, const spk_head_t* head, cons
  * the initial value. */
 void spk_fm_set_chain(int32_t mode);
 
+/* Up to SPK_INDEX_JOBS_MAX index jobs in ONE launch: job k derives the CSR row pointers rowptr [rows + 1] of the ascending index idx [n] with
+ * entries in [0, rows) (err[0] |= 1 if not ascending, |= 2 if out of range -- like spk_segment_rowptr_i32), or, with rowptr == NULL, only checks
+ * that every entry lies in [0, rows) (like spk_index_range_check).  err may be NULL when no job is a pure range check.  Device only. */
+#define SPK_INDEX_JOBS_MAX 8
+typedef struct {
+  const int64_t* idx;
+  int64_t n;
+  int64_t rows;
+  int32_t* rowptr;
+} spk_index_job_t;
+int spk_index_jobs(const spk_index_job_t* jobs, int32_t n_jobs, int32_t* err, void* stream);
+
 /* By-neighbour CSR of a pair list on the device (the transpose permutation of SURVEY.md section 7 step 4): perm [E] = the pairs
  * ordered by idx_j (stable: ascending pair index inside a column), colptr [N + 2] (column N collects out-of-range neighbours).
  * tmp: spk_transpose_plan_bytes(E, N) bytes.  No host synchronisation. */

@@ -197,6 +197,7 @@ _PROTOS = {
     "spk_painn_set_block": (None, [c_i32]),
     "spk_transpose_plan_bytes": (c_i64, [c_i64, c_i64]),
     "spk_fm_set_chain": (None, [ctypes.c_int32]),
+    "spk_index_jobs": (ctypes.c_int, [c_f, ctypes.c_int32, c_f, c_f]),
     "spk_transposed_build": (ctypes.c_int, [c_f, c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_f]),
     "spk_blocks_group_atoms": (ctypes.c_int, []),
     "spk_painn_blk_set_debug_buffer": (None, [c_f, c_i32]),

@@ -420,6 +420,11 @@ struct FmDeviceBackend {
   size_t transpose_tmp_bytes(int64_t E, int64_t N) { return (size_t)spk_transpose_plan_bytes(E, N); }
   int zero_u32(uint32_t* p, int64_t n) { pre_launch(); return spk_zero_async(p, (size_t)n * 4, stream); }
   int rowptr(const int64_t* idx, int64_t n, int64_t rows, int32_t* out, int32_t* err) { pre_launch(); return spk_segment_rowptr_i32(idx, n, rows, out, err, stream); }
+  int rowptr2(const int64_t* ia, int64_t na, int64_t ra, int32_t* oa, const int64_t* ib, int64_t nb, int64_t rb, int32_t* ob, int32_t* err) {
+    pre_launch();
+    const spk_index_job_t jobs[2] = {{ia, na, ra, oa}, {ib, nb, rb, ob}};
+    return spk_index_jobs(jobs, 2, err, stream);
+  }
   int transpose_plan(const int64_t* jj, int64_t E, int64_t N, int32_t* colptr, int32_t* perm, void* tmp) { pre_launch(); return spk_transpose_plan(jj, E, N, colptr, perm, tmp, stream); }
   int dense(const float* x, const float* w, const float* b, const float* res, float* y, float* pre, int64_t m, int k, int n_out, int act) {
     if (chain_gemm(FM_G_DENSE, x, w, b, res, nullptr, y, pre, m, k, n_out, act, 0, 0)) return SPK_OK;

@@ -121,8 +121,7 @@ struct FmEngine {
   int prepare(const FmBatch<T>& b, const FmRadial<T>& rb, FmCommonWs<T>& w, int32_t* err) {
     int rc;
     if ((rc = be.zero_u32(w.tickets, w.zero_words))) return rc;
-    if ((rc = be.rowptr(b.ii, b.E, b.N, w.rowptr, err))) return rc;
-    if ((rc = be.rowptr(b.idx_m, b.N, b.M, w.rowptr_m, err))) return rc;
+    if ((rc = be.rowptr2(b.ii, b.E, b.N, w.rowptr, b.idx_m, b.N, b.M, w.rowptr_m, err))) return rc;      // (one launch on the device)
     if ((rc = be.transpose_plan(b.jj, b.E, b.N, w.colptr, w.perm, w.plan_tmp))) return rc;
     be.flat("fm_colsrc", k_fm_colsrc<T>, b.E, w.perm, b.ii, b.E, b.N, w.csrc, (T*)nullptr);
     be.flat("fm_geom", k_fm_geom<T>, b.E * rb.n_rbf, b.R, b.off, b.ii, b.jj, b.E, b.N, rb, w.d, w.u, w.fc, w.fc1, w.phi2, w.e_act);

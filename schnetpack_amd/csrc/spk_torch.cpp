@@ -1584,16 +1584,23 @@ void static_refresh_op(int64_t owner) {
   auto it = g_static_err.find(owner);
   if (it == g_static_err.end()) return;
   int32_t* err = it->second.data_ptr<int32_t>();
+  // every declared index of the owner in ONE launch (spk_index_jobs): row pointers + checks of the ascending ones, range checks of the others
+  std::vector<spk_index_job_t> jobs;
+  Tensor any;
   for (auto& e : g_static) {
     if (e.owner != owner) continue;
-    c10::DeviceGuard guard(e.idx.device());
-    check(spk_segment_rowptr_i32(e.idx.data_ptr<int64_t>(), e.idx.size(0), e.n_rows, e.rowptr.data_ptr<int32_t>(), err, stream_of(e.idx)));
+    jobs.push_back({e.idx.data_ptr<int64_t>(), e.idx.size(0), e.n_rows, e.rowptr.data_ptr<int32_t>()});
+    any = e.idx;
   }
   for (auto& e : g_static_ranges) {
-    if (e.owner != owner) continue;
-    c10::DeviceGuard guard(e.idx.device());
-    check(spk_index_range_check(e.idx.data_ptr<int64_t>(), e.idx.numel(), e.hi, err, stream_of(e.idx)));
+    if (e.owner != owner || e.idx.numel() == 0) continue;
+    jobs.push_back({e.idx.data_ptr<int64_t>(), e.idx.numel(), e.hi, nullptr});
+    any = e.idx;
   }
+  if (jobs.empty()) return;
+  c10::DeviceGuard guard(any.device());
+  for (size_t k = 0; k < jobs.size(); k += SPK_INDEX_JOBS_MAX)
+    check(spk_index_jobs(jobs.data() + k, (int32_t)std::min<size_t>(SPK_INDEX_JOBS_MAX, jobs.size() - k), err, stream_of(any)));
 }
 bool static_enable_op(bool on) {      // returns the PREVIOUS state (so that a scope can restore it)
   const bool prev = g_static_on;

@@ -31,6 +31,10 @@ struct EmuBackend {
     for (int64_t k = 1; k < n; ++k) if (idx[k - 1] > idx[k] && err) *err |= 1;
     return 0;
   }
+  int rowptr2(const int64_t* ia, int64_t na, int64_t ra, int32_t* oa, const int64_t* ib, int64_t nb, int64_t rb, int32_t* ob, int32_t* err) {
+    const int rc = rowptr(ia, na, ra, oa, err);
+    return rc ? rc : rowptr(ib, nb, rb, ob, err);
+  }
   int transpose_plan(const int64_t* jj, int64_t E, int64_t N, int32_t* colptr, int32_t* perm, void*) {
     std::vector<int32_t> ids((size_t)E);
     std::iota(ids.begin(), ids.end(), 0);
