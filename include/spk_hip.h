@@ -146,6 +146,13 @@ const char* spk_last_error(void);
 int spk_device_info(int32_t* host_info);
 void spk_set_variant(int variant);
 int spk_get_variant(void);
+/* Split-precision matrix path (csrc/spk_split.h): the filter-network / filter products of the fused kernels as three
+ * v_mfma_f32_32x32x16_f16 products of (high, low) fp16 operand pairs with fp32 accumulation -- fp32-quality results at 3/16 of the
+ * time of v_mfma_f32_32x32x2_f32.  1 (default; environment SPK_SPLIT=0 starts with 0) or 0 = the fp32 matrix instruction everywhere
+ * (the A/B partner of profiles/r06_split_mfma.md; also the path for operands beyond the fp16 range, |x| >= 65504).  Replaces no
+ * reference interface: the reference computes these products with F.linear (nn/base.py:52-55). */
+void spk_set_split(int on);
+int spk_get_split(void);
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py;
  * off by default).  spk_profile_report() synchronises the device and returns lines
  * "<kernel-tag> <launch count> <total ms>". */

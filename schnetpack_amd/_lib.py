@@ -106,6 +106,8 @@ _PROTOS = {
     "spk_device_info": (ctypes.c_int, [P(c_i32)]),
     "spk_set_variant": (None, [ctypes.c_int]),
     "spk_get_variant": (ctypes.c_int, []),
+    "spk_set_split": (None, [ctypes.c_int]),
+    "spk_get_split": (ctypes.c_int, []),
     "spk_profile_enable": (None, [ctypes.c_int]),
     "spk_profile_report": (ctypes.c_char_p, []),
     "spk_edge_plan": (ctypes.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, c_f, P(c_i32), c_f]),
@@ -303,6 +305,15 @@ def set_variant(v):
 
 def get_variant():
     return int(lib().spk_get_variant())
+
+
+def set_split(on):
+    """Split-precision matrix path (csrc/spk_split.h) on / off; off = v_mfma_f32_32x32x2_f32 everywhere."""
+    lib().spk_set_split(1 if on else 0)
+
+
+def get_split():
+    return int(lib().spk_get_split())
 
 
 def device_info():

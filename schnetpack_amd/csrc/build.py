@@ -14,7 +14,7 @@ SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "
 HEADERS = ["spk_common.h", "spk_painn_msg.h", "spk_painn_mol.h", "spk_painn_blk.h", "spk_pack.h", "spk_gemm_tn.h", "spk_fm_engine.h", "spk_fm_kernels.h", os.path.join("..", "..", "include", "spk_hip.h")]
 LIB = os.path.join(HERE, "libspk_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-         "-mcode-object-version=5", "-Wall", "-Wno-unused-function"]
+         "-mcode-object-version=5", "-Wall", "-Wno-unused-function"] + os.environ.get("SPK_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

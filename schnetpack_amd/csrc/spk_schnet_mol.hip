@@ -20,6 +20,7 @@
 // fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout: 1e-5 parity with the reference rules out bf16.
 #include "spk_common.h"
 #include "spk_pack.h"
+#include "spk_split.h"
 
 #define ML_MAXL 6
 #define ML_LD 132          // row stride (floats) of the [32][128] activation tiles in LDS: conflict-free 16-byte accesses
@@ -198,6 +199,94 @@ __device__ __forceinline__ void ml_stage_packed(float* dst, const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------ split-precision images (spk_split.h)
+// Filter-network weights as (high, low) fp16 operand images in LDS, made from the raw fp32 tensors while they are staged.
+// W2 [NF][NF]: slot (channel tile t, k-step s, lane) = eight values W2[32 t + el][32 (s >> 1) + sp_acc_k(s & 1, hi, e)] -- the contraction
+// index in ACCUMULATOR order, so that the hidden activations go from the accumulator registers of GEMM 1 into GEMM 2 as they lie
+// (backward) or are written to LDS as two 16-byte pieces per image (forward).  The same image is the B operand of the forward
+// (columns = channels) and the A operand of the backward (rows = channels).
+template <int NTHREADS>
+__device__ __forceinline__ void ml_stage_w2_split(h16x8* __restrict__ dh, h16x8* __restrict__ dl, const float* __restrict__ w2, int tid) {
+  constexpr int PER = 2048 / NTHREADS;
+#pragma unroll 1
+  for (int p0 = 0; p0 < PER; p0 += 4) {
+    f32x4 va[4], vb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int sl = tid + (p0 + p) * NTHREADS;
+      const int lane = sl & 63, s = (sl >> 6) & 7, t = sl >> 9;
+      const float* src = w2 + (32 * t + (lane & 31)) * 128 + 32 * (s >> 1) + 16 * (s & 1) + 4 * (lane >> 5);
+      va[p] = *(const f32x4*)src;
+      vb[p] = *(const f32x4*)(src + 8);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int sl = tid + (p0 + p) * NTHREADS;
+      h16x4 ah, al, bh, bl;
+      sp_split4(va[p], ah, al);
+      sp_split4(vb[p], bh, bl);
+      dh[sl] = sp_cat(ah, bh);
+      dl[sl] = sp_cat(al, bl);
+    }
+  }
+}
+// W1 [NF][n_rbf]: slot (hidden tile t, lane): k-step 0 = basis functions 8 hi + e; k-step 1 (n_rbf > 16) = 16 + 4 hi + e for e < 4 and,
+// for n_rbf > 24 only, 24 + 4 hi + (e - 4) for e >= 4 -- the live functions of a 20-wide basis are spread evenly over the two lane
+// halves (12 evaluations per lane).  Image = [256 slots] h16x8 (k-step 0), then [256 slots] h16x4 (KPB = 3) or h16x8 (KPB = 4).
+template <int KPB>
+struct MlW1Image {
+  static constexpr int BYTES = 4096 + (KPB > 2 ? (KPB == 4 ? 4096 : 2048) : 0);     // per image (high or low)
+};
+__device__ __forceinline__ int ml_w1_k(int s, int hi, int e) { return s == 0 ? 8 * hi + e : (e < 4 ? 16 + 4 * hi + e : 20 + 4 * hi + e); }
+template <int KPB>
+__device__ __forceinline__ void ml_stage_w1_split(char* __restrict__ ih, char* __restrict__ il, const float* __restrict__ w1, int n_rbf, int slot) {
+  if (slot >= 256) return;
+  const int lane = slot & 63, t = slot >> 6, hi = lane >> 5;
+  const float* src = w1 + (32 * t + (lane & 31)) * n_rbf;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const int k = ml_w1_k(0, hi, e); x[e] = k < n_rbf ? src[k] : 0.f; }
+  h16x8 h, l;
+  sp_split8(x, h, l);
+  ((h16x8*)ih)[slot] = h; ((h16x8*)il)[slot] = l;
+  if (KPB > 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int k = ml_w1_k(1, hi, e); x[e] = (k < n_rbf && (KPB == 4 || e < 4)) ? src[k] : 0.f; }
+    sp_split8(x, h, l);
+    if (KPB == 4) { ((h16x8*)(ih + 4096))[slot] = h; ((h16x8*)(il + 4096))[slot] = l; }
+    else {
+      ((h16x4*)(ih + 4096))[slot] = h16x4{h[0], h[1], h[2], h[3]};
+      ((h16x4*)(il + 4096))[slot] = h16x4{l[0], l[1], l[2], l[3]};
+    }
+  }
+}
+template <int KPB>
+__device__ __forceinline__ void ml_w1_operand(const char* __restrict__ ih, const char* __restrict__ il, int s, int slot, h16x8& h, h16x8& l) {
+  if (s == 0) { h = ((const h16x8*)ih)[slot]; l = ((const h16x8*)il)[slot]; }
+  else if (KPB == 4) { h = ((const h16x8*)(ih + 4096))[slot]; l = ((const h16x8*)(il + 4096))[slot]; }
+  else {
+    const h16x4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    h = sp_cat(((const h16x4*)(ih + 4096))[slot], z);
+    l = sp_cat(((const h16x4*)(il + 4096))[slot], z);
+  }
+}
+// the radial basis of one pair (and its d-derivative) as split B operands: this lane's slots of the k-steps, ml_w1_k() order
+template <int KPB, bool DERIV>
+__device__ __forceinline__ void ml_basis_split(int kind, int n_rbf, const float* __restrict__ p0, const float* __restrict__ p1, int hi, float d,
+                                               h16x8 (&ph)[2], h16x8 (&pl)[2], h16x8 (&dh)[2], h16x8 (&dl)[2]) {
+#pragma unroll
+  for (int s = 0; s < (KPB > 2 ? 2 : 1); ++s) {
+    float v[8], dv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = 0.f; dv[e] = 0.f;
+      if (s == 0 || KPB == 4 || e < 4) ml_rbf(kind, n_rbf, p0, p1, ml_w1_k(s, hi, e), d, v[e], dv[e]);
+    }
+    sp_split8(v, ph[s], pl[s]);
+    if (DERIV) sp_split8(dv, dh[s], dl[s]);
+  }
+}
+
 // One 32-column output tile of a Dense layer over the 32 atom rows of the group, T-GEMM convention of spk_dense.hip:
 // A = packed weights straight from L2 (16 k-blocks of 8, all requested up front), B = activations [32][ML_LD] in LDS;
 // accumulator rows = output features 32 t + ml_row(r, hi), columns = atoms (lane & 31).
@@ -341,13 +430,18 @@ __device__ __forceinline__ f32x16 ml_dense_mma8_sum(const f32x4 (&av)[8], const 
 // ON THE MATRIX CORE: A = the 0/1 incidence of the pair tile (rows = atoms), B = the modulated products (rows = pairs,
 // columns = channels), 32 MFMAs per tile and wave, accumulator = 16 registers that live across all tiles of the wave.
 // No atomics, no re-read of the filters, no scatter pass; team 1 runs in2f while team 0 starts the first tile.
-template <int KPB>
+template <int KPB, bool SP>
 __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
   constexpr int NF = 128, KB2 = 16;
+  constexpr int W1F = SP ? 2 * MlW1Image<KPB>::BYTES / 4 : NF * KPB * 8;     // floats of the W1 image(s)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sW2 = smem;                                  // NF*NF
-  float* sW1 = sW2 + NF * NF;                         // NF*KPB*8
-  float* sb1 = sW1 + NF * KPB * 8;                    // NF
+  float* sW2 = smem;                                  // NF*NF  (SP: high image | low image, 32 KB each)
+  float* sW1 = sW2 + NF * NF;                         // NF*KPB*8  (SP: high image | low image)
+  float* sb1 = sW1 + W1F;                             // NF
+  h16x8* const sW2h = (h16x8*)sW2;
+  h16x8* const sW2l = sW2h + 2048;
+  char* const sW1h = (char*)sW1;
+  char* const sW1l = sW1h + MlW1Image<KPB>::BYTES;
   float* sb2 = sb1 + NF;                              // NF
   float* sX = sb2 + NF;                               // [32][ML_LD] atom features x_l
   float* sH = sX + 32 * ML_LD;                        // h = in2f(x); later the hidden layer of f2out
@@ -390,7 +484,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
     const int ntile = (np + 31) / 32;
     // (W2 of the first interaction -- first read by GEMM 2 of the first tile -- is staged by team 0 behind its first hidden tile,
     // while team 1 is still busy with in2f)
-    ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[0].w1, a.rb.n_rbf, KPB, tid);
+    if constexpr (SP) ml_stage_w1_split<KPB>(sW1h, sW1l, a.L[0].w1, a.rb.n_rbf, tid);
+    else ml_stage_packed<512, NF * KPB * 2>(sW1, a.L[0].w1, a.rb.n_rbf, KPB, tid);
     if (tid < NF) { sb1[tid] = a.L[0].b1[tid]; sb2[tid] = a.L[0].b2[tid]; }
 
     for (int l = 0; l < a.n_layers; ++l) {
@@ -432,6 +527,35 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           f32x16 zc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) zc[r] = sb1[32 * t + ml_row(r, hi)];
+          if constexpr (SP) {
+            // split form: A = the (high, low) images of W1, B = this pair's basis values in the lane's k-slots; three f16 matrix
+            // instructions per k-step, the cross terms in their own accumulator
+            h16x8 ph[2], pl[2], dh_[2], dl_[2];
+            ml_basis_split<KPB, false>(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, hi, d, ph, pl, dh_, dl_);
+            f32x16 zx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zx[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < (KPB > 2 ? 2 : 1); ++s) {
+              h16x8 wh, wl;
+              ml_w1_operand<KPB>(sW1h, sW1l, s, t * 64 + lane, wh, wl);
+              SP_STEP(wh, wl, ph[s], pl[s], zc, zx);
+            }
+            SP_FOLD(zc, zx);
+            // the hidden tile in LDS as the split A operand of GEMM 2: row = pair, [high: 128 halves | low: 128 halves], contraction
+            // index in accumulator order -- the lane's registers 8 s' .. 8 s' + 7 are slot (2 t + s', hi) as they lie
+            char* zr = (char*)zbuf + el * (ML_LD * 4) + 16 * hi;
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = spk_fast_ssp(zc[8 * sp + e]);
+              h16x8 h, l2;
+              sp_split8(v, h, l2);
+              *(h16x8*)(zr + 32 * (2 * t + sp)) = h;
+              *(h16x8*)(zr + 256 + 32 * (2 * t + sp)) = l2;
+            }
+          } else {
 #pragma unroll
           for (int u = 0; u < KPB; ++u) {
             const f32x4 wq = *(const f32x4*)(sW1 + ((t * KPB + u) * 64 + lane) * 4);
@@ -450,8 +574,12 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           for (int q = 0; q < 4; ++q)
             *(f32x4*)(zbuf + el * ML_LD + 32 * t + 8 * q + 4 * hi) =
                 f32x4{spk_fast_ssp(zc[4 * q]), spk_fast_ssp(zc[4 * q + 1]), spk_fast_ssp(zc[4 * q + 2]), spk_fast_ssp(zc[4 * q + 3])};
+          }
         }
-        if (l == 0 && it == 0 && team == 0) ml_stage_packed<256, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
+        if (l == 0 && it == 0 && team == 0) {
+          if constexpr (SP) ml_stage_w2_split<256>(sW2h, sW2l, a.L[0].w2, tid);
+          else ml_stage_packed<256, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
+        }
         __syncthreads();     // the team's hidden tile (and, in the first round, h) is complete
         if (active) {
           // ---- GEMM 2, operands swapped (rows = pairs, columns = channels 32 t + el): g = W2 z + b2, A operand from LDS
@@ -460,7 +588,32 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           const float bias2 = sb2[c0];
 #pragma unroll
           for (int r = 0; r < 16; ++r) g[r] = bias2;
-          {
+          if constexpr (SP) {
+            // A = hidden tile (rows = pairs) from LDS, B = W2 image (columns = channels): both split, requested two k-steps ahead
+            f32x16 gx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+            const h16x8* wbh = sW2h + (t * 8) * 64 + lane;
+            const h16x8* wbl = sW2l + (t * 8) * 64 + lane;
+            const char* zr = (const char*)zbuf + el * (ML_LD * 4) + 16 * hi;
+            h16x8 zh[8], zl[8], wh[8], wl[8];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              zh[s] = *(const h16x8*)(zr + 32 * s); zl[s] = *(const h16x8*)(zr + 256 + 32 * s);
+              wh[s] = wbh[s * 64]; wl[s] = wbl[s * 64];
+            }
+            ML_PIN();
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+              if (s + 2 < 8) {
+                zh[s + 2] = *(const h16x8*)(zr + 32 * (s + 2)); zl[s + 2] = *(const h16x8*)(zr + 256 + 32 * (s + 2));
+                wh[s + 2] = wbh[(s + 2) * 64]; wl[s + 2] = wbl[(s + 2) * 64];
+                ML_PIN();
+              }
+              SP_STEP(zh[s], zl[s], wh[s], wl[s], g, gx);
+            }
+            SP_FOLD(g, gx);
+          } else {
             const float* wbase = sW2 + ((int64_t)t * KB2 * 64 + lane) * 4;
             const float* zrow = zbuf + el * ML_LD + 4 * hi;
             // both operands come from LDS: requested THREE k-blocks ahead and pinned there (the one-ahead form written here
@@ -482,6 +635,36 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           // raw filter outputs for the backward (row = position of the pair in the list, 128-byte row segments per half wave)
           // ---- and modulation + accumulation on the matrix core: y[atom][c0] += [i = atom] W h[j][c0] + [j = atom] W h[i][c0]
           float* gt = g_g + 32 * t;
+          if constexpr (SP) {
+            // incidence product on the f16 matrix instruction: A (0 / 1, exact) carries the weight 2^-11 of the low parts itself, so
+            // the accumulator that lives across the tiles stays ONE
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              float tI[8], tJ[8];
+              h16x8 ai, aj;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int r = 8 * s2 + e;
+                const int pr = ml_row(r, hi);
+                const bool ok = pr < nvalid;
+                const MolPair rec = sP[pfirst + (ok ? pr : 0)];
+                const int pi = rec.ij & 255, pj = (rec.ij >> 8) & 255;
+                if (ok) ml_st<float>(gt, (unsigned)(((rec.ij >> 16) * NF + el) * 4), g[r]);
+                const float W = ok ? g[r] * rec.fc : 0.f;
+                tI[e] = W * sH[pj * ML_LD + c0]; tJ[e] = W * sH[pi * ML_LD + c0];
+                ai[e] = pi == el ? (_Float16)1.0f : (_Float16)0.0f;
+                aj[e] = pj == el ? (_Float16)1.0f : (_Float16)0.0f;
+              }
+              h16x8 ih, il, jh, jl;
+              sp_split8(tI, ih, il);
+              sp_split8(tJ, jh, jl);
+              const h16x8 ais = ai * (_Float16)SP_DOWN, ajs = aj * (_Float16)SP_DOWN;
+              yacc = SP_MFMA(ai, ih, yacc);
+              yacc = SP_MFMA(ais, il, yacc);
+              yacc = SP_MFMA(aj, jh, yacc);
+              yacc = SP_MFMA(ajs, jl, yacc);
+            }
+          } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int pr = ml_row(r, hi);
@@ -493,6 +676,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
             const float tI = W * sH[pj * ML_LD + c0], tJ = W * sH[pi * ML_LD + c0];
             yacc = ML_MFMA(pi == el ? 1.0f : 0.0f, tI, yacc);
             yacc = ML_MFMA(pj == el ? 1.0f : 0.0f, tJ, yacc);
+          }
           }
         }
         __syncthreads();     // every wave of the team is done with the hidden tile
@@ -525,8 +709,13 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
         }
       } else if (l + 1 < a.n_layers) {     // the filter GEMMs of this interaction are done: their LDS images can be replaced
         const int t2 = tid - 256;
-        ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l + 1].w2, NF, KB2, t2);
-        ml_stage_packed<256, NF * KPB * 2>(sW1, a.L[l + 1].w1, a.rb.n_rbf, KPB, t2);
+        if constexpr (SP) {
+          ml_stage_w2_split<256>(sW2h, sW2l, a.L[l + 1].w2, t2);
+          ml_stage_w1_split<KPB>(sW1h, sW1l, a.L[l + 1].w1, a.rb.n_rbf, t2);
+        } else {
+          ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l + 1].w2, NF, KB2, t2);
+          ml_stage_packed<256, NF * KPB * 2>(sW1, a.L[l + 1].w1, a.rb.n_rbf, KPB, t2);
+        }
         if (t2 < NF) { sb1[t2] = a.L[l + 1].b1[t2]; sb2[t2] = a.L[l + 1].b2[t2]; }
       }
       __syncthreads();
@@ -623,8 +812,11 @@ static long long* g_mol_dbg = nullptr;
 // of the backward launch, so the buffer must hold 128 + 4 * (number of groups) entries.  NULL: off (production)
 extern "C" void spk_schnet_mol_set_debug_buffer(void* p) { g_mol_dbg = (long long*)p; }
 
-static size_t mol_fwd_lds(int kpb) {
-  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64 + 8) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair);
+static size_t mol_w1_floats(int kpb, bool sp) {      // LDS floats of the staged W1 image(s): MlW1Image<KPB>::BYTES twice in the split form
+  return sp ? (size_t)2 * (4096 + (kpb > 2 ? (kpb == 4 ? 4096 : 2048) : 0)) / 4 : (size_t)128 * kpb * 8;
+}
+static size_t mol_fwd_lds(int kpb, bool sp) {
+  return (size_t)(128 * 128 + mol_w1_floats(kpb, sp) + 2 * 128 + 4 * 32 * ML_LD + 64 + 8) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair);
 }
 
 // Shapes / lists the molecule-resident kernels cover (everything else runs the general driver of spk_schnet.hip).
@@ -643,10 +835,16 @@ bool spk_schnet_mol_eligible(const spk_schnet_t* m, const spk_graph_t* g, const 
   return true;
 }
 
+template <int KPB, bool SP>
+static int launch_mol_fwd_sp(const MolFwdArgs& a, hipStream_t stream);
 template <int KPB>
 static int launch_mol_fwd(const MolFwdArgs& a, hipStream_t stream) {
-  const size_t lds = mol_fwd_lds(KPB);
-  auto kern = k_schnet_mol_fwd<KPB>;
+  return spk_get_split() ? launch_mol_fwd_sp<KPB, true>(a, stream) : launch_mol_fwd_sp<KPB, false>(a, stream);
+}
+template <int KPB, bool SP>
+static int launch_mol_fwd_sp(const MolFwdArgs& a, hipStream_t stream) {
+  const size_t lds = mol_fwd_lds(KPB, SP);
+  auto kern = k_schnet_mol_fwd<KPB, SP>;
   static SpkPerDevice attr_set;
   int attr_dev;
   if (attr_set.pending(&attr_dev)) {
@@ -745,13 +943,18 @@ struct MolBwdArgs {
   long long* dbg;
 };
 
-template <int KPB>
+template <int KPB, bool SP>
 __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
   constexpr int NF = 128, NT = 4, KB2 = 16;
+  constexpr int W1F = SP ? 2 * MlW1Image<KPB>::BYTES / 4 : NF * KPB * 8;     // floats of the W1 image(s)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sW2 = smem;                                  // NF*NF
-  float* sW1 = sW2 + NF * NF;                         // NF*KPB*8
-  float* sb1 = sW1 + NF * KPB * 8;                    // NF (+ NF unused: same footprint as the forward)
+  float* sW2 = smem;                                  // NF*NF  (SP: high image | low image, 32 KB each)
+  float* sW1 = sW2 + NF * NF;                         // NF*KPB*8  (SP: high image | low image)
+  float* sb1 = sW1 + W1F;                             // NF (+ NF unused: same footprint as the forward)
+  h16x8* const sW2h = (h16x8*)sW2;
+  h16x8* const sW2l = sW2h + 2048;
+  char* const sW1h = (char*)sW1;
+  char* const sW1l = sW1h + MlW1Image<KPB>::BYTES;
   float* sGx = sb1 + 2 * NF;                          // [32][ML_LD] dL/dx of the current level
   float* sH = sGx + 32 * ML_LD;                       // h_l (saved by the forward)
   float* sGy = sH + 32 * ML_LD;                       // dL/dy_l
@@ -900,7 +1103,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
               f32x4{acc[4 * q] * spk_sigmoid(pv[q].x), acc[4 * q + 1] * spk_sigmoid(pv[q].y), acc[4 * q + 2] * spk_sigmoid(pv[q].z), acc[4 * q + 3] * spk_sigmoid(pv[q].w)};
       } else {
         // (sW2 was last read by the derivative tasks of the interaction above: two barriers ago)
-        ml_stage_packed<256, NF * NF / 4>(sW2, P.w2, NF, KB2, tid - 256);
+        if constexpr (SP) ml_stage_w2_split<256>(sW2h, sW2l, P.w2, tid - 256);
+        else ml_stage_packed<256, NF * NF / 4>(sW2, P.w2, NF, KB2, tid - 256);
       }
       if (tid == 0) { sCnt[0] = 0; sCnt[1] = 0; }
       __syncthreads();
@@ -926,7 +1130,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           const int row = s >> 5, c4 = s & 31;
           *(f32x4*)(sH + row * ML_LD + 4 * c4) = ml_ld<f32x4>(h_g + (size_t)a0 * NF, (unsigned)(s * 16));
         }
-        ml_stage_packed<256, NF * KPB * 2>(sW1, P.w1, a.rb.n_rbf, KPB, t2);
+        if constexpr (SP) ml_stage_w1_split<KPB>(sW1h, sW1l, P.w1, a.rb.n_rbf, t2);
+        else ml_stage_packed<256, NF * KPB * 2>(sW1, P.w1, a.rb.n_rbf, KPB, t2);
         if (t2 < NF) sb1[t2] = P.b1[t2];
       }
       __syncthreads();
@@ -996,6 +1201,80 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) gl[tt][q] = ml_ld<f32x4>(g_g + 64 * tp, (unsigned)((grow * NF + 4 * hi + 32 * tt + 8 * q) * 4));
+        float s1 = 0.f, s2 = 0.f;
+        if constexpr (SP) {
+          // ---- split form (spk_split.h).  GEMM 1, value and derivative, for the four hidden tiles: A = the W1 images, B = this pair's
+          // basis values / slopes in the lane's k-slots; z' = sigmoid(a) a' goes from the accumulator registers into the B operand
+          // of GEMM 2' as it lies (W2 is staged with its contraction index in accumulator order).
+          // (lane re-derived through an opaque asm: the LDS offsets below are then formed here and not hoisted out of the task loop
+          //  into the prologue of the kernel, where the allocator parks them in scratch -- section 4.3a of DESIGN.md)
+          int lane_o = lane;
+          asm volatile("" : "+v"(lane_o));
+          const int hi_o = lane_o >> 5;
+          h16x8 ph[2], pl[2], dh[2], dl[2];
+          ml_basis_split<KPB, true>(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, hi_o, pr.d, ph, pl, dh, dl);
+          h16x8 zph[NT][2], zpl[NT][2];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) {
+            f32x16 zc, zcx, zq, zqx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { zc[r] = sb1[32 * c + ml_row(r, hi_o)]; zcx[r] = 0.f; zq[r] = 0.f; zqx[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < (KPB > 2 ? 2 : 1); ++s) {
+              h16x8 wh, wl;
+              ml_w1_operand<KPB>(sW1h, sW1l, s, c * 64 + lane_o, wh, wl);
+              SP_STEP(wh, wl, ph[s], pl[s], zc, zcx);
+              SP_STEP(wh, wl, dh[s], dl[s], zq, zqx);
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int r = 8 * sp + e;
+                float spv, sg;
+                spk_fast_softplus_sigmoid(fmaf(zcx[r], SP_DOWN, zc[r]), spv, sg);
+                v[e] = fmaf(zqx[r], SP_DOWN, zq[r]) * sg;
+              }
+              sp_split8(v, zph[c][sp], zpl[c][sp]);
+            }
+          }
+          // ---- GEMM 2' per channel tile (rows = channels 32 t + ml_row(r, hi), columns = pairs): g' = W2 z'
+          const float* gyi_p = sGy + pi * ML_LD + 4 * hi_o;
+          const float* gyj_p = sGy + pj * ML_LD + 4 * hi_o;
+          const float* hi_p = sH + pi * ML_LD + 4 * hi_o;
+          const float* hj_p = sH + pj * ML_LD + 4 * hi_o;
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * tp + tt;
+            f32x16 gp, gpx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gp[r] = 0.f; gpx[r] = 0.f; }
+            const h16x8* wbh = sW2h + (t * 8) * 64 + lane_o;
+            const h16x8* wbl = sW2l + (t * 8) * 64 + lane_o;
+            h16x8 wh[8], wl[8];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { wh[s] = wbh[s * 64]; wl[s] = wbl[s * 64]; }
+            ML_PIN();
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+              if (s + 2 < 8) { wh[s + 2] = wbh[(s + 2) * 64]; wl[s + 2] = wbl[(s + 2) * 64]; ML_PIN(); }
+              SP_STEP(wh[s], wl[s], zph[s >> 1][s & 1], zpl[s >> 1][s & 1], gp, gpx);
+            }
+            SP_FOLD(gp, gpx);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int col = 32 * t + 8 * q;
+              const f32x4 gyi = *(const f32x4*)(gyi_p + col), gyj = *(const f32x4*)(gyj_p + col);
+              const f32x4 hvi = *(const f32x4*)(hi_p + col), hvj = *(const f32x4*)(hj_p + col);
+              const f32x4 gq = gl[tt][q];
+              const float D0 = gp[4 * q] * fc + gq.x * dfc, D1 = gp[4 * q + 1] * fc + gq.y * dfc;
+              const float D2 = gp[4 * q + 2] * fc + gq.z * dfc, D3 = gp[4 * q + 3] * fc + gq.w * dfc;
+              s1 += gyi.x * hvj.x * D0 + gyi.y * hvj.y * D1 + gyi.z * hvj.z * D2 + gyi.w * hvj.w * D3;
+              s2 += gyj.x * hvi.x * D0 + gyj.y * hvi.y * D1 + gyj.z * hvi.z * D2 + gyj.w * hvi.w * D3;
+            }
+          }
+        } else {
         float phi[KPB][4], dphi[KPB][4];
 #pragma unroll
         for (int u = 0; u < KPB; ++u)
@@ -1061,7 +1340,6 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           }
         }
         // ---- GEMM 2' per channel tile (rows = channels 32 t + ml_row(r, hi), columns = pairs): g' = W2 z'
-        float s1 = 0.f, s2 = 0.f;
         const float* gyi_p = sGy + pi * ML_LD + 4 * hi;
         const float* gyj_p = sGy + pj * ML_LD + 4 * hi;
         const float* hi_p = sH + pi * ML_LD + 4 * hi;
@@ -1101,6 +1379,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
             s1 += gyi.x * hvj.x * D0 + gyi.y * hvj.y * D1 + gyi.z * hvj.z * D2 + gyi.w * hvj.w * D3;
             s2 += gyj.x * hvi.x * D0 + gyj.y * hvi.y * D1 + gyj.z * hvi.z * D2 + gyj.w * hvi.w * D3;
           }
+        }
         }
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
@@ -1165,15 +1444,21 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
   if (a.dbg && tid == 0) { a.dbg[129 + 4 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime(); a.dbg[131 + 4 * blockIdx.x] = (long long)__builtin_readcyclecounter(); }
 }
 
-static size_t mol_bwd_lds(int kpb) {
-  return (size_t)(128 * 128 + 128 * kpb * 8 + 2 * 128 + 4 * 32 * ML_LD + 64 + 2 * ML_MAXPAIRS) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
+static size_t mol_bwd_lds(int kpb, bool sp) {
+  return (size_t)(128 * 128 + mol_w1_floats(kpb, sp) + 2 * 128 + 4 * 32 * ML_LD + 64 + 2 * ML_MAXPAIRS) * sizeof(float) + ML_MAXPAIRS * sizeof(MolPair) +
          (2 * ML_MAXEDGES + 36 + 4 + 8) * sizeof(int) + ML_MAXPAIRS * sizeof(short);
 }
 
+template <int KPB, bool SP>
+static int launch_mol_bwd_sp(const MolBwdArgs& a, hipStream_t stream);
 template <int KPB>
 static int launch_mol_bwd(const MolBwdArgs& a, hipStream_t stream) {
-  const size_t lds = mol_bwd_lds(KPB);
-  auto kern = k_schnet_mol_bwd<KPB>;
+  return spk_get_split() ? launch_mol_bwd_sp<KPB, true>(a, stream) : launch_mol_bwd_sp<KPB, false>(a, stream);
+}
+template <int KPB, bool SP>
+static int launch_mol_bwd_sp(const MolBwdArgs& a, hipStream_t stream) {
+  const size_t lds = mol_bwd_lds(KPB, SP);
+  auto kern = k_schnet_mol_bwd<KPB, SP>;
   static SpkPerDevice attr_set;
   int attr_dev;
   if (attr_set.pending(&attr_dev)) {

@@ -31,6 +31,12 @@ extern "C" int spk_version(void) { return 100; }
 extern "C" const char* spk_last_error(void) { return g_err; }
 extern "C" void spk_set_variant(int v) { g_variant = v; }
 extern "C" int spk_get_variant(void) { return g_variant; }
+static int g_split = -1;
+extern "C" void spk_set_split(int on) { g_split = on ? 1 : 0; }
+extern "C" int spk_get_split(void) {
+  if (g_split < 0) { const char* e = getenv("SPK_SPLIT"); g_split = (e && e[0] == '0') ? 0 : 1; }
+  return g_split;
+}
 
 extern "C" int spk_device_info(int32_t* host_info) {
   SPK_CHECK_ARG(host_info != nullptr, "spk_device_info: null output");

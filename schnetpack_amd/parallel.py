@@ -3,6 +3,7 @@
 all-reduce of one flat gradient bucket per step (RCCL over xGMI: 2.36 MB for PaiNN(128,3) is
 latency-bound, so a single bucket beats per-parameter hooks).  Works on any torch.distributed
 backend (``nccl`` = RCCL on ROCm; ``gloo`` in the CPU tests)."""
+import os
 from typing import Iterable, List, Tuple
 
 import torch
@@ -39,6 +40,9 @@ class FlatGradAllReduce:
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
         self.as_views = as_views
+        self.collectives = 0            # all-reduces issued so far (see _reduce)
+        self.last_reduced_ptr = None
+        self.last_reduced_numel = 0
         if as_views and self.params:
             self._bind()
 
@@ -79,10 +83,22 @@ class FlatGradAllReduce:
             off += n
 
     def _reduce(self, group):
+        """The one collective of a training step.  Issued when the job has more than one rank -- and also at world size 1 when
+        the caller names a process ``group`` or ``SPK_FORCE_COLLECTIVES=1`` is set (as ``SPK_MD_FORCE_COLLECTIVES`` does for the
+        bead exchange, md.py): the RCCL path of a one-GPU box is then the path an 8-GPU job takes, and a test can count it.
+        ``self.collectives`` counts the all-reduces issued, ``self.last_reduced_ptr`` / ``last_reduced_numel`` say which buffer
+        went to the backend (the flat bucket itself: no staging copy)."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(group)
+        if world > 1 or group is not None or os.environ.get("SPK_FORCE_COLLECTIVES", "0") not in ("", "0"):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+            self.collectives += 1
+            self.last_reduced_ptr = self.flat.data_ptr()
+            self.last_reduced_numel = self.flat.numel()
+            if world > 1:
+                self.flat.div_(world)
 
     def __call__(self, group=None):
         if not self.params:
