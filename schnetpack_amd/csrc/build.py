@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["spk_util.hip", "spk_dense.hip", "spk_chain.hip", "spk_cfconv.hip", "spk_schnet.hip", "spk_schnet_mol.hip", "spk_painn.hip", "spk_painn_tile.hip", "spk_painn_blk.hip", "spk_painn_mol.hip", "spk_tabfilter.hip", "spk_nbl.hip", "spk_md.hip", "spk_potential.hip", "spk_train.hip", "spk_fm.hip"]
-HEADERS = ["spk_common.h", "spk_painn_msg.h", "spk_painn_mol.h", "spk_painn_blk.h", "spk_pack.h", "spk_gemm_tn.h", "spk_fm_engine.h", "spk_fm_kernels.h", os.path.join("..", "..", "include", "spk_hip.h")]
+HEADERS = ["spk_common.h", "spk_painn_msg.h", "spk_painn_mol.h", "spk_painn_blk.h", "spk_pack.h", "spk_gemm_tn.h", "spk_fm_engine.h", "spk_fm_kernels.h", "spk_fm_chain.h", "spk_split.h", os.path.join("..", "..", "include", "spk_hip.h")]
 LIB = os.path.join(HERE, "libspk_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-mcode-object-version=5", "-Wall", "-Wno-unused-function"] + os.environ.get("SPK_EXTRA_FLAGS", "").split()

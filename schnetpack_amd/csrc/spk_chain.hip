@@ -12,6 +12,7 @@
 // (backward chains).  The kernel can also zero a buffer for the following edge kernel, which
 // replaces a separate memset launch.
 #include "spk_common.h"
+#include "spk_split.h"
 
 #define CH_MAXL 3
 #define CH_MAXW 384
@@ -387,6 +388,42 @@ __global__ void k_pack_weight(const float* __restrict__ w, int n_out, int k_in, 
     const int i = 32 * t + (lane & 31), kk = 8 * ug + 4 * (lane >> 5) + v;
     P[s] = transposed ? w[(int64_t)kk * k_in + i] : w[(int64_t)i * k_in + kk];
   }
+}
+
+// Split-precision image of the same matrix (spk_split.h): the chunk geometry of the fp32 image -- tile t of 32 rows, KB = KC / 8 chunks of
+// 1024 bytes, a lane's 16 bytes at ((t KB + ug) 64 + lane) 16 -- with chunk ug = 2 s + part holding, for k-step s (16 contraction
+// indices), the eight fp16 HIGH parts (part 0) or the eight 2^11-scaled fp16 LOW parts (part 1) of A[32 t + (lane & 31)][16 s + 8 (lane >> 5) + e],
+// e = 0..7: the A operand of v_mfma_f32_32x32x16_f16 as it lies.  A kernel that walks the fp32 image in blocks of 8 chunks (64 k) walks
+// this one with the same offsets.
+__global__ void k_pack_weight_split(const float* __restrict__ w, int n_out, int k_in, int transposed, float* __restrict__ P) {
+  const int KC = transposed ? n_out : k_in, NW = transposed ? k_in : n_out;
+  const int KB = KC / 8;
+  const int64_t slots = (int64_t)(NW / 32) * (KC / 16) * 64;
+  for (int64_t sl = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; sl < slots; sl += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(sl & 63);
+    const int64_t blk = sl >> 6;
+    const int s = (int)(blk % (KC / 16)), t = (int)(blk / (KC / 16));
+    const int i = 32 * t + (lane & 31);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = 16 * s + 8 * (lane >> 5) + e;
+      x[e] = transposed ? w[(int64_t)kk * k_in + i] : w[(int64_t)i * k_in + kk];
+    }
+    h16x8 h, l;
+    sp_split8(x, h, l);
+    h16x8* dst = (h16x8*)P;
+    dst[((int64_t)t * KB + 2 * s) * 64 + lane] = h;
+    dst[((int64_t)t * KB + 2 * s + 1) * 64 + lane] = l;
+  }
+}
+int spk_pack_weight_split_internal(const float* w, int n_out, int k_in, int transposed, float* packed, hipStream_t stream) {
+  const int KC = transposed ? n_out : k_in, NW = transposed ? k_in : n_out;
+  SPK_CHECK_ARG(w && packed && n_out > 0 && k_in > 0, "spk_pack_weight_split: bad input");
+  SPK_CHECK_ARG(KC % 16 == 0 && NW % 32 == 0, "spk_pack_weight_split: contraction length %d must be a multiple of 16, output width %d of 32", KC, NW);
+  hipLaunchKernelGGL(k_pack_weight_split, dim3(spk_grid_for((int64_t)KC * NW / 8, 256, spk_num_cus() * 8)), dim3(256), 0, stream, w, n_out, k_in, transposed, packed);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
 }
 
 int spk_pack_weight_internal(const float* w, int n_out, int k_in, int transposed, float* packed, hipStream_t stream);

@@ -12,22 +12,39 @@ struct SpkPackEntry {
   const float* rawT;   // optional transposed copy [k_in, n_out] handed in by the caller
   int n_out, k_in;
   int64_t off_fwd, off_bwd;
+  int64_t off_fwd_s, off_bwd_s;   // split-precision images (spk_split.h; -1: contraction length not a multiple of 16)
 };
+
+// further images kept in the same buffer, found by the raw tensor they were made from (e.g. the LDS image of a filter-network weight)
+struct SpkPackExtra { const float* raw; int64_t off, floats; };
 
 struct SpkPackTable {
   std::vector<SpkPackEntry> e;
+  std::vector<SpkPackExtra> x;
   const float* base = nullptr;
   int64_t total = 0;
+  void add_extra(const float* raw, int64_t floats) { x.push_back(SpkPackExtra{raw, total, floats}); total += floats; }
+  const float* extra_of(const float* raw) const {
+    if (!base) return nullptr;
+    for (const SpkPackExtra& q : x) if (q.raw == raw) return base + q.off;
+    return nullptr;
+  }
   void add(const float* raw, const float* rawT, int n_out, int k_in) {
     SpkPackEntry x;
     x.raw = raw; x.rawT = rawT; x.n_out = n_out; x.k_in = k_in;
     x.off_fwd = total; x.off_bwd = total + (int64_t)n_out * k_in;
     total += 2 * (int64_t)n_out * k_in;
+    // the (high, low) fp16 images have the size and the chunk geometry of the fp32 ones (8 k = 1024 bytes per tile row block)
+    x.off_fwd_s = (k_in % 16 == 0) ? total : -1;
+    if (x.off_fwd_s >= 0) total += (int64_t)n_out * k_in;
+    x.off_bwd_s = (n_out % 16 == 0) ? total : -1;
+    if (x.off_bwd_s >= 0) total += (int64_t)n_out * k_in;
     e.push_back(x);
   }
 };
 
 int spk_pack_weight_internal(const float* w, int n_out, int k_in, int transposed, float* packed, hipStream_t stream);
+int spk_pack_weight_split_internal(const float* w, int n_out, int k_in, int transposed, float* packed, hipStream_t stream);
 
 static inline int spk_pack_all(const SpkPackTable& T, float* wpack, hipStream_t stream) {
   for (const SpkPackEntry& x : T.e) {
@@ -35,6 +52,8 @@ static inline int spk_pack_all(const SpkPackTable& T, float* wpack, hipStream_t 
     if (rc) return rc;
     rc = spk_pack_weight_internal(x.raw, x.n_out, x.k_in, 1, wpack + x.off_bwd, stream);
     if (rc) return rc;
+    if (x.off_fwd_s >= 0) { rc = spk_pack_weight_split_internal(x.raw, x.n_out, x.k_in, 0, wpack + x.off_fwd_s, stream); if (rc) return rc; }
+    if (x.off_bwd_s >= 0) { rc = spk_pack_weight_split_internal(x.raw, x.n_out, x.k_in, 1, wpack + x.off_bwd_s, stream); if (rc) return rc; }
   }
   return SPK_OK;
 }
@@ -44,6 +63,17 @@ static inline const float* spk_packed_of(const SpkPackTable& T, const float* raw
   if (!T.base || spk_get_variant() == SPK_VARIANT_SIMPLE) return nullptr;
   for (const SpkPackEntry& x : T.e)
     if (x.raw == raw) return T.base + (transposed ? x.off_bwd : x.off_fwd);
+  return nullptr;
+}
+
+// the split-precision image of the same layer (NULL: none, or the split path is switched off -- spk_set_split)
+static inline const float* spk_packed_split_of(const SpkPackTable& T, const float* raw, int transposed) {
+  if (!T.base || spk_get_variant() == SPK_VARIANT_SIMPLE || !spk_get_split()) return nullptr;
+  for (const SpkPackEntry& x : T.e)
+    if (x.raw == raw) {
+      const int64_t off = transposed ? x.off_bwd_s : x.off_fwd_s;
+      return off >= 0 ? T.base + off : nullptr;
+    }
   return nullptr;
 }
 

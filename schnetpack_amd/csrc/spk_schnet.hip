@@ -95,16 +95,26 @@ static SpkPackTable schnet_pack_table(const spk_schnet_t* m) {
     T.add(P.f2out_w1, P.f2out_w1T, F, NF);
     T.add(P.f2out_w2, P.f2out_w2T, F, F);
   }
+  // the split-precision LDS image of filter_network.1.weight of every interaction (spk_schnet_mol.hip: staged by a plain copy)
+  if (NF == 128)
+    for (int l = 0; l < m->n_interactions; ++l) T.add_extra(m->layers[l].fn_w2, 128 * 128);
   T.base = m->wpack;
   return T;
 }
+int spk_schnet_mol_pack_w2(const float* w2, float* image, hipStream_t stream);
 extern "C" int64_t spk_schnet_packed_floats(const spk_schnet_t* m) {
   if (!m || !m->layers || m->n_interactions <= 0 || !schnet_pack_shapes_ok(m)) return 0;
   return schnet_pack_table(m).total;
 }
 extern "C" int spk_schnet_pack_weights_f32(const spk_schnet_t* m, float* wpack, void* stream) {
   SPK_CHECK_ARG(m && wpack && spk_schnet_packed_floats(m) > 0, "spk_schnet_pack_weights_f32: model shapes have no packed form (see spk_schnet_packed_floats)");
-  return spk_pack_all(schnet_pack_table(m), wpack, (hipStream_t)stream);
+  const SpkPackTable T = schnet_pack_table(m);
+  int rc = spk_pack_all(T, wpack, (hipStream_t)stream);
+  for (const SpkPackExtra& q : T.x) {
+    if (rc) break;
+    rc = spk_schnet_mol_pack_w2(q.raw, wpack + q.off, (hipStream_t)stream);
+  }
+  return rc;
 }
 
 // forward layer from either the [out,in] weight or its transposed copy (coalesced reads)

@@ -33,6 +33,7 @@ bool spk_schnet_mol_bwd_eligible(const spk_schnet_t* m, const spk_graph_t* g, co
 struct MolLayerDev {
   const float* in2f_p;                  // packed forward image of in2f.weight [NF, F] (spk_pack_weight_f32)
   const float *w1, *b1, *w2, *b2;       // filter network, raw state_dict tensors
+  const float* w2_img;                  // split-precision LDS image of w2 (wpack), or null: made from w2 while staging
   const float *o1_p, *o1_b, *o2_p, *o2_b;  // packed forward images of f2out.0 / f2out.1 and their biases
 };
 
@@ -230,6 +231,27 @@ __device__ __forceinline__ void ml_stage_w2_split(h16x8* __restrict__ dh, h16x8*
     }
   }
 }
+// the same image made once per weight version in global memory (wpack, spk_schnet_pack_weights_f32): staging is then a plain copy
+__global__ void k_mol_pack_w2(const float* __restrict__ w2, float* __restrict__ image) {
+  ml_stage_w2_split<256>((h16x8*)image, (h16x8*)image + 2048, w2, threadIdx.x);
+}
+int spk_schnet_mol_pack_w2(const float* w2, float* image, hipStream_t stream) {
+  hipLaunchKernelGGL(k_mol_pack_w2, dim3(1), dim3(256), 0, stream, w2, image);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+template <int NTHREADS>
+__device__ __forceinline__ void ml_stage_w2_image(float* __restrict__ dst, const float* __restrict__ img, int tid) {
+  constexpr int PER = 4096 / NTHREADS;      // 16-byte pieces per thread (64 KB)
+#pragma unroll 1
+  for (int p0 = 0; p0 < PER; p0 += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v[p] = *(const f32x4*)((const char*)img + (unsigned)((tid + (p0 + p) * NTHREADS) * 16));
+#pragma unroll
+    for (int p = 0; p < 8; ++p) *(f32x4*)(dst + (tid + (p0 + p) * NTHREADS) * 4) = v[p];
+  }
+}
 // W1 [NF][n_rbf]: slot (hidden tile t, lane): k-step 0 = basis functions 8 hi + e; k-step 1 (n_rbf > 16) = 16 + 4 hi + e for e < 4 and,
 // for n_rbf > 24 only, 24 + 4 hi + (e - 4) for e >= 4 -- the live functions of a 20-wide basis are spread evenly over the two lane
 // halves (12 evaluations per lane).  Image = [256 slots] h16x8 (k-step 0), then [256 slots] h16x4 (KPB = 3) or h16x8 (KPB = 4).
@@ -353,8 +375,36 @@ __device__ __forceinline__ void ml_dense_load(f32x4 (&av)[16], const float* __re
 // (B operands are requested four k-blocks ahead of their MFMAs and pinned there: left alone the compiler issues every ds_read
 //  right in front of the four MFMAs that need it and the matrix pipe waits ~100 cycles per group -- round 3, found on spk_painn_mol.hip)
 #define ML_PIN() asm volatile("" ::: "memory")
+// Split form of a Dense block (SP; spk_split.h): `av` then holds chunks of the SPLIT weight image (k_pack_weight_split: chunk 2 s = the high
+// parts of k-step s, chunk 2 s + 1 its low parts -- same bytes, same offsets as the fp32 image), the activations are read from LDS
+// as eight consecutive fp32 values per k-step and split in registers; three f16 instructions per 16 k instead of eight f32 ones.
+#ifndef SP_AHEAD
+#define SP_AHEAD 1      // k-steps of LDS operands requested ahead of their use in the split Dense blocks
+#endif
+template <int NS>
+__device__ __forceinline__ f32x16 ml_dense_mma_sp(const f32x4* __restrict__ av, const float* __restrict__ brow /* lane's row + 8 hi + first k */, f32x16 acc) {
+  f32x16 cx;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cx[r] = 0.f;
+  f32x4 b0[NS], b1[NS];
+#pragma unroll
+  for (int s = 0; s < SP_AHEAD && s < NS; ++s) { b0[s] = *(const f32x4*)(brow + 16 * s); b1[s] = *(const f32x4*)(brow + 16 * s + 4); }
+  ML_PIN();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (s + SP_AHEAD < NS) { b0[s + SP_AHEAD] = *(const f32x4*)(brow + 16 * (s + SP_AHEAD)); b1[s + SP_AHEAD] = *(const f32x4*)(brow + 16 * (s + SP_AHEAD) + 4); ML_PIN(); }
+    h16x4 h0, l0, h1, l1;
+    sp_split4(b0[s], h0, l0);
+    sp_split4(b1[s], h1, l1);
+    SP_STEP(__builtin_bit_cast(h16x8, av[2 * s]), __builtin_bit_cast(h16x8, av[2 * s + 1]), sp_cat(h0, h1), sp_cat(l0, l1), acc, cx);
+  }
+  SP_FOLD(acc, cx);
+  return acc;
+}
+template <bool SP = false>
 __device__ __forceinline__ f32x16 ml_dense_mma(const f32x4 (&av)[16], const float* __restrict__ sIn, int lane, f32x16 acc) {
   const int hi = lane >> 5, el = lane & 31;
+  if constexpr (SP) return ml_dense_mma_sp<8>(av, sIn + el * ML_LD + 8 * hi, acc);
   const float* brow = sIn + el * ML_LD + 4 * hi;
   f32x4 bv[16];
 #pragma unroll
@@ -377,8 +427,10 @@ __device__ __forceinline__ void ml_dense_load8(f32x4 (&av)[8], const float* __re
 #pragma unroll
   for (int u = 0; u < 8; ++u) av[u] = ml_ld<f32x4>(sb, (unsigned)(lane * 16 + u * 1024));
 }
+template <bool SP = false>
 __device__ __forceinline__ f32x16 ml_dense_mma8(const f32x4 (&av)[8], const float* __restrict__ sIn, int lane, int half, f32x16 acc) {
   const int hi = lane >> 5, el = lane & 31;
+  if constexpr (SP) return ml_dense_mma_sp<4>(av, sIn + el * ML_LD + 8 * hi + 64 * half, acc);
   const float* brow = sIn + el * ML_LD + 4 * hi + 64 * half;
   f32x4 bv[8];
 #pragma unroll
@@ -394,18 +446,45 @@ __device__ __forceinline__ f32x16 ml_dense_mma8(const f32x4 (&av)[8], const floa
   }
   return acc;
 }
+template <bool SP = false>
 __device__ __forceinline__ f32x16 ml_dense_tile(const float* __restrict__ wp, const float* __restrict__ sIn, int t, int lane, f32x16 acc) {
-  const int hi = lane >> 5, el = lane & 31;
   f32x4 av[16];
   ml_dense_load(av, wp, t, lane);
-  (void)hi; (void)el;
-  return ml_dense_mma(av, sIn, lane, acc);
+  return ml_dense_mma<SP>(av, sIn, lane, acc);
 }
 
 // B operand of a Dense half-tile that is the SUM of two LDS tiles (the two teams' partial cfconv outputs)
+template <bool SP = false>
 __device__ __forceinline__ f32x16 ml_dense_mma8_sum(const f32x4 (&av)[8], const float* __restrict__ sIn0, const float* __restrict__ sIn1, int lane, int half,
                                                     f32x16 acc) {
   const int hi = lane >> 5, el = lane & 31;
+  if constexpr (SP) {
+    const int o = el * ML_LD + 8 * hi + 64 * half;
+    f32x16 cx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cx[r] = 0.f;
+    f32x4 p0[4], p1[4], q0[4], q1[4];
+#pragma unroll
+    for (int s = 0; s < SP_AHEAD; ++s) {
+      p0[s] = *(const f32x4*)(sIn0 + o + 16 * s); p1[s] = *(const f32x4*)(sIn0 + o + 16 * s + 4);
+      q0[s] = *(const f32x4*)(sIn1 + o + 16 * s); q1[s] = *(const f32x4*)(sIn1 + o + 16 * s + 4);
+    }
+    ML_PIN();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + SP_AHEAD < 4) {
+        p0[s + SP_AHEAD] = *(const f32x4*)(sIn0 + o + 16 * (s + SP_AHEAD)); p1[s + SP_AHEAD] = *(const f32x4*)(sIn0 + o + 16 * (s + SP_AHEAD) + 4);
+        q0[s + SP_AHEAD] = *(const f32x4*)(sIn1 + o + 16 * (s + SP_AHEAD)); q1[s + SP_AHEAD] = *(const f32x4*)(sIn1 + o + 16 * (s + SP_AHEAD) + 4);
+        ML_PIN();
+      }
+      h16x4 h0, l0, h1, l1;
+      sp_split4(p0[s] + q0[s], h0, l0);
+      sp_split4(p1[s] + q1[s], h1, l1);
+      SP_STEP(__builtin_bit_cast(h16x8, av[2 * s]), __builtin_bit_cast(h16x8, av[2 * s + 1]), sp_cat(h0, h1), sp_cat(l0, l1), acc, cx);
+    }
+    SP_FOLD(acc, cx);
+    return acc;
+  }
   const int off = el * ML_LD + 4 * hi + 64 * half;
   f32x4 b0[8], b1[8];
 #pragma unroll
@@ -514,7 +593,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          acc = ml_dense_tile(P.in2f_p, sX, t, lane, acc);
+          acc = ml_dense_tile<false>(P.in2f_p, sX, t, lane, acc);     // (fp32 image: this tile runs beside the other team's first pair tile, off the
+                                                                        //  critical path, and its split form pushed the kernel 170 B/lane further into scratch)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 hv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -577,7 +657,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
           }
         }
         if (l == 0 && it == 0 && team == 0) {
-          if constexpr (SP) ml_stage_w2_split<256>(sW2h, sW2l, a.L[0].w2, tid);
+          if constexpr (SP) { if (a.L[0].w2_img) ml_stage_w2_image<256>(sW2, a.L[0].w2_img, tid); else ml_stage_w2_split<256>(sW2h, sW2l, a.L[0].w2, tid); }
           else ml_stage_packed<256, NF * NF / 4>(sW2, a.L[0].w2, NF, KB2, tid);
         }
         __syncthreads();     // the team's hidden tile (and, in the first round, h) is complete
@@ -698,8 +778,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = P.o1_b[32 * t + ml_row(r, hi)];
-        acc = ml_dense_mma8_sum(avA, sY, sT, lane, 0, acc);
-        acc = ml_dense_mma8_sum(avB, sY, sT, lane, 1, acc);
+        acc = ml_dense_mma8_sum<SP>(avA, sY, sT, lane, 0, acc);
+        acc = ml_dense_mma8_sum<SP>(avB, sY, sT, lane, 1, acc);
         ml_dense_load8(avC, P.o2_p, t, lane, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -710,7 +790,7 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
       } else if (l + 1 < a.n_layers) {     // the filter GEMMs of this interaction are done: their LDS images can be replaced
         const int t2 = tid - 256;
         if constexpr (SP) {
-          ml_stage_w2_split<256>(sW2h, sW2l, a.L[l + 1].w2, t2);
+          if (a.L[l + 1].w2_img) ml_stage_w2_image<256>(sW2, a.L[l + 1].w2_img, t2); else ml_stage_w2_split<256>(sW2h, sW2l, a.L[l + 1].w2, t2);
           ml_stage_w1_split<KPB>(sW1h, sW1l, a.L[l + 1].w1, a.rb.n_rbf, t2);
         } else {
           ml_stage_packed<256, NF * NF / 4>(sW2, a.L[l + 1].w2, NF, KB2, t2);
@@ -728,8 +808,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_fwd(MolFwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = P.o2_b[32 * t + ml_row(r, hi)];
-        acc = ml_dense_mma8(avC, sH, lane, 0, acc);
-        acc = ml_dense_mma8(avB, sH, lane, 1, acc);
+        acc = ml_dense_mma8<SP>(avC, sH, lane, 0, acc);
+        acc = ml_dense_mma8<SP>(avB, sH, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float* xp = sX + el * ML_LD + 32 * t + 8 * q + 4 * hi;
@@ -875,15 +955,17 @@ int spk_schnet_mol_forward_ex(const spk_schnet_t* m, const spk_graph_t* g, const
   a.R = R; a.offsets = offsets;
   a.emb = emb; a.Z = Z; a.n_types = n_types;
   if (head) a.head = *head; else a.head.w1 = nullptr;
+  const bool split = spk_get_split() != 0;     // the launch takes the same decision (launch_mol_fwd): split images for the split kernels
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_schnet_layer_t& P = m->layers[l];
     MolLayerDev& D = a.L[l];
     D.in2f_p = spk_packed_of(ptab, P.in2f_w, 0);
-    D.o1_p = spk_packed_of(ptab, P.f2out_w1, 0);
-    D.o2_p = spk_packed_of(ptab, P.f2out_w2, 0);
+    D.o1_p = split ? spk_packed_split_of(ptab, P.f2out_w1, 0) : spk_packed_of(ptab, P.f2out_w1, 0);
+    D.o2_p = split ? spk_packed_split_of(ptab, P.f2out_w2, 0) : spk_packed_of(ptab, P.f2out_w2, 0);
     SPK_CHECK_ARG(D.in2f_p && D.o1_p && D.o2_p, "spk_schnet_mol_forward: packed weight images missing");
     D.w1 = P.fn_w1; D.b1 = P.fn_b1; D.w2 = P.fn_w2; D.b2 = P.fn_b2; D.o1_b = P.f2out_b1; D.o2_b = P.f2out_b2;
+    D.w2_img = split ? ptab.extra_of(P.fn_w2) : nullptr;
   }
   a.x0 = x0; a.x_out = x_out; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
   a.half = g->half; a.rowptr = g->rowptr; a.edge_pair = g->edge_pair; a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0;
@@ -917,6 +999,7 @@ int spk_schnet_mol_forward_ex(const spk_schnet_t* m, const spk_graph_t* g, const
 // ==========================================================================================================
 struct MolBwdLayerDev {
   const float *w1, *b1, *w2;               // filter network (raw)
+  const float* w2_img;                     // split-precision LDS image of w2 (wpack), or null
   const float *in2f_t, *o1_t, *o2_t;       // packed input-gradient images of in2f / f2out.0 / f2out.1
 };
 
@@ -1095,15 +1178,15 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           pv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (el < na) pv[q] = ml_ld<f32x4>(pre3_g + (size_t)a0 * NF + 32 * t, (unsigned)((el * NF + 8 * q + 4 * hi) * 4));
         }
-        acc = ml_dense_mma8(avA, sGx, lane, 0, acc);
-        acc = ml_dense_mma8(avB, sGx, lane, 1, acc);
+        acc = ml_dense_mma8<SP>(avA, sGx, lane, 0, acc);
+        acc = ml_dense_mma8<SP>(avB, sGx, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(sGh + el * ML_LD + 32 * t + 8 * q + 4 * hi) =
               f32x4{acc[4 * q] * spk_sigmoid(pv[q].x), acc[4 * q + 1] * spk_sigmoid(pv[q].y), acc[4 * q + 2] * spk_sigmoid(pv[q].z), acc[4 * q + 3] * spk_sigmoid(pv[q].w)};
       } else {
         // (sW2 was last read by the derivative tasks of the interaction above: two barriers ago)
-        if constexpr (SP) ml_stage_w2_split<256>(sW2h, sW2l, P.w2, tid - 256);
+        if constexpr (SP) { if (P.w2_img) ml_stage_w2_image<256>(sW2, P.w2_img, tid - 256); else ml_stage_w2_split<256>(sW2h, sW2l, P.w2, tid - 256); }
         else ml_stage_packed<256, NF * NF / 4>(sW2, P.w2, NF, KB2, tid - 256);
       }
       if (tid == 0) { sCnt[0] = 0; sCnt[1] = 0; }
@@ -1119,8 +1202,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = ml_dense_mma8(avA, sGh, lane, 0, acc);
-        acc = ml_dense_mma8(avB, sGh, lane, 1, acc);
+        acc = ml_dense_mma8<SP>(avA, sGh, lane, 0, acc);
+        acc = ml_dense_mma8<SP>(avB, sGh, lane, 1, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(sGy + el * ML_LD + 32 * t + 8 * q + 4 * hi) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -1166,8 +1249,8 @@ __global__ __launch_bounds__(512) void k_schnet_mol_bwd(MolBwdArgs a) {
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          acc = ml_dense_mma8(avA, sGh, lane, 0, acc);
-          acc = ml_dense_mma8(avB, sGh, lane, 1, acc);
+          acc = ml_dense_mma8<SP>(avA, sGh, lane, 0, acc);
+          acc = ml_dense_mma8<SP>(avB, sGh, lane, 1, acc);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float* xp = sGx + el * ML_LD + 32 * t + 8 * q + 4 * hi;
@@ -1493,15 +1576,17 @@ int spk_schnet_mol_backward_ex(const spk_schnet_t* m, const spk_graph_t* g, cons
   MolBwdArgs a;
   a.R = R; a.offsets = offsets; a.gR = gR;
   if (head) a.head = *head; else { a.head.w1 = nullptr; a.head.w1t = nullptr; a.head.negate = 0; }
+  const bool split = spk_get_split() != 0;
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_schnet_layer_t& P = m->layers[l];
     MolBwdLayerDev& D = a.L[l];
-    D.in2f_t = spk_packed_of(ptab, P.in2f_w, 1);
-    D.o1_t = spk_packed_of(ptab, P.f2out_w1, 1);
-    D.o2_t = spk_packed_of(ptab, P.f2out_w2, 1);
+    D.in2f_t = split ? spk_packed_split_of(ptab, P.in2f_w, 1) : spk_packed_of(ptab, P.in2f_w, 1);
+    D.o1_t = split ? spk_packed_split_of(ptab, P.f2out_w1, 1) : spk_packed_of(ptab, P.f2out_w1, 1);
+    D.o2_t = split ? spk_packed_split_of(ptab, P.f2out_w2, 1) : spk_packed_of(ptab, P.f2out_w2, 1);
     SPK_CHECK_ARG(D.in2f_t && D.o1_t && D.o2_t, "spk_schnet_mol_backward: packed weight images missing");
     D.w1 = P.fn_w1; D.b1 = P.fn_b1; D.w2 = P.fn_w2;
+    D.w2_img = split ? ptab.extra_of(P.fn_w2) : nullptr;
   }
   a.gx_out = gx_out; a.gx0 = gx0; a.gr = gr; a.rij = r_ij; a.idx_i = g->idx_i; a.idx_j = g->idx_j;
   a.half = g->half; a.rev = g->rev; a.rowptr = g->rowptr; a.edge_pair = g->edge_pair; a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0;
