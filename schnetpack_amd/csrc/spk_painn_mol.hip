@@ -23,6 +23,7 @@
 #include "spk_common.h"
 #include "spk_pack.h"
 #include "spk_painn_mol.h"
+#include "spk_split.h"
 
 #define PM_MAXL 6
 #define PM_LD 132                 // row stride (floats) of the [32][128] tiles in LDS: conflict-free 16-byte accesses
@@ -67,6 +68,7 @@ struct PmFwdArgs {
   RadialDev rb;
   long long* dbg;           // tuning aid: cycle stamps of thread 0 of workgroup 0 (spk_painn_mol_set_debug_buffer; null in production)
   int assign;               // tuning: 0 = dynamic (default), 1 = snake over the waves, >= 20: static greedy with this cost per edge of the younger wave
+  int split;                // host side: 1 = a.L[] holds the SPLIT weight images, launch the SP instances (spk_split.h)
   int tiled;                // host side: 1 = launch the instance with the message on the matrix core (Gaussian bases; SPK_PM_TILED=0: row form)
 };
 #define PM_STAMP(n) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[n] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -90,7 +92,31 @@ __device__ __forceinline__ void pm_load8(f32x4 (&av)[8], const char* sb /* wave-
 }
 // (B operands are requested four groups ahead: left alone the compiler issues each ds_read right in front of the four MFMAs
 //  that need it -- zero prefetch distance, the matrix pipe waits ~100 cycles per group of four)
+// SP (spk_split.h): `av` holds eight chunks of the SPLIT weight image (chunk 2 s = the high parts of k-step s, 2 s + 1 its 2^11-scaled low
+// parts; same bytes and offsets as the fp32 image, k_pack_weight_split), the activations are read as eight consecutive fp32 values
+// per k-step (brow is the fp32 form's address, lane row + 4 hi: 4 hi more make it row + 8 hi) and split in registers; three f16
+// instructions per 16 k instead of eight f32 ones, the cross terms in their own accumulator, folded in at the end of the block.
+template <bool SP = false>
 __device__ __forceinline__ f32x16 pm_mma8(const f32x4 (&av)[8], const float* __restrict__ brow, f32x16 acc) {
+  if constexpr (SP) {
+    const float* b = brow + 4 * ((threadIdx.x >> 5) & 1);
+    f32x16 cx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cx[r] = 0.f;
+    f32x4 b0[4], b1[4];
+    b0[0] = *(const f32x4*)b; b1[0] = *(const f32x4*)(b + 4);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) { b0[s + 1] = *(const f32x4*)(b + 16 * (s + 1)); b1[s + 1] = *(const f32x4*)(b + 16 * (s + 1) + 4); asm volatile("" ::: "memory"); }
+      h16x4 h0, l0, h1, l1;
+      sp_split4(b0[s], h0, l0);
+      sp_split4(b1[s], h1, l1);
+      SP_STEP(__builtin_bit_cast(h16x8, av[2 * s]), __builtin_bit_cast(h16x8, av[2 * s + 1]), sp_cat(h0, h1), sp_cat(l0, l1), acc, cx);
+    }
+    SP_FOLD(acc, cx);
+    return acc;
+  }
   f32x4 bv[8];
 #pragma unroll
   for (int u = 0; u < 4; ++u) bv[u] = *(const f32x4*)(brow + 8 * u);
@@ -109,6 +135,7 @@ __device__ __forceinline__ f32x16 pm_mma8(const f32x4 (&av)[8], const float* __r
   return acc;
 }
 // 16 k-blocks (K = 128 of the image's row, starting at k-block kb0) against ONE LDS tile
+template <bool SP = false>
 __device__ __forceinline__ f32x16 pm_tile16(const float* __restrict__ wp, int KB, int t /* wave-uniform */, int kb0, const float* __restrict__ sB, int lane,
                                             f32x16 acc) {
   const char* sb = (const char*)wp + ((size_t)t * KB + kb0) * 1024;
@@ -116,23 +143,24 @@ __device__ __forceinline__ f32x16 pm_tile16(const float* __restrict__ wp, int KB
   f32x4 a0[8], a1[8];
   pm_load8(a0, sb, lane);
   pm_load8(a1, sb + 8 * 1024, lane);
-  acc = pm_mma8(a0, brow, acc);
-  acc = pm_mma8(a1, brow + 64, acc);
+  acc = pm_mma8<SP>(a0, brow, acc);
+  acc = pm_mma8<SP>(a1, brow + 64, acc);
   return acc;
 }
 // the same weights against the THREE component planes of mu (A operand shared: 96 MFMAs per 8 k-blocks)
+template <bool SP = false>
 __device__ __forceinline__ void pm_tile16x3(const float* __restrict__ wp, int t, const float* __restrict__ sB, int lane, f32x16& c0, f32x16& c1, f32x16& c2) {
   const char* sb = (const char*)wp + (size_t)t * 16 * 1024;
   const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
   f32x4 a0[8], a1[8];
   pm_load8(a0, sb, lane);
   pm_load8(a1, sb + 8 * 1024, lane);
-  c0 = pm_mma8(a0, brow, c0);
-  c1 = pm_mma8(a0, brow + PM_TILE, c1);
-  c2 = pm_mma8(a0, brow + 2 * PM_TILE, c2);
-  c0 = pm_mma8(a1, brow + 64, c0);
-  c1 = pm_mma8(a1, brow + PM_TILE + 64, c1);
-  c2 = pm_mma8(a1, brow + 2 * PM_TILE + 64, c2);
+  c0 = pm_mma8<SP>(a0, brow, c0);
+  c1 = pm_mma8<SP>(a0, brow + PM_TILE, c1);
+  c2 = pm_mma8<SP>(a0, brow + 2 * PM_TILE, c2);
+  c0 = pm_mma8<SP>(a1, brow + 64, c0);
+  c1 = pm_mma8<SP>(a1, brow + PM_TILE + 64, c1);
+  c2 = pm_mma8<SP>(a1, brow + 2 * PM_TILE + 64, c2);
 }
 __device__ __forceinline__ f32x16 pm_bias_acc(const float* __restrict__ b, int t, int hi) {
   f32x16 acc;
@@ -169,35 +197,38 @@ __device__ __forceinline__ void pm_wload(PmW& W, const float* __restrict__ wp, i
   pm_load8(W.a0, W.sb, lane);
 }
 // 16 k-blocks against one LDS tile
+template <bool SP = false>
 __device__ __forceinline__ f32x16 pm_wmma(const PmW& W, const float* __restrict__ sB, int lane, f32x16 acc) {
   const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
   f32x4 a1[8];
   pm_load8(a1, W.sb + 8 * 1024, lane);
-  acc = pm_mma8(W.a0, brow, acc);
-  acc = pm_mma8(a1, brow + 64, acc);
+  acc = pm_mma8<SP>(W.a0, brow, acc);
+  acc = pm_mma8<SP>(a1, brow + 64, acc);
   return acc;
 }
 // 16 k-blocks, the same weights against the three component planes of an LDS tensor
+template <bool SP = false>
 __device__ __forceinline__ void pm_wmma3(const PmW& W, const float* __restrict__ sB, int lane, f32x16& c0, f32x16& c1, f32x16& c2) {
   const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
   f32x4 a1[8];
   pm_load8(a1, W.sb + 8 * 1024, lane);
-  c0 = pm_mma8(W.a0, brow, c0);
-  c1 = pm_mma8(W.a0, brow + PM_TILE, c1);
-  c2 = pm_mma8(W.a0, brow + 2 * PM_TILE, c2);
-  c0 = pm_mma8(a1, brow + 64, c0);
-  c1 = pm_mma8(a1, brow + PM_TILE + 64, c1);
-  c2 = pm_mma8(a1, brow + 2 * PM_TILE + 64, c2);
+  c0 = pm_mma8<SP>(W.a0, brow, c0);
+  c1 = pm_mma8<SP>(W.a0, brow + PM_TILE, c1);
+  c2 = pm_mma8<SP>(W.a0, brow + 2 * PM_TILE, c2);
+  c0 = pm_mma8<SP>(a1, brow + 64, c0);
+  c1 = pm_mma8<SP>(a1, brow + PM_TILE + 64, c1);
+  c2 = pm_mma8<SP>(a1, brow + 2 * PM_TILE + 64, c2);
 }
 // 24 k-blocks against three half tiles (b0, b1, b2: LDS addresses of the lane's row, k offset included)
+template <bool SP = false>
 __device__ __forceinline__ f32x16 pm_wmma_3chunks(const PmW& W, const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2, int lane,
                                                   f32x16 acc) {
   f32x4 a1[8], a2[8];
   pm_load8(a1, W.sb + 8 * 1024, lane);
-  acc = pm_mma8(W.a0, b0, acc);
+  acc = pm_mma8<SP>(W.a0, b0, acc);
   pm_load8(a2, W.sb + 16 * 1024, lane);
-  acc = pm_mma8(a1, b1, acc);
-  acc = pm_mma8(a2, b2, acc);
+  acc = pm_mma8<SP>(a1, b1, acc);
+  acc = pm_mma8<SP>(a2, b2, acc);
   return acc;
 }
 // a whole tile in registers (the W_mix^T half tile that serves the three components of M4)
@@ -207,10 +238,11 @@ __device__ __forceinline__ void pm_wfload(PmWF& W, const float* __restrict__ wp,
   pm_load8(W.a0, sb, lane);
   pm_load8(W.a1, sb + 8 * 1024, lane);
 }
+template <bool SP = false>
 __device__ __forceinline__ f32x16 pm_wfmma(const PmWF& W, const float* __restrict__ sB, int lane, f32x16 acc) {
   const float* brow = sB + (lane & 31) * PM_LD + 4 * (lane >> 5);
-  acc = pm_mma8(W.a0, brow, acc);
-  acc = pm_mma8(W.a1, brow + 64, acc);
+  acc = pm_mma8<SP>(W.a0, brow, acc);
+  acc = pm_mma8<SP>(W.a1, brow + 64, acc);
   return acc;
 }
 
@@ -605,7 +637,7 @@ __device__ __forceinline__ void pm_message_tiled_write(float* __restrict__ sMu, 
 // an epilogue could not be waited for before those stores were acknowledged.
 // The two teams of four waves (wave t of a team = SIMD t) run DIFFERENT code paths with the same sequence of barriers: the register
 // allocation of a path then only sees what that team keeps alive (team 0: V / W / sum V W across P4-P6; team 1: the K = 256 tile).
-template <int K, bool TILED, bool POT>      // K = n_rbf (a multiple of 4, <= PM_NRBF): the register-resident filter weights are indexed statically; TILED: message on the matrix core (Gaussian bases); POT: the standard potential
+template <int K, bool TILED, bool POT, bool SP>      // K = n_rbf (a multiple of 4, <= PM_NRBF): the register-resident filter weights are indexed statically; TILED: message on the matrix core (Gaussian bases); POT: the standard potential; SP: Dense phases on the split-precision matrix path (split weight images)
 __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
   constexpr int F = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -710,7 +742,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         const int* sTile = (const int*)sPhi;
         // ---- P1: pre_a = W_a1 q + b (saved), silu -> sH
         {
-          f32x16 acc = pm_wmma(Wt, sQ, lane, bz);
+          f32x16 acc = pm_wmma<SP>(Wt, sQ, lane, bz);
           pm_wload(Wt, P.ctx2_p, 16, t, 0, lane); bz = pm_bias_acc(P.ctx2_b, t, hi);
           float* preA_g = S;
 #pragma unroll
@@ -727,7 +759,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         PmTW<K> TW;
         {
           float* c_g = S + nf;
-          f32x16 acc = pm_wmma(Wt, sH, lane, bz);
+          f32x16 acc = pm_wmma<SP>(Wt, sH, lane, bz);
           pm_wload(Wt, P.ctx2_p, 16, 8 + t, 0, lane); bz = pm_bias_acc(P.ctx2_b, 8 + t, hi);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -737,7 +769,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
           }
           if (tiled) pm_tw_load<K>(TW, P.wf, P.bf, t, lane, l == 0);
           else pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);
-          acc = pm_wmma(Wt, sH, lane, bz);
+          acc = pm_wmma<SP>(Wt, sH, lane, bz);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -777,7 +809,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { V0[r] = 0.f; V1[r] = 0.f; V2[r] = 0.f; W0[r] = 0.f; W1[r] = 0.f; W2[r] = 0.f; }
-          pm_wmma3(Wt, sMu, lane, V0, V1, V2);
+          pm_wmma3<SP>(Wt, sMu, lane, V0, V1, V2);
           pm_wload(Wt, P.mix_p, 16, 4 + t, 0, lane);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -794,7 +826,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         PM_STAMP(6 + 8 * l);
         // ---- P5: W = mu W_mix^T[F:] (beside team 1's pre_b on the same SIMD); sum_x V W; mix saved
         {
-          pm_wmma3(Wt, sMu, lane, W0, W1, W2);
+          pm_wmma3<SP>(Wt, sMu, lane, W0, W1, W2);
           pm_wload(Wt, P.ic2_p, 16, 8 + t, 0, lane); bz = pm_bias_acc(P.ic2_b, 8 + t, hi);
 #pragma unroll
           for (int r = 0; r < 16; ++r) sVW[r] = V0[r] * W0[r] + V1[r] * W1[r] + V2[r] * W2[r];
@@ -817,7 +849,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         // ---- P6: a = W_b2 silu(pre_b) + b (saved);  q += a_q + a_qmu sum_x V W;  mu += a_mu W      (painn.py:110-116)
         {
           float* ag = S + 14 * nf + (size_t)a0 * 3 * F + 32 * t;
-          f32x16 tq = pm_wmma(Wt, sH, lane, bz);                       // a_qmu
+          f32x16 tq = pm_wmma<SP>(Wt, sH, lane, bz);                       // a_qmu
           pm_wload(Wt, P.ic2_p, 16, t, 0, lane); bz = pm_bias_acc(P.ic2_b, t, hi);
           if (el < na) {
 #pragma unroll
@@ -826,7 +858,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) tq[r] *= sVW[r];
-          f32x16 aq = pm_wmma(Wt, sH, lane, bz);                       // a_q
+          f32x16 aq = pm_wmma<SP>(Wt, sH, lane, bz);                       // a_q
           pm_wload(Wt, P.ic2_p, 16, 4 + t, 0, lane); bz = pm_bias_acc(P.ic2_b, 4 + t, hi);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -841,7 +873,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
               if (last) pm_st<f32x4>(a.q_out + (size_t)a0 * F + 32 * t, (unsigned)((el * F + 8 * q + 4 * hi) * 4), qv);
             }
           }
-          f32x16 am = pm_wmma(Wt, sH, lane, bz);                       // a_mu
+          f32x16 am = pm_wmma<SP>(Wt, sH, lane, bz);                       // a_mu
           if (!last) { pm_wload(Wt, a.L[l + 1].ctx1_p, 16, t, 0, lane); bz = pm_bias_acc(a.L[l + 1].ctx1_b, t, hi); }
           float* mn = mu_next_g + (size_t)a0 * 3 * F + 32 * t;
 #pragma unroll
@@ -893,7 +925,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
           float* c_g = S + nf;
           if (tiled) pm_tw_load<K>(TW, P.wf, P.bf, t, lane, l == 0);
           else pm_filt_load<K>(Wf, P.wf, P.bf, lane, l == 0);          // (requested before the MFMAs of the tile: they arrive meanwhile)
-          f32x16 acc = pm_wmma(Wt, sH, lane, bz);
+          f32x16 acc = pm_wmma<SP>(Wt, sH, lane, bz);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 cv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -930,8 +962,8 @@ __global__ __launch_bounds__(512) void k_painn_mol_fwd(PmFwdArgs a) {
         // ---- P5: pre_b = W_b1 [q | |V|] + b (K = 256; saved), silu -> sH
         {
           float* preB_g = S + 13 * nf;
-          f32x16 acc = pm_wmma(Wt, sQ, lane, bz);
-          acc = pm_wmma(Wu, sN, lane, acc);
+          f32x16 acc = pm_wmma<SP>(Wt, sQ, lane, bz);
+          acc = pm_wmma<SP>(Wu, sN, lane, acc);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 pv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -1061,6 +1093,7 @@ struct PmBwdArgs {
   const float* rij;
   const int32_t* rev;       // POT: reverse edge of every edge (symmetric list); rij, gq_out = pair vectors and dL/dq_L written by the forward launch
   float* forces;            // POT: [N, 3] = -dE/dR, written instead of gr
+  int split;                // host side: 1 = a.L[] holds the SPLIT weight images, launch the SP instances
   const int64_t* idx_j;
   const int32_t* rowptr;
   const int32_t* grp_atom0;
@@ -1313,7 +1346,7 @@ __device__ __forceinline__ void pm_pot_forces(const float* sG, const int* sRow, 
   }
 }
 
-template <int K, bool POT>
+template <int K, bool POT, bool SP>
 __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
   constexpr int F = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1436,7 +1469,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = pm_wmma_3chunks(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
+        acc = pm_wmma_3chunks<SP>(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
         if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(acc[0])); a.dbg[64 + 40] = (long long)__builtin_readcyclecounter(); }
         if (a.dbg && blockIdx.x == 0 && lane == 0 && l == a.n_layers - 1) { asm volatile("s_nop 0" :: "v"(acc[0])); a.dbg[64 + 44 + wv] = (long long)__builtin_readcyclecounter(); }
         if (team == 0) pm_split_send<0>(X2, acc, el, t, hi);
@@ -1459,7 +1492,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = pm_wmma(Wn, X2, lane, acc);
+        acc = pm_wmma<SP>(Wn, X2, lane, acc);
         float* dst = team ? X0 : sGq;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1521,7 +1554,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = pm_wfmma(Wm, team ? X2 : X1, lane, acc);
+        acc = pm_wfmma<SP>(Wm, team ? X2 : X1, lane, acc);
         // (the two K halves meet through X0 -- g_nv is in registers by now: each team hands the partner half a tile and adds the other
         //  half into gmu_x; two barriers per component instead of three, nobody idle in the epilogue)
         if (team == 0) pm_split_send<0>(X0, acc, el, t, hi);
@@ -1605,7 +1638,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = pm_wmma_3chunks(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
+        acc = pm_wmma_3chunks<SP>(W3, b0 + bo, b1 + bo, b2 + bo, lane, acc);
         if (team == 0) pm_split_send<0>(X3, acc, el, t, hi);
         else pm_split_send<2>(X3, acc, el, t, hi);
         PM_BARRIER();
@@ -1619,7 +1652,7 @@ __global__ __launch_bounds__(512) void k_painn_mol_bwd(PmBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = pm_wmma(Wn, X3, lane, acc);
+        acc = pm_wmma<SP>(Wn, X3, lane, acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float* xp = sGq + el * PM_LD + 32 * t + 8 * q + 4 * hi;
@@ -1666,10 +1699,10 @@ bool spk_painn_mol_eligible(const spk_painn_t* m, const spk_graph_t* g, const sp
   return true;
 }
 
-template <int K, bool TILED, bool POT>
+template <int K, bool TILED, bool POT, bool SP = false>
 static int launch_painn_mol_fwd_t(const PmFwdArgs& a, hipStream_t stream) {
   const size_t lds = painn_mol_fwd_lds();
-  auto kern = k_painn_mol_fwd<K, TILED, POT>;
+  auto kern = k_painn_mol_fwd<K, TILED, POT, SP>;
   static SpkPerDevice attr_set;
   int attr_dev;
   if (attr_set.pending(&attr_dev)) {
@@ -1686,6 +1719,10 @@ static int launch_painn_mol_fwd_t(const PmFwdArgs& a, hipStream_t stream) {
 }
 template <int K>
 static int launch_painn_mol_fwd(const PmFwdArgs& a, hipStream_t stream) {
+  if (a.split) {      // (the caller put the split weight images into a.L[]; the tile-form experiment keeps the fp32 images)
+    if (a.R) return launch_painn_mol_fwd_t<K, false, true, true>(a, stream);
+    return launch_painn_mol_fwd_t<K, false, false, true>(a, stream);
+  }
   if (a.R) return launch_painn_mol_fwd_t<K, false, true>(a, stream);          // the standard potential
   return a.tiled ? launch_painn_mol_fwd_t<K, true, false>(a, stream) : launch_painn_mol_fwd_t<K, false, false>(a, stream);
 }
@@ -1702,14 +1739,20 @@ int spk_painn_mol_forward_ex(const spk_painn_t* m, const spk_graph_t* g, const s
   if (head) a.head = *head; else { a.head = PmHeadDev(); }
   SPK_CHECK_ARG(!R || (head->H == 64 && head->w1 && head->b1 && head->w2 && head->idx_m && head->E && head->pre_h && (q0 || (emb && Z))), "spk_painn_mol_forward: incomplete potential arguments");
   a.n_layers = m->n_interactions;
+  // the matrix-core form of the message is an EXPERIMENT, off by default (SPK_PM_TILED=1): correct (the parity tests run it), but
+  // 214 us against 197 us of the row form at cfg 3 -- see the comment at pm_message_tiled and DESIGN.md 4.3a
+  { const char* e = getenv("SPK_PM_TILED"); a.tiled = (e && e[0] == '1' && rb->kind == SPK_RBF_GAUSSIAN) ? 1 : 0; }
+  const bool split = spk_get_split() != 0 && !(a.tiled && !R);
+  a.split = split ? 1 : 0;
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_painn_layer_t& P = m->layers[l];
     PmLayerDev& D = a.L[l];
-    D.ctx1_p = spk_packed_of(ptab, P.ctx_w1, 0); D.ctx1_b = P.ctx_b1;
-    D.ctx2_p = spk_packed_of(ptab, P.ctx_w2, 0); D.ctx2_b = P.ctx_b2;
-    D.mix_p = spk_packed_of(ptab, P.mix_w, 0);
-    D.ic1_p = spk_packed_of(ptab, P.ictx_w1, 0); D.ic1_b = P.ictx_b1;
-    D.ic2_p = spk_packed_of(ptab, P.ictx_w2, 0); D.ic2_b = P.ictx_b2;
+    auto img = [&](const float* w) { return split ? spk_packed_split_of(ptab, w, 0) : spk_packed_of(ptab, w, 0); };
+    D.ctx1_p = img(P.ctx_w1); D.ctx1_b = P.ctx_b1;
+    D.ctx2_p = img(P.ctx_w2); D.ctx2_b = P.ctx_b2;
+    D.mix_p = img(P.mix_w);
+    D.ic1_p = img(P.ictx_w1); D.ic1_b = P.ictx_b1;
+    D.ic2_p = img(P.ictx_w2); D.ic2_b = P.ictx_b2;
     D.wf = P.filt_w; D.bf = P.filt_b;
     SPK_CHECK_ARG(D.ctx1_p && D.ctx2_p && D.mix_p && D.ic1_p && D.ic2_p, "spk_painn_mol_forward: packed weight image missing");
     SPK_CHECK_ARG(D.ctx1_b && D.ctx2_b && D.ic1_b && D.ic2_b && D.wf && D.bf, "spk_painn_mol_forward: null bias / filter weights");
@@ -1717,9 +1760,6 @@ int spk_painn_mol_forward_ex(const spk_painn_t* m, const spk_graph_t* g, const s
   a.q0 = q0; a.q_out = q_out; a.mu_out = mu_out; a.rij = r_ij;
   a.idx_j = g->idx_j; a.rowptr = g->rowptr; a.grp_atom0 = g->grp_atom0; a.n_groups = g->n_groups;
   a.saved = saved; a.N = g->n_atoms; a.eps = m->epsilon; a.rb = spk_radial_dev(rb); a.dbg = g_pm_dbg; a.assign = pm_assign_mode();
-  // the matrix-core form of the message is an EXPERIMENT, off by default (SPK_PM_TILED=1): correct (the parity tests run it), but
-  // 214 us against 197 us of the row form at cfg 3 -- see the comment at pm_message_tiled and DESIGN.md 4.3a
-  { const char* e = getenv("SPK_PM_TILED"); a.tiled = (e && e[0] == '1' && rb->kind == SPK_RBF_GAUSSIAN) ? 1 : 0; }
   switch (rb->n_rbf) {
     case 20: return launch_painn_mol_fwd<20>(a, stream);
     case 16: return launch_painn_mol_fwd<16>(a, stream);
@@ -1745,10 +1785,10 @@ bool spk_painn_mol_bwd_eligible(const spk_painn_t* m, const spk_graph_t* g, cons
   return g->symmetric != 0;
 }
 
-template <int K, bool POT>
+template <int K, bool POT, bool SP = false>
 static int launch_painn_mol_bwd_t(const PmBwdArgs& a, hipStream_t stream) {
   const size_t lds = painn_mol_bwd_lds();
-  auto kern = k_painn_mol_bwd<K, POT>;
+  auto kern = k_painn_mol_bwd<K, POT, SP>;
   static SpkPerDevice attr_set;
   int attr_dev;
   if (attr_set.pending(&attr_dev)) {
@@ -1766,6 +1806,7 @@ static int launch_painn_mol_bwd_t(const PmBwdArgs& a, hipStream_t stream) {
 
 template <int K>
 static int launch_painn_mol_bwd(const PmBwdArgs& a, hipStream_t stream) {
+  if (a.split) return a.forces ? launch_painn_mol_bwd_t<K, true, true>(a, stream) : launch_painn_mol_bwd_t<K, false, true>(a, stream);
   return a.forces ? launch_painn_mol_bwd_t<K, true>(a, stream) : launch_painn_mol_bwd_t<K, false>(a, stream);
 }
 
@@ -1777,16 +1818,19 @@ int spk_painn_mol_backward_ex(const spk_painn_t* m, const spk_graph_t* g, const 
                               float* gc_scratch, float* gr, float* gq0, float* forces, hipStream_t stream) {
   PmBwdArgs a;
   a.rev = g->rev; a.forces = forces;
+  const bool split = spk_get_split() != 0;
+  a.split = split ? 1 : 0;
   SPK_CHECK_ARG(!forces || (g->rev && r_ij && gq_out && !gr && !gq0), "spk_painn_mol_backward: incomplete potential arguments");
   a.n_layers = m->n_interactions;
   for (int l = 0; l < m->n_interactions; ++l) {
     const spk_painn_layer_t& P = m->layers[l];
     PmLayerBwd& D = a.L[l];
-    D.ic2T_p = spk_packed_of(ptab, P.ictx_w2, 1);
-    D.ic1T_p = spk_packed_of(ptab, P.ictx_w1, 1);
-    D.mixT_p = spk_packed_of(ptab, P.mix_w, 1);
-    D.ctx2T_p = spk_packed_of(ptab, P.ctx_w2, 1);
-    D.ctx1T_p = spk_packed_of(ptab, P.ctx_w1, 1);
+    auto img = [&](const float* w) { return split ? spk_packed_split_of(ptab, w, 1) : spk_packed_of(ptab, w, 1); };
+    D.ic2T_p = img(P.ictx_w2);
+    D.ic1T_p = img(P.ictx_w1);
+    D.mixT_p = img(P.mix_w);
+    D.ctx2T_p = img(P.ctx_w2);
+    D.ctx1T_p = img(P.ctx_w1);
     D.wf = P.filt_w; D.bf = P.filt_b;
     SPK_CHECK_ARG(D.ic2T_p && D.ic1T_p && D.mixT_p && D.ctx2T_p && D.ctx1T_p && D.wf && D.bf, "spk_painn_mol_backward: packed weight image missing");
   }
