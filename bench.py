@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # same guide: dense f16 / bf16 matrix peak (16 x the fp32 matrix rate); the split-precision path spends 3 f16 products per fp32 product
 HBM_PEAK_GBS = 8000.0          # same guide, HBM3E spec peak
 RAMP_S = 0.15                  # untimed clock ramp in front of the warm-up steps of the eval legs (seconds of replays)
 
@@ -104,8 +105,11 @@ def compact_roofline(rf, brief=False):
     if isinstance(out.get("kernel"), str):
         out["kernel"] = out["kernel"][:48]
     out["traffic"] = _sig(rf.get("traffic"))
-    out.update(_pick(rf, ("avg_launch_us", "frac_by_convention", "issued_frac_of_peak", "mfma_busy_frac", "traffic_over_B_min")))
+    out.update(_pick(rf, ("avg_launch_us", "frac_by_convention", "issued_frac_of_peak", "mfma_busy_frac", "traffic_over_B_min", "frac_of_split_path_roof")))
+    if isinstance(rf.get("mfma_inputs"), str):
+        out["mfma_inputs"] = "f16x2" if rf["mfma_inputs"].startswith("f16x2") else "f32"
     if not brief:
+        out.update(_pick(rf, ("peak_split_path",)))
         out.update(_pick(rf, ("algorithmic_per_launch", "algorithmic_per_step", "achieved_by_convention", "executed_frac_of_peak", "issued_over_useful",
                               "B_min_bytes_per_launch")))
     m = rf.get("measured")
@@ -155,7 +159,8 @@ def compact_line(full, detail_path):
     cfg = full.get("config") or {}
     line["config"] = dict(_pick(cfg, ("workload", "model", "n_atoms", "n_edges", "frames_per_s", "parallelism", "world_size", "backend", "hip_graph", "variant", "ramp_s",
                                       "multi_gpu_measured", "beads", "beads_per_rank", "thermostat", "collectives_per_step", "trajectories_per_gpu",
-                                      "aggregate_ns_per_day", "kinetic_temperature_K", "first_loss", "last_loss", "allreduce_between_graphs")))
+                                      "aggregate_ns_per_day", "kinetic_temperature_K", "first_loss", "last_loss", "allreduce_between_graphs",
+                                      "allreduce_calls_timed", "allreduce_buffer_is_flat_bucket", "split_precision_matrix_path", "water_atoms", "water_pairs")))
     if full.get("launches_per_step") is not None:
         line["launches_per_step"] = full["launches_per_step"]
     if isinstance(line["config"].get("workload"), str) and len(line["config"]["workload"]) > 100:
@@ -163,6 +168,10 @@ def compact_line(full, detail_path):
     if isinstance(line["config"].get("parallelism"), str):
         line["config"]["parallelism"] = line["config"]["parallelism"][:64]
     line["roofline"] = compact_roofline(full.get("roofline"))
+    plw = full.get("parity_ledger_worst")
+    if isinstance(plw, dict) and isinstance(plw.get("worst_of_the_1e-5_comparisons"), dict):
+        w_ = plw["worst_of_the_1e-5_comparisons"]
+        line["parity_ledger_worst"] = {"quantity": w_["quantity"], "fixture": str(w_["fixture"])[:40], "value": _sig(w_["value"]), "bound": w_["bound"], "records": plw.get("records")}
     line["cpu_baseline"] = compact_cpu(full.get("cpu_baseline"))
     if full.get("painn") is not None:
         line["painn"] = compact_leg(full["painn"])
@@ -289,6 +298,34 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def parity_ledger_worst():
+    """Worst record of the last parity ledger the GPU test-suite wrote (tests/conftest.py::record_parity -> gpurun_out/parity_ledger.json, copied to
+    profiles/rNN_parity_ledger.json): which quantity of which fixture came closest to north_star's 1e-5."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_ledger.json")))
+    live = os.path.join(ROOT, "gpurun_out", "parity_ledger.json")
+    path = live if os.path.exists(live) else (cands[-1] if cands else None)
+    if path is None:
+        return None
+    try:
+        led = json.load(open(path))
+        recs = led["records"] if isinstance(led, dict) else led
+        # the closest approach to ITS OWN bound decides (the 1e-5 comparisons of energies / forces / representations and the looser weight-gradient ones)
+        worst, worst_1e5 = None, None
+        for r in recs:
+            v, tol = r.get("max_rel"), r.get("tolerance")
+            if not isinstance(v, (int, float)) or not tol:
+                continue
+            if worst is None or v / tol > worst["max_rel"] / worst["tolerance"]:
+                worst = r
+            if tol <= 1e-5 and (worst_1e5 is None or v > worst_1e5["max_rel"]):
+                worst_1e5 = r
+        pick = lambda r: None if r is None else {"quantity": r["quantity"], "fixture": r["fixture"], "variant": r["variant"], "value": r["max_rel"], "bound": r["tolerance"]}
+        return {"closest_to_its_bound": pick(worst), "worst_of_the_1e-5_comparisons": pick(worst_1e5), "records": len(recs), "source": os.path.relpath(path, ROOT)}
+    except Exception as exc:  # pragma: no cover
+        return {"error": str(exc)[:120]}
+
+
 def collect_pmc(args, kind, workload, timeout_s=170):
     """HBM-side traffic AND matrix-core work per launch of every hot kernel, measured IN THIS RUN: three `rocprofv3 --pmc` passes
     (FETCH_SIZE and WRITE_SIZE do not share a pass on gfx950; the third carries SQ_INSTS_VALU_MFMA_MOPS_F32, SQ_VALU_MFMA_BUSY_CYCLES
@@ -308,7 +345,9 @@ def collect_pmc(args, kind, workload, timeout_s=170):
     res = {}
     tmp = tempfile.mkdtemp(prefix="spk_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
+        # (round 6: the split-precision path issues v_mfma_f32_32x32x16_f16 -- counted by SQ_INSTS_VALU_MFMA_MOPS_F16, same 512-FLOP unit --
+        #  next to the fp32 instructions of the phases that stayed on v_mfma_f32_32x32x2_f32)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
             out = os.path.join(tmp, counter.split()[0])
             cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc"] + counter.split() + ["-d", out, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--kind", kind, "--workload", workload,
@@ -357,7 +396,8 @@ def collect_pmc(args, kind, workload, timeout_s=170):
                     elif cname == "WRITE_SIZE":
                         r["write_bytes"] = 1024.0 * per
                     else:
-                        r[{"SQ_INSTS_VALU_MFMA_MOPS_F32": "mfma_mops", "SQ_VALU_MFMA_BUSY_CYCLES": "mfma_busy_cycles", "GRBM_GUI_ACTIVE": "gui_active"}[cname]] = per
+                        r[{"SQ_INSTS_VALU_MFMA_MOPS_F32": "mfma_mops", "SQ_INSTS_VALU_MFMA_MOPS_F16": "mfma_mops_f16", "SQ_VALU_MFMA_BUSY_CYCLES": "mfma_busy_cycles",
+                           "GRBM_GUI_ACTIVE": "gui_active"}[cname]] = per
                     r["launches_" + cname] = len(vals)
                 if counter.startswith("SQ_"):
                     # MFMA-pipe busy share per dispatch, two normalisations: GRBM_GUI_ACTIVE (summed over the 8 XCDs) and the dispatch's own duration at the
@@ -794,8 +834,14 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
             if "read_bytes" in c and "write_bytes" in c:
                 meas["hbm_bytes"] = c["read_bytes"] + c["write_bytes"]
                 meas["hbm_frac_of_peak"] = round(meas["hbm_bytes"] / sec / (HBM_PEAK_GBS * 1e9), 4)
+            if c.get("mfma_mops_f16"):
+                # split-precision path: three f16 products stand for one fp32 product, so the issued f16 FLOP / 3 are the fp32-equivalent
+                # ("logical") FLOP of the split phases; their own roof is the dense f16 peak
+                meas["mfma_f16_flop_issued"] = 512.0 * c["mfma_mops_f16"]
+                meas["mfma_f16_frac_of_f16_peak"] = round(meas["mfma_f16_flop_issued"] / sec / (MFMA_F16_PEAK_TFLOPS * 1e12), 4)
             if "mfma_mops" in c:
-                meas["mfma_flop_issued"] = 512.0 * c["mfma_mops"]
+                meas["mfma_f32_flop_issued"] = 512.0 * c["mfma_mops"]
+                meas["mfma_flop_issued"] = 512.0 * c["mfma_mops"] + 512.0 * c.get("mfma_mops_f16", 0.0) / 3.0      # fp32-equivalent
                 meas["mfma_frac_of_peak"] = round(meas["mfma_flop_issued"] / sec / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
                 if tag in algo and algo[tag][0] == "mfma":
                     useful = algo[tag][1] * algo[tag][2]
@@ -809,8 +855,16 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
                 if clk is not None:
                     meas["implied_clock_ghz"] = round(clk, 3)
             hf, mf = meas.get("hbm_frac_of_peak"), meas.get("mfma_frac_of_peak")
-            if hf is not None and mf is not None:
-                meas["bound_measured"] = "latency/valu" if max(hf, mf) < 0.5 else ("mfma" if mf >= hf else "hbm")
+            if meas.get("mfma_f16_flop_issued", 0.0) > meas.get("mfma_f32_flop_issued", 0.0):
+                # the launch ran (mostly) on the f16 instruction: how busy the matrix pipe was is its share of the f16 peak plus the fp32 share
+                meas["mfma_inputs"] = "f16x2"
+                mf_pipe = meas["mfma_f16_frac_of_f16_peak"] + meas.get("mfma_f32_flop_issued", 0.0) / sec / (MFMA_F32_PEAK_TFLOPS * 1e12)
+            else:
+                meas["mfma_inputs"] = "f32" if "mfma_mops" in c else None
+                mf_pipe = mf
+            if hf is not None and mf_pipe is not None:
+                meas["matrix_pipe_frac"] = round(mf_pipe, 4)
+                meas["bound_measured"] = "latency/valu" if max(hf, mf_pipe) < 0.5 else ("mfma" if mf_pipe >= hf else "hbm")
             kd["measured"] = meas
             # executed fraction: HBM-bound kernels -- the measured bytes; MFMA-bound kernels -- the ISSUED matrix-core work of the counters
             # divided by the issued / useful ratio where a model of the useful work exists (rows of padding in the 32-row tiles are issued,
@@ -870,6 +924,27 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
                                                   "record_is_current": rec.get("csrc_digest") == csrc_digest()}
             except Exception as exc:  # pragma: no cover
                 sys.stderr.write("[bench] could not read %s: %s\n" % (pmc_file, exc))
+
+    # which matrix instruction did the work (round 6): with the split-precision path on, the filter / Dense products of the fused kernels are
+    # three v_mfma_f32_32x32x16_f16 products of (high, low) fp16 operand pairs with fp32 accumulation per fp32 product -- fp32-quality
+    # results (csrc/spk_split.h; profiles/r06_split_mfma.md).  `dtype` stays f32; `frac` stays against the fp32 matrix peak (157.3 TF: the
+    # roof of the arithmetic the contract names); frac_of_split_path_roof puts the same executed work over the roof of the path that ran,
+    # dense f16 peak / 3 products.
+    if roofline is not None and roofline["bound"] == "mfma":
+        split_on = bool(_lib.get_split())
+        if isinstance(roofline.get("measured"), dict) and roofline["measured"].get("mfma_inputs"):
+            split_on = roofline["measured"]["mfma_inputs"] == "f16x2"        # what the counters of this launch say, not what the switch says
+        elif not any(t in roofline["kernel"] for t in ("schnet_mol", "painn_mol")):
+            split_on = False
+        roofline["mfma_inputs"] = ("f16x2 split: fp16 high + 2^-11-scaled fp16 low operand pairs, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate"
+                                   if split_on else "f32 (v_mfma_f32_32x32x2_f32)")
+        if split_on:
+            roof = MFMA_F16_PEAK_TFLOPS / 3.0
+            useful = roofline.get("executed_frac_of_peak", roofline["frac"]) * MFMA_F32_PEAK_TFLOPS
+            roofline["peak_split_path"] = round(roof, 1)
+            roofline["frac_of_split_path_roof"] = round(useful / roof, 4)
+            roofline["split_note"] = ("executed fp32-equivalent TFLOP/s (= frac x 157.3) over 2500 / 3 TFLOP/s; phases that stayed on the fp32 instruction "
+                                      "(in2f beside the first pair tile, the energy head) are booked at the same roof")
 
     # context for `roofline` (which, per contract, is about the dominant launch): every launch of one force call with an algorithmic-work
     # model over the wall time of the call
@@ -1152,7 +1227,24 @@ def main():
         torch.cuda.synchronize()
         t_nl.append(time.perf_counter() - c0)
     t_nl.sort()
-    nbl = {"pairs": int(nl["_idx_i"].shape[0]), "matches_input_list": int(nl["_idx_i"].shape[0]) == E,
+    # bit-exact comparison with the list the workload was built with (north_star: "neighbour indices bit-exact"): both lists in the
+    # canonical order (idx_i, idx_j, image shift), indices and integer image shifts compared with torch.equal -- not a pair count
+    def _canonical(ii, jj, off):
+        if nl_cell is not None:
+            sh = torch.round(off.double() @ torch.linalg.inv(nl_cell[0].double())).to(torch.int64)
+        else:
+            sh = torch.zeros(ii.shape[0], 3, dtype=torch.int64, device=ii.device)
+        key = ((ii.to(torch.int64) * int(inp["_positions"].shape[0]) + jj.to(torch.int64)) * 27 + (sh[:, 0] + 1) * 9 + (sh[:, 1] + 1) * 3 + (sh[:, 2] + 1))
+        order = torch.argsort(key, stable=True)
+        return ii[order].to(torch.int64), jj[order].to(torch.int64), sh[order]
+    try:
+        nl_full = NL.neighbor_list(inp["_positions"].detach(), cutoff, **nl_kw)
+        ca = _canonical(nl_full["_idx_i"], nl_full["_idx_j"], nl_full["_offsets"])
+        cb = _canonical(inp["_idx_i"], inp["_idx_j"], inp["_offsets"])
+        nl_exact = bool(ca[0].shape == cb[0].shape and all(torch.equal(x, y) for x, y in zip(ca, cb)))
+    except Exception as exc:  # pragma: no cover
+        nl_exact = "error: %s" % str(exc)[:120]
+    nbl = {"pairs": int(nl["_idx_i"].shape[0]), "matches_input_list": nl_exact, "pair_count_matches": int(nl["_idx_i"].shape[0]) == E,
            "build_ms": round(1e3 * t_nl[len(t_nl) // 2], 4), "M_pairs_per_s": round(E / t_nl[len(t_nl) // 2] / 1e6, 1),
            "note": "count + fill incl. allocation and the one D2H of the pair count (wall clock, median of 5)"}
     if cpu is not None and args.workload == "aspirin":
@@ -1192,7 +1284,7 @@ def main():
                     wm, w_rep, w_head = painn_model, p_rep, p_head
                 else:
                     wm, w_rep, w_head = model, rep_p, head_p
-                wr = eval_leg(args, k, "water", wm, w_rep, w_head, 0, 1, dev, None, 10, 2, with_pmc=True, with_cpu=(k == "painn"), cpu_reps=0)
+                wr = eval_leg(args, k, "water", wm, w_rep, w_head, 0, 1, dev, None, 10, 2, with_pmc=True, with_cpu=True, cpu_reps=0)
                 water[k] = {"metric": "M edge-messages/s (eval force call, 32k-atom bulk-water PBC box, %s)" % ("PaiNN" if k == "painn" else "SchNet"),
                             "value": round(wr["value"], 2), "unit": "M edge-messages/s", "ms_per_step": round(1e3 * wr["dt"] / wr["steps"], 4), "steps": wr["steps"],
                             "hip_graph": wr["graph"], "n_atoms": wr["N"], "n_edges": wr["E"], "ns_per_day_at_0.5fs_per_call": round(wr["steps"] / wr["dt"] * 0.5 * 86400e-6, 3),
@@ -1327,6 +1419,13 @@ def main():
         "kernels": kernels, "scatter_add": scatter, "neighbor_list": nbl, "molecule_cliff": cliff,
     }
     line["config"]["ramp_s"] = RAMP_S
+    line["config"]["split_precision_matrix_path"] = bool(_lib.get_split())
+    if isinstance(water, dict):
+        for k_ in ("painn", "schnet"):
+            if isinstance(water.get(k_), dict) and "n_atoms" in water[k_]:
+                line["config"]["water_atoms"], line["config"]["water_pairs"] = water[k_]["n_atoms"], water[k_]["n_edges"]      # 22^3 x 3 = 31 944 atoms (the survey's 32 001 is another lattice)
+                break
+    line["parity_ledger_worst"] = parity_ledger_worst()
     line["config"]["multi_gpu_measured"] = world > 1      # N > 1 has never run on hardware from this repo: the driver's SCALE run is the measurement
     emit(line, args.detail)
     if dist is not None:
@@ -1511,6 +1610,7 @@ def train_measure(args, kind, rank, world, dev, dist, model, rep_p, head_p, step
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    coll0 = reducer.collectives
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(i)
@@ -1519,6 +1619,8 @@ def train_measure(args, kind, rank, world, dev, dist, model, rep_p, head_p, step
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    coll_timed = reducer.collectives - coll0          # all-reduces of the flat bucket issued inside the timed region (parallel.FlatGradAllReduce._reduce)
+    coll_ptr_ok = reducer.last_reduced_ptr is not None and reducer.last_reduced_ptr == reducer.flat.data_ptr()
     tstep.check()
     if dist is not None:
         tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else torch.device("cpu"), dtype=torch.float64)
@@ -1631,7 +1733,8 @@ def train_measure(args, kind, rank, world, dev, dist, model, rep_p, head_p, step
                                % (args.train_frames, args.train_frames * world, kname, reducer.numel, emax, tstep.g_bwd is not None),
                    "parallelism": "dp%d" % world, "first_loss": losses[0], "last_loss": float(loss.detach()),
                    "world_size": world, "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
-                   "allreduce_between_graphs": tstep.g_opt is not None, "multi_gpu_measured": world > 1},
+                   "allreduce_between_graphs": tstep.g_opt is not None, "multi_gpu_measured": world > 1,
+                   "allreduce_calls_timed": coll_timed, "allreduce_floats": reducer.last_reduced_numel, "allreduce_buffer_is_flat_bucket": bool(coll_ptr_ok)},
         "launches_per_step": launches,
         "roofline": roofline, "cpu_baseline": cpu,
     }

@@ -240,6 +240,128 @@ def test_bead_parallel_pile_thermostat_world2_equals_single_process_oracle():
     assert torch.allclose(got.double(), p2, rtol=1e-5, atol=1e-5 * float(p2.abs().max()))
 
 
+# ------------------------------------------------------------------------------------------------ configs[4] as stated: 8 beads, one per rank
+def _bead8_problem():
+    g = torch.Generator().manual_seed(21)
+    return torch.randn(8, 5, 3, generator=g), torch.randn(8, 5, 3, generator=g), torch.rand(1, 5, 1, generator=g) * 10 + 1
+
+
+def _toy_forces(q):
+    """A bead-local force field (harmonic wells + a quartic term): stands in for the force call of a bead, which couples nothing
+    across beads (md/calculators/base_calculator.py:166-183 folds the beads into the batch dimension)."""
+    return -q - 0.1 * q ** 3
+
+
+def _bead8_worker(rank, world, port, q, exchange):
+    """One NVT ring-polymer step of configs[4] -- PILE-L, half kick, bead mixing, force call, half kick, PILE-L
+    (md/simulator.py:126-150, md/integrators.py:204-229, md/simulation_hooks/thermostats_rpmd.py:102-119) -- with ONE bead per rank.
+    exchange == "state": a rank holds only its bead; the thermostat applications and the bead mixing all-gather (3 collectives).
+    exchange == "forces": every rank integrates all 8 beads (counter-based noise keeps the replicas identical) and evaluates the
+    forces of its own bead only; the forces are all-gathered (1 collective).  The compute functions are the host restatements of
+    the HIP kernels (the kernels cannot run in this CPU test); the exchange logic is the product's."""
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import md_oracle as MDO
+    from schnetpack_amd.md import MDState, PILELocalThermostat, RingPolymer
+    Q, P, M = _bead8_problem()
+    B, dt = 8, 2e-4
+    count = {"n": 0}
+    real_gather = dist.all_gather_into_tensor
+
+    def counting_gather(*a, **k):
+        count["n"] += 1
+        return real_gather(*a, **k)
+    dist.all_gather_into_tensor = counting_gather
+
+    def ring_compute(q_all, p_all, masses, A, bead0, n_local):
+        A = A.double()
+        m = masses.reshape(1, -1, 1).double()
+        pn = torch.einsum("bn,nak->bak", A[0], p_all.double()) + m * torch.einsum("bn,nak->bak", A[1], q_all.double())
+        qn = torch.einsum("bn,nak->bak", A[2], p_all.double()) / m + torch.einsum("bn,nak->bak", A[3], q_all.double())
+        return qn[bead0:bead0 + n_local].float(), pn[bead0:bead0 + n_local].float()
+
+    def pile_compute(p_all, masses, Mx, noise_scale, seed, step, step_dev, which, bead0, n_local, out=None):
+        xi = MDO.pile_noise(p_all.shape[0], p_all.shape[1], seed, step, which)
+        det = torch.einsum("bn,nak->bak", Mx[0].double(), p_all.double())
+        noi = torch.einsum("bk,kat->bat", Mx[1].double(), xi)
+        res = det + torch.sqrt(masses.reshape(1, -1, 1).double()) * noise_scale * noi
+        return res[bead0:bead0 + n_local].float()
+
+    grp = dist.group.WORLD if exchange == "state" else None
+    rp = RingPolymer(dt, B, 300.0, omega=40.0, group=grp, compute_fn=ring_compute)
+    th = PILELocalThermostat(300.0, 100.0, seed=7, group=grp, compute_fn=pile_compute).init(rp)
+    lo, hi = (rank, rank + 1) if exchange == "state" else (0, B)
+    st = MDState(Q[lo:hi].clone(), P[lo:hi].clone(), M)
+    F = _toy_forces(st.positions)
+    th.apply(st, step=3, which=0)
+    st.momenta += 0.5 * dt * F
+    rp.main_step(st)
+    if exchange == "state":
+        F = _toy_forces(st.positions)
+    else:                                   # the sharded force call: own bead only, then ONE all-gather of [1, N, 3] per rank
+        mine = _toy_forces(st.positions[rank:rank + 1]).contiguous()
+        F = torch.empty_like(st.positions)
+        dist.all_gather_into_tensor(F.view(-1), mine.view(-1))
+    st.momenta += 0.5 * dt * F
+    th.apply(st, step=3, which=1)
+    q.put((rank, st.positions.tolist(), st.momenta.tolist(), count["n"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["state", "forces"])
+def test_configs4_eight_beads_one_per_rank_world8(exchange):
+    """BASELINE configs[4] -- 8 PIMD beads, one bead per GPU -- on 8 gloo ranks: both exchange schemes reproduce the single-process
+    NVT step of the oracle (reference formulae in float64, same Philox stream) and issue exactly the collectives DESIGN.md section 6
+    states: 3 all-gathers per step (state) or 1 (forces)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import md_oracle as MDO
+    from schnetpack_amd import md as MD
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bead8_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, qq, pp, ncoll = q.get(timeout=180)
+        res[rank] = (torch.tensor(qq), torch.tensor(pp), ncoll)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process oracle of the same step
+    Q, P, M = _bead8_problem()
+    B, dt = 8, 2e-4
+    C = MDO.normal_mode_matrix(B)
+    _, prop = MDO.ring_polymer_propagator(B, 40.0, dt)
+    c1, c2 = MDO.pile_coefficients(B, 40.0, dt, 0.1)
+    kT = MD.KB_MD * B * 300.0
+    qd, pd, md_ = Q.double(), P.double(), M.double()
+    F = _toy_forces(qd)
+    pd = MDO.pile_apply(pd, md_, C, c1, c2, kT, MDO.pile_noise(B, 5, 7, 3, 0))
+    pd = pd + 0.5 * dt * F
+    qd, pd = MDO.ring_polymer_main_step(qd, pd, md_, C, prop)
+    pd = pd + 0.5 * dt * _toy_forces(qd)
+    pd = MDO.pile_apply(pd, md_, C, c1, c2, kT, MDO.pile_noise(B, 5, 7, 3, 1))
+    if exchange == "state":
+        got_q = torch.cat([res[r][0] for r in range(world)])
+        got_p = torch.cat([res[r][1] for r in range(world)])
+        assert all(res[r][2] == 3 for r in range(world)), [res[r][2] for r in range(world)]
+    else:
+        got_q, got_p = res[0][0], res[0][1]
+        for r in range(1, world):              # the replicas stay bit-identical
+            assert torch.equal(res[r][0], got_q) and torch.equal(res[r][1], got_p)
+        assert all(res[r][2] == 1 for r in range(world)), [res[r][2] for r in range(world)]
+    assert torch.allclose(got_q.double(), qd, atol=1e-5) and torch.allclose(got_p.double(), pd, rtol=1e-5, atol=1e-5 * float(pd.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------ GraphedTrainStep: the two-graph split
 class _FakeGraph:
     """Stands in for torch.cuda.CUDAGraph on the build box: 'capture' records which of the step's pieces were issued inside it
