@@ -15,6 +15,7 @@ from . import _lib, properties
 from . import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 from .nn import Dense, build_mlp, scatter_add
 from .nn.base import activation_id
+from .nn.fallback import note_fallback, use_aten
 
 __all__ = ["PairwiseDistances", "Atomwise", "Forces"]
 
@@ -30,6 +31,11 @@ class PairwiseDistances(nn.Module):
             offsets = inputs[properties.offsets]
         idx_i = inputs[properties.idx_i]
         idx_j = inputs[properties.idx_j]
+        if use_aten(R):          # host / non-float32 tensors: the reference's formula (atomistic/distances.py:19-25)
+            note_fallback()
+            Rij = R[idx_j] - R[idx_i]
+            inputs[properties.Rij] = Rij + offsets if offsets is not None else Rij
+            return inputs
         inputs[properties.Rij] = torch.ops.spk_hip.pairwise(R, idx_i, idx_j, offsets)
         return inputs
 
@@ -97,7 +103,7 @@ class Atomwise(nn.Module):
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         x = inputs["scalar_representation"]
-        if self._fused_head and not self.training and x.dim() == 2:
+        if self._fused_head and not self.training and x.dim() == 2 and not use_aten(x):
             idx_m = inputs[properties.idx_m]
             maxm = self._n_molecules(inputs, idx_m)
             l0 = self.outnet[0]

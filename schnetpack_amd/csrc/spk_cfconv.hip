@@ -19,6 +19,8 @@
 // On a symmetric neighbour list W_e == W_{e'} for the reversed edge, so gh is again a row-local
 // segmented reduction (gather gy of the neighbours); otherwise float atomics on gh[j].
 #include "spk_common.h"
+#include "spk_split.h"
+#include "spk_filter_split.h"
 
 
 struct CfArgs {
@@ -909,6 +911,391 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_t(CfArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Split-precision forms of the two pair kernels that carry the box regime (round 6; spk_split.h, spk_filter_split.h; n_filters = 128):
+// the filter-network GEMMs as three v_mfma_f32_32x32x16_f16 products of (high, low) fp16 operand pairs with fp32 accumulation --
+// per 32-pair tile 24 + 96 f16 instructions (3.8 k cycles of matrix-pipe time) instead of 12 KPB + 256 f32 ones (19 k), same layouts,
+// same gathers, same accumulation of the results.  W1 / W2 are staged into LDS as split images (contraction index of W2 in accumulator
+// order: the hidden activations go from the accumulator registers of GEMM 1 into GEMM 2 as they lie).
+// ------------------------------------------------------------------------------------------
+// forward: one wavefront per tile of 32 undirected pairs; GEMM 2 with rows = pairs, columns = channels (a lane owns a channel)
+template <int KPB, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_sp(CfArgs a) {
+  constexpr int NF = 128, NT = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  h16x8* sW2h = (h16x8*)smem;                               // 32 KB high | 32 KB low
+  h16x8* sW2l = sW2h + 2048;
+  char* sW1h = (char*)(smem + NF * NF);
+  char* sW1l = sW1h + MlW1Image<KPB>::BYTES;
+  float* sb1 = (float*)(sW1l + MlW1Image<KPB>::BYTES);
+  float* sb2 = sb1 + NF;
+  EdgeRec* sE = (EdgeRec*)(sb2 + NF);                       // NWAVES * 32 records
+  float* sRb = (float*)(sE + NWAVES * 32);                  // [2][32] radial-basis parameters (read per tile from LDS: as loop-invariant global
+  int* sCnt = (int*)(sRb + 64);                             //  loads the compiler hoists all 24 of a lane out of the tile loop -- and spills them)
+
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x & 31;
+    const float* src = (threadIdx.x < 32) ? a.rb.p0 : a.rb.p1;
+    sRb[threadIdx.x] = (src && k < a.rb.n_rbf) ? src[k] : 1.0f;
+  }
+  ml_stage_w2_split<NWAVES * 64>(sW2h, sW2l, a.w2, threadIdx.x);
+  ml_stage_w1_split<KPB>(sW1h, sW1l, a.w1, a.rb.n_rbf, threadIdx.x);
+  for (int s = threadIdx.x; s < NF; s += NWAVES * 64) { sb1[s] = a.b1[s]; sb2[s] = a.b2[s]; }
+  if (threadIdx.x == 0) sCnt[0] = 0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  EdgeRec* myE = sE + wv * 32;
+  const int gp1 = (int)(a.n_half_dev ? (int64_t)a.n_half_dev[0] : a.n_half);
+  const int gtiles = (gp1 + 31) / 32;
+
+  while (true) {
+    int nidx = 0;
+    if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
+    nidx = __builtin_amdgcn_readfirstlane(nidx);
+    const int ltile = a.xcd_walk ? (int)spk_xcd_tile(nidx, gtiles) : (int)blockIdx.x + nidx * (int)gridDim.x;
+    if (ltile >= gtiles) break;
+    const int64_t gtile = ltile;
+    // (lane re-derived through an opaque asm per tile: the per-lane LDS offsets of the loop body -- basis parameters, weight slots,
+    //  records -- are otherwise hoisted out of the persistent loop and parked in scratch: 440 B/lane)
+    int lane_o_ = lane;
+    asm volatile("" : "+v"(lane_o_));
+    const int lane = lane_o_, hi = lane >> 5, el = lane & 31;
+
+    // ---- per-pair geometry (lanes 32..63 mirror lanes 0..31)
+    const int pfirst = 32 * ltile;
+    const int nvalid = (gp1 - pfirst) < 32 ? (gp1 - pfirst) : 32;
+    const bool valid = el < nvalid;
+    const int64_t e = a.half[pfirst + (valid ? el : (nvalid - 1))];
+    const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+    const int i = (int)a.idx_i[e], j = (int)a.idx_j[e];
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    float fc, dfc;
+    spk_cutoff_eval_fast(a.rb.cutoff, d, fc, dfc);
+    if (!valid) { fc = 0.f; dfc = 0.f; }
+    if (hi == 0) { EdgeRec er; er.i = i; er.j = j; er.fc = fc; er.dfc = dfc; myE[el] = er; }
+
+    // ---- GEMM 1 (rows = hidden channels, columns = pairs): z = ssp(W1 phi + b1), kept as the split A operand of GEMM 2
+    h16x8 zh[NT][2], zl[NT][2];
+    {
+      h16x8 ph[2], pl[2], dh_[2], dl_[2];
+      ml_basis_split<KPB, false>(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, hi, d, ph, pl, dh_, dl_);
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        f32x16 zc, zx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { zc[r] = sb1[32 * c + pair_of(r, hi)]; zx[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < (KPB > 2 ? 2 : 1); ++s) {
+          h16x8 wh, wl;
+          ml_w1_operand<KPB>(sW1h, sW1l, s, c * 64 + lane, wh, wl);
+          SP_STEP(wh, wl, ph[s], pl[s], zc, zx);
+        }
+        SP_FOLD(zc, zx);
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = spk_fast_ssp(zc[8 * sp + k]);
+          sp_split8(v, zh[c][sp], zl[c][sp]);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one hidden tile at a time: interleaved, the four accumulator pairs push the kernel into scratch
+      }
+    }
+    spk_wave_lds_sync();   // myE visible to the whole wave
+    unsigned runmask = 0x8000u;       // bit r set <=> the centre atom changes after register r
+    {
+      int prev = myE[pair_of(0, hi)].i;
+#pragma unroll
+      for (int r = 1; r < 16; ++r) {
+        const int cur = myE[pair_of(r, hi)].i;
+        if (cur != prev) runmask |= 1u << (r - 1);
+        prev = cur;
+      }
+    }
+
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      const int c0 = 32 * t + el;   // this lane's channel
+      float hj[16], hc[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const EdgeRec er = myE[pair_of(r, hi)];
+        const unsigned oi = (unsigned)er.i * NF + c0, oj = (unsigned)er.j * NF + c0;      // (n_atoms * nf < 2^31, checked by the launcher)
+        hj[r] = a.h[oj];
+        hc[r] = a.h[oi];
+      }
+      f32x16 g, gx;
+      const float bias2 = sb2[c0];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { g[r] = bias2; gx[r] = 0.f; }
+      {
+        const h16x8* wbh = sW2h + (t * 8) * 64 + lane;
+        const h16x8* wbl = sW2l + (t * 8) * 64 + lane;
+        h16x8 wh = wbh[0], wl = wbl[0];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          h16x8 nh = wh, nl = wl;
+          if (s + 1 < 8) { nh = wbh[(s + 1) * 64]; nl = wbl[(s + 1) * 64]; }
+          SP_STEP(zh[s >> 1][s & 1], zl[s >> 1][s & 1], wh, wl, g, gx);
+          wh = nh; wl = nl;
+        }
+      }
+      SP_FOLD(g, gx);
+      if (a.gsave) {
+        float* gts = a.gsave + gtile * 32 * NF;   // this tile's filters, saved for the backward
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gts[(unsigned)pair_of(r, hi) * NF + c0] = g[r];
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const EdgeRec er = myE[pair_of(r, hi)];
+        const float W = g[r] * er.fc;
+        acc += W * hj[r];
+        unsafeAtomicAdd(a.y + ((unsigned)er.j * NF + c0), W * hc[r]);
+        if ((runmask >> r) & 1u) { unsafeAtomicAdd(a.y + ((unsigned)er.i * NF + c0), acc); acc = 0.f; }
+      }
+    }
+    spk_wave_lds_sync();   // myE may be rewritten by the next tile
+  }
+}
+
+// saved-filter backward (rows = channels, columns = pairs: a lane owns a pair), SKIPGH as in k_cfconv_pair_t
+template <int KPB, int NWAVES, bool SKIPGH>
+__global__ __launch_bounds__(NWAVES * 64) void k_cfconv_pair_t_sp(CfArgs a) {
+  constexpr int NF = 128, NT = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  h16x8* sW2h = (h16x8*)smem;
+  h16x8* sW2l = sW2h + 2048;
+  char* sW1h = (char*)(smem + NF * NF);
+  char* sW1l = sW1h + MlW1Image<KPB>::BYTES;
+  float* sb1 = (float*)(sW1l + MlW1Image<KPB>::BYTES);
+  float* sT = sb1 + 2 * NF;
+  float* sRb = sT + NWAVES * 32 * TP2;                      // [2][32] radial-basis parameters
+  int* sCnt = (int*)(sRb + 64);
+
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x & 31;
+    const float* src = (threadIdx.x < 32) ? a.rb.p0 : a.rb.p1;
+    sRb[threadIdx.x] = (src && k < a.rb.n_rbf) ? src[k] : 1.0f;
+  }
+  ml_stage_w2_split<NWAVES * 64>(sW2h, sW2l, a.w2, threadIdx.x);
+  ml_stage_w1_split<KPB>(sW1h, sW1l, a.w1, a.rb.n_rbf, threadIdx.x);
+  for (int s = threadIdx.x; s < NF; s += NWAVES * 64) sb1[s] = a.b1[s];
+  if (threadIdx.x == 0) sCnt[0] = 0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  float* myT = sT + wv * (32 * TP2);
+  const int64_t nhalf = a.n_half_dev ? (int64_t)a.n_half_dev[0] : a.n_half;
+  const int64_t ntiles = (nhalf + 31) / 32;
+
+  while (true) {
+    int nidx = 0;
+    if (lane == 0) nidx = atomicAdd(&sCnt[0], 1);
+    nidx = __builtin_amdgcn_readfirstlane(nidx);
+    const int64_t tile = a.xcd_walk ? spk_xcd_tile(nidx, ntiles) : (int64_t)blockIdx.x + (int64_t)nidx * gridDim.x;
+    if (tile >= ntiles) break;
+    int lane_o_ = lane;      // (see k_cfconv_pair_sp)
+    asm volatile("" : "+v"(lane_o_));
+    const int lane = lane_o_, hi = lane >> 5, el = lane & 31;
+
+    const int64_t hidx = tile * 32 + el;
+    const bool valid = hidx < nhalf;
+    const int64_t e = a.half[valid ? hidx : (nhalf - 1)];
+    const int64_t e2 = a.rev[e];
+    const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+    const int64_t j = a.idx_j[e];
+    const int64_t i = a.idx_i[e];
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    float fc, dfc;
+    spk_cutoff_eval_fast(a.rb.cutoff, d, fc, dfc);
+    if (!valid) { fc = 0.f; dfc = 0.f; }
+    const int ieff = valid ? (int)i : -1;
+    const int jeff = valid ? (int)j : -1;
+    const int inext = __shfl(ieff, (lane + 1) & 63, 64);
+    const unsigned long long bal = __ballot(ieff != inext);
+    const unsigned flushmask = __builtin_amdgcn_readfirstlane((unsigned)(bal & 0xffffffffull)) | 0x80000000u;
+
+    // ---- GEMM 1, value and derivative: z' = sigmoid(W1 phi + b1) (W1 phi'), kept as the split B operand of GEMM 2'
+    h16x8 zph[NT][2], zpl[NT][2];
+    {
+      h16x8 ph[2], pl[2], dh[2], dl[2];
+      ml_basis_split<KPB, true>(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, hi, d, ph, pl, dh, dl);
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        f32x16 zc, zcx, zq, zqx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { zc[r] = sb1[32 * c + pair_of(r, hi)]; zcx[r] = 0.f; zq[r] = 0.f; zqx[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < (KPB > 2 ? 2 : 1); ++s) {
+          h16x8 wh, wl;
+          ml_w1_operand<KPB>(sW1h, sW1l, s, c * 64 + lane, wh, wl);
+          SP_STEP(wh, wl, ph[s], pl[s], zc, zcx);
+          SP_STEP(wh, wl, dh[s], dl[s], zq, zqx);
+        }
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = 8 * sp + k;
+            float spv, sg;
+            spk_fast_softplus_sigmoid(fmaf(zcx[r], SP_DOWN, zc[r]), spv, sg);
+            v[k] = fmaf(zqx[r], SP_DOWN, zq[r]) * sg;
+          }
+          sp_split8(v, zph[c][sp], zpl[c][sp]);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one hidden tile at a time (register pressure)
+      }
+    }
+
+    float dsum1 = 0.f, dsum2 = 0.f;
+#ifdef SPK_DBG_DSUM
+    float dbg_p0 = 0.f, dbg_p1 = 0.f, dbg_p2 = 0.f;
+#endif
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      f32x4 hjq[4], hiq[4], gyiq[4], gyjq[4], gsv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * t + 8 * q + 4 * hi;
+        hjq[q] = *(const f32x4*)(a.h + j * NF + col);
+        gyiq[q] = *(const f32x4*)(a.gy + i * NF + col);
+        gsv[q] = *(const f32x4*)(a.gload + (tile * 32 + el) * NF + col);
+        hiq[q] = *(const f32x4*)(a.h + i * NF + col);
+        gyjq[q] = *(const f32x4*)(a.gy + j * NF + col);
+      }
+      f32x16 gp, gpx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { gp[r] = 0.f; gpx[r] = 0.f; }
+      {
+        const h16x8* wbh = sW2h + (t * 8) * 64 + lane;
+        const h16x8* wbl = sW2l + (t * 8) * 64 + lane;
+        h16x8 wh = wbh[0], wl = wbl[0];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          h16x8 nh = wh, nl = wl;
+          if (s + 1 < 8) { nh = wbh[(s + 1) * 64]; nl = wbl[(s + 1) * 64]; }
+          SP_STEP(wh, wl, zph[s >> 1][s & 1], zpl[s >> 1][s & 1], gp, gpx);
+          wh = nh; wl = nl;
+        }
+      }
+      SP_FOLD(gp, gpx);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 pA, pB;
+        const f32x4 hj = hjq[q], hc = hiq[q], gq = gsv[q];
+        const float W0 = gq.x * fc, W1v = gq.y * fc, W2v = gq.z * fc, W3 = gq.w * fc;
+        const f32x4 gyi = gyiq[q], gyj = gyjq[q];
+        const float D0 = gp[4 * q + 0] * fc + gq.x * dfc, D1 = gp[4 * q + 1] * fc + gq.y * dfc;
+        const float D2 = gp[4 * q + 2] * fc + gq.z * dfc, D3 = gp[4 * q + 3] * fc + gq.w * dfc;
+        dsum1 += gyi.x * hj.x * D0 + gyi.y * hj.y * D1 + gyi.z * hj.z * D2 + gyi.w * hj.w * D3;
+        dsum2 += gyj.x * hc.x * D0 + gyj.y * hc.y * D1 + gyj.z * hc.z * D2 + gyj.w * hc.w * D3;
+        pA.x = W0 * gyj.x; pA.y = W1v * gyj.y; pA.z = W2v * gyj.z; pA.w = W3 * gyj.w;
+        pB.x = W0 * gyi.x; pB.y = W1v * gyi.y; pB.z = W2v * gyi.z; pB.w = W3 * gyi.w;
+        if (!SKIPGH) {
+          *(f32x4*)(myT + el * TP2 + 8 * q + 4 * hi) = pA;
+          *(f32x4*)(myT + el * TP2 + 32 + 8 * q + 4 * hi) = pB;
+        }
+      }
+#ifdef SPK_DBG_DSUM
+      if (t == 0) dbg_p0 = dsum2; else if (t == 1) dbg_p1 = dsum2; else if (t == 2) dbg_p2 = dsum2;
+#endif
+      if (SKIPGH) continue;   // geometry gradient only: nothing to scatter
+      spk_wave_lds_sync();
+      {
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = myT[k * TP2 + lane];
+        float* ybase = a.y + 32 * t + el;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          acc += v[k];
+          const int ik = __builtin_amdgcn_readlane(ieff, k);
+          const int jk = __builtin_amdgcn_readlane(jeff, k);
+          const bool fl = hi ? true : (((flushmask >> k) & 1u) != 0);
+          const int row = hi ? jk : ik;
+          if (fl) {
+            if (row >= 0) unsafeAtomicAdd(ybase + (int64_t)row * NF, acc);
+            acc = 0.f;
+          }
+        }
+      }
+      spk_wave_lds_sync();
+    }
+#ifdef SPK_DBG_DSUM
+    if (a.dbg) { float* o = (float*)a.dbg + 4 * (ntiles * 32) + 4 * (tile * 64 + lane); o[0] = dbg_p0; o[1] = dbg_p1; o[2] = dbg_p2; o[3] = dsum2; }
+#endif
+    dsum1 += __shfl_xor(dsum1, 32, 64);
+    dsum2 += __shfl_xor(dsum2, 32, 64);
+    if (hi == 0 && valid) {
+      const float s1 = d > 0.f ? dsum1 / d : 0.f, s2 = d > 0.f ? dsum2 / d : 0.f;
+#ifdef SPK_DBG_DSUM
+      if (a.dbg) { float* o = (float*)a.dbg + 4 * (tile * 32 + el); o[0] = s1; o[1] = s2; o[2] = __int_as_float((int)e); o[3] = __int_as_float((int)e2); }
+#endif
+      if (a.gr_assign) {
+        a.gr[3 * e] = s1 * rx; a.gr[3 * e + 1] = s1 * ry; a.gr[3 * e + 2] = s1 * rz;
+        a.gr[3 * e2] = -s2 * rx; a.gr[3 * e2 + 1] = -s2 * ry; a.gr[3 * e2 + 2] = -s2 * rz;
+      } else {
+        a.gr[3 * e] += s1 * rx; a.gr[3 * e + 1] += s1 * ry; a.gr[3 * e + 2] += s1 * rz;
+        a.gr[3 * e2] -= s2 * rx; a.gr[3 * e2 + 1] -= s2 * ry; a.gr[3 * e2 + 2] -= s2 * rz;
+      }
+    }
+  }
+}
+
+template <int KPB>
+static int launch_pair_sp(const CfArgs& a, hipStream_t stream) {
+  constexpr int NWAVES = 8, NF = 128;
+  const size_t lds = (size_t)(NF * NF + 2 * NF) * sizeof(float) + 2 * MlW1Image<KPB>::BYTES + (size_t)NWAVES * 32 * sizeof(EdgeRec) + (64 + 4) * sizeof(int);
+  auto kern = k_cfconv_pair_sp<KPB, NWAVES>;
+  static SpkPerDevice attr_set;
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set.mark(attr_dev);
+  }
+  int grid = (int)(((a.n_half + 31) / 32 + NWAVES - 1) / NWAVES);
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  if (grid < 1) grid = 1;
+  SpkProfScope prof("cfconv_fwd_pair", stream);
+  CfArgs ax = a;
+  ax.xcd_walk = (spk_xcd_walk_default() && grid % 8 == 0 && (a.n_half + 31) / 32 >= 16 * (int64_t)grid) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, ax);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+template <int KPB>
+static int launch_pair_t_bwd_gs_sp(const CfArgs& a, hipStream_t stream) {
+  constexpr int NWAVES = 8, NF = 128;
+  const size_t lds = (size_t)(NF * NF + 2 * NF + NWAVES * 32 * TP2 + 64) * sizeof(float) + 2 * MlW1Image<KPB>::BYTES + 4 * sizeof(int);
+  auto kern = a.skip_gh ? k_cfconv_pair_t_sp<KPB, NWAVES, true> : k_cfconv_pair_t_sp<KPB, NWAVES, false>;
+  static SpkPerDevice attr_set;
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_cfconv_pair_t_sp<KPB, NWAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_cfconv_pair_t_sp<KPB, NWAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set.mark(attr_dev);
+  }
+  const int64_t ntiles = (a.n_half + 31) / 32;
+  int grid = (int)((ntiles + NWAVES - 1) / NWAVES);
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  if (grid < 1) grid = 1;
+  SpkProfScope prof(a.skip_gh ? "cfconv_bwd_pair_gs_geom" : "cfconv_bwd_pair_gs", stream);
+  CfArgs ax = a;
+  ax.xcd_walk = (spk_xcd_walk_default() && grid % 8 == 0 && ntiles >= 16 * (int64_t)grid) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, ax);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static int check_graph(const spk_graph_t* g, const char* who) {
@@ -1036,7 +1423,8 @@ static int cfconv_dispatch(const CfArgs& a, int NF, bool sym, hipStream_t stream
   if (NF == NFv && kpb == KPBv) {                                                   \
     if (mol && BWD && a.gload) return launch_pair<NFv, KPBv, BWD, BWD, true>(a, stream);   \
     if (mol) return launch_pair<NFv, KPBv, BWD, false, true>(a, stream);                   \
-    if (pair && BWD && a.gload) return launch_pair_t_bwd_gs<NFv, KPBv>(a, stream);         \
+    if (pair && BWD && a.gload) return (NFv == 128 && spk_get_split() && !getenv("SPK_CF_NOSP_BWD")) ? launch_pair_t_bwd_gs_sp<KPBv>(a, stream) : launch_pair_t_bwd_gs<NFv, KPBv>(a, stream);   \
+    if (pair && !BWD && NFv == 128 && spk_get_split() && !getenv("SPK_CF_NOSP_FWD")) return launch_pair_sp<KPBv>(a, stream);   \
     if (pair) return launch_pair<NFv, KPBv, BWD, false, false>(a, stream);                 \
     if (!BWD) return launch_mfma<NFv, KPBv, false, false>(a, stream);               \
     return sym ? launch_mfma<NFv, KPBv, BWD, true>(a, stream)                       \

@@ -16,6 +16,8 @@ spktrain, md.Simulator, ...) keeps running its own code on top.
 import importlib
 import sys
 
+import torch
+
 
 _ORIGINALS = []      # (module, name, original object) in patch order, for uninstall()
 
@@ -57,6 +59,11 @@ def _fused_potential_call(orig_call):
     def __call__(self, *args, **kwargs):
         if (self.training or len(args) != 1 or kwargs or not isinstance(args[0], dict)
                 or self._forward_hooks or self._forward_pre_hooks):
+            return orig_call(self, *args, **kwargs)
+        pos = args[0].get("_positions")
+        if not (torch.is_tensor(pos) and (pos.is_cuda or pos.is_meta) and pos.dtype == torch.float32):
+            # host / non-float32 tensors (e.g. BASELINE configs[0]: a CPU force evaluation): the reference's own forward, every mirror
+            # module on its ATen route (nn/fallback.py)
             return orig_call(self, *args, **kwargs)
         mode = self.__dict__.get("_spk_hip_mode")
         if mode is None:

@@ -219,6 +219,14 @@ class NeuralNetworkPotential(nn.Module):
         for p in self.required_derivatives:
             if p in inputs:
                 inputs[p].requires_grad_()
+        dev_ok = properties.R in inputs and (inputs[properties.R].is_cuda or inputs[properties.R].is_meta) and inputs[properties.R].dtype == torch.float32
+        if not dev_ok:           # host / non-float32 tensors: module by module, every mirror on its ATen route (nn/fallback.py)
+            for m in self.input_modules:
+                inputs = m(inputs)
+            inputs = self.representation(inputs)
+            for m in self.output_modules:
+                inputs = m(inputs)
+            return {k: inputs[k] for k in self.model_outputs}
         if self._potential_forces and not self.training and not torch.jit.is_scripting():
             inputs = self._potential_forces_forward(inputs)
             return {k: inputs[k] for k in self.model_outputs}

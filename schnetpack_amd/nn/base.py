@@ -9,6 +9,7 @@ from torch.nn.init import xavier_uniform_, zeros_
 from .. import _lib
 from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 from .activations import shifted_softplus
+from .fallback import note_fallback, use_aten
 
 __all__ = ["Dense", "activation_id"]
 
@@ -56,6 +57,9 @@ class Dense(nn.Linear):
             self.bias_init(self.bias)
 
     def forward(self, input: torch.Tensor):
+        if use_aten(input):      # host / non-float32 tensors: F.linear + activation, as the reference (nn/base.py:52-55)
+            note_fallback()
+            return self.activation(F.linear(input, self.weight, self.bias))
         if self._act_id >= 0:
             return torch.ops.spk_hip.dense(input, self.weight, self.bias, self._act_id)
         # unknown activation callable: linear part on the HIP kernel, activation by the caller's function

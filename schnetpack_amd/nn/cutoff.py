@@ -6,6 +6,7 @@ import torch
 from torch import nn
 
 from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
+from .fallback import note_fallback, use_aten
 
 __all__ = ["CosineCutoff", "cosine_cutoff"]
 
@@ -40,6 +41,9 @@ class CosineCutoff(nn.Module):
 
     def forward(self, input: torch.Tensor):
         p1: Optional[torch.Tensor] = None
+        if use_aten(input):      # host / non-float32 tensors: the reference's formula (nn/cutoff.py:30-32)
+            note_fallback()
+            return cosine_cutoff(input, self.cutoff)
         if self.training and torch.is_grad_enabled() and input.requires_grad:
             # differentiable to the third order on the device (force training differentiates twice)
             return torch.ops.spk_hip.radial_d(input, None, 2, self.cutoff, p1, self._cutoff_host, 0)

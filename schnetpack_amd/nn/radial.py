@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from .. import _lib
 from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
+from .fallback import note_fallback, use_aten
 
 __all__ = ["gaussian_rbf", "GaussianRBF", "BesselRBF"]
 
@@ -49,6 +50,9 @@ class GaussianRBF(nn.Module):
     def forward(self, inputs: torch.Tensor):
         # training-mode graphs (any order in d; with ``trainable=True`` also the gradients w.r.t. offsets / widths, nn/radial.py:40-45)
         # run the closed operator family spk_hip::radial_d / radial_c; plain evaluation the fused radial + cutoff kernel
+        if use_aten(inputs):      # host / non-float32 tensors: the reference's formula (nn/radial.py:11-14)
+            note_fallback()
+            return gaussian_rbf(inputs, self.offsets, self.widths)
         if torch.is_grad_enabled() and ((self.training and inputs.requires_grad) or (self.trainable and self.offsets.requires_grad)):
             return torch.ops.spk_hip.radial_d(inputs, None, 0, self.offsets, self.widths, 1.0, 0)
         return torch.ops.spk_hip.radial_cutoff(inputs, 0, self.offsets, self.widths, 1.0, True, False)[0]
@@ -70,6 +74,14 @@ class BesselRBF(nn.Module):
 
     def forward(self, inputs: torch.Tensor):
         p1: Optional[torch.Tensor] = None
+        if use_aten(inputs):      # host / non-float32 tensors: the reference's formula (nn/radial.py:105-109)
+            note_fallback()
+            a = self.freqs[None, :]
+            inputs_ = inputs[..., None]
+            ax = inputs_ * a
+            sinax = torch.sin(ax)
+            norm = torch.where(inputs_ == 0, torch.tensor(1.0, device=inputs_.device, dtype=inputs_.dtype), inputs_)
+            return sinax / norm
         if self.training and torch.is_grad_enabled() and inputs.requires_grad:
             return torch.ops.spk_hip.radial_d(inputs, None, 1, self.freqs, p1, 1.0, 0)
         return torch.ops.spk_hip.radial_cutoff(inputs, 1, self.freqs, p1, 1.0, True, False)[0]

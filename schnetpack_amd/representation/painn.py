@@ -17,6 +17,7 @@ from .. import properties
 from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
 from ..nn import Dense, replicate_module, scatter_add
 from ..nn.base import activation_id
+from ..nn.fallback import note_fallback, use_aten
 
 __all__ = ["PaiNN", "PaiNNInteraction", "PaiNNMixing"]
 
@@ -43,6 +44,16 @@ class PaiNNInteraction(nn.Module):
     def forward(self, q: torch.Tensor, mu: torch.Tensor, Wij: torch.Tensor, dir_ij: torch.Tensor,
                 idx_i: torch.Tensor, idx_j: torch.Tensor, n_atoms: int):
         x = self.interatomic_context_net(q)
+        if use_aten(x):          # host / non-float32 tensors: the reference's algebra (painn.py:54-66)
+            note_fallback()
+            xj = x[idx_j]
+            muj = mu[idx_j]
+            x = Wij * xj
+            dq, dmuR, dmumu = torch.split(x, self.n_atom_basis, dim=-1)
+            dq = scatter_add(dq, idx_i, dim_size=n_atoms)
+            dmu = dmuR * dir_ij[..., None] + dmumu * muj
+            dmu = scatter_add(dmu, idx_i, dim_size=n_atoms)
+            return q + dq, mu + dmu
         n3 = x.shape[-1]
         # x = Wij * x[idx_j]: one gather-multiply (the filters carry one row per pair: no index on that side)
         x = torch.ops.spk_hip.edge_mul(Wij.reshape(-1, n3), x.reshape(-1, n3), None, idx_j)
@@ -78,6 +89,15 @@ class PaiNNMixing(nn.Module):
     def forward(self, q: torch.Tensor, mu: torch.Tensor):
         mu_mix = self.mu_channel_mix(mu)
         mu_V, mu_W = torch.split(mu_mix, self.n_atom_basis, dim=-1)
+        if use_aten(mu_mix):     # host / non-float32 tensors: the reference's algebra (painn.py:103-116)
+            note_fallback()
+            mu_Vn = torch.sqrt(torch.sum(mu_V ** 2, dim=-2, keepdim=True) + self.epsilon)
+            ctx = torch.cat([q, mu_Vn], dim=-1)
+            x = self.intraatomic_context_net(ctx)
+            dq_intra, dmu_intra, dqmu_intra = torch.split(x, self.n_atom_basis, dim=-1)
+            dmu_intra = dmu_intra * mu_W
+            dqmu_intra = dqmu_intra * torch.sum(mu_V * mu_W, dim=1, keepdim=True)
+            return q + dq_intra + dqmu_intra, mu + dmu_intra
         # sum(mu_V ** 2, dim=-2, keepdim=True), dmu_intra * mu_W, sum(mu_V * mu_W, dim=1, keepdim=True): 3-vector products
         # (vec3 codes: 0 = V * s, 1 = sum over the Cartesian axis of A * B) on the halves of mu_mix as they lie
         mu_Vn = torch.sqrt(torch.ops.spk_hip.vec3(1, mu_V, mu_V) + self.epsilon)
@@ -180,24 +200,28 @@ class PaiNN(nn.Module):
         for embedding in self.electronic_embeddings:
             q = q + embedding(q, inputs)
 
-        if self._fused and not self.training:
+        aten = use_aten(r_ij) or use_aten(q)
+        if self._fused and not self.training and not aten:
             ws = self.interaction_weights()
             kind, p0, p1 = self.radial_basis.kernel_params()
             q, mu = torch.ops.spk_hip.painn(q, r_ij, idx_i, idx_j, ws, self.share_filters, self.epsilon, kind, p0, p1,
                                             self.cutoff_fn.cutoff_value())
         else:
-            d_ij = torch.ops.spk_hip.edge_norm(r_ij).unsqueeze(1)
+            d_ij = torch.norm(r_ij, dim=1, keepdim=True) if aten else torch.ops.spk_hip.edge_norm(r_ij).unsqueeze(1)
             dir_ij = r_ij / d_ij
             phi_ij = self.radial_basis(d_ij)
             fcut = self.cutoff_fn(d_ij)
-            filters = torch.ops.spk_hip.rowscale(self.filter_net(phi_ij), fcut)    # filter_net(phi_ij) * fcut[..., None]
+            if aten:
+                filters = self.filter_net(phi_ij) * fcut[..., None]
+            else:
+                filters = torch.ops.spk_hip.rowscale(self.filter_net(phi_ij), fcut)    # filter_net(phi_ij) * fcut[..., None]
             if self.share_filters:
                 filter_list = [filters] * self.n_interactions
             else:
                 filter_list = torch.split(filters, 3 * self.n_atom_basis, dim=-1)
             q = q.unsqueeze(1)
             qs = q.shape
-            mu = torch.zeros((qs[0], 3, qs[2]), device=q.device)
+            mu = torch.zeros((qs[0], 3, qs[2]), device=q.device, dtype=q.dtype if aten else torch.float32)
             for i, (interaction, mixing) in enumerate(zip(self.interactions, self.mixing)):
                 q, mu = interaction(q, mu, filter_list[i], dir_ij, idx_i, idx_j, n_atoms)
                 q, mu = mixing(q, mu)

@@ -17,7 +17,8 @@ from torch import nn
 from .. import _lib
 from .. import properties
 from .. import torchops  # noqa: F401  (registers torch.ops.spk_hip)
-from ..nn import Dense
+from ..nn import Dense, scatter_add
+from ..nn.fallback import note_fallback, use_aten
 from ..nn import replicate_module
 from ..nn.activations import shifted_softplus
 from ..nn.base import activation_id
@@ -53,6 +54,14 @@ class SchNetInteraction(nn.Module):
 
     def forward(self, x: torch.Tensor, f_ij: torch.Tensor, idx_i: torch.Tensor,
                 idx_j: torch.Tensor, rcut_ij: torch.Tensor):
+        if use_aten(x):          # host / non-float32 tensors: the reference's algebra (schnet.py:60-67)
+            note_fallback()
+            x = self.in2f(x)
+            Wij = self.filter_network(f_ij)
+            Wij = Wij * rcut_ij[:, None]
+            x_ij = x[idx_j] * Wij
+            x = scatter_add(x_ij, idx_i, dim_size=x.shape[0])
+            return self.f2out(x)
         x = self.in2f(x)
         Wij = self.filter_network(f_ij)
         Wij = torch.ops.spk_hip.rowscale(Wij, rcut_ij)                             # Wij * rcut_ij[:, None]
@@ -130,12 +139,13 @@ class SchNet(nn.Module):
 
         x = self.embed(inputs)
 
-        if self._fused and not self.training:
+        aten = use_aten(r_ij) or use_aten(x)
+        if self._fused and not self.training and not aten:
             ws = self.interaction_weights()
             kind, p0, p1 = self.radial_basis.kernel_params()
             x = torch.ops.spk_hip.schnet(x, r_ij, idx_i, idx_j, ws, self.n_filters, kind, p0, p1, self.cutoff_fn.cutoff_value())
         else:
-            d_ij = torch.ops.spk_hip.edge_norm(r_ij)
+            d_ij = torch.norm(r_ij, dim=1) if aten else torch.ops.spk_hip.edge_norm(r_ij)
             f_ij = self.radial_basis(d_ij)
             rcut_ij = self.cutoff_fn(d_ij)
             for interaction in self.interactions:

@@ -15,7 +15,7 @@ from schnetpack_amd.csrc import build as B  # noqa: E402
 rows = []
 for src in B.SOURCES:
     path = os.path.join(B.HERE, src)
-    cmd = [B._hipcc()] + B.FLAGS + ["-c", path, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+    cmd = [B._hipcc()] + B.flags_for(path) + ["-c", path, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
     out = subprocess.run(cmd, capture_output=True, text=True).stderr
     cur = {}
     for line in out.splitlines():

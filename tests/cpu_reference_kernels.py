@@ -143,12 +143,26 @@ KERNELS = {
 }
 
 
+_MIRRORS = ("schnetpack_amd.nn.scatter", "schnetpack_amd.nn.base", "schnetpack_amd.nn.cutoff", "schnetpack_amd.nn.radial",
+            "schnetpack_amd.representation.schnet", "schnetpack_amd.representation.painn", "schnetpack_amd.atomistic")
+
+
 @contextlib.contextmanager
 def reference_kernels():
+    """Test-only CPU kernels on the operators' CPU key.  The module mirrors would send host tensors down their plain-ATen route
+    (schnetpack_amd/nn/fallback.py) and never reach the operators: inside this context their ``use_aten`` says "no", so that the host
+    tensors travel through the operator library -- the thing under test."""
+    import importlib
     lib = torch.library.Library("spk_hip", "IMPL")
+    mods = [importlib.import_module(m) for m in _MIRRORS]
+    saved = [getattr(m, "use_aten") for m in mods]
     try:
         for name, fn in KERNELS.items():
             lib.impl(name, fn, "CPU", allow_override=True)
+        for m in mods:
+            m.use_aten = lambda x: False
         yield
     finally:
+        for m, f in zip(mods, saved):
+            m.use_aten = f
         lib._destroy()

@@ -190,3 +190,44 @@ def test_tabulated_filter_experiment_force_call_on_the_water_box(dev):
     # and the tables are gone again
     out2 = model(dict(inp))
     assert rel_err(out2["forces"].detach().cpu(), out0["forces"].detach().cpu()) < 2e-6
+
+
+@pytest.mark.gpu
+def test_box_split_backward_repeats_and_matches_the_fp32_matrix_path(dev):
+    """Round 6 regression: the split-precision pair backward of the general SchNet driver (k_cfconv_pair_t_sp) once came out of the
+    compiler with its two per-pair sums in packed instructions between the f16 matrix instructions, and dL/dr_ij of a few dozen
+    REVERSED edges per launch was off by percent, differently in every run (profiles/r06_box_split_glitch.md).  Twelve launches of
+    the three-interaction backward on a 3 000-atom box against the fp32 matrix path: every edge within 1e-5 of the largest entry."""
+    from schnetpack_amd import _lib, model as M
+    b = S.water_box(n_side=10, seed=3)
+    rep = O.init_schnet_params(128, 3, 20, 5.0)
+    head = O.init_atomwise_params(128, seed=1)
+    m = M.build_model("schnet", 128, 3, 20, 5.0)
+    M.load_reference_params(m, rep, head)
+    m = m.to(dev).eval()
+    r = m.representation
+    inp = M.batch_to_inputs(b, dev)
+    R = inp["_positions"]
+    r_ij = (R[inp["_idx_j"]] - R[inp["_idx_i"]] + inp["_offsets"]).contiguous()
+    x0 = r.embedding(inp["_atomic_numbers"]).detach()
+    ws = r.interaction_weights()
+    kind, p0, p1 = r.radial_basis.kernel_params()
+    gx = torch.randn(x0.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+
+    def call():
+        x, saved, scratch = torch.ops.spk_hip.schnet_forward(x0, r_ij, inp["_idx_i"], inp["_idx_j"], ws, 128, kind, p0, p1, 5.0, True)
+        gr, _ = torch.ops.spk_hip.schnet_backward(gx, r_ij, saved, scratch, inp["_idx_i"], inp["_idx_j"], ws, 128, kind, p0, p1, 5.0, True, False)
+        torch.cuda.synchronize()
+        return gr.detach().clone()
+
+    before = _lib.get_split()
+    try:
+        _lib.set_split(0)
+        ref = call()
+        scale = float(ref.abs().max())
+        _lib.set_split(1)
+        for rep_i in range(12):
+            worst = float((call() - ref).abs().max()) / scale
+            assert worst < 1e-5, "launch %d: dL/dr_ij off by %.2e of the largest entry" % (rep_i, worst)
+    finally:
+        _lib.set_split(before)

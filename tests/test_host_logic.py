@@ -43,22 +43,26 @@ def test_library_contains_gfx950_code_object():
 
 
 def test_compute_entry_points_fail_without_gpu_or_with_cpu_tensors():
-    from schnetpack_amd import ops
+    """The operators (torch.ops.spk_hip.*: the CPU dispatch key is a loud refusal) and the C ABI (ops.* through ctypes) never compute on
+    the host -- the product path fails loudly without the device.  The MODULE mirrors route host / non-float32 tensors to the reference's
+    own ATen formulas instead (SURVEY.md section 8(b) error convention; round 6, nn/fallback.py, tests/test_aten_fallback.py)."""
+    from schnetpack_amd import ops, torchops  # noqa: F401
     from schnetpack_amd._lib import SpkHipError
     from schnetpack_amd.nn import CosineCutoff, Dense, GaussianRBF, scatter_add
-    # the module mirrors go through torch.ops.spk_hip (its CPU dispatch key is a loud refusal), ops.* through ctypes
     with pytest.raises(RuntimeError, match="no CPU fallback"):
-        scatter_add(torch.ones(4, 2), torch.tensor([0, 0, 1, 1]), 2)
+        torch.ops.spk_hip.scatter_add(torch.ones(4, 2), torch.tensor([0, 0, 1, 1]), 2, 0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
-        Dense(8, 32)(torch.ones(2, 8))
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        GaussianRBF(20, 5.0).eval()(torch.ones(3))
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        CosineCutoff(5.0).eval()(torch.ones(3))
+        torch.ops.spk_hip.dense(torch.ones(2, 8), torch.ones(32, 8), None, 0)
     with pytest.raises(SpkHipError):
         ops.gather(torch.ones(3, 2), torch.tensor([0, 1]))
     with pytest.raises(SpkHipError):
         ops.scatter_add(torch.ones(4, 2), torch.tensor([0, 0, 1, 1]), 2)
+    # the mirrors on host tensors: the reference's formulas
+    assert torch.equal(scatter_add(torch.ones(4, 2), torch.tensor([0, 0, 1, 1]), 2), torch.full((2, 2), 2.0))
+    lin = Dense(8, 32)
+    assert torch.allclose(lin(torch.ones(2, 8)), torch.nn.functional.linear(torch.ones(2, 8), lin.weight, lin.bias))
+    assert GaussianRBF(20, 5.0).eval()(torch.ones(3)).shape == (3, 20)
+    assert torch.allclose(CosineCutoff(5.0).eval()(torch.ones(3)), 0.5 * (torch.cos(torch.ones(3) * torch.pi / 5.0) + 1.0))
 
 
 @pytest.mark.parametrize("kind", ["schnet", "painn"])

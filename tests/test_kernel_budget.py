@@ -23,20 +23,23 @@ BUDGET = {
     "spk_painn.hip": {"k_painn_mixing_fwd8ILi128E": (0, 2), "k_painn_mixing_bwd8ILi128E": (0, 2)},
     # the two molecule-resident launches sit AT the 256-register limit of two waves per SIMD; the metadata reports a small
     # private segment although no scratch instruction is on a hot path
-    "spk_schnet_mol.hip": {"k_schnet_mol_fwdILi3E": (128, 2), "k_schnet_mol_bwdILi3E": (128, 2)},
+    # (round 6: second template flag = the split-precision matrix path, the default; it carries the split operands of a tile on top)
+    "spk_schnet_mol.hip": {"k_schnet_mol_fwdILi3ELb0E": (128, 2), "k_schnet_mol_fwdILi3ELb1E": (192, 2), "k_schnet_mol_bwdILi3E": (128, 2)},
     # molecule-resident PaiNN (round 3): both launches at the 256-register limit; what is left in scratch are values parked in the
     # prologue and a handful of reloads in the message loops -- when whole prefetched weight tiles were being spilled behind their
     # loads the figures were 2 176 / 652 B per lane and every Dense phase waited for a chain of L2 round trips
     # instances <n_rbf, tiled, potential> / <n_rbf, potential>: the row form (default) with and without the two-launch potential; the
     # tile-form experiment (SPK_PM_TILED=1) is not a budgeted path
-    "spk_painn_mol.hip": {"k_painn_mol_fwdILi20ELb0ELb0E": (256, 2), "k_painn_mol_fwdILi20ELb0ELb1E": (320, 2),
+    # (round 6: last template flag = split Dense phases, the default)
+    "spk_painn_mol.hip": {"k_painn_mol_fwdILi20ELb0ELb0ELb0E": (256, 2), "k_painn_mol_fwdILi20ELb0ELb1ELb0E": (320, 2),
+                          "k_painn_mol_fwdILi20ELb0ELb0ELb1E": (288, 2), "k_painn_mol_fwdILi20ELb0ELb1ELb1E": (352, 2),
                           "k_painn_mol_bwdILi20ELb0E": (448, 2), "k_painn_mol_bwdILi20ELb1E": (448, 2)},
 }
 
 
 def _resources(src):
     path = os.path.join(B.HERE, src)
-    cmd = [B._hipcc()] + B.FLAGS + ["-c", path, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    cmd = [B._hipcc()] + B.flags_for(path) + ["-c", path, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900).stderr
     rows, cur = {}, None
     for line in out.splitlines():
