@@ -560,6 +560,11 @@ void spk_painn_set_tile(int32_t mode);
 /* row kernels of the PaiNN message with the radial values of a 64-edge chunk in a wave-private LDS table (F = 128, n_rbf <= 20):
  * -1 = on large lists (default), 0 = never, 1 = whenever the shape has the instance */
 void spk_painn_set_row_table(int32_t mode);
+/* Row-tile backward of the PaiNN message (round 6; representation/painn.py:50-66 transposed): a wavefront per row of the sorted, symmetric list,
+ * the filter and its slope from a split-precision GEMM (fp16 high / low operand pairs, fp32 accumulation) over 32-pair chunks of the row, no
+ * atomics; the full backward runs as a geometry launch and a transposed-sums launch.  F = 128, 16 <= n_rbf <= 31, split path on
+ * (spk_set_split).  0 = automatic (lists of >= 2^19 pairs, with or without a skin), 1 = whenever the shape has it, -1 = never. */
+void spk_painn_set_rowtile(int32_t mode);
 
 /* representation/painn.py:92-117 -- the elementwise parts of PaiNNMixing around its three
  * Dense layers.  mix [N,3,2F] = mu_channel_mix(mu) = (V | W).

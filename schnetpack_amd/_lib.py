@@ -196,6 +196,7 @@ _PROTOS = {
     "spk_painn_message_bwd_f32": (ctypes.c_int, [P(GraphT), P(RadialT), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_f]),
     "spk_painn_set_tile": (None, [c_i32]),
     "spk_painn_set_row_table": (None, [c_i32]),
+    "spk_painn_set_rowtile": (None, [c_i32]),
     "spk_painn_set_block": (None, [c_i32]),
     "spk_transpose_plan_bytes": (c_i64, [c_i64, c_i64]),
     "spk_fm_set_chain": (None, [ctypes.c_int32]),

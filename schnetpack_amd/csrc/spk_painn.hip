@@ -454,6 +454,10 @@ static int msg_dispatch(const MsgArgs& a_in, bool row_ok, hipStream_t stream, co
     SpkProfScope prof(a.mu_zero ? "painn_msg_fwd_tile_mu0" : "painn_msg_fwd_tile", stream);
     return spk_painn_msg_tile_fwd(a, stream);
   }
+  if (BWD && shape_ok && variant != SPK_VARIANT_SIMPLE && spk_painn_msg_rowtile_bwd_ok(a)) {
+    // backward with a wavefront per row and the filter GEMMs on the f16 matrix instructions (spk_painn_tile.hip, round 6)
+    return spk_painn_msg_rowtile_bwd(a, stream);
+  }
   if (BWD && shape_ok && variant != SPK_VARIANT_SIMPLE && spk_painn_msg_tile_bwd_ok(a)) {
     // backward with the value and derivative filter GEMMs on the matrix cores (spk_painn_tile.hip)
     SpkProfScope prof(a.geom_only ? "painn_msg_bwd_tile_geom" : "painn_msg_bwd_tile", stream);

@@ -641,6 +641,63 @@ def test_painn_message_backward_on_asymmetric_lists_without_atomics(dev, F, n_rb
         assert torch.equal(x, y)                # fixed summation order
 
 
+@pytest.mark.parametrize("n_rbf,mu_zero,skin", [(20, False, False), (20, True, False), (28, False, False), (20, False, True)])
+def test_painn_message_backward_row_tile(dev, n_rbf, mu_zero, skin):
+    """Row-tile backward (round 6, spk_painn_tile.hip): a wavefront per row, filter and slope from the split-precision GEMM of 32-pair chunks,
+    geometry launch + transposed-sums launch.  Symmetric ring lists whose rows need one, two and three chunks (degree 24 / 56 / 70), pairs
+    beyond the cutoff in every row (f_c = 0; with `skin` the rows are compacted first): equal to the float64 oracle, equal to the row kernel it
+    replaces, and bit-reproducible.  (The geometry-only launch of an eval-mode backward is exercised by the box force calls of test_gpu_scale.py.)"""
+    from schnetpack_amd import _lib, ops
+    F = 128
+    g = torch.Generator().manual_seed(5)
+    L = _lib.lib()
+    for degree in (24, 56, 70):
+        rb_ = S.ring_graph_batch(300, degree, seed=degree, dmin=0.9, dmax=5.6 if skin else 5.05)
+        r, idx_i, idx_j, N = rb_["r_ij"], rb_["idx_i"], rb_["idx_j"], rb_["Z"].shape[0]
+        c = torch.randn(N, 3 * F, generator=g)
+        q = torch.randn(N, F, generator=g)
+        mu = torch.zeros(N, 3, F) if mu_zero else torch.randn(N, 3, F, generator=g)
+        wf = torch.randn(3 * F, n_rbf, generator=g) * 0.3
+        bf = torch.randn(3 * F, generator=g) * 0.1
+        gq = torch.randn(N, F, generator=g)
+        gmu = torch.randn(N, 3, F, generator=g)
+        _, _, gco, gmuo, gro = _msg_oracle(c, q, mu, r, idx_i, idx_j, wf, bf, N, F, gq, gmu)
+        plan = ops.EdgePlan(idx_i.to(dev), idx_j.to(dev), N, r.to(dev))
+        assert plan.sorted and plan.symmetric
+        if skin:
+            plan.set_filter(True)
+        off, w = O.gaussian_rbf_params(n_rbf, 5.0)
+        offd, wd = off.to(dev), w.to(dev)
+        rb = ops.radial_struct(_lib.SPK_RBF_GAUSSIAN, n_rbf, offd, wd, 5.0)
+        D = lambda t: t.to(dev).contiguous()
+        cd, mud, rd, wfd, bfd, gqd, gmud = map(D, (c, mu, r, wf, bf, gq, gmu))
+
+        def run(want_sums=True):
+            gc = torch.full((N, 3 * F), float("nan"), device=dev)
+            gmu_in = torch.full((N, 3, F), float("nan"), device=dev)
+            gr = torch.zeros(r.shape[0], 3, device=dev)
+            _lib.profile_enable(True); _lib.profile_report()
+            _lib.check(L.spk_painn_message_bwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(mud), _lib.fptr(gqd), _lib.fptr(gmud),
+                                                   _lib.fptr(rd), _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(gc) if want_sums else None,
+                                                   _lib.fptr(gmu_in) if want_sums else None, _lib.fptr(gr), _lib.stream()))
+            tags = set(_lib.profile_report()); _lib.profile_enable(False)
+            return gc, gmu_in, gr, tags
+
+        try:
+            L.spk_painn_set_rowtile(1)
+            a1, a2 = run(), run()
+            assert a1[3] == {"painn_msg_bwd_rowtile_g", "painn_msg_bwd_rowtile_t"}, a1[3]
+            assert rel_err(a1[0].cpu(), gco) < TOL and rel_err(a1[1].cpu(), gmuo) < TOL and rel_err(a1[2].cpu(), gro) < TOL, degree
+            for x, y in zip(a1[:3], a2[:3]):
+                assert torch.equal(x, y)                # no atomics: fixed summation order
+            L.spk_painn_set_rowtile(-1)
+            b1 = run()
+            assert not any("rowtile" in t for t in b1[3])
+            assert rel_err(a1[2].cpu(), b1[2].cpu()) < TOL
+        finally:
+            L.spk_painn_set_rowtile(0)
+
+
 def test_painn_mixing_elementwise(dev):
     from schnetpack_amd import _lib
     g = torch.Generator().manual_seed(31)
