@@ -14,6 +14,9 @@
 //
 // Measurements and the dispatch rules that follow from them: DESIGN.md section 4.3, profiles/r01_painn_tile_experiment.json.
 #include "spk_painn_msg.h"
+#ifndef SPK_RT_HOLLOW
+#define SPK_RT_HOLLOW 0     // timing aid of the row-tile backward: 1 = no channel-block loop, 2 = no gathers, 3 = no GEMMs (results are wrong)
+#endif
 #include "spk_split.h"
 #include "spk_filter_split.h"
 
@@ -140,6 +143,10 @@ __device__ __forceinline__ f32x16 tile_gemm_split(const char* __restrict__ ih, c
   return acc;
 }
 
+// load from a wave-uniform base and a 32-bit BYTE offset per lane: global_load_dword v, v_off, s[base] -- with element indices the compiler forms a
+// 64-bit address per load (v_lshlrev_b64 + v_lshl_add_u64: half of the vector instructions of the row-tile geometry pass were address arithmetic)
+__device__ __forceinline__ float ld_off(const float* __restrict__ base, unsigned byte_off) { return *(const float*)((const char*)base + byte_off); }
+
 // sum over the 4 lanes of a quad with DPP (quad_perm [1,0,3,2] then [2,3,0,1]): VALU modifiers, no LDS crossbar round trip
 __device__ __forceinline__ float quad_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256, MINW) void k_painn_msg_tile(MsgArgs a, int nti
         {
           float cq[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) cq[r] = a.c[(unsigned)myE[16 * hi + r].j * F3 + c0];
+          for (int r = 0; r < 16; ++r) cq[r] = ld_off(a.c, ((unsigned)myE[16 * hi + r].j * F3 + c0) * 4u);
           const f32x16 Pq = gemm(cb);
           float acc = 0.f;
 #pragma unroll
@@ -267,9 +274,9 @@ __global__ __launch_bounds__(256, MINW) void k_painn_msg_tile(MsgArgs a, int nti
           float cR[8], cm[8], m0[8], m1[8], m2[8];
 #pragma unroll
           for (int rr = 0; rr < 8; ++rr) {
-            const unsigned oj = (unsigned)myE[16 * hi + g0 + rr].j * F3 + c0;
-            cR[rr] = a.c[oj + F];
-            if (!MU0) { cm[rr] = a.c[oj + 2 * F]; m0[rr] = a.mu[oj]; m1[rr] = a.mu[oj + F]; m2[rr] = a.mu[oj + 2 * F]; }
+            const unsigned bj = ((unsigned)myE[16 * hi + g0 + rr].j * F3 + c0) * 4u;       // byte offset (< 2^32: spk_painn_msg_tile_ok)
+            cR[rr] = ld_off(a.c, bj + 4 * F);
+            if (!MU0) { cm[rr] = ld_off(a.c, bj + 8 * F); m0[rr] = ld_off(a.mu, bj); m1[rr] = ld_off(a.mu, bj + 4 * F); m2[rr] = ld_off(a.mu, bj + 8 * F); }
             else { cm[rr] = 0.f; m0[rr] = 0.f; m1[rr] = 0.f; m2[rr] = 0.f; }
           }
 #pragma unroll
@@ -638,122 +645,92 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_rowtile_bwd(MsgArgs a) {
 #pragma unroll 1
       for (int cb = 0; cb < NT; ++cb) {
         const unsigned c0 = 32u * cb + el;
-        // values of the centre atom for this channel
-        float gqa = 0.f, ga0 = 0.f, ga1 = 0.f, ga2 = 0.f;
-        if (WANT_G) { gqa = a.gq_out[(unsigned)atom * F + c0]; ga0 = a.gmu_out[oa + c0]; ga1 = a.gmu_out[oa + F + c0]; ga2 = a.gmu_out[oa + 2 * F + c0]; }
         __builtin_amdgcn_sched_barrier(0);
-        // ---------------- scalar part
-        {
-          f32x16 Pq = sdd;
-          if (!GEOM) Pq = tile_gemm_split<KPB, NB>(sWh, sWl, cb, Avh, Avl, lane);
-          f32x16 Dq = sdd;
-          if (WANT_G) Dq = tile_gemm_split<KPB, NB>(sWh, sWl, cb, Adh, Adl, lane);
-          float accq = 0.f;
-#pragma unroll
-          for (int g0 = 0; g0 < 16; g0 += GS) {
-            float cq[GS], gqb[GS];
-#pragma unroll
-            for (int rr = 0; rr < GS; ++rr) {
-              const unsigned j = (unsigned)myE[16 * hi + g0 + rr].j;
-              cq[rr] = WANT_G ? a.c[j * F3 + c0] : 0.f;
-              gqb[rr] = GEOM ? 0.f : a.gq_out[j * F + c0];
-            }
-#pragma unroll
-            for (int rr = 0; rr < GS; ++rr) {
-              const int r = g0 + rr;
-              if (WANT_G) sdd[r] = fmaf(cq[rr] * gqa, Dq[r], sdd[r]);
-              if (!GEOM) accq = fmaf(Pq[r], gqb[rr], accq);
-            }
-          }
-          if (!GEOM) myA[(cb * NACC + 0) * 64 + lane] += accq;
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the gathers of one part at a time
+#if SPK_RT_HOLLOW == 1
+        continue;
+#endif
         if (!WANT_G) {
-          // ---------------- transposed sums alone: R and mu parts over ONE gather of the neighbours' gmu rows
+          // ================ transposed sums: every gather of the block is requested before its three GEMMs (ONE latency round per block:
+          // the launch is bound by the rounds of dependent gathers a wave walks through, not by their bytes)
+          float gqb[16], gb0[16], gb1[16], gb2[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned j = (unsigned)myE[16 * hi + r].j;
+            const unsigned oj = j * F3 + c0;
+            const unsigned bq = (j * F + c0) * 4u, bj = oj * 4u;       // byte offsets (< 2^32, checked by the launcher): scalar base + 32-bit lane offset
+#if SPK_RT_HOLLOW == 2
+            gqb[r] = (float)(j & 7); gb0[r] = (float)(oj & 3); gb1[r] = (float)(oj & 5); gb2[r] = (float)(oj & 9);
+#else
+            gqb[r] = ld_off(a.gq_out, bq);
+            gb0[r] = ld_off(a.gmu_out, bj); gb1[r] = ld_off(a.gmu_out, bj + 4 * F); gb2[r] = ld_off(a.gmu_out, bj + 8 * F);
+#endif
+          }
+#if SPK_RT_HOLLOW == 3
+          f32x16 Pq, PR, Pm;
+          for (int r = 0; r < 16; ++r) { Pq[r] = fc; PR[r] = d; Pm[r] = invd; }
+#else
+          const f32x16 Pq = tile_gemm_split<KPB, NB>(sWh, sWl, cb, Avh, Avl, lane);
           const f32x16 PR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Avh, Avl, lane);
           const f32x16 Pm = tile_gemm_split<KPB, NB>(sWh, sWl, 2 * NT + cb, Avh, Avl, lane);
-          float accR = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#endif
+          float accq = 0.f, accR = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
-          for (int g0 = 0; g0 < 16; g0 += GS) {
-            float gb0[GS], gb1[GS], gb2[GS];
-#pragma unroll
-            for (int rr = 0; rr < GS; ++rr) {
-              const unsigned oj = (unsigned)myE[16 * hi + g0 + rr].j * F3 + c0;
-              gb0[rr] = a.gmu_out[oj]; gb1[rr] = a.gmu_out[oj + F]; gb2[rr] = a.gmu_out[oj + 2 * F];
-            }
-#pragma unroll
-            for (int rr = 0; rr < GS; ++rr) {
-              const int r = g0 + rr;
-              const TileRec er = myE[16 * hi + r];
-              accR = fmaf(-PR[r], gb0[rr] * er.ux + gb1[rr] * er.uy + gb2[rr] * er.uz, accR);
-              v0 = fmaf(Pm[r], gb0[rr], v0); v1 = fmaf(Pm[r], gb1[rr], v1); v2 = fmaf(Pm[r], gb2[rr], v2);
-            }
+          for (int r = 0; r < 16; ++r) {
+            const TileRec er = myE[16 * hi + r];
+            accq = fmaf(Pq[r], gqb[r], accq);
+            accR = fmaf(-PR[r], gb0[r] * er.ux + gb1[r] * er.uy + gb2[r] * er.uz, accR);
+            v0 = fmaf(Pm[r], gb0[r], v0); v1 = fmaf(Pm[r], gb1[r], v1); v2 = fmaf(Pm[r], gb2[r], v2);
           }
+          myA[(cb * NACC + 0) * 64 + lane] += accq;
           myA[(cb * NACC + 1) * 64 + lane] += accR;
           myA[(cb * NACC + 2) * 64 + lane] += v0; myA[(cb * NACC + 3) * 64 + lane] += v1; myA[(cb * NACC + 4) * 64 + lane] += v2;
           continue;
         }
-        // ---------------- R part
-        {
-          const f32x16 PR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Avh, Avl, lane);
-          f32x16 DR = PR;
-          if (WANT_G) DR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Adh, Adl, lane);
-          float accR = 0.f;
+        // ================ geometry gradient: the slope GEMMs of the three parts (and the value GEMM of the R part) first, then the neighbours' rows
+        // in batches of GS edges with the gathers of ALL parts of a batch in flight together
+        // (element indices here: with the byte offsets of the sums pass this sweep spills 204 B per lane and runs 1 036 us instead of 753; split into a dd
+        //  sweep and a t sweep it needs 214 registers, no scratch -- and 849 us: profiles/r06_painn_box.md)
+        const float gqa = a.gq_out[(unsigned)atom * F + c0];
+        const float ga0 = a.gmu_out[oa + c0], ga1 = a.gmu_out[oa + F + c0], ga2 = a.gmu_out[oa + 2 * F + c0];
+#if SPK_RT_HOLLOW == 3
+        f32x16 Dq, PR, DR, Dm;
+        for (int r = 0; r < 16; ++r) { Dq[r] = fc; PR[r] = d; DR[r] = invd; Dm[r] = dfc; }
+#else
+        const f32x16 Dq = tile_gemm_split<KPB, NB>(sWh, sWl, cb, Adh, Adl, lane);
+        const f32x16 PR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Avh, Avl, lane);
+        const f32x16 DR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Adh, Adl, lane);
+        f32x16 Dm = Dq;
+        if (!MU0) Dm = tile_gemm_split<KPB, NB>(sWh, sWl, 2 * NT + cb, Adh, Adl, lane);
+#endif
 #pragma unroll
-          for (int g0 = 0; g0 < 16; g0 += GS) {
-            float cR[GS], gb0[GS], gb1[GS], gb2[GS];
+        for (int g0 = 0; g0 < 16; g0 += GS) {
+          float cq[GS], cR[GS], cm[GS], mb0[GS], mb1[GS], mb2[GS];
 #pragma unroll
-            for (int rr = 0; rr < GS; ++rr) {
-              const unsigned oj = (unsigned)myE[16 * hi + g0 + rr].j * F3 + c0;
-              cR[rr] = WANT_G ? a.c[oj + F] : 0.f;
-              if (!GEOM) { gb0[rr] = a.gmu_out[oj]; gb1[rr] = a.gmu_out[oj + F]; gb2[rr] = a.gmu_out[oj + 2 * F]; }
-              else { gb0[rr] = 0.f; gb1[rr] = 0.f; gb2[rr] = 0.f; }
-            }
-#pragma unroll
-            for (int rr = 0; rr < GS; ++rr) {
-              const int r = g0 + rr;
-              const TileRec er = myE[16 * hi + r];
-              if (WANT_G) {
-                const float gu = ga0 * er.ux + ga1 * er.uy + ga2 * er.uz;
-                sdd[r] = fmaf(cR[rr] * gu, DR[r], sdd[r]);
-                const float mR = PR[r] * cR[rr];
-                stx[r] = fmaf(ga0, mR, stx[r]); sty[r] = fmaf(ga1, mR, sty[r]); stz[r] = fmaf(ga2, mR, stz[r]);
-              }
-              if (!GEOM) accR = fmaf(-PR[r], gb0[rr] * er.ux + gb1[rr] * er.uy + gb2[rr] * er.uz, accR);
-            }
+          for (int rr = 0; rr < GS; ++rr) {
+            const unsigned oj = (unsigned)myE[16 * hi + g0 + rr].j * F3 + c0;
+#if SPK_RT_HOLLOW == 2
+            cq[rr] = (float)(oj & 3); cR[rr] = (float)(oj & 5); cm[rr] = (float)(oj & 9); mb0[rr] = (float)(oj & 17); mb1[rr] = (float)(oj & 33); mb2[rr] = (float)(oj & 65);
+#else
+            cq[rr] = a.c[oj];
+            cR[rr] = a.c[oj + F];
+            if (!MU0) { cm[rr] = a.c[oj + 2 * F]; mb0[rr] = a.mu[oj]; mb1[rr] = a.mu[oj + F]; mb2[rr] = a.mu[oj + 2 * F]; }
+            else { cm[rr] = 0.f; mb0[rr] = 0.f; mb1[rr] = 0.f; mb2[rr] = 0.f; }
+#endif
           }
-          if (!GEOM) myA[(cb * NACC + 1) * 64 + lane] += accR;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---------------- mu part
-        if (!(GEOM && MU0) && !(MU0 && !WANT_T) && (WANT_T || !MU0)) {
-          f32x16 Pm = sdd, Dm = sdd;
-          if (!GEOM) Pm = tile_gemm_split<KPB, NB>(sWh, sWl, 2 * NT + cb, Avh, Avl, lane);
-          if (!MU0 && WANT_G) Dm = tile_gemm_split<KPB, NB>(sWh, sWl, 2 * NT + cb, Adh, Adl, lane);
-          float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
-          for (int g0 = 0; g0 < 16; g0 += GS) {
-            float cm[GS], mb0[GS], mb1[GS], mb2[GS], gb0[GS], gb1[GS], gb2[GS];
-#pragma unroll
-            for (int rr = 0; rr < GS; ++rr) {
-              const unsigned oj = (unsigned)myE[16 * hi + g0 + rr].j * F3 + c0;
-              if (!MU0 && WANT_G) { cm[rr] = a.c[oj + 2 * F]; mb0[rr] = a.mu[oj]; mb1[rr] = a.mu[oj + F]; mb2[rr] = a.mu[oj + 2 * F]; }
-              else { cm[rr] = 0.f; mb0[rr] = 0.f; mb1[rr] = 0.f; mb2[rr] = 0.f; }
-              if (!GEOM) { gb0[rr] = a.gmu_out[oj]; gb1[rr] = a.gmu_out[oj + F]; gb2[rr] = a.gmu_out[oj + 2 * F]; }
-              else { gb0[rr] = 0.f; gb1[rr] = 0.f; gb2[rr] = 0.f; }
+          for (int rr = 0; rr < GS; ++rr) {
+            const int r = g0 + rr;
+            const TileRec er = myE[16 * hi + r];
+            const float gu = ga0 * er.ux + ga1 * er.uy + ga2 * er.uz;
+            float s = fmaf(cq[rr] * gqa, Dq[r], sdd[r]);
+            s = fmaf(cR[rr] * gu, DR[r], s);
+            if (!MU0) {
+              const float gm = ga0 * mb0[rr] + ga1 * mb1[rr] + ga2 * mb2[rr];
+              s = fmaf(cm[rr] * gm, Dm[r], s);
             }
-#pragma unroll
-            for (int rr = 0; rr < GS; ++rr) {
-              const int r = g0 + rr;
-              if (!MU0 && WANT_G) {
-                const float gm = ga0 * mb0[rr] + ga1 * mb1[rr] + ga2 * mb2[rr];
-                sdd[r] = fmaf(cm[rr] * gm, Dm[r], sdd[r]);
-              }
-              if (!GEOM) { v0 = fmaf(Pm[r], gb0[rr], v0); v1 = fmaf(Pm[r], gb1[rr], v1); v2 = fmaf(Pm[r], gb2[rr], v2); }
-            }
-          }
-          if (!GEOM) {
-            myA[(cb * NACC + 2) * 64 + lane] += v0; myA[(cb * NACC + 3) * 64 + lane] += v1; myA[(cb * NACC + 4) * 64 + lane] += v2;
+            sdd[r] = s;
+            const float mR = PR[r] * cR[rr];
+            stx[r] = fmaf(ga0, mR, stx[r]); sty[r] = fmaf(ga1, mR, sty[r]); stz[r] = fmaf(ga2, mR, stz[r]);
           }
         }
       }
@@ -939,7 +916,7 @@ extern "C" void spk_painn_set_tile(int32_t mode) { g_tile_mode = mode > 0 ? 1 : 
 
 bool spk_painn_msg_tile_ok(const MsgArgs& a) {
   const int kpb = a.rb.n_rbf / 8 + 1;    // room for the bias column
-  if (g_tile_mode < 0 || !(a.F == 128 || a.F == 64) || kpb < 3 || kpb > 5 || a.E < 32 || a.N * 3 * (int64_t)a.F >= (1LL << 31)) return false;
+  if (g_tile_mode < 0 || !(a.F == 128 || a.F == 64) || kpb < 3 || kpb > 5 || a.E < 32 || a.N * 3 * (int64_t)a.F >= (1LL << 30)) return false;
   return g_tile_mode > 0 || (a.E >= (1 << 19) && !a.skin_list);
 }
 
@@ -994,7 +971,7 @@ bool spk_painn_msg_rowtile_bwd_ok(const MsgArgs& a) {
   static const int env = [] { const char* e = getenv("SPK_PAINN_ROWTILE"); return e ? (e[0] == '1' ? 1 : -1) : 0; }();
   const int mode = g_rowtile_mode ? g_rowtile_mode : env;
   const int kpb = a.rb.n_rbf / 8 + 1;
-  if (mode < 0 || !spk_get_split() || a.F != 128 || kpb < 3 || kpb > 4 || !a.rowptr || a.N * 3 * (int64_t)a.F >= (1LL << 31)) return false;
+  if (mode < 0 || !spk_get_split() || a.F != 128 || kpb < 3 || kpb > 4 || !a.rowptr || a.N * 3 * (int64_t)a.F >= (1LL << 30)) return false;
   return mode > 0 || a.E >= (1 << 19);
 }
 
