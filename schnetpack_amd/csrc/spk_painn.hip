@@ -448,6 +448,8 @@ static int msg_dispatch(const MsgArgs& a_in, bool row_ok, hipStream_t stream, co
   SPK_CHECK_ARG(variant != SPK_VARIANT_MFMA || shape_ok, "%s: shape F=%d n_rbf=%d (or unsorted/asymmetric list) not supported by the row kernel", who, F, K);
   if (row_ok && variant != SPK_VARIANT_SIMPLE && spk_painn_blk_ok(a, BWD))       // large lists with a block plan (spk_painn_blk.hip)
     return BWD ? spk_painn_blk_bwd(a, stream) : spk_painn_blk_fwd(a, stream);
+  if (!BWD && shape_ok && variant != SPK_VARIANT_SIMPLE && spk_painn_msg_rowtile_fwd_ok(a))
+    return spk_painn_msg_rowtile_fwd(a, stream);      // a wavefront per row, split-precision filter GEMM, no atomics (spk_painn_tile.hip, round 6)
   if (!BWD && shape_ok && variant != SPK_VARIANT_SIMPLE && spk_painn_msg_tile_ok(a)) {
     // forward on large lists: filter GEMM on the matrix cores, 32-edge tiles (spk_painn_tile.hip); the profile scope
     // covers the init launch too

@@ -46,3 +46,5 @@ int spk_painn_msg_tile_bwd(const MsgArgs& a, hipStream_t stream);
 // row-tile backward (spk_painn_tile.hip): a wavefront per CSR row, filter and slope from the split-precision GEMM of 32-edge chunks
 bool spk_painn_msg_rowtile_bwd_ok(const MsgArgs& a);
 int spk_painn_msg_rowtile_bwd(const MsgArgs& a, hipStream_t stream);
+bool spk_painn_msg_rowtile_fwd_ok(const MsgArgs& a);
+int spk_painn_msg_rowtile_fwd(const MsgArgs& a, hipStream_t stream);

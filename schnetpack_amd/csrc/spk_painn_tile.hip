@@ -231,6 +231,9 @@ __global__ __launch_bounds__(256, MINW) void k_painn_msg_tile(MsgArgs a, int nti
       }
     }
     auto gemm = [&](int t) -> f32x16 {
+#if SPK_RT_HOLLOW == 3
+      { f32x16 o; for (int r = 0; r < 16; ++r) o[r] = fc + (float)t; return o; }
+#endif
       if (SPLIT) return tile_gemm_split<KPS, NB>(sWh, sWl, t, Avh, Avl, lane);
       return tile_gemm<KPB>(sW, t, Av, lane);
     };
@@ -251,17 +254,26 @@ __global__ __launch_bounds__(256, MINW) void k_painn_msg_tile(MsgArgs a, int nti
 #pragma unroll 1
       for (int cb = 0; cb < NT; ++cb) {
         const unsigned c0 = 32u * cb + el;
+#if SPK_RT_HOLLOW == 1
+        continue;
+#endif
         // ---- scalar part: dq_i = sum Phi_q c_q[j]
         {
           float cq[16];
 #pragma unroll
+#if SPK_RT_HOLLOW == 2
+          for (int r = 0; r < 16; ++r) cq[r] = (float)(myE[16 * hi + r].j & 7);
+#else
           for (int r = 0; r < 16; ++r) cq[r] = ld_off(a.c, ((unsigned)myE[16 * hi + r].j * F3 + c0) * 4u);
+#endif
           const f32x16 Pq = gemm(cb);
           float acc = 0.f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             acc = fmaf(Pq[r], cq[r], acc);
+#if SPK_RT_HOLLOW != 4
             if ((runmask >> r) & 1u) { unsafeAtomicAdd(a.q_out + ((unsigned)myE[16 * hi + r].i * F + c0), acc); acc = 0.f; }
+#endif
           }
         }
         // ---- vector part: dmu_i = sum (Phi_R c_R[j]) u + (Phi_mu c_mu[j]) mu[j]
@@ -275,8 +287,14 @@ __global__ __launch_bounds__(256, MINW) void k_painn_msg_tile(MsgArgs a, int nti
 #pragma unroll
           for (int rr = 0; rr < 8; ++rr) {
             const unsigned bj = ((unsigned)myE[16 * hi + g0 + rr].j * F3 + c0) * 4u;       // byte offset (< 2^32: spk_painn_msg_tile_ok)
+#if SPK_RT_HOLLOW == 2
+            cR[rr] = (float)(bj & 12);
+            if (false) {
+#else
             cR[rr] = ld_off(a.c, bj + 4 * F);
-            if (!MU0) { cm[rr] = ld_off(a.c, bj + 8 * F); m0[rr] = ld_off(a.mu, bj); m1[rr] = ld_off(a.mu, bj + 4 * F); m2[rr] = ld_off(a.mu, bj + 8 * F); }
+            if (!MU0) {
+#endif
+              cm[rr] = ld_off(a.c, bj + 8 * F); m0[rr] = ld_off(a.mu, bj); m1[rr] = ld_off(a.mu, bj + 4 * F); m2[rr] = ld_off(a.mu, bj + 8 * F); }
             else { cm[rr] = 0.f; m0[rr] = 0.f; m1[rr] = 0.f; m2[rr] = 0.f; }
           }
 #pragma unroll
@@ -287,15 +305,20 @@ __global__ __launch_bounds__(256, MINW) void k_painn_msg_tile(MsgArgs a, int nti
             a0 = fmaf(mR, er.ux, MU0 ? a0 : fmaf(mm, m0[rr], a0));
             a1 = fmaf(mR, er.uy, MU0 ? a1 : fmaf(mm, m1[rr], a1));
             a2 = fmaf(mR, er.uz, MU0 ? a2 : fmaf(mm, m2[rr], a2));
+#if SPK_RT_HOLLOW != 4
             if ((runmask >> r) & 1u) {
               float* dst = a.mu_out + ((unsigned)er.i * F3 + c0);
               unsafeAtomicAdd(dst, a0); unsafeAtomicAdd(dst + F, a1); unsafeAtomicAdd(dst + 2 * F, a2);
               a0 = 0.f; a1 = 0.f; a2 = 0.f;
             }
+#endif
           }
         }
       }
     }
+#if SPK_RT_HOLLOW == 4
+    asm volatile("" :: "v"(d));
+#endif
     spk_wave_lds_sync();   // records may be rewritten by the next tile
   }
 }
@@ -642,6 +665,65 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_rowtile_bwd(MsgArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sdd[r] = 0.f; stx[r] = 0.f; sty[r] = 0.f; stz[r] = 0.f; }
 
+      if constexpr (WANT_G && !MU0) {
+        // ---- geometry pass of an interaction with vector features, in TWO sweeps over the channel blocks so that neither needs more than the
+        // register file: (S) dd = sum_c [c_q gq_i dF_q + c_R (gmu_i . u) dF_R + c_mu (gmu_i . mu_j) dF_mu] -- three slope GEMMs, six gathers, 16
+        // running sums; (V) t = sum_c gmu_i (F_R c_R) -- one value GEMM, one gather, 48 running sums.  (In one sweep, with the gathers of a batch
+        // held together by the scheduling barrier, the kernel spills 324 B per lane: 1 183 us.)
+#pragma unroll 1
+        for (int cb = 0; cb < NT; ++cb) {
+          const unsigned c0 = 32u * cb + el;
+          __builtin_amdgcn_sched_barrier(0);
+          const float gqa = ld_off(a.gq_out, ((unsigned)atom * F + c0) * 4u);
+          const float ga0 = ld_off(a.gmu_out, (oa + c0) * 4u), ga1 = ld_off(a.gmu_out, (oa + c0) * 4u + 4 * F), ga2 = ld_off(a.gmu_out, (oa + c0) * 4u + 8 * F);
+          float cq[16], cR[16], cm[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned bj = ((unsigned)myE[16 * hi + r].j * F3 + c0) * 4u;
+            cq[r] = ld_off(a.c, bj); cR[r] = ld_off(a.c, bj + 4 * F); cm[r] = ld_off(a.c, bj + 8 * F);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x16 Dq = tile_gemm_split<KPB, NB>(sWh, sWl, cb, Adh, Adl, lane);
+          const f32x16 DR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Adh, Adl, lane);
+          const f32x16 Dm = tile_gemm_split<KPB, NB>(sWh, sWl, 2 * NT + cb, Adh, Adl, lane);
+#pragma unroll
+          for (int g0 = 0; g0 < 16; g0 += GS) {
+            float mb0[GS], mb1[GS], mb2[GS];
+#pragma unroll
+            for (int rr = 0; rr < GS; ++rr) {
+              const unsigned bj = ((unsigned)myE[16 * hi + g0 + rr].j * F3 + c0) * 4u;
+              mb0[rr] = ld_off(a.mu, bj); mb1[rr] = ld_off(a.mu, bj + 4 * F); mb2[rr] = ld_off(a.mu, bj + 8 * F);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rr = 0; rr < GS; ++rr) {
+              const int r = g0 + rr;
+              const TileRec er = myE[16 * hi + r];
+              const float gu = ga0 * er.ux + ga1 * er.uy + ga2 * er.uz;
+              const float gm = ga0 * mb0[rr] + ga1 * mb1[rr] + ga2 * mb2[rr];
+              float sv = fmaf(cq[r] * gqa, Dq[r], sdd[r]);
+              sv = fmaf(cR[r] * gu, DR[r], sv);
+              sdd[r] = fmaf(cm[r] * gm, Dm[r], sv);
+            }
+          }
+        }
+#pragma unroll 1
+        for (int cb = 0; cb < NT; ++cb) {
+          const unsigned c0 = 32u * cb + el;
+          __builtin_amdgcn_sched_barrier(0);
+          const float ga0 = ld_off(a.gmu_out, (oa + c0) * 4u), ga1 = ld_off(a.gmu_out, (oa + c0) * 4u + 4 * F), ga2 = ld_off(a.gmu_out, (oa + c0) * 4u + 8 * F);
+          float cR[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cR[r] = ld_off(a.c, ((unsigned)myE[16 * hi + r].j * F3 + c0) * 4u + 4 * F);
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x16 PR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Avh, Avl, lane);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float mR = PR[r] * cR[r];
+            stx[r] = fmaf(ga0, mR, stx[r]); sty[r] = fmaf(ga1, mR, sty[r]); stz[r] = fmaf(ga2, mR, stz[r]);
+          }
+        }
+      } else {
 #pragma unroll 1
       for (int cb = 0; cb < NT; ++cb) {
         const unsigned c0 = 32u * cb + el;
@@ -665,6 +747,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_rowtile_bwd(MsgArgs a) {
             gb0[r] = ld_off(a.gmu_out, bj); gb1[r] = ld_off(a.gmu_out, bj + 4 * F); gb2[r] = ld_off(a.gmu_out, bj + 8 * F);
 #endif
           }
+          __builtin_amdgcn_sched_barrier(0);     // all 64 gathers are requested before the first MFMA
 #if SPK_RT_HOLLOW == 3
           f32x16 Pq, PR, Pm;
           for (int r = 0; r < 16; ++r) { Pq[r] = fc; PR[r] = d; Pm[r] = invd; }
@@ -717,6 +800,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_rowtile_bwd(MsgArgs a) {
             else { cm[rr] = 0.f; mb0[rr] = 0.f; mb1[rr] = 0.f; mb2[rr] = 0.f; }
 #endif
           }
+          __builtin_amdgcn_sched_barrier(0);     // the gathers of a batch are requested together
 #pragma unroll
           for (int rr = 0; rr < GS; ++rr) {
             const int r = g0 + rr;
@@ -733,6 +817,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_rowtile_bwd(MsgArgs a) {
             stx[r] = fmaf(ga0, mR, stx[r]); sty[r] = fmaf(ga1, mR, sty[r]); stz[r] = fmaf(ga2, mR, stz[r]);
           }
         }
+      }
       }
       // ---- per-edge sums over the 32 channel lanes of each half: quad sums by DPP, 8 partials per edge through LDS
       if (WANT_G) {
@@ -785,6 +870,146 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_rowtile_bwd(MsgArgs a) {
       }
       spk_wave_lds_sync();   // the slots are zeroed for the next row
     }
+  }
+}
+
+// ---- row-tile forward (round 6) ----------------------------------------------------------------------------------------------------
+// The message sum of painn.py:50-66 with the ownership of the row-tile backward: a wavefront per row, the filter from the split-precision GEMM of
+// 32-pair chunks, lanes own a channel of the current block, running sums over the 16 registers of a half parked in LDS between the chunks and
+// added over the two halves at the end of the row: q_out = q + dq and mu_out = mu + dmu are written once -- no float atomics (hollowed out, the
+// 32-edge tile kernel spends 450 of its 540 us with the gathers switched off and the same with the GEMMs switched off: what is left is the atomic
+// flush of every run of a tile, 89 M element updates at the L2), no init launch, a fixed summation order.  Needs a sorted list with row pointers.
+template <int F, int KPB, bool MU0, int GS, bool SKIN>
+__global__ __launch_bounds__(256, 2) void k_painn_msg_rowtile_fwd(MsgArgs a) {
+  constexpr int NT = F / 32;
+  constexpr int NB = 3 * NT;
+  constexpr int NACC = 4;             // dq, dmu_x, dmu_y, dmu_z
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* sWh = (char*)smem;
+  char* sWl = sWh + PtImage<KPB, NB>::BYTES;
+  TileRec* sE = (TileRec*)(sWl + PtImage<KPB, NB>::BYTES);    // 4 waves x 32 records
+  float* sAcc = (float*)(sE + 4 * 32);                         // 4 waves x NT x NACC x 64
+  int* sLive = (int*)(sAcc + 4 * NT * NACC * 64);              // SKIN: 4 waves x RT_LIVE_CAP edge numbers
+  const int K = a.rb.n_rbf;
+
+  stage_filter_split<KPB, NB>(sWh, sWl, a.wf, a.bf, K);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  TileRec* myE = sE + wv * 32;
+  float* myA = sAcc + wv * (NT * NACC * 64);
+  int* myL = sLive + wv * RT_LIVE_CAP;
+  const int slot = slot_of_row(el);
+  constexpr unsigned F3 = 3u * F;
+
+  const int64_t per_xcd = a.xcd_map ? (a.N + 7) / 8 : a.N;
+  const int64_t a_lo = a.xcd_map ? (int64_t)(blockIdx.x & 7) * per_xcd : 0;
+  const int64_t a_hi = a.xcd_map ? (a_lo + per_xcd < a.N ? a_lo + per_xcd : a.N) : a.N;
+  const int64_t a_first = a.xcd_map ? a_lo + (int64_t)(blockIdx.x >> 3) * 4 + wv : (int64_t)blockIdx.x * 4 + wv;
+  const int64_t a_step = a.xcd_map ? (int64_t)((gridDim.x + 7) >> 3) * 4 : (int64_t)gridDim.x * 4;
+  for (int64_t atom = a_first; atom < a_hi; atom += a_step) {
+    const int32_t e0 = a.rowptr[atom], e1 = a.rowptr[atom + 1];
+    const unsigned oa = (unsigned)atom * F3;
+#pragma unroll
+    for (int q = 0; q < NT * NACC; ++q) myA[q * 64 + lane] = 0.f;
+    int32_t n_work = e1 - e0;
+    const bool compact = SKIN && n_work <= RT_LIVE_CAP;
+    if (SKIN && compact) {
+      int nl = 0;
+      for (int32_t cs = e0; cs < e1; cs += 64) {
+        const int32_t em = cs + lane;
+        bool live = em < e1;
+        if (live) {
+          const float x_ = a.rij[3 * (int64_t)em], y_ = a.rij[3 * (int64_t)em + 1], z_ = a.rij[3 * (int64_t)em + 2];
+          live = x_ * x_ + y_ * y_ + z_ * z_ < a.rb.cutoff * a.rb.cutoff;
+        }
+        const unsigned long long mask = __ballot(live);
+        const int pos = nl + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (live) myL[pos] = em;
+        nl += __popcll(mask);
+      }
+      n_work = nl;
+      spk_wave_lds_sync();
+    }
+    for (int32_t cs = 0; cs < n_work; cs += 32) {
+      const bool valid = cs + slot < n_work;
+      const int32_t sl = valid ? cs + slot : n_work - 1;
+      const int64_t e = (SKIN && compact) ? myL[sl] : e0 + sl;
+      const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+      const int cj = (int)a.idx_j[e];
+      const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+      const float invd = 1.0f / d;
+      float fc, dfc;
+      spk_cutoff_eval_fast(a.rb.cutoff, d, fc, dfc);
+      if (!valid) fc = 0.f;
+      if (hi == 0) {
+        TileRec rec; rec.i = (int)atom; rec.j = cj; rec.ux = rx * invd; rec.uy = ry * invd; rec.uz = rz * invd; rec.invd = invd; rec.r0 = 0.f; rec.r1 = 0.f;
+        myE[slot] = rec;
+      }
+      h16x8 Avh[2], Avl[2], Adh_[2], Adl_[2];
+      tile_operands_split<KPB, false>(a.rb, K, hi, d, fc, 0.f, Avh, Avl, Adh_, Adl_);
+      spk_wave_lds_sync();
+
+#pragma unroll 1
+      for (int cb = 0; cb < NT; ++cb) {
+        const unsigned c0 = 32u * cb + el;
+        __builtin_amdgcn_sched_barrier(0);
+        // the scalar rows of all 16 edges are requested before the GEMMs of the block; the vector rows follow in batches of GS edges
+        float cq[16], cR[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned bj = ((unsigned)myE[16 * hi + r].j * F3 + c0) * 4u;
+          cq[r] = ld_off(a.c, bj); cR[r] = ld_off(a.c, bj + 4 * F);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // (without it the scheduler sinks every gather to its use and waits for them one by one: 994 us instead of ...)
+        const f32x16 Pq = tile_gemm_split<KPB, NB>(sWh, sWl, cb, Avh, Avl, lane);
+        const f32x16 PR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Avh, Avl, lane);
+        f32x16 Pm = PR;
+        if (!MU0) Pm = tile_gemm_split<KPB, NB>(sWh, sWl, 2 * NT + cb, Avh, Avl, lane);
+        float accq = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int g0 = 0; g0 < 16; g0 += GS) {
+          float cm[GS], m0[GS], m1[GS], m2[GS];
+#pragma unroll
+          for (int rr = 0; rr < GS; ++rr) {
+            const unsigned bj = ((unsigned)myE[16 * hi + g0 + rr].j * F3 + c0) * 4u;
+            if (!MU0) { cm[rr] = ld_off(a.c, bj + 8 * F); m0[rr] = ld_off(a.mu, bj); m1[rr] = ld_off(a.mu, bj + 4 * F); m2[rr] = ld_off(a.mu, bj + 8 * F); }
+            else { cm[rr] = 0.f; m0[rr] = 0.f; m1[rr] = 0.f; m2[rr] = 0.f; }
+          }
+          if (!MU0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int rr = 0; rr < GS; ++rr) {
+            const int r = g0 + rr;
+            const TileRec er = myE[16 * hi + r];
+            accq = fmaf(Pq[r], cq[r], accq);
+            const float mR = PR[r] * cR[r], mm = MU0 ? 0.f : Pm[r] * cm[rr];
+            a0 = fmaf(mR, er.ux, MU0 ? a0 : fmaf(mm, m0[rr], a0));
+            a1 = fmaf(mR, er.uy, MU0 ? a1 : fmaf(mm, m1[rr], a1));
+            a2 = fmaf(mR, er.uz, MU0 ? a2 : fmaf(mm, m2[rr], a2));
+          }
+        }
+        myA[(cb * NACC + 0) * 64 + lane] += accq;
+        myA[(cb * NACC + 1) * 64 + lane] += a0; myA[(cb * NACC + 2) * 64 + lane] += a1; myA[(cb * NACC + 3) * 64 + lane] += a2;
+      }
+      spk_wave_lds_sync();   // records may be rewritten by the next chunk
+    }
+    // ---- sums of the row: both halves added, q_out / mu_out of the centre atom written once
+    spk_wave_lds_sync();
+#pragma unroll
+    for (int cb = 0; cb < NT; ++cb) {
+      float t[NACC];
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) t[q] = myA[(cb * NACC + q) * 64 + lane] + myA[(cb * NACC + q) * 64 + (lane ^ 32)];
+      if (hi == 0) {
+        const unsigned c0 = 32u * cb + el;
+        a.q_out[(unsigned)atom * F + c0] = a.q[(unsigned)atom * F + c0] + t[0];
+        a.mu_out[oa + c0] = (MU0 ? 0.f : a.mu[oa + c0]) + t[1];
+        a.mu_out[oa + F + c0] = (MU0 ? 0.f : a.mu[oa + F + c0]) + t[2];
+        a.mu_out[oa + 2 * F + c0] = (MU0 ? 0.f : a.mu[oa + 2 * F + c0]) + t[3];
+      }
+    }
+    spk_wave_lds_sync();
   }
 }
 
@@ -907,6 +1132,27 @@ int launch_rowtile_bwd(const MsgArgs& a_in, hipStream_t stream) {
   return SPK_OK;
 }
 
+template <int F, int KPB, bool SKIN>
+int launch_rowtile_fwd(const MsgArgs& a_in, hipStream_t stream) {
+  constexpr int NB = 3 * (F / 32);
+  MsgArgs a = a_in;
+  a.xcd_map = (spk_xcd_walk_default() && a.N >= (1 << 14)) ? 1 : 0;
+  const size_t lds = 2 * (size_t)PtImage<KPB, NB>::BYTES + 4 * 32 * sizeof(TileRec) + (size_t)(4 * (F / 32) * 4 * 64) * sizeof(float) + (SKIN ? 4 * RT_LIVE_CAP * sizeof(int) : 0);
+  const void* kern = a.mu_zero ? (const void*)k_painn_msg_rowtile_fwd<F, KPB, true, 8, SKIN> : (const void*)k_painn_msg_rowtile_fwd<F, KPB, false, 8, SKIN>;
+  static SpkPerDevice attr_done;
+  int attr_done_dev;
+  if (attr_done.pending(&attr_done_dev)) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_rowtile_fwd<F, KPB, true, 8, SKIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_painn_msg_rowtile_fwd<F, KPB, false, 8, SKIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done.mark(attr_done_dev);
+  }
+  const int grid = a.xcd_map ? (spk_grid_for(a.N, 4, spk_num_cus() * 2) + 7) / 8 * 8 : spk_grid_for(a.N, 4, spk_num_cus() * 2);
+  void* args[] = {(void*)&a};
+  SpkProfScope prof(a.mu_zero ? "painn_msg_fwd_rowtile_mu0" : "painn_msg_fwd_rowtile", stream);
+  SPK_HIP_TRY(hipLaunchKernel(kern, dim3(grid), dim3(256), args, lds, stream));
+  return SPK_OK;
+}
+
 int g_tile_mode = 0;   // 0 auto (large lists), 1 always when the shape allows, -1 never
 int g_rowtile_mode = 0;   // 0 auto (large sorted symmetric lists, split path on), 1 always when the shape allows, -1 never
 
@@ -979,4 +1225,19 @@ int spk_painn_msg_rowtile_bwd(const MsgArgs& a, hipStream_t stream) {
   const int kpb = a.rb.n_rbf / 8 + 1;
   if (a.skin_list) return kpb == 3 ? launch_rowtile_bwd<128, 3, true>(a, stream) : launch_rowtile_bwd<128, 4, true>(a, stream);
   return kpb == 3 ? launch_rowtile_bwd<128, 3, false>(a, stream) : launch_rowtile_bwd<128, 4, false>(a, stream);
+}
+
+// row-tile forward: sorted list with row pointers (no symmetry needed)
+bool spk_painn_msg_rowtile_fwd_ok(const MsgArgs& a) {
+  static const int env = [] { const char* e = getenv("SPK_PAINN_ROWTILE_FWD"); return e ? (e[0] == '1' ? 1 : -1) : 0; }();
+  const int mode = g_rowtile_mode ? g_rowtile_mode : env;
+  const int kpb = a.rb.n_rbf / 8 + 1;
+  if (mode < 0 || !spk_get_split() || a.F != 128 || kpb < 3 || kpb > 4 || !a.rowptr || a.N * 3 * (int64_t)a.F >= (1LL << 30)) return false;
+  return mode > 0 || a.E >= (1 << 19);
+}
+
+int spk_painn_msg_rowtile_fwd(const MsgArgs& a, hipStream_t stream) {
+  const int kpb = a.rb.n_rbf / 8 + 1;
+  if (a.skin_list) return kpb == 3 ? launch_rowtile_fwd<128, 3, true>(a, stream) : launch_rowtile_fwd<128, 4, true>(a, stream);
+  return kpb == 3 ? launch_rowtile_fwd<128, 3, false>(a, stream) : launch_rowtile_fwd<128, 4, false>(a, stream);
 }

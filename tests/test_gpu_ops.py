@@ -642,7 +642,7 @@ def test_painn_message_backward_on_asymmetric_lists_without_atomics(dev, F, n_rb
 
 
 @pytest.mark.parametrize("n_rbf,mu_zero,skin", [(20, False, False), (20, True, False), (28, False, False), (20, False, True)])
-def test_painn_message_backward_row_tile(dev, n_rbf, mu_zero, skin):
+def test_painn_message_row_tile(dev, n_rbf, mu_zero, skin):
     """Row-tile backward (round 6, spk_painn_tile.hip): a wavefront per row, filter and slope from the split-precision GEMM of 32-pair chunks,
     geometry launch + transposed-sums launch.  Symmetric ring lists whose rows need one, two and three chunks (degree 24 / 56 / 70), pairs
     beyond the cutoff in every row (f_c = 0; with `skin` the rows are compacted first): equal to the float64 oracle, equal to the row kernel it
@@ -661,7 +661,7 @@ def test_painn_message_backward_row_tile(dev, n_rbf, mu_zero, skin):
         bf = torch.randn(3 * F, generator=g) * 0.1
         gq = torch.randn(N, F, generator=g)
         gmu = torch.randn(N, 3, F, generator=g)
-        _, _, gco, gmuo, gro = _msg_oracle(c, q, mu, r, idx_i, idx_j, wf, bf, N, F, gq, gmu)
+        qo, muo, gco, gmuo, gro = _msg_oracle(c, q, mu, r, idx_i, idx_j, wf, bf, N, F, gq, gmu)
         plan = ops.EdgePlan(idx_i.to(dev), idx_j.to(dev), N, r.to(dev))
         assert plan.sorted and plan.symmetric
         if skin:
@@ -683,8 +683,22 @@ def test_painn_message_backward_row_tile(dev, n_rbf, mu_zero, skin):
             tags = set(_lib.profile_report()); _lib.profile_enable(False)
             return gc, gmu_in, gr, tags
 
+        def run_fwd():
+            qd = q.to(dev).contiguous()
+            q_out = torch.full((N, F), float("nan"), device=dev)
+            mu_out = torch.full((N, 3, F), float("nan"), device=dev)
+            _lib.profile_enable(True); _lib.profile_report()
+            _lib.check(L.spk_painn_message_fwd_f32(plan.graph(), ctypes.byref(rb), _lib.fptr(cd), _lib.fptr(qd), _lib.fptr(mud), _lib.fptr(rd),
+                                                   _lib.fptr(wfd), _lib.fptr(bfd), F, _lib.fptr(q_out), _lib.fptr(mu_out), _lib.stream()))
+            tags = set(_lib.profile_report()); _lib.profile_enable(False)
+            return q_out, mu_out, tags
+
         try:
             L.spk_painn_set_rowtile(1)
+            f1, f2 = run_fwd(), run_fwd()        # the forward in the same form (a wavefront per row, no atomics)
+            assert f1[2] == {"painn_msg_fwd_rowtile"}, f1[2]      # (the mu == 0 instance is chosen by the representation driver, not by this entry point)
+            assert rel_err(f1[0].cpu(), qo) < TOL and rel_err(f1[1].cpu(), muo) < TOL, degree
+            assert torch.equal(f1[0], f2[0]) and torch.equal(f1[1], f2[1])
             a1, a2 = run(), run()
             assert a1[3] == {"painn_msg_bwd_rowtile_g", "painn_msg_bwd_rowtile_t"}, a1[3]
             assert rel_err(a1[0].cpu(), gco) < TOL and rel_err(a1[1].cpu(), gmuo) < TOL and rel_err(a1[2].cpu(), gro) < TOL, degree
