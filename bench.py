@@ -272,8 +272,8 @@ def self_spawn(args):
 PMC_TAGS = [
     ("schnet_mol_fwd", r"k_schnet_mol_fwd<"), ("schnet_mol_bwd", r"k_schnet_mol_bwd<"),
     ("painn_mol_fwd", r"k_painn_mol_fwd<"), ("painn_mol_bwd", r"k_painn_mol_bwd<"),
-    ("cfconv_fwd_pair", r"k_cfconv_pair<[^>]*false, false, false>"), ("cfconv_bwd_pair_gs_geom", r"k_cfconv_pair_t<[^>]*true, true, true>"),
-    ("cfconv_bwd_pair_gs", r"k_cfconv_pair_t<[^>]*true, true, false>"), ("cfconv_bwd_pair", r"k_cfconv_pair_t<[^>]*true, false"),
+    ("cfconv_fwd_pair", r"k_cfconv_pair<[^>]*false, false, false>|k_cfconv_pair_sp<"), ("cfconv_bwd_pair_gs_geom", r"k_cfconv_pair_t<[^>]*true, true, true>|k_cfconv_pair_t_sp<\d+, \d+, true>"),
+    ("cfconv_bwd_pair_gs", r"k_cfconv_pair_t<[^>]*true, true, false>|k_cfconv_pair_t_sp<\d+, \d+, false>"), ("cfconv_bwd_pair", r"k_cfconv_pair_t<[^>]*true, false"),
     ("cfconv_fwd_mol", r"k_cfconv_mol<[^>]*false>"), ("cfconv_bwd_mol", r"k_cfconv_mol<[^>]*true>"),
     ("cfconv_fwd_mfma", r"k_cfconv_mfma<[^>]*false, (true|false)>"), ("cfconv_bwd_mfma_sym", r"k_cfconv_mfma<[^>]*true, true>"),
     ("cfconv_bwd_mfma_atomic", r"k_cfconv_mfma<[^>]*true, false>"),
@@ -281,6 +281,10 @@ PMC_TAGS = [
     ("painn_msg_fwd_row_mu0", r"k_painn_msg_row<\d+, \d+, false, false, true[,>]"), ("painn_msg_bwd_row_geom", r"k_painn_msg_row<\d+, \d+, true, true"),
     ("painn_msg_fwd_tile_mu0", r"k_painn_msg_tile<\d+, \d+, true"), ("painn_msg_fwd_tile", r"k_painn_msg_tile<"),
     ("painn_msg_bwd_tile_geom", r"k_painn_msg_tile_bwd<\d+, \d+, true"), ("painn_msg_bwd_tile", r"k_painn_msg_tile_bwd<\d+, \d+, false"),
+    # row-tile kernels (round 6): <F, KPB, geometry, sums, mu == 0, batch, skin> / <F, KPB, mu == 0, batch, skin>
+    ("painn_msg_bwd_rowtile_geom", r"k_painn_msg_rowtile_bwd<\d+, \d+, true, false, true"), ("painn_msg_bwd_rowtile_g", r"k_painn_msg_rowtile_bwd<\d+, \d+, true, false, false"),
+    ("painn_msg_bwd_rowtile_t", r"k_painn_msg_rowtile_bwd<\d+, \d+, false, true"),
+    ("painn_msg_fwd_rowtile_mu0", r"k_painn_msg_rowtile_fwd<\d+, \d+, true"), ("painn_msg_fwd_rowtile", r"k_painn_msg_rowtile_fwd<\d+, \d+, false"),
     ("painn_mixing_fwd", r"k_painn_mixing_fwd"), ("painn_mixing_bwd", r"k_painn_mixing_bwd"),
     ("dense_chain", r"k_dense_chain"), ("scatter_add_segsum", r"k_segsum<4, \d+>"),
 ]
@@ -629,6 +633,11 @@ def algorithmic_work(kind, E, N, n_mol, F, n_int, n_rbf):
         "painn_msg_fwd_row_mu0": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0), "painn_msg_fwd_tile_mu0": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0),
         "painn_msg_bwd_row_geom": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0), "painn_msg_bwd_tile_geom": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0),
         "painn_msg_bwd_tile": ("hbm", 2 * msg_bytes, 1.0, 2 * bmin_msg),
+        # row-tile kernels (round 6): the backward of SURVEY.md 8(d) (2 x the forward's no-reuse bytes) runs as a geometry launch (neighbour c and mu:
+        # the forward's bytes) and a transposed-sums launch (neighbour gq and gmu: 2 060 B per edge)
+        "painn_msg_fwd_rowtile": ("hbm", msg_bytes, 1.0, bmin_msg), "painn_msg_fwd_rowtile_mu0": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0),
+        "painn_msg_bwd_rowtile_g": ("hbm", msg_bytes, 1.0, bmin_msg), "painn_msg_bwd_rowtile_geom": ("hbm", E * 1564.0 + N * 4096.0, 1.0, bmin_msg0),
+        "painn_msg_bwd_rowtile_t": ("hbm", E * 2076.0 + N * 4096.0, 1.0, N * (4096.0 + 16.0 * F) + E * 28.0),
     }
 
 
@@ -934,8 +943,8 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
         split_on = bool(_lib.get_split())
         if isinstance(roofline.get("measured"), dict) and roofline["measured"].get("mfma_inputs"):
             split_on = roofline["measured"]["mfma_inputs"] == "f16x2"        # what the counters of this launch say, not what the switch says
-        elif not any(t in roofline["kernel"] for t in ("schnet_mol", "painn_mol")):
-            split_on = False
+        elif not any(t in roofline["kernel"] for t in ("schnet_mol", "painn_mol", "cfconv_fwd_pair", "cfconv_bwd_pair_gs")):
+            split_on = False        # (round 6: the pair kernels of the box regime have split forms too, n_filters = 128)
         roofline["mfma_inputs"] = ("f16x2 split: fp16 high + 2^-11-scaled fp16 low operand pairs, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate"
                                    if split_on else "f32 (v_mfma_f32_32x32x2_f32)")
         if split_on:
