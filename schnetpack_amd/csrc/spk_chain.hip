@@ -374,6 +374,170 @@ __global__ __launch_bounds__(256, 2) void k_dense_chain16(ChainArgs a, int ld0, 
   CH_STAMP(12);
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-precision form of the 32-row kernel (round 6; spk_split.h): the same stream of weight chunks read from the SPLIT packed image (same chunk
+// geometry: chunk 2 s / 2 s + 1 of a 64-k block = fp16 high / low parts of k-step s), the activations of the tile kept in LDS as a high and a low
+// fp16 image [32][K + 8] each -- split ONCE by whoever writes them (the staging of the input tile, the epilogue of a layer), read as the B operands
+// of v_mfma_f32_32x32x16_f16 as they lie.  12 matrix instructions of 32 cycles per 64-k chunk and tile instead of 32 of 64 cycles.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chain_sp_store4(_Float16* __restrict__ bh, _Float16* __restrict__ bl, f32x4 x) {
+  h16x4 h, l;
+  sp_split4(x, h, l);
+  *(h16x4*)bh = h; *(h16x4*)bl = l;
+}
+__device__ __forceinline__ void chain_mfma_sp(const f32x4 (&av)[CCH], int c, const _Float16* __restrict__ bh, const _Float16* __restrict__ bl, int hi,
+                                              f32x16& acc, f32x16& cross) {
+  h16x8 vh[4], vl[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    vh[s] = *(const h16x8*)(bh + 64 * c + 16 * s + 8 * hi);
+    vl[s] = *(const h16x8*)(bl + 64 * c + 16 * s + 8 * hi);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const h16x8 ah = __builtin_bit_cast(h16x8, av[2 * s]), al = __builtin_bit_cast(h16x8, av[2 * s + 1]);
+    SP_STEP(ah, al, vh[s], vl[s], acc, cross);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_dense_chain_sp(ChainArgs a, int ld0, int ld1) {
+  // ld0 / ld1: row strides of the two activation buffers in HALVES (K + 8); each buffer = high image [32][ld] then low image [32][ld]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* buf0 = (_Float16*)smem;
+  _Float16* buf1 = buf0 + 2 * 32 * ld0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+
+  if (a.zero_ptr) {
+    const int64_t n4 = a.zero_count / 4;
+    f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t s = blockIdx.x * 256 + threadIdx.x; s < n4; s += (int64_t)gridDim.x * 256) ((f32x4*)a.zero_ptr)[s] = z4;
+    for (int64_t s = 4 * n4 + blockIdx.x * 256 + threadIdx.x; s < a.zero_count; s += (int64_t)gridDim.x * 256) a.zero_ptr[s] = 0.f;
+  }
+
+  const int64_t ntiles = (a.M + 31) / 32;
+  for (int64_t mt = blockIdx.x; mt < ntiles; mt += gridDim.x) {
+    const int64_t m0 = mt * 32;
+    f32x4 a0[CCH], a1[CCH];
+    {
+      int l2 = 0, t2 = wv;
+      bool have = wv < a.L[0].NW / 32;
+      if (!have) have = chain_next_tile(a, 0, 1 << 20, wv, l2, t2);
+      if (have) chain_load_a(a0, a.L[l2].w, a.L[l2].KC / 8, t2, 0, lane);
+    }
+    {
+      const int KC0 = a.L[0].KC;
+      const int q4 = KC0 / 4;
+      const int total = 32 * q4;
+      for (int i0 = 0; i0 < 12; i0 += 6) {
+        if (threadIdx.x + 256 * i0 >= total) break;
+        f32x4 v[6], pz[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int s = threadIdx.x + 256 * (i0 + i);
+          if (s < total) {
+            const int row = s / q4, c4 = s - row * q4;
+            int64_t mm = m0 + row;
+            if (mm >= a.M) mm = a.M - 1;
+            v[i] = *(const f32x4*)(a.in + mm * KC0 + 4 * c4);
+            if (a.in_pre) pz[i] = *(const f32x4*)(a.in_pre + mm * KC0 + 4 * c4);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int s = threadIdx.x + 256 * (i0 + i);
+          if (s < total) {
+            const int row = s / q4, c4 = s - row * q4;
+            f32x4 x = v[i];
+            if (a.in_pre) {
+              x.x *= chain_act_grad(a.in_act, pz[i].x); x.y *= chain_act_grad(a.in_act, pz[i].y);
+              x.z *= chain_act_grad(a.in_act, pz[i].z); x.w *= chain_act_grad(a.in_act, pz[i].w);
+            }
+            chain_sp_store4(buf0 + row * ld0 + 4 * c4, buf0 + (32 + row) * ld0 + 4 * c4, x);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int64_t m = m0 + el;
+    const bool valid = m < a.M;
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {
+      const ChainLayerDev& L = a.L[l];
+      const bool last = (l == a.n_layers - 1);
+      const _Float16* bh = (l & 1) ? buf1 + el * ld1 : buf0 + el * ld0;
+      const _Float16* bl = (l & 1) ? buf1 + (32 + el) * ld1 : buf0 + (32 + el) * ld0;
+      _Float16* nxt = (l & 1) ? buf0 : buf1;
+      const int ldn = (l & 1) ? ld0 : ld1;
+      const int nch = L.KC / (8 * CCH);   // even
+      const int tcount = L.NW / 32;
+#pragma unroll 1
+      for (int t = wv; t < tcount; t += 4) {
+        f32x4 rv[4], pv[4];
+        const bool has_res = L.res && valid, has_post = (!last) && L.post_pre && valid;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t off = m * L.NW + 32 * t + 8 * q + 4 * hi;
+          rv[q] = has_res ? *(const f32x4*)(L.res + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+          pv[q] = has_post ? *(const f32x4*)(L.post_pre + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x16 acc, cross;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = L.b ? L.b[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f; cross[r] = 0.f; }
+        for (int c = 0; c < nch; c += 2) {
+          chain_load_a(a1, L.w, L.KC / 8, t, c + 1, lane);
+          chain_mfma_sp(a0, c, bh, bl, hi, acc, cross);
+          if (c + 2 < nch) {
+            chain_load_a(a0, L.w, L.KC / 8, t, c + 2, lane);
+          } else {
+            int l2, t2;
+            if (chain_next_tile(a, l, t, wv, l2, t2)) chain_load_a(a0, a.L[l2].w, a.L[l2].KC / 8, t2, 0, lane);
+          }
+          chain_mfma_sp(a1, c + 1, bh, bl, hi, acc, cross);
+        }
+        SP_FOLD(acc, cross);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * t + 8 * q + 4 * hi;
+          const int64_t off = m * L.NW + col;
+          f32x4 o;
+          o.x = acc[4 * q]; o.y = acc[4 * q + 1]; o.z = acc[4 * q + 2]; o.w = acc[4 * q + 3];
+          if (L.pre_out && valid) *(f32x4*)(L.pre_out + off) = o;
+          if (L.act != SPK_ACT_NONE) {
+            o.x = chain_act(L.act, o.x); o.y = chain_act(L.act, o.y); o.z = chain_act(L.act, o.z); o.w = chain_act(L.act, o.w);
+          }
+          if (has_res) o += rv[q];
+          if (L.out && valid) *(f32x4*)(L.out + off) = o;
+          if (!last) {
+            if (has_post) {
+              const f32x4 p = pv[q];
+              o.x *= chain_act_grad(L.post_act, p.x); o.y *= chain_act_grad(L.post_act, p.y);
+              o.z *= chain_act_grad(L.post_act, p.z); o.w *= chain_act_grad(L.post_act, p.w);
+            }
+            chain_sp_store4(nxt + el * ldn + col, nxt + (32 + el) * ldn + col, o);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// split image that belongs to a packed fp32 image (registered by spk_apply_pack, spk_pack.h; looked up by the launcher below)
+#include <mutex>
+#include <unordered_map>
+static std::mutex g_split_mu;
+static std::unordered_map<const float*, const float*> g_split_of;
+void spk_register_split_image(const float* packed, const float* split) {
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  g_split_of[packed] = split;
+}
+static const float* split_image_of(const float* packed) {
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  auto it = g_split_of.find(packed);
+  return it == g_split_of.end() ? nullptr : it->second;
+}
+
 // ---- packed weight image ------------------------------------------------------------------
 // w is a Linear weight [n_out, k_in].  transposed == 0: the layer y = x W^T (A[i][kk] = W[i][kk], contraction
 // over k_in); transposed == 1: the input-gradient layer gx = gy W (A[i][kk] = W[kk][i], contraction over n_out).
@@ -508,7 +672,26 @@ extern "C" int spk_dense_chain_f32(const spk_chain_t* c, void* stream_) {
     const int64_t ntiles32 = (c->m + 31) / 32;
     const bool rows16 = g_chain_rows ? (g_chain_rows == 16) : (ntiles32 < 2 * (int64_t)spk_num_cus());
     SpkProfScope prof(c->n_layers == 1 ? "chain1" : (c->n_layers == 2 ? "chain2" : "chain3"), stream);
-    if (rows16) {
+    bool split = !rows16 && spk_get_split() != 0;
+    const float* wsp[CH_MAXL] = {nullptr, nullptr, nullptr};
+    for (int l = 0; l < c->n_layers && split; ++l) {
+      wsp[l] = (c->layers[l].k % 64 == 0) ? split_image_of(c->layers[l].w) : nullptr;
+      if (!wsp[l]) split = false;
+    }
+    if (split) {
+      // split-precision form (round 6): same launch geometry, activations as fp16 (high, low) images in LDS
+      for (int l = 0; l < c->n_layers; ++l) a.L[l].w = wsp[l];
+      const int ldh0 = w0 + 8, ldh1 = w1 + 8;
+      static SpkPerDevice attr_sp;
+      int attr_sp_dev;
+      if (attr_sp.pending(&attr_sp_dev)) {
+        SPK_HIP_TRY(hipFuncSetAttribute((const void*)k_dense_chain_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 2 * 32 * (CH_MAXW + 8) * sizeof(_Float16))));
+        attr_sp.mark(attr_sp_dev);
+      }
+      const int grid = (int)(ntiles32 < 4096 ? ntiles32 : 4096);
+      const size_t lds = (size_t)2 * 32 * (ldh0 + ldh1) * sizeof(_Float16);
+      hipLaunchKernelGGL(k_dense_chain_sp, dim3(grid), dim3(256), lds, stream, a, ldh0, ldh1);
+    } else if (rows16) {
       const int64_t ntiles = (c->m + 15) / 16;
       const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
       const size_t lds = (size_t)16 * (ld0 + ld1) * sizeof(float);

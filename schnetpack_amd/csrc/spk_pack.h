@@ -77,18 +77,22 @@ static inline const float* spk_packed_split_of(const SpkPackTable& T, const floa
   return nullptr;
 }
 
+// (spk_chain.hip) the split image that belongs to a packed fp32 image: the chain launcher takes the split-precision kernel when every layer has one
+void spk_register_split_image(const float* packed, const float* split);
+
 static inline void spk_apply_pack(spk_chain_t& c, const SpkPackTable& T) {
   if (!T.base || spk_get_variant() == SPK_VARIANT_SIMPLE) return;
   const float* repl[3] = {nullptr, nullptr, nullptr};
+  const float* repl_s[3] = {nullptr, nullptr, nullptr};
   for (int l = 0; l < c.n_layers; ++l) {
     const spk_chain_layer_t& L = c.layers[l];
     for (const SpkPackEntry& x : T.e) {
-      if (L.trans == 0 && L.w == x.raw && L.k == x.k_in && L.n_out == x.n_out) repl[l] = T.base + x.off_fwd;
-      else if (L.trans == 1 && x.rawT && L.w == x.rawT && L.k == x.k_in && L.n_out == x.n_out) repl[l] = T.base + x.off_fwd;
-      else if (L.trans == 1 && L.w == x.raw && L.k == x.n_out && L.n_out == x.k_in) repl[l] = T.base + x.off_bwd;
+      if (L.trans == 0 && L.w == x.raw && L.k == x.k_in && L.n_out == x.n_out) { repl[l] = T.base + x.off_fwd; repl_s[l] = x.off_fwd_s >= 0 ? T.base + x.off_fwd_s : nullptr; }
+      else if (L.trans == 1 && x.rawT && L.w == x.rawT && L.k == x.k_in && L.n_out == x.n_out) { repl[l] = T.base + x.off_fwd; repl_s[l] = x.off_fwd_s >= 0 ? T.base + x.off_fwd_s : nullptr; }
+      else if (L.trans == 1 && L.w == x.raw && L.k == x.n_out && L.n_out == x.k_in) { repl[l] = T.base + x.off_bwd; repl_s[l] = x.off_bwd_s >= 0 ? T.base + x.off_bwd_s : nullptr; }
       if (repl[l]) break;
     }
     if (!repl[l]) return;
   }
-  for (int l = 0; l < c.n_layers; ++l) { c.layers[l].w = repl[l]; c.layers[l].trans = 2; }
+  for (int l = 0; l < c.n_layers; ++l) { c.layers[l].w = repl[l]; c.layers[l].trans = 2; if (repl_s[l]) spk_register_split_image(repl[l], repl_s[l]); }
 }
