@@ -1,6 +1,6 @@
 // PaiNN message (representation/painn.py:31-67) for LARGE lists (periodic boxes, configs[4] of BASELINE.json): BLOCK kernels --
 // the "unique neighbours of a block of centre atoms staged in LDS, one 16-channel slice at a time, filter on the matrix core"
-// design of DESIGN.md 4.3 / the round-3 review.  EXPERIMENT, OPT-IN (spk_painn_set_block(1) + a plan from spk_blocks_build;
+// design of HISTORY.md 4.3 / the round-3 review.  EXPERIMENT, OPT-IN (spk_painn_set_block(1) + a plan from spk_blocks_build;
 // SPK_BLOCKS=1 for the torch operators): parity-green (tests/test_gpu_painn_blk.py), bit-reproducible (no atomics), and on the
 // 32k-atom water box SLOWER than the row / tile kernels it was meant to replace -- forward 0.97 ms against 0.67 ms, backward
 // 2.8 ms (passes T + G) against 1.46 ms, force call 11.3 ms against 7.26 ms (profiles/r04_block_kernels.md).  What was measured:

@@ -1740,7 +1740,7 @@ int spk_painn_mol_forward_ex(const spk_painn_t* m, const spk_graph_t* g, const s
   SPK_CHECK_ARG(!R || (head->H == 64 && head->w1 && head->b1 && head->w2 && head->idx_m && head->E && head->pre_h && (q0 || (emb && Z))), "spk_painn_mol_forward: incomplete potential arguments");
   a.n_layers = m->n_interactions;
   // the matrix-core form of the message is an EXPERIMENT, off by default (SPK_PM_TILED=1): correct (the parity tests run it), but
-  // 214 us against 197 us of the row form at cfg 3 -- see the comment at pm_message_tiled and DESIGN.md 4.3a
+  // 214 us against 197 us of the row form at cfg 3 -- see the comment at pm_message_tiled and HISTORY.md 4.3a
   { const char* e = getenv("SPK_PM_TILED"); a.tiled = (e && e[0] == '1' && rb->kind == SPK_RBF_GAUSSIAN) ? 1 : 0; }
   const bool split = spk_get_split() != 0 && !(a.tiled && !R);
   a.split = split ? 1 : 0;

@@ -12,7 +12,7 @@
 // pre-initialised with q / mu).  Matrix row m of the tile is edge slot 16 (m>>2 & 1) + (m & 3) + 4 (m >> 3), which
 // makes the 16 registers of a half-wave 16 CONSECUTIVE edges: a row of the list is split over as few runs as possible.
 //
-// Measurements and the dispatch rules that follow from them: DESIGN.md section 4.3, profiles/r01_painn_tile_experiment.json.
+// Measurements and the dispatch rules that follow from them: HISTORY.md section 4.3, profiles/r01_painn_tile_experiment.json.
 #include "spk_painn_msg.h"
 #ifndef SPK_RT_HOLLOW
 #define SPK_RT_HOLLOW 0     // timing aid of the row-tile backward: 1 = no channel-block loop, 2 = no gathers, 3 = no GEMMs (results are wrong)

@@ -81,7 +81,7 @@ def test_molecule_resident_painn_matches_oracle_and_general_driver(dev, sizes, n
 @pytest.mark.parametrize("assign", ["snake", "30"])
 def test_tuning_switches_keep_parity(dev, sizes, n_int, n_rbf, assign):
     """The switches of the tuning runs stay correct code: the message on the matrix core (SPK_PM_TILED=1, an experiment that is off
-    by default: DESIGN.md 4.3a) and the static atom -> wave assignments (SPK_PM_ASSIGN) against the float64 oracle and, bit for bit
+    by default: HISTORY.md 4.3a) and the static atom -> wave assignments (SPK_PM_ASSIGN) against the float64 oracle and, bit for bit
     where the summation order is the same, against the default path."""
     b = _mixed_batch(5, sizes)
     (e0, f0, x0, v0), _, (rep, head) = _run(b, dev, n_int, n_rbf)

@@ -63,7 +63,7 @@ def test_bench_books_every_modelled_kernel_with_a_lower_bound():
 
 
 def test_documented_second_order_of_the_filter_node():
-    """DESIGN.md 4.12 writes down the first and second derivative of the SchNet filter node (schnet.py:60-62) for the fused training
+    """HISTORY.md 4.12 writes down the first and second derivative of the SchNet filter node (schnet.py:60-62) for the fused training
     node that is not built yet: the formulas, restated in float64, against torch autograd."""
     import math
     torch.manual_seed(0)

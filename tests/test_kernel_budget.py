@@ -1,7 +1,7 @@
 """Register / scratch budget of the hot kernels, from hipcc's kernel-resource remarks (cross-compiles: no GPU needed).
 
 Round 2 measured what scratch costs on this part: a few dozen spilled values, parked in the prologue of a kernel, added 12-14 k
-cycles to every workgroup of the molecule-resident SchNet launches, and 240 B/lane of scratch in
+cycles to every workgroup of the molecule-resident SchNet launches (HISTORY.md section 4.1a), and 240 B/lane of scratch in
 `k_gemm_pair<true>` cost the training step 6 % (section 7).  A refactoring that pushes one of these kernels back over its register
 budget compiles, passes every numerical test and is slower -- so the budget is pinned here.
 """
@@ -31,7 +31,7 @@ BUDGET = {
     "spk_schnet_mol.hip": {"k_schnet_mol_fwdILi3ELb0E": (128, 2), "k_schnet_mol_fwdILi3ELb1E": (192, 2), "k_schnet_mol_bwdILi3E": (128, 2)},
     # molecule-resident PaiNN (round 3): both launches at the 256-register limit; what is left in scratch are values parked in the
     # prologue and a handful of reloads in the message loops -- when whole prefetched weight tiles were being spilled behind their
-    # loads the figures were 2 176 / 652 B per lane and every Dense phase waited for a chain of L2 round trips
+    # loads the figures were 2 176 / 652 B per lane and every Dense phase waited for a chain of L2 round trips (HISTORY.md 4.3a)
     # instances <n_rbf, tiled, potential> / <n_rbf, potential>: the row form (default) with and without the two-launch potential; the
     # tile-form experiment (SPK_PM_TILED=1) is not a budgeted path
     # (round 6: last template flag = split Dense phases, the default)
