@@ -705,6 +705,7 @@ struct MixFwdArgs {
   float eps;
   int64_t N;
   float* mix; float* preB; float* a; float* q_out; float* mu_out;
+  const float* wmix_s; const float* w1_s; const float* w2_s;   // split-precision images of the same layers (spk_split.h; null: fp32 matrix path)
 };
 
 // A operands of pair p (32 output features) for u-steps [u0, u0 + 4) from a packed image with KB k-blocks.
@@ -1024,6 +1025,7 @@ struct MixBwdArgs {
   float eps;
   int64_t N;
   float* gq1; float* gmix;
+  const float* w2t_s; const float* w1t_s;     // split-precision images (null: fp32 matrix path)
 };
 
 template <int F, int MINB>
@@ -1196,6 +1198,237 @@ __global__ __launch_bounds__(512, 2) void k_painn_mixing_bwd8(MixBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-precision forms of the two eight-wave kernels (round 6; spk_split.h): the same stages, the same ownership (wave w owns the features
+// [16 w, 16 w + 16) of every stage), the products on v_mfma_f32_16x16x32_f16 with (high, low) fp16 operand pairs -- 6 instructions of 16 cycles
+// per 64-k chunk and tile instead of 16 of 32.  Weights come from the split packed images (32-row tile geometry of k_pack_weight_split: the lane
+// of a 16 x 16 x 32 A operand picks its 16 bytes out of the two 16-k steps of a 32-k step); the activations of a tile live in LDS as fp16 images --
+// a row of K values is [K high halves | K low halves | pad], the byte length of the fp32 row -- split once by whoever writes them.
+// ------------------------------------------------------------------------------------------
+#include "spk_split.h"
+#define MIXS_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16((A), (B), (C), 0, 0, 0)
+// A operands (high, low) x (two 32-k steps) of the 16-feature tile (32-row tile p, half k) for the 64-k chunk starting at 16-k step u0
+__device__ __forceinline__ void mixs_load_a(f32x4 (&av)[4], const float* __restrict__ w, int KB, int p, int k, int u0, int el, int g) {
+  const char* base = (const char*)w + (((int64_t)p * KB + 2 * u0) * 64) * 16;
+  const uint32_t off = (uint32_t)((2 * (g >> 1)) * 1024 + ((g & 1) * 32 + 16 * k + el) * 16);
+#pragma unroll
+  for (int ds = 0; ds < 2; ++ds) {
+    av[2 * ds] = *(const f32x4*)(base + off + (4 * ds) * 1024);          // high parts of 32-k step ds
+    av[2 * ds + 1] = *(const f32x4*)(base + off + (4 * ds + 1) * 1024);  // low parts
+  }
+}
+// one 64-k chunk c of the product: B operands from the split LDS row `row` (K = contraction length of the row)
+__device__ __forceinline__ void mixs_mfma(const f32x4 (&av)[4], const _Float16* __restrict__ row, int K, int c, int g, f32x4& acc, f32x4& crs) {
+#pragma unroll
+  for (int ds = 0; ds < 2; ++ds) {
+    const h16x8 bh = *(const h16x8*)(row + 64 * c + 32 * ds + 8 * g);
+    const h16x8 bl = *(const h16x8*)(row + K + 64 * c + 32 * ds + 8 * g);
+    const h16x8 ah = __builtin_bit_cast(h16x8, av[2 * ds]), al = __builtin_bit_cast(h16x8, av[2 * ds + 1]);
+    acc = MIXS_MFMA(ah, bh, acc);
+    crs = MIXS_MFMA(ah, bl, crs);
+    crs = MIXS_MFMA(al, bh, crs);
+  }
+}
+__device__ __forceinline__ f32x4 mixs_fold(f32x4 acc, f32x4 crs) { return acc + crs * SP_DOWN; }
+// four consecutive values of a split LDS row
+__device__ __forceinline__ void mixs_store4(_Float16* __restrict__ row, int K, int col, f32x4 v) {
+  h16x4 h, l;
+  sp_split4(v, h, l);
+  *(h16x4*)(row + col) = h; *(h16x4*)(row + K + col) = l;
+}
+
+template <int F>
+__global__ __launch_bounds__(512, 2) void k_painn_mixing_fwd8s(MixFwdArgs a) {
+  static_assert(F == 128, "the weight stream below is written out for n_atom_basis = 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDA = 2 * (F + 4), LDC = 2 * (2 * F + 4), LDH = 2 * (F + 4);      // row strides in HALVES = the fp32 rows' bytes / 2
+  constexpr int KB1 = F / 8, KB2 = 2 * F / 8;
+  constexpr int PW = F / 32;
+  _Float16* sMu = (_Float16*)smem;           // [3][16] rows of F
+  _Float16* sCt = sMu + 48 * LDA;            // [16] rows of 2F: [q | |V|]
+  _Float16* sHd = sCt + 16 * LDC;            // [16] rows of F
+  const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pw = w8 >> 1, kw = w8 & 1;
+  const int h = lane >> 4, el = lane & 15;
+  const int f0 = 16 * w8 + 4 * h;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t ntiles = (a.N + 15) / 16;
+  f32x4 wa[4], wb[4];
+  if ((int64_t)blockIdx.x < ntiles) mixs_load_a(wa, a.wmix_s, KB1, pw, kw, 0, el, h);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t m0 = tile * 16;
+    int64_t m = m0 + el;
+    const bool valid = m < a.N;
+    if (!valid) m = a.N - 1;
+    constexpr int Q4 = F / 4;
+    for (int s = threadIdx.x; s < 48 * Q4; s += 512) {
+      const int row = s / Q4, c4 = s - row * Q4;
+      const int x = row >> 4, n = row & 15;
+      int64_t mm = m0 + n;
+      if (mm >= a.N) mm = a.N - 1;
+      mixs_store4(sMu + row * LDA, F, 4 * c4, *(const f32x4*)(a.mu1 + (mm * 3 + x) * F + 4 * c4));
+    }
+    for (int s = threadIdx.x; s < 16 * Q4; s += 512) {
+      const int n = s / Q4, c4 = s - n * Q4;
+      int64_t mm = m0 + n;
+      if (mm >= a.N) mm = a.N - 1;
+      mixs_store4(sCt + n * LDC, 2 * F, 4 * c4, *(const f32x4*)(a.q1 + mm * F + 4 * c4));
+    }
+    __syncthreads();
+    // ---- stage 1: channel mix
+    f32x4 V[3], W[3], Vx[3], Wx[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { V[x] = z4; W[x] = z4; Vx[x] = z4; Wx[x] = z4; }
+#define MIXS_X3(WSET, C, ACC, CRS)                                                                \
+    _Pragma("unroll") for (int x = 0; x < 3; ++x) mixs_mfma(WSET, sMu + (16 * x + el) * LDA, F, C, h, ACC[x], CRS[x]);
+    mixs_load_a(wb, a.wmix_s, KB1, pw, kw, 4, el, h);          MIXS_X3(wa, 0, V, Vx) __builtin_amdgcn_sched_barrier(0);
+    mixs_load_a(wa, a.wmix_s, KB1, pw + PW, kw, 0, el, h);     MIXS_X3(wb, 1, V, Vx) __builtin_amdgcn_sched_barrier(0);
+    mixs_load_a(wb, a.wmix_s, KB1, pw + PW, kw, 4, el, h);     MIXS_X3(wa, 0, W, Wx) __builtin_amdgcn_sched_barrier(0);
+    mixs_load_a(wa, a.w1_s, KB2, pw, kw, 0, el, h);            MIXS_X3(wb, 1, W, Wx) __builtin_amdgcn_sched_barrier(0);
+#undef MIXS_X3
+    f32x4 sVW = z4;
+    {
+      f32x4 n2 = {a.eps, a.eps, a.eps, a.eps};
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        V[x] = mixs_fold(V[x], Vx[x]); W[x] = mixs_fold(W[x], Wx[x]);
+        n2 += V[x] * V[x];
+        sVW += V[x] * W[x];
+        if (valid) {
+          *(f32x4*)(a.mix + (m * 3 + x) * 2 * F + f0) = V[x];
+          *(f32x4*)(a.mix + (m * 3 + x) * 2 * F + F + f0) = W[x];
+        }
+      }
+      f32x4 vn;
+      vn.x = sqrtf(n2.x); vn.y = sqrtf(n2.y); vn.z = sqrtf(n2.z); vn.w = sqrtf(n2.w);
+      mixs_store4(sCt + el * LDC, 2 * F, F + f0, vn);
+    }
+    __syncthreads();
+    // ---- stage 2: hidden = silu([q | |V|] W1^T + b1)
+    {
+      f32x4 acc = a.b1 ? *(const f32x4*)(a.b1 + f0) : z4, crs = z4;
+      const _Float16* brow = sCt + el * LDC;
+      mixs_load_a(wb, a.w1_s, KB2, pw, kw, 4, el, h);   mixs_mfma(wa, brow, 2 * F, 0, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wa, a.w1_s, KB2, pw, kw, 8, el, h);   mixs_mfma(wb, brow, 2 * F, 1, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wb, a.w1_s, KB2, pw, kw, 12, el, h);  mixs_mfma(wa, brow, 2 * F, 2, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wa, a.w2_s, KB1, pw, kw, 0, el, h);   mixs_mfma(wb, brow, 2 * F, 3, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      f32x4 o = mixs_fold(acc, crs);
+      if (valid) *(f32x4*)(a.preB + m * F + f0) = o;
+      o.x = o.x * spk_sigmoid(o.x); o.y = o.y * spk_sigmoid(o.y); o.z = o.z * spk_sigmoid(o.z); o.w = o.w * spk_sigmoid(o.w);
+      mixs_store4(sHd + el * LDH, F, f0, o);
+    }
+    __syncthreads();
+    // ---- stage 3: a = hidden W2^T + b2, parts (q | mu | q mu)
+    f32x4 A[3], Ax[3];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) { A[part] = a.b2 ? *(const f32x4*)(a.b2 + part * F + f0) : z4; Ax[part] = z4; }
+    {
+      const _Float16* brow = sHd + el * LDH;
+      const bool more = tile + gridDim.x < ntiles;
+      mixs_load_a(wb, a.w2_s, KB1, pw, kw, 4, el, h);              mixs_mfma(wa, brow, F, 0, h, A[0], Ax[0]); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wa, a.w2_s, KB1, pw + PW, kw, 0, el, h);         mixs_mfma(wb, brow, F, 1, h, A[0], Ax[0]); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wb, a.w2_s, KB1, pw + PW, kw, 4, el, h);         mixs_mfma(wa, brow, F, 0, h, A[1], Ax[1]); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wa, a.w2_s, KB1, pw + 2 * PW, kw, 0, el, h);     mixs_mfma(wb, brow, F, 1, h, A[1], Ax[1]); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wb, a.w2_s, KB1, pw + 2 * PW, kw, 4, el, h);     mixs_mfma(wa, brow, F, 0, h, A[2], Ax[2]); __builtin_amdgcn_sched_barrier(0);
+      if (more) mixs_load_a(wa, a.wmix_s, KB1, pw, kw, 0, el, h);  mixs_mfma(wb, brow, F, 1, h, A[2], Ax[2]); __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- stage 4: q += a_q + a_qmu sum_x V W ;  mu += a_mu W   (q and mu re-read in fp32: the LDS copies are split images)
+    if (valid) {
+#pragma unroll
+      for (int part = 0; part < 3; ++part) { A[part] = mixs_fold(A[part], Ax[part]); *(f32x4*)(a.a + m * 3 * F + part * F + f0) = A[part]; }
+      const f32x4 q = *(const f32x4*)(a.q1 + m * F + f0);
+      *(f32x4*)(a.q_out + m * F + f0) = q + A[0] + A[2] * sVW;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const f32x4 mu = *(const f32x4*)(a.mu1 + (m * 3 + x) * F + f0);
+        *(f32x4*)(a.mu_out + (m * 3 + x) * F + f0) = mu + A[1] * W[x];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int F>
+__global__ __launch_bounds__(512, 2) void k_painn_mixing_bwd8s(MixBwdArgs a) {
+  static_assert(F == 128, "the weight stream below is written out for n_atom_basis = 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDG = 2 * (3 * F + 4), LDT = 2 * (F + 4);      // row strides in halves
+  constexpr int KB3 = 3 * F / 8, KB1 = F / 8;
+  constexpr int PW = F / 32;
+  _Float16* sGa = (_Float16*)smem;       // [16] rows of 3F: dL/da (q | mu | q mu)
+  _Float16* sT = sGa + 16 * LDG;         // [16] rows of F: dL/d hidden pre-activation
+  const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pw = w8 >> 1, kw = w8 & 1;
+  const int h = lane >> 4, el = lane & 15;
+  const int f0 = 16 * w8 + 4 * h;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t ntiles = (a.N + 15) / 16;
+  f32x4 wa[4], wb[4];
+  if ((int64_t)blockIdx.x < ntiles) mixs_load_a(wa, a.w2t_s, KB3, pw, kw, 0, el, h);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t m0 = tile * 16;
+    int64_t m = m0 + el;
+    const bool valid = m < a.N;
+    if (!valid) m = a.N - 1;
+    // ---- stage 0: gradient of the update (painn.py:111-116) for this wave's features
+    f32x4 V[3], gV[3], gq4, invn;
+    {
+      const f32x4 amu = *(const f32x4*)(a.a + m * 3 * F + F + f0), aqm = *(const f32x4*)(a.a + m * 3 * F + 2 * F + f0);
+      gq4 = *(const f32x4*)(a.gq + m * F + f0);
+      f32x4 s = z4, gam = z4, n2 = {a.eps, a.eps, a.eps, a.eps};
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const f32x4 v = *(const f32x4*)(a.mix + (m * 3 + x) * 2 * F + f0);
+        const f32x4 w = *(const f32x4*)(a.mix + (m * 3 + x) * 2 * F + F + f0);
+        const f32x4 gm = *(const f32x4*)(a.gmu + (m * 3 + x) * F + f0);
+        V[x] = v;
+        s += v * w; gam += gm * w; n2 += v * v;
+        gV[x] = gq4 * aqm * w;
+        if (valid) *(f32x4*)(a.gmix + (m * 3 + x) * 2 * F + F + f0) = gq4 * aqm * v + gm * amu;
+      }
+      invn.x = 1.0f / sqrtf(n2.x); invn.y = 1.0f / sqrtf(n2.y); invn.z = 1.0f / sqrtf(n2.z); invn.w = 1.0f / sqrtf(n2.w);
+      mixs_store4(sGa + el * LDG, 3 * F, f0, gq4);
+      mixs_store4(sGa + el * LDG, 3 * F, F + f0, gam);
+      mixs_store4(sGa + el * LDG, 3 * F, 2 * F + f0, gq4 * s);
+    }
+    __syncthreads();
+    // ---- stage 1: t = (ga W2) * silu'(preB), contraction 3F = 6 chunks
+    {
+      f32x4 acc = z4, crs = z4;
+      const _Float16* brow = sGa + el * LDG;
+      mixs_load_a(wb, a.w2t_s, KB3, pw, kw, 4, el, h);   mixs_mfma(wa, brow, 3 * F, 0, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wa, a.w2t_s, KB3, pw, kw, 8, el, h);   mixs_mfma(wb, brow, 3 * F, 1, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wb, a.w2t_s, KB3, pw, kw, 12, el, h);  mixs_mfma(wa, brow, 3 * F, 2, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wa, a.w2t_s, KB3, pw, kw, 16, el, h);  mixs_mfma(wb, brow, 3 * F, 3, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wb, a.w2t_s, KB3, pw, kw, 20, el, h);  mixs_mfma(wa, brow, 3 * F, 4, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wa, a.w1t_s, KB1, pw, kw, 0, el, h);   mixs_mfma(wb, brow, 3 * F, 5, h, acc, crs); __builtin_amdgcn_sched_barrier(0);
+      const f32x4 pb = *(const f32x4*)(a.preB + m * F + f0);
+      f32x4 o = mixs_fold(acc, crs);
+      o.x *= spk_act_grad<SPK_ACT_SILU>(pb.x); o.y *= spk_act_grad<SPK_ACT_SILU>(pb.y);
+      o.z *= spk_act_grad<SPK_ACT_SILU>(pb.z); o.w *= spk_act_grad<SPK_ACT_SILU>(pb.w);
+      mixs_store4(sT + el * LDT, F, f0, o);
+    }
+    __syncthreads();
+    // ---- stage 2: g_ctx = t W1: the q part feeds dL/dq, the |V| part the norm term of dL/dV
+    {
+      f32x4 q0 = z4, n0 = z4, q0x = z4, n0x = z4;
+      const _Float16* brow = sT + el * LDT;
+      const bool more = tile + gridDim.x < ntiles;
+      mixs_load_a(wb, a.w1t_s, KB1, pw, kw, 4, el, h);              mixs_mfma(wa, brow, F, 0, h, q0, q0x); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wa, a.w1t_s, KB1, pw + PW, kw, 0, el, h);         mixs_mfma(wb, brow, F, 1, h, q0, q0x); __builtin_amdgcn_sched_barrier(0);
+      mixs_load_a(wb, a.w1t_s, KB1, pw + PW, kw, 4, el, h);         mixs_mfma(wa, brow, F, 0, h, n0, n0x); __builtin_amdgcn_sched_barrier(0);
+      if (more) mixs_load_a(wa, a.w2t_s, KB3, pw, kw, 0, el, h);    mixs_mfma(wb, brow, F, 1, h, n0, n0x); __builtin_amdgcn_sched_barrier(0);
+      if (valid) {
+        *(f32x4*)(a.gq1 + m * F + f0) = gq4 + mixs_fold(q0, q0x);
+        const f32x4 sc = mixs_fold(n0, n0x) * invn;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) *(f32x4*)(a.gmix + (m * 3 + x) * 2 * F + f0) = gV[x] + sc * V[x];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Measured (profiles/README.md, round 2): the spill-free variant wins at every size tried (cfg 3: forward 45.9 -> 42.9 us,
 // backward 34.3 -> 29.7 us; 32 k-atom box: 185 -> 166 us and 151 -> 130 us).  SPK_MIX_OCC=2 selects the two-workgroup form.
 static bool mix_one_block_per_cu(int64_t ntiles) {
@@ -1219,7 +1452,8 @@ static int launch_painn_mixing_bwd(const MixBwdArgs& a, int F, hipStream_t strea
   const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
   SpkProfScope prof("painn_mixing_bwd", stream);
   // few tiles per CU (molecule batches): one workgroup per CU, no scratch; many tiles per CU: two resident workgroups
-  if (mix_eight_waves(ntiles)) hipLaunchKernelGGL((k_painn_mixing_bwd8<128>), dim3(grid), dim3(512), lds, stream, a);
+  if (mix_eight_waves(ntiles) && a.w2t_s && a.w1t_s) hipLaunchKernelGGL((k_painn_mixing_bwd8s<128>), dim3(grid), dim3(512), lds, stream, a);
+  else if (mix_eight_waves(ntiles)) hipLaunchKernelGGL((k_painn_mixing_bwd8<128>), dim3(grid), dim3(512), lds, stream, a);
   else if (mix_one_block_per_cu(ntiles)) hipLaunchKernelGGL((k_painn_mixing_bwd<128, 1>), dim3(grid), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL((k_painn_mixing_bwd<128, 2>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
@@ -1232,7 +1466,8 @@ static int launch_painn_mixing_fwd(const MixFwdArgs& a, int F, hipStream_t strea
   const int64_t ntiles = (a.N + 15) / 16;
   const int grid = (int)(ntiles < 8192 ? ntiles : 8192);
   SpkProfScope prof("painn_mixing_fwd", stream);
-  if (mix_eight_waves(ntiles)) hipLaunchKernelGGL((k_painn_mixing_fwd8<128>), dim3(grid), dim3(512), lds, stream, a);
+  if (mix_eight_waves(ntiles) && a.wmix_s && a.w1_s && a.w2_s) hipLaunchKernelGGL((k_painn_mixing_fwd8s<128>), dim3(grid), dim3(512), lds, stream, a);
+  else if (mix_eight_waves(ntiles)) hipLaunchKernelGGL((k_painn_mixing_fwd8<128>), dim3(grid), dim3(512), lds, stream, a);
   else if (mix_one_block_per_cu(ntiles)) hipLaunchKernelGGL((k_painn_mixing_fwd<128, 1>), dim3(grid), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL((k_painn_mixing_fwd<128, 2>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
@@ -1412,6 +1647,7 @@ extern "C" int spk_painn_forward_f32(const spk_painn_t* m, const spk_graph_t* g,
       MixFwdArgs ma;
       ma.q1 = q1; ma.mu1 = mu1; ma.wmix = pk_mix; ma.w1 = pk_w1; ma.b1 = P.ictx_b1; ma.w2 = pk_w2; ma.b2 = P.ictx_b2;
       ma.eps = m->epsilon; ma.N = N; ma.mix = mix; ma.preB = preB; ma.a = av; ma.q_out = q_out; ma.mu_out = mu_next;
+      ma.wmix_s = spk_packed_split_of(ptab, P.mix_w, 0); ma.w1_s = spk_packed_split_of(ptab, P.ictx_w1, 0); ma.w2_s = spk_packed_split_of(ptab, P.ictx_w2, 0);
       SPK_TRY(launch_painn_mixing_fwd(ma, F, stream));
       continue;
     }
@@ -1485,6 +1721,7 @@ extern "C" int spk_painn_backward_f32(const spk_painn_t* m, const spk_graph_t* g
       MixBwdArgs mb;
       mb.gq = gq; mb.gmu = gmu; mb.mix = mix; mb.a = av; mb.preB = preB; mb.w2t = pk_w2t; mb.w1t = pk_w1t;
       mb.eps = m->epsilon; mb.N = N; mb.gq1 = gq1; mb.gmix = gmix;
+      mb.w2t_s = spk_packed_split_of(ptab, P.ictx_w2, 1); mb.w1t_s = spk_packed_split_of(ptab, P.ictx_w1, 1);
       SPK_TRY(launch_painn_mixing_bwd(mb, F, stream));
     } else {
     SPK_TRY(spk_painn_mix_update_bwd_f32(nullptr, mix, av, gq, gmu, N, F, ga, gmix, stream));
