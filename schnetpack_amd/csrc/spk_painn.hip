@@ -559,11 +559,16 @@ int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
     const int K = rb->n_rbf;
     const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 2);
     const size_t lds = (size_t)K * (3 * F + 1) * sizeof(float);
+    // large lists (round 6): the same two passes in row-tile form (spk_painn_tile.hip: filter from the split-precision GEMM of 32-pair chunks) --
+    // the sums pass over the by-neighbour list, the geometry pass over the list itself; neither assumes symmetry
+    const bool rowtile = spk_painn_msg_rowtile_bwd_ok(a);
     if (!geom_only) {
       hipLaunchKernelGGL(k_gather_rows3_neg, dim3(spk_grid_for(a.E, 256, spk_num_cus() * 8)), dim3(256), 0, stream, r_ij, T->perm, a.E, T->r_perm);
       SPK_LAUNCH_CHECK();
       MsgArgs t = a;
       t.idx_i = T->idx_i; t.idx_j = T->idx_j; t.rowptr = T->rowptr; t.rij = T->r_perm; t.gr = nullptr; t.blocks = nullptr; t.geom_only = 0;
+      if (rowtile) { t.geom_only = 2; int rc2 = spk_painn_msg_rowtile_bwd(t, stream); if (rc2) return rc2; }
+      else {
       SpkProfScope prof("painn_msg_bwd_row_tsum", stream);
 #define SPK_TS_CASE(VPLv, NRBFv)                                                                                                               \
   do {                                                                                                                                         \
@@ -574,9 +579,11 @@ int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
       else { if (K <= 20) SPK_TS_CASE(2, 20); else SPK_TS_CASE(2, 32); }
 #undef SPK_TS_CASE
       SPK_LAUNCH_CHECK();
+      }
     }
     MsgArgs gm = a;
     gm.geom_only = 1; gm.blocks = nullptr;
+    if (rowtile) return spk_painn_msg_rowtile_bwd(gm, stream);
     SpkProfScope prof("painn_msg_bwd_row_geom", stream);
 #define SPK_GM_CASE(VPLv, NRBFv)                                                                                                               \
   do {                                                                                                                                         \

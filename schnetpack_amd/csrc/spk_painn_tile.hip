@@ -1121,11 +1121,11 @@ int launch_rowtile_bwd(const MsgArgs& a_in, hipStream_t stream) {
   //  lockstep behind a barrier changes nothing -- the L1 is not where the neighbour rows are shared)
   const int grid = a.xcd_map ? (spk_grid_for(a.N, 4, spk_num_cus() * 2) + 7) / 8 * 8 : spk_grid_for(a.N, 4, spk_num_cus() * 2);
   void* args[] = {(void*)&a};
-  {
+  if (a.geom_only != 2) {      // (geom_only == 2: the transposed sums alone -- the by-neighbour pass of an asymmetric list)
     SpkProfScope prof(a.geom_only ? "painn_msg_bwd_rowtile_geom" : "painn_msg_bwd_rowtile_g", stream);
     SPK_HIP_TRY(hipLaunchKernel(kg, dim3(grid), dim3(256), args, lds_g, stream));
   }
-  if (!a.geom_only) {
+  if (a.geom_only != 1) {
     SpkProfScope prof("painn_msg_bwd_rowtile_t", stream);
     SPK_HIP_TRY(hipLaunchKernel(kt, dim3(grid), dim3(256), args, lds_t, stream));
   }

@@ -639,6 +639,17 @@ def test_painn_message_backward_on_asymmetric_lists_without_atomics(dev, F, n_rb
         assert rel_err(got[0].cpu(), gco) < TOL and rel_err(got[1].cpu(), gmuo) < TOL and rel_err(got[2].cpu(), gro) < TOL
     for x, y in zip(a1[:3], a2[:3]):
         assert torch.equal(x, y)                # fixed summation order
+    if F == 128 and n_rbf == 20:
+        # round 6: on large lists the two passes run in row-tile form (forced here): sums over the by-neighbour list, geometry over the list
+        try:
+            L.spk_painn_set_rowtile(1)
+            b1, b2 = run(), run()
+        finally:
+            L.spk_painn_set_rowtile(0)
+        assert b1[3] == {"painn_msg_bwd_rowtile_t", "painn_msg_bwd_rowtile_geom"}, b1[3]
+        assert rel_err(b1[0].cpu(), gco) < TOL and rel_err(b1[1].cpu(), gmuo) < TOL and rel_err(b1[2].cpu(), gro) < TOL
+        for x, y in zip(b1[:3], b2[:3]):
+            assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("n_rbf,mu_zero,skin", [(20, False, False), (20, True, False), (28, False, False), (20, False, True)])
