@@ -20,11 +20,14 @@ BUDGET = {
     "spk_dense.hip": {"k_gemm_pairILb1E": (0, 2), "k_gemm_pairILb0E": (0, 2), "k_dense_mfmaILi0ELb1ELi0E": (0, 2), "k_dense_mfmaILi0ELb0ELi0E": (0, 2),
                       "k_dense_dual_sk": (0, 2), "k_dense_dual_tiles": (0, 2), "k_dense_mfma_skILi0ELb0ELi0ELi4ELi4E": (0, 4)},
     "spk_fm.hip": {"k_gemm_tn_batched11GemmTnBatch": (0, 2), "k_fm_painn_msg_T_dualIfE": (0, 2), "k_fm_painn_msg_tIfE": (0, 2), "k_fm_cfconv_T_dualIfE": (0, 4)},
-    "spk_painn.hip": {"k_painn_mixing_fwd8ILi128E": (0, 2), "k_painn_mixing_bwd8ILi128E": (0, 2)},
-    # row-tile backward of the PaiNN message (round 6; template flags <F, KPB, geometry, sums, mu == 0, batch, skin>): the geometry pass sits at the
-    # 256-register limit (a few more live values cost it 19 % on the water box), the transposed-sums pass runs three waves per SIMD
-    "spk_painn_tile.hip": {"k_painn_msg_rowtile_bwdILi128ELi3ELb1ELb0ELb0ELi8ELb0E": (160, 2), "k_painn_msg_rowtile_bwdILi128ELi3ELb1ELb0ELb1ELi8ELb0E": (64, 2),
-                           "k_painn_msg_rowtile_bwdILi128ELi3ELb0ELb1ELb0ELi8ELb0E": (0, 3)},
+    "spk_painn.hip": {"k_painn_mixing_fwd8ILi128E": (0, 2), "k_painn_mixing_bwd8ILi128E": (0, 2), "k_painn_mixing_fwd8sILi128E": (0, 2), "k_painn_mixing_bwd8sILi128E": (0, 2)},
+    # row-tile kernels of the PaiNN message (round 6; backward <F, KPB, geometry, sums, mu == 0, batch, skin>, forward <F, KPB, mu == 0, batch, skin>):
+    # the geometry pass sits at the 256-register limit -- in ONE sweep it spilled 140-324 B per lane and every change of a few registers moved it by
+    # 20-40 % (profiles/r06_painn_box.md); the two-sweep form keeps a few dozen bytes of prologue spills
+    "spk_painn_tile.hip": {"k_painn_msg_rowtile_bwdILi128ELi3ELb1ELb0ELb0ELi8ELb0E": (64, 2), "k_painn_msg_rowtile_bwdILi128ELi3ELb1ELb0ELb1ELi8ELb0E": (32, 2),
+                           "k_painn_msg_rowtile_bwdILi128ELi3ELb0ELb1ELb0ELi8ELb0E": (0, 2),
+                           "k_painn_msg_rowtile_fwdILi128ELi3ELb0ELi8ELb0E": (0, 2), "k_painn_msg_rowtile_fwdILi128ELi3ELb1ELi8ELb0E": (0, 2)},
+    "spk_chain.hip": {"k_dense_chain_sp": (0, 2)},
     # the two molecule-resident launches sit AT the 256-register limit of two waves per SIMD; the metadata reports a small
     # private segment although no scratch instruction is on a hot path
     # (round 6: second template flag = the split-precision matrix path, the default; it carries the split operands of a tile on top)
