@@ -665,6 +665,46 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_rowtile_bwd(MsgArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sdd[r] = 0.f; stx[r] = 0.f; sty[r] = 0.f; stz[r] = 0.f; }
 
+      if constexpr (!WANT_G) {
+        // ---- transposed sums, software-pipelined over the channel blocks: the neighbours' gmu rows of block cb + 1 (48 gathers) are requested
+        // before the GEMMs of block cb, so that a round of gather latency is hidden behind a whole block of work instead of three GEMMs.  (The gq
+        // row of the block joins in-iteration: 64 prefetched loads would need s_waitcnt vmcnt(64), one more than the counter holds.)
+        float gbA[3][16], gbB[3][16];
+        auto load_gb = [&](float (&gb)[3][16], int cb_) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned bj = ((unsigned)myE[16 * hi + r].j * F3 + 32u * cb_ + el) * 4u;
+            gb[0][r] = ld_off(a.gmu_out, bj); gb[1][r] = ld_off(a.gmu_out, bj + 4 * F); gb[2][r] = ld_off(a.gmu_out, bj + 8 * F);
+          }
+        };
+        load_gb(gbA, 0);
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb) {
+          const unsigned c0 = 32u * cb + el;
+          float (&cur)[3][16] = (cb & 1) ? gbB : gbA;
+          float (&nxt)[3][16] = (cb & 1) ? gbA : gbB;
+          float gqb[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gqb[r] = ld_off(a.gq_out, ((unsigned)myE[16 * hi + r].j * F + c0) * 4u);
+          if (cb + 1 < NT) load_gb(nxt, cb + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x16 Pq = tile_gemm_split<KPB, NB>(sWh, sWl, cb, Avh, Avl, lane);
+          const f32x16 PR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Avh, Avl, lane);
+          const f32x16 Pm = tile_gemm_split<KPB, NB>(sWh, sWl, 2 * NT + cb, Avh, Avl, lane);
+          float accq = 0.f, accR = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const TileRec er = myE[16 * hi + r];
+            accq = fmaf(Pq[r], gqb[r], accq);
+            accR = fmaf(-PR[r], cur[0][r] * er.ux + cur[1][r] * er.uy + cur[2][r] * er.uz, accR);
+            v0 = fmaf(Pm[r], cur[0][r], v0); v1 = fmaf(Pm[r], cur[1][r], v1); v2 = fmaf(Pm[r], cur[2][r], v2);
+          }
+          myA[(cb * NACC + 0) * 64 + lane] += accq;
+          myA[(cb * NACC + 1) * 64 + lane] += accR;
+          myA[(cb * NACC + 2) * 64 + lane] += v0; myA[(cb * NACC + 3) * 64 + lane] += v1; myA[(cb * NACC + 4) * 64 + lane] += v2;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else
       if constexpr (WANT_G && !MU0) {
         // ---- geometry pass of an interaction with vector features, in TWO sweeps over the channel blocks so that neither needs more than the
         // register file: (S) dd = sum_c [c_q gq_i dF_q + c_R (gmu_i . u) dF_R + c_mu (gmu_i . mu_j) dF_mu] -- three slope GEMMs, six gathers, 16
@@ -951,18 +991,25 @@ __global__ __launch_bounds__(256, 2) void k_painn_msg_rowtile_fwd(MsgArgs a) {
       tile_operands_split<KPB, false>(a.rb, K, hi, d, fc, 0.f, Avh, Avl, Adh_, Adl_);
       spk_wave_lds_sync();
 
-#pragma unroll 1
-      for (int cb = 0; cb < NT; ++cb) {
-        const unsigned c0 = 32u * cb + el;
-        __builtin_amdgcn_sched_barrier(0);
-        // the scalar rows of all 16 edges are requested before the GEMMs of the block; the vector rows follow in batches of GS edges
-        float cq[16], cR[16];
+      // software-pipelined over the channel blocks: the scalar rows (c_q, c_R) of block cb + 1 are requested before the GEMMs of block cb; the vector
+      // rows follow inside the block in batches of GS edges
+      float cA[2][16], cB[2][16];
+      auto load_c = [&](float (&cc)[2][16], int cb_) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const unsigned bj = ((unsigned)myE[16 * hi + r].j * F3 + c0) * 4u;
-          cq[r] = ld_off(a.c, bj); cR[r] = ld_off(a.c, bj + 4 * F);
+          const unsigned bj = ((unsigned)myE[16 * hi + r].j * F3 + 32u * cb_ + el) * 4u;
+          cc[0][r] = ld_off(a.c, bj); cc[1][r] = ld_off(a.c, bj + 4 * F);
         }
-        __builtin_amdgcn_sched_barrier(0);     // (without it the scheduler sinks every gather to its use and waits for them one by one: 994 us instead of ...)
+      };
+      load_c(cA, 0);
+#pragma unroll
+      for (int cb = 0; cb < NT; ++cb) {
+        const unsigned c0 = 32u * cb + el;
+        float (&cq)[16] = (cb & 1) ? cB[0] : cA[0];
+        float (&cR)[16] = (cb & 1) ? cB[1] : cA[1];
+        __builtin_amdgcn_sched_barrier(0);
+        if (cb + 1 < NT) { if (cb & 1) load_c(cA, cb + 1); else load_c(cB, cb + 1); }
+        __builtin_amdgcn_sched_barrier(0);     // (without the barriers the scheduler sinks every gather to its use and waits for them one by one: 994 us)
         const f32x16 Pq = tile_gemm_split<KPB, NB>(sWh, sWl, cb, Avh, Avl, lane);
         const f32x16 PR = tile_gemm_split<KPB, NB>(sWh, sWl, NT + cb, Avh, Avl, lane);
         f32x16 Pm = PR;
