@@ -555,6 +555,8 @@ int spk_painn_message_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb,
   // as the GEOM row form over the list itself.  No atomics, fixed summation order: bit-reproducible.
   if (g->sorted && !g->symmetric && g->rowptr && g->transposed && g->transposed->r_perm && spk_get_variant() == SPK_VARIANT_AUTO && (F == 128 || F == 64) &&
       rb->n_rbf <= 32 && g->n_edges > 0 && !getenv("SPK_NO_TRANSPOSED")) {
+    // (T->r_perm is a workspace of the PLAN, rewritten by every call: two message backwards of the same plan must not run concurrently on different
+    //  streams -- the operator library and the drivers issue a plan's launches on one stream)
     const spk_transposed_t* T = g->transposed;
     const int K = rb->n_rbf;
     const int grid = spk_grid_for(a.N, 4, spk_num_cus() * 2);

@@ -196,7 +196,10 @@ struct PotentialFmFn : public torch::autograd::Function<PotentialFmFn> {
         TORCH_CHECK((flag & 1) == 0, who, ": idx_i / idx_m are not sorted ascending. The force-matching engine walks the pair list by centre atom "
                     "(every neighbour list of the reference is sorted this way; CountNeighbors(sorted=False)-style lists are not) -- sort the list, or set "
                     "`model.fm_engine = False` to train through the operator-by-operator path, which takes any pair order");
-        TORCH_CHECK((flag & 2) == 0, who, ": an atomic number lies outside the embedding table (max_z)");
+        // (bit 1 is shared by the range checks of the step: spk_index_jobs sets it for a pair / molecule index out of range, k_fm_embed for an
+        //  atomic number outside the embedding table)
+        TORCH_CHECK((flag & 2) == 0, who, ": an index is out of range -- a pair index (idx_i / idx_j >= n_atoms), a molecule index (idx_m >= n_molecules) "
+                    "or an atomic number outside the embedding table (>= max_z)");
       }
     }
     auto sv = ctx->get_saved_variables();

@@ -88,7 +88,9 @@ class FlatAdamW:
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self._lr = float(lr)
         self._lr_dev = torch.full((1,), float(lr), device=dev)
-        # the face a learning-rate schedule needs (torch schedulers read and write param_groups[0]["lr"]; call sync_lr() after scheduler.step())
+        # the face a learning-rate schedule needs: param_groups[0]["lr"] + sync_lr().  torch.optim.lr_scheduler classes check isinstance(optimizer,
+        # torch.optim.Optimizer) and cannot be attached to this object: compute the schedule externally (or drive a scheduler on a throw-away torch
+        # optimizer with the same initial lr) and write `opt.lr = value` / `opt.param_groups[0]["lr"] = value; opt.sync_lr()` once per step
         self.param_groups = [{"params": self._params, "lr": float(lr), "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}]
 
     # ------------------------------------------------------------ learning rate (host mirror + device scalar)
@@ -116,17 +118,22 @@ class FlatAdamW:
                 "lr": self._lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "numel": self.numel}
 
     def load_state_dict(self, state):
+        """Restore a :meth:`state_dict` (a flat layout -- not interchangeable with ``torch.optim.AdamW``'s per-parameter state).  Everything is
+        validated BEFORE anything is copied: a mismatch leaves the optimizer untouched."""
         if int(state["numel"]) != self.numel:
             raise ValueError("FlatAdamW: state of %d elements, optimizer of %d" % (int(state["numel"]), self.numel))
-        with torch.no_grad():
-            self.exp_avg.copy_(state["exp_avg"])
-            self.exp_avg_sq.copy_(state["exp_avg_sq"])
-            self.step_count.copy_(state["step_count"])
         # betas / eps / weight_decay are launch arguments baked into a captured graph: a different value needs a re-capture, so it is refused here
         for k, have in (("betas", self.betas), ("eps", self.eps), ("weight_decay", self.weight_decay)):
             want = tuple(float(v) for v in state[k]) if k == "betas" else float(state[k])
             if want != have:
                 raise ValueError("FlatAdamW.load_state_dict: %s = %r differs from this optimizer's %r" % (k, want, have))
+        for k in ("exp_avg", "exp_avg_sq"):
+            if state[k].numel() != self.numel:
+                raise ValueError("FlatAdamW.load_state_dict: %s has %d elements, optimizer %d" % (k, state[k].numel(), self.numel))
+        with torch.no_grad():
+            self.exp_avg.copy_(state["exp_avg"])
+            self.exp_avg_sq.copy_(state["exp_avg_sq"])
+            self.step_count.copy_(state["step_count"])
         self.lr = state["lr"]
 
     def zero_grad(self, set_to_none: bool = True):
