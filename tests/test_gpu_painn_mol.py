@@ -273,3 +273,28 @@ def test_atomic_number_beyond_the_embedding_table_poisons_its_molecule_and_reads
         assert torch.isnan(e[1]) and torch.isnan(f[21:42]).all()
         assert rel_err(e[[0, 2]], e_good[[0, 2]]) < 1e-6
         assert rel_err(f[:21], f_good[:21]) < 1e-6 and rel_err(f[42:], f_good[42:]) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["schnet", "painn"])
+def test_headline_batches_repeat_bit_for_bit_over_forty_calls(dev, kind):
+    """Round 6 guard (profiles/r06_box_split_glitch.md): the split-precision path puts f16 matrix instructions next to packed fp32 vector work, a
+    combination that was seen to glitch in one kernel at a rate of 1e-4 per tile iteration.  The two-launch force calls of configs[1] / configs[2]
+    (256 aspirin frames: 1 792 pair tiles x 3 interactions per call) are checked over forty calls: PaiNN has a fixed summation order between
+    positions and forces -- every bit must agree; the SchNet kernels hand pair tiles to whichever wave is free, so their sums differ in the last
+    bit (1.4e-7 of the largest force, with the fp32 matrix path just the same: scripts/r06_mol_repro.py) -- bound 1e-6.  A glitch was 1e-3 .. 1e-1."""
+    from schnetpack_amd import model as M
+    b = S.molecule_batch("aspirin", 256, seed=11)
+    rep = (O.init_schnet_params if kind == "schnet" else O.init_painn_params)()
+    head = O.init_atomwise_params(128, seed=1)
+    m = M.build_model(kind)
+    M.load_reference_params(m, rep, head)
+    m = m.to(dev).eval()
+    inp = M.batch_to_inputs(b, dev)
+    f0 = m(dict(inp))["forces"].detach().clone()
+    scale = float(f0.abs().max())
+    for _ in range(40):
+        f = m(dict(inp))["forces"].detach()
+        if kind == "painn":
+            assert torch.equal(f, f0)
+        else:
+            assert float((f - f0).abs().max()) < 1e-6 * scale
