@@ -523,20 +523,17 @@ __global__ __launch_bounds__(256, 2) void k_dense_chain_sp(ChainArgs a, int ld0,
   }
 }
 
-// split image that belongs to a packed fp32 image (registered by spk_apply_pack, spk_pack.h; looked up by the launcher below)
-#include <mutex>
-#include <unordered_map>
-static std::mutex g_split_mu;
-static std::unordered_map<const float*, const float*> g_split_of;
-void spk_register_split_image(const float* packed, const float* split) {
-  std::lock_guard<std::mutex> lk(g_split_mu);
-  g_split_of[packed] = split;
+// Split images of the chain that is about to be launched: spk_apply_pack (spk_pack.h) notes, per layer, the split image that belongs to the packed fp32
+// image it put into the chain; spk_dense_chain_f32 -- called next on the same host thread -- takes them only if every layer's `w` is exactly the noted
+// packed pointer, and forgets them on the way out.  (Not a global pointer map: a chain handed to the C ABI with its own packed buffer must never meet the
+// split image of a freed model whose buffer address it happens to reuse.)
+struct ChainSplitNote { const float* packed[CH_MAXL]; const float* split[CH_MAXL]; int n; };
+static thread_local ChainSplitNote g_split_note = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, 0};
+void spk_note_split_images(const float* const* packed, const float* const* split, int n) {
+  g_split_note.n = n > CH_MAXL ? 0 : n;
+  for (int l = 0; l < g_split_note.n; ++l) { g_split_note.packed[l] = packed[l]; g_split_note.split[l] = split[l]; }
 }
-static const float* split_image_of(const float* packed) {
-  std::lock_guard<std::mutex> lk(g_split_mu);
-  auto it = g_split_of.find(packed);
-  return it == g_split_of.end() ? nullptr : it->second;
-}
+struct ChainSplitNoteClear { ~ChainSplitNoteClear() { g_split_note.n = 0; } };
 
 // ---- packed weight image ------------------------------------------------------------------
 // w is a Linear weight [n_out, k_in].  transposed == 0: the layer y = x W^T (A[i][kk] = W[i][kk], contraction
@@ -634,6 +631,7 @@ static bool chain_supported(const spk_chain_t* c) {
 }
 
 extern "C" int spk_dense_chain_f32(const spk_chain_t* c, void* stream_) {
+  ChainSplitNoteClear forget_note_on_exit;
   hipStream_t stream = (hipStream_t)stream_;
   const char* who = "spk_dense_chain_f32";
   SPK_CHECK_ARG(c != nullptr && c->n_layers >= 1 && c->n_layers <= CH_MAXL, "%s: 1..%d layers", who, CH_MAXL);
@@ -672,10 +670,10 @@ extern "C" int spk_dense_chain_f32(const spk_chain_t* c, void* stream_) {
     const int64_t ntiles32 = (c->m + 31) / 32;
     const bool rows16 = g_chain_rows ? (g_chain_rows == 16) : (ntiles32 < 2 * (int64_t)spk_num_cus());
     SpkProfScope prof(c->n_layers == 1 ? "chain1" : (c->n_layers == 2 ? "chain2" : "chain3"), stream);
-    bool split = !rows16 && spk_get_split() != 0;
+    bool split = !rows16 && spk_get_split() != 0 && g_split_note.n == c->n_layers;
     const float* wsp[CH_MAXL] = {nullptr, nullptr, nullptr};
     for (int l = 0; l < c->n_layers && split; ++l) {
-      wsp[l] = (c->layers[l].k % 64 == 0) ? split_image_of(c->layers[l].w) : nullptr;
+      wsp[l] = (c->layers[l].k % 64 == 0 && g_split_note.packed[l] == c->layers[l].w) ? g_split_note.split[l] : nullptr;
       if (!wsp[l]) split = false;
     }
     if (split) {

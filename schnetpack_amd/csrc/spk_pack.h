@@ -77,8 +77,8 @@ static inline const float* spk_packed_split_of(const SpkPackTable& T, const floa
   return nullptr;
 }
 
-// (spk_chain.hip) the split image that belongs to a packed fp32 image: the chain launcher takes the split-precision kernel when every layer has one
-void spk_register_split_image(const float* packed, const float* split);
+// (spk_chain.hip) split images of the chain that is launched next on this host thread: the launcher takes the split-precision kernel when every layer has one
+void spk_note_split_images(const float* const* packed, const float* const* split, int n);
 
 static inline void spk_apply_pack(spk_chain_t& c, const SpkPackTable& T) {
   if (!T.base || spk_get_variant() == SPK_VARIANT_SIMPLE) return;
@@ -94,5 +94,7 @@ static inline void spk_apply_pack(spk_chain_t& c, const SpkPackTable& T) {
     }
     if (!repl[l]) return;
   }
-  for (int l = 0; l < c.n_layers; ++l) { c.layers[l].w = repl[l]; c.layers[l].trans = 2; if (repl_s[l]) spk_register_split_image(repl[l], repl_s[l]); }
+  bool all_split = true;
+  for (int l = 0; l < c.n_layers; ++l) { c.layers[l].w = repl[l]; c.layers[l].trans = 2; if (!repl_s[l]) all_split = false; }
+  if (all_split) spk_note_split_images(repl, repl_s, c.n_layers);
 }
