@@ -272,7 +272,7 @@ def self_spawn(args):
 PMC_TAGS = [
     ("schnet_mol_fwd", r"k_schnet_mol_fwd<"), ("schnet_mol_bwd", r"k_schnet_mol_bwd<"),
     ("painn_mol_fwd", r"k_painn_mol_fwd<"), ("painn_mol_bwd", r"k_painn_mol_bwd<"),
-    ("cfconv_fwd_pair", r"k_cfconv_pair<[^>]*false, false, false>|k_cfconv_pair_sp<"), ("cfconv_bwd_pair_gs_geom", r"k_cfconv_pair_t<[^>]*true, true, true>|k_cfconv_pair_t_sp<\d+, \d+, true>"),
+    ("cfconv_fwd_rowtile", r"k_cfconv_rowtile_fwd<"), ("cfconv_fwd_pair", r"k_cfconv_pair<[^>]*false, false, false>|k_cfconv_pair_sp<"), ("cfconv_bwd_pair_gs_geom", r"k_cfconv_pair_t<[^>]*true, true, true>|k_cfconv_pair_t_sp<\d+, \d+, true>"),
     ("cfconv_bwd_pair_gs", r"k_cfconv_pair_t<[^>]*true, true, false>|k_cfconv_pair_t_sp<\d+, \d+, false>"), ("cfconv_bwd_pair", r"k_cfconv_pair_t<[^>]*true, false"),
     ("cfconv_fwd_mol", r"k_cfconv_mol<[^>]*false>"), ("cfconv_bwd_mol", r"k_cfconv_mol<[^>]*true>"),
     ("cfconv_fwd_mfma", r"k_cfconv_mfma<[^>]*false, (true|false)>"), ("cfconv_bwd_mfma_sym", r"k_cfconv_mfma<[^>]*true, true>"),
@@ -622,6 +622,8 @@ def algorithmic_work(kind, E, N, n_mol, F, n_int, n_rbf):
         "schnet_mol_fwd": ("mfma", mol_f, exec_mol / mol_f, n_int * bmin_cf), "schnet_mol_bwd": ("mfma", mol_b, exec_mol_bwd / mol_b, 2 * n_int * bmin_cf),
         "cfconv_fwd_mfma": ("mfma", flop_fwd, 1.0, bmin_cf), "cfconv_fwd_simple": ("mfma", flop_fwd, 1.0, bmin_cf),
         "cfconv_fwd_pair": ("mfma", flop_fwd, 0.5, bmin_cf),
+        "cfconv_fwd_rowtile": ("mfma", flop_fwd, 1.0, bmin_cf + 0.5 * E * 4.0 * F),      # (round 6) one filter per DIRECTED edge; writes the saved filters of the pairs
+
         "cfconv_bwd_mfma_sym": ("mfma", 2 * flop_fwd, 1.0, 2 * bmin_cf), "cfconv_bwd_mfma_atomic": ("mfma", 2 * flop_fwd, 1.0, 2 * bmin_cf),
         "cfconv_bwd_simple": ("mfma", 2 * flop_fwd, 1.0, 2 * bmin_cf), "cfconv_bwd_pair": ("mfma", 2 * flop_fwd, 0.5, 2 * bmin_cf),
         "cfconv_bwd_pair_gs": ("mfma", 2 * flop_fwd, gs, 2 * bmin_cf), "cfconv_bwd_pair_gs_geom": ("mfma", 2 * flop_fwd, gs, 2 * bmin_cf),
@@ -943,7 +945,7 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
         split_on = bool(_lib.get_split())
         if isinstance(roofline.get("measured"), dict) and roofline["measured"].get("mfma_inputs"):
             split_on = roofline["measured"]["mfma_inputs"] == "f16x2"        # what the counters of this launch say, not what the switch says
-        elif not any(t in roofline["kernel"] for t in ("schnet_mol", "painn_mol", "cfconv_fwd_pair", "cfconv_bwd_pair_gs")):
+        elif not any(t in roofline["kernel"] for t in ("schnet_mol", "painn_mol", "cfconv_fwd_pair", "cfconv_fwd_rowtile", "cfconv_bwd_pair_gs")):
             split_on = False        # (round 6: the pair kernels of the box regime have split forms too, n_filters = 128)
         roofline["mfma_inputs"] = ("f16x2 split: fp16 high + 2^-11-scaled fp16 low operand pairs, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate"
                                    if split_on else "f32 (v_mfma_f32_32x32x2_f32)")

@@ -53,6 +53,8 @@ struct CfArgs {
   int max_group_atoms;
   int xcd_walk;        // persistent tile loops: XCD-contiguous walk (spk_xcd_tile; set by the launchers when gridDim.x % 8 == 0 on large lists)
   RadialDev rb;
+  const int32_t* rowptr;     // row-tile forward (round 6): CSR of the sorted list
+  const int32_t* edge_pair;  //   position in `half` of the undirected pair of every edge
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1296,6 +1298,184 @@ static int launch_pair_t_bwd_gs_sp(const CfArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Row-tile forward (round 6): y[i] = sum_j W_ij o h[j] with a wavefront per ROW of the sorted list -- the filter of every DIRECTED edge from the split
+// GEMMs of 32-edge chunks of the row (twice the matrix work of the pair kernel, affordable at the f16 rate: 120 instructions of 32 cycles per chunk),
+// lanes own a channel, the sum over the row is a register sum parked in LDS between chunks and added over the two half-waves at the end: no float
+// atomics (the pair kernel needs one per pair and channel for the neighbour's direction: 110 M per launch on the water box), y written once, a fixed
+// summation order.  The raw filters of the CANONICAL edges are saved for the pair backward in its layout (row = position of the pair in `half`).
+// Lists without a per-call compaction only (a.n_half_dev == null): the saved rows are addressed through the plan's edge_pair.
+// ------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) RtRec { int j; int pos; float fc; float pad; };
+
+template <int KPB, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_cfconv_rowtile_fwd(CfArgs a) {
+  constexpr int NF = 128, NT = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  h16x8* sW2h = (h16x8*)smem;                               // 32 KB high | 32 KB low
+  h16x8* sW2l = sW2h + 2048;
+  char* sW1h = (char*)(smem + NF * NF);
+  char* sW1l = sW1h + MlW1Image<KPB>::BYTES;
+  float* sb1 = (float*)(sW1l + MlW1Image<KPB>::BYTES);
+  float* sb2 = sb1 + NF;
+  RtRec* sE = (RtRec*)(sb2 + NF);                           // NWAVES * 32 records
+  float* sRb = (float*)(sE + NWAVES * 32);                  // [2][32] radial-basis parameters
+  float* sAcc = sRb + 64;                                   // NWAVES x NT x 64 running sums
+
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x & 31;
+    const float* src = (threadIdx.x < 32) ? a.rb.p0 : a.rb.p1;
+    sRb[threadIdx.x] = (src && k < a.rb.n_rbf) ? src[k] : 1.0f;
+  }
+  ml_stage_w2_split<NWAVES * 64>(sW2h, sW2l, a.w2, threadIdx.x);
+  ml_stage_w1_split<KPB>(sW1h, sW1l, a.w1, a.rb.n_rbf, threadIdx.x);
+  for (int s = threadIdx.x; s < NF; s += NWAVES * 64) { sb1[s] = a.b1[s]; sb2[s] = a.b2[s]; }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi = lane >> 5, el = lane & 31;
+  RtRec* myE = sE + wv * 32;
+  float* myA = sAcc + wv * (NT * 64);
+
+  // the workgroups of one XCD walk a contiguous eighth of the atoms (their neighbours' rows are then shared inside that XCD's L2)
+  const int64_t per_xcd = a.xcd_walk ? (a.N + 7) / 8 : a.N;
+  const int64_t a_lo = a.xcd_walk ? (int64_t)(blockIdx.x & 7) * per_xcd : 0;
+  const int64_t a_hi = a.xcd_walk ? (a_lo + per_xcd < a.N ? a_lo + per_xcd : a.N) : a.N;
+  const int64_t a_first = a.xcd_walk ? a_lo + (int64_t)(blockIdx.x >> 3) * NWAVES + wv : (int64_t)blockIdx.x * NWAVES + wv;
+  const int64_t a_step = a.xcd_walk ? (int64_t)((gridDim.x + 7) >> 3) * NWAVES : (int64_t)gridDim.x * NWAVES;
+  for (int64_t atom = a_first; atom < a_hi; atom += a_step) {
+    const int32_t e0 = a.rowptr[atom], e1 = a.rowptr[atom + 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) myA[t * 64 + lane] = 0.f;
+    for (int32_t cs = e0; cs < e1; cs += 32) {
+      // (lane re-derived through an opaque asm per chunk: see k_cfconv_pair_sp)
+      int lane_o_ = lane;
+      asm volatile("" : "+v"(lane_o_));
+      const int lane = lane_o_, hi = lane >> 5, el = lane & 31;
+      // ---- geometry of this lane's edge (lanes 32..63 mirror lanes 0..31)
+      const bool valid = cs + el < e1;
+      const int64_t e = valid ? cs + el : e1 - 1;
+      const float rx = a.rij[3 * e], ry = a.rij[3 * e + 1], rz = a.rij[3 * e + 2];
+      const int j = (int)a.idx_j[e];
+      const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+      float fc, dfc;
+      spk_cutoff_eval_fast(a.rb.cutoff, d, fc, dfc);
+      if (!valid) fc = 0.f;
+      if (hi == 0) {
+        RtRec rec; rec.j = j; rec.fc = fc; rec.pad = 0.f; rec.pos = -1;
+        if (a.gsave && valid) { const int ep = a.edge_pair[e]; rec.pos = (a.half[ep] == (int32_t)e) ? ep : -1; }
+        myE[el] = rec;
+      }
+      // ---- GEMM 1 (rows = hidden channels, columns = edges): z = ssp(W1 phi + b1), kept as the split A operand of GEMM 2
+      h16x8 zh[NT][2], zl[NT][2];
+      {
+        h16x8 ph[2], pl[2], dh_[2], dl_[2];
+        ml_basis_split<KPB, false>(a.rb.kind, a.rb.n_rbf, sRb, sRb + 32, hi, d, ph, pl, dh_, dl_);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+          f32x16 zc, zx;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { zc[r] = sb1[32 * c + pair_of(r, hi)]; zx[r] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < (KPB > 2 ? 2 : 1); ++s) {
+            h16x8 wh, wl;
+            ml_w1_operand<KPB>(sW1h, sW1l, s, c * 64 + lane, wh, wl);
+            SP_STEP(wh, wl, ph[s], pl[s], zc, zx);
+          }
+          SP_FOLD(zc, zx);
+#pragma unroll
+          for (int sp = 0; sp < 2; ++sp) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = spk_fast_ssp(zc[8 * sp + k]);
+            sp_split8(v, zh[c][sp], zl[c][sp]);
+          }
+          __builtin_amdgcn_sched_barrier(0);      // one hidden tile at a time (register pressure)
+        }
+      }
+      spk_wave_lds_sync();   // records visible to the whole wave
+
+#pragma unroll 1
+      for (int t = 0; t < NT; ++t) {
+        const int c0 = 32 * t + el;   // this lane's channel
+        float hj[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hj[r] = *(const float*)((const char*)a.h + ((unsigned)myE[pair_of(r, hi)].j * NF + c0) * 4u);
+        __builtin_amdgcn_sched_barrier(0);        // the 16 gathers of the block are requested before its GEMM
+        f32x16 g, gx;
+        const float bias2 = sb2[c0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g[r] = bias2; gx[r] = 0.f; }
+        {
+          const h16x8* wbh = sW2h + (t * 8) * 64 + lane;
+          const h16x8* wbl = sW2l + (t * 8) * 64 + lane;
+          h16x8 wh = wbh[0], wl = wbl[0];
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            h16x8 nh = wh, nl = wl;
+            if (s + 1 < 8) { nh = wbh[(s + 1) * 64]; nl = wbl[(s + 1) * 64]; }
+            SP_STEP(zh[s >> 1][s & 1], zl[s >> 1][s & 1], wh, wl, g, gx);
+            wh = nh; wl = nl;
+          }
+        }
+        SP_FOLD(g, gx);
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const RtRec er = myE[pair_of(r, hi)];
+          if (a.gsave && er.pos >= 0) a.gsave[(size_t)er.pos * NF + c0] = g[r];     // raw filter of the canonical edge, for the pair backward
+          acc = fmaf(g[r] * er.fc, hj[r], acc);
+        }
+        myA[t * 64 + lane] += acc;
+      }
+      spk_wave_lds_sync();   // records may be rewritten by the next chunk
+    }
+    spk_wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float tot = myA[t * 64 + lane] + myA[t * 64 + (lane ^ 32)];
+      if (hi == 0) a.y[(size_t)atom * NF + 32 * t + el] = tot;
+    }
+    spk_wave_lds_sync();
+  }
+}
+
+static bool cfconv_rowtile_fwd_ok(const CfArgs& a) {
+  static const int env = [] { const char* e = getenv("SPK_CF_ROWTILE"); return e ? (e[0] == '1' ? 1 : -1) : 0; }();
+  if (env < 0 || !a.rowptr || !a.edge_pair || !a.half || a.n_half_dev || a.N * (int64_t)128 >= (1LL << 30)) return false;
+  return env > 0 || a.E >= (1 << 19);
+}
+
+template <int KPB>
+static int launch_rowtile_fwd(const CfArgs& a, hipStream_t stream) {
+  // sixteen wavefronts per workgroup, one workgroup per CU (the weight images take 77 KB of LDS): measured on the water box 8 / 12 / 16 waves = 444 / 379 / 361 us
+  // (the pair kernel with its atomics: 437 us) -- the chunk is a long dependent chain (GEMM 1, softplus, split, GEMM 2 per block) that needs other waves to fill it
+#ifdef SPK_CF_RT_WAVES
+  constexpr int NWAVES = SPK_CF_RT_WAVES, NF = 128, NT = 4;
+#else
+  constexpr int NWAVES = 16, NF = 128, NT = 4;
+#endif
+  const size_t lds = (size_t)(NF * NF + 2 * NF) * sizeof(float) + 2 * MlW1Image<KPB>::BYTES + (size_t)NWAVES * 32 * sizeof(RtRec) + 64 * sizeof(float) +
+                     (size_t)NWAVES * NT * 64 * sizeof(float);
+  auto kern = k_cfconv_rowtile_fwd<KPB, NWAVES>;
+  static SpkPerDevice attr_set;
+  int attr_dev;
+  if (attr_set.pending(&attr_dev)) {
+    SPK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set.mark(attr_dev);
+  }
+  int grid = (int)((a.N + NWAVES - 1) / NWAVES);
+  const int maxg = spk_num_cus();
+  if (grid > maxg) grid = maxg;
+  if (grid < 1) grid = 1;
+  SpkProfScope prof("cfconv_fwd_rowtile", stream);
+  CfArgs ax = a;
+  ax.xcd_walk = (spk_xcd_walk_default() && grid % 8 == 0 && a.N >= (1 << 14)) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, ax);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static int check_graph(const spk_graph_t* g, const char* who) {
@@ -1424,6 +1604,7 @@ static int cfconv_dispatch(const CfArgs& a, int NF, bool sym, hipStream_t stream
     if (mol && BWD && a.gload) return launch_pair<NFv, KPBv, BWD, BWD, true>(a, stream);   \
     if (mol) return launch_pair<NFv, KPBv, BWD, false, true>(a, stream);                   \
     if (pair && BWD && a.gload) return (NFv == 128 && spk_get_split() && !getenv("SPK_CF_NOSP_BWD")) ? launch_pair_t_bwd_gs_sp<KPBv>(a, stream) : launch_pair_t_bwd_gs<NFv, KPBv>(a, stream);   \
+    if (pair && !BWD && NFv == 128 && spk_get_split() && cfconv_rowtile_fwd_ok(a)) return launch_rowtile_fwd<KPBv>(a, stream);   \
     if (pair && !BWD && NFv == 128 && spk_get_split() && !getenv("SPK_CF_NOSP_FWD")) return launch_pair_sp<KPBv>(a, stream);   \
     if (pair) return launch_pair<NFv, KPBv, BWD, false, false>(a, stream);                 \
     if (!BWD) return launch_mfma<NFv, KPBv, false, false>(a, stream);               \
@@ -1538,6 +1719,7 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half; a.n_half_dev = g->n_half_dev;
   a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
+  a.rowptr = (g->sorted && g->symmetric) ? g->rowptr : nullptr; a.edge_pair = g->edge_pair;
   return cfconv_dispatch<false>(a, nf, g->symmetric && g->sorted, stream, who);
 }
 
@@ -1567,6 +1749,7 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half; a.n_half_dev = g->n_half_dev;
   a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
+  a.rowptr = nullptr; a.edge_pair = nullptr;
   // the row-local transposed reduction needs idx_i sorted AND a symmetric list
   const bool sym = g->symmetric && g->sorted;
   // Asymmetric list with its by-neighbour copy (spk_transposed_t): gh[j] = sum_{e: idx_j[e] = j} gy[i(e)] W_e is the FORWARD pass over

@@ -33,26 +33,30 @@ __device__ __forceinline__ void ml_rbf(int kind, int n_rbf, const float* __restr
 // (columns = channels) and the A operand of the backward (rows = channels).
 template <int NTHREADS>
 __device__ __forceinline__ void ml_stage_w2_split(h16x8* __restrict__ dh, h16x8* __restrict__ dl, const float* __restrict__ w2, int tid) {
-  constexpr int PER = 2048 / NTHREADS;
+  // 2 048 slots; batches of four per thread while they last (any workgroup size: the row-tile forward runs 1 024 threads)
 #pragma unroll 1
-  for (int p0 = 0; p0 < PER; p0 += 4) {
+  for (int p0 = 0; tid + p0 * NTHREADS < 2048; p0 += 4) {
     f32x4 va[4], vb[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int sl = tid + (p0 + p) * NTHREADS;
-      const int lane = sl & 63, s = (sl >> 6) & 7, t = sl >> 9;
-      const float* src = w2 + (32 * t + (lane & 31)) * 128 + 32 * (s >> 1) + 16 * (s & 1) + 4 * (lane >> 5);
-      va[p] = *(const f32x4*)src;
-      vb[p] = *(const f32x4*)(src + 8);
+      if (sl < 2048) {
+        const int lane = sl & 63, s = (sl >> 6) & 7, t = sl >> 9;
+        const float* src = w2 + (32 * t + (lane & 31)) * 128 + 32 * (s >> 1) + 16 * (s & 1) + 4 * (lane >> 5);
+        va[p] = *(const f32x4*)src;
+        vb[p] = *(const f32x4*)(src + 8);
+      }
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int sl = tid + (p0 + p) * NTHREADS;
-      h16x4 ah, al, bh, bl;
-      sp_split4(va[p], ah, al);
-      sp_split4(vb[p], bh, bl);
-      dh[sl] = sp_cat(ah, bh);
-      dl[sl] = sp_cat(al, bl);
+      if (sl < 2048) {
+        h16x4 ah, al, bh, bl;
+        sp_split4(va[p], ah, al);
+        sp_split4(vb[p], bh, bl);
+        dh[sl] = sp_cat(ah, bh);
+        dl[sl] = sp_cat(al, bl);
+      }
     }
   }
 }

@@ -28,6 +28,8 @@ BUDGET = {
                            "k_painn_msg_rowtile_bwdILi128ELi3ELb0ELb1ELb0ELi8ELb0E": (0, 2),
                            "k_painn_msg_rowtile_fwdILi128ELi3ELb0ELi8ELb0E": (0, 2), "k_painn_msg_rowtile_fwdILi128ELi3ELb1ELi8ELb0E": (0, 2)},
     "spk_chain.hip": {"k_dense_chain_sp": (0, 2)},
+    # row-tile forward of the SchNet convolution (round 6): sixteen waves per workgroup = 128 registers; a few prologue spills
+    "spk_cfconv.hip": {"k_cfconv_rowtile_fwdILi3ELi16E": (96, 4)},
     # the two molecule-resident launches sit AT the 256-register limit of two waves per SIMD; the metadata reports a small
     # private segment although no scratch instruction is on a hot path
     # (round 6: second template flag = the split-precision matrix path, the default; it carries the split operands of a tile on top)
