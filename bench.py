@@ -956,6 +956,11 @@ def eval_leg(args, kind, workload, model, rep_p, head_p, rank, world, dev, dist,
             roofline["frac_of_split_path_roof"] = round(useful / roof, 4)
             roofline["split_note"] = ("executed fp32-equivalent TFLOP/s (= frac x 157.3) over 2500 / 3 TFLOP/s; phases that stayed on the fp32 instruction "
                                       "(in2f beside the first pair tile, the energy head) are booked at the same roof")
+            if roofline.get("executed_frac_of_peak", roofline["frac"]) > 1.0:
+                # (a launch that issues all the work the convention books -- the row-tile forward: one filter per directed edge -- can exceed the
+                #  fp32 matrix roof because its products run on the f16 matrix instructions)
+                roofline["frac_flag"] = ("frac exceeds 1 against the fp32 matrix peak: this launch issues every product the convention books, on the f16 matrix "
+                                         "instructions with split operands; the roof of the path that ran is peak_split_path -- read frac_of_split_path_roof")
 
     # context for `roofline` (which, per contract, is about the dominant launch): every launch of one force call with an algorithmic-work
     # model over the wall time of the call
