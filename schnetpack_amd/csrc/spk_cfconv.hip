@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_rowtile_fwd(CfArgs a) {
       if (!valid) fc = 0.f;
       if (hi == 0) {
         RtRec rec; rec.j = j; rec.fc = fc; rec.pad = 0.f; rec.pos = -1;
-        if (a.gsave && valid) { const int ep = a.edge_pair[e]; rec.pos = (a.half[ep] == (int32_t)e) ? ep : -1; }
+        if (a.gsave && a.edge_pair && valid) { const int ep = a.edge_pair[e]; rec.pos = (a.half[ep] == (int32_t)e) ? ep : -1; }
         myE[el] = rec;
       }
       // ---- GEMM 1 (rows = hidden channels, columns = edges): z = ssp(W1 phi + b1), kept as the split A operand of GEMM 2
@@ -1441,7 +1441,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cfconv_rowtile_fwd(CfArgs a) {
 
 static bool cfconv_rowtile_fwd_ok(const CfArgs& a) {
   static const int env = [] { const char* e = getenv("SPK_CF_ROWTILE"); return e ? (e[0] == '1' ? 1 : -1) : 0; }();
-  if (env < 0 || !a.rowptr || !a.edge_pair || !a.half || a.n_half_dev || a.N * (int64_t)128 >= (1LL << 30)) return false;
+  // (saving filters for the pair backward needs the plan's pair positions and a list without per-call compaction; a forward that saves nothing -- asymmetric
+  //  lists, the by-neighbour pass of their backward -- only needs the rows)
+  if (env < 0 || !a.rowptr || a.N * (int64_t)128 >= (1LL << 30)) return false;
+  if (a.gsave && (!a.edge_pair || !a.half || a.n_half_dev)) return false;
   return env > 0 || a.E >= (1 << 19);
 }
 
@@ -1604,7 +1607,7 @@ static int cfconv_dispatch(const CfArgs& a, int NF, bool sym, hipStream_t stream
     if (mol && BWD && a.gload) return launch_pair<NFv, KPBv, BWD, BWD, true>(a, stream);   \
     if (mol) return launch_pair<NFv, KPBv, BWD, false, true>(a, stream);                   \
     if (pair && BWD && a.gload) return (NFv == 128 && spk_get_split() && !getenv("SPK_CF_NOSP_BWD")) ? launch_pair_t_bwd_gs_sp<KPBv>(a, stream) : launch_pair_t_bwd_gs<NFv, KPBv>(a, stream);   \
-    if (pair && !BWD && NFv == 128 && spk_get_split() && cfconv_rowtile_fwd_ok(a)) return launch_rowtile_fwd<KPBv>(a, stream);   \
+    if (!mol && !BWD && NFv == 128 && spk_get_split() && cfconv_rowtile_fwd_ok(a)) return launch_rowtile_fwd<KPBv>(a, stream);   \
     if (pair && !BWD && NFv == 128 && spk_get_split() && !getenv("SPK_CF_NOSP_FWD")) return launch_pair_sp<KPBv>(a, stream);   \
     if (pair) return launch_pair<NFv, KPBv, BWD, false, false>(a, stream);                 \
     if (!BWD) return launch_mfma<NFv, KPBv, false, false>(a, stream);               \
@@ -1719,7 +1722,7 @@ int spk_cfconv_fwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
   a.E = g->n_edges; a.N = g->n_atoms; a.rb = spk_radial_dev(rb);
   a.half = g->half; a.rev = g->rev; a.n_half = g->n_half; a.n_half_dev = g->n_half_dev;
   a.grp_atom0 = g->grp_atom0; a.grp_pair0 = g->grp_pair0; a.grp_tile0 = g->grp_tile0; a.n_groups = g->n_groups; a.max_group_atoms = g->max_group_atoms;
-  a.rowptr = (g->sorted && g->symmetric) ? g->rowptr : nullptr; a.edge_pair = g->edge_pair;
+  a.rowptr = g->sorted ? g->rowptr : nullptr; a.edge_pair = (g->sorted && g->symmetric) ? g->edge_pair : nullptr;
   return cfconv_dispatch<false>(a, nf, g->symmetric && g->sorted, stream, who);
 }
 
@@ -1765,6 +1768,7 @@ int spk_cfconv_bwd_internal(const spk_graph_t* g, const spk_radial_t* rb, const 
       CfArgs f = a;
       f.h = gy; f.gy = nullptr; f.rij = T->r_perm; f.idx_i = T->idx_i; f.idx_j = T->idx_j; f.y = gh; f.gr = nullptr; f.gr_assign = 0; f.skip_gh = 0;
       f.gsave = nullptr; f.gload = nullptr; f.half = nullptr; f.rev = nullptr; f.n_half = 0; f.n_half_dev = nullptr; f.n_groups = 0;
+      f.rowptr = T->rowptr; f.edge_pair = nullptr;      // (large lists: the row-tile forward over the by-neighbour rows)
       int rc2 = cfconv_dispatch<false>(f, nf, false, stream, who);
       if (rc2) return rc2;
     }
