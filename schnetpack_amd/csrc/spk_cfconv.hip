@@ -1450,7 +1450,7 @@ static bool cfconv_rowtile_fwd_ok(const CfArgs& a) {
 
 template <int KPB>
 static int launch_rowtile_fwd(const CfArgs& a, hipStream_t stream) {
-  // sixteen wavefronts per workgroup, one workgroup per CU (the weight images take 77 KB of LDS): measured on the water box 8 / 12 / 16 waves = 444 / 379 / 361 us
+  // sixteen wavefronts per workgroup, one workgroup per CU (the weight images take 77 KB of LDS): measured on the water box 8 / 12 / 16 waves = 444 / 391 / 382 us
   // (the pair kernel with its atomics: 437 us) -- the chunk is a long dependent chain (GEMM 1, softplus, split, GEMM 2 per block) that needs other waves to fill it
 #ifdef SPK_CF_RT_WAVES
   constexpr int NWAVES = SPK_CF_RT_WAVES, NF = 128, NT = 4;
