@@ -124,8 +124,20 @@ def trained_rmd17_params(k):
     if not os.path.exists(path):
         return None
     refshim.load()
-    sys.modules["ase.data"].atomic_masses = np.ones(119)
-    m = torch.load(path, map_location="cpu", weights_only=False)
+    # The pickle holds whole modules of the reference (its own classes are needed to unpickle it: weights_only=False).  It is a file of the
+    # reference tree / of oracle/_ref built from it, test infrastructure only.  The ase.data stub the shim installs needs `atomic_masses` while the
+    # pickle is read; it is put back afterwards so that later tests of the session see what they saw before.
+    ase_data = sys.modules["ase.data"]
+    missing = object()
+    before = getattr(ase_data, "atomic_masses", missing)
+    ase_data.atomic_masses = np.ones(119)
+    try:
+        m = torch.load(path, map_location="cpu", weights_only=False)
+    finally:
+        if before is missing:
+            del ase_data.atomic_masses
+        else:
+            ase_data.atomic_masses = before
     rep = {kk: v.detach().clone() for kk, v in m.representation.state_dict().items()}
     head = {kk: v.detach().clone() for kk, v in m.output_modules[0].state_dict().items()}
     return rep, head
